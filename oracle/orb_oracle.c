@@ -1,0 +1,996 @@
+/* orb_oracle.c -- CPU restatement of the reference ORB front-end.  TEST INFRASTRUCTURE ONLY.
+ * See orb_oracle.h for the parity status ("parity unpinned" at the OpenCV boundary).
+ *
+ * Citations "ORBextractor.cc:N" etc. are relative to /root/reference/src|include.
+ * Items tagged [OCV] restate OpenCV 3.4.x behaviour from its published sources (the library
+ * is not available in this image); everything else follows the reference's own lines.
+ *
+ * Build: gcc -O3 -ffp-contract=off (see oracle/Makefile).  No dependencies but libm.
+ */
+#include "orb_oracle.h"
+#include "../include/gfo_sincos.h"
+
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define PATCH_SIZE 31      /* ORBextractor.cc:72 */
+#define HALF_PATCH_SIZE 15 /* ORBextractor.cc:73 */
+#define EDGE_THRESHOLD 19  /* ORBextractor.cc:74 */
+#define MAX_LEVELS 32
+
+static const signed char k_pattern[256][4] = {
+#include "../include/gfo_pattern.inc"
+};
+
+typedef struct {
+    int x, y, score;
+} cand_t;
+
+struct orc_extractor {
+    int nfeatures, nlevels, ini_th, min_th;
+    float scale_factor;
+    float scale[MAX_LEVELS], inv_scale[MAX_LEVELS], sigma2[MAX_LEVELS], inv_sigma2[MAX_LEVELS];
+    int quota[MAX_LEVELS];
+    int umax[HALF_PATCH_SIZE + 1];
+    int trig_mode, rot_mode;
+    /* pyramid, unpadded, stride == width */
+    int w[MAX_LEVELS], h[MAX_LEVELS];
+    uint8_t* level[MAX_LEVELS];
+    uint8_t* blurred[MAX_LEVELS];
+    /* per-level products of the last extraction */
+    cand_t* cand[MAX_LEVELS];
+    int ncand[MAX_LEVELS];
+    int nkp[MAX_LEVELS];
+};
+
+/* [OCV] cvRound: round half to even (SSE cvtss2si under the default rounding mode). */
+int orc_cv_round(float v) { return (int)lrintf(v); }
+static int cv_round_d(double v) { return (int)lrint(v); }
+
+float orc_fast_atan2(float y, float x) { return gfo_fast_atan2f(y, x); }
+void orc_sincos(float t, float* s, float* c) { gfo_sincosf(t, s, c); }
+
+/* ------------------------------------------------------------------------------------------
+ * ORBextractor::ORBextractor -- ORBextractor.cc:409-469
+ * ---------------------------------------------------------------------------------------- */
+orc_extractor* orc_create(int nfeatures, float scale_factor, int nlevels, int ini_th, int min_th)
+{
+    if (nlevels < 1 || nlevels > MAX_LEVELS) return NULL;
+    orc_extractor* e = (orc_extractor*)calloc(1, sizeof(*e));
+    e->nfeatures = nfeatures;
+    e->scale_factor = scale_factor;
+    e->nlevels = nlevels;
+    e->ini_th = ini_th;
+    e->min_th = min_th;
+    e->scale[0] = 1.0f; /* :416-422, cumulative float product */
+    e->sigma2[0] = 1.0f;
+    for (int i = 1; i < nlevels; i++) {
+        e->scale[i] = e->scale[i - 1] * scale_factor;
+        e->sigma2[i] = e->scale[i] * e->scale[i];
+    }
+    for (int i = 0; i < nlevels; i++) { /* :426-430 */
+        e->inv_scale[i] = 1.0f / e->scale[i];
+        e->inv_sigma2[i] = 1.0f / e->sigma2[i];
+    }
+    /* :435-445 per-level quotas */
+    float factor = 1.0f / scale_factor;
+    float per_scale = nfeatures * (1 - factor) / (1 - (float)pow((double)factor, (double)nlevels));
+    int sum = 0;
+    for (int l = 0; l < nlevels - 1; l++) {
+        e->quota[l] = orc_cv_round(per_scale);
+        sum += e->quota[l];
+        per_scale *= factor;
+    }
+    e->quota[nlevels - 1] = nfeatures - sum > 0 ? nfeatures - sum : 0;
+    /* :451-468 umax */
+    int v, v0;
+    int vmax = (int)floor(HALF_PATCH_SIZE * sqrtf(2.f) / 2 + 1);
+    int vmin = (int)ceil(HALF_PATCH_SIZE * sqrtf(2.f) / 2);
+    const double hp2 = HALF_PATCH_SIZE * HALF_PATCH_SIZE;
+    for (v = 0; v <= vmax; ++v) e->umax[v] = cv_round_d(sqrt(hp2 - v * v));
+    for (v = HALF_PATCH_SIZE, v0 = 0; v >= vmin; --v) {
+        while (e->umax[v0] == e->umax[v0 + 1]) ++v0;
+        e->umax[v] = v0;
+        ++v0;
+    }
+    return e;
+}
+
+static void free_products(orc_extractor* e)
+{
+    for (int l = 0; l < MAX_LEVELS; l++) {
+        free(e->level[l]);
+        free(e->blurred[l]);
+        free(e->cand[l]);
+        e->level[l] = e->blurred[l] = NULL;
+        e->cand[l] = NULL;
+        e->ncand[l] = e->nkp[l] = 0;
+    }
+}
+
+void orc_destroy(orc_extractor* e)
+{
+    if (!e) return;
+    free_products(e);
+    free(e);
+}
+
+void orc_set_variant(orc_extractor* e, int trig_mode, int rot_mode)
+{
+    e->trig_mode = trig_mode;
+    e->rot_mode = rot_mode;
+}
+
+int orc_nlevels(const orc_extractor* e) { return e->nlevels; }
+const float* orc_scale_factors(const orc_extractor* e) { return e->scale; }
+const float* orc_inv_scale_factors(const orc_extractor* e) { return e->inv_scale; }
+const float* orc_level_sigma2(const orc_extractor* e) { return e->sigma2; }
+const float* orc_inv_level_sigma2(const orc_extractor* e) { return e->inv_sigma2; }
+const int* orc_features_per_level(const orc_extractor* e) { return e->quota; }
+const int* orc_umax(const orc_extractor* e) { return e->umax; }
+
+/* ------------------------------------------------------------------------------------------
+ * [OCV] cv::resize(..., INTER_LINEAR) for CV_8UC1, the non-IPP fixed-point path:
+ * 11-bit coefficients, horizontal pass into int, vertical pass with the >>4, >>16, +2, >>2
+ * rounding of VResizeLinear<uchar,int,short,...>.  Called at ORBextractor.cc:1189.
+ * ---------------------------------------------------------------------------------------- */
+static void resize_axis_tables(int ssize, int dsize, int* ofs, short* coef, int clamp_x)
+{
+    const double inv_scale = (double)dsize / ssize; /* resize(): inv_scale_x = dsize.width/ssize.width */
+    const double scale = 1. / inv_scale;            /* hal::resize(): scale_x = 1./inv_scale_x          */
+    for (int d = 0; d < dsize; d++) {
+        float f = (float)((d + 0.5) * scale - 0.5);
+        int s = (int)floorf(f);
+        f -= s;
+        if (clamp_x) {
+            if (s < 0) { f = 0; s = 0; }
+            if (s >= ssize - 1) { f = 0; s = ssize - 1; }
+        }
+        ofs[d] = s;
+        coef[2 * d] = (short)orc_cv_round((1.f - f) * 2048.f);
+        coef[2 * d + 1] = (short)orc_cv_round(f * 2048.f);
+    }
+}
+
+void orc_resize_linear_u8(const uint8_t* src, int sw, int sh, int sstride,
+                          uint8_t* dst, int dw, int dh, int dstride)
+{
+    int* xofs = (int*)malloc(sizeof(int) * dw);
+    int* yofs = (int*)malloc(sizeof(int) * dh);
+    short* alpha = (short*)malloc(sizeof(short) * 2 * dw);
+    short* beta = (short*)malloc(sizeof(short) * 2 * dh);
+    int* row0 = (int*)malloc(sizeof(int) * dw);
+    int* row1 = (int*)malloc(sizeof(int) * dw);
+    resize_axis_tables(sw, dw, xofs, alpha, 1);
+    resize_axis_tables(sh, dh, yofs, beta, 0);
+    for (int dy = 0; dy < dh; dy++) {
+        int sy0 = yofs[dy], sy1 = yofs[dy] + 1; /* rows clipped to [0, sh-1] */
+        if (sy0 < 0) sy0 = 0;
+        if (sy0 > sh - 1) sy0 = sh - 1;
+        if (sy1 < 0) sy1 = 0;
+        if (sy1 > sh - 1) sy1 = sh - 1;
+        const uint8_t* S0 = src + (size_t)sy0 * sstride;
+        const uint8_t* S1 = src + (size_t)sy1 * sstride;
+        for (int dx = 0; dx < dw; dx++) {
+            int sx = xofs[dx];
+            int sx1 = sx + 1 < sw ? sx + 1 : sx; /* coefficient is 0 there */
+            int a0 = alpha[2 * dx], a1 = alpha[2 * dx + 1];
+            row0[dx] = S0[sx] * a0 + S0[sx1] * a1;
+            row1[dx] = S1[sx] * a0 + S1[sx1] * a1;
+        }
+        int b0 = beta[2 * dy], b1 = beta[2 * dy + 1];
+        uint8_t* D = dst + (size_t)dy * dstride;
+        for (int dx = 0; dx < dw; dx++)
+            D[dx] = (uint8_t)((((b0 * (row0[dx] >> 4)) >> 16) + ((b1 * (row1[dx] >> 4)) >> 16) + 2) >> 2);
+    }
+    free(xofs); free(yofs); free(alpha); free(beta); free(row0); free(row1);
+}
+
+/* ComputePyramid -- ORBextractor.cc:1176-1201.  The 19-px frame is not stored: nothing on the
+ * extraction path reads it (FAST cells start 16 px inside, the angle disc reaches 15 px and the
+ * rotated pattern 18 px from keypoints that sit >= 19 px inside); orc_get_level_padded rebuilds
+ * it on demand. */
+void orc_compute_pyramid(orc_extractor* e, const uint8_t* img, int w, int h, int stride)
+{
+    free_products(e);
+    for (int l = 0; l < e->nlevels; l++) {
+        float scale = e->inv_scale[l];
+        e->w[l] = orc_cv_round((float)w * scale);
+        e->h[l] = orc_cv_round((float)h * scale);
+        e->level[l] = (uint8_t*)malloc((size_t)e->w[l] * e->h[l]);
+        if (l == 0) {
+            for (int y = 0; y < h; y++) memcpy(e->level[0] + (size_t)y * w, img + (size_t)y * stride, w);
+        } else {
+            orc_resize_linear_u8(e->level[l - 1], e->w[l - 1], e->h[l - 1], e->w[l - 1],
+                                 e->level[l], e->w[l], e->h[l], e->w[l]);
+        }
+    }
+}
+
+int orc_level_size(const orc_extractor* e, int level, int* w, int* h)
+{
+    if (level < 0 || level >= e->nlevels || !e->level[level]) return -1;
+    *w = e->w[level];
+    *h = e->h[level];
+    return 0;
+}
+
+void orc_get_level(const orc_extractor* e, int level, uint8_t* out, int out_stride)
+{
+    for (int y = 0; y < e->h[level]; y++)
+        memcpy(out + (size_t)y * out_stride, e->level[level] + (size_t)y * e->w[level], e->w[level]);
+}
+
+/* [OCV] BORDER_REFLECT_101: -k -> k, n-1+k -> n-1-k */
+static int reflect101(int p, int n)
+{
+    if (n == 1) return 0;
+    while (p < 0 || p >= n) {
+        if (p < 0) p = -p;
+        else p = 2 * (n - 1) - p;
+    }
+    return p;
+}
+
+void orc_get_level_padded(const orc_extractor* e, int level, uint8_t* out, int out_stride)
+{
+    const int w = e->w[level], h = e->h[level];
+    for (int y = -EDGE_THRESHOLD; y < h + EDGE_THRESHOLD; y++) {
+        const uint8_t* S = e->level[level] + (size_t)reflect101(y, h) * w;
+        uint8_t* D = out + (size_t)(y + EDGE_THRESHOLD) * out_stride;
+        for (int x = -EDGE_THRESHOLD; x < w + EDGE_THRESHOLD; x++) D[x + EDGE_THRESHOLD] = S[reflect101(x, w)];
+    }
+}
+
+/* ------------------------------------------------------------------------------------------
+ * [OCV] cv::GaussianBlur(src, dst, Size(7,7), 2, 2, BORDER_REFLECT_101) for CV_8UC1
+ * (ORBextractor.cc:1154-1155, applied to a clone of the level, so the border is the level's own
+ * reflection).  Taps = round(256 * normalised exp(-x^2/8)) = {18,34,49,55,49,34,18} (sum 257);
+ * both the classic integer sepFilter2D path and the 8.8 fixed-point path of 3.4.1 accumulate
+ * exactly (no intermediate rounding) and finish with (v + 2^15) >> 16 saturated to 255, so the
+ * two give the same bytes.
+ * ---------------------------------------------------------------------------------------- */
+static const int k_gauss7[7] = {18, 34, 49, 55, 49, 34, 18};
+
+void orc_gaussian_blur7_u8(const uint8_t* src, int w, int h, int sstride, uint8_t* dst, int dstride)
+{
+    int* tmp = (int*)malloc(sizeof(int) * (size_t)w * h);
+    for (int y = 0; y < h; y++) {
+        const uint8_t* S = src + (size_t)y * sstride;
+        for (int x = 0; x < w; x++) {
+            int acc = 0;
+            for (int k = -3; k <= 3; k++) acc += k_gauss7[k + 3] * S[reflect101(x + k, w)];
+            tmp[(size_t)y * w + x] = acc;
+        }
+    }
+    for (int y = 0; y < h; y++) {
+        for (int x = 0; x < w; x++) {
+            unsigned acc = 0;
+            for (int k = -3; k <= 3; k++) acc += (unsigned)k_gauss7[k + 3] * (unsigned)tmp[(size_t)reflect101(y + k, h) * w + x];
+            unsigned v = (acc + 32768u) >> 16;
+            dst[(size_t)y * dstride + x] = (uint8_t)(v > 255 ? 255 : v);
+        }
+    }
+    free(tmp);
+}
+
+void orc_get_blurred_level(const orc_extractor* e, int level, uint8_t* out, int out_stride)
+{
+    for (int y = 0; y < e->h[level]; y++)
+        memcpy(out + (size_t)y * out_stride, e->blurred[level] + (size_t)y * e->w[level], e->w[level]);
+}
+
+/* ------------------------------------------------------------------------------------------
+ * [OCV] cv::FAST(img, kps, threshold, nonmaxSuppression=true) == FAST_t<16>: 9 contiguous of
+ * 16 ring pixels all darker than v-t or all brighter than v+t; score = cornerScore<16>;
+ * 3x3 strict-max suppression on the score rows; 3-px frame skipped.  In-tree mirror:
+ * FAST_NEON.cc:3-7 (ring), :106-108 (threshold table), :121-133,198-260 (scan), :268-285 (NMS).
+ * ---------------------------------------------------------------------------------------- */
+static const int k_ring[16][2] = {{0, 3}, {1, 3}, {2, 2}, {3, 1}, {3, 0}, {3, -1}, {2, -2}, {1, -3},
+                                  {0, -3}, {-1, -3}, {-2, -2}, {-3, -1}, {-3, 0}, {-3, 1}, {-2, 2}, {-1, 3}};
+
+static int corner_score16(const uint8_t* ptr, const int* pixel, int threshold)
+{
+    int d[25];
+    const int v = ptr[0];
+    for (int k = 0; k < 25; k++) d[k] = v - ptr[pixel[k]];
+    int a0 = threshold;
+    for (int k = 0; k < 16; k += 2) {
+        int a = d[k + 1] < d[k + 2] ? d[k + 1] : d[k + 2];
+        for (int j = 3; j <= 8; j++) a = a < d[k + j] ? a : d[k + j];
+        int a1 = a < d[k] ? a : d[k];
+        int a2 = a < d[k + 9] ? a : d[k + 9];
+        if (a1 > a0) a0 = a1;
+        if (a2 > a0) a0 = a2;
+    }
+    int b0 = -a0;
+    for (int k = 0; k < 16; k += 2) {
+        int b = d[k + 1] > d[k + 2] ? d[k + 1] : d[k + 2];
+        for (int j = 3; j <= 8; j++) b = b > d[k + j] ? b : d[k + j];
+        int b1 = b > d[k] ? b : d[k];
+        int b2 = b > d[k + 9] ? b : d[k + 9];
+        if (b1 < b0) b0 = b1;
+        if (b2 < b0) b0 = b2;
+    }
+    return -b0 - 1;
+}
+
+int orc_fast9_nms(const uint8_t* img, int cols, int rows, int stride, int threshold, int* xys, int cap)
+{
+    int pixel[25];
+    for (int k = 0; k < 16; k++) pixel[k] = k_ring[k][0] + k_ring[k][1] * stride;
+    for (int k = 16; k < 25; k++) pixel[k] = pixel[k - 16];
+    if (threshold < 0) threshold = 0;
+    if (threshold > 255) threshold = 255;
+    if (cols < 1 || rows < 1) return 0;
+    uint8_t* buf = (uint8_t*)calloc((size_t)cols * 3, 1);
+    int* cpbuf = (int*)malloc(sizeof(int) * (size_t)(cols + 1) * 3);
+    int n = 0;
+    for (int i = 3; i < rows - 2; i++) {
+        const uint8_t* ptr = img + (size_t)i * stride + 3;
+        uint8_t* curr = buf + (size_t)((i - 3) % 3) * cols;
+        int* cornerpos = cpbuf + (size_t)((i - 3) % 3) * (cols + 1) + 1;
+        memset(curr, 0, cols);
+        int ncorners = 0;
+        if (i < rows - 3) {
+            for (int j = 3; j < cols - 3; j++, ptr++) {
+                const int v = ptr[0];
+                int is_corner = 0;
+                for (int pol = 0; pol < 2 && !is_corner; pol++) {
+                    int count = 0;
+                    for (int k = 0; k < 25; k++) {
+                        const int x = ptr[pixel[k]];
+                        const int hit = pol == 0 ? (x < v - threshold) : (x > v + threshold);
+                        if (hit) {
+                            if (++count > 8) { is_corner = 1; break; }
+                        } else count = 0;
+                    }
+                }
+                if (is_corner) {
+                    cornerpos[ncorners++] = j;
+                    curr[j] = (uint8_t)corner_score16(ptr, pixel, threshold);
+                }
+            }
+        }
+        cornerpos[-1] = ncorners;
+        if (i == 3) continue;
+        const uint8_t* prev = buf + (size_t)((i - 4 + 3) % 3) * cols;
+        const uint8_t* pprev = buf + (size_t)((i - 5 + 3) % 3) * cols;
+        cornerpos = cpbuf + (size_t)((i - 4 + 3) % 3) * (cols + 1) + 1;
+        ncorners = cornerpos[-1];
+        for (int k = 0; k < ncorners; k++) {
+            const int j = cornerpos[k];
+            const int score = prev[j];
+            if (score > prev[j + 1] && score > prev[j - 1] &&
+                score > pprev[j - 1] && score > pprev[j] && score > pprev[j + 1] &&
+                score > curr[j - 1] && score > curr[j] && score > curr[j + 1]) {
+                if (n < cap) {
+                    xys[3 * n] = j;
+                    xys[3 * n + 1] = i - 1;
+                    xys[3 * n + 2] = score;
+                }
+                n++;
+            }
+        }
+    }
+    free(buf);
+    free(cpbuf);
+    return n;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * ExtractorNode / DistributeOctTree -- ORBextractor.cc:481-763, restated literally with a
+ * doubly linked list.  The one deliberate difference: the reference sorts (size, node address)
+ * pairs (:684), which makes the order of equal-sized nodes depend on the allocator; here every
+ * node carries its creation sequence number and equal sizes are split NEWEST FIRST -- what a
+ * monotonically growing heap would give.
+ * ---------------------------------------------------------------------------------------- */
+typedef struct qnode {
+    int ulx, uly, urx, ury, blx, bly, brx, bry;
+    int* keys; /* indices into the candidate array, in insertion order */
+    int nkeys;
+    int no_more;
+    int seq;
+    struct qnode *prev, *next;
+} qnode;
+
+typedef struct {
+    qnode *head, *tail;
+    int size, next_seq;
+} qlist;
+
+static qnode* qnode_new(int cap)
+{
+    qnode* n = (qnode*)calloc(1, sizeof(qnode));
+    n->keys = (int*)malloc(sizeof(int) * (cap > 0 ? cap : 1));
+    return n;
+}
+static void qnode_free(qnode* n) { free(n->keys); free(n); }
+static void qlist_push_front(qlist* l, qnode* n)
+{
+    n->seq = l->next_seq++;
+    n->prev = NULL;
+    n->next = l->head;
+    if (l->head) l->head->prev = n; else l->tail = n;
+    l->head = n;
+    l->size++;
+}
+static void qlist_push_back(qlist* l, qnode* n)
+{
+    n->seq = l->next_seq++;
+    n->next = NULL;
+    n->prev = l->tail;
+    if (l->tail) l->tail->next = n; else l->head = n;
+    l->tail = n;
+    l->size++;
+}
+static qnode* qlist_erase(qlist* l, qnode* n) /* returns the following node */
+{
+    qnode* nx = n->next;
+    if (n->prev) n->prev->next = n->next; else l->head = n->next;
+    if (n->next) n->next->prev = n->prev; else l->tail = n->prev;
+    l->size--;
+    qnode_free(n);
+    return nx;
+}
+
+/* ExtractorNode::DivideNode -- ORBextractor.cc:481-537 */
+static void divide_node(const qnode* p, const cand_t* c, qnode* ch[4])
+{
+    const int halfX = (int)ceil((float)(p->urx - p->ulx) / 2);
+    const int halfY = (int)ceil((float)(p->bry - p->uly) / 2);
+    for (int i = 0; i < 4; i++) ch[i] = qnode_new(p->nkeys);
+    qnode *n1 = ch[0], *n2 = ch[1], *n3 = ch[2], *n4 = ch[3];
+    n1->ulx = p->ulx; n1->uly = p->uly;
+    n1->urx = p->ulx + halfX; n1->ury = p->uly;
+    n1->blx = p->ulx; n1->bly = p->uly + halfY;
+    n1->brx = p->ulx + halfX; n1->bry = p->uly + halfY;
+    n2->ulx = n1->urx; n2->uly = n1->ury;
+    n2->urx = p->urx; n2->ury = p->ury;
+    n2->blx = n1->brx; n2->bly = n1->bry;
+    n2->brx = p->urx; n2->bry = p->uly + halfY;
+    n3->ulx = n1->blx; n3->uly = n1->bly;
+    n3->urx = n1->brx; n3->ury = n1->bry;
+    n3->blx = p->blx; n3->bly = p->bly;
+    n3->brx = n1->brx; n3->bry = p->bly;
+    n4->ulx = n3->urx; n4->uly = n3->ury;
+    n4->urx = n2->brx; n4->ury = n2->bry;
+    n4->blx = n3->brx; n4->bly = n3->bry;
+    n4->brx = p->brx; n4->bry = p->bry;
+    for (int i = 0; i < p->nkeys; i++) {
+        const cand_t* kp = &c[p->keys[i]];
+        qnode* dst;
+        if ((float)kp->x < (float)n1->urx) dst = ((float)kp->y < (float)n1->bry) ? n1 : n3;
+        else dst = ((float)kp->y < (float)n1->bry) ? n2 : n4;
+        dst->keys[dst->nkeys++] = p->keys[i];
+    }
+    for (int i = 0; i < 4; i++)
+        if (ch[i]->nkeys == 1) ch[i]->no_more = 1;
+}
+
+typedef struct {
+    int size;
+    qnode* node;
+} size_node;
+
+static int size_node_cmp(const void* a, const void* b)
+{
+    const size_node* x = (const size_node*)a;
+    const size_node* y = (const size_node*)b;
+    if (x->size != y->size) return x->size < y->size ? -1 : 1;
+    return x->node->seq < y->node->seq ? -1 : (x->node->seq > y->node->seq ? 1 : 0);
+}
+
+/* pushes the non-empty children to the front (n1..n4 in that order), records the expandable
+ * ones; returns how many of them hold more than one key */
+static int push_children(qlist* l, qnode* ch[4], size_node* vec, int* nvec)
+{
+    int expandable = 0;
+    for (int i = 0; i < 4; i++) {
+        if (ch[i]->nkeys > 0) {
+            qlist_push_front(l, ch[i]);
+            if (ch[i]->nkeys > 1) {
+                expandable++;
+                vec[*nvec].size = ch[i]->nkeys;
+                vec[*nvec].node = ch[i];
+                (*nvec)++;
+            }
+        } else qnode_free(ch[i]);
+    }
+    return expandable;
+}
+
+/* returns number of selected keys; sel[] = candidate indices in list order */
+static int distribute_oct_tree(const cand_t* c, int nc, int minX, int maxX, int minY, int maxY, int N, int* sel)
+{
+    if (nc == 0) return 0;
+    int nIni = (int)roundf((float)(maxX - minX) / (maxY - minY)); /* :543 */
+    if (nIni < 1) nIni = 1; /* the reference divides by zero here for very tall images */
+    const float hX = (float)(maxX - minX) / nIni;
+    qlist L = {0, 0, 0, 0};
+    qnode** ini = (qnode**)malloc(sizeof(qnode*) * nIni);
+    for (int i = 0; i < nIni; i++) { /* :551-563 */
+        qnode* n = qnode_new(nc);
+        n->ulx = (int)(hX * (float)i); n->uly = 0;
+        n->urx = (int)(hX * (float)(i + 1)); n->ury = 0;
+        n->blx = n->ulx; n->bly = maxY - minY;
+        n->brx = n->urx; n->bry = maxY - minY;
+        qlist_push_back(&L, n);
+        ini[i] = n;
+    }
+    for (int i = 0; i < nc; i++) { /* :566-570 */
+        int idx = (int)((float)c[i].x / hX);
+        if (idx >= nIni) idx = nIni - 1; /* cannot happen for in-range keys; guards the array */
+        ini[idx]->keys[ini[idx]->nkeys++] = i;
+    }
+    free(ini);
+    for (qnode* it = L.head; it;) { /* :572-585 */
+        if (it->nkeys == 1) { it->no_more = 1; it = it->next; }
+        else if (it->nkeys == 0) it = qlist_erase(&L, it);
+        else it = it->next;
+    }
+    int finish = 0;
+    size_t vcap = (size_t)nc + 16;
+    size_node* vec = (size_node*)malloc(sizeof(size_node) * vcap);
+    size_node* prevvec = (size_node*)malloc(sizeof(size_node) * vcap);
+    int nvec = 0;
+    while (!finish) { /* :594 */
+        int prevSize = L.size;
+        int nToExpand = 0;
+        nvec = 0;
+        for (qnode* it = L.head; it;) {
+            if (it->no_more) { it = it->next; continue; }
+            qnode* ch[4];
+            divide_node(it, c, ch);
+            nToExpand += push_children(&L, ch, vec, &nvec);
+            it = qlist_erase(&L, it);
+        }
+        if (L.size >= N || L.size == prevSize) finish = 1; /* :667-670 */
+        else if (L.size + nToExpand * 3 > N) {              /* :671 */
+            while (!finish) {
+                prevSize = L.size;
+                int nprev = nvec;
+                memcpy(prevvec, vec, sizeof(size_node) * nprev);
+                nvec = 0;
+                qsort(prevvec, nprev, sizeof(size_node), size_node_cmp); /* :684, seq instead of address */
+                for (int j = nprev - 1; j >= 0; j--) {
+                    qnode* ch[4];
+                    divide_node(prevvec[j].node, c, ch);
+                    push_children(&L, ch, vec, &nvec);
+                    qlist_erase(&L, prevvec[j].node);
+                    if (L.size >= N) break; /* :730 */
+                }
+                if (L.size >= N || L.size == prevSize) finish = 1;
+            }
+        }
+    }
+    /* :740-760 best response per node, first wins on ties */
+    int ns = 0;
+    for (qnode* it = L.head; it; it = it->next) {
+        int best = it->keys[0];
+        int maxr = c[best].score;
+        for (int k = 1; k < it->nkeys; k++)
+            if (c[it->keys[k]].score > maxr) { best = it->keys[k]; maxr = c[best].score; }
+        sel[ns++] = best;
+    }
+    for (qnode* it = L.head; it;) it = qlist_erase(&L, it);
+    free(vec);
+    free(prevvec);
+    return ns;
+}
+
+/* IC_Angle -- ORBextractor.cc:76-103 (image = unblurred level, stride = width) */
+static float ic_angle(const uint8_t* img, int stride, int px, int py, const int* umax)
+{
+    int m_01 = 0, m_10 = 0;
+    const uint8_t* center = img + (size_t)py * stride + px;
+    for (int u = -HALF_PATCH_SIZE; u <= HALF_PATCH_SIZE; ++u) m_10 += u * center[u];
+    for (int v = 1; v <= HALF_PATCH_SIZE; ++v) {
+        int v_sum = 0;
+        const int d = umax[v];
+        for (int u = -d; u <= d; ++u) {
+            const int val_plus = center[u + v * stride], val_minus = center[u - v * stride];
+            v_sum += (val_plus - val_minus);
+            m_10 += u * (val_plus + val_minus);
+        }
+        m_01 += v * v_sum;
+    }
+    return gfo_fast_atan2f((float)m_01, (float)m_10);
+}
+
+/* computeOrbDescriptor -- ORBextractor.cc:106-146 */
+static void orb_descriptor(const orc_extractor* e, const uint8_t* img, int stride, int px, int py,
+                           float angle_deg, uint8_t* desc)
+{
+    const float factorPI = (float)(3.1415926535897932384626433832795 / 180.f);
+    const float angle = angle_deg * factorPI;
+    float a, b;
+    if (e->trig_mode == ORC_TRIG_LIBM) { a = cosf(angle); b = sinf(angle); }
+    else gfo_sincosf(angle, &b, &a);
+    const uint8_t* center = img + (size_t)py * stride + px;
+    for (int i = 0; i < 32; i++) {
+        int val = 0;
+        for (int j = 0; j < 8; j++) {
+            const signed char* p = k_pattern[i * 8 + j];
+            int t[2];
+            for (int s = 0; s < 2; s++) {
+                const float x = (float)p[2 * s], y = (float)p[2 * s + 1];
+                float fy, fx;
+                if (e->rot_mode == ORC_ROT_FMA) { fy = fmaf(x, b, y * a); fx = fmaf(x, a, -(y * b)); }
+                else { fy = x * b + y * a; fx = x * a - y * b; }
+                t[s] = center[orc_cv_round(fy) * stride + orc_cv_round(fx)];
+            }
+            val |= (t[0] < t[1]) << j;
+        }
+        desc[i] = (uint8_t)val;
+    }
+}
+
+/* ORBextractor::operator() -- ORBextractor.cc:1112-1174 with ComputeKeyPointsOctTree :767-855 */
+int orc_extract(orc_extractor* e, const uint8_t* img, int w, int h, int stride,
+                orc_keypoint* kp, uint8_t* desc, int cap)
+{
+    if (!img || w <= 0 || h <= 0) return 0; /* :1115 */
+    orc_compute_pyramid(e, img, w, h, stride);
+    const float W = 30;
+    int total = 0;
+    for (int level = 0; level < e->nlevels; ++level) {
+        const int lw = e->w[level], lh = e->h[level];
+        const uint8_t* L = e->level[level];
+        const int minBorderX = EDGE_THRESHOLD - 3, minBorderY = minBorderX;
+        const int maxBorderX = lw - EDGE_THRESHOLD + 3, maxBorderY = lh - EDGE_THRESHOLD + 3;
+        const float width = (float)(maxBorderX - minBorderX), height = (float)(maxBorderY - minBorderY);
+        int ncand = 0, ccap = 0;
+        cand_t* cand = NULL;
+        if (width >= W && height >= W) { /* nCols/nRows == 0 divides by zero in the reference */
+            const int nCols = (int)(width / W), nRows = (int)(height / W);
+            const int wCell = (int)ceil(width / nCols), hCell = (int)ceil(height / nRows);
+            int* xys = (int*)malloc(sizeof(int) * 3 * (size_t)(wCell + 6) * (hCell + 6));
+            for (int i = 0; i < nRows; i++) {
+                const float iniY = (float)(minBorderY + i * hCell);
+                float maxY = iniY + hCell + 6;
+                if (iniY >= maxBorderY - 3) continue;
+                if (maxY > maxBorderY) maxY = (float)maxBorderY;
+                for (int j = 0; j < nCols; j++) {
+                    const float iniX = (float)(minBorderX + j * wCell);
+                    float maxX = iniX + wCell + 6;
+                    if (iniX >= maxBorderX - 6) continue;
+                    if (maxX > maxBorderX) maxX = (float)maxBorderX;
+                    const int x0 = (int)iniX, y0 = (int)iniY, cw = (int)maxX - x0, chh = (int)maxY - y0;
+                    const uint8_t* sub = L + (size_t)y0 * lw + x0;
+                    int n = orc_fast9_nms(sub, cw, chh, lw, e->ini_th, xys, cw * chh);
+                    if (n == 0) n = orc_fast9_nms(sub, cw, chh, lw, e->min_th, xys, cw * chh);
+                    for (int k = 0; k < n; k++) {
+                        if (ncand == ccap) {
+                            ccap = ccap ? ccap * 2 : 4096;
+                            cand = (cand_t*)realloc(cand, sizeof(cand_t) * ccap);
+                        }
+                        cand[ncand].x = xys[3 * k] + j * wCell;
+                        cand[ncand].y = xys[3 * k + 1] + i * hCell;
+                        cand[ncand].score = xys[3 * k + 2];
+                        ncand++;
+                    }
+                }
+            }
+            free(xys);
+        }
+        e->cand[level] = cand;
+        e->ncand[level] = ncand;
+        int* sel = (int*)malloc(sizeof(int) * (ncand + 1));
+        const int nsel = distribute_oct_tree(cand, ncand, minBorderX, maxBorderX, minBorderY, maxBorderY,
+                                             e->quota[level], sel);
+        e->nkp[level] = nsel;
+        if (nsel > 0) {
+            /* :1154-1155 blur a clone of the level */
+            e->blurred[level] = (uint8_t*)malloc((size_t)lw * lh);
+            orc_gaussian_blur7_u8(L, lw, lh, lw, e->blurred[level], lw);
+        }
+        const int scaledPatchSize = (int)(PATCH_SIZE * e->scale[level]);
+        for (int k = 0; k < nsel; k++) {
+            const cand_t* c = &cand[sel[k]];
+            orc_keypoint q;
+            q.x = (float)c->x + minBorderX;
+            q.y = (float)c->y + minBorderY;
+            q.size = (float)scaledPatchSize;
+            q.response = (float)c->score;
+            q.octave = level;
+            q.class_id = -1;
+            const int px = orc_cv_round(q.x), py = orc_cv_round(q.y);
+            q.angle = ic_angle(L, lw, px, py, e->umax);
+            if (total + k < cap) {
+                if (desc) orb_descriptor(e, e->blurred[level], lw, px, py, q.angle, desc + (size_t)(total + k) * 32);
+                if (level != 0) { /* :1164-1170 */
+                    q.x *= e->scale[level];
+                    q.y *= e->scale[level];
+                }
+                if (kp) kp[total + k] = q;
+            }
+        }
+        total += nsel;
+        free(sel);
+    }
+    return total;
+}
+
+int orc_level_candidates(const orc_extractor* e, int level, int* xys, int cap)
+{
+    const int n = e->ncand[level];
+    for (int i = 0; i < n && i < cap; i++) {
+        xys[3 * i] = e->cand[level][i].x;
+        xys[3 * i + 1] = e->cand[level][i].y;
+        xys[3 * i + 2] = e->cand[level][i].score;
+    }
+    return n;
+}
+
+int orc_level_keypoint_count(const orc_extractor* e, int level) { return e->nkp[level]; }
+
+/* ------------------------------------------------------------------------------------------
+ * ORBmatcher::DescriptorDistance -- ORBmatcher.cc:1768-1784 (SWAR popcount over 8 x u32)
+ * ---------------------------------------------------------------------------------------- */
+int orc_hamming256(const uint8_t* a, const uint8_t* b)
+{
+    int dist = 0;
+    for (int i = 0; i < 8; i++) {
+        uint32_t pa, pb;
+        memcpy(&pa, a + 4 * i, 4);
+        memcpy(&pb, b + 4 * i, 4);
+        uint32_t v = pa ^ pb;
+        v = v - ((v >> 1) & 0x55555555u);
+        v = (v & 0x33333333u) + ((v >> 2) & 0x33333333u);
+        dist += (int)((((v + (v >> 4)) & 0xF0F0F0Fu) * 0x1010101u) >> 24);
+    }
+    return dist;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * Stereo association -- Frame.h:230-263 (PrepareStereoCandidates) and Frame.cc:1167-1316
+ * (ComputeStereoMatches_Undistorted, isOnline=false, DELAYED_STEREO_MATCHING bookkeeping
+ * left to the caller).  TH_HIGH=100, TH_LOW=50 (ORBmatcher.cc:57-58).
+ * ---------------------------------------------------------------------------------------- */
+typedef struct {
+    int dist, il;
+} dist_idx;
+static int dist_idx_cmp(const void* a, const void* b)
+{
+    const dist_idx* x = (const dist_idx*)a;
+    const dist_idx* y = (const dist_idx*)b;
+    if (x->dist != y->dist) return x->dist < y->dist ? -1 : 1;
+    return x->il < y->il ? -1 : (x->il > y->il ? 1 : 0);
+}
+
+int orc_stereo_match(const orc_keypoint* kl, const uint8_t* dl, int nl,
+                     const orc_keypoint* kr, const uint8_t* dr, int nr,
+                     const float* scale_factors, const orc_stereo_params* p,
+                     const float* min_d_in, const float* max_d_in,
+                     float* u_right, float* depth, int* best_dist_out, int* best_idx_out)
+{
+    const int TH_HIGH = 100, TH_LOW = 50;
+    const int thOrbDist = (TH_HIGH + TH_LOW) / 2;
+    const int nRows = p->n_rows;
+    /* row table (PrepareStereoCandidates): CSR, each row keeps insertion order by iR */
+    int* start = (int*)calloc((size_t)nRows + 1, sizeof(int));
+    int* minr_a = (int*)malloc(sizeof(int) * (nr > 0 ? nr : 1));
+    int* maxr_a = (int*)malloc(sizeof(int) * (nr > 0 ? nr : 1));
+    for (int iR = 0; iR < nr; iR++) {
+        const float kpY = kr[iR].y;
+        const float r = 2.0f * scale_factors[kr[iR].octave];
+        const float fmaxr = ceilf(kpY + r), fminr = floorf(kpY - r);
+        maxr_a[iR] = (int)((float)(nRows - 1) < fmaxr ? (float)(nRows - 1) : fmaxr);
+        minr_a[iR] = (int)(0.0f > fminr ? 0.0f : fminr);
+        for (int yi = minr_a[iR]; yi <= maxr_a[iR]; yi++) start[yi + 1]++;
+    }
+    for (int r = 0; r < nRows; r++) start[r + 1] += start[r];
+    int* items = (int*)malloc(sizeof(int) * (start[nRows] > 0 ? start[nRows] : 1));
+    int* fill = (int*)calloc((size_t)nRows, sizeof(int));
+    for (int iR = 0; iR < nr; iR++)
+        for (int yi = minr_a[iR]; yi <= maxr_a[iR]; yi++) items[start[yi] + fill[yi]++] = iR;
+    free(fill); free(minr_a); free(maxr_a);
+
+    const float minZ = p->mb;
+    int nmatched = 0;
+    dist_idx* di = (dist_idx*)malloc(sizeof(dist_idx) * (nl > 0 ? nl : 1));
+    int ndi = 0;
+    for (int iL = 0; iL < nl; iL++) {
+        u_right[iL] = -1.0f;
+        depth[iL] = -1.0f;
+        if (best_dist_out) best_dist_out[iL] = -1;
+        if (best_idx_out) best_idx_out[iL] = -1;
+    }
+    for (int iL = 0; iL < nl; iL++) {
+        float minD = 0;
+        float maxD = p->mbf / minZ;
+        const int levelL = kl[iL].octave;
+        const float vL = kl[iL].y, uL = kl[iL].x;
+        if (vL < 0 || vL > nRows - 1) continue;
+        const int row = (int)vL;
+        const int nC = start[row + 1] - start[row];
+        if (nC == 0) continue;
+        if (min_d_in && max_d_in) { minD = min_d_in[iL]; maxD = max_d_in[iL]; }
+        const float minU = uL - maxD, maxU = uL - minD;
+        if (maxU < p->min_x) continue;
+        int bestDist = TH_HIGH;
+        int bestIdxR = 0;
+        for (int iC = 0; iC < nC; iC++) {
+            const int iR = items[start[row] + iC];
+            if (kr[iR].octave < levelL - 1 || kr[iR].octave > levelL + 1) continue;
+            const float uR = kr[iR].x;
+            if (uR >= minU && uR <= maxU) {
+                const int dist = orc_hamming256(dl + (size_t)iL * 32, dr + (size_t)iR * 32);
+                if (dist < bestDist) { bestDist = dist; bestIdxR = iR; }
+            }
+        }
+        if (bestDist < thOrbDist) {
+            float bestuR = kr[bestIdxR].x;
+            float disparity = uL - bestuR;
+            if (disparity >= minD && disparity < maxD) {
+                if (disparity <= 0) { disparity = 0.01f; bestuR = uL - 0.01f; }
+                depth[iL] = p->mbf / disparity;
+                u_right[iL] = bestuR;
+                if (best_dist_out) best_dist_out[iL] = bestDist;
+                if (best_idx_out) best_idx_out[iL] = bestIdxR;
+                di[ndi].dist = bestDist;
+                di[ndi].il = iL;
+                ndi++;
+            }
+        }
+        nmatched++;
+    }
+    if (ndi > 0) { /* :1290-1313 */
+        qsort(di, ndi, sizeof(dist_idx), dist_idx_cmp);
+        const float median = (float)di[ndi / 2].dist;
+        const float thDist = 1.5f * 1.4f * median;
+        for (int i = ndi - 1; i >= 0; i--) {
+            if ((float)di[i].dist < thDist) break;
+            u_right[di[i].il] = -1;
+            depth[di[i].il] = -1;
+            nmatched--;
+        }
+    }
+    free(di); free(start); free(items);
+    return nmatched;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * Frame grid -- Frame.cc:461-476 (AssignFeaturesToGrid), :648-658 (PosInGrid),
+ * :593-646 (GetFeaturesInArea).  FRAME_GRID_COLS=64, FRAME_GRID_ROWS=48 (Frame.h:92-93).
+ * ---------------------------------------------------------------------------------------- */
+#define GRID_COLS 64
+#define GRID_ROWS 48
+
+typedef struct {
+    int* start; /* [GRID_COLS*GRID_ROWS + 1], cell = ix*GRID_ROWS + iy */
+    int* items;
+    float inv_w, inv_h;
+} grid_t;
+
+static void grid_build(grid_t* g, const orc_keypoint* kp, int n, const orc_frame_bounds* fb)
+{
+    g->inv_w = (float)GRID_COLS / (fb->max_x - fb->min_x); /* Frame.cc:129-130 */
+    g->inv_h = (float)GRID_ROWS / (fb->max_y - fb->min_y);
+    const int ncell = GRID_COLS * GRID_ROWS;
+    int* cell = (int*)malloc(sizeof(int) * (n > 0 ? n : 1));
+    g->start = (int*)calloc((size_t)ncell + 1, sizeof(int));
+    for (int i = 0; i < n; i++) {
+        const int px = (int)roundf((kp[i].x - fb->min_x) * g->inv_w);
+        const int py = (int)roundf((kp[i].y - fb->min_y) * g->inv_h);
+        if (px < 0 || px >= GRID_COLS || py < 0 || py >= GRID_ROWS) cell[i] = -1;
+        else { cell[i] = px * GRID_ROWS + py; g->start[cell[i] + 1]++; }
+    }
+    for (int c = 0; c < ncell; c++) g->start[c + 1] += g->start[c];
+    g->items = (int*)malloc(sizeof(int) * (n > 0 ? n : 1));
+    int* fill = (int*)calloc(ncell, sizeof(int));
+    for (int i = 0; i < n; i++)
+        if (cell[i] >= 0) g->items[g->start[cell[i]] + fill[cell[i]]++] = i;
+    free(fill);
+    free(cell);
+}
+static void grid_free(grid_t* g) { free(g->start); free(g->items); }
+
+static int grid_query(const grid_t* g, const orc_keypoint* kp, const orc_frame_bounds* fb,
+                      float x, float y, float r, int minLevel, int maxLevel, int* out, int cap)
+{
+    int n = 0;
+    int nMinCellX = (int)floorf((x - fb->min_x - r) * g->inv_w);
+    if (nMinCellX < 0) nMinCellX = 0;
+    if (nMinCellX >= GRID_COLS) return 0;
+    int nMaxCellX = (int)ceilf((x - fb->min_x + r) * g->inv_w);
+    if (nMaxCellX > GRID_COLS - 1) nMaxCellX = GRID_COLS - 1;
+    if (nMaxCellX < 0) return 0;
+    int nMinCellY = (int)floorf((y - fb->min_y - r) * g->inv_h);
+    if (nMinCellY < 0) nMinCellY = 0;
+    if (nMinCellY >= GRID_ROWS) return 0;
+    int nMaxCellY = (int)ceilf((y - fb->min_y + r) * g->inv_h);
+    if (nMaxCellY > GRID_ROWS - 1) nMaxCellY = GRID_ROWS - 1;
+    if (nMaxCellY < 0) return 0;
+    const int bCheckLevels = (minLevel > 0) || (maxLevel >= 0);
+    for (int ix = nMinCellX; ix <= nMaxCellX; ix++)
+        for (int iy = nMinCellY; iy <= nMaxCellY; iy++) {
+            const int c = ix * GRID_ROWS + iy;
+            for (int j = g->start[c]; j < g->start[c + 1]; j++) {
+                const int i = g->items[j];
+                if (bCheckLevels) {
+                    if (kp[i].octave < minLevel) continue;
+                    if (maxLevel >= 0 && kp[i].octave > maxLevel) continue;
+                }
+                const float distx = kp[i].x - x, disty = kp[i].y - y;
+                if (fabsf(distx) < r && fabsf(disty) < r) {
+                    if (n < cap) out[n] = i;
+                    n++;
+                }
+            }
+        }
+    return n;
+}
+
+int orc_features_in_area(const orc_keypoint* kp_un, int n, const orc_frame_bounds* fb,
+                         float x, float y, float r, int min_level, int max_level, int* out_idx, int cap)
+{
+    grid_t g;
+    grid_build(&g, kp_un, n, fb);
+    const int k = grid_query(&g, kp_un, fb, x, y, r, min_level, max_level, out_idx, cap);
+    grid_free(&g);
+    return k;
+}
+
+/* ORBmatcher::SearchByProjection(Frame&, vector<MapPoint*>&, th) -- ORBmatcher.cc:155-249 */
+int orc_search_by_projection(const orc_keypoint* kp, const uint8_t* desc, const float* u_right, int n,
+                             const float* sf, const orc_frame_bounds* fb,
+                             const orc_map_point* mps, const uint8_t* mp_desc, int m,
+                             float th, float nn_ratio, const uint8_t* kp_taken,
+                             int* out_mp, int* out_score)
+{
+    const int TH_HIGH = 100;
+    grid_t g;
+    grid_build(&g, kp, n, fb);
+    int* idx = (int*)malloc(sizeof(int) * (n > 0 ? n : 1));
+    uint8_t* blocked = (uint8_t*)malloc(n > 0 ? n : 1);
+    for (int i = 0; i < n; i++) {
+        blocked[i] = kp_taken ? kp_taken[i] : 0;
+        out_mp[i] = -1;
+        out_score[i] = 0;
+    }
+    int nmatches = 0;
+    const int bFactor = th != 1.0f;
+    for (int iMP = 0; iMP < m; iMP++) {
+        const orc_map_point* mp = &mps[iMP];
+        if (!(mp->flags & 1)) continue; /* mbTrackInView */
+        if (mp->flags & 2) continue;    /* isBad()       */
+        const int lvl = mp->level;
+        float r = mp->view_cos > 0.998 ? 2.5f : 4.0f; /* RadiusByViewingCos :243-249 (double compare) */
+        if (bFactor) r *= th;
+        const float rs = r * sf[lvl];
+        const int nidx = grid_query(&g, kp, fb, mp->proj_x, mp->proj_y, rs, lvl - 1, lvl, idx, n);
+        if (nidx == 0) continue;
+        int bestDist = 256, bestLevel = -1, bestDist2 = 256, bestLevel2 = -1, bestIdx = -1;
+        for (int k = 0; k < nidx; k++) {
+            const int i = idx[k];
+            if (blocked[i]) continue;
+            if (u_right && u_right[i] > 0) {
+                const float er = fabsf(mp->proj_xr - u_right[i]);
+                if (er > rs) continue;
+            }
+            const int dist = orc_hamming256(mp_desc + (size_t)iMP * 32, desc + (size_t)i * 32);
+            if (dist < bestDist) {
+                bestDist2 = bestDist; bestDist = dist;
+                bestLevel2 = bestLevel; bestLevel = kp[i].octave;
+                bestIdx = i;
+            } else if (dist < bestDist2) {
+                bestLevel2 = kp[i].octave;
+                bestDist2 = dist;
+            }
+        }
+        if (bestDist <= TH_HIGH) {
+            if (bestLevel == bestLevel2 && (float)bestDist > nn_ratio * (float)bestDist2) continue;
+            out_mp[bestIdx] = iMP;
+            out_score[bestIdx] = bestDist;
+            blocked[bestIdx] = (mp->flags & 4) ? 1 : 0; /* later points skip it only if Observations()>0 */
+            nmatches++;
+        }
+    }
+    free(idx);
+    free(blocked);
+    grid_free(&g);
+    return nmatches;
+}

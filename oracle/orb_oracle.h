@@ -1,0 +1,129 @@
+/* orb_oracle.h -- CPU restatement of the GF-ORB-SLAM2 ORB front-end (TEST INFRASTRUCTURE).
+ *
+ * This is the parity oracle for the MI355X path.  Only tests/, __graft_entry__.smoke()
+ * and bench.py's cpu_baseline leg may load it; the product (libgfo.so) never does.
+ *
+ * PARITY STATUS: "parity unpinned" at the OpenCV boundary.  The reference's CPU extractor
+ * calls OpenCV 3.4.1 (cv::FAST, cv::resize, cv::GaussianBlur, cv::fastAtan2, cvRound), which
+ * is neither vendored in /root/reference nor installed in this image, and the reference's
+ * tests hold no golden keypoints/descriptors.  Everything that lives
+ * in the reference's own sources (cell grid, quadtree, angle, descriptor, matchers) follows
+ * the cited lines; the OpenCV pieces restate the published 3.4.x algorithms from memory.
+ * The only known answers this oracle is pinned against are the level geometry / quotas /
+ * umax table of SURVEY.md 8 and the popcount definition of DescriptorDistance.
+ */
+#ifndef ORB_ORACLE_H
+#define ORB_ORACLE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* layout-identical to cv::KeyPoint (7 x 4 bytes) */
+typedef struct {
+    float x, y, size, angle, response;
+    int octave, class_id;
+} orc_keypoint;
+
+typedef struct orc_extractor orc_extractor;
+
+/* variant switches (default 0 everywhere = the variant the golden vectors use) */
+enum {
+    ORC_TRIG_SHARED = 0, /* include/gfo_sincos.h (double-evaluated, rounded once)        */
+    ORC_TRIG_LIBM = 1    /* host libm cosf/sinf, what the reference literally calls      */
+};
+enum {
+    ORC_ROT_UNFUSED = 0, /* x*b + y*a as two roundings of the products then one add      */
+    ORC_ROT_FMA = 1      /* fmaf(x, b, y*a): what gcc -O3 -march=native may contract to  */
+};
+
+orc_extractor* orc_create(int nfeatures, float scale_factor, int nlevels, int ini_th, int min_th);
+void orc_destroy(orc_extractor* e);
+void orc_set_variant(orc_extractor* e, int trig_mode, int rot_mode);
+
+/* tables (ORBextractor.cc:409-469) */
+int orc_nlevels(const orc_extractor* e);
+const float* orc_scale_factors(const orc_extractor* e);
+const float* orc_inv_scale_factors(const orc_extractor* e);
+const float* orc_level_sigma2(const orc_extractor* e);
+const float* orc_inv_level_sigma2(const orc_extractor* e);
+const int* orc_features_per_level(const orc_extractor* e);
+const int* orc_umax(const orc_extractor* e);
+
+/* ORBextractor::operator() (ORBextractor.cc:1112-1174).  Returns the number of keypoints
+ * produced (may exceed nfeatures, see DistributeOctTree); writes min(n, cap) of them. */
+int orc_extract(orc_extractor* e, const uint8_t* img, int w, int h, int stride,
+                orc_keypoint* kp, uint8_t* desc, int cap);
+
+/* ComputePyramid only (ORBextractor.cc:1176-1201) */
+void orc_compute_pyramid(orc_extractor* e, const uint8_t* img, int w, int h, int stride);
+
+/* inspection of the last extraction / pyramid */
+int orc_level_size(const orc_extractor* e, int level, int* w, int* h);
+void orc_get_level(const orc_extractor* e, int level, uint8_t* out, int out_stride);
+/* level with the 19-px BORDER_REFLECT_101 frame the reference keeps around it */
+void orc_get_level_padded(const orc_extractor* e, int level, uint8_t* out, int out_stride);
+void orc_get_blurred_level(const orc_extractor* e, int level, uint8_t* out, int out_stride);
+/* FAST candidates handed to DistributeOctTree for one level, in the reference's order
+ * (cell-major); coordinates relative to minBorder.  xys = {x, y, score} triplets. */
+int orc_level_candidates(const orc_extractor* e, int level, int* xys, int cap);
+int orc_level_keypoint_count(const orc_extractor* e, int level);
+
+/* building blocks exposed for unit tests */
+void orc_resize_linear_u8(const uint8_t* src, int sw, int sh, int sstride,
+                          uint8_t* dst, int dw, int dh, int dstride);
+void orc_gaussian_blur7_u8(const uint8_t* src, int w, int h, int sstride, uint8_t* dst, int dstride);
+/* cv::FAST(img, kps, threshold, true) on a w x h sub-image; out = {x, y, score} triplets */
+int orc_fast9_nms(const uint8_t* img, int w, int h, int stride, int threshold, int* xys, int cap);
+float orc_fast_atan2(float y, float x);
+void orc_sincos(float t, float* s, float* c);
+int orc_cv_round(float v);
+
+/* ORBmatcher::DescriptorDistance (ORBmatcher.cc:1768-1784) */
+int orc_hamming256(const uint8_t* a, const uint8_t* b);
+
+/* Frame::PrepareStereoCandidates + ComputeStereoMatches_Undistorted(false)
+ * (Frame.h:230-263, Frame.cc:1167-1316) with every mvpMapPoints[] NULL unless min_d/max_d
+ * are given per left keypoint (the adapter's flattening of Frame.cc:1220-1231).
+ * Outputs: u_right[nl], depth[nl] (-1 where unmatched), best_dist[nl] (-1 where no
+ * accepted match), best_idx_r[nl].  Returns nmatched as the reference counts it. */
+typedef struct {
+    int n_rows;    /* mvImagePyramid[0].rows                       */
+    float mbf, mb; /* baseline*fx and baseline                       */
+    float min_x;   /* mnMinX                                         */
+} orc_stereo_params;
+int orc_stereo_match(const orc_keypoint* kl, const uint8_t* dl, int nl,
+                     const orc_keypoint* kr, const uint8_t* dr, int nr,
+                     const float* scale_factors, const orc_stereo_params* p,
+                     const float* min_d, const float* max_d,
+                     float* u_right, float* depth, int* best_dist, int* best_idx_r);
+
+/* Frame grid (Frame.cc:461-476, 593-658) + ORBmatcher::SearchByProjection(Frame&, MapPoints, th)
+ * (ORBmatcher.cc:155-249) on flattened arrays. */
+typedef struct {
+    float min_x, min_y, max_x, max_y; /* mnMinX.. image bounds */
+} orc_frame_bounds;
+typedef struct {
+    float proj_x, proj_y, proj_xr; /* mTrackProjX/Y/XR   */
+    float view_cos;                /* mTrackViewCos      */
+    int level;                     /* mnTrackScaleLevel  */
+    int flags;                     /* bit0 mbTrackInView, bit1 isBad(), bit2 Observations()>0 */
+} orc_map_point;
+/* kp_taken[n]: 1 where F.mvpMapPoints[i] is set with Observations()>0 on entry.
+ * out_mp[n]: index of the map point finally stored in F.mvpMapPoints[i] by this call (-1 none);
+ * out_score[n]: F.mvpMatchScore[i] for those.  Returns nmatches. */
+int orc_search_by_projection(const orc_keypoint* kp_un, const uint8_t* desc, const float* u_right, int n,
+                             const float* scale_factors, const orc_frame_bounds* fb,
+                             const orc_map_point* mps, const uint8_t* mp_desc, int m,
+                             float th, float nn_ratio, const uint8_t* kp_taken,
+                             int* out_mp, int* out_score);
+int orc_features_in_area(const orc_keypoint* kp_un, int n, const orc_frame_bounds* fb,
+                         float x, float y, float r, int min_level, int max_level,
+                         int* out_idx, int cap);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

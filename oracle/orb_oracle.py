@@ -1,0 +1,261 @@
+"""ctypes binding of the CPU oracle (oracle/liborb_oracle.so).  TEST INFRASTRUCTURE ONLY.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module.
+The product path (gf_orb_slam2_amd -> libgfo.so) never does.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "liborb_oracle.so")
+
+KEYPOINT_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"),
+                           ("response", "<f4"), ("octave", "<i4"), ("class_id", "<i4")])
+MAP_POINT_DTYPE = np.dtype([("proj_x", "<f4"), ("proj_y", "<f4"), ("proj_xr", "<f4"),
+                            ("view_cos", "<f4"), ("level", "<i4"), ("flags", "<i4")])
+
+TRIG_SHARED, TRIG_LIBM = 0, 1
+ROT_UNFUSED, ROT_FMA = 0, 1
+
+
+class StereoParams(C.Structure):
+    _fields_ = [("n_rows", C.c_int), ("mbf", C.c_float), ("mb", C.c_float), ("min_x", C.c_float)]
+
+
+class FrameBounds(C.Structure):
+    _fields_ = [("min_x", C.c_float), ("min_y", C.c_float), ("max_x", C.c_float), ("max_y", C.c_float)]
+
+
+def build(force=False):
+    if force or not os.path.exists(_LIB_PATH) or any(
+            os.path.getmtime(os.path.join(_HERE, f)) > os.path.getmtime(_LIB_PATH)
+            for f in ("orb_oracle.c", "orb_oracle.h")):
+        subprocess.check_call(["make", "-C", _HERE, "-s"] + (["-B"] if force else []))
+    return _LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB_PATH):
+            build()
+        L = C.CDLL(_LIB_PATH)
+        vp, i, f = C.c_void_p, C.c_int, C.c_float
+        L.orc_create.restype = vp
+        L.orc_create.argtypes = [i, f, i, i, i]
+        L.orc_destroy.argtypes = [vp]
+        L.orc_set_variant.argtypes = [vp, i, i]
+        L.orc_nlevels.argtypes = [vp]
+        for name, rt in (("orc_scale_factors", C.POINTER(C.c_float)), ("orc_inv_scale_factors", C.POINTER(C.c_float)),
+                         ("orc_level_sigma2", C.POINTER(C.c_float)), ("orc_inv_level_sigma2", C.POINTER(C.c_float)),
+                         ("orc_features_per_level", C.POINTER(C.c_int)), ("orc_umax", C.POINTER(C.c_int))):
+            getattr(L, name).restype = rt
+            getattr(L, name).argtypes = [vp]
+        L.orc_extract.argtypes = [vp, vp, i, i, i, vp, vp, i]
+        L.orc_compute_pyramid.argtypes = [vp, vp, i, i, i]
+        L.orc_level_size.argtypes = [vp, i, C.POINTER(i), C.POINTER(i)]
+        L.orc_get_level.argtypes = [vp, i, vp, i]
+        L.orc_get_level_padded.argtypes = [vp, i, vp, i]
+        L.orc_get_blurred_level.argtypes = [vp, i, vp, i]
+        L.orc_level_candidates.argtypes = [vp, i, vp, i]
+        L.orc_level_keypoint_count.argtypes = [vp, i]
+        L.orc_resize_linear_u8.argtypes = [vp, i, i, i, vp, i, i, i]
+        L.orc_gaussian_blur7_u8.argtypes = [vp, i, i, i, vp, i]
+        L.orc_fast9_nms.argtypes = [vp, i, i, i, i, vp, i]
+        L.orc_fast_atan2.restype = f
+        L.orc_fast_atan2.argtypes = [f, f]
+        L.orc_sincos.argtypes = [f, C.POINTER(f), C.POINTER(f)]
+        L.orc_cv_round.argtypes = [f]
+        L.orc_hamming256.argtypes = [vp, vp]
+        L.orc_stereo_match.argtypes = [vp, vp, i, vp, vp, i, vp, C.POINTER(StereoParams), vp, vp, vp, vp, vp, vp]
+        L.orc_search_by_projection.argtypes = [vp, vp, vp, i, vp, C.POINTER(FrameBounds), vp, vp, i, f, f, vp, vp, vp]
+        L.orc_features_in_area.argtypes = [vp, i, C.POINTER(FrameBounds), f, f, f, i, i, vp, i]
+        _lib = L
+    return _lib
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+class OracleExtractor:
+    """Mirror of ORBextractor (include/ORBextractor.h:81-119) over the C oracle."""
+
+    def __init__(self, nfeatures=2000, scale_factor=1.2, nlevels=8, ini_th=20, min_th=7):
+        self._h = lib().orc_create(nfeatures, scale_factor, nlevels, ini_th, min_th)
+        if not self._h:
+            raise ValueError("orc_create failed")
+        self.nfeatures, self.nlevels = nfeatures, nlevels
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().orc_destroy(self._h)
+            self._h = None
+
+    def set_variant(self, trig=TRIG_SHARED, rot=ROT_UNFUSED):
+        lib().orc_set_variant(self._h, trig, rot)
+
+    def _farr(self, fn):
+        return np.ctypeslib.as_array(fn(self._h), shape=(self.nlevels,)).copy()
+
+    @property
+    def scale_factors(self):
+        return self._farr(lib().orc_scale_factors)
+
+    @property
+    def inv_scale_factors(self):
+        return self._farr(lib().orc_inv_scale_factors)
+
+    @property
+    def level_sigma2(self):
+        return self._farr(lib().orc_level_sigma2)
+
+    @property
+    def inv_level_sigma2(self):
+        return self._farr(lib().orc_inv_level_sigma2)
+
+    @property
+    def features_per_level(self):
+        return self._farr(lib().orc_features_per_level)
+
+    @property
+    def umax(self):
+        return np.ctypeslib.as_array(lib().orc_umax(self._h), shape=(16,)).copy()
+
+    def __call__(self, image, cap=None):
+        image = np.ascontiguousarray(image, dtype=np.uint8)
+        h, w = image.shape
+        cap = cap or (self.nfeatures * 2 + 64)
+        kp = np.zeros(cap, dtype=KEYPOINT_DTYPE)
+        desc = np.zeros((cap, 32), dtype=np.uint8)
+        n = lib().orc_extract(self._h, _p(image), w, h, w, _p(kp), _p(desc), cap)
+        if n > cap:
+            return self.__call__(image, cap=n)
+        return kp[:n].copy(), desc[:n].copy()
+
+    def compute_pyramid(self, image):
+        image = np.ascontiguousarray(image, dtype=np.uint8)
+        h, w = image.shape
+        lib().orc_compute_pyramid(self._h, _p(image), w, h, w)
+
+    def level_size(self, level):
+        w, h = C.c_int(), C.c_int()
+        if lib().orc_level_size(self._h, level, C.byref(w), C.byref(h)) != 0:
+            raise IndexError(level)
+        return w.value, h.value
+
+    def level(self, level, padded=False, blurred=False):
+        w, h = self.level_size(level)
+        if padded:
+            out = np.zeros((h + 38, w + 38), dtype=np.uint8)
+            lib().orc_get_level_padded(self._h, level, _p(out), w + 38)
+        elif blurred:
+            out = np.zeros((h, w), dtype=np.uint8)
+            lib().orc_get_blurred_level(self._h, level, _p(out), w)
+        else:
+            out = np.zeros((h, w), dtype=np.uint8)
+            lib().orc_get_level(self._h, level, _p(out), w)
+        return out
+
+    def level_candidates(self, level):
+        n = lib().orc_level_candidates(self._h, level, None, 0)
+        out = np.zeros((max(n, 1), 3), dtype=np.int32)
+        lib().orc_level_candidates(self._h, level, _p(out), n)
+        return out[:n]
+
+    def level_keypoint_count(self, level):
+        return lib().orc_level_keypoint_count(self._h, level)
+
+
+def resize_linear(src, dw, dh):
+    src = np.ascontiguousarray(src, dtype=np.uint8)
+    sh, sw = src.shape
+    dst = np.zeros((dh, dw), dtype=np.uint8)
+    lib().orc_resize_linear_u8(_p(src), sw, sh, sw, _p(dst), dw, dh, dw)
+    return dst
+
+
+def gaussian_blur7(src):
+    src = np.ascontiguousarray(src, dtype=np.uint8)
+    h, w = src.shape
+    dst = np.zeros_like(src)
+    lib().orc_gaussian_blur7_u8(_p(src), w, h, w, _p(dst), w)
+    return dst
+
+
+def fast9_nms(img, threshold):
+    img = np.ascontiguousarray(img, dtype=np.uint8)
+    h, w = img.shape
+    out = np.zeros((w * h + 1, 3), dtype=np.int32)
+    n = lib().orc_fast9_nms(_p(img), w, h, w, threshold, _p(out), w * h)
+    return out[:n].copy()
+
+
+def hamming256(a, b):
+    a = np.ascontiguousarray(a, dtype=np.uint8)
+    b = np.ascontiguousarray(b, dtype=np.uint8)
+    return lib().orc_hamming256(_p(a), _p(b))
+
+
+def fast_atan2(y, x):
+    return lib().orc_fast_atan2(float(y), float(x))
+
+
+def sincos(t):
+    s, c = C.c_float(), C.c_float()
+    lib().orc_sincos(float(t), C.byref(s), C.byref(c))
+    return s.value, c.value
+
+
+def stereo_match(kl, dl, kr, dr, scale_factors, n_rows, mbf, mb, min_x=0.0, min_d=None, max_d=None):
+    kl = np.ascontiguousarray(kl, dtype=KEYPOINT_DTYPE)
+    kr = np.ascontiguousarray(kr, dtype=KEYPOINT_DTYPE)
+    dl = np.ascontiguousarray(dl, dtype=np.uint8)
+    dr = np.ascontiguousarray(dr, dtype=np.uint8)
+    sf = np.ascontiguousarray(scale_factors, dtype=np.float32)
+    nl, nr = len(kl), len(kr)
+    u_right = np.zeros(max(nl, 1), np.float32)
+    depth = np.zeros(max(nl, 1), np.float32)
+    best_dist = np.zeros(max(nl, 1), np.int32)
+    best_idx = np.zeros(max(nl, 1), np.int32)
+    p = StereoParams(n_rows, mbf, mb, min_x)
+    if min_d is not None:
+        min_d = np.ascontiguousarray(min_d, np.float32)
+        max_d = np.ascontiguousarray(max_d, np.float32)
+    nm = lib().orc_stereo_match(_p(kl), _p(dl), nl, _p(kr), _p(dr), nr, _p(sf), C.byref(p), _p(min_d), _p(max_d),
+                                _p(u_right), _p(depth), _p(best_dist), _p(best_idx))
+    return nm, u_right[:nl], depth[:nl], best_dist[:nl], best_idx[:nl]
+
+
+def search_by_projection(kp_un, desc, u_right, scale_factors, bounds, mps, mp_desc, th, nn_ratio, kp_taken=None):
+    kp_un = np.ascontiguousarray(kp_un, dtype=KEYPOINT_DTYPE)
+    desc = np.ascontiguousarray(desc, dtype=np.uint8)
+    mps = np.ascontiguousarray(mps, dtype=MAP_POINT_DTYPE)
+    mp_desc = np.ascontiguousarray(mp_desc, dtype=np.uint8)
+    sf = np.ascontiguousarray(scale_factors, dtype=np.float32)
+    n, m = len(kp_un), len(mps)
+    if u_right is not None:
+        u_right = np.ascontiguousarray(u_right, np.float32)
+    if kp_taken is not None:
+        kp_taken = np.ascontiguousarray(kp_taken, np.uint8)
+    fb = FrameBounds(*bounds)
+    out_mp = np.zeros(max(n, 1), np.int32)
+    out_score = np.zeros(max(n, 1), np.int32)
+    nm = lib().orc_search_by_projection(_p(kp_un), _p(desc), _p(u_right), n, _p(sf), C.byref(fb), _p(mps), _p(mp_desc), m,
+                                        th, nn_ratio, _p(kp_taken), _p(out_mp), _p(out_score))
+    return nm, out_mp[:n], out_score[:n]
+
+
+def features_in_area(kp_un, bounds, x, y, r, min_level=-1, max_level=-1):
+    kp_un = np.ascontiguousarray(kp_un, dtype=KEYPOINT_DTYPE)
+    n = len(kp_un)
+    fb = FrameBounds(*bounds)
+    out = np.zeros(max(n, 1), np.int32)
+    k = lib().orc_features_in_area(_p(kp_un), n, C.byref(fb), x, y, r, min_level, max_level, _p(out), n)
+    return out[:k].copy()
