@@ -1,0 +1,13 @@
+"""MI355X-native ORB front-end for GF-ORB-SLAM2 (host-side mirror of the reference interface).
+
+The product is `libgfo.so` (HIP kernels for gfx950 behind the C ABI of include/gfo.h); this
+package is the thin host layer tests and bench.py drive it through.  It never imports the CPU
+oracle and has no CPU fallback: without the built library and a gfx950 device it raises.
+"""
+from ._lib import GfoError, KEYPOINT_DTYPE, MAP_POINT_DTYPE, lib_path, load_library  # noqa: F401
+from .extractor import ORBextractor  # noqa: F401
+from .matcher import ORBmatcher, StereoParams, FrameBounds  # noqa: F401
+from .build import build_library  # noqa: F401
+
+__all__ = ["ORBextractor", "ORBmatcher", "StereoParams", "FrameBounds", "GfoError", "KEYPOINT_DTYPE",
+           "MAP_POINT_DTYPE", "build_library", "load_library", "lib_path"]

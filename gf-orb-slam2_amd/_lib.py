@@ -1,0 +1,108 @@
+"""ctypes binding of include/gfo.h."""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+
+KEYPOINT_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"),
+                           ("response", "<f4"), ("octave", "<i4"), ("class_id", "<i4")])
+MAP_POINT_DTYPE = np.dtype([("proj_x", "<f4"), ("proj_y", "<f4"), ("proj_xr", "<f4"),
+                            ("view_cos", "<f4"), ("level", "<i4"), ("flags", "<i4")])
+GFO_MAX_LEVELS = 16
+GFO_STAGE_MAX = 16
+
+
+class GfoError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"gfo error {code}: {msg}")
+        self.code = code
+
+
+class Params(C.Structure):
+    _fields_ = [("nfeatures", C.c_int32), ("scale_factor", C.c_float), ("nlevels", C.c_int32),
+                ("ini_th_fast", C.c_int32), ("min_th_fast", C.c_int32), ("max_batch", C.c_int32)]
+
+
+class StereoParamsC(C.Structure):
+    _fields_ = [("n_rows", C.c_int32), ("mbf", C.c_float), ("mb", C.c_float), ("min_x", C.c_float)]
+
+
+class FrameBoundsC(C.Structure):
+    _fields_ = [("min_x", C.c_float), ("min_y", C.c_float), ("max_x", C.c_float), ("max_y", C.c_float)]
+
+
+class StageTime(C.Structure):
+    _fields_ = [("name", C.c_char * 32), ("ms", C.c_double), ("launches", C.c_int)]
+
+
+# every symbol include/gfo.h declares (tests check the library exports all of them)
+SYMBOLS = [
+    "gfo_version", "gfo_ctx_create", "gfo_ctx_destroy", "gfo_last_error", "gfo_ctx_set_stream",
+    "gfo_ctx_synchronize", "gfo_ctx_tables", "gfo_ctx_max_keypoints", "gfo_extract", "gfo_extract_batch",
+    "gfo_extract_batch_device", "gfo_batch_counts", "gfo_batch_fetch", "gfo_batch_device_views",
+    "gfo_compute_pyramid", "gfo_pyramid_level", "gfo_hamming256", "gfo_stereo_match",
+    "gfo_stereo_match_batch", "gfo_stereo_fetch", "gfo_search_by_projection", "gfo_profile_enable",
+    "gfo_profile_read", "gfo_debug_blurred_level", "gfo_debug_level_candidates",
+]
+
+
+def lib_path():
+    return os.path.join(_HERE, "libgfo.so")
+
+
+_lib = None
+
+
+def load_library():
+    """Loads libgfo.so; raises if it has not been built (no fallback of any kind)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    p = lib_path()
+    if not os.path.exists(p):
+        raise GfoError(-2, f"{p} not built: run `python -c 'import __graft_entry__ as g; g.build()'`")
+    L = C.CDLL(p)
+    vp, i, f, sz = C.c_void_p, C.c_int, C.c_float, C.c_size_t
+    ip = C.POINTER(C.c_int)
+    L.gfo_version.restype = i
+    L.gfo_ctx_create.argtypes = [C.POINTER(Params), i, C.POINTER(vp)]
+    L.gfo_ctx_destroy.argtypes = [vp]
+    L.gfo_ctx_destroy.restype = None
+    L.gfo_last_error.argtypes = [vp]
+    L.gfo_last_error.restype = C.c_char_p
+    L.gfo_ctx_set_stream.argtypes = [vp, vp]
+    L.gfo_ctx_synchronize.argtypes = [vp]
+    L.gfo_ctx_tables.argtypes = [vp, vp, vp, vp, vp, vp]
+    L.gfo_ctx_max_keypoints.argtypes = [vp]
+    L.gfo_extract.argtypes = [vp, vp, i, i, i, vp, vp, i, ip]
+    L.gfo_extract_batch.argtypes = [vp, vp, i, i, i, i, vp, vp, i, vp]
+    L.gfo_extract_batch_device.argtypes = [vp, vp, i, i, i, sz, sz]
+    L.gfo_batch_counts.argtypes = [vp, vp, vp]
+    L.gfo_batch_fetch.argtypes = [vp, i, vp, vp, i, ip]
+    L.gfo_batch_device_views.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), ip]
+    L.gfo_compute_pyramid.argtypes = [vp, vp, i, i, i]
+    L.gfo_pyramid_level.argtypes = [vp, i, i, i, vp, i, ip, ip]
+    L.gfo_hamming256.argtypes = [vp, vp]
+    L.gfo_stereo_match.argtypes = [vp, vp, vp, i, vp, vp, i, vp, i, C.POINTER(StereoParamsC), vp, vp, vp, vp, vp, vp, ip]
+    L.gfo_stereo_match_batch.argtypes = [vp, C.POINTER(StereoParamsC)]
+    L.gfo_stereo_fetch.argtypes = [vp, i, vp, vp, vp, vp, i, ip]
+    L.gfo_search_by_projection.argtypes = [vp, vp, vp, vp, i, vp, i, C.POINTER(FrameBoundsC), vp, vp, i, f, f, vp, vp, vp, ip]
+    L.gfo_profile_enable.argtypes = [vp, i]
+    L.gfo_profile_read.argtypes = [vp, C.POINTER(StageTime), i, ip, i]
+    L.gfo_debug_blurred_level.argtypes = [vp, i, i, vp, i]
+    L.gfo_debug_level_candidates.argtypes = [vp, i, i, vp, i, ip]
+    _lib = L
+    return L
+
+
+def ptr(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def check(L, ctx, rc, allow=()):
+    if rc != 0 and rc not in allow:
+        msg = L.gfo_last_error(ctx)
+        raise GfoError(rc, msg.decode() if msg else "")
+    return rc

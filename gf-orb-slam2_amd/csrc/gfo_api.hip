@@ -1,0 +1,770 @@
+// gfo_api.hip -- the extern "C" boundary of libgfo.so (include/gfo.h): context, host tables,
+// arena planning, pipeline orchestration.  Host-side C++; every device stage is a HIP kernel
+// in its own k_*.hip file.  No CPU fallback exists anywhere in this library.
+#include "gfo_internal.h"
+
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+static std::string g_create_err;
+
+static int fail(gfo_ctx* c, int code, const char* fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (c) c->err = buf;
+    else g_create_err = buf;
+    return code;
+}
+
+#define HIP_TRY(c, expr)                                                                        \
+    do {                                                                                        \
+        hipError_t e_ = (expr);                                                                 \
+        if (e_ != hipSuccess) return fail((c), GFO_ERR_DEVICE, "%s: %s", #expr, hipGetErrorString(e_)); \
+    } while (0)
+
+static inline long long align_up(long long v, long long a) { return (v + a - 1) / a * a; }
+
+// ---------------------------------------------------------------------------------------------
+// profiling
+// ---------------------------------------------------------------------------------------------
+static const char* k_stage_names[ST_COUNT] = {"resize", "blur", "fast", "quadtree", "orient_desc",
+                                              "stereo_match", "stereo_cut", "project"};
+
+static hipEvent_t ev_get(gfo_ctx* c)
+{
+    if (!c->ev_pool.empty()) {
+        hipEvent_t e = c->ev_pool.back();
+        c->ev_pool.pop_back();
+        return e;
+    }
+    hipEvent_t e = nullptr;
+    (void)hipEventCreate(&e);
+    return e;
+}
+
+void gfo_prof_begin(gfo_ctx* c, int stage)
+{
+    c->cur_stage = stage;
+    if (!c->profiling) return;
+    gfo_ctx::PendingEv p{stage, ev_get(c), ev_get(c)};
+    (void)hipEventRecord(p.a, c->stream);
+    c->pending.push_back(p);
+}
+
+void gfo_prof_end(gfo_ctx* c)
+{
+    if (c->debug_sync) {  // GFO_DEBUG_SYNC=1: attribute launch/runtime errors to their stage
+        hipError_t e = hipGetLastError();
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        if (e != hipSuccess && c->launch_err.empty())
+            c->launch_err = std::string("stage ") + k_stage_names[c->cur_stage] + ": " + hipGetErrorString(e);
+    }
+    if (!c->profiling || c->pending.empty()) return;
+    (void)hipEventRecord(c->pending.back().b, c->stream);
+}
+
+static void prof_collect(gfo_ctx* c)
+{
+    if (c->pending.empty()) return;
+    (void)hipStreamSynchronize(c->stream);
+    for (auto& p : c->pending) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) {
+            c->stage_ms[p.stage] += ms;
+            c->stage_launches[p.stage]++;
+        }
+        c->ev_pool.push_back(p.a);
+        c->ev_pool.push_back(p.b);
+    }
+    c->pending.clear();
+}
+
+// ---------------------------------------------------------------------------------------------
+// host tables -- ORBextractor::ORBextractor, ORBextractor.cc:409-469
+// ---------------------------------------------------------------------------------------------
+static void build_tables(gfo_ctx* c)
+{
+    const int n = c->prm.nlevels;
+    c->scale.assign(n, 1.f);
+    c->inv_scale.assign(n, 1.f);
+    c->sigma2.assign(n, 1.f);
+    c->inv_sigma2.assign(n, 1.f);
+    c->quota.assign(n, 0);
+    for (int i = 1; i < n; i++) {
+        c->scale[i] = c->scale[i - 1] * c->prm.scale_factor;
+        c->sigma2[i] = c->scale[i] * c->scale[i];
+    }
+    for (int i = 0; i < n; i++) {
+        c->inv_scale[i] = 1.0f / c->scale[i];
+        c->inv_sigma2[i] = 1.0f / c->sigma2[i];
+    }
+    const float factor = 1.0f / c->prm.scale_factor;
+    float per = c->prm.nfeatures * (1 - factor) / (1 - (float)pow((double)factor, (double)n));
+    int sum = 0;
+    for (int l = 0; l < n - 1; l++) {
+        c->quota[l] = (int)lrintf(per);  // cvRound: half to even
+        sum += c->quota[l];
+        per *= factor;
+    }
+    c->quota[n - 1] = c->prm.nfeatures - sum > 0 ? c->prm.nfeatures - sum : 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// arena
+// ---------------------------------------------------------------------------------------------
+static void free_arena(gfo_ctx* c)
+{
+    void* ptrs[] = {c->d_geom, c->d_input, c->d_pyr, c->d_blur, c->d_cand, c->d_cand_cnt, c->d_node_of, c->d_sel,
+                    c->d_sel_cnt, c->d_kp, c->d_desc, c->d_kp_cnt, c->d_flags, c->d_xofs, c->d_xcoef, c->d_yofs,
+                    c->d_ycoef, c->st.u_right, c->st.depth, c->st.best_dist, c->st.best_idx, c->st.nmatched,
+                    c->d_scale};
+    for (void* p : ptrs)
+        if (p) (void)hipFree(p);
+    c->d_geom = nullptr; c->d_input = c->d_pyr = c->d_blur = nullptr; c->d_cand = nullptr; c->d_cand_cnt = nullptr;
+    c->d_node_of = nullptr; c->d_sel = nullptr; c->d_sel_cnt = nullptr; c->d_kp = nullptr; c->d_desc = nullptr;
+    c->d_kp_cnt = nullptr; c->d_flags = nullptr; c->d_xofs = nullptr; c->d_xcoef = nullptr; c->d_yofs = nullptr;
+    c->d_ycoef = nullptr; c->st = GfoStereoDev{}; c->d_scale = nullptr;
+    c->planned = false;
+    c->have_batch = c->have_pyramid = c->have_stereo = false;
+}
+
+// cv::resize(INTER_LINEAR) coefficient tables, built exactly as OpenCV builds them (double
+// scale, float fraction, 11-bit rounding; x clamps the fraction at the borders, y clips rows).
+static void resize_tables(int ssize, int dsize, int* ofs, short* coef, bool clamp_x)
+{
+    const double inv_scale = (double)dsize / ssize;
+    const double scale = 1. / inv_scale;
+    for (int d = 0; d < dsize; d++) {
+        float f = (float)((d + 0.5) * scale - 0.5);
+        int s = (int)floorf(f);
+        f -= s;
+        if (clamp_x) {
+            if (s < 0) { f = 0; s = 0; }
+            if (s >= ssize - 1) { f = 0; s = ssize - 1; }
+        }
+        ofs[d] = s;
+        coef[2 * d] = (short)lrintf((1.f - f) * 2048.f);
+        coef[2 * d + 1] = (short)lrintf(f * 2048.f);
+    }
+}
+
+static int plan(gfo_ctx* c, int w, int h, int batch)
+{
+    if (c->planned && c->g.w0 == w && c->g.h0 == h && batch <= c->cap_batch) return GFO_OK;
+    if (w > 4000 || h > 4000) return fail(c, GFO_ERR_INVALID, "image %dx%d exceeds the 4000-px coordinate packing", w, h);
+    const int keep_batch = c->planned && c->g.w0 == w && c->g.h0 == h ? c->cap_batch : 0;
+    (void)hipStreamSynchronize(c->stream);
+    free_arena(c);
+    batch = batch > keep_batch ? batch : keep_batch;
+    if (batch < c->prm.max_batch) batch = c->prm.max_batch;
+    GfoGeom& g = c->g;
+    memset(&g, 0, sizeof g);
+    g.nlevels = c->prm.nlevels;
+    g.w0 = w;
+    g.h0 = h;
+    g.ini_th = c->prm.ini_th_fast;
+    g.min_th = c->prm.min_th_fast;
+    long long pyr_off = 0, blur_off = 0, cand_off = 0;
+    int cell_base = 0, tile_base = 0, sel_off = 0, xtab = 0, ytab = 0;
+    int max_cw = 8, max_ch = 8;
+    for (int l = 0; l < g.nlevels; l++) {
+        GfoLevel& L = g.lv[l];
+        const float s = c->inv_scale[l];
+        L.w = (int)lrintf((float)w * s);  // ORBextractor.cc:1180-1181
+        L.h = (int)lrintf((float)h * s);
+        if (L.w < 1 || L.h < 1) return fail(c, GFO_ERR_INVALID, "level %d of a %dx%d image is empty", l, w, h);
+        L.pitch = (int)align_up(L.w, 64);
+        L.plane_off = pyr_off;
+        if (l > 0) pyr_off += align_up((long long)L.pitch * L.h, 256);
+        L.blur_off = blur_off;
+        blur_off += align_up((long long)L.pitch * L.h, 256);
+        L.max_bx = L.w - GFO_EDGE + 3;
+        L.max_by = L.h - GFO_EDGE + 3;
+        const float width = (float)(L.max_bx - GFO_MIN_BORDER), height = (float)(L.max_by - GFO_MIN_BORDER);
+        L.cell_base = cell_base;
+        if (width >= (float)GFO_CELL_W && height >= (float)GFO_CELL_W) {  // :783-789
+            L.ncols = (int)(width / GFO_CELL_W);
+            L.nrows = (int)(height / GFO_CELL_W);
+            L.wcell = (int)ceilf(width / L.ncols);
+            L.hcell = (int)ceilf(height / L.nrows);
+            cell_base += L.ncols * L.nrows;
+            max_cw = L.wcell + 6 > max_cw ? L.wcell + 6 : max_cw;
+            max_ch = L.hcell + 6 > max_ch ? L.hcell + 6 : max_ch;
+            L.cand_cap = L.ncols * L.nrows * ((L.wcell + 1) / 2) * ((L.hcell + 1) / 2);
+        } else {
+            L.ncols = L.nrows = 0;
+            L.wcell = L.hcell = 1;
+            L.cand_cap = 0;
+        }
+        L.cand_off = cand_off;
+        cand_off += align_up(L.cand_cap, 64);
+        L.tiles_x = (L.w + 63) / 64;
+        L.tiles_y = (L.h + 15) / 16;
+        L.tile_base = tile_base;
+        tile_base += L.tiles_x * L.tiles_y;
+        L.quota = c->quota[l];
+        int nini = 1;
+        if (L.max_by - GFO_MIN_BORDER > 0) nini = (int)roundf(width / height);  // :543
+        if (nini < 1) nini = 1;
+        L.n_ini = nini;
+        L.hx = width / nini;
+        L.node_cap = (L.quota > 4 * nini ? L.quota : 4 * nini) + 8;
+        L.sel_off = sel_off;
+        L.sel_cap = L.node_cap;
+        sel_off += L.sel_cap;
+        L.scale = c->scale[l];
+        L.patch_size = (int)(GFO_PATCH * c->scale[l]);  // :839
+        L.xtab_off = xtab;
+        L.ytab_off = ytab;
+        if (l > 0) {
+            xtab += L.w;
+            ytab += L.h;
+        }
+        if (L.node_cap > 60000) return fail(c, GFO_ERR_INVALID, "level quota %d too large", L.quota);
+    }
+    if (max_cw - 6 > 64 || max_ch - 6 > 64)
+        return fail(c, GFO_ERR_INVALID, "FAST cell %dx%d exceeds the per-wave plan", max_cw - 6, max_ch - 6);
+    g.total_cells = cell_base;
+    g.total_tiles = tile_base;
+    g.total_sel_cap = sel_off;
+    g.kp_stride = (int)align_up(sel_off, 4);
+    g.fast_tile_pitch = (int)align_up(max_cw, 4);
+    g.fast_tile_rows = max_ch;
+    g.fast_smap_pitch = (int)align_up(max_cw - 6 + 2, 4);
+    g.fast_smap_rows = max_ch - 6 + 2;
+    g.pyr_img_stride = align_up(pyr_off, 256);
+    g.blur_img_stride = align_up(blur_off, 256);
+    g.cand_img_stride = align_up(cand_off, 64);
+    if (g.kp_stride > 65535) return fail(c, GFO_ERR_INVALID, "more than 65535 keypoints per image are not supported");
+
+    // resize tables
+    std::vector<int> xofs(xtab > 0 ? xtab : 1), yofs(ytab > 0 ? ytab : 1);
+    std::vector<short> xcoef(2 * (xtab > 0 ? xtab : 1)), ycoef(2 * (ytab > 0 ? ytab : 1));
+    for (int l = 1; l < g.nlevels; l++) {
+        resize_tables(g.lv[l - 1].w, g.lv[l].w, &xofs[g.lv[l].xtab_off], &xcoef[2 * g.lv[l].xtab_off], true);
+        resize_tables(g.lv[l - 1].h, g.lv[l].h, &yofs[g.lv[l].ytab_off], &ycoef[2 * g.lv[l].ytab_off], false);
+    }
+    const size_t B = (size_t)batch;
+    HIP_TRY(c, hipMalloc(&c->d_geom, sizeof(GfoGeom)));
+    HIP_TRY(c, hipMalloc(&c->d_input, B * g.lv[0].pitch * (size_t)h));
+    HIP_TRY(c, hipMalloc(&c->d_pyr, B * (size_t)(g.pyr_img_stride > 0 ? g.pyr_img_stride : 256)));
+    HIP_TRY(c, hipMalloc(&c->d_blur, B * (size_t)g.blur_img_stride));
+    HIP_TRY(c, hipMalloc(&c->d_cand, B * (size_t)(g.cand_img_stride + 64) * sizeof(uint32_t)));
+    HIP_TRY(c, hipMalloc(&c->d_node_of, B * (size_t)(g.cand_img_stride + 64) * sizeof(uint16_t)));
+    HIP_TRY(c, hipMalloc(&c->d_cand_cnt, B * g.nlevels * sizeof(int)));
+    HIP_TRY(c, hipMalloc(&c->d_sel, B * (size_t)g.total_sel_cap * sizeof(uint32_t)));
+    HIP_TRY(c, hipMalloc(&c->d_sel_cnt, B * g.nlevels * sizeof(int)));
+    HIP_TRY(c, hipMalloc(&c->d_kp, B * (size_t)g.kp_stride * sizeof(gfo_keypoint)));
+    HIP_TRY(c, hipMalloc(&c->d_desc, B * (size_t)g.kp_stride * 32));
+    HIP_TRY(c, hipMalloc(&c->d_kp_cnt, B * sizeof(int)));
+    HIP_TRY(c, hipMalloc(&c->d_flags, 4 * sizeof(int)));
+    HIP_TRY(c, hipMalloc(&c->d_xofs, xofs.size() * sizeof(int)));
+    HIP_TRY(c, hipMalloc(&c->d_xcoef, xcoef.size() * sizeof(short)));
+    HIP_TRY(c, hipMalloc(&c->d_yofs, yofs.size() * sizeof(int)));
+    HIP_TRY(c, hipMalloc(&c->d_ycoef, ycoef.size() * sizeof(short)));
+    HIP_TRY(c, hipMalloc(&c->d_scale, GFO_MAX_LEVELS * sizeof(float)));
+    const size_t P = (B + 1) / 2;
+    HIP_TRY(c, hipMalloc(&c->st.u_right, P * g.kp_stride * sizeof(float)));
+    HIP_TRY(c, hipMalloc(&c->st.depth, P * g.kp_stride * sizeof(float)));
+    HIP_TRY(c, hipMalloc(&c->st.best_dist, P * g.kp_stride * sizeof(int)));
+    HIP_TRY(c, hipMalloc(&c->st.best_idx, P * g.kp_stride * sizeof(int)));
+    HIP_TRY(c, hipMalloc(&c->st.nmatched, P * sizeof(int)));
+    HIP_TRY(c, hipMemcpy(c->d_geom, &g, sizeof g, hipMemcpyHostToDevice));
+    HIP_TRY(c, hipMemcpy(c->d_xofs, xofs.data(), xofs.size() * sizeof(int), hipMemcpyHostToDevice));
+    HIP_TRY(c, hipMemcpy(c->d_xcoef, xcoef.data(), xcoef.size() * sizeof(short), hipMemcpyHostToDevice));
+    HIP_TRY(c, hipMemcpy(c->d_yofs, yofs.data(), yofs.size() * sizeof(int), hipMemcpyHostToDevice));
+    HIP_TRY(c, hipMemcpy(c->d_ycoef, ycoef.data(), ycoef.size() * sizeof(short), hipMemcpyHostToDevice));
+    HIP_TRY(c, hipMemcpy(c->d_scale, c->scale.data(), g.nlevels * sizeof(float), hipMemcpyHostToDevice));
+    HIP_TRY(c, hipMemset(c->d_flags, 0, 4 * sizeof(int)));
+    c->cap_batch = batch;
+    c->planned = true;
+    return GFO_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// context
+// ---------------------------------------------------------------------------------------------
+extern "C" int gfo_version(void) { return GFO_VERSION; }
+
+extern "C" const char* gfo_last_error(const gfo_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_err.c_str(); }
+
+extern "C" int gfo_ctx_create(const gfo_params* p, int device, gfo_ctx** out)
+{
+    if (!p || !out) return fail(nullptr, GFO_ERR_INVALID, "null argument");
+    *out = nullptr;
+    if (p->nlevels < 1 || p->nlevels > GFO_MAX_LEVELS) return fail(nullptr, GFO_ERR_INVALID, "nlevels must be 1..%d", GFO_MAX_LEVELS);
+    if (p->nfeatures < 1 || !(p->scale_factor > 1.0f)) return fail(nullptr, GFO_ERR_INVALID, "nfeatures >= 1 and scale_factor > 1 required");
+    if (p->ini_th_fast < 1 || p->min_th_fast < 1 || p->ini_th_fast > 254 || p->min_th_fast > 254)
+        return fail(nullptr, GFO_ERR_INVALID, "FAST thresholds must be in 1..254");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1)
+        return fail(nullptr, GFO_ERR_DEVICE, "no HIP device available (this library has no CPU fallback)");
+    if (device < 0 || device >= ndev) return fail(nullptr, GFO_ERR_INVALID, "device %d out of range (0..%d)", device, ndev - 1);
+    hipDeviceProp_t prop;
+    HIP_TRY(nullptr, hipGetDeviceProperties(&prop, device));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(nullptr, GFO_ERR_DEVICE, "device %d is %s; libgfo is built for gfx950 only", device, prop.gcnArchName);
+    HIP_TRY(nullptr, hipSetDevice(device));
+    gfo_ctx* c = new gfo_ctx();
+    c->prm = *p;
+    if (c->prm.max_batch < 1) c->prm.max_batch = 1;
+    c->device = device;
+    if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess) {
+        delete c;
+        return fail(nullptr, GFO_ERR_DEVICE, "hipStreamCreate failed");
+    }
+    c->stream = c->own_stream;
+    const char* dbg = getenv("GFO_DEBUG_SYNC");
+    c->debug_sync = dbg && dbg[0] == '1';
+    build_tables(c);
+    *out = c;
+    return GFO_OK;
+}
+
+extern "C" void gfo_ctx_destroy(gfo_ctx* c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    prof_collect(c);
+    for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);
+    free_arena(c);
+    if (c->d_scratch) (void)hipFree(c->d_scratch);
+    if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+    delete c;
+}
+
+extern "C" int gfo_ctx_set_stream(gfo_ctx* c, void* s)
+{
+    if (!c) return GFO_ERR_INVALID;
+    (void)hipStreamSynchronize(c->stream);
+    c->stream = s ? (hipStream_t)s : c->own_stream;
+    return GFO_OK;
+}
+
+extern "C" int gfo_ctx_synchronize(gfo_ctx* c)
+{
+    if (!c) return GFO_ERR_INVALID;
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return GFO_OK;
+}
+
+extern "C" int gfo_ctx_tables(const gfo_ctx* c, float* scale, float* inv_scale, float* sigma2, float* inv_sigma2,
+                              int32_t* quota)
+{
+    if (!c) return GFO_ERR_INVALID;
+    const int n = c->prm.nlevels;
+    if (scale) memcpy(scale, c->scale.data(), n * sizeof(float));
+    if (inv_scale) memcpy(inv_scale, c->inv_scale.data(), n * sizeof(float));
+    if (sigma2) memcpy(sigma2, c->sigma2.data(), n * sizeof(float));
+    if (inv_sigma2) memcpy(inv_sigma2, c->inv_sigma2.data(), n * sizeof(float));
+    if (quota) memcpy(quota, c->quota.data(), n * sizeof(int));
+    return GFO_OK;
+}
+
+extern "C" int gfo_ctx_max_keypoints(const gfo_ctx* c)
+{
+    if (!c) return GFO_ERR_INVALID;
+    if (c->planned) return c->g.kp_stride;
+    int s = 0;
+    for (int l = 0; l < c->prm.nlevels; l++) s += (c->quota[l] > 32 ? c->quota[l] : 32) + 8;
+    return (int)align_up(s, 4);
+}
+
+// ---------------------------------------------------------------------------------------------
+// extraction pipeline
+// ---------------------------------------------------------------------------------------------
+static int run_pyramid(gfo_ctx* c, const GfoInput& in, int nimg)
+{
+    for (int l = 1; l < c->g.nlevels; l++) gfo_launch_resize(c, in, l, nimg);
+    c->last_in = in;
+    c->last_nimg = nimg;
+    c->have_pyramid = true;
+    return GFO_OK;
+}
+
+static int run_extract(gfo_ctx* c, const GfoInput& in, int nimg)
+{
+    HIP_TRY(c, hipMemsetAsync(c->d_cand_cnt, 0, sizeof(int) * nimg * c->g.nlevels, c->stream));
+    run_pyramid(c, in, nimg);
+    gfo_launch_blur(c, in, nimg);
+    gfo_launch_fast(c, in, nimg);
+    gfo_launch_quadtree(c, nimg);
+    gfo_launch_orient_desc(c, in, nimg);
+    if (!c->launch_err.empty()) {
+        const std::string m = c->launch_err;
+        c->launch_err.clear();
+        return fail(c, GFO_ERR_DEVICE, "%s", m.c_str());
+    }
+    HIP_TRY(c, hipGetLastError());
+    c->have_batch = true;
+    c->have_stereo = false;
+    return GFO_OK;
+}
+
+static int check_flags(gfo_ctx* c)
+{
+    int f[4] = {0, 0, 0, 0};
+    HIP_TRY(c, hipMemcpyAsync(f, c->d_flags, sizeof f, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (f[0]) {
+        (void)hipMemsetAsync(c->d_flags, 0, sizeof f, c->stream);
+        return fail(c, GFO_ERR_OVERFLOW, "internal buffer overflow (flags 0x%x: 1 candidates, 2 quadtree nodes, 4 selection, 8 keypoints)", f[0]);
+    }
+    return GFO_OK;
+}
+
+static int upload_images(gfo_ctx* c, const uint8_t* const* imgs, int nimg, int w, int h, int stride, GfoInput* in)
+{
+    const int pitch = c->g.lv[0].pitch;
+    for (int i = 0; i < nimg; i++)
+        HIP_TRY(c, hipMemcpy2DAsync(c->d_input + (size_t)i * pitch * h, pitch, imgs[i], stride, w, h,
+                                    hipMemcpyHostToDevice, c->stream));
+    in->base = c->d_input;
+    in->pitch = pitch;
+    in->img_stride = (long long)pitch * h;
+    return GFO_OK;
+}
+
+extern "C" int gfo_extract_batch_device(gfo_ctx* c, const uint8_t* d_imgs, int nimg, int w, int h, size_t pitch,
+                                        size_t img_stride)
+{
+    if (!c || !d_imgs || nimg < 1 || w < 1 || h < 1 || pitch < (size_t)w) return fail(c, GFO_ERR_INVALID, "bad argument");
+    HIP_TRY(c, hipSetDevice(c->device));
+    int rc = plan(c, w, h, nimg);
+    if (rc) return rc;
+    GfoInput in{d_imgs, (long long)pitch, (long long)img_stride};
+    return run_extract(c, in, nimg);
+}
+
+extern "C" int gfo_batch_counts(gfo_ctx* c, int* n, int* per_level)
+{
+    if (!c || !n) return GFO_ERR_INVALID;
+    if (!c->have_batch) return fail(c, GFO_ERR_STATE, "no batch has been extracted");
+    int rc = check_flags(c);
+    if (rc) return rc;
+    HIP_TRY(c, hipMemcpyAsync(n, c->d_kp_cnt, sizeof(int) * c->last_nimg, hipMemcpyDeviceToHost, c->stream));
+    if (per_level)
+        HIP_TRY(c, hipMemcpyAsync(per_level, c->d_sel_cnt, sizeof(int) * c->last_nimg * c->g.nlevels, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return GFO_OK;
+}
+
+extern "C" int gfo_batch_fetch(gfo_ctx* c, int image, gfo_keypoint* kp, uint8_t* desc, int cap, int* n)
+{
+    if (!c || !n) return GFO_ERR_INVALID;
+    if (!c->have_batch) return fail(c, GFO_ERR_STATE, "no batch has been extracted");
+    if (image < 0 || image >= c->last_nimg) return fail(c, GFO_ERR_INVALID, "image %d out of range", image);
+    int rc = check_flags(c);
+    if (rc) return rc;
+    int cnt = 0;
+    HIP_TRY(c, hipMemcpyAsync(&cnt, c->d_kp_cnt + image, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    *n = cnt;
+    const int m = cnt < cap ? cnt : cap;
+    if (m > 0 && kp)
+        HIP_TRY(c, hipMemcpyAsync(kp, c->d_kp + (size_t)image * c->g.kp_stride, sizeof(gfo_keypoint) * m, hipMemcpyDeviceToHost, c->stream));
+    if (m > 0 && desc)
+        HIP_TRY(c, hipMemcpyAsync(desc, c->d_desc + (size_t)image * c->g.kp_stride * 32, 32 * (size_t)m, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return cnt > cap ? fail(c, GFO_ERR_CAPACITY, "%d keypoints, caller capacity %d", cnt, cap) : GFO_OK;
+}
+
+extern "C" int gfo_batch_device_views(gfo_ctx* c, const gfo_keypoint** d_kp, const uint8_t** d_desc,
+                                      const int32_t** d_counts, int* kp_stride)
+{
+    if (!c) return GFO_ERR_INVALID;
+    if (!c->have_batch) return fail(c, GFO_ERR_STATE, "no batch has been extracted");
+    if (d_kp) *d_kp = c->d_kp;
+    if (d_desc) *d_desc = c->d_desc;
+    if (d_counts) *d_counts = c->d_kp_cnt;
+    if (kp_stride) *kp_stride = c->g.kp_stride;
+    return GFO_OK;
+}
+
+extern "C" int gfo_extract_batch(gfo_ctx* c, const uint8_t* const* imgs, int nimg, int w, int h, int stride,
+                                 gfo_keypoint* kp, uint8_t* desc, int cap, int* n)
+{
+    if (!c || !n) return GFO_ERR_INVALID;
+    if (!imgs || nimg < 1 || w <= 0 || h <= 0) {  // ORBextractor.cc:1115-1116: empty image, outputs untouched
+        for (int i = 0; i < nimg && n; i++) n[i] = 0;
+        return GFO_OK;
+    }
+    if (stride < w) return fail(c, GFO_ERR_INVALID, "stride < width");
+    HIP_TRY(c, hipSetDevice(c->device));
+    int rc = plan(c, w, h, nimg);
+    if (rc) return rc;
+    GfoInput in;
+    rc = upload_images(c, imgs, nimg, w, h, stride, &in);
+    if (rc) return rc;
+    rc = run_extract(c, in, nimg);
+    if (rc) return rc;
+    rc = gfo_batch_counts(c, n, nullptr);
+    if (rc) return rc;
+    int over = 0;
+    for (int i = 0; i < nimg; i++) {
+        const int m = n[i] < cap ? n[i] : cap;
+        if (n[i] > cap) over = 1;
+        if (m > 0 && kp)
+            HIP_TRY(c, hipMemcpyAsync(kp + (size_t)i * cap, c->d_kp + (size_t)i * c->g.kp_stride, sizeof(gfo_keypoint) * m, hipMemcpyDeviceToHost, c->stream));
+        if (m > 0 && desc)
+            HIP_TRY(c, hipMemcpyAsync(desc + (size_t)i * cap * 32, c->d_desc + (size_t)i * c->g.kp_stride * 32, 32 * (size_t)m, hipMemcpyDeviceToHost, c->stream));
+    }
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return over ? fail(c, GFO_ERR_CAPACITY, "an image produced more keypoints than the caller capacity %d", cap) : GFO_OK;
+}
+
+extern "C" int gfo_extract(gfo_ctx* c, const uint8_t* img, int w, int h, int stride, gfo_keypoint* kp, uint8_t* desc,
+                           int cap, int* n)
+{
+    if (!c || !n) return GFO_ERR_INVALID;
+    if (!img || w <= 0 || h <= 0) {
+        *n = 0;
+        return GFO_OK;
+    }
+    const uint8_t* one[1] = {img};
+    return gfo_extract_batch(c, one, 1, w, h, stride, kp, desc, cap, n);
+}
+
+// ---------------------------------------------------------------------------------------------
+// pyramid access -- ComputePyramid / mvImagePyramid
+// ---------------------------------------------------------------------------------------------
+extern "C" int gfo_compute_pyramid(gfo_ctx* c, const uint8_t* img, int w, int h, int stride)
+{
+    if (!c || !img || w <= 0 || h <= 0 || stride < w) return fail(c, GFO_ERR_INVALID, "bad argument");
+    HIP_TRY(c, hipSetDevice(c->device));
+    int rc = plan(c, w, h, 1);
+    if (rc) return rc;
+    GfoInput in;
+    const uint8_t* one[1] = {img};
+    rc = upload_images(c, one, 1, w, h, stride, &in);
+    if (rc) return rc;
+    c->have_batch = false;
+    run_pyramid(c, in, 1);
+    HIP_TRY(c, hipGetLastError());
+    return GFO_OK;
+}
+
+static int reflect101_host(int p, int n)
+{
+    if (n == 1) return 0;
+    while (p < 0 || p >= n) p = p < 0 ? -p : 2 * (n - 1) - p;
+    return p;
+}
+
+extern "C" int gfo_pyramid_level(gfo_ctx* c, int image, int level, int border, uint8_t* out, int out_stride, int* w, int* h)
+{
+    if (!c || !out) return GFO_ERR_INVALID;
+    if (!c->have_pyramid) return fail(c, GFO_ERR_STATE, "no pyramid has been computed");
+    if (image < 0 || image >= c->last_nimg || level < 0 || level >= c->g.nlevels || border < 0)
+        return fail(c, GFO_ERR_INVALID, "image/level out of range");
+    const GfoLevel& L = c->g.lv[level];
+    if (out_stride < L.w + 2 * border) return fail(c, GFO_ERR_CAPACITY, "out_stride too small");
+    const uint8_t* src;
+    size_t spitch;
+    if (level == 0) {
+        src = c->last_in.base + (size_t)image * c->last_in.img_stride;
+        spitch = (size_t)c->last_in.pitch;
+    } else {
+        src = c->d_pyr + (size_t)image * c->g.pyr_img_stride + L.plane_off;
+        spitch = L.pitch;
+    }
+    uint8_t* centre = out + (size_t)border * out_stride + border;
+    HIP_TRY(c, hipMemcpy2DAsync(centre, out_stride, src, spitch, L.w, L.h, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (border > 0) {  // copyMakeBorder(BORDER_REFLECT_101), ORBextractor.cc:1191-1197
+        for (int y = -border; y < L.h + border; y++) {
+            uint8_t* D = centre + (ptrdiff_t)y * out_stride;
+            const uint8_t* S = centre + (ptrdiff_t)reflect101_host(y, L.h) * out_stride;
+            if (y < 0 || y >= L.h) memcpy(D, S, L.w);
+            for (int x = 1; x <= border; x++) {
+                D[-x] = D[reflect101_host(-x, L.w)];
+                D[L.w - 1 + x] = D[reflect101_host(L.w - 1 + x, L.w)];
+            }
+        }
+    }
+    if (w) *w = L.w;
+    if (h) *h = L.h;
+    return GFO_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// matchers
+// ---------------------------------------------------------------------------------------------
+extern "C" int gfo_hamming256(const void* a, const void* b)
+{
+    // ORBmatcher::DescriptorDistance, ORBmatcher.cc:1768-1784 (popcount of the XOR)
+    uint64_t x[4], y[4];
+    memcpy(x, a, 32);
+    memcpy(y, b, 32);
+    return __builtin_popcountll(x[0] ^ y[0]) + __builtin_popcountll(x[1] ^ y[1]) +
+           __builtin_popcountll(x[2] ^ y[2]) + __builtin_popcountll(x[3] ^ y[3]);
+}
+
+static int scratch(gfo_ctx* c, size_t bytes)
+{
+    if (bytes <= c->scratch_bytes) return GFO_OK;
+    (void)hipStreamSynchronize(c->stream);
+    if (c->d_scratch) (void)hipFree(c->d_scratch);
+    c->d_scratch = nullptr;
+    c->scratch_bytes = 0;
+    HIP_TRY(c, hipMalloc(&c->d_scratch, bytes));
+    c->scratch_bytes = bytes;
+    return GFO_OK;
+}
+
+extern "C" int gfo_stereo_match(gfo_ctx* c, const gfo_keypoint* kl, const uint8_t* dl, int nl, const gfo_keypoint* kr,
+                                const uint8_t* dr, int nr, const float* sf, int nlevels, const gfo_stereo_params* p,
+                                const float* min_d, const float* max_d, float* u_right, float* depth,
+                                int32_t* best_dist, int32_t* best_idx_r, int* nmatched)
+{
+    if (!c || !p || !sf || !u_right || !depth || !nmatched || nl < 0 || nr < 0 || nlevels < 1 || nlevels > GFO_MAX_LEVELS)
+        return fail(c, GFO_ERR_INVALID, "bad argument");
+    if (nr > 65535) return fail(c, GFO_ERR_INVALID, "more than 65535 right keypoints");
+    *nmatched = 0;
+    if (nl == 0) return GFO_OK;
+    HIP_TRY(c, hipSetDevice(c->device));
+    // scratch layout
+    size_t off = 0;
+    auto take = [&](size_t bytes) { size_t o = off; off = (size_t)align_up((long long)(off + bytes), 256); return o; };
+    const size_t o_kl = take(sizeof(gfo_keypoint) * nl), o_dl = take(32 * (size_t)nl);
+    const size_t o_kr = take(sizeof(gfo_keypoint) * (nr > 0 ? nr : 1)), o_dr = take(32 * (size_t)(nr > 0 ? nr : 1));
+    const size_t o_sf = take(sizeof(float) * GFO_MAX_LEVELS);
+    const size_t o_min = take(sizeof(float) * nl), o_max = take(sizeof(float) * nl);
+    const size_t o_u = take(sizeof(float) * nl), o_dp = take(sizeof(float) * nl);
+    const size_t o_bd = take(sizeof(int) * nl), o_bi = take(sizeof(int) * nl), o_nm = take(sizeof(int));
+    int rc = scratch(c, off);
+    if (rc) return rc;
+    uint8_t* S = (uint8_t*)c->d_scratch;
+    HIP_TRY(c, hipMemcpyAsync(S + o_kl, kl, sizeof(gfo_keypoint) * nl, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(S + o_dl, dl, 32 * (size_t)nl, hipMemcpyHostToDevice, c->stream));
+    if (nr > 0) {
+        HIP_TRY(c, hipMemcpyAsync(S + o_kr, kr, sizeof(gfo_keypoint) * nr, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(c, hipMemcpyAsync(S + o_dr, dr, 32 * (size_t)nr, hipMemcpyHostToDevice, c->stream));
+    }
+    HIP_TRY(c, hipMemcpyAsync(S + o_sf, sf, sizeof(float) * nlevels, hipMemcpyHostToDevice, c->stream));
+    const bool win = min_d && max_d;
+    if (win) {
+        HIP_TRY(c, hipMemcpyAsync(S + o_min, min_d, sizeof(float) * nl, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(c, hipMemcpyAsync(S + o_max, max_d, sizeof(float) * nl, hipMemcpyHostToDevice, c->stream));
+    }
+    GfoStereoDev out{(float*)(S + o_u), (float*)(S + o_dp), (int*)(S + o_bd), (int*)(S + o_bi), (int*)(S + o_nm)};
+    gfo_launch_stereo(c, (const gfo_keypoint*)(S + o_kl), S + o_dl, nullptr, nl, (const gfo_keypoint*)(S + o_kr), S + o_dr,
+                      nullptr, nr, 0, 1, (const float*)(S + o_sf), *p, win ? (const float*)(S + o_min) : nullptr,
+                      win ? (const float*)(S + o_max) : nullptr, out, nl);
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipMemcpyAsync(u_right, out.u_right, sizeof(float) * nl, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(depth, out.depth, sizeof(float) * nl, hipMemcpyDeviceToHost, c->stream));
+    if (best_dist) HIP_TRY(c, hipMemcpyAsync(best_dist, out.best_dist, sizeof(int) * nl, hipMemcpyDeviceToHost, c->stream));
+    if (best_idx_r) HIP_TRY(c, hipMemcpyAsync(best_idx_r, out.best_idx, sizeof(int) * nl, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(nmatched, out.nmatched, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return GFO_OK;
+}
+
+extern "C" int gfo_stereo_match_batch(gfo_ctx* c, const gfo_stereo_params* p)
+{
+    if (!c || !p) return GFO_ERR_INVALID;
+    if (!c->have_batch) return fail(c, GFO_ERR_STATE, "no batch has been extracted");
+    if (c->last_nimg < 2 || (c->last_nimg & 1)) return fail(c, GFO_ERR_STATE, "stereo needs an even number of images (L,R,L,R,...)");
+    const int npairs = c->last_nimg / 2;
+    gfo_launch_stereo(c, c->d_kp, c->d_desc, c->d_kp_cnt, 0, c->d_kp + c->g.kp_stride, c->d_desc + (size_t)c->g.kp_stride * 32,
+                      nullptr, 0, 2LL * c->g.kp_stride, npairs, c->d_scale, *p, nullptr, nullptr, c->st, c->g.kp_stride);
+    HIP_TRY(c, hipGetLastError());
+    c->have_stereo = true;
+    return GFO_OK;
+}
+
+extern "C" int gfo_stereo_fetch(gfo_ctx* c, int pair, float* u_right, float* depth, int32_t* best_dist,
+                                int32_t* best_idx_r, int cap, int* nmatched)
+{
+    if (!c) return GFO_ERR_INVALID;
+    if (!c->have_stereo) return fail(c, GFO_ERR_STATE, "no stereo batch has been matched");
+    if (pair < 0 || pair >= c->last_nimg / 2) return fail(c, GFO_ERR_INVALID, "pair out of range");
+    int nl = 0;
+    HIP_TRY(c, hipMemcpyAsync(&nl, c->d_kp_cnt + 2 * pair, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    const int m = nl < cap ? nl : cap;
+    const size_t o = (size_t)pair * c->g.kp_stride;
+    if (m > 0 && u_right) HIP_TRY(c, hipMemcpyAsync(u_right, c->st.u_right + o, sizeof(float) * m, hipMemcpyDeviceToHost, c->stream));
+    if (m > 0 && depth) HIP_TRY(c, hipMemcpyAsync(depth, c->st.depth + o, sizeof(float) * m, hipMemcpyDeviceToHost, c->stream));
+    if (m > 0 && best_dist) HIP_TRY(c, hipMemcpyAsync(best_dist, c->st.best_dist + o, sizeof(int) * m, hipMemcpyDeviceToHost, c->stream));
+    if (m > 0 && best_idx_r) HIP_TRY(c, hipMemcpyAsync(best_idx_r, c->st.best_idx + o, sizeof(int) * m, hipMemcpyDeviceToHost, c->stream));
+    if (nmatched) HIP_TRY(c, hipMemcpyAsync(nmatched, c->st.nmatched + pair, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return nl > cap ? fail(c, GFO_ERR_CAPACITY, "%d left keypoints, caller capacity %d", nl, cap) : GFO_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// profiling + debug
+// ---------------------------------------------------------------------------------------------
+extern "C" int gfo_profile_enable(gfo_ctx* c, int on)
+{
+    if (!c) return GFO_ERR_INVALID;
+    prof_collect(c);
+    c->profiling = on != 0;
+    return GFO_OK;
+}
+
+extern "C" int gfo_profile_read(gfo_ctx* c, gfo_stage_time* out, int cap, int* nstages, int reset)
+{
+    if (!c || !nstages) return GFO_ERR_INVALID;
+    prof_collect(c);
+    int k = 0;
+    for (int s = 0; s < ST_COUNT; s++) {
+        if (k < cap && out) {
+            memset(&out[k], 0, sizeof out[k]);
+            strncpy(out[k].name, k_stage_names[s], sizeof out[k].name - 1);
+            out[k].ms = c->stage_ms[s];
+            out[k].launches = c->stage_launches[s];
+        }
+        k++;
+    }
+    *nstages = k;
+    if (reset)
+        for (int s = 0; s < ST_COUNT; s++) { c->stage_ms[s] = 0; c->stage_launches[s] = 0; }
+    return GFO_OK;
+}
+
+extern "C" int gfo_debug_blurred_level(gfo_ctx* c, int image, int level, uint8_t* out, int out_stride)
+{
+    if (!c || !out) return GFO_ERR_INVALID;
+    if (!c->have_batch) return fail(c, GFO_ERR_STATE, "no batch has been extracted");
+    if (image < 0 || image >= c->last_nimg || level < 0 || level >= c->g.nlevels) return fail(c, GFO_ERR_INVALID, "out of range");
+    const GfoLevel& L = c->g.lv[level];
+    HIP_TRY(c, hipMemcpy2DAsync(out, out_stride, c->d_blur + (size_t)image * c->g.blur_img_stride + L.blur_off, L.pitch,
+                                L.w, L.h, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return GFO_OK;
+}
+
+extern "C" int gfo_debug_level_candidates(gfo_ctx* c, int image, int level, int32_t* xys, int cap, int* n)
+{
+    if (!c || !n) return GFO_ERR_INVALID;
+    if (!c->have_batch) return fail(c, GFO_ERR_STATE, "no batch has been extracted");
+    if (image < 0 || image >= c->last_nimg || level < 0 || level >= c->g.nlevels) return fail(c, GFO_ERR_INVALID, "out of range");
+    const GfoLevel& L = c->g.lv[level];
+    int cnt = 0;
+    HIP_TRY(c, hipMemcpyAsync(&cnt, c->d_cand_cnt + image * c->g.nlevels + level, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (cnt > L.cand_cap) cnt = L.cand_cap;
+    *n = cnt;
+    const int m = cnt < cap ? cnt : cap;
+    if (m > 0 && xys) {
+        std::vector<uint32_t> tmp(m);
+        HIP_TRY(c, hipMemcpy(tmp.data(), c->d_cand + (size_t)image * c->g.cand_img_stride + L.cand_off, sizeof(uint32_t) * m, hipMemcpyDeviceToHost));
+        for (int i = 0; i < m; i++) {
+            xys[3 * i] = (int)(tmp[i] & 0xFFF);
+            xys[3 * i + 1] = (int)((tmp[i] >> 12) & 0xFFF);
+            xys[3 * i + 2] = (int)(tmp[i] >> 24);
+        }
+    }
+    return GFO_OK;
+}

@@ -1,0 +1,159 @@
+// gfo_internal.h -- context, level geometry and kernel launch prototypes of libgfo.so.
+// gfx950 (MI355X) only.  Nothing here is part of the ABI (include/gfo.h is).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include <vector>
+
+#include "../../include/gfo.h"
+
+#define GFO_EDGE 19          // EDGE_THRESHOLD, ORBextractor.cc:74
+#define GFO_HALF_PATCH 15    // HALF_PATCH_SIZE, ORBextractor.cc:73
+#define GFO_PATCH 31         // PATCH_SIZE, ORBextractor.cc:72
+#define GFO_MIN_BORDER 16    // EDGE_THRESHOLD-3, ORBextractor.cc:775
+#define GFO_CELL_W 30        // W, ORBextractor.cc:771
+
+// Geometry of one pyramid level, shared by host planning and every kernel (passed by value).
+struct GfoLevel {
+    int w, h, pitch;          // plane size; pitch multiple of 64 B
+    long long plane_off;      // byte offset of the plane inside one image's pyramid block (level>=1)
+    long long blur_off;       // byte offset inside one image's blurred-pyramid block
+    // FAST cell grid (ORBextractor.cc:775-789); ncols == 0 when the level is too small
+    int ncols, nrows, wcell, hcell;
+    int max_bx, max_by;       // maxBorderX/Y = w-16, h-16
+    int cell_base;            // prefix of ncols*nrows over levels
+    // blur tiling
+    int tiles_x, tiles_y, tile_base;
+    // quadtree (ORBextractor.cc:539-563)
+    int quota;                // mnFeaturesPerLevel[level]
+    int n_ini;                // root nodes
+    float hx;                 // root width
+    int node_cap;             // max nodes the selection can hold
+    // buffers (element offsets inside one image's block)
+    long long cand_off;       // u32 candidates
+    int cand_cap;
+    int sel_off, sel_cap;     // u32 selected keypoints
+    // scaling (ORBextractor.cc:839-849, 1164-1170)
+    float scale;
+    int patch_size;           // int(31*scale)
+    // resize tables: offsets (in elements) into the table buffers
+    int xtab_off, ytab_off;
+};
+
+struct GfoGeom {
+    int nlevels;
+    int w0, h0;
+    int total_cells;
+    int total_tiles;
+    int total_sel_cap;        // per image: sum of sel_cap
+    int kp_stride;            // per image output capacity (>= total_sel_cap)
+    int ini_th, min_th;
+    int fast_tile_pitch, fast_tile_rows, fast_smap_pitch, fast_smap_rows; // LDS plan per wave
+    long long pyr_img_stride;   // bytes per image of levels 1..L-1
+    long long blur_img_stride;  // bytes per image of blurred levels 0..L-1
+    long long cand_img_stride;  // u32 elements per image
+    GfoLevel lv[GFO_MAX_LEVELS];
+};
+
+// Input description of level 0 (either the arena staging buffer or a caller's device buffer)
+struct GfoInput {
+    const uint8_t* base;
+    long long pitch;
+    long long img_stride;
+};
+
+struct GfoStereoDev {
+    float* u_right;     // [pairs][kp_stride]
+    float* depth;
+    int* best_dist;
+    int* best_idx;
+    int* nmatched;      // [pairs]
+};
+
+enum GfoStage {
+    ST_RESIZE = 0, ST_BLUR, ST_FAST, ST_QUADTREE, ST_ORIENT_DESC, ST_STEREO, ST_STEREO_CUT,
+    ST_PROJECT, ST_COUNT
+};
+
+struct gfo_ctx {
+    gfo_params prm{};
+    int device = 0;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+    std::string err;
+    std::string launch_err;
+    bool debug_sync = false;
+    int cur_stage = 0;
+    // host tables (ORBextractor.cc:409-469)
+    std::vector<float> scale, inv_scale, sigma2, inv_sigma2;
+    std::vector<int> quota;
+    int umax[16]{};
+    // geometry + arena
+    bool planned = false;
+    GfoGeom g{};
+    GfoGeom* d_geom = nullptr;       // device copy of g (kernels read it through scalar loads)
+    int cap_batch = 0;
+    uint8_t* d_input = nullptr;      // staging for host images (pitch = lv[0].pitch)
+    uint8_t* d_pyr = nullptr;
+    uint8_t* d_blur = nullptr;
+    uint32_t* d_cand = nullptr;
+    int* d_cand_cnt = nullptr;       // [batch][nlevels]
+    uint16_t* d_node_of = nullptr;   // [batch][cand_img_stride] quadtree scratch
+    uint32_t* d_sel = nullptr;       // [batch][total_sel_cap]
+    int* d_sel_cnt = nullptr;        // [batch][nlevels]
+    gfo_keypoint* d_kp = nullptr;    // [batch][kp_stride]
+    uint8_t* d_desc = nullptr;       // [batch][kp_stride][32]
+    int* d_kp_cnt = nullptr;         // [batch]
+    int* d_flags = nullptr;          // [4] overflow flags
+    int* d_xofs = nullptr;           // resize tables, all levels
+    short* d_xcoef = nullptr;
+    int* d_yofs = nullptr;
+    short* d_ycoef = nullptr;
+    float* d_scale = nullptr;        // mvScaleFactor on the device
+    GfoStereoDev st{};
+    // state of the last batch
+    int last_nimg = 0;
+    GfoInput last_in{};
+    bool have_batch = false;
+    bool have_pyramid = false;
+    bool have_stereo = false;
+    // profiling
+    bool profiling = false;
+    double stage_ms[ST_COUNT]{};
+    int stage_launches[ST_COUNT]{};
+    struct PendingEv { int stage; hipEvent_t a, b; };
+    std::vector<PendingEv> pending;
+    std::vector<hipEvent_t> ev_pool;
+    // scratch for host-array matcher entry points
+    void* d_scratch = nullptr;
+    size_t scratch_bytes = 0;
+};
+
+// ---- kernel launchers (each in its own .hip file) ------------------------------------------
+void gfo_launch_resize(gfo_ctx* c, const GfoInput& in, int level, int nimg);
+void gfo_launch_blur(gfo_ctx* c, const GfoInput& in, int nimg);
+void gfo_launch_fast(gfo_ctx* c, const GfoInput& in, int nimg);
+void gfo_launch_quadtree(gfo_ctx* c, int nimg);
+void gfo_launch_orient_desc(gfo_ctx* c, const GfoInput& in, int nimg);
+void gfo_launch_stereo(gfo_ctx* c, const gfo_keypoint* kl, const uint8_t* dl, const int* nl_dev, int nl_host,
+                       const gfo_keypoint* kr, const uint8_t* dr, const int* nr_dev, int nr_host,
+                       long long pair_stride_kp, int npairs, const float* d_scale, const gfo_stereo_params& p,
+                       const float* min_d, const float* max_d, GfoStereoDev out, int out_stride);
+
+// profiling helpers (gfo_api.hip)
+void gfo_prof_begin(gfo_ctx* c, int stage);
+void gfo_prof_end(gfo_ctx* c);
+
+// device-side address helpers shared by kernels
+__device__ __forceinline__ const uint8_t* gfo_level_ptr(const GfoGeom& g, const GfoInput& in, const uint8_t* pyr,
+                                                         int level, int img, int* pitch)
+{
+    if (level == 0) {
+        *pitch = (int)in.pitch;
+        return in.base + (long long)img * in.img_stride;
+    }
+    *pitch = g.lv[level].pitch;
+    return pyr + (long long)img * g.pyr_img_stride + g.lv[level].plane_off;
+}

@@ -1,0 +1,135 @@
+// k_orient_desc.hip -- IC_Angle (ORBextractor.cc:76-103), computeOrbDescriptor (:107-146) and
+// the keypoint bookkeeping of ComputeKeyPointsOctTree / operator() (:839-849, 1144-1172).
+//
+// One wavefront per selected keypoint.
+//   angle      : the 749-px disc is swept two rows (+v / -v) per step, 31 lanes each; the
+//                int32 moments are wave-reduced with lane shuffles; fastAtan2 is the shared
+//                plain-fp32 polynomial of include/gfo_sincos.h.
+//   descriptor : 37x37 window of the BLURRED level staged in LDS (the rotated pattern reaches
+//                18 px); each lane evaluates 4 of the 256 pair tests; the wave
+//                ballot of test r*64+lane IS descriptor bytes 8r..8r+7, so the 32 bytes leave
+//                as four 64-bit words without any bit shuffling.
+// Output rows are laid out level by level, inside a level in list order (:1144-1161).
+// No workgroup barrier is used: each wave owns its LDS window (LDS operations of one wave
+// execute in issue order), so trailing waves may exit early.
+#include "gfo_internal.h"
+#include "../../include/gfo_sincos.h"
+
+struct PatQuad { signed char x0, y0, x1, y1; };
+__device__ const PatQuad k_pattern[256] = {
+#include "../../include/gfo_pattern.inc"
+};
+__device__ const int k_umax[16] = {15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3};  // ORBextractor.cc:451-468
+
+#define DW 37          // descriptor window
+#define DWP 40         // LDS pitch
+
+__global__ __launch_bounds__(256) void k_orient_desc(const GfoGeom* __restrict__ gp, GfoInput in,
+                                                     const uint8_t* __restrict__ pyr, const uint8_t* __restrict__ blur,
+                                                     const uint32_t* __restrict__ sel, const int* __restrict__ sel_cnt,
+                                                     gfo_keypoint* __restrict__ kp_out, uint8_t* __restrict__ desc_out,
+                                                     int* __restrict__ kp_cnt, int* __restrict__ flags)
+{
+    __shared__ uint8_t s_win[4][DW * DWP];
+    const GfoGeom& g = *gp;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int img = blockIdx.y;
+    const int slot = blockIdx.x * 4 + wave;
+    // level of this slot: prefix over the per-level counts (wave-uniform)
+    int level = -1, idx = 0, acc = 0;
+    for (int l = 0; l < g.nlevels; l++) {
+        const int c = sel_cnt[img * g.nlevels + l];
+        if (level < 0 && slot < acc + c) {
+            level = l;
+            idx = slot - acc;
+        }
+        acc += c;
+    }
+    const int total = acc;
+    if (slot == 0 && lane == 0) {
+        kp_cnt[img] = min(total, g.kp_stride);
+        if (total > g.kp_stride) atomicOr(&flags[0], 8);
+    }
+    if (level < 0 || slot >= g.kp_stride) return;
+    const GfoLevel& L = g.lv[level];
+    const uint32_t key = sel[(long long)img * g.total_sel_cap + L.sel_off + idx];
+    const int x = (int)(key & 0xFFF) + GFO_MIN_BORDER, y = (int)((key >> 12) & 0xFFF) + GFO_MIN_BORDER;  // :845-846
+    const int score = (int)(key >> 24);
+
+    // ---- IC_Angle on the unblurred level ----
+    int pitch;
+    const uint8_t* lv = gfo_level_ptr(g, in, pyr, level, img, &pitch);
+    const uint8_t* center = lv + (long long)y * pitch + x;
+    const int half = lane >> 5;           // 0: row +v, 1: row -v
+    const int u = (lane & 31) - GFO_HALF_PATCH;
+    const bool col_ok = (lane & 31) < 31;
+    int m10 = 0, m01 = 0;
+    if (lane < 31) m10 = u * (int)center[u];
+#pragma unroll
+    for (int v = 1; v <= GFO_HALF_PATCH; v++) {
+        const int d = k_umax[v];
+        if (col_ok && u >= -d && u <= d) {
+            const int val = center[(half ? -v : v) * pitch + u];
+            m10 += u * val;
+            m01 += half ? -v * val : v * val;
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        m10 += __shfl_xor(m10, o);
+        m01 += __shfl_xor(m01, o);
+    }
+    const float angle = gfo_fast_atan2f((float)m01, (float)m10);
+
+    // ---- stage the blurred 37x37 window ----
+    const uint8_t* bl = blur + (long long)img * g.blur_img_stride + L.blur_off + (long long)(y - 18) * L.pitch + (x - 18);
+    uint8_t* win = s_win[wave];
+    for (int t = lane; t < DW * DW; t += 64) {
+        const int r = t / DW, c = t - r * DW;
+        win[r * DWP + c] = bl[(long long)r * L.pitch + c];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const float factorPI = (float)(3.1415926535897932384626433832795 / 180.f);
+    float a, b;
+    gfo_sincosf(angle * factorPI, &b, &a);
+    const uint8_t* wc = win + 18 * DWP + 18;
+    unsigned long long word = 0;
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        const PatQuad p = k_pattern[r * 64 + lane];
+        const float x0 = (float)p.x0, y0 = (float)p.y0, x1 = (float)p.x1, y1 = (float)p.y1;
+        const int iy0 = (int)rintf(x0 * b + y0 * a), ix0 = (int)rintf(x0 * a - y0 * b);
+        const int iy1 = (int)rintf(x1 * b + y1 * a), ix1 = (int)rintf(x1 * a - y1 * b);
+        const int t0 = wc[iy0 * DWP + ix0], t1 = wc[iy1 * DWP + ix1];
+        const unsigned long long m = __ballot(t0 < t1);
+        if (lane == r) word = m;
+    }
+    const long long o = (long long)img * g.kp_stride + slot;
+    if (lane < 4) reinterpret_cast<unsigned long long*>(desc_out + o * 32)[lane] = word;
+    if (lane == 0) {
+        gfo_keypoint q;
+        q.x = (float)x;
+        q.y = (float)y;
+        if (level != 0) {  // :1164-1170
+            q.x = q.x * L.scale;
+            q.y = q.y * L.scale;
+        }
+        q.size = (float)L.patch_size;
+        q.angle = angle;
+        q.response = (float)score;
+        q.octave = level;
+        q.class_id = -1;
+        kp_out[o] = q;
+    }
+}
+
+void gfo_launch_orient_desc(gfo_ctx* c, const GfoInput& in, int nimg)
+{
+    dim3 grid((c->g.kp_stride + 3) / 4, nimg);
+    gfo_prof_begin(c, ST_ORIENT_DESC);
+    hipLaunchKernelGGL(k_orient_desc, grid, dim3(256), 0, c->stream, c->d_geom, in, c->d_pyr, c->d_blur, c->d_sel,
+                       c->d_sel_cnt, c->d_kp, c->d_desc, c->d_kp_cnt, c->d_flags);
+    gfo_prof_end(c);
+}

@@ -1,0 +1,91 @@
+"""ORBmatcher + the stereo association of Frame: host-side mirror of the reference interfaces
+(include/ORBmatcher.h:42-310, include/Frame.h:230-267) over the C ABI, on flattened arrays."""
+import ctypes as C
+from collections import namedtuple
+
+import numpy as np
+
+from ._lib import (FrameBoundsC, KEYPOINT_DTYPE, MAP_POINT_DTYPE, StereoParamsC, check, load_library, ptr)
+
+StereoParams = namedtuple("StereoParams", "n_rows mbf mb min_x")
+FrameBounds = namedtuple("FrameBounds", "min_x min_y max_x max_y")
+
+
+class ORBmatcher:
+    """ORBmatcher(nnratio=0.6, checkOri=true) -- ORBmatcher.h:46."""
+    TH_LOW = 50           # ORBmatcher.cc:58
+    TH_HIGH = 100         # ORBmatcher.cc:57
+    HISTO_LENGTH = 30     # ORBmatcher.cc:59
+
+    def __init__(self, nnratio=0.6, checkOri=True, extractor=None):
+        self._L = load_library()
+        self.mfNNratio = float(nnratio)
+        self.mbCheckOrientation = bool(checkOri)
+        if extractor is None:
+            from .extractor import ORBextractor
+            extractor = ORBextractor()
+            self._own = extractor
+        self._ctx = extractor.handle
+
+    @staticmethod
+    def DescriptorDistance(a, b):
+        """ORBmatcher.h:49, ORBmatcher.cc:1768-1784."""
+        a = np.ascontiguousarray(a, np.uint8)
+        b = np.ascontiguousarray(b, np.uint8)
+        assert a.size == 32 and b.size == 32
+        return load_library().gfo_hamming256(ptr(a), ptr(b))
+
+    def ComputeStereoMatches(self, keys_l, desc_l, keys_r, desc_r, scale_factors, params, min_d=None, max_d=None):
+        """Frame::ComputeStereoMatches_Undistorted(false) on flattened arrays (Frame.cc:1167-1316).
+        Returns (nmatched, mvuRight, mvDepth, best_dist, best_idx_r)."""
+        kl = np.ascontiguousarray(keys_l, KEYPOINT_DTYPE)
+        kr = np.ascontiguousarray(keys_r, KEYPOINT_DTYPE)
+        dl = np.ascontiguousarray(desc_l, np.uint8)
+        dr = np.ascontiguousarray(desc_r, np.uint8)
+        sf = np.ascontiguousarray(scale_factors, np.float32)
+        nl, nr = len(kl), len(kr)
+        u = np.full(max(nl, 1), -1, np.float32)
+        dp = np.full(max(nl, 1), -1, np.float32)
+        bd = np.full(max(nl, 1), -1, np.int32)
+        bi = np.full(max(nl, 1), -1, np.int32)
+        nm = C.c_int()
+        p = StereoParamsC(*params)
+        if min_d is not None:
+            min_d = np.ascontiguousarray(min_d, np.float32)
+            max_d = np.ascontiguousarray(max_d, np.float32)
+        check(self._L, self._ctx, self._L.gfo_stereo_match(self._ctx, ptr(kl), ptr(dl), nl, ptr(kr), ptr(dr), nr, ptr(sf), len(sf),
+                                                           C.byref(p), ptr(min_d), ptr(max_d), ptr(u), ptr(dp), ptr(bd), ptr(bi), C.byref(nm)))
+        return nm.value, u[:nl], dp[:nl], bd[:nl], bi[:nl]
+
+    def stereo_match_batch(self, params):
+        p = StereoParamsC(*params)
+        check(self._L, self._ctx, self._L.gfo_stereo_match_batch(self._ctx, C.byref(p)))
+
+    def stereo_fetch(self, pair, cap):
+        u = np.zeros(cap, np.float32); dp = np.zeros(cap, np.float32)
+        bd = np.zeros(cap, np.int32); bi = np.zeros(cap, np.int32)
+        nm = C.c_int()
+        check(self._L, self._ctx, self._L.gfo_stereo_fetch(self._ctx, pair, ptr(u), ptr(dp), ptr(bd), ptr(bi), cap, C.byref(nm)))
+        return nm.value, u, dp, bd, bi
+
+    def SearchByProjection(self, keys_un, desc, u_right, scale_factors, bounds, map_points, mp_desc, th=3.0, kp_taken=None):
+        """ORBmatcher::SearchByProjection(Frame&, vector<MapPoint*>&, th) -- ORBmatcher.h:64,
+        ORBmatcher.cc:155-249.  Returns (nmatches, out_mp, out_score)."""
+        kp = np.ascontiguousarray(keys_un, KEYPOINT_DTYPE)
+        desc = np.ascontiguousarray(desc, np.uint8)
+        mps = np.ascontiguousarray(map_points, MAP_POINT_DTYPE)
+        mpd = np.ascontiguousarray(mp_desc, np.uint8)
+        sf = np.ascontiguousarray(scale_factors, np.float32)
+        n, m = len(kp), len(mps)
+        if u_right is not None:
+            u_right = np.ascontiguousarray(u_right, np.float32)
+        if kp_taken is not None:
+            kp_taken = np.ascontiguousarray(kp_taken, np.uint8)
+        fb = FrameBoundsC(*bounds)
+        out_mp = np.full(max(n, 1), -1, np.int32)
+        out_sc = np.zeros(max(n, 1), np.int32)
+        nm = C.c_int()
+        check(self._L, self._ctx, self._L.gfo_search_by_projection(self._ctx, ptr(kp), ptr(desc), ptr(u_right), n, ptr(sf), len(sf),
+                                                                   C.byref(fb), ptr(mps), ptr(mpd), m, th, self.mfNNratio, ptr(kp_taken),
+                                                                   ptr(out_mp), ptr(out_sc), C.byref(nm)))
+        return nm.value, out_mp[:n], out_sc[:n]

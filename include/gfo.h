@@ -1,0 +1,188 @@
+/* gfo.h -- C ABI of the MI355X-native ORB front-end (libgfo.so).
+ *
+ * Drop-in boundary for the ORB extract + match path of GF-ORB-SLAM2.  Plain pointers and
+ * sizes only; no C++/torch/OpenCV types cross this boundary.  Every entry point names the
+ * reference interface it replaces (paths relative to the reference repository).
+ *
+ * Conventions
+ *   - every function returning int returns GFO_OK (0) or a negative gfo_status; nothing
+ *     throws or aborts across the ABI.  gfo_last_error(ctx) gives the message.
+ *   - one context = one GPU + one HIP stream + one pre-sized HBM arena; contexts are
+ *     independent (two contexts may be driven from two host threads, as the reference does
+ *     with its left/right extractors, Frame.cc:84-87); a single context is not re-entrant.
+ *   - there is NO CPU fallback: without a usable gfx950 device gfo_ctx_create fails.
+ */
+#ifndef GFO_H
+#define GFO_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GFO_VERSION 100 /* 0.1.0 */
+#define GFO_MAX_LEVELS 16
+
+typedef enum {
+    GFO_OK = 0,
+    GFO_ERR_INVALID = -1,   /* bad argument                                   */
+    GFO_ERR_DEVICE = -2,    /* HIP error / no usable device                   */
+    GFO_ERR_CAPACITY = -3,  /* caller buffer or batch capacity too small      */
+    GFO_ERR_OVERFLOW = -4,  /* an internal fixed-capacity buffer overflowed   */
+    GFO_ERR_STATE = -5      /* call order violated (e.g. no batch extracted)  */
+} gfo_status;
+
+/* Layout-identical to cv::KeyPoint (pt.x, pt.y, size, angle, response, octave, class_id):
+ * the adapter can reinterpret a std::vector<cv::KeyPoint>'s storage.  28 bytes. */
+typedef struct {
+    float x, y, size, angle, response;
+    int32_t octave, class_id;
+} gfo_keypoint;
+
+/* ORBextractor::ORBextractor(nfeatures, scaleFactor, nlevels, iniThFAST, minThFAST)
+ * include/ORBextractor.h:81-82, src/ORBextractor.cc:409-469. */
+typedef struct {
+    int32_t nfeatures;
+    float scale_factor;
+    int32_t nlevels;
+    int32_t ini_th_fast;
+    int32_t min_th_fast;
+    int32_t max_batch; /* images per device batch the arena is sized for (>=1) */
+} gfo_params;
+
+typedef struct gfo_ctx gfo_ctx;
+
+int gfo_version(void);
+
+/* Creates a context on HIP device `device`.  Arena memory is allocated lazily on the first
+ * image (its size fixes the level geometry; a different size re-plans the arena). */
+int gfo_ctx_create(const gfo_params* params, int device, gfo_ctx** out);
+void gfo_ctx_destroy(gfo_ctx* ctx);
+const char* gfo_last_error(const gfo_ctx* ctx); /* ctx may be NULL: last create error */
+
+/* Use an externally owned HIP stream (hipStream_t passed as void*); NULL restores the
+ * context's own stream.  Lets the host framework time/order work on its current stream. */
+int gfo_ctx_set_stream(gfo_ctx* ctx, void* hip_stream);
+int gfo_ctx_synchronize(gfo_ctx* ctx);
+
+/* Getters of include/ORBextractor.h:93-119 (GetLevels, GetScaleFactor, GetScaleFactors,
+ * GetInverseScaleFactors, GetScaleSigmaSquares, GetInverseScaleSigmaSquares) and the
+ * per-level quotas mnFeaturesPerLevel (ORBextractor.cc:435-445).  Each out array takes
+ * nlevels entries; any may be NULL. */
+int gfo_ctx_tables(const gfo_ctx* ctx, float* scale, float* inv_scale, float* sigma2,
+                   float* inv_sigma2, int32_t* features_per_level);
+/* Upper bound on keypoints one image can yield (DistributeOctTree may exceed the quota by a
+ * few nodes per level, ORBextractor.cc:667-737); size caller buffers with this. */
+int gfo_ctx_max_keypoints(const gfo_ctx* ctx);
+
+/* ORBextractor::operator()(image, mask, keypoints, descriptors)
+ * include/ORBextractor.h:89-91, src/ORBextractor.cc:1112-1174.  8-bit grey host image,
+ * `stride` bytes per row.  Writes min(n, cap) keypoints / 32-byte descriptors, *n = count
+ * produced; returns GFO_ERR_CAPACITY if n > cap (outputs truncated).  Empty image
+ * (w or h <= 0 or img NULL): returns GFO_OK with *n = 0 and outputs untouched (:1115). */
+int gfo_extract(gfo_ctx* ctx, const uint8_t* img, int w, int h, int stride,
+                gfo_keypoint* kp, uint8_t* desc, int cap, int* n);
+
+/* Batched form: `nimg` host images of identical size (one arena pass, every stage one
+ * launch over all images).  imgs[i] points at image i.  kp/desc are [nimg][cap] arrays. */
+int gfo_extract_batch(gfo_ctx* ctx, const uint8_t* const* imgs, int nimg, int w, int h, int stride,
+                      gfo_keypoint* kp, uint8_t* desc, int cap, int* n);
+
+/* Device-resident form: `d_imgs` is a device pointer to nimg images, `pitch` bytes per row,
+ * `img_stride` bytes between images.  Results stay in the arena; fetch with
+ * gfo_batch_counts / gfo_batch_fetch or chain gfo_stereo_match_batch. Asynchronous on the
+ * context stream. */
+int gfo_extract_batch_device(gfo_ctx* ctx, const uint8_t* d_imgs, int nimg, int w, int h,
+                             size_t pitch, size_t img_stride);
+int gfo_batch_counts(gfo_ctx* ctx, int* n /*[nimg]*/, int* per_level /*[nimg][nlevels] or NULL*/);
+int gfo_batch_fetch(gfo_ctx* ctx, int image, gfo_keypoint* kp, uint8_t* desc, int cap, int* n);
+/* device addresses of the batch results (for chaining device-side consumers):
+ * keypoints [nimg][kp_stride] gfo_keypoint, descriptors [nimg][kp_stride][32], counts [nimg] */
+int gfo_batch_device_views(gfo_ctx* ctx, const gfo_keypoint** d_kp, const uint8_t** d_desc,
+                           const int32_t** d_counts, int* kp_stride);
+
+/* ORBextractor::ComputePyramid + public member mvImagePyramid (include/ORBextractor.h:127-132,
+ * src/ORBextractor.cc:1176-1201).  Copies level `level` of image `image` of the last batch
+ * to host.  border = 0: the w_l x h_l level; border = 19: with the BORDER_REFLECT_101 frame
+ * the reference keeps (EDGE_THRESHOLD).  *w,*h receive the level size without border. */
+int gfo_compute_pyramid(gfo_ctx* ctx, const uint8_t* img, int w, int h, int stride);
+int gfo_pyramid_level(gfo_ctx* ctx, int image, int level, int border, uint8_t* out, int out_stride,
+                      int* w, int* h);
+
+/* ORBmatcher::DescriptorDistance(a, b) -- include/ORBmatcher.h:49, src/ORBmatcher.cc:1768-1784.
+ * Host helper (popcount of the 256-bit XOR); the device matchers use the same definition. */
+int gfo_hamming256(const void* a, const void* b);
+
+/* Frame::PrepareStereoCandidates + Frame::ComputeStereoMatches_Undistorted(false)
+ * include/Frame.h:230-263, src/Frame.cc:1167-1316 (ALTER_STEREO_MATCHING path). */
+typedef struct {
+    int32_t n_rows; /* mpORBextractorLeft->mvImagePyramid[0].rows */
+    float mbf;      /* Frame::mbf                                 */
+    float mb;       /* Frame::mb  (minZ; maxD = mbf/mb)           */
+    float min_x;    /* Frame::mnMinX                              */
+} gfo_stereo_params;
+/* Host-array form used by the Frame adapter.  kl/kr are mvKeysUn / mvKeysRightUn, dl/dr the
+ * descriptor rows.  min_d/max_d (each nl floats) may be NULL (= 0 and mbf/mb); they carry the
+ * per-keypoint disparity window of Frame.cc:1220-1231.  Outputs: u_right[nl] = mvuRight,
+ * depth[nl] = mvDepth (-1 where unmatched), best_dist[nl]/best_idx_r[nl] = the accepted match
+ * before the median cut (-1 if none; rebuilds mvDistIdx).  *nmatched as the reference counts. */
+int gfo_stereo_match(gfo_ctx* ctx, const gfo_keypoint* kl, const uint8_t* dl, int nl,
+                     const gfo_keypoint* kr, const uint8_t* dr, int nr,
+                     const float* scale_factors, int nlevels, const gfo_stereo_params* p,
+                     const float* min_d, const float* max_d,
+                     float* u_right, float* depth, int32_t* best_dist, int32_t* best_idx_r,
+                     int* nmatched);
+/* Device-chained form: images (2k, 2k+1) of the last batch are the left/right views of pair k.
+ * Results stay on the device; fetch with gfo_stereo_fetch. */
+int gfo_stereo_match_batch(gfo_ctx* ctx, const gfo_stereo_params* p);
+int gfo_stereo_fetch(gfo_ctx* ctx, int pair, float* u_right, float* depth, int32_t* best_dist,
+                     int32_t* best_idx_r, int cap, int* nmatched);
+
+/* Frame::AssignFeaturesToGrid / GetFeaturesInArea (src/Frame.cc:461-476, 593-658) +
+ * ORBmatcher::SearchByProjection(Frame&, const vector<MapPoint*>&, th)
+ * include/ORBmatcher.h:64, src/ORBmatcher.cc:155-249, on flattened arrays. */
+typedef struct {
+    float min_x, min_y, max_x, max_y; /* Frame::mnMinX, mnMinY, mnMaxX, mnMaxY */
+} gfo_frame_bounds;
+typedef struct {
+    float proj_x, proj_y, proj_xr; /* MapPoint::mTrackProjX / Y / XR  (MapPoint.h:107-115) */
+    float view_cos;                /* MapPoint::mTrackViewCos                              */
+    int32_t level;                 /* MapPoint::mnTrackScaleLevel                          */
+    int32_t flags;                 /* bit0 mbTrackInView, bit1 isBad(), bit2 Observations()>0 */
+} gfo_map_point;
+/* kp_un = F.mvKeysUn, desc = F.mDescriptors, u_right = F.mvuRight (may be NULL),
+ * kp_taken[n] = 1 where F.mvpMapPoints[i] is set with Observations()>0 on entry (may be NULL).
+ * out_mp[n]: index into mps of the map point left in F.mvpMapPoints[i] by the call, -1 = none;
+ * out_score[n] = F.mvpMatchScore[i] for those.  *nmatches = return value of the reference. */
+int gfo_search_by_projection(gfo_ctx* ctx, const gfo_keypoint* kp_un, const uint8_t* desc,
+                             const float* u_right, int n, const float* scale_factors, int nlevels,
+                             const gfo_frame_bounds* bounds, const gfo_map_point* mps,
+                             const uint8_t* mp_desc, int m, float th, float nn_ratio,
+                             const uint8_t* kp_taken, int32_t* out_mp, int32_t* out_score,
+                             int* nmatches);
+
+/* ---- measurement hooks (bench.py / rocprof cross-check) ---------------------------------- */
+/* When enabled, every kernel launch of the extract / stereo pipelines is bracketed by HIP
+ * events on the context stream; gfo_profile_read returns, per stage, the accumulated device
+ * milliseconds and launch count since the last reset. */
+#define GFO_STAGE_MAX 16
+typedef struct {
+    char name[32];
+    double ms;
+    int launches;
+} gfo_stage_time;
+int gfo_profile_enable(gfo_ctx* ctx, int on);
+int gfo_profile_read(gfo_ctx* ctx, gfo_stage_time* out, int cap, int* nstages, int reset);
+
+/* ---- inspection hooks for the parity tests (device -> host copies of intermediates) ------ */
+int gfo_debug_blurred_level(gfo_ctx* ctx, int image, int level, uint8_t* out, int out_stride);
+/* FAST candidates of one level handed to the quadtree: {x, y, score} int32 triplets, x/y
+ * relative to minBorder as in ORBextractor.cc:824-825; order unspecified (a set). */
+int gfo_debug_level_candidates(gfo_ctx* ctx, int image, int level, int32_t* xys, int cap, int* n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GFO_H */

@@ -1,0 +1,65 @@
+"""GPU parity tests of the extractor: HIP path (through the C ABI) vs the CPU oracle,
+bit-exact (integer / byte / index work; float fields compared by bit pattern)."""
+import numpy as np
+import pytest
+
+from conftest import synth_frame
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ext():
+    import gf_orb_slam2_amd as G
+    e = G.ORBextractor(2000, 1.2, 8, 20, 7, max_batch=4)
+    yield e
+    e.close()
+
+
+def _cmp_extract(ext, oracle, img, nfeatures=2000):
+    oe = oracle.OracleExtractor(nfeatures, 1.2, 8, 20, 7)
+    okp, odesc = oe(img)
+    gkp, gdesc = ext(img)
+    # stage-by-stage first, so a failure names the stage
+    for l in range(8):
+        np.testing.assert_array_equal(ext.pyramid_level(l), oe.level(l), err_msg=f"pyramid level {l}")
+    for l in range(8):
+        oc = oe.level_candidates(l)
+        gc = ext.debug_level_candidates(l)
+        oset = sorted(map(tuple, oc.tolist()))
+        gset = sorted(map(tuple, gc.tolist()))
+        assert gset == oset, f"FAST candidates differ at level {l}: {len(gset)} vs {len(oset)}"
+    for l in range(8):
+        if oe.level_keypoint_count(l) > 0:
+            np.testing.assert_array_equal(ext.debug_blurred_level(l), oe.level(l, blurred=True), err_msg=f"blur level {l}")
+    assert len(gkp) == len(okp)
+    for f in ("octave", "class_id"):
+        np.testing.assert_array_equal(gkp[f], okp[f], err_msg=f)
+    for f in ("x", "y", "size", "response", "angle"):
+        np.testing.assert_array_equal(gkp[f].view(np.uint32), okp[f].view(np.uint32), err_msg=f)
+    np.testing.assert_array_equal(gdesc, odesc)
+    return len(gkp)
+
+
+def test_euroc_left_bit_exact(ext, oracle, euroc_l):
+    n = _cmp_extract(ext, oracle, euroc_l)
+    assert n >= 1900
+
+
+def test_euroc_right_bit_exact(ext, oracle, euroc_r):
+    _cmp_extract(ext, oracle, euroc_r)
+
+
+@pytest.mark.parametrize("idx", [0, 1, 2])
+def test_synthetic_752x480_bit_exact(ext, oracle, idx):
+    _cmp_extract(ext, oracle, synth_frame(752, 480, idx))
+
+
+def test_batch_matches_single(ext, oracle, euroc_l, euroc_r):
+    imgs = [euroc_l, euroc_r, synth_frame(752, 480, 5), euroc_l]
+    kps, descs = ext.extract_batch(imgs)
+    for im, k, d in zip(imgs, kps, descs):
+        oe = oracle.OracleExtractor(2000, 1.2, 8, 20, 7)
+        okp, odesc = oe(im)
+        assert k.tobytes() == okp.tobytes()
+        np.testing.assert_array_equal(d, odesc)
