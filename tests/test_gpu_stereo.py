@@ -1,0 +1,114 @@
+"""GPU parity tests of the stereo association (Frame::ComputeStereoMatches_Undistorted) and of
+the device-chained extract -> match path, through the C ABI, vs the CPU oracle.  Index and
+integer outputs bit-exact; float outputs compared by bit pattern."""
+import numpy as np
+import pytest
+
+from conftest import synth_frame
+
+pytestmark = pytest.mark.gpu
+
+FX, BF = 435.2046959714599, 47.90639384423901   # EuRoC.yaml of ORB-SLAM2 (Camera.fx, Camera.bf)
+
+
+@pytest.fixture(scope="module")
+def ext():
+    import gf_orb_slam2_amd as G
+    e = G.ORBextractor(2000, 1.2, 8, 20, 7, max_batch=4)
+    yield e
+    e.close()
+
+
+def _params(rows=480):
+    import gf_orb_slam2_amd as G
+    return G.StereoParams(rows, BF, BF / FX, 0.0)
+
+
+def _cmp_stereo(got, ref):
+    assert got[0] == ref[0], f"nmatched {got[0]} vs {ref[0]}"
+    for name, a, b in zip(("u_right", "depth", "best_dist", "best_idx"), got[1:], ref[1:]):
+        assert a.tobytes() == b.tobytes(), name
+
+
+def test_stereo_host_arrays_euroc(ext, oracle, euroc_l, euroc_r):
+    import gf_orb_slam2_amd as G
+    oe = oracle.OracleExtractor(2000, 1.2, 8, 20, 7)
+    kl, dl = oe(euroc_l)
+    kr, dr = oe(euroc_r)
+    sf = oe.scale_factors
+    p = _params()
+    m = G.ORBmatcher(0.8, True, extractor=ext)
+    got = m.ComputeStereoMatches(kl, dl, kr, dr, sf, p)
+    ref = oracle.stereo_match(kl, dl, kr, dr, sf, p.n_rows, p.mbf, p.mb, p.min_x)
+    _cmp_stereo(got, ref)
+    assert (ref[1] > 0).sum() > 100       # the (unrectified) EuRoC pair still matches
+
+
+def test_stereo_disparity_windows(ext, oracle, euroc_l, euroc_r):
+    """per-keypoint [minD, maxD] windows (the map-point branch, Frame.cc:1220-1231)"""
+    import gf_orb_slam2_amd as G
+    oe = oracle.OracleExtractor(1000, 1.2, 8, 20, 7)
+    kl, dl = oe(euroc_l)
+    kr, dr = oe(euroc_r)
+    rng = np.random.default_rng(3)
+    min_d = rng.uniform(0, 30, len(kl)).astype(np.float32)
+    max_d = (min_d + rng.uniform(5, 80, len(kl))).astype(np.float32)
+    p = _params()
+    m = G.ORBmatcher(0.8, True, extractor=ext)
+    got = m.ComputeStereoMatches(kl, dl, kr, dr, oe.scale_factors, p, min_d, max_d)
+    ref = oracle.stereo_match(kl, dl, kr, dr, oe.scale_factors, p.n_rows, p.mbf, p.mb, p.min_x, min_d, max_d)
+    _cmp_stereo(got, ref)
+
+
+def test_stereo_edge_cases(ext, oracle):
+    import gf_orb_slam2_amd as G
+    m = G.ORBmatcher(0.8, True, extractor=ext)
+    sf = np.array([1.0, 1.2, 1.44], np.float32)
+    p = _params()
+    kd = oracle.KEYPOINT_DTYPE
+    # empty left / empty right
+    z = np.zeros(0, kd); zd = np.zeros((0, 32), np.uint8)
+    one = np.zeros(1, kd); one["x"] = 100; one["y"] = 50
+    od = np.zeros((1, 32), np.uint8)
+    assert m.ComputeStereoMatches(z, zd, one, od, sf, p)[0] == 0
+    got = m.ComputeStereoMatches(one, od, z, zd, sf, p)
+    ref = oracle.stereo_match(one, od, z, zd, sf, p.n_rows, p.mbf, p.mb, p.min_x)
+    _cmp_stereo(got, ref)
+    # identical descriptors, ties on distance: the lowest right index must win; rows out of range skipped
+    rng = np.random.default_rng(11)
+    n = 300
+    kl = np.zeros(n, kd); kr = np.zeros(n, kd)
+    kl["x"] = rng.uniform(100, 700, n).astype(np.float32); kl["y"] = rng.uniform(-5, 490, n).astype(np.float32)
+    kl["octave"] = rng.integers(0, 3, n)
+    kr["x"] = kl["x"] - rng.uniform(-3, 60, n).astype(np.float32); kr["y"] = kl["y"] + rng.uniform(-2, 2, n).astype(np.float32)
+    kr["octave"] = rng.integers(0, 3, n)
+    base = rng.integers(0, 256, (8, 32), dtype=np.uint8)
+    dl = base[rng.integers(0, 8, n)]
+    dr = base[rng.integers(0, 8, n)]
+    got = m.ComputeStereoMatches(kl, dl, kr, dr, sf, p)
+    ref = oracle.stereo_match(kl, dl, kr, dr, sf, p.n_rows, p.mbf, p.mb, p.min_x)
+    _cmp_stereo(got, ref)
+
+
+def test_chained_extract_and_match_on_device(ext, oracle, euroc_l, euroc_r):
+    import torch
+    import gf_orb_slam2_amd as G
+    sl = synth_frame(752, 480, 7)
+    sr = np.roll(sl, -9, axis=1)
+    imgs = np.stack([euroc_l, euroc_r, sl, sr])
+    t = torch.from_numpy(imgs).cuda()
+    ext.set_stream(torch.cuda.current_stream().cuda_stream)
+    ext.extract_batch_device(t.data_ptr(), 4, 752, 480)
+    m = G.ORBmatcher(0.8, True, extractor=ext)
+    p = _params()
+    m.stereo_match_batch(p)
+    torch.cuda.synchronize()
+    for pair in range(2):
+        oe = oracle.OracleExtractor(2000, 1.2, 8, 20, 7)
+        kl, dl = oe(imgs[2 * pair]); kr, dr = oe(imgs[2 * pair + 1])
+        gkl, gdl = ext.batch_fetch(2 * pair)
+        assert gkl.tobytes() == kl.tobytes() and (gdl == dl).all()
+        ref = oracle.stereo_match(kl, dl, kr, dr, oe.scale_factors, p.n_rows, p.mbf, p.mb, p.min_x)
+        nm, u, dp, bd, bi = m.stereo_fetch(pair, len(kl))
+        _cmp_stereo((nm, u, dp, bd, bi), ref)
+    ext.set_stream(0)
