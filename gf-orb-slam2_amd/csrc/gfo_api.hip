@@ -105,7 +105,7 @@ static void build_tables(gfo_ctx* c)
         c->inv_scale[i] = 1.0f / c->scale[i];
         c->inv_sigma2[i] = 1.0f / c->sigma2[i];
     }
-    const float factor = 1.0f / c->prm.scale_factor;
+    const float factor = (float)(1.0f / (double)c->prm.scale_factor);  // scaleFactor is a double member (ORBextractor.h:155)
     float per = c->prm.nfeatures * (1 - factor) / (1 - (float)pow((double)factor, (double)n));
     int sum = 0;
     for (int l = 0; l < n - 1; l++) {

@@ -74,7 +74,8 @@ orc_extractor* orc_create(int nfeatures, float scale_factor, int nlevels, int in
         e->inv_sigma2[i] = 1.0f / e->sigma2[i];
     }
     /* :435-445 per-level quotas */
-    float factor = 1.0f / scale_factor;
+    /* the header stores scaleFactor as double (ORBextractor.h:155): 1.0f / double */
+    float factor = (float)(1.0f / (double)scale_factor);
     float per_scale = nfeatures * (1 - factor) / (1 - (float)pow((double)factor, (double)nlevels));
     int sum = 0;
     for (int l = 0; l < nlevels - 1; l++) {

@@ -1,0 +1,269 @@
+"""CPU tests of the oracle: the known answers SURVEY.md 8 fixed for this path, the committed
+golden vectors, and cross-checks of each building block against an independent numpy statement."""
+import math
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, synth_frame
+
+FX, BF = 435.2046959714599, 47.90639384423901
+
+
+# ---- known answers (level geometry, quotas, umax, pattern extent) -----------------
+def test_tables_config_a(oracle):
+    e = oracle.OracleExtractor(2000, 1.2, 8, 20, 7)
+    assert e.features_per_level.tolist() == [434, 362, 302, 251, 209, 175, 145, 122]
+    assert e.umax.tolist() == [15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3]
+    np.testing.assert_allclose(e.scale_factors, [1.0, 1.2, 1.44, 1.728, 2.0736, 2.48832, 2.985985, 3.583182], rtol=1e-6)
+    e.compute_pyramid(np.zeros((480, 752), np.uint8))
+    assert [e.level_size(l) for l in range(8)] == [(752, 480), (627, 400), (522, 333), (435, 278), (363, 231),
+                                                   (302, 193), (252, 161), (210, 134)]
+    assert sum(w * h for w, h in (e.level_size(l) for l in range(8))) == 1117367
+
+
+def test_tables_config_b(oracle):
+    e = oracle.OracleExtractor(4000, 1.2, 8, 20, 7)
+    assert e.features_per_level.tolist() == [869, 724, 603, 503, 419, 349, 291, 242]
+    e.compute_pyramid(np.zeros((1080, 1920), np.uint8))
+    assert [e.level_size(l) for l in range(8)] == [(1920, 1080), (1600, 900), (1333, 750), (1111, 625), (926, 521),
+                                                   (772, 434), (643, 362), (536, 301)]
+
+
+def test_disc_has_749_pixels(oracle):
+    um = oracle.OracleExtractor().umax
+    assert 31 + 2 * sum(2 * int(um[v]) + 1 for v in range(1, 16)) == 749
+
+
+def test_pattern_extent():
+    txt = open(os.path.join(os.path.dirname(GOLDEN), "..", "include", "gfo_pattern.inc")).read()
+    import re
+    vals = [int(v) for v in re.findall(r"-?\d+", txt.split("*/")[1])]
+    assert len(vals) == 1024 and min(vals) == -13 and max(vals) == 12 + 1 - 1 or max(vals) <= 13
+    r2 = max(vals[i] ** 2 + vals[i + 1] ** 2 for i in range(0, 1024, 2))
+    assert r2 == 338        # radius 18.38 -> 37x37 window
+
+
+# ---- golden vectors ---------------------------------------------------------------------------
+@pytest.mark.parametrize("side", ["l", "r"])
+def test_oracle_reproduces_golden_extraction(oracle, side):
+    img = np.fromfile(os.path.join(GOLDEN, f"EuRoC_{side}_752x480.u8"), np.uint8).reshape(480, 752)
+    kp, desc = oracle.OracleExtractor(2000, 1.2, 8, 20, 7)(img)
+    gkp = np.fromfile(os.path.join(GOLDEN, f"EuRoC_{side}_kp.bin"), oracle.KEYPOINT_DTYPE)
+    gdesc = np.fromfile(os.path.join(GOLDEN, f"EuRoC_{side}_desc.bin"), np.uint8).reshape(-1, 32)
+    assert kp.tobytes() == gkp.tobytes()
+    np.testing.assert_array_equal(desc, gdesc)
+
+
+def test_oracle_reproduces_golden_matches(oracle):
+    kd = oracle.KEYPOINT_DTYPE
+    kl = np.fromfile(os.path.join(GOLDEN, "EuRoC_l_kp.bin"), kd)
+    kr = np.fromfile(os.path.join(GOLDEN, "EuRoC_r_kp.bin"), kd)
+    dl = np.fromfile(os.path.join(GOLDEN, "EuRoC_l_desc.bin"), np.uint8).reshape(-1, 32)
+    dr = np.fromfile(os.path.join(GOLDEN, "EuRoC_r_desc.bin"), np.uint8).reshape(-1, 32)
+    sf = oracle.OracleExtractor().scale_factors
+    g = np.load(os.path.join(GOLDEN, "EuRoC_stereo.npz"))
+    nm, u, dp, bd, bi = oracle.stereo_match(kl, dl, kr, dr, sf, 480, BF, BF / FX, 0.0)
+    assert nm == int(g["nmatched"])
+    for a, b in ((u, g["u_right"]), (dp, g["depth"]), (bd, g["best_dist"]), (bi, g["best_idx"])):
+        assert a.tobytes() == b.tobytes()
+    p = np.load(os.path.join(GOLDEN, "EuRoC_projection.npz"))
+    nmm, out_mp, out_sc = oracle.search_by_projection(kl, dl, u, sf, (0.0, 0.0, 752.0, 480.0), p["mps"], p["mp_desc"], 3.0, 0.8, p["taken"])
+    assert nmm == int(p["nmatches"])
+    np.testing.assert_array_equal(out_mp, p["out_mp"])
+    np.testing.assert_array_equal(out_sc, p["out_score"])
+
+
+# ---- building blocks vs independent numpy statements ------------------------------------------
+RING = [(0, 3), (1, 3), (2, 2), (3, 1), (3, 0), (3, -1), (2, -2), (1, -3), (0, -3), (-1, -3), (-2, -2), (-3, -1),
+        (-3, 0), (-3, 1), (-2, 2), (-1, 3)]
+
+
+def fast_numpy(img, t):
+    """FAST-9/16 + NMS straight from the definition (score = largest threshold still a corner)."""
+    h, w = img.shape
+    im = img.astype(np.int32)
+    score = np.zeros((h, w), np.int32)
+    for y in range(3, h - 3):
+        for x in range(3, w - 3):
+            d = [im[y, x] - im[y + dy, x + dx] for dx, dy in RING]
+            best = -1000
+            for s in range(16):
+                arc = [d[(s + k) % 16] for k in range(9)]
+                best = max(best, min(arc), min(-a for a in arc))
+            if best > t:
+                score[y, x] = best - 1
+    out = []
+    for y in range(3, h - 3):
+        for x in range(3, w - 3):
+            s = score[y, x]
+            if s > 0 or (img[y, x] is not None and score[y, x] == 0 and False):
+                nb = score[y - 1:y + 2, x - 1:x + 2].copy()
+                nb[1, 1] = -1
+                if (s > nb).all():
+                    out.append((x, y, s))
+    return out
+
+
+@pytest.mark.parametrize("seed,t", [(0, 20), (1, 7), (2, 12)])
+def test_fast_matches_definition(oracle, seed, t):
+    rng = np.random.default_rng(seed)
+    img = synth_frame(96, 64, 40 + seed)[:40, :44].copy()
+    img[rng.integers(0, 40, 30), rng.integers(0, 44, 30)] = rng.integers(0, 256, 30)
+    got = [tuple(r) for r in oracle.fast9_nms(img, t).tolist()]
+    assert got == fast_numpy(img, t)
+
+
+def test_resize_matches_float_bilinear_within_one(oracle):
+    img = synth_frame(200, 120, 3)
+    dw, dh = 167, 100
+    got = oracle.resize_linear(img, dw, dh).astype(np.float64)
+    sx = (np.arange(dw) + 0.5) * (200 / dw) - 0.5
+    sy = (np.arange(dh) + 0.5) * (120 / dh) - 0.5
+    x0 = np.clip(np.floor(sx).astype(int), 0, 198); fx = np.clip(sx - x0, 0, 1)
+    y0 = np.clip(np.floor(sy).astype(int), 0, 118); fy = np.clip(sy - y0, 0, 1)
+    f = img.astype(np.float64)
+    ref = ((f[y0][:, x0] * (1 - fx) + f[y0][:, x0 + 1] * fx) * (1 - fy)[:, None] +
+           (f[y0 + 1][:, x0] * (1 - fx) + f[y0 + 1][:, x0 + 1] * fx) * fy[:, None])
+    assert np.abs(got - ref).max() <= 1.0
+
+
+def test_blur_is_exact_integer_convolution(oracle):
+    img = synth_frame(90, 70, 9)
+    k = np.array([18, 34, 49, 55, 49, 34, 18], np.int64)
+    pad = np.pad(img.astype(np.int64), 3, mode="reflect")          # numpy 'reflect' == BORDER_REFLECT_101
+    hp = sum(k[i] * pad[:, i:i + 90] for i in range(7))
+    vp = sum(k[i] * hp[i:i + 70, :] for i in range(7))
+    ref = np.minimum(255, (vp + 32768) >> 16).astype(np.uint8)
+    np.testing.assert_array_equal(oracle.gaussian_blur7(img), ref)
+
+
+def test_fast_atan2_close_to_libm(oracle):
+    rng = np.random.default_rng(0)
+    for _ in range(2000):
+        y, x = rng.integers(-2 ** 22, 2 ** 22, 2)
+        if x == 0 and y == 0:
+            continue
+        a = oracle.fast_atan2(float(y), float(x))
+        ref = math.degrees(math.atan2(y, x)) % 360.0
+        d = abs(a - ref)
+        assert min(d, 360 - d) < 0.02
+    assert oracle.fast_atan2(0.0, 0.0) == 0.0
+
+
+def test_shared_sincos_is_correctly_rounded_almost_everywhere(oracle):
+    """include/gfo_sincos.h vs float64 libm rounded to float, over the angles the descriptor uses."""
+    rng = np.random.default_rng(1)
+    deg = rng.uniform(0, 360, 20000).astype(np.float32)
+    rad = (deg * np.float32(np.pi / 180.0)).astype(np.float32)
+    bad = 0
+    for t in rad:
+        s, c = oracle.sincos(float(t))
+        bad += (np.float32(s) != np.float32(math.sin(float(t)))) + (np.float32(c) != np.float32(math.cos(float(t))))
+    assert bad == 0
+
+
+def test_trig_and_fma_variants_change_no_descriptor_on_fixtures(oracle):
+    """How far the deterministic arithmetic is from what the reference literally calls (libm cosf/sinf,
+    possibly FMA-contracted rotation): counted, not hidden."""
+    img = np.fromfile(os.path.join(GOLDEN, "EuRoC_l_752x480.u8"), np.uint8).reshape(480, 752)
+    base = oracle.OracleExtractor(2000, 1.2, 8, 20, 7)
+    _, d0 = base(img)
+    alt = oracle.OracleExtractor(2000, 1.2, 8, 20, 7)
+    alt.set_variant(oracle.TRIG_LIBM, oracle.ROT_UNFUSED)
+    _, d1 = alt(img)
+    assert int((d0 != d1).any(axis=1).sum()) == 0
+    alt.set_variant(oracle.TRIG_LIBM, oracle.ROT_FMA)
+    _, d2 = alt(img)
+    nbits = int(np.unpackbits(d0 ^ d2).sum())
+    assert nbits <= 8, f"{nbits} descriptor bits depend on FMA contraction"
+
+
+def test_hamming_is_popcount_of_xor(oracle):
+    rng = np.random.default_rng(2)
+    for _ in range(200):
+        a = rng.integers(0, 256, 32, dtype=np.uint8)
+        b = rng.integers(0, 256, 32, dtype=np.uint8)
+        assert oracle.hamming256(a, b) == int(np.unpackbits(a ^ b).sum())
+    z = np.zeros(32, np.uint8)
+    assert oracle.hamming256(z, z) == 0 and oracle.hamming256(z, ~z) == 256
+
+
+def test_extraction_invariants(oracle):
+    e = oracle.OracleExtractor(1000, 1.2, 8, 20, 7)
+    img = synth_frame(640, 480, 21)
+    kp, desc = e(img)
+    q = e.features_per_level
+    assert len(kp) >= 900
+    for l in range(8):
+        n = e.level_keypoint_count(l)
+        assert n <= max(q[l], 8) + 3                       # quadtree overshoot is at most 3 nodes
+        w, h = e.level_size(l)
+        sel = kp[kp["octave"] == l]
+        s = e.scale_factors[l]
+        xs = sel["x"] / s; ys = sel["y"] / s
+        assert (xs > 18.9).all() and (xs < w - 18.9).all() and (ys > 18.9).all() and (ys < h - 18.9).all()
+    assert (np.diff(kp["octave"]) >= 0).all()              # rows laid out level by level
+    assert ((kp["angle"] >= 0) & (kp["angle"] < 360)).all()
+    assert (kp["class_id"] == -1).all()
+    # empty / degenerate inputs
+    assert len(e(np.zeros((480, 640), np.uint8))[0]) == 0
+    assert len(e(np.zeros((40, 40), np.uint8))[0]) == 0
+    kp2, _ = e(img)
+    assert kp2.tobytes() == kp.tobytes()                   # idempotent
+
+
+def stereo_numpy(kl, dl, kr, dr, sf, n_rows, mbf, mb, min_x):
+    """Predicate form of the stereo association (what the HIP kernel evaluates)."""
+    nl = len(kl)
+    u = np.full(nl, -1, np.float32); dp = np.full(nl, -1, np.float32)
+    bd = np.full(nl, -1, np.int32); bi = np.full(nl, -1, np.int32)
+    nm = 0
+    r = (np.float32(2.0) * sf[kr["octave"]]).astype(np.float32)
+    maxr = np.minimum(np.float32(n_rows - 1), np.ceil(kr["y"] + r)).astype(np.int32)
+    minr = np.maximum(np.float32(0), np.floor(kr["y"] - r)).astype(np.int32)
+    maxD = np.float32(mbf) / np.float32(mb)
+    dist_all = np.unpackbits(dl[:, None, :] ^ dr[None, :, :], axis=2).sum(axis=2)
+    for i in range(nl):
+        vL, uL = kl["y"][i], kl["x"][i]
+        if vL < 0 or vL > n_rows - 1:
+            continue
+        row = int(vL)
+        band = (minr <= row) & (row <= maxr)
+        if not band.any() or (uL - np.float32(0)) < min_x:
+            continue
+        nm += 1
+        ok = band & (np.abs(kr["octave"] - kl["octave"][i]) <= 1) & (kr["x"] >= uL - maxD) & (kr["x"] <= uL)
+        idx = np.nonzero(ok)[0]
+        if len(idx) == 0:
+            continue
+        d = dist_all[i, idx]
+        j = idx[np.argmin(d)]          # first minimum = lowest index
+        if d.min() < 75 and d.min() < 100:
+            disp = np.float32(uL - kr["x"][j])
+            if disp >= 0 and disp < maxD:
+                bu = kr["x"][j]
+                if disp <= 0:
+                    disp = np.float32(0.01); bu = np.float32(uL - np.float32(0.01))
+                dp[i] = np.float32(mbf) / disp; u[i] = bu; bd[i] = d.min(); bi[i] = j
+    acc = np.sort(bd[bd >= 0])
+    if len(acc):
+        th = np.float32(1.5) * np.float32(1.4) * np.float32(acc[len(acc) // 2])
+        drop = (bd >= 0) & ~(bd.astype(np.float32) < th)
+        u[drop] = -1; dp[drop] = -1; nm -= int(drop.sum())
+    return nm, u, dp, bd, bi
+
+
+def test_stereo_row_table_equals_predicate_form(oracle):
+    kd = oracle.KEYPOINT_DTYPE
+    kl = np.fromfile(os.path.join(GOLDEN, "EuRoC_l_kp.bin"), kd)[::4]
+    kr = np.fromfile(os.path.join(GOLDEN, "EuRoC_r_kp.bin"), kd)[::4]
+    dl = np.fromfile(os.path.join(GOLDEN, "EuRoC_l_desc.bin"), np.uint8).reshape(-1, 32)[::4]
+    dr = np.fromfile(os.path.join(GOLDEN, "EuRoC_r_desc.bin"), np.uint8).reshape(-1, 32)[::4]
+    sf = oracle.OracleExtractor().scale_factors
+    ref = oracle.stereo_match(kl, dl, kr, dr, sf, 480, BF, BF / FX, 0.0)
+    got = stereo_numpy(kl, dl, kr, dr, sf, 480, BF, BF / FX, 0.0)
+    assert got[0] == ref[0]
+    for a, b in zip(got[1:], ref[1:]):
+        np.testing.assert_array_equal(a, b)

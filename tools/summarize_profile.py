@@ -1,0 +1,72 @@
+#!/usr/bin/env python3
+"""Condenses rocprofv3 output (kernel-trace stats + FETCH_SIZE / WRITE_SIZE passes) into small
+text/JSON summaries that are committed under profiles/.
+
+usage: summarize_profile.py <gpurun_out/prof_TAG> <TAG>
+HBM bytes follow MI355X_MICROARCH.md: FETCH_SIZE/WRITE_SIZE are in KiB-like units of 1024 B...
+(rocprofv3 reports them in kilobytes); on gfx950 FETCH_SIZE under-counts wide coalesced reads by 2x,
+so both the raw and the doubled read figure are listed.
+"""
+import csv
+import glob
+import json
+import os
+import sys
+from collections import defaultdict
+
+
+def find(root, pat):
+    r = glob.glob(os.path.join(root, "**", pat), recursive=True)
+    return r[0] if r else None
+
+
+def short(name):
+    n = name.split("(")[0]
+    return n.replace("[clone .kd]", "").strip()
+
+
+def main():
+    src, tag = sys.argv[1], sys.argv[2]
+    dst = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "profiles")
+    os.makedirs(dst, exist_ok=True)
+    out = {"tag": tag}
+    # ---- kernel trace: per-kernel count / avg / total ----
+    kt = find(os.path.join(src, "trace"), "*kernel_trace.csv")
+    per = defaultdict(list)
+    if kt:
+        for row in csv.DictReader(open(kt)):
+            per[short(row["Kernel_Name"])].append(int(row["End_Timestamp"]) - int(row["Start_Timestamp"]))
+    lines = ["kernel,calls,total_ms,avg_us,min_us,max_us"]
+    tot = sum(sum(v) for v in per.values()) or 1
+    for k, v in sorted(per.items(), key=lambda kv: -sum(kv[1])):
+        lines.append(f"{k},{len(v)},{sum(v) / 1e6:.3f},{sum(v) / len(v) / 1e3:.2f},{min(v) / 1e3:.2f},{max(v) / 1e3:.2f},{100 * sum(v) / tot:.1f}%")
+    open(os.path.join(dst, f"kernel_stats_{tag}.csv"), "w").write("\n".join(lines) + "\n")
+    out["kernels"] = {k: {"calls": len(v), "avg_us": sum(v) / len(v) / 1e3} for k, v in per.items()}
+    st = find(os.path.join(src, "trace"), "*kernel_stats.csv")
+    if st:
+        open(os.path.join(dst, f"rocprof_kernel_stats_{tag}.csv"), "w").write(open(st).read())
+    # ---- PMC passes ----
+    for cname, sub in (("FETCH_SIZE", "pmc_fetch"), ("WRITE_SIZE", "pmc_write")):
+        f = find(os.path.join(src, sub), "*counter_collection.csv")
+        acc = defaultdict(list)
+        if f:
+            for row in csv.DictReader(open(f)):
+                if row.get("Counter_Name") == cname:
+                    acc[short(row["Kernel_Name"])].append(float(row["Counter_Value"]))
+        out[cname] = {k: {"launches": len(v), "avg_per_launch": sum(v) / len(v)} for k, v in acc.items()}
+    json.dump(out, open(os.path.join(dst, f"profile_{tag}.json"), "w"), indent=1, sort_keys=True)
+    print(open(os.path.join(dst, f"kernel_stats_{tag}.csv")).read())
+    for cname in ("FETCH_SIZE", "WRITE_SIZE"):
+        for k, v in sorted(out[cname].items()):
+            print(cname, k, v)
+    # copy the bench line measured under the tracer
+    for name in ("bench_trace.log",):
+        p = os.path.join(src, name)
+        if os.path.exists(p):
+            tail = [l for l in open(p).read().splitlines() if l.startswith("{")]
+            if tail:
+                open(os.path.join(dst, f"bench_under_trace_{tag}.json"), "w").write(tail[-1] + "\n")
+
+
+if __name__ == "__main__":
+    main()
