@@ -55,6 +55,28 @@ def lib_path():
 _lib = None
 
 
+def _share_hip_runtime_with_torch():
+    """One HIP/HSA runtime per process.  PyTorch wheels bundle their own libamdhip64.so.7; if libgfo.so
+    pulled in /opt/rocm's copy first, a later `import torch` would bring up a second runtime and fail
+    with "No HIP GPUs are available".  Pre-loading torch's copy (same SONAME) makes libgfo bind to it.
+    No torch import happens here and nothing changes when torch is absent."""
+    import importlib.util
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.origin:
+        return
+    libdir = os.path.join(os.path.dirname(spec.origin), "lib")
+    for name in ("libhsa-runtime64.so", "libamdhip64.so"):
+        cand = os.path.join(libdir, name)
+        if os.path.exists(cand):
+            try:
+                C.CDLL(cand, mode=C.RTLD_GLOBAL)
+            except OSError:
+                return
+
+
 def load_library():
     """Loads libgfo.so; raises if it has not been built (no fallback of any kind)."""
     global _lib
@@ -63,6 +85,7 @@ def load_library():
     p = lib_path()
     if not os.path.exists(p):
         raise GfoError(-2, f"{p} not built: run `python -c 'import __graft_entry__ as g; g.build()'`")
+    _share_hip_runtime_with_torch()
     L = C.CDLL(p)
     vp, i, f, sz = C.c_void_p, C.c_int, C.c_float, C.c_size_t
     ip = C.POINTER(C.c_int)

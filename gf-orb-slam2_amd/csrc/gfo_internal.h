@@ -129,6 +129,7 @@ struct gfo_ctx {
     // scratch for host-array matcher entry points
     void* d_scratch = nullptr;
     size_t scratch_bytes = 0;
+    int last_project_rounds = 0;     // Jacobi rounds of the last gfo_search_by_projection
 };
 
 // ---- kernel launchers (each in its own .hip file) ------------------------------------------

@@ -1,0 +1,94 @@
+"""GPU parity tests of ORBmatcher::SearchByProjection(Frame&, MapPoints, th) through the C ABI vs
+the CPU oracle (serial, order-dependent reference semantics).  Indices bit-exact."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ext():
+    import gf_orb_slam2_amd as G
+    e = G.ORBextractor(2000, 1.2, 8, 20, 7)
+    yield e
+    e.close()
+
+
+def _frame(oracle):
+    kd = oracle.KEYPOINT_DTYPE
+    kl = np.fromfile(os.path.join(GOLDEN, "EuRoC_l_kp.bin"), kd)
+    dl = np.fromfile(os.path.join(GOLDEN, "EuRoC_l_desc.bin"), np.uint8).reshape(-1, 32)
+    st = np.load(os.path.join(GOLDEN, "EuRoC_stereo.npz"))
+    return kl, dl, st["u_right"]
+
+
+def test_golden_projection_case(ext, oracle):
+    import gf_orb_slam2_amd as G
+    kl, dl, u = _frame(oracle)
+    g = np.load(os.path.join(GOLDEN, "EuRoC_projection.npz"))
+    m = G.ORBmatcher(0.8, True, extractor=ext)
+    sf = ext.GetScaleFactors()
+    nm, out_mp, out_sc = m.SearchByProjection(kl, dl, u, sf, (0.0, 0.0, 752.0, 480.0), g["mps"], g["mp_desc"], 3.0, g["taken"])
+    assert nm == int(g["nmatches"])
+    np.testing.assert_array_equal(out_mp, g["out_mp"])
+    np.testing.assert_array_equal(out_sc, g["out_score"])
+
+
+@pytest.mark.parametrize("seed,m,th,ratio", [(1, 3000, 3.0, 0.8), (2, 8000, 1.0, 0.6), (3, 20000, 5.0, 0.9)])
+def test_contended_maps(ext, oracle, seed, m, th, ratio):
+    """Many map points compete for the same keypoints (near-duplicate descriptors, clustered
+    projections), with blocking and non-blocking points mixed: exercises the ordered resolution."""
+    import gf_orb_slam2_amd as G
+    kl, dl, u = _frame(oracle)
+    rng = np.random.default_rng(seed)
+    n = len(kl)
+    mps = np.zeros(m, oracle.MAP_POINT_DTYPE)
+    src = rng.integers(0, n, m)                       # every map point imitates some keypoint
+    mpd = dl[src].copy()
+    flips = rng.integers(0, 256, (m, 6))
+    for j in range(6):                                # up to 6 flipped bits: lots of ties and near ties
+        sel = rng.random(m) < 0.5
+        mpd[sel, flips[sel, j] >> 3] ^= (1 << (flips[sel, j] & 7)).astype(np.uint8)
+    mps["proj_x"] = kl["x"][src] + rng.normal(0, 3, m)
+    mps["proj_y"] = kl["y"][src] + rng.normal(0, 3, m)
+    mps["proj_xr"] = mps["proj_x"] - rng.uniform(0, 30, m)
+    mps["level"] = np.clip(kl["octave"][src] + rng.integers(-1, 2, m), 0, 7)
+    mps["view_cos"] = rng.choice([1.0, 0.9985, 0.99], m)
+    fl = np.full(m, 1 | 4, np.int32)
+    fl[rng.random(m) < 0.05] = 4
+    fl[rng.random(m) < 0.05] |= 2
+    fl[rng.random(m) < 0.3] &= ~4
+    mps["flags"] = fl
+    taken = (rng.random(n) < 0.2).astype(np.uint8)
+    bounds = (0.0, 0.0, 752.0, 480.0)
+    sf = ext.GetScaleFactors()
+    ref = oracle.search_by_projection(kl, dl, u, sf, bounds, mps, mpd, th, ratio, taken)
+    got = G.ORBmatcher(ratio, True, extractor=ext).SearchByProjection(kl, dl, u, sf, bounds, mps, mpd, th, taken)
+    assert got[0] == ref[0]
+    np.testing.assert_array_equal(got[1], ref[1])
+    np.testing.assert_array_equal(got[2], ref[2])
+    assert ref[0] > 100
+
+
+def test_projection_edge_cases(ext, oracle):
+    import gf_orb_slam2_amd as G
+    kl, dl, u = _frame(oracle)
+    m = G.ORBmatcher(0.8, True, extractor=ext)
+    sf = ext.GetScaleFactors()
+    b = (0.0, 0.0, 752.0, 480.0)
+    z = np.zeros(0, oracle.MAP_POINT_DTYPE)
+    nm, out_mp, _ = m.SearchByProjection(kl, dl, None, sf, b, z, np.zeros((0, 32), np.uint8), 3.0, None)
+    assert nm == 0 and (out_mp == -1).all()
+    # projections outside the image / all filtered / no u_right / no taken
+    mps = np.zeros(50, oracle.MAP_POINT_DTYPE)
+    mps["proj_x"] = np.linspace(-500, 1500, 50); mps["proj_y"] = np.linspace(-300, 900, 50)
+    mps["level"] = 3; mps["view_cos"] = 1.0; mps["flags"] = 5
+    mpd = np.tile(dl[:1], (50, 1))
+    ref = oracle.search_by_projection(kl, dl, None, sf, b, mps, mpd, 3.0, 0.8, None)
+    got = m.SearchByProjection(kl, dl, None, sf, b, mps, mpd, 3.0, None)
+    assert got[0] == ref[0]
+    np.testing.assert_array_equal(got[1], ref[1]); np.testing.assert_array_equal(got[2], ref[2])
