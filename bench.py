@@ -60,6 +60,7 @@ def algorithmic_bytes(w, h, sizes, n_kp_img, stereo):
         "quadtree": 0,
         "orient_desc": n_kp_img * (749 + 1369 + 60),                     # disc + 37x37 window + kp/desc out
         "stereo_match": (2 * n_kp_img * 60 + n_kp_img * 8) / 2 if stereo else 0,  # per image = half a pair
+        "stereo_bucket": 0,
         "stereo_cut": 0,
     }
     survey_total = w * h + 4 * P + n_kp_img * 2178 + ((2 * n_kp_img * 60 + n_kp_img * 8) / 2 if stereo else 0)

@@ -35,7 +35,7 @@ static inline long long align_up(long long v, long long a) { return (v + a - 1) 
 // profiling
 // ---------------------------------------------------------------------------------------------
 static const char* k_stage_names[ST_COUNT] = {"resize", "blur", "fast", "quadtree", "orient_desc",
-                                              "stereo_match", "stereo_cut", "project"};
+                                              "stereo_bucket", "stereo_match", "stereo_cut", "project"};
 
 static hipEvent_t ev_get(gfo_ctx* c)
 {
@@ -123,14 +123,14 @@ static void free_arena(gfo_ctx* c)
 {
     void* ptrs[] = {c->d_geom, c->d_input, c->d_pyr, c->d_blur, c->d_cand, c->d_cand_cnt, c->d_node_of, c->d_sel,
                     c->d_sel_cnt, c->d_kp, c->d_desc, c->d_kp_cnt, c->d_flags, c->d_xofs, c->d_xcoef, c->d_yofs,
-                    c->d_ycoef, c->st.u_right, c->st.depth, c->st.best_dist, c->st.best_idx, c->st.nmatched,
-                    c->d_scale};
+                    c->d_ycoef, c->st.u_right, c->st.depth, c->st.best_dist, c->st.best_idx, c->st.nmatched, c->st.counted,
+                    c->d_scale, c->st_sort.sx, c->st_sort.sy, c->st_sort.soi, c->st_sort.sdesc, c->st_sort.row_start};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     c->d_geom = nullptr; c->d_input = c->d_pyr = c->d_blur = nullptr; c->d_cand = nullptr; c->d_cand_cnt = nullptr;
     c->d_node_of = nullptr; c->d_sel = nullptr; c->d_sel_cnt = nullptr; c->d_kp = nullptr; c->d_desc = nullptr;
     c->d_kp_cnt = nullptr; c->d_flags = nullptr; c->d_xofs = nullptr; c->d_xcoef = nullptr; c->d_yofs = nullptr;
-    c->d_ycoef = nullptr; c->st = GfoStereoDev{}; c->d_scale = nullptr;
+    c->d_ycoef = nullptr; c->st = GfoStereoDev{}; c->d_scale = nullptr; c->st_sort = GfoStereoSort{}; c->st_rows_cap = 0;
     c->planned = false;
     c->have_batch = c->have_pyramid = c->have_stereo = false;
 }
@@ -205,10 +205,10 @@ static int plan(gfo_ctx* c, int w, int h, int batch)
         }
         L.cand_off = cand_off;
         cand_off += align_up(L.cand_cap, 64);
-        L.tiles_x = (L.w + 63) / 64;
-        L.tiles_y = (L.h + 15) / 16;
-        L.tile_base = tile_base;
-        tile_base += L.tiles_x * L.tiles_y;
+        L.tiles_x = (L.w + 3) / 4;      // blur: column quads per row
+        L.tiles_y = (L.h + 31) / 32;    // blur: 32-row strips
+        L.tile_base = tile_base;        // blur: first 256-thread block of this level
+        tile_base += (L.tiles_x * L.tiles_y + 255) / 256;
         L.quota = c->quota[l];
         int nini = 1;
         if (L.max_by - GFO_MIN_BORDER > 0) nini = (int)roundf(width / height);  // :543
@@ -276,6 +276,13 @@ static int plan(gfo_ctx* c, int w, int h, int batch)
     HIP_TRY(c, hipMalloc(&c->st.best_dist, P * g.kp_stride * sizeof(int)));
     HIP_TRY(c, hipMalloc(&c->st.best_idx, P * g.kp_stride * sizeof(int)));
     HIP_TRY(c, hipMalloc(&c->st.nmatched, P * sizeof(int)));
+    HIP_TRY(c, hipMalloc(&c->st.counted, P * g.kp_stride));
+    HIP_TRY(c, hipMalloc(&c->st_sort.sx, P * g.kp_stride * sizeof(float)));
+    HIP_TRY(c, hipMalloc(&c->st_sort.sy, P * g.kp_stride * sizeof(float)));
+    HIP_TRY(c, hipMalloc(&c->st_sort.soi, P * g.kp_stride * sizeof(unsigned)));
+    HIP_TRY(c, hipMalloc(&c->st_sort.sdesc, P * g.kp_stride * 32));
+    c->st_rows_cap = h + 64;
+    HIP_TRY(c, hipMalloc(&c->st_sort.row_start, P * (size_t)(c->st_rows_cap + 1) * sizeof(int)));
     HIP_TRY(c, hipMemcpy(c->d_geom, &g, sizeof g, hipMemcpyHostToDevice));
     HIP_TRY(c, hipMemcpy(c->d_xofs, xofs.data(), xofs.size() * sizeof(int), hipMemcpyHostToDevice));
     HIP_TRY(c, hipMemcpy(c->d_xcoef, xcoef.data(), xcoef.size() * sizeof(short), hipMemcpyHostToDevice));
@@ -631,15 +638,19 @@ extern "C" int gfo_stereo_match(gfo_ctx* c, const gfo_keypoint* kl, const uint8_
     *nmatched = 0;
     if (nl == 0) return GFO_OK;
     HIP_TRY(c, hipSetDevice(c->device));
+    if (p->n_rows < 1 || p->n_rows > 8192) return fail(c, GFO_ERR_INVALID, "n_rows must be 1..8192");
     // scratch layout
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = off; off = (size_t)align_up((long long)(off + bytes), 256); return o; };
+    const int nr1 = nr > 0 ? nr : 1;
     const size_t o_kl = take(sizeof(gfo_keypoint) * nl), o_dl = take(32 * (size_t)nl);
-    const size_t o_kr = take(sizeof(gfo_keypoint) * (nr > 0 ? nr : 1)), o_dr = take(32 * (size_t)(nr > 0 ? nr : 1));
+    const size_t o_kr = take(sizeof(gfo_keypoint) * nr1), o_dr = take(32 * (size_t)nr1);
     const size_t o_sf = take(sizeof(float) * GFO_MAX_LEVELS);
     const size_t o_min = take(sizeof(float) * nl), o_max = take(sizeof(float) * nl);
     const size_t o_u = take(sizeof(float) * nl), o_dp = take(sizeof(float) * nl);
-    const size_t o_bd = take(sizeof(int) * nl), o_bi = take(sizeof(int) * nl), o_nm = take(sizeof(int));
+    const size_t o_bd = take(sizeof(int) * nl), o_bi = take(sizeof(int) * nl), o_nm = take(sizeof(int)), o_ct = take(nl);
+    const size_t o_sx = take(4 * (size_t)nr1), o_sy = take(4 * (size_t)nr1), o_soi = take(4 * (size_t)nr1),
+                 o_sd = take(32 * (size_t)nr1), o_rs = take(4 * (size_t)(p->n_rows + 1));
     int rc = scratch(c, off);
     if (rc) return rc;
     uint8_t* S = (uint8_t*)c->d_scratch;
@@ -655,10 +666,21 @@ extern "C" int gfo_stereo_match(gfo_ctx* c, const gfo_keypoint* kl, const uint8_
         HIP_TRY(c, hipMemcpyAsync(S + o_min, min_d, sizeof(float) * nl, hipMemcpyHostToDevice, c->stream));
         HIP_TRY(c, hipMemcpyAsync(S + o_max, max_d, sizeof(float) * nl, hipMemcpyHostToDevice, c->stream));
     }
-    GfoStereoDev out{(float*)(S + o_u), (float*)(S + o_dp), (int*)(S + o_bd), (int*)(S + o_bi), (int*)(S + o_nm)};
-    gfo_launch_stereo(c, (const gfo_keypoint*)(S + o_kl), S + o_dl, nullptr, nl, (const gfo_keypoint*)(S + o_kr), S + o_dr,
-                      nullptr, nr, 0, 1, (const float*)(S + o_sf), *p, win ? (const float*)(S + o_min) : nullptr,
-                      win ? (const float*)(S + o_max) : nullptr, out, nl);
+    GfoStereoDev out{(float*)(S + o_u), (float*)(S + o_dp), (int*)(S + o_bd), (int*)(S + o_bi), (int*)(S + o_nm), S + o_ct};
+    GfoStereoLaunch sl{};
+    sl.kl = (const gfo_keypoint*)(S + o_kl); sl.dl = S + o_dl;
+    sl.kr = (const gfo_keypoint*)(S + o_kr); sl.dr = S + o_dr;
+    sl.cnt_dev = nullptr; sl.nl_host = nl; sl.nr_host = nr;
+    sl.pair_stride_kp = 0; sl.npairs = 1;
+    sl.d_scale = (const float*)(S + o_sf);
+    sl.p = *p;
+    sl.min_d = win ? (const float*)(S + o_min) : nullptr;
+    sl.max_d = win ? (const float*)(S + o_max) : nullptr;
+    sl.out = out; sl.out_stride = nl;
+    sl.sort = GfoStereoSort{(float*)(S + o_sx), (float*)(S + o_sy), (unsigned*)(S + o_soi), S + o_sd, (int*)(S + o_rs)};
+    sl.sort_stride = nr1;
+    sl.window = gfo_stereo_window(sf, nlevels);
+    gfo_launch_stereo(c, sl);
     HIP_TRY(c, hipGetLastError());
     HIP_TRY(c, hipMemcpyAsync(u_right, out.u_right, sizeof(float) * nl, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipMemcpyAsync(depth, out.depth, sizeof(float) * nl, hipMemcpyDeviceToHost, c->stream));
@@ -675,8 +697,19 @@ extern "C" int gfo_stereo_match_batch(gfo_ctx* c, const gfo_stereo_params* p)
     if (!c->have_batch) return fail(c, GFO_ERR_STATE, "no batch has been extracted");
     if (c->last_nimg < 2 || (c->last_nimg & 1)) return fail(c, GFO_ERR_STATE, "stereo needs an even number of images (L,R,L,R,...)");
     const int npairs = c->last_nimg / 2;
-    gfo_launch_stereo(c, c->d_kp, c->d_desc, c->d_kp_cnt, 0, c->d_kp + c->g.kp_stride, c->d_desc + (size_t)c->g.kp_stride * 32,
-                      nullptr, 0, 2LL * c->g.kp_stride, npairs, c->d_scale, *p, nullptr, nullptr, c->st, c->g.kp_stride);
+    if (p->n_rows < 1 || p->n_rows > c->st_rows_cap) return fail(c, GFO_ERR_INVALID, "n_rows %d exceeds the planned %d", p->n_rows, c->st_rows_cap);
+    GfoStereoLaunch sl{};
+    sl.kl = c->d_kp; sl.dl = c->d_desc;
+    sl.kr = c->d_kp + c->g.kp_stride; sl.dr = c->d_desc + (size_t)c->g.kp_stride * 32;
+    sl.cnt_dev = c->d_kp_cnt; sl.nl_host = 0; sl.nr_host = 0;
+    sl.pair_stride_kp = 2LL * c->g.kp_stride; sl.npairs = npairs;
+    sl.d_scale = c->d_scale;
+    sl.p = *p;
+    sl.min_d = nullptr; sl.max_d = nullptr;
+    sl.out = c->st; sl.out_stride = c->g.kp_stride;
+    sl.sort = c->st_sort; sl.sort_stride = c->g.kp_stride;
+    sl.window = gfo_stereo_window(c->scale.data(), c->g.nlevels);
+    gfo_launch_stereo(c, sl);
     HIP_TRY(c, hipGetLastError());
     c->have_stereo = true;
     return GFO_OK;

@@ -70,10 +70,34 @@ struct GfoStereoDev {
     int* best_dist;
     int* best_idx;
     int* nmatched;      // [pairs]
+    unsigned char* counted;  // [pairs][kp_stride] 1 where the reference's loop reaches nmatched++ (Frame.cc:1286)
+};
+
+// right keypoints of a pair counting-sorted by floor(y), compact SoA (k_stereo_bucket)
+struct GfoStereoSort {
+    float* sx;
+    float* sy;
+    unsigned* soi;      // octave << 16 | original index
+    uint8_t* sdesc;     // 32 B per keypoint
+    int* row_start;     // [pairs][n_rows + 1]
+};
+
+struct GfoStereoLaunch {
+    const gfo_keypoint* kl; const uint8_t* dl;
+    const gfo_keypoint* kr; const uint8_t* dr;
+    const int* cnt_dev; int nl_host, nr_host;
+    long long pair_stride_kp;
+    int npairs;
+    const float* d_scale;
+    gfo_stereo_params p;
+    const float* min_d; const float* max_d;
+    GfoStereoDev out; int out_stride;
+    GfoStereoSort sort; int sort_stride;
+    int window;
 };
 
 enum GfoStage {
-    ST_RESIZE = 0, ST_BLUR, ST_FAST, ST_QUADTREE, ST_ORIENT_DESC, ST_STEREO, ST_STEREO_CUT,
+    ST_RESIZE = 0, ST_BLUR, ST_FAST, ST_QUADTREE, ST_ORIENT_DESC, ST_STEREO_BUCKET, ST_STEREO, ST_STEREO_CUT,
     ST_PROJECT, ST_COUNT
 };
 
@@ -113,6 +137,8 @@ struct gfo_ctx {
     short* d_ycoef = nullptr;
     float* d_scale = nullptr;        // mvScaleFactor on the device
     GfoStereoDev st{};
+    GfoStereoSort st_sort{};
+    int st_rows_cap = 0;             // rows the row_start table of st_sort is sized for
     // state of the last batch
     int last_nimg = 0;
     GfoInput last_in{};
@@ -138,10 +164,8 @@ void gfo_launch_blur(gfo_ctx* c, const GfoInput& in, int nimg);
 void gfo_launch_fast(gfo_ctx* c, const GfoInput& in, int nimg);
 void gfo_launch_quadtree(gfo_ctx* c, int nimg);
 void gfo_launch_orient_desc(gfo_ctx* c, const GfoInput& in, int nimg);
-void gfo_launch_stereo(gfo_ctx* c, const gfo_keypoint* kl, const uint8_t* dl, const int* nl_dev, int nl_host,
-                       const gfo_keypoint* kr, const uint8_t* dr, const int* nr_dev, int nr_host,
-                       long long pair_stride_kp, int npairs, const float* d_scale, const gfo_stereo_params& p,
-                       const float* min_d, const float* max_d, GfoStereoDev out, int out_stride);
+void gfo_launch_stereo(gfo_ctx* c, const GfoStereoLaunch& s);
+int gfo_stereo_window(const float* scale, int nlevels);
 
 // profiling helpers (gfo_api.hip)
 void gfo_prof_begin(gfo_ctx* c, int stage);

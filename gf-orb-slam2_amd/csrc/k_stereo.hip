@@ -2,99 +2,170 @@
 // (Frame.h:230-263, Frame.cc:1167-1316; ALTER_STEREO_MATCHING path), plus
 // ORBmatcher::DescriptorDistance (ORBmatcher.cc:1768-1784) as XOR + popcount.
 //
-// The reference builds a row -> right-keypoint table and scans one row's list per left
-// keypoint.  Membership of right keypoint iR in row `r` is the pure predicate
-// minr(iR) <= r <= maxr(iR), and the scan keeps the FIRST minimum in iR order, i.e. the
-// lexicographic minimum of (distance, iR).  So one wavefront per left keypoint sweeps all
-// right keypoints (64 per step), applies the band / octave / disparity-window predicates,
-// takes the 256-bit Hamming distance with v_bcnt, and wave-reduces min(dist << 16 | iR):
-// no table, no ordering problem, identical indices.
-// The outlier cut (:1290-1313) needs only the (ndi/2)-th order statistic of the accepted
-// distances, which a 128-bin LDS histogram gives exactly (no sort).
+// The reference builds a row -> right-keypoint table and scans one row's list per left keypoint.
+// Membership of right keypoint iR in row `r` is the pure predicate minr(iR) <= r <= maxr(iR), and
+// the scan keeps the FIRST minimum in iR order, i.e. the lexicographic minimum of (distance, iR).
+// Device form:
+//   k_stereo_bucket : one workgroup per pair counting-sorts the right keypoints by floor(y)
+//                     (LDS histogram + scan) and writes them as a compact SoA in bucket order
+//                     (x, y, octave|iR, 32-byte descriptor), so the matcher reads contiguous memory;
+//   k_stereo_match  : one wavefront per left keypoint sweeps the buckets [row-W, row+W]
+//                     (W = ceil(2*max scale)+1 covers every band that can contain `row`), applies the
+//                     exact band / octave / disparity-window predicates, takes the 256-bit Hamming
+//                     distance with v_bcnt and wave-reduces min(dist << 16 | iR);
+//   k_stereo_cut    : the outlier cut (:1290-1313) needs only the (ndi/2)-th order statistic of the
+//                     accepted distances: a 128-bin LDS histogram gives it exactly (no sort).
 #include "gfo_internal.h"
 
 #define TH_HIGH 100  // ORBmatcher.cc:57
 #define TH_LOW 50    // ORBmatcher.cc:58
 
-__device__ __forceinline__ int hamming256(const uint4 a0, const uint4 a1, const uint4* __restrict__ b)
+__device__ __forceinline__ int hamming256(const uint4 a0, const uint4 a1, const uint4 b0, const uint4 b1)
 {
-    const uint4 b0 = b[0], b1 = b[1];
     return __popc(a0.x ^ b0.x) + __popc(a0.y ^ b0.y) + __popc(a0.z ^ b0.z) + __popc(a0.w ^ b0.w) +
            __popc(a1.x ^ b1.x) + __popc(a1.y ^ b1.y) + __popc(a1.z ^ b1.z) + __popc(a1.w ^ b1.w);
 }
 
-__global__ __launch_bounds__(256) void k_stereo_match(const gfo_keypoint* __restrict__ kl_all,
-                                                      const uint8_t* __restrict__ dl_all,
-                                                      const gfo_keypoint* __restrict__ kr_all,
-                                                      const uint8_t* __restrict__ dr_all,
-                                                      const int* __restrict__ cnt_dev, int nl_host, int nr_host,
-                                                      long long pair_stride, const float* __restrict__ scale,
-                                                      gfo_stereo_params p, const float* __restrict__ min_d,
-                                                      const float* __restrict__ max_d, GfoStereoDev out,
-                                                      int out_stride)
+struct StereoArgs {
+    const gfo_keypoint* kl;
+    const uint8_t* dl;
+    const gfo_keypoint* kr;
+    const uint8_t* dr;
+    const int* cnt_dev;       // [2*pairs] (left, right) counts, or null -> host counts
+    int nl_host, nr_host;
+    long long pair_stride;    // keypoints between consecutive pairs in kl/kr (and x32 bytes in dl/dr)
+    const float* scale;
+    gfo_stereo_params p;
+    const float* min_d;
+    const float* max_d;
+    GfoStereoDev out;
+    int out_stride;
+    // bucketed right side, [pairs][sort_stride]
+    float* sx;
+    float* sy;
+    unsigned* soi;            // octave << 16 | iR
+    uint4* sdesc;             // 2 x uint4 per keypoint
+    int* row_start;           // [pairs][n_rows + 1]
+    int sort_stride;
+    int window;               // W
+};
+
+__global__ __launch_bounds__(256) void k_stereo_bucket(StereoArgs a)
+{
+    extern __shared__ int s_hist[];  // n_rows + 256
+    const int pair = blockIdx.x, tid = threadIdx.x;
+    const int nRows = a.p.n_rows;
+    int* s_part = s_hist + nRows;
+    const int nr = a.cnt_dev ? a.cnt_dev[2 * pair + 1] : a.nr_host;
+    const gfo_keypoint* kr = a.kr + pair * a.pair_stride;
+    const uint4* dr = reinterpret_cast<const uint4*>(a.dr + pair * a.pair_stride * 32);
+    for (int r = tid; r < nRows; r += 256) s_hist[r] = 0;
+    __syncthreads();
+    for (int i = tid; i < nr; i += 256) {
+        const int b = min(max((int)floorf(kr[i].y), 0), nRows - 1);
+        atomicAdd(&s_hist[b], 1);
+    }
+    __syncthreads();
+    // exclusive scan over nRows entries
+    const int chunk = (nRows + 255) / 256;
+    const int b0 = tid * chunk, e0 = min(b0 + chunk, nRows);
+    int s = 0;
+    for (int r = b0; r < e0; r++) s += s_hist[r];
+    s_part[tid] = s;
+    __syncthreads();
+    for (int off = 1; off < 256; off <<= 1) {
+        const int v = tid >= off ? s_part[tid - off] : 0;
+        __syncthreads();
+        s_part[tid] += v;
+        __syncthreads();
+    }
+    int run = s_part[tid] - s;
+    int* rs = a.row_start + (long long)pair * (nRows + 1);
+    for (int r = b0; r < e0; r++) {
+        const int v = s_hist[r];
+        rs[r] = run;
+        s_hist[r] = run;  // fill cursor
+        run += v;
+    }
+    if (tid == 255) rs[nRows] = s_part[255];
+    __syncthreads();
+    const long long so = (long long)pair * a.sort_stride;
+    for (int i = tid; i < nr; i += 256) {
+        const gfo_keypoint k = kr[i];
+        const int b = min(max((int)floorf(k.y), 0), nRows - 1);
+        const int pos = atomicAdd(&s_hist[b], 1);
+        a.sx[so + pos] = k.x;
+        a.sy[so + pos] = k.y;
+        a.soi[so + pos] = ((unsigned)k.octave << 16) | (unsigned)i;
+        a.sdesc[2 * (so + pos)] = dr[2 * i];
+        a.sdesc[2 * (so + pos) + 1] = dr[2 * i + 1];
+    }
+}
+
+__global__ __launch_bounds__(256) void k_stereo_match(StereoArgs a)
 {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int pair = blockIdx.y;
     const int iL = blockIdx.x * 4 + wave;
-    const int nl = cnt_dev ? cnt_dev[2 * pair] : nl_host;
-    const int nr = cnt_dev ? cnt_dev[2 * pair + 1] : nr_host;
+    const int nl = a.cnt_dev ? a.cnt_dev[2 * pair] : a.nl_host;
     if (iL >= nl) return;
-    const gfo_keypoint* kl = kl_all + pair * pair_stride;
-    const gfo_keypoint* kr = kr_all + pair * pair_stride;
-    const uint8_t* dl = dl_all + pair * pair_stride * 32;
-    const uint8_t* dr = dr_all + pair * pair_stride * 32;
-    const long long o = (long long)pair * out_stride + iL;
+    const gfo_keypoint* kl = a.kl + pair * a.pair_stride;
+    const uint8_t* dl = a.dl + pair * a.pair_stride * 32;
+    const long long o = (long long)pair * a.out_stride + iL;
+    const long long so = (long long)pair * a.sort_stride;
     float res_u = -1.0f, res_depth = -1.0f;
     int res_dist = -1, res_idx = -1, counted = 0;
 
     const gfo_keypoint L = kl[iL];
     const float vL = L.y, uL = L.x;
-    const int nRows = p.n_rows;
+    const int nRows = a.p.n_rows;
     if (!(vL < 0 || vL > (float)(nRows - 1))) {  // Frame.cc:1208
         const int row = (int)vL;
-        float minD = 0.f, maxD = p.mbf / p.mb;      // :1199-1200 (minZ = mb)
-        if (min_d && max_d) {                      // :1220-1231 flattened by the adapter
-            minD = min_d[iL];
-            maxD = max_d[iL];
+        float minD = 0.f, maxD = a.p.mbf / a.p.mb;  // :1199-1200 (minZ = mb)
+        if (a.min_d && a.max_d) {                  // :1220-1231 flattened by the adapter
+            minD = a.min_d[iL];
+            maxD = a.max_d[iL];
         }
         const float minU = uL - maxD, maxU = uL - minD;
         const uint4* dlp = reinterpret_cast<const uint4*>(dl + (long long)iL * 32);
         const uint4 a0 = dlp[0], a1 = dlp[1];
-        unsigned best = ((unsigned)TH_HIGH << 16);  // bestDist = TH_HIGH, strict < below
+        const int* rs = a.row_start + (long long)pair * (nRows + 1);
+        const int jb = rs[max(row - a.window, 0)], je = rs[min(row + a.window + 1, nRows)];
+        unsigned best = ((unsigned)TH_HIGH << 16);  // bestDist = TH_HIGH, iR = 0: only dist < TH_HIGH replaces it
         bool any = false;
-        for (int iR = lane; iR < nr; iR += 64) {
-            const gfo_keypoint R = kr[iR];
+        for (int j = jb + lane; j < je; j += 64) {
+            const float ry = a.sy[so + j];
+            const unsigned oi = a.soi[so + j];
+            const int oct = (int)(oi >> 16);
             // Frame.h:248-256 row band of this right keypoint
-            const float r = 2.0f * scale[R.octave];
-            const int maxr = (int)fminf((float)(nRows - 1), ceilf(R.y + r));
-            const int minr = (int)fmaxf(0.0f, floorf(R.y - r));
+            const float r = 2.0f * a.scale[oct];
+            const int maxr = (int)fminf((float)(nRows - 1), ceilf(ry + r));
+            const int minr = (int)fmaxf(0.0f, floorf(ry - r));
             if (row < minr || row > maxr) continue;
             any = true;
-            if (R.octave < L.octave - 1 || R.octave > L.octave + 1) continue;  // :1250
-            if (R.x >= minU && R.x <= maxU) {                                  // :1255
-                const unsigned dist = (unsigned)hamming256(a0, a1, reinterpret_cast<const uint4*>(dr + (long long)iR * 32));
-                const unsigned cand = (dist << 16) | (unsigned)iR;
-                if (dist < (best >> 16) || cand < best) best = min(best, cand);
+            if (oct < L.octave - 1 || oct > L.octave + 1) continue;  // :1250
+            const float rx = a.sx[so + j];
+            if (rx >= minU && rx <= maxU) {                          // :1255
+                const unsigned dist = (unsigned)hamming256(a0, a1, a.sdesc[2 * (so + j)], a.sdesc[2 * (so + j) + 1]);
+                best = min(best, (dist << 16) | (oi & 0xFFFF));      // first minimum in iR order (:1260)
             }
         }
-        // NOTE: `cand < best` alone is the rule (lexicographic (dist, iR)); the initial best carries iR = 0
-        // with dist = TH_HIGH, and only dist < TH_HIGH may replace it, which the first clause guarantees.
         const bool have_cands = __any(any);
-        if (have_cands && !(maxU < p.min_x)) {  // :1213, :1236
+        if (have_cands && !(maxU < a.p.min_x)) {  // :1213, :1236
             counted = 1;
 #pragma unroll
             for (int s = 32; s > 0; s >>= 1) best = min(best, (unsigned)__shfl_xor((int)best, s));
             const int bestDist = (int)(best >> 16);
             const int bestIdxR = (int)(best & 0xFFFF);
             if (bestDist < (TH_HIGH + TH_LOW) / 2) {  // :1269
-                float bestuR = kr[bestIdxR].x;
+                float bestuR = (a.kr + pair * a.pair_stride)[bestIdxR].x;
                 float disparity = uL - bestuR;
                 if (disparity >= minD && disparity < maxD) {
                     if (disparity <= 0) {
                         disparity = 0.01f;
                         bestuR = uL - 0.01f;
                     }
-                    res_depth = p.mbf / disparity;
+                    res_depth = a.p.mbf / disparity;
                     res_u = bestuR;
                     res_dist = bestDist;
                     res_idx = bestIdxR;
@@ -103,11 +174,11 @@ __global__ __launch_bounds__(256) void k_stereo_match(const gfo_keypoint* __rest
         }
     }
     if (lane == 0) {
-        out.u_right[o] = res_u;
-        out.depth[o] = res_depth;
-        out.best_dist[o] = res_dist;
-        out.best_idx[o] = res_idx;
-        if (counted) atomicAdd(&out.nmatched[pair], 1);
+        a.out.u_right[o] = res_u;
+        a.out.depth[o] = res_depth;
+        a.out.best_dist[o] = res_dist;
+        a.out.best_idx[o] = res_idx;
+        a.out.counted[o] = (unsigned char)counted;  // summed per pair by k_stereo_cut (no same-line atomics)
     }
 }
 
@@ -115,17 +186,20 @@ __global__ __launch_bounds__(256) void k_stereo_cut(const int* __restrict__ cnt_
                                                     int out_stride)
 {
     __shared__ int hist[128];
-    __shared__ int s_med, s_drop;
+    __shared__ int s_med, s_drop, s_cnt;
     const int pair = blockIdx.x, tid = threadIdx.x;
     const int nl = cnt_dev ? cnt_dev[2 * pair] : nl_host;
     const long long o = (long long)pair * out_stride;
     if (tid < 128) hist[tid] = 0;
-    if (tid == 0) s_drop = 0;
+    if (tid == 0) s_drop = 0, s_cnt = 0;
     __syncthreads();
+    int mine = 0;
     for (int i = tid; i < nl; i += 256) {
         const int d = out.best_dist[o + i];
         if (d >= 0) atomicAdd(&hist[d], 1);
+        mine += out.counted[o + i];
     }
+    if (mine) atomicAdd(&s_cnt, mine);
     __syncthreads();
     if (tid == 0) {
         int ndi = 0;
@@ -141,7 +215,10 @@ __global__ __launch_bounds__(256) void k_stereo_cut(const int* __restrict__ cnt_
         s_med = med;
     }
     __syncthreads();
-    if (s_med < 0) return;
+    if (s_med < 0) {
+        if (tid == 0) out.nmatched[pair] = s_cnt;
+        return;
+    }
     const float thDist = 1.5f * 1.4f * (float)s_med;  // :1298
     int drop = 0;
     for (int i = tid; i < nl; i += 256) {
@@ -154,24 +231,43 @@ __global__ __launch_bounds__(256) void k_stereo_cut(const int* __restrict__ cnt_
     }
     if (drop) atomicAdd(&s_drop, drop);
     __syncthreads();
-    if (tid == 0 && s_drop) out.nmatched[pair] -= s_drop;
+    if (tid == 0) out.nmatched[pair] = s_cnt - s_drop;
 }
 
-void gfo_launch_stereo(gfo_ctx* c, const gfo_keypoint* kl, const uint8_t* dl, const int* cnt_dev, int nl_host,
-                       const gfo_keypoint* kr, const uint8_t* dr, const int* /*unused*/, int nr_host,
-                       long long pair_stride_kp, int npairs, const float* d_scale, const gfo_stereo_params& p,
-                       const float* min_d, const float* max_d, GfoStereoDev out, int out_stride)
+int gfo_stereo_window(const float* scale, int nlevels)
 {
-    (void)hipMemsetAsync(out.nmatched, 0, sizeof(int) * npairs, c->stream);
-    const int max_nl = cnt_dev ? out_stride : nl_host;
-    if (max_nl > 0) {
-        dim3 grid((max_nl + 3) / 4, npairs);
-        gfo_prof_begin(c, ST_STEREO);
-        hipLaunchKernelGGL(k_stereo_match, grid, dim3(256), 0, c->stream, kl, dl, kr, dr, cnt_dev, nl_host, nr_host,
-                           pair_stride_kp, d_scale, p, min_d, max_d, out, out_stride);
-        gfo_prof_end(c);
-        gfo_prof_begin(c, ST_STEREO_CUT);
-        hipLaunchKernelGGL(k_stereo_cut, dim3(npairs), dim3(256), 0, c->stream, cnt_dev, nl_host, out, out_stride);
-        gfo_prof_end(c);
+    float mx = 0.f;
+    for (int l = 0; l < nlevels; l++) mx = scale[l] > mx ? scale[l] : mx;
+    return (int)ceilf(2.0f * mx) + 1;
+}
+
+void gfo_launch_stereo(gfo_ctx* c, const GfoStereoLaunch& s)
+{
+    StereoArgs a{};
+    a.kl = s.kl; a.dl = s.dl; a.kr = s.kr; a.dr = s.dr;
+    a.cnt_dev = s.cnt_dev; a.nl_host = s.nl_host; a.nr_host = s.nr_host;
+    a.pair_stride = s.pair_stride_kp;
+    a.scale = s.d_scale;
+    a.p = s.p;
+    a.min_d = s.min_d; a.max_d = s.max_d;
+    a.out = s.out; a.out_stride = s.out_stride;
+    a.sx = s.sort.sx; a.sy = s.sort.sy; a.soi = s.sort.soi; a.sdesc = reinterpret_cast<uint4*>(s.sort.sdesc);
+    a.row_start = s.sort.row_start;
+    a.sort_stride = s.sort_stride;
+    a.window = s.window;
+    const int max_nl = s.cnt_dev ? s.out_stride : s.nl_host;
+    if (max_nl <= 0) {
+        (void)hipMemsetAsync(s.out.nmatched, 0, sizeof(int) * s.npairs, c->stream);
+        return;
     }
+    gfo_prof_begin(c, ST_STEREO_BUCKET);
+    hipLaunchKernelGGL(k_stereo_bucket, dim3(s.npairs), dim3(256), (size_t)(s.p.n_rows + 256) * sizeof(int), c->stream, a);
+    gfo_prof_end(c);
+    dim3 grid((max_nl + 3) / 4, s.npairs);
+    gfo_prof_begin(c, ST_STEREO);
+    hipLaunchKernelGGL(k_stereo_match, grid, dim3(256), 0, c->stream, a);
+    gfo_prof_end(c);
+    gfo_prof_begin(c, ST_STEREO_CUT);
+    hipLaunchKernelGGL(k_stereo_cut, dim3(s.npairs), dim3(256), 0, c->stream, s.cnt_dev, s.nl_host, s.out, s.out_stride);
+    gfo_prof_end(c);
 }
