@@ -235,7 +235,8 @@ static int plan(gfo_ctx* c, int w, int h, int batch)
     g.total_tiles = tile_base;
     g.total_sel_cap = sel_off;
     g.kp_stride = (int)align_up(sel_off, 4);
-    g.fast_tile_pitch = (int)align_up(max_cw, 4);
+    g.fast_tile_pitch = (int)align_up(max_cw + 3, 4);   // +3: tile rows start at the aligned dword left of the cell
+    g.fast_npx_max = (int)align_up((long long)(max_cw - 6) * (max_ch - 6), 8);
     g.fast_tile_rows = max_ch;
     g.fast_smap_pitch = (int)align_up(max_cw - 6 + 2, 4);
     g.fast_smap_rows = max_ch - 6 + 2;
@@ -258,7 +259,7 @@ static int plan(gfo_ctx* c, int w, int h, int batch)
     HIP_TRY(c, hipMalloc(&c->d_blur, B * (size_t)g.blur_img_stride));
     HIP_TRY(c, hipMalloc(&c->d_cand, B * (size_t)(g.cand_img_stride + 64) * sizeof(uint32_t)));
     HIP_TRY(c, hipMalloc(&c->d_node_of, B * (size_t)(g.cand_img_stride + 64) * sizeof(uint16_t)));
-    HIP_TRY(c, hipMalloc(&c->d_cand_cnt, B * g.nlevels * sizeof(int)));
+    HIP_TRY(c, hipMalloc(&c->d_cand_cnt, B * g.nlevels * GFO_CNT_STRIDE * sizeof(int)));
     HIP_TRY(c, hipMalloc(&c->d_sel, B * (size_t)g.total_sel_cap * sizeof(uint32_t)));
     HIP_TRY(c, hipMalloc(&c->d_sel_cnt, B * g.nlevels * sizeof(int)));
     HIP_TRY(c, hipMalloc(&c->d_kp, B * (size_t)g.kp_stride * sizeof(gfo_keypoint)));
@@ -399,7 +400,7 @@ static int run_pyramid(gfo_ctx* c, const GfoInput& in, int nimg)
 
 static int run_extract(gfo_ctx* c, const GfoInput& in, int nimg)
 {
-    HIP_TRY(c, hipMemsetAsync(c->d_cand_cnt, 0, sizeof(int) * nimg * c->g.nlevels, c->stream));
+    HIP_TRY(c, hipMemsetAsync(c->d_cand_cnt, 0, sizeof(int) * nimg * c->g.nlevels * GFO_CNT_STRIDE, c->stream));
     run_pyramid(c, in, nimg);
     gfo_launch_blur(c, in, nimg);
     gfo_launch_fast(c, in, nimg);
@@ -785,7 +786,7 @@ extern "C" int gfo_debug_level_candidates(gfo_ctx* c, int image, int level, int3
     if (image < 0 || image >= c->last_nimg || level < 0 || level >= c->g.nlevels) return fail(c, GFO_ERR_INVALID, "out of range");
     const GfoLevel& L = c->g.lv[level];
     int cnt = 0;
-    HIP_TRY(c, hipMemcpyAsync(&cnt, c->d_cand_cnt + image * c->g.nlevels + level, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(&cnt, c->d_cand_cnt + (image * c->g.nlevels + level) * GFO_CNT_STRIDE, sizeof(int), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     if (cnt > L.cand_cap) cnt = L.cand_cap;
     *n = cnt;

@@ -14,6 +14,8 @@
 #define GFO_PATCH 31         // PATCH_SIZE, ORBextractor.cc:72
 #define GFO_MIN_BORDER 16    // EDGE_THRESHOLD-3, ORBextractor.cc:775
 #define GFO_CELL_W 30        // W, ORBextractor.cc:771
+#define GFO_CNT_STRIDE 32     // ints between per-(image,level) candidate counters: one 128-B line each,
+                             // so the per-cell atomicAdds of different levels/images never share a line
 
 // Geometry of one pyramid level, shared by host planning and every kernel (passed by value).
 struct GfoLevel {
@@ -51,6 +53,7 @@ struct GfoGeom {
     int kp_stride;            // per image output capacity (>= total_sel_cap)
     int ini_th, min_th;
     int fast_tile_pitch, fast_tile_rows, fast_smap_pitch, fast_smap_rows; // LDS plan per wave
+    int fast_npx_max;         // largest scan area of a cell (queue capacity), multiple of 8
     long long pyr_img_stride;   // bytes per image of levels 1..L-1
     long long blur_img_stride;  // bytes per image of blurred levels 0..L-1
     long long cand_img_stride;  // u32 elements per image

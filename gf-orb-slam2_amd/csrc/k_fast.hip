@@ -3,29 +3,42 @@
 // cv::FAST / FAST_t<16> (in-tree mirror: FAST_NEON.cc:91-287).
 //
 // One wavefront owns one 30-px cell (+6 px overlap, +3 px ring halo): the cell's pixels are
-// staged in LDS once, every lane scores its share of the scan area, and the cell-local
-// 3x3 suppression and the "retry with minThFAST when the cell came up empty" decision are
-// wave-uniform (ballot / popcount), so no workgroup-wide state is needed.  Four cells per
-// 256-thread workgroup; all levels of all images are ONE launch.
-//
-// Score map S: S(p) = max over the 16 nine-pixel arcs of min |v - ring| with a common sign,
-// i.e. the largest t for which p is still a FAST corner, plus one.  It does not depend on the
-// threshold, so  corner(t) <=> S > t  and  cornerScore = S - 1  (FAST_NEON.cc:231,
-// Fast_gpu.cu:196-219).  Because suppressed-by relations only involve pixels with S >= S(p),
-// the reference's "compare against the score buffer of corners at threshold t" reduces to
-// "strict local maximum of S inside the cell's scan area, and S > t" (FAST).
+// staged in LDS once (aligned dword loads) and the wave runs a filter cascade with WAVE-LEVEL
+// COMPACTION between the stages, so the expensive stages run with all 64 lanes busy:
+//   A  every pixel      : compass test -- any 9-arc of the 16-ring holds >= 2 of the ring pixels
+//                         {0,4,8,12}, so a corner needs two of them beyond the threshold (5 LDS reads)
+//   B1 survivors of A   : OpenCV's opposite-pair test on the full ring (FAST_NEON.cc:205-225 mirror)
+//   B2 survivors of B1  : the score S = max over the sixteen 9-arcs of min |v - ring| (common sign)
+//   N  survivors of B1  : strict 3x3 local maximum of S inside the cell's scan area
+//   E  maxima           : append (x, y, S-1) for S > iniThFAST, or S > minThFAST when the cell
+//                         produced nothing at iniThFAST (ORBextractor.cc:811-818)
+// S does not depend on the threshold (corner(t) <=> S > t, cornerScore = S - 1: FAST_NEON.cc:231,
+// Fast_gpu.cu:196-219), and a neighbour can suppress a corner only if its S is >= the corner's,
+// so "compare against the score buffer of corners at threshold t" (FAST_NEON.cc:268-285) is
+// "strict local maximum of S" -- one suppression pass serves both thresholds (FAST).
+// Four cells per 256-thread workgroup; all levels of all images are ONE launch.
 //
 // Candidates are appended to the level's list with one atomicAdd per cell; their order in
 // memory is unspecified.  The order the reference hands to DistributeOctTree (cell-major,
 // row-major inside a cell) matters only as a tie-break on equal response, and it is a pure
 // function of (x, y) that the quadtree kernel recomputes.
 #include "gfo_internal.h"
+#include <stdlib.h>
 
-__device__ __forceinline__ int fast_score16(const uint8_t* __restrict__ c, int tp, int tq)
+// Each wave owns its LDS region and LDS operations of one wave execute in issue order, so a
+// compiler-level fence is all that is needed between phases (no workgroup barrier: waves of a
+// workgroup run their cells independently and may exit early).
+__device__ __forceinline__ void wave_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+__device__ __forceinline__ void ring_diffs(const uint8_t* __restrict__ c, int tp, int* d)
 {
     // ring in the order of FAST_NEON.cc:3-7
     const int v = c[0];
-    int d[16];
     d[0] = v - c[3 * tp];
     d[1] = v - c[3 * tp + 1];
     d[2] = v - c[2 * tp + 2];
@@ -42,40 +55,69 @@ __device__ __forceinline__ int fast_score16(const uint8_t* __restrict__ c, int t
     d[13] = v - c[tp - 3];
     d[14] = v - c[2 * tp - 2];
     d[15] = v - c[3 * tp - 1];
-    // necessary condition for S > tq: every opposite pair holds a pixel beyond the threshold
-    bool dark = true, bright = true;
+}
+
+// OpenCV's opposite-pair prefilter (necessary for S > tq): every opposite pair must hold a pixel
+// beyond the threshold.  min_k max(d_k, d_k+8) > tq  <=> dark side possible;  max_k min(...) < -tq
+// <=> bright side possible.  Returns bit0 = dark, bit1 = bright.
+__device__ __forceinline__ int pair_test(const uint8_t* __restrict__ c, int tp, int tq)
+{
+    int d[16];
+    ring_diffs(c, tp, d);
+    int mn = 255, mx = -255;
 #pragma unroll
     for (int k = 0; k < 8; k++) {
-        dark = dark && (d[k] > tq || d[k + 8] > tq);
-        bright = bright && (d[k] < -tq || d[k + 8] < -tq);
+        mn = min(mn, max(d[k], d[k + 8]));
+        mx = max(mx, min(d[k], d[k + 8]));
     }
-    if (!dark && !bright) return 0;
-    int lo2[16], hi2[16], lo4[16], hi4[16];
+    return (mn > tq ? 1 : 0) | (mx < -tq ? 2 : 0);
+}
+
+typedef short __attribute__((ext_vector_type(2))) s16x2;
+__device__ __forceinline__ unsigned pmin(unsigned a, unsigned b)
+{
+    return __builtin_bit_cast(unsigned, __builtin_elementwise_min(__builtin_bit_cast(s16x2, a), __builtin_bit_cast(s16x2, b)));
+}
+__device__ __forceinline__ unsigned pmax(unsigned a, unsigned b)
+{
+    return __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(s16x2, a), __builtin_bit_cast(s16x2, b)));
+}
+__device__ __forceinline__ unsigned rot16(unsigned a) { return __builtin_amdgcn_alignbit(a, a, 16); }
+
+// max over the sixteen 9-arcs of min(sign * d) for one polarity (sign = +1 dark, -1 bright), two ring
+// positions (k, k+8) per register in packed i16: the arc minima for k and k+8 come out of one op.
+__device__ __forceinline__ int arc_score(const uint8_t* __restrict__ c, int tp, bool bright)
+{
+    int d[16];
+    ring_diffs(c, tp, d);
+    const int m = bright ? -1 : 0;
+    unsigned P[8], R[8];
 #pragma unroll
-    for (int k = 0; k < 16; k++) {
-        lo2[k] = min(d[k], d[(k + 1) & 15]);
-        hi2[k] = max(d[k], d[(k + 1) & 15]);
+    for (int k = 0; k < 8; k++) {
+        const int lo = (d[k] ^ m) - m, hi = (d[k + 8] ^ m) - m;  // conditional negate
+        P[k] = ((unsigned)lo & 0xFFFFu) | ((unsigned)hi << 16);
+        R[k] = rot16(P[k]);  // = packed (d[k+8], d[k]) : ring positions k+8 .. k+15
     }
+    unsigned X2[10], X4[12];
 #pragma unroll
-    for (int k = 0; k < 16; k++) {
-        lo4[k] = min(lo2[k], lo2[(k + 2) & 15]);
-        hi4[k] = max(hi2[k], hi2[(k + 2) & 15]);
-    }
-    int a = -255, b = 255;
+    for (int k = 0; k < 7; k++) X2[k] = pmin(P[k], P[k + 1]);
+    X2[7] = pmin(P[7], R[0]);
+    X2[8] = rot16(X2[0]);
+    X2[9] = rot16(X2[1]);
 #pragma unroll
-    for (int k = 0; k < 16; k++) {
-        const int lo9 = min(min(lo4[k], lo4[(k + 4) & 15]), d[(k + 8) & 15]);
-        const int hi9 = max(max(hi4[k], hi4[(k + 4) & 15]), d[(k + 8) & 15]);
-        a = max(a, lo9);
-        b = min(b, hi9);
-    }
-    const int s = max(a, -b);
-    return s > tq ? s : 0;
+    for (int k = 0; k < 8; k++) X4[k] = pmin(X2[k], X2[k + 2]);
+#pragma unroll
+    for (int k = 0; k < 4; k++) X4[8 + k] = rot16(X4[k]);
+    unsigned best = 0x80008000u;  // (-32768, -32768)
+#pragma unroll
+    for (int k = 0; k < 8; k++) best = pmax(best, pmin(pmin(X4[k], X4[k + 4]), R[k]));
+    const int b0 = (int)(short)(best & 0xFFFF), b1 = (int)(short)(best >> 16);
+    return max(b0, b1);
 }
 
 __global__ __launch_bounds__(256) void k_fast(const GfoGeom* __restrict__ gp, GfoInput in,
                                               const uint8_t* __restrict__ pyr, uint32_t* __restrict__ cand,
-                                              int* __restrict__ cand_cnt, int* __restrict__ flags)
+                                              int* __restrict__ cand_cnt, int* __restrict__ flags, int dbg_stop)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     const GfoGeom& g = *gp;
@@ -84,80 +126,151 @@ __global__ __launch_bounds__(256) void k_fast(const GfoGeom* __restrict__ gp, Gf
     const int cell = blockIdx.x * 4 + wave;
     const int TP = g.fast_tile_pitch, SP = g.fast_smap_pitch;
     const int tile_bytes = TP * g.fast_tile_rows, smap_bytes = SP * g.fast_smap_rows;
-    uint8_t* tile = lds + wave * (tile_bytes + smap_bytes);
+    const int per_wave = tile_bytes + smap_bytes + 2 * g.fast_npx_max;  // one u16 queue, compacted in place
+    uint8_t* tile = lds + wave * per_wave;
     uint8_t* smap = tile + tile_bytes;
+    unsigned short* qa = reinterpret_cast<unsigned short*>(smap + smap_bytes);
+    unsigned short* qb = qa;  // stage B1 writes entry j <= i after reading entry i (same wave, in order)
 
-    bool active = cell < g.total_cells;
-    int level = 0, cw = 0, ch = 0, sw = 0, sh = 0, ci = 0, cj = 0;
-    if (active) {
-        while (level + 1 < g.nlevels && cell >= g.lv[level + 1].cell_base) level++;
-    }
+    if (cell >= g.total_cells) return;
+    int level = 0;
+    while (level + 1 < g.nlevels && cell >= g.lv[level + 1].cell_base) level++;
     const GfoLevel& L = g.lv[level];
-    if (active) {
-        const int cidx = cell - L.cell_base;
-        ci = cidx / L.ncols;
-        cj = cidx - ci * L.ncols;
-        const int iniX = GFO_MIN_BORDER + cj * L.wcell, iniY = GFO_MIN_BORDER + ci * L.hcell;
-        const int maxX = min(iniX + L.wcell + 6, L.max_bx), maxY = min(iniY + L.hcell + 6, L.max_by);
-        if (iniY >= L.max_by - 3 || iniX >= L.max_bx - 6) active = false;  // ORBextractor.cc:796,805
-        cw = maxX - iniX;
-        ch = maxY - iniY;
-        sw = cw - 6;
-        sh = ch - 6;
-        if (sw <= 0 || sh <= 0) active = false;
-        if (active) {
-            int pitch;
-            const uint8_t* src = gfo_level_ptr(g, in, pyr, level, img, &pitch);
-            src += (long long)iniY * pitch + iniX;
-            const float inv_cw = 1.0f / (float)cw;
-            for (int t = lane; t < cw * ch; t += 64) {
-                const int r = (int)(((float)t + 0.5f) * inv_cw);
-                const int c = t - r * cw;
-                tile[r * TP + c] = src[(long long)r * pitch + c];
+    const int wcell = L.wcell, hcell = L.hcell;
+    const int cidx = cell - L.cell_base;
+    const int ci = cidx / L.ncols;
+    const int cj = cidx - ci * L.ncols;
+    const int iniX = GFO_MIN_BORDER + cj * wcell, iniY = GFO_MIN_BORDER + ci * hcell;
+    const int maxX = min(iniX + wcell + 6, L.max_bx), maxY = min(iniY + hcell + 6, L.max_by);
+    if (iniY >= L.max_by - 3 || iniX >= L.max_bx - 6) return;  // ORBextractor.cc:796,805
+    const int cw = maxX - iniX, ch = maxY - iniY;
+    const int sw = cw - 6, sh = ch - 6;
+    if (sw <= 0 || sh <= 0) return;
+    const int x_al = iniX & ~3;
+    const int xoff = iniX - x_al;
+    {
+        int pitch;
+        const uint8_t* src = gfo_level_ptr(g, in, pyr, level, img, &pitch);
+        src += (long long)iniY * pitch + x_al;
+        const int dpr = (xoff + cw + 3) >> 2;  // dwords per tile row
+        const float inv_dpr = 1.0f / (float)dpr;
+        uint32_t* t32 = reinterpret_cast<uint32_t*>(tile);
+        const int tp4 = TP >> 2;
+        const int ndw = dpr * ch;
+        // all global loads of a chunk are in flight before the first LDS store
+        for (int b = 0; b < ndw; b += 64 * 8) {
+            uint32_t v[8];
+            int dst[8];
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                const int t = b + k * 64 + lane;
+                const int tt = min(t, ndw - 1);
+                const int r = (int)(((float)tt + 0.5f) * inv_dpr);
+                const int c = tt - r * dpr;
+                dst[k] = t < ndw ? r * tp4 + c : -1;
+                v[k] = *reinterpret_cast<const uint32_t*>(src + (long long)r * pitch + 4 * c);
             }
-            uint32_t* sm32 = reinterpret_cast<uint32_t*>(smap);
-            for (int t = lane; t < ((sh + 2) * SP) / 4; t += 64) sm32[t] = 0;
+#pragma unroll
+            for (int k = 0; k < 8; k++)
+                if (dst[k] >= 0) t32[dst[k]] = v[k];
         }
+        uint32_t* sm32 = reinterpret_cast<uint32_t*>(smap);
+        for (int t = lane; t < ((sh + 2) * SP) >> 2; t += 64) sm32[t] = 0;
     }
-    __syncthreads();
+    wave_sync();
+    if (dbg_stop == 1) return;
     const int tq = min(g.ini_th, g.min_th);
     const int npx = sw * sh;
-    const float inv_sw = active ? 1.0f / (float)sw : 0.f;
-    if (active) {
-        for (int p = lane; p < npx; p += 64) {
-            const int py = (int)(((float)p + 0.5f) * inv_sw);
-            const int px = p - py * sw;
-            const int s = fast_score16(tile + (py + 3) * TP + px + 3, TP, tq);
-            smap[(py + 1) * SP + px + 1] = (uint8_t)s;
+    const float inv_sw = 1.0f / (float)sw;
+    const uint8_t* t0 = tile + 3 * TP + xoff + 3;  // scan pixel (0,0)
+    // ---- A: compass test over every scan pixel, compacted into qa ----
+    // lanes map to (row, column) directly: two rows of up to 32 columns per step, or one of up to 64
+    int na = 0;
+    {
+        const int lsh = sw <= 32 ? 5 : 6;
+        const int rows_per = 64 >> lsh;
+        const int lx = lane & ((1 << lsh) - 1), ly = lane >> lsh;
+        for (int y0 = 0; y0 < sh; y0 += rows_per) {
+            const int py = y0 + ly;
+            bool pass = false;
+            if (lx < sw && py < sh) {
+                const uint8_t* c = t0 + py * TP + lx;
+                const int v = c[0];
+                const int a = v - c[3 * TP], b = v - c[3], e = v - c[-3 * TP], f = v - c[-3];
+                // second largest / second smallest of the four differences
+                const int mxab = max(a, b), mnab = min(a, b), mxef = max(e, f), mnef = min(e, f);
+                const int second_hi = max(min(mxab, mxef), max(mnab, mnef));
+                const int second_lo = min(max(mnab, mnef), min(mxab, mxef));
+                pass = second_hi > tq || second_lo < -tq;
+            }
+            const unsigned long long m = __ballot(pass);
+            if (pass) qa[na + __popcll(m & ((1ull << lane) - 1))] = (unsigned short)(py * sw + lx);
+            na += __popcll(m);
         }
     }
-    __syncthreads();
-    if (!active) return;
-    // strict local maxima of S; per-lane bitmask over this lane's pixels (<= 64 iterations)
-    unsigned long long ismax = 0;
+    wave_sync();
+    if (dbg_stop == 2) { if (na == 12345) flags[1] = 1; return; }
+    // ---- B1: opposite-pair test on the survivors, compacted into qb ----
+    int nb = 0;
+    {
+        for (int i0 = 0; i0 < na; i0 += 64) {
+            const int i = i0 + lane;
+            int pol = 0;
+            int p = 0;
+            if (i < na) {
+                p = qa[i];
+                const int py = (int)(((float)p + 0.5f) * inv_sw);
+                const int px = p - py * sw;
+                pol = pair_test(t0 + py * TP + px, TP, tq);
+            }
+            const bool pass = pol != 0;
+            const unsigned long long m = __ballot(pass);
+            if (pass) qb[nb + __popcll(m & ((1ull << lane) - 1))] = (unsigned short)(p | (pol << 13));  // bits 13,14 = polarity
+            nb += __popcll(m);
+        }
+    }
+    wave_sync();
+    if (dbg_stop == 3) { if (nb == 12345) flags[1] = 1; return; }
+    // ---- B2: score of the survivors into the cell's score map ----
+    {
+        for (int i = lane; i < nb; i += 64) {
+            const int e = qb[i];
+            const int p = e & 0x1FFF;
+            const int py = (int)(((float)p + 0.5f) * inv_sw);
+            const int px = p - py * sw;
+            const uint8_t* c = t0 + py * TP + px;
+            int s = arc_score(c, TP, (e & 0x2000) == 0);           // one polarity per lane ...
+            if ((e & 0x6000) == 0x6000) s = max(s, arc_score(c, TP, false));  // ... both only when both prefilters passed (rare)
+            smap[(py + 1) * SP + px + 1] = (uint8_t)(s > tq ? s : 0);
+        }
+    }
+    wave_sync();
+    if (dbg_stop == 4) return;
+    // ---- N: strict local maxima of S (flag kept in bit 15 of the queue entry) ----
     int n_ini = 0, n_min = 0;
-    int it = 0;
-    for (int p0 = 0; p0 < npx; p0 += 64, it++) {
-        const int p = p0 + lane;
+    for (int i0 = 0; i0 < nb; i0 += 64) {
+        const int i = i0 + lane;
         bool mx = false;
         int s = 0;
-        if (p < npx) {
+        if (i < nb) {
+            const int p = qb[i] & 0x1FFF;
             const int py = (int)(((float)p + 0.5f) * inv_sw);
             const int px = p - py * sw;
             const uint8_t* q = smap + (py + 1) * SP + px + 1;
             s = q[0];
             mx = s >= 2 && s > q[-1] && s > q[1] && s > q[-SP - 1] && s > q[-SP] && s > q[-SP + 1] &&
                  s > q[SP - 1] && s > q[SP] && s > q[SP + 1];
+            if (mx) qb[i] = (unsigned short)(p | 0x8000);  // bit 15 = local maximum
         }
-        if (mx) ismax |= 1ull << it;
         n_ini += __popcll(__ballot(mx && s > g.ini_th));
         n_min += __popcll(__ballot(mx && s > g.min_th));
     }
+    wave_sync();
     const int th = n_ini > 0 ? g.ini_th : g.min_th;  // ORBextractor.cc:811-818
     const int total = n_ini > 0 ? n_ini : n_min;
     if (total == 0) return;
     int base = 0;
-    int* cnt = cand_cnt + img * g.nlevels + level;
+    int* cnt = cand_cnt + (img * g.nlevels + level) * GFO_CNT_STRIDE;
     if (lane == 0) base = atomicAdd(cnt, total);
     base = __shfl(base, 0);
     if (base + total > L.cand_cap) {
@@ -166,19 +279,22 @@ __global__ __launch_bounds__(256) void k_fast(const GfoGeom* __restrict__ gp, Gf
     }
     uint32_t* out = cand + (long long)img * g.cand_img_stride + L.cand_off + base;
     int run = 0;
-    it = 0;
-    for (int p0 = 0; p0 < npx; p0 += 64, it++) {
-        const int p = p0 + lane;
+    for (int i0 = 0; i0 < nb; i0 += 64) {
+        const int i = i0 + lane;
         bool emit = false;
         uint32_t key = 0;
-        if (p < npx && ((ismax >> it) & 1)) {
-            const int py = (int)(((float)p + 0.5f) * inv_sw);
-            const int px = p - py * sw;
-            const int s = smap[(py + 1) * SP + px + 1];
-            if (s > th) {
-                emit = true;
-                const int x = px + 3 + cj * L.wcell, y = py + 3 + ci * L.hcell;  // ORBextractor.cc:824-825
-                key = (uint32_t)x | ((uint32_t)y << 12) | ((uint32_t)(s - 1) << 24);
+        if (i < nb) {
+            const int e = qb[i];
+            if (e & 0x8000) {
+                const int p = e & 0x1FFF;
+                const int py = (int)(((float)p + 0.5f) * inv_sw);
+                const int px = p - py * sw;
+                const int s = smap[(py + 1) * SP + px + 1];
+                if (s > th) {
+                    emit = true;
+                    const int x = px + 3 + cj * wcell, y = py + 3 + ci * hcell;  // ORBextractor.cc:824-825
+                    key = (uint32_t)x | ((uint32_t)y << 12) | ((uint32_t)(s - 1) << 24);
+                }
             }
         }
         const unsigned long long m = __ballot(emit);
@@ -190,10 +306,11 @@ __global__ __launch_bounds__(256) void k_fast(const GfoGeom* __restrict__ gp, Gf
 void gfo_launch_fast(gfo_ctx* c, const GfoInput& in, int nimg)
 {
     const GfoGeom& g = c->g;
-    const size_t lds = 4 * (size_t)(g.fast_tile_pitch * g.fast_tile_rows + g.fast_smap_pitch * g.fast_smap_rows);
+    const size_t lds = 4 * (size_t)(g.fast_tile_pitch * g.fast_tile_rows + g.fast_smap_pitch * g.fast_smap_rows + 2 * g.fast_npx_max);
     dim3 grid((g.total_cells + 3) / 4, nimg);
     gfo_prof_begin(c, ST_FAST);
+    static const int dbg_stop = getenv("GFO_FAST_STOP") ? atoi(getenv("GFO_FAST_STOP")) : 0;  // timing experiments only
     hipLaunchKernelGGL(k_fast, grid, dim3(256), lds, c->stream, c->d_geom, in, c->d_pyr, c->d_cand, c->d_cand_cnt,
-                       c->d_flags);
+                       c->d_flags, dbg_stop);
     gfo_prof_end(c);
 }

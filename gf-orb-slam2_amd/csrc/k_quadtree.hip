@@ -84,7 +84,7 @@ __global__ __launch_bounds__(QT_THREADS) void k_quadtree(const GfoGeom* __restri
     const int level = blockIdx.x, img = blockIdx.y, tid = threadIdx.x;
     const GfoLevel& L = g.lv[level];
     const int N = L.quota;
-    const int K = min(cand_cnt[img * g.nlevels + level], L.cand_cap);
+    const int K = min(cand_cnt[(img * g.nlevels + level) * GFO_CNT_STRIDE], L.cand_cap);
     const uint32_t* keys = cand + (long long)img * g.cand_img_stride + L.cand_off;
     uint16_t* node_of = node_of_all + (long long)img * g.cand_img_stride + L.cand_off;
     int* out_cnt = sel_cnt + img * g.nlevels + level;
