@@ -255,8 +255,8 @@ static int plan(gfo_ctx* c, int w, int h, int batch)
     const size_t B = (size_t)batch;
     HIP_TRY(c, hipMalloc(&c->d_geom, sizeof(GfoGeom)));
     HIP_TRY(c, hipMalloc(&c->d_input, B * g.lv[0].pitch * (size_t)h));
-    HIP_TRY(c, hipMalloc(&c->d_pyr, B * (size_t)(g.pyr_img_stride > 0 ? g.pyr_img_stride : 256)));
-    HIP_TRY(c, hipMalloc(&c->d_blur, B * (size_t)g.blur_img_stride));
+    HIP_TRY(c, hipMalloc(&c->d_pyr, B * (size_t)(g.pyr_img_stride > 0 ? g.pyr_img_stride : 256) + 256));
+    HIP_TRY(c, hipMalloc(&c->d_blur, B * (size_t)g.blur_img_stride + 256));  // +256: window staging may read 3 B past a row end
     HIP_TRY(c, hipMalloc(&c->d_cand, B * (size_t)(g.cand_img_stride + 64) * sizeof(uint32_t)));
     HIP_TRY(c, hipMalloc(&c->d_node_of, B * (size_t)(g.cand_img_stride + 64) * sizeof(uint16_t)));
     HIP_TRY(c, hipMalloc(&c->d_cand_cnt, B * g.nlevels * GFO_CNT_STRIDE * sizeof(int)));

@@ -21,8 +21,34 @@ __device__ const PatQuad k_pattern[256] = {
 };
 __device__ const int k_umax[16] = {15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3};  // ORBextractor.cc:451-468
 
-#define DW 37          // descriptor window
-#define DWP 40         // LDS pitch
+#define DW 37          // descriptor window (blurred level), rows
+#define DWP 44         // its LDS pitch: 11 dwords cover 37 px + up to 3 px of alignment slack
+#define OW 31          // orientation patch (unblurred level), rows
+#define OWP 40         // its LDS pitch: 9 dwords (+1 spare)
+
+// Copies `rows` rows of `dpr` dwords from global (row pitch `pitch`) to LDS (row pitch `lpitch` bytes);
+// every lane issues all of its global loads before the first LDS store.
+template <int MAXK>
+__device__ __forceinline__ void stage_rows(const uint8_t* __restrict__ src, long long pitch, uint8_t* lds, int lpitch,
+                                           int dpr, int rows, int lane)
+{
+    const int ndw = dpr * rows;
+    const float inv = 1.0f / (float)dpr;
+    unsigned v[MAXK];
+    int dst[MAXK];
+#pragma unroll
+    for (int k = 0; k < MAXK; k++) {
+        const int t = k * 64 + lane;
+        const int tt = min(t, ndw - 1);
+        const int r = (int)(((float)tt + 0.5f) * inv);
+        const int c = tt - r * dpr;
+        dst[k] = t < ndw ? r * lpitch + 4 * c : -1;
+        v[k] = *reinterpret_cast<const unsigned*>(src + (long long)r * pitch + 4 * c);
+    }
+#pragma unroll
+    for (int k = 0; k < MAXK; k++)
+        if (dst[k] >= 0) *reinterpret_cast<unsigned*>(lds + dst[k]) = v[k];
+}
 
 __global__ __launch_bounds__(256) void k_orient_desc(const GfoGeom* __restrict__ gp, GfoInput in,
                                                      const uint8_t* __restrict__ pyr, const uint8_t* __restrict__ blur,
@@ -30,7 +56,8 @@ __global__ __launch_bounds__(256) void k_orient_desc(const GfoGeom* __restrict__
                                                      gfo_keypoint* __restrict__ kp_out, uint8_t* __restrict__ desc_out,
                                                      int* __restrict__ kp_cnt, int* __restrict__ flags)
 {
-    __shared__ uint8_t s_win[4][DW * DWP];
+    __shared__ __attribute__((aligned(16))) uint8_t s_win[4][DW * DWP];
+    __shared__ __attribute__((aligned(16))) uint8_t s_pat[4][OW * OWP];
     const GfoGeom& g = *gp;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int img = blockIdx.y;
@@ -56,10 +83,24 @@ __global__ __launch_bounds__(256) void k_orient_desc(const GfoGeom* __restrict__
     const int x = (int)(key & 0xFFF) + GFO_MIN_BORDER, y = (int)((key >> 12) & 0xFFF) + GFO_MIN_BORDER;  // :845-846
     const int score = (int)(key >> 24);
 
-    // ---- IC_Angle on the unblurred level ----
+    // ---- stage both windows (dword loads, all in flight together) ----
     int pitch;
     const uint8_t* lv = gfo_level_ptr(g, in, pyr, level, img, &pitch);
-    const uint8_t* center = lv + (long long)y * pitch + x;
+    const int ox_al = (x - GFO_HALF_PATCH) & ~3, ooff = (x - GFO_HALF_PATCH) - ox_al;
+    const int odpr = (ooff + OW + 3) >> 2;  // <= 9
+    uint8_t* pat = s_pat[wave];
+    stage_rows<5>(lv + (long long)(y - GFO_HALF_PATCH) * pitch + ox_al, pitch, pat, OWP, odpr, OW, lane);
+    const int wx_al = (x - 18) & ~3, woff = (x - 18) - wx_al;
+    const int wdpr = (woff + DW + 3) >> 2;  // <= 11
+    uint8_t* win = s_win[wave];
+    stage_rows<7>(blur + (long long)img * g.blur_img_stride + L.blur_off + (long long)(y - 18) * L.pitch + wx_al, L.pitch, win,
+                  DWP, wdpr, DW, lane);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+    // ---- IC_Angle on the unblurred patch ----
+    const uint8_t* center = pat + GFO_HALF_PATCH * OWP + ooff + GFO_HALF_PATCH;
     const int half = lane >> 5;           // 0: row +v, 1: row -v
     const int u = (lane & 31) - GFO_HALF_PATCH;
     const bool col_ok = (lane & 31) < 31;
@@ -69,7 +110,7 @@ __global__ __launch_bounds__(256) void k_orient_desc(const GfoGeom* __restrict__
     for (int v = 1; v <= GFO_HALF_PATCH; v++) {
         const int d = k_umax[v];
         if (col_ok && u >= -d && u <= d) {
-            const int val = center[(half ? -v : v) * pitch + u];
+            const int val = center[(half ? -v : v) * OWP + u];
             m10 += u * val;
             m01 += half ? -v * val : v * val;
         }
@@ -81,20 +122,11 @@ __global__ __launch_bounds__(256) void k_orient_desc(const GfoGeom* __restrict__
     }
     const float angle = gfo_fast_atan2f((float)m01, (float)m10);
 
-    // ---- stage the blurred 37x37 window ----
-    const uint8_t* bl = blur + (long long)img * g.blur_img_stride + L.blur_off + (long long)(y - 18) * L.pitch + (x - 18);
-    uint8_t* win = s_win[wave];
-    for (int t = lane; t < DW * DW; t += 64) {
-        const int r = t / DW, c = t - r * DW;
-        win[r * DWP + c] = bl[(long long)r * L.pitch + c];
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    // ---- descriptor on the blurred window ----
     const float factorPI = (float)(3.1415926535897932384626433832795 / 180.f);
     float a, b;
     gfo_sincosf(angle * factorPI, &b, &a);
-    const uint8_t* wc = win + 18 * DWP + 18;
+    const uint8_t* wc = win + 18 * DWP + woff + 18;
     unsigned long long word = 0;
 #pragma unroll
     for (int r = 0; r < 4; r++) {
