@@ -33,6 +33,10 @@ class FrameBoundsC(C.Structure):
     _fields_ = [("min_x", C.c_float), ("min_y", C.c_float), ("max_x", C.c_float), ("max_y", C.c_float)]
 
 
+class FeatureVectorC(C.Structure):
+    _fields_ = [("node_ids", C.c_void_p), ("node_start", C.c_void_p), ("items", C.c_void_p), ("n_nodes", C.c_int32)]
+
+
 class StageTime(C.Structure):
     _fields_ = [("name", C.c_char * 32), ("ms", C.c_double), ("launches", C.c_int)]
 
@@ -43,7 +47,7 @@ SYMBOLS = [
     "gfo_ctx_synchronize", "gfo_ctx_tables", "gfo_ctx_max_keypoints", "gfo_extract", "gfo_extract_batch",
     "gfo_extract_batch_device", "gfo_batch_counts", "gfo_batch_fetch", "gfo_batch_device_views",
     "gfo_compute_pyramid", "gfo_pyramid_level", "gfo_hamming256", "gfo_stereo_match",
-    "gfo_stereo_match_batch", "gfo_stereo_fetch", "gfo_search_by_projection", "gfo_profile_enable",
+    "gfo_stereo_match_batch", "gfo_stereo_fetch", "gfo_search_by_projection", "gfo_search_by_bow", "gfo_profile_enable",
     "gfo_profile_read", "gfo_debug_blurred_level", "gfo_debug_level_candidates",
 ]
 
@@ -112,6 +116,7 @@ def load_library():
     L.gfo_stereo_match_batch.argtypes = [vp, C.POINTER(StereoParamsC)]
     L.gfo_stereo_fetch.argtypes = [vp, i, vp, vp, vp, vp, i, ip]
     L.gfo_search_by_projection.argtypes = [vp, vp, vp, vp, i, vp, i, C.POINTER(FrameBoundsC), vp, vp, i, f, f, vp, vp, vp, ip]
+    L.gfo_search_by_bow.argtypes = [vp, vp, vp, vp, i, C.POINTER(FeatureVectorC), vp, vp, i, C.POINTER(FeatureVectorC), f, i, vp, ip]
     L.gfo_profile_enable.argtypes = [vp, i]
     L.gfo_profile_read.argtypes = [vp, C.POINTER(StageTime), i, ip, i]
     L.gfo_debug_blurred_level.argtypes = [vp, i, i, vp, i]

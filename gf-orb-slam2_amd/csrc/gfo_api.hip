@@ -35,7 +35,7 @@ static inline long long align_up(long long v, long long a) { return (v + a - 1) 
 // profiling
 // ---------------------------------------------------------------------------------------------
 static const char* k_stage_names[ST_COUNT] = {"resize", "blur", "fast", "quadtree", "orient_desc",
-                                              "stereo_bucket", "stereo_match", "stereo_cut", "project"};
+                                              "stereo_bucket", "stereo_match", "stereo_cut", "project", "bow"};
 
 static hipEvent_t ev_get(gfo_ctx* c)
 {

@@ -101,7 +101,7 @@ struct GfoStereoLaunch {
 
 enum GfoStage {
     ST_RESIZE = 0, ST_BLUR, ST_FAST, ST_QUADTREE, ST_ORIENT_DESC, ST_STEREO_BUCKET, ST_STEREO, ST_STEREO_CUT,
-    ST_PROJECT, ST_COUNT
+    ST_PROJECT, ST_BOW, ST_COUNT
 };
 
 struct gfo_ctx {

@@ -1,0 +1,228 @@
+// k_bow.hip -- ORBmatcher::SearchByBoW(KeyFrame*, Frame&, vector<MapPoint*>&) (ORBmatcher.cc:270-404)
+// on flattened arrays: the two DBoW2::FeatureVector maps arrive as CSR (node ids ascending).
+//
+// Keypoints of different vocabulary nodes are disjoint on both sides, so nodes are independent; inside
+// a node the reference is sequential (every accepted match blocks its frame keypoint for the following
+// keyframe keypoints, :320,343).  Device form: ONE WAVEFRONT PER COMMON NODE walks the node's keyframe
+// keypoints in order; for each, the 64 lanes sweep the node's frame keypoints, take the 256-bit
+// Hamming distance and wave-reduce the two smallest (distance, position) keys -- "first minimum wins"
+// (:326-336) is the smaller position.  The rotation-consistency filter (:349-360, 382-401,
+// ComputeThreeMaxima :1723-1764) is one small workgroup: 30-bin histogram, the reference's exact
+// three-maxima scan on one lane, then the sweep that clears the other bins.
+// The node intersection (the lower_bound walk, :292-380) is a host-side merge of two sorted id lists.
+#include "gfo_internal.h"
+
+#define TH_LOW 50        // ORBmatcher.cc:58
+#define HISTO_LENGTH 30  // ORBmatcher.cc:59
+
+struct BowArgs {
+    const uint8_t* kf_desc;
+    const float* kf_angle;
+    const uint8_t* kf_valid;
+    const int* kf_start;       // CSR of the keyframe feature vector
+    const unsigned* kf_items;
+    const uint8_t* f_desc;
+    const float* f_angle;
+    const int* f_start;
+    const unsigned* f_items;
+    const int2* pairs;         // (kf node slot, frame node slot) of every common node
+    int npairs;
+    int n_f;
+    float nn_ratio;
+    int check_ori;
+    int* out;                  // [n_f] keyframe keypoint index or -1
+    int* rot_bin;              // [n_f]
+    int* counters;             // [0] nmatches
+};
+
+__global__ __launch_bounds__(256) void k_bow_match(BowArgs a)
+{
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int pi = blockIdx.x * 4 + wave;
+    if (pi >= a.npairs) return;
+    const int2 pr = a.pairs[pi];
+    const int kb = a.kf_start[pr.x], ke = a.kf_start[pr.x + 1];
+    const int fb = a.f_start[pr.y], fe = a.f_start[pr.y + 1];
+    const float factor = 1.0f / HISTO_LENGTH;  // :284 (applied to degrees, as the reference does)
+    int accepted = 0;
+    for (int ik = kb; ik < ke; ik++) {
+        const unsigned realIdxKF = a.kf_items[ik];
+        if (!a.kf_valid[realIdxKF]) continue;  // :306-310 (wave-uniform)
+        const uint4* dk = reinterpret_cast<const uint4*>(a.kf_desc + (long long)realIdxKF * 32);
+        const uint4 k0 = dk[0], k1 = dk[1];
+        unsigned b1 = 0xFFFFFFFFu, b2 = 0xFFFFFFFFu;  // two smallest (dist << 20 | position)
+        for (int j = fb + lane; j < fe; j += 64) {
+            const unsigned realIdxF = a.f_items[j];
+            if (a.out[realIdxF] >= 0) continue;  // :320 already matched (this wave wrote it: same-wave program order)
+            const uint4* df = reinterpret_cast<const uint4*>(a.f_desc + (long long)realIdxF * 32);
+            const uint4 f0 = df[0], f1 = df[1];
+            const unsigned dist = __popc(k0.x ^ f0.x) + __popc(k0.y ^ f0.y) + __popc(k0.z ^ f0.z) + __popc(k0.w ^ f0.w) +
+                                  __popc(k1.x ^ f1.x) + __popc(k1.y ^ f1.y) + __popc(k1.z ^ f1.z) + __popc(k1.w ^ f1.w);
+            const unsigned key = (dist << 20) | (unsigned)(j - fb);
+            if (key < b1) { b2 = b1; b1 = key; }
+            else if (key < b2) b2 = key;
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const unsigned o1 = (unsigned)__shfl_xor((int)b1, o), o2 = (unsigned)__shfl_xor((int)b2, o);
+            const unsigned lo = min(b1, o1), hi = max(b1, o1);
+            b1 = lo;
+            b2 = min(hi, min(b2, o2));
+        }
+        if (b1 == 0xFFFFFFFFu) continue;
+        const int bestDist1 = (int)(b1 >> 20);
+        const int bestDist2 = b2 == 0xFFFFFFFFu ? 256 : (int)(b2 >> 20);
+        if (bestDist1 <= TH_LOW && (float)bestDist1 < a.nn_ratio * (float)bestDist2) {  // :339-341
+            const unsigned bestIdxF = a.f_items[fb + (int)(b1 & 0xFFFFF)];
+            if (lane == 0) {
+                a.out[bestIdxF] = (int)realIdxKF;
+                if (a.check_ori) {
+                    float rot = a.kf_angle[realIdxKF] - a.f_angle[bestIdxF];
+                    if (rot < 0.0f) rot += 360.0f;
+                    int bin = (int)roundf(rot * factor);
+                    if (bin == HISTO_LENGTH) bin = 0;
+                    a.rot_bin[bestIdxF] = bin;
+                }
+            }
+            accepted++;
+            // make lane 0's store visible to the whole wave's next sweep
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        }
+    }
+    if (lane == 0 && accepted) atomicAdd(&a.counters[0], accepted);
+}
+
+__global__ __launch_bounds__(256) void k_bow_rotation(BowArgs a)
+{
+    __shared__ int histo[HISTO_LENGTH];
+    __shared__ int keep[3];
+    __shared__ int s_drop;
+    const int tid = threadIdx.x;
+    if (tid < HISTO_LENGTH) histo[tid] = 0;
+    if (tid == 0) s_drop = 0;
+    __syncthreads();
+    for (int i = tid; i < a.n_f; i += 256) {
+        const int b = a.rot_bin[i];
+        if (b >= 0) atomicAdd(&histo[b], 1);
+    }
+    __syncthreads();
+    if (tid == 0) {  // ComputeThreeMaxima, ORBmatcher.cc:1723-1764
+        int max1 = 0, max2 = 0, max3 = 0, ind1 = -1, ind2 = -1, ind3 = -1;
+        for (int i = 0; i < HISTO_LENGTH; i++) {
+            const int s = histo[i];
+            if (s > max1) { max3 = max2; max2 = max1; max1 = s; ind3 = ind2; ind2 = ind1; ind1 = i; }
+            else if (s > max2) { max3 = max2; max2 = s; ind3 = ind2; ind2 = i; }
+            else if (s > max3) { max3 = s; ind3 = i; }
+        }
+        if ((float)max2 < 0.1f * (float)max1) { ind2 = -1; ind3 = -1; }
+        else if ((float)max3 < 0.1f * (float)max1) ind3 = -1;
+        keep[0] = ind1; keep[1] = ind2; keep[2] = ind3;
+    }
+    __syncthreads();
+    int drop = 0;
+    for (int i = tid; i < a.n_f; i += 256) {
+        const int b = a.rot_bin[i];
+        if (b >= 0 && b != keep[0] && b != keep[1] && b != keep[2]) {
+            a.out[i] = -1;
+            drop++;
+        }
+    }
+    if (drop) atomicAdd(&s_drop, drop);
+    __syncthreads();
+    if (tid == 0) a.counters[0] -= s_drop;
+}
+
+#define BTRY(c, expr)                                                                             \
+    do {                                                                                          \
+        hipError_t e_ = (expr);                                                                   \
+        if (e_ != hipSuccess) {                                                                   \
+            (c)->err = std::string(#expr) + ": " + hipGetErrorString(e_);                         \
+            return GFO_ERR_DEVICE;                                                                \
+        }                                                                                         \
+    } while (0)
+
+extern "C" int gfo_search_by_bow(gfo_ctx* c, const uint8_t* kf_desc, const float* kf_angle, const uint8_t* kf_mp_valid,
+                                 int n_kf, const gfo_feature_vector* kf_fv, const uint8_t* f_desc, const float* f_angle,
+                                 int n_f, const gfo_feature_vector* f_fv, float nn_ratio, int check_orientation,
+                                 int32_t* out_kf_idx, int* nmatches)
+{
+    if (!c) return GFO_ERR_INVALID;
+    if (!kf_fv || !f_fv || !out_kf_idx || !nmatches || n_kf < 0 || n_f < 0 || (n_kf > 0 && (!kf_desc || !kf_mp_valid)) ||
+        (n_f > 0 && !f_desc) || (check_orientation && n_kf > 0 && n_f > 0 && (!kf_angle || !f_angle))) {
+        c->err = "gfo_search_by_bow: bad argument";
+        return GFO_ERR_INVALID;
+    }
+    *nmatches = 0;
+    for (int i = 0; i < n_f; i++) out_kf_idx[i] = -1;
+    if (n_kf == 0 || n_f == 0) return GFO_OK;
+    // node intersection: merge of two ascending id lists (the lower_bound walk of :292-380)
+    std::vector<int2> pairs;
+    int max_f_items = 0;
+    for (int a = 0, b = 0; a < kf_fv->n_nodes && b < f_fv->n_nodes;) {
+        if (kf_fv->node_ids[a] == f_fv->node_ids[b]) {
+            pairs.push_back(make_int2(a, b));
+            const int nf = f_fv->node_start[b + 1] - f_fv->node_start[b];
+            max_f_items = nf > max_f_items ? nf : max_f_items;
+            a++; b++;
+        } else if (kf_fv->node_ids[a] < f_fv->node_ids[b]) a++;
+        else b++;
+    }
+    if (pairs.empty()) return GFO_OK;
+    if (max_f_items >= (1 << 20)) {
+        c->err = "gfo_search_by_bow: node with more than 2^20 frame keypoints";
+        return GFO_ERR_INVALID;
+    }
+    BTRY(c, hipSetDevice(c->device));
+    const int nk_items = kf_fv->node_start[kf_fv->n_nodes], nf_items = f_fv->node_start[f_fv->n_nodes];
+    size_t off = 0;
+    auto take = [&](size_t bytes) { size_t o = off; off = (off + bytes + 255) / 256 * 256; return o; };
+    const size_t o_kd = take(32 * (size_t)n_kf), o_ka = take(4 * (size_t)n_kf), o_kv = take(n_kf),
+                 o_ks = take(4 * (size_t)(kf_fv->n_nodes + 1)), o_ki = take(4 * (size_t)(nk_items > 0 ? nk_items : 1)),
+                 o_fd = take(32 * (size_t)n_f), o_fa = take(4 * (size_t)n_f), o_fs = take(4 * (size_t)(f_fv->n_nodes + 1)),
+                 o_fi = take(4 * (size_t)(nf_items > 0 ? nf_items : 1)), o_pr = take(sizeof(int2) * pairs.size()),
+                 o_out = take(4 * (size_t)n_f), o_rb = take(4 * (size_t)n_f), o_cnt = take(16);
+    if (off > c->scratch_bytes) {
+        (void)hipStreamSynchronize(c->stream);
+        if (c->d_scratch) (void)hipFree(c->d_scratch);
+        c->d_scratch = nullptr;
+        c->scratch_bytes = 0;
+        BTRY(c, hipMalloc(&c->d_scratch, off));
+        c->scratch_bytes = off;
+    }
+    uint8_t* S = (uint8_t*)c->d_scratch;
+    hipStream_t st = c->stream;
+    BTRY(c, hipMemcpyAsync(S + o_kd, kf_desc, 32 * (size_t)n_kf, hipMemcpyHostToDevice, st));
+    if (kf_angle) BTRY(c, hipMemcpyAsync(S + o_ka, kf_angle, 4 * (size_t)n_kf, hipMemcpyHostToDevice, st));
+    BTRY(c, hipMemcpyAsync(S + o_kv, kf_mp_valid, n_kf, hipMemcpyHostToDevice, st));
+    BTRY(c, hipMemcpyAsync(S + o_ks, kf_fv->node_start, 4 * (size_t)(kf_fv->n_nodes + 1), hipMemcpyHostToDevice, st));
+    if (nk_items) BTRY(c, hipMemcpyAsync(S + o_ki, kf_fv->items, 4 * (size_t)nk_items, hipMemcpyHostToDevice, st));
+    BTRY(c, hipMemcpyAsync(S + o_fd, f_desc, 32 * (size_t)n_f, hipMemcpyHostToDevice, st));
+    if (f_angle) BTRY(c, hipMemcpyAsync(S + o_fa, f_angle, 4 * (size_t)n_f, hipMemcpyHostToDevice, st));
+    BTRY(c, hipMemcpyAsync(S + o_fs, f_fv->node_start, 4 * (size_t)(f_fv->n_nodes + 1), hipMemcpyHostToDevice, st));
+    if (nf_items) BTRY(c, hipMemcpyAsync(S + o_fi, f_fv->items, 4 * (size_t)nf_items, hipMemcpyHostToDevice, st));
+    BTRY(c, hipMemcpyAsync(S + o_pr, pairs.data(), sizeof(int2) * pairs.size(), hipMemcpyHostToDevice, st));
+    BTRY(c, hipMemsetAsync(S + o_out, 0xFF, 4 * (size_t)n_f, st));
+    BTRY(c, hipMemsetAsync(S + o_rb, 0xFF, 4 * (size_t)n_f, st));
+    BTRY(c, hipMemsetAsync(S + o_cnt, 0, 16, st));
+    BowArgs a{};
+    a.kf_desc = S + o_kd; a.kf_angle = (const float*)(S + o_ka); a.kf_valid = S + o_kv;
+    a.kf_start = (const int*)(S + o_ks); a.kf_items = (const unsigned*)(S + o_ki);
+    a.f_desc = S + o_fd; a.f_angle = (const float*)(S + o_fa);
+    a.f_start = (const int*)(S + o_fs); a.f_items = (const unsigned*)(S + o_fi);
+    a.pairs = (const int2*)(S + o_pr); a.npairs = (int)pairs.size();
+    a.n_f = n_f; a.nn_ratio = nn_ratio; a.check_ori = check_orientation ? 1 : 0;
+    a.out = (int*)(S + o_out); a.rot_bin = (int*)(S + o_rb); a.counters = (int*)(S + o_cnt);
+    gfo_prof_begin(c, ST_BOW);
+    hipLaunchKernelGGL(k_bow_match, dim3((a.npairs + 3) / 4), dim3(256), 0, st, a);
+    if (a.check_ori) hipLaunchKernelGGL(k_bow_rotation, dim3(1), dim3(256), 0, st, a);
+    gfo_prof_end(c);
+    BTRY(c, hipGetLastError());
+    int cnt[4];
+    BTRY(c, hipMemcpyAsync(out_kf_idx, a.out, 4 * (size_t)n_f, hipMemcpyDeviceToHost, st));
+    BTRY(c, hipMemcpyAsync(cnt, a.counters, 16, hipMemcpyDeviceToHost, st));
+    BTRY(c, hipStreamSynchronize(st));
+    *nmatches = cnt[0];
+    return GFO_OK;
+}

@@ -5,7 +5,7 @@ from collections import namedtuple
 
 import numpy as np
 
-from ._lib import (FrameBoundsC, KEYPOINT_DTYPE, MAP_POINT_DTYPE, StereoParamsC, check, load_library, ptr)
+from ._lib import (FeatureVectorC, FrameBoundsC, KEYPOINT_DTYPE, MAP_POINT_DTYPE, StereoParamsC, check, load_library, ptr)
 
 StereoParams = namedtuple("StereoParams", "n_rows mbf mb min_x")
 FrameBounds = namedtuple("FrameBounds", "min_x min_y max_x max_y")
@@ -89,3 +89,28 @@ class ORBmatcher:
                                                                    C.byref(fb), ptr(mps), ptr(mpd), m, th, self.mfNNratio, ptr(kp_taken),
                                                                    ptr(out_mp), ptr(out_sc), C.byref(nm)))
         return nm.value, out_mp[:n], out_sc[:n]
+
+    def SearchByBoW(self, kf_desc, kf_angle, kf_mp_valid, kf_fv, f_desc, f_angle, f_fv):
+        """ORBmatcher::SearchByBoW(KeyFrame*, Frame&, vpMapPointMatches) -- ORBmatcher.h:272, ORBmatcher.cc:270-404.
+        kf_fv / f_fv = (node_ids, node_start, items): the CSR of each DBoW2::FeatureVector.
+        Returns (nmatches, out_kf_idx)."""
+        kf_desc = np.ascontiguousarray(kf_desc, np.uint8)
+        f_desc = np.ascontiguousarray(f_desc, np.uint8)
+        kf_angle = np.ascontiguousarray(kf_angle, np.float32)
+        f_angle = np.ascontiguousarray(f_angle, np.float32)
+        kf_mp_valid = np.ascontiguousarray(kf_mp_valid, np.uint8)
+        keep = []
+
+        def fv(t):
+            ids, start, items = (np.ascontiguousarray(t[0], np.uint32), np.ascontiguousarray(t[1], np.int32),
+                                 np.ascontiguousarray(t[2], np.uint32))
+            keep.append((ids, start, items))
+            return FeatureVectorC(ids.ctypes.data, start.ctypes.data, items.ctypes.data, len(ids))
+        a, b = fv(kf_fv), fv(f_fv)
+        n_f = len(f_desc)
+        out = np.full(max(n_f, 1), -1, np.int32)
+        nm = C.c_int()
+        check(self._L, self._ctx, self._L.gfo_search_by_bow(self._ctx, ptr(kf_desc), ptr(kf_angle), ptr(kf_mp_valid), len(kf_desc),
+                                                            C.byref(a), ptr(f_desc), ptr(f_angle), n_f, C.byref(b), self.mfNNratio,
+                                                            1 if self.mbCheckOrientation else 0, ptr(out), C.byref(nm)))
+        return nm.value, out[:n_f]

@@ -163,6 +163,24 @@ int gfo_search_by_projection(gfo_ctx* ctx, const gfo_keypoint* kp_un, const uint
                              const uint8_t* kp_taken, int32_t* out_mp, int32_t* out_score,
                              int* nmatches);
 
+/* ORBmatcher::SearchByBoW(KeyFrame* pKF, Frame& F, vector<MapPoint*>& vpMapPointMatches)
+ * include/ORBmatcher.h:272, src/ORBmatcher.cc:270-404.  The two DBoW2::FeatureVector maps
+ * (Thirdparty/DBoW2/DBoW2/FeatureVector.h: map<NodeId, vector<unsigned>>) are passed flattened to CSR in
+ * the map's own (ascending node id) order; the DBoW2 transform that produces them stays on the host.
+ * kf_mp_valid[i] = 1 where pKF->GetMapPointMatches()[i] is set and !isBad().  kf_angle = pKF->mvKeysUn[i].angle,
+ * f_angle = F.mvKeys[i].angle (used when check_orientation, = mbCheckOrientation).
+ * out_kf_idx[n_f]: index i of the keyframe keypoint whose map point is left in vpMapPointMatches[j], -1 = NULL. */
+typedef struct {
+    const uint32_t* node_ids;   /* [n_nodes] ascending                    */
+    const int32_t* node_start;  /* [n_nodes + 1] offsets into items        */
+    const uint32_t* items;      /* keypoint indices in the vector's order  */
+    int32_t n_nodes;
+} gfo_feature_vector;
+int gfo_search_by_bow(gfo_ctx* ctx, const uint8_t* kf_desc, const float* kf_angle, const uint8_t* kf_mp_valid,
+                      int n_kf, const gfo_feature_vector* kf_fv, const uint8_t* f_desc, const float* f_angle,
+                      int n_f, const gfo_feature_vector* f_fv, float nn_ratio, int check_orientation,
+                      int32_t* out_kf_idx, int* nmatches);
+
 /* ---- measurement hooks (bench.py / rocprof cross-check) ---------------------------------- */
 /* When enabled, every kernel launch of the extract / stereo pipelines is bracketed by HIP
  * events on the context stream; gfo_profile_read returns, per stage, the accumulated device

@@ -995,3 +995,91 @@ int orc_search_by_projection(const orc_keypoint* kp, const uint8_t* desc, const 
     grid_free(&g);
     return nmatches;
 }
+
+/* ------------------------------------------------------------------------------------------
+ * ORBmatcher::ComputeThreeMaxima -- ORBmatcher.cc:1723-1764
+ * ---------------------------------------------------------------------------------------- */
+void orc_three_maxima(const int* histo, int L, int* ind1, int* ind2, int* ind3)
+{
+    int max1 = 0, max2 = 0, max3 = 0;
+    for (int i = 0; i < L; i++) {
+        const int s = histo[i];
+        if (s > max1) {
+            max3 = max2; max2 = max1; max1 = s;
+            *ind3 = *ind2; *ind2 = *ind1; *ind1 = i;
+        } else if (s > max2) {
+            max3 = max2; max2 = s;
+            *ind3 = *ind2; *ind2 = i;
+        } else if (s > max3) {
+            max3 = s;
+            *ind3 = i;
+        }
+    }
+    if ((float)max2 < 0.1f * (float)max1) { *ind2 = -1; *ind3 = -1; }
+    else if ((float)max3 < 0.1f * (float)max1) *ind3 = -1;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * ORBmatcher::SearchByBoW(KeyFrame*, Frame&, vpMapPointMatches) -- ORBmatcher.cc:270-404.
+ * TH_LOW = 50, HISTO_LENGTH = 30; note factor = 1/HISTO_LENGTH (:284) is applied to a rotation in
+ * degrees, as the reference does (bins 0..12 are the only ones that can fill).
+ * ---------------------------------------------------------------------------------------- */
+int orc_search_by_bow(const uint8_t* kf_desc, const float* kf_angle, const uint8_t* kf_mp_valid, int n_kf,
+                      const orc_feature_vector* kfv, const uint8_t* f_desc, const float* f_angle, int n_f,
+                      const orc_feature_vector* ffv, float nn_ratio, int check_orientation, int* out)
+{
+    enum { HISTO_LENGTH = 30, TH_LOW_ = 50 };
+    (void)n_kf;
+    for (int i = 0; i < n_f; i++) out[i] = -1;
+    int nmatches = 0;
+    int* rot_bin = (int*)malloc(sizeof(int) * (n_f > 0 ? n_f : 1)); /* bin of the match stored at F index */
+    int histo[HISTO_LENGTH];
+    memset(histo, 0, sizeof histo);
+    for (int i = 0; i < n_f; i++) rot_bin[i] = -1;
+    const float factor = 1.0f / HISTO_LENGTH;
+    int a = 0, b = 0;
+    while (a < kfv->n_nodes && b < ffv->n_nodes) { /* :292-380 */
+        if (kfv->node_ids[a] == ffv->node_ids[b]) {
+            for (int ik = kfv->node_start[a]; ik < kfv->node_start[a + 1]; ik++) {
+                const unsigned realIdxKF = kfv->items[ik];
+                if (!kf_mp_valid[realIdxKF]) continue;
+                int bestDist1 = 256, bestIdxF = -1, bestDist2 = 256;
+                for (int jf = ffv->node_start[b]; jf < ffv->node_start[b + 1]; jf++) {
+                    const unsigned realIdxF = ffv->items[jf];
+                    if (out[realIdxF] >= 0) continue;
+                    const int dist = orc_hamming256(kf_desc + (size_t)realIdxKF * 32, f_desc + (size_t)realIdxF * 32);
+                    if (dist < bestDist1) { bestDist2 = bestDist1; bestDist1 = dist; bestIdxF = (int)realIdxF; }
+                    else if (dist < bestDist2) bestDist2 = dist;
+                }
+                if (bestDist1 <= TH_LOW_) {
+                    if ((float)bestDist1 < nn_ratio * (float)bestDist2) {
+                        out[bestIdxF] = (int)realIdxKF;
+                        if (check_orientation) {
+                            float rot = kf_angle[realIdxKF] - f_angle[bestIdxF];
+                            if (rot < 0.0) rot += 360.0f;
+                            int bin = (int)roundf(rot * factor);
+                            if (bin == HISTO_LENGTH) bin = 0;
+                            rot_bin[bestIdxF] = bin;
+                            histo[bin]++;
+                        }
+                        nmatches++;
+                    }
+                }
+            }
+            a++; b++;
+        } else if (kfv->node_ids[a] < ffv->node_ids[b]) a++; /* lower_bound on a sorted map */
+        else b++;
+    }
+    if (check_orientation) { /* :382-401 */
+        int ind1 = -1, ind2 = -1, ind3 = -1;
+        orc_three_maxima(histo, HISTO_LENGTH, &ind1, &ind2, &ind3);
+        for (int i = 0; i < n_f; i++) {
+            const int bin = rot_bin[i];
+            if (bin < 0 || bin == ind1 || bin == ind2 || bin == ind3) continue;
+            out[i] = -1;
+            nmatches--;
+        }
+    }
+    free(rot_bin);
+    return nmatches;
+}

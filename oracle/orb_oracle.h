@@ -123,6 +123,22 @@ int orc_features_in_area(const orc_keypoint* kp_un, int n, const orc_frame_bound
                          float x, float y, float r, int min_level, int max_level,
                          int* out_idx, int cap);
 
+/* ORBmatcher::SearchByBoW(KeyFrame*, Frame&, vector<MapPoint*>&) -- ORBmatcher.cc:270-404, with the
+ * two DBoW2::FeatureVector maps flattened to CSR (node ids ascending, as std::map iterates them).
+ * kf_mp_valid[i] = 1 where vpMapPointsKF[i] is set and not bad.  out_kf_idx[n_f]: index of the KF
+ * keypoint whose map point ends up in vpMapPointMatches[i], -1 = NULL.  Returns nmatches. */
+typedef struct {
+    const uint32_t* node_ids;   /* [n_nodes] ascending                       */
+    const int32_t* node_start;  /* [n_nodes + 1] offsets into items           */
+    const uint32_t* items;      /* keypoint indices, in the vector's order    */
+    int32_t n_nodes;
+} orc_feature_vector;
+int orc_search_by_bow(const uint8_t* kf_desc, const float* kf_angle, const uint8_t* kf_mp_valid, int n_kf,
+                      const orc_feature_vector* kf_fv, const uint8_t* f_desc, const float* f_angle, int n_f,
+                      const orc_feature_vector* f_fv, float nn_ratio, int check_orientation, int* out_kf_idx);
+/* ORBmatcher::ComputeThreeMaxima -- ORBmatcher.cc:1723-1764 on the bin sizes */
+void orc_three_maxima(const int* histo_sizes, int L, int* ind1, int* ind2, int* ind3);
+
 #ifdef __cplusplus
 }
 #endif

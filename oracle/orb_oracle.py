@@ -252,6 +252,57 @@ def search_by_projection(kp_un, desc, u_right, scale_factors, bounds, mps, mp_de
     return nm, out_mp[:n], out_score[:n]
 
 
+class FeatureVectorC(C.Structure):
+    _fields_ = [("node_ids", C.c_void_p), ("node_start", C.c_void_p), ("items", C.c_void_p), ("n_nodes", C.c_int32)]
+
+
+def make_feature_vector(node_of_keypoint):
+    """CSR of a DBoW2::FeatureVector from the node id of every keypoint (-1 = not in the vector):
+    node ids ascending, keypoint indices ascending inside a node (as DBoW2 appends them)."""
+    node_of_keypoint = np.asarray(node_of_keypoint)
+    ids = np.unique(node_of_keypoint[node_of_keypoint >= 0]).astype(np.uint32)
+    start = np.zeros(len(ids) + 1, np.int32)
+    items = []
+    for k, nid in enumerate(ids):
+        idx = np.nonzero(node_of_keypoint == nid)[0]
+        items.append(idx)
+        start[k + 1] = start[k] + len(idx)
+    items = np.concatenate(items).astype(np.uint32) if items else np.zeros(0, np.uint32)
+    return ids, start, items
+
+
+def _fv_struct(fv):
+    ids, start, items = (np.ascontiguousarray(fv[0], np.uint32), np.ascontiguousarray(fv[1], np.int32),
+                         np.ascontiguousarray(fv[2], np.uint32))
+    return FeatureVectorC(ids.ctypes.data, start.ctypes.data, items.ctypes.data, len(ids)), (ids, start, items)
+
+
+def search_by_bow(kf_desc, kf_angle, kf_mp_valid, kf_fv, f_desc, f_angle, f_fv, nn_ratio, check_orientation=True):
+    kf_desc = np.ascontiguousarray(kf_desc, np.uint8)
+    f_desc = np.ascontiguousarray(f_desc, np.uint8)
+    kf_angle = np.ascontiguousarray(kf_angle, np.float32)
+    f_angle = np.ascontiguousarray(f_angle, np.float32)
+    kf_mp_valid = np.ascontiguousarray(kf_mp_valid, np.uint8)
+    a, keep_a = _fv_struct(kf_fv)
+    b, keep_b = _fv_struct(f_fv)
+    out = np.full(max(len(f_desc), 1), -1, np.int32)
+    L = lib()
+    L.orc_search_by_bow.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(FeatureVectorC), C.c_void_p, C.c_void_p,
+                                    C.c_int, C.POINTER(FeatureVectorC), C.c_float, C.c_int, C.c_void_p]
+    nm = L.orc_search_by_bow(_p(kf_desc), _p(kf_angle), _p(kf_mp_valid), len(kf_desc), C.byref(a), _p(f_desc), _p(f_angle),
+                             len(f_desc), C.byref(b), nn_ratio, 1 if check_orientation else 0, _p(out))
+    return nm, out[:len(f_desc)]
+
+
+def three_maxima(sizes):
+    sizes = np.ascontiguousarray(sizes, np.int32)
+    i1, i2, i3 = C.c_int(-1), C.c_int(-1), C.c_int(-1)
+    L = lib()
+    L.orc_three_maxima.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    L.orc_three_maxima(_p(sizes), len(sizes), C.byref(i1), C.byref(i2), C.byref(i3))
+    return i1.value, i2.value, i3.value
+
+
 def features_in_area(kp_un, bounds, x, y, r, min_level=-1, max_level=-1):
     kp_un = np.ascontiguousarray(kp_un, dtype=KEYPOINT_DTYPE)
     n = len(kp_un)

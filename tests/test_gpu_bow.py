@@ -1,0 +1,67 @@
+"""GPU parity tests of ORBmatcher::SearchByBoW(KeyFrame*, Frame&, ...) through the C ABI vs the CPU
+oracle.  Indices bit-exact."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ext():
+    import gf_orb_slam2_amd as G
+    e = G.ORBextractor(2000, 1.2, 8, 20, 7)
+    yield e
+    e.close()
+
+
+def _case(oracle, seed, flips, node_shift, angle_sigma, p_invalid=0.1):
+    kd = oracle.KEYPOINT_DTYPE
+    kl = np.fromfile(os.path.join(GOLDEN, "EuRoC_l_kp.bin"), kd)
+    dl = np.fromfile(os.path.join(GOLDEN, "EuRoC_l_desc.bin"), np.uint8).reshape(-1, 32)
+    rng = np.random.default_rng(seed)
+    fd = dl.copy()
+    for _ in range(flips):
+        sel = rng.random(len(fd)) < 0.5
+        bits = rng.integers(0, 256, len(fd))
+        fd[sel, bits[sel] >> 3] ^= (1 << (bits[sel] & 7)).astype(np.uint8)
+    perm = rng.permutation(len(fd))
+    fd = fd[perm]
+    fa = ((kl["angle"][perm] + rng.normal(0, angle_sigma, len(fd))) % 360).astype(np.float32)
+    # a toy vocabulary: the node of a descriptor is its leading bits (a real one is a k-means tree)
+    node_k = (dl[:, 0] >> node_shift).astype(np.int64)
+    node_f = (fd[:, 0] >> node_shift).astype(np.int64)
+    node_k[rng.random(len(node_k)) < 0.02] = -1          # keypoints missing from the feature vector
+    valid = (rng.random(len(dl)) >= p_invalid).astype(np.uint8)
+    return dl, kl["angle"].copy(), valid, oracle.make_feature_vector(node_k), fd, fa, oracle.make_feature_vector(node_f)
+
+
+@pytest.mark.parametrize("seed,flips,shift,sigma,ratio,ori", [(0, 10, 2, 5.0, 0.7, True), (1, 4, 4, 40.0, 0.9, True),
+                                                              (2, 20, 0, 2.0, 0.6, False), (3, 0, 6, 0.0, 0.75, True)])
+def test_bow_matches_oracle(ext, oracle, seed, flips, shift, sigma, ratio, ori):
+    import gf_orb_slam2_amd as G
+    kd_, ka, valid, kfv, fd, fa, ffv = _case(oracle, seed, flips, shift, sigma)
+    ref = oracle.search_by_bow(kd_, ka, valid, kfv, fd, fa, ffv, ratio, ori)
+    got = G.ORBmatcher(ratio, ori, extractor=ext).SearchByBoW(kd_, ka, valid, kfv, fd, fa, ffv)
+    assert got[0] == ref[0]
+    np.testing.assert_array_equal(got[1], ref[1])
+    if flips <= 10:
+        assert ref[0] > 200
+
+
+def test_bow_edge_cases(ext, oracle):
+    import gf_orb_slam2_amd as G
+    m = G.ORBmatcher(0.7, True, extractor=ext)
+    kd_, ka, valid, kfv, fd, fa, ffv = _case(oracle, 5, 6, 3, 3.0)
+    empty = (np.zeros(0, np.uint32), np.zeros(1, np.int32), np.zeros(0, np.uint32))
+    assert m.SearchByBoW(kd_, ka, valid, empty, fd, fa, ffv)[0] == 0
+    assert m.SearchByBoW(kd_, ka, valid, kfv, fd, fa, empty)[0] == 0
+    none_valid = np.zeros_like(valid)
+    nm, out = m.SearchByBoW(kd_, ka, none_valid, kfv, fd, fa, ffv)
+    assert nm == 0 and (out == -1).all()
+    # disjoint vocabularies
+    kfv2 = (kfv[0] + 1000, kfv[1], kfv[2])
+    assert m.SearchByBoW(kd_, ka, valid, kfv2, fd, fa, ffv)[0] == 0

@@ -267,3 +267,75 @@ def test_stereo_row_table_equals_predicate_form(oracle):
     assert got[0] == ref[0]
     for a, b in zip(got[1:], ref[1:]):
         np.testing.assert_array_equal(a, b)
+
+
+def bow_python(kd_, ka, valid, kfv, fd, fa, ffv, ratio, ori):
+    """SearchByBoW written straight from ORBmatcher.cc:270-404 with Python containers."""
+    kmap = {int(n): list(kfv[2][kfv[1][i]:kfv[1][i + 1]]) for i, n in enumerate(kfv[0])}
+    fmap = {int(n): list(ffv[2][ffv[1][i]:ffv[1][i + 1]]) for i, n in enumerate(ffv[0])}
+    out = [-1] * len(fd)
+    hist = [[] for _ in range(30)]
+    nm = 0
+    for node in sorted(set(kmap) & set(fmap)):
+        for rk in kmap[node]:
+            if not valid[rk]:
+                continue
+            b1, bi, b2 = 256, -1, 256
+            for rf in fmap[node]:
+                if out[rf] >= 0:
+                    continue
+                d = int(np.unpackbits(kd_[rk] ^ fd[rf]).sum())
+                if d < b1:
+                    b2, b1, bi = b1, d, rf
+                elif d < b2:
+                    b2 = d
+            if b1 <= 50 and np.float32(b1) < np.float32(ratio) * np.float32(b2):
+                out[bi] = int(rk)
+                if ori:
+                    rot = np.float32(ka[rk]) - np.float32(fa[bi])
+                    if rot < 0:
+                        rot = np.float32(rot + np.float32(360.0))
+                    v = float(np.float32(rot * np.float32(1.0 / 30)))
+                    b = int(np.floor(v + 0.5))
+                    hist[0 if b == 30 else b].append(bi)
+                nm += 1
+    if ori:
+        sizes = [len(h) for h in hist]
+        order = sorted(range(30), key=lambda i: (-sizes[i], i))
+        m1, m2, m3 = sizes[order[0]], sizes[order[1]], sizes[order[2]]
+        keep = {order[0]} if m1 > 0 else set()
+        if m1 > 0 and not (m2 < 0.1 * m1) and m2 > 0:
+            keep.add(order[1])
+            if not (m3 < 0.1 * m1) and m3 > 0:
+                keep.add(order[2])
+        for i in range(30):
+            if i not in keep:
+                for j in hist[i]:
+                    out[j] = -1
+                    nm -= 1
+    return nm, np.array(out, np.int32)
+
+
+def test_bow_oracle_against_python_statement(oracle):
+    kd = oracle.KEYPOINT_DTYPE
+    kl = np.fromfile(os.path.join(GOLDEN, "EuRoC_l_kp.bin"), kd)[:600]
+    dl = np.fromfile(os.path.join(GOLDEN, "EuRoC_l_desc.bin"), np.uint8).reshape(-1, 32)[:600]
+    rng = np.random.default_rng(4)
+    fd = dl.copy()
+    for _ in range(8):
+        sel = rng.random(len(fd)) < 0.5
+        bits = rng.integers(0, 256, len(fd))
+        fd[sel, bits[sel] >> 3] ^= (1 << (bits[sel] & 7)).astype(np.uint8)
+    perm = rng.permutation(len(fd))
+    fd = fd[perm]
+    fa = ((kl["angle"][perm] + rng.normal(0, 20, len(fd))) % 360).astype(np.float32)
+    valid = (rng.random(len(dl)) > 0.1).astype(np.uint8)
+    kfv = oracle.make_feature_vector(dl[:, 0] >> 3)
+    ffv = oracle.make_feature_vector(fd[:, 0] >> 3)
+    for ratio, ori in ((0.7, True), (0.9, False)):
+        ref = bow_python(dl, kl["angle"], valid, kfv, fd, fa, ffv, ratio, ori)
+        got = oracle.search_by_bow(dl, kl["angle"], valid, kfv, fd, fa, ffv, ratio, ori)
+        assert got[0] == ref[0]
+        np.testing.assert_array_equal(got[1], ref[1])
+    assert oracle.three_maxima([5, 1, 9, 0, 9, 3]) == (2, 4, 0)
+    assert oracle.three_maxima([100, 5, 3] + [0] * 27) == (0, -1, -1)
