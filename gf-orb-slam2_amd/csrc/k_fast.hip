@@ -180,7 +180,6 @@ __global__ __launch_bounds__(256) void k_fast(const GfoGeom* __restrict__ gp, Gf
     wave_sync();
     if (dbg_stop == 1) return;
     const int tq = min(g.ini_th, g.min_th);
-    const int npx = sw * sh;
     const float inv_sw = 1.0f / (float)sw;
     const uint8_t* t0 = tile + 3 * TP + xoff + 3;  // scan pixel (0,0)
     // ---- A: compass test over every scan pixel, compacted into qa ----
@@ -306,6 +305,7 @@ __global__ __launch_bounds__(256) void k_fast(const GfoGeom* __restrict__ gp, Gf
 void gfo_launch_fast(gfo_ctx* c, const GfoInput& in, int nimg)
 {
     const GfoGeom& g = c->g;
+    if (g.total_cells == 0) return;  // image too small for a single 30-px cell on any level: no candidates
     const size_t lds = 4 * (size_t)(g.fast_tile_pitch * g.fast_tile_rows + g.fast_smap_pitch * g.fast_smap_rows + 2 * g.fast_npx_max);
     dim3 grid((g.total_cells + 3) / 4, nimg);
     gfo_prof_begin(c, ST_FAST);

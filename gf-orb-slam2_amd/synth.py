@@ -24,6 +24,7 @@ def synth_frame(w, h, idx=0):
     img += 70.0
     for _ in range(400):
         rw, rh = rng.integers(6, 41, 2)
+        rw, rh = min(int(rw), w - 1), min(int(rh), h - 1)   # tiny test images: keep the rectangle inside
         x = rng.integers(0, w - rw)
         y = rng.integers(0, h - rh)
         img[y:y + rh, x:x + rw] += rng.choice([-1.0, 1.0]) * rng.uniform(25, 90)

@@ -1,0 +1,142 @@
+"""GPU parity at the other sizes BASELINE.json names and at awkward ones: 1920x1080 @4000 features,
+a 50k-point local map, odd widths (unaligned rows), tiny images (empty levels), 1 level, small quotas,
+re-planning one context across sizes, ragged batches.  Bit-exact vs the oracle."""
+import numpy as np
+import pytest
+
+from conftest import synth_frame
+
+pytestmark = pytest.mark.gpu
+
+
+def _same(ext, oe, img):
+    gk, gd = ext(img)
+    ok, od = oe(img)
+    assert len(gk) == len(ok)
+    assert gk.tobytes() == ok.tobytes()
+    np.testing.assert_array_equal(gd, od)
+    return len(gk)
+
+
+def test_1080p_4000_features(oracle):
+    import gf_orb_slam2_amd as G
+    ext = G.ORBextractor(4000, 1.2, 8, 20, 7, max_batch=2)
+    oe = oracle.OracleExtractor(4000, 1.2, 8, 20, 7)
+    n = _same(ext, oe, synth_frame(1920, 1080, 11))
+    assert n >= 3500
+    assert ext.mnFeaturesPerLevel.tolist() == [869, 724, 603, 503, 419, 349, 291, 242]
+    ext.close()
+
+
+@pytest.mark.parametrize("w,h", [(1241, 376), (640, 480), (333, 217), (130, 100), (64, 48), (37, 300)])
+def test_awkward_sizes_one_context(oracle, w, h):
+    import gf_orb_slam2_amd as G
+    ext = G.ORBextractor(1000, 1.2, 8, 20, 7)
+    oe = oracle.OracleExtractor(1000, 1.2, 8, 20, 7)
+    _same(ext, oe, synth_frame(w, h, w + h))
+    _same(ext, oe, synth_frame(752, 480, 1))       # re-plan on a size change
+    ext.close()
+
+
+@pytest.mark.parametrize("nf,sf,nl,ini,mn", [(500, 1.2, 8, 20, 7), (3000, 1.1, 12, 12, 5), (50, 1.5, 4, 40, 10), (1000, 2.0, 3, 20, 7),
+                                             (1200, 1.2, 1, 20, 7), (7, 1.2, 8, 20, 7)])
+def test_extractor_parameters(oracle, nf, sf, nl, ini, mn):
+    import gf_orb_slam2_amd as G
+    ext = G.ORBextractor(nf, sf, nl, ini, mn)
+    oe = oracle.OracleExtractor(nf, sf, nl, ini, mn)
+    np.testing.assert_array_equal(ext.GetScaleFactors().view(np.uint32), oe.scale_factors.view(np.uint32))
+    np.testing.assert_array_equal(ext.GetInverseScaleSigmaSquares().view(np.uint32), oe.inv_level_sigma2.view(np.uint32))
+    np.testing.assert_array_equal(ext.mnFeaturesPerLevel, oe.features_per_level)
+    _same(ext, oe, synth_frame(752, 480, 31))
+    ext.close()
+
+
+def test_flat_and_saturated_images(oracle):
+    """no corners at all / only the minThFAST fallback fires / saturated blocks"""
+    import gf_orb_slam2_amd as G
+    ext = G.ORBextractor(1000, 1.2, 8, 20, 7)
+    oe = oracle.OracleExtractor(1000, 1.2, 8, 20, 7)
+    assert _same(ext, oe, np.full((480, 752), 128, np.uint8)) == 0
+    faint = (128 + 6 * ((np.indices((480, 752)).sum(0) // 23) % 2)).astype(np.uint8)      # contrast 12 < iniTh
+    faint[::37, ::41] += 9
+    _same(ext, oe, faint)
+    blocks = np.where((np.indices((480, 752)) // 16).sum(0) % 2 == 0, 255, 0).astype(np.uint8)
+    _same(ext, oe, blocks)
+    assert ext(np.zeros((0, 0), np.uint8))[0].size == 0          # empty image: untouched outputs
+    ext.close()
+
+
+def test_ragged_batches_and_device_pitch(oracle):
+    import torch
+    import gf_orb_slam2_amd as G
+    ext = G.ORBextractor(800, 1.2, 8, 20, 7, max_batch=2)
+    oe = oracle.OracleExtractor(800, 1.2, 8, 20, 7)
+    imgs = [synth_frame(501, 397, i) for i in range(5)]           # odd width, batch larger than max_batch
+    kps, descs = ext.extract_batch(imgs)
+    for im, k, d in zip(imgs, kps, descs):
+        ok, od = oe(im)
+        assert k.tobytes() == ok.tobytes() and (d == od).all()
+    # device-resident input with pitch == width (unaligned rows) and a padded pitch
+    for pitch in (501, 560):
+        buf = np.zeros((3, 397, pitch), np.uint8)
+        for i in range(3):
+            buf[i, :, :501] = imgs[i]
+        t = torch.from_numpy(buf).cuda()
+        ext.set_stream(torch.cuda.current_stream().cuda_stream)
+        ext.extract_batch_device(t.data_ptr(), 3, 501, 397, pitch=pitch, img_stride=pitch * 397)
+        torch.cuda.synchronize()
+        for i in range(3):
+            k, d = ext.batch_fetch(i)
+            ok, od = oe(imgs[i])
+            assert k.tobytes() == ok.tobytes() and (d == od).all()
+        ext.set_stream(0)
+    ext.close()
+
+
+def test_pyramid_with_reference_border(oracle, euroc_l):
+    """mvImagePyramid with its 19-px BORDER_REFLECT_101 frame (ORBextractor.cc:1182-1197)"""
+    import gf_orb_slam2_amd as G
+    ext = G.ORBextractor(2000, 1.2, 8, 20, 7)
+    oe = oracle.OracleExtractor(2000, 1.2, 8, 20, 7)
+    ext.ComputePyramid(euroc_l)
+    oe.compute_pyramid(euroc_l)
+    for l in range(8):
+        np.testing.assert_array_equal(ext.pyramid_level(l, border=19), oe.level(l, padded=True))
+        np.testing.assert_array_equal(ext.pyramid_level(l), oe.level(l))
+    ext.close()
+
+
+def test_projection_against_50k_map(oracle):
+    """config 4: 1920x1080 @4000 features, SearchByProjection against a 50 000-point synthetic local map"""
+    import gf_orb_slam2_amd as G
+    ext = G.ORBextractor(4000, 1.2, 8, 20, 7)
+    img = synth_frame(1920, 1080, 3)
+    kp, desc = ext(img)
+    rng = np.random.default_rng(7)
+    n, m = len(kp), 50000
+    mps = np.zeros(m, oracle.MAP_POINT_DTYPE)
+    mpd = rng.integers(0, 256, (m, 32), dtype=np.uint8)
+    nv = min(n, 3500)
+    vis = rng.choice(m, nv, replace=False)
+    src = rng.choice(n, nv, replace=False)
+    d = desc[src].copy()
+    for j in range(60):
+        sel = rng.random(nv) < rng.random(nv)
+        bits = rng.integers(0, 256, nv)
+        d[sel, bits[sel] >> 3] ^= (1 << (bits[sel] & 7)).astype(np.uint8)
+    mpd[vis] = d
+    mps["proj_x"] = rng.uniform(0, 1920, m); mps["proj_y"] = rng.uniform(0, 1080, m)
+    mps["proj_x"][vis] = kp["x"][src] + rng.normal(0, 2, nv)
+    mps["proj_y"][vis] = kp["y"][src] + rng.normal(0, 2, nv)
+    mps["level"] = rng.integers(0, 8, m); mps["level"][vis] = kp["octave"][src]
+    mps["proj_xr"] = mps["proj_x"] - 10
+    mps["view_cos"] = 1.0
+    mps["flags"] = 5
+    bounds = (0.0, 0.0, 1920.0, 1080.0)
+    sf = ext.GetScaleFactors()
+    ref = oracle.search_by_projection(kp, desc, None, sf, bounds, mps, mpd, 3.0, 0.8, None)
+    got = G.ORBmatcher(0.8, True, extractor=ext).SearchByProjection(kp, desc, None, sf, bounds, mps, mpd, 3.0, None)
+    assert got[0] == ref[0] and ref[0] > 1500
+    np.testing.assert_array_equal(got[1], ref[1])
+    np.testing.assert_array_equal(got[2], ref[2])
+    ext.close()
