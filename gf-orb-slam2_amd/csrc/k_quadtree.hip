@@ -17,6 +17,7 @@
 // One workgroup per (image, level); node tables live in LDS, keys and their node index in HBM
 // scratch (L2-resident: a level holds a few thousand candidates).
 #include "gfo_internal.h"
+#include <stdlib.h>
 
 #define QT_THREADS 256
 
@@ -24,24 +25,32 @@ struct QtBox {
     short ulx, uly, urx, bry;
 };
 
-// exclusive scan of vals[0..n) in place (LDS), returns the total; all threads call it
+// exclusive scan of vals[0..n) in place (LDS), returns the total; all threads call it.
+// Per-thread chunk sums are scanned inside each wave with lane shuffles; only the four wave totals
+// cross a workgroup barrier (3 barriers per scan).
 __device__ int qt_scan(int* vals, int n, int* part)
 {
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int chunk = (n + QT_THREADS - 1) / QT_THREADS;
     const int b = tid * chunk, e = min(b + chunk, n);
     int s = 0;
     for (int i = b; i < e; i++) s += vals[i];
-    part[tid] = s;
-    __syncthreads();
-    for (int off = 1; off < QT_THREADS; off <<= 1) {
-        int v = tid >= off ? part[tid - off] : 0;
-        __syncthreads();
-        part[tid] += v;
-        __syncthreads();
+    int incl = s;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int v = __shfl_up(incl, o);
+        if (lane >= o) incl += v;
     }
-    const int total = part[QT_THREADS - 1];
-    int run = part[tid] - s;
+    if (lane == 63) part[wave] = incl;
+    __syncthreads();
+    int wbase = 0, total = 0;
+#pragma unroll
+    for (int w = 0; w < QT_THREADS / 64; w++) {
+        const int t = part[w];
+        if (w < wave) wbase += t;
+        total += t;
+    }
+    int run = wbase + incl - s;
     for (int i = b; i < e; i++) {
         const int v = vals[i];
         vals[i] = run;
@@ -77,16 +86,16 @@ __global__ __launch_bounds__(QT_THREADS) void k_quadtree(const GfoGeom* __restri
                                                          const int* __restrict__ cand_cnt,
                                                          uint16_t* __restrict__ node_of_all,
                                                          uint32_t* __restrict__ sel, int* __restrict__ sel_cnt,
-                                                         int* __restrict__ flags, int ncap)
+                                                         int* __restrict__ flags, int ncap, int klds)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     const GfoGeom& g = *gp;
-    const int level = blockIdx.x, img = blockIdx.y, tid = threadIdx.x;
+    const int level = blockIdx.y, img = blockIdx.x, tid = threadIdx.x;  // level-major dispatch: the heavy level-0 blocks start first
     const GfoLevel& L = g.lv[level];
     const int N = L.quota;
     const int K = min(cand_cnt[(img * g.nlevels + level) * GFO_CNT_STRIDE], L.cand_cap);
-    const uint32_t* keys = cand + (long long)img * g.cand_img_stride + L.cand_off;
-    uint16_t* node_of = node_of_all + (long long)img * g.cand_img_stride + L.cand_off;
+    const uint32_t* gkeys = cand + (long long)img * g.cand_img_stride + L.cand_off;
+    uint16_t* gnode = node_of_all + (long long)img * g.cand_img_stride + L.cand_off;
     int* out_cnt = sel_cnt + img * g.nlevels + level;
     uint32_t* out = sel + (long long)img * g.total_sel_cap + L.sel_off;
     if (K == 0) {
@@ -108,6 +117,17 @@ __global__ __launch_bounds__(QT_THREADS) void k_quadtree(const GfoGeom* __restri
     int* npos = sc2 + ncap;           // new position of an unsplit node
     int* part = npos + ncap;          // QT_THREADS
     __shared__ int s_cut, s_misc;
+    // Keys and their node index live in LDS when the level's candidate list fits (the usual case: a few
+    // thousand keys); every pass then runs at LDS latency.  Larger lists stay in HBM/L2 (same code, generic
+    // pointers).
+    uint32_t* lkeys = reinterpret_cast<uint32_t*>(part + QT_THREADS);
+    uint16_t* lnode = reinterpret_cast<uint16_t*>(lkeys + klds);
+    const bool in_lds = K <= klds;
+    const uint32_t* keys = in_lds ? lkeys : gkeys;
+    uint16_t* node_of = in_lds ? lnode : gnode;
+    if (in_lds) {
+        for (int k = tid; k < K; k += QT_THREADS) lkeys[k] = gkeys[k];
+    }
 
     // ---- roots (:543-585) ----
     const int nini = L.n_ini;
@@ -348,23 +368,28 @@ __global__ __launch_bounds__(QT_THREADS) void k_quadtree(const GfoGeom* __restri
     if (tid == 0) *out_cnt = n;
 }
 
-size_t gfo_quadtree_lds_bytes(int ncap)
+size_t gfo_quadtree_lds_bytes(int ncap, int klds)
 {
     int p2 = 1;
     while (p2 < ncap) p2 <<= 1;
-    return (size_t)p2 * 8 + (size_t)ncap * (2 * sizeof(QtBox) + 2 * 4 + 4 * 4 + 4 * 4 + 3 * 4) + QT_THREADS * 4 + 64;
+    return (size_t)p2 * 8 + (size_t)ncap * (2 * sizeof(QtBox) + 2 * 4 + 4 * 4 + 4 * 4 + 3 * 4) + QT_THREADS * 4 + (size_t)klds * 6 + 64;
 }
 
 void gfo_launch_quadtree(gfo_ctx* c, int nimg)
 {
     int ncap = 0;
     for (int l = 0; l < c->g.nlevels; l++) ncap = c->g.lv[l].node_cap > ncap ? c->g.lv[l].node_cap : ncap;
-    const size_t lds = gfo_quadtree_lds_bytes(ncap);
+    // keys kept in LDS (6 B each).  Measured on MI355X: 0 (keys in L2, 4 workgroups per CU) beats 6144
+    // (LDS-resident keys, 2 workgroups per CU) -- the kernel is barrier-bound, not load-bound.
+    static const int klds_env = getenv("GFO_QT_KLDS") ? atoi(getenv("GFO_QT_KLDS")) : 0;
+    int klds = klds_env;
+    while (klds > 0 && gfo_quadtree_lds_bytes(ncap, klds) > 150 * 1024) klds -= 1024;
+    const size_t lds = gfo_quadtree_lds_bytes(ncap, klds);
     if (lds > 64 * 1024)
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_quadtree), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    dim3 grid(c->g.nlevels, nimg);
+    dim3 grid(nimg, c->g.nlevels);
     gfo_prof_begin(c, ST_QUADTREE);
     hipLaunchKernelGGL(k_quadtree, grid, dim3(QT_THREADS), lds, c->stream, c->d_geom, c->d_cand, c->d_cand_cnt,
-                       c->d_node_of, c->d_sel, c->d_sel_cnt, c->d_flags, ncap);
+                       c->d_node_of, c->d_sel, c->d_sel_cnt, c->d_flags, ncap, klds);
     gfo_prof_end(c);
 }
