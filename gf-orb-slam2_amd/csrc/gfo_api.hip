@@ -422,6 +422,10 @@ static int check_flags(gfo_ctx* c)
     int f[4] = {0, 0, 0, 0};
     HIP_TRY(c, hipMemcpyAsync(f, c->d_flags, sizeof f, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (getenv("GFO_FAST_STOP") && atoi(getenv("GFO_FAST_STOP")) == 9) {
+        fprintf(stderr, "[gfo] FAST selectivity: scan px %d, after compass %d, after pair test %d\n", f[1], f[2], f[3]);
+        (void)hipMemsetAsync(c->d_flags, 0, sizeof f, c->stream);
+    }
     if (f[0]) {
         (void)hipMemsetAsync(c->d_flags, 0, sizeof f, c->stream);
         return fail(c, GFO_ERR_OVERFLOW, "internal buffer overflow (flags 0x%x: 1 candidates, 2 quadtree nodes, 4 selection, 8 keypoints)", f[0]);

@@ -7,7 +7,7 @@
 // COMPACTION between the stages, so the expensive stages run with all 64 lanes busy:
 //   A  every pixel      : compass test -- any 9-arc of the 16-ring holds >= 2 of the ring pixels
 //                         {0,4,8,12}, so a corner needs two of them beyond the threshold (5 LDS reads)
-//   B1 survivors of A   : OpenCV's opposite-pair test on the full ring (FAST_NEON.cc:205-225 mirror)
+//   B1 survivors of A   : the exact 9-contiguous-of-16 test at min(iniTh, minTh) on bit masks of the ring
 //   B2 survivors of B1  : the score S = max over the sixteen 9-arcs of min |v - ring| (common sign)
 //   N  survivors of B1  : strict 3x3 local maximum of S inside the cell's scan area
 //   E  maxima           : append (x, y, S-1) for S > iniThFAST, or S > minThFAST when the cell
@@ -57,20 +57,31 @@ __device__ __forceinline__ void ring_diffs(const uint8_t* __restrict__ c, int tp
     d[15] = v - c[3 * tp - 1];
 }
 
-// OpenCV's opposite-pair prefilter (necessary for S > tq): every opposite pair must hold a pixel
-// beyond the threshold.  min_k max(d_k, d_k+8) > tq  <=> dark side possible;  max_k min(...) < -tq
-// <=> bright side possible.  Returns bit0 = dark, bit1 = bright.
-__device__ __forceinline__ int pair_test(const uint8_t* __restrict__ c, int tp, int tq)
+// Exact FAST-9 test at threshold tq: bit k of the dark (bright) mask says ring pixel k is darker
+// (brighter) than the centre by more than tq; a corner needs 9 contiguous set bits on the circular
+// 16-bit mask (FAST_NEON.cc:226-259 mirror: the count > K run test).  Returns bit0 = dark arc exists,
+// bit1 = bright arc exists.
+__device__ __forceinline__ bool has_arc9(unsigned m16)
+{
+    unsigned w = m16 | (m16 << 16);
+    unsigned r = w & (w >> 1);
+    r &= r >> 2;
+    r &= r >> 4;
+    r &= w >> 8;
+    return (r & 0xFFFFu) != 0;
+}
+
+__device__ __forceinline__ int corner_test(const uint8_t* __restrict__ c, int tp, int tq)
 {
     int d[16];
     ring_diffs(c, tp, d);
-    int mn = 255, mx = -255;
+    unsigned md = 0, mb = 0;
 #pragma unroll
-    for (int k = 0; k < 8; k++) {
-        mn = min(mn, max(d[k], d[k + 8]));
-        mx = max(mx, min(d[k], d[k + 8]));
+    for (int k = 0; k < 16; k++) {
+        md |= (unsigned)(d[k] > tq) << k;
+        mb |= (unsigned)(d[k] < -tq) << k;
     }
-    return (mn > tq ? 1 : 0) | (mx < -tq ? 2 : 0);
+    return (has_arc9(md) ? 1 : 0) | (has_arc9(mb) ? 2 : 0);
 }
 
 typedef short __attribute__((ext_vector_type(2))) s16x2;
@@ -179,9 +190,15 @@ __global__ __launch_bounds__(256) void k_fast(const GfoGeom* __restrict__ gp, Gf
     }
     wave_sync();
     if (dbg_stop == 1) return;
-    const int tq = min(g.ini_th, g.min_th);
     const float inv_sw = 1.0f / (float)sw;
     const uint8_t* t0 = tile + 3 * TP + xoff + 3;  // scan pixel (0,0)
+    // The cascade runs at iniThFAST first; only a cell that yields no maximum there repeats it at
+    // minThFAST (ORBextractor.cc:811-818).  Scores left in the map by the first round are true S values,
+    // so the second round needs no re-initialisation (a stored S <= threshold never suppresses a corner).
+    int th = g.ini_th, total = 0, nb = 0;
+    for (int round = 0; round < 2; round++) {
+    const int tq = round == 0 ? g.ini_th : g.min_th;
+    th = tq;
     // ---- A: compass test over every scan pixel, compacted into qa ----
     // lanes map to (row, column) directly: two rows of up to 32 columns per step, or one of up to 64
     int na = 0;
@@ -209,8 +226,8 @@ __global__ __launch_bounds__(256) void k_fast(const GfoGeom* __restrict__ gp, Gf
     }
     wave_sync();
     if (dbg_stop == 2) { if (na == 12345) flags[1] = 1; return; }
-    // ---- B1: opposite-pair test on the survivors, compacted into qb ----
-    int nb = 0;
+    // ---- B1: exact 9-arc test at this round's threshold on the survivors, compacted into qb ----
+    nb = 0;
     {
         for (int i0 = 0; i0 < na; i0 += 64) {
             const int i = i0 + lane;
@@ -220,7 +237,7 @@ __global__ __launch_bounds__(256) void k_fast(const GfoGeom* __restrict__ gp, Gf
                 p = qa[i];
                 const int py = (int)(((float)p + 0.5f) * inv_sw);
                 const int px = p - py * sw;
-                pol = pair_test(t0 + py * TP + px, TP, tq);
+                pol = corner_test(t0 + py * TP + px, TP, tq);
             }
             const bool pass = pol != 0;
             const unsigned long long m = __ballot(pass);
@@ -244,29 +261,29 @@ __global__ __launch_bounds__(256) void k_fast(const GfoGeom* __restrict__ gp, Gf
         }
     }
     wave_sync();
-    if (dbg_stop == 4) return;
+    if (dbg_stop == 4 && round == 1) return;
+    if (dbg_stop == 9) { if (lane == 0) { atomicAdd(&flags[1], sw * sh); atomicAdd(&flags[2], na); atomicAdd(&flags[3], nb); } }
     // ---- N: strict local maxima of S (flag kept in bit 15 of the queue entry) ----
-    int n_ini = 0, n_min = 0;
+    int n_max = 0;
     for (int i0 = 0; i0 < nb; i0 += 64) {
         const int i = i0 + lane;
         bool mx = false;
-        int s = 0;
         if (i < nb) {
             const int p = qb[i] & 0x1FFF;
             const int py = (int)(((float)p + 0.5f) * inv_sw);
             const int px = p - py * sw;
             const uint8_t* q = smap + (py + 1) * SP + px + 1;
-            s = q[0];
-            mx = s >= 2 && s > q[-1] && s > q[1] && s > q[-SP - 1] && s > q[-SP] && s > q[-SP + 1] &&
+            const int s = q[0];
+            mx = s >= 2 && s > tq && s > q[-1] && s > q[1] && s > q[-SP - 1] && s > q[-SP] && s > q[-SP + 1] &&
                  s > q[SP - 1] && s > q[SP] && s > q[SP + 1];
-            if (mx) qb[i] = (unsigned short)(p | 0x8000);  // bit 15 = local maximum
+            if (mx) qb[i] = (unsigned short)(p | 0x8000);  // bit 15 = local maximum above the threshold
         }
-        n_ini += __popcll(__ballot(mx && s > g.ini_th));
-        n_min += __popcll(__ballot(mx && s > g.min_th));
+        n_max += __popcll(__ballot(mx));
     }
     wave_sync();
-    const int th = n_ini > 0 ? g.ini_th : g.min_th;  // ORBextractor.cc:811-818
-    const int total = n_ini > 0 ? n_ini : n_min;
+    total = n_max;
+    if (total > 0) break;
+    }  // round
     if (total == 0) return;
     int base = 0;
     int* cnt = cand_cnt + (img * g.nlevels + level) * GFO_CNT_STRIDE;
