@@ -224,13 +224,14 @@ static int plan(gfo_ctx* c, int w, int h, int batch)
         L.xtab_off = xtab;
         L.ytab_off = ytab;
         if (l > 0) {
-            xtab += L.w;
-            ytab += L.h;
+            xtab += (int)align_up(L.w + 3, 4) + 4;   // padded: see the table construction below
+            ytab += (int)align_up(L.h + 3, 4) + 4;
         }
         if (L.node_cap > 60000) return fail(c, GFO_ERR_INVALID, "level quota %d too large", L.quota);
     }
     if (max_cw - 6 > 64 || max_ch - 6 > 64)
         return fail(c, GFO_ERR_INVALID, "FAST cell %dx%d exceeds the per-wave plan", max_cw - 6, max_ch - 6);
+    const int xtab_n = xtab, ytab_n = ytab;
     g.total_cells = cell_base;
     g.total_tiles = tile_base;
     g.total_sel_cap = sel_off;
@@ -245,12 +246,27 @@ static int plan(gfo_ctx* c, int w, int h, int batch)
     g.cand_img_stride = align_up(cand_off, 64);
     if (g.kp_stride > 65535) return fail(c, GFO_ERR_INVALID, "more than 65535 keypoints per image are not supported");
 
-    // resize tables
-    std::vector<int> xofs(xtab > 0 ? xtab : 1), yofs(ytab > 0 ? ytab : 1);
-    std::vector<short> xcoef(2 * (xtab > 0 ? xtab : 1)), ycoef(2 * (ytab > 0 ? ytab : 1));
+    // resize tables: one {offset, coef0 | coef1 << 16} pair per output column / row, each level padded with
+    // 3 copies of its last entry and kept 16-byte aligned (k_resize reads a thread's 4 entries as two int4)
+    std::vector<int> xtabv(2 * (size_t)(xtab_n > 0 ? xtab_n : 4)), ytabv(2 * (size_t)(ytab_n > 0 ? ytab_n : 4));
     for (int l = 1; l < g.nlevels; l++) {
-        resize_tables(g.lv[l - 1].w, g.lv[l].w, &xofs[g.lv[l].xtab_off], &xcoef[2 * g.lv[l].xtab_off], true);
-        resize_tables(g.lv[l - 1].h, g.lv[l].h, &yofs[g.lv[l].ytab_off], &ycoef[2 * g.lv[l].ytab_off], false);
+        const int dw = g.lv[l].w, dh = g.lv[l].h;
+        std::vector<int> ofs(dw > dh ? dw : dh);
+        std::vector<short> coef(2 * ofs.size());
+        resize_tables(g.lv[l - 1].w, dw, ofs.data(), coef.data(), true);
+        for (int d = 0; d < dw + 3 + 4; d++) {
+            const int s_ = d < dw ? d : dw - 1;
+            if (g.lv[l].xtab_off + d >= xtab_n) break;
+            xtabv[2 * (g.lv[l].xtab_off + d)] = ofs[s_];
+            xtabv[2 * (g.lv[l].xtab_off + d) + 1] = (int)((unsigned short)coef[2 * s_] | ((unsigned)(unsigned short)coef[2 * s_ + 1] << 16));
+        }
+        resize_tables(g.lv[l - 1].h, dh, ofs.data(), coef.data(), false);
+        for (int d = 0; d < dh + 3 + 4; d++) {
+            const int s_ = d < dh ? d : dh - 1;
+            if (g.lv[l].ytab_off + d >= ytab_n) break;
+            ytabv[2 * (g.lv[l].ytab_off + d)] = ofs[s_];
+            ytabv[2 * (g.lv[l].ytab_off + d) + 1] = (int)((unsigned short)coef[2 * s_] | ((unsigned)(unsigned short)coef[2 * s_ + 1] << 16));
+        }
     }
     const size_t B = (size_t)batch;
     HIP_TRY(c, hipMalloc(&c->d_geom, sizeof(GfoGeom)));
@@ -266,10 +282,8 @@ static int plan(gfo_ctx* c, int w, int h, int batch)
     HIP_TRY(c, hipMalloc(&c->d_desc, B * (size_t)g.kp_stride * 32));
     HIP_TRY(c, hipMalloc(&c->d_kp_cnt, B * sizeof(int)));
     HIP_TRY(c, hipMalloc(&c->d_flags, 4 * sizeof(int)));
-    HIP_TRY(c, hipMalloc(&c->d_xofs, xofs.size() * sizeof(int)));
-    HIP_TRY(c, hipMalloc(&c->d_xcoef, xcoef.size() * sizeof(short)));
-    HIP_TRY(c, hipMalloc(&c->d_yofs, yofs.size() * sizeof(int)));
-    HIP_TRY(c, hipMalloc(&c->d_ycoef, ycoef.size() * sizeof(short)));
+    HIP_TRY(c, hipMalloc(&c->d_xofs, xtabv.size() * sizeof(int) + 64));
+    HIP_TRY(c, hipMalloc(&c->d_yofs, ytabv.size() * sizeof(int) + 64));
     HIP_TRY(c, hipMalloc(&c->d_scale, GFO_MAX_LEVELS * sizeof(float)));
     const size_t P = (B + 1) / 2;
     HIP_TRY(c, hipMalloc(&c->st.u_right, P * g.kp_stride * sizeof(float)));
@@ -285,10 +299,8 @@ static int plan(gfo_ctx* c, int w, int h, int batch)
     c->st_rows_cap = h + 64;
     HIP_TRY(c, hipMalloc(&c->st_sort.row_start, P * (size_t)(c->st_rows_cap + 1) * sizeof(int)));
     HIP_TRY(c, hipMemcpy(c->d_geom, &g, sizeof g, hipMemcpyHostToDevice));
-    HIP_TRY(c, hipMemcpy(c->d_xofs, xofs.data(), xofs.size() * sizeof(int), hipMemcpyHostToDevice));
-    HIP_TRY(c, hipMemcpy(c->d_xcoef, xcoef.data(), xcoef.size() * sizeof(short), hipMemcpyHostToDevice));
-    HIP_TRY(c, hipMemcpy(c->d_yofs, yofs.data(), yofs.size() * sizeof(int), hipMemcpyHostToDevice));
-    HIP_TRY(c, hipMemcpy(c->d_ycoef, ycoef.data(), ycoef.size() * sizeof(short), hipMemcpyHostToDevice));
+    HIP_TRY(c, hipMemcpy(c->d_xofs, xtabv.data(), xtabv.size() * sizeof(int), hipMemcpyHostToDevice));
+    HIP_TRY(c, hipMemcpy(c->d_yofs, ytabv.data(), ytabv.size() * sizeof(int), hipMemcpyHostToDevice));
     HIP_TRY(c, hipMemcpy(c->d_scale, c->scale.data(), g.nlevels * sizeof(float), hipMemcpyHostToDevice));
     HIP_TRY(c, hipMemset(c->d_flags, 0, 4 * sizeof(int)));
     c->cap_batch = batch;

@@ -200,28 +200,66 @@ __global__ __launch_bounds__(256) void k_fast(const GfoGeom* __restrict__ gp, Gf
     const int tq = round == 0 ? g.ini_th : g.min_th;
     th = tq;
     // ---- A: compass test over every scan pixel, compacted into qa ----
-    // lanes map to (row, column) directly: two rows of up to 32 columns per step, or one of up to 64
+    // A lane takes one aligned dword (4 pixels) of a tile row: centre, the rows 3 above/below and the
+    // dwords left/right come in as five LDS dword reads, and the "second largest / second smallest of the
+    // four compass differences" network runs on packed i16 (even and odd bytes of the dword), so four
+    // pixels cost ~40 VALU operations instead of ~100.
     int na = 0;
     {
-        const int lsh = sw <= 32 ? 5 : 6;
-        const int rows_per = 64 >> lsh;
-        const int lx = lane & ((1 << lsh) - 1), ly = lane >> lsh;
-        for (int y0 = 0; y0 < sh; y0 += rows_per) {
-            const int py = y0 + ly;
-            bool pass = false;
-            if (lx < sw && py < sh) {
-                const uint8_t* c = t0 + py * TP + lx;
-                const int v = c[0];
-                const int a = v - c[3 * TP], b = v - c[3], e = v - c[-3 * TP], f = v - c[-3];
-                // second largest / second smallest of the four differences
-                const int mxab = max(a, b), mnab = min(a, b), mxef = max(e, f), mnef = min(e, f);
-                const int second_hi = max(min(mxab, mxef), max(mnab, mnef));
-                const int second_lo = min(max(mnab, mnef), min(mxab, mxef));
-                pass = second_hi > tq || second_lo < -tq;
+        const uint32_t* t32 = reinterpret_cast<const uint32_t*>(tile);
+        const int tp4 = TP >> 2;
+        const int X0 = xoff + 3;                       // tile column of scan pixel 0
+        const int q_lo = X0 >> 2, q_hi = (X0 + sw - 1) >> 2;
+        const int nq = q_hi - q_lo + 1;
+        const float inv_nq = 1.0f / (float)nq;
+        const int ntask = nq * sh;
+        const unsigned tq2 = (unsigned)tq | ((unsigned)tq << 16);
+        for (int t0i = 0; t0i < ntask; t0i += 64) {
+            const int t = t0i + lane;
+            unsigned passbits = 0;  // bit j: pixel j of the dword passes
+            int py = 0, c0 = 0;
+            if (t < ntask) {
+                py = (int)(((float)t + 0.5f) * inv_nq);
+                const int q = q_lo + (t - py * nq);
+                const int idx = (py + 3) * tp4 + q;
+                const unsigned C = t32[idx], Wm = t32[idx - 1], Wp = t32[idx + 1];
+                const unsigned U = t32[idx + 3 * tp4], D = t32[idx - 3 * tp4];
+                const unsigned Lw = __builtin_amdgcn_alignbyte(C, Wm, 1);   // pixels at column-3
+                const unsigned Rw = __builtin_amdgcn_alignbyte(Wp, C, 3);   // pixels at column+3
+                unsigned sign = 0;
+#pragma unroll
+                for (int h = 0; h < 2; h++) {  // h = 0: bytes 0,2   h = 1: bytes 1,3
+                    const unsigned sh8 = 8 * h;
+                    const s16x2 vc = __builtin_bit_cast(s16x2, (C >> sh8) & 0x00FF00FFu);
+                    const s16x2 a = vc - __builtin_bit_cast(s16x2, (U >> sh8) & 0x00FF00FFu);
+                    const s16x2 b = vc - __builtin_bit_cast(s16x2, (Rw >> sh8) & 0x00FF00FFu);
+                    const s16x2 e = vc - __builtin_bit_cast(s16x2, (D >> sh8) & 0x00FF00FFu);
+                    const s16x2 f = vc - __builtin_bit_cast(s16x2, (Lw >> sh8) & 0x00FF00FFu);
+                    const s16x2 mxab = __builtin_elementwise_max(a, b), mnab = __builtin_elementwise_min(a, b);
+                    const s16x2 mxef = __builtin_elementwise_max(e, f), mnef = __builtin_elementwise_min(e, f);
+                    const s16x2 in1 = __builtin_elementwise_min(mxab, mxef), in2 = __builtin_elementwise_max(mnab, mnef);
+                    const s16x2 s_hi = __builtin_elementwise_max(in1, in2), s_lo = __builtin_elementwise_min(in2, in1);
+                    // sign bit set <=> second_hi > tq  or  second_lo < -tq
+                    const s16x2 t1 = __builtin_bit_cast(s16x2, tq2) - s_hi;
+                    const s16x2 t2 = s_lo + __builtin_bit_cast(s16x2, tq2);
+                    const unsigned sg = (__builtin_bit_cast(unsigned, t1) | __builtin_bit_cast(unsigned, t2)) & 0x80008000u;
+                    sign |= sg >> (h ? 0 : 1);  // h=0 -> bits 14,30 ; h=1 -> bits 15,31
+                }
+                // sign bits: pixel0 -> bit14, pixel1 -> bit15, pixel2 -> bit30, pixel3 -> bit31
+                passbits = ((sign >> 14) & 3u) | ((sign >> 28) & 12u);
+                c0 = 4 * q - X0;  // scan column of pixel 0 (may be negative)
+                unsigned valid = 0;
+#pragma unroll
+                for (int j = 0; j < 4; j++) valid |= (unsigned)(c0 + j >= 0 && c0 + j < sw) << j;
+                passbits &= valid;
             }
-            const unsigned long long m = __ballot(pass);
-            if (pass) qa[na + __popcll(m & ((1ull << lane) - 1))] = (unsigned short)(py * sw + lx);
-            na += __popcll(m);
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const bool pass = (passbits >> j) & 1u;
+                const unsigned long long m = __ballot(pass);
+                if (pass) qa[na + __popcll(m & ((1ull << lane) - 1))] = (unsigned short)(py * sw + c0 + j);
+                na += __popcll(m);
+            }
         }
     }
     wave_sync();

@@ -2,35 +2,36 @@
 // INTER_LINEAR) in OpenCV's 11-bit fixed point.  The coefficient tables (xofs/alpha, yofs/beta)
 // are built on the host in double exactly as cv::resize builds them (gfo_api.hip, plan()).
 //
-// HBM-bound byte work.  A thread owns 4 adjacent output columns and walks down a strip of 16 output
-// rows: the column tables are read once per thread, each source row segment is fetched as three
-// coalesced dwords (12 bytes cover the <= 11-byte footprint of 4 outputs for scale factors up to 2),
-// and the horizontal pass of a source row is reused when the next output row needs the same row
-// (sy advances by ~1.2 per output row, so ~1.2 source rows are filtered per output row, not 2).
+// HBM-bound byte work.  A thread owns a 4x4 block of output pixels: the column tables are read once,
+// the <= 6 source rows the block touches are fetched up front as three coalesced dwords each (12 bytes
+// cover the <= 11-byte footprint of 4 outputs for scale factors up to 2) so every load of the thread is
+// in flight at once, each source row is filtered horizontally once, and the four output rows are
+// blended from those sums.  (Blocks that touch more than 6 source rows -- scale factors above 1.5 --
+// take the row-by-row path.)
 // One launch per level (level l needs all of level l-1); all images of the batch per launch.
 // The 19-px reflect frame of the reference is never materialised: nothing on the extraction
 // path reads it (gfo_pyramid_level rebuilds it on request).
 #include "gfo_internal.h"
 
-#define RS_STRIP 16
+#define RS_STRIP 4
+#define RS_MAXR 6   // source rows a 4-row strip touches at scale factors up to 1.5 (4*1.5 rows)
 
 struct HQuad {
     int h[4];
 };
 
+// One source row segment -> the four horizontal sums.  `fast`: the 16 bytes at base_x cover every tap.
 __device__ __forceinline__ HQuad resize_hrow(const uint8_t* __restrict__ row, int base_x, bool fast, const int* sx,
                                              const int* a0, const int* a1, int sw)
 {
     HQuad q;
     if (fast) {
-        const unsigned w0 = *reinterpret_cast<const unsigned*>(row + base_x);
-        const unsigned w1 = *reinterpret_cast<const unsigned*>(row + base_x + 4);
-        const unsigned w2 = *reinterpret_cast<const unsigned*>(row + base_x + 8);
+        const uint4 w = *reinterpret_cast<const uint4*>(row + base_x);  // one 16-byte load (dword aligned)
 #pragma unroll
         for (int k = 0; k < 4; k++) {
-            const int off = sx[k] - base_x;  // 0..10
-            const unsigned lo = off < 4 ? w0 : (off < 8 ? w1 : w2);
-            const unsigned hi = off < 4 ? w1 : (off < 8 ? w2 : 0u);
+            const int off = sx[k] - base_x;  // 0..14
+            const unsigned lo = off < 4 ? w.x : (off < 8 ? w.y : (off < 12 ? w.z : w.w));
+            const unsigned hi = off < 4 ? w.y : (off < 8 ? w.z : (off < 12 ? w.w : 0u));
             const unsigned two = __builtin_amdgcn_alignbyte(hi, lo, off & 3);
             q.h[k] = (int)(two & 255u) * a0[k] + (int)((two >> 8) & 255u) * a1[k];
         }
@@ -44,17 +45,18 @@ __device__ __forceinline__ HQuad resize_hrow(const uint8_t* __restrict__ row, in
     return q;
 }
 
+// Tables: one int2 per output column / row = {source offset, coef0 | coef1 << 16}; every level's table is
+// padded with 3 copies of its last entry so a thread may read its 4 entries as two 16-byte loads.
 __global__ __launch_bounds__(256) void k_resize(const GfoGeom* __restrict__ gp, GfoInput in, uint8_t* __restrict__ pyr,
-                                                int level, const int* __restrict__ xofs_all,
-                                                const short* __restrict__ xcoef_all, const int* __restrict__ yofs_all,
-                                                const short* __restrict__ ycoef_all)
+                                                int level, const int2* __restrict__ xtab_all,
+                                                const int2* __restrict__ ytab_all)
 {
     const GfoGeom& g = *gp;
     const GfoLevel& L = g.lv[level];
     const int img = blockIdx.y;
     const int quads = (L.w + 3) >> 2;
     const int strips = (L.h + RS_STRIP - 1) / RS_STRIP;
-    // one wave = up to 64 quads of ONE strip, so the row tables and the row-reuse branch are wave-uniform
+    // one wave = up to 64 quads of ONE strip, so the row tables are wave-uniform
     const int wps = (quads + 63) >> 6;
     const int wv = __builtin_amdgcn_readfirstlane((blockIdx.x * 256 + threadIdx.x) >> 6);
     const int strip = wv / wps;
@@ -65,39 +67,72 @@ __global__ __launch_bounds__(256) void k_resize(const GfoGeom* __restrict__ gp, 
     const int sh = g.lv[level - 1].h, sw = g.lv[level - 1].w;
     uint8_t* dst = pyr + (long long)img * g.pyr_img_stride + L.plane_off;
 
-    const int* xofs = xofs_all + L.xtab_off;
-    const short* xcoef = xcoef_all + 2 * L.xtab_off;
     const int dx0 = quad * 4;
-    int sx[4], a0[4], a1[4];
+    const int4* xt = reinterpret_cast<const int4*>(xtab_all + L.xtab_off + dx0);
+    const int4 xa = xt[0], xb = xt[1];
+    int sx[4] = {xa.x, xa.z, xb.x, xb.z};
+    const int cw[4] = {xa.y, xa.w, xb.y, xb.w};
+    int a0[4], a1[4];
 #pragma unroll
     for (int k = 0; k < 4; k++) {
-        const int dx = min(dx0 + k, L.w - 1);
-        sx[k] = xofs[dx];
-        a0[k] = xcoef[2 * dx];
-        a1[k] = xcoef[2 * dx + 1];
+        a0[k] = cw[k] & 0xFFFF;
+        a1[k] = cw[k] >> 16;
     }
     const int base_x = sx[0] & ~3;
-    // three dwords must cover sx[3]+1 and stay inside the source row
-    const bool fast = (sx[3] + 1 - base_x) < 12 && base_x + 12 <= sw && sx[1] >= sx[0] && sx[2] >= sx[0] && sx[3] >= sx[0];
+    // sixteen bytes must cover sx[3]+1 and stay inside the source row
+    const bool fast = (sx[3] + 1 - base_x) < 16 && base_x + 16 <= sw;
     const int dy0 = strip * RS_STRIP, dy1 = min(dy0 + RS_STRIP, L.h);
-    int prev_row = -1;
-    HQuad prev;
-    prev.h[0] = prev.h[1] = prev.h[2] = prev.h[3] = 0;
-    for (int dy = dy0; dy < dy1; dy++) {
-        const int sy = yofs_all[L.ytab_off + dy];
-        const int b0 = ycoef_all[2 * (L.ytab_off + dy)], b1 = ycoef_all[2 * (L.ytab_off + dy) + 1];
-        const int sy0 = min(max(sy, 0), sh - 1), sy1 = min(max(sy + 1, 0), sh - 1);
-        const HQuad r0 = sy0 == prev_row ? prev : resize_hrow(src + (long long)sy0 * spitch, base_x, fast, sx, a0, a1, sw);
-        const HQuad r1 = sy1 == sy0 ? r0 : resize_hrow(src + (long long)sy1 * spitch, base_x, fast, sx, a0, a1, sw);
+    const int4* yt = reinterpret_cast<const int4*>(ytab_all + L.ytab_off + dy0);
+    const int4 ya = yt[0], yb = yt[1];
+    const int syv[4] = {ya.x, ya.z, yb.x, yb.z};
+    const int bw[4] = {ya.y, ya.w, yb.y, yb.w};
+    const int r_first = min(max(syv[0], 0), sh - 1);
+    const int r_last = min(max(syv[dy1 - dy0 - 1] + 1, 0), sh - 1);
+    if (r_last - r_first < RS_MAXR) {
+        // all source rows of the block in flight together
+        HQuad rows[RS_MAXR];
+#pragma unroll
+        for (int k = 0; k < RS_MAXR; k++) {
+            const int r = min(r_first + k, sh - 1);
+            rows[k] = resize_hrow(src + (long long)r * spitch, base_x, fast, sx, a0, a1, sw);
+        }
+#pragma unroll
+        for (int j = 0; j < RS_STRIP; j++) {
+            const int dy = dy0 + j;
+            if (dy >= dy1) break;
+            const int b0 = bw[j] & 0xFFFF, b1 = bw[j] >> 16;
+            const int i0 = min(max(syv[j], 0), sh - 1) - r_first, i1 = min(max(syv[j] + 1, 0), sh - 1) - r_first;
+            unsigned packed = 0;
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                int h0 = rows[0].h[k], h1 = rows[0].h[k];
+#pragma unroll
+                for (int m = 1; m < RS_MAXR; m++) {  // register select (no dynamic indexing of the row array)
+                    h0 = i0 == m ? rows[m].h[k] : h0;
+                    h1 = i1 == m ? rows[m].h[k] : h1;
+                }
+                const int v = (((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2) >> 2;
+                packed |= (unsigned)(v & 255) << (8 * k);
+            }
+            *reinterpret_cast<unsigned*>(dst + (long long)dy * L.pitch + dx0) = packed;  // pitch multiple of 64: tail dword stays in-row
+        }
+        return;
+    }
+#pragma unroll
+    for (int j = 0; j < RS_STRIP; j++) {  // steep scale factors: row by row
+        const int dy = dy0 + j;
+        if (dy >= dy1) break;
+        const int b0 = bw[j] & 0xFFFF, b1 = bw[j] >> 16;
+        const int sy0 = min(max(syv[j], 0), sh - 1), sy1 = min(max(syv[j] + 1, 0), sh - 1);
+        const HQuad r0 = resize_hrow(src + (long long)sy0 * spitch, base_x, fast, sx, a0, a1, sw);
+        const HQuad r1 = resize_hrow(src + (long long)sy1 * spitch, base_x, fast, sx, a0, a1, sw);
         unsigned packed = 0;
 #pragma unroll
         for (int k = 0; k < 4; k++) {
             const int v = (((b0 * (r0.h[k] >> 4)) >> 16) + ((b1 * (r1.h[k] >> 4)) >> 16) + 2) >> 2;
             packed |= (unsigned)(v & 255) << (8 * k);
         }
-        *reinterpret_cast<unsigned*>(dst + (long long)dy * L.pitch + dx0) = packed;  // pitch multiple of 64: tail dword stays in-row
-        prev = r1;
-        prev_row = sy1;
+        *reinterpret_cast<unsigned*>(dst + (long long)dy * L.pitch + dx0) = packed;
     }
 }
 
@@ -108,7 +143,7 @@ void gfo_launch_resize(gfo_ctx* c, const GfoInput& in, int level, int nimg)
     const int waves = ((quads + 63) / 64) * strips;
     dim3 grid((waves + 3) / 4, nimg);
     gfo_prof_begin(c, ST_RESIZE);
-    hipLaunchKernelGGL(k_resize, grid, dim3(256), 0, c->stream, c->d_geom, in, c->d_pyr, level, c->d_xofs, c->d_xcoef,
-                       c->d_yofs, c->d_ycoef);
+    hipLaunchKernelGGL(k_resize, grid, dim3(256), 0, c->stream, c->d_geom, in, c->d_pyr, level,
+                       reinterpret_cast<const int2*>(c->d_xofs), reinterpret_cast<const int2*>(c->d_yofs));
     gfo_prof_end(c);
 }

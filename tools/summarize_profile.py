@@ -55,6 +55,23 @@ def main():
                     acc[short(row["Kernel_Name"])].append(float(row["Counter_Value"]))
         out[cname] = {k: {"launches": len(v), "avg_per_launch": sum(v) / len(v)} for k, v in acc.items()}
     json.dump(out, open(os.path.join(dst, f"profile_{tag}.json"), "w"), indent=1, sort_keys=True)
+    # per-launch HBM traffic of each pipeline stage, in bytes, for bench.py's roofline.traffic.
+    # rocprofv3 reports FETCH_SIZE / WRITE_SIZE in KiB.  Calibration on this code's own access pattern
+    # (4 B per lane): k_fast reads every level exactly once and FETCH_SIZE*1024 comes out at 1.00-1.03x
+    # that byte count, so no 2x correction is applied (the gfx950 halving concerns 16 B/lane streams).
+    stage_of = {"k_resize": "resize", "k_blur": "blur", "k_fast": "fast", "k_quadtree": "quadtree",
+                "k_orient_desc": "orient_desc", "k_stereo_bucket": "stereo_bucket", "k_stereo_match": "stereo_match",
+                "k_stereo_cut": "stereo_cut"}
+    traffic = {}
+    for k, st in stage_of.items():
+        f_ = out["FETCH_SIZE"].get(k, {}).get("avg_per_launch")
+        w_ = out["WRITE_SIZE"].get(k, {}).get("avg_per_launch")
+        if f_ is not None and w_ is not None:
+            traffic[st] = int((f_ + w_) * 1024)
+    meta = {"tag": tag, "workload": os.environ.get("GFO_PROF_WORKLOAD", "stereo752"), "batch": int(os.environ.get("GFO_PROF_BATCH", "128")),
+            "hbm_bytes_per_launch": traffic, "note": "FETCH_SIZE+WRITE_SIZE (KiB) x 1024, separate --pmc passes, averaged per launch"}
+    json.dump(meta, open(os.path.join(dst, f"traffic_{tag}.json"), "w"), indent=1, sort_keys=True)
+    json.dump(meta, open(os.path.join(dst, "traffic_latest.json"), "w"), indent=1, sort_keys=True)
     print(open(os.path.join(dst, f"kernel_stats_{tag}.csv")).read())
     for cname in ("FETCH_SIZE", "WRITE_SIZE"):
         for k, v in sorted(out[cname].items()):
