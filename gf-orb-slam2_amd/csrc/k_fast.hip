@@ -5,8 +5,8 @@
 // One wavefront owns one 30-px cell (+6 px overlap, +3 px ring halo): the cell's pixels are
 // staged in LDS once (aligned dword loads) and the wave runs a filter cascade with WAVE-LEVEL
 // COMPACTION between the stages, so the expensive stages run with all 64 lanes busy:
-//   A  every pixel      : compass test -- any 9-arc of the 16-ring holds >= 2 of the ring pixels
-//                         {0,4,8,12}, so a corner needs two of them beyond the threshold (5 LDS reads)
+//   A  every pixel      : compass test -- a 9-arc of the 16-ring holds a pixel of every opposite pair, so
+//                         (ring 0 or 8) and (ring 4 or 12) must both be beyond the threshold (5 LDS reads)
 //   B1 survivors of A   : the exact 9-contiguous-of-16 test at min(iniTh, minTh) on bit masks of the ring
 //   B2 survivors of B1  : the score S = max over the sixteen 9-arcs of min |v - ring| (common sign)
 //   N  survivors of B1  : strict 3x3 local maximum of S inside the cell's scan area
@@ -235,11 +235,10 @@ __global__ __launch_bounds__(256) void k_fast(const GfoGeom* __restrict__ gp, Gf
                     const s16x2 b = vc - __builtin_bit_cast(s16x2, (Rw >> sh8) & 0x00FF00FFu);
                     const s16x2 e = vc - __builtin_bit_cast(s16x2, (D >> sh8) & 0x00FF00FFu);
                     const s16x2 f = vc - __builtin_bit_cast(s16x2, (Lw >> sh8) & 0x00FF00FFu);
-                    const s16x2 mxab = __builtin_elementwise_max(a, b), mnab = __builtin_elementwise_min(a, b);
-                    const s16x2 mxef = __builtin_elementwise_max(e, f), mnef = __builtin_elementwise_min(e, f);
-                    const s16x2 in1 = __builtin_elementwise_min(mxab, mxef), in2 = __builtin_elementwise_max(mnab, mnef);
-                    const s16x2 s_hi = __builtin_elementwise_max(in1, in2), s_lo = __builtin_elementwise_min(in2, in1);
-                    // sign bit set <=> second_hi > tq  or  second_lo < -tq
+                    // a 9-arc holds at least one pixel of every opposite pair: (a,e) = ring 0/8, (b,f) = ring 4/12
+                    const s16x2 s_hi = __builtin_elementwise_min(__builtin_elementwise_max(a, e), __builtin_elementwise_max(b, f));
+                    const s16x2 s_lo = __builtin_elementwise_max(__builtin_elementwise_min(a, e), __builtin_elementwise_min(b, f));
+                    // sign bit set <=> both pairs hold a darker pixel (s_hi > tq) or both a brighter one (s_lo < -tq)
                     const s16x2 t1 = __builtin_bit_cast(s16x2, tq2) - s_hi;
                     const s16x2 t2 = s_lo + __builtin_bit_cast(s16x2, tq2);
                     const unsigned sg = (__builtin_bit_cast(unsigned, t1) | __builtin_bit_cast(unsigned, t2)) & 0x80008000u;
