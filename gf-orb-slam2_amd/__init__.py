@@ -4,7 +4,7 @@ The product is `libgfo.so` (HIP kernels for gfx950 behind the C ABI of include/g
 package is the thin host layer tests and bench.py drive it through.  It never imports the CPU
 oracle and has no CPU fallback: without the built library and a gfx950 device it raises.
 """
-from ._lib import GfoError, KEYPOINT_DTYPE, MAP_POINT_DTYPE, lib_path, load_library  # noqa: F401
+from ._lib import GfoError, KEYPOINT_DTYPE, MAP_POINT_DTYPE, PROJ_QUERY_DTYPE, lib_path, load_library  # noqa: F401
 from .extractor import ORBextractor  # noqa: F401
 from .matcher import ORBmatcher, StereoParams, FrameBounds  # noqa: F401
 from .build import build_library  # noqa: F401

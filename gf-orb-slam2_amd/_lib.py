@@ -10,6 +10,8 @@ KEYPOINT_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle"
                            ("response", "<f4"), ("octave", "<i4"), ("class_id", "<i4")])
 MAP_POINT_DTYPE = np.dtype([("proj_x", "<f4"), ("proj_y", "<f4"), ("proj_xr", "<f4"),
                             ("view_cos", "<f4"), ("level", "<i4"), ("flags", "<i4")])
+PROJ_QUERY_DTYPE = np.dtype([("u", "<f4"), ("v", "<f4"), ("ur", "<f4"), ("radius", "<f4"), ("min_level", "<i4"),
+                             ("max_level", "<i4"), ("angle", "<f4"), ("flags", "<i4")])
 GFO_MAX_LEVELS = 16
 GFO_STAGE_MAX = 16
 
@@ -33,6 +35,10 @@ class FrameBoundsC(C.Structure):
     _fields_ = [("min_x", C.c_float), ("min_y", C.c_float), ("max_x", C.c_float), ("max_y", C.c_float)]
 
 
+class ProjModeC(C.Structure):
+    _fields_ = [("use_ratio", C.c_int32), ("nn_ratio", C.c_float), ("th_dist", C.c_int32), ("check_orientation", C.c_int32)]
+
+
 class FeatureVectorC(C.Structure):
     _fields_ = [("node_ids", C.c_void_p), ("node_start", C.c_void_p), ("items", C.c_void_p), ("n_nodes", C.c_int32)]
 
@@ -47,7 +53,7 @@ SYMBOLS = [
     "gfo_ctx_synchronize", "gfo_ctx_tables", "gfo_ctx_max_keypoints", "gfo_extract", "gfo_extract_batch",
     "gfo_extract_batch_device", "gfo_batch_counts", "gfo_batch_fetch", "gfo_batch_device_views",
     "gfo_compute_pyramid", "gfo_pyramid_level", "gfo_hamming256", "gfo_stereo_match",
-    "gfo_stereo_match_batch", "gfo_stereo_fetch", "gfo_search_by_projection", "gfo_search_by_bow", "gfo_profile_enable",
+    "gfo_stereo_match_batch", "gfo_stereo_fetch", "gfo_search_by_projection", "gfo_search_by_projection_queries", "gfo_search_by_bow", "gfo_profile_enable",
     "gfo_profile_read", "gfo_debug_blurred_level", "gfo_debug_level_candidates",
 ]
 
@@ -116,6 +122,8 @@ def load_library():
     L.gfo_stereo_match_batch.argtypes = [vp, C.POINTER(StereoParamsC)]
     L.gfo_stereo_fetch.argtypes = [vp, i, vp, vp, vp, vp, i, ip]
     L.gfo_search_by_projection.argtypes = [vp, vp, vp, vp, i, vp, i, C.POINTER(FrameBoundsC), vp, vp, i, f, f, vp, vp, vp, ip]
+    L.gfo_search_by_projection_queries.argtypes = [vp, vp, vp, vp, vp, i, C.POINTER(FrameBoundsC), vp, vp, i, C.POINTER(ProjModeC),
+                                                   vp, vp, vp, ip]
     L.gfo_search_by_bow.argtypes = [vp, vp, vp, vp, i, C.POINTER(FeatureVectorC), vp, vp, i, C.POINTER(FeatureVectorC), f, i, vp, ip]
     L.gfo_profile_enable.argtypes = [vp, i]
     L.gfo_profile_read.argtypes = [vp, C.POINTER(StageTime), i, ip, i]

@@ -30,13 +30,16 @@ struct ProjArgs {
     const float* u_right;     // may be null
     const uint8_t* taken0;    // may be null
     int n;
-    const float* scale;
     gfo_frame_bounds fb;
     float inv_w, inv_h;
-    const gfo_map_point* mps;
+    const gfo_proj_query* q;  // one per projected map point, in the reference's visiting order
     const uint8_t* mp_desc;
     int m;
-    float th, nn_ratio;
+    int use_ratio;
+    float nn_ratio;
+    int th_dist;
+    const float* kp_angle;    // rotation check only
+    int* rot_bin;             // [m] histogram bin of an accepted query, -1 otherwise
     // grid
     int* cell_start;          // [NCELL+1]
     int* cell_items;          // [n]
@@ -117,17 +120,14 @@ __global__ __launch_bounds__(256) void k_project_eval(ProjArgs a)
         if (slot >= a.counters[0]) return;
         iMP = a.live[slot];
     }
-    const gfo_map_point mp = a.mps[iMP];
+    const gfo_proj_query mp = a.q[iMP];
     int new_pick = -1, new_dist = 256;
     bool is_live = false;
-    if ((mp.flags & 1) && !(mp.flags & 2)) {  // mbTrackInView && !isBad(), :163-167
-        const int lvl = mp.level;
-        float r = (double)mp.view_cos > 0.998 ? 2.5f : 4.0f;  // RadiusByViewingCos, :243-249
-        if (a.th != 1.0f) r *= a.th;
-        const float rs = r * a.scale[lvl];
-        // GetFeaturesInArea(projX, projY, rs, lvl-1, lvl), Frame.cc:593-646
-        const float x = mp.proj_x, y = mp.proj_y;
-        const int minLevel = lvl - 1, maxLevel = lvl;
+    if (mp.flags & 1) {  // visible and usable (mbTrackInView && !isBad(), :163-167 / :1467-1490)
+        const float rs = mp.radius;
+        // GetFeaturesInArea(u, v, rs, minLevel, maxLevel), Frame.cc:593-646
+        const float x = mp.u, y = mp.v;
+        const int minLevel = mp.min_level, maxLevel = mp.max_level;
         int cx0 = max(0, (int)floorf((x - a.fb.min_x - rs) * a.inv_w));
         int cx1 = min(GRID_COLS - 1, (int)ceilf((x - a.fb.min_x + rs) * a.inv_w));
         int cy0 = max(0, (int)floorf((y - a.fb.min_y - rs) * a.inv_h));
@@ -153,7 +153,7 @@ __global__ __launch_bounds__(256) void k_project_eval(ProjArgs a)
                     if (!ROUND0) blocked = blocked || a.block_by[i] < iMP;
                     if (blocked) continue;
                     if (a.u_right && a.u_right[i] > 0) {  // :201-206
-                        const float er = fabsf(mp.proj_xr - a.u_right[i]);
+                        const float er = fabsf(mp.ur - a.u_right[i]);
                         if (er > rs) continue;
                     }
                     const unsigned dist = (unsigned)hamming_u4(a0, a1, reinterpret_cast<const uint4*>(a.desc + (long long)i * 32));
@@ -177,10 +177,10 @@ __global__ __launch_bounds__(256) void k_project_eval(ProjArgs a)
             if (k1 != ~0ull) {
                 const int bestDist = (int)(k1 >> 32);
                 const int bestIdx = (int)(k1 & 0xFFFFF);
-                if (bestDist <= TH_HIGH) {  // :228
+                if (bestDist <= a.th_dist) {  // :228 / :1536
                     is_live = true;
                     bool accept = true;
-                    if (k2 != ~0ull) {
+                    if (a.use_ratio && k2 != ~0ull) {
                         const int bestDist2 = (int)(k2 >> 32);
                         const int idx2 = (int)(k2 & 0xFFFFF);
                         const int bestLevel = a.kp[bestIdx].octave, bestLevel2 = a.kp[idx2].octave;
@@ -218,7 +218,7 @@ __global__ void k_project_claims(ProjArgs a, int nlive)
     if (t >= nlive) return;
     const int iMP = a.live[t];
     const int k = a.pick[iMP];
-    if (k >= 0 && (a.mps[iMP].flags & 4)) atomicMin(&a.block_by[k], iMP);
+    if (k >= 0 && (a.q[iMP].flags & 4)) atomicMin(&a.block_by[k], iMP);
 }
 
 __global__ void k_project_commit(ProjArgs a, int nlive)
@@ -254,6 +254,61 @@ __global__ void k_project_score(ProjArgs a, int nlive)
 
 static inline size_t al256(size_t v) { return (v + 255) / 256 * 256; }
 
+#define HISTO_LENGTH 30  // ORBmatcher.cc:59
+
+// rotation consistency (ORBmatcher.cc:1548-1591): bin of every accepted query, histogram, the reference's
+// three-maxima scan, then every query in a discarded bin clears the keypoint it took and costs one match.
+__global__ __launch_bounds__(256) void k_project_rotation(ProjArgs a, int nlive)
+{
+    __shared__ int histo[HISTO_LENGTH];
+    __shared__ int keep[3];
+    __shared__ int s_drop;
+    const int tid = threadIdx.x;
+    if (tid < HISTO_LENGTH) histo[tid] = 0;
+    if (tid == 0) s_drop = 0;
+    __syncthreads();
+    const float factor = 1.0f / HISTO_LENGTH;
+    for (int t = tid; t < nlive; t += 256) {
+        const int iq = a.live[t];
+        const int k = a.pick[iq];
+        int bin = -1;
+        if (k >= 0) {
+            float rot = a.q[iq].angle - a.kp_angle[k];
+            if (rot < 0.0f) rot += 360.0f;
+            bin = (int)roundf(rot * factor);
+            if (bin == HISTO_LENGTH) bin = 0;
+            atomicAdd(&histo[bin], 1);
+        }
+        a.rot_bin[iq] = bin;
+    }
+    __syncthreads();
+    if (tid == 0) {  // ComputeThreeMaxima, ORBmatcher.cc:1723-1764
+        int max1 = 0, max2 = 0, max3 = 0, ind1 = -1, ind2 = -1, ind3 = -1;
+        for (int i = 0; i < HISTO_LENGTH; i++) {
+            const int s = histo[i];
+            if (s > max1) { max3 = max2; max2 = max1; max1 = s; ind3 = ind2; ind2 = ind1; ind1 = i; }
+            else if (s > max2) { max3 = max2; max2 = s; ind3 = ind2; ind2 = i; }
+            else if (s > max3) { max3 = s; ind3 = i; }
+        }
+        if ((float)max2 < 0.1f * (float)max1) { ind2 = -1; ind3 = -1; }
+        else if ((float)max3 < 0.1f * (float)max1) ind3 = -1;
+        keep[0] = ind1; keep[1] = ind2; keep[2] = ind3;
+    }
+    __syncthreads();
+    int drop = 0;
+    for (int t = tid; t < nlive; t += 256) {
+        const int iq = a.live[t];
+        const int b = a.rot_bin[iq];
+        if (b >= 0 && b != keep[0] && b != keep[1] && b != keep[2]) {
+            a.out_mp[a.pick[iq]] = -1;  // benign race: every writer stores -1
+            drop++;
+        }
+    }
+    if (drop) atomicAdd(&s_drop, drop);
+    __syncthreads();
+    if (tid == 0) a.counters[2] -= s_drop;
+}
+
 #define PTRY(c, expr)                                                                             \
     do {                                                                                          \
         hipError_t e_ = (expr);                                                                   \
@@ -263,14 +318,15 @@ static inline size_t al256(size_t v) { return (v + 255) / 256 * 256; }
         }                                                                                         \
     } while (0)
 
-extern "C" int gfo_search_by_projection(gfo_ctx* c, const gfo_keypoint* kp_un, const uint8_t* desc, const float* u_right,
-                                        int n, const float* sf, int nlevels, const gfo_frame_bounds* fb,
-                                        const gfo_map_point* mps, const uint8_t* mp_desc, int m, float th, float nn_ratio,
-                                        const uint8_t* kp_taken, int32_t* out_mp, int32_t* out_score, int* nmatches)
+extern "C" int gfo_search_by_projection_queries(gfo_ctx* c, const gfo_keypoint* kp_un, const uint8_t* desc,
+                                                const float* u_right, const float* kp_angle, int n,
+                                                const gfo_frame_bounds* fb, const gfo_proj_query* queries,
+                                                const uint8_t* q_desc, int m, const gfo_proj_mode* mode,
+                                                const uint8_t* kp_taken, int32_t* out_mp, int32_t* out_score, int* nmatches)
 {
     if (!c) return GFO_ERR_INVALID;
-    if (!fb || !sf || !out_mp || !out_score || !nmatches || n < 0 || m < 0 || nlevels < 1 || nlevels > GFO_MAX_LEVELS ||
-        (n > 0 && (!kp_un || !desc)) || (m > 0 && (!mps || !mp_desc))) {
+    if (!fb || !mode || !out_mp || !out_score || !nmatches || n < 0 || m < 0 || (n > 0 && (!kp_un || !desc)) ||
+        (m > 0 && (!queries || !q_desc)) || (mode->check_orientation && n > 0 && !kp_angle)) {
         c->err = "gfo_search_by_projection: bad argument";
         return GFO_ERR_INVALID;
     }
@@ -285,11 +341,11 @@ extern "C" int gfo_search_by_projection(gfo_ctx* c, const gfo_keypoint* kp_un, c
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = off; off = al256(off + bytes); return o; };
     const size_t o_kp = take(sizeof(gfo_keypoint) * n), o_desc = take(32 * (size_t)n), o_ur = take(4 * (size_t)n),
-                 o_tk = take(n), o_sf = take(4 * GFO_MAX_LEVELS), o_mps = take(sizeof(gfo_map_point) * m),
+                 o_tk = take(n), o_ang = take(4 * (size_t)n), o_q = take(sizeof(gfo_proj_query) * m),
                  o_mpd = take(32 * (size_t)m), o_cs = take(4 * (NCELL + 1)), o_ci = take(4 * (size_t)n),
                  o_kc = take(2 * (size_t)n), o_pick = take(8 * (size_t)m), o_pd = take(8 * (size_t)m),
                  o_live = take(4 * (size_t)m), o_cnt = take(16), o_bb = take(4 * (size_t)n), o_om = take(4 * (size_t)n),
-                 o_os = take(4 * (size_t)n);
+                 o_os = take(4 * (size_t)n), o_rb = take(4 * (size_t)m);
     if (off > c->scratch_bytes) {
         (void)hipStreamSynchronize(c->stream);
         if (c->d_scratch) (void)hipFree(c->d_scratch);
@@ -304,9 +360,9 @@ extern "C" int gfo_search_by_projection(gfo_ctx* c, const gfo_keypoint* kp_un, c
     PTRY(c, hipMemcpyAsync(S + o_desc, desc, 32 * (size_t)n, hipMemcpyHostToDevice, st));
     if (u_right) PTRY(c, hipMemcpyAsync(S + o_ur, u_right, 4 * (size_t)n, hipMemcpyHostToDevice, st));
     if (kp_taken) PTRY(c, hipMemcpyAsync(S + o_tk, kp_taken, n, hipMemcpyHostToDevice, st));
-    PTRY(c, hipMemcpyAsync(S + o_sf, sf, 4 * (size_t)nlevels, hipMemcpyHostToDevice, st));
-    PTRY(c, hipMemcpyAsync(S + o_mps, mps, sizeof(gfo_map_point) * m, hipMemcpyHostToDevice, st));
-    PTRY(c, hipMemcpyAsync(S + o_mpd, mp_desc, 32 * (size_t)m, hipMemcpyHostToDevice, st));
+    if (kp_angle) PTRY(c, hipMemcpyAsync(S + o_ang, kp_angle, 4 * (size_t)n, hipMemcpyHostToDevice, st));
+    PTRY(c, hipMemcpyAsync(S + o_q, queries, sizeof(gfo_proj_query) * m, hipMemcpyHostToDevice, st));
+    PTRY(c, hipMemcpyAsync(S + o_mpd, q_desc, 32 * (size_t)m, hipMemcpyHostToDevice, st));
     PTRY(c, hipMemsetAsync(S + o_cnt, 0, 16, st));
     PTRY(c, hipMemsetAsync(S + o_om, 0xFF, 4 * (size_t)n, st));
     PTRY(c, hipMemsetAsync(S + o_os, 0, 4 * (size_t)n, st));
@@ -316,15 +372,17 @@ extern "C" int gfo_search_by_projection(gfo_ctx* c, const gfo_keypoint* kp_un, c
     a.u_right = u_right ? (const float*)(S + o_ur) : nullptr;
     a.taken0 = kp_taken ? S + o_tk : nullptr;
     a.n = n;
-    a.scale = (const float*)(S + o_sf);
     a.fb = *fb;
     a.inv_w = (float)GRID_COLS / (fb->max_x - fb->min_x);  // Frame.cc:129-130
     a.inv_h = (float)GRID_ROWS / (fb->max_y - fb->min_y);
-    a.mps = (const gfo_map_point*)(S + o_mps);
+    a.q = (const gfo_proj_query*)(S + o_q);
     a.mp_desc = S + o_mpd;
     a.m = m;
-    a.th = th;
-    a.nn_ratio = nn_ratio;
+    a.use_ratio = mode->use_ratio;
+    a.nn_ratio = mode->nn_ratio;
+    a.th_dist = mode->th_dist;
+    a.kp_angle = (const float*)(S + o_ang);
+    a.rot_bin = (int*)(S + o_rb);
     a.cell_start = (int*)(S + o_cs);
     a.cell_items = (int*)(S + o_ci);
     a.kp_cell = (unsigned short*)(S + o_kc);
@@ -362,6 +420,7 @@ extern "C" int gfo_search_by_projection(gfo_ctx* c, const gfo_keypoint* kp_un, c
         }
         hipLaunchKernelGGL(k_project_owner, g1, b1, 0, st, a, nlive);
         hipLaunchKernelGGL(k_project_score, g1, b1, 0, st, a, nlive);
+        if (mode->check_orientation) hipLaunchKernelGGL(k_project_rotation, dim3(1), dim3(256), 0, st, a, nlive);
     }
     gfo_prof_end(c);
     PTRY(c, hipGetLastError());
@@ -372,4 +431,38 @@ extern "C" int gfo_search_by_projection(gfo_ctx* c, const gfo_keypoint* kp_un, c
     *nmatches = cnt[2];
     c->last_project_rounds = rounds + 1;
     return GFO_OK;
+}
+
+// ORBmatcher::SearchByProjection(Frame&, const vector<MapPoint*>&, th): every map point becomes a query with
+// r = RadiusByViewingCos(viewCos) (* th), window r * scale[level], levels [level-1, level] (ORBmatcher.cc:171-180).
+extern "C" int gfo_search_by_projection(gfo_ctx* c, const gfo_keypoint* kp_un, const uint8_t* desc, const float* u_right,
+                                        int n, const float* sf, int nlevels, const gfo_frame_bounds* fb,
+                                        const gfo_map_point* mps, const uint8_t* mp_desc, int m, float th, float nn_ratio,
+                                        const uint8_t* kp_taken, int32_t* out_mp, int32_t* out_score, int* nmatches)
+{
+    if (!c) return GFO_ERR_INVALID;
+    if (!sf || nlevels < 1 || nlevels > GFO_MAX_LEVELS || m < 0 || (m > 0 && !mps)) {
+        c->err = "gfo_search_by_projection: bad argument";
+        return GFO_ERR_INVALID;
+    }
+    std::vector<gfo_proj_query> q((size_t)(m > 0 ? m : 1));
+    const bool bFactor = th != 1.0f;
+    for (int i = 0; i < m; i++) {
+        const gfo_map_point& p = mps[i];
+        gfo_proj_query& d = q[i];
+        const int lvl = p.level;
+        float r = (double)p.view_cos > 0.998 ? 2.5f : 4.0f;  // RadiusByViewingCos, :243-249
+        if (bFactor) r *= th;
+        d.u = p.proj_x;
+        d.v = p.proj_y;
+        d.ur = p.proj_xr;
+        d.radius = (lvl >= 0 && lvl < nlevels) ? r * sf[lvl] : 0.f;
+        d.min_level = lvl - 1;
+        d.max_level = lvl;
+        d.angle = 0.f;
+        d.flags = (((p.flags & 1) && !(p.flags & 2) && lvl >= 0 && lvl < nlevels) ? 1 : 0) | (p.flags & 4);
+    }
+    gfo_proj_mode mode = {1, nn_ratio, TH_HIGH, 0};
+    return gfo_search_by_projection_queries(c, kp_un, desc, u_right, nullptr, n, fb, q.data(), mp_desc, m, &mode, kp_taken,
+                                            out_mp, out_score, nmatches);
 }

@@ -5,7 +5,7 @@ from collections import namedtuple
 
 import numpy as np
 
-from ._lib import (FeatureVectorC, FrameBoundsC, KEYPOINT_DTYPE, MAP_POINT_DTYPE, StereoParamsC, check, load_library, ptr)
+from ._lib import (FeatureVectorC, FrameBoundsC, KEYPOINT_DTYPE, PROJ_QUERY_DTYPE, ProjModeC, MAP_POINT_DTYPE, StereoParamsC, check, load_library, ptr)
 
 StereoParams = namedtuple("StereoParams", "n_rows mbf mb min_x")
 FrameBounds = namedtuple("FrameBounds", "min_x min_y max_x max_y")
@@ -114,3 +114,28 @@ class ORBmatcher:
                                                             C.byref(a), ptr(f_desc), ptr(f_angle), n_f, C.byref(b), self.mfNNratio,
                                                             1 if self.mbCheckOrientation else 0, ptr(out), C.byref(nm)))
         return nm.value, out[:n_f]
+
+    def SearchByProjectionQueries(self, keys_un, desc, u_right, kp_angle, bounds, queries, q_desc, use_ratio=False,
+                                  th_dist=None, kp_taken=None):
+        """The query form both projection overloads reduce to (gfo_search_by_projection_queries); with
+        use_ratio=False and mbCheckOrientation it is ORBmatcher::SearchByProjection(CurrentFrame, LastFrame, th, ...)
+        (ORBmatcher.cc:1440-1593) once the caller has projected the last frame's map points.
+        Returns (nmatches, out_query, out_score)."""
+        kp = np.ascontiguousarray(keys_un, KEYPOINT_DTYPE)
+        desc = np.ascontiguousarray(desc, np.uint8)
+        q = np.ascontiguousarray(queries, PROJ_QUERY_DTYPE)
+        qd = np.ascontiguousarray(q_desc, np.uint8)
+        n, m = len(kp), len(q)
+        u_right = None if u_right is None else np.ascontiguousarray(u_right, np.float32)
+        kp_angle = None if kp_angle is None else np.ascontiguousarray(kp_angle, np.float32)
+        kp_taken = None if kp_taken is None else np.ascontiguousarray(kp_taken, np.uint8)
+        fb = FrameBoundsC(*bounds)
+        mode = ProjModeC(1 if use_ratio else 0, self.mfNNratio, self.TH_HIGH if th_dist is None else th_dist,
+                         1 if self.mbCheckOrientation else 0)
+        out_q = np.full(max(n, 1), -1, np.int32)
+        out_s = np.zeros(max(n, 1), np.int32)
+        nm = C.c_int()
+        check(self._L, self._ctx, self._L.gfo_search_by_projection_queries(self._ctx, ptr(kp), ptr(desc), ptr(u_right), ptr(kp_angle), n,
+                                                                           C.byref(fb), ptr(q), ptr(qd), m, C.byref(mode), ptr(kp_taken),
+                                                                           ptr(out_q), ptr(out_s), C.byref(nm)))
+        return nm.value, out_q[:n], out_s[:n]

@@ -163,6 +163,35 @@ int gfo_search_by_projection(gfo_ctx* ctx, const gfo_keypoint* kp_un, const uint
                              const uint8_t* kp_taken, int32_t* out_mp, int32_t* out_score,
                              int* nmatches);
 
+/* Generalised projection search on explicit queries: the common core of
+ *   ORBmatcher::SearchByProjection(Frame& F, const vector<MapPoint*>&, th)                 ORBmatcher.cc:155-241
+ *   ORBmatcher::SearchByProjection(Frame& Cur, const Frame& Last, th, bMono, nVisible)     ORBmatcher.cc:1440-1593
+ * A query is one projected map point: where it lands (u, v, ur), how far to look (radius, the
+ * GetFeaturesInArea level window), its descriptor, and whether taking a keypoint blocks later queries
+ * (Observations() > 0).  Queries are processed in array order with the reference's serial semantics.
+ * Mode: use_ratio/nn_ratio = best-vs-second test of :228-231 (same-level rule included); th_dist = TH_HIGH
+ * (or ORBdist); check_orientation = the 30-bin rotation histogram of :1548-1591 between query.angle and
+ * kp_angle[] (ComputeThreeMaxima :1723-1764): a keypoint is cleared if ANY accepted query that took it falls
+ * in a discarded bin, and *nmatches drops once per such query, as the reference's loop does. */
+typedef struct {
+    float u, v, ur;                /* projection; ur is compared with u_right[] when that is > 0        */
+    float radius;                  /* window half-size = r passed to GetFeaturesInArea, and the ur gate */
+    int32_t min_level, max_level;  /* level window of GetFeaturesInArea (Frame.cc:593), -1 = open       */
+    float angle;                   /* source keypoint angle in degrees (rotation check only)            */
+    int32_t flags;                 /* bit0 active (visible, not bad), bit2 Observations() > 0           */
+} gfo_proj_query;
+typedef struct {
+    int32_t use_ratio;
+    float nn_ratio;
+    int32_t th_dist;
+    int32_t check_orientation;
+} gfo_proj_mode;
+int gfo_search_by_projection_queries(gfo_ctx* ctx, const gfo_keypoint* kp_un, const uint8_t* desc,
+                                     const float* u_right, const float* kp_angle, int n,
+                                     const gfo_frame_bounds* bounds, const gfo_proj_query* queries,
+                                     const uint8_t* q_desc, int m, const gfo_proj_mode* mode,
+                                     const uint8_t* kp_taken, int32_t* out_q, int32_t* out_score, int* nmatches);
+
 /* ORBmatcher::SearchByBoW(KeyFrame* pKF, Frame& F, vector<MapPoint*>& vpMapPointMatches)
  * include/ORBmatcher.h:272, src/ORBmatcher.cc:270-404.  The two DBoW2::FeatureVector maps
  * (Thirdparty/DBoW2/DBoW2/FeatureVector.h: map<NodeId, vector<unsigned>>) are passed flattened to CSR in

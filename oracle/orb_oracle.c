@@ -1083,3 +1083,86 @@ int orc_search_by_bow(const uint8_t* kf_desc, const float* kf_angle, const uint8
     free(rot_bin);
     return nmatches;
 }
+
+/* ------------------------------------------------------------------------------------------
+ * ORBmatcher::SearchByProjection(Frame& CurrentFrame, const Frame& LastFrame, th, bMono, ...)
+ * -- ORBmatcher.cc:1440-1593 -- on pre-projected queries; with use_ratio it is the map-point overload
+ * (:155-241) again (used to cross-check the two oracle functions against each other).
+ * ---------------------------------------------------------------------------------------- */
+int orc_search_by_projection_queries(const orc_keypoint* kp, const uint8_t* desc, const float* u_right,
+                                     const float* kp_angle, int n, const orc_frame_bounds* fb,
+                                     const orc_proj_query* q, const uint8_t* q_desc, int m, const orc_proj_mode* mode,
+                                     const uint8_t* kp_taken, int* out_q, int* out_score)
+{
+    enum { HISTO_LENGTH = 30 };
+    grid_t g;
+    grid_build(&g, kp, n, fb);
+    int* idx = (int*)malloc(sizeof(int) * (n > 0 ? n : 1));
+    uint8_t* blocked = (uint8_t*)malloc(n > 0 ? n : 1);
+    int* hist_kp = (int*)malloc(sizeof(int) * (m > 0 ? m : 1));  /* rotHist entries: keypoint index ... */
+    int* hist_bin = (int*)malloc(sizeof(int) * (m > 0 ? m : 1)); /* ... and its bin, in push order      */
+    int nh = 0, histo[HISTO_LENGTH];
+    memset(histo, 0, sizeof histo);
+    for (int i = 0; i < n; i++) {
+        blocked[i] = kp_taken ? kp_taken[i] : 0;
+        out_q[i] = -1;
+        out_score[i] = 0;
+    }
+    const float factor = 1.0f / HISTO_LENGTH;
+    int nmatches = 0;
+    for (int iq = 0; iq < m; iq++) {
+        const orc_proj_query* p = &q[iq];
+        if (!(p->flags & 1)) continue;
+        const int nidx = grid_query(&g, kp, fb, p->u, p->v, p->radius, p->min_level, p->max_level, idx, n);
+        if (nidx == 0) continue;
+        int bestDist = 256, bestLevel = -1, bestDist2 = 256, bestLevel2 = -1, bestIdx = -1;
+        for (int k = 0; k < nidx; k++) {
+            const int i = idx[k];
+            if (blocked[i]) continue;
+            if (u_right && u_right[i] > 0) {
+                const float er = fabsf(p->ur - u_right[i]);
+                if (er > p->radius) continue;
+            }
+            const int dist = orc_hamming256(q_desc + (size_t)iq * 32, desc + (size_t)i * 32);
+            if (dist < bestDist) {
+                bestDist2 = bestDist; bestDist = dist;
+                bestLevel2 = bestLevel; bestLevel = kp[i].octave;
+                bestIdx = i;
+            } else if (dist < bestDist2) {
+                bestLevel2 = kp[i].octave;
+                bestDist2 = dist;
+            }
+        }
+        if (bestDist <= mode->th_dist) {
+            if (mode->use_ratio && bestLevel == bestLevel2 && (float)bestDist > mode->nn_ratio * (float)bestDist2) continue;
+            out_q[bestIdx] = iq;
+            out_score[bestIdx] = bestDist;
+            blocked[bestIdx] = (p->flags & 4) ? 1 : 0;
+            nmatches++;
+            if (mode->check_orientation) {
+                float rot = p->angle - kp_angle[bestIdx];
+                if (rot < 0.0) rot += 360.0f;
+                int bin = (int)roundf(rot * factor);
+                if (bin == HISTO_LENGTH) bin = 0;
+                hist_kp[nh] = bestIdx;
+                hist_bin[nh] = bin;
+                nh++;
+                histo[bin]++;
+            }
+        }
+    }
+    if (mode->check_orientation) {
+        int ind1 = -1, ind2 = -1, ind3 = -1;
+        orc_three_maxima(histo, HISTO_LENGTH, &ind1, &ind2, &ind3);
+        for (int e = 0; e < nh; e++) {
+            const int b = hist_bin[e];
+            if (b != ind1 && b != ind2 && b != ind3) {
+                out_q[hist_kp[e]] = -1;
+                nmatches--;
+            }
+        }
+    }
+    free(idx); free(blocked); free(hist_kp); free(hist_bin);
+    grid_free(&g);
+    return nmatches;
+}

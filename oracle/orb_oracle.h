@@ -123,6 +123,27 @@ int orc_features_in_area(const orc_keypoint* kp_un, int n, const orc_frame_bound
                          float x, float y, float r, int min_level, int max_level,
                          int* out_idx, int cap);
 
+/* ORBmatcher::SearchByProjection(Frame& Cur, const Frame& Last, th, bMono, ...) -- ORBmatcher.cc:1440-1593 --
+ * and the map-point overload, on explicit queries (one per projected map point, visited in array order).
+ * The adapter-side projection (:1467-1497: u, v, invzc, ur = u - mbf*invzc, radius = th*scale[octave], the
+ * forward/backward level window) is done by the caller.  out_q[n] = query left in mvpMapPoints[i] (-1 NULL). */
+typedef struct {
+    float u, v, ur, radius;
+    int32_t min_level, max_level;
+    float angle;
+    int32_t flags; /* bit0 active, bit2 Observations() > 0 */
+} orc_proj_query;
+typedef struct {
+    int32_t use_ratio;
+    float nn_ratio;
+    int32_t th_dist;
+    int32_t check_orientation;
+} orc_proj_mode;
+int orc_search_by_projection_queries(const orc_keypoint* kp_un, const uint8_t* desc, const float* u_right,
+                                     const float* kp_angle, int n, const orc_frame_bounds* fb,
+                                     const orc_proj_query* q, const uint8_t* q_desc, int m, const orc_proj_mode* mode,
+                                     const uint8_t* kp_taken, int* out_q, int* out_score);
+
 /* ORBmatcher::SearchByBoW(KeyFrame*, Frame&, vector<MapPoint*>&) -- ORBmatcher.cc:270-404, with the
  * two DBoW2::FeatureVector maps flattened to CSR (node ids ascending, as std::map iterates them).
  * kf_mp_valid[i] = 1 where vpMapPointsKF[i] is set and not bad.  out_kf_idx[n_f]: index of the KF

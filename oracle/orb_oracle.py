@@ -16,6 +16,8 @@ KEYPOINT_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle"
                            ("response", "<f4"), ("octave", "<i4"), ("class_id", "<i4")])
 MAP_POINT_DTYPE = np.dtype([("proj_x", "<f4"), ("proj_y", "<f4"), ("proj_xr", "<f4"),
                             ("view_cos", "<f4"), ("level", "<i4"), ("flags", "<i4")])
+PROJ_QUERY_DTYPE = np.dtype([("u", "<f4"), ("v", "<f4"), ("ur", "<f4"), ("radius", "<f4"), ("min_level", "<i4"),
+                             ("max_level", "<i4"), ("angle", "<f4"), ("flags", "<i4")])
 
 TRIG_SHARED, TRIG_LIBM = 0, 1
 ROT_UNFUSED, ROT_FMA = 0, 1
@@ -250,6 +252,33 @@ def search_by_projection(kp_un, desc, u_right, scale_factors, bounds, mps, mp_de
     nm = lib().orc_search_by_projection(_p(kp_un), _p(desc), _p(u_right), n, _p(sf), C.byref(fb), _p(mps), _p(mp_desc), m,
                                         th, nn_ratio, _p(kp_taken), _p(out_mp), _p(out_score))
     return nm, out_mp[:n], out_score[:n]
+
+
+class ProjMode(C.Structure):
+    _fields_ = [("use_ratio", C.c_int32), ("nn_ratio", C.c_float), ("th_dist", C.c_int32), ("check_orientation", C.c_int32)]
+
+
+def search_by_projection_queries(kp_un, desc, u_right, kp_angle, bounds, queries, q_desc, use_ratio, nn_ratio, th_dist,
+                                 check_orientation, kp_taken=None):
+    kp_un = np.ascontiguousarray(kp_un, dtype=KEYPOINT_DTYPE)
+    desc = np.ascontiguousarray(desc, dtype=np.uint8)
+    queries = np.ascontiguousarray(queries, dtype=PROJ_QUERY_DTYPE)
+    q_desc = np.ascontiguousarray(q_desc, dtype=np.uint8)
+    n, m = len(kp_un), len(queries)
+    u_right = None if u_right is None else np.ascontiguousarray(u_right, np.float32)
+    kp_angle = None if kp_angle is None else np.ascontiguousarray(kp_angle, np.float32)
+    kp_taken = None if kp_taken is None else np.ascontiguousarray(kp_taken, np.uint8)
+    fb = FrameBounds(*bounds)
+    mode = ProjMode(1 if use_ratio else 0, nn_ratio, th_dist, 1 if check_orientation else 0)
+    out_q = np.zeros(max(n, 1), np.int32)
+    out_s = np.zeros(max(n, 1), np.int32)
+    L = lib()
+    vp = C.c_void_p
+    L.orc_search_by_projection_queries.argtypes = [vp, vp, vp, vp, C.c_int, C.POINTER(FrameBounds), vp, vp, C.c_int,
+                                                   C.POINTER(ProjMode), vp, vp, vp]
+    nm = L.orc_search_by_projection_queries(_p(kp_un), _p(desc), _p(u_right), _p(kp_angle), n, C.byref(fb), _p(queries),
+                                            _p(q_desc), m, C.byref(mode), _p(kp_taken), _p(out_q), _p(out_s))
+    return nm, out_q[:n], out_s[:n]
 
 
 class FeatureVectorC(C.Structure):

@@ -92,3 +92,67 @@ def test_projection_edge_cases(ext, oracle):
     got = m.SearchByProjection(kl, dl, None, sf, b, mps, mpd, 3.0, None)
     assert got[0] == ref[0]
     np.testing.assert_array_equal(got[1], ref[1]); np.testing.assert_array_equal(got[2], ref[2])
+
+
+def _frame_queries(oracle, kl, dl, seed, th, forward=False, backward=False):
+    """Flattening an adapter does for SearchByProjection(CurrentFrame, LastFrame, th, bMono): the last
+    frame's keypoints with a map point, projected into the current frame (ORBmatcher.cc:1465-1510)."""
+    rng = np.random.default_rng(seed)
+    n = len(kl)
+    m = n
+    q = np.zeros(m, oracle.PROJ_QUERY_DTYPE)
+    sf = oracle.OracleExtractor().scale_factors
+    q["u"] = kl["x"] + rng.normal(0, 4, m); q["v"] = kl["y"] + rng.normal(0, 4, m)
+    q["ur"] = q["u"] - rng.uniform(0, 40, m).astype(np.float32)
+    octv = kl["octave"]
+    q["radius"] = (np.float32(th) * sf[octv]).astype(np.float32)
+    if forward:
+        q["min_level"] = octv; q["max_level"] = -1
+    elif backward:
+        q["min_level"] = 0; q["max_level"] = octv
+    else:
+        q["min_level"] = octv - 1; q["max_level"] = octv + 1
+    q["angle"] = ((kl["angle"] + rng.normal(0, 25, m)) % 360).astype(np.float32)
+    fl = np.full(m, 1 | 4, np.int32)
+    fl[rng.random(m) < 0.25] = 0          # no map point / outlier / behind the camera / outside the image
+    fl[rng.random(m) < 0.2] &= ~4
+    q["flags"] = fl
+    qd = dl.copy()
+    for _ in range(12):
+        sel = rng.random(m) < 0.5
+        bits = rng.integers(0, 256, m)
+        qd[sel, bits[sel] >> 3] ^= (1 << (bits[sel] & 7)).astype(np.uint8)
+    perm = rng.permutation(m)             # the last frame's keypoint order is unrelated to the current one's
+    return q[perm], qd[perm]
+
+
+@pytest.mark.parametrize("seed,th,fwd,bwd,ori", [(1, 7.0, False, False, True), (2, 15.0, True, False, True),
+                                                 (3, 15.0, False, True, False), (4, 3.0, False, False, True)])
+def test_frame_to_frame_projection(ext, oracle, seed, th, fwd, bwd, ori):
+    import gf_orb_slam2_amd as G
+    kl, dl, u = _frame(oracle)
+    q, qd = _frame_queries(oracle, kl, dl, seed, th, fwd, bwd)
+    taken = (np.random.default_rng(seed).random(len(kl)) < 0.1).astype(np.uint8)
+    b = (0.0, 0.0, 752.0, 480.0)
+    ref = oracle.search_by_projection_queries(kl, dl, u, kl["angle"], b, q, qd, False, 0.9, 100, ori, taken)
+    got = G.ORBmatcher(0.9, ori, extractor=ext).SearchByProjectionQueries(kl, dl, u, kl["angle"], b, q, qd, kp_taken=taken)
+    assert got[0] == ref[0] and ref[0] > 300
+    np.testing.assert_array_equal(got[1], ref[1])
+    np.testing.assert_array_equal(got[2][got[1] >= 0], ref[2][ref[1] >= 0])
+
+
+def test_query_form_reproduces_map_point_overload(oracle):
+    """the two oracle statements (literal map-point overload vs query form) agree: pins the flattening"""
+    kl, dl, u = _frame(oracle)
+    g = np.load(os.path.join(GOLDEN, "EuRoC_projection.npz"))
+    mps = g["mps"]
+    sf = oracle.OracleExtractor().scale_factors
+    q = np.zeros(len(mps), oracle.PROJ_QUERY_DTYPE)
+    r = np.where(mps["view_cos"].astype(np.float64) > 0.998, np.float32(2.5), np.float32(4.0)) * np.float32(3.0)
+    q["u"], q["v"], q["ur"] = mps["proj_x"], mps["proj_y"], mps["proj_xr"]
+    q["radius"] = (r.astype(np.float32) * sf[mps["level"]]).astype(np.float32)
+    q["min_level"] = mps["level"] - 1; q["max_level"] = mps["level"]
+    q["flags"] = (((mps["flags"] & 1) != 0) & ((mps["flags"] & 2) == 0)).astype(np.int32) | (mps["flags"] & 4)
+    got = oracle.search_by_projection_queries(kl, dl, u, None, (0.0, 0.0, 752.0, 480.0), q, g["mp_desc"], True, 0.8, 100, False, g["taken"])
+    assert got[0] == int(g["nmatches"])
+    np.testing.assert_array_equal(got[1], g["out_mp"])
