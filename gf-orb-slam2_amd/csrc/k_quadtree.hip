@@ -19,7 +19,8 @@
 #include "gfo_internal.h"
 #include <stdlib.h>
 
-#define QT_THREADS 256
+#define QT_MAX_THREADS 1024
+#define QT_THREADS ((int)blockDim.x)   // 256 (small quotas) or 1024 (large ones): see gfo_launch_quadtree
 
 struct QtBox {
     short ulx, uly, urx, bry;
@@ -44,7 +45,6 @@ __device__ int qt_scan(int* vals, int n, int* part)
     if (lane == 63) part[wave] = incl;
     __syncthreads();
     int wbase = 0, total = 0;
-#pragma unroll
     for (int w = 0; w < QT_THREADS / 64; w++) {
         const int t = part[w];
         if (w < wave) wbase += t;
@@ -81,7 +81,7 @@ __device__ __forceinline__ QtBox qt_child_box(QtBox b, int q)
     return c;
 }
 
-__global__ __launch_bounds__(QT_THREADS) void k_quadtree(const GfoGeom* __restrict__ gp,
+__global__ __launch_bounds__(QT_MAX_THREADS) void k_quadtree(const GfoGeom* __restrict__ gp,
                                                          const uint32_t* __restrict__ cand,
                                                          const int* __restrict__ cand_cnt,
                                                          uint16_t* __restrict__ node_of_all,
@@ -120,7 +120,7 @@ __global__ __launch_bounds__(QT_THREADS) void k_quadtree(const GfoGeom* __restri
     // Keys and their node index live in LDS when the level's candidate list fits (the usual case: a few
     // thousand keys); every pass then runs at LDS latency.  Larger lists stay in HBM/L2 (same code, generic
     // pointers).
-    uint32_t* lkeys = reinterpret_cast<uint32_t*>(part + QT_THREADS);
+    uint32_t* lkeys = reinterpret_cast<uint32_t*>(part + QT_MAX_THREADS);
     uint16_t* lnode = reinterpret_cast<uint16_t*>(lkeys + klds);
     const bool in_lds = K <= klds;
     const uint32_t* keys = in_lds ? lkeys : gkeys;
@@ -372,7 +372,7 @@ size_t gfo_quadtree_lds_bytes(int ncap, int klds)
 {
     int p2 = 1;
     while (p2 < ncap) p2 <<= 1;
-    return (size_t)p2 * 8 + (size_t)ncap * (2 * sizeof(QtBox) + 2 * 4 + 4 * 4 + 4 * 4 + 3 * 4) + QT_THREADS * 4 + (size_t)klds * 6 + 64;
+    return (size_t)p2 * 8 + (size_t)ncap * (2 * sizeof(QtBox) + 2 * 4 + 4 * 4 + 4 * 4 + 3 * 4) + QT_MAX_THREADS * 4 + (size_t)klds * 6 + 64;
 }
 
 void gfo_launch_quadtree(gfo_ctx* c, int nimg)
@@ -388,8 +388,12 @@ void gfo_launch_quadtree(gfo_ctx* c, int nimg)
     if (lds > 64 * 1024)
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_quadtree), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     dim3 grid(nimg, c->g.nlevels);
+    // the per-pass key loops are latency-bound inside a workgroup: large quotas (1080p @4000 features) get
+    // 1024 threads per (image, level), the 752x480 @2000 case runs best with 256
+    static const int nt_env = getenv("GFO_QT_THREADS") ? atoi(getenv("GFO_QT_THREADS")) : 0;
+    const int nthreads = nt_env ? nt_env : (c->g.lv[0].quota >= 600 ? 1024 : 256);
     gfo_prof_begin(c, ST_QUADTREE);
-    hipLaunchKernelGGL(k_quadtree, grid, dim3(QT_THREADS), lds, c->stream, c->d_geom, c->d_cand, c->d_cand_cnt,
+    hipLaunchKernelGGL(k_quadtree, grid, dim3(nthreads), lds, c->stream, c->d_geom, c->d_cand, c->d_cand_cnt,
                        c->d_node_of, c->d_sel, c->d_sel_cnt, c->d_flags, ncap, klds);
     gfo_prof_end(c);
 }
