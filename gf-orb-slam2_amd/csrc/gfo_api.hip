@@ -236,11 +236,11 @@ static int plan(gfo_ctx* c, int w, int h, int batch)
     g.total_tiles = tile_base;
     g.total_sel_cap = sel_off;
     g.kp_stride = (int)align_up(sel_off, 4);
-    g.fast_tile_pitch = (int)align_up(max_cw + 3, 4);   // +3: tile rows start at the aligned dword left of the cell
+    g.fast_tile_pitch = (int)align_up(max_cw + 3, 16);  // +3: tile rows start at the aligned dword left of the cell; 16-B segments
     g.fast_npx_max = (int)align_up((long long)(max_cw - 6) * (max_ch - 6), 8);
     g.fast_tile_rows = max_ch;
     g.fast_smap_pitch = (int)align_up(max_cw - 6 + 2, 4);
-    g.fast_smap_rows = max_ch - 6 + 2;
+    g.fast_smap_rows = (int)align_up((long long)(max_ch - 6 + 2) * g.fast_smap_pitch, 16) / g.fast_smap_pitch + 1;  // zeroed in 16-B steps
     g.pyr_img_stride = align_up(pyr_off, 256);
     g.blur_img_stride = align_up(blur_off, 256);
     g.cand_img_stride = align_up(cand_off, 64);

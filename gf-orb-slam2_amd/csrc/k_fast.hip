@@ -136,7 +136,7 @@ __global__ __launch_bounds__(256) void k_fast(const GfoGeom* __restrict__ gp, Gf
     const int img = blockIdx.y;
     const int cell = blockIdx.x * 4 + wave;
     const int TP = g.fast_tile_pitch, SP = g.fast_smap_pitch;
-    const int tile_bytes = TP * g.fast_tile_rows, smap_bytes = SP * g.fast_smap_rows;
+    const int tile_bytes = TP * g.fast_tile_rows, smap_bytes = (SP * g.fast_smap_rows + 15) & ~15;
     const int per_wave = tile_bytes + smap_bytes + 2 * g.fast_npx_max;  // one u16 queue, compacted in place
     uint8_t* tile = lds + wave * per_wave;
     uint8_t* smap = tile + tile_bytes;
@@ -163,30 +163,36 @@ __global__ __launch_bounds__(256) void k_fast(const GfoGeom* __restrict__ gp, Gf
         int pitch;
         const uint8_t* src = gfo_level_ptr(g, in, pyr, level, img, &pitch);
         src += (long long)iniY * pitch + x_al;
-        const int dpr = (xoff + cw + 3) >> 2;  // dwords per tile row
-        const float inv_dpr = 1.0f / (float)dpr;
-        uint32_t* t32 = reinterpret_cast<uint32_t*>(tile);
-        const int tp4 = TP >> 2;
-        const int ndw = dpr * ch;
-        // all global loads of a chunk are in flight before the first LDS store
-        for (int b = 0; b < ndw; b += 64 * 8) {
-            uint32_t v[8];
-            int dst[8];
+        // 16-byte row segments: TP is a multiple of 16, every lane issues its (<= 4) wide loads before the
+        // first LDS store; the segment right of the cell may run a few bytes past maxX but stays inside the
+        // image row (maxX <= w - 16)
+        const int spr = (xoff + cw + 15) >> 4;  // 16-byte segments per tile row
+        const float inv_spr = 1.0f / (float)spr;
+        uint4* t128 = reinterpret_cast<uint4*>(tile);
+        const int tp16 = TP >> 4;
+        const int nseg = spr * ch;
+        for (int b = 0; b < nseg; b += 64 * 4) {
+            uint4 v[4];
+            int dst[4];
 #pragma unroll
-            for (int k = 0; k < 8; k++) {
+            for (int k = 0; k < 4; k++) {
                 const int t = b + k * 64 + lane;
-                const int tt = min(t, ndw - 1);
-                const int r = (int)(((float)tt + 0.5f) * inv_dpr);
-                const int c = tt - r * dpr;
-                dst[k] = t < ndw ? r * tp4 + c : -1;
-                v[k] = *reinterpret_cast<const uint32_t*>(src + (long long)r * pitch + 4 * c);
+                const int tt = min(t, nseg - 1);
+                const int r = (int)(((float)tt + 0.5f) * inv_spr);
+                const int c = tt - r * spr;
+                dst[k] = t < nseg ? r * tp16 + c : -1;
+                const uint8_t* p = src + (long long)r * pitch + 16 * c;
+                // 4-byte aligned (x_al), not 16: four dword loads the compiler may merge into one dwordx4
+                const uint32_t* p32 = reinterpret_cast<const uint32_t*>(p);
+                v[k] = make_uint4(p32[0], p32[1], p32[2], p32[3]);
             }
 #pragma unroll
-            for (int k = 0; k < 8; k++)
-                if (dst[k] >= 0) t32[dst[k]] = v[k];
+            for (int k = 0; k < 4; k++)
+                if (dst[k] >= 0) t128[dst[k]] = v[k];
         }
-        uint32_t* sm32 = reinterpret_cast<uint32_t*>(smap);
-        for (int t = lane; t < ((sh + 2) * SP) >> 2; t += 64) sm32[t] = 0;
+        uint4* sm128 = reinterpret_cast<uint4*>(smap);
+        const uint4 z4 = make_uint4(0, 0, 0, 0);
+        for (int t = lane; t < ((sh + 2) * SP + 15) >> 4; t += 64) sm128[t] = z4;
     }
     wave_sync();
     if (dbg_stop == 1) return;
@@ -360,7 +366,7 @@ void gfo_launch_fast(gfo_ctx* c, const GfoInput& in, int nimg)
 {
     const GfoGeom& g = c->g;
     if (g.total_cells == 0) return;  // image too small for a single 30-px cell on any level: no candidates
-    const size_t lds = 4 * (size_t)(g.fast_tile_pitch * g.fast_tile_rows + g.fast_smap_pitch * g.fast_smap_rows + 2 * g.fast_npx_max);
+    const size_t lds = 4 * (size_t)(g.fast_tile_pitch * g.fast_tile_rows + ((g.fast_smap_pitch * g.fast_smap_rows + 15) & ~15) + 2 * g.fast_npx_max);
     dim3 grid((g.total_cells + 3) / 4, nimg);
     gfo_prof_begin(c, ST_FAST);
     static const int dbg_stop = getenv("GFO_FAST_STOP") ? atoi(getenv("GFO_FAST_STOP")) : 0;  // timing experiments only
