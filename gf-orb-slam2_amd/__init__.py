@@ -6,8 +6,8 @@ oracle and has no CPU fallback: without the built library and a gfx950 device it
 """
 from ._lib import GfoError, KEYPOINT_DTYPE, MAP_POINT_DTYPE, PROJ_QUERY_DTYPE, lib_path, load_library  # noqa: F401
 from .extractor import ORBextractor  # noqa: F401
-from .matcher import ORBmatcher, StereoParams, FrameBounds  # noqa: F401
+from .matcher import ORBmatcher, ORBVocabulary, StereoParams, FrameBounds  # noqa: F401
 from .build import build_library  # noqa: F401
 
-__all__ = ["ORBextractor", "ORBmatcher", "StereoParams", "FrameBounds", "GfoError", "KEYPOINT_DTYPE",
+__all__ = ["ORBextractor", "ORBmatcher", "ORBVocabulary", "StereoParams", "FrameBounds", "GfoError", "KEYPOINT_DTYPE",
            "MAP_POINT_DTYPE", "build_library", "load_library", "lib_path"]

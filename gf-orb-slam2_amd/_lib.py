@@ -35,6 +35,11 @@ class FrameBoundsC(C.Structure):
     _fields_ = [("min_x", C.c_float), ("min_y", C.c_float), ("max_x", C.c_float), ("max_y", C.c_float)]
 
 
+class VocabularyC(C.Structure):
+    _fields_ = [("first_child", C.c_void_p), ("n_children", C.c_void_p), ("descriptors", C.c_void_p), ("word_id", C.c_void_p),
+                ("weight", C.c_void_p), ("n_nodes", C.c_int32), ("depth", C.c_int32)]
+
+
 class ProjModeC(C.Structure):
     _fields_ = [("use_ratio", C.c_int32), ("nn_ratio", C.c_float), ("th_dist", C.c_int32), ("check_orientation", C.c_int32)]
 
@@ -53,7 +58,7 @@ SYMBOLS = [
     "gfo_ctx_synchronize", "gfo_ctx_tables", "gfo_ctx_max_keypoints", "gfo_extract", "gfo_extract_batch",
     "gfo_extract_batch_device", "gfo_batch_counts", "gfo_batch_fetch", "gfo_batch_device_views",
     "gfo_compute_pyramid", "gfo_pyramid_level", "gfo_hamming256", "gfo_stereo_match",
-    "gfo_stereo_match_batch", "gfo_stereo_fetch", "gfo_search_by_projection", "gfo_search_by_projection_queries", "gfo_search_by_bow", "gfo_profile_enable",
+    "gfo_stereo_match_batch", "gfo_stereo_fetch", "gfo_search_by_projection", "gfo_search_by_projection_queries", "gfo_search_by_bow", "gfo_vocabulary_upload", "gfo_bow_transform", "gfo_profile_enable",
     "gfo_profile_read", "gfo_debug_blurred_level", "gfo_debug_level_candidates",
 ]
 
@@ -125,6 +130,8 @@ def load_library():
     L.gfo_search_by_projection_queries.argtypes = [vp, vp, vp, vp, vp, i, C.POINTER(FrameBoundsC), vp, vp, i, C.POINTER(ProjModeC),
                                                    vp, vp, vp, ip]
     L.gfo_search_by_bow.argtypes = [vp, vp, vp, vp, i, C.POINTER(FeatureVectorC), vp, vp, i, C.POINTER(FeatureVectorC), f, i, vp, ip]
+    L.gfo_vocabulary_upload.argtypes = [vp, C.POINTER(VocabularyC)]
+    L.gfo_bow_transform.argtypes = [vp, vp, i, i, vp, vp, vp]
     L.gfo_profile_enable.argtypes = [vp, i]
     L.gfo_profile_read.argtypes = [vp, C.POINTER(StageTime), i, ip, i]
     L.gfo_debug_blurred_level.argtypes = [vp, i, i, vp, i]

@@ -357,6 +357,7 @@ extern "C" void gfo_ctx_destroy(gfo_ctx* c)
     for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);
     free_arena(c);
     if (c->d_scratch) (void)hipFree(c->d_scratch);
+    if (c->d_voc) (void)hipFree(c->d_voc);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
 }

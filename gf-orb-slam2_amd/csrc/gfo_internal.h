@@ -158,7 +158,11 @@ struct gfo_ctx {
     // scratch for host-array matcher entry points
     void* d_scratch = nullptr;
     size_t scratch_bytes = 0;
-    int last_project_rounds = 0;     // Jacobi rounds of the last gfo_search_by_projection
+    int last_project_rounds = 0;
+    // resident vocabulary tree (gfo_vocabulary_upload)
+    void* d_voc = nullptr;
+    size_t voc_desc_off = 0, voc_fc_off = 0, voc_nc_off = 0, voc_wid_off = 0, voc_w_off = 0;
+    int voc_nodes = 0, voc_depth = 0;     // Jacobi rounds of the last gfo_search_by_projection
 };
 
 // ---- kernel launchers (each in its own .hip file) ------------------------------------------

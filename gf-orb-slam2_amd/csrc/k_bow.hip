@@ -226,3 +226,135 @@ extern "C" int gfo_search_by_bow(gfo_ctx* c, const uint8_t* kf_desc, const float
     *nmatches = cnt[0];
     return GFO_OK;
 }
+
+// ---------------------------------------------------------------------------------------------
+// DBoW2 TemplatedVocabulary<FORB>::transform -- the per-descriptor descent of the vocabulary tree
+// (TemplatedVocabulary.h:1231-1272).  One wavefront per descriptor: the children of the current node are
+// compared 64 at a time, the wave keeps the FIRST minimum (min of dist << 16 | child rank), and walks down
+// until it reaches a leaf.  Depth is ~6, so the kernel is a chain of dependent 32-byte reads: L2/MALL-resident
+// for any vocabulary that fits the 256 MiB Infinity Cache (the ORB vocabulary is ~35 MB).
+// ---------------------------------------------------------------------------------------------
+struct VocDev {
+    const int* first_child;
+    const int* n_children;
+    const uint8_t* descriptors;
+    const int* word_id;
+    const float* weight;
+    int n_nodes, depth;
+};
+
+__global__ __launch_bounds__(256) void k_bow_transform(VocDev v, const uint8_t* __restrict__ desc, int n, int levelsup,
+                                                       int* __restrict__ word_id, float* __restrict__ weight,
+                                                       int* __restrict__ node_id)
+{
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int i = blockIdx.x * 4 + wave;
+    if (i >= n) return;
+    const uint4* d = reinterpret_cast<const uint4*>(desc + (long long)i * 32);
+    const uint4 a0 = d[0], a1 = d[1];
+    const int nid_level = v.depth - levelsup;
+    int nid = 0, final_id = 0, level = 0;
+    for (int guard = 0; guard < 64; guard++) {  // the tree is at most v.depth deep; the guard bounds a malformed one
+        const int nc = v.n_children[final_id];
+        if (nc <= 0) break;
+        ++level;
+        const int fc = v.first_child[final_id];
+        unsigned best = 0xFFFFFFFFu;
+        for (int c = lane; c < nc; c += 64) {
+            const uint4* q = reinterpret_cast<const uint4*>(v.descriptors + (long long)(fc + c) * 32);
+            const uint4 b0 = q[0], b1 = q[1];
+            const unsigned dist = __popc(a0.x ^ b0.x) + __popc(a0.y ^ b0.y) + __popc(a0.z ^ b0.z) + __popc(a0.w ^ b0.w) +
+                                  __popc(a1.x ^ b1.x) + __popc(a1.y ^ b1.y) + __popc(a1.z ^ b1.z) + __popc(a1.w ^ b1.w);
+            best = min(best, (dist << 16) | (unsigned)c);
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) best = min(best, (unsigned)__shfl_xor((int)best, o));
+        final_id = fc + (int)(best & 0xFFFF);
+        if (level == nid_level) nid = final_id;
+    }
+    if (lane == 0) {
+        word_id[i] = v.word_id[final_id];
+        weight[i] = v.weight[final_id];
+        node_id[i] = nid;
+    }
+}
+
+extern "C" int gfo_vocabulary_upload(gfo_ctx* c, const gfo_vocabulary* voc)
+{
+    if (!c) return GFO_ERR_INVALID;
+    if (!voc || voc->n_nodes < 1 || !voc->first_child || !voc->n_children || !voc->descriptors || !voc->word_id || !voc->weight) {
+        c->err = "gfo_vocabulary_upload: bad argument";
+        return GFO_ERR_INVALID;
+    }
+    for (int i = 0; i < voc->n_nodes; i++) {
+        const int nc = voc->n_children[i], fc = voc->first_child[i];
+        if (nc < 0 || nc > 65535 || (nc > 0 && (fc <= i || fc + nc > voc->n_nodes))) {
+            c->err = "gfo_vocabulary_upload: children must follow their parent as one contiguous range";
+            return GFO_ERR_INVALID;
+        }
+    }
+    BTRY(c, hipSetDevice(c->device));
+    (void)hipStreamSynchronize(c->stream);
+    if (c->d_voc) (void)hipFree(c->d_voc);
+    c->d_voc = nullptr;
+    const size_t nn = (size_t)voc->n_nodes;
+    const size_t bytes = nn * (4 + 4 + 32 + 4 + 4) + 1024;
+    BTRY(c, hipMalloc(&c->d_voc, bytes));
+    uint8_t* p = (uint8_t*)c->d_voc;
+    c->voc_desc_off = 0;
+    c->voc_fc_off = (nn * 32 + 255) / 256 * 256;
+    c->voc_nc_off = c->voc_fc_off + nn * 4;
+    c->voc_wid_off = c->voc_nc_off + nn * 4;
+    c->voc_w_off = c->voc_wid_off + nn * 4;
+    BTRY(c, hipMemcpy(p + c->voc_desc_off, voc->descriptors, nn * 32, hipMemcpyHostToDevice));
+    BTRY(c, hipMemcpy(p + c->voc_fc_off, voc->first_child, nn * 4, hipMemcpyHostToDevice));
+    BTRY(c, hipMemcpy(p + c->voc_nc_off, voc->n_children, nn * 4, hipMemcpyHostToDevice));
+    BTRY(c, hipMemcpy(p + c->voc_wid_off, voc->word_id, nn * 4, hipMemcpyHostToDevice));
+    BTRY(c, hipMemcpy(p + c->voc_w_off, voc->weight, nn * 4, hipMemcpyHostToDevice));
+    c->voc_nodes = voc->n_nodes;
+    c->voc_depth = voc->depth;
+    return GFO_OK;
+}
+
+extern "C" int gfo_bow_transform(gfo_ctx* c, const uint8_t* desc, int n, int levelsup, int32_t* word_id, float* weight,
+                                 int32_t* node_id)
+{
+    if (!c) return GFO_ERR_INVALID;
+    if (n < 0 || (n > 0 && (!desc || !word_id || !weight || !node_id))) {
+        c->err = "gfo_bow_transform: bad argument";
+        return GFO_ERR_INVALID;
+    }
+    if (!c->d_voc) {
+        c->err = "gfo_bow_transform: no vocabulary uploaded";
+        return GFO_ERR_STATE;
+    }
+    if (n == 0) return GFO_OK;
+    BTRY(c, hipSetDevice(c->device));
+    size_t off = 0;
+    auto take = [&](size_t bytes) { size_t o = off; off = (off + bytes + 255) / 256 * 256; return o; };
+    const size_t o_d = take(32 * (size_t)n), o_w = take(4 * (size_t)n), o_wt = take(4 * (size_t)n), o_n = take(4 * (size_t)n);
+    if (off > c->scratch_bytes) {
+        (void)hipStreamSynchronize(c->stream);
+        if (c->d_scratch) (void)hipFree(c->d_scratch);
+        c->d_scratch = nullptr;
+        c->scratch_bytes = 0;
+        BTRY(c, hipMalloc(&c->d_scratch, off));
+        c->scratch_bytes = off;
+    }
+    uint8_t* S = (uint8_t*)c->d_scratch;
+    uint8_t* V = (uint8_t*)c->d_voc;
+    VocDev v{(const int*)(V + c->voc_fc_off), (const int*)(V + c->voc_nc_off), V + c->voc_desc_off,
+             (const int*)(V + c->voc_wid_off), (const float*)(V + c->voc_w_off), c->voc_nodes, c->voc_depth};
+    hipStream_t st = c->stream;
+    BTRY(c, hipMemcpyAsync(S + o_d, desc, 32 * (size_t)n, hipMemcpyHostToDevice, st));
+    gfo_prof_begin(c, ST_BOW);
+    hipLaunchKernelGGL(k_bow_transform, dim3((n + 3) / 4), dim3(256), 0, st, v, S + o_d, n, levelsup, (int*)(S + o_w),
+                       (float*)(S + o_wt), (int*)(S + o_n));
+    gfo_prof_end(c);
+    BTRY(c, hipGetLastError());
+    BTRY(c, hipMemcpyAsync(word_id, S + o_w, 4 * (size_t)n, hipMemcpyDeviceToHost, st));
+    BTRY(c, hipMemcpyAsync(weight, S + o_wt, 4 * (size_t)n, hipMemcpyDeviceToHost, st));
+    BTRY(c, hipMemcpyAsync(node_id, S + o_n, 4 * (size_t)n, hipMemcpyDeviceToHost, st));
+    BTRY(c, hipStreamSynchronize(st));
+    return GFO_OK;
+}

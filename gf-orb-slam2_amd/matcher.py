@@ -5,7 +5,7 @@ from collections import namedtuple
 
 import numpy as np
 
-from ._lib import (FeatureVectorC, FrameBoundsC, KEYPOINT_DTYPE, PROJ_QUERY_DTYPE, ProjModeC, MAP_POINT_DTYPE, StereoParamsC, check, load_library, ptr)
+from ._lib import (FeatureVectorC, FrameBoundsC, KEYPOINT_DTYPE, PROJ_QUERY_DTYPE, ProjModeC, VocabularyC, MAP_POINT_DTYPE, StereoParamsC, check, load_library, ptr)
 
 StereoParams = namedtuple("StereoParams", "n_rows mbf mb min_x")
 FrameBounds = namedtuple("FrameBounds", "min_x min_y max_x max_y")
@@ -139,3 +139,44 @@ class ORBmatcher:
                                                                            C.byref(fb), ptr(q), ptr(qd), m, C.byref(mode), ptr(kp_taken),
                                                                            ptr(out_q), ptr(out_s), C.byref(nm)))
         return nm.value, out_q[:n], out_s[:n]
+
+
+class ORBVocabulary:
+    """DBoW2 TemplatedVocabulary<FORB> as far as Frame::ComputeBoW needs it (Frame.cc:661-668): a flattened tree
+    resident on the device and transform(descriptors, levelsup) -> (BowVector, FeatureVector)."""
+
+    def __init__(self, tree, extractor):
+        self._L = load_library()
+        self._ctx = extractor.handle
+        arrs = [np.ascontiguousarray(tree[k]) for k in ("first_child", "n_children", "descriptors", "word_id", "weight")]
+        v = VocabularyC(*[a.ctypes.data for a in arrs], len(arrs[0]), int(tree["depth"]))
+        check(self._L, self._ctx, self._L.gfo_vocabulary_upload(self._ctx, C.byref(v)))
+
+    def transform_raw(self, desc, levelsup=4):
+        desc = np.ascontiguousarray(desc, np.uint8)
+        n = len(desc)
+        wid = np.zeros(max(n, 1), np.int32); wt = np.zeros(max(n, 1), np.float32); nid = np.zeros(max(n, 1), np.int32)
+        check(self._L, self._ctx, self._L.gfo_bow_transform(self._ctx, ptr(desc), n, levelsup, ptr(wid), ptr(wt), ptr(nid)))
+        return wid[:n], wt[:n], nid[:n]
+
+    def transform(self, desc, levelsup=4):
+        """(BowVector as {word: summed weight, L1-normalised}, FeatureVector as CSR (node_ids, node_start, items)) --
+        TemplatedVocabulary.h:1140-1212 for TF_IDF weighting with L1 scoring."""
+        wid, wt, nid = self.transform_raw(desc, levelsup)
+        keep = wt > 0
+        bow = {}
+        for w_, v_ in zip(wid[keep].tolist(), wt[keep].tolist()):
+            bow[w_] = bow.get(w_, 0.0) + v_
+        norm = sum(abs(v_) for v_ in bow.values())
+        if norm > 0:
+            bow = {k: v_ / norm for k, v_ in bow.items()}
+        node = np.where(keep, nid, -1)
+        ids = np.unique(node[node >= 0]).astype(np.uint32)
+        start = np.zeros(len(ids) + 1, np.int32)
+        items = []
+        for k, n_ in enumerate(ids):
+            idx = np.nonzero(node == n_)[0]
+            items.append(idx)
+            start[k + 1] = start[k] + len(idx)
+        items = np.concatenate(items).astype(np.uint32) if items else np.zeros(0, np.uint32)
+        return bow, (ids, start, items)

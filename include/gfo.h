@@ -210,6 +210,27 @@ int gfo_search_by_bow(gfo_ctx* ctx, const uint8_t* kf_desc, const float* kf_angl
                       int n_f, const gfo_feature_vector* f_fv, float nn_ratio, int check_orientation,
                       int32_t* out_kf_idx, int* nmatches);
 
+/* Frame::ComputeBoW -> DBoW2 TemplatedVocabulary<FORB>::transform(features, BowVector&, FeatureVector&, levelsup)
+ * src/Frame.cc:661-668, Thirdparty/DBoW2/DBoW2/TemplatedVocabulary.h:1140-1212 and the per-feature tree descent
+ * :1231-1272 with FORB::distance (FORB.cpp:81).  The vocabulary tree is passed flattened: node 0 is the root,
+ * the children of a node are the contiguous range [first_child, first_child + n_children) in the vocabulary's
+ * own child order (ties keep the FIRST minimum, :1251-1260), a leaf has n_children == 0.
+ * Per descriptor i the call returns the word id, the word weight and the node id at level L - levelsup
+ * (0 = root when that level is <= 0); the adapter folds them into the two maps (only weight > 0 entries,
+ * in feature order, :1169-1175).  The tree stays resident in the context until replaced. */
+typedef struct {
+    const int32_t* first_child;   /* [n_nodes]                               */
+    const int32_t* n_children;    /* [n_nodes] 0 = leaf (word)               */
+    const uint8_t* descriptors;   /* [n_nodes][32] node centres (root unused) */
+    const int32_t* word_id;       /* [n_nodes] valid on leaves               */
+    const float* weight;          /* [n_nodes] valid on leaves               */
+    int32_t n_nodes;
+    int32_t depth;                /* m_L                                     */
+} gfo_vocabulary;
+int gfo_vocabulary_upload(gfo_ctx* ctx, const gfo_vocabulary* voc);
+int gfo_bow_transform(gfo_ctx* ctx, const uint8_t* desc, int n, int levelsup,
+                      int32_t* word_id, float* weight, int32_t* node_id);
+
 /* ---- measurement hooks (bench.py / rocprof cross-check) ---------------------------------- */
 /* When enabled, every kernel launch of the extract / stereo pipelines is bracketed by HIP
  * events on the context stream; gfo_profile_read returns, per stage, the accumulated device

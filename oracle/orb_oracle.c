@@ -1166,3 +1166,31 @@ int orc_search_by_projection_queries(const orc_keypoint* kp, const uint8_t* desc
     grid_free(&g);
     return nmatches;
 }
+
+/* ------------------------------------------------------------------------------------------
+ * DBoW2 TemplatedVocabulary<FORB>::transform(feature, word_id, weight, nid, levelsup)
+ * -- Thirdparty/DBoW2/DBoW2/TemplatedVocabulary.h:1231-1272, distance = FORB::distance (FORB.cpp:81)
+ * ---------------------------------------------------------------------------------------- */
+void orc_bow_transform(const orc_vocabulary* voc, const uint8_t* desc, int n, int levelsup,
+                       int32_t* word_id, float* weight, int32_t* node_id)
+{
+    const int nid_level = voc->depth - levelsup;
+    for (int i = 0; i < n; i++) {
+        int nid = 0; /* root when nid_level <= 0 */
+        int final_id = 0, current_level = 0;
+        do {
+            ++current_level;
+            const int fc = voc->first_child[final_id], nc = voc->n_children[final_id];
+            final_id = fc;
+            int best_d = orc_hamming256(desc + (size_t)i * 32, voc->descriptors + (size_t)fc * 32);
+            for (int c = 1; c < nc; c++) {
+                const int d = orc_hamming256(desc + (size_t)i * 32, voc->descriptors + (size_t)(fc + c) * 32);
+                if (d < best_d) { best_d = d; final_id = fc + c; }
+            }
+            if (current_level == nid_level) nid = final_id;
+        } while (voc->n_children[final_id] > 0);
+        word_id[i] = voc->word_id[final_id];
+        weight[i] = voc->weight[final_id];
+        node_id[i] = nid;
+    }
+}

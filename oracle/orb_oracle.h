@@ -160,6 +160,19 @@ int orc_search_by_bow(const uint8_t* kf_desc, const float* kf_angle, const uint8
 /* ORBmatcher::ComputeThreeMaxima -- ORBmatcher.cc:1723-1764 on the bin sizes */
 void orc_three_maxima(const int* histo_sizes, int L, int* ind1, int* ind2, int* ind3);
 
+/* DBoW2 TemplatedVocabulary<FORB>::transform, per-feature descent (TemplatedVocabulary.h:1231-1272) on a
+ * flattened tree (node 0 = root, children contiguous in the vocabulary's order, leaf: n_children == 0). */
+typedef struct {
+    const int32_t* first_child;
+    const int32_t* n_children;
+    const uint8_t* descriptors;
+    const int32_t* word_id;
+    const float* weight;
+    int32_t n_nodes, depth;
+} orc_vocabulary;
+void orc_bow_transform(const orc_vocabulary* voc, const uint8_t* desc, int n, int levelsup,
+                       int32_t* word_id, float* weight, int32_t* node_id);
+
 #ifdef __cplusplus
 }
 #endif

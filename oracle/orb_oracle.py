@@ -254,6 +254,57 @@ def search_by_projection(kp_un, desc, u_right, scale_factors, bounds, mps, mp_de
     return nm, out_mp[:n], out_score[:n]
 
 
+class VocabularyC(C.Structure):
+    _fields_ = [("first_child", C.c_void_p), ("n_children", C.c_void_p), ("descriptors", C.c_void_p), ("word_id", C.c_void_p),
+                ("weight", C.c_void_p), ("n_nodes", C.c_int32), ("depth", C.c_int32)]
+
+
+def make_vocabulary(k, depth, seed=0, p_stop=0.05, ragged=True):
+    """A synthetic k-ary vocabulary tree of the given depth, flattened breadth-first (children contiguous).
+    Node centres are random 256-bit strings refined towards their parent (so descents are not all ties);
+    a fraction of the words carries weight 0 (stop words); with ragged=True some nodes have fewer children
+    and some branches end early.  Returns dict of arrays + depth."""
+    rng = np.random.default_rng(seed)
+    first, nch, desc, level = [0], [0], [np.zeros(32, np.uint8)], [0]
+    i = 0
+    while i < len(first):
+        if level[i] < depth and not (ragged and level[i] >= 1 and rng.random() < 0.05):
+            kk = int(rng.integers(max(2, k - 3), k + 1)) if ragged else k
+            first[i] = len(first)
+            nch[i] = kk
+            for _ in range(kk):
+                d = desc[i].copy()
+                nflip = 128 if level[i] == 0 else 128 >> level[i]
+                bits = rng.choice(256, nflip, replace=False)
+                for b in bits:
+                    d[b >> 3] ^= np.uint8(1 << (b & 7))
+                first.append(0); nch.append(0); desc.append(d); level.append(level[i] + 1)
+        i += 1
+    n = len(first)
+    nch_a = np.array(nch, np.int32)
+    word = np.full(n, -1, np.int32)
+    leaves = np.nonzero(nch_a == 0)[0]
+    word[leaves] = np.arange(len(leaves), dtype=np.int32)
+    w = np.zeros(n, np.float32)
+    w[leaves] = rng.uniform(0.1, 5.0, len(leaves)).astype(np.float32)
+    w[leaves[rng.random(len(leaves)) < p_stop]] = 0.0
+    return {"first_child": np.array(first, np.int32), "n_children": nch_a, "descriptors": np.stack(desc).astype(np.uint8),
+            "word_id": word, "weight": w, "depth": depth}
+
+
+def bow_transform(voc, desc, levelsup=4):
+    desc = np.ascontiguousarray(desc, np.uint8)
+    n = len(desc)
+    arrs = [np.ascontiguousarray(voc[k]) for k in ("first_child", "n_children", "descriptors", "word_id", "weight")]
+    v = VocabularyC(*[a.ctypes.data for a in arrs], len(arrs[0]), voc["depth"])
+    wid = np.zeros(max(n, 1), np.int32); wt = np.zeros(max(n, 1), np.float32); nid = np.zeros(max(n, 1), np.int32)
+    L = lib()
+    L.orc_bow_transform.argtypes = [C.POINTER(VocabularyC), C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.orc_bow_transform.restype = None
+    L.orc_bow_transform(C.byref(v), _p(desc), n, levelsup, _p(wid), _p(wt), _p(nid))
+    return wid[:n], wt[:n], nid[:n]
+
+
 class ProjMode(C.Structure):
     _fields_ = [("use_ratio", C.c_int32), ("nn_ratio", C.c_float), ("th_dist", C.c_int32), ("check_orientation", C.c_int32)]
 

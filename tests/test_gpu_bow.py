@@ -65,3 +65,27 @@ def test_bow_edge_cases(ext, oracle):
     # disjoint vocabularies
     kfv2 = (kfv[0] + 1000, kfv[1], kfv[2])
     assert m.SearchByBoW(kd_, ka, valid, kfv2, fd, fa, ffv)[0] == 0
+
+
+@pytest.mark.parametrize("k,depth,levelsup,seed", [(10, 4, 2, 0), (6, 5, 4, 1), (10, 3, 4, 2), (4, 6, 3, 3)])
+def test_vocabulary_transform_matches_oracle(ext, oracle, k, depth, levelsup, seed):
+    """Frame::ComputeBoW's tree descent (DBoW2 transform) on a synthetic vocabulary: word, weight and the node
+    at level L - levelsup, first minimum on ties."""
+    import gf_orb_slam2_amd as G
+    voc = oracle.make_vocabulary(k, depth, seed)
+    dl = np.fromfile(os.path.join(GOLDEN, "EuRoC_l_desc.bin"), np.uint8).reshape(-1, 32)
+    # some descriptors equal to node centres and some equidistant ones, to hit exact ties
+    extra = voc["descriptors"][np.random.default_rng(seed).integers(1, len(voc["descriptors"]), 64)]
+    desc = np.concatenate([dl, extra, np.zeros((3, 32), np.uint8), np.full((3, 32), 255, np.uint8)])
+    ref = oracle.bow_transform(voc, desc, levelsup)
+    v = G.ORBVocabulary(voc, ext)
+    got = v.transform_raw(desc, levelsup)
+    for a, b in zip(got, ref):
+        assert a.tobytes() == b.tobytes()
+    # and the chained use: transform -> SearchByBoW agrees with the oracle run on the oracle's transform
+    bow, fv = v.transform(dl, levelsup)
+    assert abs(sum(bow.values()) - 1.0) < 1e-5
+    wid, wt, nid = ref[0][:len(dl)], ref[1][:len(dl)], ref[2][:len(dl)]
+    fv_ref = oracle.make_feature_vector(np.where(wt > 0, nid, -1))
+    for a, b in zip(fv, fv_ref):
+        np.testing.assert_array_equal(a, b)
