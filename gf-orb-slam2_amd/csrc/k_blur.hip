@@ -5,8 +5,9 @@
 // Streaming form, no LDS and no barriers: a thread owns 4 adjacent columns and walks down a
 // 32-row strip.  Per row it loads the 12 bytes [x-4, x+8) as three coalesced dwords (the lanes of a
 // wave read one contiguous 256-B run three times, shifted by 4 B: served by L1), forms the four
-// horizontal sums in packed u16 (max 257*255 = 65535 fits exactly), keeps the last seven rows of
-// sums in registers, and emits one dword of output per row.  Vertical halo: 6 extra rows per 32.
+// horizontal sums with two v_dot4_u32_u8 each (no byte unpacking; max 257*255 = 65535 fits u16 exactly),
+// keeps the last seven rows of sums packed in registers, and emits one dword of output per row.
+// Vertical halo: 6 extra rows per 32.
 // All levels of all images are one launch (block index -> level through the prefix table).
 #include "gfo_internal.h"
 
@@ -19,50 +20,46 @@ __device__ __forceinline__ int gfo_reflect101(int p, int n)
     return min(max(p, 0), n - 1);
 }
 
-typedef unsigned short __attribute__((ext_vector_type(2))) us2;
-
 struct HRow {
     unsigned lo, hi;  // four u16 horizontal sums: (x0, x0+1), (x0+2, x0+3)
 };
 
-__device__ __forceinline__ unsigned hsum2(unsigned a06, unsigned a15, unsigned a24, unsigned a3)
+// Horizontal pass of 4 pixels as v_dot4_u32_u8: output j (pixel x0+j) = B[j+1..j+4] . (18,34,49,55) +
+// B[j+5..j+8] . (49,34,18,0) over the 12 loaded bytes B = pixels x0-4 .. x0+7; the 4-byte windows are cut
+// out of the three dwords with v_alignbyte, so no byte is unpacked.
+__device__ __forceinline__ HRow hpass_dot(unsigned d0, unsigned d1, unsigned d2)
 {
-    // packed u16: 18*(p0+p6) + 34*(p1+p5) + 49*(p2+p4) + 55*p3, two pixels per register
-    const unsigned k18 = 18u | (18u << 16), k34 = 34u | (34u << 16), k49 = 49u | (49u << 16), k55 = 55u | (55u << 16);
-    us2 acc = __builtin_bit_cast(us2, a3) * __builtin_bit_cast(us2, k55);
-    acc += __builtin_bit_cast(us2, a06) * __builtin_bit_cast(us2, k18);
-    acc += __builtin_bit_cast(us2, a15) * __builtin_bit_cast(us2, k34);
-    acc += __builtin_bit_cast(us2, a24) * __builtin_bit_cast(us2, k49);
-    return __builtin_bit_cast(unsigned, acc);
-}
-
-__device__ __forceinline__ unsigned pk(unsigned a, unsigned b) { return a | (b << 16); }
-
-// horizontal pass for 4 pixels from the 10 source pixels p[0..9] = columns x0-3 .. x0+6
-__device__ __forceinline__ HRow hpass(const unsigned* p)
-{
+    const unsigned klo = 18u | (34u << 8) | (49u << 16) | (55u << 24);
+    const unsigned khi = 49u | (34u << 8) | (18u << 16);
+    const unsigned s0 = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d2, d1, 1), khi,
+                                               __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d1, d0, 1), klo, 0u, false), false);
+    const unsigned s1 = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d2, d1, 2), khi,
+                                               __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d1, d0, 2), klo, 0u, false), false);
+    const unsigned s2 = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d2, d1, 3), khi,
+                                               __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d1, d0, 3), klo, 0u, false), false);
+    const unsigned s3 = __builtin_amdgcn_udot4(d2, khi, __builtin_amdgcn_udot4(d1, klo, 0u, false), false);
     HRow r;
-    // outputs 0,1 use p[0..6], p[1..7]; outputs 2,3 use p[2..8], p[3..9]
-    r.lo = hsum2(pk(p[0] + p[6], p[1] + p[7]), pk(p[1] + p[5], p[2] + p[6]), pk(p[2] + p[4], p[3] + p[5]), pk(p[3], p[4]));
-    r.hi = hsum2(pk(p[2] + p[8], p[3] + p[9]), pk(p[3] + p[7], p[4] + p[8]), pk(p[4] + p[6], p[5] + p[7]), pk(p[5], p[6]));
+    r.lo = s0 | (s1 << 16);  // each sum <= 257 * 255 = 65535
+    r.hi = s2 | (s3 << 16);
     return r;
 }
 
 __device__ __forceinline__ HRow load_hrow(const uint8_t* __restrict__ row, int x0, int w, bool interior)
 {
-    unsigned p[10];
+    unsigned d0, d1, d2;
     if (interior) {
-        const unsigned d0 = *reinterpret_cast<const unsigned*>(row + x0 - 4);
-        const unsigned d1 = *reinterpret_cast<const unsigned*>(row + x0);
-        const unsigned d2 = *reinterpret_cast<const unsigned*>(row + x0 + 4);
-        p[0] = (d0 >> 8) & 255; p[1] = (d0 >> 16) & 255; p[2] = d0 >> 24;
-        p[3] = d1 & 255; p[4] = (d1 >> 8) & 255; p[5] = (d1 >> 16) & 255; p[6] = d1 >> 24;
-        p[7] = d2 & 255; p[8] = (d2 >> 8) & 255; p[9] = (d2 >> 16) & 255;
+        d0 = *reinterpret_cast<const unsigned*>(row + x0 - 4);
+        d1 = *reinterpret_cast<const unsigned*>(row + x0);
+        d2 = *reinterpret_cast<const unsigned*>(row + x0 + 4);
     } else {
+        unsigned b[12];
 #pragma unroll
-        for (int k = 0; k < 10; k++) p[k] = row[gfo_reflect101(x0 - 3 + k, w)];
+        for (int k = 0; k < 12; k++) b[k] = row[gfo_reflect101(x0 - 4 + k, w)];
+        d0 = b[0] | (b[1] << 8) | (b[2] << 16) | (b[3] << 24);
+        d1 = b[4] | (b[5] << 8) | (b[6] << 16) | (b[7] << 24);
+        d2 = b[8] | (b[9] << 8) | (b[10] << 16) | (b[11] << 24);
     }
-    return hpass(p);
+    return hpass_dot(d0, d1, d2);
 }
 
 __device__ __forceinline__ unsigned vout(unsigned a06, unsigned a15, unsigned a24, unsigned a3)
