@@ -54,14 +54,33 @@ __global__ __launch_bounds__(256) void k_orient_desc(const GfoGeom* __restrict__
                                                      const uint8_t* __restrict__ pyr, const uint8_t* __restrict__ blur,
                                                      const uint32_t* __restrict__ sel, const int* __restrict__ sel_cnt,
                                                      gfo_keypoint* __restrict__ kp_out, uint8_t* __restrict__ desc_out,
-                                                     int* __restrict__ kp_cnt, int* __restrict__ flags)
+                                                     int* __restrict__ kp_cnt, int* __restrict__ flags, int nimg,
+                                                     int blocks_per_img)
 {
     __shared__ __attribute__((aligned(16))) uint8_t s_win[4][DW * DWP];
     __shared__ __attribute__((aligned(16))) uint8_t s_pat[4][OW * OWP];
     const GfoGeom& g = *gp;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int img = blockIdx.y;
-    const int slot = blockIdx.x * 4 + wave;
+    // XCD-aware placement (speed only): workgroups are dealt round-robin over the 8 XCDs, so workgroup b runs
+    // on XCD b % 8.  All workgroups of one image are given the same b % 8, so an image's windows (2.2 MB of
+    // pyramid + blurred pyramid, overlapping heavily between keypoints) are fetched into ONE 4-MB L2 instead
+    // of all eight.  Any placement gives the same results.
+    int img, blk;
+    {
+        const int b = blockIdx.x;
+        const int groups = nimg >> 3;  // full groups of 8 images
+        const int swz = groups * 8 * blocks_per_img;
+        if (b < swz) {
+            const int xcd = b & 7, s = b >> 3;
+            img = (s / blocks_per_img) * 8 + xcd;
+            blk = s - (s / blocks_per_img) * blocks_per_img;
+        } else {  // the < 8 images left over: plain order
+            const int r = b - swz;
+            img = groups * 8 + r / blocks_per_img;
+            blk = r - (r / blocks_per_img) * blocks_per_img;
+        }
+    }
+    const int slot = blk * 4 + wave;
     // level of this slot: prefix over the per-level counts (wave-uniform)
     int level = -1, idx = 0, acc = 0;
     for (int l = 0; l < g.nlevels; l++) {
@@ -159,9 +178,10 @@ __global__ __launch_bounds__(256) void k_orient_desc(const GfoGeom* __restrict__
 
 void gfo_launch_orient_desc(gfo_ctx* c, const GfoInput& in, int nimg)
 {
-    dim3 grid((c->g.kp_stride + 3) / 4, nimg);
+    const int bpi = (c->g.kp_stride + 3) / 4;
+    dim3 grid((unsigned)bpi * (unsigned)nimg);
     gfo_prof_begin(c, ST_ORIENT_DESC);
     hipLaunchKernelGGL(k_orient_desc, grid, dim3(256), 0, c->stream, c->d_geom, in, c->d_pyr, c->d_blur, c->d_sel,
-                       c->d_sel_cnt, c->d_kp, c->d_desc, c->d_kp_cnt, c->d_flags);
+                       c->d_sel_cnt, c->d_kp, c->d_desc, c->d_kp_cnt, c->d_flags, nimg, bpi);
     gfo_prof_end(c);
 }
