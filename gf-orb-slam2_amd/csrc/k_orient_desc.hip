@@ -104,34 +104,39 @@ __global__ __launch_bounds__(256) void k_orient_desc(const GfoGeom* __restrict__
     uint8_t* pat = s_pat[wave * 2 + half];
     uint8_t* win = s_win[wave * 2 + half];
     {
+        // the LDS offsets are recomputed at store time rather than kept: 22 fewer live registers while the
+        // loads are in flight (occupancy matters more than the extra integer operations here)
         unsigned vp[OD_PAT_K], vw[OD_WIN_K];
-        int dp[OD_PAT_K], dw[OD_WIN_K];
         const int pn = odpr * OW, wn = wdpr * DW;
         const float pinv = 1.0f / (float)odpr, winv = 1.0f / (float)wdpr;
 #pragma unroll
         for (int k = 0; k < OD_PAT_K; k++) {
-            const int t = k * 32 + hl;
-            const int tt = min(t, pn - 1);
+            const int tt = min(k * 32 + hl, pn - 1);
             const int r = (int)(((float)tt + 0.5f) * pinv);
-            const int c = tt - r * odpr;
-            dp[k] = t < pn ? r * OWP + 4 * c : -1;
-            vp[k] = *reinterpret_cast<const unsigned*>(psrc + (long long)r * pitch + 4 * c);
+            vp[k] = *reinterpret_cast<const unsigned*>(psrc + (long long)r * pitch + 4 * (tt - r * odpr));
+        }
+#pragma unroll
+        for (int k = 0; k < OD_WIN_K; k++) {
+            const int tt = min(k * 32 + hl, wn - 1);
+            const int r = (int)(((float)tt + 0.5f) * winv);
+            vw[k] = *reinterpret_cast<const unsigned*>(wsrc + (long long)r * lpitch + 4 * (tt - r * wdpr));
+        }
+#pragma unroll
+        for (int k = 0; k < OD_PAT_K; k++) {
+            const int t = k * 32 + hl;
+            if (t < pn) {
+                const int r = (int)(((float)t + 0.5f) * pinv);
+                *reinterpret_cast<unsigned*>(pat + r * OWP + 4 * (t - r * odpr)) = vp[k];
+            }
         }
 #pragma unroll
         for (int k = 0; k < OD_WIN_K; k++) {
             const int t = k * 32 + hl;
-            const int tt = min(t, wn - 1);
-            const int r = (int)(((float)tt + 0.5f) * winv);
-            const int c = tt - r * wdpr;
-            dw[k] = t < wn ? r * DWP + 4 * c : -1;
-            vw[k] = *reinterpret_cast<const unsigned*>(wsrc + (long long)r * lpitch + 4 * c);
+            if (t < wn) {
+                const int r = (int)(((float)t + 0.5f) * winv);
+                *reinterpret_cast<unsigned*>(win + r * DWP + 4 * (t - r * wdpr)) = vw[k];
+            }
         }
-#pragma unroll
-        for (int k = 0; k < OD_PAT_K; k++)
-            if (dp[k] >= 0) *reinterpret_cast<unsigned*>(pat + dp[k]) = vp[k];
-#pragma unroll
-        for (int k = 0; k < OD_WIN_K; k++)
-            if (dw[k] >= 0) *reinterpret_cast<unsigned*>(win + dw[k]) = vw[k];
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
