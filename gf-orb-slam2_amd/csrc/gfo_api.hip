@@ -404,7 +404,15 @@ extern "C" int gfo_ctx_max_keypoints(const gfo_ctx* c)
 // ---------------------------------------------------------------------------------------------
 static int run_pyramid(gfo_ctx* c, const GfoInput& in, int nimg)
 {
-    for (int l = 1; l < c->g.nlevels; l++) gfo_launch_resize(c, in, l, nimg);
+    // big levels: one launch each (they fill the chip); the small top levels: one fused launch, one workgroup
+    // per image (each of them alone is latency-bound)
+    static const int tail_px = getenv("GFO_RESIZE_TAIL_PX") ? atoi(getenv("GFO_RESIZE_TAIL_PX")) : 100000;
+    int l = 1;
+    for (; l < c->g.nlevels; l++) {
+        if (c->g.lv[l].w * c->g.lv[l].h <= tail_px && nimg >= 32) break;
+        gfo_launch_resize(c, in, l, nimg);
+    }
+    if (l < c->g.nlevels) gfo_launch_resize_tail(c, in, l, nimg);
     c->last_in = in;
     c->last_nimg = nimg;
     c->have_pyramid = true;

@@ -167,6 +167,7 @@ struct gfo_ctx {
 
 // ---- kernel launchers (each in its own .hip file) ------------------------------------------
 void gfo_launch_resize(gfo_ctx* c, const GfoInput& in, int level, int nimg);
+void gfo_launch_resize_tail(gfo_ctx* c, const GfoInput& in, int level_begin, int nimg);
 void gfo_launch_blur(gfo_ctx* c, const GfoInput& in, int nimg);
 void gfo_launch_fast(gfo_ctx* c, const GfoInput& in, int nimg);
 void gfo_launch_quadtree(gfo_ctx* c, int nimg);

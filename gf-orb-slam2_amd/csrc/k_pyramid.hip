@@ -47,21 +47,12 @@ __device__ __forceinline__ HQuad resize_hrow(const uint8_t* __restrict__ row, in
 
 // Tables: one int2 per output column / row = {source offset, coef0 | coef1 << 16}; every level's table is
 // padded with 3 copies of its last entry so a thread may read its 4 entries as two 16-byte loads.
-__global__ __launch_bounds__(256) void k_resize(const GfoGeom* __restrict__ gp, GfoInput in, uint8_t* __restrict__ pyr,
-                                                int level, const int2* __restrict__ xtab_all,
-                                                const int2* __restrict__ ytab_all)
+// One 4x4 output block (column quad `quad`, row strip `strip`) of level `level` of image `img`.
+__device__ __forceinline__ void resize_block(const GfoGeom& g, const GfoInput& in, uint8_t* __restrict__ pyr, int level, int img,
+                                             int quad, int strip, const int2* __restrict__ xtab_all,
+                                             const int2* __restrict__ ytab_all)
 {
-    const GfoGeom& g = *gp;
     const GfoLevel& L = g.lv[level];
-    const int img = blockIdx.y;
-    const int quads = (L.w + 3) >> 2;
-    const int strips = (L.h + RS_STRIP - 1) / RS_STRIP;
-    // one wave = up to 64 quads of ONE strip, so the row tables are wave-uniform
-    const int wps = (quads + 63) >> 6;
-    const int wv = __builtin_amdgcn_readfirstlane((blockIdx.x * 256 + threadIdx.x) >> 6);
-    const int strip = wv / wps;
-    const int quad = (wv - strip * wps) * 64 + (threadIdx.x & 63);
-    if (strip >= strips || quad >= quads) return;
     int spitch;
     const uint8_t* src = gfo_level_ptr(g, in, pyr, level - 1, img, &spitch);
     const int sh = g.lv[level - 1].h, sw = g.lv[level - 1].w;
@@ -136,6 +127,47 @@ __global__ __launch_bounds__(256) void k_resize(const GfoGeom* __restrict__ gp, 
     }
 }
 
+__global__ __launch_bounds__(256) void k_resize(const GfoGeom* __restrict__ gp, GfoInput in, uint8_t* __restrict__ pyr,
+                                                int level, const int2* __restrict__ xtab_all,
+                                                const int2* __restrict__ ytab_all)
+{
+    const GfoGeom& g = *gp;
+    const GfoLevel& L = g.lv[level];
+    const int quads = (L.w + 3) >> 2;
+    const int strips = (L.h + RS_STRIP - 1) / RS_STRIP;
+    // one wave = up to 64 quads of ONE strip, so the row tables are wave-uniform
+    const int wps = (quads + 63) >> 6;
+    const int wv = __builtin_amdgcn_readfirstlane((blockIdx.x * 256 + threadIdx.x) >> 6);
+    const int strip = wv / wps;
+    const int quad = (wv - strip * wps) * 64 + (threadIdx.x & 63);
+    if (strip >= strips || quad >= quads) return;
+    resize_block(g, in, pyr, level, blockIdx.y, quad, strip, xtab_all, ytab_all);
+}
+
+// The small top levels of the pyramid are launch-latency bound as separate kernels (each is a dependent
+// launch that cannot fill the chip).  One 1024-thread workgroup per image computes levels
+// [level_begin, nlevels) back to back: a workgroup barrier orders level l's stores before level l+1's loads
+// (same CU, same L1/L2 path).
+__global__ __launch_bounds__(1024) void k_resize_tail(const GfoGeom* __restrict__ gp, GfoInput in, uint8_t* __restrict__ pyr,
+                                                      int level_begin, const int2* __restrict__ xtab_all,
+                                                      const int2* __restrict__ ytab_all)
+{
+    const GfoGeom& g = *gp;
+    const int img = blockIdx.x;
+    for (int level = level_begin; level < g.nlevels; level++) {
+        const GfoLevel& L = g.lv[level];
+        const int quads = (L.w + 3) >> 2;
+        const int strips = (L.h + RS_STRIP - 1) / RS_STRIP;
+        const int ntask = quads * strips;
+        for (int t = threadIdx.x; t < ntask; t += 1024) {
+            const int strip = t / quads;
+            resize_block(g, in, pyr, level, img, t - strip * quads, strip, xtab_all, ytab_all);
+        }
+        __threadfence_block();
+        __syncthreads();
+    }
+}
+
 void gfo_launch_resize(gfo_ctx* c, const GfoInput& in, int level, int nimg)
 {
     const GfoLevel& L = c->g.lv[level];
@@ -144,6 +176,14 @@ void gfo_launch_resize(gfo_ctx* c, const GfoInput& in, int level, int nimg)
     dim3 grid((waves + 3) / 4, nimg);
     gfo_prof_begin(c, ST_RESIZE);
     hipLaunchKernelGGL(k_resize, grid, dim3(256), 0, c->stream, c->d_geom, in, c->d_pyr, level,
+                       reinterpret_cast<const int2*>(c->d_xofs), reinterpret_cast<const int2*>(c->d_yofs));
+    gfo_prof_end(c);
+}
+
+void gfo_launch_resize_tail(gfo_ctx* c, const GfoInput& in, int level_begin, int nimg)
+{
+    gfo_prof_begin(c, ST_RESIZE);
+    hipLaunchKernelGGL(k_resize_tail, dim3(nimg), dim3(1024), 0, c->stream, c->d_geom, in, c->d_pyr, level_begin,
                        reinterpret_cast<const int2*>(c->d_xofs), reinterpret_cast<const int2*>(c->d_yofs));
     gfo_prof_end(c);
 }
