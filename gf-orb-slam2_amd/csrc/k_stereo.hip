@@ -9,7 +9,7 @@
 //   k_stereo_bucket : one workgroup per pair counting-sorts the right keypoints by floor(y)
 //                     (LDS histogram + scan) and writes them as a compact SoA in bucket order
 //                     (x, y, octave|iR, 32-byte descriptor), so the matcher reads contiguous memory;
-//   k_stereo_match  : one wavefront per left keypoint sweeps the buckets [row-W, row+W]
+//   k_stereo_match  : one 32-lane half-wave per left keypoint sweeps the buckets [row-W, row+W]
 //                     (W = ceil(2*max scale)+1 covers every band that can contain `row`), applies the
 //                     exact band / octave / disparity-window predicates, takes the 256-bit Hamming
 //                     distance with v_bcnt and wave-reduces min(dist << 16 | iR);
@@ -102,13 +102,19 @@ __global__ __launch_bounds__(256) void k_stereo_bucket(StereoArgs a)
     }
 }
 
+// Two left keypoints per wavefront, one per 32-lane half: the work per keypoint is a short chain of
+// dependent loads (keypoint -> bucket range -> ~80 candidates), so the kernel is latency-bound and two
+// independent chains per wave halve the waves to retire.
 __global__ __launch_bounds__(256) void k_stereo_match(StereoArgs a)
 {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int half = lane >> 5, hl = lane & 31;
     const int pair = blockIdx.y;
-    const int iL = blockIdx.x * 4 + wave;
     const int nl = a.cnt_dev ? a.cnt_dev[2 * pair] : a.nl_host;
-    if (iL >= nl) return;
+    const int iL0 = (blockIdx.x * 4 + wave) * 2;
+    if (iL0 >= nl) return;                         // wave-uniform
+    const bool act = iL0 + half < nl;
+    const int iL = min(iL0 + half, nl - 1);        // an idle second half redoes the last keypoint, writes nothing
     const gfo_keypoint* kl = a.kl + pair * a.pair_stride;
     const uint8_t* dl = a.dl + pair * a.pair_stride * 32;
     const long long o = (long long)pair * a.out_stride + iL;
@@ -119,61 +125,61 @@ __global__ __launch_bounds__(256) void k_stereo_match(StereoArgs a)
     const gfo_keypoint L = kl[iL];
     const float vL = L.y, uL = L.x;
     const int nRows = a.p.n_rows;
-    if (!(vL < 0 || vL > (float)(nRows - 1))) {  // Frame.cc:1208
-        const int row = (int)vL;
-        float minD = 0.f, maxD = a.p.mbf / a.p.mb;  // :1199-1200 (minZ = mb)
-        if (a.min_d && a.max_d) {                  // :1220-1231 flattened by the adapter
-            minD = a.min_d[iL];
-            maxD = a.max_d[iL];
+    const bool in_rows = !(vL < 0 || vL > (float)(nRows - 1));  // Frame.cc:1208
+    const int row = in_rows ? (int)vL : 0;
+    float minD = 0.f, maxD = a.p.mbf / a.p.mb;  // :1199-1200 (minZ = mb)
+    if (a.min_d && a.max_d) {                  // :1220-1231 flattened by the adapter
+        minD = a.min_d[iL];
+        maxD = a.max_d[iL];
+    }
+    const float minU = uL - maxD, maxU = uL - minD;
+    const uint4* dlp = reinterpret_cast<const uint4*>(dl + (long long)iL * 32);
+    const uint4 a0 = dlp[0], a1 = dlp[1];
+    const int* rs = a.row_start + (long long)pair * (nRows + 1);
+    const int jb = rs[max(row - a.window, 0)], je = in_rows ? rs[min(row + a.window + 1, nRows)] : jb;
+    unsigned best = ((unsigned)TH_HIGH << 16);  // bestDist = TH_HIGH, iR = 0: only dist < TH_HIGH replaces it
+    bool any = false;
+    for (int j = jb + hl; j < je; j += 32) {
+        const float ry = a.sy[so + j];
+        const unsigned oi = a.soi[so + j];
+        const int oct = (int)(oi >> 16);
+        // Frame.h:248-256 row band of this right keypoint
+        const float r = 2.0f * a.scale[oct];
+        const int maxr = (int)fminf((float)(nRows - 1), ceilf(ry + r));
+        const int minr = (int)fmaxf(0.0f, floorf(ry - r));
+        if (row < minr || row > maxr) continue;
+        any = true;
+        if (oct < L.octave - 1 || oct > L.octave + 1) continue;  // :1250
+        const float rx = a.sx[so + j];
+        if (rx >= minU && rx <= maxU) {                          // :1255
+            const unsigned dist = (unsigned)hamming256(a0, a1, a.sdesc[2 * (so + j)], a.sdesc[2 * (so + j) + 1]);
+            best = min(best, (dist << 16) | (oi & 0xFFFF));      // first minimum in iR order (:1260)
         }
-        const float minU = uL - maxD, maxU = uL - minD;
-        const uint4* dlp = reinterpret_cast<const uint4*>(dl + (long long)iL * 32);
-        const uint4 a0 = dlp[0], a1 = dlp[1];
-        const int* rs = a.row_start + (long long)pair * (nRows + 1);
-        const int jb = rs[max(row - a.window, 0)], je = rs[min(row + a.window + 1, nRows)];
-        unsigned best = ((unsigned)TH_HIGH << 16);  // bestDist = TH_HIGH, iR = 0: only dist < TH_HIGH replaces it
-        bool any = false;
-        for (int j = jb + lane; j < je; j += 64) {
-            const float ry = a.sy[so + j];
-            const unsigned oi = a.soi[so + j];
-            const int oct = (int)(oi >> 16);
-            // Frame.h:248-256 row band of this right keypoint
-            const float r = 2.0f * a.scale[oct];
-            const int maxr = (int)fminf((float)(nRows - 1), ceilf(ry + r));
-            const int minr = (int)fmaxf(0.0f, floorf(ry - r));
-            if (row < minr || row > maxr) continue;
-            any = true;
-            if (oct < L.octave - 1 || oct > L.octave + 1) continue;  // :1250
-            const float rx = a.sx[so + j];
-            if (rx >= minU && rx <= maxU) {                          // :1255
-                const unsigned dist = (unsigned)hamming256(a0, a1, a.sdesc[2 * (so + j)], a.sdesc[2 * (so + j) + 1]);
-                best = min(best, (dist << 16) | (oi & 0xFFFF));      // first minimum in iR order (:1260)
-            }
-        }
-        const bool have_cands = __any(any);
-        if (have_cands && !(maxU < a.p.min_x)) {  // :1213, :1236
-            counted = 1;
+    }
+    const unsigned long long anym = __ballot(any);
+    const bool have_cands = ((anym >> (32 * half)) & 0xFFFFFFFFull) != 0;
 #pragma unroll
-            for (int s = 32; s > 0; s >>= 1) best = min(best, (unsigned)__shfl_xor((int)best, s));
-            const int bestDist = (int)(best >> 16);
-            const int bestIdxR = (int)(best & 0xFFFF);
-            if (bestDist < (TH_HIGH + TH_LOW) / 2) {  // :1269
-                float bestuR = (a.kr + pair * a.pair_stride)[bestIdxR].x;
-                float disparity = uL - bestuR;
-                if (disparity >= minD && disparity < maxD) {
-                    if (disparity <= 0) {
-                        disparity = 0.01f;
-                        bestuR = uL - 0.01f;
-                    }
-                    res_depth = a.p.mbf / disparity;
-                    res_u = bestuR;
-                    res_dist = bestDist;
-                    res_idx = bestIdxR;
+    for (int s = 16; s > 0; s >>= 1) best = min(best, (unsigned)__shfl_xor((int)best, s));  // inside the half
+    if (in_rows && have_cands && !(maxU < a.p.min_x)) {  // :1213, :1236
+        counted = 1;
+        const int bestDist = (int)(best >> 16);
+        const int bestIdxR = (int)(best & 0xFFFF);
+        if (bestDist < (TH_HIGH + TH_LOW) / 2) {  // :1269
+            float bestuR = (a.kr + pair * a.pair_stride)[bestIdxR].x;
+            float disparity = uL - bestuR;
+            if (disparity >= minD && disparity < maxD) {
+                if (disparity <= 0) {
+                    disparity = 0.01f;
+                    bestuR = uL - 0.01f;
                 }
+                res_depth = a.p.mbf / disparity;
+                res_u = bestuR;
+                res_dist = bestDist;
+                res_idx = bestIdxR;
             }
         }
     }
-    if (lane == 0) {
+    if (hl == 0 && act) {
         a.out.u_right[o] = res_u;
         a.out.depth[o] = res_depth;
         a.out.best_dist[o] = res_dist;
@@ -263,7 +269,7 @@ void gfo_launch_stereo(gfo_ctx* c, const GfoStereoLaunch& s)
     gfo_prof_begin(c, ST_STEREO_BUCKET);
     hipLaunchKernelGGL(k_stereo_bucket, dim3(s.npairs), dim3(256), (size_t)(s.p.n_rows + 256) * sizeof(int), c->stream, a);
     gfo_prof_end(c);
-    dim3 grid((max_nl + 3) / 4, s.npairs);
+    dim3 grid((max_nl + 7) / 8, s.npairs);  // 4 waves x 2 left keypoints per workgroup
     gfo_prof_begin(c, ST_STEREO);
     hipLaunchKernelGGL(k_stereo_match, grid, dim3(256), 0, c->stream, a);
     gfo_prof_end(c);
