@@ -58,7 +58,7 @@ SYMBOLS = [
     "gfo_ctx_synchronize", "gfo_ctx_tables", "gfo_ctx_max_keypoints", "gfo_extract", "gfo_extract_batch",
     "gfo_extract_batch_device", "gfo_batch_counts", "gfo_batch_fetch", "gfo_batch_device_views",
     "gfo_compute_pyramid", "gfo_pyramid_level", "gfo_hamming256", "gfo_stereo_match",
-    "gfo_stereo_match_batch", "gfo_stereo_fetch", "gfo_search_by_projection", "gfo_search_by_projection_queries", "gfo_search_by_bow", "gfo_vocabulary_upload", "gfo_bow_transform", "gfo_profile_enable",
+    "gfo_stereo_match_batch", "gfo_stereo_match_sad_batch", "gfo_stereo_fetch", "gfo_search_by_projection", "gfo_search_by_projection_queries", "gfo_search_by_bow", "gfo_vocabulary_upload", "gfo_bow_transform", "gfo_profile_enable",
     "gfo_profile_read", "gfo_debug_blurred_level", "gfo_debug_level_candidates",
 ]
 
@@ -125,6 +125,7 @@ def load_library():
     L.gfo_hamming256.argtypes = [vp, vp]
     L.gfo_stereo_match.argtypes = [vp, vp, vp, i, vp, vp, i, vp, i, C.POINTER(StereoParamsC), vp, vp, vp, vp, vp, vp, ip]
     L.gfo_stereo_match_batch.argtypes = [vp, C.POINTER(StereoParamsC)]
+    L.gfo_stereo_match_sad_batch.argtypes = [vp, f, f]
     L.gfo_stereo_fetch.argtypes = [vp, i, vp, vp, vp, vp, i, ip]
     L.gfo_search_by_projection.argtypes = [vp, vp, vp, vp, i, vp, i, C.POINTER(FrameBoundsC), vp, vp, i, f, f, vp, vp, vp, ip]
     L.gfo_search_by_projection_queries.argtypes = [vp, vp, vp, vp, vp, i, C.POINTER(FrameBoundsC), vp, vp, i, C.POINTER(ProjModeC),

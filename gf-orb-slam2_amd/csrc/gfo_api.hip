@@ -124,13 +124,13 @@ static void free_arena(gfo_ctx* c)
     void* ptrs[] = {c->d_geom, c->d_input, c->d_pyr, c->d_blur, c->d_cand, c->d_cand_cnt, c->d_node_of, c->d_sel,
                     c->d_sel_cnt, c->d_kp, c->d_desc, c->d_kp_cnt, c->d_flags, c->d_xofs, c->d_xcoef, c->d_yofs,
                     c->d_ycoef, c->st.u_right, c->st.depth, c->st.best_dist, c->st.best_idx, c->st.nmatched, c->st.counted,
-                    c->d_scale, c->st_sort.sx, c->st_sort.sy, c->st_sort.soi, c->st_sort.sdesc, c->st_sort.row_start};
+                    c->d_scale, c->d_inv_scale, c->st_sort.sx, c->st_sort.sy, c->st_sort.soi, c->st_sort.sdesc, c->st_sort.row_start};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     c->d_geom = nullptr; c->d_input = c->d_pyr = c->d_blur = nullptr; c->d_cand = nullptr; c->d_cand_cnt = nullptr;
     c->d_node_of = nullptr; c->d_sel = nullptr; c->d_sel_cnt = nullptr; c->d_kp = nullptr; c->d_desc = nullptr;
     c->d_kp_cnt = nullptr; c->d_flags = nullptr; c->d_xofs = nullptr; c->d_xcoef = nullptr; c->d_yofs = nullptr;
-    c->d_ycoef = nullptr; c->st = GfoStereoDev{}; c->d_scale = nullptr; c->st_sort = GfoStereoSort{}; c->st_rows_cap = 0;
+    c->d_ycoef = nullptr; c->st = GfoStereoDev{}; c->d_scale = nullptr; c->d_inv_scale = nullptr; c->st_sort = GfoStereoSort{}; c->st_rows_cap = 0;
     c->planned = false;
     c->have_batch = c->have_pyramid = c->have_stereo = false;
 }
@@ -285,6 +285,7 @@ static int plan(gfo_ctx* c, int w, int h, int batch)
     HIP_TRY(c, hipMalloc(&c->d_xofs, xtabv.size() * sizeof(int) + 64));
     HIP_TRY(c, hipMalloc(&c->d_yofs, ytabv.size() * sizeof(int) + 64));
     HIP_TRY(c, hipMalloc(&c->d_scale, GFO_MAX_LEVELS * sizeof(float)));
+    HIP_TRY(c, hipMalloc(&c->d_inv_scale, GFO_MAX_LEVELS * sizeof(float)));
     const size_t P = (B + 1) / 2;
     HIP_TRY(c, hipMalloc(&c->st.u_right, P * g.kp_stride * sizeof(float)));
     HIP_TRY(c, hipMalloc(&c->st.depth, P * g.kp_stride * sizeof(float)));
@@ -302,6 +303,7 @@ static int plan(gfo_ctx* c, int w, int h, int batch)
     HIP_TRY(c, hipMemcpy(c->d_xofs, xtabv.data(), xtabv.size() * sizeof(int), hipMemcpyHostToDevice));
     HIP_TRY(c, hipMemcpy(c->d_yofs, ytabv.data(), ytabv.size() * sizeof(int), hipMemcpyHostToDevice));
     HIP_TRY(c, hipMemcpy(c->d_scale, c->scale.data(), g.nlevels * sizeof(float), hipMemcpyHostToDevice));
+    HIP_TRY(c, hipMemcpy(c->d_inv_scale, c->inv_scale.data(), g.nlevels * sizeof(float), hipMemcpyHostToDevice));
     HIP_TRY(c, hipMemset(c->d_flags, 0, 4 * sizeof(int)));
     c->cap_batch = batch;
     c->planned = true;
@@ -736,6 +738,28 @@ extern "C" int gfo_stereo_match_batch(gfo_ctx* c, const gfo_stereo_params* p)
     sl.sort = c->st_sort; sl.sort_stride = c->g.kp_stride;
     sl.window = gfo_stereo_window(c->scale.data(), c->g.nlevels);
     gfo_launch_stereo(c, sl);
+    HIP_TRY(c, hipGetLastError());
+    c->have_stereo = true;
+    return GFO_OK;
+}
+
+extern "C" int gfo_stereo_match_sad_batch(gfo_ctx* c, float mbf, float mb)
+{
+    if (!c || !(mb > 0)) return GFO_ERR_INVALID;
+    if (!c->have_batch) return fail(c, GFO_ERR_STATE, "no batch has been extracted");
+    if (c->last_nimg < 2 || (c->last_nimg & 1)) return fail(c, GFO_ERR_STATE, "stereo needs an even number of images (L,R,L,R,...)");
+    const int npairs = c->last_nimg / 2;
+    GfoStereoLaunch sl{};
+    sl.kl = c->d_kp; sl.dl = c->d_desc;
+    sl.kr = c->d_kp + c->g.kp_stride; sl.dr = c->d_desc + (size_t)c->g.kp_stride * 32;
+    sl.cnt_dev = c->d_kp_cnt;
+    sl.pair_stride_kp = 2LL * c->g.kp_stride; sl.npairs = npairs;
+    sl.d_scale = c->d_scale;
+    sl.p = gfo_stereo_params{c->g.h0, mbf, mb, 0.f};  // nRows = mvImagePyramid[0].rows
+    sl.out = c->st; sl.out_stride = c->g.kp_stride;
+    sl.sort = c->st_sort; sl.sort_stride = c->g.kp_stride;
+    sl.window = gfo_stereo_window(c->scale.data(), c->g.nlevels);
+    gfo_launch_stereo_sad(c, sl, c->last_in, c->d_inv_scale);
     HIP_TRY(c, hipGetLastError());
     c->have_stereo = true;
     return GFO_OK;

@@ -139,6 +139,7 @@ struct gfo_ctx {
     int* d_yofs = nullptr;
     short* d_ycoef = nullptr;
     float* d_scale = nullptr;        // mvScaleFactor on the device
+    float* d_inv_scale = nullptr;    // mvInvScaleFactor on the device
     GfoStereoDev st{};
     GfoStereoSort st_sort{};
     int st_rows_cap = 0;             // rows the row_start table of st_sort is sized for
@@ -174,6 +175,7 @@ void gfo_launch_quadtree(gfo_ctx* c, int nimg);
 void gfo_launch_orient_desc(gfo_ctx* c, const GfoInput& in, int nimg);
 void gfo_launch_stereo(gfo_ctx* c, const GfoStereoLaunch& s);
 int gfo_stereo_window(const float* scale, int nlevels);
+void gfo_launch_stereo_sad(gfo_ctx* c, const GfoStereoLaunch& s, const GfoInput& in, const float* d_inv_scale);
 
 // profiling helpers (gfo_api.hip)
 void gfo_prof_begin(gfo_ctx* c, int stage);

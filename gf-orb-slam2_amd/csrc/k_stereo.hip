@@ -240,6 +240,223 @@ __global__ __launch_bounds__(256) void k_stereo_cut(const int* __restrict__ cnt_
     if (tid == 0) out.nmatched[pair] = s_cnt - s_drop;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Frame::ComputeStereoMatches (Frame.cc:889-1078), the SAD sub-pixel variant the reference compiles out with
+// ALTER_STEREO_MATCHING: same row-band Hamming search (on mvKeys / mvKeysRight, maxU < 0 instead of
+// < mnMinX), then an 11x11 SAD over 11 horizontal shifts on the keypoint's pyramid level of BOTH images,
+// parabola fit, and the same 2.1 x median cut on the SAD values.  One wavefront per left keypoint: lanes
+// sweep the candidates, then split the 121 window pixels; the eleven shift sums are wave-reduced.
+// All SAD terms are integers (differences of u8), so the float/double accumulation of the reference
+// (cv::norm on CV_32F) is exact and integer accumulation gives the same numbers.
+// ---------------------------------------------------------------------------------------------
+struct SadArgs {
+    StereoArgs s;
+    const GfoGeom* g;
+    GfoInput in;
+    const uint8_t* pyr;
+    const float* inv_scale;
+};
+
+__global__ __launch_bounds__(256) void k_stereo_match_sad(SadArgs A)
+{
+    const StereoArgs& a = A.s;
+    const GfoGeom& g = *A.g;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int pair = blockIdx.y;
+    const int iL = blockIdx.x * 4 + wave;
+    const int nl = a.cnt_dev[2 * pair];
+    if (iL >= nl) return;
+    const gfo_keypoint* kl = a.kl + pair * a.pair_stride;
+    const gfo_keypoint* kr = a.kr + pair * a.pair_stride;
+    const uint8_t* dl = a.dl + pair * a.pair_stride * 32;
+    const long long o = (long long)pair * a.out_stride + iL;
+    const long long so = (long long)pair * a.sort_stride;
+    float res_u = -1.0f, res_depth = -1.0f;
+    int res_dist = -1, res_idx = -1;
+    const gfo_keypoint L = kl[iL];
+    const float vL = L.y, uL = L.x;
+    const int nRows = a.p.n_rows;
+    const int row = (int)vL;
+    const float minD = 0.f, maxD = a.p.mbf / a.p.mb;
+    const float minU = uL - maxD, maxU = uL - minD;
+    if (row >= 0 && row <= nRows - 1 && !(maxU < 0)) {
+        const uint4* dlp = reinterpret_cast<const uint4*>(dl + (long long)iL * 32);
+        const uint4 a0 = dlp[0], a1 = dlp[1];
+        const int* rs = a.row_start + (long long)pair * (nRows + 1);
+        const int jb = rs[max(row - a.window, 0)], je = rs[min(row + a.window + 1, nRows)];
+        unsigned best = ((unsigned)TH_HIGH << 16);
+        for (int j = jb + lane; j < je; j += 64) {
+            const float ry = a.sy[so + j];
+            const unsigned oi = a.soi[so + j];
+            const int oct = (int)(oi >> 16);
+            const float r = 2.0f * a.scale[oct];
+            const int maxr = min((int)ceilf(ry + r), nRows - 1), minr = max((int)floorf(ry - r), 0);  // :910-916 (clamped)
+            if (row < minr || row > maxr) continue;
+            if (oct < L.octave - 1 || oct > L.octave + 1) continue;
+            const float rx = a.sx[so + j];
+            if (rx >= minU && rx <= maxU) {
+                const unsigned dist = (unsigned)hamming256(a0, a1, a.sdesc[2 * (so + j)], a.sdesc[2 * (so + j) + 1]);
+                best = min(best, (dist << 16) | (oi & 0xFFFF));
+            }
+        }
+#pragma unroll
+        for (int s = 32; s > 0; s >>= 1) best = min(best, (unsigned)__shfl_xor((int)best, s));
+        const int bestDist = (int)(best >> 16), bestIdxR = (int)(best & 0xFFFF);
+        if (bestDist < (TH_HIGH + TH_LOW) / 2) {  // :973
+            const int lvl = L.octave;
+            const float uR0 = kr[bestIdxR].x;
+            const float sfac = A.inv_scale[lvl];
+            const float scaleduL = roundf(uL * sfac), scaledvL = roundf(vL * sfac), scaleduR0 = roundf(uR0 * sfac);
+            const int w = 5, LL = 5;
+            int pl, prr;
+            const uint8_t* IL = gfo_level_ptr(g, A.in, A.pyr, lvl, 2 * pair, &pl);
+            const uint8_t* IR = gfo_level_ptr(g, A.in, A.pyr, lvl, 2 * pair + 1, &prr);
+            const int cu = (int)scaleduL, cv = (int)scaledvL, cr = (int)scaleduR0;
+            const float iniu = scaleduR0 + LL - w, endu = scaleduR0 + LL + w + 1;
+            if (!(iniu < 0 || endu >= (float)g.lv[lvl].w)) {  // :1004
+                const int ilc = IL[(long long)cv * pl + cu];
+                int acc[11];
+#pragma unroll
+                for (int k = 0; k < 11; k++) acc[k] = 0;
+                for (int p0 = 0; p0 < 121; p0 += 64) {
+                    const int p = p0 + lane;
+                    if (p < 121) {
+                        const int dy = p / 11 - w, dx = p - (p / 11) * 11 - w;
+                        const int il = (int)IL[(long long)(cv + dy) * pl + cu + dx] - ilc;
+                        const uint8_t* rrow = IR + (long long)(cv + dy) * prr + cr + dx;
+                        const uint8_t* rcen = IR + (long long)cv * prr + cr;
+#pragma unroll
+                        for (int k = 0; k < 11; k++) {
+                            const int ir = (int)rrow[k - LL] - (int)rcen[k - LL];
+                            acc[k] += abs(il - ir);
+                        }
+                    }
+                }
+#pragma unroll
+                for (int k = 0; k < 11; k++)
+#pragma unroll
+                    for (int s = 32; s > 0; s >>= 1) acc[k] += __shfl_xor(acc[k], s);
+                int sadBest = 2147483647, bestinc = 0;
+#pragma unroll
+                for (int k = 0; k < 11; k++)
+                    if ((float)acc[k] < (float)sadBest) { sadBest = acc[k]; bestinc = k - LL; }  // :1019 (float < int compare)
+                if (!(bestinc == -LL || bestinc == LL)) {
+                    float d1 = 0.f, d2 = 0.f, d3 = 0.f;
+#pragma unroll
+                    for (int k = 1; k < 10; k++)
+                        if (k - LL == bestinc) { d1 = (float)acc[k - 1]; d2 = (float)acc[k]; d3 = (float)acc[k + 1]; }
+                    const float deltaR = (d1 - d3) / (2.0f * (d1 + d3 - 2.0f * d2));
+                    if (!(deltaR < -1 || deltaR > 1)) {
+                        float bestuR = g.lv[lvl].scale * ((float)scaleduR0 + (float)bestinc + deltaR);
+                        float disparity = uL - bestuR;
+                        if (disparity >= minD && disparity < maxD) {
+                            if (disparity <= 0) { disparity = 0.01f; bestuR = uL - 0.01f; }
+                            res_depth = a.p.mbf / disparity;
+                            res_u = bestuR;
+                            res_dist = sadBest;
+                            res_idx = bestIdxR;
+                        }
+                    }
+                }
+            }
+        }
+    }
+    if (lane == 0) {
+        a.out.u_right[o] = res_u;
+        a.out.depth[o] = res_depth;
+        a.out.best_dist[o] = res_dist;
+        a.out.best_idx[o] = res_idx;
+        a.out.counted[o] = res_dist >= 0 ? 1 : 0;
+    }
+}
+
+// exact rank-(n/2) order statistic of the SAD values (< 2^16) by a two-level 256-bin histogram, then the cut
+__global__ __launch_bounds__(256) void k_stereo_cut_sad(const int* __restrict__ cnt_dev, GfoStereoDev out, int out_stride)
+{
+    __shared__ int hist[256];
+    __shared__ int s_hi, s_rank, s_med, s_drop, s_n;
+    const int pair = blockIdx.x, tid = threadIdx.x;
+    const int nl = cnt_dev[2 * pair];
+    const long long o = (long long)pair * out_stride;
+    hist[tid] = 0;
+    if (tid == 0) s_drop = 0, s_n = 0;
+    __syncthreads();
+    int mine = 0;
+    for (int i = tid; i < nl; i += 256) {
+        const int d = out.best_dist[o + i];
+        if (d >= 0) { atomicAdd(&hist[min(d >> 8, 255)], 1); mine++; }
+    }
+    if (mine) atomicAdd(&s_n, mine);
+    __syncthreads();
+    const int ndi = s_n;
+    if (ndi == 0) { if (tid == 0) out.nmatched[pair] = 0; return; }
+    if (tid == 0) {
+        int acc = 0, b = 0;
+        for (; b < 256; b++) { if (acc + hist[b] > ndi / 2) break; acc += hist[b]; }
+        s_hi = b;
+        s_rank = ndi / 2 - acc;  // rank inside the bin
+    }
+    __syncthreads();
+    const int hi = s_hi;
+    __syncthreads();
+    hist[tid] = 0;
+    __syncthreads();
+    for (int i = tid; i < nl; i += 256) {
+        const int d = out.best_dist[o + i];
+        if (d >= 0 && min(d >> 8, 255) == hi) atomicAdd(&hist[d & 255], 1);
+    }
+    __syncthreads();
+    if (tid == 0) {
+        int acc = 0, b = 0;
+        for (; b < 256; b++) { acc += hist[b]; if (acc > s_rank) break; }
+        s_med = (hi << 8) | b;
+    }
+    __syncthreads();
+    const float thDist = 1.5f * 1.4f * (float)s_med;  // :1061
+    int drop = 0;
+    for (int i = tid; i < nl; i += 256) {
+        const int d = out.best_dist[o + i];
+        if (d >= 0 && !((float)d < thDist)) {
+            out.u_right[o + i] = -1.0f;
+            out.depth[o + i] = -1.0f;
+            drop++;
+        }
+    }
+    if (drop) atomicAdd(&s_drop, drop);
+    __syncthreads();
+    if (tid == 0) out.nmatched[pair] = ndi - s_drop;
+}
+
+void gfo_launch_stereo_sad(gfo_ctx* c, const GfoStereoLaunch& s, const GfoInput& in, const float* d_inv_scale)
+{
+    SadArgs A{};
+    StereoArgs& a = A.s;
+    a.kl = s.kl; a.dl = s.dl; a.kr = s.kr; a.dr = s.dr;
+    a.cnt_dev = s.cnt_dev; a.nl_host = 0; a.nr_host = 0;
+    a.pair_stride = s.pair_stride_kp;
+    a.scale = s.d_scale;
+    a.p = s.p;
+    a.min_d = nullptr; a.max_d = nullptr;
+    a.out = s.out; a.out_stride = s.out_stride;
+    a.sx = s.sort.sx; a.sy = s.sort.sy; a.soi = s.sort.soi; a.sdesc = reinterpret_cast<uint4*>(s.sort.sdesc);
+    a.row_start = s.sort.row_start;
+    a.sort_stride = s.sort_stride;
+    a.window = s.window;
+    A.g = c->d_geom;
+    A.in = in;
+    A.pyr = c->d_pyr;
+    A.inv_scale = d_inv_scale;
+    gfo_prof_begin(c, ST_STEREO_BUCKET);
+    hipLaunchKernelGGL(k_stereo_bucket, dim3(s.npairs), dim3(256), (size_t)(s.p.n_rows + 256) * sizeof(int), c->stream, a);
+    gfo_prof_end(c);
+    gfo_prof_begin(c, ST_STEREO);
+    hipLaunchKernelGGL(k_stereo_match_sad, dim3((s.out_stride + 3) / 4, s.npairs), dim3(256), 0, c->stream, A);
+    gfo_prof_end(c);
+    gfo_prof_begin(c, ST_STEREO_CUT);
+    hipLaunchKernelGGL(k_stereo_cut_sad, dim3(s.npairs), dim3(256), 0, c->stream, s.cnt_dev, s.out, s.out_stride);
+    gfo_prof_end(c);
+}
+
 int gfo_stereo_window(const float* scale, int nlevels)
 {
     float mx = 0.f;

@@ -61,6 +61,10 @@ class ORBmatcher:
         p = StereoParamsC(*params)
         check(self._L, self._ctx, self._L.gfo_stereo_match_batch(self._ctx, C.byref(p)))
 
+    def stereo_match_sad_batch(self, mbf, mb):
+        """Frame::ComputeStereoMatches (SAD variant, Frame.cc:889-1078) on the pairs of the last batch."""
+        check(self._L, self._ctx, self._L.gfo_stereo_match_sad_batch(self._ctx, mbf, mb))
+
     def stereo_fetch(self, pair, cap):
         u = np.zeros(cap, np.float32); dp = np.zeros(cap, np.float32)
         bd = np.zeros(cap, np.int32); bi = np.zeros(cap, np.int32)

@@ -137,6 +137,12 @@ int gfo_stereo_match(gfo_ctx* ctx, const gfo_keypoint* kl, const uint8_t* dl, in
 /* Device-chained form: images (2k, 2k+1) of the last batch are the left/right views of pair k.
  * Results stay on the device; fetch with gfo_stereo_fetch. */
 int gfo_stereo_match_batch(gfo_ctx* ctx, const gfo_stereo_params* p);
+/* Frame::ComputeStereoMatches (src/Frame.cc:889-1078): the SAD sub-pixel variant the reference compiles out
+ * with ALTER_STEREO_MATCHING (include/Frame.h:38).  It reads pyramid pixels of BOTH cameras, so it exists in the
+ * batched form only: images (2k, 2k+1) of the last batch, keypoints as extracted (mvKeys / mvKeysRight).
+ * gfo_stereo_fetch then returns mvuRight, mvDepth, best_dist = the SAD value kept in vDistIdx, and
+ * *nmatched = matches surviving the median cut. */
+int gfo_stereo_match_sad_batch(gfo_ctx* ctx, float mbf, float mb);
 int gfo_stereo_fetch(gfo_ctx* ctx, int pair, float* u_right, float* depth, int32_t* best_dist,
                      int32_t* best_idx_r, int cap, int* nmatched);
 

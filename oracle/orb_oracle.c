@@ -1194,3 +1194,116 @@ void orc_bow_transform(const orc_vocabulary* voc, const uint8_t* desc, int n, in
         node_id[i] = nid;
     }
 }
+
+/* ------------------------------------------------------------------------------------------
+ * Frame::ComputeStereoMatches -- Frame.cc:889-1078: best Hamming match along the row band, then an
+ * 11x11 SAD search over 11 horizontal shifts on the keypoint's pyramid level and a parabola fit.
+ * ---------------------------------------------------------------------------------------- */
+int orc_stereo_match_sad(const orc_extractor* el, const orc_extractor* er,
+                         const orc_keypoint* kl, const uint8_t* dl, int nl,
+                         const orc_keypoint* kr, const uint8_t* dr, int nr,
+                         float mbf, float mb, float* u_right, float* depth, int* best_dist_out)
+{
+    const int TH_HIGH = 100, TH_LOW = 50;
+    const int thOrbDist = (TH_HIGH + TH_LOW) / 2;
+    const int nRows = el->h[0];
+    int* start = (int*)calloc((size_t)nRows + 1, sizeof(int));
+    int* minr_a = (int*)malloc(sizeof(int) * (nr > 0 ? nr : 1));
+    int* maxr_a = (int*)malloc(sizeof(int) * (nr > 0 ? nr : 1));
+    for (int iR = 0; iR < nr; iR++) { /* :905-917 */
+        const float kpY = kr[iR].y;
+        const float r = 2.0f * el->scale[kr[iR].octave];
+        int maxr = (int)ceilf(kpY + r), minr = (int)floorf(kpY - r);
+        if (minr < 0) minr = 0;
+        if (maxr > nRows - 1) maxr = nRows - 1;
+        minr_a[iR] = minr; maxr_a[iR] = maxr;
+        for (int yi = minr; yi <= maxr; yi++) start[yi + 1]++;
+    }
+    for (int r = 0; r < nRows; r++) start[r + 1] += start[r];
+    int* items = (int*)malloc(sizeof(int) * (start[nRows] > 0 ? start[nRows] : 1));
+    int* fill = (int*)calloc((size_t)nRows, sizeof(int));
+    for (int iR = 0; iR < nr; iR++)
+        for (int yi = minr_a[iR]; yi <= maxr_a[iR]; yi++) items[start[yi] + fill[yi]++] = iR;
+    free(fill); free(minr_a); free(maxr_a);
+    const float minZ = mb, minD = 0, maxD = mbf / minZ;
+    dist_idx* di = (dist_idx*)malloc(sizeof(dist_idx) * (nl > 0 ? nl : 1));
+    int ndi = 0;
+    for (int iL = 0; iL < nl; iL++) { u_right[iL] = -1.0f; depth[iL] = -1.0f; if (best_dist_out) best_dist_out[iL] = -1; }
+    for (int iL = 0; iL < nl; iL++) {
+        const int levelL = kl[iL].octave;
+        const float vL = kl[iL].y, uL = kl[iL].x;
+        int row = (int)vL;
+        if (row < 0 || row > nRows - 1) continue; /* the reference would index out of bounds */
+        const int nC = start[row + 1] - start[row];
+        if (nC == 0) continue;
+        const float minU = uL - maxD, maxU = uL - minD;
+        if (maxU < 0) continue;
+        int bestDist = TH_HIGH, bestIdxR = 0;
+        for (int iC = 0; iC < nC; iC++) {
+            const int iR = items[start[row] + iC];
+            if (kr[iR].octave < levelL - 1 || kr[iR].octave > levelL + 1) continue;
+            const float uR = kr[iR].x;
+            if (uR >= minU && uR <= maxU) {
+                const int dist = orc_hamming256(dl + (size_t)iL * 32, dr + (size_t)iR * 32);
+                if (dist < bestDist) { bestDist = dist; bestIdxR = iR; }
+            }
+        }
+        if (bestDist < thOrbDist) { /* :973-1057 */
+            const float uR0 = kr[bestIdxR].x;
+            const float scaleFactor = el->inv_scale[levelL];
+            const float scaleduL = roundf(uL * scaleFactor);
+            const float scaledvL = roundf(vL * scaleFactor);
+            const float scaleduR0 = roundf(uR0 * scaleFactor);
+            const int w = 5, L = 5;
+            const uint8_t* IL = el->level[levelL];
+            const uint8_t* IR = er->level[levelL];
+            const int lw = el->w[levelL], rw = er->w[levelL];
+            const int cu = (int)scaleduL, cv = (int)scaledvL, cr = (int)scaleduR0;
+            const float iniu = scaleduR0 + L - w, endu = scaleduR0 + L + w + 1;
+            if (iniu < 0 || endu >= (float)rw) continue;
+            int sadBest = 2147483647, bestincR = 0;
+            float vDists[11];
+            const float ilc = (float)IL[(size_t)cv * lw + cu];
+            for (int incR = -L; incR <= L; incR++) {
+                const float irc = (float)IR[(size_t)cv * rw + cr + incR];
+                double acc = 0; /* cv::norm(NORM_L1) on CV_32F accumulates in double */
+                for (int dy = -w; dy <= w; dy++)
+                    for (int dx = -w; dx <= w; dx++) {
+                        const float a = (float)IL[(size_t)(cv + dy) * lw + cu + dx] - ilc;
+                        const float b = (float)IR[(size_t)(cv + dy) * rw + cr + incR + dx] - irc;
+                        acc += fabs((double)(a - b));
+                    }
+                const float dist = (float)acc;
+                if (dist < (float)sadBest) { sadBest = (int)dist; bestincR = incR; }
+                vDists[L + incR] = dist;
+            }
+            if (bestincR == -L || bestincR == L) continue;
+            const float dist1 = vDists[L + bestincR - 1], dist2 = vDists[L + bestincR], dist3 = vDists[L + bestincR + 1];
+            const float deltaR = (dist1 - dist3) / (2.0f * (dist1 + dist3 - 2.0f * dist2));
+            if (deltaR < -1 || deltaR > 1) continue;
+            float bestuR = el->scale[levelL] * ((float)scaleduR0 + (float)bestincR + deltaR);
+            float disparity = uL - bestuR;
+            if (disparity >= minD && disparity < maxD) {
+                if (disparity <= 0) { disparity = 0.01f; bestuR = uL - 0.01f; }
+                depth[iL] = mbf / disparity;
+                u_right[iL] = bestuR;
+                if (best_dist_out) best_dist_out[iL] = sadBest;
+                di[ndi].dist = sadBest; di[ndi].il = iL; ndi++;
+            }
+        }
+    }
+    int kept = ndi;
+    if (ndi > 0) { /* :1059-1076 (the reference reads vDistIdx[0] even when empty) */
+        qsort(di, ndi, sizeof(dist_idx), dist_idx_cmp);
+        const float median = (float)di[ndi / 2].dist;
+        const float thDist = 1.5f * 1.4f * median;
+        for (int i = ndi - 1; i >= 0; i--) {
+            if ((float)di[i].dist < thDist) break;
+            u_right[di[i].il] = -1;
+            depth[di[i].il] = -1;
+            kept--;
+        }
+    }
+    free(di); free(start); free(items);
+    return kept;
+}

@@ -100,6 +100,16 @@ int orc_stereo_match(const orc_keypoint* kl, const uint8_t* dl, int nl,
                      const float* min_d, const float* max_d,
                      float* u_right, float* depth, int* best_dist, int* best_idx_r);
 
+/* Frame::ComputeStereoMatches (the SAD sub-pixel variant, Frame.cc:889-1078; compiled out by
+ * ALTER_STEREO_MATCHING in the reference's default build).  el / er hold the pyramids of the left and right
+ * image (orc_extract / orc_compute_pyramid was run on them); kl/kr are mvKeys / mvKeysRight.
+ * Rows outside the image are clamped in the row table (the reference indexes it unchecked).
+ * best_dist[nl] = the SAD value pushed into vDistIdx (-1 if none).  Returns the number of matches kept. */
+int orc_stereo_match_sad(const orc_extractor* el, const orc_extractor* er,
+                         const orc_keypoint* kl, const uint8_t* dl, int nl,
+                         const orc_keypoint* kr, const uint8_t* dr, int nr,
+                         float mbf, float mb, float* u_right, float* depth, int* best_dist);
+
 /* Frame grid (Frame.cc:461-476, 593-658) + ORBmatcher::SearchByProjection(Frame&, MapPoints, th)
  * (ORBmatcher.cc:155-249) on flattened arrays. */
 typedef struct {

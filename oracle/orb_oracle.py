@@ -235,6 +235,19 @@ def stereo_match(kl, dl, kr, dr, scale_factors, n_rows, mbf, mb, min_x=0.0, min_
     return nm, u_right[:nl], depth[:nl], best_dist[:nl], best_idx[:nl]
 
 
+def stereo_match_sad(ext_l, ext_r, kl, dl, kr, dr, mbf, mb):
+    """Frame::ComputeStereoMatches (SAD variant); ext_l / ext_r are OracleExtractors that extracted the two images."""
+    kl = np.ascontiguousarray(kl, dtype=KEYPOINT_DTYPE); kr = np.ascontiguousarray(kr, dtype=KEYPOINT_DTYPE)
+    dl = np.ascontiguousarray(dl, dtype=np.uint8); dr = np.ascontiguousarray(dr, dtype=np.uint8)
+    nl, nr = len(kl), len(kr)
+    u = np.zeros(max(nl, 1), np.float32); dp = np.zeros(max(nl, 1), np.float32); bd = np.zeros(max(nl, 1), np.int32)
+    L = lib()
+    vp = C.c_void_p
+    L.orc_stereo_match_sad.argtypes = [vp, vp, vp, vp, C.c_int, vp, vp, C.c_int, C.c_float, C.c_float, vp, vp, vp]
+    n = L.orc_stereo_match_sad(ext_l._h, ext_r._h, _p(kl), _p(dl), nl, _p(kr), _p(dr), nr, mbf, mb, _p(u), _p(dp), _p(bd))
+    return n, u[:nl], dp[:nl], bd[:nl]
+
+
 def search_by_projection(kp_un, desc, u_right, scale_factors, bounds, mps, mp_desc, th, nn_ratio, kp_taken=None):
     kp_un = np.ascontiguousarray(kp_un, dtype=KEYPOINT_DTYPE)
     desc = np.ascontiguousarray(desc, dtype=np.uint8)

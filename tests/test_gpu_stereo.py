@@ -112,3 +112,28 @@ def test_chained_extract_and_match_on_device(ext, oracle, euroc_l, euroc_r):
         nm, u, dp, bd, bi = m.stereo_fetch(pair, len(kl))
         _cmp_stereo((nm, u, dp, bd, bi), ref)
     ext.set_stream(0)
+
+
+def test_sad_subpixel_variant(ext, oracle, euroc_l, euroc_r):
+    """Frame::ComputeStereoMatches, the variant behind ALTER_STEREO_MATCHING (Frame.cc:889-1078)"""
+    import torch
+    import gf_orb_slam2_amd as G
+    from gf_orb_slam2_amd.synth import synth_stereo_pair
+    sl, sr = synth_stereo_pair(752, 480, 3)
+    imgs = np.stack([sl, sr, euroc_l, euroc_r])
+    t = torch.from_numpy(imgs).cuda()
+    ext.set_stream(torch.cuda.current_stream().cuda_stream)
+    ext.extract_batch_device(t.data_ptr(), 4, 752, 480)
+    m = G.ORBmatcher(0.8, True, extractor=ext)
+    m.stereo_match_sad_batch(BF, BF / FX)
+    torch.cuda.synchronize()
+    for pair in range(2):
+        el = oracle.OracleExtractor(2000, 1.2, 8, 20, 7); er = oracle.OracleExtractor(2000, 1.2, 8, 20, 7)
+        kl, dl = el(imgs[2 * pair]); kr, dr = er(imgs[2 * pair + 1])
+        n, u, dp, bd = oracle.stereo_match_sad(el, er, kl, dl, kr, dr, BF, BF / FX)
+        gn, gu, gdp, gbd, gbi = m.stereo_fetch(pair, len(kl))
+        assert gn == n
+        assert gu.tobytes() == u.tobytes() and gdp.tobytes() == dp.tobytes()
+        np.testing.assert_array_equal(gbd, bd)
+        assert n > (500 if pair == 0 else 50)
+    ext.set_stream(0)
