@@ -48,6 +48,9 @@ __device__ __forceinline__ HQuad resize_hrow(const uint8_t* __restrict__ row, in
 // Tables: one int2 per output column / row = {source offset, coef0 | coef1 << 16}; every level's table is
 // padded with 3 copies of its last entry so a thread may read its 4 entries as two 16-byte loads.
 // One 4x4 output block (column quad `quad`, row strip `strip`) of level `level` of image `img`.
+// UNI: the strip (hence every row index) is the same for all lanes of the wave, so the source-row pair of an
+// output row is picked by a scalar branch instead of per-lane select chains.
+template <bool UNI>
 __device__ __forceinline__ void resize_block(const GfoGeom& g, const GfoInput& in, uint8_t* __restrict__ pyr, int level, int img,
                                              int quad, int strip, const int2* __restrict__ xtab_all,
                                              const int2* __restrict__ ytab_all)
@@ -93,16 +96,35 @@ __device__ __forceinline__ void resize_block(const GfoGeom& g, const GfoInput& i
             if (dy >= dy1) break;
             const int b0 = bw[j] & 0xFFFF, b1 = bw[j] >> 16;
             const int i0 = min(max(syv[j], 0), sh - 1) - r_first, i1 = min(max(syv[j] + 1, 0), sh - 1) - r_first;
+            HQuad ra = rows[0], rb = rows[0];
+            bool picked = false;
+            if (UNI) {
+                const int i0u = __builtin_amdgcn_readfirstlane(i0);
+                if (i1 == i0u + 1) {  // the usual case: rows (i0, i0+1); wave-uniform branch
+                    picked = true;
+                    switch (i0u) {
+                    case 0: ra = rows[0]; rb = rows[1]; break;
+                    case 1: ra = rows[1]; rb = rows[2]; break;
+                    case 2: ra = rows[2]; rb = rows[3]; break;
+                    case 3: ra = rows[3]; rb = rows[4]; break;
+                    default: ra = rows[4]; rb = rows[5]; break;
+                    }
+                }
+            }
+            if (!picked) {
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+#pragma unroll
+                    for (int m = 1; m < RS_MAXR; m++) {  // register select (no dynamic indexing of the row array)
+                        ra.h[k] = i0 == m ? rows[m].h[k] : ra.h[k];
+                        rb.h[k] = i1 == m ? rows[m].h[k] : rb.h[k];
+                    }
+                }
+            }
             unsigned packed = 0;
 #pragma unroll
             for (int k = 0; k < 4; k++) {
-                int h0 = rows[0].h[k], h1 = rows[0].h[k];
-#pragma unroll
-                for (int m = 1; m < RS_MAXR; m++) {  // register select (no dynamic indexing of the row array)
-                    h0 = i0 == m ? rows[m].h[k] : h0;
-                    h1 = i1 == m ? rows[m].h[k] : h1;
-                }
-                const int v = (((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2) >> 2;
+                const int v = (((b0 * (ra.h[k] >> 4)) >> 16) + ((b1 * (rb.h[k] >> 4)) >> 16) + 2) >> 2;
                 packed |= (unsigned)(v & 255) << (8 * k);
             }
             *reinterpret_cast<unsigned*>(dst + (long long)dy * L.pitch + dx0) = packed;  // pitch multiple of 64: tail dword stays in-row
@@ -141,7 +163,7 @@ __global__ __launch_bounds__(256) void k_resize(const GfoGeom* __restrict__ gp, 
     const int strip = wv / wps;
     const int quad = (wv - strip * wps) * 64 + (threadIdx.x & 63);
     if (strip >= strips || quad >= quads) return;
-    resize_block(g, in, pyr, level, blockIdx.y, quad, strip, xtab_all, ytab_all);
+    resize_block<true>(g, in, pyr, level, blockIdx.y, quad, strip, xtab_all, ytab_all);
 }
 
 // The small top levels of the pyramid are launch-latency bound as separate kernels (each is a dependent
@@ -161,7 +183,7 @@ __global__ __launch_bounds__(1024) void k_resize_tail(const GfoGeom* __restrict_
         const int ntask = quads * strips;
         for (int t = threadIdx.x; t < ntask; t += 1024) {
             const int strip = t / quads;
-            resize_block(g, in, pyr, level, img, t - strip * quads, strip, xtab_all, ytab_all);
+            resize_block<false>(g, in, pyr, level, img, t - strip * quads, strip, xtab_all, ytab_all);
         }
         __threadfence_block();
         __syncthreads();
