@@ -37,7 +37,7 @@ struct BowArgs {
 
 __global__ __launch_bounds__(256) void k_bow_match(BowArgs a)
 {
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;  // uniform: keep it scalar
     const int pi = blockIdx.x * 4 + wave;
     if (pi >= a.npairs) return;
     const int2 pr = a.pairs[pi];
@@ -247,7 +247,7 @@ __global__ __launch_bounds__(256) void k_bow_transform(VocDev v, const uint8_t* 
                                                        int* __restrict__ word_id, float* __restrict__ weight,
                                                        int* __restrict__ node_id)
 {
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;  // uniform: keep it scalar
     const int i = blockIdx.x * 4 + wave;
     if (i >= n) return;
     const uint4* d = reinterpret_cast<const uint4*>(desc + (long long)i * 32);

@@ -132,7 +132,8 @@ __global__ __launch_bounds__(256) void k_fast(const GfoGeom* __restrict__ gp, Gf
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     const GfoGeom& g = *gp;
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    // the wave index is uniform: keep it (and the cell geometry derived from it) in scalar registers
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int img = blockIdx.y;
     const int cell = blockIdx.x * 4 + wave;
     const int TP = g.fast_tile_pitch, SP = g.fast_smap_pitch;

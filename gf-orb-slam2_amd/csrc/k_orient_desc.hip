@@ -43,7 +43,7 @@ __global__ __launch_bounds__(256) void k_orient_desc(const GfoGeom* __restrict__
     __shared__ __attribute__((aligned(16))) uint8_t s_win[8][DW * DWP];   // [wave*2 + half]
     __shared__ __attribute__((aligned(16))) uint8_t s_pat[8][OW * OWP];
     const GfoGeom& g = *gp;
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;  // uniform: keep it scalar
     const int half = lane >> 5, hl = lane & 31;
     // XCD-aware placement (speed only): workgroups are dealt round-robin over the 8 XCDs, so workgroup b runs
     // on XCD b % 8.  All workgroups of one image are given the same b % 8, so an image's windows (2.2 MB of

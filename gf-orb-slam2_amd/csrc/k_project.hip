@@ -110,7 +110,7 @@ __device__ __forceinline__ int hamming_u4(const uint4 a0, const uint4 a1, const 
 template <bool ROUND0>
 __global__ __launch_bounds__(256) void k_project_eval(ProjArgs a)
 {
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;  // uniform: keep it scalar
     const int slot = blockIdx.x * 4 + wave;
     int iMP;
     if (ROUND0) {

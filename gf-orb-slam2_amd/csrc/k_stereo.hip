@@ -107,7 +107,7 @@ __global__ __launch_bounds__(256) void k_stereo_bucket(StereoArgs a)
 // independent chains per wave halve the waves to retire.
 __global__ __launch_bounds__(256) void k_stereo_match(StereoArgs a)
 {
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;  // uniform: keep it scalar
     const int half = lane >> 5, hl = lane & 31;
     const int pair = blockIdx.y;
     const int nl = a.cnt_dev ? a.cnt_dev[2 * pair] : a.nl_host;
@@ -261,7 +261,7 @@ __global__ __launch_bounds__(256) void k_stereo_match_sad(SadArgs A)
 {
     const StereoArgs& a = A.s;
     const GfoGeom& g = *A.g;
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;  // uniform: keep it scalar
     const int pair = blockIdx.y;
     const int iL = blockIdx.x * 4 + wave;
     const int nl = a.cnt_dev[2 * pair];
