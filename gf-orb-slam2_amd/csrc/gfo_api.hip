@@ -408,7 +408,7 @@ static int run_pyramid(gfo_ctx* c, const GfoInput& in, int nimg)
 {
     // big levels: one launch each (they fill the chip); the small top levels: one fused launch, one workgroup
     // per image (each of them alone is latency-bound)
-    static const int tail_px = getenv("GFO_RESIZE_TAIL_PX") ? atoi(getenv("GFO_RESIZE_TAIL_PX")) : 100000;
+    static const int tail_px = getenv("GFO_RESIZE_TAIL_PX") ? atoi(getenv("GFO_RESIZE_TAIL_PX")) : 60000;  // measured: fusing levels of <= 60k px wins, larger ones lose
     int l = 1;
     for (; l < c->g.nlevels; l++) {
         if (c->g.lv[l].w * c->g.lv[l].h <= tail_px && nimg >= 32) break;
