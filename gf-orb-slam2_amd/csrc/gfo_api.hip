@@ -172,7 +172,7 @@ static int plan(gfo_ctx* c, int w, int h, int batch)
     g.ini_th = c->prm.ini_th_fast;
     g.min_th = c->prm.min_th_fast;
     long long pyr_off = 0, blur_off = 0, cand_off = 0;
-    int cell_base = 0, tile_base = 0, sel_off = 0, xtab = 0, ytab = 0;
+    int cell_base = 0, tile_base = 0, blur_b = 0, sel_off = 0, xtab = 0, ytab = 0;
     int max_cw = 8, max_ch = 8;
     for (int l = 0; l < g.nlevels; l++) {
         GfoLevel& L = g.lv[l];
@@ -207,8 +207,15 @@ static int plan(gfo_ctx* c, int w, int h, int batch)
         cand_off += align_up(L.cand_cap, 64);
         L.tiles_x = (L.w + 3) / 4;      // blur: column quads per row
         L.tiles_y = (L.h + 31) / 32;    // blur: 32-row strips
-        L.tile_base = tile_base;        // blur: first 256-thread block of this level
-        tile_base += (L.tiles_x * L.tiles_y + 255) / 256;
+        {
+            int nint = (L.w - 8) / 4;
+            if (nint > L.tiles_x - 1) nint = L.tiles_x - 1;
+            if (nint < 0) nint = 0;
+            L.tile_base = tile_base;        // blur: first block of this level in the interior launch
+            tile_base += (nint * L.tiles_y + 255) / 256;
+            L.blur_base_b = blur_b;         // ... and in the border launch
+            blur_b += ((L.tiles_x - nint) * L.tiles_y + 255) / 256;
+        }
         L.quota = c->quota[l];
         int nini = 1;
         if (L.max_by - GFO_MIN_BORDER > 0) nini = (int)roundf(width / height);  // :543
@@ -234,6 +241,7 @@ static int plan(gfo_ctx* c, int w, int h, int batch)
     const int xtab_n = xtab, ytab_n = ytab;
     g.total_cells = cell_base;
     g.total_tiles = tile_base;
+    g.blur_total_b = blur_b;
     g.total_sel_cap = sel_off;
     g.kp_stride = (int)align_up(sel_off, 4);
     g.fast_tile_pitch = (int)align_up(max_cw + 3, 16);  // +3: tile rows start at the aligned dword left of the cell; 16-B segments

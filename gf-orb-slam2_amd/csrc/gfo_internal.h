@@ -27,7 +27,8 @@ struct GfoLevel {
     int max_bx, max_by;       // maxBorderX/Y = w-16, h-16
     int cell_base;            // prefix of ncols*nrows over levels
     // blur tiling
-    int tiles_x, tiles_y, tile_base;
+    int tiles_x, tiles_y, tile_base;   // blur: quads per row, 32-row strips, first block of the interior launch
+    int blur_base_b;                   // blur: first block of the border launch
     // quadtree (ORBextractor.cc:539-563)
     int quota;                // mnFeaturesPerLevel[level]
     int n_ini;                // root nodes
@@ -48,7 +49,8 @@ struct GfoGeom {
     int nlevels;
     int w0, h0;
     int total_cells;
-    int total_tiles;
+    int total_tiles;          // blocks of the blur interior launch
+    int blur_total_b;         // blocks of the blur border launch
     int total_sel_cap;        // per image: sum of sel_cap
     int kp_stride;            // per image output capacity (>= total_sel_cap)
     int ini_th, min_th;

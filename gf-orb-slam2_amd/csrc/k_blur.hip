@@ -44,22 +44,32 @@ __device__ __forceinline__ HRow hpass_dot(unsigned d0, unsigned d1, unsigned d2)
     return r;
 }
 
-__device__ __forceinline__ HRow load_hrow(const uint8_t* __restrict__ row, int x0, int w, bool interior)
+struct RawRow {
+    unsigned d0, d1, d2;  // pixels x0-4 .. x0+7
+};
+
+__device__ __forceinline__ RawRow load_raw(const uint8_t* __restrict__ row, int x0, int w, bool interior)
 {
-    unsigned d0, d1, d2;
+    RawRow r;
     if (interior) {
-        d0 = *reinterpret_cast<const unsigned*>(row + x0 - 4);
-        d1 = *reinterpret_cast<const unsigned*>(row + x0);
-        d2 = *reinterpret_cast<const unsigned*>(row + x0 + 4);
+        r.d0 = *reinterpret_cast<const unsigned*>(row + x0 - 4);
+        r.d1 = *reinterpret_cast<const unsigned*>(row + x0);
+        r.d2 = *reinterpret_cast<const unsigned*>(row + x0 + 4);
     } else {
         unsigned b[12];
 #pragma unroll
         for (int k = 0; k < 12; k++) b[k] = row[gfo_reflect101(x0 - 4 + k, w)];
-        d0 = b[0] | (b[1] << 8) | (b[2] << 16) | (b[3] << 24);
-        d1 = b[4] | (b[5] << 8) | (b[6] << 16) | (b[7] << 24);
-        d2 = b[8] | (b[9] << 8) | (b[10] << 16) | (b[11] << 24);
+        r.d0 = b[0] | (b[1] << 8) | (b[2] << 16) | (b[3] << 24);
+        r.d1 = b[4] | (b[5] << 8) | (b[6] << 16) | (b[7] << 24);
+        r.d2 = b[8] | (b[9] << 8) | (b[10] << 16) | (b[11] << 24);
     }
-    return hpass_dot(d0, d1, d2);
+    return r;
+}
+
+__device__ __forceinline__ HRow load_hrow(const uint8_t* __restrict__ row, int x0, int w, bool interior)
+{
+    const RawRow r = load_raw(row, x0, w, interior);
+    return hpass_dot(r.d0, r.d1, r.d2);
 }
 
 __device__ __forceinline__ unsigned vout(unsigned a06, unsigned a15, unsigned a24, unsigned a3)
@@ -68,24 +78,32 @@ __device__ __forceinline__ unsigned vout(unsigned a06, unsigned a15, unsigned a2
     return min((acc + 32768u) >> 16, 255u);
 }
 
+// BORDER = false: the quads whose three dwords lie inside the row (no reflection, no byte loads) -- the bulk.
+// BORDER = true : the first quad of every row and the last one or two (reflected bytes), a thin separate launch,
+// so the streaming loop above carries no slow path at all.
+template <bool BORDER>
 __global__ __launch_bounds__(256) void k_blur(const GfoGeom* __restrict__ gp, GfoInput in,
                                               const uint8_t* __restrict__ pyr, uint8_t* __restrict__ blur)
 {
     const GfoGeom& g = *gp;
     const int blk = blockIdx.x, img = blockIdx.y;
     int level = 0;
-    while (level + 1 < g.nlevels && blk >= g.lv[level + 1].tile_base) level++;
+    while (level + 1 < g.nlevels && blk >= (BORDER ? g.lv[level + 1].blur_base_b : g.lv[level + 1].tile_base)) level++;
     const GfoLevel& L = g.lv[level];
-    const int t = (blk - L.tile_base) * 256 + threadIdx.x;
-    const int quads = L.tiles_x;  // ceil(w/4)
-    const int strip = t / quads, quad = t - strip * quads;
-    if (strip >= L.tiles_y) return;
-    const int x0 = quad * 4, y0 = strip * BLUR_STRIP;
+    const int t = (blk - (BORDER ? L.blur_base_b : L.tile_base)) * 256 + threadIdx.x;
     const int w = L.w, h = L.h;
+    const int quads = L.tiles_x;                       // ceil(w/4)
+    const int nint = max(0, min((w - 8) / 4, quads - 1));   // interior quads are 1 .. nint
+    const int per_row = BORDER ? quads - nint : nint;
+    if (per_row <= 0) return;
+    const int strip = t / per_row, qi = t - strip * per_row;
+    if (strip >= L.tiles_y) return;
+    const int quad = BORDER ? (qi == 0 ? 0 : nint + qi) : qi + 1;
+    const int x0 = quad * 4, y0 = strip * BLUR_STRIP;
     int pitch;
     const uint8_t* src = gfo_level_ptr(g, in, pyr, level, img, &pitch);
     uint8_t* dst = blur + (long long)img * g.blur_img_stride + L.blur_off;
-    const bool interior = x0 >= 4 && x0 + 8 <= w;  // the three dwords stay inside the row
+    const bool interior = !BORDER;
     const int y1 = min(y0 + BLUR_STRIP, h);
 
     HRow r0, r1, r2, r3, r4, r5, r6;
@@ -95,8 +113,15 @@ __global__ __launch_bounds__(256) void k_blur(const GfoGeom* __restrict__ gp, Gf
     r3 = load_hrow(src + (long long)y0 * pitch, x0, w, interior);
     r4 = load_hrow(src + (long long)gfo_reflect101(y0 + 1, h) * pitch, x0, w, interior);
     r5 = load_hrow(src + (long long)gfo_reflect101(y0 + 2, h) * pitch, x0, w, interior);
+    // the raw dwords of row y+4 are requested one step before they are filtered (two rows of loads in flight
+    // per thread).  Measured alternatives that were slower: a 7-row unrolled window (106 VGPRs, 4 waves/SIMD),
+    // and one load per lane with the neighbour dwords fetched by lane shuffle (the ds_bpermute traffic costs
+    // more than the L1-served overlapping loads).
+    RawRow nxt = load_raw(src + (long long)gfo_reflect101(y0 + 3, h) * pitch, x0, w, interior);
     for (int y = y0; y < y1; y++) {
-        r6 = load_hrow(src + (long long)gfo_reflect101(y + 3, h) * pitch, x0, w, interior);
+        const RawRow cur = nxt;
+        nxt = load_raw(src + (long long)gfo_reflect101(y + 4, h) * pitch, x0, w, interior);
+        r6 = hpass_dot(cur.d0, cur.d1, cur.d2);
         // vertical pass on the four columns (u32 accumulation: 257 * 65535 < 2^32)
         const unsigned o0 = vout((r0.lo & 0xFFFF) + (r6.lo & 0xFFFF), (r1.lo & 0xFFFF) + (r5.lo & 0xFFFF), (r2.lo & 0xFFFF) + (r4.lo & 0xFFFF), r3.lo & 0xFFFF);
         const unsigned o1 = vout((r0.lo >> 16) + (r6.lo >> 16), (r1.lo >> 16) + (r5.lo >> 16), (r2.lo >> 16) + (r4.lo >> 16), r3.lo >> 16);
@@ -109,8 +134,10 @@ __global__ __launch_bounds__(256) void k_blur(const GfoGeom* __restrict__ gp, Gf
 
 void gfo_launch_blur(gfo_ctx* c, const GfoInput& in, int nimg)
 {
-    dim3 grid(c->g.total_tiles, nimg);
     gfo_prof_begin(c, ST_BLUR);
-    hipLaunchKernelGGL(k_blur, grid, dim3(256), 0, c->stream, c->d_geom, in, c->d_pyr, c->d_blur);
+    if (c->g.total_tiles > 0)
+        hipLaunchKernelGGL(k_blur<false>, dim3(c->g.total_tiles, nimg), dim3(256), 0, c->stream, c->d_geom, in, c->d_pyr, c->d_blur);
+    if (c->g.blur_total_b > 0)
+        hipLaunchKernelGGL(k_blur<true>, dim3(c->g.blur_total_b, nimg), dim3(256), 0, c->stream, c->d_geom, in, c->d_pyr, c->d_blur);
     gfo_prof_end(c);
 }
