@@ -139,7 +139,8 @@ __global__ __launch_bounds__(256) void k_project_eval(ProjArgs a)
             unsigned long long k1 = ~0ull, k2 = ~0ull;  // two smallest (dist, ix, iy, idx) keys
             for (int ix = cx0; ix <= cx1; ix++) {
                 // cells (ix, cy0..cy1) are contiguous in the CSR
-                const int beg = a.cell_start[ix * GRID_ROWS + cy0], end = a.cell_start[ix * GRID_ROWS + cy1 + 1];
+                const int beg = max(a.cell_start[ix * GRID_ROWS + cy0], 0);
+                const int end = min(a.cell_start[ix * GRID_ROWS + cy1 + 1], a.n);  // bounded by the keypoint count whatever the table holds
                 for (int j = beg + lane; j < end; j += 64) {
                     const int i = a.cell_items[j];
                     const gfo_keypoint kp = a.kp[i];

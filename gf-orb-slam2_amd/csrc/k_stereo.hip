@@ -136,7 +136,9 @@ __global__ __launch_bounds__(256) void k_stereo_match(StereoArgs a)
     const uint4* dlp = reinterpret_cast<const uint4*>(dl + (long long)iL * 32);
     const uint4 a0 = dlp[0], a1 = dlp[1];
     const int* rs = a.row_start + (long long)pair * (nRows + 1);
-    const int jb = rs[max(row - a.window, 0)], je = in_rows ? rs[min(row + a.window + 1, nRows)] : jb;
+    int jb = rs[max(row - a.window, 0)], je = in_rows ? rs[min(row + a.window + 1, nRows)] : jb;
+    jb = min(max(jb, 0), a.sort_stride);  // the table is this kernel's input: never trust it with a loop bound
+    je = min(max(je, jb), a.sort_stride);
     unsigned best = ((unsigned)TH_HIGH << 16);  // bestDist = TH_HIGH, iR = 0: only dist < TH_HIGH replaces it
     bool any = false;
     for (int j = jb + hl; j < je; j += 32) {
@@ -283,7 +285,9 @@ __global__ __launch_bounds__(256) void k_stereo_match_sad(SadArgs A)
         const uint4* dlp = reinterpret_cast<const uint4*>(dl + (long long)iL * 32);
         const uint4 a0 = dlp[0], a1 = dlp[1];
         const int* rs = a.row_start + (long long)pair * (nRows + 1);
-        const int jb = rs[max(row - a.window, 0)], je = rs[min(row + a.window + 1, nRows)];
+        int jb = rs[max(row - a.window, 0)], je = rs[min(row + a.window + 1, nRows)];
+        jb = min(max(jb, 0), a.sort_stride);
+        je = min(max(je, jb), a.sort_stride);
         unsigned best = ((unsigned)TH_HIGH << 16);
         for (int j = jb + lane; j < je; j += 64) {
             const float ry = a.sy[so + j];

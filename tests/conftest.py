@@ -38,3 +38,15 @@ def oracle():
 def synth_frame(w, h, idx=0):
     from gf_orb_slam2_amd.synth import synth_frame as f
     return f(w, h, idx)
+
+
+@pytest.fixture(scope="session", autouse=True)
+def _gpu_runtime_first():
+    """On a GPU box bring torch's HIP runtime up before libgfo issues its first call (the order bench.py and
+    smoke() use): every later `import torch` inside a test is then a no-op instead of a second runtime
+    initialisation in the middle of the session."""
+    import torch
+    if torch.cuda.is_available():
+        torch.cuda.init()
+        torch.zeros(1, device="cuda").cpu()
+    yield
