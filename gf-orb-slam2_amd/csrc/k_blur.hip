@@ -66,11 +66,65 @@ __device__ __forceinline__ RawRow load_raw(const uint8_t* __restrict__ row, int 
     return r;
 }
 
-__device__ __forceinline__ HRow load_hrow(const uint8_t* __restrict__ row, int x0, int w, bool interior)
+// Border quads (the first of a row and the last one or two): the twelve bytes are a fixed, per-thread
+// rearrangement of one 16-byte window of the row (bytes [0,16) on the left, [w-16,w) on the right) --
+// BORDER_REFLECT_101 folds every out-of-row position back inside it.  The rearrangement is three v_perm_b32
+// selectors computed once per thread, so a row costs one wide load instead of twelve byte loads (the lanes of
+// a border wave sit in different rows: every load instruction touches 64 cache lines, so their count is what
+// the launch costs).
+struct BorderSel {
+    int ws;            // window start; < 0: row narrower than 16 px, byte path
+    unsigned sel[3];   // v_perm selector of output dword d over the dword pair (lo[d], lo[d]+1)
+    int lo[3];
+};
+
+__device__ __forceinline__ BorderSel border_sel(int x0, int w)
 {
-    const RawRow r = load_raw(row, x0, w, interior);
-    return hpass_dot(r.d0, r.d1, r.d2);
+    BorderSel b;
+    b.ws = w < 16 ? -1 : (x0 == 0 ? 0 : w - 16);
+#pragma unroll
+    for (int d = 0; d < 3; d++) {
+        int j[4], m = 15;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            j[k] = gfo_reflect101(x0 - 4 + 4 * d + k, w) - max(b.ws, 0);
+            m = min(m, j[k]);
+        }
+        b.lo[d] = min(max(m >> 2, 0), 3);
+        unsigned sel = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) sel |= (unsigned)((j[k] - 4 * b.lo[d]) & 7) << (8 * k);
+        b.sel[d] = sel;
+    }
+    return b;
 }
+
+__device__ __forceinline__ RawRow load_raw_border(const uint8_t* __restrict__ row, int x0, int w, const BorderSel& b)
+{
+    if (b.ws < 0) return load_raw(row, x0, w, false);
+    const uint4 v = *reinterpret_cast<const uint4*>(row + b.ws);
+    const unsigned dw[5] = {v.x, v.y, v.z, v.w, 0u};
+    unsigned out[3];
+#pragma unroll
+    for (int d = 0; d < 3; d++) {
+        const int l = b.lo[d];
+        const unsigned lo = l == 0 ? dw[0] : (l == 1 ? dw[1] : (l == 2 ? dw[2] : dw[3]));
+        const unsigned hi = l == 0 ? dw[1] : (l == 1 ? dw[2] : (l == 2 ? dw[3] : dw[4]));
+        out[d] = __builtin_amdgcn_perm(hi, lo, b.sel[d]);
+    }
+    RawRow r;
+    r.d0 = out[0]; r.d1 = out[1]; r.d2 = out[2];
+    return r;
+}
+
+template <bool BORDER>
+__device__ __forceinline__ RawRow load_row(const uint8_t* __restrict__ row, int x0, int w, const BorderSel& b)
+{
+    if (BORDER) return load_raw_border(row, x0, w, b);
+    return load_raw(row, x0, w, true);
+}
+
+__device__ __forceinline__ HRow hrow(const RawRow& r) { return hpass_dot(r.d0, r.d1, r.d2); }
 
 __device__ __forceinline__ unsigned vout(unsigned a06, unsigned a15, unsigned a24, unsigned a3)
 {
@@ -79,14 +133,12 @@ __device__ __forceinline__ unsigned vout(unsigned a06, unsigned a15, unsigned a2
 }
 
 // BORDER = false: the quads whose three dwords lie inside the row (no reflection, no byte loads) -- the bulk.
-// BORDER = true : the first quad of every row and the last one or two (reflected bytes), a thin separate launch,
-// so the streaming loop above carries no slow path at all.
+// BORDER = true : the first quad of every row and the last one or two (reflected bytes), in blocks of their
+// own, so the streaming loop carries no slow path at all.
 template <bool BORDER>
-__global__ __launch_bounds__(256) void k_blur(const GfoGeom* __restrict__ gp, GfoInput in,
-                                              const uint8_t* __restrict__ pyr, uint8_t* __restrict__ blur)
+__device__ __forceinline__ void blur_body(const GfoGeom& g, const GfoInput& in, const uint8_t* __restrict__ pyr,
+                                          uint8_t* __restrict__ blur, int blk, int img)
 {
-    const GfoGeom& g = *gp;
-    const int blk = blockIdx.x, img = blockIdx.y;
     int level = 0;
     while (level + 1 < g.nlevels && blk >= (BORDER ? g.lv[level + 1].blur_base_b : g.lv[level + 1].tile_base)) level++;
     const GfoLevel& L = g.lv[level];
@@ -103,24 +155,25 @@ __global__ __launch_bounds__(256) void k_blur(const GfoGeom* __restrict__ gp, Gf
     int pitch;
     const uint8_t* src = gfo_level_ptr(g, in, pyr, level, img, &pitch);
     uint8_t* dst = blur + (long long)img * g.blur_img_stride + L.blur_off;
-    const bool interior = !BORDER;
+    BorderSel bs;
+    if (BORDER) bs = border_sel(x0, w);
     const int y1 = min(y0 + BLUR_STRIP, h);
 
     HRow r0, r1, r2, r3, r4, r5, r6;
-    r0 = load_hrow(src + (long long)gfo_reflect101(y0 - 3, h) * pitch, x0, w, interior);
-    r1 = load_hrow(src + (long long)gfo_reflect101(y0 - 2, h) * pitch, x0, w, interior);
-    r2 = load_hrow(src + (long long)gfo_reflect101(y0 - 1, h) * pitch, x0, w, interior);
-    r3 = load_hrow(src + (long long)y0 * pitch, x0, w, interior);
-    r4 = load_hrow(src + (long long)gfo_reflect101(y0 + 1, h) * pitch, x0, w, interior);
-    r5 = load_hrow(src + (long long)gfo_reflect101(y0 + 2, h) * pitch, x0, w, interior);
+    r0 = hrow(load_row<BORDER>(src + (long long)gfo_reflect101(y0 - 3, h) * pitch, x0, w, bs));
+    r1 = hrow(load_row<BORDER>(src + (long long)gfo_reflect101(y0 - 2, h) * pitch, x0, w, bs));
+    r2 = hrow(load_row<BORDER>(src + (long long)gfo_reflect101(y0 - 1, h) * pitch, x0, w, bs));
+    r3 = hrow(load_row<BORDER>(src + (long long)y0 * pitch, x0, w, bs));
+    r4 = hrow(load_row<BORDER>(src + (long long)gfo_reflect101(y0 + 1, h) * pitch, x0, w, bs));
+    r5 = hrow(load_row<BORDER>(src + (long long)gfo_reflect101(y0 + 2, h) * pitch, x0, w, bs));
     // the raw dwords of row y+4 are requested one step before they are filtered (two rows of loads in flight
     // per thread).  Measured alternatives that were slower: a 7-row unrolled window (106 VGPRs, 4 waves/SIMD),
     // and one load per lane with the neighbour dwords fetched by lane shuffle (the ds_bpermute traffic costs
     // more than the L1-served overlapping loads).
-    RawRow nxt = load_raw(src + (long long)gfo_reflect101(y0 + 3, h) * pitch, x0, w, interior);
+    RawRow nxt = load_row<BORDER>(src + (long long)gfo_reflect101(y0 + 3, h) * pitch, x0, w, bs);
     for (int y = y0; y < y1; y++) {
         const RawRow cur = nxt;
-        nxt = load_raw(src + (long long)gfo_reflect101(y + 4, h) * pitch, x0, w, interior);
+        nxt = load_row<BORDER>(src + (long long)gfo_reflect101(y + 4, h) * pitch, x0, w, bs);
         r6 = hpass_dot(cur.d0, cur.d1, cur.d2);
         // vertical pass on the four columns (u32 accumulation: 257 * 65535 < 2^32)
         const unsigned o0 = vout((r0.lo & 0xFFFF) + (r6.lo & 0xFFFF), (r1.lo & 0xFFFF) + (r5.lo & 0xFFFF), (r2.lo & 0xFFFF) + (r4.lo & 0xFFFF), r3.lo & 0xFFFF);
@@ -132,12 +185,24 @@ __global__ __launch_bounds__(256) void k_blur(const GfoGeom* __restrict__ gp, Gf
     }
 }
 
+// One launch: the first blur_total_b blocks of every image are its border blocks (long, thin chains of
+// scattered rows -- dispatched first so they run underneath the streaming bulk), the rest the interior.
+__global__ __launch_bounds__(256) void k_blur(const GfoGeom* __restrict__ gp, GfoInput in,
+                                              const uint8_t* __restrict__ pyr, uint8_t* __restrict__ blur)
+{
+    const GfoGeom& g = *gp;
+    const int nb = g.blur_total_b;
+    if ((int)blockIdx.x < nb)
+        blur_body<true>(g, in, pyr, blur, blockIdx.x, blockIdx.y);
+    else
+        blur_body<false>(g, in, pyr, blur, blockIdx.x - nb, blockIdx.y);
+}
+
 void gfo_launch_blur(gfo_ctx* c, const GfoInput& in, int nimg)
 {
     gfo_prof_begin(c, ST_BLUR);
-    if (c->g.total_tiles > 0)
-        hipLaunchKernelGGL(k_blur<false>, dim3(c->g.total_tiles, nimg), dim3(256), 0, c->stream, c->d_geom, in, c->d_pyr, c->d_blur);
-    if (c->g.blur_total_b > 0)
-        hipLaunchKernelGGL(k_blur<true>, dim3(c->g.blur_total_b, nimg), dim3(256), 0, c->stream, c->d_geom, in, c->d_pyr, c->d_blur);
+    if (c->g.total_tiles + c->g.blur_total_b > 0)
+        hipLaunchKernelGGL(k_blur, dim3(c->g.total_tiles + c->g.blur_total_b, nimg), dim3(256), 0, c->stream, c->d_geom, in,
+                           c->d_pyr, c->d_blur);
     gfo_prof_end(c);
 }
