@@ -20,26 +20,32 @@ struct HQuad {
     int h[4];
 };
 
-// One source row segment -> the four horizontal sums.  `fast`: the 16 bytes at base_x cover every tap.
+typedef unsigned short gfo_u16x2 __attribute__((ext_vector_type(2)));
+
+// One source row segment -> the four horizontal sums.
+// `fast`: the 12 bytes at base_x cover every tap.  The window is first shifted so that it starts at sx[0]
+// (two v_alignbyte), after which the byte pair of output k sits at the fixed offsets (rel[k], rel[k]+1) < 8:
+// one v_perm_b32 spreads the pair into two u16 and one v_dot2_u32_u16 multiplies it by the packed
+// coefficients {alpha0, alpha1} of the table -- 2.5 VALU operations per output and row.
 __device__ __forceinline__ HQuad resize_hrow(const uint8_t* __restrict__ row, int base_x, bool fast, const int* sx,
-                                             const int* a0, const int* a1, int sw)
+                                             const unsigned* sel, const int* cw, int sw)
 {
     HQuad q;
     if (fast) {
-        const uint4 w = *reinterpret_cast<const uint4*>(row + base_x);  // one 16-byte load (dword aligned)
+        const uint32_t* p = reinterpret_cast<const uint32_t*>(row + base_x);
+        const unsigned w0 = p[0], w1 = p[1], w2 = p[2];
+        const unsigned o0 = (unsigned)(sx[0] - base_x);  // 0..3
+        const unsigned A = __builtin_amdgcn_alignbyte(w1, w0, o0), B = __builtin_amdgcn_alignbyte(w2, w1, o0);
 #pragma unroll
         for (int k = 0; k < 4; k++) {
-            const int off = sx[k] - base_x;  // 0..14
-            const unsigned lo = off < 4 ? w.x : (off < 8 ? w.y : (off < 12 ? w.z : w.w));
-            const unsigned hi = off < 4 ? w.y : (off < 8 ? w.z : (off < 12 ? w.w : 0u));
-            const unsigned two = __builtin_amdgcn_alignbyte(hi, lo, off & 3);
-            q.h[k] = (int)(two & 255u) * a0[k] + (int)((two >> 8) & 255u) * a1[k];
+            const unsigned two = __builtin_amdgcn_perm(B, A, sel[k]);  // {byte rel, 0, byte rel+1, 0}
+            q.h[k] = (int)__builtin_amdgcn_udot2(__builtin_bit_cast(gfo_u16x2, two), __builtin_bit_cast(gfo_u16x2, (unsigned)cw[k]), 0u, false);
         }
     } else {
 #pragma unroll
         for (int k = 0; k < 4; k++) {
             const int s1 = min(sx[k] + 1, sw - 1);
-            q.h[k] = (int)row[sx[k]] * a0[k] + (int)row[s1] * a1[k];
+            q.h[k] = (int)row[sx[k]] * (cw[k] & 0xFFFF) + (int)row[s1] * (int)((unsigned)cw[k] >> 16);
         }
     }
     return q;
@@ -64,17 +70,17 @@ __device__ __forceinline__ void resize_block(const GfoGeom& g, const GfoInput& i
     const int dx0 = quad * 4;
     const int4* xt = reinterpret_cast<const int4*>(xtab_all + L.xtab_off + dx0);
     const int4 xa = xt[0], xb = xt[1];
-    int sx[4] = {xa.x, xa.z, xb.x, xb.z};
+    const int sx[4] = {xa.x, xa.z, xb.x, xb.z};
     const int cw[4] = {xa.y, xa.w, xb.y, xb.w};
-    int a0[4], a1[4];
+    unsigned sel[4];
 #pragma unroll
     for (int k = 0; k < 4; k++) {
-        a0[k] = cw[k] & 0xFFFF;
-        a1[k] = cw[k] >> 16;
+        const unsigned rel = (unsigned)(sx[k] - sx[0]) & 7u;
+        sel[k] = rel | (0x0Cu << 8) | ((rel + 1u) << 16) | (0x0Cu << 24);  // selector 0x0C = constant zero byte
     }
     const int base_x = sx[0] & ~3;
-    // sixteen bytes must cover sx[3]+1 and stay inside the source row
-    const bool fast = (sx[3] + 1 - base_x) < 16 && base_x + 16 <= sw;
+    // eight bytes from sx[0] must cover sx[3]+1 (scale factors up to 2), twelve from base_x stay inside the row
+    const bool fast = (sx[3] + 1 - sx[0]) < 8 && base_x + 12 <= sw;
     const int dy0 = strip * RS_STRIP, dy1 = min(dy0 + RS_STRIP, L.h);
     const int4* yt = reinterpret_cast<const int4*>(ytab_all + L.ytab_off + dy0);
     const int4 ya = yt[0], yb = yt[1];
@@ -88,7 +94,7 @@ __device__ __forceinline__ void resize_block(const GfoGeom& g, const GfoInput& i
 #pragma unroll
         for (int k = 0; k < RS_MAXR; k++) {
             const int r = min(r_first + k, sh - 1);
-            rows[k] = resize_hrow(src + (long long)r * spitch, base_x, fast, sx, a0, a1, sw);
+            rows[k] = resize_hrow(src + (long long)r * spitch, base_x, fast, sx, sel, cw, sw);
         }
 #pragma unroll
         for (int j = 0; j < RS_STRIP; j++) {
@@ -124,8 +130,8 @@ __device__ __forceinline__ void resize_block(const GfoGeom& g, const GfoInput& i
             unsigned packed = 0;
 #pragma unroll
             for (int k = 0; k < 4; k++) {
-                const int v = (((b0 * (ra.h[k] >> 4)) >> 16) + ((b1 * (rb.h[k] >> 4)) >> 16) + 2) >> 2;
-                packed |= (unsigned)(v & 255) << (8 * k);
+                const unsigned v = ((__umul24(b0, ra.h[k] >> 4) >> 16) + (__umul24(b1, rb.h[k] >> 4) >> 16) + 2u) >> 2;  // operands < 2^16
+                packed |= (v & 255u) << (8 * k);
             }
             *reinterpret_cast<unsigned*>(dst + (long long)dy * L.pitch + dx0) = packed;  // pitch multiple of 64: tail dword stays in-row
         }
@@ -137,13 +143,13 @@ __device__ __forceinline__ void resize_block(const GfoGeom& g, const GfoInput& i
         if (dy >= dy1) break;
         const int b0 = bw[j] & 0xFFFF, b1 = bw[j] >> 16;
         const int sy0 = min(max(syv[j], 0), sh - 1), sy1 = min(max(syv[j] + 1, 0), sh - 1);
-        const HQuad r0 = resize_hrow(src + (long long)sy0 * spitch, base_x, fast, sx, a0, a1, sw);
-        const HQuad r1 = resize_hrow(src + (long long)sy1 * spitch, base_x, fast, sx, a0, a1, sw);
+        const HQuad r0 = resize_hrow(src + (long long)sy0 * spitch, base_x, fast, sx, sel, cw, sw);
+        const HQuad r1 = resize_hrow(src + (long long)sy1 * spitch, base_x, fast, sx, sel, cw, sw);
         unsigned packed = 0;
 #pragma unroll
         for (int k = 0; k < 4; k++) {
-            const int v = (((b0 * (r0.h[k] >> 4)) >> 16) + ((b1 * (r1.h[k] >> 4)) >> 16) + 2) >> 2;
-            packed |= (unsigned)(v & 255) << (8 * k);
+            const unsigned v = ((__umul24(b0, r0.h[k] >> 4) >> 16) + (__umul24(b1, r1.h[k] >> 4) >> 16) + 2u) >> 2;
+            packed |= (v & 255u) << (8 * k);
         }
         *reinterpret_cast<unsigned*>(dst + (long long)dy * L.pitch + dx0) = packed;
     }
