@@ -122,14 +122,14 @@ static void build_tables(gfo_ctx* c)
 static void free_arena(gfo_ctx* c)
 {
     void* ptrs[] = {c->d_geom, c->d_input, c->d_pyr, c->d_blur, c->d_cand, c->d_cand_cnt, c->d_node_of, c->d_sel,
-                    c->d_sel_cnt, c->d_kp, c->d_desc, c->d_kp_cnt, c->d_flags, c->d_xofs, c->d_xcoef, c->d_yofs,
+                    c->d_sel_cnt, c->d_kp, c->d_desc, c->d_kp_cnt, c->d_flags, c->d_xofs, c->d_xcoef, c->d_yofs, c->d_band,
                     c->d_ycoef, c->st.u_right, c->st.depth, c->st.best_dist, c->st.best_idx, c->st.nmatched, c->st.counted,
                     c->d_scale, c->d_inv_scale, c->st_sort.sx, c->st_sort.sy, c->st_sort.soi, c->st_sort.sdesc, c->st_sort.row_start};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     c->d_geom = nullptr; c->d_input = c->d_pyr = c->d_blur = nullptr; c->d_cand = nullptr; c->d_cand_cnt = nullptr;
     c->d_node_of = nullptr; c->d_sel = nullptr; c->d_sel_cnt = nullptr; c->d_kp = nullptr; c->d_desc = nullptr;
-    c->d_kp_cnt = nullptr; c->d_flags = nullptr; c->d_xofs = nullptr; c->d_xcoef = nullptr; c->d_yofs = nullptr;
+    c->d_kp_cnt = nullptr; c->d_flags = nullptr; c->d_xofs = nullptr; c->d_xcoef = nullptr; c->d_yofs = nullptr; c->d_band = nullptr;
     c->d_ycoef = nullptr; c->st = GfoStereoDev{}; c->d_scale = nullptr; c->d_inv_scale = nullptr; c->st_sort = GfoStereoSort{}; c->st_rows_cap = 0;
     c->planned = false;
     c->have_batch = c->have_pyramid = c->have_stereo = false;
@@ -276,6 +276,83 @@ static int plan(gfo_ctx* c, int w, int h, int batch)
             ytabv[2 * (g.lv[l].ytab_off + d) + 1] = (int)((unsigned short)coef[2 * s_] | ((unsigned)(unsigned short)coef[2 * s_ + 1] << 16));
         }
     }
+    // banded pyramid: the levels are split into (at most) two groups -- the large ones and the small ones past
+    // the GFO_RESIZE_TAIL_PX mark -- each one launch; per group, the fewest bands whose per-workgroup LDS
+    // footprint fits the budget.  Ranges are derived top-down inside a group: the rows a level must hold are its
+    // own share plus the source rows the level above reads for ITS computed rows.
+    std::vector<int> bandv;
+    g.pyr_nb = 0;
+    c->n_band_groups = 0;
+    if (g.nlevels >= 2) {
+        const int budget = (getenv("GFO_PYR_LDS_KB") ? atoi(getenv("GFO_PYR_LDS_KB")) : 32) * 1024;
+        const int tail_px = getenv("GFO_RESIZE_TAIL_PX") ? atoi(getenv("GFO_RESIZE_TAIL_PX")) : 60000;
+        const int nl = g.nlevels;
+        auto sy_of = [&](int l, int dy) {
+            const int v = ytabv[2 * (size_t)(g.lv[l].ytab_off + dy)], sh = g.lv[l - 1].h;
+            return v < 0 ? 0 : (v > sh - 1 ? sh - 1 : v);
+        };
+        int split = 1;
+        while (split < nl && g.lv[split].w * g.lv[split].h > tail_px) split++;
+        if (split == 1 || nl - split < 2) split = nl;   // nothing large, or a tail of one level: a single group
+        const int bounds[3] = {1, split, nl};
+        bool ok = true;
+        for (int gi = 0; gi < 2 && ok; gi++) {
+            const int lb = bounds[gi], le = bounds[gi + 1];
+            if (le <= lb) continue;
+            GfoBandGroup bg = {lb, le, 0, 0, (int)(bandv.size() / 4)};
+            for (int nb = 1; nb <= 64 && bg.nb == 0; nb++) {
+                if (g.lv[le - 1].h < 2 * nb && nb > 1) break;
+                std::vector<int> tab(4 * (size_t)nb * nl, 0);
+                int maxrows[GFO_MAX_LEVELS] = {0};
+                for (int b = 0; b < nb; b++) {
+                    int c0_up = 0, c1_up = 0;
+                    for (int l = le - 1; l >= lb; l--) {
+                        const int hl = g.lv[l].h;
+                        const int o0 = (int)((long long)b * hl / nb), o1 = (int)((long long)(b + 1) * hl / nb);
+                        int c0 = o0, c1 = o1;
+                        if (l < le - 1 && c1_up > c0_up) {
+                            const int lo = sy_of(l + 1, c0_up);
+                            int hi = sy_of(l + 1, c1_up - 1) + 1;
+                            if (hi > hl - 1) hi = hl - 1;
+                            c0 = lo < c0 ? lo : c0;
+                            c1 = hi + 1 > c1 ? hi + 1 : c1;
+                        }
+                        int* t = &tab[4 * ((size_t)b * nl + l)];
+                        t[0] = c0; t[1] = c1; t[2] = o0; t[3] = o1;
+                        if (c1 - c0 > maxrows[l]) maxrows[l] = c1 - c0;
+                        c0_up = c0;
+                        c1_up = c1;
+                    }
+                }
+                int lds = 0;
+                for (int l = lb; l < le - 1; l++) lds += (int)align_up((long long)align_up(g.lv[l].w, 16) * maxrows[l], 16);
+                if (getenv("GFO_DEBUG_PLAN")) fprintf(stderr, "[gfo] pyramid bands, levels %d..%d: nb %d -> %d B of LDS (budget %d)\n", lb, le - 1, nb, lds, budget);
+                if (lds <= budget) {
+                    bg.nb = nb;
+                    bg.lds_bytes = lds;
+                    int off = 0;
+                    for (int l = lb; l < le - 1; l++) {
+                        g.band_lp[l] = (int)align_up(g.lv[l].w, 16);
+                        g.band_lds_off[l] = off;
+                        off += (int)align_up((long long)g.band_lp[l] * maxrows[l], 16);
+                    }
+                    bandv.insert(bandv.end(), tab.begin(), tab.end());
+                }
+            }
+            if (bg.nb == 0 || gfo_pyramid_bands_prepare(bg.lds_bytes) != 0) {
+                (void)hipGetLastError();
+                ok = false;
+                break;
+            }
+            c->band_groups[c->n_band_groups++] = bg;
+            g.pyr_nb = g.pyr_nb == 0 || bg.nb < g.pyr_nb ? bg.nb : g.pyr_nb;
+        }
+        if (!ok) {
+            c->n_band_groups = 0;
+            g.pyr_nb = 0;
+        }
+        c->band_threads = getenv("GFO_PYR_THREADS") ? atoi(getenv("GFO_PYR_THREADS")) : 512;
+    }
     const size_t B = (size_t)batch;
     HIP_TRY(c, hipMalloc(&c->d_geom, sizeof(GfoGeom)));
     HIP_TRY(c, hipMalloc(&c->d_input, B * g.lv[0].pitch * (size_t)h));
@@ -292,6 +369,8 @@ static int plan(gfo_ctx* c, int w, int h, int batch)
     HIP_TRY(c, hipMalloc(&c->d_flags, 4 * sizeof(int)));
     HIP_TRY(c, hipMalloc(&c->d_xofs, xtabv.size() * sizeof(int) + 64));
     HIP_TRY(c, hipMalloc(&c->d_yofs, ytabv.size() * sizeof(int) + 64));
+    HIP_TRY(c, hipMalloc(&c->d_band, (bandv.size() + 4) * sizeof(int)));
+    if (!bandv.empty()) HIP_TRY(c, hipMemcpy(c->d_band, bandv.data(), bandv.size() * sizeof(int), hipMemcpyHostToDevice));
     HIP_TRY(c, hipMalloc(&c->d_scale, GFO_MAX_LEVELS * sizeof(float)));
     HIP_TRY(c, hipMalloc(&c->d_inv_scale, GFO_MAX_LEVELS * sizeof(float)));
     const size_t P = (B + 1) / 2;
@@ -417,6 +496,16 @@ static int run_pyramid(gfo_ctx* c, const GfoInput& in, int nimg)
     // big levels: one launch each (they fill the chip); the small top levels: one fused launch, one workgroup
     // per image (each of them alone is latency-bound)
     static const int tail_px = getenv("GFO_RESIZE_TAIL_PX") ? atoi(getenv("GFO_RESIZE_TAIL_PX")) : 60000;  // measured: fusing levels of <= 60k px wins, larger ones lose
+    // a batch that fills the chip with band workgroups: the whole pyramid in one launch, every level through LDS
+    const char* bm = getenv("GFO_PYR_BAND_MIN_WG");   // tests force either path
+    const int band_min_wg = bm ? atoi(bm) : 256;
+    if (c->g.pyr_nb > 0 && nimg * c->g.pyr_nb >= band_min_wg) {
+        gfo_launch_pyramid_bands(c, in, nimg);
+        c->last_in = in;
+        c->last_nimg = nimg;
+        c->have_pyramid = true;
+        return GFO_OK;
+    }
     int l = 1;
     for (; l < c->g.nlevels; l++) {
         if (c->g.lv[l].w * c->g.lv[l].h <= tail_px && nimg >= 32) break;

@@ -45,6 +45,11 @@ struct GfoLevel {
     int xtab_off, ytab_off;
 };
 
+// One launch of the banded pyramid: levels [lb, le) in nb bands per image
+struct GfoBandGroup {
+    int lb, le, nb, lds_bytes, tab_off;   // tab_off in int4 elements into d_band
+};
+
 struct GfoGeom {
     int nlevels;
     int w0, h0;
@@ -59,6 +64,10 @@ struct GfoGeom {
     long long pyr_img_stride;   // bytes per image of levels 1..L-1
     long long blur_img_stride;  // bytes per image of blurred levels 0..L-1
     long long cand_img_stride;  // u32 elements per image
+    // banded pyramid (k_pyramid_bands): smallest band count of the groups (0 = not planned), LDS offset and
+    // pitch of each level's band
+    int pyr_nb;
+    int band_lds_off[GFO_MAX_LEVELS], band_lp[GFO_MAX_LEVELS];
     GfoLevel lv[GFO_MAX_LEVELS];
 };
 
@@ -139,6 +148,9 @@ struct gfo_ctx {
     int* d_xofs = nullptr;           // resize tables, all levels
     short* d_xcoef = nullptr;
     int* d_yofs = nullptr;
+    int* d_band = nullptr;        // per group: int4 [nb][nlevels] = {c0, c1, o0, o1}
+    GfoBandGroup band_groups[2];
+    int n_band_groups = 0, band_threads = 512;
     short* d_ycoef = nullptr;
     float* d_scale = nullptr;        // mvScaleFactor on the device
     float* d_inv_scale = nullptr;    // mvInvScaleFactor on the device
@@ -171,6 +183,8 @@ struct gfo_ctx {
 // ---- kernel launchers (each in its own .hip file) ------------------------------------------
 void gfo_launch_resize(gfo_ctx* c, const GfoInput& in, int level, int nimg);
 void gfo_launch_resize_tail(gfo_ctx* c, const GfoInput& in, int level_begin, int nimg);
+void gfo_launch_pyramid_bands(gfo_ctx* c, const GfoInput& in, int nimg);
+int gfo_pyramid_bands_prepare(int lds_bytes);
 void gfo_launch_blur(gfo_ctx* c, const GfoInput& in, int nimg);
 void gfo_launch_fast(gfo_ctx* c, const GfoInput& in, int nimg);
 void gfo_launch_quadtree(gfo_ctx* c, int nimg);

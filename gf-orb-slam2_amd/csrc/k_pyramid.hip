@@ -53,22 +53,22 @@ __device__ __forceinline__ HQuad resize_hrow(const uint8_t* __restrict__ row, in
 
 // Tables: one int2 per output column / row = {source offset, coef0 | coef1 << 16}; every level's table is
 // padded with 3 copies of its last entry so a thread may read its 4 entries as two 16-byte loads.
-// One 4x4 output block (column quad `quad`, row strip `strip`) of level `level` of image `img`.
+//
+// One 4x4 output block (column quad `quad`, rows dy0 .. dy0+3) of a level.
+//   source : rows [srow0, srow_hi] of the level below live at src + (r - srow0) * spitch (a whole plane in HBM,
+//            or the band of it a workgroup keeps in LDS); sw x sh is the full size of that level
+//   output : rows < row_end; a row in [own0, own1) goes to the plane in HBM (dstg), every row to the LDS band
+//            (dstl, row lrow0 first) when BAND
 // UNI: the strip (hence every row index) is the same for all lanes of the wave, so the source-row pair of an
 // output row is picked by a scalar branch instead of per-lane select chains.
-template <bool UNI>
-__device__ __forceinline__ void resize_block(const GfoGeom& g, const GfoInput& in, uint8_t* __restrict__ pyr, int level, int img,
-                                             int quad, int strip, const int2* __restrict__ xtab_all,
-                                             const int2* __restrict__ ytab_all)
+template <bool UNI, bool BAND>
+__device__ __forceinline__ void resize_block(const uint8_t* __restrict__ src, int spitch, int srow0, int srow_hi, int sh, int sw,
+                                             uint8_t* __restrict__ dstg, int gpitch, int own0, int own1,
+                                             uint8_t* __restrict__ dstl, int lpitch, int lrow0, int row_end, int quad,
+                                             int dy0, const int2* __restrict__ xtab, const int2* __restrict__ ytab)
 {
-    const GfoLevel& L = g.lv[level];
-    int spitch;
-    const uint8_t* src = gfo_level_ptr(g, in, pyr, level - 1, img, &spitch);
-    const int sh = g.lv[level - 1].h, sw = g.lv[level - 1].w;
-    uint8_t* dst = pyr + (long long)img * g.pyr_img_stride + L.plane_off;
-
     const int dx0 = quad * 4;
-    const int4* xt = reinterpret_cast<const int4*>(xtab_all + L.xtab_off + dx0);
+    const int4* xt = reinterpret_cast<const int4*>(xtab + dx0);
     const int4 xa = xt[0], xb = xt[1];
     const int sx[4] = {xa.x, xa.z, xb.x, xb.z};
     const int cw[4] = {xa.y, xa.w, xb.y, xb.w};
@@ -81,26 +81,27 @@ __device__ __forceinline__ void resize_block(const GfoGeom& g, const GfoInput& i
     const int base_x = sx[0] & ~3;
     // eight bytes from sx[0] must cover sx[3]+1 (scale factors up to 2), twelve from base_x stay inside the row
     const bool fast = (sx[3] + 1 - sx[0]) < 8 && base_x + 12 <= sw;
-    const int dy0 = strip * RS_STRIP, dy1 = min(dy0 + RS_STRIP, L.h);
-    const int4* yt = reinterpret_cast<const int4*>(ytab_all + L.ytab_off + dy0);
+    const int dy1 = min(dy0 + RS_STRIP, row_end);   // rows [dy0, dy1) of the level
+    const int4* yt = reinterpret_cast<const int4*>(ytab + dy0);
     const int4 ya = yt[0], yb = yt[1];
     const int syv[4] = {ya.x, ya.z, yb.x, yb.z};
     const int bw[4] = {ya.y, ya.w, yb.y, yb.w};
     const int r_first = min(max(syv[0], 0), sh - 1);
     const int r_last = min(max(syv[dy1 - dy0 - 1] + 1, 0), sh - 1);
+    src -= (long long)srow0 * spitch;
     if (r_last - r_first < RS_MAXR) {
         // all source rows of the block in flight together
         HQuad rows[RS_MAXR];
 #pragma unroll
         for (int k = 0; k < RS_MAXR; k++) {
-            const int r = min(r_first + k, sh - 1);
+            const int r = min(r_first + k, srow_hi);
             rows[k] = resize_hrow(src + (long long)r * spitch, base_x, fast, sx, sel, cw, sw);
         }
 #pragma unroll
         for (int j = 0; j < RS_STRIP; j++) {
             const int dy = dy0 + j;
             if (dy >= dy1) break;
-            const int b0 = bw[j] & 0xFFFF, b1 = bw[j] >> 16;
+            const unsigned b0 = bw[j] & 0xFFFF, b1 = (unsigned)bw[j] >> 16;
             const int i0 = min(max(syv[j], 0), sh - 1) - r_first, i1 = min(max(syv[j] + 1, 0), sh - 1) - r_first;
             HQuad ra = rows[0], rb = rows[0];
             bool picked = false;
@@ -133,7 +134,9 @@ __device__ __forceinline__ void resize_block(const GfoGeom& g, const GfoInput& i
                 const unsigned v = ((__umul24(b0, ra.h[k] >> 4) >> 16) + (__umul24(b1, rb.h[k] >> 4) >> 16) + 2u) >> 2;  // operands < 2^16
                 packed |= (v & 255u) << (8 * k);
             }
-            *reinterpret_cast<unsigned*>(dst + (long long)dy * L.pitch + dx0) = packed;  // pitch multiple of 64: tail dword stays in-row
+            // pitches are multiples of 16: the tail dword stays in-row
+            if (!BAND || (dy >= own0 && dy < own1)) *reinterpret_cast<unsigned*>(dstg + (long long)dy * gpitch + dx0) = packed;
+            if (BAND && dstl) *reinterpret_cast<unsigned*>(dstl + (dy - lrow0) * lpitch + dx0) = packed;
         }
         return;
     }
@@ -141,7 +144,7 @@ __device__ __forceinline__ void resize_block(const GfoGeom& g, const GfoInput& i
     for (int j = 0; j < RS_STRIP; j++) {  // steep scale factors: row by row
         const int dy = dy0 + j;
         if (dy >= dy1) break;
-        const int b0 = bw[j] & 0xFFFF, b1 = bw[j] >> 16;
+        const unsigned b0 = bw[j] & 0xFFFF, b1 = (unsigned)bw[j] >> 16;
         const int sy0 = min(max(syv[j], 0), sh - 1), sy1 = min(max(syv[j] + 1, 0), sh - 1);
         const HQuad r0 = resize_hrow(src + (long long)sy0 * spitch, base_x, fast, sx, sel, cw, sw);
         const HQuad r1 = resize_hrow(src + (long long)sy1 * spitch, base_x, fast, sx, sel, cw, sw);
@@ -151,8 +154,24 @@ __device__ __forceinline__ void resize_block(const GfoGeom& g, const GfoInput& i
             const unsigned v = ((__umul24(b0, r0.h[k] >> 4) >> 16) + (__umul24(b1, r1.h[k] >> 4) >> 16) + 2u) >> 2;
             packed |= (v & 255u) << (8 * k);
         }
-        *reinterpret_cast<unsigned*>(dst + (long long)dy * L.pitch + dx0) = packed;
+        if (!BAND || (dy >= own0 && dy < own1)) *reinterpret_cast<unsigned*>(dstg + (long long)dy * gpitch + dx0) = packed;
+        if (BAND && dstl) *reinterpret_cast<unsigned*>(dstl + (dy - lrow0) * lpitch + dx0) = packed;
     }
+}
+
+// Whole-plane form: level `level` of image `img` from the plane below it in HBM.
+template <bool UNI>
+__device__ __forceinline__ void resize_plane_block(const GfoGeom& g, const GfoInput& in, uint8_t* __restrict__ pyr, int level,
+                                                   int img, int quad, int strip, const int2* __restrict__ xtab_all,
+                                                   const int2* __restrict__ ytab_all)
+{
+    const GfoLevel& L = g.lv[level];
+    int spitch;
+    const uint8_t* src = gfo_level_ptr(g, in, pyr, level - 1, img, &spitch);
+    const int sh = g.lv[level - 1].h, sw = g.lv[level - 1].w;
+    uint8_t* dst = pyr + (long long)img * g.pyr_img_stride + L.plane_off;
+    resize_block<UNI, false>(src, spitch, 0, sh - 1, sh, sw, dst, L.pitch, 0, L.h, nullptr, 0, 0, L.h, quad, strip * RS_STRIP,
+                             xtab_all + L.xtab_off, ytab_all + L.ytab_off);
 }
 
 __global__ __launch_bounds__(256) void k_resize(const GfoGeom* __restrict__ gp, GfoInput in, uint8_t* __restrict__ pyr,
@@ -169,7 +188,7 @@ __global__ __launch_bounds__(256) void k_resize(const GfoGeom* __restrict__ gp, 
     const int strip = wv / wps;
     const int quad = (wv - strip * wps) * 64 + (threadIdx.x & 63);
     if (strip >= strips || quad >= quads) return;
-    resize_block<true>(g, in, pyr, level, blockIdx.y, quad, strip, xtab_all, ytab_all);
+    resize_plane_block<true>(g, in, pyr, level, blockIdx.y, quad, strip, xtab_all, ytab_all);
 }
 
 // The small top levels of the pyramid are launch-latency bound as separate kernels (each is a dependent
@@ -189,9 +208,58 @@ __global__ __launch_bounds__(1024) void k_resize_tail(const GfoGeom* __restrict_
         const int ntask = quads * strips;
         for (int t = threadIdx.x; t < ntask; t += 1024) {
             const int strip = t / quads;
-            resize_block<false>(g, in, pyr, level, img, t - strip * quads, strip, xtab_all, ytab_all);
+            resize_plane_block<false>(g, in, pyr, level, img, t - strip * quads, strip, xtab_all, ytab_all);
         }
         __threadfence_block();
+        __syncthreads();
+    }
+}
+
+// Banded form (large batches): a workgroup owns a horizontal band of the image through a GROUP of consecutive
+// levels [lb, le).  It computes the band of level lb from the plane below it in HBM, keeps it in LDS, computes
+// the band of level lb+1 from that, and so on: inside a group a level is read from HBM zero times and written
+// once, and the group is one launch.  (A band must also compute the rows the level above needs beyond its own
+// share; that halo grows by 1 + 1.2x per level, which is why the pyramid is split into two groups rather than
+// run as one chain of seven.)
+// band_tab[band][level] = {c0, c1, o0, o1}: rows [c0,c1) are computed, rows [o0,o1) are written to HBM.
+__global__ __launch_bounds__(1024) void k_pyramid_bands(const GfoGeom* __restrict__ gp, GfoInput in, uint8_t* __restrict__ pyr,
+                                                        const int2* __restrict__ xtab_all, const int2* __restrict__ ytab_all,
+                                                        const int4* __restrict__ band_tab, int lb, int le)
+{
+    extern __shared__ __align__(16) uint8_t band_lds[];
+    const GfoGeom& g = *gp;
+    const int band = blockIdx.x, img = blockIdx.y, nl = g.nlevels;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int nwaves = blockDim.x >> 6;
+    int4 below = make_int4(0, 0, 0, 0);
+    for (int level = lb; level < le; level++) {
+        const GfoLevel& L = g.lv[level];
+        const int4 rg = band_tab[band * nl + level];
+        const int quads = (L.w + 3) >> 2, wps = (quads + 63) >> 6;
+        const int nstrips = (rg.y - rg.x + RS_STRIP - 1) / RS_STRIP;
+        uint8_t* dstg = pyr + (long long)img * g.pyr_img_stride + L.plane_off;
+        uint8_t* dstl = level < le - 1 ? band_lds + g.band_lds_off[level] : nullptr;
+        const int lp = g.band_lp[level];
+        const int2* xt = xtab_all + L.xtab_off;
+        const int2* yt = ytab_all + L.ytab_off;
+        const int sh = g.lv[level - 1].h, sw = g.lv[level - 1].w;
+        for (int wt = wave; wt < wps * nstrips; wt += nwaves) {
+            const int s = wt / wps;
+            const int quad = (wt - s * wps) * 64 + lane;
+            if (quad >= quads) continue;
+            const int dy0 = rg.x + s * RS_STRIP;
+            if (level == lb) {
+                int spitch;
+                const uint8_t* src = gfo_level_ptr(g, in, pyr, lb - 1, img, &spitch);
+                resize_block<true, true>(src, spitch, 0, sh - 1, sh, sw, dstg, L.pitch, rg.z, rg.w, dstl, lp, rg.x, rg.y, quad,
+                                         dy0, xt, yt);
+            } else {
+                const uint8_t* src = band_lds + g.band_lds_off[level - 1];
+                resize_block<true, true>(src, g.band_lp[level - 1], below.x, below.y - 1, sh, sw, dstg, L.pitch, rg.z, rg.w, dstl,
+                                         lp, rg.x, rg.y, quad, dy0, xt, yt);
+            }
+        }
+        below = rg;
         __syncthreads();
     }
 }
@@ -214,4 +282,22 @@ void gfo_launch_resize_tail(gfo_ctx* c, const GfoInput& in, int level_begin, int
     hipLaunchKernelGGL(k_resize_tail, dim3(nimg), dim3(1024), 0, c->stream, c->d_geom, in, c->d_pyr, level_begin,
                        reinterpret_cast<const int2*>(c->d_xofs), reinterpret_cast<const int2*>(c->d_yofs));
     gfo_prof_end(c);
+}
+
+void gfo_launch_pyramid_bands(gfo_ctx* c, const GfoInput& in, int nimg)
+{
+    gfo_prof_begin(c, ST_RESIZE);
+    for (int k = 0; k < c->n_band_groups; k++) {
+        const GfoBandGroup& bg = c->band_groups[k];
+        hipLaunchKernelGGL(k_pyramid_bands, dim3(bg.nb, nimg), dim3(c->band_threads), bg.lds_bytes, c->stream, c->d_geom, in,
+                           c->d_pyr, reinterpret_cast<const int2*>(c->d_xofs), reinterpret_cast<const int2*>(c->d_yofs),
+                           reinterpret_cast<const int4*>(c->d_band) + bg.tab_off, bg.lb, bg.le);
+    }
+    gfo_prof_end(c);
+}
+
+int gfo_pyramid_bands_prepare(int lds_bytes)
+{
+    if (lds_bytes <= 64 * 1024) return 0;
+    return (int)hipFuncSetAttribute(reinterpret_cast<const void*>(k_pyramid_bands), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
 }

@@ -140,3 +140,25 @@ def test_projection_against_50k_map(oracle):
     np.testing.assert_array_equal(got[1], ref[1])
     np.testing.assert_array_equal(got[2], ref[2])
     ext.close()
+
+
+@pytest.mark.parametrize("w,h,sf,nl,lds_kb,threads", [(752, 480, 1.2, 8, 64, 1024), (752, 480, 1.2, 8, 16, 256), (752, 480, 1.2, 8, 150, 512),
+                                                       (1241, 376, 1.2, 8, 64, 1024), (333, 217, 1.2, 8, 8, 1024), (1920, 1080, 1.2, 8, 64, 1024),
+                                                       (640, 480, 1.1, 12, 32, 1024), (640, 480, 2.0, 3, 64, 1024), (640, 480, 1.5, 4, 24, 512),
+                                                       (130, 100, 1.2, 8, 64, 1024), (37, 300, 1.2, 6, 4, 1024)])
+def test_banded_pyramid_equals_oracle(oracle, monkeypatch, w, h, sf, nl, lds_kb, threads):
+    """The one-launch banded pyramid (every level through LDS, the path large batches take) forced on a single
+    image: every level bit-exact against the oracle's cv::resize chain, then the whole extraction."""
+    import gf_orb_slam2_amd as G
+    monkeypatch.setenv("GFO_PYR_BAND_MIN_WG", "1")
+    monkeypatch.setenv("GFO_PYR_LDS_KB", str(lds_kb))
+    monkeypatch.setenv("GFO_PYR_THREADS", str(threads))
+    img = synth_frame(w, h, 3 * w + h)
+    ext = G.ORBextractor(800, sf, nl, 20, 7)
+    oe = oracle.OracleExtractor(800, sf, nl, 20, 7)
+    ext.ComputePyramid(img)
+    oe.compute_pyramid(img)
+    for l in range(nl):
+        np.testing.assert_array_equal(ext.pyramid_level(l), oe.level(l), err_msg=f"level {l}")
+    _same(ext, oe, img)
+    ext.close()
