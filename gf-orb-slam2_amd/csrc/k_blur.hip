@@ -126,10 +126,24 @@ __device__ __forceinline__ RawRow load_row(const uint8_t* __restrict__ row, int 
 
 __device__ __forceinline__ HRow hrow(const RawRow& r) { return hpass_dot(r.d0, r.d1, r.d2); }
 
-__device__ __forceinline__ unsigned vout(unsigned a06, unsigned a15, unsigned a24, unsigned a3)
+typedef unsigned short gfo_bu16x2 __attribute__((ext_vector_type(2)));
+
+// Vertical pass of one column: the seven rows' u16 sums sit in the low (HI = false) or high half of their
+// registers; v_dot2_u32_u16 against {tap, 0} (or {0, tap}) multiplies the wanted half and adds it to the
+// running sum without unpacking anything.  u32 accumulation (257 * 65535 + 2^15 < 2^32), one rounding.
+template <bool HI>
+__device__ __forceinline__ unsigned vcol(unsigned a0, unsigned a1, unsigned a2, unsigned a3, unsigned a4, unsigned a5, unsigned a6)
 {
-    const unsigned acc = 18u * a06 + 34u * a15 + 49u * a24 + 55u * a3;
-    return min((acc + 32768u) >> 16, 255u);
+#define GFO_TAP(v, k, acc) __builtin_amdgcn_udot2(__builtin_bit_cast(gfo_bu16x2, v), __builtin_bit_cast(gfo_bu16x2, (unsigned)(HI ? ((k) << 16) : (k))), acc, false)
+    unsigned acc = GFO_TAP(a0, 18u, 32768u);
+    acc = GFO_TAP(a6, 18u, acc);
+    acc = GFO_TAP(a1, 34u, acc);
+    acc = GFO_TAP(a5, 34u, acc);
+    acc = GFO_TAP(a2, 49u, acc);
+    acc = GFO_TAP(a4, 49u, acc);
+    acc = GFO_TAP(a3, 55u, acc);
+#undef GFO_TAP
+    return min(acc >> 16, 255u);
 }
 
 // BORDER = false: the quads whose three dwords lie inside the row (no reflection, no byte loads) -- the bulk.
@@ -175,11 +189,10 @@ __device__ __forceinline__ void blur_body(const GfoGeom& g, const GfoInput& in, 
         const RawRow cur = nxt;
         nxt = load_row<BORDER>(src + (long long)gfo_reflect101(y + 4, h) * pitch, x0, w, bs);
         r6 = hpass_dot(cur.d0, cur.d1, cur.d2);
-        // vertical pass on the four columns (u32 accumulation: 257 * 65535 < 2^32)
-        const unsigned o0 = vout((r0.lo & 0xFFFF) + (r6.lo & 0xFFFF), (r1.lo & 0xFFFF) + (r5.lo & 0xFFFF), (r2.lo & 0xFFFF) + (r4.lo & 0xFFFF), r3.lo & 0xFFFF);
-        const unsigned o1 = vout((r0.lo >> 16) + (r6.lo >> 16), (r1.lo >> 16) + (r5.lo >> 16), (r2.lo >> 16) + (r4.lo >> 16), r3.lo >> 16);
-        const unsigned o2 = vout((r0.hi & 0xFFFF) + (r6.hi & 0xFFFF), (r1.hi & 0xFFFF) + (r5.hi & 0xFFFF), (r2.hi & 0xFFFF) + (r4.hi & 0xFFFF), r3.hi & 0xFFFF);
-        const unsigned o3 = vout((r0.hi >> 16) + (r6.hi >> 16), (r1.hi >> 16) + (r5.hi >> 16), (r2.hi >> 16) + (r4.hi >> 16), r3.hi >> 16);
+        const unsigned o0 = vcol<false>(r0.lo, r1.lo, r2.lo, r3.lo, r4.lo, r5.lo, r6.lo);
+        const unsigned o1 = vcol<true>(r0.lo, r1.lo, r2.lo, r3.lo, r4.lo, r5.lo, r6.lo);
+        const unsigned o2 = vcol<false>(r0.hi, r1.hi, r2.hi, r3.hi, r4.hi, r5.hi, r6.hi);
+        const unsigned o3 = vcol<true>(r0.hi, r1.hi, r2.hi, r3.hi, r4.hi, r5.hi, r6.hi);
         *reinterpret_cast<unsigned*>(dst + (long long)y * L.pitch + x0) = o0 | (o1 << 8) | (o2 << 16) | (o3 << 24);
         r0 = r1; r1 = r2; r2 = r3; r3 = r4; r4 = r5; r5 = r6;
     }
