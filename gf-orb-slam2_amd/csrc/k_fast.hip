@@ -221,6 +221,8 @@ __global__ __launch_bounds__(256) void k_fast(const GfoGeom* __restrict__ gp, Gf
         const float inv_nq = 1.0f / (float)nq;
         const int ntask = nq * sh;
         const unsigned tq2 = (unsigned)tq | ((unsigned)tq << 16);
+        const unsigned valid_lo = (0xFu << (X0 & 3)) & 0xFu;                 // first dword: pixels left of scan column 0 drop out
+        const unsigned valid_hi = 0xFu >> (3 - ((X0 + sw - 1) & 3));        // last dword: pixels right of scan column sw-1
         for (int t0i = 0; t0i < ntask; t0i += 64) {
             const int t = t0i + lane;
             unsigned passbits = 0;  // bit j: pixel j of the dword passes
@@ -236,12 +238,13 @@ __global__ __launch_bounds__(256) void k_fast(const GfoGeom* __restrict__ gp, Gf
                 unsigned sign = 0;
 #pragma unroll
                 for (int h = 0; h < 2; h++) {  // h = 0: bytes 0,2   h = 1: bytes 1,3
-                    const unsigned sh8 = 8 * h;
-                    const s16x2 vc = __builtin_bit_cast(s16x2, (C >> sh8) & 0x00FF00FFu);
-                    const s16x2 a = vc - __builtin_bit_cast(s16x2, (U >> sh8) & 0x00FF00FFu);
-                    const s16x2 b = vc - __builtin_bit_cast(s16x2, (Rw >> sh8) & 0x00FF00FFu);
-                    const s16x2 e = vc - __builtin_bit_cast(s16x2, (D >> sh8) & 0x00FF00FFu);
-                    const s16x2 f = vc - __builtin_bit_cast(s16x2, (Lw >> sh8) & 0x00FF00FFu);
+                    // one v_perm_b32 per operand spreads bytes (h, h+2) into two u16 (selector 0x0C = zero byte)
+                    const unsigned ps = h ? 0x0C030C01u : 0x0C020C00u;
+                    const s16x2 vc = __builtin_bit_cast(s16x2, __builtin_amdgcn_perm(0u, C, ps));
+                    const s16x2 a = vc - __builtin_bit_cast(s16x2, __builtin_amdgcn_perm(0u, U, ps));
+                    const s16x2 b = vc - __builtin_bit_cast(s16x2, __builtin_amdgcn_perm(0u, Rw, ps));
+                    const s16x2 e = vc - __builtin_bit_cast(s16x2, __builtin_amdgcn_perm(0u, D, ps));
+                    const s16x2 f = vc - __builtin_bit_cast(s16x2, __builtin_amdgcn_perm(0u, Lw, ps));
                     // a 9-arc holds at least one pixel of every opposite pair: (a,e) = ring 0/8, (b,f) = ring 4/12
                     const s16x2 s_hi = __builtin_elementwise_min(__builtin_elementwise_max(a, e), __builtin_elementwise_max(b, f));
                     const s16x2 s_lo = __builtin_elementwise_max(__builtin_elementwise_min(a, e), __builtin_elementwise_min(b, f));
@@ -254,9 +257,8 @@ __global__ __launch_bounds__(256) void k_fast(const GfoGeom* __restrict__ gp, Gf
                 // sign bits: pixel0 -> bit14, pixel1 -> bit15, pixel2 -> bit30, pixel3 -> bit31
                 passbits = ((sign >> 14) & 3u) | ((sign >> 28) & 12u);
                 c0 = 4 * q - X0;  // scan column of pixel 0 (may be negative)
-                unsigned valid = 0;
-#pragma unroll
-                for (int j = 0; j < 4; j++) valid |= (unsigned)(c0 + j >= 0 && c0 + j < sw) << j;
+                // only the first and the last dword of a row can hold pixels outside the scan columns
+                const unsigned valid = (q == q_lo ? valid_lo : 0xFu) & (q == q_hi ? valid_hi : 0xFu);
                 passbits &= valid;
             }
 #pragma unroll
