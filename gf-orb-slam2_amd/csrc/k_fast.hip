@@ -261,11 +261,13 @@ __global__ __launch_bounds__(256) void k_fast(const GfoGeom* __restrict__ gp, Gf
                 const unsigned valid = (q == q_lo ? valid_lo : 0xFu) & (q == q_hi ? valid_hi : 0xFu);
                 passbits &= valid;
             }
+            const int p0 = py * sw + c0;
 #pragma unroll
             for (int j = 0; j < 4; j++) {
-                const bool pass = (passbits >> j) & 1u;
+                const bool pass = (passbits & (1u << j)) != 0;
                 const unsigned long long m = __ballot(pass);
-                if (pass) qa[na + __popcll(m & ((1ull << lane) - 1))] = (unsigned short)(py * sw + c0 + j);
+                // slot = na + (passing lanes below this one): v_mbcnt accumulates onto the running count
+                if (__builtin_amdgcn_inverse_ballot_w64(m)) qa[__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, (unsigned)na))] = (unsigned short)(p0 + j);
                 na += __popcll(m);
             }
         }
@@ -287,7 +289,8 @@ __global__ __launch_bounds__(256) void k_fast(const GfoGeom* __restrict__ gp, Gf
             }
             const bool pass = pol != 0;
             const unsigned long long m = __ballot(pass);
-            if (pass) qb[nb + __popcll(m & ((1ull << lane) - 1))] = (unsigned short)(p | (pol << 13));  // bits 13,14 = polarity
+            if (__builtin_amdgcn_inverse_ballot_w64(m))
+                qb[__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, (unsigned)nb))] = (unsigned short)(p | (pol << 13));  // bits 13,14 = polarity
             nb += __popcll(m);
         }
     }
@@ -360,7 +363,7 @@ __global__ __launch_bounds__(256) void k_fast(const GfoGeom* __restrict__ gp, Gf
             }
         }
         const unsigned long long m = __ballot(emit);
-        if (emit) out[run + __popcll(m & ((1ull << lane) - 1))] = key;
+        if (__builtin_amdgcn_inverse_ballot_w64(m)) out[__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, (unsigned)run))] = key;
         run += __popcll(m);
     }
 }
