@@ -244,10 +244,12 @@ static int plan(gfo_ctx* c, int w, int h, int batch)
     g.blur_total_b = blur_b;
     g.total_sel_cap = sel_off;
     g.kp_stride = (int)align_up(sel_off, 4);
-    g.fast_tile_pitch = (int)align_up(max_cw + 3, 16);  // +3: tile rows start at the aligned dword left of the cell; 16-B segments
+    // +3: tile rows start at the aligned dword left of the cell; 16-B segments.  Bucketed to the three pitches
+    // k_fast is instantiated for (48/44, 64/60, 80/76: tile / score-map pitch).
+    g.fast_tile_pitch = max_cw <= 45 ? 48 : (max_cw <= 61 ? 64 : 80);
     g.fast_npx_max = (int)align_up((long long)(max_cw - 6) * (max_ch - 6), 8);
     g.fast_tile_rows = max_ch;
-    g.fast_smap_pitch = (int)align_up(max_cw - 6 + 2, 4);
+    g.fast_smap_pitch = g.fast_tile_pitch - 4;
     g.fast_smap_rows = (int)align_up((long long)(max_ch - 6 + 2) * g.fast_smap_pitch, 16) / g.fast_smap_pitch + 1;  // zeroed in 16-B steps
     g.pyr_img_stride = align_up(pyr_off, 256);
     g.blur_img_stride = align_up(blur_off, 256);

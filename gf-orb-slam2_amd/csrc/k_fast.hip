@@ -126,6 +126,9 @@ __device__ __forceinline__ int arc_score(const uint8_t* __restrict__ c, int tp, 
     return max(b0, b1);
 }
 
+// TP / SP: pitch of the pixel tile and of the score map in LDS, compile-time so that every ring and neighbour
+// offset is an immediate of the LDS instruction (three buckets cover cells up to 64 px).
+template <int TP, int SP>
 __global__ __launch_bounds__(256) void k_fast(const GfoGeom* __restrict__ gp, GfoInput in,
                                               const uint8_t* __restrict__ pyr, uint32_t* __restrict__ cand,
                                               int* __restrict__ cand_cnt, int* __restrict__ flags, int dbg_stop)
@@ -136,7 +139,6 @@ __global__ __launch_bounds__(256) void k_fast(const GfoGeom* __restrict__ gp, Gf
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int img = blockIdx.y;
     const int cell = blockIdx.x * 4 + wave;
-    const int TP = g.fast_tile_pitch, SP = g.fast_smap_pitch;
     const int tile_bytes = TP * g.fast_tile_rows, smap_bytes = (SP * g.fast_smap_rows + 15) & ~15;
     const int per_wave = tile_bytes + smap_bytes + 2 * g.fast_npx_max;  // one u16 queue, compacted in place
     uint8_t* tile = lds + wave * per_wave;
@@ -376,7 +378,12 @@ void gfo_launch_fast(gfo_ctx* c, const GfoInput& in, int nimg)
     dim3 grid((g.total_cells + 3) / 4, nimg);
     gfo_prof_begin(c, ST_FAST);
     static const int dbg_stop = getenv("GFO_FAST_STOP") ? atoi(getenv("GFO_FAST_STOP")) : 0;  // timing experiments only
-    hipLaunchKernelGGL(k_fast, grid, dim3(256), lds, c->stream, c->d_geom, in, c->d_pyr, c->d_cand, c->d_cand_cnt,
-                       c->d_flags, dbg_stop);
+#define GFO_FAST_LAUNCH(TP_, SP_)                                                                                       \
+    hipLaunchKernelGGL((k_fast<TP_, SP_>), grid, dim3(256), lds, c->stream, c->d_geom, in, c->d_pyr, c->d_cand, c->d_cand_cnt, \
+                       c->d_flags, dbg_stop)
+    if (g.fast_tile_pitch == 48) GFO_FAST_LAUNCH(48, 44);
+    else if (g.fast_tile_pitch == 64) GFO_FAST_LAUNCH(64, 60);
+    else GFO_FAST_LAUNCH(80, 76);
+#undef GFO_FAST_LAUNCH
     gfo_prof_end(c);
 }
