@@ -71,15 +71,23 @@ __device__ __forceinline__ bool has_arc9(unsigned m16)
     return (r & 0xFFFFu) != 0;
 }
 
-__device__ __forceinline__ int corner_test(const uint8_t* __restrict__ c, int tp, int tq)
+// One ring pixel into the two masks: the compare sets VCC and v_addc_co_u32 shifts the mask left while adding
+// the carry -- two VALU operations per pixel and polarity (the C form costs three: compare, select, or).
+#define GFO_RING_BIT(mask, r, bound, CMP) asm("v_cmp_" CMP "_i32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(mask) : "v"(r), "v"(bound) : "vcc")
+
+template <int TP>
+__device__ __forceinline__ int corner_test(const uint8_t* __restrict__ c, int tq)
 {
-    int d[16];
-    ring_diffs(c, tp, d);
+    // ring in the order of FAST_NEON.cc:3-7, visited from position 15 down so that position k lands in bit k
+    const int v = c[0];
+    const int lo = v - tq, hi = v + tq;   // darker: r < v - tq ; brighter: r > v + tq
+    const int r[16] = {c[3 * TP], c[3 * TP + 1], c[2 * TP + 2], c[TP + 3], c[3], c[-TP + 3], c[-2 * TP + 2], c[-3 * TP + 1],
+                       c[-3 * TP], c[-3 * TP - 1], c[-2 * TP - 2], c[-TP - 3], c[-3], c[TP - 3], c[2 * TP - 2], c[3 * TP - 1]};
     unsigned md = 0, mb = 0;
 #pragma unroll
-    for (int k = 0; k < 16; k++) {
-        md |= (unsigned)(d[k] > tq) << k;
-        mb |= (unsigned)(d[k] < -tq) << k;
+    for (int k = 15; k >= 0; k--) {
+        GFO_RING_BIT(md, r[k], lo, "lt");
+        GFO_RING_BIT(mb, r[k], hi, "gt");
     }
     return (has_arc9(md) ? 1 : 0) | (has_arc9(mb) ? 2 : 0);
 }
@@ -199,7 +207,6 @@ __global__ __launch_bounds__(256) void k_fast(const GfoGeom* __restrict__ gp, Gf
     }
     wave_sync();
     if (dbg_stop == 1) return;
-    const float inv_sw = 1.0f / (float)sw;
     const uint8_t* t0 = tile + 3 * TP + xoff + 3;  // scan pixel (0,0)
     // The cascade runs at iniThFAST first; only a cell that yields no maximum there repeats it at
     // minThFAST (ORBextractor.cc:811-818).  Scores left in the map by the first round are true S values,
@@ -220,19 +227,24 @@ __global__ __launch_bounds__(256) void k_fast(const GfoGeom* __restrict__ gp, Gf
         const int X0 = xoff + 3;                       // tile column of scan pixel 0
         const int q_lo = X0 >> 2, q_hi = (X0 + sw - 1) >> 2;
         const int nq = q_hi - q_lo + 1;
-        const float inv_nq = 1.0f / (float)nq;
-        const int ntask = nq * sh;
+        // lane -> (row lr of the iteration, dword lq of the row), fixed for the cell: 64 / nq rows per iteration,
+        // so the loop body has no index arithmetic beyond one add
+        const int rpi = 64 / nq;                       // nq <= 18 (cells up to 64 px)
+        const int lr = (int)(((float)lane + 0.5f) * (1.0f / (float)nq));
+        const int lq = lane - lr * nq;
+        const bool lane_on = lr < rpi;
+        const int q = q_lo + lq;
+        const int c0 = 4 * q - X0;                     // scan column of pixel 0 of the dword (may be negative)
         const unsigned tq2 = (unsigned)tq | ((unsigned)tq << 16);
         const unsigned valid_lo = (0xFu << (X0 & 3)) & 0xFu;                 // first dword: pixels left of scan column 0 drop out
         const unsigned valid_hi = 0xFu >> (3 - ((X0 + sw - 1) & 3));        // last dword: pixels right of scan column sw-1
-        for (int t0i = 0; t0i < ntask; t0i += 64) {
-            const int t = t0i + lane;
+        // only the first and the last dword of a row can hold pixels outside the scan columns
+        const unsigned valid = (q == q_lo ? valid_lo : 0xFu) & (q == q_hi ? valid_hi : 0xFu);
+        int idx = (lr + 3) * tp4 + q;
+        for (int y0 = 0; y0 < sh; y0 += rpi, idx += rpi * tp4) {
+            const int py = y0 + lr;
             unsigned passbits = 0;  // bit j: pixel j of the dword passes
-            int py = 0, c0 = 0;
-            if (t < ntask) {
-                py = (int)(((float)t + 0.5f) * inv_nq);
-                const int q = q_lo + (t - py * nq);
-                const int idx = (py + 3) * tp4 + q;
+            if (lane_on && py < sh) {
                 const unsigned C = t32[idx], Wm = t32[idx - 1], Wp = t32[idx + 1];
                 const unsigned U = t32[idx + 3 * tp4], D = t32[idx - 3 * tp4];
                 const unsigned Lw = __builtin_amdgcn_alignbyte(C, Wm, 1);   // pixels at column-3
@@ -258,12 +270,9 @@ __global__ __launch_bounds__(256) void k_fast(const GfoGeom* __restrict__ gp, Gf
                 }
                 // sign bits: pixel0 -> bit14, pixel1 -> bit15, pixel2 -> bit30, pixel3 -> bit31
                 passbits = ((sign >> 14) & 3u) | ((sign >> 28) & 12u);
-                c0 = 4 * q - X0;  // scan column of pixel 0 (may be negative)
-                // only the first and the last dword of a row can hold pixels outside the scan columns
-                const unsigned valid = (q == q_lo ? valid_lo : 0xFu) & (q == q_hi ? valid_hi : 0xFu);
                 passbits &= valid;
             }
-            const int p0 = py * sw + c0;
+            const int p0 = (py << 6) + c0;   // queue entry: px | py << 6 (cells are at most 64 px wide)
 #pragma unroll
             for (int j = 0; j < 4; j++) {
                 const bool pass = (passbits & (1u << j)) != 0;
@@ -285,12 +294,9 @@ __global__ __launch_bounds__(256) void k_fast(const GfoGeom* __restrict__ gp, Gf
             int p = 0;
             if (i < na) {
                 p = qa[i];
-                const int py = (int)(((float)p + 0.5f) * inv_sw);
-                const int px = p - py * sw;
-                pol = corner_test(t0 + py * TP + px, TP, tq);
+                pol = corner_test<TP>(t0 + (p >> 6) * TP + (p & 63), tq);
             }
-            const bool pass = pol != 0;
-            const unsigned long long m = __ballot(pass);
+            const unsigned long long m = __ballot(pol != 0);
             if (__builtin_amdgcn_inverse_ballot_w64(m))
                 qb[__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, (unsigned)nb))] = (unsigned short)(p | (pol << 13));  // bits 13,14 = polarity
             nb += __popcll(m);
@@ -303,8 +309,7 @@ __global__ __launch_bounds__(256) void k_fast(const GfoGeom* __restrict__ gp, Gf
         for (int i = lane; i < nb; i += 64) {
             const int e = qb[i];
             const int p = e & 0x1FFF;
-            const int py = (int)(((float)p + 0.5f) * inv_sw);
-            const int px = p - py * sw;
+            const int py = p >> 6, px = p & 63;
             const uint8_t* c = t0 + py * TP + px;
             int s = arc_score(c, TP, (e & 0x2000) == 0);           // one polarity per lane ...
             if ((e & 0x6000) == 0x6000) s = max(s, arc_score(c, TP, false));  // ... both only when both prefilters passed (rare)
@@ -321,8 +326,7 @@ __global__ __launch_bounds__(256) void k_fast(const GfoGeom* __restrict__ gp, Gf
         bool mx = false;
         if (i < nb) {
             const int p = qb[i] & 0x1FFF;
-            const int py = (int)(((float)p + 0.5f) * inv_sw);
-            const int px = p - py * sw;
+            const int py = p >> 6, px = p & 63;
             const uint8_t* q = smap + (py + 1) * SP + px + 1;
             const int s = q[0];
             mx = s >= 2 && s > tq && s > q[-1] && s > q[1] && s > q[-SP - 1] && s > q[-SP] && s > q[-SP + 1] &&
@@ -354,8 +358,7 @@ __global__ __launch_bounds__(256) void k_fast(const GfoGeom* __restrict__ gp, Gf
             const int e = qb[i];
             if (e & 0x8000) {
                 const int p = e & 0x1FFF;
-                const int py = (int)(((float)p + 0.5f) * inv_sw);
-                const int px = p - py * sw;
+                const int py = p >> 6, px = p & 63;
                 const int s = smap[(py + 1) * SP + px + 1];
                 if (s > th) {
                     emit = true;
