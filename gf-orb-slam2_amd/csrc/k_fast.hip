@@ -35,28 +35,6 @@ __device__ __forceinline__ void wave_sync()
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-__device__ __forceinline__ void ring_diffs(const uint8_t* __restrict__ c, int tp, int* d)
-{
-    // ring in the order of FAST_NEON.cc:3-7
-    const int v = c[0];
-    d[0] = v - c[3 * tp];
-    d[1] = v - c[3 * tp + 1];
-    d[2] = v - c[2 * tp + 2];
-    d[3] = v - c[tp + 3];
-    d[4] = v - c[3];
-    d[5] = v - c[-tp + 3];
-    d[6] = v - c[-2 * tp + 2];
-    d[7] = v - c[-3 * tp + 1];
-    d[8] = v - c[-3 * tp];
-    d[9] = v - c[-3 * tp - 1];
-    d[10] = v - c[-2 * tp - 2];
-    d[11] = v - c[-tp - 3];
-    d[12] = v - c[-3];
-    d[13] = v - c[tp - 3];
-    d[14] = v - c[2 * tp - 2];
-    d[15] = v - c[3 * tp - 1];
-}
-
 // Exact FAST-9 test at threshold tq: bit k of the dark (bright) mask says ring pixel k is darker
 // (brighter) than the centre by more than tq; a corner needs 9 contiguous set bits on the circular
 // 16-bit mask (FAST_NEON.cc:226-259 mirror: the count > K run test).  Returns bit0 = dark arc exists,
@@ -105,16 +83,21 @@ __device__ __forceinline__ unsigned rot16(unsigned a) { return __builtin_amdgcn_
 
 // max over the sixteen 9-arcs of min(sign * d) for one polarity (sign = +1 dark, -1 bright), two ring
 // positions (k, k+8) per register in packed i16: the arc minima for k and k+8 come out of one op.
-__device__ __forceinline__ int arc_score(const uint8_t* __restrict__ c, int tp, bool bright)
+// The differences are formed packed as well: (r[k], r[k+8]) is one v_lshl_or, centre minus ring one v_pk_sub,
+// and the polarity one v_pk_mul by (+-1, +-1).
+template <int TP>
+__device__ __forceinline__ int arc_score(const uint8_t* __restrict__ c, bool bright)
 {
-    int d[16];
-    ring_diffs(c, tp, d);
-    const int m = bright ? -1 : 0;
+    const unsigned v = c[0];
+    const unsigned r[16] = {c[3 * TP], c[3 * TP + 1], c[2 * TP + 2], c[TP + 3], c[3], c[-TP + 3], c[-2 * TP + 2], c[-3 * TP + 1],
+                            c[-3 * TP], c[-3 * TP - 1], c[-2 * TP - 2], c[-TP - 3], c[-3], c[TP - 3], c[2 * TP - 2], c[3 * TP - 1]};
+    const s16x2 v2 = __builtin_bit_cast(s16x2, v | (v << 16));
+    const s16x2 sg = __builtin_bit_cast(s16x2, bright ? 0xFFFFFFFFu : 0x00010001u);
     unsigned P[8], R[8];
 #pragma unroll
     for (int k = 0; k < 8; k++) {
-        const int lo = (d[k] ^ m) - m, hi = (d[k + 8] ^ m) - m;  // conditional negate
-        P[k] = ((unsigned)lo & 0xFFFFu) | ((unsigned)hi << 16);
+        const s16x2 d = v2 - __builtin_bit_cast(s16x2, r[k] | (r[k + 8] << 16));
+        P[k] = __builtin_bit_cast(unsigned, d * sg);   // packed (d[k], d[k+8]), negated for the bright polarity
         R[k] = rot16(P[k]);  // = packed (d[k+8], d[k]) : ring positions k+8 .. k+15
     }
     unsigned X2[10], X4[12];
@@ -311,8 +294,9 @@ __global__ __launch_bounds__(256) void k_fast(const GfoGeom* __restrict__ gp, Gf
             const int p = e & 0x1FFF;
             const int py = p >> 6, px = p & 63;
             const uint8_t* c = t0 + py * TP + px;
-            int s = arc_score(c, TP, (e & 0x2000) == 0);           // one polarity per lane ...
-            if ((e & 0x6000) == 0x6000) s = max(s, arc_score(c, TP, false));  // ... both only when both prefilters passed (rare)
+            // a dark and a bright 9-arc cannot coexist on a 16-pixel ring, so the polarity B1 found is the only one
+            // whose arc minima can exceed the threshold: S comes from that polarity alone
+            const int s = arc_score<TP>(c, (e & 0x2000) == 0);
             smap[(py + 1) * SP + px + 1] = (uint8_t)(s > tq ? s : 0);
         }
     }
