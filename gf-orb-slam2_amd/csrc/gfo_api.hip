@@ -122,14 +122,14 @@ static void build_tables(gfo_ctx* c)
 static void free_arena(gfo_ctx* c)
 {
     void* ptrs[] = {c->d_geom, c->d_input, c->d_pyr, c->d_blur, c->d_cand, c->d_cand_cnt, c->d_node_of, c->d_sel,
-                    c->d_sel_cnt, c->d_kp, c->d_desc, c->d_kp_cnt, c->d_flags, c->d_xofs, c->d_xcoef, c->d_yofs, c->d_band,
+                    c->d_sel_cnt, c->d_kp, c->d_desc, c->d_kp_cnt, c->d_flags, c->d_xofs, c->d_xcoef, c->d_yofs, c->d_band, c->d_cell_tab,
                     c->d_ycoef, c->st.u_right, c->st.depth, c->st.best_dist, c->st.best_idx, c->st.nmatched, c->st.counted,
                     c->d_scale, c->d_inv_scale, c->st_sort.sx, c->st_sort.sy, c->st_sort.soi, c->st_sort.sdesc, c->st_sort.row_start};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     c->d_geom = nullptr; c->d_input = c->d_pyr = c->d_blur = nullptr; c->d_cand = nullptr; c->d_cand_cnt = nullptr;
     c->d_node_of = nullptr; c->d_sel = nullptr; c->d_sel_cnt = nullptr; c->d_kp = nullptr; c->d_desc = nullptr;
-    c->d_kp_cnt = nullptr; c->d_flags = nullptr; c->d_xofs = nullptr; c->d_xcoef = nullptr; c->d_yofs = nullptr; c->d_band = nullptr;
+    c->d_kp_cnt = nullptr; c->d_flags = nullptr; c->d_xofs = nullptr; c->d_xcoef = nullptr; c->d_yofs = nullptr; c->d_band = nullptr; c->d_cell_tab = nullptr;
     c->d_ycoef = nullptr; c->st = GfoStereoDev{}; c->d_scale = nullptr; c->d_inv_scale = nullptr; c->st_sort = GfoStereoSort{}; c->st_rows_cap = 0;
     c->planned = false;
     c->have_batch = c->have_pyramid = c->have_stereo = false;
@@ -371,6 +371,14 @@ static int plan(gfo_ctx* c, int w, int h, int batch)
     HIP_TRY(c, hipMalloc(&c->d_flags, 4 * sizeof(int)));
     HIP_TRY(c, hipMalloc(&c->d_xofs, xtabv.size() * sizeof(int) + 64));
     HIP_TRY(c, hipMalloc(&c->d_yofs, ytabv.size() * sizeof(int) + 64));
+    {
+        std::vector<int> cells((size_t)g.total_cells + 4, 0);
+        for (int l = 0; l < g.nlevels; l++)
+            for (int i = 0; i < g.lv[l].nrows; i++)
+                for (int j = 0; j < g.lv[l].ncols; j++) cells[(size_t)g.lv[l].cell_base + i * g.lv[l].ncols + j] = l | (i << 4) | (j << 16);
+        HIP_TRY(c, hipMalloc(&c->d_cell_tab, cells.size() * sizeof(int)));
+        HIP_TRY(c, hipMemcpy(c->d_cell_tab, cells.data(), cells.size() * sizeof(int), hipMemcpyHostToDevice));
+    }
     HIP_TRY(c, hipMalloc(&c->d_band, (bandv.size() + 4) * sizeof(int)));
     if (!bandv.empty()) HIP_TRY(c, hipMemcpy(c->d_band, bandv.data(), bandv.size() * sizeof(int), hipMemcpyHostToDevice));
     HIP_TRY(c, hipMalloc(&c->d_scale, GFO_MAX_LEVELS * sizeof(float)));

@@ -148,6 +148,7 @@ struct gfo_ctx {
     int* d_xofs = nullptr;           // resize tables, all levels
     short* d_xcoef = nullptr;
     int* d_yofs = nullptr;
+    int* d_cell_tab = nullptr;    // FAST: cell -> level | row << 4 | column << 16
     int* d_band = nullptr;        // per group: int4 [nb][nlevels] = {c0, c1, o0, o1}
     GfoBandGroup band_groups[2];
     int n_band_groups = 0, band_threads = 512;

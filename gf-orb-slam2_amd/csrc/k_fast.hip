@@ -122,7 +122,8 @@ __device__ __forceinline__ int arc_score(const uint8_t* __restrict__ c, bool bri
 template <int TP, int SP>
 __global__ __launch_bounds__(256) void k_fast(const GfoGeom* __restrict__ gp, GfoInput in,
                                               const uint8_t* __restrict__ pyr, uint32_t* __restrict__ cand,
-                                              int* __restrict__ cand_cnt, int* __restrict__ flags, int dbg_stop)
+                                              int* __restrict__ cand_cnt, int* __restrict__ flags, const int* __restrict__ cell_tab,
+                                              int dbg_stop)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     const GfoGeom& g = *gp;
@@ -138,13 +139,12 @@ __global__ __launch_bounds__(256) void k_fast(const GfoGeom* __restrict__ gp, Gf
     unsigned short* qb = qa;  // stage B1 writes entry j <= i after reading entry i (same wave, in order)
 
     if (cell >= g.total_cells) return;
-    int level = 0;
-    while (level + 1 < g.nlevels && cell >= g.lv[level + 1].cell_base) level++;
+    // cell -> (level, row, column) through the table plan() uploads: one scalar load instead of a search over the
+    // level prefix table and an integer division
+    const int ce = __builtin_amdgcn_readfirstlane(cell_tab[cell]);
+    const int level = ce & 15, ci = (ce >> 4) & 0xFFF, cj = ce >> 16;
     const GfoLevel& L = g.lv[level];
     const int wcell = L.wcell, hcell = L.hcell;
-    const int cidx = cell - L.cell_base;
-    const int ci = cidx / L.ncols;
-    const int cj = cidx - ci * L.ncols;
     const int iniX = GFO_MIN_BORDER + cj * wcell, iniY = GFO_MIN_BORDER + ci * hcell;
     const int maxX = min(iniX + wcell + 6, L.max_bx), maxY = min(iniY + hcell + 6, L.max_by);
     if (iniY >= L.max_by - 3 || iniX >= L.max_bx - 6) return;  // ORBextractor.cc:796,805
@@ -367,7 +367,7 @@ void gfo_launch_fast(gfo_ctx* c, const GfoInput& in, int nimg)
     static const int dbg_stop = getenv("GFO_FAST_STOP") ? atoi(getenv("GFO_FAST_STOP")) : 0;  // timing experiments only
 #define GFO_FAST_LAUNCH(TP_, SP_)                                                                                       \
     hipLaunchKernelGGL((k_fast<TP_, SP_>), grid, dim3(256), lds, c->stream, c->d_geom, in, c->d_pyr, c->d_cand, c->d_cand_cnt, \
-                       c->d_flags, dbg_stop)
+                       c->d_flags, c->d_cell_tab, dbg_stop)
     if (g.fast_tile_pitch == 48) GFO_FAST_LAUNCH(48, 44);
     else if (g.fast_tile_pitch == 64) GFO_FAST_LAUNCH(64, 60);
     else GFO_FAST_LAUNCH(80, 76);
