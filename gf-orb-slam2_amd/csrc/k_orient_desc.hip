@@ -19,19 +19,18 @@
 #include "gfo_internal.h"
 #include "../../include/gfo_sincos.h"
 
-struct PatQuad { signed char x0, y0, x1, y1; };
+// the 256 test pairs as floats (one 16-byte load per lane and round, no integer -> float conversion in the loop)
+struct PatQuad { float x0, y0, x1, y1; };
 __device__ const PatQuad k_pattern[256] = {
 #include "../../include/gfo_pattern.inc"
 };
 __device__ const int k_umax[16] = {15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3};  // ORBextractor.cc:451-468
 
 #define DW 37          // descriptor window (blurred level), rows
-#define DWP 44         // its LDS pitch: 11 dwords cover 37 px + up to 3 px of alignment slack
+#define DWP 48         // its LDS pitch: three 16-byte segments cover 37 px + up to 3 px of alignment slack
 #define OW 31          // orientation patch (unblurred level), rows
-#define OWP 40         // its LDS pitch: 9 dwords (+1 spare)
-
-#define OD_PAT_K 9      // dword loads per lane for the 31-row patch  (<= 9 dwords x 31 rows = 279, 32 lanes)
-#define OD_WIN_K 13     // dword loads per lane for the 37-row window (<= 11 dwords x 37 rows = 407, 32 lanes)
+#define OWP 48         // its LDS pitch: three 16-byte segments
+#define OD_STEPS 4     // 10 rows per step: 4 steps cover the 31-row patch and the 37-row window
 
 __global__ __launch_bounds__(256) void k_orient_desc(const GfoGeom* __restrict__ gp, GfoInput in,
                                                      const uint8_t* __restrict__ pyr, const uint8_t* __restrict__ blur,
@@ -91,51 +90,37 @@ __global__ __launch_bounds__(256) void k_orient_desc(const GfoGeom* __restrict__
     const int x = (int)(key & 0xFFF) + GFO_MIN_BORDER, y = (int)((key >> 12) & 0xFFF) + GFO_MIN_BORDER;  // :845-846
     const int score = (int)(key >> 24);
 
-    // ---- stage both windows of this half's keypoint (dword loads, all in flight together) ----
+    // ---- stage both windows of this half's keypoint: 16-byte loads, all in flight together ----
+    // A row of either window is three 16-byte segments from the aligned dword left of it (31 + 3 and 37 + 3
+    // bytes fit in 48; the bytes past the window belong to the same row or, at the right image border, to the
+    // next row, which exists because keypoints keep 19 px from every edge).  The lane -> (row, segment) map is
+    // fixed -- 10 rows x 3 segments per step -- so a load or store costs a pointer increment, not an index
+    // decomposition.
     int pitch;
     const uint8_t* lv = gfo_level_ptr(g, in, pyr, level, img, &pitch);
     const int ox_al = (x - GFO_HALF_PATCH) & ~3, ooff = (x - GFO_HALF_PATCH) - ox_al;
-    const int odpr = (ooff + OW + 3) >> 2;  // <= 9
     const int wx_al = (x - 18) & ~3, woff = (x - 18) - wx_al;
-    const int wdpr = (woff + DW + 3) >> 2;  // <= 11
     const int lpitch = L.pitch;
-    const uint8_t* psrc = lv + (long long)(y - GFO_HALF_PATCH) * pitch + ox_al;
-    const uint8_t* wsrc = blur + (long long)img * g.blur_img_stride + L.blur_off + (long long)(y - 18) * lpitch + wx_al;
+    const int rw = (hl * 11) >> 5, seg = hl - 3 * rw;   // hl / 3, hl % 3 for hl < 32; rw == 10: idle lanes
+    const bool ld_on = rw < 10;
+    const uint8_t* psrc = lv + (long long)(y - GFO_HALF_PATCH + rw) * pitch + (ox_al + 16 * seg);
+    const uint8_t* wsrc = blur + (long long)img * g.blur_img_stride + L.blur_off + (long long)(y - 18 + rw) * lpitch + (wx_al + 16 * seg);
     uint8_t* pat = s_pat[wave * 2 + half];
     uint8_t* win = s_win[wave * 2 + half];
     {
-        // the LDS offsets are recomputed at store time rather than kept: 22 fewer live registers while the
-        // loads are in flight (occupancy matters more than the extra integer operations here)
-        unsigned vp[OD_PAT_K], vw[OD_WIN_K];
-        const int pn = odpr * OW, wn = wdpr * DW;
-        const float pinv = 1.0f / (float)odpr, winv = 1.0f / (float)wdpr;
+        uint4 vp[OD_STEPS], vw[OD_STEPS];
 #pragma unroll
-        for (int k = 0; k < OD_PAT_K; k++) {
-            const int tt = min(k * 32 + hl, pn - 1);
-            const int r = (int)(((float)tt + 0.5f) * pinv);
-            vp[k] = *reinterpret_cast<const unsigned*>(psrc + (long long)r * pitch + 4 * (tt - r * odpr));
+        for (int k = 0; k < OD_STEPS; k++) {
+            const int rp = min(10 * k + rw, OW - 1), rq = min(10 * k + rw, DW - 1);   // clamped: idle lanes re-read a valid row
+            vp[k] = *reinterpret_cast<const uint4*>(psrc + (long long)(rp - rw) * pitch);
+            vw[k] = *reinterpret_cast<const uint4*>(wsrc + (long long)(rq - rw) * lpitch);
         }
+        uint4* pl = reinterpret_cast<uint4*>(pat + rw * OWP + 16 * seg);
+        uint4* wl = reinterpret_cast<uint4*>(win + rw * DWP + 16 * seg);
 #pragma unroll
-        for (int k = 0; k < OD_WIN_K; k++) {
-            const int tt = min(k * 32 + hl, wn - 1);
-            const int r = (int)(((float)tt + 0.5f) * winv);
-            vw[k] = *reinterpret_cast<const unsigned*>(wsrc + (long long)r * lpitch + 4 * (tt - r * wdpr));
-        }
-#pragma unroll
-        for (int k = 0; k < OD_PAT_K; k++) {
-            const int t = k * 32 + hl;
-            if (t < pn) {
-                const int r = (int)(((float)t + 0.5f) * pinv);
-                *reinterpret_cast<unsigned*>(pat + r * OWP + 4 * (t - r * odpr)) = vp[k];
-            }
-        }
-#pragma unroll
-        for (int k = 0; k < OD_WIN_K; k++) {
-            const int t = k * 32 + hl;
-            if (t < wn) {
-                const int r = (int)(((float)t + 0.5f) * winv);
-                *reinterpret_cast<unsigned*>(win + r * DWP + 4 * (t - r * wdpr)) = vw[k];
-            }
+        for (int k = 0; k < OD_STEPS; k++) {
+            if (ld_on && 10 * k + rw < OW) pl[k * (10 * OWP / 16)] = vp[k];
+            if (ld_on && 10 * k + rw < DW) wl[k * (10 * DWP / 16)] = vw[k];
         }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -143,19 +128,20 @@ __global__ __launch_bounds__(256) void k_orient_desc(const GfoGeom* __restrict__
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
     // ---- IC_Angle on the unblurred patch: lane = column u, one disc row per step ----
+    // Every lane reads its column of every row (the read stays inside the staged 48-byte row) and the disc
+    // is applied as a select on |u| <= umax(|v|): no divergent branch, so no exec-mask bookkeeping per row.
+    // Lane 31 (u = 16) lies outside every row of the disc and contributes zeros.
     const uint8_t* center = pat + GFO_HALF_PATCH * OWP + ooff + GFO_HALF_PATCH;
     const int u = hl - GFO_HALF_PATCH;
+    const int au = u < 0 ? -u : u;
     int m10 = 0, m01 = 0;
-    if (hl < 31) {
 #pragma unroll
-        for (int v = -GFO_HALF_PATCH; v <= GFO_HALF_PATCH; v++) {
-            const int d = k_umax[v < 0 ? -v : v];
-            if (u >= -d && u <= d) {
-                const int val = center[v * OWP + u];
-                m10 += u * val;
-                m01 += v * val;
-            }
-        }
+    for (int v = -GFO_HALF_PATCH; v <= GFO_HALF_PATCH; v++) {
+        const int d = k_umax[v < 0 ? -v : v];
+        int val = center[v * OWP + u];
+        val = au <= d ? val : 0;
+        m10 += u * val;
+        m01 += v * val;
     }
 #pragma unroll
     for (int o = 16; o > 0; o >>= 1) {  // stays inside the 32-lane half
@@ -168,17 +154,21 @@ __global__ __launch_bounds__(256) void k_orient_desc(const GfoGeom* __restrict__
     const float factorPI = (float)(3.1415926535897932384626433832795 / 180.f);
     float a, b;
     gfo_sincosf(angle * factorPI, &b, &a);
-    const uint8_t* wc = win + 18 * DWP + woff + 18;
+    // rounding to nearest-even by the 1.5 * 2^23 constant: the sum's low mantissa bits ARE the integer, biased by
+    // 0x4B400000; both biases of a point are folded into the window base pointer (rintf + convert would be two
+    // more operations per coordinate)
+    const float magic = 12582912.0f;
+    const unsigned wbase = (unsigned)(18 * DWP + woff + 18) - 0x4B400000u * (unsigned)(DWP + 1);   // mod 2^32
     unsigned word = 0;
 #pragma unroll
     for (int r = 0; r < 8; r++) {
         const PatQuad p = k_pattern[r * 32 + hl];
-        const float x0 = (float)p.x0, y0 = (float)p.y0, x1 = (float)p.x1, y1 = (float)p.y1;
-        const int iy0 = (int)rintf(x0 * b + y0 * a), ix0 = (int)rintf(x0 * a - y0 * b);
-        const int iy1 = (int)rintf(x1 * b + y1 * a), ix1 = (int)rintf(x1 * a - y1 * b);
-        const int t0 = wc[iy0 * DWP + ix0], t1 = wc[iy1 * DWP + ix1];
+        const float fy0 = (p.x0 * b + p.y0 * a) + magic, fx0 = (p.x0 * a - p.y0 * b) + magic;
+        const float fy1 = (p.x1 * b + p.y1 * a) + magic, fx1 = (p.x1 * a - p.y1 * b) + magic;
+        const unsigned iy0 = __float_as_uint(fy0), ix0 = __float_as_uint(fx0), iy1 = __float_as_uint(fy1), ix1 = __float_as_uint(fx1);
+        const int t0 = win[iy0 * (unsigned)DWP + ix0 + wbase], t1 = win[iy1 * (unsigned)DWP + ix1 + wbase];   // u32 arithmetic: the biases cancel
         const unsigned long long m = __ballot(t0 < t1);
-        if (hl == r) word = (unsigned)(m >> (32 * half));  // tests 32r..32r+31 of THIS half's keypoint
+        word = hl == r ? (unsigned)(m >> (32 * half)) : word;  // tests 32r..32r+31 of THIS half's keypoint
     }
     if (!act) return;
     const long long o = (long long)img * g.kp_stride + slot;
