@@ -134,14 +134,20 @@ __global__ __launch_bounds__(256) void k_orient_desc(const GfoGeom* __restrict__
     const uint8_t* center = pat + GFO_HALF_PATCH * OWP + ooff + GFO_HALF_PATCH;
     const int u = hl - GFO_HALF_PATCH;
     const int au = u < 0 ? -u : u;
-    int m10 = 0, m01 = 0;
+    // rows +v and -v share umax(v) (the reference pairs them the same way, ORBextractor.cc:88-100): one select
+    // per pair, m10 takes u * (sum), m01 takes v * (difference); integer sums, so the order is immaterial
+    int m10, m01 = 0;
+    {
+        const int val = center[u];
+        m10 = u * (au <= GFO_HALF_PATCH ? val : 0);
+    }
 #pragma unroll
-    for (int v = -GFO_HALF_PATCH; v <= GFO_HALF_PATCH; v++) {
-        const int d = k_umax[v < 0 ? -v : v];
-        int val = center[v * OWP + u];
-        val = au <= d ? val : 0;
-        m10 += u * val;
-        m01 += v * val;
+    for (int v = 1; v <= GFO_HALF_PATCH; v++) {
+        const int d = k_umax[v];
+        const int vp = center[v * OWP + u], vm = center[-v * OWP + u];
+        const bool in = au <= d;
+        m10 += u * (in ? vp + vm : 0);
+        m01 += v * (in ? vp - vm : 0);
     }
 #pragma unroll
     for (int o = 16; o > 0; o >>= 1) {  // stays inside the 32-lane half
