@@ -59,15 +59,19 @@ def main():
     # rocprofv3 reports FETCH_SIZE / WRITE_SIZE in KiB.  Calibration on this code's own access pattern
     # (4 B per lane): k_fast reads every level exactly once and FETCH_SIZE*1024 comes out at 1.00-1.03x
     # that byte count, so no 2x correction is applied (the gfx950 halving concerns 16 B/lane streams).
-    stage_of = {"k_resize": "resize", "k_blur": "blur", "k_fast": "fast", "k_quadtree": "quadtree",
-                "k_orient_desc": "orient_desc", "k_stereo_bucket": "stereo_bucket", "k_stereo_match": "stereo_match",
-                "k_stereo_cut": "stereo_cut"}
+    # a stage may be several launches per step (the banded pyramid is two, the per-level fallback up to seven):
+    # stage bytes per step = all bytes of the stage's kernels / steps, steps = launches of k_quadtree (one per step)
+    stage_of = (("k_resize", "resize"), ("k_pyramid_bands", "resize"), ("k_blur", "blur"), ("k_fast", "fast"), ("k_quadtree", "quadtree"),
+                ("k_orient_desc", "orient_desc"), ("k_stereo_bucket", "stereo_bucket"), ("k_stereo_match", "stereo_match"),
+                ("k_stereo_cut", "stereo_cut"))
     traffic = {}
-    for k, st in stage_of.items():
-        f_ = out["FETCH_SIZE"].get(k, {}).get("avg_per_launch")
-        w_ = out["WRITE_SIZE"].get(k, {}).get("avg_per_launch")
-        if f_ is not None and w_ is not None:
-            traffic[st] = int((f_ + w_) * 1024)
+    for cname in ("FETCH_SIZE", "WRITE_SIZE"):
+        steps = max([v["launches"] for k, v in out[cname].items() if "k_quadtree" in k] or [1])
+        for k, v in out[cname].items():
+            for pat, st in stage_of:
+                if pat in k and not (pat == "k_stereo_match" and "sad" in k):
+                    traffic[st] = traffic.get(st, 0) + int(v["avg_per_launch"] * v["launches"] * 1024 / steps)
+                    break
     meta = {"tag": tag, "workload": os.environ.get("GFO_PROF_WORKLOAD", "stereo752"), "batch": int(os.environ.get("GFO_PROF_BATCH", "128")),
             "hbm_bytes_per_launch": traffic, "note": "FETCH_SIZE+WRITE_SIZE (KiB) x 1024, separate --pmc passes, averaged per launch"}
     json.dump(meta, open(os.path.join(dst, f"traffic_{tag}.json"), "w"), indent=1, sort_keys=True)
