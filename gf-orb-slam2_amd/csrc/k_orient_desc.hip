@@ -21,6 +21,7 @@
 
 // the 256 test pairs as floats (one 16-byte load per lane and round, no integer -> float conversion in the loop)
 struct PatQuad { float x0, y0, x1, y1; };
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 __device__ const PatQuad k_pattern[256] = {
 #include "../../include/gfo_pattern.inc"
 };
@@ -169,9 +170,11 @@ __global__ __launch_bounds__(256) void k_orient_desc(const GfoGeom* __restrict__
 #pragma unroll
     for (int r = 0; r < 8; r++) {
         const PatQuad p = k_pattern[r * 32 + hl];
-        const float fy0 = (p.x0 * b + p.y0 * a) + magic, fx0 = (p.x0 * a - p.y0 * b) + magic;
-        const float fy1 = (p.x1 * b + p.y1 * a) + magic, fx1 = (p.x1 * a - p.y1 * b) + magic;
-        const unsigned iy0 = __float_as_uint(fy0), ix0 = __float_as_uint(fx0), iy1 = __float_as_uint(fy1), ix1 = __float_as_uint(fx1);
+        // both points of the pair at once: packed-fp32 multiply / add (v_pk_mul_f32, v_pk_add_f32), each lane op
+        // still the plain IEEE single operation of the scalar form (no contraction: -ffp-contract=off)
+        const f32x2 px = {p.x0, p.x1}, py = {p.y0, p.y1};
+        const f32x2 fy = (px * b + py * a) + magic, fx = (px * a - py * b) + magic;
+        const unsigned iy0 = __float_as_uint(fy.x), ix0 = __float_as_uint(fx.x), iy1 = __float_as_uint(fy.y), ix1 = __float_as_uint(fx.y);
         const int t0 = win[iy0 * (unsigned)DWP + ix0 + wbase], t1 = win[iy1 * (unsigned)DWP + ix1 + wbase];   // u32 arithmetic: the biases cancel
         const unsigned long long m = __ballot(t0 < t1);
         word = hl == r ? (unsigned)(m >> (32 * half)) : word;  // tests 32r..32r+31 of THIS half's keypoint
