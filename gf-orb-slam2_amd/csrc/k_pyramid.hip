@@ -92,10 +92,19 @@ __device__ __forceinline__ void resize_block(const uint8_t* __restrict__ src, in
     if (r_last - r_first < RS_MAXR) {
         // all source rows of the block in flight together
         HQuad rows[RS_MAXR];
+        // one branch for the six rows (only the last one or two quads of a row take the byte path)
+        if (fast) {
 #pragma unroll
-        for (int k = 0; k < RS_MAXR; k++) {
-            const int r = min(r_first + k, srow_hi);
-            rows[k] = resize_hrow(src + (long long)r * spitch, base_x, fast, sx, sel, cw, sw);
+            for (int k = 0; k < RS_MAXR; k++) {
+                const int r = min(r_first + k, srow_hi);
+                rows[k] = resize_hrow(src + (long long)r * spitch, base_x, true, sx, sel, cw, sw);
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < RS_MAXR; k++) {
+                const int r = min(r_first + k, srow_hi);
+                rows[k] = resize_hrow(src + (long long)r * spitch, base_x, false, sx, sel, cw, sw);
+            }
         }
 #pragma unroll
         for (int j = 0; j < RS_STRIP; j++) {
@@ -104,21 +113,23 @@ __device__ __forceinline__ void resize_block(const uint8_t* __restrict__ src, in
             const unsigned b0 = bw[j] & 0xFFFF, b1 = (unsigned)bw[j] >> 16;
             const int i0 = min(max(syv[j], 0), sh - 1) - r_first, i1 = min(max(syv[j] + 1, 0), sh - 1) - r_first;
             HQuad ra = rows[0], rb = rows[0];
-            bool picked = false;
+            // Output row j of the strip blends source rows (i0, i0 + 1) with i0 = j or j + 1 at scale factors up
+            // to 1.33 (sy advances by 1 or 2 per row): with wave-uniform rows those two cases are two scalar
+            // compares; anything else (steeper factors, the clamped last row) takes the per-lane select chains.
+            bool generic = true;
             if (UNI) {
-                const int i0u = __builtin_amdgcn_readfirstlane(i0);
-                if (i1 == i0u + 1) {  // the usual case: rows (i0, i0+1); wave-uniform branch
-                    picked = true;
-                    switch (i0u) {
-                    case 0: ra = rows[0]; rb = rows[1]; break;
-                    case 1: ra = rows[1]; rb = rows[2]; break;
-                    case 2: ra = rows[2]; rb = rows[3]; break;
-                    case 3: ra = rows[3]; rb = rows[4]; break;
-                    default: ra = rows[4]; rb = rows[5]; break;
-                    }
+                const int i0u = __builtin_amdgcn_readfirstlane(i0), i1u = __builtin_amdgcn_readfirstlane(i1);
+                if (i1u == i0u + 1 && i0u == j) {
+                    ra = rows[j];
+                    rb = rows[j + 1];
+                    generic = false;
+                } else if (i1u == i0u + 1 && i0u == j + 1) {
+                    ra = rows[j + 1];
+                    rb = rows[j + 2];
+                    generic = false;
                 }
             }
-            if (!picked) {
+            if (generic) {
 #pragma unroll
                 for (int k = 0; k < 4; k++) {
 #pragma unroll
@@ -243,8 +254,9 @@ __global__ __launch_bounds__(1024) void k_pyramid_bands(const GfoGeom* __restric
         const int2* xt = xtab_all + L.xtab_off;
         const int2* yt = ytab_all + L.ytab_off;
         const int sh = g.lv[level - 1].h, sw = g.lv[level - 1].w;
+        const unsigned inv_wps = (65536u + wps - 1) / wps;   // wt / wps by multiplication: exact while wt * wps < 2^16
         for (int wt = wave; wt < wps * nstrips; wt += nwaves) {
-            const int s = wt / wps;
+            const int s = (int)(((unsigned)wt * inv_wps) >> 16);
             const int quad = (wt - s * wps) * 64 + lane;
             if (quad >= quads) continue;
             const int dy0 = rg.x + s * RS_STRIP;
