@@ -440,6 +440,13 @@ extern "C" int gfo_ctx_create(const gfo_params* p, int device, gfo_ctx** out)
         return fail(nullptr, GFO_ERR_DEVICE, "hipStreamCreate failed");
     }
     c->stream = c->own_stream;
+    if (hipStreamCreateWithFlags(&c->side_stream, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess) {
+        (void)hipGetLastError();
+        c->fork_blur = false;   // extraction then simply runs in one stream
+    }
+    if (getenv("GFO_FORK_BLUR")) c->fork_blur = c->fork_blur && atoi(getenv("GFO_FORK_BLUR")) != 0;
     const char* dbg = getenv("GFO_DEBUG_SYNC");
     c->debug_sync = dbg && dbg[0] == '1';
     build_tables(c);
@@ -457,6 +464,12 @@ extern "C" void gfo_ctx_destroy(gfo_ctx* c)
     free_arena(c);
     if (c->d_scratch) (void)hipFree(c->d_scratch);
     if (c->d_voc) (void)hipFree(c->d_voc);
+    if (c->side_stream) {
+        (void)hipStreamSynchronize(c->side_stream);
+        (void)hipStreamDestroy(c->side_stream);
+    }
+    if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+    if (c->ev_join) (void)hipEventDestroy(c->ev_join);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
 }
@@ -532,9 +545,27 @@ static int run_extract(gfo_ctx* c, const GfoInput& in, int nimg)
 {
     HIP_TRY(c, hipMemsetAsync(c->d_cand_cnt, 0, sizeof(int) * nimg * c->g.nlevels * GFO_CNT_STRIDE, c->stream));
     run_pyramid(c, in, nimg);
-    gfo_launch_blur(c, in, nimg);
-    gfo_launch_fast(c, in, nimg);
-    gfo_launch_quadtree(c, nimg);
+    // fork: the blur (vector-pipe bound) next to FAST and the quadtree (the latter mostly barrier waits); join
+    // before the descriptors.  Per-kernel profiling and debug runs keep everything in one stream.
+    const bool fork = c->fork_blur && !c->profiling && !c->debug_sync;
+    if (fork) {
+        // FAST first (it fills the vector pipes by itself); the fork point is after it, so that the blur shares the
+        // chip with the quadtree, whose workgroups mostly wait at barriers
+        hipStream_t main_stream = c->stream;
+        gfo_launch_fast(c, in, nimg);
+        HIP_TRY(c, hipEventRecord(c->ev_fork, main_stream));
+        HIP_TRY(c, hipStreamWaitEvent(c->side_stream, c->ev_fork, 0));
+        gfo_launch_quadtree(c, nimg);
+        c->stream = c->side_stream;
+        gfo_launch_blur(c, in, nimg);
+        c->stream = main_stream;
+        HIP_TRY(c, hipEventRecord(c->ev_join, c->side_stream));
+        HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev_join, 0));
+    } else {
+        gfo_launch_blur(c, in, nimg);
+        gfo_launch_fast(c, in, nimg);
+        gfo_launch_quadtree(c, nimg);
+    }
     gfo_launch_orient_desc(c, in, nimg);
     if (!c->launch_err.empty()) {
         const std::string m = c->launch_err;

@@ -120,6 +120,11 @@ struct gfo_ctx {
     int device = 0;
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
+    // the blur depends only on the pyramid and is needed only by orient_desc: it runs on this side stream next to
+    // FAST and the quadtree (fork / join by events); all work is still ordered on `stream` for the caller
+    hipStream_t side_stream = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    bool fork_blur = true;
     std::string err;
     std::string launch_err;
     bool debug_sync = false;
