@@ -31,3 +31,17 @@ for _ in range(50):
     ts.append(time.perf_counter() - t0)
 ts = np.array(ts) * 1e3
 print(f"one stereo pair, host buffers in and out: median {np.median(ts):.3f} ms, min {ts.min():.3f} ms, p90 {np.percentile(ts, 90):.3f} ms")
+
+# where the time goes: device time of each stage for this 2-image batch (HIP events), the rest is host-side
+ext.profile_enable(True)
+for _ in range(20):
+    once()
+prof = ext.profile_read()
+ext.profile_enable(False)
+print("device us per pair:", {k: round(ms / 20 * 1e3, 1) for k, (ms, n) in prof.items()}, "sum", round(sum(ms for ms, n in prof.values()) / 20 * 1e3, 1))
+for name, fn in (("extract_batch", lambda: ext.extract_batch(imgs)), ("stereo_match_batch", lambda: m.stereo_match_batch(sp)),
+                 ("stereo_fetch", lambda: m.stereo_fetch(0, 2064))):
+    t0 = time.perf_counter()
+    for _ in range(50):
+        fn()
+    print(f"{name}: {(time.perf_counter() - t0) / 50 * 1e3:.3f} ms")
