@@ -86,8 +86,15 @@ __global__ __launch_bounds__(QT_MAX_THREADS) void k_quadtree(const GfoGeom* __re
                                                          const int* __restrict__ cand_cnt,
                                                          uint16_t* __restrict__ node_of_all,
                                                          uint32_t* __restrict__ sel, int* __restrict__ sel_cnt,
-                                                         int* __restrict__ flags, int ncap, int klds)
+                                                         int* __restrict__ flags, int ncap, int klds,
+                                                         unsigned long long* __restrict__ dbg_ts)
 {
+    // debugging aid (GFO_QT_TIMING=1): thread 0 of block (0, 0) stamps the constant-rate clock at phase boundaries
+    int ts_i = 0;
+#define QT_TS(label)                                                                              \
+    if (dbg_ts && threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == 0 && ts_i < 120)          \
+    dbg_ts[ts_i++] = (wall_clock64() << 8) | (unsigned)(label)
+
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     const GfoGeom& g = *gp;
     const int level = blockIdx.y, img = blockIdx.x, tid = threadIdx.x;  // level-major dispatch: the heavy level-0 blocks start first
@@ -102,6 +109,7 @@ __global__ __launch_bounds__(QT_MAX_THREADS) void k_quadtree(const GfoGeom* __re
         if (tid == 0) *out_cnt = 0;
         return;
     }
+    QT_TS(1);
     // LDS carve-up (ncap entries each unless noted)
     unsigned long long* srt = reinterpret_cast<unsigned long long*>(lds);   // sort keys / best keys, pow2(ncap)
     int p2 = 1;
@@ -162,6 +170,7 @@ __global__ __launch_bounds__(QT_MAX_THREADS) void k_quadtree(const GfoGeom* __re
     for (int k = tid; k < K; k += QT_THREADS) node_of[k] = (uint16_t)sc1[node_of[k]];
     __syncthreads();
 
+    QT_TS(2);
     QtBox* box = boxA;
     int* cnt = cntA;
     QtBox* boxn = boxB;
@@ -171,6 +180,7 @@ __global__ __launch_bounds__(QT_MAX_THREADS) void k_quadtree(const GfoGeom* __re
 
     for (int iter = 0; iter < 64; iter++) {
         // ---- child histograms of the nodes that may be split in this pass ----
+        QT_TS(3);
         const int lim = phase2 ? xlen : n;
         for (int i = tid; i < 4 * lim; i += QT_THREADS) cc[i] = 0;
         __syncthreads();
@@ -179,6 +189,7 @@ __global__ __launch_bounds__(QT_MAX_THREADS) void k_quadtree(const GfoGeom* __re
             if (i < lim && cnt[i] > 1) atomicAdd(&cc[4 * i + qt_quadrant(keys[k], box[i])], 1);
         }
         __syncthreads();
+        QT_TS(4);
         int m_split;  // number of nodes split in this pass
         if (!phase2) {
             // every node with more than one key is split, in list order (:606-665)
@@ -191,6 +202,7 @@ __global__ __launch_bounds__(QT_MAX_THREADS) void k_quadtree(const GfoGeom* __re
             __syncthreads();
             const int ctot = qt_scan(sc1, n, part);
             const int nsingle = qt_scan(sc2, n, part);
+            QT_TS(5);
             if (ctot + nsingle > ncap) {
                 if (tid == 0) { atomicOr(&flags[0], 2); *out_cnt = 0; }
                 return;
@@ -214,11 +226,13 @@ __global__ __launch_bounds__(QT_MAX_THREADS) void k_quadtree(const GfoGeom* __re
                 }
             }
             __syncthreads();
+            QT_TS(7);
             for (int k = tid; k < K; k += QT_THREADS) {
                 const int i = node_of[k];
                 node_of[k] = (uint16_t)(cnt[i] > 1 ? cpos[4 * i + qt_quadrant(keys[k], box[i])] : npos[i]);
             }
             __syncthreads();
+            QT_TS(8);
             const int prev = n;
             n = ctot + nsingle;
             xlen = ctot;
@@ -238,6 +252,41 @@ __global__ __launch_bounds__(QT_MAX_THREADS) void k_quadtree(const GfoGeom* __re
             continue;
         }
         // ---- final phase: split the largest nodes first until N is reached (:673-735) ----
+        // Order the expandable nodes by (size desc, position asc).  Keys are distinct (the position is part of
+        // them), so the sorted slot of a key is simply the number of larger keys.  For the few hundred nodes of
+        // the usual quotas every thread counts them directly -- xlen broadcast reads of LDS, one barrier -- which
+        // takes a fifth of the time of the 45 dependent compare-exchange rounds of a bitonic network (each round
+        // is a full LDS round trip); large lists (1080p, 4000 features) keep the network.
+        const int per_thread = (xlen + QT_THREADS - 1) / QT_THREADS;
+        if (xlen * per_thread <= 2048) {
+            unsigned long long* keyv = reinterpret_cast<unsigned long long*>(cpos);   // 4*ncap ints, free until the rebuild
+            for (int i = tid; i < xlen; i += QT_THREADS)
+                keyv[i] = cnt[i] > 1 ? ((unsigned long long)(unsigned)cnt[i] << 16) | (unsigned)(0xFFFF - i) : 0ull;
+            for (int i = tid; i < p2; i += QT_THREADS) srt[i] = 0;
+            __syncthreads();
+            // two own keys per sweep; the sweep reads eight list entries at a time (independent broadcast loads in
+            // flight together -- one load per iteration would make every step a full LDS round trip)
+            const int xlen8 = (xlen + 7) & ~7;   // entries [xlen, xlen8) are zeroed below: never larger than a key
+            for (int i = xlen + tid; i < xlen8; i += QT_THREADS) keyv[i] = 0;
+            __syncthreads();
+            for (int i = tid; i < xlen; i += 2 * QT_THREADS) {
+                const unsigned long long m0 = keyv[i], m1 = i + QT_THREADS < xlen ? keyv[i + QT_THREADS] : 0ull;
+                int r0 = 0, r1 = 0;
+                for (int j = 0; j < xlen8; j += 8) {
+                    unsigned long long kj[8];
+#pragma unroll
+                    for (int u = 0; u < 8; u++) kj[u] = keyv[j + u];
+#pragma unroll
+                    for (int u = 0; u < 8; u++) {
+                        r0 += kj[u] > m0 ? 1 : 0;
+                        r1 += kj[u] > m1 ? 1 : 0;
+                    }
+                }
+                if (m0) srt[r0] = m0;
+                if (m1) srt[r1] = m1;
+            }
+            __syncthreads();
+        } else {
         for (int i = tid; i < p2; i += QT_THREADS) {
             unsigned long long key = 0;
             if (i < xlen && cnt[i] > 1) key = ((unsigned long long)(unsigned)cnt[i] << 16) | (unsigned)(0xFFFF - i);
@@ -256,6 +305,8 @@ __global__ __launch_bounds__(QT_MAX_THREADS) void k_quadtree(const GfoGeom* __re
                 }
                 __syncthreads();
             }
+        }
+        QT_TS(6);
         // sorted descending: expandable nodes first, (size desc, position asc)
         for (int i = tid; i < xlen; i += QT_THREADS) {
             const unsigned long long key = srt[i];
@@ -329,11 +380,13 @@ __global__ __launch_bounds__(QT_MAX_THREADS) void k_quadtree(const GfoGeom* __re
                 sc1[i] = pos;  // sc1 is free again: new position of kept node i
             } else sc1[i] = -1;
         __syncthreads();
+        QT_TS(7);
         for (int k = tid; k < K; k += QT_THREADS) {
             const int i = node_of[k];
             node_of[k] = (uint16_t)(sc1[i] >= 0 ? sc1[i] : cpos[4 * i + qt_quadrant(keys[k], box[i])]);
         }
         __syncthreads();
+        QT_TS(8);
         const int prev = n;
         n = n + growth;
         xlen = ctot;
@@ -344,6 +397,7 @@ __global__ __launch_bounds__(QT_MAX_THREADS) void k_quadtree(const GfoGeom* __re
 
     // ---- keep the best response of every node, first in the reference's key order on ties
     //      (:740-760).  Key order = cell-major then row-major: rank = (cell_i, cell_j, y, x).
+    QT_TS(9);
     for (int i = tid; i < n; i += QT_THREADS) srt[i] = 0;
     __syncthreads();
     for (int k = tid; k < K; k += QT_THREADS) {
@@ -365,7 +419,9 @@ __global__ __launch_bounds__(QT_MAX_THREADS) void k_quadtree(const GfoGeom* __re
         const unsigned s = (unsigned)(v >> 48) - 1;
         out[i] = (uint32_t)(rank & 0xFFFFFF) | (s << 24);
     }
+    QT_TS(10);
     if (tid == 0) *out_cnt = n;
+#undef QT_TS
 }
 
 size_t gfo_quadtree_lds_bytes(int ncap, int klds)
@@ -392,8 +448,20 @@ void gfo_launch_quadtree(gfo_ctx* c, int nimg)
     // 1024 threads per (image, level), the 752x480 @2000 case runs best with 256
     static const int nt_env = getenv("GFO_QT_THREADS") ? atoi(getenv("GFO_QT_THREADS")) : 0;
     const int nthreads = nt_env ? nt_env : (c->g.lv[0].quota >= 600 ? 1024 : 256);
+    static const bool timing = getenv("GFO_QT_TIMING") != nullptr;
+    unsigned long long* d_ts = nullptr;
+    if (timing && hipMalloc(&d_ts, 128 * sizeof(unsigned long long)) == hipSuccess) (void)hipMemsetAsync(d_ts, 0, 128 * sizeof(unsigned long long), c->stream);
     gfo_prof_begin(c, ST_QUADTREE);
     hipLaunchKernelGGL(k_quadtree, grid, dim3(nthreads), lds, c->stream, c->d_geom, c->d_cand, c->d_cand_cnt,
-                       c->d_node_of, c->d_sel, c->d_sel_cnt, c->d_flags, ncap, klds);
+                       c->d_node_of, c->d_sel, c->d_sel_cnt, c->d_flags, ncap, klds, d_ts);
+    if (d_ts) {   // debugging aid: blocks until the kernel is done and prints the phase times of block (0, 0)
+        unsigned long long ts[128];
+        (void)hipStreamSynchronize(c->stream);
+        (void)hipMemcpy(ts, d_ts, sizeof ts, hipMemcpyDeviceToHost);
+        (void)hipFree(d_ts);
+        fprintf(stderr, "[gfo] quadtree block (0,0), 10 ns ticks since start:");
+        for (int i = 0; i < 128 && ts[i]; i++) fprintf(stderr, " %llu:%llu", ts[i] & 255, (ts[i] >> 8) - (ts[0] >> 8));
+        fprintf(stderr, "\n");
+    }
     gfo_prof_end(c);
 }
