@@ -29,6 +29,19 @@ struct QtBox {
 // exclusive scan of vals[0..n) in place (LDS), returns the total; all threads call it.
 // Per-thread chunk sums are scanned inside each wave with lane shuffles; only the four wave totals
 // cross a workgroup barrier (3 barriers per scan).
+__device__ __forceinline__ int qt_wave_incl_scan(int v)
+{
+    // inclusive scan over the 64 lanes in the DPP network (row shifts, then the row_bcast:15 / row_bcast:31
+    // steps): six dependent VALU operations instead of six LDS round trips of a shuffle-based scan
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xF, 0xF, false);  // row_shr:1
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xF, 0xF, false);  // row_shr:2
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xF, 0xF, false);  // row_shr:4
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xF, 0xF, false);  // row_shr:8
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xA, 0xF, false);  // row_bcast:15 -> rows 1 and 3
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xC, 0xF, false);  // row_bcast:31 -> rows 2 and 3
+    return v;
+}
+
 __device__ int qt_scan(int* vals, int n, int* part)
 {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -36,12 +49,7 @@ __device__ int qt_scan(int* vals, int n, int* part)
     const int b = tid * chunk, e = min(b + chunk, n);
     int s = 0;
     for (int i = b; i < e; i++) s += vals[i];
-    int incl = s;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const int v = __shfl_up(incl, o);
-        if (lane >= o) incl += v;
-    }
+    const int incl = qt_wave_incl_scan(s);
     if (lane == 63) part[wave] = incl;
     __syncthreads();
     int wbase = 0, total = 0;
@@ -58,6 +66,35 @@ __device__ int qt_scan(int* vals, int n, int* part)
     }
     __syncthreads();
     return total;
+}
+
+// Two exclusive scans over the same index range in one pass: the values ride in the two halves of a word
+// (totals stay below 2^16: the caller checks 4 * ncap < 65536, otherwise it scans twice).
+__device__ int2 qt_scan2(int* a, int* b2, int n, int* part)
+{
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int chunk = (n + QT_THREADS - 1) / QT_THREADS;
+    const int b = tid * chunk, e = min(b + chunk, n);
+    unsigned s = 0;
+    for (int i = b; i < e; i++) s += (unsigned)a[i] | ((unsigned)b2[i] << 16);
+    const unsigned incl = (unsigned)qt_wave_incl_scan((int)s);
+    if (lane == 63) part[wave] = (int)incl;
+    __syncthreads();
+    unsigned wbase = 0, total = 0;
+    for (int w = 0; w < QT_THREADS / 64; w++) {
+        const unsigned t = (unsigned)part[w];
+        if (w < wave) wbase += t;
+        total += t;
+    }
+    unsigned run = wbase + incl - s;
+    for (int i = b; i < e; i++) {
+        const unsigned v = (unsigned)a[i] | ((unsigned)b2[i] << 16);
+        a[i] = (int)(run & 0xFFFFu);
+        b2[i] = (int)(run >> 16);
+        run += v;
+    }
+    __syncthreads();
+    return make_int2((int)(total & 0xFFFFu), (int)(total >> 16));
 }
 
 __device__ __forceinline__ int qt_quadrant(uint32_t key, QtBox b)
@@ -200,8 +237,15 @@ __global__ __launch_bounds__(QT_MAX_THREADS) void k_quadtree(const GfoGeom* __re
                 sc2[i] = cnt[i] > 1 ? 0 : 1;
             }
             __syncthreads();
-            const int ctot = qt_scan(sc1, n, part);
-            const int nsingle = qt_scan(sc2, n, part);
+            int ctot, nsingle;
+            if (4 * ncap < 65536) {
+                const int2 t2 = qt_scan2(sc1, sc2, n, part);
+                ctot = t2.x;
+                nsingle = t2.y;
+            } else {
+                ctot = qt_scan(sc1, n, part);
+                nsingle = qt_scan(sc2, n, part);
+            }
             QT_TS(5);
             if (ctot + nsingle > ncap) {
                 if (tid == 0) { atomicOr(&flags[0], 2); *out_cnt = 0; }
@@ -258,30 +302,32 @@ __global__ __launch_bounds__(QT_MAX_THREADS) void k_quadtree(const GfoGeom* __re
         // takes a fifth of the time of the 45 dependent compare-exchange rounds of a bitonic network (each round
         // is a full LDS round trip); large lists (1080p, 4000 features) keep the network.
         const int per_thread = (xlen + QT_THREADS - 1) / QT_THREADS;
-        if (xlen * per_thread <= 2048) {
-            unsigned long long* keyv = reinterpret_cast<unsigned long long*>(cpos);   // 4*ncap ints, free until the rebuild
-            for (int i = tid; i < xlen; i += QT_THREADS)
-                keyv[i] = cnt[i] > 1 ? ((unsigned long long)(unsigned)cnt[i] << 16) | (unsigned)(0xFFFF - i) : 0ull;
+        if (xlen * per_thread <= 2048 && K < 65536) {
+            // 32-bit keys (size << 16 | inverted position): sizes are bounded by the candidate count, and a level
+            // with 65536 or more candidates takes the 64-bit network below
+            // (cpos: 4*ncap ints, free until the rebuild; rounded up to a 16-byte boundary for the wide reads)
+            unsigned* keyv = reinterpret_cast<unsigned*>((reinterpret_cast<uintptr_t>(cpos) + 15) & ~(uintptr_t)15);
+            const int xlen8 = (xlen + 7) & ~7;   // entries [xlen, xlen8) are zero: never larger than a key
+            for (int i = tid; i < xlen8; i += QT_THREADS)
+                keyv[i] = i < xlen && cnt[i] > 1 ? ((unsigned)cnt[i] << 16) | (unsigned)(0xFFFF - i) : 0u;
             for (int i = tid; i < p2; i += QT_THREADS) srt[i] = 0;
             __syncthreads();
-            // two own keys per sweep; the sweep reads eight list entries at a time (independent broadcast loads in
+            // two own keys per sweep; the sweep reads eight list entries at a time (two 16-byte broadcast loads in
             // flight together -- one load per iteration would make every step a full LDS round trip)
-            const int xlen8 = (xlen + 7) & ~7;   // entries [xlen, xlen8) are zeroed below: never larger than a key
-            for (int i = xlen + tid; i < xlen8; i += QT_THREADS) keyv[i] = 0;
-            __syncthreads();
+            const uint4* kv4 = reinterpret_cast<const uint4*>(keyv);
             for (int i = tid; i < xlen; i += 2 * QT_THREADS) {
-                const unsigned long long m0 = keyv[i], m1 = i + QT_THREADS < xlen ? keyv[i + QT_THREADS] : 0ull;
+                const unsigned m0 = keyv[i], m1 = i + QT_THREADS < xlen ? keyv[i + QT_THREADS] : 0u;
                 int r0 = 0, r1 = 0;
-                for (int j = 0; j < xlen8; j += 8) {
-                    unsigned long long kj[8];
-#pragma unroll
-                    for (int u = 0; u < 8; u++) kj[u] = keyv[j + u];
+                for (int j = 0; j < xlen8 / 4; j += 2) {
+                    const uint4 a = kv4[j], b = kv4[j + 1];
+                    const unsigned kj[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
 #pragma unroll
                     for (int u = 0; u < 8; u++) {
                         r0 += kj[u] > m0 ? 1 : 0;
                         r1 += kj[u] > m1 ? 1 : 0;
                     }
                 }
+                // the consumers read 64-bit entries: size << 16 | inverted position, same layout
                 if (m0) srt[r0] = m0;
                 if (m1) srt[r1] = m1;
             }
@@ -319,8 +365,12 @@ __global__ __launch_bounds__(QT_MAX_THREADS) void k_quadtree(const GfoGeom* __re
             sc2[i] = key ? nch - 1 : 0;   // growth of the list
         }
         __syncthreads();
-        qt_scan(sc1, xlen, part);
-        qt_scan(sc2, xlen, part);  // exclusive: growth before split t
+        if (4 * ncap < 65536) {
+            qt_scan2(sc1, sc2, xlen, part);
+        } else {
+            qt_scan(sc1, xlen, part);
+            qt_scan(sc2, xlen, part);  // exclusive: growth before split t
+        }
         if (tid == 0) s_cut = xlen, s_misc = 0;
         __syncthreads();
         // first t whose split brings the list to >= N (:730); splits t = 0..cut inclusive happen
