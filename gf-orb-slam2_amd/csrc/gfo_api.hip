@@ -519,9 +519,11 @@ static int run_pyramid(gfo_ctx* c, const GfoInput& in, int nimg)
     // big levels: one launch each (they fill the chip); the small top levels: one fused launch, one workgroup
     // per image (each of them alone is latency-bound)
     static const int tail_px = getenv("GFO_RESIZE_TAIL_PX") ? atoi(getenv("GFO_RESIZE_TAIL_PX")) : 60000;  // measured: fusing levels of <= 60k px wins, larger ones lose
-    // a batch that fills the chip with band workgroups: the whole pyramid in one launch, every level through LDS
-    const char* bm = getenv("GFO_PYR_BAND_MIN_WG");   // tests force either path
-    const int band_min_wg = bm ? atoi(bm) : 256;
+    // the banded form whenever it is planned: one launch per level group beats seven dependent launches even for a
+    // single stereo pair (38 vs 47 us), and for large batches it also halves the HBM traffic.  GFO_PYR_BAND_MIN_WG
+    // (workgroups a launch must have) lets the tests force the per-level path.
+    const char* bm = getenv("GFO_PYR_BAND_MIN_WG");
+    const int band_min_wg = bm ? atoi(bm) : 0;
     if (c->g.pyr_nb > 0 && nimg * c->g.pyr_nb >= band_min_wg) {
         gfo_launch_pyramid_bands(c, in, nimg);
         c->last_in = in;

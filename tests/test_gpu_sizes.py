@@ -162,3 +162,26 @@ def test_banded_pyramid_equals_oracle(oracle, monkeypatch, w, h, sf, nl, lds_kb,
         np.testing.assert_array_equal(ext.pyramid_level(l), oe.level(l), err_msg=f"level {l}")
     _same(ext, oe, img)
     ext.close()
+
+
+@pytest.mark.parametrize("w,h,nimg", [(752, 480, 1), (333, 217, 1), (752, 480, 34), (640, 480, 33)])
+def test_per_level_pyramid_path(oracle, monkeypatch, w, h, nimg):
+    """The fallback the banded pyramid replaces (one launch per level, the small top levels fused into one
+    workgroup per image for batches of 32 and more) stays bit-exact: forced by asking for more band workgroups
+    than any launch has."""
+    import gf_orb_slam2_amd as G
+    monkeypatch.setenv("GFO_PYR_BAND_MIN_WG", "100000000")
+    imgs = [synth_frame(w, h, 7 * w + i) for i in range(min(nimg, 3))]
+    batch = [imgs[i % len(imgs)] for i in range(nimg)]
+    ext = G.ORBextractor(900, 1.2, 8, 20, 7, max_batch=nimg)
+    oe = oracle.OracleExtractor(900, 1.2, 8, 20, 7)
+    kps, descs = ext.extract_batch(batch)
+    ref = [oe(im) for im in imgs]
+    for i in range(nimg):
+        ok, od = ref[i % len(imgs)]
+        assert kps[i].tobytes() == ok.tobytes() and (descs[i] == od).all()
+    ext.ComputePyramid(imgs[0])
+    oe.compute_pyramid(imgs[0])
+    for l in range(8):
+        np.testing.assert_array_equal(ext.pyramid_level(l), oe.level(l))
+    ext.close()
