@@ -50,7 +50,37 @@ struct StereoArgs {
     int window;               // W
 };
 
-__global__ __launch_bounds__(256) void k_stereo_bucket(StereoArgs a)
+// inclusive scan over the 64 lanes in the DPP network (see k_quadtree.hip)
+__device__ __forceinline__ int st_wave_incl_scan(int v)
+{
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xF, 0xF, false);  // row_shr:1
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xF, 0xF, false);  // row_shr:2
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xF, 0xF, false);  // row_shr:4
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xF, 0xF, false);  // row_shr:8
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xA, 0xF, false);  // row_bcast:15
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xC, 0xF, false);  // row_bcast:31
+    return v;
+}
+
+// inclusive scan of one value per thread over the workgroup (s_part: one int per wave); two barriers
+__device__ __forceinline__ int st_block_incl_scan(int v, int* s_part, int* total)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    const int incl = st_wave_incl_scan(v);
+    if (lane == 63) s_part[wave] = incl;
+    __syncthreads();
+    int base = 0, tot = 0;
+    for (int w = 0; w < nw; w++) {
+        const int t = s_part[w];
+        if (w < wave) base += t;
+        tot += t;
+    }
+    __syncthreads();
+    *total = tot;
+    return base + incl;
+}
+
+__global__ __launch_bounds__(1024) void k_stereo_bucket(StereoArgs a)
 {
     extern __shared__ int s_hist[];  // n_rows + 256
     const int pair = blockIdx.x, tid = threadIdx.x;
@@ -59,27 +89,22 @@ __global__ __launch_bounds__(256) void k_stereo_bucket(StereoArgs a)
     const int nr = a.cnt_dev ? a.cnt_dev[2 * pair + 1] : a.nr_host;
     const gfo_keypoint* kr = a.kr + pair * a.pair_stride;
     const uint4* dr = reinterpret_cast<const uint4*>(a.dr + pair * a.pair_stride * 32);
-    for (int r = tid; r < nRows; r += 256) s_hist[r] = 0;
+    const int NT = blockDim.x;   // 1024: the count / scatter loops are chains of dependent global loads, so more
+                                 // threads means fewer serial round trips (8 -> 2 for 2000 keypoints)
+    for (int r = tid; r < nRows; r += NT) s_hist[r] = 0;
     __syncthreads();
-    for (int i = tid; i < nr; i += 256) {
+    for (int i = tid; i < nr; i += NT) {
         const int b = min(max((int)floorf(kr[i].y), 0), nRows - 1);
         atomicAdd(&s_hist[b], 1);
     }
     __syncthreads();
     // exclusive scan over nRows entries
-    const int chunk = (nRows + 255) / 256;
-    const int b0 = tid * chunk, e0 = min(b0 + chunk, nRows);
+    const int chunk = (nRows + NT - 1) / NT;
+    const int b0 = min(tid * chunk, nRows), e0 = min(b0 + chunk, nRows);
     int s = 0;
     for (int r = b0; r < e0; r++) s += s_hist[r];
-    s_part[tid] = s;
-    __syncthreads();
-    for (int off = 1; off < 256; off <<= 1) {
-        const int v = tid >= off ? s_part[tid - off] : 0;
-        __syncthreads();
-        s_part[tid] += v;
-        __syncthreads();
-    }
-    int run = s_part[tid] - s;
+    int total;
+    int run = st_block_incl_scan(s, s_part, &total) - s;
     int* rs = a.row_start + (long long)pair * (nRows + 1);
     for (int r = b0; r < e0; r++) {
         const int v = s_hist[r];
@@ -87,10 +112,10 @@ __global__ __launch_bounds__(256) void k_stereo_bucket(StereoArgs a)
         s_hist[r] = run;  // fill cursor
         run += v;
     }
-    if (tid == 255) rs[nRows] = s_part[255];
+    if (tid == 0) rs[nRows] = total;
     __syncthreads();
     const long long so = (long long)pair * a.sort_stride;
-    for (int i = tid; i < nr; i += 256) {
+    for (int i = tid; i < nr; i += NT) {
         const gfo_keypoint k = kr[i];
         const int b = min(max((int)floorf(k.y), 0), nRows - 1);
         const int pos = atomicAdd(&s_hist[b], 1);
@@ -190,46 +215,40 @@ __global__ __launch_bounds__(256) void k_stereo_match(StereoArgs a)
     }
 }
 
-__global__ __launch_bounds__(256) void k_stereo_cut(const int* __restrict__ cnt_dev, int nl_host, GfoStereoDev out,
-                                                    int out_stride)
+__global__ __launch_bounds__(1024) void k_stereo_cut(const int* __restrict__ cnt_dev, int nl_host, GfoStereoDev out,
+                                                     int out_stride)
 {
     __shared__ int hist[128];
+    __shared__ int s_part[16];
     __shared__ int s_med, s_drop, s_cnt;
-    const int pair = blockIdx.x, tid = threadIdx.x;
+    const int pair = blockIdx.x, tid = threadIdx.x, NT = blockDim.x;
     const int nl = cnt_dev ? cnt_dev[2 * pair] : nl_host;
     const long long o = (long long)pair * out_stride;
     if (tid < 128) hist[tid] = 0;
-    if (tid == 0) s_drop = 0, s_cnt = 0;
+    if (tid == 0) s_drop = 0, s_cnt = 0, s_med = 1 << 30;
     __syncthreads();
     int mine = 0;
-    for (int i = tid; i < nl; i += 256) {
+    for (int i = tid; i < nl; i += NT) {
         const int d = out.best_dist[o + i];
         if (d >= 0) atomicAdd(&hist[d], 1);
         mine += out.counted[o + i];
     }
     if (mine) atomicAdd(&s_cnt, mine);
     __syncthreads();
-    if (tid == 0) {
-        int ndi = 0;
-        for (int d = 0; d < 128; d++) ndi += hist[d];
-        int med = -1;
-        if (ndi > 0) {
-            int acc = 0;
-            for (int d = 0; d < 128; d++) {
-                acc += hist[d];
-                if (acc > ndi / 2) { med = d; break; }  // element of rank ndi/2 in the sorted list (:1297)
-            }
-        }
-        s_med = med;
-    }
+    // median = the distance whose running count first exceeds ndi / 2 (the element of rank ndi/2 in the sorted
+    // list, :1297): a workgroup scan over the 128 bins instead of one thread walking them
+    int ndi;
+    const int h = tid < 128 ? hist[tid] : 0;
+    const int incl = st_block_incl_scan(h, s_part, &ndi);
+    if (tid < 128 && ndi > 0 && incl > ndi / 2) atomicMin(&s_med, tid);
     __syncthreads();
-    if (s_med < 0) {
+    if (ndi == 0) {
         if (tid == 0) out.nmatched[pair] = s_cnt;
         return;
     }
     const float thDist = 1.5f * 1.4f * (float)s_med;  // :1298
     int drop = 0;
-    for (int i = tid; i < nl; i += 256) {
+    for (int i = tid; i < nl; i += NT) {
         const int d = out.best_dist[o + i];
         if (d >= 0 && !((float)d < thDist)) {
             out.u_right[o + i] = -1.0f;
@@ -451,7 +470,7 @@ void gfo_launch_stereo_sad(gfo_ctx* c, const GfoStereoLaunch& s, const GfoInput&
     A.pyr = c->d_pyr;
     A.inv_scale = d_inv_scale;
     gfo_prof_begin(c, ST_STEREO_BUCKET);
-    hipLaunchKernelGGL(k_stereo_bucket, dim3(s.npairs), dim3(256), (size_t)(s.p.n_rows + 256) * sizeof(int), c->stream, a);
+    hipLaunchKernelGGL(k_stereo_bucket, dim3(s.npairs), dim3(1024), (size_t)(s.p.n_rows + 256) * sizeof(int), c->stream, a);
     gfo_prof_end(c);
     gfo_prof_begin(c, ST_STEREO);
     hipLaunchKernelGGL(k_stereo_match_sad, dim3((s.out_stride + 3) / 4, s.npairs), dim3(256), 0, c->stream, A);
@@ -488,13 +507,13 @@ void gfo_launch_stereo(gfo_ctx* c, const GfoStereoLaunch& s)
         return;
     }
     gfo_prof_begin(c, ST_STEREO_BUCKET);
-    hipLaunchKernelGGL(k_stereo_bucket, dim3(s.npairs), dim3(256), (size_t)(s.p.n_rows + 256) * sizeof(int), c->stream, a);
+    hipLaunchKernelGGL(k_stereo_bucket, dim3(s.npairs), dim3(1024), (size_t)(s.p.n_rows + 256) * sizeof(int), c->stream, a);
     gfo_prof_end(c);
     dim3 grid((max_nl + 7) / 8, s.npairs);  // 4 waves x 2 left keypoints per workgroup
     gfo_prof_begin(c, ST_STEREO);
     hipLaunchKernelGGL(k_stereo_match, grid, dim3(256), 0, c->stream, a);
     gfo_prof_end(c);
     gfo_prof_begin(c, ST_STEREO_CUT);
-    hipLaunchKernelGGL(k_stereo_cut, dim3(s.npairs), dim3(256), 0, c->stream, s.cnt_dev, s.nl_host, s.out, s.out_stride);
+    hipLaunchKernelGGL(k_stereo_cut, dim3(s.npairs), dim3(1024), 0, c->stream, s.cnt_dev, s.nl_host, s.out, s.out_stride);
     gfo_prof_end(c);
 }
