@@ -7,7 +7,7 @@
 // COMPACTION between the stages, so the expensive stages run with all 64 lanes busy:
 //   A  every pixel      : compass test -- a 9-arc of the 16-ring holds a pixel of every opposite pair, so
 //                         (ring 0 or 8) and (ring 4 or 12) must both be beyond the threshold (5 LDS reads)
-//   B1 survivors of A   : the exact 9-contiguous-of-16 test at min(iniTh, minTh) on bit masks of the ring
+//   B1 survivors of A   : the exact 9-contiguous-of-16 test at the round's threshold on bit masks of the ring
 //   B2 survivors of B1  : the score S = max over the sixteen 9-arcs of min |v - ring| (common sign)
 //   N  survivors of B1  : strict 3x3 local maximum of S inside the cell's scan area
 //   E  maxima           : append (x, y, S-1) for S > iniThFAST, or S > minThFAST when the cell
@@ -16,6 +16,7 @@
 // Fast_gpu.cu:196-219), and a neighbour can suppress a corner only if its S is >= the corner's,
 // so "compare against the score buffer of corners at threshold t" (FAST_NEON.cc:268-285) is
 // "strict local maximum of S" -- one suppression pass serves both thresholds (FAST).
+// Queue entries are 16 bit: px | py << 6, polarity in bits 13-14, the local-maximum flag in bit 15.
 // Four cells per 256-thread workgroup; all levels of all images are ONE launch.
 //
 // Candidates are appended to the level's list with one atomicAdd per cell; their order in
