@@ -7,16 +7,16 @@
 // COMPACTION between the stages, so the expensive stages run with all 64 lanes busy:
 //   A  every pixel      : compass test -- a 9-arc of the 16-ring holds a pixel of every opposite pair, so
 //                         (ring 0 or 8) and (ring 4 or 12) must both be beyond the threshold (5 LDS reads)
-//   B1 survivors of A   : the exact 9-contiguous-of-16 test at the round's threshold on bit masks of the ring
-//   B2 survivors of B1  : the score S = max over the sixteen 9-arcs of min |v - ring| (common sign)
-//   N  survivors of B1  : strict 3x3 local maximum of S inside the cell's scan area
+//   B  survivors of A   : the score S = max over the sixteen 9-arcs of min |v - ring| (common sign); a pixel
+//                         is a corner at threshold t iff S > t, so the exact test costs nothing extra
+//   N  corners          : strict 3x3 local maximum of S inside the cell's scan area
 //   E  maxima           : append (x, y, S-1) for S > iniThFAST, or S > minThFAST when the cell
 //                         produced nothing at iniThFAST (ORBextractor.cc:811-818)
 // S does not depend on the threshold (corner(t) <=> S > t, cornerScore = S - 1: FAST_NEON.cc:231,
 // Fast_gpu.cu:196-219), and a neighbour can suppress a corner only if its S is >= the corner's,
 // so "compare against the score buffer of corners at threshold t" (FAST_NEON.cc:268-285) is
 // "strict local maximum of S" -- one suppression pass serves both thresholds (FAST).
-// Queue entries are 16 bit: px | py << 6, polarity in bits 13-14, the local-maximum flag in bit 15.
+// Queue entries are 16 bit: px | py << 6, the local-maximum flag in bit 15.
 // Four cells per 256-thread workgroup; all levels of all images are ONE launch.
 //
 // Candidates are appended to the level's list with one atomicAdd per cell; their order in
@@ -36,41 +36,6 @@ __device__ __forceinline__ void wave_sync()
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-// Exact FAST-9 test at threshold tq: bit k of the dark (bright) mask says ring pixel k is darker
-// (brighter) than the centre by more than tq; a corner needs 9 contiguous set bits on the circular
-// 16-bit mask (FAST_NEON.cc:226-259 mirror: the count > K run test).  Returns bit0 = dark arc exists,
-// bit1 = bright arc exists.
-__device__ __forceinline__ bool has_arc9(unsigned m16)
-{
-    unsigned w = m16 | (m16 << 16);
-    unsigned r = w & (w >> 1);
-    r &= r >> 2;
-    r &= r >> 4;
-    r &= w >> 8;
-    return (r & 0xFFFFu) != 0;
-}
-
-// One ring pixel into the two masks: the compare sets VCC and v_addc_co_u32 shifts the mask left while adding
-// the carry -- two VALU operations per pixel and polarity (the C form costs three: compare, select, or).
-#define GFO_RING_BIT(mask, r, bound, CMP) asm("v_cmp_" CMP "_i32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(mask) : "v"(r), "v"(bound) : "vcc")
-
-template <int TP>
-__device__ __forceinline__ int corner_test(const uint8_t* __restrict__ c, int tq)
-{
-    // ring in the order of FAST_NEON.cc:3-7, visited from position 15 down so that position k lands in bit k
-    const int v = c[0];
-    const int lo = v - tq, hi = v + tq;   // darker: r < v - tq ; brighter: r > v + tq
-    const int r[16] = {c[3 * TP], c[3 * TP + 1], c[2 * TP + 2], c[TP + 3], c[3], c[-TP + 3], c[-2 * TP + 2], c[-3 * TP + 1],
-                       c[-3 * TP], c[-3 * TP - 1], c[-2 * TP - 2], c[-TP - 3], c[-3], c[TP - 3], c[2 * TP - 2], c[3 * TP - 1]};
-    unsigned md = 0, mb = 0;
-#pragma unroll
-    for (int k = 15; k >= 0; k--) {
-        GFO_RING_BIT(md, r[k], lo, "lt");
-        GFO_RING_BIT(mb, r[k], hi, "gt");
-    }
-    return (has_arc9(md) ? 1 : 0) | (has_arc9(mb) ? 2 : 0);
-}
-
 typedef short __attribute__((ext_vector_type(2))) s16x2;
 __device__ __forceinline__ unsigned pmin(unsigned a, unsigned b)
 {
@@ -82,40 +47,65 @@ __device__ __forceinline__ unsigned pmax(unsigned a, unsigned b)
 }
 __device__ __forceinline__ unsigned rot16(unsigned a) { return __builtin_amdgcn_alignbit(a, a, 16); }
 
-// max over the sixteen 9-arcs of min(sign * d) for one polarity (sign = +1 dark, -1 bright), two ring
-// positions (k, k+8) per register in packed i16: the arc minima for k and k+8 come out of one op.
-// The differences are formed packed as well: (r[k], r[k+8]) is one v_lshl_or, centre minus ring one v_pk_sub,
-// and the polarity one v_pk_mul by (+-1, +-1).
+// Score of a pixel = max over the sixteen 9-arcs of min(sign * d) (sign = +1 dark, -1 bright), computed with two
+// ring positions (k, k+8) per register in packed i16: the arc minima for k and k+8 come out of one op.  The
+// differences are formed packed as well: (r[k], r[k+8]) is one v_lshl_or, centre minus ring one v_pk_sub, and
+// the polarity one v_pk_mul by (+-1, +-1).
+// Survivors of the compass test: score directly.  corner(t) <=> S > t, so the exact 9-contiguous test and the
+// score are one computation (the packed arc minima); the polarity to score comes from the compass pixels
+// themselves -- a 9-arc holds a pixel of each opposite pair, so a dark arc needs (d0 or d8) and (d4 or d12)
+// above t, a bright arc the mirror image.  Both can hold for one pixel (rarely); then both are scored.
 template <int TP>
-__device__ __forceinline__ int arc_score(const uint8_t* __restrict__ c, bool bright)
+__device__ __forceinline__ int corner_score(const uint8_t* __restrict__ c, int tq)
 {
     const unsigned v = c[0];
     const unsigned r[16] = {c[3 * TP], c[3 * TP + 1], c[2 * TP + 2], c[TP + 3], c[3], c[-TP + 3], c[-2 * TP + 2], c[-3 * TP + 1],
                             c[-3 * TP], c[-3 * TP - 1], c[-2 * TP - 2], c[-TP - 3], c[-3], c[TP - 3], c[2 * TP - 2], c[3 * TP - 1]};
     const s16x2 v2 = __builtin_bit_cast(s16x2, v | (v << 16));
-    const s16x2 sg = __builtin_bit_cast(s16x2, bright ? 0xFFFFFFFFu : 0x00010001u);
-    unsigned P[8], R[8];
+    s16x2 D[8];
 #pragma unroll
-    for (int k = 0; k < 8; k++) {
-        const s16x2 d = v2 - __builtin_bit_cast(s16x2, r[k] | (r[k + 8] << 16));
-        P[k] = __builtin_bit_cast(unsigned, d * sg);   // packed (d[k], d[k+8]), negated for the bright polarity
-        R[k] = rot16(P[k]);  // = packed (d[k+8], d[k]) : ring positions k+8 .. k+15
+    for (int k = 0; k < 8; k++) D[k] = v2 - __builtin_bit_cast(s16x2, r[k] | (r[k + 8] << 16));   // (d[k], d[k+8])
+    // compass: per opposite pair the larger / smaller difference, both halves of a register at once
+    const s16x2 hi08 = __builtin_elementwise_max(D[0], __builtin_bit_cast(s16x2, rot16(__builtin_bit_cast(unsigned, D[0]))));
+    const s16x2 hi4c = __builtin_elementwise_max(D[4], __builtin_bit_cast(s16x2, rot16(__builtin_bit_cast(unsigned, D[4]))));
+    const s16x2 lo08 = __builtin_elementwise_min(D[0], __builtin_bit_cast(s16x2, rot16(__builtin_bit_cast(unsigned, D[0]))));
+    const s16x2 lo4c = __builtin_elementwise_min(D[4], __builtin_bit_cast(s16x2, rot16(__builtin_bit_cast(unsigned, D[4]))));
+    const int s_hi = (int)(short)(__builtin_bit_cast(unsigned, __builtin_elementwise_min(hi08, hi4c)) & 0xFFFF);
+    const int s_lo = (int)(short)(__builtin_bit_cast(unsigned, __builtin_elementwise_max(lo08, lo4c)) & 0xFFFF);
+    const bool dark = s_hi > tq, bright = s_lo < -tq;
+    int best = 0;
+#pragma unroll 1
+    for (int pass = 0; pass < 2; pass++) {
+        // pass 0: the dark polarity where it is possible, else the bright one; pass 1: bright for the pixels
+        // that allow both (skipped by the whole wave when no lane has one)
+        const bool run = pass == 0 ? (dark || bright) : (dark && bright);
+        if (__ballot(run) == 0) break;
+        const bool neg = pass == 0 ? !dark : true;
+        const s16x2 sg = __builtin_bit_cast(s16x2, neg ? 0xFFFFFFFFu : 0x00010001u);
+        unsigned P[8], R[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            P[k] = __builtin_bit_cast(unsigned, D[k] * sg);
+            R[k] = rot16(P[k]);
+        }
+        unsigned X2[10], X4[12];
+#pragma unroll
+        for (int k = 0; k < 7; k++) X2[k] = pmin(P[k], P[k + 1]);
+        X2[7] = pmin(P[7], R[0]);
+        X2[8] = rot16(X2[0]);
+        X2[9] = rot16(X2[1]);
+#pragma unroll
+        for (int k = 0; k < 8; k++) X4[k] = pmin(X2[k], X2[k + 2]);
+#pragma unroll
+        for (int k = 0; k < 4; k++) X4[8 + k] = rot16(X4[k]);
+        unsigned bst = 0x80008000u;  // (-32768, -32768)
+#pragma unroll
+        for (int k = 0; k < 8; k++) bst = pmax(bst, pmin(pmin(X4[k], X4[k + 4]), R[k]));
+        const int b0 = (int)(short)(bst & 0xFFFF), b1 = (int)(short)(bst >> 16);
+        const int sc = max(b0, b1);
+        if (run) best = max(best, sc);
     }
-    unsigned X2[10], X4[12];
-#pragma unroll
-    for (int k = 0; k < 7; k++) X2[k] = pmin(P[k], P[k + 1]);
-    X2[7] = pmin(P[7], R[0]);
-    X2[8] = rot16(X2[0]);
-    X2[9] = rot16(X2[1]);
-#pragma unroll
-    for (int k = 0; k < 8; k++) X4[k] = pmin(X2[k], X2[k + 2]);
-#pragma unroll
-    for (int k = 0; k < 4; k++) X4[8 + k] = rot16(X4[k]);
-    unsigned best = 0x80008000u;  // (-32768, -32768)
-#pragma unroll
-    for (int k = 0; k < 8; k++) best = pmax(best, pmin(pmin(X4[k], X4[k + 4]), R[k]));
-    const int b0 = (int)(short)(best & 0xFFFF), b1 = (int)(short)(best >> 16);
-    return max(b0, b1);
+    return best;
 }
 
 // TP / SP: pitch of the pixel tile and of the score map in LDS, compile-time so that every ring and neighbour
@@ -269,39 +259,26 @@ __global__ __launch_bounds__(256) void k_fast(const GfoGeom* __restrict__ gp, Gf
     }
     wave_sync();
     if (dbg_stop == 2) { if (na == 12345) flags[1] = 1; return; }
-    // ---- B1: exact 9-arc test at this round's threshold on the survivors, compacted into qb ----
+    // ---- B: score S of the survivors (corner <=> S > threshold), written to the cell's score map; the corners
+    //         are compacted into qb ----
     nb = 0;
     {
         for (int i0 = 0; i0 < na; i0 += 64) {
             const int i = i0 + lane;
-            int pol = 0;
-            int p = 0;
-            if (i < na) {
-                p = qa[i];
-                pol = corner_test<TP>(t0 + (p >> 6) * TP + (p & 63), tq);
-            }
-            const unsigned long long m = __ballot(pol != 0);
+            int p = 0, sc = 0;
+            if (i < na) p = qa[i];
+            const int py = p >> 6, px = p & 63;
+            sc = corner_score<TP>(t0 + py * TP + px, tq);   // every lane (idle ones re-score entry 0's pixel: wave votes inside)
+            const bool corner = i < na && sc > tq;
+            if (corner) smap[(py + 1) * SP + px + 1] = (uint8_t)sc;
+            const unsigned long long m = __ballot(corner);
             if (__builtin_amdgcn_inverse_ballot_w64(m))
-                qb[__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, (unsigned)nb))] = (unsigned short)(p | (pol << 13));  // bits 13,14 = polarity
+                qb[__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, (unsigned)nb))] = (unsigned short)p;
             nb += __popcll(m);
         }
     }
     wave_sync();
     if (dbg_stop == 3) { if (nb == 12345) flags[1] = 1; return; }
-    // ---- B2: score of the survivors into the cell's score map ----
-    {
-        for (int i = lane; i < nb; i += 64) {
-            const int e = qb[i];
-            const int p = e & 0x1FFF;
-            const int py = p >> 6, px = p & 63;
-            const uint8_t* c = t0 + py * TP + px;
-            // a dark and a bright 9-arc cannot coexist on a 16-pixel ring, so the polarity B1 found is the only one
-            // whose arc minima can exceed the threshold: S comes from that polarity alone
-            const int s = arc_score<TP>(c, (e & 0x2000) == 0);
-            smap[(py + 1) * SP + px + 1] = (uint8_t)(s > tq ? s : 0);
-        }
-    }
-    wave_sync();
     if (dbg_stop == 4 && round == 1) return;
     if (dbg_stop == 9) { if (lane == 0) { atomicAdd(&flags[1], sw * sh); atomicAdd(&flags[2], na); atomicAdd(&flags[3], nb); } }
     // ---- N: strict local maxima of S (flag kept in bit 15 of the queue entry) ----
