@@ -185,10 +185,9 @@ __global__ __launch_bounds__(256) void k_fast(const GfoGeom* __restrict__ gp, Gf
     // The cascade runs at iniThFAST first; only a cell that yields no maximum there repeats it at
     // minThFAST (ORBextractor.cc:811-818).  Scores left in the map by the first round are true S values,
     // so the second round needs no re-initialisation (a stored S <= threshold never suppresses a corner).
-    int th = g.ini_th, total = 0, nb = 0;
+    int total = 0, nb = 0;
     for (int round = 0; round < 2; round++) {
     const int tq = round == 0 ? g.ini_th : g.min_th;
-    th = tq;
     // ---- A: compass test over every scan pixel, compacted into qa ----
     // A lane takes one aligned dword (4 pixels) of a tile row: centre, the rows 3 above/below and the
     // dwords left/right come in as five LDS dword reads, and the "second largest / second smallest of the
@@ -281,27 +280,37 @@ __global__ __launch_bounds__(256) void k_fast(const GfoGeom* __restrict__ gp, Gf
     if (dbg_stop == 3) { if (nb == 12345) flags[1] = 1; return; }
     if (dbg_stop == 4 && round == 1) return;
     if (dbg_stop == 9) { if (lane == 0) { atomicAdd(&flags[1], sw * sh); atomicAdd(&flags[2], na); atomicAdd(&flags[3], nb); } }
-    // ---- N: strict local maxima of S (flag kept in bit 15 of the queue entry) ----
+    // ---- N: strict local maxima of S among the corners; their keys (x, y, S-1) are compacted into the tile's
+    //         LDS (the pixels are no longer needed once a maximum exists: a cell with none leaves the tile
+    //         untouched for the second round) ----
     int n_max = 0;
+    uint32_t* keyq = reinterpret_cast<uint32_t*>(tile);
     for (int i0 = 0; i0 < nb; i0 += 64) {
         const int i = i0 + lane;
         bool mx = false;
+        uint32_t key = 0;
         if (i < nb) {
-            const int p = qb[i] & 0x1FFF;
+            const int p = qb[i];
             const int py = p >> 6, px = p & 63;
             const uint8_t* q = smap + (py + 1) * SP + px + 1;
             const int s = q[0];
-            mx = s >= 2 && s > tq && s > q[-1] && s > q[1] && s > q[-SP - 1] && s > q[-SP] && s > q[-SP + 1] &&
-                 s > q[SP - 1] && s > q[SP] && s > q[SP + 1];
-            if (mx) qb[i] = (unsigned short)(p | 0x8000);  // bit 15 = local maximum above the threshold
+            const int nmax = max(max(max(max((int)q[-1], (int)q[1]), max((int)q[-SP - 1], (int)q[-SP])),
+                                     max(max((int)q[-SP + 1], (int)q[SP - 1]), max((int)q[SP], (int)q[SP + 1]))), tq);
+            mx = s > nmax;   // strictly above the eight neighbours and above the threshold (S >= 2 follows: tq >= 1)
+            const int x = px + 3 + cj * wcell, y = py + 3 + ci * hcell;  // ORBextractor.cc:824-825
+            key = (uint32_t)x | ((uint32_t)y << 12) | ((uint32_t)(s - 1) << 24);
         }
-        n_max += __popcll(__ballot(mx));
+        const unsigned long long m = __ballot(mx);
+        if (__builtin_amdgcn_inverse_ballot_w64(m))
+            keyq[__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, (unsigned)n_max))] = key;
+        n_max += __popcll(m);
     }
     wave_sync();
     total = n_max;
     if (total > 0) break;
     }  // round
     if (total == 0) return;
+    // ---- E: one atomicAdd reserves the cell's slots in the level's candidate list, then a straight copy ----
     int base = 0;
     int* cnt = cand_cnt + (img * g.nlevels + level) * GFO_CNT_STRIDE;
     if (lane == 0) base = atomicAdd(cnt, total);
@@ -311,28 +320,8 @@ __global__ __launch_bounds__(256) void k_fast(const GfoGeom* __restrict__ gp, Gf
         return;
     }
     uint32_t* out = cand + (long long)img * g.cand_img_stride + L.cand_off + base;
-    int run = 0;
-    for (int i0 = 0; i0 < nb; i0 += 64) {
-        const int i = i0 + lane;
-        bool emit = false;
-        uint32_t key = 0;
-        if (i < nb) {
-            const int e = qb[i];
-            if (e & 0x8000) {
-                const int p = e & 0x1FFF;
-                const int py = p >> 6, px = p & 63;
-                const int s = smap[(py + 1) * SP + px + 1];
-                if (s > th) {
-                    emit = true;
-                    const int x = px + 3 + cj * wcell, y = py + 3 + ci * hcell;  // ORBextractor.cc:824-825
-                    key = (uint32_t)x | ((uint32_t)y << 12) | ((uint32_t)(s - 1) << 24);
-                }
-            }
-        }
-        const unsigned long long m = __ballot(emit);
-        if (__builtin_amdgcn_inverse_ballot_w64(m)) out[__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, (unsigned)run))] = key;
-        run += __popcll(m);
-    }
+    const uint32_t* keyq = reinterpret_cast<const uint32_t*>(tile);
+    for (int i = lane; i < total; i += 64) out[i] = keyq[i];
 }
 
 void gfo_launch_fast(gfo_ctx* c, const GfoInput& in, int nimg)
