@@ -118,11 +118,16 @@ __global__ __launch_bounds__(256) void k_orient_desc(const GfoGeom* __restrict__
         }
         uint4* pl = reinterpret_cast<uint4*>(pat + rw * OWP + 16 * seg);
         uint4* wl = reinterpret_cast<uint4*>(win + rw * DWP + 16 * seg);
+        // steps 0-2 store unconditionally: every row they touch exists, and the two idle lanes (rw == 10) hold
+        // exactly the bytes that lane rw == 0 of the next step writes to the same place; only the last step is
+        // predicated (rows 30 / 30..36)
 #pragma unroll
-        for (int k = 0; k < OD_STEPS; k++) {
-            if (ld_on && 10 * k + rw < OW) pl[k * (10 * OWP / 16)] = vp[k];
-            if (ld_on && 10 * k + rw < DW) wl[k * (10 * DWP / 16)] = vw[k];
+        for (int k = 0; k < OD_STEPS - 1; k++) {
+            pl[k * (10 * OWP / 16)] = vp[k];
+            wl[k * (10 * DWP / 16)] = vw[k];
         }
+        if (ld_on && 10 * (OD_STEPS - 1) + rw < OW) pl[(OD_STEPS - 1) * (10 * OWP / 16)] = vp[OD_STEPS - 1];
+        if (ld_on && 10 * (OD_STEPS - 1) + rw < DW) wl[(OD_STEPS - 1) * (10 * DWP / 16)] = vw[OD_STEPS - 1];
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
