@@ -151,29 +151,38 @@ __global__ __launch_bounds__(256) void k_fast(const GfoGeom* __restrict__ gp, Gf
         // 16-byte row segments: TP is a multiple of 16, every lane issues its (<= 4) wide loads before the
         // first LDS store; the segment right of the cell may run a few bytes past maxX but stays inside the
         // image row (maxX <= w - 16)
-        const int spr = (xoff + cw + 15) >> 4;  // 16-byte segments per tile row
-        const float inv_spr = 1.0f / (float)spr;
-        uint4* t128 = reinterpret_cast<uint4*>(tile);
-        const int tp16 = TP >> 4;
-        const int nseg = spr * ch;
-        for (int b = 0; b < nseg; b += 64 * 4) {
-            uint4 v[4];
-            int dst[4];
+        const int spr = (xoff + cw + 15) >> 4;  // 16-byte segments per tile row (3 for a 30-px cell, at most 6)
+        // fixed lane -> (row of the step, segment) map: 64 / spr rows per step, so a load is a pointer increment
+        // (two steps for a 30-px cell); all loads of a lane are issued before its first LDS store
+        const int rps = 64 / spr;
+        const int lr = (int)(((float)lane + 0.5f) * (1.0f / (float)spr));
+        const int lc = lane - lr * spr;
+        const bool ld_on = lr < rps;
+        const uint8_t* lp = src + (long long)min(lr, ch - 1) * pitch + 16 * lc;
+        uint4* t128 = reinterpret_cast<uint4*>(tile) + lr * (TP >> 4) + lc;
+        const long long gstep = (long long)rps * pitch;
+        const int lstep = rps * (TP >> 4);
+        // rows past the cell's last one are clamped to it (loaded, not stored)
+        const uint8_t* p_last = lp + (long long)(ch - 1 - min(lr, ch - 1)) * pitch;
+        if (2 * rps >= ch) {   // the usual cell: two steps, no per-step bookkeeping (wave-uniform branch)
+            const uint32_t* pa = reinterpret_cast<const uint32_t*>(lr < ch ? lp : p_last);
+            const uint32_t* pb = reinterpret_cast<const uint32_t*>(rps + lr < ch ? lp + gstep : p_last);
+            // 4-byte aligned (x_al), not 16: four dword loads the compiler may merge into one dwordx4
+            const uint4 va = make_uint4(pa[0], pa[1], pa[2], pa[3]), vb = make_uint4(pb[0], pb[1], pb[2], pb[3]);
+            if (ld_on && lr < ch) t128[0] = va;
+            if (ld_on && rps + lr < ch) t128[lstep] = vb;
+        } else {
+            uint4 v[6];
 #pragma unroll
-            for (int k = 0; k < 4; k++) {
-                const int t = b + k * 64 + lane;
-                const int tt = min(t, nseg - 1);
-                const int r = (int)(((float)tt + 0.5f) * inv_spr);
-                const int c = tt - r * spr;
-                dst[k] = t < nseg ? r * tp16 + c : -1;
-                const uint8_t* p = src + (long long)r * pitch + 16 * c;
-                // 4-byte aligned (x_al), not 16: four dword loads the compiler may merge into one dwordx4
-                const uint32_t* p32 = reinterpret_cast<const uint32_t*>(p);
-                v[k] = make_uint4(p32[0], p32[1], p32[2], p32[3]);
+            for (int k = 0; k < 6; k++) {
+                if (k * rps < ch) {   // wave-uniform
+                    const uint32_t* p32 = reinterpret_cast<const uint32_t*>(k * rps + lr < ch ? lp + k * gstep : p_last);
+                    v[k] = make_uint4(p32[0], p32[1], p32[2], p32[3]);
+                }
             }
 #pragma unroll
-            for (int k = 0; k < 4; k++)
-                if (dst[k] >= 0) t128[dst[k]] = v[k];
+            for (int k = 0; k < 6; k++)
+                if (k * rps < ch && ld_on && k * rps + lr < ch) t128[k * lstep] = v[k];
         }
         uint4* sm128 = reinterpret_cast<uint4*>(smap);
         const uint4 z4 = make_uint4(0, 0, 0, 0);
