@@ -185,3 +185,21 @@ def test_per_level_pyramid_path(oracle, monkeypatch, w, h, nimg):
     for l in range(8):
         np.testing.assert_array_equal(ext.pyramid_level(l), oe.level(l))
     ext.close()
+
+
+def test_maximum_image_size(oracle):
+    """The largest image the 12-bit coordinate packing admits (4000 px a side): 4000x3000, 5000 features, bit-exact;
+    one pixel more is refused with GFO_ERR_INVALID instead of being mis-packed."""
+    import gf_orb_slam2_amd as G
+    from gf_orb_slam2_amd._lib import GfoError
+    base = synth_frame(1000, 750, 99)                  # tiled 4 x 4 (generating 12 MP of value noise takes 40 s)
+    img = np.ascontiguousarray(np.tile(base, (4, 4)))
+    assert img.shape == (3000, 4000)
+    ext = G.ORBextractor(5000, 1.2, 8, 20, 7)
+    oe = oracle.OracleExtractor(5000, 1.2, 8, 20, 7)
+    n = _same(ext, oe, img)
+    assert n >= 4000
+    with pytest.raises(GfoError):
+        ext(np.zeros((100, 4001), np.uint8))
+    _same(ext, oe, synth_frame(752, 480, 5))      # the context is still usable after the refusal
+    ext.close()
