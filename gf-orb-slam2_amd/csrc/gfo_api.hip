@@ -60,12 +60,13 @@ void gfo_prof_begin(gfo_ctx* c, int stage)
 
 void gfo_prof_end(gfo_ctx* c)
 {
-    if (c->debug_sync) {  // GFO_DEBUG_SYNC=1: attribute launch/runtime errors to their stage
-        hipError_t e = hipGetLastError();
-        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-        if (e != hipSuccess && c->launch_err.empty())
-            c->launch_err = std::string("stage ") + k_stage_names[c->cur_stage] + ": " + hipGetErrorString(e);
-    }
+    // a refused launch (bad configuration) is recorded with its stage; the pipeline driver stops before it
+    // launches anything that would consume the missing results.  GFO_DEBUG_SYNC=1 additionally waits for the
+    // stage, so that runtime faults are attributed too.
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess && c->debug_sync) e = hipStreamSynchronize(c->stream);
+    if (e != hipSuccess && c->launch_err.empty())
+        c->launch_err = std::string("stage ") + k_stage_names[c->cur_stage] + ": " + hipGetErrorString(e);
     if (!c->profiling || c->pending.empty()) return;
     (void)hipEventRecord(c->pending.back().b, c->stream);
 }
@@ -234,7 +235,11 @@ static int plan(gfo_ctx* c, int w, int h, int batch)
             xtab += (int)align_up(L.w + 3, 4) + 4;   // padded: see the table construction below
             ytab += (int)align_up(L.h + 3, 4) + 4;
         }
-        if (L.node_cap > 60000) return fail(c, GFO_ERR_INVALID, "level quota %d too large", L.quota);
+        if (L.node_cap > 60000 || gfo_quadtree_lds_bytes(L.node_cap, 0) > 160 * 1024)
+            return fail(c, GFO_ERR_INVALID,
+                        "level %d takes %d of the %d features: its quadtree state (%zu B) does not fit the 160 KB of LDS -- use more "
+                        "pyramid levels or fewer features",
+                        l, L.quota, c->prm.nfeatures, gfo_quadtree_lds_bytes(L.node_cap, 0));
     }
     if (max_cw - 6 > 64 || max_ch - 6 > 64)
         return fail(c, GFO_ERR_INVALID, "FAST cell %dx%d exceeds the per-wave plan", max_cw - 6, max_ch - 6);
@@ -568,10 +573,12 @@ static int run_extract(gfo_ctx* c, const GfoInput& in, int nimg)
         gfo_launch_fast(c, in, nimg);
         gfo_launch_quadtree(c, nimg);
     }
-    gfo_launch_orient_desc(c, in, nimg);
+    // nothing that consumes the selection may run if a stage before it was refused
+    if (c->launch_err.empty()) gfo_launch_orient_desc(c, in, nimg);
     if (!c->launch_err.empty()) {
         const std::string m = c->launch_err;
         c->launch_err.clear();
+        c->have_batch = false;
         return fail(c, GFO_ERR_DEVICE, "%s", m.c_str());
     }
     HIP_TRY(c, hipGetLastError());

@@ -189,6 +189,7 @@ struct gfo_ctx {
 // ---- kernel launchers (each in its own .hip file) ------------------------------------------
 void gfo_launch_resize(gfo_ctx* c, const GfoInput& in, int level, int nimg);
 void gfo_launch_resize_tail(gfo_ctx* c, const GfoInput& in, int level_begin, int nimg);
+size_t gfo_quadtree_lds_bytes(int ncap, int klds);
 void gfo_launch_pyramid_bands(gfo_ctx* c, const GfoInput& in, int nimg);
 int gfo_pyramid_bands_prepare(int lds_bytes);
 void gfo_launch_blur(gfo_ctx* c, const GfoInput& in, int nimg);

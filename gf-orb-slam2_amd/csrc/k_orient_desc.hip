@@ -67,7 +67,9 @@ __global__ __launch_bounds__(256) void k_orient_desc(const GfoGeom* __restrict__
     // per-level counts (wave-uniform): a slot's level follows from their prefix; output rows are level by
     // level, list order inside a level (:1144-1161)
     int total = 0;
-    for (int l = 0; l < g.nlevels; l++) total += sel_cnt[img * g.nlevels + l];
+    // (counts are clamped to the slots a level owns: a selection that was never written cannot send this kernel
+    //  outside its buffers)
+    for (int l = 0; l < g.nlevels; l++) total += min(max(sel_cnt[img * g.nlevels + l], 0), g.lv[l].sel_cap);
     if (blk == 0 && wave == 0 && lane == 0) {
         kp_cnt[img] = min(total, g.kp_stride);
         if (total > g.kp_stride) atomicOr(&flags[0], 8);
@@ -79,7 +81,7 @@ __global__ __launch_bounds__(256) void k_orient_desc(const GfoGeom* __restrict__
     const int slot = min(slot0 + half, nkp - 1);
     int level = 0, idx = slot, acc = 0;
     for (int l = 0; l < g.nlevels; l++) {
-        const int c = sel_cnt[img * g.nlevels + l];
+        const int c = min(max(sel_cnt[img * g.nlevels + l], 0), g.lv[l].sel_cap);
         if (slot >= acc && slot < acc + c) {
             level = l;
             idx = slot - acc;

@@ -203,3 +203,19 @@ def test_maximum_image_size(oracle):
         ext(np.zeros((100, 4001), np.uint8))
     _same(ext, oe, synth_frame(752, 480, 5))      # the context is still usable after the refusal
     ext.close()
+
+
+def test_oversized_level_quota_is_refused_cleanly(oracle):
+    """4000 features on ONE level need more quadtree state than the 160 KB of LDS: the plan refuses the image with
+    GFO_ERR_INVALID (-1) and a message; nothing is launched, the process and other contexts stay healthy."""
+    import gf_orb_slam2_amd as G
+    from gf_orb_slam2_amd._lib import GfoError
+    img = synth_frame(752, 480, 2)
+    bad = G.ORBextractor(4000, 1.2, 1, 20, 7)
+    with pytest.raises(GfoError) as ei:
+        bad(img)
+    assert ei.value.code == -1 and "LDS" in str(ei.value)
+    bad.close()
+    ext = G.ORBextractor(2000, 1.2, 8, 20, 7)
+    _same(ext, oracle.OracleExtractor(2000, 1.2, 8, 20, 7), img)
+    ext.close()
