@@ -71,6 +71,15 @@ void gfo_prof_end(gfo_ctx* c)
     (void)hipEventRecord(c->pending.back().b, c->stream);
 }
 
+// Launch refusals recorded by gfo_prof_end() become the call's error (GFO_ERR_DEVICE, stage named).
+int gfo_take_launch_err(gfo_ctx* c)
+{
+    if (c->launch_err.empty()) return GFO_OK;
+    const std::string m = c->launch_err;
+    c->launch_err.clear();
+    return fail(c, GFO_ERR_DEVICE, "%s", m.c_str());
+}
+
 static void prof_collect(gfo_ctx* c)
 {
     if (c->pending.empty()) return;
@@ -576,11 +585,10 @@ static int run_extract(gfo_ctx* c, const GfoInput& in, int nimg)
     // nothing that consumes the selection may run if a stage before it was refused
     if (c->launch_err.empty()) gfo_launch_orient_desc(c, in, nimg);
     if (!c->launch_err.empty()) {
-        const std::string m = c->launch_err;
-        c->launch_err.clear();
         c->have_batch = false;
-        return fail(c, GFO_ERR_DEVICE, "%s", m.c_str());
+        return gfo_take_launch_err(c);
     }
+    if (int lrc = gfo_take_launch_err(c)) return lrc;
     HIP_TRY(c, hipGetLastError());
     c->have_batch = true;
     c->have_stereo = false;
@@ -730,6 +738,7 @@ extern "C" int gfo_compute_pyramid(gfo_ctx* c, const uint8_t* img, int w, int h,
     if (rc) return rc;
     c->have_batch = false;
     run_pyramid(c, in, 1);
+    if (int lrc = gfo_take_launch_err(c)) return lrc;
     HIP_TRY(c, hipGetLastError());
     return GFO_OK;
 }
@@ -856,6 +865,7 @@ extern "C" int gfo_stereo_match(gfo_ctx* c, const gfo_keypoint* kl, const uint8_
     sl.sort_stride = nr1;
     sl.window = gfo_stereo_window(sf, nlevels);
     gfo_launch_stereo(c, sl);
+    if (int lrc = gfo_take_launch_err(c)) return lrc;
     HIP_TRY(c, hipGetLastError());
     HIP_TRY(c, hipMemcpyAsync(u_right, out.u_right, sizeof(float) * nl, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipMemcpyAsync(depth, out.depth, sizeof(float) * nl, hipMemcpyDeviceToHost, c->stream));
@@ -885,6 +895,7 @@ extern "C" int gfo_stereo_match_batch(gfo_ctx* c, const gfo_stereo_params* p)
     sl.sort = c->st_sort; sl.sort_stride = c->g.kp_stride;
     sl.window = gfo_stereo_window(c->scale.data(), c->g.nlevels);
     gfo_launch_stereo(c, sl);
+    if (int lrc = gfo_take_launch_err(c)) return lrc;
     HIP_TRY(c, hipGetLastError());
     c->have_stereo = true;
     return GFO_OK;
@@ -907,6 +918,7 @@ extern "C" int gfo_stereo_match_sad_batch(gfo_ctx* c, float mbf, float mb)
     sl.sort = c->st_sort; sl.sort_stride = c->g.kp_stride;
     sl.window = gfo_stereo_window(c->scale.data(), c->g.nlevels);
     gfo_launch_stereo_sad(c, sl, c->last_in, c->d_inv_scale);
+    if (int lrc = gfo_take_launch_err(c)) return lrc;
     HIP_TRY(c, hipGetLastError());
     c->have_stereo = true;
     return GFO_OK;

@@ -190,6 +190,7 @@ struct gfo_ctx {
 void gfo_launch_resize(gfo_ctx* c, const GfoInput& in, int level, int nimg);
 void gfo_launch_resize_tail(gfo_ctx* c, const GfoInput& in, int level_begin, int nimg);
 size_t gfo_quadtree_lds_bytes(int ncap, int klds);
+int gfo_take_launch_err(gfo_ctx* c);
 void gfo_launch_pyramid_bands(gfo_ctx* c, const GfoInput& in, int nimg);
 int gfo_pyramid_bands_prepare(int lds_bytes);
 void gfo_launch_blur(gfo_ctx* c, const GfoInput& in, int nimg);

@@ -218,6 +218,7 @@ extern "C" int gfo_search_by_bow(gfo_ctx* c, const uint8_t* kf_desc, const float
     hipLaunchKernelGGL(k_bow_match, dim3((a.npairs + 3) / 4), dim3(256), 0, st, a);
     if (a.check_ori) hipLaunchKernelGGL(k_bow_rotation, dim3(1), dim3(256), 0, st, a);
     gfo_prof_end(c);
+    if (int lrc = gfo_take_launch_err(c)) return lrc;
     BTRY(c, hipGetLastError());
     int cnt[4];
     BTRY(c, hipMemcpyAsync(out_kf_idx, a.out, 4 * (size_t)n_f, hipMemcpyDeviceToHost, st));
@@ -351,6 +352,7 @@ extern "C" int gfo_bow_transform(gfo_ctx* c, const uint8_t* desc, int n, int lev
     hipLaunchKernelGGL(k_bow_transform, dim3((n + 3) / 4), dim3(256), 0, st, v, S + o_d, n, levelsup, (int*)(S + o_w),
                        (float*)(S + o_wt), (int*)(S + o_n));
     gfo_prof_end(c);
+    if (int lrc = gfo_take_launch_err(c)) return lrc;
     BTRY(c, hipGetLastError());
     BTRY(c, hipMemcpyAsync(word_id, S + o_w, 4 * (size_t)n, hipMemcpyDeviceToHost, st));
     BTRY(c, hipMemcpyAsync(weight, S + o_wt, 4 * (size_t)n, hipMemcpyDeviceToHost, st));

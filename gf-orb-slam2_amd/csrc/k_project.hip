@@ -424,6 +424,7 @@ extern "C" int gfo_search_by_projection_queries(gfo_ctx* c, const gfo_keypoint* 
         if (mode->check_orientation) hipLaunchKernelGGL(k_project_rotation, dim3(1), dim3(256), 0, st, a, nlive);
     }
     gfo_prof_end(c);
+    if (int lrc = gfo_take_launch_err(c)) return lrc;
     PTRY(c, hipGetLastError());
     PTRY(c, hipMemcpyAsync(out_mp, a.out_mp, 4 * (size_t)n, hipMemcpyDeviceToHost, st));
     PTRY(c, hipMemcpyAsync(out_score, a.out_score, 4 * (size_t)n, hipMemcpyDeviceToHost, st));
