@@ -46,7 +46,7 @@ typedef struct {
  * Limits of this implementation (refused with GFO_ERR_INVALID and a message when an image is planned):
  * images up to 4000 px a side (12-bit coordinate packing), FAST cells up to 64 px, and a per-level feature
  * quota of at most 2040 (the quadtree state of one level lives in the 160 KB of LDS) -- with the usual 8 levels
- * at scale 1.2 that is nfeatures up to ~9400; thresholds 1..254. */
+ * at scale 1.2 that is nfeatures up to ~9300 (9000 is tested bit-exact); thresholds 1..254. */
 typedef struct {
     int32_t nfeatures;
     float scale_factor;
