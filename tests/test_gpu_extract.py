@@ -63,3 +63,32 @@ def test_batch_matches_single(ext, oracle, euroc_l, euroc_r):
         okp, odesc = oe(im)
         assert k.tobytes() == okp.tobytes()
         np.testing.assert_array_equal(d, odesc)
+
+
+def test_two_contexts_from_two_threads(oracle, euroc_l, euroc_r):
+    """The reference runs its left and right extractor objects from two threads at once (Frame.cc:84-87): two
+    contexts driven concurrently (ctypes releases the GIL during the calls) stay bit-exact, 30 frames each."""
+    import threading
+    import gf_orb_slam2_amd as G
+    refs = [oracle.OracleExtractor(2000, 1.2, 8, 20, 7)(im) for im in (euroc_l, euroc_r)]
+    exts = [G.ORBextractor(2000, 1.2, 8, 20, 7) for _ in range(2)]
+    errors = []
+
+    def work(i, img):
+        try:
+            for _ in range(30):
+                k, d = exts[i](img)
+                if k.tobytes() != refs[i][0].tobytes() or not (d == refs[i][1]).all():
+                    errors.append(f"thread {i}: result differs")
+                    return
+        except Exception as e:  # noqa: BLE001
+            errors.append(f"thread {i}: {e!r}")
+
+    ts = [threading.Thread(target=work, args=(i, im)) for i, im in enumerate((euroc_l, euroc_r))]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    for e in exts:
+        e.close()
+    assert not errors, errors
