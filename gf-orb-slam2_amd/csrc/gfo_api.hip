@@ -132,14 +132,14 @@ static void build_tables(gfo_ctx* c)
 static void free_arena(gfo_ctx* c)
 {
     void* ptrs[] = {c->d_geom, c->d_input, c->d_pyr, c->d_blur, c->d_cand, c->d_cand_cnt, c->d_node_of, c->d_sel,
-                    c->d_sel_cnt, c->d_kp, c->d_desc, c->d_kp_cnt, c->d_flags, c->d_xofs, c->d_xcoef, c->d_yofs, c->d_band, c->d_cell_tab,
+                    c->d_sel_cnt, c->d_kp, c->d_desc, c->d_kp_cnt, c->d_flags, c->d_xofs, c->d_xcoef, c->d_yofs, c->d_band, c->d_cell_tab, c->d_qt_scratch,
                     c->d_ycoef, c->st.u_right, c->st.depth, c->st.best_dist, c->st.best_idx, c->st.nmatched, c->st.counted,
                     c->d_scale, c->d_inv_scale, c->st_sort.sx, c->st_sort.sy, c->st_sort.soi, c->st_sort.sdesc, c->st_sort.row_start};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     c->d_geom = nullptr; c->d_input = c->d_pyr = c->d_blur = nullptr; c->d_cand = nullptr; c->d_cand_cnt = nullptr;
     c->d_node_of = nullptr; c->d_sel = nullptr; c->d_sel_cnt = nullptr; c->d_kp = nullptr; c->d_desc = nullptr;
-    c->d_kp_cnt = nullptr; c->d_flags = nullptr; c->d_xofs = nullptr; c->d_xcoef = nullptr; c->d_yofs = nullptr; c->d_band = nullptr; c->d_cell_tab = nullptr;
+    c->d_kp_cnt = nullptr; c->d_flags = nullptr; c->d_xofs = nullptr; c->d_xcoef = nullptr; c->d_yofs = nullptr; c->d_band = nullptr; c->d_cell_tab = nullptr; c->d_qt_scratch = nullptr;
     c->d_ycoef = nullptr; c->st = GfoStereoDev{}; c->d_scale = nullptr; c->d_inv_scale = nullptr; c->st_sort = GfoStereoSort{}; c->st_rows_cap = 0;
     c->planned = false;
     c->have_batch = c->have_pyramid = c->have_stereo = false;
@@ -244,11 +244,7 @@ static int plan(gfo_ctx* c, int w, int h, int batch)
             xtab += (int)align_up(L.w + 3, 4) + 4;   // padded: see the table construction below
             ytab += (int)align_up(L.h + 3, 4) + 4;
         }
-        if (L.node_cap > 60000 || gfo_quadtree_lds_bytes(L.node_cap, 0) > 160 * 1024)
-            return fail(c, GFO_ERR_INVALID,
-                        "level %d takes %d of the %d features: its quadtree state (%zu B) does not fit the 160 KB of LDS -- use more "
-                        "pyramid levels or fewer features",
-                        l, L.quota, c->prm.nfeatures, gfo_quadtree_lds_bytes(L.node_cap, 0));
+        if (L.node_cap > 60000) return fail(c, GFO_ERR_INVALID, "level %d takes %d of the %d features: more than 60000 nodes per level are not supported", l, L.quota, c->prm.nfeatures);
     }
     if (max_cw - 6 > 64 || max_ch - 6 > 64)
         return fail(c, GFO_ERR_INVALID, "FAST cell %dx%d exceeds the per-wave plan", max_cw - 6, max_ch - 6);
@@ -392,6 +388,20 @@ static int plan(gfo_ctx* c, int w, int h, int batch)
                 for (int j = 0; j < g.lv[l].ncols; j++) cells[(size_t)g.lv[l].cell_base + i * g.lv[l].ncols + j] = l | (i << 4) | (j << 16);
         HIP_TRY(c, hipMalloc(&c->d_cell_tab, cells.size() * sizeof(int)));
         HIP_TRY(c, hipMemcpy(c->d_cell_tab, cells.data(), cells.size() * sizeof(int), hipMemcpyHostToDevice));
+    }
+    {
+        // quadtree: a level whose node tables exceed the 160 KB of LDS runs the global-memory variant of the kernel
+        // (the usual 8-level configurations never do: that takes more than 2040 features on one level)
+        int ncap_max = 0;
+        for (int l = 0; l < g.nlevels; l++) ncap_max = g.lv[l].node_cap > ncap_max ? g.lv[l].node_cap : ncap_max;
+        c->qt_scratch_stride = 0;
+        if (gfo_quadtree_lds_bytes(ncap_max, 0) > 160 * 1024) {
+            c->qt_scratch_stride = align_up((long long)gfo_quadtree_lds_bytes(ncap_max, 0), 256);
+            const size_t total = c->qt_scratch_stride * B * (size_t)g.nlevels;
+            if (total > ((size_t)4 << 30))
+                return fail(c, GFO_ERR_INVALID, "quadtree scratch for %d features on one level x %zu images (%zu MB) exceeds 4 GB: lower max_batch", c->prm.nfeatures, B, total >> 20);
+            HIP_TRY(c, hipMalloc(&c->d_qt_scratch, total));
+        }
     }
     HIP_TRY(c, hipMalloc(&c->d_band, (bandv.size() + 4) * sizeof(int)));
     if (!bandv.empty()) HIP_TRY(c, hipMemcpy(c->d_band, bandv.data(), bandv.size() * sizeof(int), hipMemcpyHostToDevice));

@@ -153,6 +153,8 @@ struct gfo_ctx {
     int* d_xofs = nullptr;           // resize tables, all levels
     short* d_xcoef = nullptr;
     int* d_yofs = nullptr;
+    uint8_t* d_qt_scratch = nullptr;   // quadtree state in HBM, only when a level's state exceeds LDS
+    size_t qt_scratch_stride = 0;      // bytes per (image, level) workgroup
     int* d_cell_tab = nullptr;    // FAST: cell -> level | row << 4 | column << 16
     int* d_band = nullptr;        // per group: int4 [nb][nlevels] = {c0, c1, o0, o1}
     GfoBandGroup band_groups[2];

@@ -44,9 +44,10 @@ typedef struct {
 /* ORBextractor::ORBextractor(nfeatures, scaleFactor, nlevels, iniThFAST, minThFAST)
  * include/ORBextractor.h:81-82, src/ORBextractor.cc:409-469.
  * Limits of this implementation (refused with GFO_ERR_INVALID and a message when an image is planned):
- * images up to 4000 px a side (12-bit coordinate packing), FAST cells up to 64 px, and a per-level feature
- * quota of at most 2040 (the quadtree state of one level lives in the 160 KB of LDS) -- with the usual 8 levels
- * at scale 1.2 that is nfeatures up to ~9300 (9000 is tested bit-exact); thresholds 1..254. */
+ * images up to 4000 px a side (12-bit coordinate packing), FAST cells up to 64 px, at most 60000 quadtree nodes
+ * per level, thresholds 1..254.  A level that takes more than 2040 features (with the usual 8 levels at scale
+ * 1.2: nfeatures above ~9300) still runs, but its quadtree tables no longer fit the 160 KB of LDS and live in
+ * HBM -- markedly slower. */
 typedef struct {
     int32_t nfeatures;
     float scale_factor;
