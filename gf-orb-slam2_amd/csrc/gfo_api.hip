@@ -296,7 +296,7 @@ static int plan(gfo_ctx* c, int w, int h, int batch)
     g.pyr_nb = 0;
     c->n_band_groups = 0;
     if (g.nlevels >= 2) {
-        const int budget = (getenv("GFO_PYR_LDS_KB") ? atoi(getenv("GFO_PYR_LDS_KB")) : 32) * 1024;
+        const int budget = (getenv("GFO_PYR_LDS_KB") ? atoi(getenv("GFO_PYR_LDS_KB")) : 24) * 1024;   // measured best with 256 threads (752x480)
         const int tail_px = getenv("GFO_RESIZE_TAIL_PX") ? atoi(getenv("GFO_RESIZE_TAIL_PX")) : 60000;
         const int nl = g.nlevels;
         auto sy_of = [&](int l, int dy) {
@@ -363,7 +363,7 @@ static int plan(gfo_ctx* c, int w, int h, int batch)
             c->n_band_groups = 0;
             g.pyr_nb = 0;
         }
-        c->band_threads = getenv("GFO_PYR_THREADS") ? atoi(getenv("GFO_PYR_THREADS")) : 512;
+        c->band_threads = getenv("GFO_PYR_THREADS") ? atoi(getenv("GFO_PYR_THREADS")) : 0;   // 0: by launch size (k_pyramid.hip)
     }
     const size_t B = (size_t)batch;
     HIP_TRY(c, hipMalloc(&c->d_geom, sizeof(GfoGeom)));

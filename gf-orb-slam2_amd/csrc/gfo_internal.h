@@ -158,7 +158,7 @@ struct gfo_ctx {
     int* d_cell_tab = nullptr;    // FAST: cell -> level | row << 4 | column << 16
     int* d_band = nullptr;        // per group: int4 [nb][nlevels] = {c0, c1, o0, o1}
     GfoBandGroup band_groups[2];
-    int n_band_groups = 0, band_threads = 512;
+    int n_band_groups = 0, band_threads = 0;
     short* d_ycoef = nullptr;
     float* d_scale = nullptr;        // mvScaleFactor on the device
     float* d_inv_scale = nullptr;    // mvInvScaleFactor on the device
