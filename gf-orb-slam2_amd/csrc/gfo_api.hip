@@ -216,7 +216,7 @@ static int plan(gfo_ctx* c, int w, int h, int batch)
         L.cand_off = cand_off;
         cand_off += align_up(L.cand_cap, 64);
         L.tiles_x = (L.w + 3) / 4;      // blur: column quads per row
-        L.tiles_y = (L.h + 31) / 32;    // blur: 32-row strips
+        L.tiles_y = (L.h + GFO_BLUR_STRIP - 1) / GFO_BLUR_STRIP;    // blur: strips of GFO_BLUR_STRIP rows
         {
             int nint = (L.w - 8) / 4;
             if (nint > L.tiles_x - 1) nint = L.tiles_x - 1;

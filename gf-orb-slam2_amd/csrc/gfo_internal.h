@@ -18,6 +18,10 @@
                              // so the per-cell atomicAdds of different levels/images never share a line
 
 // Geometry of one pyramid level, shared by host planning and every kernel (passed by value).
+#ifndef GFO_BLUR_STRIP
+#define GFO_BLUR_STRIP 32   // rows a blur thread walks (6 halo rows each): shared by plan() and k_blur
+#endif
+
 struct GfoLevel {
     int w, h, pitch;          // plane size; pitch multiple of 64 B
     long long plane_off;      // byte offset of the plane inside one image's pyramid block (level>=1)

@@ -11,7 +11,7 @@
 // All levels of all images are one launch (block index -> level through the prefix table).
 #include "gfo_internal.h"
 
-#define BLUR_STRIP 32
+#define BLUR_STRIP GFO_BLUR_STRIP
 
 __device__ __forceinline__ int gfo_reflect101(int p, int n)
 {
