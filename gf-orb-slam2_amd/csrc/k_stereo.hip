@@ -16,6 +16,7 @@
 //   k_stereo_cut    : the outlier cut (:1290-1313) needs only the (ndi/2)-th order statistic of the
 //                     accepted distances: a 128-bin LDS histogram gives it exactly (no sort).
 #include "gfo_internal.h"
+#include <stdlib.h>
 
 #define TH_HIGH 100  // ORBmatcher.cc:57
 #define TH_LOW 50    // ORBmatcher.cc:58
@@ -136,7 +137,7 @@ __global__ __launch_bounds__(256) void k_stereo_match(StereoArgs a)
     const int half = lane >> 5, hl = lane & 31;
     const int pair = blockIdx.y;
     const int nl = a.cnt_dev ? a.cnt_dev[2 * pair] : a.nl_host;
-    const int iL0 = (blockIdx.x * 4 + wave) * 2;
+    const int iL0 = (blockIdx.x * (int)(blockDim.x >> 6) + wave) * 2;
     if (iL0 >= nl) return;                         // wave-uniform
     const bool act = iL0 + half < nl;
     const int iL = min(iL0 + half, nl - 1);        // an idle second half redoes the last keypoint, writes nothing
@@ -509,9 +510,10 @@ void gfo_launch_stereo(gfo_ctx* c, const GfoStereoLaunch& s)
     gfo_prof_begin(c, ST_STEREO_BUCKET);
     hipLaunchKernelGGL(k_stereo_bucket, dim3(s.npairs), dim3(1024), (size_t)(s.p.n_rows + 256) * sizeof(int), c->stream, a);
     gfo_prof_end(c);
-    dim3 grid((max_nl + 7) / 8, s.npairs);  // 4 waves x 2 left keypoints per workgroup
+    static const int snw = getenv("GFO_STEREO_WAVES") ? atoi(getenv("GFO_STEREO_WAVES")) : 4;   // waves per workgroup, 2 left keypoints each
+    dim3 grid((max_nl + 2 * snw - 1) / (2 * snw), s.npairs);
     gfo_prof_begin(c, ST_STEREO);
-    hipLaunchKernelGGL(k_stereo_match, grid, dim3(256), 0, c->stream, a);
+    hipLaunchKernelGGL(k_stereo_match, grid, dim3(64 * snw), 0, c->stream, a);
     gfo_prof_end(c);
     gfo_prof_begin(c, ST_STEREO_CUT);
     hipLaunchKernelGGL(k_stereo_cut, dim3(s.npairs), dim3(1024), 0, c->stream, s.cnt_dev, s.nl_host, s.out, s.out_stride);
