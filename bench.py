@@ -133,8 +133,8 @@ def cpu_baseline(w, h, nfeatures, stereo, budget_s=10.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=128, help="images per GPU per step (even)")
     ap.add_argument("--workload", default="stereo752", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
