@@ -148,8 +148,13 @@ void gfo_launch_quadtree(gfo_ctx* c, int nimg)
     while (klds > 0 && gfo_quadtree_lds_bytes(ncap, klds) > 150 * 1024) klds -= 1024;
     const size_t lds = gfo_quadtree_lds_bytes(ncap, klds);
     const bool gmem = lds > 160 * 1024;   // state of the largest level does not fit LDS: scratch in HBM (plan() sized it)
-    if (!gmem && lds > 64 * 1024)
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_quadtree), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (!gmem && lds > 64 * 1024) {
+        static size_t granted = 0;   // per process: the attribute only ever grows
+        if (lds > granted) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_quadtree), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            granted = lds;
+        }
+    }
     dim3 grid(nimg, c->g.nlevels);
     // the per-pass key loops are latency-bound inside a workgroup: large quotas (1080p @4000 features) get
     // 1024 threads per (image, level), the 752x480 @2000 case runs best with 256
