@@ -288,31 +288,26 @@ static int plan(gfo_ctx* c, int w, int h, int batch)
             ytabv[2 * (g.lv[l].ytab_off + d) + 1] = (int)((unsigned short)coef[2 * s_] | ((unsigned)(unsigned short)coef[2 * s_ + 1] << 16));
         }
     }
-    // banded pyramid: the levels are split into (at most) two groups -- the large ones and the small ones past
-    // the GFO_RESIZE_TAIL_PX mark -- each one launch; per group, the fewest bands whose per-workgroup LDS
-    // footprint fits the budget.  Ranges are derived top-down inside a group: the rows a level must hold are its
-    // own share plus the source rows the level above reads for ITS computed rows.
+    // banded pyramid: the levels are cut into groups of consecutive levels, each one launch of k_pyramid_bands
+    // (a group of ONE level is an ordinary k_resize launch).  Greedy from level 1: the longest group (up to
+    // GFO_PYR_GROUP levels) for which some band count <= 64 keeps the per-workgroup LDS footprint within the
+    // budget; inside a group the fewest such bands.  Ranges are derived top-down inside a group: the rows a level
+    // must hold are its own share plus the source rows the level above reads for ITS computed rows.
     std::vector<int> bandv;
     g.pyr_nb = 0;
     c->n_band_groups = 0;
     if (g.nlevels >= 2) {
         const int budget = (getenv("GFO_PYR_LDS_KB") ? atoi(getenv("GFO_PYR_LDS_KB")) : 24) * 1024;   // measured best with 256 threads (752x480)
-        const int tail_px = getenv("GFO_RESIZE_TAIL_PX") ? atoi(getenv("GFO_RESIZE_TAIL_PX")) : 60000;
+        const int max_group = getenv("GFO_PYR_GROUP") ? atoi(getenv("GFO_PYR_GROUP")) : 4;
         const int nl = g.nlevels;
         auto sy_of = [&](int l, int dy) {
             const int v = ytabv[2 * (size_t)(g.lv[l].ytab_off + dy)], sh = g.lv[l - 1].h;
             return v < 0 ? 0 : (v > sh - 1 ? sh - 1 : v);
         };
-        int split = 1;
-        while (split < nl && g.lv[split].w * g.lv[split].h > tail_px) split++;
-        if (split == 1 || nl - split < 2) split = nl;   // nothing large, or a tail of one level: a single group
-        const int bounds[3] = {1, split, nl};
-        bool ok = true;
-        for (int gi = 0; gi < 2 && ok; gi++) {
-            const int lb = bounds[gi], le = bounds[gi + 1];
-            if (le <= lb) continue;
-            GfoBandGroup bg = {lb, le, 0, 0, (int)(bandv.size() / 4)};
-            for (int nb = 1; nb <= 64 && bg.nb == 0; nb++) {
+        // plan of one group [lb, le): fills bg / tab / lds offsets on success
+        double px_own = 0.0, px_done = 0.0;   // pixels the levels hold / pixels the bands compute (halo included)
+        auto plan_group = [&](int lb, int le, GfoBandGroup* out_bg, std::vector<int>* out_tab, int* lp_out, int* off_out) {
+            for (int nb = 1; nb <= 64; nb++) {
                 if (g.lv[le - 1].h < 2 * nb && nb > 1) break;
                 std::vector<int> tab(4 * (size_t)nb * nl, 0);
                 int maxrows[GFO_MAX_LEVELS] = {0};
@@ -340,26 +335,57 @@ static int plan(gfo_ctx* c, int w, int h, int batch)
                 for (int l = lb; l < le - 1; l++) lds += (int)align_up((long long)align_up(g.lv[l].w, 16) * maxrows[l], 16);
                 if (getenv("GFO_DEBUG_PLAN")) fprintf(stderr, "[gfo] pyramid bands, levels %d..%d: nb %d -> %d B of LDS (budget %d)\n", lb, le - 1, nb, lds, budget);
                 if (lds <= budget) {
-                    bg.nb = nb;
-                    bg.lds_bytes = lds;
+                    out_bg->lb = lb; out_bg->le = le; out_bg->nb = nb; out_bg->lds_bytes = lds;
                     int off = 0;
                     for (int l = lb; l < le - 1; l++) {
-                        g.band_lp[l] = (int)align_up(g.lv[l].w, 16);
-                        g.band_lds_off[l] = off;
-                        off += (int)align_up((long long)g.band_lp[l] * maxrows[l], 16);
+                        lp_out[l] = (int)align_up(g.lv[l].w, 16);
+                        off_out[l] = off;
+                        off += (int)align_up((long long)lp_out[l] * maxrows[l], 16);
                     }
-                    bandv.insert(bandv.end(), tab.begin(), tab.end());
+                    for (int l = lb; l < le; l++) {
+                        px_own += (double)g.lv[l].w * g.lv[l].h;
+                        for (int b = 0; b < nb; b++) px_done += (double)g.lv[l].w * (tab[4 * ((size_t)b * nl + l) + 1] - tab[4 * ((size_t)b * nl + l)]);
+                    }
+                    out_tab->swap(tab);
+                    return true;
                 }
             }
-            if (bg.nb == 0 || gfo_pyramid_bands_prepare(bg.lds_bytes) != 0) {
-                (void)hipGetLastError();
-                ok = false;
-                break;
+            return false;
+        };
+        bool ok = true;
+        int lb = 1;
+        while (lb < nl && ok) {
+            int take = 0;
+            GfoBandGroup bg = {0, 0, 0, 0, 0};
+            std::vector<int> tab;
+            for (int size = (nl - lb < max_group ? nl - lb : max_group); size >= 2 && take == 0; size--)
+                if (plan_group(lb, lb + size, &bg, &tab, g.band_lp, g.band_lds_off)) take = size;
+            if (take == 0) {          // not even two levels fit: this level is an ordinary per-level launch
+                bg.lb = lb; bg.le = lb + 1; bg.nb = 0; bg.lds_bytes = 0;
+                take = 1;
+            } else {
+                bg.tab_off = (int)(bandv.size() / 4);
+                bandv.insert(bandv.end(), tab.begin(), tab.end());
+                if (gfo_pyramid_bands_prepare(bg.lds_bytes) != 0) {
+                    (void)hipGetLastError();
+                    ok = false;
+                    break;
+                }
             }
+            if (c->n_band_groups >= GFO_MAX_LEVELS) { ok = false; break; }
             c->band_groups[c->n_band_groups++] = bg;
-            g.pyr_nb = g.pyr_nb == 0 || bg.nb < g.pyr_nb ? bg.nb : g.pyr_nb;
+            if (bg.nb > 0) g.pyr_nb = g.pyr_nb == 0 || bg.nb < g.pyr_nb ? bg.nb : g.pyr_nb;
+            lb += take;
         }
-        if (!ok) {
+        if (getenv("GFO_DEBUG_PLAN") && px_own > 0) fprintf(stderr, "[gfo] pyramid bands: %d groups, computed / owned pixels = %.3f\n", c->n_band_groups, px_done / px_own);
+        // wide images pay the halo rows at full width: past 1.3x recomputation the per-level launches win (1080p: 1.4)
+        const double max_over = getenv("GFO_PYR_MAX_OVERHEAD") ? atof(getenv("GFO_PYR_MAX_OVERHEAD")) : 1.30;
+        if (px_own > 0 && px_done / px_own > max_over) ok = false;
+        // measured: for rows wider than ~1000 px (1080p: level 1 = 1600 px) the per-level launches are already efficient
+        // and beat every band configuration (477 vs >= 499 us per 128 images); bands are for the VGA-class sizes
+        const int max_band_w = getenv("GFO_PYR_MAX_W") ? atoi(getenv("GFO_PYR_MAX_W")) : 1024;
+        if (g.lv[1].w > max_band_w) ok = false;
+        if (!ok || g.pyr_nb == 0) {   // nothing banded at all: the plain per-level path
             c->n_band_groups = 0;
             g.pyr_nb = 0;
         }

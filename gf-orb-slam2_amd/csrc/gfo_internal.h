@@ -161,7 +161,7 @@ struct gfo_ctx {
     size_t qt_scratch_stride = 0;      // bytes per (image, level) workgroup
     int* d_cell_tab = nullptr;    // FAST: cell -> level | row << 4 | column << 16
     int* d_band = nullptr;        // per group: int4 [nb][nlevels] = {c0, c1, o0, o1}
-    GfoBandGroup band_groups[2];
+    GfoBandGroup band_groups[GFO_MAX_LEVELS];   // nb == 0: a single level launched as k_resize
     int n_band_groups = 0, band_threads = 0;
     short* d_ycoef = nullptr;
     float* d_scale = nullptr;        // mvScaleFactor on the device

@@ -298,17 +298,21 @@ void gfo_launch_resize_tail(gfo_ctx* c, const GfoInput& in, int level_begin, int
 
 void gfo_launch_pyramid_bands(gfo_ctx* c, const GfoInput& in, int nimg)
 {
-    gfo_prof_begin(c, ST_RESIZE);
     for (int k = 0; k < c->n_band_groups; k++) {
         const GfoBandGroup& bg = c->band_groups[k];
+        if (bg.nb == 0) {   // a level whose neighbours do not fit a band with it
+            gfo_launch_resize(c, in, bg.lb, nimg);
+            continue;
+        }
+        gfo_prof_begin(c, ST_RESIZE);
         // 256 threads when the launch has workgroups to spare (more of them resident per CU), 512 for a handful of
         // images, where the time of ONE workgroup is what counts
         const int threads = c->band_threads > 0 ? c->band_threads : (bg.nb * nimg >= 2048 ? 256 : 512);
         hipLaunchKernelGGL(k_pyramid_bands, dim3(bg.nb, nimg), dim3(threads), bg.lds_bytes, c->stream, c->d_geom, in,
                            c->d_pyr, reinterpret_cast<const int2*>(c->d_xofs), reinterpret_cast<const int2*>(c->d_yofs),
                            reinterpret_cast<const int4*>(c->d_band) + bg.tab_off, bg.lb, bg.le);
+        gfo_prof_end(c);
     }
-    gfo_prof_end(c);
 }
 
 int gfo_pyramid_bands_prepare(int lds_bytes)

@@ -44,6 +44,9 @@ def test_random_extractions_match_oracle(oracle, monkeypatch, seed):
         img = _random_image(rng, w, h, int(rng.integers(0, 5)))
         monkeypatch.setenv("GFO_PYR_BAND_MIN_WG", "0" if it % 2 == 0 else "100000000")
         monkeypatch.setenv("GFO_PYR_LDS_KB", str(int(rng.choice([8, 16, 32, 64]))))
+        monkeypatch.setenv("GFO_PYR_MAX_W", "100000")
+        monkeypatch.setenv("GFO_PYR_MAX_OVERHEAD", "100")
+        monkeypatch.setenv("GFO_PYR_GROUP", str(int(rng.integers(2, 6))))
         ext = G.ORBextractor(nf, sf, nl, ini, mn)
         try:
             gk, gd = ext(img)

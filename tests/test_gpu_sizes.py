@@ -151,6 +151,9 @@ def test_banded_pyramid_equals_oracle(oracle, monkeypatch, w, h, sf, nl, lds_kb,
     image: every level bit-exact against the oracle's cv::resize chain, then the whole extraction."""
     import gf_orb_slam2_amd as G
     monkeypatch.setenv("GFO_PYR_BAND_MIN_WG", "1")
+    monkeypatch.setenv("GFO_PYR_MAX_W", "100000")          # also the wide images that default to the per-level path
+    monkeypatch.setenv("GFO_PYR_MAX_OVERHEAD", "100")
+    monkeypatch.setenv("GFO_PYR_GROUP", str(2 + (w + lds_kb) % 3))   # groups of up to 2, 3 or 4 levels
     monkeypatch.setenv("GFO_PYR_LDS_KB", str(lds_kb))
     monkeypatch.setenv("GFO_PYR_THREADS", str(threads))
     img = synth_frame(w, h, 3 * w + h)

@@ -45,6 +45,9 @@ for it in range(cases):
         img.reshape(-1)[idx] = rng.integers(0, 256, len(idx), dtype=np.uint8)
     os.environ["GFO_PYR_BAND_MIN_WG"] = "0" if it % 2 == 0 else "100000000"
     os.environ["GFO_PYR_LDS_KB"] = str(int(rng.choice([8, 16, 32, 64])))
+    os.environ["GFO_PYR_MAX_W"] = "100000"
+    os.environ["GFO_PYR_MAX_OVERHEAD"] = "100"
+    os.environ["GFO_PYR_GROUP"] = str(2 + it % 4)
     ext = G.ORBextractor(nf, sf, nl, ini, mn)
     try:
         gk, gd = ext(img)
