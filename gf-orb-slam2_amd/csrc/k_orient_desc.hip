@@ -50,21 +50,10 @@ __global__ __launch_bounds__(64 * OD_WAVES) void k_orient_desc(const GfoGeom* __
     // on XCD b % 8.  All workgroups of one image are given the same b % 8, so an image's windows (2.2 MB of
     // pyramid + blurred pyramid, overlapping heavily between keypoints) are fetched into ONE 4-MB L2 instead
     // of all eight.  Any placement gives the same results.
-    int img, blk;
-    {
-        const int b = blockIdx.x;
-        const int groups = nimg >> 3;  // full groups of 8 images
-        const int swz = groups * 8 * blocks_per_img;
-        if (b < swz) {
-            const int xcd = b & 7, s_ = b >> 3;
-            img = (s_ / blocks_per_img) * 8 + xcd;
-            blk = s_ - (s_ / blocks_per_img) * blocks_per_img;
-        } else {  // the < 8 images left over: plain order
-            const int r = b - swz;
-            img = groups * 8 + r / blocks_per_img;
-            blk = r - (r / blocks_per_img) * blocks_per_img;
-        }
-    }
+    // The grid is (8 * blocks_per_img, ceil(nimg / 8)): x is a multiple of 8, so the flattened workgroup index
+    // modulo 8 -- the XCD -- is blockIdx.x & 7, with no division anywhere.
+    const int img = blockIdx.y * 8 + (blockIdx.x & 7), blk = blockIdx.x >> 3;
+    if (img >= nimg) return;   // the last group of 8 may be partly empty
     // per-level counts (wave-uniform): a slot's level follows from their prefix; output rows are level by
     // level, list order inside a level (:1144-1161)
     int total = 0;
@@ -210,7 +199,7 @@ __global__ __launch_bounds__(64 * OD_WAVES) void k_orient_desc(const GfoGeom* __
 void gfo_launch_orient_desc(gfo_ctx* c, const GfoInput& in, int nimg)
 {
     const int bpi = (c->g.kp_stride + 2 * OD_WAVES - 1) / (2 * OD_WAVES);  // OD_WAVES waves x 2 keypoints per workgroup
-    dim3 grid((unsigned)bpi * (unsigned)nimg);
+    dim3 grid((unsigned)bpi * 8u, (unsigned)(nimg + 7) / 8u);
     gfo_prof_begin(c, ST_ORIENT_DESC);
     hipLaunchKernelGGL(k_orient_desc, grid, dim3(64 * OD_WAVES), 0, c->stream, c->d_geom, in, c->d_pyr, c->d_blur, c->d_sel,
                        c->d_sel_cnt, c->d_kp, c->d_desc, c->d_kp_cnt, c->d_flags, nimg, bpi);
