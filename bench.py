@@ -1,18 +1,19 @@
 #!/usr/bin/env python3
-"""bench.py -- frames/s of the MI355X ORB front-end (extract + stereo match) on synthetic
-752x480 grayscale frames at 2000 features, plus the roofline figure of the dominant kernel and
-the CPU oracle timed beside it.
+"""bench.py -- frames/s of the MI355X ORB front-end on synthetic frames, the roofline figure of the dominant
+kernel and the CPU oracle timed beside it.
 
   python bench.py --gpus 1 --steps 20 --warmup 3
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
          --master-port P bench.py --gpus N --steps K --warmup W
 
-A "step" is one pass of the hot path over one resident batch of `--batch` images per GPU
-(left/right interleaved: L0,R0,L1,R1,...): pyramid -> blur -> FAST cells -> quadtree ->
-orientation+descriptor for every image, then the stereo Hamming association of every pair.
-Inputs are already in HBM when the timed region starts.  Independent frames shard one batch
-per GPU (weak scaling); the only collective is the RCCL all-gather of the per-image keypoint
-counts.  Rank 0 prints ONE JSON line.
+Headline workload (BASELINE.json metric): `stereo752` = stereo 752x480 pairs at 2000 features, extract L+R + the
+stereo Hamming association.  A "step" is one pass of the hot path over one resident batch of `--batch` images per
+GPU: pyramid -> blur -> FAST cells -> quadtree -> orientation+descriptor for every image, then the matcher of the
+workload (stereo association of every pair / SearchByProjection of every frame against the resident local map).
+Inputs are already in HBM when the timed region starts; the steps walk over several distinct input batches so that
+no step finds its input in the Infinity Cache.  Independent frames shard one batch per GPU (weak scaling); the only
+collective is the RCCL all-gather of the per-image keypoint counts.  Rank 0 prints ONE JSON line; the other
+BASELINE configs are measured after the headline and reported in the same line under "other_configs".
 """
 import argparse
 import ctypes
@@ -27,12 +28,14 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 WORKLOADS = {
-    # name: (w, h, nfeatures, stereo, BASELINE.json config it corresponds to)
-    "stereo752": (752, 480, 2000, True, "configs[2]: stereo 752x480 pair, 2000 features/image, extract L+R + stereo Hamming match"),
-    "extract752": (752, 480, 2000, False, "configs[1]: 752x480 synthetic stream, 2000 features, extract-only"),
-    "extract1080": (1920, 1080, 4000, False, "configs[3] (extract part): 1920x1080, 4000 features"),
+    # name: (w, h, nfeatures, matcher, BASELINE.json config it corresponds to)
+    "stereo752": (752, 480, 2000, "stereo", "configs[2]: stereo 752x480 pair, 2000 features/image, extract L+R + stereo Hamming match"),
+    "extract752": (752, 480, 2000, None, "configs[1]: 752x480 synthetic stream, 2000 features, extract-only"),
+    "extract1080": (1920, 1080, 4000, None, "configs[3] (extract part): 1920x1080, 4000 features"),
+    "proj1080": (1920, 1080, 4000, "project", "configs[3]: 1920x1080 @4000 features, extract + SearchByProjection against a 50k-descriptor synthetic local map"),
 }
 FX, BF = 435.2046959714599, 47.90639384423901
+MAP_POINTS = 50000
 
 
 class _DevArray:
@@ -49,29 +52,39 @@ def level_sizes(w, h, inv_scale):
     return out
 
 
-def algorithmic_bytes(w, h, sizes, n_kp_img, stereo):
-    """Algorithmic HBM bytes per IMAGE of each stage (DESIGN.md 'bytes per unit')."""
+def algorithmic_bytes(w, h, sizes, n_kp_img, matcher, m_map=MAP_POINTS):
+    """Algorithmic HBM bytes per IMAGE of each stage (DESIGN.md 'bytes per unit', SURVEY.md 8d)."""
     P = sum(a * b for a, b in sizes)
     px = [a * b for a, b in sizes]
+    stereo_b = (2 * n_kp_img * 60 + n_kp_img * 8) / 2 if matcher == "stereo" else 0
+    project_b = m_map * (32 + 24) + n_kp_img * 60 + m_map * 8 if matcher == "project" else 0
     d = {
         "resize": sum(px[l - 1] + px[l] for l in range(1, len(px))),   # read level l-1, write level l
         "blur": 2 * P,                                                   # read level, write blurred level
         "fast": P,                                                       # read every level once
         "quadtree": 0,
         "orient_desc": n_kp_img * (749 + 1369 + 60),                     # disc + 37x37 window + kp/desc out
-        "stereo_match": (2 * n_kp_img * 60 + n_kp_img * 8) / 2 if stereo else 0,  # per image = half a pair
+        "stereo_match": stereo_b,                                        # per image = half a pair
         "stereo_bucket": 0,
         "stereo_cut": 0,
+        "project": project_b,                                            # M (desc + projection) + N (desc + kp) + M results
     }
-    survey_total = w * h + 4 * P + n_kp_img * 2178 + ((2 * n_kp_img * 60 + n_kp_img * 8) / 2 if stereo else 0)
+    survey_total = w * h + 4 * P + n_kp_img * 2178 + stereo_b + project_b
     return d, survey_total
+
+
+def host_cores():
+    try:
+        return len(os.sched_getaffinity(0))
+    except AttributeError:
+        return os.cpu_count() or 1
 
 
 def cpu_baseline(w, h, nfeatures, stereo, budget_s=10.0):
     """The CPU oracle (oracle/, kind 'port') on a bounded sample of the same synthetic stream, on this host:
     one thread (the headline `value`), two threads (the reference's own left/right arrangement, Frame.cc:84-87)
-    and up to 32 threads with one stereo pair per thread.  ctypes releases the GIL, so
-    the threads run the C oracle concurrently."""
+    and every core this process may run on, one stereo pair per thread.  ctypes releases
+    the GIL, so the threads run the C oracle concurrently."""
     from concurrent.futures import ThreadPoolExecutor
     from gf_orb_slam2_amd.synth import synth_stereo_pair
     from oracle import orb_oracle as O
@@ -111,8 +124,8 @@ def cpu_baseline(w, h, nfeatures, stereo, budget_s=10.0):
         for i in range(n2):
             one_pair(oe_l, oe_r, i, side)
         v2 = 2 * n2 / (time.perf_counter() - t0)
-    # all cores (capped at 32 threads): one pair per thread
-    nt = max(1, min(32, os.cpu_count() or 1))
+    # all cores this process may use: one pair per thread
+    nt = max(1, host_cores())
     exts = [(make(), make()) for _ in range(nt)]
     per = max(2, n1 // 4)
 
@@ -125,9 +138,143 @@ def cpu_baseline(w, h, nfeatures, stereo, budget_s=10.0):
         vn = 2 * per * nt / (time.perf_counter() - t0)
     return {"value": round(v1, 2), "unit": "frames/s", "cores": 1, "kind": "port",
             "sample": f"{n1} stereo pairs ({2 * n1} images) of the same {w}x{h} synthetic stream, oracle/orb_oracle.c, "
-                      f"single thread; {os.cpu_count()} host cores present",
+                      f"single thread; {os.cpu_count()} host cores present, {nt} usable by this process",
             "threads_2": round(v2, 2), "threads_n": {"threads": nt, "value": round(vn, 2)},
             "reference_published": "13.7-22.2 ms per stereo frame on unstated hardware (README.md:7-16) = 90-146 images/s"}
+
+
+class Job:
+    """One workload on this rank: input batches resident in HBM, `nctx` independent contexts (arena + HIP stream)
+    the steps alternate between, so the tail of one batch overlaps the head of the next."""
+
+    def __init__(self, G, torch, name, B, nctx, local_rank, rank, world, dist, n_inputs=4):
+        from gf_orb_slam2_amd.sharding import shard_pairs
+        from gf_orb_slam2_amd.synth import synth_local_map, synth_stereo_pair, synth_stream
+        self.G, self.torch, self.name, self.B, self.world, self.dist = G, torch, name, B, world, dist
+        self.w, self.h, self.nfeat, self.matcher, self.cfg_name = WORKLOADS[name]
+        w, h = self.w, self.h
+        offs = None
+        if self.matcher == "project":
+            frames, offs = synth_stream(w, h, B, idx=3 + rank)     # one scene per rank, a moving camera
+        else:
+            frames = []
+            for p in shard_pairs(rank, world, B // 2):             # distinct pairs per rank (independent streams)
+                l, r = synth_stereo_pair(w, h, p)
+                frames += [l, r]
+        base = np.stack(frames)
+        # several distinct input batches (vertical rolls of the first: new images for FAST, same disparities) so that
+        # consecutive steps do not re-read one batch out of the 256 MB Infinity Cache
+        self.host_batches = [base] + [np.roll(base, 37 * k, axis=1) for k in range(1, n_inputs)] if self.matcher != "project" else [base]
+        self.d_inputs = [torch.from_numpy(b).cuda() for b in self.host_batches]
+        self.L = G.load_library()
+        self.sp = G.StereoParams(h, BF, BF / FX, 0.0)
+        self.exts, self.matchers, self.streams, self.counts_ts, self.gathered = [], [], [], [], []
+        for k in range(nctx):
+            st = torch.cuda.Stream()
+            e = G.ORBextractor(self.nfeat, 1.2, 8, 20, 7, device=local_rank, max_batch=B)
+            e.set_stream(st.cuda_stream)
+            # first pass plans the arena; then bind the device-side count vector for the collective
+            e.extract_batch_device(self.d_inputs[0].data_ptr(), B, w, h)
+            p_kp, p_desc, p_cnt, stride = ctypes.c_void_p(), ctypes.c_void_p(), ctypes.c_void_p(), ctypes.c_int()
+            self.L.gfo_batch_device_views(e.handle, ctypes.byref(p_kp), ctypes.byref(p_desc), ctypes.byref(p_cnt), ctypes.byref(stride))
+            self.exts.append(e)
+            self.matchers.append(G.ORBmatcher(0.8, True, extractor=e))
+            self.streams.append(st)
+            self.counts_ts.append(torch.as_tensor(_DevArray(p_cnt.value, B), device="cuda"))
+            self.gathered.append(torch.zeros(world * B, dtype=torch.int32, device="cuda") if world > 1 else None)
+        self.bounds = (0.0, 0.0, float(w), float(h))
+        self.d_mps = None
+        if self.matcher == "project":
+            kp0, desc0 = self.exts[0].batch_fetch(0)
+            mpd, mps = synth_local_map(kp0, desc0, offs, w, h, MAP_POINTS, 4000, seed=7)
+            self.d_mps = torch.from_numpy(mps.view(np.uint8).reshape(B, -1)).cuda()   # [B][M] projections, resident
+            for m in self.matchers:
+                m.map_upload(mpd)                                                      # one resident map per context
+        self.step_no = 0
+        self.nctx = nctx
+
+    def step(self, ctx=None, h2d_from=None):
+        k = self.step_no % self.nctx if ctx is None else ctx
+        d_in = self.d_inputs[self.step_no % len(self.d_inputs)]
+        self.step_no += 1
+        if h2d_from is not None:   # PCIe-inclusive variant: the batch comes from pinned host memory first
+            with self.torch.cuda.stream(self.streams[k]):
+                d_in.copy_(h2d_from, non_blocking=True)
+        self.exts[k].extract_batch_device(d_in.data_ptr(), self.B, self.w, self.h)
+        if self.matcher == "stereo":
+            self.matchers[k].stereo_match_batch(self.sp)
+        elif self.matcher == "project":
+            self.matchers[k].search_by_projection_batch(self.d_mps.data_ptr(), self.bounds, th=3.0, device_ptrs=True)
+        if self.world > 1:
+            from gf_orb_slam2_amd.sharding import gather_counts
+            with self.torch.cuda.stream(self.streams[k]):
+                gather_counts(self.counts_ts[k], self.world, self.dist, self.gathered[k])
+
+    def timed(self, steps, warmup, barrier=True, **kw):
+        torch, dist, world = self.torch, self.dist, self.world
+        for _ in range(warmup):
+            self.step(**kw)
+        if world > 1 and barrier:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            self.step(**kw)
+        torch.cuda.synchronize()
+        if world > 1 and barrier:
+            dist.barrier()
+        dt = time.perf_counter() - t0
+        if world > 1 and barrier:
+            tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt = float(tt.item())
+        return dt
+
+    def profile(self, nsteps):
+        """per-kernel device time from HIP events on the launch stream, context 0 alone (clean per-kernel durations)"""
+        ext = self.exts[0]
+        ext.profile_enable(True)
+        for _ in range(max(1, nsteps)):
+            self.step(ctx=0)
+        self.torch.cuda.synchronize()
+        prof = ext.profile_read()
+        ext.profile_enable(False)
+        return prof
+
+    def roofline(self, prof, nsteps, value_per_gpu, traffic_workload):
+        counts = self.exts[0].batch_counts(self.B)
+        n_kp_img = float(counts.mean())
+        sizes = level_sizes(self.w, self.h, self.exts[0].GetInverseScaleFactors())
+        per_img, survey_total = algorithmic_bytes(self.w, self.h, sizes, n_kp_img, self.matcher)
+        stage_ms = {k: v[0] / max(1, nsteps) for k, v in prof.items() if v[1] > 0}
+        dom = max(stage_ms, key=stage_ms.get)
+        dom_ms_total, dom_launches = prof[dom]
+        avg_launch_ms = dom_ms_total / dom_launches
+        launches_per_step = dom_launches / max(1, nsteps)
+        bytes_per_launch = per_img[dom] * self.B / launches_per_step
+        achieved = bytes_per_launch / (avg_launch_ms * 1e-3) / 1e9
+        traffic, traffic_source = None, None
+        tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
+        if os.path.exists(tpath):
+            try:
+                tj = json.load(open(tpath))
+                if tj.get("workload") == traffic_workload and tj.get("batch") == self.B:
+                    traffic = tj.get("hbm_bytes_per_launch", {}).get(dom)
+                    traffic_source = f"profiles/traffic_{tj.get('tag')}.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of an earlier run of this command; not measured in this run)"
+            except Exception:
+                traffic = None
+        return n_kp_img, {
+            "bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": 8000.0, "unit": "GB/s",
+            "frac": round(achieved / 8000.0, 5), "traffic": traffic, "traffic_source": traffic_source,
+            "avg_launch_ms": round(avg_launch_ms, 4), "algorithmic_bytes_per_launch": int(bytes_per_launch),
+            "pipeline_frac_hbm": round(value_per_gpu * survey_total / 8e12, 5),
+            "stage_ms_per_step": {k: round(v, 4) for k, v in stage_ms.items()}}
+
+    def close(self):
+        for e in self.exts:
+            e.close()
+        self.d_inputs = None
+        self.d_mps = None
 
 
 def main():
@@ -138,6 +285,7 @@ def main():
     ap.add_argument("--batch", type=int, default=128, help="images per GPU per step (even)")
     ap.add_argument("--workload", default="stereo752", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-other-configs", action="store_true", help="skip the short passes over the other BASELINE configs")
     ap.add_argument("--profile-steps", type=int, default=3)
     ap.add_argument("--streams", type=int, default=3,
                     help="independent contexts (arena + HIP stream) the steps alternate between, so the tail of one "
@@ -158,119 +306,94 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     import gf_orb_slam2_amd as G
-    from gf_orb_slam2_amd.sharding import gather_counts, shard_pairs
-    from gf_orb_slam2_amd.synth import synth_stereo_pair
 
-    w, h, nfeat, stereo, cfg_name = WORKLOADS[args.workload]
     B = args.batch - (args.batch & 1)
-    # distinct synthetic pairs per rank (frame index continues across ranks: independent streams)
-    frames = []
-    for p in shard_pairs(rank, world, B // 2):
-        l, r = synth_stereo_pair(w, h, p)
-        frames += [l, r]
-    d_imgs = torch.from_numpy(np.stack(frames)).cuda()
-
     nctx = max(1, args.streams)
-    L = G.load_library()
-    sp = G.StereoParams(h, BF, BF / FX, 0.0)
-    exts, matchers, streams, counts_ts, gathered = [], [], [], [], []
-    for k in range(nctx):
-        st = torch.cuda.Stream()
-        e = G.ORBextractor(nfeat, 1.2, 8, 20, 7, device=local_rank, max_batch=B)
-        e.set_stream(st.cuda_stream)
-        # first pass plans the arena; then bind the device-side count vector for the collective
-        e.extract_batch_device(d_imgs.data_ptr(), B, w, h)
-        p_kp, p_desc, p_cnt, stride = ctypes.c_void_p(), ctypes.c_void_p(), ctypes.c_void_p(), ctypes.c_int()
-        L.gfo_batch_device_views(e.handle, ctypes.byref(p_kp), ctypes.byref(p_desc), ctypes.byref(p_cnt), ctypes.byref(stride))
-        exts.append(e)
-        matchers.append(G.ORBmatcher(0.8, True, extractor=e))
-        streams.append(st)
-        counts_ts.append(torch.as_tensor(_DevArray(p_cnt.value, B), device="cuda"))
-        gathered.append(torch.zeros(world * B, dtype=torch.int32, device="cuda") if world > 1 else None)
-    ext = exts[0]
-    step_no = [0]
+    job = Job(G, torch, args.workload, B, nctx, local_rank, rank, world, dist)
+    dt = job.timed(args.steps, args.warmup)
+    total_frames = world * B * args.steps
+    value = total_frames / dt
 
-    def step():
-        k = step_no[0] % nctx
-        step_no[0] += 1
-        exts[k].extract_batch_device(d_imgs.data_ptr(), B, w, h)
-        if stereo:
-            matchers[k].stereo_match_batch(sp)
-        if world > 1:
-            with torch.cuda.stream(streams[k]):
-                gather_counts(counts_ts[k], world, dist, gathered[k])
+    # a timed region shorter than half a second says little about a sustained rate: repeat for >= 1 s
+    sustained = None
+    if dt < 0.5:
+        n_s = int(min(20000, max(args.steps, 1.2 / max(dt / args.steps, 1e-6))))
+        dts = job.timed(n_s, 0)
+        sustained = {"value": round(world * B * n_s / dts, 1), "seconds": round(dts, 3), "steps": n_s}
 
-    for _ in range(args.warmup):
-        step()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
+    extra = {}
+    if world == 1:
+        # PCIe-inclusive rate (never `value`): every step first copies its batch from pinned host memory
+        pinned = torch.from_numpy(job.host_batches[0]).pin_memory()
+        n_h = max(5, min(args.steps, 30))
+        dth = job.timed(n_h, 2, h2d_from=pinned)
+        extra["value_with_h2d"] = round(B * n_h / dth, 1)
+        del pinned
+        # median of 20 single batches, one context, each batch synchronised
+        lat = []
+        for _ in range(20):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            job.step(ctx=0)
+            torch.cuda.synchronize()
+            lat.append(time.perf_counter() - t0)
+        extra["median_of_20"] = {"ms_per_batch": round(float(np.median(lat)) * 1e3, 4), "value": round(B / float(np.median(lat)), 1),
+                                 "note": "one context, every batch synchronised (no overlap between batches)"}
 
-    counts = ext.batch_counts(B)
-    n_kp_img = float(counts.mean())
-
-    # ---- per-kernel device time, HIP events on the launch stream (untimed extra steps) ----
-    step_no[0] = 0
-    nctx = 1                      # the profiled steps run alone on context 0: clean per-kernel durations
-    ext.profile_enable(True)
-    for _ in range(max(1, args.profile_steps)):
-        step()
-    torch.cuda.synchronize()
-    prof = ext.profile_read()
-    ext.profile_enable(False)
-
+    prof = job.profile(args.profile_steps)
+    line = None
     if rank == 0:
-        sizes = level_sizes(w, h, ext.GetInverseScaleFactors())
-        per_img, survey_total = algorithmic_bytes(w, h, sizes, n_kp_img, stereo)
-        stage_ms = {k: v[0] / max(1, args.profile_steps) for k, v in prof.items() if v[1] > 0}
-        dom = max(stage_ms, key=stage_ms.get)
-        dom_ms_total, dom_launches = prof[dom]
-        avg_launch_ms = dom_ms_total / dom_launches
-        launches_per_step = dom_launches / max(1, args.profile_steps)
-        bytes_per_launch = per_img[dom] * B / launches_per_step
-        achieved = bytes_per_launch / (avg_launch_ms * 1e-3) / 1e9
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
-        if os.path.exists(tpath):
-            try:
-                tj = json.load(open(tpath))
-                if tj.get("workload") == args.workload and tj.get("batch") == B:
-                    traffic = tj.get("hbm_bytes_per_launch", {}).get(dom)
-            except Exception:
-                traffic = None
-        total_frames = world * B * args.steps
-        value = total_frames / dt
+        n_kp_img, roof = job.roofline(prof, args.profile_steps, value / world, args.workload)
+        stereo = job.matcher == "stereo"
         line = {
             "metric": "frames/sec ORB extract+match, 752x480 @2000 kp" if args.workload == "stereo752" else f"frames/sec ORB {args.workload}",
             "value": round(value, 1), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-            "config": {"workload": cfg_name, "frame": "one camera image (a stereo pair = 2 frames + 1 association)",
+            "config": {"workload": job.cfg_name, "frame": "one camera image (a stereo pair = 2 frames + 1 association)",
                        "images_per_step_per_gpu": B, "stereo_pairs_per_s": round(value / 2, 1) if stereo else None,
-                       "width": w, "height": h, "nfeatures": nfeat, "levels": 8, "scale_factor": 1.2, "fast_th": [20, 7],
-                       "mean_keypoints_per_image": round(n_kp_img, 1), "contexts_per_gpu": max(1, args.streams), "sharding": f"{world} x independent streams, RCCL all-gather of counts" if world > 1 else "single GPU"},
-            "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": 8000.0, "unit": "GB/s",
-                         "frac": round(achieved / 8000.0, 5), "traffic": traffic,
-                         "avg_launch_ms": round(avg_launch_ms, 4), "algorithmic_bytes_per_launch": int(bytes_per_launch),
-                         "pipeline_frac_hbm": round(value / world * survey_total / 8e12, 5),
-                         "stage_ms_per_step": {k: round(v, 4) for k, v in stage_ms.items()}},
+                       "width": job.w, "height": job.h, "nfeatures": job.nfeat, "levels": 8, "scale_factor": 1.2, "fast_th": [20, 7],
+                       "map_points": MAP_POINTS if job.matcher == "project" else None,
+                       "mean_keypoints_per_image": round(n_kp_img, 1), "contexts_per_gpu": nctx,
+                       "distinct_input_batches": len(job.d_inputs),
+                       "sharding": f"{world} x independent streams, RCCL all-gather of counts" if world > 1 else "single GPU"},
+            "roofline": roof,
         }
+        if sustained:
+            line["sustained"] = sustained
+        line.update(extra)
+    job.close()
+    del job
+    torch.cuda.empty_cache()
+
+    # ---- the other BASELINE configs, short passes, same line ----
+    if world == 1 and not args.no_other_configs:
+        others = []
+        for name in ("extract752", "extract1080", "proj1080", "stereo752"):
+            if name == args.workload:
+                continue
+            try:
+                ob = 64 if WORKLOADS[name][0] > 1000 else B
+                j = Job(G, torch, name, ob, nctx, local_rank, rank, world, dist, n_inputs=2)
+                steps_o = 20
+                dto = j.timed(steps_o, 3)
+                vo = ob * steps_o / dto
+                p = j.profile(2)
+                _, roof_o = j.roofline(p, 2, vo, name)
+                others.append({"workload": j.cfg_name, "name": name, "value": round(vo, 1), "unit": "frames/s", "images_per_step": ob,
+                               "steps": steps_o, "ms_per_step": round(dto / steps_o * 1e3, 4), "roofline": roof_o})
+                j.close()
+                del j
+                torch.cuda.empty_cache()
+            except Exception as ex:   # a failing side measurement must not lose the headline line
+                others.append({"name": name, "error": repr(ex)})
+        line["other_configs"] = others
+
+    if rank == 0:
         if not args.no_cpu_baseline and world == 1:
-            line["cpu_baseline"] = cpu_baseline(w, h, nfeat, stereo)
+            w, h, nfeat, matcher, _ = WORKLOADS[args.workload]
+            line["cpu_baseline"] = cpu_baseline(w, h, nfeat, matcher == "stereo")
         print(json.dumps(line), flush=True)
-    for e in exts:
-        e.close()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

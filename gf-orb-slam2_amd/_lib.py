@@ -40,6 +40,11 @@ class VocabularyC(C.Structure):
                 ("weight", C.c_void_p), ("n_nodes", C.c_int32), ("depth", C.c_int32)]
 
 
+class ProjectionBatchC(C.Structure):
+    _fields_ = [("mps", C.c_void_p), ("kp_taken", C.c_void_p), ("on_device", C.c_int32), ("stereo", C.c_int32),
+                ("th", C.c_float), ("nn_ratio", C.c_float), ("bounds", FrameBoundsC)]
+
+
 class ProjModeC(C.Structure):
     _fields_ = [("use_ratio", C.c_int32), ("nn_ratio", C.c_float), ("th_dist", C.c_int32), ("check_orientation", C.c_int32)]
 
@@ -58,7 +63,8 @@ SYMBOLS = [
     "gfo_ctx_synchronize", "gfo_ctx_tables", "gfo_ctx_max_keypoints", "gfo_extract", "gfo_extract_batch",
     "gfo_extract_batch_device", "gfo_batch_counts", "gfo_batch_fetch", "gfo_batch_device_views",
     "gfo_compute_pyramid", "gfo_pyramid_level", "gfo_hamming256", "gfo_stereo_match",
-    "gfo_stereo_match_batch", "gfo_stereo_match_sad_batch", "gfo_stereo_fetch", "gfo_search_by_projection", "gfo_search_by_projection_queries", "gfo_search_by_bow", "gfo_vocabulary_upload", "gfo_bow_transform", "gfo_profile_enable",
+    "gfo_stereo_match_batch", "gfo_stereo_match_sad_batch", "gfo_stereo_fetch", "gfo_search_by_projection", "gfo_search_by_projection_queries",
+    "gfo_map_upload", "gfo_search_by_projection_batch", "gfo_projection_fetch", "gfo_projection_device_views", "gfo_search_by_bow", "gfo_vocabulary_upload", "gfo_bow_transform", "gfo_profile_enable",
     "gfo_profile_read", "gfo_debug_blurred_level", "gfo_debug_level_candidates",
 ]
 
@@ -130,6 +136,10 @@ def load_library():
     L.gfo_search_by_projection.argtypes = [vp, vp, vp, vp, i, vp, i, C.POINTER(FrameBoundsC), vp, vp, i, f, f, vp, vp, vp, ip]
     L.gfo_search_by_projection_queries.argtypes = [vp, vp, vp, vp, vp, i, C.POINTER(FrameBoundsC), vp, vp, i, C.POINTER(ProjModeC),
                                                    vp, vp, vp, ip]
+    L.gfo_map_upload.argtypes = [vp, vp, i]
+    L.gfo_search_by_projection_batch.argtypes = [vp, C.POINTER(ProjectionBatchC)]
+    L.gfo_projection_fetch.argtypes = [vp, i, vp, vp, i, ip]
+    L.gfo_projection_device_views.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), ip, ip]
     L.gfo_search_by_bow.argtypes = [vp, vp, vp, vp, i, C.POINTER(FeatureVectorC), vp, vp, i, C.POINTER(FeatureVectorC), f, i, vp, ip]
     L.gfo_vocabulary_upload.argtypes = [vp, C.POINTER(VocabularyC)]
     L.gfo_bow_transform.argtypes = [vp, vp, i, i, vp, vp, vp]

@@ -514,6 +514,8 @@ extern "C" void gfo_ctx_destroy(gfo_ctx* c)
     free_arena(c);
     if (c->d_scratch) (void)hipFree(c->d_scratch);
     if (c->d_voc) (void)hipFree(c->d_voc);
+    if (c->pj.base) (void)hipFree(c->pj.base);
+    if (c->d_map_desc) (void)hipFree(c->d_map_desc);
     if (c->side_stream) {
         (void)hipStreamSynchronize(c->side_stream);
         (void)hipStreamDestroy(c->side_stream);
@@ -628,6 +630,7 @@ static int run_extract(gfo_ctx* c, const GfoInput& in, int nimg)
     HIP_TRY(c, hipGetLastError());
     c->have_batch = true;
     c->have_stereo = false;
+    c->have_projection = false;
     return GFO_OK;
 }
 

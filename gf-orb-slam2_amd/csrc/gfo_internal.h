@@ -114,6 +114,23 @@ struct GfoStereoLaunch {
     int window;
 };
 
+// work buffers of the batched projection search (k_project.hip), one block per frame
+struct GfoProjBuf {
+    void* base = nullptr;
+    int frames_cap = 0, m_cap = 0, n_cap = 0;
+    int* cell_start = nullptr;
+    void* cell_xy = nullptr;
+    unsigned* cell_meta = nullptr;
+    int* pick = nullptr;
+    int* pick_dist = nullptr;
+    unsigned* live = nullptr;
+    int* rot_bin = nullptr;
+    int* tab_g = nullptr;
+    int* counters = nullptr;
+    int* out_mp = nullptr;
+    int* out_score = nullptr;
+};
+
 enum GfoStage {
     ST_RESIZE = 0, ST_BLUR, ST_FAST, ST_QUADTREE, ST_ORIENT_DESC, ST_STEREO_BUCKET, ST_STEREO, ST_STEREO_CUT,
     ST_PROJECT, ST_BOW, ST_COUNT
@@ -186,6 +203,12 @@ struct gfo_ctx {
     void* d_scratch = nullptr;
     size_t scratch_bytes = 0;
     int last_project_rounds = 0;
+    // batched projection search: resident local-map descriptors + per-frame work buffers
+    GfoProjBuf pj{};
+    uint8_t* d_map_desc = nullptr;
+    int map_cap = 0, map_m = 0;
+    bool have_projection = false;
+    int proj_frames = 0, proj_step = 1;
     // resident vocabulary tree (gfo_vocabulary_upload)
     void* d_voc = nullptr;
     size_t voc_desc_off = 0, voc_fc_off = 0, voc_nc_off = 0, voc_wid_off = 0, voc_w_off = 0;

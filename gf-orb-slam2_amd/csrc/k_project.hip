@@ -1,77 +1,129 @@
 // k_project.hip -- Frame::AssignFeaturesToGrid / GetFeaturesInArea (Frame.cc:461-476, 593-658) and
-// ORBmatcher::SearchByProjection(Frame&, const vector<MapPoint*>&, th) (ORBmatcher.cc:155-249).
+// ORBmatcher::SearchByProjection, both overloads (ORBmatcher.cc:155-249 map points, :1440-1593 frame to frame),
+// for a BATCH of frames in three launches, nothing returning to the host in between:
 //
-// The reference is ORDER-DEPENDENT: map points are visited in vector order, every accepted match
-// writes F.mvpMapPoints[bestIdx], and later map points skip keypoints already taken by a point with
-// observations (ORBmatcher.cc:197-199, 233).  The device version reproduces the serial result exactly
-// with a Jacobi fixed-point iteration:
-//   state  = each map point's tentative pick;
-//   update = every map point i re-evaluates its candidates treating keypoint k as taken iff it was
-//            taken on entry or some map point j < i (with observations) currently picks k;
-//   the serial answer is the unique fixed point, map point i is final after at most (its rank among
-//   the matching points) rounds, and "nothing changed in a round" proves convergence.
-// Points whose best distance exceeds TH_HIGH under the entry state can never match (more blocking only
-// removes candidates), so only the few thousand "live" points are re-evaluated after round 0.
+//   k_proj_grid     one workgroup per frame: the 64x48 grid as a CSR whose items carry (x, y) and
+//                   index | octave << 16 | cell row << 24, so a candidate costs one 12-byte sequential read
+//   k_proj_round0   one THREAD per projected point (a 50 000-point local map against 4000 keypoints leaves
+//                   0-3 candidates per point: a wavefront per point would idle 60 lanes): every point is
+//                   evaluated against the entry state; points that can ever match go to the frame's live list
+//   k_proj_resolve  one workgroup per frame: the order dependence, resolved in LDS (below), then the owner /
+//                   score / rotation-histogram epilogue
 //
-// Candidate order matters only for ties (strict '<' keeps the first candidate, :212-225).  The
-// reference iterates cells (ix, iy) then the cell's list in keypoint order, so "first" is the minimum
-// of (dist, ix, iy, idx): candidates can be scanned in any order with that 64-bit key, and the
-// best / second-best pair is the two smallest keys (a stable sort by distance).
+// The reference is ORDER-DEPENDENT: points are visited in vector order, every accepted match writes
+// F.mvpMapPoints[bestIdx], and later points skip keypoints already taken by a point with observations
+// (ORBmatcher.cc:197-199, 233).  The device version reproduces the serial result exactly with a fixed-point
+// iteration:
+//   state  = each live point's tentative pick;
+//   update = every point i re-evaluates its candidates treating keypoint k as taken iff it was taken on entry
+//            or some point j < i (with observations) currently picks k (claim table: atomicMin per keypoint);
+//   the serial answer is the unique fixed point, point i is final after at most (its rank among the matching
+//   points) rounds, and "nothing changed in a round" proves convergence.
+// Points whose best distance exceeds the threshold under the entry state can never match (more blocking only
+// removes candidates), so only the few thousand live points are re-evaluated after round 0.
+//
+// Candidate order matters only for ties (strict '<' keeps the first candidate, :212-225).  The reference
+// iterates cells (ix, iy) then the cell's list in keypoint order, so "first" is the minimum of
+// (dist, ix, iy, idx): candidates can be scanned in any order with that 64-bit key, and the best /
+// second-best pair is the two smallest keys (a stable sort by distance).
 #include "gfo_internal.h"
 
 #define GRID_COLS 64   // FRAME_GRID_COLS, Frame.h:92
 #define GRID_ROWS 48   // FRAME_GRID_ROWS, Frame.h:93
 #define NCELL (GRID_COLS * GRID_ROWS)
 #define TH_HIGH 100    // ORBmatcher.cc:57
+#define HISTO_LENGTH 30  // ORBmatcher.cc:59
 
-struct ProjArgs {
-    const gfo_keypoint* kp;
-    const uint8_t* desc;
-    const float* u_right;     // may be null
-    const uint8_t* taken0;    // may be null
-    int n;
+enum { PJ_NLIVE = 0, PJ_ROUNDS = 1, PJ_NMATCH = 2, PJ_ERR = 3, PJ_CNT = 8 };
+
+// Everything is [frame][...]: frame f of a per-frame array starts at base + f * stride (stride 0 = shared).
+struct ProjB {
+    const gfo_keypoint* kp; long long kp_stride;     // elements
+    const uint8_t* desc;                              // [frame][kp_stride][32]
+    const float* u_right; long long ur_stride;        // may be null
+    const uint8_t* taken0; long long tk_stride;       // may be null
+    const float* kp_angle; long long ang_stride;      // rotation check; null = kp[i].angle
+    const int* n_dev; int n_dev_stride; int n_host;   // keypoints of frame f = n_dev ? n_dev[f * n_dev_stride] : n_host
     gfo_frame_bounds fb;
     float inv_w, inv_h;
-    const gfo_proj_query* q;  // one per projected map point, in the reference's visiting order
-    const uint8_t* mp_desc;
+    // projected points: form 0 = gfo_proj_query, form 1 = gfo_map_point (turned into a query on the fly)
+    int form;
+    const void* q; long long q_stride;                // elements per frame
+    const uint8_t* q_desc; long long qd_stride;       // bytes per frame (0: the resident map, shared)
     int m;
-    int use_ratio;
-    float nn_ratio;
-    int th_dist;
-    const float* kp_angle;    // rotation check only
-    int* rot_bin;             // [m] histogram bin of an accepted query, -1 otherwise
-    // grid
-    int* cell_start;          // [NCELL+1]
-    int* cell_items;          // [n]
-    unsigned short* kp_cell;  // [n] ix<<8|iy, 0xFFFF = outside
-    // state
-    int* pick;                // [m] keypoint index or -1
-    int* pick_dist;           // [m]
-    int* live;                // [m] compacted indices of live map points
-    int* counters;            // [0] n_live, [1] changed, [2] nmatches
-    int* block_by;            // [n] lowest live map point (with observations) currently picking k
-    int* out_mp;              // [n]
-    int* out_score;           // [n]
+    float th; int bfactor; float scale[GFO_MAX_LEVELS]; int nlevels;   // form 1: r * mvScaleFactors[level]
+    int use_ratio; float nn_ratio; int th_dist; int check_ori;
+    // per-frame scratch
+    int n_cap;                 // stride of the per-keypoint arrays
+    int* cell_start;           // [NCELL + 1]
+    float2* cell_xy;           // [n_cap] keypoint position, in cell order
+    unsigned* cell_meta;       // [n_cap] index | octave << 16 | cell row << 24
+    int* pick;                 // [m] keypoint picked by a live point, -1 none
+    int* pick_dist;            // [m]
+    unsigned* live;            // [m] live point | has-observations << 31
+    int* rot_bin;              // [m]
+    int* tab_g;                // [n_cap] claim / owner table when it does not fit LDS
+    int* counters;             // [PJ_CNT]
+    int* out_mp; int* out_score;   // [n_cap]
 };
 
-// one workgroup builds the whole grid (N <= 65535)
-__global__ __launch_bounds__(1024) void k_grid_build(ProjArgs a)
+struct ProjQ {
+    float u, v, ur, radius, angle;
+    int min_level, max_level;
+    bool active, obs;
+};
+
+__device__ __forceinline__ ProjQ load_query(const ProjB& a, int f, int iq)
+{
+    ProjQ r;
+    if (a.form == 0) {
+        const gfo_proj_query p = reinterpret_cast<const gfo_proj_query*>(a.q)[(long long)f * a.q_stride + iq];
+        r.u = p.u; r.v = p.v; r.ur = p.ur; r.radius = p.radius; r.angle = p.angle;
+        r.min_level = p.min_level; r.max_level = p.max_level;
+        r.active = (p.flags & 1) != 0;
+        r.obs = (p.flags & 4) != 0;
+    } else {
+        // ORBmatcher.cc:163-180: mbTrackInView && !isBad(); r = RadiusByViewingCos(viewCos) [* th];
+        // window r * mvScaleFactors[level], levels [level - 1, level]
+        const gfo_map_point p = reinterpret_cast<const gfo_map_point*>(a.q)[(long long)f * a.q_stride + iq];
+        const int lvl = p.level;
+        const bool lvl_ok = lvl >= 0 && lvl < a.nlevels;
+        float rr = (double)p.view_cos > 0.998 ? 2.5f : 4.0f;   // RadiusByViewingCos, :243-249
+        if (a.bfactor) rr *= a.th;
+        r.u = p.proj_x; r.v = p.proj_y; r.ur = p.proj_xr; r.angle = 0.f;
+        r.radius = lvl_ok ? rr * a.scale[lvl] : 0.f;
+        r.min_level = lvl - 1; r.max_level = lvl;
+        r.active = (p.flags & 1) && !(p.flags & 2) && lvl_ok;
+        r.obs = (p.flags & 4) != 0;
+    }
+    return r;
+}
+
+__device__ __forceinline__ int frame_n(const ProjB& a, int f)
+{
+    int n = a.n_dev ? a.n_dev[(long long)f * a.n_dev_stride] : a.n_host;
+    return n < 0 ? 0 : (n > a.n_cap ? a.n_cap : n);
+}
+
+// one workgroup builds one frame's grid (N <= 65535); it also clears the frame's counters
+__global__ __launch_bounds__(1024) void k_proj_grid(ProjB a)
 {
     __shared__ int s_cnt[NCELL];
     __shared__ int s_part[1024];
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, f = blockIdx.x;
+    const int n = frame_n(a, f);
+    const gfo_keypoint* kp = a.kp + (long long)f * a.kp_stride;
+    int* cell_start = a.cell_start + (long long)f * (NCELL + 1);
+    float2* cell_xy = a.cell_xy + (long long)f * a.n_cap;
+    unsigned* cell_meta = a.cell_meta + (long long)f * a.n_cap;
+    if (tid < PJ_CNT) a.counters[f * PJ_CNT + tid] = 0;
     for (int c = tid; c < NCELL; c += 1024) s_cnt[c] = 0;
     __syncthreads();
-    for (int i = tid; i < a.n; i += 1024) {
+    for (int i = tid; i < n; i += 1024) {
         // Frame::PosInGrid, Frame.cc:648-658 (round half away from zero)
-        const int px = (int)roundf((a.kp[i].x - a.fb.min_x) * a.inv_w);
-        const int py = (int)roundf((a.kp[i].y - a.fb.min_y) * a.inv_h);
-        unsigned short cell = 0xFFFF;
-        if (!(px < 0 || px >= GRID_COLS || py < 0 || py >= GRID_ROWS)) {
-            cell = (unsigned short)((px << 8) | py);
-            atomicAdd(&s_cnt[px * GRID_ROWS + py], 1);
-        }
-        a.kp_cell[i] = cell;
+        const int px = (int)roundf((kp[i].x - a.fb.min_x) * a.inv_w);
+        const int py = (int)roundf((kp[i].y - a.fb.min_y) * a.inv_h);
+        if (!(px < 0 || px >= GRID_COLS || py < 0 || py >= GRID_ROWS)) atomicAdd(&s_cnt[px * GRID_ROWS + py], 1);
     }
     __syncthreads();
     // exclusive scan of 3072 counters: 3 per thread
@@ -87,15 +139,21 @@ __global__ __launch_bounds__(1024) void k_grid_build(ProjArgs a)
     }
     int run = s_part[tid] - s;
     for (int k = 0; k < 3; k++) {
-        a.cell_start[tid * 3 + k] = run;
+        cell_start[tid * 3 + k] = run;
         s_cnt[tid * 3 + k] = run;   // becomes the fill cursor
         run += loc[k];
     }
-    if (tid == 1023) a.cell_start[NCELL] = run;
+    if (tid == 1023) cell_start[NCELL] = run;
     __syncthreads();
-    for (int i = tid; i < a.n; i += 1024) {
-        const unsigned short cell = a.kp_cell[i];
-        if (cell != 0xFFFF) a.cell_items[atomicAdd(&s_cnt[(cell >> 8) * GRID_ROWS + (cell & 0xFF)], 1)] = i;
+    for (int i = tid; i < n; i += 1024) {
+        const gfo_keypoint k = kp[i];
+        const int px = (int)roundf((k.x - a.fb.min_x) * a.inv_w);
+        const int py = (int)roundf((k.y - a.fb.min_y) * a.inv_h);
+        if (px < 0 || px >= GRID_COLS || py < 0 || py >= GRID_ROWS) continue;
+        const int slot = atomicAdd(&s_cnt[px * GRID_ROWS + py], 1);
+        cell_xy[slot] = make_float2(k.x, k.y);
+        // octaves outside 0..255 cannot come out of the extractor; host arrays are checked at the ABI
+        cell_meta[slot] = (unsigned)i | ((unsigned)(k.octave & 0xFF) << 16) | ((unsigned)py << 24);
     }
 }
 
@@ -106,74 +164,68 @@ __device__ __forceinline__ int hamming_u4(const uint4 a0, const uint4 a1, const 
            __popc(a1.x ^ b1.x) + __popc(a1.y ^ b1.y) + __popc(a1.z ^ b1.z) + __popc(a1.w ^ b1.w);
 }
 
-// One wavefront evaluates one map point.  round0: all map points, builds the live list.
-template <bool ROUND0>
-__global__ __launch_bounds__(256) void k_project_eval(ProjArgs a)
+// Evaluates one projected point against the frame's grid.  ROUND0: only the entry state blocks; otherwise a
+// keypoint is also blocked when the claim table names a lower-indexed point.  TABG: the table lives in HBM and is
+// read past the L1 (other waves of the workgroup update it with L2 atomics).
+template <bool ROUND0, bool TABG>
+__device__ __forceinline__ void eval_point(const ProjB& a, int f, int n, int iq, const ProjQ& q, const int* tab,
+                                           int* out_pick, int* out_dist, bool* out_live)
 {
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;  // uniform: keep it scalar
-    const int slot = blockIdx.x * 4 + wave;
-    int iMP;
-    if (ROUND0) {
-        if (slot >= a.m) return;
-        iMP = slot;
-    } else {
-        if (slot >= a.counters[0]) return;
-        iMP = a.live[slot];
-    }
-    const gfo_proj_query mp = a.q[iMP];
     int new_pick = -1, new_dist = 256;
     bool is_live = false;
-    if (mp.flags & 1) {  // visible and usable (mbTrackInView && !isBad(), :163-167 / :1467-1490)
-        const float rs = mp.radius;
+    if (q.active) {
+        const float rs = q.radius, x = q.u, y = q.v;
         // GetFeaturesInArea(u, v, rs, minLevel, maxLevel), Frame.cc:593-646
-        const float x = mp.u, y = mp.v;
-        const int minLevel = mp.min_level, maxLevel = mp.max_level;
-        int cx0 = max(0, (int)floorf((x - a.fb.min_x - rs) * a.inv_w));
-        int cx1 = min(GRID_COLS - 1, (int)ceilf((x - a.fb.min_x + rs) * a.inv_w));
-        int cy0 = max(0, (int)floorf((y - a.fb.min_y - rs) * a.inv_h));
-        int cy1 = min(GRID_ROWS - 1, (int)ceilf((y - a.fb.min_y + rs) * a.inv_h));
+        const int cx0 = max(0, (int)floorf((x - a.fb.min_x - rs) * a.inv_w));
+        const int cx1 = min(GRID_COLS - 1, (int)ceilf((x - a.fb.min_x + rs) * a.inv_w));
+        const int cy0 = max(0, (int)floorf((y - a.fb.min_y - rs) * a.inv_h));
+        const int cy1 = min(GRID_ROWS - 1, (int)ceilf((y - a.fb.min_y + rs) * a.inv_h));
         if (!(cx0 >= GRID_COLS || cx1 < 0 || cy0 >= GRID_ROWS || cy1 < 0)) {
-            const bool check_levels = (minLevel > 0) || (maxLevel >= 0);
-            const uint4* dmp = reinterpret_cast<const uint4*>(a.mp_desc + (long long)iMP * 32);
-            const uint4 a0 = dmp[0], a1 = dmp[1];
+            const bool check_levels = (q.min_level > 0) || (q.max_level >= 0);
+            const int* cell_start = a.cell_start + (long long)f * (NCELL + 1);
+            const float2* cell_xy = a.cell_xy + (long long)f * a.n_cap;
+            const unsigned* cell_meta = a.cell_meta + (long long)f * a.n_cap;
+            const uint8_t* desc = a.desc + (long long)f * a.kp_stride * 32;
+            const float* u_right = a.u_right ? a.u_right + (long long)f * a.ur_stride : nullptr;
+            const uint8_t* taken0 = a.taken0 ? a.taken0 + (long long)f * a.tk_stride : nullptr;
+            uint4 a0 = make_uint4(0, 0, 0, 0), a1 = a0;
+            bool have_desc = false;
             unsigned long long k1 = ~0ull, k2 = ~0ull;  // two smallest (dist, ix, iy, idx) keys
             for (int ix = cx0; ix <= cx1; ix++) {
                 // cells (ix, cy0..cy1) are contiguous in the CSR
-                const int beg = max(a.cell_start[ix * GRID_ROWS + cy0], 0);
-                const int end = min(a.cell_start[ix * GRID_ROWS + cy1 + 1], a.n);  // bounded by the keypoint count whatever the table holds
-                for (int j = beg + lane; j < end; j += 64) {
-                    const int i = a.cell_items[j];
-                    const gfo_keypoint kp = a.kp[i];
+                const int beg = cell_start[ix * GRID_ROWS + cy0];
+                const int end = cell_start[ix * GRID_ROWS + cy1 + 1];
+                for (int j = beg; j < end; j++) {
+                    const float2 p = cell_xy[j];
+                    if (!(fabsf(p.x - x) < rs && fabsf(p.y - y) < rs)) continue;
+                    const unsigned meta = cell_meta[j];
+                    const int oct = (int)((meta >> 16) & 0xFF);
                     if (check_levels) {
-                        if (kp.octave < minLevel) continue;
-                        if (maxLevel >= 0 && kp.octave > maxLevel) continue;
+                        if (oct < q.min_level) continue;
+                        if (q.max_level >= 0 && oct > q.max_level) continue;
                     }
-                    if (!(fabsf(kp.x - x) < rs && fabsf(kp.y - y) < rs)) continue;
+                    const int i = (int)(meta & 0xFFFF);
                     // F.mvpMapPoints[idx] with Observations() > 0, :197-199
-                    bool blocked = a.taken0 && a.taken0[i];
-                    if (!ROUND0) blocked = blocked || a.block_by[i] < iMP;
-                    if (blocked) continue;
-                    if (a.u_right && a.u_right[i] > 0) {  // :201-206
-                        const float er = fabsf(mp.ur - a.u_right[i]);
-                        if (er > rs) continue;
+                    if (taken0 && taken0[i]) continue;
+                    if (!ROUND0) {
+                        const int claim = TABG ? __hip_atomic_load(&tab[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : tab[i];
+                        if (claim < iq) continue;
                     }
-                    const unsigned dist = (unsigned)hamming_u4(a0, a1, reinterpret_cast<const uint4*>(a.desc + (long long)i * 32));
-                    const unsigned iy = a.kp_cell[i] & 0xFF;
+                    if (u_right) {  // :201-206
+                        const float ur = u_right[i];
+                        if (ur > 0 && fabsf(q.ur - ur) > rs) continue;
+                    }
+                    if (!have_desc) {
+                        const uint4* dq = reinterpret_cast<const uint4*>(a.q_desc + (long long)f * a.qd_stride + (long long)iq * 32);
+                        a0 = dq[0]; a1 = dq[1];
+                        have_desc = true;
+                    }
+                    const unsigned dist = (unsigned)hamming_u4(a0, a1, reinterpret_cast<const uint4*>(desc + (long long)i * 32));
                     const unsigned long long key = ((unsigned long long)dist << 32) | ((unsigned long long)ix << 26) |
-                                                   ((unsigned long long)iy << 20) | (unsigned)i;
+                                                   ((unsigned long long)(meta >> 24) << 20) | (unsigned)i;
                     if (key < k1) { k2 = k1; k1 = key; }
                     else if (key < k2) k2 = key;
                 }
-            }
-            // wave merge of the per-lane (k1, k2) pairs
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) {
-                const unsigned long long o1 = __shfl_xor(k1, o), o2 = __shfl_xor(k2, o);
-                const unsigned long long lo = k1 < o1 ? k1 : o1;
-                const unsigned long long hi = k1 < o1 ? o1 : k1;
-                const unsigned long long s2 = k2 < o2 ? k2 : o2;
-                k1 = lo;
-                k2 = hi < s2 ? hi : s2;
             }
             if (k1 != ~0ull) {
                 const int bestDist = (int)(k1 >> 32);
@@ -184,7 +236,8 @@ __global__ __launch_bounds__(256) void k_project_eval(ProjArgs a)
                     if (a.use_ratio && k2 != ~0ull) {
                         const int bestDist2 = (int)(k2 >> 32);
                         const int idx2 = (int)(k2 & 0xFFFFF);
-                        const int bestLevel = a.kp[bestIdx].octave, bestLevel2 = a.kp[idx2].octave;
+                        const gfo_keypoint* kp = a.kp + (long long)f * a.kp_stride;
+                        const int bestLevel = kp[bestIdx].octave, bestLevel2 = kp[idx2].octave;
                         if (bestLevel == bestLevel2 && (float)bestDist > a.nn_ratio * (float)bestDist2) accept = false;  // :230
                     }
                     // (no second candidate: bestLevel2 = -1 != bestLevel, bestDist2 = 256 -> always accepted)
@@ -196,120 +249,164 @@ __global__ __launch_bounds__(256) void k_project_eval(ProjArgs a)
             }
         }
     }
-    if (lane == 0) {
-        if (ROUND0) {
-            a.pick[iMP] = new_pick;
-            a.pick_dist[iMP] = new_dist;
-            if (is_live) a.live[atomicAdd(&a.counters[0], 1)] = iMP;
-        } else {
-            if (a.pick[iMP] != new_pick || a.pick_dist[iMP] != new_dist) {
-                atomicOr(&a.counters[1], 1);
-            }
-            // written to the shadow half, swapped by the host each round (Jacobi: reads see the old state)
-            a.pick[a.m + iMP] = new_pick;
-            a.pick_dist[a.m + iMP] = new_dist;
-        }
+    *out_pick = new_pick;
+    *out_dist = new_dist;
+    *out_live = is_live;
+}
+
+// round 0: every projected point against the entry state; builds the frame's live list (order irrelevant)
+__global__ __launch_bounds__(256) void k_proj_round0(ProjB a)
+{
+    const int f = blockIdx.y;
+    const int iq = blockIdx.x * 256 + threadIdx.x;
+    const int n = frame_n(a, f);
+    int pick = -1, dist = 256;
+    bool live = false, obs = false;
+    if (iq < a.m && n > 0) {
+        const ProjQ q = load_query(a, f, iq);
+        obs = q.obs;
+        eval_point<true, false>(a, f, n, iq, q, nullptr, &pick, &dist, &live);
+    }
+    const unsigned long long mask = __ballot(live);
+    if (mask == 0) return;
+    const int lane = threadIdx.x & 63;
+    const int leader = __ffsll((long long)mask) - 1;
+    int base = 0;
+    if (lane == leader) base = atomicAdd(&a.counters[f * PJ_CNT + PJ_NLIVE], __popcll(mask));
+    base = __shfl(base, leader);
+    if (live) {
+        const int slot = base + __popcll(mask & ((1ull << lane) - 1));
+        a.live[(long long)f * a.m + slot] = (unsigned)iq | (obs ? 0x80000000u : 0u);
+        a.pick[(long long)f * a.m + iq] = pick;
+        a.pick_dist[(long long)f * a.m + iq] = dist;
     }
 }
 
-// block_by[k] = min live map point WITH observations whose current pick is k
-__global__ void k_project_claims(ProjArgs a, int nlive)
+// One workgroup per frame: claim / re-evaluate rounds until nothing changes, then the epilogue:
+//   owner of a keypoint = the LAST accepted point that picked it (:233 overwrites), its distance the score;
+//   rotation consistency (ORBmatcher.cc:1548-1591): bin of every accepted point, histogram, the reference's
+//   three-maxima scan, then every point in a discarded bin clears the keypoint it took and costs one match.
+template <bool TABG>
+__global__ __launch_bounds__(1024) void k_proj_resolve(ProjB a)
 {
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= nlive) return;
-    const int iMP = a.live[t];
-    const int k = a.pick[iMP];
-    if (k >= 0 && (a.q[iMP].flags & 4)) atomicMin(&a.block_by[k], iMP);
-}
-
-__global__ void k_project_commit(ProjArgs a, int nlive)
-{
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= nlive) return;
-    const int iMP = a.live[t];
-    a.pick[iMP] = a.pick[a.m + iMP];
-    a.pick_dist[iMP] = a.pick_dist[a.m + iMP];
-}
-
-// final owner of a keypoint = the LAST accepted map point that picked it (:233 overwrites)
-__global__ void k_project_owner(ProjArgs a, int nlive)
-{
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= nlive) return;
-    const int iMP = a.live[t];
-    const int k = a.pick[iMP];
-    if (k >= 0) {
-        atomicMax(&a.out_mp[k], iMP);
-        atomicAdd(&a.counters[2], 1);
-    }
-}
-
-__global__ void k_project_score(ProjArgs a, int nlive)
-{
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= nlive) return;
-    const int iMP = a.live[t];
-    const int k = a.pick[iMP];
-    if (k >= 0 && a.out_mp[k] == iMP) a.out_score[k] = a.pick_dist[iMP];
-}
-
-static inline size_t al256(size_t v) { return (v + 255) / 256 * 256; }
-
-#define HISTO_LENGTH 30  // ORBmatcher.cc:59
-
-// rotation consistency (ORBmatcher.cc:1548-1591): bin of every accepted query, histogram, the reference's
-// three-maxima scan, then every query in a discarded bin clears the keypoint it took and costs one match.
-__global__ __launch_bounds__(256) void k_project_rotation(ProjArgs a, int nlive)
-{
+    extern __shared__ int lds_tab[];
     __shared__ int histo[HISTO_LENGTH];
     __shared__ int keep[3];
-    __shared__ int s_drop;
-    const int tid = threadIdx.x;
+    __shared__ int s_acc[2];
+    const int tid = threadIdx.x, f = blockIdx.x;
+    const int n = frame_n(a, f);
+    int* tab = TABG ? a.tab_g + (long long)f * a.n_cap : lds_tab;
+    int* pick = a.pick + (long long)f * a.m;
+    int* pick_dist = a.pick_dist + (long long)f * a.m;
+    const unsigned* live = a.live + (long long)f * a.m;
+    int* out_mp = a.out_mp + (long long)f * a.n_cap;
+    int* out_score = a.out_score + (long long)f * a.n_cap;
+    int nlive = a.counters[f * PJ_CNT + PJ_NLIVE];
+    if (nlive > a.m) nlive = a.m;
+    int rounds = 0;
+    if (nlive > 0) {
+        for (;;) {
+            rounds++;
+            for (int k = tid; k < n; k += 1024) tab[k] = 0x7FFFFFFF;
+            __syncthreads();
+            for (int t = tid; t < nlive; t += 1024) {
+                const unsigned e = live[t];
+                if (e & 0x80000000u) {
+                    const int k = pick[e & 0x7FFFFFFFu];
+                    if (k >= 0) atomicMin(&tab[k], (int)(e & 0x7FFFFFFFu));
+                }
+            }
+            __syncthreads();
+            int changed = 0;
+            for (int t = tid; t < nlive; t += 1024) {
+                const int iq = (int)(live[t] & 0x7FFFFFFFu);
+                const ProjQ q = load_query(a, f, iq);
+                int np, nd;
+                bool lv;
+                eval_point<false, TABG>(a, f, n, iq, q, tab, &np, &nd, &lv);
+                if (np != pick[iq] || nd != pick_dist[iq]) {
+                    changed = 1;
+                    pick[iq] = np;
+                    pick_dist[iq] = nd;
+                }
+            }
+            if (!__syncthreads_or(changed)) break;
+            if (rounds > nlive + 1) {   // cannot happen (point i is final after rank(i) rounds); never spin
+                if (tid == 0) a.counters[f * PJ_CNT + PJ_ERR] = 1;
+                break;
+            }
+        }
+    }
+    // ---- epilogue ----
     if (tid < HISTO_LENGTH) histo[tid] = 0;
-    if (tid == 0) s_drop = 0;
+    if (tid < 2) s_acc[tid] = 0;
+    for (int k = tid; k < n; k += 1024) tab[k] = -1;
     __syncthreads();
-    const float factor = 1.0f / HISTO_LENGTH;
-    for (int t = tid; t < nlive; t += 256) {
-        const int iq = a.live[t];
-        const int k = a.pick[iq];
-        int bin = -1;
+    int cnt = 0;
+    for (int t = tid; t < nlive; t += 1024) {
+        const int iq = (int)(live[t] & 0x7FFFFFFFu);
+        const int k = pick[iq];
         if (k >= 0) {
-            float rot = a.q[iq].angle - a.kp_angle[k];
-            if (rot < 0.0f) rot += 360.0f;
-            bin = (int)roundf(rot * factor);
-            if (bin == HISTO_LENGTH) bin = 0;
-            atomicAdd(&histo[bin], 1);
-        }
-        a.rot_bin[iq] = bin;
-    }
-    __syncthreads();
-    if (tid == 0) {  // ComputeThreeMaxima, ORBmatcher.cc:1723-1764
-        int max1 = 0, max2 = 0, max3 = 0, ind1 = -1, ind2 = -1, ind3 = -1;
-        for (int i = 0; i < HISTO_LENGTH; i++) {
-            const int s = histo[i];
-            if (s > max1) { max3 = max2; max2 = max1; max1 = s; ind3 = ind2; ind2 = ind1; ind1 = i; }
-            else if (s > max2) { max3 = max2; max2 = s; ind3 = ind2; ind2 = i; }
-            else if (s > max3) { max3 = s; ind3 = i; }
-        }
-        if ((float)max2 < 0.1f * (float)max1) { ind2 = -1; ind3 = -1; }
-        else if ((float)max3 < 0.1f * (float)max1) ind3 = -1;
-        keep[0] = ind1; keep[1] = ind2; keep[2] = ind3;
-    }
-    __syncthreads();
-    int drop = 0;
-    for (int t = tid; t < nlive; t += 256) {
-        const int iq = a.live[t];
-        const int b = a.rot_bin[iq];
-        if (b >= 0 && b != keep[0] && b != keep[1] && b != keep[2]) {
-            a.out_mp[a.pick[iq]] = -1;  // benign race: every writer stores -1
-            drop++;
+            atomicMax(&tab[k], iq);
+            cnt++;
+            if (a.check_ori) {
+                const ProjQ q = load_query(a, f, iq);
+                const float ka = a.kp_angle ? a.kp_angle[(long long)f * a.ang_stride + k] : a.kp[(long long)f * a.kp_stride + k].angle;
+                float rot = q.angle - ka;
+                if (rot < 0.0f) rot += 360.0f;
+                int bin = (int)roundf(rot * (1.0f / HISTO_LENGTH));
+                if (bin == HISTO_LENGTH) bin = 0;
+                atomicAdd(&histo[bin], 1);
+                a.rot_bin[(long long)f * a.m + iq] = bin;
+            }
         }
     }
-    if (drop) atomicAdd(&s_drop, drop);
+    if (cnt) atomicAdd(&s_acc[0], cnt);
     __syncthreads();
-    if (tid == 0) a.counters[2] -= s_drop;
+    for (int k = tid; k < n; k += 1024) {
+        const int o = TABG ? __hip_atomic_load(&tab[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : tab[k];
+        out_score[k] = o >= 0 ? pick_dist[o] : 0;
+    }
+    if (a.check_ori) {
+        if (tid == 0) {  // ComputeThreeMaxima, ORBmatcher.cc:1723-1764
+            int max1 = 0, max2 = 0, max3 = 0, ind1 = -1, ind2 = -1, ind3 = -1;
+            for (int i = 0; i < HISTO_LENGTH; i++) {
+                const int s = histo[i];
+                if (s > max1) { max3 = max2; max2 = max1; max1 = s; ind3 = ind2; ind2 = ind1; ind1 = i; }
+                else if (s > max2) { max3 = max2; max2 = s; ind3 = ind2; ind2 = i; }
+                else if (s > max3) { max3 = s; ind3 = i; }
+            }
+            if ((float)max2 < 0.1f * (float)max1) { ind2 = -1; ind3 = -1; }
+            else if ((float)max3 < 0.1f * (float)max1) ind3 = -1;
+            keep[0] = ind1; keep[1] = ind2; keep[2] = ind3;
+        }
+        __syncthreads();
+        int drop = 0;
+        for (int t = tid; t < nlive; t += 1024) {
+            const int iq = (int)(live[t] & 0x7FFFFFFFu);
+            const int k = pick[iq];
+            if (k < 0) continue;
+            const int b = a.rot_bin[(long long)f * a.m + iq];
+            if (b != keep[0] && b != keep[1] && b != keep[2]) {
+                if (TABG) __hip_atomic_store(&tab[k], -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                else tab[k] = -1;   // benign race: every writer stores -1
+                drop++;
+            }
+        }
+        if (drop) atomicAdd(&s_acc[1], drop);
+        __syncthreads();
+    }
+    for (int k = tid; k < n; k += 1024)
+        out_mp[k] = TABG ? __hip_atomic_load(&tab[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : tab[k];
+    if (tid == 0) {
+        a.counters[f * PJ_CNT + PJ_NMATCH] = s_acc[0] - s_acc[1];
+        a.counters[f * PJ_CNT + PJ_ROUNDS] = rounds + 1;
+    }
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------------------------
 #define PTRY(c, expr)                                                                             \
     do {                                                                                          \
         hipError_t e_ = (expr);                                                                   \
@@ -319,6 +416,68 @@ __global__ __launch_bounds__(256) void k_project_rotation(ProjArgs a, int nlive)
         }                                                                                         \
     } while (0)
 
+static inline size_t al256(size_t v) { return (v + 255) / 256 * 256; }
+
+static int pj_fail(gfo_ctx* c, int code, const char* msg)
+{
+    c->err = msg;
+    return code;
+}
+
+// work buffers of the projection search, grown on demand and kept (never on a steady-state call)
+static int pj_reserve(gfo_ctx* c, int frames, int m, int n_cap)
+{
+    GfoProjBuf& b = c->pj;
+    if (frames <= b.frames_cap && m <= b.m_cap && n_cap <= b.n_cap) return GFO_OK;
+    PTRY(c, hipStreamSynchronize(c->stream));
+    if (b.base) (void)hipFree(b.base);
+    b = GfoProjBuf{};
+    c->have_projection = false;
+    const size_t F = (size_t)(frames > 1 ? frames : 1), M = (size_t)(m > 1 ? m : 1), N = (size_t)(n_cap > 1 ? n_cap : 1);
+    size_t off = 0;
+    auto take = [&](size_t bytes) { size_t o = off; off = al256(off + bytes); return o; };
+    const size_t o_cs = take(F * (NCELL + 1) * 4), o_xy = take(F * N * 8), o_me = take(F * N * 4), o_pk = take(F * M * 4),
+                 o_pd = take(F * M * 4), o_lv = take(F * M * 4), o_rb = take(F * M * 4), o_tg = take(F * N * 4),
+                 o_ct = take(F * PJ_CNT * 4), o_om = take(F * N * 4), o_os = take(F * N * 4);
+    PTRY(c, hipMalloc(&b.base, off));
+    uint8_t* S = (uint8_t*)b.base;
+    b.cell_start = (int*)(S + o_cs); b.cell_xy = S + o_xy; b.cell_meta = (unsigned*)(S + o_me);
+    b.pick = (int*)(S + o_pk); b.pick_dist = (int*)(S + o_pd); b.live = (unsigned*)(S + o_lv); b.rot_bin = (int*)(S + o_rb);
+    b.tab_g = (int*)(S + o_tg); b.counters = (int*)(S + o_ct); b.out_mp = (int*)(S + o_om); b.out_score = (int*)(S + o_os);
+    b.frames_cap = (int)F; b.m_cap = (int)M; b.n_cap = (int)N;
+    return GFO_OK;
+}
+
+static void pj_bind(const gfo_ctx* c, ProjB* a)
+{
+    const GfoProjBuf& b = c->pj;
+    a->n_cap = b.n_cap;
+    a->cell_start = b.cell_start; a->cell_xy = (float2*)b.cell_xy; a->cell_meta = b.cell_meta;
+    a->pick = b.pick; a->pick_dist = b.pick_dist; a->live = b.live; a->rot_bin = b.rot_bin;
+    a->tab_g = b.tab_g; a->counters = b.counters; a->out_mp = b.out_mp; a->out_score = b.out_score;
+}
+
+// the three launches; n_max bounds the keypoints of any frame (sizes the LDS table)
+static int pj_launch(gfo_ctx* c, const ProjB& a, int frames, int n_max)
+{
+    hipStream_t st = c->stream;
+    gfo_prof_begin(c, ST_PROJECT);
+    hipLaunchKernelGGL(k_proj_grid, dim3(frames), dim3(1024), 0, st, a);
+    hipLaunchKernelGGL(k_proj_round0, dim3((a.m + 255) / 256, frames), dim3(256), 0, st, a);
+    const size_t tab_bytes = (size_t)n_max * 4;
+    if (tab_bytes <= 96 * 1024) {
+        if (tab_bytes > 48 * 1024)   // beyond the default dynamic-LDS grant: raised per call (per device), rare
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_proj_resolve<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+        hipLaunchKernelGGL(k_proj_resolve<false>, dim3(frames), dim3(1024), tab_bytes, st, a);
+    } else {
+        hipLaunchKernelGGL(k_proj_resolve<true>, dim3(frames), dim3(1024), 0, st, a);
+    }
+    gfo_prof_end(c);
+    if (int lrc = gfo_take_launch_err(c)) return lrc;
+    PTRY(c, hipGetLastError());
+    return GFO_OK;
+}
+
 extern "C" int gfo_search_by_projection_queries(gfo_ctx* c, const gfo_keypoint* kp_un, const uint8_t* desc,
                                                 const float* u_right, const float* kp_angle, int n,
                                                 const gfo_frame_bounds* fb, const gfo_proj_query* queries,
@@ -327,14 +486,12 @@ extern "C" int gfo_search_by_projection_queries(gfo_ctx* c, const gfo_keypoint* 
 {
     if (!c) return GFO_ERR_INVALID;
     if (!fb || !mode || !out_mp || !out_score || !nmatches || n < 0 || m < 0 || (n > 0 && (!kp_un || !desc)) ||
-        (m > 0 && (!queries || !q_desc)) || (mode->check_orientation && n > 0 && !kp_angle)) {
-        c->err = "gfo_search_by_projection: bad argument";
-        return GFO_ERR_INVALID;
-    }
-    if (n > 65535) {
-        c->err = "gfo_search_by_projection: more than 65535 keypoints";
-        return GFO_ERR_INVALID;
-    }
+        (m > 0 && (!queries || !q_desc)) || (mode->check_orientation && n > 0 && !kp_angle))
+        return pj_fail(c, GFO_ERR_INVALID, "gfo_search_by_projection: bad argument");
+    if (n > 65535) return pj_fail(c, GFO_ERR_INVALID, "gfo_search_by_projection: more than 65535 keypoints");
+    if (!(fb->max_x > fb->min_x) || !(fb->max_y > fb->min_y)) return pj_fail(c, GFO_ERR_INVALID, "gfo_search_by_projection: empty frame bounds");
+    for (int i = 0; i < n; i++)
+        if (kp_un[i].octave < 0 || kp_un[i].octave > 255) return pj_fail(c, GFO_ERR_INVALID, "gfo_search_by_projection: keypoint octave outside 0..255");
     *nmatches = 0;
     for (int i = 0; i < n; i++) { out_mp[i] = -1; out_score[i] = 0; }
     if (n == 0 || m == 0) return GFO_OK;
@@ -343,18 +500,16 @@ extern "C" int gfo_search_by_projection_queries(gfo_ctx* c, const gfo_keypoint* 
     auto take = [&](size_t bytes) { size_t o = off; off = al256(off + bytes); return o; };
     const size_t o_kp = take(sizeof(gfo_keypoint) * n), o_desc = take(32 * (size_t)n), o_ur = take(4 * (size_t)n),
                  o_tk = take(n), o_ang = take(4 * (size_t)n), o_q = take(sizeof(gfo_proj_query) * m),
-                 o_mpd = take(32 * (size_t)m), o_cs = take(4 * (NCELL + 1)), o_ci = take(4 * (size_t)n),
-                 o_kc = take(2 * (size_t)n), o_pick = take(8 * (size_t)m), o_pd = take(8 * (size_t)m),
-                 o_live = take(4 * (size_t)m), o_cnt = take(16), o_bb = take(4 * (size_t)n), o_om = take(4 * (size_t)n),
-                 o_os = take(4 * (size_t)n), o_rb = take(4 * (size_t)m);
+                 o_mpd = take(32 * (size_t)m);
     if (off > c->scratch_bytes) {
         (void)hipStreamSynchronize(c->stream);
         if (c->d_scratch) (void)hipFree(c->d_scratch);
         c->d_scratch = nullptr;
         c->scratch_bytes = 0;
-        PTRY(c, hipMalloc(&c->d_scratch, off));
-        c->scratch_bytes = off;
+        PTRY(c, hipMalloc(&c->d_scratch, off + off / 2));   // headroom: the next, slightly larger frame does not reallocate
+        c->scratch_bytes = off + off / 2;
     }
+    if (int rc = pj_reserve(c, 1, m + m / 2, n + n / 2)) return rc;
     uint8_t* S = (uint8_t*)c->d_scratch;
     hipStream_t st = c->stream;
     PTRY(c, hipMemcpyAsync(S + o_kp, kp_un, sizeof(gfo_keypoint) * n, hipMemcpyHostToDevice, st));
@@ -364,74 +519,35 @@ extern "C" int gfo_search_by_projection_queries(gfo_ctx* c, const gfo_keypoint* 
     if (kp_angle) PTRY(c, hipMemcpyAsync(S + o_ang, kp_angle, 4 * (size_t)n, hipMemcpyHostToDevice, st));
     PTRY(c, hipMemcpyAsync(S + o_q, queries, sizeof(gfo_proj_query) * m, hipMemcpyHostToDevice, st));
     PTRY(c, hipMemcpyAsync(S + o_mpd, q_desc, 32 * (size_t)m, hipMemcpyHostToDevice, st));
-    PTRY(c, hipMemsetAsync(S + o_cnt, 0, 16, st));
-    PTRY(c, hipMemsetAsync(S + o_om, 0xFF, 4 * (size_t)n, st));
-    PTRY(c, hipMemsetAsync(S + o_os, 0, 4 * (size_t)n, st));
-    ProjArgs a{};
+    ProjB a{};
     a.kp = (const gfo_keypoint*)(S + o_kp);
     a.desc = S + o_desc;
     a.u_right = u_right ? (const float*)(S + o_ur) : nullptr;
     a.taken0 = kp_taken ? S + o_tk : nullptr;
-    a.n = n;
+    a.kp_angle = kp_angle ? (const float*)(S + o_ang) : nullptr;
+    a.n_dev = nullptr; a.n_host = n;
     a.fb = *fb;
     a.inv_w = (float)GRID_COLS / (fb->max_x - fb->min_x);  // Frame.cc:129-130
     a.inv_h = (float)GRID_ROWS / (fb->max_y - fb->min_y);
-    a.q = (const gfo_proj_query*)(S + o_q);
-    a.mp_desc = S + o_mpd;
+    a.form = 0;
+    a.q = S + o_q;
+    a.q_desc = S + o_mpd;
     a.m = m;
     a.use_ratio = mode->use_ratio;
     a.nn_ratio = mode->nn_ratio;
     a.th_dist = mode->th_dist;
-    a.kp_angle = (const float*)(S + o_ang);
-    a.rot_bin = (int*)(S + o_rb);
-    a.cell_start = (int*)(S + o_cs);
-    a.cell_items = (int*)(S + o_ci);
-    a.kp_cell = (unsigned short*)(S + o_kc);
-    a.pick = (int*)(S + o_pick);
-    a.pick_dist = (int*)(S + o_pd);
-    a.live = (int*)(S + o_live);
-    a.counters = (int*)(S + o_cnt);
-    a.block_by = (int*)(S + o_bb);
-    a.out_mp = (int*)(S + o_om);
-    a.out_score = (int*)(S + o_os);
-
-    gfo_prof_begin(c, ST_PROJECT);
-    hipLaunchKernelGGL(k_grid_build, dim3(1), dim3(1024), 0, st, a);
-    hipLaunchKernelGGL(k_project_eval<true>, dim3((m + 3) / 4), dim3(256), 0, st, a);
-    int cnt[4] = {0, 0, 0, 0};
-    PTRY(c, hipMemcpyAsync(cnt, a.counters, 16, hipMemcpyDeviceToHost, st));
-    PTRY(c, hipStreamSynchronize(st));
-    const int nlive = cnt[0];
-    int rounds = 0;
-    if (nlive > 0) {
-        const dim3 g1((nlive + 255) / 256), b1(256);
-        for (;; rounds++) {
-            if (rounds > nlive + 1) {
-                c->err = "gfo_search_by_projection: fixed point not reached";
-                return GFO_ERR_STATE;
-            }
-            PTRY(c, hipMemsetAsync(a.block_by, 0x7F, 4 * (size_t)n, st));
-            PTRY(c, hipMemsetAsync(a.counters + 1, 0, 4, st));
-            hipLaunchKernelGGL(k_project_claims, g1, b1, 0, st, a, nlive);
-            hipLaunchKernelGGL(k_project_eval<false>, dim3((nlive + 3) / 4), dim3(256), 0, st, a);
-            hipLaunchKernelGGL(k_project_commit, g1, b1, 0, st, a, nlive);
-            PTRY(c, hipMemcpyAsync(cnt, a.counters, 16, hipMemcpyDeviceToHost, st));
-            PTRY(c, hipStreamSynchronize(st));
-            if (!cnt[1]) break;
-        }
-        hipLaunchKernelGGL(k_project_owner, g1, b1, 0, st, a, nlive);
-        hipLaunchKernelGGL(k_project_score, g1, b1, 0, st, a, nlive);
-        if (mode->check_orientation) hipLaunchKernelGGL(k_project_rotation, dim3(1), dim3(256), 0, st, a, nlive);
-    }
-    gfo_prof_end(c);
-    if (int lrc = gfo_take_launch_err(c)) return lrc;
-    PTRY(c, hipGetLastError());
+    a.check_ori = mode->check_orientation;
+    pj_bind(c, &a);
+    if (int rc = pj_launch(c, a, 1, n)) return rc;
+    int cnt[PJ_CNT];
     PTRY(c, hipMemcpyAsync(out_mp, a.out_mp, 4 * (size_t)n, hipMemcpyDeviceToHost, st));
     PTRY(c, hipMemcpyAsync(out_score, a.out_score, 4 * (size_t)n, hipMemcpyDeviceToHost, st));
-    PTRY(c, hipMemcpyAsync(cnt, a.counters, 16, hipMemcpyDeviceToHost, st));
+    PTRY(c, hipMemcpyAsync(cnt, a.counters, sizeof cnt, hipMemcpyDeviceToHost, st));
     PTRY(c, hipStreamSynchronize(st));
-    *nmatches = cnt[2];
-    c->last_project_rounds = rounds + 1;
+    if (cnt[PJ_ERR]) return pj_fail(c, GFO_ERR_STATE, "gfo_search_by_projection: fixed point not reached");
+    *nmatches = cnt[PJ_NMATCH];
+    c->last_project_rounds = cnt[PJ_ROUNDS];
+    c->have_projection = false;
     return GFO_OK;
 }
 
@@ -443,10 +559,8 @@ extern "C" int gfo_search_by_projection(gfo_ctx* c, const gfo_keypoint* kp_un, c
                                         const uint8_t* kp_taken, int32_t* out_mp, int32_t* out_score, int* nmatches)
 {
     if (!c) return GFO_ERR_INVALID;
-    if (!sf || nlevels < 1 || nlevels > GFO_MAX_LEVELS || m < 0 || (m > 0 && !mps)) {
-        c->err = "gfo_search_by_projection: bad argument";
-        return GFO_ERR_INVALID;
-    }
+    if (!sf || nlevels < 1 || nlevels > GFO_MAX_LEVELS || m < 0 || (m > 0 && !mps))
+        return pj_fail(c, GFO_ERR_INVALID, "gfo_search_by_projection: bad argument");
     std::vector<gfo_proj_query> q((size_t)(m > 0 ? m : 1));
     const bool bFactor = th != 1.0f;
     for (int i = 0; i < m; i++) {
@@ -467,4 +581,123 @@ extern "C" int gfo_search_by_projection(gfo_ctx* c, const gfo_keypoint* kp_un, c
     gfo_proj_mode mode = {1, nn_ratio, TH_HIGH, 0};
     return gfo_search_by_projection_queries(c, kp_un, desc, u_right, nullptr, n, fb, q.data(), mp_desc, m, &mode, kp_taken,
                                             out_mp, out_score, nmatches);
+}
+
+// ---- the resident local map and the batched, device-chained search --------------------------------------------
+extern "C" int gfo_map_upload(gfo_ctx* c, const uint8_t* mp_desc, int m)
+{
+    if (!c) return GFO_ERR_INVALID;
+    if (m < 0 || (m > 0 && !mp_desc)) return pj_fail(c, GFO_ERR_INVALID, "gfo_map_upload: bad argument");
+    PTRY(c, hipSetDevice(c->device));
+    if (m > c->map_cap) {
+        PTRY(c, hipStreamSynchronize(c->stream));
+        if (c->d_map_desc) (void)hipFree(c->d_map_desc);
+        c->d_map_desc = nullptr;
+        c->map_cap = 0;
+        PTRY(c, hipMalloc(&c->d_map_desc, 32 * (size_t)(m + m / 4 + 64)));
+        c->map_cap = m + m / 4 + 64;
+    }
+    if (m > 0) PTRY(c, hipMemcpyAsync(c->d_map_desc, mp_desc, 32 * (size_t)m, hipMemcpyHostToDevice, c->stream));
+    PTRY(c, hipStreamSynchronize(c->stream));   // the caller's buffer is free on return
+    c->map_m = m;
+    return GFO_OK;
+}
+
+extern "C" int gfo_search_by_projection_batch(gfo_ctx* c, const gfo_projection_batch* p)
+{
+    if (!c || !p) return GFO_ERR_INVALID;
+    if (!c->have_batch) return pj_fail(c, GFO_ERR_STATE, "gfo_search_by_projection_batch: no batch has been extracted");
+    if (c->map_m <= 0 || !c->d_map_desc) return pj_fail(c, GFO_ERR_STATE, "gfo_search_by_projection_batch: no map uploaded (gfo_map_upload)");
+    if (!p->mps) return pj_fail(c, GFO_ERR_INVALID, "gfo_search_by_projection_batch: null projections");
+    if (p->stereo && !c->have_stereo) return pj_fail(c, GFO_ERR_STATE, "gfo_search_by_projection_batch: stereo chain requested but no stereo batch has been matched");
+    if (!(p->bounds.max_x > p->bounds.min_x) || !(p->bounds.max_y > p->bounds.min_y))
+        return pj_fail(c, GFO_ERR_INVALID, "gfo_search_by_projection_batch: empty frame bounds");
+    PTRY(c, hipSetDevice(c->device));
+    const int frames = p->stereo ? c->last_nimg / 2 : c->last_nimg;
+    const int m = c->map_m, ks = c->g.kp_stride;
+    if (int rc = pj_reserve(c, c->cap_batch > frames ? c->cap_batch : frames, m, ks)) return rc;
+    hipStream_t st = c->stream;
+    const gfo_map_point* d_mps = p->mps;
+    const uint8_t* d_taken = p->kp_taken;
+    if (!p->on_device) {   // host projections: staged through the scratch buffer
+        const size_t b_mps = al256(sizeof(gfo_map_point) * (size_t)m * frames), b_tk = p->kp_taken ? al256((size_t)ks * frames) : 0;
+        if (b_mps + b_tk > c->scratch_bytes) {
+            PTRY(c, hipStreamSynchronize(st));
+            if (c->d_scratch) (void)hipFree(c->d_scratch);
+            c->d_scratch = nullptr;
+            c->scratch_bytes = 0;
+            PTRY(c, hipMalloc(&c->d_scratch, b_mps + b_tk));
+            c->scratch_bytes = b_mps + b_tk;
+        }
+        uint8_t* S = (uint8_t*)c->d_scratch;
+        PTRY(c, hipMemcpyAsync(S, p->mps, sizeof(gfo_map_point) * (size_t)m * frames, hipMemcpyHostToDevice, st));
+        d_mps = (const gfo_map_point*)S;
+        if (p->kp_taken) {
+            PTRY(c, hipMemcpyAsync(S + b_mps, p->kp_taken, (size_t)ks * frames, hipMemcpyHostToDevice, st));
+            d_taken = S + b_mps;
+        }
+    }
+    ProjB a{};
+    const int step = p->stereo ? 2 : 1;   // stereo: frame k = left image 2k
+    a.kp = c->d_kp; a.kp_stride = (long long)step * ks;
+    a.desc = c->d_desc;
+    a.u_right = p->stereo ? c->st.u_right : nullptr; a.ur_stride = ks;
+    a.taken0 = d_taken; a.tk_stride = ks;
+    a.kp_angle = nullptr;
+    a.n_dev = c->d_kp_cnt; a.n_dev_stride = step; a.n_host = 0;
+    a.fb = p->bounds;
+    a.inv_w = (float)GRID_COLS / (p->bounds.max_x - p->bounds.min_x);  // Frame.cc:129-130
+    a.inv_h = (float)GRID_ROWS / (p->bounds.max_y - p->bounds.min_y);
+    a.form = 1;
+    a.q = d_mps; a.q_stride = m;
+    a.q_desc = c->d_map_desc; a.qd_stride = 0;
+    a.m = m;
+    a.th = p->th; a.bfactor = p->th != 1.0f;
+    a.nlevels = c->g.nlevels;
+    for (int l = 0; l < c->g.nlevels; l++) a.scale[l] = c->scale[l];
+    a.use_ratio = 1; a.nn_ratio = p->nn_ratio; a.th_dist = TH_HIGH; a.check_ori = 0;
+    pj_bind(c, &a);
+    if (int rc = pj_launch(c, a, frames, ks)) return rc;
+    c->have_projection = true;
+    c->proj_frames = frames;
+    c->proj_step = step;
+    return GFO_OK;
+}
+
+extern "C" int gfo_projection_fetch(gfo_ctx* c, int frame, int32_t* out_mp, int32_t* out_score, int cap, int* nmatches)
+{
+    if (!c) return GFO_ERR_INVALID;
+    if (!c->have_projection) return pj_fail(c, GFO_ERR_STATE, "gfo_projection_fetch: no batched projection search has run");
+    if (frame < 0 || frame >= c->proj_frames) return pj_fail(c, GFO_ERR_INVALID, "gfo_projection_fetch: frame out of range");
+    hipStream_t st = c->stream;
+    const int step = c->proj_step;
+    int cnt[PJ_CNT], n = 0;
+    PTRY(c, hipMemcpyAsync(cnt, c->pj.counters + frame * PJ_CNT, sizeof cnt, hipMemcpyDeviceToHost, st));
+    PTRY(c, hipMemcpyAsync(&n, c->d_kp_cnt + frame * step, sizeof n, hipMemcpyDeviceToHost, st));
+    PTRY(c, hipStreamSynchronize(st));
+    if (cnt[PJ_ERR]) return pj_fail(c, GFO_ERR_STATE, "gfo_search_by_projection_batch: fixed point not reached");
+    const int k = n < cap ? n : cap;
+    if (k > 0 && out_mp) PTRY(c, hipMemcpyAsync(out_mp, c->pj.out_mp + (size_t)frame * c->pj.n_cap, 4 * (size_t)k, hipMemcpyDeviceToHost, st));
+    if (k > 0 && out_score) PTRY(c, hipMemcpyAsync(out_score, c->pj.out_score + (size_t)frame * c->pj.n_cap, 4 * (size_t)k, hipMemcpyDeviceToHost, st));
+    PTRY(c, hipStreamSynchronize(st));
+    if (nmatches) *nmatches = cnt[PJ_NMATCH];
+    c->last_project_rounds = cnt[PJ_ROUNDS];
+    if (n > cap) {
+        c->err = "gfo_projection_fetch: more keypoints than the caller capacity";
+        return GFO_ERR_CAPACITY;
+    }
+    return GFO_OK;
+}
+
+extern "C" int gfo_projection_device_views(gfo_ctx* c, const int32_t** d_out_mp, const int32_t** d_out_score,
+                                           const int32_t** d_counters, int* stride, int* counters_stride)
+{
+    if (!c) return GFO_ERR_INVALID;
+    if (!c->have_projection) return pj_fail(c, GFO_ERR_STATE, "gfo_projection_device_views: no batched projection search has run");
+    if (d_out_mp) *d_out_mp = c->pj.out_mp;
+    if (d_out_score) *d_out_score = c->pj.out_score;
+    if (d_counters) *d_counters = c->pj.counters;
+    if (stride) *stride = c->pj.n_cap;
+    if (counters_stride) *counters_stride = PJ_CNT;
+    return GFO_OK;
 }

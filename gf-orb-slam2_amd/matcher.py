@@ -5,7 +5,8 @@ from collections import namedtuple
 
 import numpy as np
 
-from ._lib import (FeatureVectorC, FrameBoundsC, KEYPOINT_DTYPE, PROJ_QUERY_DTYPE, ProjModeC, VocabularyC, MAP_POINT_DTYPE, StereoParamsC, check, load_library, ptr)
+from ._lib import (FeatureVectorC, FrameBoundsC, GfoError, KEYPOINT_DTYPE, PROJ_QUERY_DTYPE, ProjModeC, ProjectionBatchC, VocabularyC,
+                   MAP_POINT_DTYPE, StereoParamsC, check, load_library, ptr)
 
 StereoParams = namedtuple("StereoParams", "n_rows mbf mb min_x")
 FrameBounds = namedtuple("FrameBounds", "min_x min_y max_x max_y")
@@ -24,8 +25,16 @@ class ORBmatcher:
         if extractor is None:
             from .extractor import ORBextractor
             extractor = ORBextractor()
-            self._own = extractor
-        self._ctx = extractor.handle
+        # the matcher borrows the extractor's context (arena, stream): keep the OBJECT, not a copy of its handle,
+        # so a closed extractor is seen as closed instead of leaving a dangling gfo_ctx pointer here
+        self._ext = extractor
+
+    @property
+    def _ctx(self):
+        h = self._ext.handle
+        if not h or not h.value:
+            raise GfoError(-5, "the extractor this matcher was created on has been closed")
+        return h
 
     @staticmethod
     def DescriptorDistance(a, b):
@@ -94,6 +103,36 @@ class ORBmatcher:
                                                                    ptr(out_mp), ptr(out_sc), C.byref(nm)))
         return nm.value, out_mp[:n], out_sc[:n]
 
+    # ---- device-resident chain: extract_batch_device -> [stereo_match_batch] -> search_by_projection_batch ----
+    def map_upload(self, mp_desc):
+        """Descriptors of the local map (MapPoint::GetDescriptor(), vector order); resident until replaced."""
+        mpd = np.ascontiguousarray(mp_desc, np.uint8).reshape(-1, 32)
+        check(self._L, self._ctx, self._L.gfo_map_upload(self._ctx, ptr(mpd), len(mpd)))
+        self._map_m = len(mpd)
+
+    def search_by_projection_batch(self, map_points, bounds, th=3.0, kp_taken=None, stereo=False, device_ptrs=False):
+        """SearchByProjection(F, mvpLocalMapPoints, th) for every frame of the last device batch against the resident
+        map.  map_points: [frames][m] MAP_POINT_DTYPE (host array), or a raw device address when device_ptrs."""
+        if device_ptrs:
+            mps_p, tk_p = C.c_void_p(int(map_points)), C.c_void_p(int(kp_taken)) if kp_taken else None
+            keep = None
+        else:
+            mps = np.ascontiguousarray(map_points, MAP_POINT_DTYPE)
+            tk = None if kp_taken is None else np.ascontiguousarray(kp_taken, np.uint8)
+            keep = (mps, tk)
+            mps_p, tk_p = ptr(mps), ptr(tk)
+        a = ProjectionBatchC(mps_p, tk_p, 1 if device_ptrs else 0, 1 if stereo else 0, th, self.mfNNratio, FrameBoundsC(*bounds))
+        check(self._L, self._ctx, self._L.gfo_search_by_projection_batch(self._ctx, C.byref(a)))
+        if keep is not None:   # host arrays are staged with an asynchronous copy: hold them until the stream is done
+            self._ext.synchronize()
+
+    def projection_fetch(self, frame, cap):
+        out_mp = np.full(max(cap, 1), -1, np.int32)
+        out_sc = np.zeros(max(cap, 1), np.int32)
+        nm = C.c_int()
+        check(self._L, self._ctx, self._L.gfo_projection_fetch(self._ctx, frame, ptr(out_mp), ptr(out_sc), cap, C.byref(nm)))
+        return nm.value, out_mp, out_sc
+
     def SearchByBoW(self, kf_desc, kf_angle, kf_mp_valid, kf_fv, f_desc, f_angle, f_fv):
         """ORBmatcher::SearchByBoW(KeyFrame*, Frame&, vpMapPointMatches) -- ORBmatcher.h:272, ORBmatcher.cc:270-404.
         kf_fv / f_fv = (node_ids, node_start, items): the CSR of each DBoW2::FeatureVector.
@@ -151,10 +190,17 @@ class ORBVocabulary:
 
     def __init__(self, tree, extractor):
         self._L = load_library()
-        self._ctx = extractor.handle
+        self._ext = extractor
         arrs = [np.ascontiguousarray(tree[k]) for k in ("first_child", "n_children", "descriptors", "word_id", "weight")]
         v = VocabularyC(*[a.ctypes.data for a in arrs], len(arrs[0]), int(tree["depth"]))
         check(self._L, self._ctx, self._L.gfo_vocabulary_upload(self._ctx, C.byref(v)))
+
+    @property
+    def _ctx(self):
+        h = self._ext.handle
+        if not h or not h.value:
+            raise GfoError(-5, "the extractor this vocabulary was uploaded to has been closed")
+        return h
 
     def transform_raw(self, desc, levelsup=4):
         desc = np.ascontiguousarray(desc, np.uint8)

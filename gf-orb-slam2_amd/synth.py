@@ -43,3 +43,58 @@ def synth_stereo_pair(w, h, idx=0):
     noise = rng.integers(-2, 3, right.shape, dtype=np.int16)
     right = np.clip(right.astype(np.int16) + noise, 0, 255).astype(np.uint8)
     return left, right
+
+
+def synth_stream(w, h, nframes, idx=0, max_shift=24):
+    """`nframes` views of ONE synthetic scene, as a camera moving over it sees them: crops of a
+    (w + 2 max_shift) x (h + 2 max_shift) synth_frame at per-frame integer offsets, each with its own +-2 grey
+    levels of sensor noise.  Frame 0 sits at the centre offset.  Returns (frames, offsets[(ox, oy)])."""
+    ms = int(max_shift)
+    base = synth_frame(w + 2 * ms, h + 2 * ms, idx).astype(np.int16)
+    rng = np.random.default_rng(991 + idx)
+    offs = [(ms, ms)] + [(int(rng.integers(0, 2 * ms + 1)), int(rng.integers(0, 2 * ms + 1))) for _ in range(nframes - 1)]
+    frames = []
+    for ox, oy in offs:
+        noise = rng.integers(-2, 3, (h, w), dtype=np.int16)
+        frames.append(np.clip(base[oy:oy + h, ox:ox + w] + noise, 0, 255).astype(np.uint8))
+    return frames, offs
+
+
+MAP_POINT_DTYPE = np.dtype([("proj_x", "<f4"), ("proj_y", "<f4"), ("proj_xr", "<f4"),
+                            ("view_cos", "<f4"), ("level", "<i4"), ("flags", "<i4")])
+
+
+def synth_local_map(kp0, desc0, offs, w, h, m=50000, n_vis=4000, seed=7, nlevels=8):
+    """SURVEY.md 8d input S3 for a stream: a local map of `m` descriptors -- a visible subset that imitates frame
+    0's keypoints (their descriptors with k ~ U{0..60} random bits flipped), uniform random 256-bit strings for the
+    rest -- and its projection into every frame: matching keypoint position (moved by the frame's offset against
+    frame 0) + N(0, 2 px), levels copied, viewCos = 1, mbTrackInView and Observations() > 0 everywhere; the other
+    points project uniformly over the image at random levels.  Returns (mp_desc [m, 32], mps [nframes, m])."""
+    rng = np.random.default_rng(seed)
+    n = len(kp0)
+    nv = min(n, n_vis, m)
+    mpd = rng.integers(0, 256, (m, 32), dtype=np.uint8)
+    vis = rng.choice(m, nv, replace=False)
+    src = rng.choice(n, nv, replace=False)
+    d = desc0[src].copy()
+    kflip = rng.integers(0, 61, nv)
+    for j in range(60):
+        sel = j < kflip
+        bits = rng.integers(0, 256, nv)
+        d[sel, bits[sel] >> 3] ^= (1 << (bits[sel] & 7)).astype(np.uint8)
+    mpd[vis] = d
+    level_rand = rng.integers(0, nlevels, m)
+    mps = np.zeros((len(offs), m), MAP_POINT_DTYPE)
+    ox0, oy0 = offs[0]
+    for f, (ox, oy) in enumerate(offs):
+        p = mps[f]
+        p["proj_x"] = rng.uniform(0, w, m)
+        p["proj_y"] = rng.uniform(0, h, m)
+        p["proj_x"][vis] = kp0["x"][src] - (ox - ox0) + rng.normal(0, 2, nv)
+        p["proj_y"][vis] = kp0["y"][src] - (oy - oy0) + rng.normal(0, 2, nv)
+        p["level"] = level_rand
+        p["level"][vis] = kp0["octave"][src]
+        p["proj_xr"] = p["proj_x"] - 10
+        p["view_cos"] = 1.0
+        p["flags"] = 5
+    return mpd, mps

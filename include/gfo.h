@@ -203,6 +203,41 @@ int gfo_search_by_projection_queries(gfo_ctx* ctx, const gfo_keypoint* kp_un, co
                                      const uint8_t* q_desc, int m, const gfo_proj_mode* mode,
                                      const uint8_t* kp_taken, int32_t* out_q, int32_t* out_score, int* nmatches);
 
+/* Device-resident, batched form of SearchByProjection(Frame&, vector<MapPoint*>&, th) -- the chain
+ *   gfo_extract_batch_device -> [gfo_stereo_match_batch] -> gfo_search_by_projection_batch
+ * never leaves the GPU: keypoints, descriptors (and mvuRight) are read where the extractor / stereo matcher
+ * left them in the arena, the Frame grid (Frame.cc:461-476) is built per frame on the device, and the local
+ * map's descriptors stay resident between frames as Tracking::mvpLocalMapPoints does (Tracking.cc:2335-2346
+ * calls the matcher once per frame with the same map and fresh projections).
+ *
+ * gfo_map_upload: descriptors [m][32] of the local map (MapPoint::GetDescriptor() in vector order); resident
+ * until replaced by the next upload.  The host buffer is free on return.
+ * gfo_search_by_projection_batch: one search per frame of the last batch.  mps is [frames][m]: the per-frame
+ * projection of every map point (Frame::isInFrustum fills mTrackProjX/Y/XR, mnTrackScaleLevel, mTrackViewCos,
+ * mbTrackInView per frame, Frame.cc:512-590).  The extractor's keypoints stand for mvKeysUn (rectified or
+ * distortion-free input); bounds = mnMinX..mnMaxY.  stereo = 1: frame k is the pair k of the last
+ * gfo_stereo_match_batch (left keypoints + mvuRight), otherwise frame k = image k with mvuRight = -1.
+ * on_device = 1: mps / kp_taken are device pointers used in place (they must stay valid until the stream has
+ * consumed them); 0: host arrays, copied.  kp_taken (optional) is [frames][kp_stride] with kp_stride from
+ * gfo_batch_device_views.  Asynchronous on the context stream; results stay on the device. */
+typedef struct {
+    const gfo_map_point* mps;
+    const uint8_t* kp_taken;
+    int32_t on_device;
+    int32_t stereo;
+    float th;               /* the `th` argument (window factor) */
+    float nn_ratio;         /* ORBmatcher::mfNNratio             */
+    gfo_frame_bounds bounds;
+} gfo_projection_batch;
+int gfo_map_upload(gfo_ctx* ctx, const uint8_t* mp_desc, int m);
+int gfo_search_by_projection_batch(gfo_ctx* ctx, const gfo_projection_batch* p);
+/* out_mp / out_score as gfo_search_by_projection, for the first min(n, cap) keypoints of the frame */
+int gfo_projection_fetch(gfo_ctx* ctx, int frame, int32_t* out_mp, int32_t* out_score, int cap, int* nmatches);
+/* device views of the batch results: out_mp / out_score are [frames][*stride], counters [frames][*counters_stride]
+ * int32 with [0] live points, [1] fixed-point rounds, [2] nmatches */
+int gfo_projection_device_views(gfo_ctx* ctx, const int32_t** d_out_mp, const int32_t** d_out_score,
+                                const int32_t** d_counters, int* stride, int* counters_stride);
+
 /* ORBmatcher::SearchByBoW(KeyFrame* pKF, Frame& F, vector<MapPoint*>& vpMapPointMatches)
  * include/ORBmatcher.h:272, src/ORBmatcher.cc:270-404.  The two DBoW2::FeatureVector maps
  * (Thirdparty/DBoW2/DBoW2/FeatureVector.h: map<NodeId, vector<unsigned>>) are passed flattened to CSR in

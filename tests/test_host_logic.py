@@ -35,13 +35,34 @@ def test_bench_byte_accounting_matches_survey():
     inv = np.float32(1.0) / np.cumprod(np.concatenate([[np.float32(1.0)], np.full(7, np.float32(1.2))]).astype(np.float32)).astype(np.float32)
     sizes = bench.level_sizes(752, 480, inv)
     assert sum(a * b for a, b in sizes) == 1117367
-    per, total = bench.algorithmic_bytes(752, 480, sizes, 2000, stereo=False)
+    per, total = bench.algorithmic_bytes(752, 480, sizes, 2000, None)
     assert total == 9186428
     assert per["blur"] == 2 * 1117367 and per["fast"] == 1117367 and per["orient_desc"] == 2000 * 2178
-    _, total_st = bench.algorithmic_bytes(752, 480, sizes, 2000, stereo=True)
+    _, total_st = bench.algorithmic_bytes(752, 480, sizes, 2000, "stereo")
     assert total_st == 9186428 + 256000 / 2              # half a pair's association per image
     sizes_b = bench.level_sizes(1920, 1080, inv)
-    assert bench.algorithmic_bytes(1920, 1080, sizes_b, 4000, False)[1] == 36462884
+    assert bench.algorithmic_bytes(1920, 1080, sizes_b, 4000, None)[1] == 36462884
+    per_p, total_p = bench.algorithmic_bytes(1920, 1080, sizes_b, 4000, "project", 50000)
+    assert per_p["project"] == 3440000 and total_p == 36462884 + 3440000
+
+
+def test_synthetic_stream_and_local_map():
+    """input S3 as a stream: one scene, shifted crops; the map imitates frame 0's keypoints"""
+    from gf_orb_slam2_amd.synth import MAP_POINT_DTYPE, synth_local_map, synth_stream
+    import gf_orb_slam2_amd as G
+    assert MAP_POINT_DTYPE == G.MAP_POINT_DTYPE
+    frames, offs = synth_stream(160, 120, 3, idx=1, max_shift=8)
+    assert len(frames) == 3 and frames[0].shape == (120, 160) and offs[0] == (8, 8)
+    ox, oy = offs[1]
+    a, b = frames[0][20:100, 20:140].astype(int), frames[1][20 + 8 - oy:100 + 8 - oy, 20 + 8 - ox:140 + 8 - ox].astype(int)
+    assert np.abs(a - b).max() <= 4                      # same scene, +-2 grey levels of noise each
+    kp = np.zeros(50, G.KEYPOINT_DTYPE)
+    kp["x"] = np.linspace(20, 140, 50); kp["y"] = 60; kp["octave"] = np.arange(50) % 8
+    desc = np.random.default_rng(0).integers(0, 256, (50, 32), dtype=np.uint8)
+    mpd, mps = synth_local_map(kp, desc, offs, 160, 120, m=500, n_vis=40, seed=7)
+    assert mpd.shape == (500, 32) and mps.shape == (3, 500) and (mps["flags"] == 5).all()
+    d = np.unpackbits(mpd[:, None, :] ^ desc[None, :, :], axis=2).sum(2).min(1)
+    assert (d <= 60).sum() >= 40                         # the visible subset stays within 60 flipped bits of a keypoint
 
 
 def test_sharding_partitions():
@@ -90,3 +111,22 @@ def test_count_all_gather_two_ranks_gloo():
     for rank, got, tmax in res:
         assert got == expect
         assert tmax == 1.5
+
+
+def test_matcher_on_closed_extractor_raises():
+    """ORBmatcher / ORBVocabulary borrow the extractor's context: once it is closed every call must raise GfoError(-5)
+    on the host side instead of handing a freed gfo_ctx to the library (no GPU needed: the handle is null)."""
+    import ctypes
+    import pytest
+    import gf_orb_slam2_amd as G
+
+    class Closed:
+        handle = ctypes.c_void_p()
+
+    m = G.ORBmatcher(0.8, True, extractor=Closed())
+    for call in (lambda: m.stereo_match_batch(G.StereoParams(480, 1.0, 1.0, 0.0)),
+                 lambda: m.map_upload(np.zeros((4, 32), np.uint8)),
+                 lambda: m.projection_fetch(0, 4)):
+        with pytest.raises(G.GfoError) as e:
+            call()
+        assert e.value.code == -5
