@@ -2,13 +2,18 @@
 // ORBmatcher::SearchByProjection, both overloads (ORBmatcher.cc:155-249 map points, :1440-1593 frame to frame),
 // for a BATCH of frames in three launches, nothing returning to the host in between:
 //
-//   k_proj_grid     one workgroup per frame: the 64x48 grid as a CSR whose items carry (x, y) and
-//                   index | octave << 16 | cell row << 24, so a candidate costs one 12-byte sequential read
+//   k_proj_grid     one workgroup per frame: the 64x48 grid as a CSR whose 16-byte items carry (x, y) and
+//                   index | octave << 16 | cell row << 24, so a candidate costs one gather
 //   k_proj_round0   one THREAD per projected point (a 50 000-point local map against 4000 keypoints leaves
 //                   0-3 candidates per point: a wavefront per point would idle 60 lanes): every point is
 //                   evaluated against the entry state; points that can ever match go to the frame's live list
-//   k_proj_resolve  one workgroup per frame: the order dependence, resolved in LDS (below), then the owner /
-//                   score / rotation-histogram epilogue
+//                   TOGETHER WITH their sorted candidate list (what blocks a candidate later is the only thing
+//                   that changes between rounds: window, level, mvuRight gate and distance are static)
+//   k_proj_resolve  one workgroup per frame: the order dependence, resolved in LDS over the cached candidate
+//                   lists (below), then the owner / score / rotation-histogram epilogue.  Measured on MI355X:
+//                   re-evaluating the live points from the grid each round cost 885 us per batch (a workgroup's
+//                   fully divergent gathers go through ONE CU's address unit, ~2 clk per distinct line); the
+//                   cached lists turn a round into a coalesced 32-byte read and a few LDS lookups per point
 //
 // The reference is ORDER-DEPENDENT: points are visited in vector order, every accepted match writes
 // F.mvpMapPoints[bestIdx], and later points skip keypoints already taken by a point with observations
@@ -27,6 +32,7 @@
 // (dist, ix, iy, idx): candidates can be scanned in any order with that 64-bit key, and the best /
 // second-best pair is the two smallest keys (a stable sort by distance).
 #include "gfo_internal.h"
+#include <stdlib.h>
 
 #define GRID_COLS 64   // FRAME_GRID_COLS, Frame.h:92
 #define GRID_ROWS 48   // FRAME_GRID_ROWS, Frame.h:93
@@ -34,7 +40,8 @@
 #define TH_HIGH 100    // ORBmatcher.cc:57
 #define HISTO_LENGTH 30  // ORBmatcher.cc:59
 
-enum { PJ_NLIVE = 0, PJ_ROUNDS = 1, PJ_NMATCH = 2, PJ_ERR = 3, PJ_CNT = 8 };
+enum { PJ_NLIVE = 0, PJ_ROUNDS = 1, PJ_NMATCH = 2, PJ_ERR = 3, PJ_FALLBACK = 4, PJ_CNT = 8 };
+#define PJ_K 7   // cached candidates per live point: 7 entries + 1 header word = 32 bytes
 
 // Everything is [frame][...]: frame f of a per-frame array starts at base + f * stride (stride 0 = shared).
 struct ProjB {
@@ -56,13 +63,14 @@ struct ProjB {
     // per-frame scratch
     int n_cap;                 // stride of the per-keypoint arrays
     int* cell_start;           // [NCELL + 1]
-    float2* cell_xy;           // [n_cap] keypoint position, in cell order
-    unsigned* cell_meta;       // [n_cap] index | octave << 16 | cell row << 24
-    int* pick;                 // [m] keypoint picked by a live point, -1 none
-    int* pick_dist;            // [m]
+    float4* cell_item;         // [n_cap] in cell order: x, y, bits of (index | octave << 16 | cell row << 24), 0
+    int* pick;                 // [m] by live slot: keypoint picked, -1 none
+    int* pick_dist;            // [m] by live slot
     unsigned* live;            // [m] live point | has-observations << 31
-    int* rot_bin;              // [m]
-    int* tab_g;                // [n_cap] claim / owner table when it does not fit LDS
+    uint4* cand;               // [m][2] by live slot: header (count | truncated << 8) + PJ_K entries
+                               //        dist << 23 | octave << 16 | index, in the reference's candidate order
+    int* rot_bin;              // [m] by live slot
+    int* tab_g;                // [2 * n_cap] claim / owner and score tables when they do not fit LDS
     int* counters;             // [PJ_CNT]
     int* out_mp; int* out_score;   // [n_cap]
 };
@@ -114,8 +122,7 @@ __global__ __launch_bounds__(1024) void k_proj_grid(ProjB a)
     const int n = frame_n(a, f);
     const gfo_keypoint* kp = a.kp + (long long)f * a.kp_stride;
     int* cell_start = a.cell_start + (long long)f * (NCELL + 1);
-    float2* cell_xy = a.cell_xy + (long long)f * a.n_cap;
-    unsigned* cell_meta = a.cell_meta + (long long)f * a.n_cap;
+    float4* cell_item = a.cell_item + (long long)f * a.n_cap;
     if (tid < PJ_CNT) a.counters[f * PJ_CNT + tid] = 0;
     for (int c = tid; c < NCELL; c += 1024) s_cnt[c] = 0;
     __syncthreads();
@@ -151,9 +158,9 @@ __global__ __launch_bounds__(1024) void k_proj_grid(ProjB a)
         const int py = (int)roundf((k.y - a.fb.min_y) * a.inv_h);
         if (px < 0 || px >= GRID_COLS || py < 0 || py >= GRID_ROWS) continue;
         const int slot = atomicAdd(&s_cnt[px * GRID_ROWS + py], 1);
-        cell_xy[slot] = make_float2(k.x, k.y);
-        // octaves outside 0..255 cannot come out of the extractor; host arrays are checked at the ABI
-        cell_meta[slot] = (unsigned)i | ((unsigned)(k.octave & 0xFF) << 16) | ((unsigned)py << 24);
+        // octaves outside 0..127 cannot come out of the extractor; host arrays are checked at the ABI
+        const unsigned meta = (unsigned)i | ((unsigned)(k.octave & 0x7F) << 16) | ((unsigned)py << 24);
+        cell_item[slot] = make_float4(k.x, k.y, __uint_as_float(meta), 0.f);
     }
 }
 
@@ -164,121 +171,197 @@ __device__ __forceinline__ int hamming_u4(const uint4 a0, const uint4 a1, const 
            __popc(a1.x ^ b1.x) + __popc(a1.y ^ b1.y) + __popc(a1.z ^ b1.z) + __popc(a1.w ^ b1.w);
 }
 
-// Evaluates one projected point against the frame's grid.  ROUND0: only the entry state blocks; otherwise a
-// keypoint is also blocked when the claim table names a lower-indexed point.  TABG: the table lives in HBM and is
-// read past the L1 (other waves of the workgroup update it with L2 atomics).
-template <bool ROUND0, bool TABG>
-__device__ __forceinline__ void eval_point(const ProjB& a, int f, int n, int iq, const ProjQ& q, const int* tab,
-                                           int* out_pick, int* out_dist, bool* out_live)
+// key of a candidate = (dist, cell column, cell row, index): the reference's iteration order breaks distance ties.
+// The octave rides in the lowest 7 bits (it cannot disturb the order: two candidates never share an index).
+//   [43:35] dist  [34:29] cell column  [28:23] cell row  [22:7] index  [6:0] octave
+__device__ __forceinline__ unsigned long long cand_key(unsigned dist, int ix, unsigned meta)
 {
-    int new_pick = -1, new_dist = 256;
-    bool is_live = false;
-    if (q.active) {
-        const float rs = q.radius, x = q.u, y = q.v;
-        // GetFeaturesInArea(u, v, rs, minLevel, maxLevel), Frame.cc:593-646
-        const int cx0 = max(0, (int)floorf((x - a.fb.min_x - rs) * a.inv_w));
-        const int cx1 = min(GRID_COLS - 1, (int)ceilf((x - a.fb.min_x + rs) * a.inv_w));
-        const int cy0 = max(0, (int)floorf((y - a.fb.min_y - rs) * a.inv_h));
-        const int cy1 = min(GRID_ROWS - 1, (int)ceilf((y - a.fb.min_y + rs) * a.inv_h));
-        if (!(cx0 >= GRID_COLS || cx1 < 0 || cy0 >= GRID_ROWS || cy1 < 0)) {
-            const bool check_levels = (q.min_level > 0) || (q.max_level >= 0);
-            const int* cell_start = a.cell_start + (long long)f * (NCELL + 1);
-            const float2* cell_xy = a.cell_xy + (long long)f * a.n_cap;
-            const unsigned* cell_meta = a.cell_meta + (long long)f * a.n_cap;
-            const uint8_t* desc = a.desc + (long long)f * a.kp_stride * 32;
-            const float* u_right = a.u_right ? a.u_right + (long long)f * a.ur_stride : nullptr;
-            const uint8_t* taken0 = a.taken0 ? a.taken0 + (long long)f * a.tk_stride : nullptr;
-            uint4 a0 = make_uint4(0, 0, 0, 0), a1 = a0;
-            bool have_desc = false;
-            unsigned long long k1 = ~0ull, k2 = ~0ull;  // two smallest (dist, ix, iy, idx) keys
-            for (int ix = cx0; ix <= cx1; ix++) {
-                // cells (ix, cy0..cy1) are contiguous in the CSR
-                const int beg = cell_start[ix * GRID_ROWS + cy0];
-                const int end = cell_start[ix * GRID_ROWS + cy1 + 1];
-                for (int j = beg; j < end; j++) {
-                    const float2 p = cell_xy[j];
-                    if (!(fabsf(p.x - x) < rs && fabsf(p.y - y) < rs)) continue;
-                    const unsigned meta = cell_meta[j];
-                    const int oct = (int)((meta >> 16) & 0xFF);
-                    if (check_levels) {
-                        if (oct < q.min_level) continue;
-                        if (q.max_level >= 0 && oct > q.max_level) continue;
-                    }
-                    const int i = (int)(meta & 0xFFFF);
-                    // F.mvpMapPoints[idx] with Observations() > 0, :197-199
-                    if (taken0 && taken0[i]) continue;
-                    if (!ROUND0) {
-                        const int claim = TABG ? __hip_atomic_load(&tab[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : tab[i];
-                        if (claim < iq) continue;
-                    }
-                    if (u_right) {  // :201-206
-                        const float ur = u_right[i];
-                        if (ur > 0 && fabsf(q.ur - ur) > rs) continue;
-                    }
-                    if (!have_desc) {
-                        const uint4* dq = reinterpret_cast<const uint4*>(a.q_desc + (long long)f * a.qd_stride + (long long)iq * 32);
-                        a0 = dq[0]; a1 = dq[1];
-                        have_desc = true;
-                    }
-                    const unsigned dist = (unsigned)hamming_u4(a0, a1, reinterpret_cast<const uint4*>(desc + (long long)i * 32));
-                    const unsigned long long key = ((unsigned long long)dist << 32) | ((unsigned long long)ix << 26) |
-                                                   ((unsigned long long)(meta >> 24) << 20) | (unsigned)i;
-                    if (key < k1) { k2 = k1; k1 = key; }
-                    else if (key < k2) k2 = key;
-                }
+    return ((unsigned long long)dist << 35) | ((unsigned long long)ix << 29) | ((unsigned long long)(meta >> 24) << 23) |
+           ((unsigned long long)(meta & 0xFFFFu) << 7) | (unsigned long long)((meta >> 16) & 0x7Fu);
+}
+
+// The acceptance rule on the best and second-best UNBLOCKED candidates (entries dist << 23 | octave << 16 | index,
+// -1 = none): ORBmatcher.cc:228-233 / :1536.
+__device__ __forceinline__ void accept_rule(const ProjB& a, int e1, int e2, int* pick, int* dist)
+{
+    *pick = -1;
+    *dist = 256;
+    if (e1 < 0) return;
+    const int bestDist = e1 >> 23;
+    if (bestDist > a.th_dist) return;
+    if (a.use_ratio && e2 >= 0) {
+        const int bestDist2 = e2 >> 23;
+        // same level and not distinctive enough (:230); no second candidate: bestLevel2 = -1, always accepted
+        if (((e1 >> 16) & 0x7F) == ((e2 >> 16) & 0x7F) && (float)bestDist > a.nn_ratio * (float)bestDist2) return;
+    }
+    *pick = e1 & 0xFFFF;
+    *dist = bestDist;
+}
+
+// Scans the grid window of one projected point in two phases, so that no lane waits for HBM inside the divergent
+// scan loop: phase 1 walks the cells and keeps the (at most PJ_HOLD) items that pass the window and level tests --
+// for a 50 000-point map most lanes keep none; phase 2 fetches, for every kept item at once, what the remaining
+// filters need (taken on entry, mvuRight gate, `blocked(i)`, the keypoint's descriptor) and offers the survivors to
+// `sink(key)`.  Items beyond PJ_HOLD are finished on the spot (contended maps only).
+#define PJ_HOLD 4
+template <class Blocked, class Sink>
+__device__ __forceinline__ void scan_candidates(const ProjB& a, int f, int n, int iq, const ProjQ& q, const int* cell_start,
+                                                const float4* cell_item, Blocked blocked, Sink sink)
+{
+    const float rs = q.radius, x = q.u, y = q.v;
+    // GetFeaturesInArea(u, v, rs, minLevel, maxLevel), Frame.cc:593-646
+    int cx0 = max(0, (int)floorf((x - a.fb.min_x - rs) * a.inv_w));
+    int cx1 = min(GRID_COLS - 1, (int)ceilf((x - a.fb.min_x + rs) * a.inv_w));
+    const int cy0 = max(0, (int)floorf((y - a.fb.min_y - rs) * a.inv_h));
+    const int cy1 = min(GRID_ROWS - 1, (int)ceilf((y - a.fb.min_y + rs) * a.inv_h));
+    if (!q.active || cx0 >= GRID_COLS || cx1 < 0 || cy0 >= GRID_ROWS || cy1 < 0) { cx0 = 0; cx1 = -1; }   // no cells
+    const bool check_levels = (q.min_level > 0) || (q.max_level >= 0);
+    const uint8_t* desc = a.desc + (long long)f * a.kp_stride * 32;
+    const float* u_right = a.u_right ? a.u_right + (long long)f * a.ur_stride : nullptr;
+    const uint8_t* taken0 = a.taken0 ? a.taken0 + (long long)f * a.tk_stride : nullptr;
+    uint4 a0 = make_uint4(0, 0, 0, 0), a1 = a0;
+    bool have_desc = false;
+    // finishes one kept item (j = position in the cell-ordered item array, ix = its cell column)
+    auto finish = [&](bool valid, int j, int ix) {
+        const float4 it = cell_item[valid ? j : 0];
+        const unsigned meta = __float_as_uint(it.z);
+        const int i = min((int)(meta & 0xFFFF), n - 1);
+        const uint4* dk = reinterpret_cast<const uint4*>(desc + (long long)i * 32);
+        const uint4 b0 = dk[0], b1 = dk[1];
+        const int tk = taken0 ? (int)taken0[i] : 0;            // F.mvpMapPoints[idx] with Observations() > 0, :197-199
+        const float ur = u_right ? u_right[i] : -1.0f;         // :201-206
+        if (!valid || tk || blocked(i) || (ur > 0 && fabsf(q.ur - ur) > rs)) return;
+        const unsigned dist = (unsigned)(__popc(a0.x ^ b0.x) + __popc(a0.y ^ b0.y) + __popc(a0.z ^ b0.z) + __popc(a0.w ^ b0.w) +
+                                         __popc(a1.x ^ b1.x) + __popc(a1.y ^ b1.y) + __popc(a1.z ^ b1.z) + __popc(a1.w ^ b1.w));
+        sink(cand_key(dist, ix, meta));
+    };
+    auto need_desc = [&]() {
+        if (!have_desc) {
+            const uint4* dq = reinterpret_cast<const uint4*>(a.q_desc + (long long)f * a.qd_stride + (long long)iq * 32);
+            a0 = dq[0]; a1 = dq[1];
+            have_desc = true;
+        }
+    };
+    int hold[PJ_HOLD], nh = 0;
+#pragma unroll
+    for (int s = 0; s < PJ_HOLD; s++) hold[s] = 0;
+    for (int ix = cx0; ix <= cx1; ix++) {
+        // cells (ix, cy0..cy1) are contiguous in the CSR
+        const int beg = cell_start[ix * GRID_ROWS + cy0];
+        const int end = cell_start[ix * GRID_ROWS + cy1 + 1];
+        for (int j = beg; j < end; j++) {
+            const float4 it = cell_item[j];
+            if (!(fabsf(it.x - x) < rs && fabsf(it.y - y) < rs)) continue;
+            const int oct = (int)((__float_as_uint(it.z) >> 16) & 0x7F);
+            if (check_levels) {
+                if (oct < q.min_level) continue;
+                if (q.max_level >= 0 && oct > q.max_level) continue;
             }
-            if (k1 != ~0ull) {
-                const int bestDist = (int)(k1 >> 32);
-                const int bestIdx = (int)(k1 & 0xFFFFF);
-                if (bestDist <= a.th_dist) {  // :228 / :1536
-                    is_live = true;
-                    bool accept = true;
-                    if (a.use_ratio && k2 != ~0ull) {
-                        const int bestDist2 = (int)(k2 >> 32);
-                        const int idx2 = (int)(k2 & 0xFFFFF);
-                        const gfo_keypoint* kp = a.kp + (long long)f * a.kp_stride;
-                        const int bestLevel = kp[bestIdx].octave, bestLevel2 = kp[idx2].octave;
-                        if (bestLevel == bestLevel2 && (float)bestDist > a.nn_ratio * (float)bestDist2) accept = false;  // :230
-                    }
-                    // (no second candidate: bestLevel2 = -1 != bestLevel, bestDist2 = 256 -> always accepted)
-                    if (accept) {
-                        new_pick = bestIdx;
-                        new_dist = bestDist;
-                    }
-                }
+            const int c = j | (ix << 16);
+            if (nh < PJ_HOLD) {
+#pragma unroll
+                for (int s = 0; s < PJ_HOLD; s++) hold[s] = nh == s ? c : hold[s];
+                nh++;
+            } else {
+                need_desc();
+                finish(true, j, ix);
             }
         }
     }
-    *out_pick = new_pick;
-    *out_dist = new_dist;
-    *out_live = is_live;
+    if (__ballot(nh > 0) == 0) return;
+    if (nh > 0) need_desc();
+#pragma unroll
+    for (int s0 = 0; s0 < PJ_HOLD; s0 += 2) {
+        if (s0 > 0 && __ballot(nh > s0) == 0) break;
+        // two items per step: their loads are independent and go out together
+        finish(nh > s0, hold[s0] & 0xFFFF, hold[s0] >> 16);
+        finish(nh > s0 + 1, hold[s0 + 1] & 0xFFFF, hold[s0 + 1] >> 16);
+    }
 }
 
-// round 0: every projected point against the entry state; builds the frame's live list (order irrelevant)
-__global__ __launch_bounds__(256) void k_proj_round0(ProjB a)
+// cached form of a candidate: dist << 23 | octave << 16 | index (-1 = none)
+__device__ __forceinline__ int key_entry(unsigned long long key)
 {
+    if (key == ~0ull) return -1;
+    return (int)(((unsigned)(key >> 35) << 23) | ((unsigned)(key & 0x7Fu) << 16) | (unsigned)((key >> 7) & 0xFFFFu));
+}
+
+// round 0: every projected point against the entry state; the points that can ever match (best distance within
+// the threshold before anyone blocks anything) get a live slot holding their PJ_K first candidates in order.
+// LDSGRID: the workgroup first copies the frame's grid (cell table + items, 78 KB for 4128 keypoints) into LDS and
+// walks its share of the points against that copy: the scan is all gathers, and a CU's address unit retires a fully
+// divergent global gather at ~2 clk per distinct line where LDS serves 128 B/clk.  Grids too large for LDS (more
+// than ~4000 keypoints) are read from HBM in place.
+template <bool LDSGRID>
+__global__ __launch_bounds__(LDSGRID ? 1024 : 256, 8) void k_proj_round0(ProjB a, int chunk)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds_grid[];
     const int f = blockIdx.y;
-    const int iq = blockIdx.x * 256 + threadIdx.x;
     const int n = frame_n(a, f);
-    int pick = -1, dist = 256;
-    bool live = false, obs = false;
-    if (iq < a.m && n > 0) {
-        const ProjQ q = load_query(a, f, iq);
-        obs = q.obs;
-        eval_point<true, false>(a, f, n, iq, q, nullptr, &pick, &dist, &live);
-    }
-    const unsigned long long mask = __ballot(live);
-    if (mask == 0) return;
+    const int* cell_start = a.cell_start + (long long)f * (NCELL + 1);
+    const float4* cell_item = a.cell_item + (long long)f * a.n_cap;
     const int lane = threadIdx.x & 63;
-    const int leader = __ffsll((long long)mask) - 1;
-    int base = 0;
-    if (lane == leader) base = atomicAdd(&a.counters[f * PJ_CNT + PJ_NLIVE], __popcll(mask));
-    base = __shfl(base, leader);
-    if (live) {
-        const int slot = base + __popcll(mask & ((1ull << lane) - 1));
-        a.live[(long long)f * a.m + slot] = (unsigned)iq | (obs ? 0x80000000u : 0u);
-        a.pick[(long long)f * a.m + iq] = pick;
-        a.pick_dist[(long long)f * a.m + iq] = dist;
+    if (LDSGRID) {
+        float4* l_item = reinterpret_cast<float4*>(lds_grid);
+        int* l_start = reinterpret_cast<int*>(lds_grid + (size_t)a.n_cap * 16);
+        const int n_in = min(cell_start[NCELL], a.n_cap);   // keypoints inside the grid
+        for (int i = threadIdx.x; i < n_in; i += 1024) l_item[i] = cell_item[i];
+        for (int i = threadIdx.x; i <= NCELL; i += 1024) l_start[i] = cell_start[i];
+        __syncthreads();
+        cell_start = l_start;
+        cell_item = l_item;
+    }
+    const int q_begin = blockIdx.x * chunk;
+    const int q_end = min(a.m, q_begin + chunk);
+    for (int iq0 = q_begin; iq0 < q_end; iq0 += (int)blockDim.x) {
+        const int iq = iq0 + (int)threadIdx.x;
+        int pick = -1, dist = 256;
+        bool live = false, obs = false, trunc = false;
+        unsigned long long k[PJ_K];   // the PJ_K smallest keys, ascending
+#pragma unroll
+        for (int s = 0; s < PJ_K; s++) k[s] = ~0ull;
+        if (iq < q_end && n > 0) {
+            const ProjQ q = load_query(a, f, iq);
+            obs = q.obs;
+            {
+                scan_candidates(a, f, n, iq, q, cell_start, cell_item, [](int) { return false; },
+                                [&](unsigned long long key) {
+                                    unsigned long long x = key;
+#pragma unroll
+                                    for (int s = 0; s < PJ_K; s++) {
+                                        const unsigned long long lo = k[s] < x ? k[s] : x;
+                                        x = k[s] < x ? x : k[s];
+                                        k[s] = lo;
+                                    }
+                                    if (x != ~0ull) trunc = true;
+                                });
+                if (k[0] != ~0ull) {
+                    const int e1 = key_entry(k[0]), e2 = key_entry(k[1]);
+                    live = (e1 >> 23) <= a.th_dist;   // :228 / :1536
+                    accept_rule(a, e1, e2, &pick, &dist);
+                }
+            }
+        }
+        const unsigned long long mask = __ballot(live);
+        if (mask == 0) continue;
+        const int leader = __ffsll((long long)mask) - 1;
+        int base = 0;
+        if (lane == leader) base = atomicAdd(&a.counters[f * PJ_CNT + PJ_NLIVE], __popcll(mask));
+        base = __shfl(base, leader);
+        if (live) {
+            const long long slot = (long long)f * a.m + base + __popcll(mask & ((1ull << lane) - 1));
+            a.live[slot] = (unsigned)iq | (obs ? 0x80000000u : 0u);
+            a.pick[slot] = pick;
+            a.pick_dist[slot] = dist;
+            int e[PJ_K], cnt = 0;
+#pragma unroll
+            for (int s = 0; s < PJ_K; s++) {
+                e[s] = key_entry(k[s]);
+                cnt += k[s] != ~0ull;
+            }
+            a.cand[2 * slot] = make_uint4((unsigned)cnt | (trunc ? 0x100u : 0u), (unsigned)e[0], (unsigned)e[1], (unsigned)e[2]);
+            a.cand[2 * slot + 1] = make_uint4((unsigned)e[3], (unsigned)e[4], (unsigned)e[5], (unsigned)e[6]);
+        }
     }
 }
 
@@ -286,24 +369,31 @@ __global__ __launch_bounds__(256) void k_proj_round0(ProjB a)
 //   owner of a keypoint = the LAST accepted point that picked it (:233 overwrites), its distance the score;
 //   rotation consistency (ORBmatcher.cc:1548-1591): bin of every accepted point, histogram, the reference's
 //   three-maxima scan, then every point in a discarded bin clears the keypoint it took and costs one match.
+// TABG: the per-keypoint tables live in HBM (more than 12 288 keypoints) and are read past the L1, because the
+// other waves of the workgroup update them with L2 atomics.
 template <bool TABG>
 __global__ __launch_bounds__(1024) void k_proj_resolve(ProjB a)
 {
     extern __shared__ int lds_tab[];
     __shared__ int histo[HISTO_LENGTH];
     __shared__ int keep[3];
-    __shared__ int s_acc[2];
+    __shared__ int s_acc[3];
     const int tid = threadIdx.x, f = blockIdx.x;
     const int n = frame_n(a, f);
-    int* tab = TABG ? a.tab_g + (long long)f * a.n_cap : lds_tab;
+    int* tab = TABG ? a.tab_g + 2LL * f * a.n_cap : lds_tab;   // claim table, then owner table
+    int* sc = tab + (TABG ? a.n_cap : n);                       // score of the owner
     int* pick = a.pick + (long long)f * a.m;
     int* pick_dist = a.pick_dist + (long long)f * a.m;
     const unsigned* live = a.live + (long long)f * a.m;
+    const uint4* cand = a.cand + 2LL * f * a.m;
+    int* rot_bin = a.rot_bin + (long long)f * a.m;
     int* out_mp = a.out_mp + (long long)f * a.n_cap;
     int* out_score = a.out_score + (long long)f * a.n_cap;
+    auto tab_load = [&](const int* p) { return TABG ? __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *p; };
     int nlive = a.counters[f * PJ_CNT + PJ_NLIVE];
     if (nlive > a.m) nlive = a.m;
-    int rounds = 0;
+    if (tid < 3) s_acc[tid] = 0;
+    int rounds = 0, fallbacks = 0;
     if (nlive > 0) {
         for (;;) {
             rounds++;
@@ -311,23 +401,46 @@ __global__ __launch_bounds__(1024) void k_proj_resolve(ProjB a)
             __syncthreads();
             for (int t = tid; t < nlive; t += 1024) {
                 const unsigned e = live[t];
-                if (e & 0x80000000u) {
-                    const int k = pick[e & 0x7FFFFFFFu];
-                    if (k >= 0) atomicMin(&tab[k], (int)(e & 0x7FFFFFFFu));
-                }
+                const int k = pick[t];
+                if ((e & 0x80000000u) && k >= 0) atomicMin(&tab[k], (int)(e & 0x7FFFFFFFu));
             }
             __syncthreads();
             int changed = 0;
             for (int t = tid; t < nlive; t += 1024) {
                 const int iq = (int)(live[t] & 0x7FFFFFFFu);
-                const ProjQ q = load_query(a, f, iq);
+                const uint4 c0 = cand[2 * t], c1 = cand[2 * t + 1];
+                const int cnt = (int)(c0.x & 0xFF);
+                const int ent[PJ_K] = {(int)c0.y, (int)c0.z, (int)c0.w, (int)c1.x, (int)c1.y, (int)c1.z, (int)c1.w};
+                int e1 = -1, e2 = -1;
+#pragma unroll
+                for (int s = 0; s < PJ_K; s++) {
+                    if (s < cnt && e2 < 0) {
+                        const bool free_ = tab_load(&tab[ent[s] & 0xFFFF]) >= iq;   // not claimed by a lower point
+                        if (free_) { if (e1 < 0) e1 = ent[s]; else e2 = ent[s]; }
+                    }
+                }
                 int np, nd;
-                bool lv;
-                eval_point<false, TABG>(a, f, n, iq, q, tab, &np, &nd, &lv);
-                if (np != pick[iq] || nd != pick_dist[iq]) {
+                if ((c0.x & 0x100u) && e2 < 0) {
+                    // the cached prefix ran out before a best and a second were found, and the point has more
+                    // candidates than the cache holds: full re-evaluation from the grid (rare)
+                    unsigned long long k1 = ~0ull, k2 = ~0ull;
+                    const ProjQ q = load_query(a, f, iq);
+                    scan_candidates(a, f, n, iq, q, a.cell_start + (long long)f * (NCELL + 1), a.cell_item + (long long)f * a.n_cap,
+                                    [&](int i) { return tab_load(&tab[i]) < iq; },
+                                    [&](unsigned long long x) {
+                                        const unsigned long long hi = x < k1 ? k1 : x;
+                                        k1 = x < k1 ? x : k1;
+                                        k2 = hi < k2 ? hi : k2;
+                                    });
+                    e1 = key_entry(k1);
+                    e2 = key_entry(k2);
+                    fallbacks++;
+                }
+                accept_rule(a, e1, e2, &np, &nd);
+                if (np != pick[t] || nd != pick_dist[t]) {
                     changed = 1;
-                    pick[iq] = np;
-                    pick_dist[iq] = nd;
+                    pick[t] = np;
+                    pick_dist[t] = nd;
                 }
             }
             if (!__syncthreads_or(changed)) break;
@@ -339,33 +452,35 @@ __global__ __launch_bounds__(1024) void k_proj_resolve(ProjB a)
     }
     // ---- epilogue ----
     if (tid < HISTO_LENGTH) histo[tid] = 0;
-    if (tid < 2) s_acc[tid] = 0;
-    for (int k = tid; k < n; k += 1024) tab[k] = -1;
+    for (int k = tid; k < n; k += 1024) { tab[k] = -1; sc[k] = 0; }
     __syncthreads();
     int cnt = 0;
     for (int t = tid; t < nlive; t += 1024) {
+        const int k = pick[t];
+        if (k < 0) continue;
         const int iq = (int)(live[t] & 0x7FFFFFFFu);
-        const int k = pick[iq];
-        if (k >= 0) {
-            atomicMax(&tab[k], iq);
-            cnt++;
-            if (a.check_ori) {
-                const ProjQ q = load_query(a, f, iq);
-                const float ka = a.kp_angle ? a.kp_angle[(long long)f * a.ang_stride + k] : a.kp[(long long)f * a.kp_stride + k].angle;
-                float rot = q.angle - ka;
-                if (rot < 0.0f) rot += 360.0f;
-                int bin = (int)roundf(rot * (1.0f / HISTO_LENGTH));
-                if (bin == HISTO_LENGTH) bin = 0;
-                atomicAdd(&histo[bin], 1);
-                a.rot_bin[(long long)f * a.m + iq] = bin;
-            }
+        atomicMax(&tab[k], iq);
+        cnt++;
+        if (a.check_ori) {
+            const ProjQ q = load_query(a, f, iq);
+            const float ka = a.kp_angle ? a.kp_angle[(long long)f * a.ang_stride + k] : a.kp[(long long)f * a.kp_stride + k].angle;
+            float rot = q.angle - ka;
+            if (rot < 0.0f) rot += 360.0f;
+            int bin = (int)roundf(rot * (1.0f / HISTO_LENGTH));
+            if (bin == HISTO_LENGTH) bin = 0;
+            atomicAdd(&histo[bin], 1);
+            rot_bin[t] = bin;
         }
     }
     if (cnt) atomicAdd(&s_acc[0], cnt);
+    if (fallbacks) atomicAdd(&s_acc[2], fallbacks);
     __syncthreads();
-    for (int k = tid; k < n; k += 1024) {
-        const int o = TABG ? __hip_atomic_load(&tab[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : tab[k];
-        out_score[k] = o >= 0 ? pick_dist[o] : 0;
+    for (int t = tid; t < nlive; t += 1024) {   // the owner's distance is the keypoint's score
+        const int k = pick[t];
+        if (k >= 0 && tab_load(&tab[k]) == (int)(live[t] & 0x7FFFFFFFu)) {
+            if (TABG) __hip_atomic_store(&sc[k], pick_dist[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            else sc[k] = pick_dist[t];
+        }
     }
     if (a.check_ori) {
         if (tid == 0) {  // ComputeThreeMaxima, ORBmatcher.cc:1723-1764
@@ -383,10 +498,9 @@ __global__ __launch_bounds__(1024) void k_proj_resolve(ProjB a)
         __syncthreads();
         int drop = 0;
         for (int t = tid; t < nlive; t += 1024) {
-            const int iq = (int)(live[t] & 0x7FFFFFFFu);
-            const int k = pick[iq];
+            const int k = pick[t];
             if (k < 0) continue;
-            const int b = a.rot_bin[(long long)f * a.m + iq];
+            const int b = rot_bin[t];
             if (b != keep[0] && b != keep[1] && b != keep[2]) {
                 if (TABG) __hip_atomic_store(&tab[k], -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 else tab[k] = -1;   // benign race: every writer stores -1
@@ -394,13 +508,16 @@ __global__ __launch_bounds__(1024) void k_proj_resolve(ProjB a)
             }
         }
         if (drop) atomicAdd(&s_acc[1], drop);
-        __syncthreads();
     }
-    for (int k = tid; k < n; k += 1024)
-        out_mp[k] = TABG ? __hip_atomic_load(&tab[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : tab[k];
+    __syncthreads();
+    for (int k = tid; k < n; k += 1024) {
+        out_mp[k] = tab_load(&tab[k]);
+        out_score[k] = tab_load(&sc[k]);
+    }
     if (tid == 0) {
         a.counters[f * PJ_CNT + PJ_NMATCH] = s_acc[0] - s_acc[1];
         a.counters[f * PJ_CNT + PJ_ROUNDS] = rounds + 1;
+        a.counters[f * PJ_CNT + PJ_FALLBACK] = s_acc[2];
     }
 }
 
@@ -436,13 +553,13 @@ static int pj_reserve(gfo_ctx* c, int frames, int m, int n_cap)
     const size_t F = (size_t)(frames > 1 ? frames : 1), M = (size_t)(m > 1 ? m : 1), N = (size_t)(n_cap > 1 ? n_cap : 1);
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = off; off = al256(off + bytes); return o; };
-    const size_t o_cs = take(F * (NCELL + 1) * 4), o_xy = take(F * N * 8), o_me = take(F * N * 4), o_pk = take(F * M * 4),
-                 o_pd = take(F * M * 4), o_lv = take(F * M * 4), o_rb = take(F * M * 4), o_tg = take(F * N * 4),
-                 o_ct = take(F * PJ_CNT * 4), o_om = take(F * N * 4), o_os = take(F * N * 4);
+    const size_t o_cs = take(F * (NCELL + 1) * 4), o_it = take(F * N * 16), o_pk = take(F * M * 4),
+                 o_pd = take(F * M * 4), o_lv = take(F * M * 4), o_cd = take(F * M * 32), o_rb = take(F * M * 4),
+                 o_tg = take(F * N * 8), o_ct = take(F * PJ_CNT * 4), o_om = take(F * N * 4), o_os = take(F * N * 4);
     PTRY(c, hipMalloc(&b.base, off));
     uint8_t* S = (uint8_t*)b.base;
-    b.cell_start = (int*)(S + o_cs); b.cell_xy = S + o_xy; b.cell_meta = (unsigned*)(S + o_me);
-    b.pick = (int*)(S + o_pk); b.pick_dist = (int*)(S + o_pd); b.live = (unsigned*)(S + o_lv); b.rot_bin = (int*)(S + o_rb);
+    b.cell_start = (int*)(S + o_cs); b.cell_item = S + o_it;
+    b.pick = (int*)(S + o_pk); b.pick_dist = (int*)(S + o_pd); b.live = (unsigned*)(S + o_lv); b.cand = S + o_cd; b.rot_bin = (int*)(S + o_rb);
     b.tab_g = (int*)(S + o_tg); b.counters = (int*)(S + o_ct); b.out_mp = (int*)(S + o_om); b.out_score = (int*)(S + o_os);
     b.frames_cap = (int)F; b.m_cap = (int)M; b.n_cap = (int)N;
     return GFO_OK;
@@ -452,8 +569,8 @@ static void pj_bind(const gfo_ctx* c, ProjB* a)
 {
     const GfoProjBuf& b = c->pj;
     a->n_cap = b.n_cap;
-    a->cell_start = b.cell_start; a->cell_xy = (float2*)b.cell_xy; a->cell_meta = b.cell_meta;
-    a->pick = b.pick; a->pick_dist = b.pick_dist; a->live = b.live; a->rot_bin = b.rot_bin;
+    a->cell_start = b.cell_start; a->cell_item = (float4*)b.cell_item;
+    a->pick = b.pick; a->pick_dist = b.pick_dist; a->live = b.live; a->cand = (uint4*)b.cand; a->rot_bin = b.rot_bin;
     a->tab_g = b.tab_g; a->counters = b.counters; a->out_mp = b.out_mp; a->out_score = b.out_score;
 }
 
@@ -463,8 +580,23 @@ static int pj_launch(gfo_ctx* c, const ProjB& a, int frames, int n_max)
     hipStream_t st = c->stream;
     gfo_prof_begin(c, ST_PROJECT);
     hipLaunchKernelGGL(k_proj_grid, dim3(frames), dim3(1024), 0, st, a);
-    hipLaunchKernelGGL(k_proj_round0, dim3((a.m + 255) / 256, frames), dim3(256), 0, st, a);
-    const size_t tab_bytes = (size_t)n_max * 4;
+    // round 0 against an LDS copy of the grid when it fits twice per CU: workgroups of 1024 threads, as many per
+    // frame as it takes to put ~2 on every CU (each pays the 78 KB copy once, then walks its chunk of the points)
+    const size_t grid_bytes = (size_t)a.n_cap * 16 + (NCELL + 1) * 4;
+    static const int lds_grid_on = getenv("GFO_PROJ_LDSGRID") ? atoi(getenv("GFO_PROJ_LDSGRID")) : 1;
+    if (lds_grid_on && grid_bytes <= 78 * 1024 && a.m >= 4096) {
+        int per_frame = (512 + frames - 1) / frames;
+        const int max_pf = (a.m + 2047) / 2048;     // at least two passes of 1024 points per workgroup
+        if (per_frame > max_pf) per_frame = max_pf;
+        if (per_frame < 1) per_frame = 1;
+        const int chunk = ((a.m + per_frame - 1) / per_frame + 63) / 64 * 64;
+        if (grid_bytes > 48 * 1024)
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_proj_round0<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+        hipLaunchKernelGGL(k_proj_round0<true>, dim3((a.m + chunk - 1) / chunk, frames), dim3(1024), grid_bytes, st, a, chunk);
+    } else {
+        hipLaunchKernelGGL(k_proj_round0<false>, dim3((a.m + 255) / 256, frames), dim3(256), 0, st, a, 256);
+    }
+    const size_t tab_bytes = (size_t)n_max * 8;   // claim / owner table + score table
     if (tab_bytes <= 96 * 1024) {
         if (tab_bytes > 48 * 1024)   // beyond the default dynamic-LDS grant: raised per call (per device), rare
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_proj_resolve<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
@@ -491,7 +623,7 @@ extern "C" int gfo_search_by_projection_queries(gfo_ctx* c, const gfo_keypoint* 
     if (n > 65535) return pj_fail(c, GFO_ERR_INVALID, "gfo_search_by_projection: more than 65535 keypoints");
     if (!(fb->max_x > fb->min_x) || !(fb->max_y > fb->min_y)) return pj_fail(c, GFO_ERR_INVALID, "gfo_search_by_projection: empty frame bounds");
     for (int i = 0; i < n; i++)
-        if (kp_un[i].octave < 0 || kp_un[i].octave > 255) return pj_fail(c, GFO_ERR_INVALID, "gfo_search_by_projection: keypoint octave outside 0..255");
+        if (kp_un[i].octave < 0 || kp_un[i].octave > 127) return pj_fail(c, GFO_ERR_INVALID, "gfo_search_by_projection: keypoint octave outside 0..127");
     *nmatches = 0;
     for (int i = 0; i < n; i++) { out_mp[i] = -1; out_score[i] = 0; }
     if (n == 0 || m == 0) return GFO_OK;
