@@ -111,18 +111,26 @@ __device__ __forceinline__ int corner_score(const uint8_t* __restrict__ c, int t
 
 // TP / SP: pitch of the pixel tile and of the score map in LDS, compile-time so that every ring and neighbour
 // offset is an immediate of the LDS instruction (three buckets cover cells up to 64 px).
-template <int TP, int SP>
+// XCD8: workgroups are dealt round-robin over the 8 XCDs (workgroup b runs on XCD b % 8), so with the plain
+// (cells, images) grid the four neighbours of a cell -- which share its 6-px overlap rows and columns and the
+// 16-byte segments around them -- sit on four OTHER XCDs and every one of them pulls the shared lines through the
+// fabric into its own L2 (measured 344 MB fetched per 143 MB of pyramid).  The XCD8 grid is
+// (8 * cell blocks, ceil(images / 8)): blockIdx.x & 7 picks the image inside a group of eight, so ALL cells of an
+// image run on one XCD and an image's levels (1.1 MB) enter exactly one 4-MB L2.  Speed only: any placement gives
+// the same candidates.
+template <int TP, int SP, bool XCD8>
 __global__ __launch_bounds__(256) void k_fast(const GfoGeom* __restrict__ gp, GfoInput in,
                                               const uint8_t* __restrict__ pyr, uint32_t* __restrict__ cand,
                                               int* __restrict__ cand_cnt, int* __restrict__ flags, const int* __restrict__ cell_tab,
-                                              int dbg_stop)
+                                              int nimg, int dbg_stop)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     const GfoGeom& g = *gp;
     // the wave index is uniform: keep it (and the cell geometry derived from it) in scalar registers
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-    const int img = blockIdx.y;
-    const int cell = blockIdx.x * (int)(blockDim.x >> 6) + wave;
+    const int img = XCD8 ? (int)(blockIdx.y * 8 + (blockIdx.x & 7)) : (int)blockIdx.y;
+    if (XCD8 && img >= nimg) return;   // the last group of 8 may be partly empty
+    const int cell = (int)(XCD8 ? blockIdx.x >> 3 : blockIdx.x) * (int)(blockDim.x >> 6) + wave;
     const int tile_bytes = TP * g.fast_tile_rows, smap_bytes = (SP * g.fast_smap_rows + 15) & ~15;
     const int per_wave = tile_bytes + smap_bytes + 2 * g.fast_npx_max;  // one u16 queue, compacted in place
     uint8_t* tile = lds + wave * per_wave;
@@ -340,12 +348,22 @@ void gfo_launch_fast(gfo_ctx* c, const GfoInput& in, int nimg)
     if (g.total_cells == 0) return;  // image too small for a single 30-px cell on any level: no candidates
     static const int nw = getenv("GFO_FAST_WAVES") ? atoi(getenv("GFO_FAST_WAVES")) : 1;   // cells (waves) per workgroup: 1 measured 2 % faster than 4
     const size_t lds = nw * (size_t)(g.fast_tile_pitch * g.fast_tile_rows + ((g.fast_smap_pitch * g.fast_smap_rows + 15) & ~15) + 2 * g.fast_npx_max);
-    dim3 grid((g.total_cells + nw - 1) / nw, nimg);
+    const int cell_blocks = (g.total_cells + nw - 1) / nw;
+    // one image per XCD from 8 images up (below that, 7 of 8 workgroups would be empty: plain grid)
+    static const int xcd_env = getenv("GFO_FAST_XCD") ? atoi(getenv("GFO_FAST_XCD")) : 1;
+    const bool xcd8 = xcd_env && nimg >= 8;
+    const dim3 grid = xcd8 ? dim3((unsigned)cell_blocks * 8u, (unsigned)(nimg + 7) / 8u) : dim3(cell_blocks, nimg);
     gfo_prof_begin(c, ST_FAST);
     static const int dbg_stop = getenv("GFO_FAST_STOP") ? atoi(getenv("GFO_FAST_STOP")) : 0;  // timing experiments only
 #define GFO_FAST_LAUNCH(TP_, SP_)                                                                                       \
-    hipLaunchKernelGGL((k_fast<TP_, SP_>), grid, dim3(64 * nw), lds, c->stream, c->d_geom, in, c->d_pyr, c->d_cand, c->d_cand_cnt, \
-                       c->d_flags, c->d_cell_tab, dbg_stop)
+    do {                                                                                                                \
+        if (xcd8)                                                                                                       \
+            hipLaunchKernelGGL((k_fast<TP_, SP_, true>), grid, dim3(64 * nw), lds, c->stream, c->d_geom, in, c->d_pyr, c->d_cand, \
+                               c->d_cand_cnt, c->d_flags, c->d_cell_tab, nimg, dbg_stop);                               \
+        else                                                                                                            \
+            hipLaunchKernelGGL((k_fast<TP_, SP_, false>), grid, dim3(64 * nw), lds, c->stream, c->d_geom, in, c->d_pyr, c->d_cand, \
+                               c->d_cand_cnt, c->d_flags, c->d_cell_tab, nimg, dbg_stop);                               \
+    } while (0)
     if (g.fast_tile_pitch == 48) GFO_FAST_LAUNCH(48, 44);
     else if (g.fast_tile_pitch == 64) GFO_FAST_LAUNCH(64, 60);
     else GFO_FAST_LAUNCH(80, 76);

@@ -4,7 +4,7 @@ cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT; OUT=$R/gpurun_out/pmc_fast; rm -rf $OUT; mkdir -p $OUT; cd $R
 for s in 1 2 3 4 0; do
   export GFO_FAST_STOP=$s
-  rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES --output-format csv -d $OUT/s$s -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --profile-steps 1 --streams 1 > $OUT/s$s.log 2>&1
+  rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES --output-format csv -d $OUT/s$s -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-other-configs --profile-steps 1 --streams 1 > $OUT/s$s.log 2>&1
 done
 python3 - <<'PY'
 import csv, glob, os, collections

@@ -4,7 +4,7 @@
 # Outputs land under gpurun_out/prof_<tag>/ ; tools/summarize_profile.py turns them into profiles/.
 set -o pipefail
 TAG=${1:-r01}
-ARGS=${2:---steps 10 --warmup 2 --no-cpu-baseline --streams 1}
+ARGS=${2:---steps 10 --warmup 2 --no-cpu-baseline --no-other-configs --streams 1}
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/prof_$TAG

@@ -1,7 +1,7 @@
 #!/bin/bash
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT; OUT=$R/gpurun_out/trace_q; rm -rf $OUT; mkdir -p $OUT; cd $R
-rocprofv3 --kernel-trace --output-format csv -d $OUT -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --profile-steps 1 ${BENCH_ARGS} > $OUT/log.txt 2>&1
+rocprofv3 --kernel-trace --output-format csv -d $OUT -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-other-configs --profile-steps 1 ${BENCH_ARGS} > $OUT/log.txt 2>&1
 python3 - <<'PY'
 import csv, glob, os, collections
 root=os.path.join(os.environ['GRAFT_REPO_ROOT'],'gpurun_out','trace_q')
