@@ -70,7 +70,8 @@ SYMBOLS = [
 
 
 def lib_path():
-    return os.path.join(_HERE, "libgfo.so")
+    # GFO_LIB: an instrumented build of the same ABI (tools/pmc_fast_phases.sh); the product is always libgfo.so
+    return os.environ.get("GFO_LIB") or os.path.join(_HERE, "libgfo.so")
 
 
 _lib = None
@@ -98,8 +99,38 @@ def _share_hip_runtime_with_torch():
                 return
 
 
+def mapped_hip_runtimes():
+    """Distinct files of the HIP / HSA runtime mapped into this process: {soname stem: set(paths)}."""
+    found = {"libamdhip64": set(), "libhsa-runtime64": set()}
+    try:
+        with open("/proc/self/maps") as f:
+            for line in f:
+                path = line.rsplit(None, 1)[-1] if "/" in line else ""
+                base = os.path.basename(path)
+                for stem in found:
+                    if base.startswith(stem + ".so"):
+                        found[stem].add(os.path.realpath(path))
+    except OSError:
+        pass
+    return found
+
+
+def _check_single_hip_runtime():
+    """Two copies of libamdhip64 / libhsa-runtime64 in one process (PyTorch's bundled one plus /opt/rocm's) each
+    bring up their own runtime; the second then reports "No HIP GPUs are available" or stalls.  Refuse loudly."""
+    dup = {k: sorted(v) for k, v in mapped_hip_runtimes().items() if len(v) > 1}
+    if dup:
+        raise GfoError(-2, "two HIP runtimes are mapped into this process: " + "; ".join(f"{k}: {v}" for k, v in dup.items()) +
+                       " -- import gf_orb_slam2_amd (or torch) before anything else loads /opt/rocm's libamdhip64, so "
+                       "that libgfo.so binds to the copy PyTorch ships")
+
+
 def load_library():
-    """Loads libgfo.so; raises if it has not been built (no fallback of any kind)."""
+    """Loads libgfo.so; raises if it has not been built (no fallback of any kind).
+
+    Import order: any order of `import torch` / `import gf_orb_slam2_amd` works -- this function pre-loads PyTorch's
+    bundled libamdhip64 / libhsa-runtime64 (same SONAMEs as /opt/rocm's) so that libgfo.so and a later `import torch`
+    share ONE runtime, then verifies through /proc/self/maps that a single copy of each is mapped."""
     global _lib
     if _lib is not None:
         return _lib
@@ -108,6 +139,7 @@ def load_library():
         raise GfoError(-2, f"{p} not built: run `python -c 'import __graft_entry__ as g; g.build()'`")
     _share_hip_runtime_with_torch()
     L = C.CDLL(p)
+    _check_single_hip_runtime()
     vp, i, f, sz = C.c_void_p, C.c_int, C.c_float, C.c_size_t
     ip = C.POINTER(C.c_int)
     L.gfo_version.restype = i

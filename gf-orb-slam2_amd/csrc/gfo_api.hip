@@ -639,10 +639,12 @@ static int check_flags(gfo_ctx* c)
     int f[4] = {0, 0, 0, 0};
     HIP_TRY(c, hipMemcpyAsync(f, c->d_flags, sizeof f, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
+#ifdef GFO_FAST_DEBUG
     if (getenv("GFO_FAST_STOP") && atoi(getenv("GFO_FAST_STOP")) == 9) {
         fprintf(stderr, "[gfo] FAST selectivity: scan px %d, after compass %d, after pair test %d\n", f[1], f[2], f[3]);
         (void)hipMemsetAsync(c->d_flags, 0, sizeof f, c->stream);
     }
+#endif
     if (f[0]) {
         (void)hipMemsetAsync(c->d_flags, 0, sizeof f, c->stream);
         return fail(c, GFO_ERR_OVERFLOW, "internal buffer overflow (flags 0x%x: 1 candidates, 2 quadtree nodes, 4 selection, 8 keypoints)", f[0]);
@@ -666,6 +668,7 @@ extern "C" int gfo_extract_batch_device(gfo_ctx* c, const uint8_t* d_imgs, int n
                                         size_t img_stride)
 {
     if (!c || !d_imgs || nimg < 1 || w < 1 || h < 1 || pitch < (size_t)w) return fail(c, GFO_ERR_INVALID, "bad argument");
+    if (nimg > 1 && img_stride < pitch * (size_t)h) return fail(c, GFO_ERR_INVALID, "img_stride %zu < pitch * h = %zu: images overlap", img_stride, pitch * (size_t)h);
     HIP_TRY(c, hipSetDevice(c->device));
     int rc = plan(c, w, h, nimg);
     if (rc) return rc;
@@ -860,6 +863,11 @@ extern "C" int gfo_stereo_match(gfo_ctx* c, const gfo_keypoint* kl, const uint8_
     if (nr > 65535) return fail(c, GFO_ERR_INVALID, "more than 65535 right keypoints");
     *nmatched = 0;
     if (nl == 0) return GFO_OK;
+    // the kernels index scale[octave] (Frame.h:244, Frame.cc:1204-1206 do the same, unchecked): refuse what would read past it
+    for (int i = 0; i < nl; i++)
+        if (kl[i].octave < 0 || kl[i].octave >= nlevels) return fail(c, GFO_ERR_INVALID, "left keypoint %d: octave %d outside 0..%d", i, kl[i].octave, nlevels - 1);
+    for (int i = 0; i < nr; i++)
+        if (kr[i].octave < 0 || kr[i].octave >= nlevels) return fail(c, GFO_ERR_INVALID, "right keypoint %d: octave %d outside 0..%d", i, kr[i].octave, nlevels - 1);
     HIP_TRY(c, hipSetDevice(c->device));
     if (p->n_rows < 1 || p->n_rows > 8192) return fail(c, GFO_ERR_INVALID, "n_rows must be 1..8192");
     // scratch layout

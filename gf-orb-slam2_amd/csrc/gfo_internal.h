@@ -176,6 +176,7 @@ struct gfo_ctx {
     int* d_yofs = nullptr;
     uint8_t* d_qt_scratch = nullptr;   // quadtree state in HBM, only when a level's state exceeds LDS
     size_t qt_scratch_stride = 0;      // bytes per (image, level) workgroup
+    size_t qt_lds_granted = 0;         // dynamic LDS limit already raised for k_quadtree on this context's device
     int* d_cell_tab = nullptr;    // FAST: cell -> level | row << 4 | column << 16
     int* d_band = nullptr;        // per group: int4 [nb][nlevels] = {c0, c1, o0, o1}
     GfoBandGroup band_groups[GFO_MAX_LEVELS];   // nb == 0: a single level launched as k_resize

@@ -122,7 +122,11 @@ template <int TP, int SP, bool XCD8>
 __global__ __launch_bounds__(256) void k_fast(const GfoGeom* __restrict__ gp, GfoInput in,
                                               const uint8_t* __restrict__ pyr, uint32_t* __restrict__ cand,
                                               int* __restrict__ cand_cnt, int* __restrict__ flags, const int* __restrict__ cell_tab,
-                                              int nimg, int dbg_stop)
+                                              int nimg
+#ifdef GFO_FAST_DEBUG
+                                              , int dbg_stop   // tools/pmc_fast_phases.sh only: truncate after a phase
+#endif
+                                              )
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     const GfoGeom& g = *gp;
@@ -198,7 +202,9 @@ __global__ __launch_bounds__(256) void k_fast(const GfoGeom* __restrict__ gp, Gf
         for (int t = lane; t < ((sh + 2) * SP + 15) >> 4; t += 64) sm128[t] = z4;
     }
     wave_sync();
+#ifdef GFO_FAST_DEBUG
     if (dbg_stop == 1) return;
+#endif
     const uint8_t* t0 = tile + 3 * TP + xoff + 3;  // scan pixel (0,0)
     // The cascade runs at iniThFAST first; only a cell that yields no maximum there repeats it at
     // minThFAST (ORBextractor.cc:811-818).  Scores left in the map by the first round are true S values,
@@ -275,7 +281,9 @@ __global__ __launch_bounds__(256) void k_fast(const GfoGeom* __restrict__ gp, Gf
         }
     }
     wave_sync();
+#ifdef GFO_FAST_DEBUG
     if (dbg_stop == 2) { if (na == 12345) flags[1] = 1; return; }
+#endif
     // ---- B: score S of the survivors (corner <=> S > threshold), written to the cell's score map; the corners
     //         are compacted into qb ----
     nb = 0;
@@ -295,9 +303,11 @@ __global__ __launch_bounds__(256) void k_fast(const GfoGeom* __restrict__ gp, Gf
         }
     }
     wave_sync();
+#ifdef GFO_FAST_DEBUG
     if (dbg_stop == 3) { if (nb == 12345) flags[1] = 1; return; }
     if (dbg_stop == 4 && round == 1) return;
     if (dbg_stop == 9) { if (lane == 0) { atomicAdd(&flags[1], sw * sh); atomicAdd(&flags[2], na); atomicAdd(&flags[3], nb); } }
+#endif
     // ---- N: strict local maxima of S among the corners; their keys (x, y, S-1) are compacted into the tile's
     //         LDS (the pixels are no longer needed once a maximum exists: a cell with none leaves the tile
     //         untouched for the second round) ----
@@ -354,19 +364,25 @@ void gfo_launch_fast(gfo_ctx* c, const GfoInput& in, int nimg)
     const bool xcd8 = xcd_env && nimg >= 8;
     const dim3 grid = xcd8 ? dim3((unsigned)cell_blocks * 8u, (unsigned)(nimg + 7) / 8u) : dim3(cell_blocks, nimg);
     gfo_prof_begin(c, ST_FAST);
-    static const int dbg_stop = getenv("GFO_FAST_STOP") ? atoi(getenv("GFO_FAST_STOP")) : 0;  // timing experiments only
+#ifdef GFO_FAST_DEBUG
+    static const int dbg_stop = getenv("GFO_FAST_STOP") ? atoi(getenv("GFO_FAST_STOP")) : 0;  // instruction-count experiments only
+#define GFO_FAST_DBG_ARG , dbg_stop
+#else
+#define GFO_FAST_DBG_ARG
+#endif
 #define GFO_FAST_LAUNCH(TP_, SP_)                                                                                       \
     do {                                                                                                                \
         if (xcd8)                                                                                                       \
             hipLaunchKernelGGL((k_fast<TP_, SP_, true>), grid, dim3(64 * nw), lds, c->stream, c->d_geom, in, c->d_pyr, c->d_cand, \
-                               c->d_cand_cnt, c->d_flags, c->d_cell_tab, nimg, dbg_stop);                               \
+                               c->d_cand_cnt, c->d_flags, c->d_cell_tab, nimg GFO_FAST_DBG_ARG);                        \
         else                                                                                                            \
             hipLaunchKernelGGL((k_fast<TP_, SP_, false>), grid, dim3(64 * nw), lds, c->stream, c->d_geom, in, c->d_pyr, c->d_cand, \
-                               c->d_cand_cnt, c->d_flags, c->d_cell_tab, nimg, dbg_stop);                               \
+                               c->d_cand_cnt, c->d_flags, c->d_cell_tab, nimg GFO_FAST_DBG_ARG);                        \
     } while (0)
     if (g.fast_tile_pitch == 48) GFO_FAST_LAUNCH(48, 44);
     else if (g.fast_tile_pitch == 64) GFO_FAST_LAUNCH(64, 60);
     else GFO_FAST_LAUNCH(80, 76);
 #undef GFO_FAST_LAUNCH
+#undef GFO_FAST_DBG_ARG
     gfo_prof_end(c);
 }

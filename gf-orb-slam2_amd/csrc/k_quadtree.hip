@@ -148,12 +148,15 @@ void gfo_launch_quadtree(gfo_ctx* c, int nimg)
     while (klds > 0 && gfo_quadtree_lds_bytes(ncap, klds) > 150 * 1024) klds -= 1024;
     const size_t lds = gfo_quadtree_lds_bytes(ncap, klds);
     const bool gmem = lds > 160 * 1024;   // state of the largest level does not fit LDS: scratch in HBM (plan() sized it)
-    if (!gmem && lds > 64 * 1024) {
-        static size_t granted = 0;   // per process: the attribute only ever grows
-        if (lds > granted) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_quadtree), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            granted = lds;
+    if (!gmem && lds > 64 * 1024 && lds > c->qt_lds_granted) {
+        // raised per context (= per device; contexts may be driven from different threads): the grant only grows
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_quadtree), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            if (c->launch_err.empty()) c->launch_err = std::string("stage quadtree: cannot raise the dynamic LDS limit: ") + hipGetErrorString(e);
+            return;
         }
+        c->qt_lds_granted = lds;
     }
     dim3 grid(nimg, c->g.nlevels);
     // the per-pass key loops are latency-bound inside a workgroup: large quotas (1080p @4000 features) get

@@ -162,9 +162,8 @@ __global__ __launch_bounds__(256) void k_stereo_match(StereoArgs a)
     const uint4* dlp = reinterpret_cast<const uint4*>(dl + (long long)iL * 32);
     const uint4 a0 = dlp[0], a1 = dlp[1];
     const int* rs = a.row_start + (long long)pair * (nRows + 1);
-    int jb = rs[max(row - a.window, 0)], je = in_rows ? rs[min(row + a.window + 1, nRows)] : jb;
-    jb = min(max(jb, 0), a.sort_stride);  // the table is this kernel's input: never trust it with a loop bound
-    je = min(max(je, jb), a.sort_stride);
+    // every entry of row_start[0..nRows] is written by k_stereo_bucket of this launch sequence (values 0..nr)
+    const int jb = rs[max(row - a.window, 0)], je = in_rows ? rs[min(row + a.window + 1, nRows)] : jb;
     unsigned best = ((unsigned)TH_HIGH << 16);  // bestDist = TH_HIGH, iR = 0: only dist < TH_HIGH replaces it
     bool any = false;
     for (int j = jb + hl; j < je; j += 32) {
@@ -198,7 +197,7 @@ __global__ __launch_bounds__(256) void k_stereo_match(StereoArgs a)
             if (disparity >= minD && disparity < maxD) {
                 if (disparity <= 0) {
                     disparity = 0.01f;
-                    bestuR = uL - 0.01f;
+                    bestuR = (float)((double)uL - 0.01);   // `uL-0.01` is double arithmetic in the reference (Frame.cc:1278)
                 }
                 res_depth = a.p.mbf / disparity;
                 res_u = bestuR;
@@ -305,9 +304,7 @@ __global__ __launch_bounds__(256) void k_stereo_match_sad(SadArgs A)
         const uint4* dlp = reinterpret_cast<const uint4*>(dl + (long long)iL * 32);
         const uint4 a0 = dlp[0], a1 = dlp[1];
         const int* rs = a.row_start + (long long)pair * (nRows + 1);
-        int jb = rs[max(row - a.window, 0)], je = rs[min(row + a.window + 1, nRows)];
-        jb = min(max(jb, 0), a.sort_stride);
-        je = min(max(je, jb), a.sort_stride);
+        const int jb = rs[max(row - a.window, 0)], je = rs[min(row + a.window + 1, nRows)];
         unsigned best = ((unsigned)TH_HIGH << 16);
         for (int j = jb + lane; j < je; j += 64) {
             const float ry = a.sy[so + j];
@@ -374,7 +371,7 @@ __global__ __launch_bounds__(256) void k_stereo_match_sad(SadArgs A)
                         float bestuR = g.lv[lvl].scale * ((float)scaleduR0 + (float)bestinc + deltaR);
                         float disparity = uL - bestuR;
                         if (disparity >= minD && disparity < maxD) {
-                            if (disparity <= 0) { disparity = 0.01f; bestuR = uL - 0.01f; }
+                            if (disparity <= 0) { disparity = 0.01f; bestuR = (float)((double)uL - 0.01); }   // Frame.cc:1053-1054
                             res_depth = a.p.mbf / disparity;
                             res_u = bestuR;
                             res_dist = sadBest;

@@ -96,9 +96,12 @@ int gfo_extract_batch(gfo_ctx* ctx, const uint8_t* const* imgs, int nimg, int w,
                       gfo_keypoint* kp, uint8_t* desc, int cap, int* n);
 
 /* Device-resident form: `d_imgs` is a device pointer to nimg images, `pitch` bytes per row,
- * `img_stride` bytes between images.  Results stay in the arena; fetch with
- * gfo_batch_counts / gfo_batch_fetch or chain gfo_stereo_match_batch. Asynchronous on the
- * context stream. */
+ * `img_stride` bytes between images (>= pitch * h).  Results stay in the arena; fetch with
+ * gfo_batch_counts / gfo_batch_fetch or chain gfo_stereo_match_batch / gfo_search_by_projection_batch.
+ * Asynchronous on the context stream.
+ * Lifetime: level 0 of the pyramid IS the caller's buffer (it is never copied), so d_imgs must stay valid and
+ * unchanged until the next gfo_extract* / gfo_compute_pyramid call on this context or gfo_ctx_destroy --
+ * gfo_pyramid_level(level 0) and gfo_stereo_match_sad_batch read it after this call has returned. */
 int gfo_extract_batch_device(gfo_ctx* ctx, const uint8_t* d_imgs, int nimg, int w, int h,
                              size_t pitch, size_t img_stride);
 int gfo_batch_counts(gfo_ctx* ctx, int* n /*[nimg]*/, int* per_level /*[nimg][nlevels] or NULL*/);

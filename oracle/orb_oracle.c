@@ -8,8 +8,8 @@
  * Build: gcc -O3 -ffp-contract=off (see oracle/Makefile).  No dependencies but libm.
  */
 #include "orb_oracle.h"
-#include "../include/gfo_sincos.h"
 
+#include <float.h>
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
@@ -44,12 +44,53 @@ struct orc_extractor {
     int nkp[MAX_LEVELS];
 };
 
+/* array forms for the sweep tests (tests/test_oracle.py) */
+void orc_fast_atan2_n(const float* y, const float* x, int n, float* out)
+{
+    for (int i = 0; i < n; i++) out[i] = orc_fast_atan2(y[i], x[i]);
+}
+void orc_sincos_n(const float* t, int n, float* s, float* c)
+{
+    for (int i = 0; i < n; i++) orc_sincos(t[i], &s[i], &c[i]);
+}
+
 /* [OCV] cvRound: round half to even (SSE cvtss2si under the default rounding mode). */
 int orc_cv_round(float v) { return (int)lrintf(v); }
 static int cv_round_d(double v) { return (int)lrint(v); }
 
-float orc_fast_atan2(float y, float x) { return gfo_fast_atan2f(y, x); }
-void orc_sincos(float t, float* s, float* c) { gfo_sincosf(t, s, c); }
+/* cv::fastAtan2(y, x), OpenCV 3.4.x scalar path (modules/core/src/mathfuncs_core.simd.hpp, atan_f32): a degree-7 odd
+ * polynomial of min/max in plain float, folded into [0, 360).  Call site: src/ORBextractor.cc:102.  [OCV]
+ * Restated HERE, independently of the product's include/gfo_sincos.h (which the kernels use): the constants below
+ * were typed a second time from the published coefficients, so a mistyped digit on either side shows up
+ * as a GPU-vs-oracle mismatch instead of passing silently. */
+static const float k_rad2deg = 57.295779513082320876798154814105f;            /* (float)(180 / CV_PI) */
+static const float k_atan_c1 = 0.9997878412794807f, k_atan_c3 = -0.3258083974640975f;
+static const float k_atan_c5 = 0.1555786518463281f, k_atan_c7 = -0.04432655554792128f;
+float orc_fast_atan2(float y, float x)
+{
+    const float q1 = k_atan_c1 * k_rad2deg, q3 = k_atan_c3 * k_rad2deg, q5 = k_atan_c5 * k_rad2deg, q7 = k_atan_c7 * k_rad2deg;
+    const float tiny = (float)DBL_EPSILON;
+    const float mx = fabsf(x), my = fabsf(y);
+    const int steep = !(mx >= my);                      /* ax >= ay takes the first branch, NaNs included */
+    const float num = steep ? mx : my, den = (steep ? my : mx) + tiny;
+    const float r = num / den, r2 = r * r;
+    float deg = (((q7 * r2 + q5) * r2 + q3) * r2 + q1) * r;
+    if (steep) deg = 90.f - deg;
+    if (x < 0) deg = 180.f - deg;
+    if (y < 0) deg = 360.f - deg;
+    return deg;
+}
+
+/* a = (float)cos(angle), b = (float)sin(angle) of src/ORBextractor.cc:111-112, evaluated in the widest host type and
+ * rounded ONCE to float: the correctly rounded result (up to ties finer than 2^-63), which is what a correctly
+ * rounded libm gives the reference.  Independent of include/gfo_sincos.h (the kernels' double-precision evaluation);
+ * tests/test_oracle.py asserts the two agree on every angle the fixtures produce and on a 1M-angle sweep. */
+void orc_sincos(float t, float* s, float* c)
+{
+    const long double w = (long double)t;
+    *s = (float)sinl(w);
+    *c = (float)cosl(w);
+}
 
 /* ------------------------------------------------------------------------------------------
  * ORBextractor::ORBextractor -- ORBextractor.cc:409-469
@@ -597,7 +638,7 @@ static float ic_angle(const uint8_t* img, int stride, int px, int py, const int*
         }
         m_01 += v * v_sum;
     }
-    return gfo_fast_atan2f((float)m_01, (float)m_10);
+    return orc_fast_atan2((float)m_01, (float)m_10);
 }
 
 /* computeOrbDescriptor -- ORBextractor.cc:106-146 */
@@ -608,7 +649,7 @@ static void orb_descriptor(const orc_extractor* e, const uint8_t* img, int strid
     const float angle = angle_deg * factorPI;
     float a, b;
     if (e->trig_mode == ORC_TRIG_LIBM) { a = cosf(angle); b = sinf(angle); }
-    else gfo_sincosf(angle, &b, &a);
+    else orc_sincos(angle, &b, &a);
     const uint8_t* center = img + (size_t)py * stride + px;
     for (int i = 0; i < 32; i++) {
         int val = 0;
@@ -826,7 +867,7 @@ int orc_stereo_match(const orc_keypoint* kl, const uint8_t* dl, int nl,
             float bestuR = kr[bestIdxR].x;
             float disparity = uL - bestuR;
             if (disparity >= minD && disparity < maxD) {
-                if (disparity <= 0) { disparity = 0.01f; bestuR = uL - 0.01f; }
+                if (disparity <= 0) { disparity = 0.01f; bestuR = (float)((double)uL - 0.01); /* double arithmetic, then narrowed: Frame.cc:1054,1278 */ }
                 depth[iL] = p->mbf / disparity;
                 u_right[iL] = bestuR;
                 if (best_dist_out) best_dist_out[iL] = bestDist;
@@ -1284,7 +1325,7 @@ int orc_stereo_match_sad(const orc_extractor* el, const orc_extractor* er,
             float bestuR = el->scale[levelL] * ((float)scaleduR0 + (float)bestincR + deltaR);
             float disparity = uL - bestuR;
             if (disparity >= minD && disparity < maxD) {
-                if (disparity <= 0) { disparity = 0.01f; bestuR = uL - 0.01f; }
+                if (disparity <= 0) { disparity = 0.01f; bestuR = (float)((double)uL - 0.01); /* double arithmetic, then narrowed: Frame.cc:1054,1278 */ }
                 depth[iL] = mbf / disparity;
                 u_right[iL] = bestuR;
                 if (best_dist_out) best_dist_out[iL] = sadBest;

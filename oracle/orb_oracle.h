@@ -31,7 +31,7 @@ typedef struct orc_extractor orc_extractor;
 
 /* variant switches (default 0 everywhere = the variant the golden vectors use) */
 enum {
-    ORC_TRIG_SHARED = 0, /* include/gfo_sincos.h (double-evaluated, rounded once)        */
+    ORC_TRIG_SHARED = 0, /* correctly rounded sin/cos (long double, rounded once); the kernels' include/gfo_sincos.h agrees with it */
     ORC_TRIG_LIBM = 1    /* host libm cosf/sinf, what the reference literally calls      */
 };
 enum {
@@ -79,6 +79,8 @@ void orc_gaussian_blur7_u8(const uint8_t* src, int w, int h, int sstride, uint8_
 int orc_fast9_nms(const uint8_t* img, int w, int h, int stride, int threshold, int* xys, int cap);
 float orc_fast_atan2(float y, float x);
 void orc_sincos(float t, float* s, float* c);
+void orc_fast_atan2_n(const float* y, const float* x, int n, float* out);
+void orc_sincos_n(const float* t, int n, float* s, float* c);
 int orc_cv_round(float v);
 
 /* ORBmatcher::DescriptorDistance (ORBmatcher.cc:1768-1784) */

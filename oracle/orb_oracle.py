@@ -74,6 +74,8 @@ def lib():
         L.orc_fast_atan2.argtypes = [f, f]
         L.orc_sincos.argtypes = [f, C.POINTER(f), C.POINTER(f)]
         L.orc_cv_round.argtypes = [f]
+        L.orc_fast_atan2_n.argtypes = [vp, vp, i, vp]
+        L.orc_sincos_n.argtypes = [vp, i, vp, vp]
         L.orc_hamming256.argtypes = [vp, vp]
         L.orc_stereo_match.argtypes = [vp, vp, i, vp, vp, i, vp, C.POINTER(StereoParams), vp, vp, vp, vp, vp, vp]
         L.orc_search_by_projection.argtypes = [vp, vp, vp, i, vp, C.POINTER(FrameBounds), vp, vp, i, f, f, vp, vp, vp]
@@ -213,6 +215,20 @@ def sincos(t):
     s, c = C.c_float(), C.c_float()
     lib().orc_sincos(float(t), C.byref(s), C.byref(c))
     return s.value, c.value
+
+
+def fast_atan2_n(y, x):
+    y = np.ascontiguousarray(y, np.float32); x = np.ascontiguousarray(x, np.float32)
+    out = np.zeros(len(y), np.float32)
+    lib().orc_fast_atan2_n(_p(y), _p(x), len(y), _p(out))
+    return out
+
+
+def sincos_n(t):
+    t = np.ascontiguousarray(t, np.float32)
+    s = np.zeros(len(t), np.float32); c = np.zeros(len(t), np.float32)
+    lib().orc_sincos_n(_p(t), len(t), _p(s), _p(c))
+    return s, c
 
 
 def stereo_match(kl, dl, kr, dr, scale_factors, n_rows, mbf, mb, min_x=0.0, min_d=None, max_d=None):

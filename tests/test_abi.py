@@ -74,3 +74,15 @@ def test_bad_parameters_rejected_before_touching_the_device(G):
         assert L.gfo_ctx_create(ctypes.byref(bad), 0, ctypes.byref(ctx)) == -1
         assert not ctx.value
     assert L.gfo_ctx_create(None, 0, ctypes.byref(ctx)) == -1
+
+
+def test_one_hip_runtime_is_mapped():
+    """load_library() pre-loads PyTorch's bundled HIP/HSA runtime and then verifies that libgfo.so did not bring in a
+    second copy (two runtimes in one process stall or lose the GPU); any import order must end with one of each."""
+    import gf_orb_slam2_amd as G
+    from gf_orb_slam2_amd._lib import mapped_hip_runtimes
+    G.load_library()
+    import torch  # noqa: F401  (after libgfo, the order a lazy importer gets)
+    m = mapped_hip_runtimes()
+    assert len(m["libamdhip64"]) == 1, m
+    assert len(m["libhsa-runtime64"]) <= 1, m

@@ -137,3 +137,30 @@ def test_sad_subpixel_variant(ext, oracle, euroc_l, euroc_r):
         np.testing.assert_array_equal(gbd, bd)
         assert n > (500 if pair == 0 else 50)
     ext.set_stream(0)
+
+
+def test_host_keypoints_with_bad_octaves_are_refused(oracle):
+    """the kernels index mvScaleFactors[octave] as Frame.h:244 does: a host keypoint outside the pyramid is an error,
+    not an out-of-bounds read; overlapping device images are refused too"""
+    import gf_orb_slam2_amd as G
+    ext = G.ORBextractor(500, 1.2, 8, 20, 7)
+    kd = oracle.KEYPOINT_DTYPE
+    kl = np.zeros(4, kd); kl["x"] = [10, 20, 30, 40]; kl["y"] = 12
+    kr = kl.copy()
+    d = np.zeros((4, 32), np.uint8)
+    m = G.ORBmatcher(0.8, True, extractor=ext)
+    sf = ext.GetScaleFactors()
+    prm = G.StereoParams(480, 47.9, 0.11, 0.0)
+    m.ComputeStereoMatches(kl, d, kr, d, sf, prm)
+    for bad in (-1, 8, 1 << 20):
+        k2 = kl.copy(); k2["octave"][2] = bad
+        for args in ((k2, d, kr, d), (kl, d, k2, d)):
+            with pytest.raises(G.GfoError) as e:
+                m.ComputeStereoMatches(*args, sf, prm)
+            assert e.value.code == -1
+    import torch
+    t = torch.zeros(2 * 240 * 320, dtype=torch.uint8, device="cuda")
+    with pytest.raises(G.GfoError) as e:
+        ext.extract_batch_device(t.data_ptr(), 2, 320, 240, pitch=320, img_stride=320 * 100)
+    assert e.value.code == -1
+    ext.close()

@@ -6,7 +6,7 @@ import os
 import numpy as np
 import pytest
 
-from conftest import GOLDEN, synth_frame
+from conftest import GOLDEN, ROOT, synth_frame
 
 FX, BF = 435.2046959714599, 47.90639384423901
 
@@ -152,8 +152,67 @@ def test_fast_atan2_close_to_libm(oracle):
     assert oracle.fast_atan2(0.0, 0.0) == 0.0
 
 
+def _product_trig():
+    """The PRODUCT's trig header (include/gfo_sincos.h, what the HIP kernels compile) built as a host library of
+    array functions -- so the oracle's independent restatements can be compared with it without a GPU."""
+    import ctypes
+    import subprocess
+    bdir = os.path.join(ROOT, "tests", "_build")
+    os.makedirs(bdir, exist_ok=True)
+    src, so = os.path.join(bdir, "product_trig.c"), os.path.join(bdir, "libproduct_trig.so")
+    code = ('#include "../../include/gfo_sincos.h"\n'
+            'void pt_atan2_n(const float* y, const float* x, int n, float* o) { for (int i = 0; i < n; i++) o[i] = gfo_fast_atan2f(y[i], x[i]); }\n'
+            'void pt_sincos_n(const float* t, int n, float* s, float* c) { for (int i = 0; i < n; i++) gfo_sincosf(t[i], &s[i], &c[i]); }\n')
+    if not os.path.exists(src) or open(src).read() != code:
+        open(src, "w").write(code)
+    hdr = os.path.join(ROOT, "include", "gfo_sincos.h")
+    if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(src), os.path.getmtime(hdr)):
+        subprocess.check_call(["gcc", "-O2", "-march=x86-64-v3", "-ffp-contract=off", "-fPIC", "-shared", "-o", so, src, "-lm"])
+    L = ctypes.CDLL(so)
+    vp = ctypes.c_void_p
+    L.pt_atan2_n.argtypes = [vp, vp, ctypes.c_int, vp]
+    L.pt_sincos_n.argtypes = [vp, ctypes.c_int, vp, vp]
+    return L
+
+
+def test_oracle_trig_is_independent_of_the_product_header_and_agrees_with_it(oracle):
+    """oracle/orb_oracle.c restates fastAtan2 and sin/cos on its own (separately typed constants; long double sin/cos
+    rounded once) -- it must not include the product's include/gfo_sincos.h -- and the two must agree bit for bit on
+    every angle the fixtures produce and on 1M-sample sweeps: a mistyped polynomial constant on EITHER side fails here
+    (CPU) and in every GPU parity test."""
+    src = open(os.path.join(ROOT, "oracle", "orb_oracle.c")).read()
+    assert '#include "../include/gfo_sincos.h"' not in src
+    P = _product_trig()
+    rng = np.random.default_rng(11)
+    # fastAtan2 on intensity-centroid moments (|m| < 2^23, ORBextractor.cc:76-103) and on arbitrary floats
+    n = 1_000_000
+    y = rng.integers(-2 ** 23, 2 ** 23, n).astype(np.float32)
+    x = rng.integers(-2 ** 23, 2 ** 23, n).astype(np.float32)
+    y[:1000] = 0; x[1000:2000] = 0; y[2000:3000] = x[2000:3000]; y[3000:4000] = -x[3000:4000]
+    got = np.zeros(n, np.float32)
+    P.pt_atan2_n(y.ctypes.data, x.ctypes.data, n, got.ctypes.data)
+    np.testing.assert_array_equal(got.view(np.uint32), oracle.fast_atan2_n(y, x).view(np.uint32))
+    yf = (rng.standard_normal(n) * 10.0 ** rng.uniform(-6, 6, n)).astype(np.float32)
+    xf = (rng.standard_normal(n) * 10.0 ** rng.uniform(-6, 6, n)).astype(np.float32)
+    P.pt_atan2_n(yf.ctypes.data, xf.ctypes.data, n, got.ctypes.data)
+    np.testing.assert_array_equal(got.view(np.uint32), oracle.fast_atan2_n(yf, xf).view(np.uint32))
+    # sin/cos on the angles of the golden keypoints and on a sweep of [0, 360) degrees, radians formed as the
+    # reference does (float angle * (float)(CV_PI / 180.f), ORBextractor.cc:75,110)
+    factor = np.float32(np.pi / np.float32(180.0))
+    degs = [np.fromfile(os.path.join(GOLDEN, f"EuRoC_{s_}_kp.bin"), oracle.KEYPOINT_DTYPE)["angle"] for s_ in "lr"]
+    degs.append(rng.uniform(0, 360, n).astype(np.float32))
+    degs.append(np.nextafter(np.float32(360.0), np.float32(0)) * rng.random(n).astype(np.float32) ** 4)   # dense near 0
+    for deg in degs:
+        rad = (deg.astype(np.float32) * factor).astype(np.float32)
+        s1 = np.zeros(len(rad), np.float32); c1 = np.zeros(len(rad), np.float32)
+        P.pt_sincos_n(rad.ctypes.data, len(rad), s1.ctypes.data, c1.ctypes.data)
+        s2, c2 = oracle.sincos_n(rad)
+        np.testing.assert_array_equal(s1.view(np.uint32), s2.view(np.uint32))
+        np.testing.assert_array_equal(c1.view(np.uint32), c2.view(np.uint32))
+
+
 def test_shared_sincos_is_correctly_rounded_almost_everywhere(oracle):
-    """include/gfo_sincos.h vs float64 libm rounded to float, over the angles the descriptor uses."""
+    """the oracle's sin/cos vs float64 libm rounded to float, over the angles the descriptor uses."""
     rng = np.random.default_rng(1)
     deg = rng.uniform(0, 360, 20000).astype(np.float32)
     rad = (deg * np.float32(np.pi / 180.0)).astype(np.float32)
