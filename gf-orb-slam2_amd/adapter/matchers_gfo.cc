@@ -1,0 +1,457 @@
+// matchers_gfo.cc -- the matcher bodies a maintainer swaps in on the reference side.
+//
+// Compile this file inside the reference tree next to (a trimmed) src/Frame.cc / src/ORBmatcher.cc and link
+// libgfo.so.  Every function below has the reference's own signature (include/Frame.h, include/ORBmatcher.h,
+// unchanged) and replaces the body the reference defines at the cited lines; each is guarded by its own macro so the
+// swap can be done one function at a time (-DGFO_ADAPTER_ALL takes all of them):
+//
+//   GFO_ADAPTER_STEREO        Frame::ComputeStereoMatches_Undistorted(bool)                     src/Frame.cc:1167-1316
+//   GFO_ADAPTER_PROJECTION    ORBmatcher::SearchByProjection(Frame&, vector<MapPoint*>&, th)    src/ORBmatcher.cc:155-241
+//   GFO_ADAPTER_PROJ_LAST     ORBmatcher::SearchByProjection(Cur, Last, th, bMono, nVisible)    src/ORBmatcher.cc:1440-1593
+//   GFO_ADAPTER_PROJ_KF       ORBmatcher::SearchByProjection(Cur, KF*, sAlreadyFound, th, dist) src/ORBmatcher.cc:1595-1721
+//   GFO_ADAPTER_BOW           ORBmatcher::SearchByBoW(KeyFrame*, Frame&, vector<MapPoint*>&)    src/ORBmatcher.cc:270-404
+//   GFO_ADAPTER_COMPUTE_BOW   Frame::ComputeBoW()                                               src/Frame.cc:661-668
+//
+// Each body flattens the reference's objects into plain arrays, calls the C ABI (include/gfo.h) and writes the
+// results back into the same members the reference fills.  Error behaviour follows the reference (no exceptions,
+// no status): a gfo error is reported on stderr and the function returns "nothing matched".
+//
+// The device context of a frame is the one its left extractor owns (adapter/ORBextractor_gfo.cc keeps it in a side
+// table because include/ORBextractor.h cannot carry a new member): gfo_context_of().
+#ifdef GFO_ADAPTER_ALL
+#define GFO_ADAPTER_STEREO
+#define GFO_ADAPTER_PROJECTION
+#define GFO_ADAPTER_PROJ_LAST
+#define GFO_ADAPTER_PROJ_KF
+#define GFO_ADAPTER_BOW
+#define GFO_ADAPTER_COMPUTE_BOW
+#endif
+
+#include "Frame.h"
+#include "KeyFrame.h"
+#include "MapPoint.h"
+#include "ORBmatcher.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <set>
+#include <vector>
+
+#include "gfo.h"
+
+namespace ORB_SLAM2
+{
+
+gfo_ctx* gfo_context_of(const ORBextractor* e);   // adapter/ORBextractor_gfo.cc
+
+namespace
+{
+static_assert(sizeof(cv::KeyPoint) == sizeof(gfo_keypoint), "gfo_keypoint must mirror cv::KeyPoint");
+
+inline const gfo_keypoint* as_gfo(const std::vector<cv::KeyPoint>& v) { return reinterpret_cast<const gfo_keypoint*>(v.data()); }
+
+void report(gfo_ctx* c, const char* where) { fprintf(stderr, "[gfo] %s: %s\n", where, gfo_last_error(c)); }
+
+// DBoW2::FeatureVector (std::map<NodeId, std::vector<unsigned int>>, iterated in ascending node id) as the CSR
+// gfo_search_by_bow takes
+struct FlatFeatVec {
+    std::vector<uint32_t> ids, items;
+    std::vector<int32_t> start;
+    gfo_feature_vector view;
+    explicit FlatFeatVec(const DBoW2::FeatureVector& fv)
+    {
+        start.push_back(0);
+        for (DBoW2::FeatureVector::const_iterator it = fv.begin(); it != fv.end(); ++it) {
+            ids.push_back(it->first);
+            items.insert(items.end(), it->second.begin(), it->second.end());
+            start.push_back((int32_t)items.size());
+        }
+        view.node_ids = ids.data();
+        view.node_start = start.data();
+        view.items = items.data();
+        view.n_nodes = (int32_t)ids.size();
+    }
+};
+
+// continuous descriptor rows (mDescriptors is created by the extractor adapter as one N x 32 block; a row view
+// handed in from elsewhere may not be)
+inline const uint8_t* rows32(const cv::Mat& m, cv::Mat& keep)
+{
+    if (m.isContinuous()) return m.data;
+    keep = m.clone();
+    return keep.data;
+}
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------------------------
+#ifdef GFO_ADAPTER_STEREO
+int Frame::ComputeStereoMatches_Undistorted(bool /*isOnline*/)
+{
+    const int nRows = mpORBextractorLeft->mvImagePyramid[0].rows;
+    mvuRight.assign(N, -1.0f);
+    mvDepth.assign(N, -1.0f);
+    mvStereoMatched.assign(N, true);
+    mvDistIdx.clear();
+    std::vector<float> minD, maxD;
+    bool windows = false;                      // Frame.cc:1220-1231: per-keypoint disparity window
+    for (int iL = 0; iL < N && !windows; iL++) windows = mvpMapPoints[iL] != NULL;
+    if (windows) {
+        minD.assign(N, 0.f);
+        maxD.assign(N, mbf / mb);
+        for (int iL = 0; iL < N; iL++) {
+            MapPoint* pMP = mvpMapPoints[iL];
+            if (!pMP || pMP->isBad()) continue;
+            cv::Mat Pw = pMP->GetWorldPos(), Pc;
+            if (!WorldToCameraPoint(Pw, Pc)) continue;
+            const float disp = float(mbf) / Pc.at<float>(2);
+            minD[iL] = std::max(disp - float(DISPARITY_THRES), 0.0f);
+            maxD[iL] = std::min(disp + float(DISPARITY_THRES), float(mbf) / float(mb));
+        }
+    }
+    gfo_stereo_params p = {nRows, mbf, mb, mnMinX};
+    std::vector<int32_t> bestDist(N), bestIdx(N);
+    int nmatched = 0;
+    cv::Mat keepL, keepR;
+    gfo_ctx* c = gfo_context_of(mpORBextractorLeft);
+    const int rc = gfo_stereo_match(c, as_gfo(mvKeysUn), rows32(mDescriptors, keepL), N, as_gfo(mvKeysRightUn),
+                                    rows32(mDescriptorsRight, keepR), (int)mvKeysRightUn.size(), mvScaleFactors.data(),
+                                    (int)mvScaleFactors.size(), &p, windows ? minD.data() : NULL, windows ? maxD.data() : NULL,
+                                    mvuRight.data(), mvDepth.data(), bestDist.data(), bestIdx.data(), &nmatched);
+    if (rc != GFO_OK) {
+        report(c, "ComputeStereoMatches_Undistorted");
+        return 0;
+    }
+    for (int iL = 0; iL < N; iL++)             // rebuild mvDistIdx as :1281 fills it, sorted as :1296
+        if (bestDist[iL] >= 0) mvDistIdx.push_back(std::pair<int, int>(bestDist[iL], iL));
+    std::sort(mvDistIdx.begin(), mvDistIdx.end());
+    return nmatched;
+}
+#endif
+
+// ---------------------------------------------------------------------------------------------------------------
+#ifdef GFO_ADAPTER_PROJECTION
+int ORBmatcher::SearchByProjection(Frame& F, const std::vector<MapPoint*>& vpMapPoints, const float th)
+{
+    const int M = (int)vpMapPoints.size(), N = F.N;
+    std::vector<gfo_map_point> mps(M);
+    cv::Mat mpDesc(M > 0 ? M : 1, 32, CV_8U);
+    for (int i = 0; i < M; i++) {
+        MapPoint* pMP = vpMapPoints[i];
+        gfo_map_point& m = mps[i];
+        m.proj_x = pMP->mTrackProjX; m.proj_y = pMP->mTrackProjY; m.proj_xr = pMP->mTrackProjXR;
+        m.view_cos = pMP->mTrackViewCos; m.level = pMP->mnTrackScaleLevel;
+        m.flags = (pMP->mbTrackInView ? 1 : 0) | (pMP->isBad() ? 2 : 0) | (pMP->Observations() > 0 ? 4 : 0);
+        pMP->GetDescriptor().copyTo(mpDesc.row(i));
+    }
+    std::vector<uint8_t> taken(N);
+    for (int i = 0; i < N; i++) taken[i] = F.mvpMapPoints[i] && F.mvpMapPoints[i]->Observations() > 0;
+    gfo_frame_bounds fb = {Frame::mnMinX, Frame::mnMinY, Frame::mnMaxX, Frame::mnMaxY};
+    std::vector<int32_t> outMp(N), outScore(N);
+    int nmatches = 0;
+    cv::Mat keep;
+    gfo_ctx* c = gfo_context_of(F.mpORBextractorLeft);
+    const int rc = gfo_search_by_projection(c, as_gfo(F.mvKeysUn), rows32(F.mDescriptors, keep), F.mvuRight.data(), N,
+                                            F.mvScaleFactors.data(), (int)F.mvScaleFactors.size(), &fb, mps.data(), mpDesc.data, M,
+                                            th, mfNNratio, taken.data(), outMp.data(), outScore.data(), &nmatches);
+    if (rc != GFO_OK) {
+        report(c, "SearchByProjection(F, MapPoints)");
+        return 0;
+    }
+    for (int i = 0; i < N; i++)
+        if (outMp[i] >= 0) {
+            F.mvpMapPoints[i] = vpMapPoints[outMp[i]];   // ORBmatcher.cc:233
+            F.mvpMatchScore[i] = outScore[i];            // :235
+        }
+    return nmatches;
+}
+#endif
+
+// ---------------------------------------------------------------------------------------------------------------
+#ifdef GFO_ADAPTER_PROJ_LAST
+// TrackWithMotionModel's matcher (Tracking.cc:1516).  The projection of the last frame's map points (:1465-1497)
+// stays on the host -- it is the reference's own cv::Mat arithmetic, a few thousand 3x3 products -- and becomes the
+// query array; window search, Hamming, ordered resolution and the rotation histogram run on the device.
+// Compiled without BUDGETING_FEATURE_MATCHING (the reference's default; the budgeted variant stops after
+// MAX_NUM_FEATURE_MATCHING accepted matches, :1547-1552, which this body does not reproduce).
+int ORBmatcher::SearchByProjection(Frame& CurrentFrame, const Frame& LastFrame, const float th, const bool bMono,
+                                   double& numVisibleMpt)
+{
+    const cv::Mat Rcw = CurrentFrame.mTcw.rowRange(0, 3).colRange(0, 3);
+    const cv::Mat tcw = CurrentFrame.mTcw.rowRange(0, 3).col(3);
+    const cv::Mat twc = -Rcw.t() * tcw;
+    const cv::Mat Rlw = LastFrame.mTcw.rowRange(0, 3).colRange(0, 3);
+    const cv::Mat tlw = LastFrame.mTcw.rowRange(0, 3).col(3);
+    const cv::Mat tlc = Rlw * twc + tlw;
+    const bool bForward = tlc.at<float>(2) > CurrentFrame.mb && !bMono;
+    const bool bBackward = -tlc.at<float>(2) > CurrentFrame.mb && !bMono;
+
+    std::vector<gfo_proj_query> q;
+    std::vector<MapPoint*> qmp;
+    q.reserve(LastFrame.N);
+    qmp.reserve(LastFrame.N);
+    for (int i = 0; i < LastFrame.N; i++) {
+        MapPoint* pMP = LastFrame.mvpMapPoints[i];
+        if (!pMP || LastFrame.mvbOutlier[i]) continue;
+        cv::Mat x3Dw = pMP->GetWorldPos();
+        cv::Mat x3Dc = Rcw * x3Dw + tcw;
+        const float xc = x3Dc.at<float>(0);
+        const float yc = x3Dc.at<float>(1);
+        const float invzc = 1.0 / x3Dc.at<float>(2);
+        if (invzc < 0) continue;
+        float u = CurrentFrame.fx * xc * invzc + CurrentFrame.cx;
+        float v = CurrentFrame.fy * yc * invzc + CurrentFrame.cy;
+        if (u < CurrentFrame.mnMinX || u > CurrentFrame.mnMaxX) continue;
+        if (v < CurrentFrame.mnMinY || v > CurrentFrame.mnMaxY) continue;
+        numVisibleMpt++;
+        const int nLastOctave = LastFrame.mvKeys[i].octave;
+        gfo_proj_query e;
+        e.u = u;
+        e.v = v;
+        e.ur = u - CurrentFrame.mbf * invzc;                                // :1523
+        e.radius = th * CurrentFrame.mvScaleFactors[nLastOctave];            // :1502
+        if (bForward) { e.min_level = nLastOctave; e.max_level = -1; }       // GetFeaturesInArea(u, v, r, octave)
+        else if (bBackward) { e.min_level = 0; e.max_level = nLastOctave; }
+        else { e.min_level = nLastOctave - 1; e.max_level = nLastOctave + 1; }
+        e.angle = LastFrame.mvKeysUn[i].angle;                               // :1557
+        e.flags = 1 | (pMP->Observations() > 0 ? 4 : 0);                     // what later queries see at :1520-1522
+        q.push_back(e);
+        qmp.push_back(pMP);
+    }
+    const int M = (int)q.size(), N = CurrentFrame.N;
+    cv::Mat qDesc(M > 0 ? M : 1, 32, CV_8U);
+    for (int i = 0; i < M; i++) qmp[i]->GetDescriptor().copyTo(qDesc.row(i));
+    std::vector<uint8_t> taken(N);
+    std::vector<float> angle(N);
+    for (int i = 0; i < N; i++) {
+        taken[i] = CurrentFrame.mvpMapPoints[i] && CurrentFrame.mvpMapPoints[i]->Observations() > 0;
+        angle[i] = CurrentFrame.mvKeysUn[i].angle;
+    }
+    gfo_frame_bounds fb = {Frame::mnMinX, Frame::mnMinY, Frame::mnMaxX, Frame::mnMaxY};
+    gfo_proj_mode mode = {0, 0.f, TH_HIGH, mbCheckOrientation ? 1 : 0};      // no ratio test in this overload (:1541)
+    std::vector<int32_t> outQ(N), outScore(N);
+    int nmatches = 0;
+    cv::Mat keep;
+    gfo_ctx* c = gfo_context_of(CurrentFrame.mpORBextractorLeft);
+    const int rc = gfo_search_by_projection_queries(c, as_gfo(CurrentFrame.mvKeysUn), rows32(CurrentFrame.mDescriptors, keep),
+                                                    CurrentFrame.mvuRight.data(), angle.data(), N, &fb, q.data(), qDesc.data, M, &mode,
+                                                    taken.data(), outQ.data(), outScore.data(), &nmatches);
+    if (rc != GFO_OK) {
+        report(c, "SearchByProjection(Cur, Last)");
+        return 0;
+    }
+    // out_q[i]: >= 0 the query left in mvpMapPoints[i]; -2 a slot this call wrote and its rotation check cleared
+    // (:1579-1586 store NULL); -1 untouched
+    for (int i = 0; i < N; i++) {
+        if (outQ[i] >= 0) CurrentFrame.mvpMapPoints[i] = qmp[outQ[i]];
+        else if (outQ[i] == -2) CurrentFrame.mvpMapPoints[i] = static_cast<MapPoint*>(NULL);
+    }
+    return nmatches;
+}
+#endif
+
+// ---------------------------------------------------------------------------------------------------------------
+#ifdef GFO_ADAPTER_PROJ_KF
+// Relocalization's matcher (Tracking.cc, Relocalization()).  Differences from the overload above, all of them in
+// the flattening: a keypoint with ANY map point is skipped (:1664-1665), so every accepted match blocks the slot for
+// later map points (flag bit 2 always set, taken = "slot is set"); no mvuRight gate; the threshold is ORBdist; the
+// level window is [predicted - 1, predicted + 1].
+int ORBmatcher::SearchByProjection(Frame& CurrentFrame, KeyFrame* pKF, const std::set<MapPoint*>& sAlreadyFound, const float th,
+                                   const int ORBdist)
+{
+    const cv::Mat Rcw = CurrentFrame.mTcw.rowRange(0, 3).colRange(0, 3);
+    const cv::Mat tcw = CurrentFrame.mTcw.rowRange(0, 3).col(3);
+    const cv::Mat Ow = -Rcw.t() * tcw;
+    const std::vector<MapPoint*> vpMPs = pKF->GetMapPointMatches();
+    std::vector<gfo_proj_query> q;
+    std::vector<MapPoint*> qmp;
+    for (size_t i = 0, iend = vpMPs.size(); i < iend; i++) {
+        MapPoint* pMP = vpMPs[i];
+        if (!pMP || pMP->isBad() || sAlreadyFound.count(pMP)) continue;
+        cv::Mat x3Dw = pMP->GetWorldPos();
+        cv::Mat x3Dc = Rcw * x3Dw + tcw;
+        const float xc = x3Dc.at<float>(0);
+        const float yc = x3Dc.at<float>(1);
+        const float invzc = 1.0 / x3Dc.at<float>(2);
+        const float u = CurrentFrame.fx * xc * invzc + CurrentFrame.cx;
+        const float v = CurrentFrame.fy * yc * invzc + CurrentFrame.cy;
+        if (u < CurrentFrame.mnMinX || u > CurrentFrame.mnMaxX) continue;
+        if (v < CurrentFrame.mnMinY || v > CurrentFrame.mnMaxY) continue;
+        cv::Mat PO = x3Dw - Ow;
+        float dist3D = cv::norm(PO);
+        const float maxDistance = pMP->GetMaxDistanceInvariance();
+        const float minDistance = pMP->GetMinDistanceInvariance();
+        if (dist3D < minDistance || dist3D > maxDistance) continue;
+        const int nPredictedLevel = pMP->PredictScale(dist3D, &CurrentFrame);
+        gfo_proj_query e;
+        e.u = u;
+        e.v = v;
+        e.ur = 0.f;
+        e.radius = th * CurrentFrame.mvScaleFactors[nPredictedLevel];       // :1650
+        e.min_level = nPredictedLevel - 1;
+        e.max_level = nPredictedLevel + 1;
+        e.angle = pKF->mvKeysUn[i].angle;                                    // :1689
+        e.flags = 1 | 4;
+        q.push_back(e);
+        qmp.push_back(pMP);
+    }
+    const int M = (int)q.size(), N = CurrentFrame.N;
+    cv::Mat qDesc(M > 0 ? M : 1, 32, CV_8U);
+    for (int i = 0; i < M; i++) qmp[i]->GetDescriptor().copyTo(qDesc.row(i));
+    std::vector<uint8_t> taken(N);
+    std::vector<float> angle(N);
+    for (int i = 0; i < N; i++) {
+        taken[i] = CurrentFrame.mvpMapPoints[i] != NULL;
+        angle[i] = CurrentFrame.mvKeysUn[i].angle;
+    }
+    gfo_frame_bounds fb = {Frame::mnMinX, Frame::mnMinY, Frame::mnMaxX, Frame::mnMaxY};
+    gfo_proj_mode mode = {0, 0.f, ORBdist, mbCheckOrientation ? 1 : 0};
+    std::vector<int32_t> outQ(N), outScore(N);
+    int nmatches = 0;
+    cv::Mat keep;
+    gfo_ctx* c = gfo_context_of(CurrentFrame.mpORBextractorLeft);
+    const int rc = gfo_search_by_projection_queries(c, as_gfo(CurrentFrame.mvKeysUn), rows32(CurrentFrame.mDescriptors, keep), NULL,
+                                                    angle.data(), N, &fb, q.data(), qDesc.data, M, &mode, taken.data(), outQ.data(),
+                                                    outScore.data(), &nmatches);
+    if (rc != GFO_OK) {
+        report(c, "SearchByProjection(Cur, KF)");
+        return 0;
+    }
+    for (int i = 0; i < N; i++) {
+        if (outQ[i] >= 0) CurrentFrame.mvpMapPoints[i] = qmp[outQ[i]];
+        else if (outQ[i] == -2) CurrentFrame.mvpMapPoints[i] = NULL;         // written by this call, cleared by its rotation check (:1713)
+    }
+    return nmatches;
+}
+#endif
+
+// ---------------------------------------------------------------------------------------------------------------
+#ifdef GFO_ADAPTER_BOW
+int ORBmatcher::SearchByBoW(KeyFrame* pKF, Frame& F, std::vector<MapPoint*>& vpMapPointMatches)
+{
+    const std::vector<MapPoint*> vpMapPointsKF = pKF->GetMapPointMatches();
+    vpMapPointMatches = std::vector<MapPoint*>(F.N, static_cast<MapPoint*>(NULL));
+    const int nKF = (int)vpMapPointsKF.size(), nF = F.N;
+    FlatFeatVec kfv(pKF->mFeatVec), ffv(F.mFeatVec);
+    std::vector<uint8_t> valid(nKF);
+    std::vector<float> kfAngle(nKF), fAngle(nF);
+    for (int i = 0; i < nKF; i++) {
+        MapPoint* pMP = vpMapPointsKF[i];
+        valid[i] = pMP && !pMP->isBad();                 // :303-309
+        kfAngle[i] = pKF->mvKeysUn[i].angle;             // :348
+    }
+    for (int i = 0; i < nF; i++) fAngle[i] = F.mvKeys[i].angle;   // :352
+    std::vector<int32_t> out(nF > 0 ? nF : 1);
+    int nmatches = 0;
+    cv::Mat keepK, keepF;
+    gfo_ctx* c = gfo_context_of(F.mpORBextractorLeft);
+    const int rc = gfo_search_by_bow(c, rows32(pKF->mDescriptors, keepK), kfAngle.data(), valid.data(), nKF, &kfv.view,
+                                     rows32(F.mDescriptors, keepF), fAngle.data(), nF, &ffv.view, mfNNratio,
+                                     mbCheckOrientation ? 1 : 0, out.data(), &nmatches);
+    if (rc != GFO_OK) {
+        report(c, "SearchByBoW");
+        return 0;
+    }
+    for (int i = 0; i < nF; i++)
+        if (out[i] >= 0) vpMapPointMatches[i] = vpMapPointsKF[out[i]];      // :343
+    return nmatches;
+}
+#endif
+
+// ---------------------------------------------------------------------------------------------------------------
+#ifdef GFO_ADAPTER_COMPUTE_BOW
+namespace
+{
+// TemplatedVocabulary keeps its tree in protected members (Thirdparty/DBoW2/DBoW2/TemplatedVocabulary.h:428-441);
+// a derived type reads them.  The tree is flattened breadth first so that the children of a node are consecutive
+// (gfo_vocabulary), keeping the vocabulary's own child order (ties in the descent keep the FIRST minimum, :1251-1260).
+struct VocabularyView : public ORBVocabulary {
+    struct Flat {
+        std::vector<int32_t> first_child, n_children, word_id, orig_id;
+        std::vector<float> weight;
+        std::vector<uint8_t> desc;
+        int depth;
+    };
+    void flatten(Flat& f) const
+    {
+        const size_t n = m_nodes.size();
+        f.first_child.assign(n, 0); f.n_children.assign(n, 0); f.word_id.assign(n, 0); f.orig_id.assign(n, 0);
+        f.weight.assign(n, 0.f); f.desc.assign(n * 32, 0);
+        f.depth = m_L;
+        std::vector<DBoW2::NodeId> order(1, 0);                      // new index -> original NodeId, root first
+        for (size_t head = 0; head < order.size(); head++) {
+            const Node& nd = m_nodes[order[head]];
+            f.first_child[head] = (int32_t)order.size();
+            f.n_children[head] = (int32_t)nd.children.size();
+            for (size_t k = 0; k < nd.children.size(); k++) order.push_back(nd.children[k]);
+        }
+        for (size_t i = 0; i < order.size() && i < n; i++) {
+            const Node& nd = m_nodes[order[i]];
+            f.orig_id[i] = (int32_t)nd.id;
+            f.word_id[i] = (int32_t)nd.word_id;
+            f.weight[i] = (float)nd.weight;
+            if (i > 0 && nd.descriptor.cols == 32) memcpy(&f.desc[i * 32], nd.descriptor.data, 32);
+        }
+    }
+    using ORBVocabulary::m_weighting;
+    using ORBVocabulary::m_scoring_object;
+};
+
+std::mutex g_voc_mu;
+std::map<std::pair<gfo_ctx*, const ORBVocabulary*>, VocabularyView::Flat> g_voc;   // uploaded trees, per context
+}  // namespace
+
+void Frame::ComputeBoW()
+{
+    if (!mBowVec.empty()) return;
+    mFeatVec.clear();
+    if (mpORBvocabulary->empty() || N == 0) return;
+    gfo_ctx* c = gfo_context_of(mpORBextractorLeft);
+    const VocabularyView::Flat* flat;
+    {
+        std::lock_guard<std::mutex> lk(g_voc_mu);
+        std::pair<gfo_ctx*, const ORBVocabulary*> key(c, mpORBvocabulary);
+        std::map<std::pair<gfo_ctx*, const ORBVocabulary*>, VocabularyView::Flat>::iterator it = g_voc.find(key);
+        if (it == g_voc.end()) {
+            VocabularyView::Flat f;
+            static_cast<const VocabularyView*>(mpORBvocabulary)->flatten(f);
+            gfo_vocabulary v = {f.first_child.data(), f.n_children.data(), f.desc.data(), f.word_id.data(), f.weight.data(),
+                                (int32_t)f.first_child.size(), f.depth};
+            if (gfo_vocabulary_upload(c, &v) != GFO_OK) {
+                report(c, "ComputeBoW (vocabulary upload)");
+                return;
+            }
+            it = g_voc.insert(std::make_pair(key, f)).first;
+        }
+        flat = &it->second;
+    }
+    std::vector<int32_t> word(N), node(N);
+    std::vector<float> weight(N);
+    cv::Mat keep;
+    if (gfo_bow_transform(c, rows32(mDescriptors, keep), N, 4, word.data(), weight.data(), node.data()) != GFO_OK) {   // levelsup = 4, Frame.cc:666
+        report(c, "ComputeBoW");
+        return;
+    }
+    // the fold of TemplatedVocabulary::transform(features, v, fv, levelsup), :1140-1212, in feature order
+    const VocabularyView* voc = static_cast<const VocabularyView*>(mpORBvocabulary);
+    DBoW2::LNorm norm;
+    const bool must = voc->m_scoring_object->mustNormalize(norm);
+    const bool tf = voc->m_weighting == DBoW2::TF || voc->m_weighting == DBoW2::TF_IDF;
+    for (int i = 0; i < N; i++) {
+        if (!(weight[i] > 0)) continue;                                       // stopped word
+        if (tf) mBowVec.addWeight((DBoW2::WordId)word[i], weight[i]);
+        else mBowVec.addIfNotExist((DBoW2::WordId)word[i], weight[i]);
+        mFeatVec.addFeature((DBoW2::NodeId)flat->orig_id[node[i]], (unsigned int)i);
+    }
+    if (tf && !mBowVec.empty() && !must) {
+        const double nd = mBowVec.size();
+        for (DBoW2::BowVector::iterator vit = mBowVec.begin(); vit != mBowVec.end(); vit++) vit->second /= nd;
+    }
+    if (must) mBowVec.normalize(norm);
+}
+#endif
+
+}  // namespace ORB_SLAM2

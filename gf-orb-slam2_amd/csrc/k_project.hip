@@ -502,8 +502,9 @@ __global__ __launch_bounds__(1024) void k_proj_resolve(ProjB a)
             if (k < 0) continue;
             const int b = rot_bin[t];
             if (b != keep[0] && b != keep[1] && b != keep[2]) {
-                if (TABG) __hip_atomic_store(&tab[k], -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                else tab[k] = -1;   // benign race: every writer stores -1
+                // -2: matched by this call, then cleared by its rotation check (the reference stores NULL there, :1586)
+                if (TABG) __hip_atomic_store(&tab[k], -2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                else tab[k] = -2;   // benign race: every writer stores the same value
                 drop++;
             }
         }

@@ -186,7 +186,9 @@ int gfo_search_by_projection(gfo_ctx* ctx, const gfo_keypoint* kp_un, const uint
  * Mode: use_ratio/nn_ratio = best-vs-second test of :228-231 (same-level rule included); th_dist = TH_HIGH
  * (or ORBdist); check_orientation = the 30-bin rotation histogram of :1548-1591 between query.angle and
  * kp_angle[] (ComputeThreeMaxima :1723-1764): a keypoint is cleared if ANY accepted query that took it falls
- * in a discarded bin, and *nmatches drops once per such query, as the reference's loop does. */
+ * in a discarded bin, and *nmatches drops once per such query, as the reference's loop does.
+ * out_q[i]: the query whose map point the call leaves in mvpMapPoints[i]; -1: the call did not touch the slot;
+ * -2: the call matched the slot and its rotation check then cleared it (the reference stores NULL there, :1586). */
 typedef struct {
     float u, v, ur;                /* projection; ur is compared with u_right[] when that is > 0        */
     float radius;                  /* window half-size = r passed to GetFeaturesInArea, and the ur gate */

@@ -1198,12 +1198,84 @@ int orc_search_by_projection_queries(const orc_keypoint* kp, const uint8_t* desc
         for (int e = 0; e < nh; e++) {
             const int b = hist_bin[e];
             if (b != ind1 && b != ind2 && b != ind3) {
-                out_q[hist_kp[e]] = -1;
+                out_q[hist_kp[e]] = -2; /* mvpMapPoints[..] = NULL: written by this call, then cleared (:1586) */
                 nmatches--;
             }
         }
     }
     free(idx); free(blocked); free(hist_kp); free(hist_bin);
+    grid_free(&g);
+    return nmatches;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * ORBmatcher::SearchByProjection(Frame& CurrentFrame, KeyFrame* pKF, const set<MapPoint*>& sAlreadyFound,
+ * th, ORBdist) -- ORBmatcher.cc:1595-1721 -- literally, on pre-projected map points (the projection, the distance
+ * test and PredictScale of :1617-1650 are the caller's): q[i].flags bit0 = "reaches the window search".
+ * Unlike the two overloads above, a keypoint with ANY map point is skipped (:1664-1665) and there is no mvuRight
+ * gate.  kp_set[i] = 1 where CurrentFrame.mvpMapPoints[i] != NULL on entry.  out_q as above (-2 = cleared).
+ * ---------------------------------------------------------------------------------------- */
+int orc_search_by_projection_kf(const orc_keypoint* kp, const uint8_t* desc, const float* kp_angle, int n,
+                                const orc_frame_bounds* fb, const orc_proj_query* q, const uint8_t* q_desc, int m,
+                                int orb_dist, int check_orientation, const uint8_t* kp_set, int* out_q, int* out_score)
+{
+    enum { HISTO_LENGTH = 30 };
+    grid_t g;
+    grid_build(&g, kp, n, fb);
+    int* idx = (int*)malloc(sizeof(int) * (n > 0 ? n : 1));
+    uint8_t* set = (uint8_t*)malloc(n > 0 ? n : 1);
+    int* hist_kp = (int*)malloc(sizeof(int) * (m > 0 ? m : 1));
+    int* hist_bin = (int*)malloc(sizeof(int) * (m > 0 ? m : 1));
+    int nh = 0, histo[HISTO_LENGTH];
+    memset(histo, 0, sizeof histo);
+    for (int i = 0; i < n; i++) {
+        set[i] = kp_set ? kp_set[i] : 0;
+        out_q[i] = -1;
+        out_score[i] = 0;
+    }
+    const float factor = 1.0f / HISTO_LENGTH;
+    int nmatches = 0;
+    for (int iq = 0; iq < m; iq++) {
+        const orc_proj_query* p = &q[iq];
+        if (!(p->flags & 1)) continue;
+        const int nidx = grid_query(&g, kp, fb, p->u, p->v, p->radius, p->min_level, p->max_level, idx, n);
+        if (nidx == 0) continue;
+        int bestDist = 256, bestIdx2 = -1;
+        for (int k = 0; k < nidx; k++) {
+            const int i2 = idx[k];
+            if (set[i2]) continue; /* :1664 */
+            const int dist = orc_hamming256(q_desc + (size_t)iq * 32, desc + (size_t)i2 * 32);
+            if (dist < bestDist) { bestDist = dist; bestIdx2 = i2; }
+        }
+        if (bestDist <= orb_dist) { /* :1679 */
+            set[bestIdx2] = 1;
+            out_q[bestIdx2] = iq;
+            out_score[bestIdx2] = bestDist;
+            nmatches++;
+            if (check_orientation) {
+                float rot = p->angle - kp_angle[bestIdx2];
+                if (rot < 0.0) rot += 360.0f;
+                int bin = (int)roundf(rot * factor);
+                if (bin == HISTO_LENGTH) bin = 0;
+                hist_kp[nh] = bestIdx2;
+                hist_bin[nh] = bin;
+                nh++;
+                histo[bin]++;
+            }
+        }
+    }
+    if (check_orientation) {
+        int ind1 = -1, ind2 = -1, ind3 = -1;
+        orc_three_maxima(histo, HISTO_LENGTH, &ind1, &ind2, &ind3);
+        for (int e = 0; e < nh; e++) {
+            const int b = hist_bin[e];
+            if (b != ind1 && b != ind2 && b != ind3) {
+                out_q[hist_kp[e]] = -2;
+                nmatches--;
+            }
+        }
+    }
+    free(idx); free(set); free(hist_kp); free(hist_bin);
     grid_free(&g);
     return nmatches;
 }

@@ -156,6 +156,13 @@ int orc_search_by_projection_queries(const orc_keypoint* kp_un, const uint8_t* d
                                      const orc_proj_query* q, const uint8_t* q_desc, int m, const orc_proj_mode* mode,
                                      const uint8_t* kp_taken, int* out_q, int* out_score);
 
+/* ORBmatcher::SearchByProjection(Frame& Cur, KeyFrame*, const set<MapPoint*>& sAlreadyFound, th, ORBdist) --
+ * ORBmatcher.cc:1595-1721 on pre-projected map points: any set keypoint is skipped, no mvuRight gate, no ratio.
+ * kp_set[i] = 1 where Cur.mvpMapPoints[i] != NULL on entry. */
+int orc_search_by_projection_kf(const orc_keypoint* kp_un, const uint8_t* desc, const float* kp_angle, int n,
+                                const orc_frame_bounds* fb, const orc_proj_query* q, const uint8_t* q_desc, int m,
+                                int orb_dist, int check_orientation, const uint8_t* kp_set, int* out_q, int* out_score);
+
 /* ORBmatcher::SearchByBoW(KeyFrame*, Frame&, vector<MapPoint*>&) -- ORBmatcher.cc:270-404, with the
  * two DBoW2::FeatureVector maps flattened to CSR (node ids ascending, as std::map iterates them).
  * kf_mp_valid[i] = 1 where vpMapPointsKF[i] is set and not bad.  out_kf_idx[n_f]: index of the KF

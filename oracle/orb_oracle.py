@@ -361,6 +361,27 @@ def search_by_projection_queries(kp_un, desc, u_right, kp_angle, bounds, queries
     return nm, out_q[:n], out_s[:n]
 
 
+def search_by_projection_kf(kp_un, desc, kp_angle, bounds, queries, q_desc, orb_dist, check_orientation, kp_set=None):
+    """ORBmatcher::SearchByProjection(CurrentFrame, KeyFrame*, sAlreadyFound, th, ORBdist), ORBmatcher.cc:1595-1721,
+    on pre-projected map points (literal statement: any set keypoint is skipped)."""
+    kp_un = np.ascontiguousarray(kp_un, dtype=KEYPOINT_DTYPE)
+    desc = np.ascontiguousarray(desc, dtype=np.uint8)
+    queries = np.ascontiguousarray(queries, dtype=PROJ_QUERY_DTYPE)
+    q_desc = np.ascontiguousarray(q_desc, dtype=np.uint8)
+    n, m = len(kp_un), len(queries)
+    kp_angle = np.ascontiguousarray(kp_angle, np.float32)
+    kp_set = None if kp_set is None else np.ascontiguousarray(kp_set, np.uint8)
+    fb = FrameBounds(*bounds)
+    out_q = np.zeros(max(n, 1), np.int32)
+    out_s = np.zeros(max(n, 1), np.int32)
+    L = lib()
+    vp = C.c_void_p
+    L.orc_search_by_projection_kf.argtypes = [vp, vp, vp, C.c_int, C.POINTER(FrameBounds), vp, vp, C.c_int, C.c_int, C.c_int, vp, vp, vp]
+    nm = L.orc_search_by_projection_kf(_p(kp_un), _p(desc), _p(kp_angle), n, C.byref(fb), _p(queries), _p(q_desc), m, int(orb_dist),
+                                       1 if check_orientation else 0, _p(kp_set), _p(out_q), _p(out_s))
+    return nm, out_q[:n], out_s[:n]
+
+
 class FeatureVectorC(C.Structure):
     _fields_ = [("node_ids", C.c_void_p), ("node_start", C.c_void_p), ("items", C.c_void_p), ("n_nodes", C.c_int32)]
 

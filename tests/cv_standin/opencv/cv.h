@@ -1,11 +1,21 @@
-// Minimal OpenCV type stand-in used ONLY to syntax-check gf-orb-slam2_amd/adapter/ORBextractor_gfo.cc
-// against the reference's unchanged include/ORBextractor.h (tests/test_adapter_compiles.py).
+// Minimal OpenCV type stand-in used ONLY to syntax-check gf-orb-slam2_amd/adapter/*.cc against the reference's
+// unchanged headers (include/ORBextractor.h, Frame.h, ORBmatcher.h, ...; tests/test_adapter_compiles.py): the
+// declarations those headers and the adapters name, with empty bodies.
 // It is NOT OpenCV, nothing is linked or run with it, no reference source file is compiled with it,
 // and the oracle does not use it.
 #pragma once
 #include <cstddef>
 #include <cstring>
 #include <vector>
+#include <algorithm>
+#include <climits>
+#include <cmath>
+#include <iostream>
+#include <list>
+#include <map>
+#include <set>
+#include <sstream>
+#include <string>
 
 #define CV_8U 0
 #define CV_8UC1 0
@@ -32,9 +42,37 @@ public:
     bool empty() const { return data == nullptr || rows == 0 || cols == 0; }
     int type() const { return CV_8UC1; }
     Mat operator()(const Rect& r) const { Mat m; m.data = data + (size_t)r.y * step + r.x; m.rows = r.height; m.cols = r.width; m.step = step; m.store = store; return m; }
+    // what the reference's headers and the matcher adapters name (declarations only matter: nothing runs)
+    template <class T> T& at(int) { return *reinterpret_cast<T*>(data); }
+    template <class T> const T& at(int) const { return *reinterpret_cast<const T*>(data); }
+    template <class T> T& at(int, int) { return *reinterpret_cast<T*>(data); }
+    template <class T> const T& at(int, int) const { return *reinterpret_cast<const T*>(data); }
+    template <class T> T* ptr(int = 0) { return reinterpret_cast<T*>(data); }
+    template <class T> const T* ptr(int = 0) const { return reinterpret_cast<const T*>(data); }
+    Mat clone() const { return *this; }
+    Mat row(int) const { return *this; }
+    Mat col(int) const { return *this; }
+    Mat rowRange(int, int) const { return *this; }
+    Mat colRange(int, int) const { return *this; }
+    Mat t() const { return *this; }
+    Mat inv() const { return *this; }
+    void copyTo(Mat) const {}
+    bool isContinuous() const { return true; }
+    void release() {}
+    static Mat zeros(int r, int c, int t) { return Mat(r, c, t); }
+    static Mat eye(int r, int c, int t) { return Mat(r, c, t); }
 private:
     std::vector<unsigned char> store;
 };
+
+inline Mat operator*(const Mat& a, const Mat&) { return a; }
+inline Mat operator*(const Mat& a, double) { return a; }
+inline Mat operator*(double, const Mat& a) { return a; }
+inline Mat operator+(const Mat& a, const Mat&) { return a; }
+inline Mat operator-(const Mat& a, const Mat&) { return a; }
+inline Mat operator-(const Mat& a) { return a; }
+inline double norm(const Mat&) { return 0; }
+#define CV_32F 5
 
 class _InputArray
 {
@@ -58,6 +96,28 @@ private:
     Mat* m_;
 };
 typedef const _OutputArray& OutputArray;
+struct FileNode {
+    FileNode operator[](const char*) const { return FileNode(); }
+    FileNode operator[](int) const { return FileNode(); }
+    operator int() const { return 0; }
+    operator float() const { return 0; }
+    operator double() const { return 0; }
+    operator std::string() const { return ""; }
+    size_t size() const { return 0; }
+    int type() const { return 0; }
+    bool empty() const { return true; }
+    enum { SEQ = 5 };
+};
+struct FileStorage {
+    enum { READ = 0, WRITE = 1 };
+    FileStorage() {}
+    FileStorage(const std::string&, int) {}
+    bool isOpened() const { return false; }
+    void release() {}
+    FileNode operator[](const char*) const { return FileNode(); }
+    FileNode operator[](const std::string&) const { return FileNode(); }
+    template <class T> FileStorage& operator<<(const T&) { return *this; }
+};
 }  // namespace cv
 
 static inline int cvRound(float v) { return (int)(v + (v >= 0 ? 0.5f : -0.5f)); }

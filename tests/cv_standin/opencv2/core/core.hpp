@@ -1,0 +1,3 @@
+// stand-in: see ../opencv/cv.h
+#pragma once
+#include "../../opencv/cv.h"

@@ -141,6 +141,29 @@ def test_frame_to_frame_projection(ext, oracle, seed, th, fwd, bwd, ori):
     np.testing.assert_array_equal(got[2][got[1] >= 0], ref[2][ref[1] >= 0])
 
 
+@pytest.mark.parametrize("seed,th,orb_dist,ori", [(1, 10.0, 100, True), (2, 3.0, 64, True), (3, 10.0, 100, False)])
+def test_keyframe_projection_overload(ext, oracle, seed, th, orb_dist, ori):
+    """SearchByProjection(CurrentFrame, KeyFrame*, sAlreadyFound, th, ORBdist) (ORBmatcher.cc:1595-1721): the
+    adapter's flattening -- every query blocks the slot it takes, a slot with ANY map point is taken on entry, no
+    mvuRight gate, level window [l-1, l+1], threshold ORBdist -- through the query form, against the oracle's literal
+    statement of that overload."""
+    import gf_orb_slam2_amd as G
+    kl, dl, u = _frame(oracle)
+    q, qd = _frame_queries(oracle, kl, dl, 100 + seed, th)
+    active = (q["flags"] & 1) != 0
+    q["flags"] = np.where(active, 1 | 4, 0)          # adapter: flags = 1 | 4 for every map point that reaches the search
+    q["ur"] = 0
+    kp_set = (np.random.default_rng(seed).random(len(kl)) < 0.3).astype(np.uint8)   # mvpMapPoints[i] != NULL on entry
+    b = (0.0, 0.0, 752.0, 480.0)
+    ref = oracle.search_by_projection_kf(kl, dl, kl["angle"], b, q, qd, orb_dist, ori, kp_set)
+    got = G.ORBmatcher(0.9, ori, extractor=ext).SearchByProjectionQueries(kl, dl, None, kl["angle"], b, q, qd, use_ratio=False,
+                                                                           th_dist=orb_dist, kp_taken=kp_set)
+    assert got[0] == ref[0] and ref[0] > 200
+    np.testing.assert_array_equal(got[1], ref[1])
+    assert (got[1] == -2).any() == bool(ori)          # the rotation check really cleared something when it ran
+    np.testing.assert_array_equal(got[2][got[1] >= 0], ref[2][ref[1] >= 0])
+
+
 def test_query_form_reproduces_map_point_overload(oracle):
     """the two oracle statements (literal map-point overload vs query form) agree: pins the flattening"""
     kl, dl, u = _frame(oracle)
