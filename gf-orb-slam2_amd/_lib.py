@@ -61,7 +61,7 @@ class StageTime(C.Structure):
 SYMBOLS = [
     "gfo_version", "gfo_ctx_create", "gfo_ctx_destroy", "gfo_last_error", "gfo_ctx_set_stream",
     "gfo_ctx_synchronize", "gfo_ctx_tables", "gfo_ctx_max_keypoints", "gfo_extract", "gfo_extract_batch",
-    "gfo_extract_batch_device", "gfo_batch_counts", "gfo_batch_fetch", "gfo_batch_device_views",
+    "gfo_extract_stereo", "gfo_extract_batch_device", "gfo_batch_counts", "gfo_batch_fetch", "gfo_batch_device_views",
     "gfo_compute_pyramid", "gfo_pyramid_level", "gfo_hamming256", "gfo_stereo_match",
     "gfo_stereo_match_batch", "gfo_stereo_match_sad_batch", "gfo_stereo_fetch", "gfo_search_by_projection", "gfo_search_by_projection_queries",
     "gfo_map_upload", "gfo_search_by_projection_batch", "gfo_projection_fetch", "gfo_projection_device_views", "gfo_search_by_bow", "gfo_vocabulary_upload", "gfo_bow_transform", "gfo_profile_enable",
@@ -154,6 +154,7 @@ def load_library():
     L.gfo_ctx_max_keypoints.argtypes = [vp]
     L.gfo_extract.argtypes = [vp, vp, i, i, i, vp, vp, i, ip]
     L.gfo_extract_batch.argtypes = [vp, vp, i, i, i, i, vp, vp, i, vp]
+    L.gfo_extract_stereo.argtypes = [vp, vp, vp, i, i, i, C.POINTER(StereoParamsC), vp, vp, vp, vp, i, ip, ip, vp, vp, vp, vp, ip]
     L.gfo_extract_batch_device.argtypes = [vp, vp, i, i, i, sz, sz]
     L.gfo_batch_counts.argtypes = [vp, vp, vp]
     L.gfo_batch_fetch.argtypes = [vp, i, vp, vp, i, ip]

@@ -143,6 +143,11 @@ static void free_arena(gfo_ctx* c)
     c->d_ycoef = nullptr; c->st = GfoStereoDev{}; c->d_scale = nullptr; c->d_inv_scale = nullptr; c->st_sort = GfoStereoSort{}; c->st_rows_cap = 0;
     c->planned = false;
     c->have_batch = c->have_pyramid = c->have_stereo = false;
+    c->plan_gen++;                         // every captured launch sequence points into the old arena
+    if (c->graph_exec) {
+        (void)hipGraphExecDestroy(c->graph_exec);
+        c->graph_exec = nullptr;
+    }
 }
 
 // cv::resize(INTER_LINEAR) coefficient tables, built exactly as OpenCV builds them (double
@@ -403,7 +408,7 @@ static int plan(gfo_ctx* c, int w, int h, int batch)
     HIP_TRY(c, hipMalloc(&c->d_sel_cnt, B * g.nlevels * sizeof(int)));
     HIP_TRY(c, hipMalloc(&c->d_kp, B * (size_t)g.kp_stride * sizeof(gfo_keypoint)));
     HIP_TRY(c, hipMalloc(&c->d_desc, B * (size_t)g.kp_stride * 32));
-    HIP_TRY(c, hipMalloc(&c->d_kp_cnt, B * sizeof(int)));
+    HIP_TRY(c, hipMalloc(&c->d_kp_cnt, B * sizeof(int) + 16));   // +16: k_pack_results copies in 16-byte units
     HIP_TRY(c, hipMalloc(&c->d_flags, 4 * sizeof(int)));
     HIP_TRY(c, hipMalloc(&c->d_xofs, xtabv.size() * sizeof(int) + 64));
     HIP_TRY(c, hipMalloc(&c->d_yofs, ytabv.size() * sizeof(int) + 64));
@@ -438,7 +443,7 @@ static int plan(gfo_ctx* c, int w, int h, int batch)
     HIP_TRY(c, hipMalloc(&c->st.depth, P * g.kp_stride * sizeof(float)));
     HIP_TRY(c, hipMalloc(&c->st.best_dist, P * g.kp_stride * sizeof(int)));
     HIP_TRY(c, hipMalloc(&c->st.best_idx, P * g.kp_stride * sizeof(int)));
-    HIP_TRY(c, hipMalloc(&c->st.nmatched, P * sizeof(int)));
+    HIP_TRY(c, hipMalloc(&c->st.nmatched, P * sizeof(int) + 16));
     HIP_TRY(c, hipMalloc(&c->st.counted, P * g.kp_stride));
     HIP_TRY(c, hipMalloc(&c->st_sort.sx, P * g.kp_stride * sizeof(float)));
     HIP_TRY(c, hipMalloc(&c->st_sort.sy, P * g.kp_stride * sizeof(float)));
@@ -499,6 +504,7 @@ extern "C" int gfo_ctx_create(const gfo_params* p, int device, gfo_ctx** out)
     if (getenv("GFO_FORK_BLUR")) c->fork_blur = c->fork_blur && atoi(getenv("GFO_FORK_BLUR")) != 0;
     const char* dbg = getenv("GFO_DEBUG_SYNC");
     c->debug_sync = dbg && dbg[0] == '1';
+    if (getenv("GFO_GRAPH")) c->graph_ok = atoi(getenv("GFO_GRAPH")) != 0;
     build_tables(c);
     *out = c;
     return GFO_OK;
@@ -514,6 +520,8 @@ extern "C" void gfo_ctx_destroy(gfo_ctx* c)
     free_arena(c);
     if (c->d_scratch) (void)hipFree(c->d_scratch);
     if (c->d_voc) (void)hipFree(c->d_voc);
+    if (c->h_in) (void)hipHostFree(c->h_in);
+    if (c->h_out) (void)hipHostFree(c->h_out);
     if (c->pj.base) (void)hipFree(c->pj.base);
     if (c->d_map_desc) (void)hipFree(c->d_map_desc);
     if (c->side_stream) {
@@ -595,7 +603,42 @@ static int run_pyramid(gfo_ctx* c, const GfoInput& in, int nimg)
     return GFO_OK;
 }
 
-static int run_extract(gfo_ctx* c, const GfoInput& in, int nimg)
+// Results of a small batch, gathered by ONE kernel straight into the context's pinned host buffer (mapped into the
+// device's address space): nine separate D2H copies cost ~75 us of copy-engine latency on the per-frame path
+// (profiles/latency_timeline_r02.txt), this costs ~10 us of PCIe writes at the end of the captured launch sequence.
+#define GFO_PACK_MAX 10
+struct GfoPack {
+    const uint4* src[GFO_PACK_MAX];
+    uint4* dst[GFO_PACK_MAX];
+    int n16[GFO_PACK_MAX];     // 16-byte units
+    int nseg;
+};
+
+__global__ __launch_bounds__(256) void k_pack_results(GfoPack p)
+{
+    const int t = blockIdx.x * 256 + threadIdx.x, stride = gridDim.x * 256;
+    for (int s = 0; s < p.nseg; s++)
+        for (int i = t; i < p.n16[s]; i += stride) p.dst[s][i] = p.src[s][i];
+}
+
+static GfoStereoLaunch stereo_batch_launch(gfo_ctx* c, const gfo_stereo_params& p)
+{
+    GfoStereoLaunch sl{};
+    sl.kl = c->d_kp; sl.dl = c->d_desc;
+    sl.kr = c->d_kp + c->g.kp_stride; sl.dr = c->d_desc + (size_t)c->g.kp_stride * 32;
+    sl.cnt_dev = c->d_kp_cnt; sl.nl_host = 0; sl.nr_host = 0;
+    sl.pair_stride_kp = 2LL * c->g.kp_stride; sl.npairs = c->last_nimg / 2;
+    sl.d_scale = c->d_scale;
+    sl.p = p;
+    sl.min_d = nullptr; sl.max_d = nullptr;
+    sl.out = c->st; sl.out_stride = c->g.kp_stride;
+    sl.sort = c->st_sort; sl.sort_stride = c->g.kp_stride;
+    sl.window = gfo_stereo_window(c->scale.data(), c->g.nlevels);
+    return sl;
+}
+
+// the launches of one extraction (+ the stereo association of its pairs when sp is given), in stream order
+static int extract_launches(gfo_ctx* c, const GfoInput& in, int nimg, const gfo_stereo_params* sp, const GfoPack* pack)
 {
     HIP_TRY(c, hipMemsetAsync(c->d_cand_cnt, 0, sizeof(int) * nimg * c->g.nlevels * GFO_CNT_STRIDE, c->stream));
     run_pyramid(c, in, nimg);
@@ -622,14 +665,84 @@ static int run_extract(gfo_ctx* c, const GfoInput& in, int nimg)
     }
     // nothing that consumes the selection may run if a stage before it was refused
     if (c->launch_err.empty()) gfo_launch_orient_desc(c, in, nimg);
+    if (c->launch_err.empty() && sp) {
+        c->last_nimg = nimg;
+        gfo_launch_stereo(c, stereo_batch_launch(c, *sp));
+    }
+    if (c->launch_err.empty() && pack) {
+        int total = 0;
+        for (int s_ = 0; s_ < pack->nseg; s_++) total += pack->n16[s_];
+        hipLaunchKernelGGL(k_pack_results, dim3((total + 1023) / 1024 > 0 ? (total + 1023) / 1024 : 1), dim3(256), 0, c->stream, *pack);
+    }
+    return GFO_OK;
+}
+
+// Small batches of host images (the per-frame path of the drop-in adapter) replay the fixed launch sequence as a
+// captured hipGraph: one submission instead of 8-11, no host-side launch gaps between 10-50 us kernels.
+static bool graph_key_eq(const gfo_ctx::GraphKey& a, const gfo_ctx::GraphKey& b)
+{
+    return a.base == b.base && a.pack_dst == b.pack_dst && a.pitch == b.pitch && a.img_stride == b.img_stride && a.nimg == b.nimg && a.stereo == b.stereo &&
+           memcmp(&a.sp, &b.sp, sizeof a.sp) == 0 && a.plan_gen == b.plan_gen;
+}
+
+static int run_extract(gfo_ctx* c, const GfoInput& in, int nimg, const gfo_stereo_params* sp = nullptr, const GfoPack* pack = nullptr)
+{
+    static const int graph_max_img = getenv("GFO_GRAPH_MAX_IMAGES") ? atoi(getenv("GFO_GRAPH_MAX_IMAGES")) : 8;
+    bool done = false;
+    if (c->graph_ok && !c->profiling && !c->debug_sync && nimg <= graph_max_img && in.base == c->d_input && c->stream == c->own_stream) {
+        gfo_ctx::GraphKey key{};
+        key.base = in.base; key.pitch = in.pitch; key.img_stride = in.img_stride; key.nimg = nimg; key.stereo = sp ? 1 : 0;
+        if (sp) key.sp = *sp;
+        key.plan_gen = c->plan_gen;
+        key.pack_dst = pack ? (const void*)pack->dst[0] : nullptr;
+        if (c->graph_exec && !graph_key_eq(key, c->graph_key)) {
+            (void)hipGraphExecDestroy(c->graph_exec);
+            c->graph_exec = nullptr;
+        }
+        if (!c->graph_exec) {
+            hipGraph_t graph = nullptr;
+            if (hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal) == hipSuccess) {
+                const int lrc = extract_launches(c, in, nimg, sp, pack);
+                const hipError_t e = hipStreamEndCapture(c->stream, &graph);
+                if (lrc == GFO_OK && e == hipSuccess && graph && c->launch_err.empty() &&
+                    hipGraphInstantiate(&c->graph_exec, graph, nullptr, nullptr, 0) == hipSuccess) {
+                    c->graph_key = key;
+                    if (getenv("GFO_DEBUG_PLAN")) fprintf(stderr, "[gfo] captured the launch sequence of %d image(s)%s as a hipGraph\n", nimg, sp ? " + stereo association" : "");
+                } else {
+                    if (getenv("GFO_DEBUG_PLAN")) fprintf(stderr, "[gfo] launch-sequence capture failed (launches %d, end capture %s, launch error '%s'): plain launches from now on\n", lrc, hipGetErrorString(e), c->launch_err.c_str());
+                    c->graph_exec = nullptr;
+                    c->graph_ok = false;          // this runtime / configuration does not capture: plain launches from now on
+                    c->launch_err.clear();
+                    (void)hipGetLastError();
+                }
+                if (graph) (void)hipGraphDestroy(graph);
+            } else {
+                (void)hipGetLastError();
+                c->graph_ok = false;
+            }
+        }
+        if (c->graph_exec) {
+            if (hipGraphLaunch(c->graph_exec, c->stream) == hipSuccess) done = true;
+            else {
+                (void)hipGetLastError();
+                c->graph_ok = false;
+            }
+        }
+    }
+    if (!done) {
+        const int lrc = extract_launches(c, in, nimg, sp, pack);
+        if (lrc) return lrc;
+    }
     if (!c->launch_err.empty()) {
         c->have_batch = false;
         return gfo_take_launch_err(c);
     }
-    if (int lrc = gfo_take_launch_err(c)) return lrc;
     HIP_TRY(c, hipGetLastError());
+    c->last_in = in;
+    c->last_nimg = nimg;
+    c->have_pyramid = true;
     c->have_batch = true;
-    c->have_stereo = false;
+    c->have_stereo = sp != nullptr;
     c->have_projection = false;
     return GFO_OK;
 }
@@ -721,6 +834,94 @@ extern "C" int gfo_batch_device_views(gfo_ctx* c, const gfo_keypoint** d_kp, con
     return GFO_OK;
 }
 
+// grow-only pinned host buffers of the latency path
+static int pinned(gfo_ctx* c, uint8_t** buf, size_t* cap, size_t bytes)
+{
+    if (bytes <= *cap) return GFO_OK;
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (*buf) (void)hipHostFree(*buf);
+    *buf = nullptr;
+    *cap = 0;
+    HIP_TRY(c, hipHostMalloc((void**)buf, bytes, hipHostMallocDefault));
+    *cap = bytes;
+    return GFO_OK;
+}
+
+#define GFO_SMALL_BATCH 8   // up to this many host images go through pinned staging: one H2D, one D2H, one sync
+
+// Small host batch: images -> pinned -> one H2D; kernels (a graph replay); every result -> pinned in one burst of
+// D2H copies; ONE stream synchronisation; then plain memcpy into the caller's arrays.
+static int extract_small(gfo_ctx* c, const uint8_t* const* imgs, int nimg, int w, int h, int stride, const gfo_stereo_params* sp,
+                         gfo_keypoint* const* kp, uint8_t* const* desc, int cap, int* n, float* u_right, float* depth,
+                         int32_t* best_dist, int32_t* best_idx_r, int* nmatched)
+{
+    const int pitch = c->g.lv[0].pitch, ks = c->g.kp_stride;
+    const size_t img_bytes = (size_t)pitch * h;
+    int rc = pinned(c, &c->h_in, &c->h_in_bytes, img_bytes * nimg);
+    if (rc) return rc;
+    for (int i = 0; i < nimg; i++) {
+        uint8_t* d = c->h_in + i * img_bytes;
+        if (stride == pitch) memcpy(d, imgs[i], img_bytes);
+        else
+            for (int y = 0; y < h; y++) memcpy(d + (size_t)y * pitch, imgs[i] + (size_t)y * stride, w);
+    }
+    // result layout in the pinned buffer (fixed for a planned geometry, so the captured pack kernel stays valid)
+    size_t off = 0;
+    auto take = [&](size_t bytes) { size_t o = off; off = (size_t)align_up((long long)(off + bytes), 64); return o; };
+    const size_t o_fl = take(16), o_cnt = take(16 * (size_t)((nimg + 3) / 4)), o_kp = take(sizeof(gfo_keypoint) * (size_t)ks * nimg),
+                 o_ds = take(32 * (size_t)ks * nimg);
+    const size_t o_ur = take(4 * (size_t)ks), o_dp = take(4 * (size_t)ks), o_bd = take(4 * (size_t)ks), o_bi = take(4 * (size_t)ks),
+                 o_nm = take(16);
+    rc = pinned(c, &c->h_out, &c->h_out_bytes, off);
+    if (rc) return rc;
+    uint8_t* H = c->h_out;
+    hipStream_t st = c->stream;
+    GfoPack pk{};
+    auto seg = [&](const void* src, size_t dst_off, size_t bytes) {
+        pk.src[pk.nseg] = (const uint4*)src; pk.dst[pk.nseg] = (uint4*)(H + dst_off); pk.n16[pk.nseg] = (int)((bytes + 15) / 16); pk.nseg++;
+    };
+    seg(c->d_flags, o_fl, 16);
+    seg(c->d_kp_cnt, o_cnt, 4 * (size_t)nimg);          // the count vector is allocated in 16-byte multiples (plan)
+    seg(c->d_kp, o_kp, sizeof(gfo_keypoint) * (size_t)ks * nimg);
+    seg(c->d_desc, o_ds, 32 * (size_t)ks * nimg);
+    if (sp) {
+        seg(c->st.u_right, o_ur, 4 * (size_t)ks);
+        seg(c->st.depth, o_dp, 4 * (size_t)ks);
+        seg(c->st.best_dist, o_bd, 4 * (size_t)ks);
+        seg(c->st.best_idx, o_bi, 4 * (size_t)ks);
+        seg(c->st.nmatched, o_nm, 4);
+    }
+    HIP_TRY(c, hipMemcpyAsync(c->d_input, c->h_in, img_bytes * nimg, hipMemcpyHostToDevice, st));
+    GfoInput in{c->d_input, pitch, (long long)img_bytes};
+    rc = run_extract(c, in, nimg, sp, &pk);
+    if (rc) return rc;
+    HIP_TRY(c, hipStreamSynchronize(st));
+    const int* fl = reinterpret_cast<const int*>(H + o_fl);
+    if (fl[0]) {
+        (void)hipMemsetAsync(c->d_flags, 0, 16, st);
+        return fail(c, GFO_ERR_OVERFLOW, "internal buffer overflow (flags 0x%x: 1 candidates, 2 quadtree nodes, 4 selection, 8 keypoints)", fl[0]);
+    }
+    int over = 0;
+    for (int i = 0; i < nimg; i++) {
+        n[i] = reinterpret_cast<const int*>(H + o_cnt)[i];
+        const int m = n[i] < cap ? n[i] : cap;
+        if (n[i] > cap) over = 1;
+        if (m > 0 && kp[i]) memcpy(kp[i], H + o_kp + sizeof(gfo_keypoint) * (size_t)ks * i, sizeof(gfo_keypoint) * (size_t)m);
+        if (m > 0 && desc[i]) memcpy(desc[i], H + o_ds + 32 * (size_t)ks * i, 32 * (size_t)m);
+    }
+    if (sp) {
+        const int m = n[0] < cap ? n[0] : cap;
+        if (m > 0) {
+            memcpy(u_right, H + o_ur, 4 * (size_t)m);
+            memcpy(depth, H + o_dp, 4 * (size_t)m);
+            if (best_dist) memcpy(best_dist, H + o_bd, 4 * (size_t)m);
+            if (best_idx_r) memcpy(best_idx_r, H + o_bi, 4 * (size_t)m);
+        }
+        *nmatched = *reinterpret_cast<const int*>(H + o_nm);
+    }
+    return over ? fail(c, GFO_ERR_CAPACITY, "an image produced more keypoints than the caller capacity %d", cap) : GFO_OK;
+}
+
 extern "C" int gfo_extract_batch(gfo_ctx* c, const uint8_t* const* imgs, int nimg, int w, int h, int stride,
                                  gfo_keypoint* kp, uint8_t* desc, int cap, int* n)
 {
@@ -733,6 +934,15 @@ extern "C" int gfo_extract_batch(gfo_ctx* c, const uint8_t* const* imgs, int nim
     HIP_TRY(c, hipSetDevice(c->device));
     int rc = plan(c, w, h, nimg);
     if (rc) return rc;
+    if (nimg <= GFO_SMALL_BATCH) {
+        gfo_keypoint* kps[GFO_SMALL_BATCH];
+        uint8_t* ds[GFO_SMALL_BATCH];
+        for (int i = 0; i < nimg; i++) {
+            kps[i] = kp ? kp + (size_t)i * cap : nullptr;
+            ds[i] = desc ? desc + (size_t)i * cap * 32 : nullptr;
+        }
+        return extract_small(c, imgs, nimg, w, h, stride, nullptr, kps, ds, cap, n, nullptr, nullptr, nullptr, nullptr, nullptr);
+    }
     GfoInput in;
     rc = upload_images(c, imgs, nimg, w, h, stride, &in);
     if (rc) return rc;
@@ -751,6 +961,29 @@ extern "C" int gfo_extract_batch(gfo_ctx* c, const uint8_t* const* imgs, int nim
     }
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     return over ? fail(c, GFO_ERR_CAPACITY, "an image produced more keypoints than the caller capacity %d", cap) : GFO_OK;
+}
+
+extern "C" int gfo_extract_stereo(gfo_ctx* c, const uint8_t* img_l, const uint8_t* img_r, int w, int h, int stride,
+                                  const gfo_stereo_params* p, gfo_keypoint* kp_l, uint8_t* desc_l, gfo_keypoint* kp_r,
+                                  uint8_t* desc_r, int cap, int* n_l, int* n_r, float* u_right, float* depth,
+                                  int32_t* best_dist, int32_t* best_idx_r, int* nmatched)
+{
+    if (!c || !p || !n_l || !n_r || !u_right || !depth || !nmatched) return fail(c, GFO_ERR_INVALID, "bad argument");
+    *n_l = *n_r = *nmatched = 0;
+    if (!img_l || !img_r || w <= 0 || h <= 0) return GFO_OK;   // empty image: outputs untouched (:1115)
+    if (stride < w) return fail(c, GFO_ERR_INVALID, "stride < width");
+    HIP_TRY(c, hipSetDevice(c->device));
+    int rc = plan(c, w, h, 2);
+    if (rc) return rc;
+    if (p->n_rows < 1 || p->n_rows > c->st_rows_cap) return fail(c, GFO_ERR_INVALID, "n_rows %d exceeds the planned %d", p->n_rows, c->st_rows_cap);
+    const uint8_t* imgs[2] = {img_l, img_r};
+    gfo_keypoint* kps[2] = {kp_l, kp_r};
+    uint8_t* ds[2] = {desc_l, desc_r};
+    int n[2] = {0, 0};
+    rc = extract_small(c, imgs, 2, w, h, stride, p, kps, ds, cap, n, u_right, depth, best_dist, best_idx_r, nmatched);
+    *n_l = n[0];
+    *n_r = n[1];
+    return rc;
 }
 
 extern "C" int gfo_extract(gfo_ctx* c, const uint8_t* img, int w, int h, int stride, gfo_keypoint* kp, uint8_t* desc,
@@ -928,20 +1161,8 @@ extern "C" int gfo_stereo_match_batch(gfo_ctx* c, const gfo_stereo_params* p)
     if (!c || !p) return GFO_ERR_INVALID;
     if (!c->have_batch) return fail(c, GFO_ERR_STATE, "no batch has been extracted");
     if (c->last_nimg < 2 || (c->last_nimg & 1)) return fail(c, GFO_ERR_STATE, "stereo needs an even number of images (L,R,L,R,...)");
-    const int npairs = c->last_nimg / 2;
     if (p->n_rows < 1 || p->n_rows > c->st_rows_cap) return fail(c, GFO_ERR_INVALID, "n_rows %d exceeds the planned %d", p->n_rows, c->st_rows_cap);
-    GfoStereoLaunch sl{};
-    sl.kl = c->d_kp; sl.dl = c->d_desc;
-    sl.kr = c->d_kp + c->g.kp_stride; sl.dr = c->d_desc + (size_t)c->g.kp_stride * 32;
-    sl.cnt_dev = c->d_kp_cnt; sl.nl_host = 0; sl.nr_host = 0;
-    sl.pair_stride_kp = 2LL * c->g.kp_stride; sl.npairs = npairs;
-    sl.d_scale = c->d_scale;
-    sl.p = *p;
-    sl.min_d = nullptr; sl.max_d = nullptr;
-    sl.out = c->st; sl.out_stride = c->g.kp_stride;
-    sl.sort = c->st_sort; sl.sort_stride = c->g.kp_stride;
-    sl.window = gfo_stereo_window(c->scale.data(), c->g.nlevels);
-    gfo_launch_stereo(c, sl);
+    gfo_launch_stereo(c, stereo_batch_launch(c, *p));
     if (int lrc = gfo_take_launch_err(c)) return lrc;
     HIP_TRY(c, hipGetLastError());
     c->have_stereo = true;

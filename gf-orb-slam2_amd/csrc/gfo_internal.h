@@ -210,6 +210,14 @@ struct gfo_ctx {
     int map_cap = 0, map_m = 0;
     bool have_projection = false;
     int proj_frames = 0, proj_step = 1;
+    // latency path (host images, small batches): pinned staging for one-copy / one-sync transfers and a captured
+    // hipGraph of the fixed launch sequence
+    uint8_t* h_in = nullptr;  size_t h_in_bytes = 0;     // hipHostMalloc
+    uint8_t* h_out = nullptr; size_t h_out_bytes = 0;
+    bool graph_ok = true;
+    hipGraphExec_t graph_exec = nullptr;
+    struct GraphKey { const void* base; const void* pack_dst; long long pitch, img_stride; int nimg, stereo; gfo_stereo_params sp; int plan_gen; } graph_key{};
+    int plan_gen = 0;
     // resident vocabulary tree (gfo_vocabulary_upload)
     void* d_voc = nullptr;
     size_t voc_desc_off = 0, voc_fc_off = 0, voc_nc_off = 0, voc_wid_off = 0, voc_w_off = 0;

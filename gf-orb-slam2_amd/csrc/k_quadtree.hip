@@ -143,8 +143,11 @@ void gfo_launch_quadtree(gfo_ctx* c, int nimg)
     for (int l = 0; l < c->g.nlevels; l++) ncap = c->g.lv[l].node_cap > ncap ? c->g.lv[l].node_cap : ncap;
     // keys kept in LDS (6 B each).  Measured on MI355X: 0 (keys in L2, 4 workgroups per CU) beats 6144
     // (LDS-resident keys, 2 workgroups per CU) -- the kernel is barrier-bound, not load-bound.
-    static const int klds_env = getenv("GFO_QT_KLDS") ? atoi(getenv("GFO_QT_KLDS")) : 0;
-    int klds = klds_env;
+    // A handful of images (the per-frame latency path) is a different regime: 16 workgroups on 256 CUs, the level-0
+    // workgroup IS the critical path, so it gets LDS-resident keys and 1024 threads (0.237 -> 0.214 ms per stereo frame).
+    static const int klds_env = getenv("GFO_QT_KLDS") ? atoi(getenv("GFO_QT_KLDS")) : -1;
+    const bool few = nimg <= 8;
+    int klds = klds_env >= 0 ? klds_env : (few ? 6144 : 0);
     while (klds > 0 && gfo_quadtree_lds_bytes(ncap, klds) > 150 * 1024) klds -= 1024;
     const size_t lds = gfo_quadtree_lds_bytes(ncap, klds);
     const bool gmem = lds > 160 * 1024;   // state of the largest level does not fit LDS: scratch in HBM (plan() sized it)
@@ -162,7 +165,7 @@ void gfo_launch_quadtree(gfo_ctx* c, int nimg)
     // the per-pass key loops are latency-bound inside a workgroup: large quotas (1080p @4000 features) get
     // 1024 threads per (image, level), the 752x480 @2000 case runs best with 256
     static const int nt_env = getenv("GFO_QT_THREADS") ? atoi(getenv("GFO_QT_THREADS")) : 0;
-    const int nthreads = nt_env ? nt_env : (c->g.lv[0].quota >= 600 ? 1024 : 256);
+    const int nthreads = nt_env ? nt_env : (c->g.lv[0].quota >= 600 || few ? 1024 : 256);
     static const bool timing = getenv("GFO_QT_TIMING") != nullptr;
     unsigned long long* d_ts = nullptr;
     if (timing && hipMalloc(&d_ts, 128 * sizeof(unsigned long long)) == hipSuccess) (void)hipMemsetAsync(d_ts, 0, 128 * sizeof(unsigned long long), c->stream);

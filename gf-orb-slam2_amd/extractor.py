@@ -91,6 +91,34 @@ class ORBextractor:
         self._last_shape = (h, w)
         return [kp[i, :cnt[i]].copy() for i in range(n)], [desc[i, :cnt[i]].copy() for i in range(n)]
 
+    def extract_stereo(self, left, right, params):
+        """One stereo frame in one submission (gfo_extract_stereo): the reference's stereo Frame constructor body --
+        ExtractORB x2 (Frame.cc:84-87) + ComputeStereoMatches_Undistorted (:1167-1316).
+        Returns (kp_l, desc_l, kp_r, desc_r, nmatched, mvuRight, mvDepth, best_dist, best_idx_r)."""
+        from ._lib import StereoParamsC
+        left = np.ascontiguousarray(left, np.uint8)
+        right = np.ascontiguousarray(right, np.uint8)
+        h, w = left.shape
+        assert right.shape == (h, w)
+        cap = max(self.max_keypoints(), self.nfeatures + 64)
+        p = StereoParamsC(*params)
+        while True:
+            kl = np.zeros(cap, KEYPOINT_DTYPE); kr = np.zeros(cap, KEYPOINT_DTYPE)
+            dl = np.zeros((cap, 32), np.uint8); dr = np.zeros((cap, 32), np.uint8)
+            u = np.zeros(cap, np.float32); dp = np.zeros(cap, np.float32)
+            bd = np.zeros(cap, np.int32); bi = np.zeros(cap, np.int32)
+            nl, nr, nm = C.c_int(), C.c_int(), C.c_int()
+            rc = self._L.gfo_extract_stereo(self._ctx, ptr(left), ptr(right), w, h, w, C.byref(p), ptr(kl), ptr(dl), ptr(kr), ptr(dr), cap,
+                                            C.byref(nl), C.byref(nr), ptr(u), ptr(dp), ptr(bd), ptr(bi), C.byref(nm))
+            if rc == -3:
+                cap = max(nl.value, nr.value, self.max_keypoints())
+                continue
+            check(self._L, self._ctx, rc)
+            break
+        self._last_shape = (h, w)
+        a, b = nl.value, nr.value
+        return kl[:a].copy(), dl[:a].copy(), kr[:b].copy(), dr[:b].copy(), nm.value, u[:a].copy(), dp[:a].copy(), bd[:a].copy(), bi[:a].copy()
+
     # device-resident path (bench / chained stereo)
     def extract_batch_device(self, dev_ptr, nimg, w, h, pitch=None, img_stride=None):
         pitch = pitch or w

@@ -145,6 +145,17 @@ int gfo_stereo_match(gfo_ctx* ctx, const gfo_keypoint* kl, const uint8_t* dl, in
 /* Device-chained form: images (2k, 2k+1) of the last batch are the left/right views of pair k.
  * Results stay on the device; fetch with gfo_stereo_fetch. */
 int gfo_stereo_match_batch(gfo_ctx* ctx, const gfo_stereo_params* p);
+/* One stereo frame in ONE submission: the body of the reference's stereo Frame constructor --
+ * ExtractORB(0, imLeft) and ExtractORB(1, imRight) on two threads (src/Frame.cc:84-87, 478-484), then
+ * ComputeStereoMatches_Undistorted (:100, 1167-1316) -- as one H2D copy of both images, one replay of the captured
+ * launch sequence (both extractions + the association), one D2H burst and one synchronisation.  The extracted
+ * keypoints stand for mvKeysUn / mvKeysRightUn (rectified input, as the reference's stereo examples provide).
+ * kp/desc buffers take `cap` entries per image; u_right/depth/best_dist/best_idx_r take cap entries (left keypoints). */
+int gfo_extract_stereo(gfo_ctx* ctx, const uint8_t* img_l, const uint8_t* img_r, int w, int h, int stride,
+                       const gfo_stereo_params* p, gfo_keypoint* kp_l, uint8_t* desc_l, gfo_keypoint* kp_r,
+                       uint8_t* desc_r, int cap, int* n_l, int* n_r, float* u_right, float* depth,
+                       int32_t* best_dist, int32_t* best_idx_r, int* nmatched);
+
 /* Frame::ComputeStereoMatches (src/Frame.cc:889-1078): the SAD sub-pixel variant the reference compiles out
  * with ALTER_STEREO_MATCHING (include/Frame.h:38).  It reads pyramid pixels of BOTH cameras, so it exists in the
  * batched form only: images (2k, 2k+1) of the last batch, keypoints as extracted (mvKeys / mvKeysRight).

@@ -164,3 +164,39 @@ def test_host_keypoints_with_bad_octaves_are_refused(oracle):
         ext.extract_batch_device(t.data_ptr(), 2, 320, 240, pitch=320, img_stride=320 * 100)
     assert e.value.code == -1
     ext.close()
+
+
+def test_stereo_frame_in_one_submission(oracle, euroc_l, euroc_r):
+    """gfo_extract_stereo = ExtractORB x2 + ComputeStereoMatches_Undistorted (Frame.cc:84-100) as one H2D, one replay
+    of the captured launch sequence, one D2H, one synchronisation: same bits as the oracle, on the first call (which
+    captures the graph), on replays, after a change of image size (re-plan, new graph) and with other stereo
+    parameters (a different graph key)."""
+    import gf_orb_slam2_amd as G
+    ext = G.ORBextractor(2000, 1.2, 8, 20, 7, max_batch=2)
+    oe = oracle.OracleExtractor(2000, 1.2, 8, 20, 7)
+    sf = oe.scale_factors
+
+    def check(l, r, prm):
+        okl, odl = oe(l)
+        okr, odr = oe(r)
+        ref = oracle.stereo_match(okl, odl, okr, odr, sf, prm.n_rows, prm.mbf, prm.mb, prm.min_x)
+        kl, dl, kr, dr, nm, u, dp, bd, bi = ext.extract_stereo(l, r, prm)
+        assert kl.tobytes() == okl.tobytes() and kr.tobytes() == okr.tobytes()
+        assert (dl == odl).all() and (dr == odr).all()
+        assert nm == ref[0]
+        for a, b in zip((u, dp, bd, bi), ref[1:]):
+            assert a.tobytes() == b.tobytes()
+        return nm
+
+    p1 = G.StereoParams(480, BF, BF / FX, 0.0)
+    for _ in range(3):                                   # capture, then two replays
+        assert check(euroc_l, euroc_r, p1) > 500
+    crop_l, crop_r = np.ascontiguousarray(euroc_l[40:400, 100:700]), np.ascontiguousarray(euroc_r[40:400, 100:700])
+    check(crop_l, crop_r, G.StereoParams(360, BF, BF / FX, 0.0))         # other size: arena re-planned, graph rebuilt
+    check(crop_l, crop_r, G.StereoParams(360, 30.0, 0.2, 0.0))           # other calibration: graph key differs
+    check(euroc_l, euroc_r, p1)
+    # the plain batch path shares the pinned staging / single-sync code
+    (k0, k1), (d0, d1) = ext.extract_batch([euroc_l, euroc_r])
+    ok, od = oe(euroc_l)
+    assert k0.tobytes() == ok.tobytes() and (d0 == od).all()
+    ext.close()
