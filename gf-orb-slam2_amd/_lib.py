@@ -118,7 +118,9 @@ def mapped_hip_runtimes():
 def _check_single_hip_runtime():
     """Two copies of libamdhip64 / libhsa-runtime64 in one process (PyTorch's bundled one plus /opt/rocm's) each
     bring up their own runtime; the second then reports "No HIP GPUs are available" or stalls.  Refuse loudly."""
-    dup = {k: sorted(v) for k, v in mapped_hip_runtimes().items() if len(v) > 1}
+    # libamdhip64 only: a second libhsa-runtime64 is mapped legitimately by tools that preload /opt/rocm's own copy
+    # (rocprofv3's rocprofiler-sdk does) and was never the failing case
+    dup = {k: sorted(v) for k, v in mapped_hip_runtimes().items() if len(v) > 1 and k == "libamdhip64"}
     if dup:
         raise GfoError(-2, "two HIP runtimes are mapped into this process: " + "; ".join(f"{k}: {v}" for k, v in dup.items()) +
                        " -- import gf_orb_slam2_amd (or torch) before anything else loads /opt/rocm's libamdhip64, so "

@@ -55,8 +55,7 @@ __device__ __forceinline__ unsigned rot16(unsigned a) { return __builtin_amdgcn_
 // Survivors of the compass test: score directly.  corner(t) <=> S > t, so the exact 9-contiguous test and the
 // score are one computation (the packed arc minima); the polarity to score comes from the compass pixels
 // themselves -- a 9-arc holds a pixel of each opposite pair, so a dark arc needs (d0 or d8) and (d4 or d12)
-// above t, a bright arc the mirror image.  Where both hold, the all-eight-pairs test picks the one polarity that
-// can still be a corner (below).
+// above t, a bright arc the mirror image.  Both can hold for one pixel (rarely); then both are scored.
 template <int TP>
 __device__ __forceinline__ int corner_score(const uint8_t* __restrict__ c, int tq)
 {
@@ -75,27 +74,14 @@ __device__ __forceinline__ int corner_score(const uint8_t* __restrict__ c, int t
     const int s_hi = (int)(short)(__builtin_bit_cast(unsigned, __builtin_elementwise_min(hi08, hi4c)) & 0xFFFF);
     const int s_lo = (int)(short)(__builtin_bit_cast(unsigned, __builtin_elementwise_max(lo08, lo4c)) & 0xFFFF);
     const bool dark = s_hi > tq, bright = s_lo < -tq;
-    // ONE polarity is scored per pixel.  A dark and a bright 9-arc cannot coexist (18 > 16 ring pixels), so a pixel
-    // whose compass pixels allow both (saddles, edge crossings: ~5 % of the survivors, i.e. nearly every wave holds
-    // one) only needs the polarity that can still be a corner: a dark 9-arc covers at least one member of EVERY
-    // opposite pair (k, k+8), so "all eight pairs hold a pixel darker than v - t" is necessary for it -- and when both
-    // polarities pass that test no pair has two members of one sign, so neither has a 9-arc and either choice scores
-    // <= t.  18 packed ops for the whole wave instead of a second scoring pass (~100).
-    bool neg = !dark;
-    if (__ballot(dark && bright) != 0) {
-        unsigned m8 = __builtin_bit_cast(unsigned, __builtin_elementwise_min(hi08, hi4c));   // pairs 0 and 4, both halves alike
-#pragma unroll
-        for (int k = 1; k < 8; k++) {
-            if (k == 4) continue;
-            const unsigned dk = __builtin_bit_cast(unsigned, D[k]);
-            m8 = pmin(m8, pmax(dk, rot16(dk)));
-        }
-        const bool all8dark = (int)(short)(m8 & 0xFFFF) > tq;
-        if (dark && bright) neg = !all8dark;
-    }
-    const bool run = dark || bright;
     int best = 0;
-    {
+#pragma unroll 1
+    for (int pass = 0; pass < 2; pass++) {
+        // pass 0: the dark polarity where it is possible, else the bright one; pass 1: bright for the pixels
+        // that allow both (skipped by the whole wave when no lane has one)
+        const bool run = pass == 0 ? (dark || bright) : (dark && bright);
+        if (__ballot(run) == 0) break;
+        const bool neg = pass == 0 ? !dark : true;
         const s16x2 sg = __builtin_bit_cast(s16x2, neg ? 0xFFFFFFFFu : 0x00010001u);
         unsigned P[8], R[8];
 #pragma unroll
@@ -117,7 +103,8 @@ __device__ __forceinline__ int corner_score(const uint8_t* __restrict__ c, int t
 #pragma unroll
         for (int k = 0; k < 8; k++) bst = pmax(bst, pmin(pmin(X4[k], X4[k + 4]), R[k]));
         const int b0 = (int)(short)(bst & 0xFFFF), b1 = (int)(short)(bst >> 16);
-        if (run) best = max(b0, b1);
+        const int sc = max(b0, b1);
+        if (run) best = max(best, sc);
     }
     return best;
 }
@@ -265,27 +252,23 @@ __global__ __launch_bounds__(256) void k_fast(const GfoGeom* __restrict__ gp, Gf
                     // one v_perm_b32 per operand spreads bytes (h, h+2) into two u16 (selector 0x0C = zero byte)
                     const unsigned ps = h ? 0x0C030C01u : 0x0C020C00u;
                     const s16x2 vc = __builtin_bit_cast(s16x2, __builtin_amdgcn_perm(0u, C, ps));
-                    const s16x2 pu = __builtin_bit_cast(s16x2, __builtin_amdgcn_perm(0u, U, ps));
-                    const s16x2 pr = __builtin_bit_cast(s16x2, __builtin_amdgcn_perm(0u, Rw, ps));
-                    const s16x2 pd = __builtin_bit_cast(s16x2, __builtin_amdgcn_perm(0u, D, ps));
-                    const s16x2 pl = __builtin_bit_cast(s16x2, __builtin_amdgcn_perm(0u, Lw, ps));
-                    // a 9-arc holds at least one pixel of every opposite pair: (U, D) = ring 0/8, (R, L) = ring 4/12.
-                    // Both pairs hold a darker pixel  <=>  v - max(min(U, D), min(R, L)) > t;
-                    // both pairs hold a brighter one  <=>  min(max(U, D), max(R, L)) - v > t   (12 packed ops per pixel pair)
-                    const s16x2 dk = vc - __builtin_elementwise_max(__builtin_elementwise_min(pu, pd), __builtin_elementwise_min(pr, pl));
-                    const s16x2 br = __builtin_elementwise_min(__builtin_elementwise_max(pu, pd), __builtin_elementwise_max(pr, pl)) - vc;
-                    // sign bit set <=> max(dk, br) > tq
-                    const s16x2 t1 = __builtin_bit_cast(s16x2, tq2) - __builtin_elementwise_max(dk, br);
-                    const unsigned sg = __builtin_bit_cast(unsigned, t1) & 0x80008000u;
+                    const s16x2 a = vc - __builtin_bit_cast(s16x2, __builtin_amdgcn_perm(0u, U, ps));
+                    const s16x2 b = vc - __builtin_bit_cast(s16x2, __builtin_amdgcn_perm(0u, Rw, ps));
+                    const s16x2 e = vc - __builtin_bit_cast(s16x2, __builtin_amdgcn_perm(0u, D, ps));
+                    const s16x2 f = vc - __builtin_bit_cast(s16x2, __builtin_amdgcn_perm(0u, Lw, ps));
+                    // a 9-arc holds at least one pixel of every opposite pair: (a,e) = ring 0/8, (b,f) = ring 4/12
+                    const s16x2 s_hi = __builtin_elementwise_min(__builtin_elementwise_max(a, e), __builtin_elementwise_max(b, f));
+                    const s16x2 s_lo = __builtin_elementwise_max(__builtin_elementwise_min(a, e), __builtin_elementwise_min(b, f));
+                    // sign bit set <=> both pairs hold a darker pixel (s_hi > tq) or both a brighter one (s_lo < -tq)
+                    const s16x2 t1 = __builtin_bit_cast(s16x2, tq2) - s_hi;
+                    const s16x2 t2 = s_lo + __builtin_bit_cast(s16x2, tq2);
+                    const unsigned sg = (__builtin_bit_cast(unsigned, t1) | __builtin_bit_cast(unsigned, t2)) & 0x80008000u;
                     sign |= sg >> (h ? 0 : 1);  // h=0 -> bits 14,30 ; h=1 -> bits 15,31
                 }
                 // sign bits: pixel0 -> bit14, pixel1 -> bit15, pixel2 -> bit30, pixel3 -> bit31
                 passbits = ((sign >> 14) & 3u) | ((sign >> 28) & 12u);
                 passbits &= valid;
             }
-            // (measured alternative: gathering the pass bits of all iterations per lane and letting every lane pop its
-            //  lowest set bit per round -- survivors cluster, the busiest lane holds 8-12 of them, and the rounds cost
-            //  more than these four ballots per iteration: 386 vs 373 vector instructions per cell for stage A)
             const int p0 = (py << 6) + c0;   // queue entry: px | py << 6 (cells are at most 64 px wide)
 #pragma unroll
             for (int j = 0; j < 4; j++) {
