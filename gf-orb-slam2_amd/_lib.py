@@ -37,7 +37,11 @@ class FrameBoundsC(C.Structure):
 
 class VocabularyC(C.Structure):
     _fields_ = [("first_child", C.c_void_p), ("n_children", C.c_void_p), ("descriptors", C.c_void_p), ("word_id", C.c_void_p),
-                ("weight", C.c_void_p), ("n_nodes", C.c_int32), ("depth", C.c_int32)]
+                ("weight", C.c_void_p), ("n_nodes", C.c_int32), ("depth", C.c_int32), ("weight64", C.c_void_p)]
+
+
+class BowModeC(C.Structure):
+    _fields_ = [("weighting", C.c_int32), ("norm", C.c_int32)]
 
 
 class ProjectionBatchC(C.Structure):
@@ -64,7 +68,7 @@ SYMBOLS = [
     "gfo_extract_stereo", "gfo_extract_batch_device", "gfo_batch_counts", "gfo_batch_fetch", "gfo_batch_device_views",
     "gfo_compute_pyramid", "gfo_pyramid_level", "gfo_hamming256", "gfo_stereo_match",
     "gfo_stereo_match_batch", "gfo_stereo_match_sad_batch", "gfo_stereo_fetch", "gfo_search_by_projection", "gfo_search_by_projection_queries",
-    "gfo_map_upload", "gfo_search_by_projection_batch", "gfo_projection_fetch", "gfo_projection_device_views", "gfo_search_by_bow", "gfo_vocabulary_upload", "gfo_bow_transform", "gfo_profile_enable",
+    "gfo_map_upload", "gfo_search_by_projection_batch", "gfo_projection_fetch", "gfo_projection_device_views", "gfo_search_by_bow", "gfo_vocabulary_upload", "gfo_bow_transform", "gfo_compute_bow", "gfo_profile_enable",
     "gfo_profile_read", "gfo_debug_blurred_level", "gfo_debug_level_candidates",
 ]
 
@@ -178,6 +182,7 @@ def load_library():
     L.gfo_search_by_bow.argtypes = [vp, vp, vp, vp, i, C.POINTER(FeatureVectorC), vp, vp, i, C.POINTER(FeatureVectorC), f, i, vp, ip]
     L.gfo_vocabulary_upload.argtypes = [vp, C.POINTER(VocabularyC)]
     L.gfo_bow_transform.argtypes = [vp, vp, i, i, vp, vp, vp]
+    L.gfo_compute_bow.argtypes = [vp, vp, i, i, C.POINTER(BowModeC), vp, vp, ip, vp, vp, vp, ip]
     L.gfo_profile_enable.argtypes = [vp, i]
     L.gfo_profile_read.argtypes = [vp, C.POINTER(StageTime), i, ip, i]
     L.gfo_debug_blurred_level.argtypes = [vp, i, i, vp, i]

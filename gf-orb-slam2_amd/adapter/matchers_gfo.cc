@@ -372,6 +372,7 @@ struct VocabularyView : public ORBVocabulary {
     struct Flat {
         std::vector<int32_t> first_child, n_children, word_id, orig_id;
         std::vector<float> weight;
+        std::vector<double> weight64;
         std::vector<uint8_t> desc;
         int depth;
     };
@@ -379,7 +380,7 @@ struct VocabularyView : public ORBVocabulary {
     {
         const size_t n = m_nodes.size();
         f.first_child.assign(n, 0); f.n_children.assign(n, 0); f.word_id.assign(n, 0); f.orig_id.assign(n, 0);
-        f.weight.assign(n, 0.f); f.desc.assign(n * 32, 0);
+        f.weight.assign(n, 0.f); f.weight64.assign(n, 0.0); f.desc.assign(n * 32, 0);
         f.depth = m_L;
         std::vector<DBoW2::NodeId> order(1, 0);                      // new index -> original NodeId, root first
         for (size_t head = 0; head < order.size(); head++) {
@@ -393,6 +394,7 @@ struct VocabularyView : public ORBVocabulary {
             f.orig_id[i] = (int32_t)nd.id;
             f.word_id[i] = (int32_t)nd.word_id;
             f.weight[i] = (float)nd.weight;
+            f.weight64[i] = nd.weight;                         // WordValue is a double: the fold sums it unrounded
             if (i > 0 && nd.descriptor.cols == 32) memcpy(&f.desc[i * 32], nd.descriptor.data, 32);
         }
     }
@@ -419,7 +421,7 @@ void Frame::ComputeBoW()
             VocabularyView::Flat f;
             static_cast<const VocabularyView*>(mpORBvocabulary)->flatten(f);
             gfo_vocabulary v = {f.first_child.data(), f.n_children.data(), f.desc.data(), f.word_id.data(), f.weight.data(),
-                                (int32_t)f.first_child.size(), f.depth};
+                                (int32_t)f.first_child.size(), f.depth, f.weight64.data()};
             if (gfo_vocabulary_upload(c, &v) != GFO_OK) {
                 report(c, "ComputeBoW (vocabulary upload)");
                 return;
@@ -428,22 +430,42 @@ void Frame::ComputeBoW()
         }
         flat = &it->second;
     }
-    std::vector<int32_t> word(N), node(N);
-    std::vector<float> weight(N);
-    cv::Mat keep;
-    if (gfo_bow_transform(c, rows32(mDescriptors, keep), N, 4, word.data(), weight.data(), node.data()) != GFO_OK) {   // levelsup = 4, Frame.cc:666
-        report(c, "ComputeBoW");
-        return;
-    }
-    // the fold of TemplatedVocabulary::transform(features, v, fv, levelsup), :1140-1212, in feature order
     const VocabularyView* voc = static_cast<const VocabularyView*>(mpORBvocabulary);
     DBoW2::LNorm norm;
     const bool must = voc->m_scoring_object->mustNormalize(norm);
+    cv::Mat keep;
+    const uint8_t* desc = rows32(mDescriptors, keep);
+    if (N <= 8192) {
+        // descent AND fold on the device: both maps come back flattened in std::map order (TemplatedVocabulary.h:1140-1212)
+        std::vector<uint32_t> bw(N), fn(N), fi(N);
+        std::vector<double> bv(N);
+        std::vector<int32_t> fs(N + 1);
+        int nw = 0, nf = 0;
+        gfo_bow_mode mode = {(int32_t)voc->m_weighting, must ? (norm == DBoW2::L1 ? 1 : 2) : 0};
+        if (gfo_compute_bow(c, desc, N, 4, &mode, bw.data(), bv.data(), &nw, fn.data(), fs.data(), fi.data(), &nf) != GFO_OK) {   // levelsup = 4, Frame.cc:666
+            report(c, "ComputeBoW");
+            return;
+        }
+        for (int k = 0; k < nw; k++) mBowVec.insert(mBowVec.end(), DBoW2::BowVector::value_type((DBoW2::WordId)bw[k], bv[k]));
+        for (int j = 0; j < nf; j++) {
+            std::vector<unsigned int>& items = mFeatVec[(DBoW2::NodeId)flat->orig_id[fn[j]]];
+            items.assign(fi.begin() + fs[j], fi.begin() + fs[j + 1]);
+        }
+        return;
+    }
+    // more descriptors than one fold workgroup sorts: descent on the device, the fold of :1140-1212 here, in feature order
+    std::vector<int32_t> word(N), node(N);
+    std::vector<float> weight(N);
+    if (gfo_bow_transform(c, desc, N, 4, word.data(), weight.data(), node.data()) != GFO_OK) {
+        report(c, "ComputeBoW");
+        return;
+    }
     const bool tf = voc->m_weighting == DBoW2::TF || voc->m_weighting == DBoW2::TF_IDF;
     for (int i = 0; i < N; i++) {
         if (!(weight[i] > 0)) continue;                                       // stopped word
-        if (tf) mBowVec.addWeight((DBoW2::WordId)word[i], weight[i]);
-        else mBowVec.addIfNotExist((DBoW2::WordId)word[i], weight[i]);
+        const double w = (double)weight[i];                                    // float table on this path
+        if (tf) mBowVec.addWeight((DBoW2::WordId)word[i], w);
+        else mBowVec.addIfNotExist((DBoW2::WordId)word[i], w);
         mFeatVec.addFeature((DBoW2::NodeId)flat->orig_id[node[i]], (unsigned int)i);
     }
     if (tf && !mBowVec.empty() && !must) {

@@ -220,7 +220,7 @@ struct gfo_ctx {
     int plan_gen = 0;
     // resident vocabulary tree (gfo_vocabulary_upload)
     void* d_voc = nullptr;
-    size_t voc_desc_off = 0, voc_fc_off = 0, voc_nc_off = 0, voc_wid_off = 0, voc_w_off = 0;
+    size_t voc_desc_off = 0, voc_fc_off = 0, voc_nc_off = 0, voc_wid_off = 0, voc_w_off = 0, voc_w64_off = 0;
     int voc_nodes = 0, voc_depth = 0;     // Jacobi rounds of the last gfo_search_by_projection
 };
 

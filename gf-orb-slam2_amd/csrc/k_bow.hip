@@ -241,12 +241,13 @@ struct VocDev {
     const uint8_t* descriptors;
     const int* word_id;
     const float* weight;
+    const double* weight64;
     int n_nodes, depth;
 };
 
 __global__ __launch_bounds__(256) void k_bow_transform(VocDev v, const uint8_t* __restrict__ desc, int n, int levelsup,
                                                        int* __restrict__ word_id, float* __restrict__ weight,
-                                                       int* __restrict__ node_id)
+                                                       int* __restrict__ node_id, double* __restrict__ weight64)
 {
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;  // uniform: keep it scalar
     const int i = blockIdx.x * 4 + wave;
@@ -275,9 +276,149 @@ __global__ __launch_bounds__(256) void k_bow_transform(VocDev v, const uint8_t* 
     }
     if (lane == 0) {
         word_id[i] = v.word_id[final_id];
-        weight[i] = v.weight[final_id];
+        if (weight) weight[i] = v.weight[final_id];
+        if (weight64) weight64[i] = v.weight64[final_id];
         node_id[i] = nid;
     }
+}
+
+// ---------------------------------------------------------------------------------------------
+// The fold of TemplatedVocabulary::transform(features, v, fv, levelsup) (TemplatedVocabulary.h:1140-1212): one
+// workgroup turns the per-feature (word, weight, node) triples into both maps, flattened in std::map order.
+// Two sorts of (key << 32 | feature index) in LDS -- by node for the FeatureVector, by word for the BowVector --
+// give every segment its members in feature order, which is the order the reference inserts and ADDS them in, so
+// the double sums come out bit for bit (addWeight: v1, then += v2, += v3 ...); the normalisation sum runs over the
+// words in ascending order, serially, as BowVector::normalize does.
+// ---------------------------------------------------------------------------------------------
+struct BowFold {
+    const int* word; const double* wt; const int* node; int n;
+    int weighting, norm;
+    unsigned* bow_words; double* bow_values; unsigned* fv_nodes; int* fv_start; unsigned* fv_items; int* counts;   // counts[0] words, [1] fv nodes
+};
+
+__device__ void bow_bitonic(unsigned long long* key, int p2, int tid)
+{
+    for (int k2 = 2; k2 <= p2; k2 <<= 1)
+        for (int j = k2 >> 1; j > 0; j >>= 1) {
+            for (int i = tid; i < p2; i += 1024) {
+                const int ixj = i ^ j;
+                if (ixj > i) {
+                    const unsigned long long a = key[i], b = key[ixj];
+                    const bool up = (i & k2) == 0;
+                    if (up ? a > b : a < b) { key[i] = b; key[ixj] = a; }
+                }
+            }
+            __syncthreads();
+        }
+}
+
+// exclusive scan of flag[0..n) (ints in LDS) in place; returns the total.  1024 threads.
+__device__ int bow_scan(int* v, int n, int* part, int tid)
+{
+    const int chunk = (n + 1023) / 1024;
+    const int b = min(tid * chunk, n), e = min(b + chunk, n);
+    int s = 0;
+    for (int i = b; i < e; i++) s += v[i];
+    part[tid] = s;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+        const int t = tid >= off ? part[tid - off] : 0;
+        __syncthreads();
+        part[tid] += t;
+        __syncthreads();
+    }
+    int run = part[tid] - s;
+    const int total = part[1023];
+    for (int i = b; i < e; i++) { const int x = v[i]; v[i] = run; run += x; }
+    __syncthreads();
+    return total;
+}
+
+__global__ __launch_bounds__(1024) void k_bow_fold(BowFold a, int p2)
+{
+    extern __shared__ unsigned long long lds_key[];          // p2 keys
+    int* flag = reinterpret_cast<int*>(lds_key + p2);         // p2 ints
+    __shared__ int part[1024];
+    __shared__ int s_nvalid;
+    const int tid = threadIdx.x, n = a.n;
+    // ---- FeatureVector: sort the kept features by (node, feature) ----
+    for (int i = tid; i < p2; i += 1024)
+        lds_key[i] = i < n && a.wt[i] > 0 ? ((unsigned long long)(unsigned)a.node[i] << 32) | (unsigned)i : ~0ull;   // w > 0: not stopped (:1169)
+    if (tid == 0) s_nvalid = 0;
+    __syncthreads();
+    bow_bitonic(lds_key, p2, tid);
+    int cnt = 0;
+    for (int i = tid; i < n; i += 1024) {
+        const bool ok = lds_key[i] != ~0ull;
+        cnt += ok;
+        flag[i] = ok && (i == 0 || (lds_key[i] >> 32) != (lds_key[i - 1] >> 32)) ? 1 : 0;
+    }
+    if (cnt) atomicAdd(&s_nvalid, cnt);
+    __syncthreads();
+    const int nvalid = s_nvalid;
+    // the scan is exclusive: keep the segment-start marks aside (bit 31 of the key's index half is free: n <= 8192)
+    for (int i = tid; i < n; i += 1024)
+        if (flag[i]) lds_key[i] |= 0x80000000ull;
+    __syncthreads();
+    const int nseg = bow_scan(flag, n, part, tid);
+    for (int i = tid; i < nvalid; i += 1024) {
+        const unsigned long long k = lds_key[i];
+        a.fv_items[i] = (unsigned)(k & 0x7FFFFFFFu);
+        if (k & 0x80000000ull) {
+            a.fv_nodes[flag[i]] = (unsigned)(k >> 32);
+            a.fv_start[flag[i]] = i;
+        }
+    }
+    if (tid == 0) { a.fv_start[nseg] = nvalid; a.counts[1] = nseg; }
+    __syncthreads();
+    // ---- BowVector: sort by (word, feature); one thread per word walks its features in order ----
+    for (int i = tid; i < p2; i += 1024)
+        lds_key[i] = i < n && a.wt[i] > 0 ? ((unsigned long long)(unsigned)a.word[i] << 32) | (unsigned)i : ~0ull;
+    __syncthreads();
+    bow_bitonic(lds_key, p2, tid);
+    for (int i = tid; i < n; i += 1024)
+        flag[i] = i < nvalid && (i == 0 || (lds_key[i] >> 32) != (lds_key[i - 1] >> 32)) ? 1 : 0;
+    __syncthreads();
+    for (int i = tid; i < n; i += 1024)
+        if (flag[i]) lds_key[i] |= 0x80000000ull;
+    __syncthreads();
+    const int nwords = bow_scan(flag, n, part, tid);
+    const bool tf = a.weighting == 0 || a.weighting == 1;
+    for (int i = tid; i < nvalid; i += 1024) {
+        const unsigned long long k = lds_key[i];
+        if (!(k & 0x80000000ull)) continue;
+        const unsigned w = (unsigned)(k >> 32);
+        double v = a.wt[(int)(k & 0x7FFFFFFFu)];              // insert(id, v)
+        if (tf)                                                // addWeight: += in feature order
+            for (int j = i + 1; j < nvalid && (unsigned)(lds_key[j] >> 32) == w; j++) v += a.wt[(int)(lds_key[j] & 0x7FFFFFFFu)];
+        a.bow_words[flag[i]] = w;
+        a.bow_values[flag[i]] = v;
+    }
+    __syncthreads();
+    // the stores above are read back below by other threads of this workgroup
+    __threadfence_block();
+    __syncthreads();
+    if (tf && nwords > 0 && a.norm == 0) {                     // "unnecessary when normalizing" (:1177-1183)
+        const double nd = (double)nwords;
+        for (int k = tid; k < nwords; k += 1024) a.bow_values[k] /= nd;
+    }
+    if (a.norm != 0) {
+        __shared__ double s_norm;
+        if (tid == 0) {                                        // BowVector::normalize: one running sum over the map order
+            double nrm = 0.0;
+            if (a.norm == 1) for (int k = 0; k < nwords; k++) nrm += fabs(a.bow_values[k]);
+            else {
+                for (int k = 0; k < nwords; k++) nrm += a.bow_values[k] * a.bow_values[k];
+                nrm = sqrt(nrm);
+            }
+            s_norm = nrm;
+        }
+        __syncthreads();
+        const double nrm = s_norm;
+        if (nrm > 0.0)
+            for (int k = tid; k < nwords; k += 1024) a.bow_values[k] /= nrm;
+    }
+    if (tid == 0) a.counts[0] = nwords;
 }
 
 extern "C" int gfo_vocabulary_upload(gfo_ctx* c, const gfo_vocabulary* voc)
@@ -299,7 +440,7 @@ extern "C" int gfo_vocabulary_upload(gfo_ctx* c, const gfo_vocabulary* voc)
     if (c->d_voc) (void)hipFree(c->d_voc);
     c->d_voc = nullptr;
     const size_t nn = (size_t)voc->n_nodes;
-    const size_t bytes = nn * (4 + 4 + 32 + 4 + 4) + 1024;
+    const size_t bytes = nn * (4 + 4 + 32 + 4 + 4 + 8) + 2048;
     BTRY(c, hipMalloc(&c->d_voc, bytes));
     uint8_t* p = (uint8_t*)c->d_voc;
     c->voc_desc_off = 0;
@@ -307,11 +448,17 @@ extern "C" int gfo_vocabulary_upload(gfo_ctx* c, const gfo_vocabulary* voc)
     c->voc_nc_off = c->voc_fc_off + nn * 4;
     c->voc_wid_off = c->voc_nc_off + nn * 4;
     c->voc_w_off = c->voc_wid_off + nn * 4;
+    c->voc_w64_off = (c->voc_w_off + nn * 4 + 255) / 256 * 256;
     BTRY(c, hipMemcpy(p + c->voc_desc_off, voc->descriptors, nn * 32, hipMemcpyHostToDevice));
     BTRY(c, hipMemcpy(p + c->voc_fc_off, voc->first_child, nn * 4, hipMemcpyHostToDevice));
     BTRY(c, hipMemcpy(p + c->voc_nc_off, voc->n_children, nn * 4, hipMemcpyHostToDevice));
     BTRY(c, hipMemcpy(p + c->voc_wid_off, voc->word_id, nn * 4, hipMemcpyHostToDevice));
     BTRY(c, hipMemcpy(p + c->voc_w_off, voc->weight, nn * 4, hipMemcpyHostToDevice));
+    {
+        std::vector<double> w64(nn);
+        for (size_t i = 0; i < nn; i++) w64[i] = voc->weight64 ? voc->weight64[i] : (double)voc->weight[i];
+        BTRY(c, hipMemcpy(p + c->voc_w64_off, w64.data(), nn * 8, hipMemcpyHostToDevice));
+    }
     c->voc_nodes = voc->n_nodes;
     c->voc_depth = voc->depth;
     return GFO_OK;
@@ -345,12 +492,12 @@ extern "C" int gfo_bow_transform(gfo_ctx* c, const uint8_t* desc, int n, int lev
     uint8_t* S = (uint8_t*)c->d_scratch;
     uint8_t* V = (uint8_t*)c->d_voc;
     VocDev v{(const int*)(V + c->voc_fc_off), (const int*)(V + c->voc_nc_off), V + c->voc_desc_off,
-             (const int*)(V + c->voc_wid_off), (const float*)(V + c->voc_w_off), c->voc_nodes, c->voc_depth};
+             (const int*)(V + c->voc_wid_off), (const float*)(V + c->voc_w_off), (const double*)(V + c->voc_w64_off), c->voc_nodes, c->voc_depth};
     hipStream_t st = c->stream;
     BTRY(c, hipMemcpyAsync(S + o_d, desc, 32 * (size_t)n, hipMemcpyHostToDevice, st));
     gfo_prof_begin(c, ST_BOW);
     hipLaunchKernelGGL(k_bow_transform, dim3((n + 3) / 4), dim3(256), 0, st, v, S + o_d, n, levelsup, (int*)(S + o_w),
-                       (float*)(S + o_wt), (int*)(S + o_n));
+                       (float*)(S + o_wt), (int*)(S + o_n), (double*)nullptr);
     gfo_prof_end(c);
     if (int lrc = gfo_take_launch_err(c)) return lrc;
     BTRY(c, hipGetLastError());
@@ -358,5 +505,74 @@ extern "C" int gfo_bow_transform(gfo_ctx* c, const uint8_t* desc, int n, int lev
     BTRY(c, hipMemcpyAsync(weight, S + o_wt, 4 * (size_t)n, hipMemcpyDeviceToHost, st));
     BTRY(c, hipMemcpyAsync(node_id, S + o_n, 4 * (size_t)n, hipMemcpyDeviceToHost, st));
     BTRY(c, hipStreamSynchronize(st));
+    return GFO_OK;
+}
+
+
+extern "C" int gfo_compute_bow(gfo_ctx* c, const uint8_t* desc, int n, int levelsup, const gfo_bow_mode* mode,
+                               uint32_t* bow_words, double* bow_values, int* n_words, uint32_t* fv_node_ids,
+                               int32_t* fv_start, uint32_t* fv_items, int* n_fv_nodes)
+{
+    if (!c) return GFO_ERR_INVALID;
+    if (n < 0 || !mode || !n_words || !n_fv_nodes || !fv_start || (n > 0 && (!desc || !bow_words || !bow_values || !fv_node_ids || !fv_items)) ||
+        mode->weighting < 0 || mode->weighting > 3 || mode->norm < 0 || mode->norm > 2) {
+        c->err = "gfo_compute_bow: bad argument";
+        return GFO_ERR_INVALID;
+    }
+    if (!c->d_voc) {
+        c->err = "gfo_compute_bow: no vocabulary uploaded";
+        return GFO_ERR_STATE;
+    }
+    *n_words = *n_fv_nodes = 0;
+    fv_start[0] = 0;
+    if (n == 0) return GFO_OK;
+    if (n > 8192) {
+        c->err = "gfo_compute_bow: more than 8192 descriptors (use gfo_bow_transform and fold on the host)";
+        return GFO_ERR_CAPACITY;
+    }
+    BTRY(c, hipSetDevice(c->device));
+    size_t off = 0;
+    auto take = [&](size_t bytes) { size_t o = off; off = (off + bytes + 255) / 256 * 256; return o; };
+    const size_t N = (size_t)n;
+    const size_t o_d = take(32 * N), o_w = take(4 * N), o_wt = take(8 * N), o_n = take(4 * N), o_bw = take(4 * N), o_bv = take(8 * N),
+                 o_fn = take(4 * N), o_fs = take(4 * (N + 1)), o_fi = take(4 * N), o_ct = take(16);
+    if (off > c->scratch_bytes) {
+        (void)hipStreamSynchronize(c->stream);
+        if (c->d_scratch) (void)hipFree(c->d_scratch);
+        c->d_scratch = nullptr;
+        c->scratch_bytes = 0;
+        BTRY(c, hipMalloc(&c->d_scratch, off + off / 2));
+        c->scratch_bytes = off + off / 2;
+    }
+    uint8_t* S = (uint8_t*)c->d_scratch;
+    uint8_t* V = (uint8_t*)c->d_voc;
+    VocDev v{(const int*)(V + c->voc_fc_off), (const int*)(V + c->voc_nc_off), V + c->voc_desc_off,
+             (const int*)(V + c->voc_wid_off), (const float*)(V + c->voc_w_off), (const double*)(V + c->voc_w64_off), c->voc_nodes, c->voc_depth};
+    hipStream_t st = c->stream;
+    BTRY(c, hipMemcpyAsync(S + o_d, desc, 32 * N, hipMemcpyHostToDevice, st));
+    gfo_prof_begin(c, ST_BOW);
+    hipLaunchKernelGGL(k_bow_transform, dim3((n + 3) / 4), dim3(256), 0, st, v, S + o_d, n, levelsup, (int*)(S + o_w), (float*)nullptr,
+                       (int*)(S + o_n), (double*)(S + o_wt));
+    int p2 = 1;
+    while (p2 < n) p2 <<= 1;
+    BowFold f{(const int*)(S + o_w), (const double*)(S + o_wt), (const int*)(S + o_n), n, mode->weighting, mode->norm,
+              (unsigned*)(S + o_bw), (double*)(S + o_bv), (unsigned*)(S + o_fn), (int*)(S + o_fs), (unsigned*)(S + o_fi), (int*)(S + o_ct)};
+    const size_t lds = (size_t)p2 * 12;
+    if (lds > 48 * 1024)
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bow_fold), hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
+    hipLaunchKernelGGL(k_bow_fold, dim3(1), dim3(1024), lds, st, f, p2);
+    gfo_prof_end(c);
+    if (int lrc = gfo_take_launch_err(c)) return lrc;
+    BTRY(c, hipGetLastError());
+    int cnt[4] = {0, 0, 0, 0};
+    BTRY(c, hipMemcpyAsync(cnt, S + o_ct, 16, hipMemcpyDeviceToHost, st));
+    BTRY(c, hipMemcpyAsync(bow_words, S + o_bw, 4 * N, hipMemcpyDeviceToHost, st));
+    BTRY(c, hipMemcpyAsync(bow_values, S + o_bv, 8 * N, hipMemcpyDeviceToHost, st));
+    BTRY(c, hipMemcpyAsync(fv_node_ids, S + o_fn, 4 * N, hipMemcpyDeviceToHost, st));
+    BTRY(c, hipMemcpyAsync(fv_start, S + o_fs, 4 * (N + 1), hipMemcpyDeviceToHost, st));
+    BTRY(c, hipMemcpyAsync(fv_items, S + o_fi, 4 * N, hipMemcpyDeviceToHost, st));
+    BTRY(c, hipStreamSynchronize(st));
+    *n_words = cnt[0];
+    *n_fv_nodes = cnt[1];
     return GFO_OK;
 }

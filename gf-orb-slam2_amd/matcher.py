@@ -5,7 +5,7 @@ from collections import namedtuple
 
 import numpy as np
 
-from ._lib import (FeatureVectorC, FrameBoundsC, GfoError, KEYPOINT_DTYPE, PROJ_QUERY_DTYPE, ProjModeC, ProjectionBatchC, VocabularyC,
+from ._lib import (FeatureVectorC, FrameBoundsC, GfoError, KEYPOINT_DTYPE, PROJ_QUERY_DTYPE, BowModeC, ProjModeC, ProjectionBatchC, VocabularyC,
                    MAP_POINT_DTYPE, StereoParamsC, check, load_library, ptr)
 
 StereoParams = namedtuple("StereoParams", "n_rows mbf mb min_x")
@@ -192,7 +192,8 @@ class ORBVocabulary:
         self._L = load_library()
         self._ext = extractor
         arrs = [np.ascontiguousarray(tree[k]) for k in ("first_child", "n_children", "descriptors", "word_id", "weight")]
-        v = VocabularyC(*[a.ctypes.data for a in arrs], len(arrs[0]), int(tree["depth"]))
+        w64 = np.ascontiguousarray(tree["weight64"], np.float64) if "weight64" in tree else None
+        v = VocabularyC(*[a.ctypes.data for a in arrs], len(arrs[0]), int(tree["depth"]), None if w64 is None else w64.ctypes.data)
         check(self._L, self._ctx, self._L.gfo_vocabulary_upload(self._ctx, C.byref(v)))
 
     @property
@@ -209,8 +210,26 @@ class ORBVocabulary:
         check(self._L, self._ctx, self._L.gfo_bow_transform(self._ctx, ptr(desc), n, levelsup, ptr(wid), ptr(wt), ptr(nid)))
         return wid[:n], wt[:n], nid[:n]
 
+    WEIGHTING = {"TF_IDF": 0, "TF": 1, "IDF": 2, "BINARY": 3}    # DBoW2::WeightingType
+    NORM = {None: 0, "L1": 1, "L2": 2}                              # DBoW2::LNorm when the scoring normalises
+
+    def compute_bow(self, desc, levelsup=4, weighting="TF_IDF", norm="L1"):
+        """Frame::ComputeBoW in full on the device (gfo_compute_bow): returns the two maps flattened in std::map order,
+        (bow_words, bow_values[float64]) and the FeatureVector CSR (node_ids, start, items)."""
+        desc = np.ascontiguousarray(desc, np.uint8)
+        n = len(desc)
+        m = max(n, 1)
+        bw = np.zeros(m, np.uint32); bv = np.zeros(m, np.float64); fn = np.zeros(m, np.uint32); fs = np.zeros(m + 1, np.int32)
+        fi = np.zeros(m, np.uint32)
+        nw, nf = C.c_int(), C.c_int()
+        mode = BowModeC(self.WEIGHTING[weighting], self.NORM[norm])
+        check(self._L, self._ctx, self._L.gfo_compute_bow(self._ctx, ptr(desc), n, levelsup, C.byref(mode), ptr(bw), ptr(bv), C.byref(nw),
+                                                          ptr(fn), ptr(fs), ptr(fi), C.byref(nf)))
+        return (bw[:nw.value].copy(), bv[:nw.value].copy()), (fn[:nf.value].copy(), fs[:nf.value + 1].copy(), fi[:fs[nf.value]].copy())
+
     def transform(self, desc, levelsup=4):
-        """(BowVector as {word: summed weight, L1-normalised}, FeatureVector as CSR (node_ids, node_start, items)) --
+        """Host-side fold of transform_raw (float weights; kept for comparison with compute_bow).
+        (BowVector as {word: summed weight, L1-normalised}, FeatureVector as CSR (node_ids, node_start, items)) --
         TemplatedVocabulary.h:1140-1212 for TF_IDF weighting with L1 scoring."""
         wid, wt, nid = self.transform_raw(desc, levelsup)
         keep = wt > 0

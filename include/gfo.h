@@ -288,10 +288,31 @@ typedef struct {
     const float* weight;          /* [n_nodes] valid on leaves               */
     int32_t n_nodes;
     int32_t depth;                /* m_L                                     */
+    const double* weight64;       /* [n_nodes] optional: Node::weight as DBoW2 holds it (WordValue = double); NULL = weight[] */
 } gfo_vocabulary;
 int gfo_vocabulary_upload(gfo_ctx* ctx, const gfo_vocabulary* voc);
 int gfo_bow_transform(gfo_ctx* ctx, const uint8_t* desc, int n, int levelsup,
                       int32_t* word_id, float* weight, int32_t* node_id);
+
+/* Frame::ComputeBoW in full -- mpORBvocabulary->transform(vCurrentDesc, mBowVec, mFeatVec, levelsup), src/Frame.cc:661-668,
+ * Thirdparty/DBoW2/DBoW2/TemplatedVocabulary.h:1140-1212: the tree descent of every descriptor AND the fold of the
+ * (word, weight, node) triples into the two maps, on the device.  The maps come back flattened in their own
+ * (std::map, ascending key) order:
+ *   BowVector     bow_words[k] ascending, bow_values[k] = the WordValue the reference ends up with: weights of a word
+ *                 summed in feature order (TF_IDF, TF; BowVector::addWeight) or the first one kept (IDF, BINARY;
+ *                 addIfNotExist), divided by the number of words when the scoring does not normalise (:1177-1183), then
+ *                 BowVector::normalize(norm) (BowVector.cpp:62-84) -- every sum in the reference's order, in double;
+ *   FeatureVector fv_node_ids[j] ascending, fv_items[fv_start[j] .. fv_start[j+1]) = the feature indices of that node,
+ *                 ascending (FeatureVector::addFeature appends in feature order).
+ * Stopped words (weight <= 0) enter neither map.  bow_* and fv_items / fv_node_ids take n entries, fv_start n + 1.
+ * At most 8192 descriptors per call (one workgroup sorts them in LDS). */
+typedef struct {
+    int32_t weighting;   /* DBoW2::WeightingType: 0 TF_IDF, 1 TF, 2 IDF, 3 BINARY (BowVector.h:26-32)  */
+    int32_t norm;        /* 0 = the scoring does not normalise, 1 = L1, 2 = L2 (mustNormalize, ScoringObject.h:69-80) */
+} gfo_bow_mode;
+int gfo_compute_bow(gfo_ctx* ctx, const uint8_t* desc, int n, int levelsup, const gfo_bow_mode* mode,
+                    uint32_t* bow_words, double* bow_values, int* n_words,
+                    uint32_t* fv_node_ids, int32_t* fv_start, uint32_t* fv_items, int* n_fv_nodes);
 
 /* ---- measurement hooks (bench.py / rocprof cross-check) ---------------------------------- */
 /* When enabled, every kernel launch of the extract / stereo pipelines is bracketed by HIP

@@ -1284,28 +1284,103 @@ int orc_search_by_projection_kf(const orc_keypoint* kp, const uint8_t* desc, con
  * DBoW2 TemplatedVocabulary<FORB>::transform(feature, word_id, weight, nid, levelsup)
  * -- Thirdparty/DBoW2/DBoW2/TemplatedVocabulary.h:1231-1272, distance = FORB::distance (FORB.cpp:81)
  * ---------------------------------------------------------------------------------------- */
+static void bow_descend(const orc_vocabulary* voc, const uint8_t* d, int levelsup, int* word, double* weight, int* node)
+{
+    const int nid_level = voc->depth - levelsup;
+    int nid = 0; /* root when nid_level <= 0 */
+    int final_id = 0, current_level = 0;
+    do {
+        ++current_level;
+        const int fc = voc->first_child[final_id], nc = voc->n_children[final_id];
+        final_id = fc;
+        int best_d = orc_hamming256(d, voc->descriptors + (size_t)fc * 32);
+        for (int c = 1; c < nc; c++) {
+            const int dd = orc_hamming256(d, voc->descriptors + (size_t)(fc + c) * 32);
+            if (dd < best_d) { best_d = dd; final_id = fc + c; }
+        }
+        if (current_level == nid_level) nid = final_id;
+    } while (voc->n_children[final_id] > 0);
+    *word = voc->word_id[final_id];
+    *weight = voc->weight64 ? voc->weight64[final_id] : (double)voc->weight[final_id];
+    *node = nid;
+}
+
 void orc_bow_transform(const orc_vocabulary* voc, const uint8_t* desc, int n, int levelsup,
                        int32_t* word_id, float* weight, int32_t* node_id)
 {
-    const int nid_level = voc->depth - levelsup;
     for (int i = 0; i < n; i++) {
-        int nid = 0; /* root when nid_level <= 0 */
-        int final_id = 0, current_level = 0;
-        do {
-            ++current_level;
-            const int fc = voc->first_child[final_id], nc = voc->n_children[final_id];
-            final_id = fc;
-            int best_d = orc_hamming256(desc + (size_t)i * 32, voc->descriptors + (size_t)fc * 32);
-            for (int c = 1; c < nc; c++) {
-                const int d = orc_hamming256(desc + (size_t)i * 32, voc->descriptors + (size_t)(fc + c) * 32);
-                if (d < best_d) { best_d = d; final_id = fc + c; }
-            }
-            if (current_level == nid_level) nid = final_id;
-        } while (voc->n_children[final_id] > 0);
-        word_id[i] = voc->word_id[final_id];
-        weight[i] = voc->weight[final_id];
-        node_id[i] = nid;
+        int w, nd;
+        double wt;
+        bow_descend(voc, desc + (size_t)i * 32, levelsup, &w, &wt, &nd);
+        word_id[i] = w;
+        weight[i] = (float)wt;
+        node_id[i] = nd;
     }
+}
+
+int orc_compute_bow(const orc_vocabulary* voc, const uint8_t* desc, int n, int levelsup, int weighting, int norm,
+                    uint32_t* bow_words, double* bow_values, uint32_t* fv_node_ids, int32_t* fv_start, uint32_t* fv_items,
+                    int* n_fv_nodes)
+{
+    /* the two maps as sorted arrays; fv: per node a growing list (kept as (node, feature) pairs, stable) */
+    int nw = 0, npairs = 0;
+    uint32_t* pn = (uint32_t*)malloc(sizeof(uint32_t) * (n > 0 ? n : 1));
+    uint32_t* pf = (uint32_t*)malloc(sizeof(uint32_t) * (n > 0 ? n : 1));
+    const int tf = weighting == 0 || weighting == 1;
+    for (int i = 0; i < n; i++) { /* :1161-1176 / :1187-1202 */
+        int id, nid;
+        double w;
+        bow_descend(voc, desc + (size_t)i * 32, levelsup, &id, &w, &nid);
+        if (!(w > 0)) continue; /* stopped */
+        /* lower_bound in the BowVector */
+        int lo = 0, hi = nw;
+        while (lo < hi) { const int mid = (lo + hi) / 2; if (bow_words[mid] < (uint32_t)id) lo = mid + 1; else hi = mid; }
+        if (lo < nw && bow_words[lo] == (uint32_t)id) {
+            if (tf) bow_values[lo] += w; /* addWeight; addIfNotExist leaves the first value */
+        } else {
+            memmove(bow_words + lo + 1, bow_words + lo, sizeof(uint32_t) * (size_t)(nw - lo));
+            memmove(bow_values + lo + 1, bow_values + lo, sizeof(double) * (size_t)(nw - lo));
+            bow_words[lo] = (uint32_t)id;
+            bow_values[lo] = w;
+            nw++;
+        }
+        pn[npairs] = (uint32_t)nid; /* fv.addFeature(nid, i_feature) */
+        pf[npairs] = (uint32_t)i;
+        npairs++;
+    }
+    if (tf && nw > 0 && norm == 0) { /* :1177-1183 */
+        const double nd = (double)nw;
+        for (int k = 0; k < nw; k++) bow_values[k] /= nd;
+    }
+    if (norm != 0) { /* BowVector::normalize */
+        double nrm = 0.0;
+        if (norm == 1) for (int k = 0; k < nw; k++) nrm += fabs(bow_values[k]);
+        else {
+            for (int k = 0; k < nw; k++) nrm += bow_values[k] * bow_values[k];
+            nrm = sqrt(nrm);
+        }
+        if (nrm > 0.0)
+            for (int k = 0; k < nw; k++) bow_values[k] /= nrm;
+    }
+    /* FeatureVector in map order: nodes ascending, features in insertion (= ascending) order */
+    int nseg = 0, pos = 0;
+    uint8_t* used = (uint8_t*)calloc(npairs > 0 ? npairs : 1, 1);
+    for (;;) {
+        uint32_t best = 0;
+        int found = 0;
+        for (int k = 0; k < npairs; k++)
+            if (!used[k] && (!found || pn[k] < best)) { best = pn[k]; found = 1; }
+        if (!found) break;
+        fv_node_ids[nseg] = best;
+        fv_start[nseg] = pos;
+        for (int k = 0; k < npairs; k++)
+            if (!used[k] && pn[k] == best) { fv_items[pos++] = pf[k]; used[k] = 1; }
+        nseg++;
+    }
+    fv_start[nseg] = pos;
+    *n_fv_nodes = nseg;
+    free(pn); free(pf); free(used);
+    return nw;
 }
 
 /* ------------------------------------------------------------------------------------------

@@ -188,9 +188,18 @@ typedef struct {
     const int32_t* word_id;
     const float* weight;
     int32_t n_nodes, depth;
+    const double* weight64; /* optional: Node::weight as DBoW2 holds it (WordValue = double); NULL = weight[] */
 } orc_vocabulary;
 void orc_bow_transform(const orc_vocabulary* voc, const uint8_t* desc, int n, int levelsup,
                        int32_t* word_id, float* weight, int32_t* node_id);
+
+/* TemplatedVocabulary::transform(features, BowVector&, FeatureVector&, levelsup) -- TemplatedVocabulary.h:1140-1212 --
+ * with BowVector::addWeight / addIfNotExist / normalize (BowVector.cpp:34-84) and FeatureVector::addFeature, literally:
+ * the two std::maps are kept as sorted arrays.  weighting: 0 TF_IDF, 1 TF, 2 IDF, 3 BINARY; norm: 0 none, 1 L1, 2 L2.
+ * Outputs in map order; bow_* / fv_node_ids / fv_items take n entries, fv_start n + 1.  Returns the word count. */
+int orc_compute_bow(const orc_vocabulary* voc, const uint8_t* desc, int n, int levelsup, int weighting, int norm,
+                    uint32_t* bow_words, double* bow_values, uint32_t* fv_node_ids, int32_t* fv_start, uint32_t* fv_items,
+                    int* n_fv_nodes);
 
 #ifdef __cplusplus
 }

@@ -285,7 +285,7 @@ def search_by_projection(kp_un, desc, u_right, scale_factors, bounds, mps, mp_de
 
 class VocabularyC(C.Structure):
     _fields_ = [("first_child", C.c_void_p), ("n_children", C.c_void_p), ("descriptors", C.c_void_p), ("word_id", C.c_void_p),
-                ("weight", C.c_void_p), ("n_nodes", C.c_int32), ("depth", C.c_int32)]
+                ("weight", C.c_void_p), ("n_nodes", C.c_int32), ("depth", C.c_int32), ("weight64", C.c_void_p)]
 
 
 def make_vocabulary(k, depth, seed=0, p_stop=0.05, ragged=True):
@@ -317,21 +317,43 @@ def make_vocabulary(k, depth, seed=0, p_stop=0.05, ragged=True):
     w = np.zeros(n, np.float32)
     w[leaves] = rng.uniform(0.1, 5.0, len(leaves)).astype(np.float32)
     w[leaves[rng.random(len(leaves)) < p_stop]] = 0.0
+    # DBoW2 keeps Node::weight as a double (idf = log(N / Ni)): values a float cannot hold exactly
+    w64 = np.zeros(n, np.float64)
+    w64[leaves] = np.log(rng.uniform(1.1, 400.0, len(leaves)))
+    w64[w == 0.0] = 0.0
     return {"first_child": np.array(first, np.int32), "n_children": nch_a, "descriptors": np.stack(desc).astype(np.uint8),
-            "word_id": word, "weight": w, "depth": depth}
+            "word_id": word, "weight": w, "weight64": w64, "depth": depth}
 
 
 def bow_transform(voc, desc, levelsup=4):
     desc = np.ascontiguousarray(desc, np.uint8)
     n = len(desc)
     arrs = [np.ascontiguousarray(voc[k]) for k in ("first_child", "n_children", "descriptors", "word_id", "weight")]
-    v = VocabularyC(*[a.ctypes.data for a in arrs], len(arrs[0]), voc["depth"])
+    v = VocabularyC(*[a.ctypes.data for a in arrs], len(arrs[0]), voc["depth"], None)
     wid = np.zeros(max(n, 1), np.int32); wt = np.zeros(max(n, 1), np.float32); nid = np.zeros(max(n, 1), np.int32)
     L = lib()
     L.orc_bow_transform.argtypes = [C.POINTER(VocabularyC), C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
     L.orc_bow_transform.restype = None
     L.orc_bow_transform(C.byref(v), _p(desc), n, levelsup, _p(wid), _p(wt), _p(nid))
     return wid[:n], wt[:n], nid[:n]
+
+
+def compute_bow(voc, desc, levelsup=4, weighting=0, norm=1):
+    """TemplatedVocabulary::transform(features, BowVector, FeatureVector, levelsup) with the fold, literally.
+    Returns (bow_words, bow_values[float64], fv_node_ids, fv_start, fv_items)."""
+    desc = np.ascontiguousarray(desc, np.uint8)
+    n = len(desc)
+    arrs = [np.ascontiguousarray(voc[k]) for k in ("first_child", "n_children", "descriptors", "word_id", "weight")]
+    w64 = np.ascontiguousarray(voc["weight64"], np.float64) if "weight64" in voc else None
+    v = VocabularyC(*[a.ctypes.data for a in arrs], len(arrs[0]), voc["depth"], None if w64 is None else w64.ctypes.data)
+    m = max(n, 1)
+    bw = np.zeros(m, np.uint32); bv = np.zeros(m, np.float64); fn = np.zeros(m, np.uint32); fs = np.zeros(m + 1, np.int32)
+    fi = np.zeros(m, np.uint32); nf = C.c_int()
+    L = lib()
+    vp = C.c_void_p
+    L.orc_compute_bow.argtypes = [C.POINTER(VocabularyC), vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp, C.POINTER(C.c_int)]
+    nw = L.orc_compute_bow(C.byref(v), _p(desc), n, levelsup, weighting, norm, _p(bw), _p(bv), _p(fn), _p(fs), _p(fi), C.byref(nf))
+    return bw[:nw].copy(), bv[:nw].copy(), fn[:nf.value].copy(), fs[:nf.value + 1].copy(), fi[:fs[nf.value]].copy()
 
 
 class ProjMode(C.Structure):

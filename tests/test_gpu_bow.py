@@ -89,3 +89,36 @@ def test_vocabulary_transform_matches_oracle(ext, oracle, k, depth, levelsup, se
     fv_ref = oracle.make_feature_vector(np.where(wt > 0, nid, -1))
     for a, b in zip(fv, fv_ref):
         np.testing.assert_array_equal(a, b)
+
+
+@pytest.mark.parametrize("weighting,norm", [("TF_IDF", "L1"), ("TF_IDF", None), ("TF", "L2"), ("IDF", "L1"), ("BINARY", None)])
+def test_compute_bow_folds_both_maps_on_the_device(oracle, weighting, norm):
+    """Frame::ComputeBoW in full (gfo_compute_bow): descent + the fold into BowVector / FeatureVector, against the oracle's
+    literal std::map statement (addWeight / addIfNotExist / normalize in the reference's summation order, double
+    weights): word ids, node ids, index lists identical, WordValues bit for bit."""
+    import gf_orb_slam2_amd as G
+    ext = G.ORBextractor(500, 1.2, 8, 20, 7)
+    W = {"TF_IDF": 0, "TF": 1, "IDF": 2, "BINARY": 3}[weighting]
+    Nn = {None: 0, "L1": 1, "L2": 2}[norm]
+    for seed, k, depth, n in ((0, 10, 3, 2000), (1, 4, 5, 3500), (2, 6, 2, 8192), (3, 10, 4, 1), (4, 10, 4, 77)):
+        voc = oracle.make_vocabulary(k, depth, seed=seed, p_stop=0.1)
+        rng = np.random.default_rng(100 + seed)
+        leaves = voc["descriptors"][voc["n_children"] == 0]
+        desc = leaves[rng.integers(0, len(leaves), n)].copy()          # near the words: many features share a word
+        flips = rng.integers(0, 256, (n, 5))
+        for j in range(5):
+            desc[np.arange(n), flips[:, j] >> 3] ^= (1 << (flips[:, j] & 7)).astype(np.uint8)
+        V = G.ORBVocabulary(voc, ext)
+        for levelsup in (1, depth + 1):
+            (bw, bv), (fn, fs, fi) = V.compute_bow(desc, levelsup, weighting, norm)
+            rw, rv, rn, rs, ri = oracle.compute_bow(voc, desc, levelsup, W, Nn)
+            np.testing.assert_array_equal(bw, rw)
+            assert bv.tobytes() == rv.tobytes()
+            np.testing.assert_array_equal(fn, rn)
+            np.testing.assert_array_equal(fs, rs)
+            np.testing.assert_array_equal(fi, ri)
+            assert len(bw) > 0 and (np.diff(bw.astype(np.int64)) > 0).all() and (np.diff(fn.astype(np.int64)) > 0).all()
+    with pytest.raises(G.GfoError) as e:
+        V.compute_bow(np.zeros((8193, 32), np.uint8))
+    assert e.value.code == -3
+    ext.close()
