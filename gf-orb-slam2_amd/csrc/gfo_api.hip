@@ -677,8 +677,15 @@ static int extract_launches(gfo_ctx* c, const GfoInput& in, int nimg, const gfo_
     return GFO_OK;
 }
 
-// Small batches of host images (the per-frame path of the drop-in adapter) replay the fixed launch sequence as a
-// captured hipGraph: one submission instead of 8-11, no host-side launch gaps between 10-50 us kernels.
+// Small batches of host images (the per-frame path of the drop-in adapter) CAN replay the fixed launch sequence as a
+// captured hipGraph (GFO_GRAPH=1): one submission instead of 8-11.  Off by default, for two measured reasons
+// (MI355X, ROCm 7.2): (1) it buys nothing -- 0.2714 vs 0.2736 ms per stereo frame (profiles/latency_pair_r02*.json):
+// the launches are already asynchronous and the kernels are 10-50 us each, so the host stays ahead of the GPU either
+// way; (2) while ANY stream of the process is capturing -- in every capture mode, relaxed included -- a synchronous
+// HIP call of ANOTHER host thread (hipMemcpy / hipMalloc, e.g. the other extractor thread of Frame.cc:84-87 planning
+// its arena) fails with "operation failed due to a previous error during capture"
+// (tests/test_gpu_extract.py::test_capture_in_one_thread_planning_in_another reproduces it when the graph is on).
+// A library that other host threads share a process with cannot impose that.
 static bool graph_key_eq(const gfo_ctx::GraphKey& a, const gfo_ctx::GraphKey& b)
 {
     return a.base == b.base && a.pack_dst == b.pack_dst && a.pitch == b.pitch && a.img_stride == b.img_stride && a.nimg == b.nimg && a.stereo == b.stereo &&
@@ -701,7 +708,7 @@ static int run_extract(gfo_ctx* c, const GfoInput& in, int nimg, const gfo_stere
         }
         if (!c->graph_exec) {
             hipGraph_t graph = nullptr;
-            if (hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal) == hipSuccess) {
+            if (hipStreamBeginCapture(c->stream, hipStreamCaptureModeRelaxed) == hipSuccess) {
                 const int lrc = extract_launches(c, in, nimg, sp, pack);
                 const hipError_t e = hipStreamEndCapture(c->stream, &graph);
                 if (lrc == GFO_OK && e == hipSuccess && graph && c->launch_err.empty() &&

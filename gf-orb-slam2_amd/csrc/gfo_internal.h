@@ -214,7 +214,7 @@ struct gfo_ctx {
     // hipGraph of the fixed launch sequence
     uint8_t* h_in = nullptr;  size_t h_in_bytes = 0;     // hipHostMalloc
     uint8_t* h_out = nullptr; size_t h_out_bytes = 0;
-    bool graph_ok = true;
+    bool graph_ok = false;   // GFO_GRAPH=1 opts in (see run_extract)
     hipGraphExec_t graph_exec = nullptr;
     struct GraphKey { const void* base; const void* pack_dst; long long pitch, img_stride; int nimg, stereo; gfo_stereo_params sp; int plan_gen; } graph_key{};
     int plan_gen = 0;

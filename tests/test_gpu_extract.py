@@ -92,3 +92,54 @@ def test_two_contexts_from_two_threads(oracle, euroc_l, euroc_r):
     for e in exts:
         e.close()
     assert not errors, errors
+
+
+def test_two_threads_replanning_against_each_other(oracle):
+    """The reference runs its left and right extractor on two host threads (Frame.cc:84-87): one thread may be planning
+    an arena (hipMalloc / hipMemcpy) while the other is mid-pipeline.  Both alternate between two image sizes here, so
+    that every call re-plans: results stay bit-exact and nothing fails.  (This is the test that showed hipGraph capture
+    cannot be on by default: with GFO_GRAPH=1 the planning thread's hipMemcpy fails while the other thread captures.)"""
+    import threading
+    import gf_orb_slam2_amd as G
+    imgs = [synth_frame(400, 300, 5), synth_frame(336, 256, 6)]
+    oe = oracle.OracleExtractor(600, 1.2, 8, 20, 7)
+    refs = [oe(im) for im in imgs]
+    exts = [G.ORBextractor(600, 1.2, 8, 20, 7) for _ in range(2)]
+    errors = []
+
+    def work(t):
+        try:
+            for it in range(40):
+                k = (it + t) & 1
+                kp, d = exts[t](imgs[k])
+                if kp.tobytes() != refs[k][0].tobytes() or not (d == refs[k][1]).all():
+                    errors.append(f"thread {t} iteration {it}: result differs")
+                    return
+        except Exception as ex:  # noqa: BLE001
+            errors.append(f"thread {t}: {ex!r}")
+
+    th = [threading.Thread(target=work, args=(t,)) for t in range(2)]
+    for x in th:
+        x.start()
+    for x in th:
+        x.join()
+    for e in exts:
+        e.close()
+    assert not errors, errors
+
+
+def test_graph_replay_opt_in(oracle, euroc_l):
+    """GFO_GRAPH=1: the per-frame launch sequence is captured once per geometry and replayed (single HIP thread only,
+    see gfo_api.hip); same bits as the plain launches"""
+    import os
+    import gf_orb_slam2_amd as G
+    os.environ["GFO_GRAPH"] = "1"
+    try:
+        ext = G.ORBextractor(2000, 1.2, 8, 20, 7)
+    finally:
+        del os.environ["GFO_GRAPH"]
+    ok, od = oracle.OracleExtractor(2000, 1.2, 8, 20, 7)(euroc_l)
+    for _ in range(3):
+        kp, d = ext(euroc_l)
+        assert kp.tobytes() == ok.tobytes() and (d == od).all()
+    ext.close()

@@ -105,3 +105,50 @@ def test_full_batch_stereo_properties(batch, oracle):
     assert g[0] == o[0]
     for a, b in zip(g[1:], o[1:]):
         assert a.tobytes() == b.tobytes()
+
+
+def test_count_all_gather_over_rccl_single_rank():
+    """bench.py's only collective, on the real backend: torch.distributed 'nccl' (= RCCL) all-gathering the per-image
+    keypoint counts straight out of the arena (the int32 vector is aliased through __cuda_array_interface__, no
+    copy).  One rank is all a 1-GPU box offers; it still exercises init_process_group('nccl'), the aliased device
+    pointer as an RCCL send buffer and the stream ordering against the extraction (the N > 1 logic is covered by the
+    2-rank gloo test in tests/test_host_logic.py)."""
+    import ctypes
+    import os
+    import torch
+    import torch.distributed as dist
+    import gf_orb_slam2_amd as G
+    from gf_orb_slam2_amd.sharding import gather_counts
+    from gf_orb_slam2_amd.synth import synth_frame
+    import bench
+
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29531")
+    created = not dist.is_initialized()
+    if created:
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        B = 8
+        imgs = np.stack([synth_frame(320, 240, i) for i in range(B)])
+        d = torch.from_numpy(imgs).cuda()
+        st = torch.cuda.Stream()
+        ext = G.ORBextractor(300, 1.2, 8, 20, 7, max_batch=B)
+        ext.set_stream(st.cuda_stream)
+        ext.extract_batch_device(d.data_ptr(), B, 320, 240)
+        L = G.load_library()
+        p_cnt, stride = ctypes.c_void_p(), ctypes.c_int()
+        L.gfo_batch_device_views(ext.handle, None, None, ctypes.byref(p_cnt), ctypes.byref(stride))
+        counts = torch.as_tensor(bench._DevArray(p_cnt.value, B), device="cuda")
+        out = torch.full((B,), -1, dtype=torch.int32, device="cuda")
+        with torch.cuda.stream(st):
+            # gather_counts short-cuts world == 1; call the collective itself
+            dist.all_gather_into_tensor(out, counts)
+        torch.cuda.synchronize()
+        ref = ext.batch_counts(B)
+        assert (out.cpu().numpy() == ref).all() and (ref > 100).all()
+        assert gather_counts(counts, 1, dist) is counts
+        ext.set_stream(0)
+        ext.close()
+    finally:
+        if created:
+            dist.destroy_process_group()
