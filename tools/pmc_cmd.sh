@@ -1,0 +1,23 @@
+#!/bin/bash
+# SQ counters of an arbitrary python command: tools/pmc_cmd.sh <tag> <script.py> [args]  -> gpurun_out/pmc_<tag>/summary.txt
+cd /tmp && export TMPDIR=/tmp
+TAG=$1; shift
+R=$GRAFT_REPO_ROOT; OUT=$R/gpurun_out/pmc_$TAG; rm -rf $OUT; mkdir -p $OUT; cd $R
+rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_VMEM_RD --output-format csv -d $OUT/a -- python3 "$@" > $OUT/a.log 2>&1
+rocprofv3 --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --output-format csv -d $OUT/b -- python3 "$@" > $OUT/b.log 2>&1
+python3 - "$OUT" <<'PY'
+import csv, glob, os, sys, collections
+root=sys.argv[1]
+for sub in ('a','b'):
+    f=glob.glob(os.path.join(root,sub,'**','*counter_collection.csv'),recursive=True)
+    if not f: print('no csv',sub); continue
+    acc=collections.defaultdict(lambda: collections.defaultdict(list))
+    for row in csv.DictReader(open(f[0])):
+        k=row['Kernel_Name'].split('(')[0].replace('void ','')
+        acc[k][row['Counter_Name']].append(float(row['Counter_Value']))
+    for k,v in acc.items():
+        if not k.startswith('k_'): continue
+        line = k + ' ' + ' '.join(f"{c}={sum(x)/len(x):.4g}" for c,x in sorted(v.items()))
+        print(line)
+        open(os.path.join(root, 'summary.txt'), 'a').write(line + '\n')
+PY
