@@ -233,6 +233,11 @@ class Job:
     def profile(self, nsteps):
         """per-kernel device time from HIP events on the launch stream, context 0 alone (clean per-kernel durations)"""
         ext = self.exts[0]
+        # the chip lowers its clocks while idle and takes ~15 launches to come back (k_fast: 186 us right after a
+        # synchronisation, 167 us in a running stream -- rocprofv3 shows the same ramp): warm up first and switch the
+        # per-kernel events on without a synchronisation in between
+        for _ in range(30):
+            self.step(ctx=0)
         ext.profile_enable(True)
         for _ in range(max(1, nsteps)):
             self.step(ctx=0)
@@ -263,12 +268,29 @@ class Job:
                     traffic_source = f"profiles/traffic_{tj.get('tag')}.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of an earlier run of this command; not measured in this run)"
             except Exception:
                 traffic = None
+        tj_all = {}
+        try:
+            if os.path.exists(tpath):
+                tj0 = json.load(open(tpath))
+                if tj0.get("workload") == traffic_workload and tj0.get("batch") == self.B:
+                    tj_all = tj0.get("hbm_bytes_per_launch", {})
+        except Exception:
+            tj_all = {}
+        per_stage = {}
+        for k, ms in stage_ms.items():
+            lps = prof[k][1] / max(1, nsteps)
+            bpl = per_img[k] * self.B / max(lps, 1e-9)
+            al = prof[k][0] / prof[k][1]
+            per_stage[k] = {"avg_launch_ms": round(al, 4), "launches_per_step": round(lps, 2), "algorithmic_bytes_per_launch": int(bpl),
+                            "achieved_GBps": round(bpl / (al * 1e-3) / 1e9, 1), "frac": round(bpl / (al * 1e-3) / 8e12, 5),
+                            "traffic_per_step": tj_all.get(k)}
         return n_kp_img, {
             "bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": 8000.0, "unit": "GB/s",
             "frac": round(achieved / 8000.0, 5), "traffic": traffic, "traffic_source": traffic_source,
             "avg_launch_ms": round(avg_launch_ms, 4), "algorithmic_bytes_per_launch": int(bytes_per_launch),
             "pipeline_frac_hbm": round(value_per_gpu * survey_total / 8e12, 5),
-            "stage_ms_per_step": {k: round(v, 4) for k, v in stage_ms.items()}}
+            "stage_ms_per_step": {k: round(v, 4) for k, v in stage_ms.items()},
+            "all_kernels": per_stage}
 
     def close(self):
         for e in self.exts:
@@ -286,7 +308,7 @@ def main():
     ap.add_argument("--workload", default="stereo752", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-other-configs", action="store_true", help="skip the short passes over the other BASELINE configs")
-    ap.add_argument("--profile-steps", type=int, default=3)
+    ap.add_argument("--profile-steps", type=int, default=10)
     ap.add_argument("--streams", type=int, default=3,
                     help="independent contexts (arena + HIP stream) the steps alternate between, so the tail of one "
                          "batch overlaps the head of the next")
@@ -378,8 +400,8 @@ def main():
                 steps_o = 20
                 dto = j.timed(steps_o, 3)
                 vo = ob * steps_o / dto
-                p = j.profile(2)
-                _, roof_o = j.roofline(p, 2, vo, name)
+                p = j.profile(5)
+                _, roof_o = j.roofline(p, 5, vo, name)
                 others.append({"workload": j.cfg_name, "name": name, "value": round(vo, 1), "unit": "frames/s", "images_per_step": ob,
                                "steps": steps_o, "ms_per_step": round(dto / steps_o * 1e3, 4), "roofline": roof_o})
                 j.close()

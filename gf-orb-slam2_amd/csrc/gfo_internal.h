@@ -3,6 +3,7 @@
 #pragma once
 
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 #include <string>
 #include <vector>
@@ -242,6 +243,19 @@ void gfo_launch_stereo_sad(gfo_ctx* c, const GfoStereoLaunch& s, const GfoInput&
 // profiling helpers (gfo_api.hip)
 void gfo_prof_begin(gfo_ctx* c, int stage);
 void gfo_prof_end(gfo_ctx* c);
+void gfo_prof_kernel_events(gfo_ctx* c, hipEvent_t* a, hipEvent_t* b);
+
+// Every kernel launch of the library.  With profiling on (gfo_profile_enable) the launch carries a start / stop event
+// pair (hipExtLaunchKernelGGL): they take the kernel's own begin / end timestamps, i.e. the duration rocprofv3's kernel
+// trace reports -- events recorded around a plain launch also count the dispatch latency behind the previous
+// kernel (measured +20 us on a 166 us kernel).
+#define GFO_LAUNCH(c, kern, grid, block, lds, stream, ...)                                                               \
+    do {                                                                                                                 \
+        hipEvent_t ea_ = nullptr, eb_ = nullptr;                                                                         \
+        if ((c)->profiling) gfo_prof_kernel_events((c), &ea_, &eb_);                                                     \
+        if (ea_) hipExtLaunchKernelGGL(kern, grid, block, (std::uint32_t)(lds), stream, ea_, eb_, 0, __VA_ARGS__);       \
+        else hipLaunchKernelGGL(kern, grid, block, lds, stream, __VA_ARGS__);                                            \
+    } while (0)
 
 // device-side address helpers shared by kernels
 __device__ __forceinline__ const uint8_t* gfo_level_ptr(const GfoGeom& g, const GfoInput& in, const uint8_t* pyr,

@@ -215,7 +215,7 @@ void gfo_launch_blur(gfo_ctx* c, const GfoInput& in, int nimg)
 {
     gfo_prof_begin(c, ST_BLUR);
     if (c->g.total_tiles + c->g.blur_total_b > 0)
-        hipLaunchKernelGGL(k_blur, dim3(c->g.total_tiles + c->g.blur_total_b, nimg), dim3(256), 0, c->stream, c->d_geom, in,
+        GFO_LAUNCH(c, k_blur, dim3(c->g.total_tiles + c->g.blur_total_b, nimg), dim3(256), 0, c->stream, c->d_geom, in,
                            c->d_pyr, c->d_blur);
     gfo_prof_end(c);
 }

@@ -215,8 +215,8 @@ extern "C" int gfo_search_by_bow(gfo_ctx* c, const uint8_t* kf_desc, const float
     a.n_f = n_f; a.nn_ratio = nn_ratio; a.check_ori = check_orientation ? 1 : 0;
     a.out = (int*)(S + o_out); a.rot_bin = (int*)(S + o_rb); a.counters = (int*)(S + o_cnt);
     gfo_prof_begin(c, ST_BOW);
-    hipLaunchKernelGGL(k_bow_match, dim3((a.npairs + 3) / 4), dim3(256), 0, st, a);
-    if (a.check_ori) hipLaunchKernelGGL(k_bow_rotation, dim3(1), dim3(256), 0, st, a);
+    GFO_LAUNCH(c, k_bow_match, dim3((a.npairs + 3) / 4), dim3(256), 0, st, a);
+    if (a.check_ori) GFO_LAUNCH(c, k_bow_rotation, dim3(1), dim3(256), 0, st, a);
     gfo_prof_end(c);
     if (int lrc = gfo_take_launch_err(c)) return lrc;
     BTRY(c, hipGetLastError());
@@ -496,7 +496,7 @@ extern "C" int gfo_bow_transform(gfo_ctx* c, const uint8_t* desc, int n, int lev
     hipStream_t st = c->stream;
     BTRY(c, hipMemcpyAsync(S + o_d, desc, 32 * (size_t)n, hipMemcpyHostToDevice, st));
     gfo_prof_begin(c, ST_BOW);
-    hipLaunchKernelGGL(k_bow_transform, dim3((n + 3) / 4), dim3(256), 0, st, v, S + o_d, n, levelsup, (int*)(S + o_w),
+    GFO_LAUNCH(c, k_bow_transform, dim3((n + 3) / 4), dim3(256), 0, st, v, S + o_d, n, levelsup, (int*)(S + o_w),
                        (float*)(S + o_wt), (int*)(S + o_n), (double*)nullptr);
     gfo_prof_end(c);
     if (int lrc = gfo_take_launch_err(c)) return lrc;
@@ -551,7 +551,7 @@ extern "C" int gfo_compute_bow(gfo_ctx* c, const uint8_t* desc, int n, int level
     hipStream_t st = c->stream;
     BTRY(c, hipMemcpyAsync(S + o_d, desc, 32 * N, hipMemcpyHostToDevice, st));
     gfo_prof_begin(c, ST_BOW);
-    hipLaunchKernelGGL(k_bow_transform, dim3((n + 3) / 4), dim3(256), 0, st, v, S + o_d, n, levelsup, (int*)(S + o_w), (float*)nullptr,
+    GFO_LAUNCH(c, k_bow_transform, dim3((n + 3) / 4), dim3(256), 0, st, v, S + o_d, n, levelsup, (int*)(S + o_w), (float*)nullptr,
                        (int*)(S + o_n), (double*)(S + o_wt));
     int p2 = 1;
     while (p2 < n) p2 <<= 1;
@@ -560,7 +560,7 @@ extern "C" int gfo_compute_bow(gfo_ctx* c, const uint8_t* desc, int n, int level
     const size_t lds = (size_t)p2 * 12;
     if (lds > 48 * 1024)
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bow_fold), hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
-    hipLaunchKernelGGL(k_bow_fold, dim3(1), dim3(1024), lds, st, f, p2);
+    GFO_LAUNCH(c, k_bow_fold, dim3(1), dim3(1024), lds, st, f, p2);
     gfo_prof_end(c);
     if (int lrc = gfo_take_launch_err(c)) return lrc;
     BTRY(c, hipGetLastError());

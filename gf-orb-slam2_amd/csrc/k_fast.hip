@@ -390,10 +390,10 @@ void gfo_launch_fast(gfo_ctx* c, const GfoInput& in, int nimg)
 #define GFO_FAST_LAUNCH(TP_, SP_)                                                                                       \
     do {                                                                                                                \
         if (xcd8)                                                                                                       \
-            hipLaunchKernelGGL((k_fast<TP_, SP_, true>), grid, dim3(64 * nw), lds, c->stream, c->d_geom, in, c->d_pyr, c->d_cand, \
+            GFO_LAUNCH(c, (k_fast<TP_, SP_, true>), grid, dim3(64 * nw), lds, c->stream, c->d_geom, in, c->d_pyr, c->d_cand, \
                                c->d_cand_cnt, c->d_flags, c->d_cell_tab, nimg GFO_FAST_DBG_ARG);                        \
         else                                                                                                            \
-            hipLaunchKernelGGL((k_fast<TP_, SP_, false>), grid, dim3(64 * nw), lds, c->stream, c->d_geom, in, c->d_pyr, c->d_cand, \
+            GFO_LAUNCH(c, (k_fast<TP_, SP_, false>), grid, dim3(64 * nw), lds, c->stream, c->d_geom, in, c->d_pyr, c->d_cand, \
                                c->d_cand_cnt, c->d_flags, c->d_cell_tab, nimg GFO_FAST_DBG_ARG);                        \
     } while (0)
     if (g.fast_tile_pitch == 48) GFO_FAST_LAUNCH(48, 44);

@@ -201,7 +201,7 @@ void gfo_launch_orient_desc(gfo_ctx* c, const GfoInput& in, int nimg)
     const int bpi = (c->g.kp_stride + 2 * OD_WAVES - 1) / (2 * OD_WAVES);  // OD_WAVES waves x 2 keypoints per workgroup
     dim3 grid((unsigned)bpi * 8u, (unsigned)(nimg + 7) / 8u);
     gfo_prof_begin(c, ST_ORIENT_DESC);
-    hipLaunchKernelGGL(k_orient_desc, grid, dim3(64 * OD_WAVES), 0, c->stream, c->d_geom, in, c->d_pyr, c->d_blur, c->d_sel,
+    GFO_LAUNCH(c, k_orient_desc, grid, dim3(64 * OD_WAVES), 0, c->stream, c->d_geom, in, c->d_pyr, c->d_blur, c->d_sel,
                        c->d_sel_cnt, c->d_kp, c->d_desc, c->d_kp_cnt, c->d_flags, nimg, bpi);
     gfo_prof_end(c);
 }

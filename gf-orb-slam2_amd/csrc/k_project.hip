@@ -580,7 +580,7 @@ static int pj_launch(gfo_ctx* c, const ProjB& a, int frames, int n_max)
 {
     hipStream_t st = c->stream;
     gfo_prof_begin(c, ST_PROJECT);
-    hipLaunchKernelGGL(k_proj_grid, dim3(frames), dim3(1024), 0, st, a);
+    GFO_LAUNCH(c, k_proj_grid, dim3(frames), dim3(1024), 0, st, a);
     // round 0 against an LDS copy of the grid when it fits twice per CU: workgroups of 1024 threads, as many per
     // frame as it takes to put ~2 on every CU (each pays the 78 KB copy once, then walks its chunk of the points)
     const size_t grid_bytes = (size_t)a.n_cap * 16 + (NCELL + 1) * 4;
@@ -593,17 +593,17 @@ static int pj_launch(gfo_ctx* c, const ProjB& a, int frames, int n_max)
         const int chunk = ((a.m + per_frame - 1) / per_frame + 63) / 64 * 64;
         if (grid_bytes > 48 * 1024)
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_proj_round0<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
-        hipLaunchKernelGGL(k_proj_round0<true>, dim3((a.m + chunk - 1) / chunk, frames), dim3(1024), grid_bytes, st, a, chunk);
+        GFO_LAUNCH(c, k_proj_round0<true>, dim3((a.m + chunk - 1) / chunk, frames), dim3(1024), grid_bytes, st, a, chunk);
     } else {
-        hipLaunchKernelGGL(k_proj_round0<false>, dim3((a.m + 255) / 256, frames), dim3(256), 0, st, a, 256);
+        GFO_LAUNCH(c, k_proj_round0<false>, dim3((a.m + 255) / 256, frames), dim3(256), 0, st, a, 256);
     }
     const size_t tab_bytes = (size_t)n_max * 8;   // claim / owner table + score table
     if (tab_bytes <= 96 * 1024) {
         if (tab_bytes > 48 * 1024)   // beyond the default dynamic-LDS grant: raised per call (per device), rare
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_proj_resolve<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-        hipLaunchKernelGGL(k_proj_resolve<false>, dim3(frames), dim3(1024), tab_bytes, st, a);
+        GFO_LAUNCH(c, k_proj_resolve<false>, dim3(frames), dim3(1024), tab_bytes, st, a);
     } else {
-        hipLaunchKernelGGL(k_proj_resolve<true>, dim3(frames), dim3(1024), 0, st, a);
+        GFO_LAUNCH(c, k_proj_resolve<true>, dim3(frames), dim3(1024), 0, st, a);
     }
     gfo_prof_end(c);
     if (int lrc = gfo_take_launch_err(c)) return lrc;

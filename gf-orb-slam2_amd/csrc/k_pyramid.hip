@@ -283,7 +283,7 @@ void gfo_launch_resize(gfo_ctx* c, const GfoInput& in, int level, int nimg)
     const int waves = ((quads + 63) / 64) * strips;
     dim3 grid((waves + 3) / 4, nimg);
     gfo_prof_begin(c, ST_RESIZE);
-    hipLaunchKernelGGL(k_resize, grid, dim3(256), 0, c->stream, c->d_geom, in, c->d_pyr, level,
+    GFO_LAUNCH(c, k_resize, grid, dim3(256), 0, c->stream, c->d_geom, in, c->d_pyr, level,
                        reinterpret_cast<const int2*>(c->d_xofs), reinterpret_cast<const int2*>(c->d_yofs));
     gfo_prof_end(c);
 }
@@ -291,7 +291,7 @@ void gfo_launch_resize(gfo_ctx* c, const GfoInput& in, int level, int nimg)
 void gfo_launch_resize_tail(gfo_ctx* c, const GfoInput& in, int level_begin, int nimg)
 {
     gfo_prof_begin(c, ST_RESIZE);
-    hipLaunchKernelGGL(k_resize_tail, dim3(nimg), dim3(1024), 0, c->stream, c->d_geom, in, c->d_pyr, level_begin,
+    GFO_LAUNCH(c, k_resize_tail, dim3(nimg), dim3(1024), 0, c->stream, c->d_geom, in, c->d_pyr, level_begin,
                        reinterpret_cast<const int2*>(c->d_xofs), reinterpret_cast<const int2*>(c->d_yofs));
     gfo_prof_end(c);
 }
@@ -308,7 +308,7 @@ void gfo_launch_pyramid_bands(gfo_ctx* c, const GfoInput& in, int nimg)
         // 256 threads when the launch has workgroups to spare (more of them resident per CU), 512 for a handful of
         // images, where the time of ONE workgroup is what counts
         const int threads = c->band_threads > 0 ? c->band_threads : (bg.nb * nimg >= 2048 ? 256 : 512);
-        hipLaunchKernelGGL(k_pyramid_bands, dim3(bg.nb, nimg), dim3(threads), bg.lds_bytes, c->stream, c->d_geom, in,
+        GFO_LAUNCH(c, k_pyramid_bands, dim3(bg.nb, nimg), dim3(threads), bg.lds_bytes, c->stream, c->d_geom, in,
                            c->d_pyr, reinterpret_cast<const int2*>(c->d_xofs), reinterpret_cast<const int2*>(c->d_yofs),
                            reinterpret_cast<const int4*>(c->d_band) + bg.tab_off, bg.lb, bg.le);
         gfo_prof_end(c);

@@ -171,10 +171,10 @@ void gfo_launch_quadtree(gfo_ctx* c, int nimg)
     if (timing && hipMalloc(&d_ts, 128 * sizeof(unsigned long long)) == hipSuccess) (void)hipMemsetAsync(d_ts, 0, 128 * sizeof(unsigned long long), c->stream);
     gfo_prof_begin(c, ST_QUADTREE);
     if (gmem)
-        hipLaunchKernelGGL(k_quadtree_gmem, grid, dim3(1024), 0, c->stream, c->d_geom, c->d_cand, c->d_cand_cnt, c->d_node_of,
+        GFO_LAUNCH(c, k_quadtree_gmem, grid, dim3(1024), 0, c->stream, c->d_geom, c->d_cand, c->d_cand_cnt, c->d_node_of,
                            c->d_sel, c->d_sel_cnt, c->d_flags, ncap, 0, d_ts, c->d_qt_scratch, (unsigned long long)c->qt_scratch_stride);
     else
-        hipLaunchKernelGGL(k_quadtree, grid, dim3(nthreads), lds, c->stream, c->d_geom, c->d_cand, c->d_cand_cnt, c->d_node_of,
+        GFO_LAUNCH(c, k_quadtree, grid, dim3(nthreads), lds, c->stream, c->d_geom, c->d_cand, c->d_cand_cnt, c->d_node_of,
                            c->d_sel, c->d_sel_cnt, c->d_flags, ncap, klds, d_ts, (uint8_t*)nullptr, 0ull);
     if (d_ts) {   // debugging aid: blocks until the kernel is done and prints the phase times of block (0, 0)
         unsigned long long ts[128];

@@ -468,13 +468,13 @@ void gfo_launch_stereo_sad(gfo_ctx* c, const GfoStereoLaunch& s, const GfoInput&
     A.pyr = c->d_pyr;
     A.inv_scale = d_inv_scale;
     gfo_prof_begin(c, ST_STEREO_BUCKET);
-    hipLaunchKernelGGL(k_stereo_bucket, dim3(s.npairs), dim3(1024), (size_t)(s.p.n_rows + 256) * sizeof(int), c->stream, a);
+    GFO_LAUNCH(c, k_stereo_bucket, dim3(s.npairs), dim3(1024), (size_t)(s.p.n_rows + 256) * sizeof(int), c->stream, a);
     gfo_prof_end(c);
     gfo_prof_begin(c, ST_STEREO);
-    hipLaunchKernelGGL(k_stereo_match_sad, dim3((s.out_stride + 3) / 4, s.npairs), dim3(256), 0, c->stream, A);
+    GFO_LAUNCH(c, k_stereo_match_sad, dim3((s.out_stride + 3) / 4, s.npairs), dim3(256), 0, c->stream, A);
     gfo_prof_end(c);
     gfo_prof_begin(c, ST_STEREO_CUT);
-    hipLaunchKernelGGL(k_stereo_cut_sad, dim3(s.npairs), dim3(256), 0, c->stream, s.cnt_dev, s.out, s.out_stride);
+    GFO_LAUNCH(c, k_stereo_cut_sad, dim3(s.npairs), dim3(256), 0, c->stream, s.cnt_dev, s.out, s.out_stride);
     gfo_prof_end(c);
 }
 
@@ -505,14 +505,14 @@ void gfo_launch_stereo(gfo_ctx* c, const GfoStereoLaunch& s)
         return;
     }
     gfo_prof_begin(c, ST_STEREO_BUCKET);
-    hipLaunchKernelGGL(k_stereo_bucket, dim3(s.npairs), dim3(1024), (size_t)(s.p.n_rows + 256) * sizeof(int), c->stream, a);
+    GFO_LAUNCH(c, k_stereo_bucket, dim3(s.npairs), dim3(1024), (size_t)(s.p.n_rows + 256) * sizeof(int), c->stream, a);
     gfo_prof_end(c);
     static const int snw = getenv("GFO_STEREO_WAVES") ? atoi(getenv("GFO_STEREO_WAVES")) : 4;   // waves per workgroup, 2 left keypoints each
     dim3 grid((max_nl + 2 * snw - 1) / (2 * snw), s.npairs);
     gfo_prof_begin(c, ST_STEREO);
-    hipLaunchKernelGGL(k_stereo_match, grid, dim3(64 * snw), 0, c->stream, a);
+    GFO_LAUNCH(c, k_stereo_match, grid, dim3(64 * snw), 0, c->stream, a);
     gfo_prof_end(c);
     gfo_prof_begin(c, ST_STEREO_CUT);
-    hipLaunchKernelGGL(k_stereo_cut, dim3(s.npairs), dim3(1024), 0, c->stream, s.cnt_dev, s.nl_host, s.out, s.out_stride);
+    GFO_LAUNCH(c, k_stereo_cut, dim3(s.npairs), dim3(1024), 0, c->stream, s.cnt_dev, s.nl_host, s.out, s.out_stride);
     gfo_prof_end(c);
 }
