@@ -179,3 +179,41 @@ def test_query_form_reproduces_map_point_overload(oracle):
     got = oracle.search_by_projection_queries(kl, dl, u, None, (0.0, 0.0, 752.0, 480.0), q, g["mp_desc"], True, 0.8, 100, False, g["taken"])
     assert got[0] == int(g["nmatches"])
     np.testing.assert_array_equal(got[1], g["out_mp"])
+
+
+def test_more_keypoints_than_fit_the_lds_tables(ext, oracle):
+    """20 000 keypoints: the claim / owner tables of the resolve kernel (8 B per keypoint) and the grid copy of round 0
+    no longer fit LDS, so both run their HBM variants (tables read past the L1, grid gathered in place) -- same result as
+    the serial oracle, ratio test, taken keypoints, mvuRight gate and the rotation check included"""
+    import gf_orb_slam2_amd as G
+    rng = np.random.default_rng(9)
+    n, m = 20000, 30000
+    kp = np.zeros(n, oracle.KEYPOINT_DTYPE)
+    kp["x"] = rng.uniform(20, 1900, n).astype(np.float32); kp["y"] = rng.uniform(20, 1060, n).astype(np.float32)
+    kp["octave"] = rng.integers(0, 8, n); kp["angle"] = rng.uniform(0, 360, n).astype(np.float32)
+    desc = rng.integers(0, 256, (n, 32), dtype=np.uint8)
+    u = np.where(rng.random(n) < 0.5, kp["x"] - rng.uniform(1, 40, n), -1).astype(np.float32)
+    sf = ext.GetScaleFactors()
+    src = rng.integers(0, n, m)
+    q = np.zeros(m, oracle.PROJ_QUERY_DTYPE)
+    q["u"] = kp["x"][src] + rng.normal(0, 3, m); q["v"] = kp["y"][src] + rng.normal(0, 3, m)
+    q["ur"] = q["u"] - rng.uniform(0, 40, m).astype(np.float32)
+    q["radius"] = (np.float32(7.0) * sf[kp["octave"][src]]).astype(np.float32)
+    q["min_level"] = kp["octave"][src] - 1; q["max_level"] = kp["octave"][src] + 1
+    q["angle"] = ((kp["angle"][src] + rng.normal(0, 20, m)) % 360).astype(np.float32)
+    fl = np.full(m, 5, np.int32); fl[rng.random(m) < 0.2] = 0; fl[rng.random(m) < 0.3] &= ~4
+    q["flags"] = fl
+    qd = desc[src].copy()
+    for _ in range(10):
+        sel = rng.random(m) < 0.5
+        bits = rng.integers(0, 256, m)
+        qd[sel, bits[sel] >> 3] ^= (1 << (bits[sel] & 7)).astype(np.uint8)
+    taken = (rng.random(n) < 0.1).astype(np.uint8)
+    b = (0.0, 0.0, 1920.0, 1080.0)
+    for use_ratio, ori in ((True, False), (False, True)):
+        ref = oracle.search_by_projection_queries(kp, desc, u, kp["angle"], b, q, qd, use_ratio, 0.8, 100, ori, taken)
+        got = G.ORBmatcher(0.8, ori, extractor=ext).SearchByProjectionQueries(kp, desc, u, kp["angle"], b, q, qd, use_ratio=use_ratio,
+                                                                              kp_taken=taken)
+        assert got[0] == ref[0] and ref[0] > 5000
+        np.testing.assert_array_equal(got[1], ref[1])
+        np.testing.assert_array_equal(got[2][got[1] >= 0], ref[2][ref[1] >= 0])
