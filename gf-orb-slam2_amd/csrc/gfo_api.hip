@@ -1113,7 +1113,8 @@ extern "C" int gfo_stereo_match(gfo_ctx* c, const gfo_keypoint* kl, const uint8_
         if (kr[i].octave < 0 || kr[i].octave >= nlevels) return fail(c, GFO_ERR_INVALID, "right keypoint %d: octave %d outside 0..%d", i, kr[i].octave, nlevels - 1);
     HIP_TRY(c, hipSetDevice(c->device));
     if (p->n_rows < 1 || p->n_rows > 8192) return fail(c, GFO_ERR_INVALID, "n_rows must be 1..8192");
-    // scratch layout
+    // scratch layout: inputs first, outputs next, work buffers last -- the input and output regions are mirrored in
+    // pinned host memory, so the call is one H2D copy, three kernels, one D2H copy and one synchronisation
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = off; off = (size_t)align_up((long long)(off + bytes), 256); return o; };
     const int nr1 = nr > 0 ? nr : 1;
@@ -1121,25 +1122,34 @@ extern "C" int gfo_stereo_match(gfo_ctx* c, const gfo_keypoint* kl, const uint8_
     const size_t o_kr = take(sizeof(gfo_keypoint) * nr1), o_dr = take(32 * (size_t)nr1);
     const size_t o_sf = take(sizeof(float) * GFO_MAX_LEVELS);
     const size_t o_min = take(sizeof(float) * nl), o_max = take(sizeof(float) * nl);
+    const size_t in_bytes = off;
     const size_t o_u = take(sizeof(float) * nl), o_dp = take(sizeof(float) * nl);
-    const size_t o_bd = take(sizeof(int) * nl), o_bi = take(sizeof(int) * nl), o_nm = take(sizeof(int)), o_ct = take(nl);
+    const size_t o_bd = take(sizeof(int) * nl), o_bi = take(sizeof(int) * nl), o_nm = take(sizeof(int));
+    const size_t out_bytes = off - in_bytes;
+    const size_t o_ct = take(nl);
     const size_t o_sx = take(4 * (size_t)nr1), o_sy = take(4 * (size_t)nr1), o_soi = take(4 * (size_t)nr1),
                  o_sd = take(32 * (size_t)nr1), o_rs = take(4 * (size_t)(p->n_rows + 1));
     int rc = scratch(c, off);
     if (rc) return rc;
+    rc = pinned(c, &c->h_in, &c->h_in_bytes, in_bytes);
+    if (rc) return rc;
+    rc = pinned(c, &c->h_out, &c->h_out_bytes, out_bytes);
+    if (rc) return rc;
     uint8_t* S = (uint8_t*)c->d_scratch;
-    HIP_TRY(c, hipMemcpyAsync(S + o_kl, kl, sizeof(gfo_keypoint) * nl, hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(c, hipMemcpyAsync(S + o_dl, dl, 32 * (size_t)nl, hipMemcpyHostToDevice, c->stream));
-    if (nr > 0) {
-        HIP_TRY(c, hipMemcpyAsync(S + o_kr, kr, sizeof(gfo_keypoint) * nr, hipMemcpyHostToDevice, c->stream));
-        HIP_TRY(c, hipMemcpyAsync(S + o_dr, dr, 32 * (size_t)nr, hipMemcpyHostToDevice, c->stream));
-    }
-    HIP_TRY(c, hipMemcpyAsync(S + o_sf, sf, sizeof(float) * nlevels, hipMemcpyHostToDevice, c->stream));
+    uint8_t* HI = c->h_in;
     const bool win = min_d && max_d;
-    if (win) {
-        HIP_TRY(c, hipMemcpyAsync(S + o_min, min_d, sizeof(float) * nl, hipMemcpyHostToDevice, c->stream));
-        HIP_TRY(c, hipMemcpyAsync(S + o_max, max_d, sizeof(float) * nl, hipMemcpyHostToDevice, c->stream));
+    memcpy(HI + o_kl, kl, sizeof(gfo_keypoint) * nl);
+    memcpy(HI + o_dl, dl, 32 * (size_t)nl);
+    if (nr > 0) {
+        memcpy(HI + o_kr, kr, sizeof(gfo_keypoint) * nr);
+        memcpy(HI + o_dr, dr, 32 * (size_t)nr);
     }
+    memcpy(HI + o_sf, sf, sizeof(float) * nlevels);
+    if (win) {
+        memcpy(HI + o_min, min_d, sizeof(float) * nl);
+        memcpy(HI + o_max, max_d, sizeof(float) * nl);
+    }
+    HIP_TRY(c, hipMemcpyAsync(S, HI, in_bytes, hipMemcpyHostToDevice, c->stream));
     GfoStereoDev out{(float*)(S + o_u), (float*)(S + o_dp), (int*)(S + o_bd), (int*)(S + o_bi), (int*)(S + o_nm), S + o_ct};
     GfoStereoLaunch sl{};
     sl.kl = (const gfo_keypoint*)(S + o_kl); sl.dl = S + o_dl;
@@ -1157,12 +1167,14 @@ extern "C" int gfo_stereo_match(gfo_ctx* c, const gfo_keypoint* kl, const uint8_
     gfo_launch_stereo(c, sl);
     if (int lrc = gfo_take_launch_err(c)) return lrc;
     HIP_TRY(c, hipGetLastError());
-    HIP_TRY(c, hipMemcpyAsync(u_right, out.u_right, sizeof(float) * nl, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(c, hipMemcpyAsync(depth, out.depth, sizeof(float) * nl, hipMemcpyDeviceToHost, c->stream));
-    if (best_dist) HIP_TRY(c, hipMemcpyAsync(best_dist, out.best_dist, sizeof(int) * nl, hipMemcpyDeviceToHost, c->stream));
-    if (best_idx_r) HIP_TRY(c, hipMemcpyAsync(best_idx_r, out.best_idx, sizeof(int) * nl, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(c, hipMemcpyAsync(nmatched, out.nmatched, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    uint8_t* HO = c->h_out;
+    HIP_TRY(c, hipMemcpyAsync(HO, S + in_bytes, out_bytes, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
+    memcpy(u_right, HO + (o_u - in_bytes), sizeof(float) * nl);
+    memcpy(depth, HO + (o_dp - in_bytes), sizeof(float) * nl);
+    if (best_dist) memcpy(best_dist, HO + (o_bd - in_bytes), sizeof(int) * nl);
+    if (best_idx_r) memcpy(best_idx_r, HO + (o_bi - in_bytes), sizeof(int) * nl);
+    memcpy(nmatched, HO + (o_nm - in_bytes), sizeof(int));
     return GFO_OK;
 }
 
