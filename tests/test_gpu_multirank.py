@@ -1,0 +1,35 @@
+"""bench.py's N > 1 control flow, rehearsed on the one GPU a test box has: two ranks share device 0 and talk over gloo
+(GFO_BENCH_REHEARSAL=1; RCCL refuses two ranks on one device).  What it checks is what the driver's multi-GPU run
+relies on: the rendezvous on 127.0.0.1, one context set per rank, the count all-gather in every step, the barriers,
+max-over-ranks timing and rank 0 printing exactly one JSON line with the whole-job aggregate."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+
+def test_two_ranks_rehearsal():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, GFO_BENCH_REHEARSAL="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "2", "--batch", "16",
+           "--profile-steps", "2"]
+    r = subprocess.run(cmd, capture_output=True, text=True, env=env, cwd=ROOT, timeout=170)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["steps"] == 6 and d["warmup"] == 2
+    assert d["value"] > 0 and d["unit"] == "frames/s"
+    # whole-job aggregate: 2 ranks x 16 images x 6 steps over the max-over-ranks time
+    assert abs(d["value"] - 2 * 16 * 6 / (d["ms_per_step"] * 6 * 1e-3)) / d["value"] < 0.01
+    assert "roofline" in d and "cpu_baseline" not in d and "other_configs" not in d
