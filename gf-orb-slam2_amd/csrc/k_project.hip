@@ -622,6 +622,8 @@ extern "C" int gfo_search_by_projection_queries(gfo_ctx* c, const gfo_keypoint* 
         (m > 0 && (!queries || !q_desc)) || (mode->check_orientation && n > 0 && !kp_angle))
         return pj_fail(c, GFO_ERR_INVALID, "gfo_search_by_projection: bad argument");
     if (n > 65535) return pj_fail(c, GFO_ERR_INVALID, "gfo_search_by_projection: more than 65535 keypoints");
+    // "no candidate" is bestDist = 256 in the reference (:187, :1517): a threshold of 256 or more would accept it
+    if (mode->th_dist < 0 || mode->th_dist > 255) return pj_fail(c, GFO_ERR_INVALID, "gfo_search_by_projection: th_dist must be 0..255");
     if (!(fb->max_x > fb->min_x) || !(fb->max_y > fb->min_y)) return pj_fail(c, GFO_ERR_INVALID, "gfo_search_by_projection: empty frame bounds");
     for (int i = 0; i < n; i++)
         if (kp_un[i].octave < 0 || kp_un[i].octave > 127) return pj_fail(c, GFO_ERR_INVALID, "gfo_search_by_projection: keypoint octave outside 0..127");

@@ -1174,7 +1174,7 @@ int orc_search_by_projection_queries(const orc_keypoint* kp, const uint8_t* desc
                 bestDist2 = dist;
             }
         }
-        if (bestDist <= mode->th_dist) {
+        if (bestIdx >= 0 && bestDist <= mode->th_dist) { /* th_dist < 256 in every caller of the reference: no candidate leaves bestDist = 256 */
             if (mode->use_ratio && bestLevel == bestLevel2 && (float)bestDist > mode->nn_ratio * (float)bestDist2) continue;
             out_q[bestIdx] = iq;
             out_score[bestIdx] = bestDist;
@@ -1247,7 +1247,7 @@ int orc_search_by_projection_kf(const orc_keypoint* kp, const uint8_t* desc, con
             const int dist = orc_hamming256(q_desc + (size_t)iq * 32, desc + (size_t)i2 * 32);
             if (dist < bestDist) { bestDist = dist; bestIdx2 = i2; }
         }
-        if (bestDist <= orb_dist) { /* :1679 */
+        if (bestIdx2 >= 0 && bestDist <= orb_dist) { /* :1679; ORBdist < 256 in every caller */
             set[bestIdx2] = 1;
             out_q[bestIdx2] = iq;
             out_score[bestIdx2] = bestDist;

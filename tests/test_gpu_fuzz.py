@@ -84,3 +84,60 @@ def test_random_stereo_pairs_match_oracle(oracle):
             for a, b in zip(got[1:], ref[1:]):
                 assert a.tobytes() == b.tobytes(), f"case {it}"
         ext.close()
+
+
+def test_projection_queries_fuzz(oracle):
+    """random frames, bounds (non-zero origin included), query sets, modes: the query-form projection search against the
+    oracle's serial statement.  Sizes straddle the switch between the two round-0 paths (grid in LDS from 4096 queries)."""
+    import gf_orb_slam2_amd as G
+    ext = G.ORBextractor(500, 1.2, 8, 20, 7)
+    rng = np.random.default_rng(2026)
+    sf = ext.GetScaleFactors()
+    for case in range(40):
+        n = int(rng.integers(1, 3500))
+        m = int(rng.choice([0, 1, 50, 700, 4095, 4096, 6000, 12000]))
+        x0, y0 = float(rng.choice([0.0, -37.5, 12.25])), float(rng.choice([0.0, -20.0, 8.5]))
+        w, h = float(rng.integers(200, 2000)), float(rng.integers(150, 1200))
+        b = (x0, y0, x0 + w, y0 + h)
+        kp = np.zeros(n, oracle.KEYPOINT_DTYPE)
+        kp["x"] = rng.uniform(x0 - 5, x0 + w + 5, n).astype(np.float32)      # a few keypoints outside the grid
+        kp["y"] = rng.uniform(y0 - 5, y0 + h + 5, n).astype(np.float32)
+        kp["octave"] = rng.integers(0, 8, n)
+        kp["angle"] = rng.uniform(0, 360, n).astype(np.float32)
+        desc = rng.integers(0, 256, (n, 32), dtype=np.uint8)
+        u = None if rng.random() < 0.4 else np.where(rng.random(n) < 0.6, kp["x"] - rng.uniform(0.5, 60, n), -1).astype(np.float32)
+        taken = None if rng.random() < 0.4 else (rng.random(n) < 0.15).astype(np.uint8)
+        q = np.zeros(m, oracle.PROJ_QUERY_DTYPE)
+        qd = np.zeros((m, 32), np.uint8)
+        if m:
+            src = rng.integers(0, n, m)
+            spread = float(rng.choice([0.5, 3.0, 15.0]))
+            q["u"] = kp["x"][src] + rng.normal(0, spread, m); q["v"] = kp["y"][src] + rng.normal(0, spread, m)
+            q["ur"] = q["u"] - rng.uniform(0, 60, m).astype(np.float32)
+            q["radius"] = (np.float32(rng.choice([1.0, 3.0, 7.0, 15.0])) * sf[kp["octave"][src]]).astype(np.float32)
+            mode_l = int(rng.integers(0, 4))
+            octv = kp["octave"][src]
+            if mode_l == 0: q["min_level"] = octv - 1; q["max_level"] = octv + 1
+            elif mode_l == 1: q["min_level"] = octv; q["max_level"] = -1
+            elif mode_l == 2: q["min_level"] = 0; q["max_level"] = octv
+            else: q["min_level"] = -1; q["max_level"] = -1
+            q["angle"] = ((kp["angle"][src] + rng.normal(0, 30, m)) % 360).astype(np.float32)
+            fl = np.full(m, 5, np.int32); fl[rng.random(m) < 0.15] = 0; fl[rng.random(m) < 0.3] &= ~4
+            q["flags"] = fl
+            qd = desc[src].copy()
+            for _ in range(int(rng.integers(0, 40))):
+                sel = rng.random(m) < 0.5
+                bits = rng.integers(0, 256, m)
+                qd[sel, bits[sel] >> 3] ^= (1 << (bits[sel] & 7)).astype(np.uint8)
+        use_ratio, ori = bool(rng.integers(0, 2)), bool(rng.integers(0, 2))
+        ratio, th = float(rng.choice([0.6, 0.8, 0.95])), int(rng.choice([40, 64, 100, 255]))
+        ref = oracle.search_by_projection_queries(kp, desc, u, kp["angle"], b, q, qd, use_ratio, ratio, th, ori, taken)
+        got = G.ORBmatcher(ratio, ori, extractor=ext).SearchByProjectionQueries(kp, desc, u, kp["angle"], b, q, qd, use_ratio=use_ratio,
+                                                                               th_dist=th, kp_taken=taken)
+        assert got[0] == ref[0], f"case {case}"
+        np.testing.assert_array_equal(got[1], ref[1], err_msg=f"case {case}")
+        np.testing.assert_array_equal(got[2][got[1] >= 0], ref[2][ref[1] >= 0], err_msg=f"case {case}")
+    with pytest.raises(G.GfoError) as e:          # 256 would accept "no candidate" (bestDist = 256 in the reference)
+        G.ORBmatcher(0.8, False, extractor=ext).SearchByProjectionQueries(kp, desc, None, kp["angle"], b, q, qd, th_dist=256)
+    assert e.value.code == -1
+    ext.close()
