@@ -210,7 +210,7 @@ typedef struct {
 typedef struct {
     int32_t use_ratio;
     float nn_ratio;
-    int32_t th_dist;
+    int32_t th_dist;            /* 0..255: TH_HIGH (100) or ORBdist; 256 is the reference's "no candidate" value of bestDist */
     int32_t check_orientation;
 } gfo_proj_mode;
 int gfo_search_by_projection_queries(gfo_ctx* ctx, const gfo_keypoint* kp_un, const uint8_t* desc,
