@@ -73,6 +73,9 @@ struct ProjB {
     int* tab_g;                // [2 * n_cap] claim / owner and score tables when they do not fit LDS
     int* counters;             // [PJ_CNT]
     int* out_mp; int* out_score;   // [n_cap]
+#ifdef GFO_PROJ_DEBUG
+    int dbg_stop;
+#endif
 };
 
 struct ProjQ {
@@ -268,6 +271,9 @@ __device__ __forceinline__ void scan_candidates(const ProjB& a, int f, int n, in
             }
         }
     }
+#ifdef GFO_PROJ_DEBUG
+    if (a.dbg_stop == 2) { if (nh == 12345) sink(0ull); return; }   // tools/pmc_proj_phases.sh: stop after the grid scan
+#endif
     if (__ballot(nh > 0) == 0) return;
     if (nh > 0) need_desc();
 #pragma unroll
@@ -323,6 +329,9 @@ __global__ __launch_bounds__(LDSGRID ? 1024 : 256, 8) void k_proj_round0(ProjB a
         if (iq < q_end && n > 0) {
             const ProjQ q = load_query(a, f, iq);
             obs = q.obs;
+#ifdef GFO_PROJ_DEBUG
+            if (a.dbg_stop == 1) { if (q.radius == 12345.f) live = true; } else   // stop after the query load
+#endif
             {
                 scan_candidates(a, f, n, iq, q, cell_start, cell_item, [](int) { return false; },
                                 [&](unsigned long long key) {
@@ -568,6 +577,9 @@ static int pj_reserve(gfo_ctx* c, int frames, int m, int n_cap)
 
 static void pj_bind(const gfo_ctx* c, ProjB* a)
 {
+#ifdef GFO_PROJ_DEBUG
+    a->dbg_stop = getenv("GFO_PROJ_STOP") ? atoi(getenv("GFO_PROJ_STOP")) : 0;
+#endif
     const GfoProjBuf& b = c->pj;
     a->n_cap = b.n_cap;
     a->cell_start = b.cell_start; a->cell_item = (float4*)b.cell_item;
