@@ -120,7 +120,8 @@ struct GfoProjBuf {
     void* base = nullptr;
     int frames_cap = 0, m_cap = 0, n_cap = 0;
     int* cell_start = nullptr;
-    void* cell_item = nullptr;
+    void* cell_xy = nullptr;
+    unsigned* cell_meta = nullptr;
     void* cand = nullptr;
     int* pick = nullptr;
     int* pick_dist = nullptr;

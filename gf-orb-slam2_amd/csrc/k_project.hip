@@ -2,8 +2,8 @@
 // ORBmatcher::SearchByProjection, both overloads (ORBmatcher.cc:155-249 map points, :1440-1593 frame to frame),
 // for a BATCH of frames in three launches, nothing returning to the host in between:
 //
-//   k_proj_grid     one workgroup per frame: the 64x48 grid as a CSR whose 16-byte items carry (x, y) and
-//                   index | octave << 16 | cell row << 24, so a candidate costs one gather
+//   k_proj_grid     one workgroup per frame: a 128x96 scan grid over the keypoints the frame assigns to its 64x48 grid,
+//                   as a CSR of positions and meta words (index | octave | reference cell) in cell order
 //   k_proj_round0   one THREAD per projected point (a 50 000-point local map against 4000 keypoints leaves
 //                   0-3 candidates per point: a wavefront per point would idle 60 lanes): every point is
 //                   evaluated against the entry state; points that can ever match go to the frame's live list
@@ -37,6 +37,15 @@
 #define GRID_COLS 64   // FRAME_GRID_COLS, Frame.h:92
 #define GRID_ROWS 48   // FRAME_GRID_ROWS, Frame.h:93
 #define NCELL (GRID_COLS * GRID_ROWS)
+// The SCAN grid.  Which keypoints GetFeaturesInArea returns does not depend on the grid: every keypoint the frame has
+// assigned to a cell (PosInGrid, Frame.cc:648-658) that passes |dx| < r, |dy| < r lies in a cell of the query's range
+// (round() of a value inside [floor(lo), ceil(hi)] stays inside), so any spatial index over the assigned keypoints
+// finds the same set; the reference's 64x48 cell only enters the ORDER of the candidates (the key below) and is
+// carried in each item.  The scan therefore uses cells of half the size: a level-0 window (15 px) in 30 x 22.5-px cells
+// visits 12x its own area, in 15 x 11-px cells 3.5x -- and a wave's scan loop runs as long as its unluckiest lane.
+#define SG_COLS 128
+#define SG_ROWS 96
+#define NSG (SG_COLS * SG_ROWS)
 #define TH_HIGH 100    // ORBmatcher.cc:57
 #define HISTO_LENGTH 30  // ORBmatcher.cc:59
 
@@ -62,8 +71,10 @@ struct ProjB {
     int use_ratio; float nn_ratio; int th_dist; int check_ori;
     // per-frame scratch
     int n_cap;                 // stride of the per-keypoint arrays
-    int* cell_start;           // [NCELL + 1]
-    float4* cell_item;         // [n_cap] in cell order: x, y, bits of (index | octave << 16 | cell row << 24), 0
+    float sinv_w, sinv_h;      // scan-grid cells per pixel
+    int* cell_start;           // [NSG + 1] CSR over the scan grid, column-major
+    float2* cell_xy;           // [n_cap] keypoint positions in scan-cell order
+    unsigned* cell_meta;       // [n_cap] index | octave << 16 | reference cell column << 20 | reference cell row << 26
     int* pick;                 // [m] by live slot: keypoint picked, -1 none
     int* pick_dist;            // [m] by live slot
     unsigned* live;            // [m] live point | has-observations << 31
@@ -116,29 +127,36 @@ __device__ __forceinline__ int frame_n(const ProjB& a, int f)
     return n < 0 ? 0 : (n > a.n_cap ? a.n_cap : n);
 }
 
-// one workgroup builds one frame's grid (N <= 65535); it also clears the frame's counters
+// one workgroup builds one frame's scan grid (N <= 65535); it also clears the frame's counters
 __global__ __launch_bounds__(1024) void k_proj_grid(ProjB a)
 {
-    __shared__ int s_cnt[NCELL];
+    __shared__ int s_cnt[NSG];
     __shared__ int s_part[1024];
     const int tid = threadIdx.x, f = blockIdx.x;
     const int n = frame_n(a, f);
     const gfo_keypoint* kp = a.kp + (long long)f * a.kp_stride;
-    int* cell_start = a.cell_start + (long long)f * (NCELL + 1);
-    float4* cell_item = a.cell_item + (long long)f * a.n_cap;
+    int* cell_start = a.cell_start + (long long)f * (NSG + 1);
+    float2* cell_xy = a.cell_xy + (long long)f * a.n_cap;
+    unsigned* cell_meta = a.cell_meta + (long long)f * a.n_cap;
     if (tid < PJ_CNT) a.counters[f * PJ_CNT + tid] = 0;
-    for (int c = tid; c < NCELL; c += 1024) s_cnt[c] = 0;
+    for (int c = tid; c < NSG; c += 1024) s_cnt[c] = 0;
     __syncthreads();
+    auto scan_cell = [&](float x, float y) {
+        const int fx = min(max((int)floorf((x - a.fb.min_x) * a.sinv_w), 0), SG_COLS - 1);
+        const int fy = min(max((int)floorf((y - a.fb.min_y) * a.sinv_h), 0), SG_ROWS - 1);
+        return fx * SG_ROWS + fy;
+    };
     for (int i = tid; i < n; i += 1024) {
-        // Frame::PosInGrid, Frame.cc:648-658 (round half away from zero)
+        // Frame::PosInGrid, Frame.cc:648-658 (round half away from zero): only assigned keypoints can be candidates
         const int px = (int)roundf((kp[i].x - a.fb.min_x) * a.inv_w);
         const int py = (int)roundf((kp[i].y - a.fb.min_y) * a.inv_h);
-        if (!(px < 0 || px >= GRID_COLS || py < 0 || py >= GRID_ROWS)) atomicAdd(&s_cnt[px * GRID_ROWS + py], 1);
+        if (!(px < 0 || px >= GRID_COLS || py < 0 || py >= GRID_ROWS)) atomicAdd(&s_cnt[scan_cell(kp[i].x, kp[i].y)], 1);
     }
     __syncthreads();
-    // exclusive scan of 3072 counters: 3 per thread
-    int loc[3], s = 0;
-    for (int k = 0; k < 3; k++) { loc[k] = s_cnt[tid * 3 + k]; s += loc[k]; }
+    // exclusive scan of 12288 counters: 12 per thread
+    int loc[NSG / 1024], s = 0;
+#pragma unroll
+    for (int k = 0; k < NSG / 1024; k++) { loc[k] = s_cnt[tid * (NSG / 1024) + k]; s += loc[k]; }
     s_part[tid] = s;
     __syncthreads();
     for (int off = 1; off < 1024; off <<= 1) {
@@ -148,22 +166,23 @@ __global__ __launch_bounds__(1024) void k_proj_grid(ProjB a)
         __syncthreads();
     }
     int run = s_part[tid] - s;
-    for (int k = 0; k < 3; k++) {
-        cell_start[tid * 3 + k] = run;
-        s_cnt[tid * 3 + k] = run;   // becomes the fill cursor
+#pragma unroll
+    for (int k = 0; k < NSG / 1024; k++) {
+        cell_start[tid * (NSG / 1024) + k] = run;
+        s_cnt[tid * (NSG / 1024) + k] = run;   // becomes the fill cursor
         run += loc[k];
     }
-    if (tid == 1023) cell_start[NCELL] = run;
+    if (tid == 1023) cell_start[NSG] = run;
     __syncthreads();
     for (int i = tid; i < n; i += 1024) {
         const gfo_keypoint k = kp[i];
         const int px = (int)roundf((k.x - a.fb.min_x) * a.inv_w);
         const int py = (int)roundf((k.y - a.fb.min_y) * a.inv_h);
         if (px < 0 || px >= GRID_COLS || py < 0 || py >= GRID_ROWS) continue;
-        const int slot = atomicAdd(&s_cnt[px * GRID_ROWS + py], 1);
-        // octaves outside 0..127 cannot come out of the extractor; host arrays are checked at the ABI
-        const unsigned meta = (unsigned)i | ((unsigned)(k.octave & 0x7F) << 16) | ((unsigned)py << 24);
-        cell_item[slot] = make_float4(k.x, k.y, __uint_as_float(meta), 0.f);
+        const int slot = atomicAdd(&s_cnt[scan_cell(k.x, k.y)], 1);
+        cell_xy[slot] = make_float2(k.x, k.y);
+        // octaves outside 0..15 cannot come out of the extractor (GFO_MAX_LEVELS); host arrays are checked at the ABI
+        cell_meta[slot] = (unsigned)i | ((unsigned)(k.octave & 0xF) << 16) | ((unsigned)px << 20) | ((unsigned)py << 26);
     }
 }
 
@@ -177,10 +196,10 @@ __device__ __forceinline__ int hamming_u4(const uint4 a0, const uint4 a1, const 
 // key of a candidate = (dist, cell column, cell row, index): the reference's iteration order breaks distance ties.
 // The octave rides in the lowest 7 bits (it cannot disturb the order: two candidates never share an index).
 //   [43:35] dist  [34:29] cell column  [28:23] cell row  [22:7] index  [6:0] octave
-__device__ __forceinline__ unsigned long long cand_key(unsigned dist, int ix, unsigned meta)
+__device__ __forceinline__ unsigned long long cand_key(unsigned dist, unsigned meta)
 {
-    return ((unsigned long long)dist << 35) | ((unsigned long long)ix << 29) | ((unsigned long long)(meta >> 24) << 23) |
-           ((unsigned long long)(meta & 0xFFFFu) << 7) | (unsigned long long)((meta >> 16) & 0x7Fu);
+    return ((unsigned long long)dist << 35) | ((unsigned long long)((meta >> 20) & 63u) << 29) | ((unsigned long long)(meta >> 26) << 23) |
+           ((unsigned long long)(meta & 0xFFFFu) << 7) | (unsigned long long)((meta >> 16) & 0xFu);
 }
 
 // The acceptance rule on the best and second-best UNBLOCKED candidates (entries dist << 23 | octave << 16 | index,
@@ -207,27 +226,31 @@ __device__ __forceinline__ void accept_rule(const ProjB& a, int e1, int e2, int*
 // filters need (taken on entry, mvuRight gate, `blocked(i)`, the keypoint's descriptor) and offers the survivors to
 // `sink(key)`.  Items beyond PJ_HOLD are finished on the spot (contended maps only).
 #define PJ_HOLD 4
-template <class Blocked, class Sink>
-__device__ __forceinline__ void scan_candidates(const ProjB& a, int f, int n, int iq, const ProjQ& q, const int* cell_start,
-                                                const float4* cell_item, Blocked blocked, Sink sink)
+template <class StartT, class Blocked, class Sink>
+__device__ __forceinline__ void scan_candidates(const ProjB& a, int f, int n, int iq, const ProjQ& q, const StartT* cell_start,
+                                                const float2* cell_xy, const unsigned* cell_meta, Blocked blocked, Sink sink)
 {
     const float rs = q.radius, x = q.u, y = q.v;
-    // GetFeaturesInArea(u, v, rs, minLevel, maxLevel), Frame.cc:593-646
-    int cx0 = max(0, (int)floorf((x - a.fb.min_x - rs) * a.inv_w));
-    int cx1 = min(GRID_COLS - 1, (int)ceilf((x - a.fb.min_x + rs) * a.inv_w));
-    const int cy0 = max(0, (int)floorf((y - a.fb.min_y - rs) * a.inv_h));
-    const int cy1 = min(GRID_ROWS - 1, (int)ceilf((y - a.fb.min_y + rs) * a.inv_h));
-    if (!q.active || cx0 >= GRID_COLS || cx1 < 0 || cy0 >= GRID_ROWS || cy1 < 0) { cx0 = 0; cx1 = -1; }   // no cells
+    // the scan cells the window touches, with a hundredth of a cell of slack on either side: the window test below is
+    // the reference's own (GetFeaturesInArea, Frame.cc:627-640), the cell range only has to be a superset
+    // (both ends are clamped INTO the grid, as the keypoints' cells are: a keypoint slightly outside the frame bounds is
+    //  still assigned -- PosInGrid rounds -- and sits in a border cell, so a window that lies entirely outside the bounds
+    //  must still visit that border cell)
+    const float sgx = (float)(SG_COLS - 1), sgy = (float)(SG_ROWS - 1);
+    int cx0 = (int)fminf(fmaxf(floorf((x - a.fb.min_x - rs) * a.sinv_w - 0.01f), 0.f), sgx);
+    int cx1 = (int)fminf(fmaxf(floorf((x - a.fb.min_x + rs) * a.sinv_w + 0.01f), 0.f), sgx);
+    const int cy0 = (int)fminf(fmaxf(floorf((y - a.fb.min_y - rs) * a.sinv_h - 0.01f), 0.f), sgy);
+    const int cy1 = (int)fminf(fmaxf(floorf((y - a.fb.min_y + rs) * a.sinv_h + 0.01f), 0.f), sgy);
+    if (!q.active || !(rs > 0.f)) { cx0 = 0; cx1 = -1; }   // no cells (a zero or NaN radius admits nothing: the window test is strict)
     const bool check_levels = (q.min_level > 0) || (q.max_level >= 0);
     const uint8_t* desc = a.desc + (long long)f * a.kp_stride * 32;
     const float* u_right = a.u_right ? a.u_right + (long long)f * a.ur_stride : nullptr;
     const uint8_t* taken0 = a.taken0 ? a.taken0 + (long long)f * a.tk_stride : nullptr;
     uint4 a0 = make_uint4(0, 0, 0, 0), a1 = a0;
     bool have_desc = false;
-    // finishes one kept item (j = position in the cell-ordered item array, ix = its cell column)
-    auto finish = [&](bool valid, int j, int ix) {
-        const float4 it = cell_item[valid ? j : 0];
-        const unsigned meta = __float_as_uint(it.z);
+    // finishes one kept item (j = position in the cell-ordered item arrays)
+    auto finish = [&](bool valid, int j) {
+        const unsigned meta = cell_meta[valid ? j : 0];
         const int i = min((int)(meta & 0xFFFF), n - 1);
         const uint4* dk = reinterpret_cast<const uint4*>(desc + (long long)i * 32);
         const uint4 b0 = dk[0], b1 = dk[1];
@@ -236,7 +259,7 @@ __device__ __forceinline__ void scan_candidates(const ProjB& a, int f, int n, in
         if (!valid || tk || blocked(i) || (ur > 0 && fabsf(q.ur - ur) > rs)) return;
         const unsigned dist = (unsigned)(__popc(a0.x ^ b0.x) + __popc(a0.y ^ b0.y) + __popc(a0.z ^ b0.z) + __popc(a0.w ^ b0.w) +
                                          __popc(a1.x ^ b1.x) + __popc(a1.y ^ b1.y) + __popc(a1.z ^ b1.z) + __popc(a1.w ^ b1.w));
-        sink(cand_key(dist, ix, meta));
+        sink(cand_key(dist, meta));
     };
     auto need_desc = [&]() {
         if (!have_desc) {
@@ -250,24 +273,23 @@ __device__ __forceinline__ void scan_candidates(const ProjB& a, int f, int n, in
     for (int s = 0; s < PJ_HOLD; s++) hold[s] = 0;
     for (int ix = cx0; ix <= cx1; ix++) {
         // cells (ix, cy0..cy1) are contiguous in the CSR
-        const int beg = cell_start[ix * GRID_ROWS + cy0];
-        const int end = cell_start[ix * GRID_ROWS + cy1 + 1];
+        const int beg = (int)cell_start[ix * SG_ROWS + cy0];
+        const int end = (int)cell_start[ix * SG_ROWS + cy1 + 1];
         for (int j = beg; j < end; j++) {
-            const float4 it = cell_item[j];
+            const float2 it = cell_xy[j];
             if (!(fabsf(it.x - x) < rs && fabsf(it.y - y) < rs)) continue;
-            const int oct = (int)((__float_as_uint(it.z) >> 16) & 0x7F);
             if (check_levels) {
+                const int oct = (int)((cell_meta[j] >> 16) & 0xF);
                 if (oct < q.min_level) continue;
                 if (q.max_level >= 0 && oct > q.max_level) continue;
             }
-            const int c = j | (ix << 16);
             if (nh < PJ_HOLD) {
 #pragma unroll
-                for (int s = 0; s < PJ_HOLD; s++) hold[s] = nh == s ? c : hold[s];
+                for (int s = 0; s < PJ_HOLD; s++) hold[s] = nh == s ? j : hold[s];
                 nh++;
             } else {
                 need_desc();
-                finish(true, j, ix);
+                finish(true, j);
             }
         }
     }
@@ -280,8 +302,8 @@ __device__ __forceinline__ void scan_candidates(const ProjB& a, int f, int n, in
     for (int s0 = 0; s0 < PJ_HOLD; s0 += 2) {
         if (s0 > 0 && __ballot(nh > s0) == 0) break;
         // two items per step: their loads are independent and go out together
-        finish(nh > s0, hold[s0] & 0xFFFF, hold[s0] >> 16);
-        finish(nh > s0 + 1, hold[s0 + 1] & 0xFFFF, hold[s0 + 1] >> 16);
+        finish(nh > s0, hold[s0]);
+        finish(nh > s0 + 1, hold[s0 + 1]);
     }
 }
 
@@ -289,12 +311,12 @@ __device__ __forceinline__ void scan_candidates(const ProjB& a, int f, int n, in
 __device__ __forceinline__ int key_entry(unsigned long long key)
 {
     if (key == ~0ull) return -1;
-    return (int)(((unsigned)(key >> 35) << 23) | ((unsigned)(key & 0x7Fu) << 16) | (unsigned)((key >> 7) & 0xFFFFu));
+    return (int)(((unsigned)(key >> 35) << 23) | ((unsigned)(key & 0x7Fu) << 16) | (unsigned)((key >> 7) & 0xFFFFu));   // octave < 16
 }
 
 // round 0: every projected point against the entry state; the points that can ever match (best distance within
 // the threshold before anyone blocks anything) get a live slot holding their PJ_K first candidates in order.
-// LDSGRID: the workgroup first copies the frame's grid (cell table + items, 78 KB for 4128 keypoints) into LDS and
+// LDSGRID: the workgroup first copies the frame's scan grid (cell table + items, 74 KB for 4128 keypoints) into LDS and
 // walks its share of the points against that copy: the scan is all gathers, and a CU's address unit retires a fully
 // divergent global gather at ~2 clk per distinct line where LDS serves 128 B/clk.  Grids too large for LDS (more
 // than ~4000 keypoints) are read from HBM in place.
@@ -304,18 +326,23 @@ __global__ __launch_bounds__(LDSGRID ? 1024 : 256, 8) void k_proj_round0(ProjB a
     extern __shared__ __attribute__((aligned(16))) uint8_t lds_grid[];
     const int f = blockIdx.y;
     const int n = frame_n(a, f);
-    const int* cell_start = a.cell_start + (long long)f * (NCELL + 1);
-    const float4* cell_item = a.cell_item + (long long)f * a.n_cap;
+    const int* g_start = a.cell_start + (long long)f * (NSG + 1);
+    const float2* cell_xy = a.cell_xy + (long long)f * a.n_cap;
+    const unsigned* cell_meta = a.cell_meta + (long long)f * a.n_cap;
+    const unsigned short* l_start = nullptr;
     const int lane = threadIdx.x & 63;
     if (LDSGRID) {
-        float4* l_item = reinterpret_cast<float4*>(lds_grid);
-        int* l_start = reinterpret_cast<int*>(lds_grid + (size_t)a.n_cap * 16);
-        const int n_in = min(cell_start[NCELL], a.n_cap);   // keypoints inside the grid
-        for (int i = threadIdx.x; i < n_in; i += 1024) l_item[i] = cell_item[i];
-        for (int i = threadIdx.x; i <= NCELL; i += 1024) l_start[i] = cell_start[i];
+        // LDS copy of the frame's scan grid: positions, meta words, cell table as u16 (N <= 65535)
+        float2* w_xy = reinterpret_cast<float2*>(lds_grid);
+        unsigned* w_meta = reinterpret_cast<unsigned*>(lds_grid + (size_t)a.n_cap * 8);
+        unsigned short* w_start = reinterpret_cast<unsigned short*>(lds_grid + (size_t)a.n_cap * 12);
+        const int n_in = min(g_start[NSG], a.n_cap);   // keypoints inside the grid
+        for (int i = threadIdx.x; i < n_in; i += 1024) { w_xy[i] = cell_xy[i]; w_meta[i] = cell_meta[i]; }
+        for (int i = threadIdx.x; i <= NSG; i += 1024) w_start[i] = (unsigned short)g_start[i];
         __syncthreads();
-        cell_start = l_start;
-        cell_item = l_item;
+        cell_xy = w_xy;
+        cell_meta = w_meta;
+        l_start = w_start;
     }
     const int q_begin = blockIdx.x * chunk;
     const int q_end = min(a.m, q_begin + chunk);
@@ -333,17 +360,18 @@ __global__ __launch_bounds__(LDSGRID ? 1024 : 256, 8) void k_proj_round0(ProjB a
             if (a.dbg_stop == 1) { if (q.radius == 12345.f) live = true; } else   // stop after the query load
 #endif
             {
-                scan_candidates(a, f, n, iq, q, cell_start, cell_item, [](int) { return false; },
-                                [&](unsigned long long key) {
-                                    unsigned long long x = key;
+                auto sink0 = [&](unsigned long long key) {
+                    unsigned long long x = key;
 #pragma unroll
-                                    for (int s = 0; s < PJ_K; s++) {
-                                        const unsigned long long lo = k[s] < x ? k[s] : x;
-                                        x = k[s] < x ? x : k[s];
-                                        k[s] = lo;
-                                    }
-                                    if (x != ~0ull) trunc = true;
-                                });
+                    for (int s = 0; s < PJ_K; s++) {
+                        const unsigned long long lo = k[s] < x ? k[s] : x;
+                        x = k[s] < x ? x : k[s];
+                        k[s] = lo;
+                    }
+                    if (x != ~0ull) trunc = true;
+                };
+                if (LDSGRID) scan_candidates(a, f, n, iq, q, l_start, cell_xy, cell_meta, [](int) { return false; }, sink0);
+                else scan_candidates(a, f, n, iq, q, g_start, cell_xy, cell_meta, [](int) { return false; }, sink0);
                 if (k[0] != ~0ull) {
                     const int e1 = key_entry(k[0]), e2 = key_entry(k[1]);
                     live = (e1 >> 23) <= a.th_dist;   // :228 / :1536
@@ -434,7 +462,8 @@ __global__ __launch_bounds__(1024) void k_proj_resolve(ProjB a)
                     // candidates than the cache holds: full re-evaluation from the grid (rare)
                     unsigned long long k1 = ~0ull, k2 = ~0ull;
                     const ProjQ q = load_query(a, f, iq);
-                    scan_candidates(a, f, n, iq, q, a.cell_start + (long long)f * (NCELL + 1), a.cell_item + (long long)f * a.n_cap,
+                    scan_candidates(a, f, n, iq, q, a.cell_start + (long long)f * (NSG + 1), a.cell_xy + (long long)f * a.n_cap,
+                                    a.cell_meta + (long long)f * a.n_cap,
                                     [&](int i) { return tab_load(&tab[i]) < iq; },
                                     [&](unsigned long long x) {
                                         const unsigned long long hi = x < k1 ? k1 : x;
@@ -563,12 +592,12 @@ static int pj_reserve(gfo_ctx* c, int frames, int m, int n_cap)
     const size_t F = (size_t)(frames > 1 ? frames : 1), M = (size_t)(m > 1 ? m : 1), N = (size_t)(n_cap > 1 ? n_cap : 1);
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = off; off = al256(off + bytes); return o; };
-    const size_t o_cs = take(F * (NCELL + 1) * 4), o_it = take(F * N * 16), o_pk = take(F * M * 4),
+    const size_t o_cs = take(F * (NSG + 1) * 4), o_it = take(F * N * 8), o_me = take(F * N * 4), o_pk = take(F * M * 4),
                  o_pd = take(F * M * 4), o_lv = take(F * M * 4), o_cd = take(F * M * 32), o_rb = take(F * M * 4),
                  o_tg = take(F * N * 8), o_ct = take(F * PJ_CNT * 4), o_om = take(F * N * 4), o_os = take(F * N * 4);
     PTRY(c, hipMalloc(&b.base, off));
     uint8_t* S = (uint8_t*)b.base;
-    b.cell_start = (int*)(S + o_cs); b.cell_item = S + o_it;
+    b.cell_start = (int*)(S + o_cs); b.cell_xy = S + o_it; b.cell_meta = (unsigned*)(S + o_me);
     b.pick = (int*)(S + o_pk); b.pick_dist = (int*)(S + o_pd); b.live = (unsigned*)(S + o_lv); b.cand = S + o_cd; b.rot_bin = (int*)(S + o_rb);
     b.tab_g = (int*)(S + o_tg); b.counters = (int*)(S + o_ct); b.out_mp = (int*)(S + o_om); b.out_score = (int*)(S + o_os);
     b.frames_cap = (int)F; b.m_cap = (int)M; b.n_cap = (int)N;
@@ -582,7 +611,7 @@ static void pj_bind(const gfo_ctx* c, ProjB* a)
 #endif
     const GfoProjBuf& b = c->pj;
     a->n_cap = b.n_cap;
-    a->cell_start = b.cell_start; a->cell_item = (float4*)b.cell_item;
+    a->cell_start = b.cell_start; a->cell_xy = (float2*)b.cell_xy; a->cell_meta = b.cell_meta;
     a->pick = b.pick; a->pick_dist = b.pick_dist; a->live = b.live; a->cand = (uint4*)b.cand; a->rot_bin = b.rot_bin;
     a->tab_g = b.tab_g; a->counters = b.counters; a->out_mp = b.out_mp; a->out_score = b.out_score;
 }
@@ -595,7 +624,7 @@ static int pj_launch(gfo_ctx* c, const ProjB& a, int frames, int n_max)
     GFO_LAUNCH(c, k_proj_grid, dim3(frames), dim3(1024), 0, st, a);
     // round 0 against an LDS copy of the grid when it fits twice per CU: workgroups of 1024 threads, as many per
     // frame as it takes to put ~2 on every CU (each pays the 78 KB copy once, then walks its chunk of the points)
-    const size_t grid_bytes = (size_t)a.n_cap * 16 + (NCELL + 1) * 4;
+    const size_t grid_bytes = (size_t)a.n_cap * 12 + (NSG + 1) * 2 + 16;
     static const int lds_grid_on = getenv("GFO_PROJ_LDSGRID") ? atoi(getenv("GFO_PROJ_LDSGRID")) : 1;
     if (lds_grid_on && grid_bytes <= 78 * 1024 && a.m >= 4096) {
         int per_frame = (512 + frames - 1) / frames;
@@ -638,7 +667,7 @@ extern "C" int gfo_search_by_projection_queries(gfo_ctx* c, const gfo_keypoint* 
     if (mode->th_dist < 0 || mode->th_dist > 255) return pj_fail(c, GFO_ERR_INVALID, "gfo_search_by_projection: th_dist must be 0..255");
     if (!(fb->max_x > fb->min_x) || !(fb->max_y > fb->min_y)) return pj_fail(c, GFO_ERR_INVALID, "gfo_search_by_projection: empty frame bounds");
     for (int i = 0; i < n; i++)
-        if (kp_un[i].octave < 0 || kp_un[i].octave > 127) return pj_fail(c, GFO_ERR_INVALID, "gfo_search_by_projection: keypoint octave outside 0..127");
+        if (kp_un[i].octave < 0 || kp_un[i].octave >= GFO_MAX_LEVELS) return pj_fail(c, GFO_ERR_INVALID, "gfo_search_by_projection: keypoint octave outside 0..15");
     *nmatches = 0;
     for (int i = 0; i < n; i++) { out_mp[i] = -1; out_score[i] = 0; }
     if (n == 0 || m == 0) return GFO_OK;
@@ -676,6 +705,8 @@ extern "C" int gfo_search_by_projection_queries(gfo_ctx* c, const gfo_keypoint* 
     a.fb = *fb;
     a.inv_w = (float)GRID_COLS / (fb->max_x - fb->min_x);  // Frame.cc:129-130
     a.inv_h = (float)GRID_ROWS / (fb->max_y - fb->min_y);
+    a.sinv_w = (float)SG_COLS / (fb->max_x - fb->min_x);
+    a.sinv_h = (float)SG_ROWS / (fb->max_y - fb->min_y);
     a.form = 0;
     a.q = S + o_q;
     a.q_desc = S + o_mpd;
@@ -795,6 +826,8 @@ extern "C" int gfo_search_by_projection_batch(gfo_ctx* c, const gfo_projection_b
     a.fb = p->bounds;
     a.inv_w = (float)GRID_COLS / (p->bounds.max_x - p->bounds.min_x);  // Frame.cc:129-130
     a.inv_h = (float)GRID_ROWS / (p->bounds.max_y - p->bounds.min_y);
+    a.sinv_w = (float)SG_COLS / (p->bounds.max_x - p->bounds.min_x);
+    a.sinv_h = (float)SG_ROWS / (p->bounds.max_y - p->bounds.min_y);
     a.form = 1;
     a.q = d_mps; a.q_stride = m;
     a.q_desc = c->d_map_desc; a.qd_stride = 0;
