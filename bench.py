@@ -197,14 +197,32 @@ class Job:
         k = self.step_no % self.nctx if ctx is None else ctx
         d_in = self.d_inputs[self.step_no % len(self.d_inputs)]
         self.step_no += 1
-        if h2d_from is not None:   # PCIe-inclusive variant: the batch comes from pinned host memory first
-            with self.torch.cuda.stream(self.streams[k]):
+        if h2d_from is not None:
+            # PCIe-inclusive variant: the batch comes from pinned host memory first.  ONE copy stream feeds all contexts
+            # (concurrent H2D copies from several streams share the link badly: 35 GB/s aggregate against 56 GB/s for one
+            # stream, measured), double-buffered through the input batches: a buffer is overwritten only after the step
+            # that last read it, and a step starts only after its copy.
+            torch = self.torch
+            if not hasattr(self, "copy_stream"):
+                self.copy_stream = torch.cuda.Stream()
+                self.buf_done = [None] * len(self.d_inputs)
+            b = (self.step_no - 1) % len(self.d_inputs)
+            if self.buf_done[b] is not None:
+                self.copy_stream.wait_event(self.buf_done[b])
+            with torch.cuda.stream(self.copy_stream):
                 d_in.copy_(h2d_from, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(self.copy_stream)
+            self.streams[k].wait_event(ev)
         self.exts[k].extract_batch_device(d_in.data_ptr(), self.B, self.w, self.h)
         if self.matcher == "stereo":
             self.matchers[k].stereo_match_batch(self.sp)
         elif self.matcher == "project":
             self.matchers[k].search_by_projection_batch(self.d_mps.data_ptr(), self.bounds, th=3.0, device_ptrs=True)
+        if h2d_from is not None:
+            done = self.torch.cuda.Event()
+            done.record(self.streams[k])
+            self.buf_done[(self.step_no - 1) % len(self.d_inputs)] = done
         if self.world > 1:
             from gf_orb_slam2_amd.sharding import gather_counts
             with self.torch.cuda.stream(self.streams[k]):
