@@ -167,7 +167,13 @@ __device__ __forceinline__ void blur_body(const GfoGeom& g, const GfoInput& in, 
     const int quad = BORDER ? (qi == 0 ? 0 : nint + qi) : qi + 1;
     const int x0 = quad * 4, y0 = strip * BLUR_STRIP;
     int pitch;
+#ifdef GFO_BLUR_DEBUG
+    // tools/blur_read_bound.sh only: every image reads image (img & 1)'s levels, so the reads are served by the caches
+    // and the kernel's time shows what removing its HBM read could gain at most (results are wrong by construction)
+    const uint8_t* src = gfo_level_ptr(g, in, pyr, level, img & 1, &pitch);
+#else
     const uint8_t* src = gfo_level_ptr(g, in, pyr, level, img, &pitch);
+#endif
     uint8_t* dst = blur + (long long)img * g.blur_img_stride + L.blur_off;
     BorderSel bs;
     if (BORDER) bs = border_sel(x0, w);
