@@ -41,8 +41,11 @@ __global__ __launch_bounds__(64 * OD_WAVES) void k_orient_desc(const GfoGeom* __
                                                      int* __restrict__ kp_cnt, int* __restrict__ flags, int nimg,
                                                      int blocks_per_img)
 {
+    // ONE LDS region per keypoint, used twice: first the 31-row patch (angle), then -- once the angle's reads are done --
+    // the 37-row window, whose bytes wait in registers meanwhile.  14 KB per workgroup instead of 26 KB: LDS no longer
+    // caps the kernel at 6 waves per SIMD (the registers allow 8), and the chain of dependent loads at the head of
+    // every wave is what the extra waves hide.
     __shared__ __attribute__((aligned(16))) uint8_t s_win[2 * OD_WAVES][DW * DWP];   // [wave*2 + half]
-    __shared__ __attribute__((aligned(16))) uint8_t s_pat[2 * OD_WAVES][OW * OWP];
     const GfoGeom& g = *gp;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;  // uniform: keep it scalar
     const int half = lane >> 5, hl = lane & 31;
@@ -98,28 +101,27 @@ __global__ __launch_bounds__(64 * OD_WAVES) void k_orient_desc(const GfoGeom* __
     const bool ld_on = rw < 10;
     const uint8_t* psrc = lv + (long long)(y - GFO_HALF_PATCH + rw) * pitch + (ox_al + 16 * seg);
     const uint8_t* wsrc = blur + (long long)img * g.blur_img_stride + L.blur_off + (long long)(y - 18 + rw) * lpitch + (wx_al + 16 * seg);
-    uint8_t* pat = s_pat[wave * 2 + half];
     uint8_t* win = s_win[wave * 2 + half];
+    uint8_t* pat = win;   // same bytes, earlier in time
+    uint4 vw0, vw1, vw2, vw3;   // the window's bytes, in registers until the patch has been consumed
     {
-        uint4 vp[OD_STEPS], vw[OD_STEPS];
+        uint4 vp[OD_STEPS];
 #pragma unroll
         for (int k = 0; k < OD_STEPS; k++) {
-            const int rp = min(10 * k + rw, OW - 1), rq = min(10 * k + rw, DW - 1);   // clamped: idle lanes re-read a valid row
+            const int rp = min(10 * k + rw, OW - 1);   // clamped: idle lanes re-read a valid row
             vp[k] = *reinterpret_cast<const uint4*>(psrc + (long long)(rp - rw) * pitch);
-            vw[k] = *reinterpret_cast<const uint4*>(wsrc + (long long)(rq - rw) * lpitch);
         }
+        vw0 = *reinterpret_cast<const uint4*>(wsrc);
+        vw1 = *reinterpret_cast<const uint4*>(wsrc + (long long)(min(10 + rw, DW - 1) - rw) * lpitch);
+        vw2 = *reinterpret_cast<const uint4*>(wsrc + (long long)(min(20 + rw, DW - 1) - rw) * lpitch);
+        vw3 = *reinterpret_cast<const uint4*>(wsrc + (long long)(min(30 + rw, DW - 1) - rw) * lpitch);
         uint4* pl = reinterpret_cast<uint4*>(pat + rw * OWP + 16 * seg);
-        uint4* wl = reinterpret_cast<uint4*>(win + rw * DWP + 16 * seg);
         // steps 0-2 store unconditionally: every row they touch exists, and the two idle lanes (rw == 10) hold
         // exactly the bytes that lane rw == 0 of the next step writes to the same place; only the last step is
-        // predicated (rows 30 / 30..36)
+        // predicated (row 30)
 #pragma unroll
-        for (int k = 0; k < OD_STEPS - 1; k++) {
-            pl[k * (10 * OWP / 16)] = vp[k];
-            wl[k * (10 * DWP / 16)] = vw[k];
-        }
+        for (int k = 0; k < OD_STEPS - 1; k++) pl[k * (10 * OWP / 16)] = vp[k];
         if (ld_on && 10 * (OD_STEPS - 1) + rw < OW) pl[(OD_STEPS - 1) * (10 * OWP / 16)] = vp[OD_STEPS - 1];
-        if (ld_on && 10 * (OD_STEPS - 1) + rw < DW) wl[(OD_STEPS - 1) * (10 * DWP / 16)] = vw[OD_STEPS - 1];
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -153,6 +155,20 @@ __global__ __launch_bounds__(64 * OD_WAVES) void k_orient_desc(const GfoGeom* __
         m01 += __shfl_xor(m01, o);
     }
     const float angle = gfo_fast_atan2f((float)m01, (float)m10);
+
+    // ---- the patch has been read (LDS operations of a wave execute in issue order): the window takes its place ----
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    {
+        uint4* wl = reinterpret_cast<uint4*>(win + rw * DWP + 16 * seg);
+        wl[0] = vw0;
+        wl[10 * DWP / 16] = vw1;
+        wl[2 * (10 * DWP / 16)] = vw2;
+        if (ld_on && 30 + rw < DW) wl[3 * (10 * DWP / 16)] = vw3;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
     // ---- descriptor on the blurred window ----
     const float factorPI = (float)(3.1415926535897932384626433832795 / 180.f);
