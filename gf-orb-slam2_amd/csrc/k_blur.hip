@@ -206,7 +206,14 @@ __device__ __forceinline__ void blur_body(const GfoGeom& g, const GfoInput& in, 
 
 // One launch: the first blur_total_b blocks of every image are its border blocks (long, thin chains of
 // scattered rows -- dispatched first so they run underneath the streaming bulk), the rest the interior.
-__global__ __launch_bounds__(256) void k_blur(const GfoGeom* __restrict__ gp, GfoInput in,
+// Register budget.  The kernel alone is indifferent (6 waves per SIMD at 77 registers, 8 at 64 with a 16-byte spill:
+// 109 vs 105 us), but it shares the chip with the quadtree of its own batch and with the other contexts' kernels, and
+// there every register it does not hold is a wave of somebody else: 194.0k -> 201.3k frames/s for the whole pipeline
+// (same-box A/B, tools/ab_variant.sh; DESIGN.md "footprint").
+#ifndef GFO_BLUR_WAVES
+#define GFO_BLUR_WAVES 8
+#endif
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(GFO_BLUR_WAVES, GFO_BLUR_WAVES))) void k_blur(const GfoGeom* __restrict__ gp, GfoInput in,
                                               const uint8_t* __restrict__ pyr, uint8_t* __restrict__ blur)
 {
     const GfoGeom& g = *gp;

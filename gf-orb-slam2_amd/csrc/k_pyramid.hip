@@ -233,7 +233,17 @@ __global__ __launch_bounds__(1024) void k_resize_tail(const GfoGeom* __restrict_
 // share; that halo grows by 1 + 1.2x per level, which is why the pyramid is split into two groups rather than
 // run as one chain of seven.)
 // band_tab[band][level] = {c0, c1, o0, o1}: rows [c0,c1) are computed, rows [o0,o1) are written to HBM.
-__global__ __launch_bounds__(1024) void k_pyramid_bands(const GfoGeom* __restrict__ gp, GfoInput in, uint8_t* __restrict__ pyr,
+// register budget of the banded kernel (DESIGN.md "footprint"): 6 waves per SIMD = 80 registers is faster alone
+// (124 -> 116 us for the two launches) and under overlap (+1.8 % pipeline throughput); 7 and 8 spill (140 / 172 us)
+#ifndef GFO_BANDS_WAVES
+#define GFO_BANDS_WAVES 6
+#endif
+#if GFO_BANDS_WAVES > 0
+#define BANDS_OCC_ATTR __attribute__((amdgpu_waves_per_eu(GFO_BANDS_WAVES, GFO_BANDS_WAVES)))
+#else
+#define BANDS_OCC_ATTR
+#endif
+__global__ __launch_bounds__(1024) BANDS_OCC_ATTR void k_pyramid_bands(const GfoGeom* __restrict__ gp, GfoInput in, uint8_t* __restrict__ pyr,
                                                         const int2* __restrict__ xtab_all, const int2* __restrict__ ytab_all,
                                                         const int4* __restrict__ band_tab, int lb, int le)
 {

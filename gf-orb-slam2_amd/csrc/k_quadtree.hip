@@ -118,6 +118,15 @@ __device__ __forceinline__ QtBox qt_child_box(QtBox b, int q)
     return c;
 }
 
+// register budget: see DESIGN.md "footprint" (GFO_QT_WAVES = waves per SIMD the allocation aims at; 0 = compiler default)
+#ifndef GFO_QT_WAVES
+#define GFO_QT_WAVES 6   // 80 registers instead of 102: +0.9 % pipeline throughput; 8 (64, spilling) costs 12 us of its own
+#endif
+#if GFO_QT_WAVES > 0
+#define QT_OCC_ATTR __attribute__((amdgpu_waves_per_eu(GFO_QT_WAVES, GFO_QT_WAVES)))
+#else
+#define QT_OCC_ATTR
+#endif
 #define QT_KERNEL k_quadtree
 #define QT_STATE_BASE extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
 #include "k_quadtree_body.inc"
