@@ -538,6 +538,7 @@ extern "C" void gfo_ctx_destroy(gfo_ctx* c)
 extern "C" int gfo_ctx_set_stream(gfo_ctx* c, void* s)
 {
     if (!c) return GFO_ERR_INVALID;
+    (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     c->stream = s ? (hipStream_t)s : c->own_stream;
     return GFO_OK;
@@ -546,6 +547,7 @@ extern "C" int gfo_ctx_set_stream(gfo_ctx* c, void* s)
 extern "C" int gfo_ctx_synchronize(gfo_ctx* c)
 {
     if (!c) return GFO_ERR_INVALID;
+    HIP_TRY(c, hipSetDevice(c->device));   // the calling thread may be on another device
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     return GFO_OK;
 }
@@ -803,6 +805,7 @@ extern "C" int gfo_batch_counts(gfo_ctx* c, int* n, int* per_level)
 {
     if (!c || !n) return GFO_ERR_INVALID;
     if (!c->have_batch) return fail(c, GFO_ERR_STATE, "no batch has been extracted");
+    HIP_TRY(c, hipSetDevice(c->device));   // the calling thread may be on another device
     int rc = check_flags(c);
     if (rc) return rc;
     HIP_TRY(c, hipMemcpyAsync(n, c->d_kp_cnt, sizeof(int) * c->last_nimg, hipMemcpyDeviceToHost, c->stream));
@@ -816,6 +819,7 @@ extern "C" int gfo_batch_fetch(gfo_ctx* c, int image, gfo_keypoint* kp, uint8_t*
 {
     if (!c || !n) return GFO_ERR_INVALID;
     if (!c->have_batch) return fail(c, GFO_ERR_STATE, "no batch has been extracted");
+    HIP_TRY(c, hipSetDevice(c->device));   // the calling thread may be on another device
     if (image < 0 || image >= c->last_nimg) return fail(c, GFO_ERR_INVALID, "image %d out of range", image);
     int rc = check_flags(c);
     if (rc) return rc;
@@ -1039,6 +1043,7 @@ extern "C" int gfo_pyramid_level(gfo_ctx* c, int image, int level, int border, u
 {
     if (!c || !out) return GFO_ERR_INVALID;
     if (!c->have_pyramid) return fail(c, GFO_ERR_STATE, "no pyramid has been computed");
+    HIP_TRY(c, hipSetDevice(c->device));   // the calling thread may be on another device
     if (image < 0 || image >= c->last_nimg || level < 0 || level >= c->g.nlevels || border < 0)
         return fail(c, GFO_ERR_INVALID, "image/level out of range");
     const GfoLevel& L = c->g.lv[level];
@@ -1182,6 +1187,7 @@ extern "C" int gfo_stereo_match_batch(gfo_ctx* c, const gfo_stereo_params* p)
 {
     if (!c || !p) return GFO_ERR_INVALID;
     if (!c->have_batch) return fail(c, GFO_ERR_STATE, "no batch has been extracted");
+    HIP_TRY(c, hipSetDevice(c->device));   // the calling thread may be on another device
     if (c->last_nimg < 2 || (c->last_nimg & 1)) return fail(c, GFO_ERR_STATE, "stereo needs an even number of images (L,R,L,R,...)");
     if (p->n_rows < 1 || p->n_rows > c->st_rows_cap) return fail(c, GFO_ERR_INVALID, "n_rows %d exceeds the planned %d", p->n_rows, c->st_rows_cap);
     gfo_launch_stereo(c, stereo_batch_launch(c, *p));
@@ -1195,6 +1201,7 @@ extern "C" int gfo_stereo_match_sad_batch(gfo_ctx* c, float mbf, float mb)
 {
     if (!c || !(mb > 0)) return GFO_ERR_INVALID;
     if (!c->have_batch) return fail(c, GFO_ERR_STATE, "no batch has been extracted");
+    HIP_TRY(c, hipSetDevice(c->device));   // the calling thread may be on another device
     if (c->last_nimg < 2 || (c->last_nimg & 1)) return fail(c, GFO_ERR_STATE, "stereo needs an even number of images (L,R,L,R,...)");
     const int npairs = c->last_nimg / 2;
     GfoStereoLaunch sl{};
@@ -1219,6 +1226,7 @@ extern "C" int gfo_stereo_fetch(gfo_ctx* c, int pair, float* u_right, float* dep
 {
     if (!c) return GFO_ERR_INVALID;
     if (!c->have_stereo) return fail(c, GFO_ERR_STATE, "no stereo batch has been matched");
+    HIP_TRY(c, hipSetDevice(c->device));   // the calling thread may be on another device
     if (pair < 0 || pair >= c->last_nimg / 2) return fail(c, GFO_ERR_INVALID, "pair out of range");
     int nl = 0;
     HIP_TRY(c, hipMemcpyAsync(&nl, c->d_kp_cnt + 2 * pair, sizeof(int), hipMemcpyDeviceToHost, c->stream));
@@ -1240,6 +1248,7 @@ extern "C" int gfo_stereo_fetch(gfo_ctx* c, int pair, float* u_right, float* dep
 extern "C" int gfo_profile_enable(gfo_ctx* c, int on)
 {
     if (!c) return GFO_ERR_INVALID;
+    (void)hipSetDevice(c->device);
     prof_collect(c);
     c->profiling = on != 0;
     return GFO_OK;
@@ -1248,6 +1257,7 @@ extern "C" int gfo_profile_enable(gfo_ctx* c, int on)
 extern "C" int gfo_profile_read(gfo_ctx* c, gfo_stage_time* out, int cap, int* nstages, int reset)
 {
     if (!c || !nstages) return GFO_ERR_INVALID;
+    (void)hipSetDevice(c->device);
     prof_collect(c);
     int k = 0;
     for (int s = 0; s < ST_COUNT; s++) {
@@ -1269,6 +1279,7 @@ extern "C" int gfo_debug_blurred_level(gfo_ctx* c, int image, int level, uint8_t
 {
     if (!c || !out) return GFO_ERR_INVALID;
     if (!c->have_batch) return fail(c, GFO_ERR_STATE, "no batch has been extracted");
+    HIP_TRY(c, hipSetDevice(c->device));   // the calling thread may be on another device
     if (image < 0 || image >= c->last_nimg || level < 0 || level >= c->g.nlevels) return fail(c, GFO_ERR_INVALID, "out of range");
     const GfoLevel& L = c->g.lv[level];
     HIP_TRY(c, hipMemcpy2DAsync(out, out_stride, c->d_blur + (size_t)image * c->g.blur_img_stride + L.blur_off, L.pitch,
@@ -1281,6 +1292,7 @@ extern "C" int gfo_debug_level_candidates(gfo_ctx* c, int image, int level, int3
 {
     if (!c || !n) return GFO_ERR_INVALID;
     if (!c->have_batch) return fail(c, GFO_ERR_STATE, "no batch has been extracted");
+    HIP_TRY(c, hipSetDevice(c->device));   // the calling thread may be on another device
     if (image < 0 || image >= c->last_nimg || level < 0 || level >= c->g.nlevels) return fail(c, GFO_ERR_INVALID, "out of range");
     const GfoLevel& L = c->g.lv[level];
     int cnt = 0;

@@ -848,6 +848,7 @@ extern "C" int gfo_projection_fetch(gfo_ctx* c, int frame, int32_t* out_mp, int3
 {
     if (!c) return GFO_ERR_INVALID;
     if (!c->have_projection) return pj_fail(c, GFO_ERR_STATE, "gfo_projection_fetch: no batched projection search has run");
+    PTRY(c, hipSetDevice(c->device));
     if (frame < 0 || frame >= c->proj_frames) return pj_fail(c, GFO_ERR_INVALID, "gfo_projection_fetch: frame out of range");
     hipStream_t st = c->stream;
     const int step = c->proj_step;
