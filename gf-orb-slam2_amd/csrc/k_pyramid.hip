@@ -327,7 +327,8 @@ void gfo_launch_pyramid_bands(gfo_ctx* c, const GfoInput& in, int nimg)
         gfo_prof_begin(c, ST_RESIZE);
         // 256 threads when the launch has workgroups to spare (more of them resident per CU), 512 for a handful of
         // images, where the time of ONE workgroup is what counts
-        const int threads = c->band_threads > 0 ? c->band_threads : (bg.nb * nimg >= 2048 ? 256 : 512);
+        const bool bt_ok = c->band_threads >= 64 && c->band_threads <= 1024 && (c->band_threads & 63) == 0;
+        const int threads = bt_ok ? c->band_threads : (bg.nb * nimg >= 2048 ? 256 : 512);
         GFO_LAUNCH(c, k_pyramid_bands, dim3(bg.nb, nimg), dim3(threads), bg.lds_bytes, c->stream, c->d_geom, in,
                            c->d_pyr, reinterpret_cast<const int2*>(c->d_xofs), reinterpret_cast<const int2*>(c->d_yofs),
                            reinterpret_cast<const int4*>(c->d_band) + bg.tab_off, bg.lb, bg.le);

@@ -174,7 +174,8 @@ void gfo_launch_quadtree(gfo_ctx* c, int nimg)
     // the per-pass key loops are latency-bound inside a workgroup: large quotas (1080p @4000 features) get
     // 1024 threads per (image, level), the 752x480 @2000 case runs best with 256
     static const int nt_env = getenv("GFO_QT_THREADS") ? atoi(getenv("GFO_QT_THREADS")) : 0;
-    const int nthreads = nt_env ? nt_env : (c->g.lv[0].quota >= 600 || few ? 1024 : 256);
+    const bool nt_ok = nt_env >= 64 && nt_env <= QT_MAX_THREADS && (nt_env & 63) == 0;   // anything else: the default
+    const int nthreads = nt_ok ? nt_env : (c->g.lv[0].quota >= 600 || few ? 1024 : 256);
     static const bool timing = getenv("GFO_QT_TIMING") != nullptr;
     unsigned long long* d_ts = nullptr;
     if (timing && hipMalloc(&d_ts, 128 * sizeof(unsigned long long)) == hipSuccess) (void)hipMemsetAsync(d_ts, 0, 128 * sizeof(unsigned long long), c->stream);

@@ -507,7 +507,8 @@ void gfo_launch_stereo(gfo_ctx* c, const GfoStereoLaunch& s)
     gfo_prof_begin(c, ST_STEREO_BUCKET);
     GFO_LAUNCH(c, k_stereo_bucket, dim3(s.npairs), dim3(1024), (size_t)(s.p.n_rows + 256) * sizeof(int), c->stream, a);
     gfo_prof_end(c);
-    static const int snw = getenv("GFO_STEREO_WAVES") ? atoi(getenv("GFO_STEREO_WAVES")) : 4;   // waves per workgroup, 2 left keypoints each
+    static const int snw_env = getenv("GFO_STEREO_WAVES") ? atoi(getenv("GFO_STEREO_WAVES")) : 4;   // waves per workgroup, 2 left keypoints each
+    const int snw = snw_env < 1 ? 1 : (snw_env > 4 ? 4 : snw_env);                                     // the kernel is built for <= 256 threads
     dim3 grid((max_nl + 2 * snw - 1) / (2 * snw), s.npairs);
     gfo_prof_begin(c, ST_STEREO);
     GFO_LAUNCH(c, k_stereo_match, grid, dim3(64 * snw), 0, c->stream, a);
