@@ -33,7 +33,9 @@ __device__ const int k_umax[16] = {15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 1
 #define OWP 48         // its LDS pitch: three 16-byte segments
 #define OD_STEPS 4     // 10 rows per step: 4 steps cover the 31-row patch and the 37-row window
 
+#ifndef OD_WAVES
 #define OD_WAVES 4   // waves per workgroup, 2 keypoints each (2-wave workgroups measured 5 % slower)
+#endif
 __global__ __launch_bounds__(64 * OD_WAVES) void k_orient_desc(const GfoGeom* __restrict__ gp, GfoInput in,
                                                      const uint8_t* __restrict__ pyr, const uint8_t* __restrict__ blur,
                                                      const uint32_t* __restrict__ sel, const int* __restrict__ sel_cnt,
