@@ -373,11 +373,11 @@ void gfo_launch_fast(gfo_ctx* c, const GfoInput& in, int nimg)
 {
     const GfoGeom& g = c->g;
     if (g.total_cells == 0) return;  // image too small for a single 30-px cell on any level: no candidates
-    // cells (waves) per workgroup.  Alone the kernel is 2-4 % faster with one (a cell's slot is free the moment its wave
-    // ends), but in the running pipeline four-wave workgroups leave more of a CU to the other contexts' kernels:
-    // 206.1k -> 207.8k frames/s (same-box A/B).  Small batches keep one: there the kernel's own time is what counts.
+    // cells (waves) per workgroup: one -- a cell's slot is free the moment its wave ends (166 us against 172 with four).
+    // In the running three-context pipeline four-wave workgroups measured +0.8 % (206.1k -> 207.8k frames/s, same-box
+    // A/B: they leave more of a CU to the other contexts' kernels); not worth 6 us of the kernel's own time.
     static const int nw_env = getenv("GFO_FAST_WAVES") ? atoi(getenv("GFO_FAST_WAVES")) : 0;
-    const int nw = nw_env >= 1 && nw_env <= 4 ? nw_env : (nimg >= 64 ? 4 : 1);
+    const int nw = nw_env >= 1 && nw_env <= 4 ? nw_env : 1;
     const size_t lds = nw * (size_t)(g.fast_tile_pitch * g.fast_tile_rows + ((g.fast_smap_pitch * g.fast_smap_rows + 15) & ~15) + 2 * g.fast_npx_max);
     const int cell_blocks = (g.total_cells + nw - 1) / nw;
     // one image per XCD from 8 images up (below that, 7 of 8 workgroups would be empty: plain grid)
