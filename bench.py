@@ -14,6 +14,8 @@ Inputs are already in HBM when the timed region starts; the steps walk over seve
 no step finds its input in the Infinity Cache.  Independent frames shard one batch per GPU (weak scaling); the only
 collective is the RCCL all-gather of the per-image keypoint counts.  Rank 0 prints ONE JSON line; the other
 BASELINE configs are measured after the headline and reported in the same line under "other_configs".
+roofline.traffic is measured in the run itself (N = 1): two short child passes of this command under
+`rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` before the process initialises the GPU (live_traffic()).
 """
 import argparse
 import ctypes
@@ -71,6 +73,71 @@ def algorithmic_bytes(w, h, sizes, n_kp_img, matcher, m_map=MAP_POINTS):
     }
     survey_total = w * h + 4 * P + n_kp_img * 2178 + stereo_b + project_b
     return d, survey_total
+
+
+STAGE_OF_KERNEL = (("k_resize", "resize"), ("k_pyramid_bands", "resize"), ("k_blur", "blur"), ("k_fast", "fast"), ("k_quadtree", "quadtree"),
+                   ("k_orient_desc", "orient_desc"), ("k_stereo_bucket", "stereo_bucket"), ("k_stereo_match", "stereo_match"),
+                   ("k_stereo_cut", "stereo_cut"), ("k_proj_", "project"))
+# stages whose kernels read 16 bytes per lane: MI355X_MICROARCH.md (HBM): gfx950 tallies such a stream's 128-byte requests
+# at 64 bytes, so FETCH_SIZE is doubled for them; the other stages read 4 bytes per lane and were calibrated at 1.00-1.03x
+# of a known byte count on this code's own access pattern (tools/summarize_profile.py)
+WIDE_READ_STAGES = ("fast", "orient_desc")
+
+
+def live_traffic(workload, batch):
+    """HBM bytes per step and stage from the PMC counters, measured NOW: two child passes of this script under
+    `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` (the two do not fit one pass on gfx950), run before this process
+    touches the GPU.  Returns (per_stage dict, note) -- the dict is None when the profiler is missing, refuses or fails
+    (then the committed profiles/traffic_latest.json is used and labelled as such)."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    if any("rocprof" in (os.environ.get(k) or "").lower() for k in ("LD_PRELOAD", "ROCP_TOOL_LIBRARIES", "ROCPROFILER_LIBRARY")) \
+            or any(k.startswith("ROCPROF") for k in os.environ):
+        return None, "this run is itself under a profiler"
+    exe = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
+    if not exe:
+        return None, "rocprofv3 not found"
+    raw, steps_seen = {}, 0
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        tmp = tempfile.mkdtemp(prefix="gfo_pmc_", dir="/tmp")
+        cmd = [exe, "--pmc", counter, "--output-format", "csv", "-d", tmp, "--", "python3", os.path.join(ROOT, "bench.py"),
+               "--pmc-child", "--workload", workload, "--batch", str(batch), "--steps", "6", "--warmup", "2", "--streams", "1"]
+        env = dict(os.environ, TMPDIR="/tmp")
+        try:
+            r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=420)
+            files = glob.glob(os.path.join(tmp, "**", "*counter_collection.csv"), recursive=True)
+            if r.returncode != 0 or not files:
+                return None, f"rocprofv3 --pmc {counter} pass failed (rc {r.returncode})"
+            per, launches = {}, {}
+            for row in csv.DictReader(open(files[0])):
+                if row.get("Counter_Name") != counter:
+                    continue
+                kn = row["Kernel_Name"]
+                for pat, st in STAGE_OF_KERNEL:
+                    if pat in kn and not (pat == "k_stereo_match" and "sad" in kn):
+                        per[st] = per.get(st, 0.0) + float(row["Counter_Value"]) * 1024.0   # reported in KiB
+                        launches[st] = launches.get(st, 0) + 1
+                        break
+            steps = launches.get("quadtree", 0)     # one k_quadtree launch per step
+            if steps == 0:
+                return None, f"no kernels in the {counter} pass"
+            raw[counter] = {st: v / steps for st, v in per.items()}
+            steps_seen = steps
+        except Exception as ex:   # timeout, unreadable output: the headline must not depend on the profiler
+            return None, f"rocprofv3 --pmc {counter} pass: {ex!r}"
+        finally:
+            shutil.rmtree(tmp, ignore_errors=True)
+    out = {}
+    for st in set(raw["FETCH_SIZE"]) | set(raw["WRITE_SIZE"]):
+        f, w = raw["FETCH_SIZE"].get(st, 0.0), raw["WRITE_SIZE"].get(st, 0.0)
+        out[st] = {"fetch_raw": int(f), "write": int(w), "bytes": int((2.0 * f if st in WIDE_READ_STAGES else f) + w)}
+    return out, (f"measured in this run: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE child passes ({steps_seen} steps each, one context), "
+                 "KiB x 1024, per step; FETCH doubled for the stages that read 16 B per lane "
+                 f"({', '.join(WIDE_READ_STAGES)}) as MI355X_MICROARCH.md prescribes for gfx950")
+
 
 
 def host_cores():
@@ -264,7 +331,7 @@ class Job:
         ext.profile_enable(False)
         return prof
 
-    def roofline(self, prof, nsteps, value_per_gpu, traffic_workload):
+    def roofline(self, prof, nsteps, value_per_gpu, traffic_workload, live=None, live_note=None):
         counts = self.exts[0].batch_counts(self.B)
         n_kp_img = float(counts.mean())
         sizes = level_sizes(self.w, self.h, self.exts[0].GetInverseScaleFactors())
@@ -276,24 +343,26 @@ class Job:
         launches_per_step = dom_launches / max(1, nsteps)
         bytes_per_launch = per_img[dom] * self.B / launches_per_step
         achieved = bytes_per_launch / (avg_launch_ms * 1e-3) / 1e9
-        traffic, traffic_source = None, None
-        tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
-        if os.path.exists(tpath):
+        # HBM traffic per step and stage: measured in this run (live_traffic) when the profiler was available, else the
+        # committed summary of an earlier run of the same command, labelled as such
+        traffic, traffic_source, tj_all, raw_all = None, None, {}, {}
+        if live:
+            tj_all = {k: v["bytes"] for k, v in live.items()}
+            raw_all = {k: {"fetch_raw": v["fetch_raw"], "write": v["write"]} for k, v in live.items()}
+            traffic_source = live_note
+        else:
+            tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
             try:
                 tj = json.load(open(tpath))
                 if tj.get("workload") == traffic_workload and tj.get("batch") == self.B:
-                    traffic = tj.get("hbm_bytes_per_launch", {}).get(dom)
-                    traffic_source = f"profiles/traffic_{tj.get('tag')}.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of an earlier run of this command; not measured in this run)"
+                    x2, rw = tj.get("hbm_bytes_per_launch_fetch_x2", {}), tj.get("hbm_bytes_per_launch", {})
+                    tj_all = {k: (x2.get(k, v) if k in WIDE_READ_STAGES else v) for k, v in rw.items()}
+                    traffic_source = (f"profiles/traffic_{tj.get('tag')}.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of an earlier run of "
+                                      f"this command; not measured in this run: {live_note or 'live measurement off'})")
             except Exception:
-                traffic = None
-        tj_all = {}
-        try:
-            if os.path.exists(tpath):
-                tj0 = json.load(open(tpath))
-                if tj0.get("workload") == traffic_workload and tj0.get("batch") == self.B:
-                    tj_all = tj0.get("hbm_bytes_per_launch", {})
-        except Exception:
-            tj_all = {}
+                tj_all = {}
+        if dom in tj_all:
+            traffic = int(tj_all[dom] / max(launches_per_step, 1e-9))
         per_stage = {}
         for k, ms in stage_ms.items():
             lps = prof[k][1] / max(1, nsteps)
@@ -301,7 +370,7 @@ class Job:
             al = prof[k][0] / prof[k][1]
             per_stage[k] = {"avg_launch_ms": round(al, 4), "launches_per_step": round(lps, 2), "algorithmic_bytes_per_launch": int(bpl),
                             "achieved_GBps": round(bpl / (al * 1e-3) / 1e9, 1), "frac": round(bpl / (al * 1e-3) / 8e12, 5),
-                            "traffic_per_step": tj_all.get(k)}
+                            "traffic_per_step": tj_all.get(k), "traffic_counters_per_step": raw_all.get(k)}
         return n_kp_img, {
             "bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": 8000.0, "unit": "GB/s",
             "frac": round(achieved / 8000.0, 5), "traffic": traffic, "traffic_source": traffic_source,
@@ -330,12 +399,20 @@ def main():
     ap.add_argument("--streams", type=int, default=3,
                     help="independent contexts (arena + HIP stream) the steps alternate between, so the tail of one "
                          "batch overlaps the head of the next")
+    ap.add_argument("--no-live-traffic", action="store_true",
+                    help="do not run the two rocprofv3 --pmc child passes; roofline.traffic then comes from profiles/traffic_latest.json")
+    ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)   # internal: the pass live_traffic() profiles
     args = ap.parse_args()
 
-    import torch
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    # the PMC passes run first, as children, while this process has not touched the GPU yet
+    live, live_note = None, "live measurement off (--no-live-traffic)"
+    if world == 1 and not args.no_live_traffic and not args.pmc_child:
+        live, live_note = live_traffic(args.workload, args.batch - (args.batch & 1))
+
+    import torch
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the product has no CPU path)")
     # rehearsal of the N > 1 control flow on a one-GPU box (tools/rehearse_multirank.sh): every rank on device 0 and
@@ -358,6 +435,10 @@ def main():
     B = args.batch - (args.batch & 1)
     nctx = max(1, args.streams)
     job = Job(G, torch, args.workload, B, nctx, local_rank, rank, world, dist)
+    if args.pmc_child:      # only the kernels are wanted (counters are read per dispatch by the profiler around this process)
+        job.timed(args.steps, args.warmup)
+        job.close()
+        return
     dt = job.timed(args.steps, args.warmup)
     total_frames = world * B * args.steps
     value = total_frames / dt
@@ -391,7 +472,7 @@ def main():
     prof = job.profile(args.profile_steps)
     line = None
     if rank == 0:
-        n_kp_img, roof = job.roofline(prof, args.profile_steps, value / world, args.workload)
+        n_kp_img, roof = job.roofline(prof, args.profile_steps, value / world, args.workload, live, live_note)
         stereo = job.matcher == "stereo"
         line = {
             "metric": "frames/sec ORB extract+match, 752x480 @2000 kp" if args.workload == "stereo752" else f"frames/sec ORB {args.workload}",
