@@ -216,7 +216,15 @@ __global__ __launch_bounds__(256) RESIZE_OCC_ATTR void k_resize(const GfoGeom* _
 // launch that cannot fill the chip).  One 1024-thread workgroup per image computes levels
 // [level_begin, nlevels) back to back: a workgroup barrier orders level l's stores before level l+1's loads
 // (same CU, same L1/L2 path).
-__global__ __launch_bounds__(1024) void k_resize_tail(const GfoGeom* __restrict__ gp, GfoInput in, uint8_t* __restrict__ pyr,
+#ifndef GFO_TAIL_WAVES
+#define GFO_TAIL_WAVES 0
+#endif
+#if GFO_TAIL_WAVES > 0
+#define TAIL_OCC_ATTR __attribute__((amdgpu_waves_per_eu(GFO_TAIL_WAVES, GFO_TAIL_WAVES)))
+#else
+#define TAIL_OCC_ATTR
+#endif
+__global__ __launch_bounds__(1024) TAIL_OCC_ATTR void k_resize_tail(const GfoGeom* __restrict__ gp, GfoInput in, uint8_t* __restrict__ pyr,
                                                       int level_begin, const int2* __restrict__ xtab_all,
                                                       const int2* __restrict__ ytab_all)
 {

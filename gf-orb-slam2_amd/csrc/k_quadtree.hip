@@ -175,7 +175,12 @@ void gfo_launch_quadtree(gfo_ctx* c, int nimg)
     // 1024 threads per (image, level), the 752x480 @2000 case runs best with 256
     static const int nt_env = getenv("GFO_QT_THREADS") ? atoi(getenv("GFO_QT_THREADS")) : 0;
     const bool nt_ok = nt_env >= 64 && nt_env <= QT_MAX_THREADS && (nt_env & 63) == 0;   // anything else: the default
-    const int nthreads = nt_ok ? nt_env : (c->g.lv[0].quota >= 600 || few ? 1024 : 256);
+    // ... and from 48 images on with 128: alone the launch takes 126 instead of 83 us per 128 images, but a two-wave
+    // workgroup that mostly waits at barriers leaves the CU to the blur beside it and to the other contexts' kernels
+    // (stereo752 pipeline 213.7k -> 217.0k frames/s; 192 threads 216.5k, 64 threads 202k)
+    // (large quotas, 1080p @4000: 256 instead of 1024 threads, +1 %)
+    const bool big_quota = c->g.lv[0].quota >= 600, big_batch = nimg >= 48;
+    const int nthreads = nt_ok ? nt_env : (few ? 1024 : (big_quota ? (big_batch ? 256 : 1024) : (big_batch ? 128 : 256)));
     static const bool timing = getenv("GFO_QT_TIMING") != nullptr;
     unsigned long long* d_ts = nullptr;
     if (timing && hipMalloc(&d_ts, 128 * sizeof(unsigned long long)) == hipSuccess) (void)hipMemsetAsync(d_ts, 0, 128 * sizeof(unsigned long long), c->stream);
