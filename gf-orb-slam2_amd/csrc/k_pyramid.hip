@@ -12,6 +12,7 @@
 // The 19-px reflect frame of the reference is never materialised: nothing on the extraction
 // path reads it (gfo_pyramid_level rebuilds it on request).
 #include "gfo_internal.h"
+#include <stdlib.h>
 
 #define RS_STRIP 4
 #define RS_MAXR 6   // source rows a 4-row strip touches at scale factors up to 1.5 (4*1.5 rows)
@@ -235,7 +236,7 @@ __global__ __launch_bounds__(1024) TAIL_OCC_ATTR void k_resize_tail(const GfoGeo
         const int quads = (L.w + 3) >> 2;
         const int strips = (L.h + RS_STRIP - 1) / RS_STRIP;
         const int ntask = quads * strips;
-        for (int t = threadIdx.x; t < ntask; t += 1024) {
+        for (int t = threadIdx.x; t < ntask; t += (int)blockDim.x) {
             const int strip = t / quads;
             resize_plane_block<false>(g, in, pyr, level, img, t - strip * quads, strip, xtab_all, ytab_all);
         }
@@ -319,7 +320,9 @@ void gfo_launch_resize(gfo_ctx* c, const GfoInput& in, int level, int nimg)
 void gfo_launch_resize_tail(gfo_ctx* c, const GfoInput& in, int level_begin, int nimg)
 {
     gfo_prof_begin(c, ST_RESIZE);
-    GFO_LAUNCH(c, k_resize_tail, dim3(nimg), dim3(1024), 0, c->stream, c->d_geom, in, c->d_pyr, level_begin,
+    static const int tt_env = getenv("GFO_TAIL_THREADS") ? atoi(getenv("GFO_TAIL_THREADS")) : 0;
+    const int tail_threads = tt_env >= 64 && tt_env <= 1024 && (tt_env & 63) == 0 ? tt_env : 1024;
+    GFO_LAUNCH(c, k_resize_tail, dim3(nimg), dim3(tail_threads), 0, c->stream, c->d_geom, in, c->d_pyr, level_begin,
                        reinterpret_cast<const int2*>(c->d_xofs), reinterpret_cast<const int2*>(c->d_yofs));
     gfo_prof_end(c);
 }
