@@ -107,10 +107,23 @@ def live_traffic(workload, batch):
                "--pmc-child", "--workload", workload, "--batch", str(batch), "--steps", "6", "--warmup", "2", "--streams", "1"]
         env = dict(os.environ, TMPDIR="/tmp")
         try:
-            r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=420)
+            # a pass takes ~5 s; it gets 75 s (a cold box pages torch in for a minute) and is killed as a GROUP -- rocprofv3
+            # is a launcher, the process that holds the GPU is its child -- so that a stalled profiler can neither delay
+            # the benchmark for long nor sit on the GPU while it is timed
+            proc = subprocess.Popen(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, start_new_session=True)
+            try:
+                rc = proc.wait(timeout=75)
+            except subprocess.TimeoutExpired:
+                import signal
+                try:
+                    os.killpg(proc.pid, signal.SIGKILL)
+                except OSError:
+                    pass
+                proc.wait()
+                return None, f"rocprofv3 --pmc {counter} pass did not finish in 75 s and was killed"
             files = glob.glob(os.path.join(tmp, "**", "*counter_collection.csv"), recursive=True)
-            if r.returncode != 0 or not files:
-                return None, f"rocprofv3 --pmc {counter} pass failed (rc {r.returncode})"
+            if rc != 0 or not files:
+                return None, f"rocprofv3 --pmc {counter} pass failed (rc {rc})"
             per, launches = {}, {}
             for row in csv.DictReader(open(files[0])):
                 if row.get("Counter_Name") != counter:
@@ -403,6 +416,9 @@ def main():
                     help="do not run the two rocprofv3 --pmc child passes; roofline.traffic then comes from profiles/traffic_latest.json")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)   # internal: the pass live_traffic() profiles
     args = ap.parse_args()
+    if os.environ.get("GFO_BENCH_WATCHDOG"):      # diagnosis of a stalled run: dump every thread's stack after N seconds and exit
+        import faulthandler
+        faulthandler.dump_traceback_later(float(os.environ["GFO_BENCH_WATCHDOG"]), exit=True)
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
