@@ -150,13 +150,14 @@ void gfo_launch_quadtree(gfo_ctx* c, int nimg)
 {
     int ncap = 0;
     for (int l = 0; l < c->g.nlevels; l++) ncap = c->g.lv[l].node_cap > ncap ? c->g.lv[l].node_cap : ncap;
-    // keys kept in LDS (6 B each).  Measured on MI355X: 0 (keys in L2, 4 workgroups per CU) beats 6144
-    // (LDS-resident keys, 2 workgroups per CU) -- the kernel is barrier-bound, not load-bound.
-    // A handful of images (the per-frame latency path) is a different regime: 16 workgroups on 256 CUs, the level-0
-    // workgroup IS the critical path, so it gets LDS-resident keys and 1024 threads (0.237 -> 0.214 ms per stereo frame).
+    // keys kept in LDS (6 B each, up to 6144 of them).  Alone, a large batch ran 4 % faster with the keys in L2 (four
+    // workgroups per CU instead of two); in the running pipeline LDS-resident keys win (214.4k -> 219.1k frames/s,
+    // same-box A/B: less L2 traffic next to the other contexts' kernels, and fewer quadtree workgroups per CU leave the
+    // wave slots to kernels that use them).  For a handful of images (the per-frame latency path) the level-0 workgroup IS
+    // the critical path: LDS-resident keys and 1024 threads (0.237 -> 0.214 ms per stereo frame).
     static const int klds_env = getenv("GFO_QT_KLDS") ? atoi(getenv("GFO_QT_KLDS")) : -1;
     const bool few = nimg <= 8;
-    int klds = klds_env >= 0 ? klds_env : (few ? 6144 : 0);
+    int klds = klds_env >= 0 ? klds_env : 6144;
     while (klds > 0 && gfo_quadtree_lds_bytes(ncap, klds) > 150 * 1024) klds -= 1024;
     const size_t lds = gfo_quadtree_lds_bytes(ncap, klds);
     const bool gmem = lds > 160 * 1024;   // state of the largest level does not fit LDS: scratch in HBM (plan() sized it)
@@ -175,12 +176,8 @@ void gfo_launch_quadtree(gfo_ctx* c, int nimg)
     // 1024 threads per (image, level), the 752x480 @2000 case runs best with 256
     static const int nt_env = getenv("GFO_QT_THREADS") ? atoi(getenv("GFO_QT_THREADS")) : 0;
     const bool nt_ok = nt_env >= 64 && nt_env <= QT_MAX_THREADS && (nt_env & 63) == 0;   // anything else: the default
-    // ... and from 48 images on with 128: alone the launch takes 126 instead of 83 us per 128 images, but a two-wave
-    // workgroup that mostly waits at barriers leaves the CU to the blur beside it and to the other contexts' kernels
-    // (stereo752 pipeline 213.7k -> 217.0k frames/s; 192 threads 216.5k, 64 threads 202k)
-    // (large quotas, 1080p @4000: 256 instead of 1024 threads, +1 %)
-    const bool big_quota = c->g.lv[0].quota >= 600, big_batch = nimg >= 48;
-    const int nthreads = nt_ok ? nt_env : (few ? 1024 : (big_quota ? (big_batch ? 256 : 1024) : (big_batch ? 128 : 256)));
+    // (with LDS-resident keys 128 / 192 / 256 threads give the same pipeline rate, 219k; 256 is the fastest alone: 96 us)
+    const int nthreads = nt_ok ? nt_env : (c->g.lv[0].quota >= 600 && nimg < 48 ? 1024 : (few ? 1024 : 256));
     static const bool timing = getenv("GFO_QT_TIMING") != nullptr;
     unsigned long long* d_ts = nullptr;
     if (timing && hipMalloc(&d_ts, 128 * sizeof(unsigned long long)) == hipSuccess) (void)hipMemsetAsync(d_ts, 0, 128 * sizeof(unsigned long long), c->stream);
