@@ -36,6 +36,10 @@ WORKLOADS = {
     "extract1080": (1920, 1080, 4000, None, "configs[3] (extract part): 1920x1080, 4000 features"),
     "proj1080": (1920, 1080, 4000, "project", "configs[3]: 1920x1080 @4000 features, extract + SearchByProjection against a 50k-descriptor synthetic local map"),
 }
+# independent contexts (arena + HIP stream) the steps alternate between, per workload: the measured best on MI355X
+# (same-box A/B, tools/ab_args.sh: stereo752 2/3 contexts 214k/222k, extract752 239k/228k, extract1080 58.9k/60.0k,
+#  proj1080 50.0k/47.3k frames/s) -- how many kernels may share the chip before they only take each other's wave slots
+CONTEXTS = {"stereo752": 3, "extract752": 2, "extract1080": 3, "proj1080": 2}
 FX, BF = 435.2046959714599, 47.90639384423901
 MAP_POINTS = 50000
 
@@ -409,9 +413,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-other-configs", action="store_true", help="skip the short passes over the other BASELINE configs")
     ap.add_argument("--profile-steps", type=int, default=10)
-    ap.add_argument("--streams", type=int, default=3,
+    ap.add_argument("--streams", type=int, default=0,
                     help="independent contexts (arena + HIP stream) the steps alternate between, so the tail of one "
-                         "batch overlaps the head of the next")
+                         "batch overlaps the head of the next (0 = the workload's measured best, CONTEXTS)")
     ap.add_argument("--no-live-traffic", action="store_true",
                     help="do not run the two rocprofv3 --pmc child passes; roofline.traffic then comes from profiles/traffic_latest.json")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)   # internal: the pass live_traffic() profiles
@@ -449,7 +453,7 @@ def main():
     import gf_orb_slam2_amd as G
 
     B = args.batch - (args.batch & 1)
-    nctx = max(1, args.streams)
+    nctx = args.streams if args.streams >= 1 else CONTEXTS[args.workload]   # 0: the workload's default
     job = Job(G, torch, args.workload, B, nctx, local_rank, rank, world, dist)
     if args.pmc_child:      # only the kernels are wanted (counters are read per dispatch by the profiler around this process)
         job.timed(args.steps, args.warmup)
@@ -519,13 +523,13 @@ def main():
                 continue
             try:
                 ob = 64 if WORKLOADS[name][0] > 1000 else B
-                j = Job(G, torch, name, ob, nctx, local_rank, rank, world, dist, n_inputs=2)
+                j = Job(G, torch, name, ob, args.streams if args.streams >= 1 else CONTEXTS[name], local_rank, rank, world, dist, n_inputs=2)
                 steps_o = 20
                 dto = j.timed(steps_o, 3)
                 vo = ob * steps_o / dto
                 p = j.profile(5)
                 _, roof_o = j.roofline(p, 5, vo, name)
-                others.append({"workload": j.cfg_name, "name": name, "value": round(vo, 1), "unit": "frames/s", "images_per_step": ob,
+                others.append({"workload": j.cfg_name, "name": name, "value": round(vo, 1), "unit": "frames/s", "images_per_step": ob, "contexts": j.nctx,
                                "steps": steps_o, "ms_per_step": round(dto / steps_o * 1e3, 4), "roofline": roof_o})
                 j.close()
                 del j
