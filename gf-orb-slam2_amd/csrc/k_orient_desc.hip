@@ -57,8 +57,16 @@ __global__ __launch_bounds__(64 * OD_WAVES) void k_orient_desc(const GfoGeom* __
     // of all eight.  Any placement gives the same results.
     // The grid is (8 * blocks_per_img, ceil(nimg / 8)): x is a multiple of 8, so the flattened workgroup index
     // modulo 8 -- the XCD -- is blockIdx.x & 7, with no division anywhere.
-    const int img = blockIdx.y * 8 + (blockIdx.x & 7), blk = blockIdx.x >> 3;
-    if (img >= nimg) return;   // the last group of 8 may be partly empty
+    const int img_fwd = blockIdx.y * 8 + (blockIdx.x & 7), blk = blockIdx.x >> 3;
+    if (img_fwd >= nimg) return;   // the last group of 8 may be partly empty
+    // Images in DESCENDING order: the blur before this kernel wrote them ascending, and the level + blurred level of a
+    // 128-image batch (286 MB) is a little more than the 256-MB Infinity Cache holds -- walking them in the same
+    // direction would find every image just evicted, walking back finds all but the first few still on the die.
+#ifdef GFO_OD_FORWARD
+    const int img = img_fwd;
+#else
+    const int img = nimg - 1 - img_fwd;
+#endif
     // per-level counts (wave-uniform): a slot's level follows from their prefix; output rows are level by
     // level, list order inside a level (:1144-1161)
     int total = 0;
