@@ -130,6 +130,22 @@ __device__ __forceinline__ void resize_block(const uint8_t* __restrict__ src, in
                     generic = false;
                 }
             }
+            if (!UNI) {
+                // rows differ between the lanes of a wave (k_resize_tail: a wave spans several strips of a small level),
+                // but at scale factors up to 1.33 every lane still has i0 in {j, j+1} and i1 = i0 + 1: ONE select per
+                // value between the two cases instead of the five-deep chains (the clamped last row of a level and
+                // steeper factors take the chains -- a wave-uniform branch)
+                const bool two = i1 == i0 + 1 && (i0 == j || i0 == j + 1);
+                if (__ballot(!two) == 0) {
+                    const bool first = i0 == j;
+#pragma unroll
+                    for (int k = 0; k < 4; k++) {
+                        ra.h[k] = first ? rows[j].h[k] : rows[j + 1].h[k];
+                        rb.h[k] = first ? rows[j + 1].h[k] : rows[j + 2].h[k];
+                    }
+                    generic = false;
+                }
+            }
             if (generic) {
 #pragma unroll
                 for (int k = 0; k < 4; k++) {
