@@ -39,7 +39,12 @@ WORKLOADS = {
 # independent contexts (arena + HIP stream) the steps alternate between, per workload: the measured best on MI355X
 # (same-box A/B, tools/ab_args.sh: stereo752 2/3 contexts 214k/222k, extract752 239k/228k, extract1080 58.9k/60.0k,
 #  proj1080 50.0k/47.3k frames/s) -- how many kernels may share the chip before they only take each other's wave slots
-CONTEXTS = {"stereo752": 3, "extract752": 2, "extract1080": 3, "proj1080": 2}
+CONTEXTS = {"stereo752": 2, "extract752": 2, "extract1080": 3, "proj1080": 2}
+# gfo_ctx_chain stage per workload (0 = free-running): with two contexts the phase between their kernel chains settles at
+# random after every synchronisation -- stereo752 then runs at 214k or 225k frames/s; each context chained after the other's
+# pyramid gives 227k every time (3 free-running contexts: 221k).  extract752's free-running phase is the better one
+# (241k against 232k chained); the 1080p workloads do not care.
+CHAIN_STAGE = {"stereo752": 1, "extract752": 0, "extract1080": 0, "proj1080": 0}
 FX, BF = 435.2046959714599, 47.90639384423901
 MAP_POINTS = 50000
 
@@ -266,6 +271,10 @@ class Job:
             self.streams.append(st)
             self.counts_ts.append(torch.as_tensor(_DevArray(p_cnt.value, B), device="cuda"))
             self.gathered.append(torch.zeros(world * B, dtype=torch.int32, device="cuda") if world > 1 else None)
+        if nctx > 1 and CHAIN_STAGE.get(name, 0) and not os.environ.get("GFO_BENCH_NO_CHAIN"):
+            for k in range(nctx):                       # a ring: context k starts behind context k-1's stage
+                self.exts[k].chain_after(self.exts[(k - 1) % nctx], CHAIN_STAGE[name])
+        self.chained = nctx > 1 and bool(CHAIN_STAGE.get(name, 0)) and not os.environ.get("GFO_BENCH_NO_CHAIN")
         self.bounds = (0.0, 0.0, float(w), float(h))
         self.d_mps = None
         if self.matcher == "project":
@@ -504,6 +513,7 @@ def main():
                        "width": job.w, "height": job.h, "nfeatures": job.nfeat, "levels": 8, "scale_factor": 1.2, "fast_th": [20, 7],
                        "map_points": MAP_POINTS if job.matcher == "project" else None,
                        "mean_keypoints_per_image": round(n_kp_img, 1), "contexts_per_gpu": nctx,
+                       "contexts_chained_after_stage": CHAIN_STAGE[args.workload] if job.chained else None,
                        "distinct_input_batches": len(job.d_inputs),
                        "sharding": f"{world} x independent streams, RCCL all-gather of counts" if world > 1 else "single GPU"},
             "roofline": roof,

@@ -64,7 +64,7 @@ class StageTime(C.Structure):
 # every symbol include/gfo.h declares (tests check the library exports all of them)
 SYMBOLS = [
     "gfo_version", "gfo_ctx_create", "gfo_ctx_destroy", "gfo_last_error", "gfo_ctx_set_stream",
-    "gfo_ctx_synchronize", "gfo_ctx_tables", "gfo_ctx_max_keypoints", "gfo_extract", "gfo_extract_batch",
+    "gfo_ctx_synchronize", "gfo_ctx_chain", "gfo_ctx_tables", "gfo_ctx_max_keypoints", "gfo_extract", "gfo_extract_batch",
     "gfo_extract_stereo", "gfo_extract_batch_device", "gfo_batch_counts", "gfo_batch_fetch", "gfo_batch_device_views",
     "gfo_compute_pyramid", "gfo_pyramid_level", "gfo_hamming256", "gfo_stereo_match",
     "gfo_stereo_match_batch", "gfo_stereo_match_sad_batch", "gfo_stereo_fetch", "gfo_search_by_projection", "gfo_search_by_projection_queries",
@@ -156,6 +156,7 @@ def load_library():
     L.gfo_last_error.restype = C.c_char_p
     L.gfo_ctx_set_stream.argtypes = [vp, vp]
     L.gfo_ctx_synchronize.argtypes = [vp]
+    L.gfo_ctx_chain.argtypes = [vp, vp, C.c_int]
     L.gfo_ctx_tables.argtypes = [vp, vp, vp, vp, vp, vp]
     L.gfo_ctx_max_keypoints.argtypes = [vp]
     L.gfo_extract.argtypes = [vp, vp, i, i, i, vp, vp, i, ip]

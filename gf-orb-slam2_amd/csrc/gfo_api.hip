@@ -10,6 +10,11 @@
 #include <string.h>
 
 static std::string g_create_err;
+// live contexts, for gfo_ctx_chain's edges (a destroyed context must disappear from the others' `chain_after`)
+#include <mutex>
+#include <vector>
+static std::mutex g_ctx_mu;
+static std::vector<gfo_ctx*> g_ctx_live;
 
 static int fail(gfo_ctx* c, int code, const char* fmt, ...)
 {
@@ -491,6 +496,10 @@ extern "C" int gfo_ctx_create(const gfo_params* p, int device, gfo_ctx** out)
     c->prm = *p;
     if (c->prm.max_batch < 1) c->prm.max_batch = 1;
     c->device = device;
+    {
+        std::lock_guard<std::mutex> lk(g_ctx_mu);
+        g_ctx_live.push_back(c);
+    }
     if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess) {
         delete c;
         return fail(nullptr, GFO_ERR_DEVICE, "hipStreamCreate failed");
@@ -529,6 +538,14 @@ extern "C" void gfo_ctx_destroy(gfo_ctx* c)
         (void)hipStreamSynchronize(c->side_stream);
         (void)hipStreamDestroy(c->side_stream);
     }
+    {
+        std::lock_guard<std::mutex> lk(g_ctx_mu);
+        for (size_t i = 0; i < g_ctx_live.size(); i++)
+            if (g_ctx_live[i] == c) { g_ctx_live.erase(g_ctx_live.begin() + i); break; }
+        for (gfo_ctx* o : g_ctx_live)
+            if (o->chain_after == c) o->chain_after = nullptr;
+    }
+    if (c->ev_pace) (void)hipEventDestroy(c->ev_pace);
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
@@ -549,6 +566,32 @@ extern "C" int gfo_ctx_synchronize(gfo_ctx* c)
     if (!c) return GFO_ERR_INVALID;
     HIP_TRY(c, hipSetDevice(c->device));   // the calling thread may be on another device
     HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return GFO_OK;
+}
+
+extern "C" int gfo_ctx_chain(gfo_ctx* c, gfo_ctx* after, int stage)
+{
+    if (!c) return GFO_ERR_INVALID;
+    std::lock_guard<std::mutex> lk(g_ctx_mu);
+    if (!after) {
+        c->chain_after = nullptr;
+        return GFO_OK;
+    }
+    if (after == c || stage < GFO_STAGE_PYRAMID || stage > GFO_STAGE_DESCRIPTORS) return fail(c, GFO_ERR_INVALID, "gfo_ctx_chain: bad context or stage");
+    bool live = false;
+    for (gfo_ctx* o : g_ctx_live) live = live || o == after;
+    if (!live) return fail(c, GFO_ERR_INVALID, "gfo_ctx_chain: `after` is not a live context");
+    if (after->device != c->device) return fail(c, GFO_ERR_INVALID, "gfo_ctx_chain: the two contexts are on different devices");
+    if (!after->ev_pace) {
+        (void)hipSetDevice(after->device);
+        if (hipEventCreateWithFlags(&after->ev_pace, hipEventDisableTiming) != hipSuccess) {
+            (void)hipGetLastError();
+            after->ev_pace = nullptr;
+            return fail(c, GFO_ERR_DEVICE, "gfo_ctx_chain: hipEventCreate failed");
+        }
+    }
+    after->pace_stage = stage;
+    c->chain_after = after;
     return GFO_OK;
 }
 
@@ -647,8 +690,19 @@ static GfoStereoLaunch stereo_batch_launch(gfo_ctx* c, const gfo_stereo_params& 
 // the launches of one extraction (+ the stereo association of its pairs when sp is given), in stream order
 static int extract_launches(gfo_ctx* c, const GfoInput& in, int nimg, const gfo_stereo_params* sp, const GfoPack* pack)
 {
+    // gfo_ctx_chain: start behind the stage event of the context this one is chained after (work already submitted there)
+    if (gfo_ctx* a = c->chain_after)
+        if (a->ev_pace && a->pace_recorded) HIP_TRY(c, hipStreamWaitEvent(c->stream, a->ev_pace, 0));
+#define GFO_PACE_POINT(S)                                                    \
+    do {                                                                     \
+        if (c->pace_stage == (S) && c->ev_pace) {                            \
+            HIP_TRY(c, hipEventRecord(c->ev_pace, c->stream));               \
+            c->pace_recorded = true;                                         \
+        }                                                                    \
+    } while (0)
     HIP_TRY(c, hipMemsetAsync(c->d_cand_cnt, 0, sizeof(int) * nimg * c->g.nlevels * GFO_CNT_STRIDE, c->stream));
     run_pyramid(c, in, nimg);
+    GFO_PACE_POINT(GFO_STAGE_PYRAMID);
     // fork: the blur (vector-pipe bound) next to FAST and the quadtree (the latter mostly barrier waits); join
     // before the descriptors.  Per-kernel profiling and debug runs keep everything in one stream.
     const bool fork = c->fork_blur && !c->profiling && !c->debug_sync;
@@ -657,6 +711,7 @@ static int extract_launches(gfo_ctx* c, const GfoInput& in, int nimg, const gfo_
         // chip with the quadtree, whose workgroups mostly wait at barriers
         hipStream_t main_stream = c->stream;
         gfo_launch_fast(c, in, nimg);
+        GFO_PACE_POINT(GFO_STAGE_FAST);
         HIP_TRY(c, hipEventRecord(c->ev_fork, main_stream));
         HIP_TRY(c, hipStreamWaitEvent(c->side_stream, c->ev_fork, 0));
         gfo_launch_quadtree(c, nimg);
@@ -669,11 +724,15 @@ static int extract_launches(gfo_ctx* c, const GfoInput& in, int nimg, const gfo_
         // same order as the forked form (FAST reads the levels while the pyramid kernel's output is still cache-resident;
         // with the blur in between it measured 190 instead of 165 us), so that per-kernel profiles describe the real pipeline
         gfo_launch_fast(c, in, nimg);
+        GFO_PACE_POINT(GFO_STAGE_FAST);
         gfo_launch_quadtree(c, nimg);
         gfo_launch_blur(c, in, nimg);
     }
+    GFO_PACE_POINT(GFO_STAGE_SELECT);
     // nothing that consumes the selection may run if a stage before it was refused
     if (c->launch_err.empty()) gfo_launch_orient_desc(c, in, nimg);
+    GFO_PACE_POINT(GFO_STAGE_DESCRIPTORS);
+#undef GFO_PACE_POINT
     if (c->launch_err.empty() && sp) {
         c->last_nimg = nimg;
         gfo_launch_stereo(c, stereo_batch_launch(c, *sp));
@@ -705,7 +764,8 @@ static int run_extract(gfo_ctx* c, const GfoInput& in, int nimg, const gfo_stere
 {
     static const int graph_max_img = getenv("GFO_GRAPH_MAX_IMAGES") ? atoi(getenv("GFO_GRAPH_MAX_IMAGES")) : 8;
     bool done = false;
-    if (c->graph_ok && !c->profiling && !c->debug_sync && nimg <= graph_max_img && in.base == c->d_input && c->stream == c->own_stream) {
+    if (c->graph_ok && !c->profiling && !c->debug_sync && nimg <= graph_max_img && in.base == c->d_input && c->stream == c->own_stream &&
+        !c->chain_after && !c->pace_stage) {   // (a chained context orders itself against another context's events: not capturable)
         gfo_ctx::GraphKey key{};
         key.base = in.base; key.pitch = in.pitch; key.img_stride = in.img_stride; key.nimg = nimg; key.stereo = sp ? 1 : 0;
         if (sp) key.sp = *sp;

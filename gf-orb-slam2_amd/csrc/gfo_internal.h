@@ -147,6 +147,12 @@ struct gfo_ctx {
     // FAST and the quadtree (fork / join by events); all work is still ordered on `stream` for the caller
     hipStream_t side_stream = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    // gfo_ctx_chain: this context's extractions wait for `chain_after`'s pace event; `pace_stage` != 0 means some
+    // context waits on THIS one, which then records ev_pace after that stage of every extraction
+    gfo_ctx* chain_after = nullptr;
+    hipEvent_t ev_pace = nullptr;
+    int pace_stage = 0;
+    bool pace_recorded = false;
     bool fork_blur = true;
     std::string err;
     std::string launch_err;

@@ -64,6 +64,15 @@ class ORBextractor:
     def synchronize(self):
         check(self._L, self._ctx, self._L.gfo_ctx_synchronize(self._ctx))
 
+    STAGE_PYRAMID, STAGE_FAST, STAGE_SELECT, STAGE_DESCRIPTORS = 1, 2, 3, 4
+
+    def chain_after(self, other, stage=1):
+        """gfo_ctx_chain: every extraction submitted to this extractor starts on the device only after the extraction most
+        recently submitted to `other` has finished `stage` (None removes the edge).  For applications that alternate
+        batches between extractors; changes no result."""
+        h = other.handle if other is not None else None
+        check(self._L, self._ctx, self._L.gfo_ctx_chain(self._ctx, h, int(stage)))
+
     # operator()
     def __call__(self, image, mask=None):
         if image is None or image.size == 0:

@@ -143,3 +143,31 @@ def test_graph_replay_opt_in(oracle, euroc_l):
         kp, d = ext(euroc_l)
         assert kp.tobytes() == ok.tobytes() and (d == od).all()
     ext.close()
+
+
+def test_chained_contexts_give_the_same_results_and_survive_destruction(oracle):
+    """gfo_ctx_chain: an ordering edge between two contexts' submissions changes no result, refuses nonsense, and an edge
+    to a destroyed context is gone rather than dangling."""
+    import gf_orb_slam2_amd as G
+    imgs = [synth_frame(320, 240, 900 + i) for i in range(4)]
+    a = G.ORBextractor(500, 1.2, 8, 20, 7, max_batch=2)
+    b = G.ORBextractor(500, 1.2, 8, 20, 7, max_batch=2)
+    ref = [oracle.OracleExtractor(500, 1.2, 8, 20, 7)(im) for im in imgs]
+    for stage in (1, 2, 3, 4):
+        a.chain_after(b, stage)
+        b.chain_after(a, stage)
+        for rep in range(3):                       # alternate, as a pipelined application does
+            ka, da = a.extract_batch(imgs[:2])
+            kb, db = b.extract_batch(imgs[2:])
+            for i in range(2):
+                assert ka[i].tobytes() == ref[i][0].tobytes() and (da[i] == ref[i][1]).all()
+                assert kb[i].tobytes() == ref[2 + i][0].tobytes() and (db[i] == ref[2 + i][1]).all()
+    with pytest.raises(G.GfoError):
+        a.chain_after(a, 1)
+    with pytest.raises(G.GfoError):
+        a.chain_after(b, 9)
+    b.close()                                      # a's edge to b must not dangle
+    ka, da = a.extract_batch(imgs[:2])
+    assert ka[0].tobytes() == ref[0][0].tobytes()
+    a.chain_after(None)
+    a.close()
