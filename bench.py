@@ -271,10 +271,12 @@ class Job:
             self.streams.append(st)
             self.counts_ts.append(torch.as_tensor(_DevArray(p_cnt.value, B), device="cuda"))
             self.gathered.append(torch.zeros(world * B, dtype=torch.int32, device="cuda") if world > 1 else None)
-        if nctx > 1 and CHAIN_STAGE.get(name, 0) and not os.environ.get("GFO_BENCH_NO_CHAIN"):
+        # (GFO_BENCH_CHAIN=<stage> overrides the table for experiments; 0 = free-running)
+        self.chain_stage = int(os.environ["GFO_BENCH_CHAIN"]) if os.environ.get("GFO_BENCH_CHAIN") else CHAIN_STAGE.get(name, 0)
+        self.chained = nctx > 1 and self.chain_stage > 0
+        if self.chained:
             for k in range(nctx):                       # a ring: context k starts behind context k-1's stage
-                self.exts[k].chain_after(self.exts[(k - 1) % nctx], CHAIN_STAGE[name])
-        self.chained = nctx > 1 and bool(CHAIN_STAGE.get(name, 0)) and not os.environ.get("GFO_BENCH_NO_CHAIN")
+                self.exts[k].chain_after(self.exts[(k - 1) % nctx], self.chain_stage)
         self.bounds = (0.0, 0.0, float(w), float(h))
         self.d_mps = None
         if self.matcher == "project":
@@ -513,7 +515,7 @@ def main():
                        "width": job.w, "height": job.h, "nfeatures": job.nfeat, "levels": 8, "scale_factor": 1.2, "fast_th": [20, 7],
                        "map_points": MAP_POINTS if job.matcher == "project" else None,
                        "mean_keypoints_per_image": round(n_kp_img, 1), "contexts_per_gpu": nctx,
-                       "contexts_chained_after_stage": CHAIN_STAGE[args.workload] if job.chained else None,
+                       "contexts_chained_after_stage": job.chain_stage if job.chained else None,
                        "distinct_input_batches": len(job.d_inputs),
                        "sharding": f"{world} x independent streams, RCCL all-gather of counts" if world > 1 else "single GPU"},
             "roofline": roof,
