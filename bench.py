@@ -274,9 +274,7 @@ class Job:
         # (GFO_BENCH_CHAIN=<stage> overrides the table for experiments; 0 = free-running)
         self.chain_stage = int(os.environ["GFO_BENCH_CHAIN"]) if os.environ.get("GFO_BENCH_CHAIN") else CHAIN_STAGE.get(name, 0)
         self.chained = nctx > 1 and self.chain_stage > 0
-        if self.chained:
-            for k in range(nctx):                       # a ring: context k starts behind context k-1's stage
-                self.exts[k].chain_after(self.exts[(k - 1) % nctx], self.chain_stage)
+        self.chain(True)
         self.bounds = (0.0, 0.0, float(w), float(h))
         self.d_mps = None
         if self.matcher == "project":
@@ -287,6 +285,14 @@ class Job:
                 m.map_upload(mpd)                                                      # one resident map per context
         self.step_no = 0
         self.nctx = nctx
+
+    def chain(self, on):
+        """(un)chain the contexts in a ring: context k starts behind context k-1's stage"""
+        if not self.chained:
+            return
+        n = len(self.exts)
+        for k in range(n):
+            self.exts[k].chain_after(self.exts[(k - 1) % n] if on else None, self.chain_stage)
 
     def step(self, ctx=None, h2d_from=None):
         k = self.step_no % self.nctx if ctx is None else ctx
@@ -486,7 +492,9 @@ def main():
         # PCIe-inclusive rate (never `value`): every step first copies its batch from pinned host memory
         pinned = torch.from_numpy(job.host_batches[0]).pin_memory()
         n_h = max(5, min(args.steps, 30))
+        job.chain(False)      # the copies already pace the contexts; chained on top of that they serialise (77k against 111k)
         dth = job.timed(n_h, 2, h2d_from=pinned)
+        job.chain(True)
         extra["value_with_h2d"] = round(B * n_h / dth, 1)
         del pinned
         # median of 20 single batches, one context, each batch synchronised
