@@ -544,8 +544,8 @@ def main():
             try:
                 ob = 64 if WORKLOADS[name][0] > 1000 else B
                 j = Job(G, torch, name, ob, args.streams if args.streams >= 1 else CONTEXTS[name], local_rank, rank, world, dist, n_inputs=2)
-                steps_o = 20
-                dto = j.timed(steps_o, 3)
+                steps_o = 100
+                dto = j.timed(steps_o, 15)   # (the chip needs ~15 launches after an idle period to return to its running clock)
                 vo = ob * steps_o / dto
                 p = j.profile(5)
                 _, roof_o = j.roofline(p, 5, vo, name)
