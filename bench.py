@@ -93,6 +93,24 @@ STAGE_OF_KERNEL = (("k_resize", "resize"), ("k_pyramid_bands", "resize"), ("k_bl
 WIDE_READ_STAGES = ("fast", "orient_desc")
 
 
+def pmc_bytes_per_step(csv_path, counter):
+    """rocprofv3 counter_collection.csv -> ({stage: bytes per step}, steps).  FETCH_SIZE / WRITE_SIZE come in KiB per
+    dispatch; a stage may be several launches per step (the pyramid), a step is one k_quadtree launch."""
+    import csv
+    per, launches = {}, {}
+    for row in csv.DictReader(open(csv_path)):
+        if row.get("Counter_Name") != counter:
+            continue
+        kn = row["Kernel_Name"]
+        for pat, st in STAGE_OF_KERNEL:
+            if pat in kn and not (pat == "k_stereo_match" and "sad" in kn):
+                per[st] = per.get(st, 0.0) + float(row["Counter_Value"]) * 1024.0
+                launches[st] = launches.get(st, 0) + 1
+                break
+    steps = launches.get("quadtree", 0)
+    return ({st: v / steps for st, v in per.items()} if steps else {}), steps
+
+
 def live_traffic(workload, batch):
     """HBM bytes per step and stage from the PMC counters, measured NOW: two child passes of this script under
     `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` (the two do not fit one pass on gfx950), run before this process
@@ -133,20 +151,10 @@ def live_traffic(workload, batch):
             files = glob.glob(os.path.join(tmp, "**", "*counter_collection.csv"), recursive=True)
             if rc != 0 or not files:
                 return None, f"rocprofv3 --pmc {counter} pass failed (rc {rc})"
-            per, launches = {}, {}
-            for row in csv.DictReader(open(files[0])):
-                if row.get("Counter_Name") != counter:
-                    continue
-                kn = row["Kernel_Name"]
-                for pat, st in STAGE_OF_KERNEL:
-                    if pat in kn and not (pat == "k_stereo_match" and "sad" in kn):
-                        per[st] = per.get(st, 0.0) + float(row["Counter_Value"]) * 1024.0   # reported in KiB
-                        launches[st] = launches.get(st, 0) + 1
-                        break
-            steps = launches.get("quadtree", 0)     # one k_quadtree launch per step
+            per_step, steps = pmc_bytes_per_step(files[0], counter)
             if steps == 0:
                 return None, f"no kernels in the {counter} pass"
-            raw[counter] = {st: v / steps for st, v in per.items()}
+            raw[counter] = per_step
             steps_seen = steps
         except Exception as ex:   # timeout, unreadable output: the headline must not depend on the profiler
             return None, f"rocprofv3 --pmc {counter} pass: {ex!r}"
