@@ -43,7 +43,7 @@ struct StereoArgs {
     int out_stride;
     // bucketed right side, [pairs][sort_stride]
     float* sx;
-    float* sy;
+    unsigned* sband;          // row band minr | maxr << 16 of the bucketed right keypoint
     unsigned* soi;            // octave << 16 | iR
     uint4* sdesc;             // 2 x uint4 per keypoint
     int* row_start;           // [pairs][n_rows + 1]
@@ -121,7 +121,11 @@ __global__ __launch_bounds__(1024) void k_stereo_bucket(StereoArgs a)
         const int b = min(max((int)floorf(k.y), 0), nRows - 1);
         const int pos = atomicAdd(&s_hist[b], 1);
         a.sx[so + pos] = k.x;
-        a.sy[so + pos] = k.y;
+        // the row band of this right keypoint (Frame.h:248-256), once here instead of once per left keypoint that visits it
+        const float rr = 2.0f * a.scale[k.octave];
+        const int maxr = (int)fminf((float)(nRows - 1), ceilf(k.y + rr));
+        const int minr = (int)fmaxf(0.0f, floorf(k.y - rr));
+        a.sband[so + pos] = (unsigned)minr | ((unsigned)maxr << 16);   // n_rows <= 65535 (checked by the launcher)
         a.soi[so + pos] = ((unsigned)k.octave << 16) | (unsigned)i;
         a.sdesc[2 * (so + pos)] = dr[2 * i];
         a.sdesc[2 * (so + pos) + 1] = dr[2 * i + 1];
@@ -167,14 +171,10 @@ __global__ __launch_bounds__(256) void k_stereo_match(StereoArgs a)
     unsigned best = ((unsigned)TH_HIGH << 16);  // bestDist = TH_HIGH, iR = 0: only dist < TH_HIGH replaces it
     bool any = false;
     for (int j = jb + hl; j < je; j += 32) {
-        const float ry = a.sy[so + j];
+        const unsigned band = a.sband[so + j];   // row band of this right keypoint, packed by k_stereo_bucket
         const unsigned oi = a.soi[so + j];
         const int oct = (int)(oi >> 16);
-        // Frame.h:248-256 row band of this right keypoint
-        const float r = 2.0f * a.scale[oct];
-        const int maxr = (int)fminf((float)(nRows - 1), ceilf(ry + r));
-        const int minr = (int)fmaxf(0.0f, floorf(ry - r));
-        if (row < minr || row > maxr) continue;
+        if (row < (int)(band & 0xFFFF) || row > (int)(band >> 16)) continue;
         any = true;
         if (oct < L.octave - 1 || oct > L.octave + 1) continue;  // :1250
         const float rx = a.sx[so + j];
@@ -307,12 +307,10 @@ __global__ __launch_bounds__(256) void k_stereo_match_sad(SadArgs A)
         const int jb = rs[max(row - a.window, 0)], je = rs[min(row + a.window + 1, nRows)];
         unsigned best = ((unsigned)TH_HIGH << 16);
         for (int j = jb + lane; j < je; j += 64) {
-            const float ry = a.sy[so + j];
+            const unsigned band = a.sband[so + j];   // :910-916 (clamped), packed by k_stereo_bucket
             const unsigned oi = a.soi[so + j];
             const int oct = (int)(oi >> 16);
-            const float r = 2.0f * a.scale[oct];
-            const int maxr = min((int)ceilf(ry + r), nRows - 1), minr = max((int)floorf(ry - r), 0);  // :910-916 (clamped)
-            if (row < minr || row > maxr) continue;
+            if (row < (int)(band & 0xFFFF) || row > (int)(band >> 16)) continue;
             if (oct < L.octave - 1 || oct > L.octave + 1) continue;
             const float rx = a.sx[so + j];
             if (rx >= minU && rx <= maxU) {
@@ -459,7 +457,7 @@ void gfo_launch_stereo_sad(gfo_ctx* c, const GfoStereoLaunch& s, const GfoInput&
     a.p = s.p;
     a.min_d = nullptr; a.max_d = nullptr;
     a.out = s.out; a.out_stride = s.out_stride;
-    a.sx = s.sort.sx; a.sy = s.sort.sy; a.soi = s.sort.soi; a.sdesc = reinterpret_cast<uint4*>(s.sort.sdesc);
+    a.sx = s.sort.sx; a.sband = reinterpret_cast<unsigned*>(s.sort.sy); a.soi = s.sort.soi; a.sdesc = reinterpret_cast<uint4*>(s.sort.sdesc);
     a.row_start = s.sort.row_start;
     a.sort_stride = s.sort_stride;
     a.window = s.window;
@@ -495,7 +493,7 @@ void gfo_launch_stereo(gfo_ctx* c, const GfoStereoLaunch& s)
     a.p = s.p;
     a.min_d = s.min_d; a.max_d = s.max_d;
     a.out = s.out; a.out_stride = s.out_stride;
-    a.sx = s.sort.sx; a.sy = s.sort.sy; a.soi = s.sort.soi; a.sdesc = reinterpret_cast<uint4*>(s.sort.sdesc);
+    a.sx = s.sort.sx; a.sband = reinterpret_cast<unsigned*>(s.sort.sy); a.soi = s.sort.soi; a.sdesc = reinterpret_cast<uint4*>(s.sort.sdesc);
     a.row_start = s.sort.row_start;
     a.sort_stride = s.sort_stride;
     a.window = s.window;
