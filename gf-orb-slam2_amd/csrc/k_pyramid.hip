@@ -66,7 +66,7 @@ template <bool UNI, bool BAND>
 __device__ __forceinline__ void resize_block(const uint8_t* __restrict__ src, int spitch, int srow0, int srow_hi, int sh, int sw,
                                              uint8_t* __restrict__ dstg, int gpitch, int own0, int own1,
                                              uint8_t* __restrict__ dstl, int lpitch, int lrow0, int row_end, int quad,
-                                             int dy0, const int2* __restrict__ xtab, const int2* __restrict__ ytab)
+                                             int dy0, const int2* __restrict__ xtab, const int2* __restrict__ ytab, int over_mode)
 {
     const int dx0 = quad * 4;
     const int4* xt = reinterpret_cast<const int4*>(xtab + dx0);
@@ -80,14 +80,20 @@ __device__ __forceinline__ void resize_block(const uint8_t* __restrict__ src, in
         sel[k] = rel | (0x0Cu << 8) | ((rel + 1u) << 16) | (0x0Cu << 24);  // selector 0x0C = constant zero byte
     }
     const int base_x = sx[0] & ~3;
-    // eight bytes from sx[0] must cover sx[3]+1 (scale factors up to 2), twelve from base_x stay inside the row
-    const bool fast = (sx[3] + 1 - sx[0]) < 8 && base_x + 12 <= sw;
     const int dy1 = min(dy0 + RS_STRIP, row_end);   // rows [dy0, dy1) of the level
     const int4* yt = reinterpret_cast<const int4*>(ytab + dy0);
     const int4 ya = yt[0], yb = yt[1];
     const int syv[4] = {ya.x, ya.z, yb.x, yb.z};
     const int bw[4] = {ya.y, ya.w, yb.y, yb.w};
     const int r_first = min(max(syv[0], 0), sh - 1);
+    // The 12-byte row window: eight bytes from sx[0] must cover sx[3]+1 (scale factors up to 2), and the twelve from
+    // base_x must be readable.  Inside the row they are; in the last quad(s) of a row they run up to 11 bytes past it,
+    // into the next row -- harmless (the selectors never pick those bytes) wherever a next row or arena slack exists:
+    // over_mode 1 = the source is a pyramid plane of the arena (256 bytes of slack behind the last one), 2 = the source
+    // is the caller's image: allowed unless one of the rows this block loads is the image's last, 0 = never (LDS bands).
+    // Without this the last quads take the byte path, and a wave holding one of them (one in two or three) runs BOTH.
+    const bool over = over_mode == 1 || (over_mode == 2 && r_first + RS_MAXR - 1 < sh - 1);
+    const bool fast = (sx[3] + 1 - sx[0]) < 8 && (base_x + 12 <= sw || over);
     const int r_last = min(max(syv[dy1 - dy0 - 1] + 1, 0), sh - 1);
     src -= (long long)srow0 * spitch;
     if (r_last - r_first < RS_MAXR) {
@@ -199,7 +205,7 @@ __device__ __forceinline__ void resize_plane_block(const GfoGeom& g, const GfoIn
     const int sh = g.lv[level - 1].h, sw = g.lv[level - 1].w;
     uint8_t* dst = pyr + (long long)img * g.pyr_img_stride + L.plane_off;
     resize_block<UNI, false>(src, spitch, 0, sh - 1, sh, sw, dst, L.pitch, 0, L.h, nullptr, 0, 0, L.h, quad, strip * RS_STRIP,
-                             xtab_all + L.xtab_off, ytab_all + L.ytab_off);
+                             xtab_all + L.xtab_off, ytab_all + L.ytab_off, level - 1 == 0 ? 2 : 1);
 }
 
 // register budget of the per-level kernel (the 1080p path: its levels do not fit the banded form): 8 waves per SIMD =
@@ -309,11 +315,11 @@ __global__ __launch_bounds__(1024) BANDS_OCC_ATTR void k_pyramid_bands(const Gfo
                 int spitch;
                 const uint8_t* src = gfo_level_ptr(g, in, pyr, lb - 1, img, &spitch);
                 resize_block<true, true>(src, spitch, 0, sh - 1, sh, sw, dstg, L.pitch, rg.z, rg.w, dstl, lp, rg.x, rg.y, quad,
-                                         dy0, xt, yt);
+                                         dy0, xt, yt, lb - 1 == 0 ? 2 : 1);
             } else {
                 const uint8_t* src = band_lds + g.band_lds_off[level - 1];
                 resize_block<true, true>(src, g.band_lp[level - 1], below.x, below.y - 1, sh, sw, dstg, L.pitch, rg.z, rg.w, dstl,
-                                         lp, rg.x, rg.y, quad, dy0, xt, yt);
+                                         lp, rg.x, rg.y, quad, dy0, xt, yt, 0);
             }
         }
         below = rg;
