@@ -523,6 +523,13 @@ extern "C" int gfo_ctx_create(const gfo_params* p, int device, gfo_ctx** out)
 extern "C" void gfo_ctx_destroy(gfo_ctx* c)
 {
     if (!c) return;
+    {   // first: no other context may start a new wait on this one's events (gfo_ctx_chain)
+        std::lock_guard<std::mutex> lk(g_ctx_mu);
+        for (size_t i = 0; i < g_ctx_live.size(); i++)
+            if (g_ctx_live[i] == c) { g_ctx_live.erase(g_ctx_live.begin() + i); break; }
+        for (gfo_ctx* o : g_ctx_live)
+            if (o->chain_after == c) o->chain_after = nullptr;
+    }
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     prof_collect(c);
@@ -537,13 +544,6 @@ extern "C" void gfo_ctx_destroy(gfo_ctx* c)
     if (c->side_stream) {
         (void)hipStreamSynchronize(c->side_stream);
         (void)hipStreamDestroy(c->side_stream);
-    }
-    {
-        std::lock_guard<std::mutex> lk(g_ctx_mu);
-        for (size_t i = 0; i < g_ctx_live.size(); i++)
-            if (g_ctx_live[i] == c) { g_ctx_live.erase(g_ctx_live.begin() + i); break; }
-        for (gfo_ctx* o : g_ctx_live)
-            if (o->chain_after == c) o->chain_after = nullptr;
     }
     if (c->ev_pace) (void)hipEventDestroy(c->ev_pace);
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
