@@ -700,8 +700,12 @@ static int extract_launches(gfo_ctx* c, const GfoInput& in, int nimg, const gfo_
             c->pace_recorded = true;                                         \
         }                                                                    \
     } while (0)
-    HIP_TRY(c, hipMemsetAsync(c->d_cand_cnt, 0, sizeof(int) * nimg * c->g.nlevels * GFO_CNT_STRIDE, c->stream));
+    c->zero_cnt_pending = true;     // cleared by the first pyramid kernel; by a fill only when there is none (one level)
     run_pyramid(c, in, nimg);
+    if (c->zero_cnt_pending) {
+        c->zero_cnt_pending = false;
+        HIP_TRY(c, hipMemsetAsync(c->d_cand_cnt, 0, sizeof(int) * nimg * c->g.nlevels * GFO_CNT_STRIDE, c->stream));
+    }
     GFO_PACE_POINT(GFO_STAGE_PYRAMID);
     // fork: the blur (vector-pipe bound) next to FAST and the quadtree (the latter mostly barrier waits); join
     // before the descriptors.  Per-kernel profiling and debug runs keep everything in one stream.

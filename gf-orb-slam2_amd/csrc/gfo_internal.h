@@ -147,6 +147,7 @@ struct gfo_ctx {
     // FAST and the quadtree (fork / join by events); all work is still ordered on `stream` for the caller
     hipStream_t side_stream = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    bool zero_cnt_pending = false;   // the next pyramid launch clears the candidate counters (k_pyramid.hip)
     // gfo_ctx_chain: this context's extractions wait for `chain_after`'s pace event; `pace_stage` != 0 means some
     // context waits on THIS one, which then records ev_pace after that stage of every extraction
     gfo_ctx* chain_after = nullptr;
@@ -233,6 +234,13 @@ struct gfo_ctx {
 };
 
 // ---- kernel launchers (each in its own .hip file) ------------------------------------------
+// the candidate-counter pointer for the first pyramid launch of an extraction (nullptr afterwards)
+inline int* gfo_take_zero_cnt(gfo_ctx* c)
+{
+    if (!c->zero_cnt_pending) return nullptr;
+    c->zero_cnt_pending = false;
+    return c->d_cand_cnt;
+}
 void gfo_launch_resize(gfo_ctx* c, const GfoInput& in, int level, int nimg);
 void gfo_launch_resize_tail(gfo_ctx* c, const GfoInput& in, int level_begin, int nimg);
 size_t gfo_quadtree_lds_bytes(int ncap, int klds);

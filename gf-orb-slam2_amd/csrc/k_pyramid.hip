@@ -193,6 +193,13 @@ __device__ __forceinline__ void resize_block(const uint8_t* __restrict__ src, in
     }
 }
 
+// The first pyramid launch of an extraction also clears the per-(image, level) candidate counters FAST appends to
+// (one word each, a 128-byte line apart): a separate 5-us fill kernel per batch otherwise.
+__device__ __forceinline__ void zero_candidate_counters(int* __restrict__ zero_cnt, int img, int nlevels, int tid)
+{
+    if (zero_cnt && tid < nlevels) zero_cnt[(img * nlevels + tid) * GFO_CNT_STRIDE] = 0;
+}
+
 // Whole-plane form: level `level` of image `img` from the plane below it in HBM.
 template <bool UNI>
 __device__ __forceinline__ void resize_plane_block(const GfoGeom& g, const GfoInput& in, uint8_t* __restrict__ pyr, int level,
@@ -220,9 +227,10 @@ __device__ __forceinline__ void resize_plane_block(const GfoGeom& g, const GfoIn
 #endif
 __global__ __launch_bounds__(256) RESIZE_OCC_ATTR void k_resize(const GfoGeom* __restrict__ gp, GfoInput in, uint8_t* __restrict__ pyr,
                                                 int level, const int2* __restrict__ xtab_all,
-                                                const int2* __restrict__ ytab_all)
+                                                const int2* __restrict__ ytab_all, int* __restrict__ zero_cnt)
 {
     const GfoGeom& g = *gp;
+    if (blockIdx.x == 0) zero_candidate_counters(zero_cnt, blockIdx.y, g.nlevels, threadIdx.x);
     const GfoLevel& L = g.lv[level];
     const int quads = (L.w + 3) >> 2;
     const int strips = (L.h + RS_STRIP - 1) / RS_STRIP;
@@ -249,10 +257,11 @@ __global__ __launch_bounds__(256) RESIZE_OCC_ATTR void k_resize(const GfoGeom* _
 #endif
 __global__ __launch_bounds__(1024) TAIL_OCC_ATTR void k_resize_tail(const GfoGeom* __restrict__ gp, GfoInput in, uint8_t* __restrict__ pyr,
                                                       int level_begin, const int2* __restrict__ xtab_all,
-                                                      const int2* __restrict__ ytab_all)
+                                                      const int2* __restrict__ ytab_all, int* __restrict__ zero_cnt)
 {
     const GfoGeom& g = *gp;
     const int img = blockIdx.x;
+    zero_candidate_counters(zero_cnt, img, g.nlevels, threadIdx.x);
     for (int level = level_begin; level < g.nlevels; level++) {
         const GfoLevel& L = g.lv[level];
         const int quads = (L.w + 3) >> 2;
@@ -286,11 +295,12 @@ __global__ __launch_bounds__(1024) TAIL_OCC_ATTR void k_resize_tail(const GfoGeo
 #endif
 __global__ __launch_bounds__(1024) BANDS_OCC_ATTR void k_pyramid_bands(const GfoGeom* __restrict__ gp, GfoInput in, uint8_t* __restrict__ pyr,
                                                         const int2* __restrict__ xtab_all, const int2* __restrict__ ytab_all,
-                                                        const int4* __restrict__ band_tab, int lb, int le)
+                                                        const int4* __restrict__ band_tab, int lb, int le, int* __restrict__ zero_cnt)
 {
     extern __shared__ __align__(16) uint8_t band_lds[];
     const GfoGeom& g = *gp;
     const int band = blockIdx.x, img = blockIdx.y, nl = g.nlevels;
+    if (band == 0) zero_candidate_counters(zero_cnt, img, nl, threadIdx.x);
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int nwaves = blockDim.x >> 6;
     int4 below = make_int4(0, 0, 0, 0);
@@ -335,7 +345,7 @@ void gfo_launch_resize(gfo_ctx* c, const GfoInput& in, int level, int nimg)
     dim3 grid((waves + 3) / 4, nimg);
     gfo_prof_begin(c, ST_RESIZE);
     GFO_LAUNCH(c, k_resize, grid, dim3(256), 0, c->stream, c->d_geom, in, c->d_pyr, level,
-                       reinterpret_cast<const int2*>(c->d_xofs), reinterpret_cast<const int2*>(c->d_yofs));
+                       reinterpret_cast<const int2*>(c->d_xofs), reinterpret_cast<const int2*>(c->d_yofs), gfo_take_zero_cnt(c));
     gfo_prof_end(c);
 }
 
@@ -345,7 +355,7 @@ void gfo_launch_resize_tail(gfo_ctx* c, const GfoInput& in, int level_begin, int
     static const int tt_env = getenv("GFO_TAIL_THREADS") ? atoi(getenv("GFO_TAIL_THREADS")) : 0;
     const int tail_threads = tt_env >= 64 && tt_env <= 1024 && (tt_env & 63) == 0 ? tt_env : 1024;
     GFO_LAUNCH(c, k_resize_tail, dim3(nimg), dim3(tail_threads), 0, c->stream, c->d_geom, in, c->d_pyr, level_begin,
-                       reinterpret_cast<const int2*>(c->d_xofs), reinterpret_cast<const int2*>(c->d_yofs));
+                       reinterpret_cast<const int2*>(c->d_xofs), reinterpret_cast<const int2*>(c->d_yofs), gfo_take_zero_cnt(c));
     gfo_prof_end(c);
 }
 
@@ -364,7 +374,7 @@ void gfo_launch_pyramid_bands(gfo_ctx* c, const GfoInput& in, int nimg)
         const int threads = bt_ok ? c->band_threads : (bg.nb * nimg >= 2048 ? 256 : 512);
         GFO_LAUNCH(c, k_pyramid_bands, dim3(bg.nb, nimg), dim3(threads), bg.lds_bytes, c->stream, c->d_geom, in,
                            c->d_pyr, reinterpret_cast<const int2*>(c->d_xofs), reinterpret_cast<const int2*>(c->d_yofs),
-                           reinterpret_cast<const int4*>(c->d_band) + bg.tab_off, bg.lb, bg.le);
+                           reinterpret_cast<const int4*>(c->d_band) + bg.tab_off, bg.lb, bg.le, gfo_take_zero_cnt(c));
         gfo_prof_end(c);
     }
 }
