@@ -20,7 +20,7 @@
 
 // Geometry of one pyramid level, shared by host planning and every kernel (passed by value).
 #ifndef GFO_BLUR_STRIP
-#define GFO_BLUR_STRIP 32   // rows a blur thread walks (6 halo rows each): shared by plan() and k_blur
+#define GFO_BLUR_STRIP 24   // rows a blur thread walks (6 halo rows each): shared by plan() and k_blur
 #endif
 
 struct GfoLevel {
