@@ -200,3 +200,28 @@ def test_stereo_frame_in_one_submission(oracle, euroc_l, euroc_r):
     ok, od = oe(euroc_l)
     assert k0.tobytes() == ok.tobytes() and (d0 == od).all()
     ext.close()
+
+
+def test_chained_contexts_alternate_stereo_frames(oracle, euroc_l, euroc_r):
+    """Two contexts alternating stereo frames as a pipelined application does, chained behind each other's pyramid
+    (gfo_ctx_chain): every frame equals the unchained result, whichever context served it."""
+    import gf_orb_slam2_amd as G
+    prm = G.StereoParams(480, 47.90639384423901, 47.90639384423901 / 435.2046959714599, 0.0)
+    exts = [G.ORBextractor(1000, 1.2, 8, 20, 7, max_batch=2) for _ in range(3)]
+    ms = [G.ORBmatcher(0.8, True, extractor=e) for e in exts]
+    (rkl, rkr), (rdl, rdr) = exts[2].extract_batch([euroc_l, euroc_r])     # unchained reference run
+    ms[2].stereo_match_batch(prm)
+    ref = ms[2].stereo_fetch(0, max(len(rkl), 1))
+    exts[0].chain_after(exts[1], exts[0].STAGE_PYRAMID)
+    exts[1].chain_after(exts[0], exts[1].STAGE_PYRAMID)
+    for it in range(6):
+        k = it & 1
+        (kl, kr), (dl, dr) = exts[k].extract_batch([euroc_l, euroc_r])
+        ms[k].stereo_match_batch(prm)
+        got = ms[k].stereo_fetch(0, max(len(kl), 1))
+        assert kl.tobytes() == rkl.tobytes() and kr.tobytes() == rkr.tobytes() and (dl == rdl).all() and (dr == rdr).all()
+        assert got[0] == ref[0]
+        for a, b in zip(got[1:], ref[1:]):
+            assert a.tobytes() == b.tobytes()
+    for e in exts:
+        e.close()
