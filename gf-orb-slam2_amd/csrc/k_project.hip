@@ -225,7 +225,9 @@ __device__ __forceinline__ void accept_rule(const ProjB& a, int e1, int e2, int*
 // for a 50 000-point map most lanes keep none; phase 2 fetches, for every kept item at once, what the remaining
 // filters need (taken on entry, mvuRight gate, `blocked(i)`, the keypoint's descriptor) and offers the survivors to
 // `sink(key)`.  Items beyond PJ_HOLD are finished on the spot (contended maps only).
+#ifndef PJ_HOLD
 #define PJ_HOLD 4
+#endif
 template <class StartT, class Blocked, class Sink>
 __device__ __forceinline__ void scan_candidates(const ProjB& a, int f, int n, int iq, const ProjQ& q, const StartT* cell_start,
                                                 const float2* cell_xy, const unsigned* cell_meta, Blocked blocked, Sink sink)
