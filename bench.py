@@ -170,6 +170,27 @@ def live_traffic(workload, batch):
 
 
 
+def side_config(name, batch, streams):
+    """One of the other BASELINE configs: THIS command with --workload <name> in a process of its own (400 steps), its
+    line condensed.  A fresh process because the rate depends on which hardware queue the runtime binds every stream to
+    on first use: a second job in a process that has already run one inherits a worse assignment (extract752 233k against
+    249k, proj1080 46.5k against 51.2k frames/s, measured both ways)."""
+    import subprocess
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--workload", name, "--batch", str(batch), "--steps", "400", "--warmup", "30",
+           "--streams", str(streams), "--no-other-configs", "--no-cpu-baseline", "--no-live-traffic", "--profile-steps", "5"]
+    try:
+        r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=240)
+        lines = [l for l in r.stdout.decode(errors="replace").splitlines() if l.startswith("{")]
+        if r.returncode != 0 or not lines:
+            return {"name": name, "error": f"child process failed (rc {r.returncode})"}
+        j = json.loads(lines[-1])
+        return {"workload": j["config"]["workload"], "name": name, "value": j["value"], "unit": "frames/s", "images_per_step": batch,
+                "contexts": j["config"]["contexts_per_gpu"], "steps": j["steps"], "ms_per_step": j["ms_per_step"],
+                "process": "its own (same command with --workload)", "roofline": j["roofline"]}
+    except Exception as ex:      # a failing side measurement must not lose the headline line
+        return {"name": name, "error": repr(ex)}
+
+
 def host_cores():
     try:
         return len(os.sched_getaffinity(0))
@@ -549,21 +570,8 @@ def main():
         for name in ("extract752", "extract1080", "proj1080", "stereo752"):
             if name == args.workload:
                 continue
-            try:
-                ob = 64 if WORKLOADS[name][0] > 1000 else B
-                j = Job(G, torch, name, ob, args.streams if args.streams >= 1 else CONTEXTS[name], local_rank, rank, world, dist, n_inputs=2)
-                steps_o = 100
-                dto = j.timed(steps_o, 15)   # (the chip needs ~15 launches after an idle period to return to its running clock)
-                vo = ob * steps_o / dto
-                p = j.profile(5)
-                _, roof_o = j.roofline(p, 5, vo, name)
-                others.append({"workload": j.cfg_name, "name": name, "value": round(vo, 1), "unit": "frames/s", "images_per_step": ob, "contexts": j.nctx,
-                               "steps": steps_o, "ms_per_step": round(dto / steps_o * 1e3, 4), "roofline": roof_o})
-                j.close()
-                del j
-                torch.cuda.empty_cache()
-            except Exception as ex:   # a failing side measurement must not lose the headline line
-                others.append({"name": name, "error": repr(ex)})
+            ob = 64 if WORKLOADS[name][0] > 1000 else B
+            others.append(side_config(name, ob, args.streams))
         line["other_configs"] = others
 
     if rank == 0:
