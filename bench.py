@@ -13,7 +13,11 @@ workload (stereo association of every pair / SearchByProjection of every frame a
 Inputs are already in HBM when the timed region starts; the steps walk over several distinct input batches so that
 no step finds its input in the Infinity Cache.  Independent frames shard one batch per GPU (weak scaling); the only
 collective is the RCCL all-gather of the per-image keypoint counts.  Rank 0 prints ONE JSON line; the other
-BASELINE configs are measured after the headline and reported in the same line under "other_configs".
+BASELINE configs are measured after the headline (the same command with --workload, each in a process of its own) and
+reported in the same line under "other_configs".
+The steps alternate between a few independent contexts (arena + HIP stream; CONTEXTS per workload), for stereo752 two of
+them chained behind each other's pyramid (gfo_ctx_chain).  Setup ends with PRIME_STEPS untimed batches (clock ramp of a
+fresh process, config.priming_steps); --warmup is run as given, untimed, directly in front of the timed steps.
 roofline.traffic is measured in the run itself (N = 1): two short child passes of this command under
 `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` before the process initialises the GPU (live_traffic()).
 """
