@@ -98,6 +98,12 @@ STAGE_OF_KERNEL = (("k_resize", "resize"), ("k_pyramid_bands", "resize"), ("k_bl
 WIDE_READ_STAGES = ("fast", "orient_desc")
 
 
+def under_profiler():
+    """rocprofv3 (or a tool built on rocprofiler) is wrapped around this process: child processes would inherit it"""
+    return any("rocprof" in (os.environ.get(k) or "").lower() for k in ("LD_PRELOAD", "ROCP_TOOL_LIBRARIES", "ROCPROFILER_LIBRARY")) \
+        or any(k.startswith("ROCPROF") for k in os.environ)
+
+
 def pmc_bytes_per_step(csv_path, counter):
     """rocprofv3 counter_collection.csv -> ({stage: bytes per step}, steps).  FETCH_SIZE / WRITE_SIZE come in KiB per
     dispatch; a stage may be several launches per step (the pyramid), a step is one k_quadtree launch."""
@@ -126,8 +132,7 @@ def live_traffic(workload, batch):
     import shutil
     import subprocess
     import tempfile
-    if any("rocprof" in (os.environ.get(k) or "").lower() for k in ("LD_PRELOAD", "ROCP_TOOL_LIBRARIES", "ROCPROFILER_LIBRARY")) \
-            or any(k.startswith("ROCPROF") for k in os.environ):
+    if under_profiler():
         return None, "this run is itself under a profiler"
     exe = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
     if not exe:
@@ -579,7 +584,9 @@ def main():
     torch.cuda.empty_cache()
 
     # ---- the other BASELINE configs, short passes, same line ----
-    if world == 1 and not args.no_other_configs:
+    if world == 1 and not args.no_other_configs and under_profiler():
+        line["other_configs"] = "skipped: this run is under a profiler (they run as child processes of this command)"
+    elif world == 1 and not args.no_other_configs:
         others = []
         for name in ("extract752", "extract1080", "proj1080", "stereo752"):
             if name == args.workload:
