@@ -625,15 +625,16 @@ static int run_pyramid(gfo_ctx* c, const GfoInput& in, int nimg)
     // big levels: one launch each (they fill the chip); the small top levels: one fused launch, one workgroup
     // per image (each of them alone is latency-bound)
     static const int tail_px = getenv("GFO_RESIZE_TAIL_PX") ? atoi(getenv("GFO_RESIZE_TAIL_PX")) : 60000;  // measured: fusing levels of <= 60k px wins, larger ones lose
-    // The banded form (one launch per level group, levels chained through LDS) for batches below 48 images: it beats
-    // seven dependent launches for a single stereo pair (38 vs 47 us) and up to 32 images (169.5k vs 166k frames/s).
+    // The banded form (one launch per level group, levels chained through LDS) for batches below 32 images.
     // From 64 images on the per-level kernels win IN THE PIPELINE although they are slower alone (127 vs 116 us per 128
     // images) and move more bytes: they hold no LDS and 64 registers, so the other contexts' kernels run beside them
     // (same-box A/B, stereo752: 64 images 190.3k -> 201.3k, 128 images 205.2k -> 214.0k, 256 images 210.5k -> 211.7k).
     // GFO_PYR_BAND_MIN_WG (workgroups a launch must have) and GFO_PYR_BAND_MAX_IMG let the tests force either path.
     const char* bm = getenv("GFO_PYR_BAND_MIN_WG");
     const int band_min_wg = bm ? atoi(bm) : 0;
-    static const int band_max_img = getenv("GFO_PYR_BAND_MAX_IMG") ? atoi(getenv("GFO_PYR_BAND_MAX_IMG")) : 48;
+    // (after the row-window change in k_resize the per-level form also wins at 32 images -- 179.5k vs 176k; for one frame
+    //  or one stereo pair the two forms are within the run-to-run spread of the latency harness, +-4 %)
+    static const int band_max_img = getenv("GFO_PYR_BAND_MAX_IMG") ? atoi(getenv("GFO_PYR_BAND_MAX_IMG")) : 32;
     if (c->g.pyr_nb > 0 && nimg * c->g.pyr_nb >= band_min_wg && nimg < band_max_img) {
         gfo_launch_pyramid_bands(c, in, nimg);
         c->last_in = in;

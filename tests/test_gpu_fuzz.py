@@ -42,7 +42,7 @@ def test_random_extractions_match_oracle(oracle, monkeypatch, seed):
         ini = int(rng.integers(5, 60))
         mn = int(rng.integers(1, ini + 1))
         img = _random_image(rng, w, h, int(rng.integers(0, 5)))
-        monkeypatch.setenv("GFO_PYR_BAND_MIN_WG", "0" if it % 2 == 0 else "100000000")
+        monkeypatch.setenv("GFO_PYR_BAND_MIN_WG", "1" if it % 2 == 0 else "100000000")   # banded (forced: a single image takes the per-level form by default) / per-level
         monkeypatch.setenv("GFO_PYR_LDS_KB", str(int(rng.choice([8, 16, 32, 64]))))
         monkeypatch.setenv("GFO_PYR_MAX_W", "100000")
         monkeypatch.setenv("GFO_PYR_MAX_OVERHEAD", "100")

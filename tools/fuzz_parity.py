@@ -43,7 +43,7 @@ for it in range(cases):
         img = ((xx * 255 // max(w - 1, 1) + yy * 255 // max(h - 1, 1)) // 2).astype(np.uint8)
         idx = rng.integers(0, h * w, max(h * w // 200, 1))
         img.reshape(-1)[idx] = rng.integers(0, 256, len(idx), dtype=np.uint8)
-    os.environ["GFO_PYR_BAND_MIN_WG"] = "0" if it % 2 == 0 else "100000000"
+    os.environ["GFO_PYR_BAND_MIN_WG"] = "1" if it % 2 == 0 else "100000000"   # banded (forced) / per-level
     os.environ["GFO_PYR_LDS_KB"] = str(int(rng.choice([8, 16, 32, 64])))
     os.environ["GFO_PYR_MAX_W"] = "100000"
     os.environ["GFO_PYR_MAX_OVERHEAD"] = "100"
