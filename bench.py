@@ -43,7 +43,7 @@ WORKLOADS = {
 # independent contexts (arena + HIP stream) the steps alternate between, per workload: the measured best on MI355X
 # (same-box A/B, tools/ab_args.sh: stereo752 2/3 contexts 214k/222k, extract752 239k/228k, extract1080 58.9k/60.0k,
 #  proj1080 50.0k/47.3k frames/s) -- how many kernels may share the chip before they only take each other's wave slots
-PRIME_STEPS = 24   # untimed batches at the end of Job setup (clock ramp of a fresh process, see Job.__init__)
+PRIME_STEPS = 48   # untimed batches at the end of Job setup (clock ramp of a fresh process, see Job.__init__)
 CONTEXTS = {"stereo752": 2, "extract752": 2, "extract1080": 3, "proj1080": 2}
 # gfo_ctx_chain stage per workload (0 = free-running): with two contexts the phase between their kernel chains settles at
 # random after every synchronisation -- stereo752 then runs at 214k or 225k frames/s; each context chained after the other's
