@@ -46,7 +46,17 @@ __device__ __forceinline__ unsigned pmax(unsigned a, unsigned b)
 {
     return __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(s16x2, a), __builtin_bit_cast(s16x2, b)));
 }
-__device__ __forceinline__ unsigned rot16(unsigned a) { return __builtin_amdgcn_alignbit(a, a, 16); }
+// the two halves swapped: written as a vector shuffle (not v_alignbit) so that instruction selection can fold it into the
+// op_sel bits of the packed operation that consumes it -- pmin(a, rot16(a)) is ONE v_pk_min_i16 with op_sel, no rotation
+__device__ __forceinline__ unsigned rot16(unsigned a)
+{
+#ifdef GFO_FAST_ALIGNBIT_ROT
+    return __builtin_amdgcn_alignbit(a, a, 16);
+#else
+    const s16x2 v = __builtin_bit_cast(s16x2, a);
+    return __builtin_bit_cast(unsigned, __builtin_shufflevector(v, v, 1, 0));
+#endif
+}
 
 // Score of a pixel = max over the sixteen 9-arcs of min(sign * d) (sign = +1 dark, -1 bright), computed with two
 // ring positions (k, k+8) per register in packed i16: the arc minima for k and k+8 come out of one op.  The
