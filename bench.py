@@ -139,6 +139,8 @@ def live_traffic(workload, batch):
         return None, "rocprofv3 not found"
     raw, steps_seen = {}, 0
     for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        if counter == "WRITE_SIZE":
+            time.sleep(2.0)     # both stalls of a PMC pass seen in this project began within a second of the previous session's end
         tmp = tempfile.mkdtemp(prefix="gfo_pmc_", dir="/tmp")
         cmd = [exe, "--pmc", counter, "--output-format", "csv", "-d", tmp, "--", "python3", os.path.join(ROOT, "bench.py"),
                "--pmc-child", "--workload", workload, "--batch", str(batch), "--steps", "6", "--warmup", "2", "--streams", "1"]
