@@ -20,7 +20,16 @@
 #include "../../include/gfo_sincos.h"
 
 // the 256 test pairs as floats (one 16-byte load per lane and round, no integer -> float conversion in the loop)
-struct PatQuad { float x0, y0, x1, y1; };
+// In memory the two x and the two y of a test pair sit side by side, as the packed-fp32 operands want them (three register
+// moves per round otherwise); the table file lists (x0, y0, x1, y1), the constructor reorders at compile time.
+struct PatQuad {
+#ifdef GFO_OD_FILE_ORDER
+    float x0, y0, x1, y1;
+#else
+    float x0, x1, y0, y1;
+#endif
+    constexpr PatQuad(float ax0, float ay0, float ax1, float ay1) : x0(ax0), x1(ax1), y0(ay0), y1(ay1) {}
+};
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 __device__ const PatQuad k_pattern[256] = {
 #include "../../include/gfo_pattern.inc"
