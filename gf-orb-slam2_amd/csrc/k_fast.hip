@@ -91,8 +91,11 @@ __device__ __forceinline__ int corner_score(const uint8_t* __restrict__ c, int t
     // opposite pair (k, k+8), so "all eight pairs hold a pixel darker than v - t" is necessary for it -- and when both
     // polarities pass that test no pair has two members of one sign, so neither has a 9-arc and either choice scores
     // <= t.  18 packed ops for the whole wave instead of a second scoring pass (~100).
-    bool neg = !dark;
-    if (__ballot(dark && bright) != 0) {
+    // (lane masks in scalar registers from here on: as per-lane bools the compiler carried them through the branch as 0 / 1
+    //  integers and paid half a dozen vector selects and compares to turn them back into masks)
+    const unsigned long long m_dark = __builtin_amdgcn_ballot_w64(dark), m_bright = __builtin_amdgcn_ballot_w64(bright);
+    unsigned long long m_neg = ~m_dark;
+    if ((m_dark & m_bright) != 0) {
         unsigned m8 = __builtin_bit_cast(unsigned, __builtin_elementwise_min(hi08, hi4c));   // pairs 0 and 4, both halves alike
 #pragma unroll
         for (int k = 1; k < 8; k++) {
@@ -100,10 +103,11 @@ __device__ __forceinline__ int corner_score(const uint8_t* __restrict__ c, int t
             const unsigned dk = __builtin_bit_cast(unsigned, D[k]);
             m8 = pmin(m8, pmax(dk, rot16(dk)));
         }
-        const bool all8dark = (int)(short)(m8 & 0xFFFF) > tq;
-        if (dark && bright) neg = !all8dark;
+        const unsigned long long m_all8 = __builtin_amdgcn_ballot_w64((int)(short)(m8 & 0xFFFF) > tq);
+        m_neg |= m_bright & ~m_all8;       // dark && bright: bright polarity unless all eight pairs can still be dark
     }
-    const bool run = dark || bright;
+    const bool neg = __builtin_amdgcn_inverse_ballot_w64(m_neg);
+    const bool run = __builtin_amdgcn_inverse_ballot_w64(m_dark | m_bright);
     int best = 0;
     {
         const s16x2 sg = __builtin_bit_cast(s16x2, neg ? 0xFFFFFFFFu : 0x00010001u);
@@ -300,7 +304,7 @@ __global__ __launch_bounds__(256) void k_fast(const GfoGeom* __restrict__ gp, Gf
 #pragma unroll
             for (int j = 0; j < 4; j++) {
                 const bool pass = (passbits & (1u << j)) != 0;
-                const unsigned long long m = __ballot(pass);
+                const unsigned long long m = __builtin_amdgcn_ballot_w64(pass);
                 // slot = na + (passing lanes below this one): v_mbcnt accumulates onto the running count
                 if (__builtin_amdgcn_inverse_ballot_w64(m)) qa[__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, (unsigned)na))] = (unsigned short)(p0 + j);
                 na += __popcll(m);
@@ -323,7 +327,7 @@ __global__ __launch_bounds__(256) void k_fast(const GfoGeom* __restrict__ gp, Gf
             sc = corner_score<TP>(t0 + py * TP + px, tq);   // every lane (idle ones re-score entry 0's pixel: wave votes inside)
             const bool corner = i < na && sc > tq;
             if (corner) smap[(py + 1) * SP + px + 1] = (uint8_t)sc;
-            const unsigned long long m = __ballot(corner);
+            const unsigned long long m = __builtin_amdgcn_ballot_w64(corner);   // (the mask itself: __ballot goes through a 0 / 1 integer)
             if (__builtin_amdgcn_inverse_ballot_w64(m))
                 qb[__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, (unsigned)nb))] = (unsigned short)p;
             nb += __popcll(m);
@@ -355,7 +359,7 @@ __global__ __launch_bounds__(256) void k_fast(const GfoGeom* __restrict__ gp, Gf
             const int x = px + 3 + cj * wcell, y = py + 3 + ci * hcell;  // ORBextractor.cc:824-825
             key = (uint32_t)x | ((uint32_t)y << 12) | ((uint32_t)(s - 1) << 24);
         }
-        const unsigned long long m = __ballot(mx);
+        const unsigned long long m = __builtin_amdgcn_ballot_w64(mx);
         if (__builtin_amdgcn_inverse_ballot_w64(m))
             keyq[__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, (unsigned)n_max))] = key;
         n_max += __popcll(m);
