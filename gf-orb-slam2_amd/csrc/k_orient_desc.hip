@@ -208,7 +208,7 @@ __global__ __launch_bounds__(64 * OD_WAVES) void k_orient_desc(const GfoGeom* __
         const f32x2 fy = (px * b + py * a) + magic, fx = (px * a - py * b) + magic;
         const unsigned iy0 = __float_as_uint(fy.x), ix0 = __float_as_uint(fx.x), iy1 = __float_as_uint(fy.y), ix1 = __float_as_uint(fx.y);
         const int t0 = win[iy0 * (unsigned)DWP + ix0 + wbase], t1 = win[iy1 * (unsigned)DWP + ix1 + wbase];   // u32 arithmetic: the biases cancel
-        const unsigned long long m = __ballot(t0 < t1);
+        const unsigned long long m = __builtin_amdgcn_ballot_w64(t0 < t1);
         word = hl == r ? (unsigned)(m >> (32 * half)) : word;  // tests 32r..32r+31 of THIS half's keypoint
     }
     if (!act) return;

@@ -298,11 +298,11 @@ __device__ __forceinline__ void scan_candidates(const ProjB& a, int f, int n, in
 #ifdef GFO_PROJ_DEBUG
     if (a.dbg_stop == 2) { if (nh == 12345) sink(0ull); return; }   // tools/pmc_proj_phases.sh: stop after the grid scan
 #endif
-    if (__ballot(nh > 0) == 0) return;
+    if (__builtin_amdgcn_ballot_w64(nh > 0) == 0) return;
     if (nh > 0) need_desc();
 #pragma unroll
     for (int s0 = 0; s0 < PJ_HOLD; s0 += 2) {
-        if (s0 > 0 && __ballot(nh > s0) == 0) break;
+        if (s0 > 0 && __builtin_amdgcn_ballot_w64(nh > s0) == 0) break;
         // two items per step: their loads are independent and go out together
         finish(nh > s0, hold[s0]);
         finish(nh > s0 + 1, hold[s0 + 1]);
@@ -381,7 +381,7 @@ __global__ __launch_bounds__(LDSGRID ? 1024 : 256, 8) void k_proj_round0(ProjB a
                 }
             }
         }
-        const unsigned long long mask = __ballot(live);
+        const unsigned long long mask = __builtin_amdgcn_ballot_w64(live);
         if (mask == 0) continue;
         const int leader = __ffsll((long long)mask) - 1;
         int base = 0;

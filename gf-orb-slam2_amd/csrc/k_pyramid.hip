@@ -142,7 +142,7 @@ __device__ __forceinline__ void resize_block(const uint8_t* __restrict__ src, in
                 // value between the two cases instead of the five-deep chains (the clamped last row of a level and
                 // steeper factors take the chains -- a wave-uniform branch)
                 const bool two = i1 == i0 + 1 && (i0 == j || i0 == j + 1);
-                if (__ballot(!two) == 0) {
+                if (__builtin_amdgcn_ballot_w64(!two) == 0) {
                     const bool first = i0 == j;
 #pragma unroll
                     for (int k = 0; k < 4; k++) {

@@ -183,7 +183,7 @@ __global__ __launch_bounds__(256) void k_stereo_match(StereoArgs a)
             best = min(best, (dist << 16) | (oi & 0xFFFF));      // first minimum in iR order (:1260)
         }
     }
-    const unsigned long long anym = __ballot(any);
+    const unsigned long long anym = __builtin_amdgcn_ballot_w64(any);
     const bool have_cands = ((anym >> (32 * half)) & 0xFFFFFFFFull) != 0;
 #pragma unroll
     for (int s = 16; s > 0; s >>= 1) best = min(best, (unsigned)__shfl_xor((int)best, s));  // inside the half
