@@ -264,16 +264,17 @@ __global__ __launch_bounds__(256) void k_fast(const GfoGeom* __restrict__ gp, Gf
         const unsigned valid_hi = 0xFu >> (3 - ((X0 + sw - 1) & 3));        // last dword: pixels right of scan column sw-1
         // only the first and the last dword of a row can hold pixels outside the scan columns
         const unsigned valid = (q == q_lo ? valid_lo : 0xFu) & (q == q_hi ? valid_hi : 0xFu);
+        // the same four bits at the positions the compass test leaves its results in (14, 15, 30, 31)
+        const unsigned valid_sign = ((valid & 3u) << 14) | ((valid & 12u) << 28);
         int idx = (lr + 3) * tp4 + q;
         for (int y0 = 0; y0 < sh; y0 += rpi, idx += rpi * tp4) {
             const int py = y0 + lr;
-            unsigned passbits = 0;  // bit j: pixel j of the dword passes
+            unsigned sign = 0;      // pixel0 -> bit 14, pixel1 -> bit 15, pixel2 -> bit 30, pixel3 -> bit 31: the pixel passes
             if (lane_on && py < sh) {
                 const unsigned C = t32[idx], Wm = t32[idx - 1], Wp = t32[idx + 1];
                 const unsigned U = t32[idx + 3 * tp4], D = t32[idx - 3 * tp4];
                 const unsigned Lw = __builtin_amdgcn_alignbyte(C, Wm, 1);   // pixels at column-3
                 const unsigned Rw = __builtin_amdgcn_alignbyte(Wp, C, 3);   // pixels at column+3
-                unsigned sign = 0;
 #pragma unroll
                 for (int h = 0; h < 2; h++) {  // h = 0: bytes 0,2   h = 1: bytes 1,3
                     // one v_perm_b32 per operand spreads bytes (h, h+2) into two u16 (selector 0x0C = zero byte)
@@ -293,20 +294,23 @@ __global__ __launch_bounds__(256) void k_fast(const GfoGeom* __restrict__ gp, Gf
                     const unsigned sg = __builtin_bit_cast(unsigned, t1) & 0x80008000u;
                     sign |= sg >> (h ? 0 : 1);  // h=0 -> bits 14,30 ; h=1 -> bits 15,31
                 }
-                // sign bits: pixel0 -> bit14, pixel1 -> bit15, pixel2 -> bit30, pixel3 -> bit31
-                passbits = ((sign >> 14) & 3u) | ((sign >> 28) & 12u);
-                passbits &= valid;
+                sign &= valid_sign;   // pixels of the first / last dword that lie outside the scan columns
             }
             // (measured alternative: gathering the pass bits of all iterations per lane and letting every lane pop its
             //  lowest set bit per round -- survivors cluster, the busiest lane holds 8-12 of them, and the rounds cost
             //  more than these four ballots per iteration: 386 vs 373 vector instructions per cell for stage A)
             const int p0 = (py << 6) + c0;   // queue entry: px | py << 6 (cells are at most 64 px wide)
+            // The four pass bits are tested where they are -- bits 31 and 15 are the sign bits of the word and of its low half,
+            // bits 30 and 14 those of the word shifted left by one: four compares instead of compressing them into a nibble
+            // and extracting them again.  The slot is the count of passing lanes below this one (v_mbcnt) behind a queue
+            // pointer that advances in a scalar register.
+            const unsigned sign1 = sign << 1;
 #pragma unroll
             for (int j = 0; j < 4; j++) {
-                const bool pass = (passbits & (1u << j)) != 0;
+                const bool pass = j == 3 ? (int)sign < 0 : j == 1 ? (short)(sign & 0xFFFFu) < 0 : j == 2 ? (int)sign1 < 0 : (short)(sign1 & 0xFFFFu) < 0;
                 const unsigned long long m = __builtin_amdgcn_ballot_w64(pass);
-                // slot = na + (passing lanes below this one): v_mbcnt accumulates onto the running count
-                if (__builtin_amdgcn_inverse_ballot_w64(m)) qa[__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, (unsigned)na))] = (unsigned short)(p0 + j);
+                unsigned short* qj = qa + na;
+                if (__builtin_amdgcn_inverse_ballot_w64(m)) qj[__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u))] = (unsigned short)(p0 + j);
                 na += __popcll(m);
             }
         }
