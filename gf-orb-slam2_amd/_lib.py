@@ -70,6 +70,7 @@ SYMBOLS = [
     "gfo_stereo_match_batch", "gfo_stereo_match_sad_batch", "gfo_stereo_fetch", "gfo_search_by_projection", "gfo_search_by_projection_queries",
     "gfo_map_upload", "gfo_search_by_projection_batch", "gfo_projection_fetch", "gfo_projection_device_views", "gfo_search_by_bow", "gfo_vocabulary_upload", "gfo_bow_transform", "gfo_compute_bow", "gfo_profile_enable",
     "gfo_profile_read", "gfo_debug_blurred_level", "gfo_debug_level_candidates",
+    "gfo_contexts_created", "gfo_arenas_planned", "gfo_ctx_id", "gfo_vocabulary_nodes", "gfo_ctx_set_combining", "gfo_combiner_stats",
 ]
 
 
@@ -188,6 +189,13 @@ def load_library():
     L.gfo_profile_read.argtypes = [vp, C.POINTER(StageTime), i, ip, i]
     L.gfo_debug_blurred_level.argtypes = [vp, i, i, vp, i]
     L.gfo_debug_level_candidates.argtypes = [vp, i, i, vp, i, ip]
+    L.gfo_contexts_created.restype = i
+    L.gfo_arenas_planned.restype = i
+    L.gfo_ctx_id.argtypes = [vp]
+    L.gfo_ctx_id.restype = C.c_uint64
+    L.gfo_vocabulary_nodes.argtypes = [vp]
+    L.gfo_ctx_set_combining.argtypes = [vp, i]
+    L.gfo_combiner_stats.argtypes = [vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
     _lib = L
     return L
 

@@ -15,11 +15,11 @@
 //     19-px-framed buffers like the reference builds them (ORBextractor.cc:1182-1197).
 //
 // The header cannot carry a new member and its inline destructor is empty, so the gfo context of an extractor lives
-// in a side table keyed by the object's address, as a CACHE: the table remembers the constructor arguments of every
-// extractor and (re)creates a context on demand, and only the GFO_MAX_CONTEXTS (default 4) most recently used
-// contexts stay alive.  Tracking::updateORBExtractor (src/Tracking.cc:298-320) deletes and re-creates both
-// extractors at run time: the contexts of the deleted pair fall out of the cache as soon as the new pair is in use,
-// whether or not the allocator hands the new objects the old addresses.
+// in a side table keyed by the object's address (adapter/gfo_context_table.h, which states the rules): a live extractor
+// keeps its context however many extractors there are -- a rig of K stereo cameras holds 2K contexts and never
+// re-creates one (gfo_contexts_created() stays put; tools/c/boundary_throughput.c asserts it through the C ABI) --
+// a constructor at a known address retires the old object's context at once (Tracking::updateORBExtractor,
+// src/Tracking.cc:298-320), and a context whose owner has not called for thousands of lookups is reclaimed.
 //
 // Error behaviour follows the reference: no exceptions, no return codes.  Empty image -> return with
 // the outputs untouched (ORBextractor.cc:1115-1116); any gfo error -> message on stderr and the
@@ -30,74 +30,39 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
-#include <map>
-#include <mutex>
 
 #include "gfo.h"
+#include "gfo_context_table.h"
 
 namespace ORB_SLAM2
 {
 
 namespace
 {
-struct Entry {
-    gfo_params prm;
-    gfo_ctx* ctx;
-    unsigned long stamp;
-};
-std::mutex g_mu;
-std::map<const ORBextractor*, Entry> g_tab;
-unsigned long g_clock = 0;
-
-int max_contexts()
+bool full_pyramid()
 {
-    static const int n = getenv("GFO_MAX_CONTEXTS") ? atoi(getenv("GFO_MAX_CONTEXTS")) : 4;
-    return n < 2 ? 2 : n;
+    static const bool full = getenv("GFO_FULL_PYRAMID") && getenv("GFO_FULL_PYRAMID")[0] == '1';
+    return full;
 }
 
-// the caller holds g_mu
-void evict_lru(const ORBextractor* keep)
+// Frames of several extractors -- the left / right pair of a Frame constructor (Frame.cc:84-87), the cameras of a rig --
+// arrive on several threads at once: with the frame combiner on they share one device batch instead of competing for the
+// runtime's four hardware queues (include/gfo.h, gfo_ctx_set_combining; GFO_COMBINE=0 opts out).  Not with
+// GFO_FULL_PYRAMID=1: the levels fetched after operator() must be in the extractor's own context.
+void configure_context(gfo_ctx* c)
 {
-    for (;;) {
-        int alive = 0;
-        std::map<const ORBextractor*, Entry>::iterator oldest = g_tab.end();
-        for (std::map<const ORBextractor*, Entry>::iterator it = g_tab.begin(); it != g_tab.end(); ++it) {
-            if (!it->second.ctx) continue;
-            alive++;
-            if (it->first != keep && (oldest == g_tab.end() || it->second.stamp < oldest->second.stamp)) oldest = it;
-        }
-        if (alive <= max_contexts() || oldest == g_tab.end()) return;
-        gfo_ctx_destroy(oldest->second.ctx);   // its owner (if it still exists) gets a fresh one on its next call
-        oldest->second.ctx = NULL;
-    }
+    static const bool combine = !(getenv("GFO_COMBINE") && getenv("GFO_COMBINE")[0] == '0');
+    gfo_ctx_set_combining(c, combine && !full_pyramid() ? 1 : 0);
 }
 
-gfo_ctx* ctx_of(const ORBextractor* self)
-{
-    std::lock_guard<std::mutex> lk(g_mu);
-    std::map<const ORBextractor*, Entry>::iterator it = g_tab.find(self);
-    if (it == g_tab.end()) return NULL;   // not constructed through this file
-    Entry& e = it->second;
-    e.stamp = ++g_clock;
-    if (!e.ctx) {
-        int dev = 0;
-        if (const char* d = getenv("GFO_DEVICE")) dev = atoi(d);
-        if (gfo_ctx_create(&e.prm, dev, &e.ctx) != GFO_OK) {
-            fprintf(stderr, "[gfo] ORBextractor: %s\n", gfo_last_error(NULL));
-            e.ctx = NULL;
-            return NULL;
-        }
-        evict_lru(self);
-    }
-    return e.ctx;
-}
+struct Table : gfo_adapter::ContextTable {
+    Table() { on_create = configure_context; }
+} g_tab;
+
+gfo_ctx* ctx_of(const ORBextractor* self) { return g_tab.get(self); }
 
 struct AtExit {
-    ~AtExit()
-    {
-        for (std::map<const ORBextractor*, Entry>::iterator it = g_tab.begin(); it != g_tab.end(); ++it)
-            if (it->second.ctx) gfo_ctx_destroy(it->second.ctx);
-    }
+    ~AtExit() { g_tab.destroy_all(); }
 } g_at_exit;
 }  // namespace
 
@@ -107,21 +72,14 @@ gfo_ctx* gfo_context_of(const ORBextractor* e) { return ctx_of(e); }
 ORBextractor::ORBextractor(int _nfeatures, float _scaleFactor, int _nlevels, int _iniThFAST, int _minThFAST)
     : nfeatures(_nfeatures), scaleFactor(_scaleFactor), nlevels(_nlevels), iniThFAST(_iniThFAST), minThFAST(_minThFAST)
 {
-    Entry e;
-    e.prm.nfeatures = _nfeatures;
-    e.prm.scale_factor = _scaleFactor;
-    e.prm.nlevels = _nlevels;
-    e.prm.ini_th_fast = _iniThFAST;
-    e.prm.min_th_fast = _minThFAST;
-    e.prm.max_batch = 1;
-    e.ctx = NULL;
-    e.stamp = 0;
-    {
-        std::lock_guard<std::mutex> lk(g_mu);
-        std::map<const ORBextractor*, Entry>::iterator it = g_tab.find(this);
-        if (it != g_tab.end() && it->second.ctx) gfo_ctx_destroy(it->second.ctx);   // the address of a deleted extractor, reused
-        g_tab[this] = e;
-    }
+    gfo_params prm;
+    prm.nfeatures = _nfeatures;
+    prm.scale_factor = _scaleFactor;
+    prm.nlevels = _nlevels;
+    prm.ini_th_fast = _iniThFAST;
+    prm.min_th_fast = _minThFAST;
+    prm.max_batch = 1;
+    g_tab.declare(this, prm);   // an address the table knows: the previous owner is gone, its context is retired
     mvScaleFactor.resize(nlevels);
     mvInvScaleFactor.resize(nlevels);
     mvLevelSigma2.resize(nlevels);
@@ -202,8 +160,7 @@ void ORBextractor::operator()(cv::InputArray _image, cv::InputArray /*_mask*/, s
         _descriptors.create(n, 32, CV_8U);
         memcpy(_descriptors.getMat().data, exact.data, (size_t)n * 32);
     }
-    static const bool full = getenv("GFO_FULL_PYRAMID") && getenv("GFO_FULL_PYRAMID")[0] == '1';
-    if (full) {
+    if (full_pyramid()) {
         fetch_pyramid(c, mvImagePyramid, mvInvScaleFactor, nlevels, image.cols, image.rows);
     } else {
         // sized headers only (allocated once per image size): the default build reads mvImagePyramid[0].rows and nothing else

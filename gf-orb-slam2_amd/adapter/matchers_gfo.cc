@@ -402,8 +402,13 @@ struct VocabularyView : public ORBVocabulary {
     using ORBVocabulary::m_scoring_object;
 };
 
+// One flattened copy per vocabulary (shared by every context), and per CONTEXT ID which vocabulary it holds.  A context's
+// id is never reused (gfo_ctx_id), so an extractor re-created at the address of a deleted one (Tracking::updateORBExtractor,
+// src/Tracking.cc:298-320) -- new context, same pointer -- is seen as holding nothing and gets its upload; and the context
+// itself has the last word (gfo_vocabulary_nodes): nothing here can claim residency the device does not have.
 std::mutex g_voc_mu;
-std::map<std::pair<gfo_ctx*, const ORBVocabulary*>, VocabularyView::Flat> g_voc;   // uploaded trees, per context
+std::map<const ORBVocabulary*, VocabularyView::Flat> g_voc_flat;
+std::map<uint64_t, const ORBVocabulary*> g_voc_on_ctx;
 }  // namespace
 
 void Frame::ComputeBoW()
@@ -412,23 +417,30 @@ void Frame::ComputeBoW()
     mFeatVec.clear();
     if (mpORBvocabulary->empty() || N == 0) return;
     gfo_ctx* c = gfo_context_of(mpORBextractorLeft);
+    if (!c) return;
     const VocabularyView::Flat* flat;
     {
         std::lock_guard<std::mutex> lk(g_voc_mu);
-        std::pair<gfo_ctx*, const ORBVocabulary*> key(c, mpORBvocabulary);
-        std::map<std::pair<gfo_ctx*, const ORBVocabulary*>, VocabularyView::Flat>::iterator it = g_voc.find(key);
-        if (it == g_voc.end()) {
-            VocabularyView::Flat f;
-            static_cast<const VocabularyView*>(mpORBvocabulary)->flatten(f);
-            gfo_vocabulary v = {f.first_child.data(), f.n_children.data(), f.desc.data(), f.word_id.data(), f.weight.data(),
-                                (int32_t)f.first_child.size(), f.depth, f.weight64.data()};
+        std::map<const ORBVocabulary*, VocabularyView::Flat>::iterator it = g_voc_flat.find(mpORBvocabulary);
+        if (it == g_voc_flat.end()) {
+            it = g_voc_flat.insert(std::make_pair(mpORBvocabulary, VocabularyView::Flat())).first;
+            static_cast<const VocabularyView*>(mpORBvocabulary)->flatten(it->second);
+        }
+        flat = &it->second;
+        const uint64_t id = gfo_ctx_id(c);
+        std::map<uint64_t, const ORBVocabulary*>::iterator on = g_voc_on_ctx.find(id);
+        const bool resident = on != g_voc_on_ctx.end() && on->second == mpORBvocabulary &&
+                              gfo_vocabulary_nodes(c) == (int)flat->first_child.size();
+        if (!resident) {
+            gfo_vocabulary v = {flat->first_child.data(), flat->n_children.data(), flat->desc.data(), flat->word_id.data(),
+                                flat->weight.data(), (int32_t)flat->first_child.size(), flat->depth, flat->weight64.data()};
             if (gfo_vocabulary_upload(c, &v) != GFO_OK) {
                 report(c, "ComputeBoW (vocabulary upload)");
                 return;
             }
-            it = g_voc.insert(std::make_pair(key, f)).first;
+            if (g_voc_on_ctx.size() > 4096) g_voc_on_ctx.clear();   // ids of long-gone contexts; the survivors re-upload once
+            g_voc_on_ctx[id] = mpORBvocabulary;
         }
-        flat = &it->second;
     }
     const VocabularyView* voc = static_cast<const VocabularyView*>(mpORBvocabulary);
     DBoW2::LNorm norm;

@@ -13,10 +13,12 @@ static std::string g_create_err;
 // live contexts, for gfo_ctx_chain's edges (a destroyed context must disappear from the others' `chain_after`)
 #include <mutex>
 #include <vector>
+#include <atomic>
 static std::mutex g_ctx_mu;
 static std::vector<gfo_ctx*> g_ctx_live;
+static std::atomic<int> g_contexts_created{0}, g_arenas_planned{0};
 
-static int fail(gfo_ctx* c, int code, const char* fmt, ...)
+int gfo_fail(gfo_ctx* c, int code, const char* fmt, ...)
 {
     char buf[512];
     va_list ap;
@@ -28,6 +30,7 @@ static int fail(gfo_ctx* c, int code, const char* fmt, ...)
     return code;
 }
 
+#define fail gfo_fail
 #define HIP_TRY(c, expr)                                                                        \
     do {                                                                                        \
         hipError_t e_ = (expr);                                                                 \
@@ -176,7 +179,7 @@ static void resize_tables(int ssize, int dsize, int* ofs, short* coef, bool clam
     }
 }
 
-static int plan(gfo_ctx* c, int w, int h, int batch)
+int gfo_plan(gfo_ctx* c, int w, int h, int batch)
 {
     if (c->planned && c->g.w0 == w && c->g.h0 == h && batch <= c->cap_batch) return GFO_OK;
     if (w > 4000 || h > 4000) return fail(c, GFO_ERR_INVALID, "image %dx%d exceeds the 4000-px coordinate packing", w, h);
@@ -465,6 +468,7 @@ static int plan(gfo_ctx* c, int w, int h, int batch)
     HIP_TRY(c, hipMemset(c->d_flags, 0, 4 * sizeof(int)));
     c->cap_batch = batch;
     c->planned = true;
+    g_arenas_planned++;
     return GFO_OK;
 }
 
@@ -496,10 +500,6 @@ extern "C" int gfo_ctx_create(const gfo_params* p, int device, gfo_ctx** out)
     c->prm = *p;
     if (c->prm.max_batch < 1) c->prm.max_batch = 1;
     c->device = device;
-    {
-        std::lock_guard<std::mutex> lk(g_ctx_mu);
-        g_ctx_live.push_back(c);
-    }
     if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess) {
         delete c;
         return fail(nullptr, GFO_ERR_DEVICE, "hipStreamCreate failed");
@@ -516,9 +516,19 @@ extern "C" int gfo_ctx_create(const gfo_params* p, int device, gfo_ctx** out)
     c->debug_sync = dbg && dbg[0] == '1';
     if (getenv("GFO_GRAPH")) c->graph_ok = atoi(getenv("GFO_GRAPH")) != 0;
     build_tables(c);
+    {   // registered only now that nothing above can fail: gfo_ctx_chain / gfo_ctx_destroy dereference every entry
+        std::lock_guard<std::mutex> lk(g_ctx_mu);
+        g_ctx_live.push_back(c);
+    }
+    c->id = (uint64_t)++g_contexts_created;
     *out = c;
     return GFO_OK;
 }
+
+extern "C" int gfo_contexts_created(void) { return g_contexts_created.load(); }
+extern "C" int gfo_arenas_planned(void) { return g_arenas_planned.load(); }
+extern "C" uint64_t gfo_ctx_id(const gfo_ctx* c) { return c ? c->id : 0; }
+extern "C" int gfo_vocabulary_nodes(const gfo_ctx* c) { return c && c->d_voc ? c->voc_nodes : 0; }
 
 extern "C" void gfo_ctx_destroy(gfo_ctx* c)
 {
@@ -530,6 +540,7 @@ extern "C" void gfo_ctx_destroy(gfo_ctx* c)
         for (gfo_ctx* o : g_ctx_live)
             if (o->chain_after == c) o->chain_after = nullptr;
     }
+    gfo_engine_release(c);   // the combiner's engine (and its batch contexts) goes with its last member
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     prof_collect(c);
@@ -692,8 +703,12 @@ static GfoStereoLaunch stereo_batch_launch(gfo_ctx* c, const gfo_stereo_params& 
 static int extract_launches(gfo_ctx* c, const GfoInput& in, int nimg, const gfo_stereo_params* sp, const GfoPack* pack)
 {
     // gfo_ctx_chain: start behind the stage event of the context this one is chained after (work already submitted there)
-    if (gfo_ctx* a = c->chain_after)
-        if (a->ev_pace && a->pace_recorded) HIP_TRY(c, hipStreamWaitEvent(c->stream, a->ev_pace, 0));
+    // (under g_ctx_mu: gfo_ctx_destroy(after) on another thread clears the edge and frees the event under the same lock)
+    if (c->chain_after) {
+        std::lock_guard<std::mutex> lk(g_ctx_mu);
+        if (gfo_ctx* a = c->chain_after)
+            if (a->ev_pace && a->pace_recorded) HIP_TRY(c, hipStreamWaitEvent(c->stream, a->ev_pace, 0));
+    }
 #define GFO_PACE_POINT(S)                                                    \
     do {                                                                     \
         if (c->pace_stage == (S) && c->ev_pace) {                            \
@@ -864,7 +879,7 @@ extern "C" int gfo_extract_batch_device(gfo_ctx* c, const uint8_t* d_imgs, int n
     if (!c || !d_imgs || nimg < 1 || w < 1 || h < 1 || pitch < (size_t)w) return fail(c, GFO_ERR_INVALID, "bad argument");
     if (nimg > 1 && img_stride < pitch * (size_t)h) return fail(c, GFO_ERR_INVALID, "img_stride %zu < pitch * h = %zu: images overlap", img_stride, pitch * (size_t)h);
     HIP_TRY(c, hipSetDevice(c->device));
-    int rc = plan(c, w, h, nimg);
+    int rc = gfo_plan(c, w, h, nimg);
     if (rc) return rc;
     GfoInput in{d_imgs, (long long)pitch, (long long)img_stride};
     return run_extract(c, in, nimg);
@@ -932,76 +947,115 @@ static int pinned(gfo_ctx* c, uint8_t** buf, size_t* cap, size_t bytes)
 
 #define GFO_SMALL_BATCH 8   // up to this many host images go through pinned staging: one H2D, one D2H, one sync
 
-// Small host batch: images -> pinned -> one H2D; kernels (a graph replay); every result -> pinned in one burst of
-// D2H copies; ONE stream synchronisation; then plain memcpy into the caller's arrays.
-static int extract_small(gfo_ctx* c, const uint8_t* const* imgs, int nimg, int w, int h, int stride, const gfo_stereo_params* sp,
-                         gfo_keypoint* const* kp, uint8_t* const* desc, int cap, int* n, float* u_right, float* depth,
-                         int32_t* best_dist, int32_t* best_idx_r, int* nmatched)
+// Small host batch: images -> pinned -> one H2D; kernels; every result -> pinned by ONE kernel (k_pack_results);
+// ONE stream synchronisation; then plain memcpy into the caller's arrays.  In four steps so that the frame combiner
+// (gfo_combine.hip) can let every caller stage and collect its own frame while one of them submits the batch:
+//   gfo_small_prepare   pinned buffers + the result layout for up to nimg_cap images
+//   gfo_small_stage     image i -> its place in the pinned input
+//   gfo_small_submit    one H2D of the first nimg images, the launches, the pack kernel, the synchronisation
+//   gfo_small_collect   image i's keypoints / descriptors (and pair i/2's stereo outputs) -> the caller's arrays
+int gfo_small_prepare(gfo_ctx* c, int nimg_cap, GfoSmallLayout* L)
 {
-    const int pitch = c->g.lv[0].pitch, ks = c->g.kp_stride;
-    const size_t img_bytes = (size_t)pitch * h;
-    int rc = pinned(c, &c->h_in, &c->h_in_bytes, img_bytes * nimg);
+    const int pitch = c->g.lv[0].pitch, ks = c->g.kp_stride, h = c->g.h0;
+    L->nimg_cap = nimg_cap;
+    L->img_bytes = (size_t)pitch * h;
+    int rc = pinned(c, &c->h_in, &c->h_in_bytes, L->img_bytes * nimg_cap);
     if (rc) return rc;
-    for (int i = 0; i < nimg; i++) {
-        uint8_t* d = c->h_in + i * img_bytes;
-        if (stride == pitch) memcpy(d, imgs[i], img_bytes);
-        else
-            for (int y = 0; y < h; y++) memcpy(d + (size_t)y * pitch, imgs[i] + (size_t)y * stride, w);
-    }
-    // result layout in the pinned buffer (fixed for a planned geometry, so the captured pack kernel stays valid)
+    // result layout in the pinned buffer (fixed for a planned geometry and capacity)
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = off; off = (size_t)align_up((long long)(off + bytes), 64); return o; };
-    const size_t o_fl = take(16), o_cnt = take(16 * (size_t)((nimg + 3) / 4)), o_kp = take(sizeof(gfo_keypoint) * (size_t)ks * nimg),
-                 o_ds = take(32 * (size_t)ks * nimg);
-    const size_t o_ur = take(4 * (size_t)ks), o_dp = take(4 * (size_t)ks), o_bd = take(4 * (size_t)ks), o_bi = take(4 * (size_t)ks),
-                 o_nm = take(16);
-    rc = pinned(c, &c->h_out, &c->h_out_bytes, off);
-    if (rc) return rc;
+    const size_t npair = (size_t)(nimg_cap + 1) / 2;
+    L->o_fl = take(16); L->o_cnt = take(16 * (size_t)((nimg_cap + 3) / 4)); L->o_kp = take(sizeof(gfo_keypoint) * (size_t)ks * nimg_cap);
+    L->o_ds = take(32 * (size_t)ks * nimg_cap);
+    L->o_ur = take(4 * (size_t)ks * npair); L->o_dp = take(4 * (size_t)ks * npair); L->o_bd = take(4 * (size_t)ks * npair);
+    L->o_bi = take(4 * (size_t)ks * npair); L->o_nm = take(16 * ((npair + 3) / 4));
+    return pinned(c, &c->h_out, &c->h_out_bytes, off);
+}
+
+void gfo_small_stage(gfo_ctx* c, const GfoSmallLayout& L, int i, const uint8_t* img, int w, int h, int stride)
+{
+    const int pitch = c->g.lv[0].pitch;
+    uint8_t* d = c->h_in + (size_t)i * L.img_bytes;
+    if (stride == pitch) memcpy(d, img, L.img_bytes);
+    else
+        for (int y = 0; y < h; y++) memcpy(d + (size_t)y * pitch, img + (size_t)y * stride, w);
+}
+
+int gfo_small_submit(gfo_ctx* c, const GfoSmallLayout& L, int nimg, const gfo_stereo_params* sp, bool copy_in)
+{
+    const int pitch = c->g.lv[0].pitch, ks = c->g.kp_stride;
     uint8_t* H = c->h_out;
     hipStream_t st = c->stream;
     GfoPack pk{};
     auto seg = [&](const void* src, size_t dst_off, size_t bytes) {
         pk.src[pk.nseg] = (const uint4*)src; pk.dst[pk.nseg] = (uint4*)(H + dst_off); pk.n16[pk.nseg] = (int)((bytes + 15) / 16); pk.nseg++;
     };
-    seg(c->d_flags, o_fl, 16);
-    seg(c->d_kp_cnt, o_cnt, 4 * (size_t)nimg);          // the count vector is allocated in 16-byte multiples (plan)
-    seg(c->d_kp, o_kp, sizeof(gfo_keypoint) * (size_t)ks * nimg);
-    seg(c->d_desc, o_ds, 32 * (size_t)ks * nimg);
+    const size_t npair = (size_t)nimg / 2;
+    seg(c->d_flags, L.o_fl, 16);
+    seg(c->d_kp_cnt, L.o_cnt, 4 * (size_t)nimg);          // the count vector is allocated in 16-byte multiples (plan)
+    seg(c->d_kp, L.o_kp, sizeof(gfo_keypoint) * (size_t)ks * nimg);
+    seg(c->d_desc, L.o_ds, 32 * (size_t)ks * nimg);
     if (sp) {
-        seg(c->st.u_right, o_ur, 4 * (size_t)ks);
-        seg(c->st.depth, o_dp, 4 * (size_t)ks);
-        seg(c->st.best_dist, o_bd, 4 * (size_t)ks);
-        seg(c->st.best_idx, o_bi, 4 * (size_t)ks);
-        seg(c->st.nmatched, o_nm, 4);
+        seg(c->st.u_right, L.o_ur, 4 * (size_t)ks * npair);
+        seg(c->st.depth, L.o_dp, 4 * (size_t)ks * npair);
+        seg(c->st.best_dist, L.o_bd, 4 * (size_t)ks * npair);
+        seg(c->st.best_idx, L.o_bi, 4 * (size_t)ks * npair);
+        seg(c->st.nmatched, L.o_nm, 4 * npair);             // allocated with 16 bytes of slack (plan)
     }
-    HIP_TRY(c, hipMemcpyAsync(c->d_input, c->h_in, img_bytes * nimg, hipMemcpyHostToDevice, st));
-    GfoInput in{c->d_input, pitch, (long long)img_bytes};
-    rc = run_extract(c, in, nimg, sp, &pk);
+    if (copy_in) HIP_TRY(c, hipMemcpyAsync(c->d_input, c->h_in, L.img_bytes * nimg, hipMemcpyHostToDevice, st));   // (the combiner's callers queue their own)
+    GfoInput in{c->d_input, pitch, (long long)L.img_bytes};
+    int rc = run_extract(c, in, nimg, sp, &pk);
     if (rc) return rc;
     HIP_TRY(c, hipStreamSynchronize(st));
-    const int* fl = reinterpret_cast<const int*>(H + o_fl);
+    const int* fl = reinterpret_cast<const int*>(H + L.o_fl);
     if (fl[0]) {
         (void)hipMemsetAsync(c->d_flags, 0, 16, st);
         return fail(c, GFO_ERR_OVERFLOW, "internal buffer overflow (flags 0x%x: 1 candidates, 2 quadtree nodes, 4 selection, 8 keypoints)", fl[0]);
     }
+    return GFO_OK;
+}
+
+// returns 1 when the image produced more keypoints than `cap` (outputs truncated), else 0
+int gfo_small_collect(gfo_ctx* c, const GfoSmallLayout& L, int i, gfo_keypoint* kp, uint8_t* desc, int cap, int* n)
+{
+    const int ks = c->g.kp_stride;
+    const uint8_t* H = c->h_out;
+    *n = reinterpret_cast<const int*>(H + L.o_cnt)[i];
+    const int m = *n < cap ? *n : cap;
+    if (m > 0 && kp) memcpy(kp, H + L.o_kp + sizeof(gfo_keypoint) * (size_t)ks * i, sizeof(gfo_keypoint) * (size_t)m);
+    if (m > 0 && desc) memcpy(desc, H + L.o_ds + 32 * (size_t)ks * i, 32 * (size_t)m);
+    return *n > cap;
+}
+
+void gfo_small_collect_stereo(gfo_ctx* c, const GfoSmallLayout& L, int pair, int n_left, int cap, float* u_right, float* depth,
+                              int32_t* best_dist, int32_t* best_idx_r, int* nmatched)
+{
+    const int ks = c->g.kp_stride;
+    const uint8_t* H = c->h_out;
+    const int m = n_left < cap ? n_left : cap;
+    const size_t o = 4 * (size_t)ks * pair;
+    if (m > 0) {
+        memcpy(u_right, H + L.o_ur + o, 4 * (size_t)m);
+        memcpy(depth, H + L.o_dp + o, 4 * (size_t)m);
+        if (best_dist) memcpy(best_dist, H + L.o_bd + o, 4 * (size_t)m);
+        if (best_idx_r) memcpy(best_idx_r, H + L.o_bi + o, 4 * (size_t)m);
+    }
+    *nmatched = reinterpret_cast<const int*>(H + L.o_nm)[pair];
+}
+
+static int extract_small(gfo_ctx* c, const uint8_t* const* imgs, int nimg, int w, int h, int stride, const gfo_stereo_params* sp,
+                         gfo_keypoint* const* kp, uint8_t* const* desc, int cap, int* n, float* u_right, float* depth,
+                         int32_t* best_dist, int32_t* best_idx_r, int* nmatched)
+{
+    GfoSmallLayout L;
+    int rc = gfo_small_prepare(c, nimg, &L);
+    if (rc) return rc;
+    for (int i = 0; i < nimg; i++) gfo_small_stage(c, L, i, imgs[i], w, h, stride);
+    rc = gfo_small_submit(c, L, nimg, sp, true);
+    if (rc) return rc;
     int over = 0;
-    for (int i = 0; i < nimg; i++) {
-        n[i] = reinterpret_cast<const int*>(H + o_cnt)[i];
-        const int m = n[i] < cap ? n[i] : cap;
-        if (n[i] > cap) over = 1;
-        if (m > 0 && kp[i]) memcpy(kp[i], H + o_kp + sizeof(gfo_keypoint) * (size_t)ks * i, sizeof(gfo_keypoint) * (size_t)m);
-        if (m > 0 && desc[i]) memcpy(desc[i], H + o_ds + 32 * (size_t)ks * i, 32 * (size_t)m);
-    }
-    if (sp) {
-        const int m = n[0] < cap ? n[0] : cap;
-        if (m > 0) {
-            memcpy(u_right, H + o_ur, 4 * (size_t)m);
-            memcpy(depth, H + o_dp, 4 * (size_t)m);
-            if (best_dist) memcpy(best_dist, H + o_bd, 4 * (size_t)m);
-            if (best_idx_r) memcpy(best_idx_r, H + o_bi, 4 * (size_t)m);
-        }
-        *nmatched = *reinterpret_cast<const int*>(H + o_nm);
-    }
+    for (int i = 0; i < nimg; i++) over |= gfo_small_collect(c, L, i, kp[i], desc[i], cap, &n[i]);
+    if (sp) gfo_small_collect_stereo(c, L, 0, n[0], cap, u_right, depth, best_dist, best_idx_r, nmatched);
     return over ? fail(c, GFO_ERR_CAPACITY, "an image produced more keypoints than the caller capacity %d", cap) : GFO_OK;
 }
 
@@ -1014,8 +1068,14 @@ extern "C" int gfo_extract_batch(gfo_ctx* c, const uint8_t* const* imgs, int nim
         return GFO_OK;
     }
     if (stride < w) return fail(c, GFO_ERR_INVALID, "stride < width");
+    if (c->combining && nimg == 1) {   // one frame of one caller: may share a device batch with other callers' frames
+        gfo_keypoint* kps[1] = {kp};
+        uint8_t* ds[1] = {desc};
+        c->have_batch = c->have_pyramid = c->have_stereo = false;   // the device-side state lives in the combiner's arena
+        return gfo_combined_extract(c, 1, imgs, w, h, stride, nullptr, kps, ds, cap, n, nullptr, nullptr, nullptr, nullptr, nullptr);
+    }
     HIP_TRY(c, hipSetDevice(c->device));
-    int rc = plan(c, w, h, nimg);
+    int rc = gfo_plan(c, w, h, nimg);
     if (rc) return rc;
     if (nimg <= GFO_SMALL_BATCH) {
         gfo_keypoint* kps[GFO_SMALL_BATCH];
@@ -1055,14 +1115,21 @@ extern "C" int gfo_extract_stereo(gfo_ctx* c, const uint8_t* img_l, const uint8_
     *n_l = *n_r = *nmatched = 0;
     if (!img_l || !img_r || w <= 0 || h <= 0) return GFO_OK;   // empty image: outputs untouched (:1115)
     if (stride < w) return fail(c, GFO_ERR_INVALID, "stride < width");
-    HIP_TRY(c, hipSetDevice(c->device));
-    int rc = plan(c, w, h, 2);
-    if (rc) return rc;
-    if (p->n_rows < 1 || p->n_rows > c->st_rows_cap) return fail(c, GFO_ERR_INVALID, "n_rows %d exceeds the planned %d", p->n_rows, c->st_rows_cap);
     const uint8_t* imgs[2] = {img_l, img_r};
     gfo_keypoint* kps[2] = {kp_l, kp_r};
     uint8_t* ds[2] = {desc_l, desc_r};
     int n[2] = {0, 0};
+    if (c->combining) {
+        c->have_batch = c->have_pyramid = c->have_stereo = false;
+        const int crc = gfo_combined_extract(c, 2, imgs, w, h, stride, p, kps, ds, cap, n, u_right, depth, best_dist, best_idx_r, nmatched);
+        *n_l = n[0];
+        *n_r = n[1];
+        return crc;
+    }
+    HIP_TRY(c, hipSetDevice(c->device));
+    int rc = gfo_plan(c, w, h, 2);
+    if (rc) return rc;
+    if (p->n_rows < 1 || p->n_rows > c->st_rows_cap) return fail(c, GFO_ERR_INVALID, "n_rows %d exceeds the planned %d", p->n_rows, c->st_rows_cap);
     rc = extract_small(c, imgs, 2, w, h, stride, p, kps, ds, cap, n, u_right, depth, best_dist, best_idx_r, nmatched);
     *n_l = n[0];
     *n_r = n[1];
@@ -1088,7 +1155,7 @@ extern "C" int gfo_compute_pyramid(gfo_ctx* c, const uint8_t* img, int w, int h,
 {
     if (!c || !img || w <= 0 || h <= 0 || stride < w) return fail(c, GFO_ERR_INVALID, "bad argument");
     HIP_TRY(c, hipSetDevice(c->device));
-    int rc = plan(c, w, h, 1);
+    int rc = gfo_plan(c, w, h, 1);
     if (rc) return rc;
     GfoInput in;
     const uint8_t* one[1] = {img};

@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
 #include <stdint.h>
+#include <memory>
 #include <string>
 #include <vector>
 
@@ -138,8 +139,11 @@ enum GfoStage {
     ST_PROJECT, ST_BOW, ST_COUNT
 };
 
+struct GfoEngine;   // gfo_combine.hip
+
 struct gfo_ctx {
     gfo_params prm{};
+    uint64_t id = 0;                 // process-wide serial number (gfo_ctx_id), never reused
     int device = 0;
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
@@ -227,6 +231,9 @@ struct gfo_ctx {
     hipGraphExec_t graph_exec = nullptr;
     struct GraphKey { const void* base; const void* pack_dst; long long pitch, img_stride; int nimg, stereo; gfo_stereo_params sp; int plan_gen; } graph_key{};
     int plan_gen = 0;
+    // frame combiner (gfo_ctx_set_combining): per-frame host calls of this context may run inside a shared device batch
+    bool combining = false;
+    std::shared_ptr<GfoEngine> engine;
     // resident vocabulary tree (gfo_vocabulary_upload)
     void* d_voc = nullptr;
     size_t voc_desc_off = 0, voc_fc_off = 0, voc_nc_off = 0, voc_wid_off = 0, voc_w_off = 0, voc_w64_off = 0;
@@ -254,6 +261,27 @@ void gfo_launch_orient_desc(gfo_ctx* c, const GfoInput& in, int nimg);
 void gfo_launch_stereo(gfo_ctx* c, const GfoStereoLaunch& s);
 int gfo_stereo_window(const float* scale, int nlevels);
 void gfo_launch_stereo_sad(gfo_ctx* c, const GfoStereoLaunch& s, const GfoInput& in, const float* d_inv_scale);
+
+// host-side pieces of gfo_api.hip the frame combiner (gfo_combine.hip) builds on
+int gfo_fail(gfo_ctx* c, int code, const char* fmt, ...);
+int gfo_plan(gfo_ctx* c, int w, int h, int batch);
+struct GfoSmallLayout {
+    int nimg_cap;
+    size_t img_bytes;
+    size_t o_fl, o_cnt, o_kp, o_ds, o_ur, o_dp, o_bd, o_bi, o_nm;   // offsets into the pinned result buffer
+};
+int gfo_small_prepare(gfo_ctx* c, int nimg_cap, GfoSmallLayout* L);
+void gfo_small_stage(gfo_ctx* c, const GfoSmallLayout& L, int i, const uint8_t* img, int w, int h, int stride);
+int gfo_small_submit(gfo_ctx* c, const GfoSmallLayout& L, int nimg, const gfo_stereo_params* sp, bool copy_in);
+int gfo_small_collect(gfo_ctx* c, const GfoSmallLayout& L, int i, gfo_keypoint* kp, uint8_t* desc, int cap, int* n);
+void gfo_small_collect_stereo(gfo_ctx* c, const GfoSmallLayout& L, int pair, int n_left, int cap, float* u_right, float* depth,
+                              int32_t* best_dist, int32_t* best_idx_r, int* nmatched);
+
+// gfo_combine.hip
+int gfo_combined_extract(gfo_ctx* c, int kind, const uint8_t* const* imgs, int w, int h, int stride, const gfo_stereo_params* sp,
+                         gfo_keypoint* const* kp, uint8_t* const* desc, int cap, int* n, float* u_right, float* depth,
+                         int32_t* best_dist, int32_t* best_idx_r, int* nmatched);
+void gfo_engine_release(gfo_ctx* c);
 
 // profiling helpers (gfo_api.hip)
 void gfo_prof_begin(gfo_ctx* c, int stage);

@@ -14,7 +14,10 @@ class ORBextractor:
     cv::KeyPoint, descriptors an (N, 32) uint8 array (operator(), ORBextractor.h:89-91).
     """
 
-    def __init__(self, nfeatures=2000, scaleFactor=1.2, nlevels=8, iniThFAST=20, minThFAST=7, device=0, max_batch=1):
+    def __init__(self, nfeatures=2000, scaleFactor=1.2, nlevels=8, iniThFAST=20, minThFAST=7, device=0, max_batch=1, combining=False):
+        """combining=True opts the per-frame entry points (`__call__` on one image, `extract_stereo`) into the frame combiner
+        (gfo_ctx_set_combining): frames that several threads submit at once through several such extractors share one
+        device batch.  Same results, bit for bit; the pyramid / debug hooks of a combined call are not available."""
         self._L = load_library()
         self._ctx = C.c_void_p()
         prm = Params(nfeatures, scaleFactor, nlevels, iniThFAST, minThFAST, max_batch)
@@ -27,6 +30,8 @@ class ORBextractor:
         check(self._L, self._ctx, self._L.gfo_ctx_tables(self._ctx, ptr(s), ptr(si), ptr(g), ptr(gi), ptr(q)))
         self._tables = (s, si, g, gi, q)
         self._last_shape = None
+        if combining:
+            check(self._L, self._ctx, self._L.gfo_ctx_set_combining(self._ctx, 1))
 
     def close(self):
         if getattr(self, "_ctx", None) and self._ctx.value:
@@ -54,6 +59,19 @@ class ORBextractor:
     @property
     def handle(self):
         return self._ctx
+
+    @property
+    def ctx_id(self):
+        return int(self._L.gfo_ctx_id(self._ctx))
+
+    def set_combining(self, on=True):
+        check(self._L, self._ctx, self._L.gfo_ctx_set_combining(self._ctx, 1 if on else 0))
+
+    def combiner_stats(self):
+        """(device batches, requests) the frame combiner's engine of this extractor has served"""
+        b, r = C.c_int64(), C.c_int64()
+        check(self._L, self._ctx, self._L.gfo_combiner_stats(self._ctx, C.byref(b), C.byref(r)))
+        return b.value, r.value
 
     def max_keypoints(self):
         return self._L.gfo_ctx_max_keypoints(self._ctx)

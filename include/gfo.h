@@ -83,6 +83,20 @@ int gfo_ctx_synchronize(gfo_ctx* ctx);
 enum { GFO_STAGE_PYRAMID = 1, GFO_STAGE_FAST = 2, GFO_STAGE_SELECT = 3, GFO_STAGE_DESCRIPTORS = 4 };
 int gfo_ctx_chain(gfo_ctx* ctx, gfo_ctx* after, int stage);
 
+/* Frame combiner.  The reference extracts one frame per call, and a process that tracks K cameras does so from K threads
+ * (Frame::Frame, src/Frame.cc:84-100).  With combining on, the per-frame host entry points of this context --
+ * gfo_extract (one image) and gfo_extract_stereo -- may execute inside ONE device batch together with the frames other
+ * threads submit at the same time through other combining contexts of equal parameters, device and image size: the
+ * callers' concurrency becomes batch size (every stage of the library is one launch over all images of a batch) instead
+ * of competing streams.  Each call still blocks until ITS results are in the caller's arrays and returns exactly what
+ * the direct call returns, bit for bit; one caller alone runs a batch of one.  What changes: the device-side state of
+ * the frame (pyramid, batch views, debug hooks) lives in the shared engine, not in this context -- gfo_pyramid_level,
+ * gfo_batch_* and gfo_stereo_match_batch after a combined call return GFO_ERR_STATE.  Off by default; the drop-in
+ * adapter turns it on (unless GFO_FULL_PYRAMID asks for the levels).  GFO_COMBINE_MAX (default 32) bounds the images of a
+ * batch.  gfo_combiner_stats: device batches and requests the context's engine has served so far. */
+int gfo_ctx_set_combining(gfo_ctx* ctx, int on);
+int gfo_combiner_stats(const gfo_ctx* ctx, int64_t* batches, int64_t* requests);
+
 /* Getters of include/ORBextractor.h:93-119 (GetLevels, GetScaleFactor, GetScaleFactors,
  * GetInverseScaleFactors, GetScaleSigmaSquares, GetInverseScaleSigmaSquares) and the
  * per-level quotas mnFeaturesPerLevel (ORBextractor.cc:435-445).  Each out array takes
@@ -302,6 +316,12 @@ typedef struct {
     const double* weight64;       /* [n_nodes] optional: Node::weight as DBoW2 holds it (WordValue = double); NULL = weight[] */
 } gfo_vocabulary;
 int gfo_vocabulary_upload(gfo_ctx* ctx, const gfo_vocabulary* voc);
+/* Residency is a property of the CONTEXT, never of its address: gfo_vocabulary_nodes returns the node count of the tree
+ * resident in ctx (0 = none -- a context that has just been created holds none, whatever lived at its address before),
+ * gfo_ctx_id a process-wide serial number that no two contexts ever share (a `new` right after a `delete` returns the
+ * same pointer; the id still differs).  The adapter asks these instead of remembering "uploaded" per pointer. */
+int gfo_vocabulary_nodes(const gfo_ctx* ctx);
+uint64_t gfo_ctx_id(const gfo_ctx* ctx);
 int gfo_bow_transform(gfo_ctx* ctx, const uint8_t* desc, int n, int levelsup,
                       int32_t* word_id, float* weight, int32_t* node_id);
 
@@ -337,6 +357,11 @@ typedef struct {
 } gfo_stage_time;
 int gfo_profile_enable(gfo_ctx* ctx, int on);
 int gfo_profile_read(gfo_ctx* ctx, gfo_stage_time* out, int cap, int* nstages, int reset);
+/* Process-wide monotonic counters: contexts created by gfo_ctx_create and arenas (re)planned -- hipMalloc of a whole
+ * arena -- since the library was loaded.  A steady-state per-frame loop must leave both unchanged
+ * (tools/c/boundary_throughput.c and the adapter's context table assert it). */
+int gfo_contexts_created(void);
+int gfo_arenas_planned(void);
 
 /* ---- inspection hooks for the parity tests (device -> host copies of intermediates) ------ */
 int gfo_debug_blurred_level(gfo_ctx* ctx, int image, int level, uint8_t* out, int out_stride);

@@ -1,0 +1,162 @@
+"""GPU parity tests of the frame combiner (gfo_ctx_set_combining, csrc/gfo_combine.hip): per-frame calls of K host
+threads through K contexts are executed as shared device batches -- the reference's own call pattern, one frame per
+call (Frame.cc:84-100, ORBextractor.cc:1112-1174), from many threads.  Every result must equal the oracle's, bit for
+bit, whichever batch a frame lands in and whoever it shares it with."""
+import threading
+
+import numpy as np
+import pytest
+
+from conftest import synth_frame
+
+pytestmark = pytest.mark.gpu
+
+FX, BF = 435.2046959714599, 47.90639384423901
+
+
+def _run_threads(fns):
+    errors = []
+
+    def wrap(i, fn):
+        try:
+            fn()
+        except Exception as e:  # noqa: BLE001
+            errors.append(f"thread {i}: {e!r}")
+
+    ts = [threading.Thread(target=wrap, args=(i, f)) for i, f in enumerate(fns)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not errors, errors[:4]
+
+
+def test_eight_stereo_streams_share_device_batches(oracle, euroc_l, euroc_r):
+    """K = 8 camera streams, one thread and one combining context each, 12 stereo frames per stream; the streams carry
+    DIFFERENT images (EuRoC pair, its swap, synthetic pairs), so a frame delivered to the wrong caller or assembled from
+    the wrong slot of a batch cannot pass.  Also: the engine really batched (fewer device batches than requests) and no
+    context or arena was created after the first frames."""
+    import gf_orb_slam2_amd as G
+    K, REPS = 8, 12
+    pairs = [(euroc_l, euroc_r), (euroc_r, euroc_l)] + [(synth_frame(752, 480, 10 + i), synth_frame(752, 480, 30 + i)) for i in range(2)]
+    oe = oracle.OracleExtractor(2000, 1.2, 8, 20, 7)
+    prm = G.StereoParams(480, BF, BF / FX, 0.0)
+    refs = []
+    for l, r in pairs:
+        okl, odl = oe(l)
+        okr, odr = oe(r)
+        refs.append((okl, odl, okr, odr) + tuple(oracle.stereo_match(okl, odl, okr, odr, oe.scale_factors, prm.n_rows, prm.mbf, prm.mb, prm.min_x)))
+    exts = [G.ORBextractor(2000, 1.2, 8, 20, 7, max_batch=2, combining=True) for _ in range(K)]
+    L = exts[0]._L
+    bad = []
+
+    def frame(k):
+        l, r = pairs[k % len(pairs)]
+        okl, odl, okr, odr, nm, u, dp, bd, bi = refs[k % len(pairs)]
+        kl, dl, kr, dr, gnm, gu, gdp, gbd, gbi = exts[k].extract_stereo(l, r, prm)
+        if not (kl.tobytes() == okl.tobytes() and kr.tobytes() == okr.tobytes() and (dl == odl).all() and (dr == odr).all() and
+                gnm == nm and gu.tobytes() == u.tobytes() and gdp.tobytes() == dp.tobytes() and gbd.tobytes() == bd.tobytes() and
+                gbi.tobytes() == bi.tobytes()):
+            bad.append(k)
+
+    _run_threads([lambda k=k: frame(k) for k in range(K)])          # first frames: engine, slots, arenas
+    created, planned = L.gfo_contexts_created(), L.gfo_arenas_planned()
+    b0, r0 = exts[0].combiner_stats()
+    _run_threads([lambda k=k: [frame(k) for _ in range(REPS)] for k in range(K)])
+    b1, r1 = exts[0].combiner_stats()
+    assert not bad, f"streams with a wrong result: {sorted(set(bad))}"
+    assert r1 - r0 == K * REPS
+    assert b1 - b0 < K * REPS, "eight concurrent streams never shared a batch"
+    # steady state creates nothing (a slot the first frames did not reach may still be prepared once: <= 8 slots in all)
+    assert L.gfo_contexts_created() - created <= 8 and L.gfo_arenas_planned() - planned <= 8
+    created, planned = L.gfo_contexts_created(), L.gfo_arenas_planned()
+    _run_threads([lambda k=k: [frame(k) for _ in range(4)] for k in range(K)])
+    assert not bad
+    assert (L.gfo_contexts_created(), L.gfo_arenas_planned()) == (created, planned)
+    for e in exts:
+        e.close()
+
+
+def test_left_right_extractors_combine_single_images(oracle, euroc_l, euroc_r):
+    """The adapter's pattern: the left and right ORBextractor of a stereo rig on two threads (Frame.cc:84-87), here four
+    rigs at once, gfo_extract of ONE image per call -- combined requests of one image each -- then the host-array
+    association on the left extractor's context."""
+    import gf_orb_slam2_amd as G
+    RIGS, REPS = 4, 6
+    oe = oracle.OracleExtractor(1500, 1.2, 8, 20, 7)
+    imgs = [euroc_l, euroc_r, synth_frame(752, 480, 3), synth_frame(752, 480, 4)]
+    refs = [oe(im) for im in imgs]
+    exts = [G.ORBextractor(1500, 1.2, 8, 20, 7, combining=True) for _ in range(2 * RIGS)]
+    bad = []
+
+    def cam(i):
+        for _ in range(REPS):
+            k, d = exts[i](imgs[i % 4])
+            if k.tobytes() != refs[i % 4][0].tobytes() or not (d == refs[i % 4][1]).all():
+                bad.append(i)
+
+    _run_threads([lambda i=i: cam(i) for i in range(2 * RIGS)])
+    assert not bad, sorted(set(bad))
+    b, r = exts[0].combiner_stats()
+    assert r == 2 * RIGS * REPS and b < r
+    # the association on host arrays runs on the extractor's own context, combining or not
+    m = G.ORBmatcher(0.8, True, extractor=exts[0])
+    prm = G.StereoParams(480, BF, BF / FX, 0.0)
+    got = m.ComputeStereoMatches(refs[0][0], refs[0][1], refs[1][0], refs[1][1], oe.scale_factors, prm)
+    ref = oracle.stereo_match(refs[0][0], refs[0][1], refs[1][0], refs[1][1], oe.scale_factors, prm.n_rows, prm.mbf, prm.mb, prm.min_x)
+    assert got[0] == ref[0] and all(a.tobytes() == b_.tobytes() for a, b_ in zip(got[1:], ref[1:]))
+    for e in exts:
+        e.close()
+
+
+def test_combining_context_alone_and_mixed_shapes(oracle, euroc_l, euroc_r):
+    """One caller alone = a batch of one (same bits as the direct path); contexts with different parameters or image
+    sizes get engines of their own; the device-side hooks of a combined call answer GFO_ERR_STATE instead of handing out
+    another frame's pyramid; switching combining off restores the direct path on the same context."""
+    import gf_orb_slam2_amd as G
+    prm = G.StereoParams(480, BF, BF / FX, 0.0)
+    a = G.ORBextractor(2000, 1.2, 8, 20, 7, max_batch=2, combining=True)
+    b = G.ORBextractor(700, 1.2, 6, 25, 9, combining=True)          # other parameters: its own engine
+    oa, ob = oracle.OracleExtractor(2000, 1.2, 8, 20, 7), oracle.OracleExtractor(700, 1.2, 6, 25, 9)
+    ka, da = a(euroc_l)
+    assert ka.tobytes() == oa(euroc_l)[0].tobytes() and (da == oa(euroc_l)[1]).all()
+    crop = np.ascontiguousarray(euroc_r[30:410, 60:700])
+    for im in (euroc_r, crop, euroc_r):                              # b changes image size: engine per size
+        kb, db = b(im)
+        okb, odb = ob(im)
+        assert kb.tobytes() == okb.tobytes() and (db == odb).all()
+    with pytest.raises(G.GfoError) as e:
+        a.pyramid_level(0)
+    assert e.value.code == -5
+    r = a.extract_stereo(euroc_l, euroc_r, prm)
+    okl, odl = oa(euroc_l)
+    okr, odr = oa(euroc_r)
+    ref = oracle.stereo_match(okl, odl, okr, odr, oa.scale_factors, prm.n_rows, prm.mbf, prm.mb, prm.min_x)
+    assert r[0].tobytes() == okl.tobytes() and r[2].tobytes() == okr.tobytes() and r[4] == ref[0]
+    with pytest.raises(G.GfoError):                                  # n_rows beyond what the engine planned
+        a.extract_stereo(euroc_l, euroc_r, G.StereoParams(4000, BF, BF / FX, 0.0))
+    a.set_combining(False)
+    ka2, _ = a(euroc_l)
+    assert ka2.tobytes() == ka.tobytes()
+    oa(euroc_l)
+    np.testing.assert_array_equal(a.pyramid_level(1), oa.level(1))   # direct path: the context owns its pyramid again
+    a.close()
+    b.close()
+
+
+def test_context_ids_and_vocabulary_residency(oracle):
+    """residency must be a property of the context, not of its address.  A context created right after another
+    one was destroyed (very likely at the same address) has a new id and holds no vocabulary."""
+    import gf_orb_slam2_amd as G
+    e1 = G.ORBextractor(500, 1.2, 8, 20, 7)
+    L = e1._L
+    assert L.gfo_vocabulary_nodes(e1.handle) == 0
+    voc = oracle.make_vocabulary(6, 3, seed=5)
+    G.ORBVocabulary(voc, e1)
+    assert L.gfo_vocabulary_nodes(e1.handle) == len(voc["first_child"])
+    id1, addr1 = e1.ctx_id, e1.handle.value
+    e1.close()
+    e2 = G.ORBextractor(500, 1.2, 8, 20, 7)
+    assert e2.ctx_id != id1 and e2.ctx_id > 0
+    assert L.gfo_vocabulary_nodes(e2.handle) == 0, f"fresh context (same address: {e2.handle.value == addr1}) claims a vocabulary"
+    e2.close()

@@ -153,3 +153,24 @@ def test_bench_reads_the_pmc_csv_per_stage_and_step(tmp_path):
     assert per["resize"] == 160 * 1024 and per["fast"] == 64 * 1024 and per["quadtree"] == 4 * 1024 and per["stereo_match"] == 8 * 1024
     per_w, _ = bench.pmc_bytes_per_step(str(p), "WRITE_SIZE")
     assert per_w == {}            # no quadtree launch carries WRITE_SIZE in this file: no step count, nothing reported
+
+
+def test_adapter_context_table_keeps_live_extractors_and_retires_dead_ones():
+    """adapter/gfo_context_table.h (what ORBextractor_gfo.cc keeps its contexts in) against a counting stand-in of
+    gfo_ctx_create / gfo_ctx_destroy: 32 live extractors called round-robin never lose a context (no re-creation in
+    steady state), an extractor re-created at the address of a deleted one
+    (Tracking::updateORBExtractor, src/Tracking.cc:298-320) gets a NEW context and the old one is destroyed at once
+    (nothing keyed by the pointer may survive), dead objects at other addresses are reclaimed when idle."""
+    import shutil
+    import subprocess
+    if shutil.which("g++") is None:
+        pytest.skip("g++ missing")
+    out = os.path.join(ROOT, "tests", "_build")
+    os.makedirs(out, exist_ok=True)
+    exe = os.path.join(out, "context_table_check")
+    r = subprocess.run(["g++", "-std=c++11", "-O1", "-Wall", "-I", os.path.join(ROOT, "include"),
+                        "-I", os.path.join(ROOT, "gf-orb-slam2_amd", "adapter"),
+                        os.path.join(ROOT, "tests", "host", "context_table_check.cc"), "-o", exe], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+    r = subprocess.run([exe], capture_output=True, text=True)
+    assert r.returncode == 0 and r.stdout.startswith("OK"), r.stdout + r.stderr
