@@ -18,8 +18,14 @@ reported in the same line under "other_configs".
 The steps alternate between a few independent contexts (arena + HIP stream; CONTEXTS per workload), for stereo752 two of
 them chained behind each other's pyramid (gfo_ctx_chain).  Setup ends with PRIME_STEPS untimed batches (clock ramp of a
 fresh process, config.priming_steps); --warmup is run as given, untimed, directly in front of the timed steps.
-roofline.traffic is measured in the run itself (N = 1): two short child passes of this command under
-`rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` before the process initialises the GPU (live_traffic()).
+roofline.traffic: with --live-traffic it is measured in the run itself (N = 1): two short child passes of this command
+under `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` before the process initialises the GPU (live_traffic()); without
+it (the default since round 3: two such passes stalled in round 2 and the cause was never established)
+it is the committed summary of the latest such measurement of this command, profiles/traffic_latest.json, labelled as such.
+Beside `value` (inputs and results resident in HBM) the line carries `value_with_h2d` (every step's batch copied in from
+pinned host memory), `value_delivered` (copied in AND every result -- counts, keypoints, descriptors, stereo outputs --
+landed in pinned host memory: gfo_batch_deliver) and `per_frame_boundary` (the reference's own call pattern, one stereo
+frame per call from K host threads through the C ABI: tools/c/boundary_throughput.c).
 """
 import argparse
 import ctypes
@@ -138,37 +144,46 @@ def live_traffic(workload, batch):
     if not exe:
         return None, "rocprofv3 not found"
     raw, steps_seen = {}, 0
+    logdir = os.path.join(ROOT, "gpurun_out") if os.path.isdir(os.path.join(ROOT, "gpurun_out")) else "/tmp"
     for counter in ("FETCH_SIZE", "WRITE_SIZE"):
-        if counter == "WRITE_SIZE":
-            time.sleep(2.0)     # both stalls of a PMC pass seen in this project began within a second of the previous session's end
         tmp = tempfile.mkdtemp(prefix="gfo_pmc_", dir="/tmp")
         cmd = [exe, "--pmc", counter, "--output-format", "csv", "-d", tmp, "--", "python3", os.path.join(ROOT, "bench.py"),
                "--pmc-child", "--workload", workload, "--batch", str(batch), "--steps", "6", "--warmup", "2", "--streams", "1"]
-        env = dict(os.environ, TMPDIR="/tmp")
+        # the child dumps every thread's stack after 50 s (faulthandler) and exits: if a pass ever stalls again, the log
+        # says whether python was inside libgfo, inside the HIP runtime, or already gone (then it is the profiler's teardown)
+        env = dict(os.environ, TMPDIR="/tmp", GFO_BENCH_WATCHDOG="50")
+        log_path = os.path.join(logdir, f"pmc_pass_{counter}.log")
         try:
             # a pass takes ~5 s; it gets 75 s (a cold box pages torch in for a minute) and is killed as a GROUP -- rocprofv3
             # is a launcher, the process that holds the GPU is its child -- so that a stalled profiler can neither delay
             # the benchmark for long nor sit on the GPU while it is timed
-            proc = subprocess.Popen(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, start_new_session=True)
-            try:
-                rc = proc.wait(timeout=75)
-            except subprocess.TimeoutExpired:
-                import signal
+            with open(log_path, "wb") as log:
+                proc = subprocess.Popen(cmd, cwd="/tmp", env=env, stdout=log, stderr=subprocess.STDOUT, start_new_session=True)
                 try:
-                    os.killpg(proc.pid, signal.SIGKILL)
-                except OSError:
-                    pass
-                proc.wait()
-                return None, f"rocprofv3 --pmc {counter} pass did not finish in 75 s and was killed"
+                    rc = proc.wait(timeout=75)
+                except subprocess.TimeoutExpired:
+                    import signal
+                    try:      # who is still there, and where: evidence first, then the kill
+                        ps = subprocess.run(["ps", "-o", "pid,ppid,stat,etimes,wchan:24,args", "-g", str(os.getpgid(proc.pid))],
+                                            stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=5).stdout
+                        log.write(b"\n---- pass exceeded 75 s; process group at that moment ----\n" + ps)
+                    except Exception:
+                        pass
+                    try:
+                        os.killpg(proc.pid, signal.SIGKILL)
+                    except OSError:
+                        pass
+                    proc.wait()
+                    return None, f"rocprofv3 --pmc {counter} pass did not finish in 75 s and was killed (evidence: {log_path})"
             files = glob.glob(os.path.join(tmp, "**", "*counter_collection.csv"), recursive=True)
             if rc != 0 or not files:
-                return None, f"rocprofv3 --pmc {counter} pass failed (rc {rc})"
+                return None, f"rocprofv3 --pmc {counter} pass failed (rc {rc}; log: {log_path})"
             per_step, steps = pmc_bytes_per_step(files[0], counter)
             if steps == 0:
                 return None, f"no kernels in the {counter} pass"
             raw[counter] = per_step
             steps_seen = steps
-        except Exception as ex:   # timeout, unreadable output: the headline must not depend on the profiler
+        except Exception as ex:   # unreadable output: the headline must not depend on the profiler
             return None, f"rocprofv3 --pmc {counter} pass: {ex!r}"
         finally:
             shutil.rmtree(tmp, ignore_errors=True)
@@ -189,7 +204,7 @@ def side_config(name, batch, streams):
     249k, proj1080 46.5k against 51.2k frames/s, measured both ways)."""
     import subprocess
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--workload", name, "--batch", str(batch), "--steps", "400", "--warmup", "30",
-           "--streams", str(streams), "--no-other-configs", "--no-cpu-baseline", "--no-live-traffic", "--profile-steps", "5"]
+           "--streams", str(streams), "--no-other-configs", "--no-cpu-baseline", "--no-boundary", "--profile-steps", "5"]
     try:
         r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=240)
         lines = [l for l in r.stdout.decode(errors="replace").splitlines() if l.startswith("{")]
@@ -201,6 +216,39 @@ def side_config(name, batch, streams):
                 "process": "its own (same command with --workload)", "roofline": j["roofline"]}
     except Exception as ex:      # a failing side measurement must not lose the headline line
         return {"name": name, "error": repr(ex)}
+
+
+def per_frame_boundary(seconds=1.0):
+    """The reference's own call pattern through the C ABI: one stereo frame per call, K host threads (K camera streams),
+    tools/c/boundary_throughput.c built with the host compiler and run as a child process (it initialises the GPU itself).
+    gfo_extract_stereo at K = 1, 4, 8, 16 and the adapter's two-context pattern at K = 4, 8, contexts combining as the
+    adapter sets them (gfo_ctx_set_combining)."""
+    import shutil
+    import subprocess
+    cc = shutil.which("gcc") or shutil.which("cc")
+    if not cc:
+        return {"error": "no C compiler on this host: tools/c/boundary_throughput.c not built"}
+    exe = "/tmp/gfo_boundary_throughput"
+    try:
+        subprocess.run([cc, "-O2", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tools", "c", "boundary_throughput.c"), "-o", exe,
+                        "-ldl", "-lpthread", "-lm"], check=True, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120)
+        from gf_orb_slam2_amd._lib import lib_path
+        pts = []
+        for mode, ks in (("stereo", "1,4,8,16"), ("adapter", "4,8")):
+            r = subprocess.run([exe, lib_path(), os.path.join(ROOT, "tests", "golden"), str(seconds), mode, ks, "1"], stdout=subprocess.PIPE,
+                               stderr=subprocess.DEVNULL, timeout=180)
+            j = json.loads(r.stdout.decode(errors="replace"))
+            for p in j["points"]:
+                pts.append({k: p[k] for k in ("path", "combining", "streams", "host_threads", "images_per_s", "stereo_frames_per_s",
+                                              "frames_per_device_batch", "latency_ms", "result_mismatches", "errors",
+                                              "contexts_created_in_timed_region", "arenas_planned_in_timed_region")})
+            if r.returncode != 0:
+                return {"error": f"harness rc {r.returncode}", "points": pts}
+        best = max((p for p in pts if p["path"] == "gfo_extract_stereo"), key=lambda p: p["images_per_s"])
+        return {"workload": j["workload"], "unit": "images/s", "harness": "tools/c/boundary_throughput.c (C, dlopen of libgfo.so, no Python in the loop)",
+                "seconds_per_point": seconds, "best_images_per_s": best["images_per_s"], "best_at_streams": best["streams"], "points": pts}
+    except Exception as ex:      # a failing side measurement must not lose the headline line
+        return {"error": repr(ex)}
 
 
 def host_cores():
@@ -277,7 +325,7 @@ class Job:
     """One workload on this rank: input batches resident in HBM, `nctx` independent contexts (arena + HIP stream)
     the steps alternate between, so the tail of one batch overlaps the head of the next."""
 
-    def __init__(self, G, torch, name, B, nctx, local_rank, rank, world, dist, n_inputs=4, prime=True):
+    def __init__(self, G, torch, name, B, nctx, local_rank, rank, world, dist, n_inputs=4, prime=True, gather_every=1):
         from gf_orb_slam2_amd.sharding import shard_pairs
         from gf_orb_slam2_amd.synth import synth_local_map, synth_stereo_pair, synth_stream
         self.G, self.torch, self.name, self.B, self.world, self.dist = G, torch, name, B, world, dist
@@ -326,6 +374,8 @@ class Job:
                 m.map_upload(mpd)                                                      # one resident map per context
         self.step_no = 0
         self.nctx = nctx
+        self.gather_every = max(0, int(gather_every))   # 0 = never: separates straggler coupling from kernel time on a real node
+        self.deliver_blocks = None
         # Setup ends with PRIME_STEPS untimed batches through the whole pipeline: a freshly started process finds the chip
         # at its idle clock and the first ~25 batches run at 0.60-0.70 ms instead of 0.55 (tools/short_run_probe.py) -- with
         # the driver's --steps 20 --warmup 3 that start-up transient is most of the measurement (212k against 236k
@@ -343,7 +393,7 @@ class Job:
         for k in range(n):
             self.exts[k].chain_after(self.exts[(k - 1) % n] if on else None, self.chain_stage)
 
-    def step(self, ctx=None, h2d_from=None):
+    def step(self, ctx=None, h2d_from=None, deliver=False):
         k = self.step_no % self.nctx if ctx is None else ctx
         d_in = self.d_inputs[self.step_no % len(self.d_inputs)]
         self.step_no += 1
@@ -373,7 +423,15 @@ class Job:
             done = self.torch.cuda.Event()
             done.record(self.streams[k])
             self.buf_done[(self.step_no - 1) % len(self.d_inputs)] = done
-        if self.world > 1:
+        if deliver:
+            # every result of the batch -> pinned host memory (one block per context), on the context's copy stream: the D2H
+            # runs beside the next step's kernels and opposite to its H2D (the link is full duplex)
+            if self.deliver_blocks is None:
+                lay = self.exts[k].batch_deliver()
+                self.deliver_layout = lay
+                self.deliver_blocks = [self.torch.empty(lay.bytes, dtype=self.torch.uint8).pin_memory() for _ in range(self.nctx)]
+            self.exts[k].batch_deliver(self.deliver_blocks[k].data_ptr(), self.deliver_layout.bytes)
+        if self.world > 1 and self.gather_every and self.step_no % self.gather_every == 0:
             from gf_orb_slam2_amd.sharding import gather_counts
             with self.torch.cuda.stream(self.streams[k]):
                 gather_counts(self.counts_ts[k], self.world, self.dist, self.gathered[k])
@@ -389,6 +447,9 @@ class Job:
         for _ in range(steps):
             self.step(**kw)
         torch.cuda.synchronize()
+        if kw.get("deliver"):
+            for e in self.exts:
+                e.deliver_wait()
         if world > 1 and barrier:
             dist.barrier()
         dt = time.perf_counter() - t0
@@ -482,8 +543,14 @@ def main():
     ap.add_argument("--streams", type=int, default=0,
                     help="independent contexts (arena + HIP stream) the steps alternate between, so the tail of one "
                          "batch overlaps the head of the next (0 = the workload's measured best, CONTEXTS)")
-    ap.add_argument("--no-live-traffic", action="store_true",
-                    help="do not run the two rocprofv3 --pmc child passes; roofline.traffic then comes from profiles/traffic_latest.json")
+    ap.add_argument("--live-traffic", action="store_true",
+                    help="measure roofline.traffic in this run: two rocprofv3 --pmc child passes (FETCH_SIZE, WRITE_SIZE) before the GPU is "
+                         "initialised (+10 s).  Default: the committed profiles/traffic_latest.json, labelled as such")
+    ap.add_argument("--no-live-traffic", action="store_true", help=argparse.SUPPRESS)   # the round-2 spelling of the default
+    ap.add_argument("--gather-every", type=int, default=1,
+                    help="N > 1 GPUs: all-gather the keypoint counts every this many steps (1 = every step, as north_star names it; "
+                         "0 = never -- separates straggler coupling between ranks from kernel time on a real node)")
+    ap.add_argument("--no-boundary", action="store_true", help="skip the per-frame boundary harness (per_frame_boundary)")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)   # internal: the pass live_traffic() profiles
     args = ap.parse_args()
     if os.environ.get("GFO_BENCH_WATCHDOG"):      # diagnosis of a stalled run: dump every thread's stack after N seconds and exit
@@ -494,8 +561,8 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     # the PMC passes run first, as children, while this process has not touched the GPU yet
-    live, live_note = None, "live measurement off (--no-live-traffic)"
-    if world == 1 and not args.no_live_traffic and not args.pmc_child:
+    live, live_note = None, "live measurement off (opt in with --live-traffic)"
+    if world == 1 and args.live_traffic and not args.pmc_child:
         live, live_note = live_traffic(args.workload, args.batch - (args.batch & 1))
 
     import torch
@@ -520,7 +587,7 @@ def main():
 
     B = args.batch - (args.batch & 1)
     nctx = args.streams if args.streams >= 1 else CONTEXTS[args.workload]   # 0: the workload's default
-    job = Job(G, torch, args.workload, B, nctx, local_rank, rank, world, dist)
+    job = Job(G, torch, args.workload, B, nctx, local_rank, rank, world, dist, prime=not args.pmc_child, gather_every=args.gather_every)
     if args.pmc_child:      # only the kernels are wanted (counters are read per dispatch by the profiler around this process)
         job.timed(args.steps, args.warmup)
         job.close()
@@ -545,6 +612,17 @@ def main():
         dth = job.timed(n_h, 2, h2d_from=pinned)
         job.chain(True)
         extra["value_with_h2d"] = round(B * n_h / dth, 1)
+        # ... and the results out: every step also lands counts, keypoints, descriptors (and the stereo outputs) of its batch in
+        # pinned host memory, where ORBextractor::operator() leaves them (ORBextractor.cc:1137-1173).  Opposite directions of
+        # a full-duplex link: the ceiling stays the input copy
+        dtd = job.timed(n_h, 2, h2d_from=pinned, deliver=True)
+        lay = job.deliver_layout
+        extra["value_delivered"] = round(B * n_h / dtd, 1)
+        extra["delivery"] = {"host_bytes_in_per_step": int(B * job.w * job.h), "host_bytes_out_per_step": int(lay.bytes),
+                             "pcie_ceiling_frames_per_s": round(56.5e9 / (job.w * job.h), 0),
+                             "note": "in: one H2D per step from pinned memory on a copy stream; out: gfo_batch_deliver, D2H on the context's "
+                                     "copy stream, full duplex with the next step's H2D; ceiling = 56.5 GB/s measured H2D rate / bytes per frame in",
+                             "ratio_to_value_with_h2d": round((B * n_h / dtd) / (B * n_h / dth), 3)}
         del pinned
         # median of 20 single batches, one context, each batch synchronised
         lat = []
@@ -573,7 +651,7 @@ def main():
                        "map_points": MAP_POINTS if job.matcher == "project" else None,
                        "mean_keypoints_per_image": round(n_kp_img, 1), "contexts_per_gpu": nctx,
                        "contexts_chained_after_stage": job.chain_stage if job.chained else None,
-                       "priming_steps": PRIME_STEPS,
+                       "priming_steps": PRIME_STEPS, "gather_every": args.gather_every if world > 1 else None,
                        "distinct_input_batches": len(job.d_inputs),
                        "sharding": f"{world} x independent streams, RCCL all-gather of counts" if world > 1 else "single GPU"},
             "roofline": roof,
@@ -597,6 +675,8 @@ def main():
             others.append(side_config(name, ob, args.streams))
         line["other_configs"] = others
 
+    if rank == 0 and world == 1 and not args.no_boundary and not under_profiler():
+        line["per_frame_boundary"] = per_frame_boundary()
     if rank == 0:
         if not args.no_cpu_baseline and world == 1:
             w, h, nfeat, matcher, _ = WORKLOADS[args.workload]

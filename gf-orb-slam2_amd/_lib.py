@@ -57,6 +57,12 @@ class FeatureVectorC(C.Structure):
     _fields_ = [("node_ids", C.c_void_p), ("node_start", C.c_void_p), ("items", C.c_void_p), ("n_nodes", C.c_int32)]
 
 
+class DeliveryC(C.Structure):
+    _fields_ = [("nimg", C.c_int32), ("kp_stride", C.c_int32), ("stereo", C.c_int32)] + \
+               [(k, C.c_size_t) for k in ("off_flags", "off_counts", "off_kp", "off_desc", "off_u_right", "off_depth", "off_best_dist",
+                                          "off_best_idx", "off_nmatched", "bytes")]
+
+
 class StageTime(C.Structure):
     _fields_ = [("name", C.c_char * 32), ("ms", C.c_double), ("launches", C.c_int)]
 
@@ -71,6 +77,7 @@ SYMBOLS = [
     "gfo_map_upload", "gfo_search_by_projection_batch", "gfo_projection_fetch", "gfo_projection_device_views", "gfo_search_by_bow", "gfo_vocabulary_upload", "gfo_bow_transform", "gfo_compute_bow", "gfo_profile_enable",
     "gfo_profile_read", "gfo_debug_blurred_level", "gfo_debug_level_candidates",
     "gfo_contexts_created", "gfo_arenas_planned", "gfo_ctx_id", "gfo_vocabulary_nodes", "gfo_ctx_set_combining", "gfo_combiner_stats",
+    "gfo_batch_deliver", "gfo_deliver_wait",
 ]
 
 
@@ -189,6 +196,8 @@ def load_library():
     L.gfo_profile_read.argtypes = [vp, C.POINTER(StageTime), i, ip, i]
     L.gfo_debug_blurred_level.argtypes = [vp, i, i, vp, i]
     L.gfo_debug_level_candidates.argtypes = [vp, i, i, vp, i, ip]
+    L.gfo_batch_deliver.argtypes = [vp, vp, sz, C.POINTER(DeliveryC)]
+    L.gfo_deliver_wait.argtypes = [vp]
     L.gfo_contexts_created.restype = i
     L.gfo_arenas_planned.restype = i
     L.gfo_ctx_id.argtypes = [vp]

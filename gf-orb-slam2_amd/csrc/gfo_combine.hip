@@ -33,7 +33,7 @@
 namespace
 {
 enum { SLOT_FREE = 0, SLOT_FORMING, SLOT_CLOSED, SLOT_RUNNING, SLOT_DRAINING };
-const int NSLOT = 8;          // batches on the device (GFO_COMBINE_INFLIGHT) + one forming + those still being collected
+const int NSLOT = 8;          // upper bound; an engine uses `inflight + 2` of them: batches on the device, one forming, one being collected
 
 struct Slot {
     gfo_ctx* bc = nullptr;    // the batch context: arena + pinned buffers + stream
@@ -52,7 +52,7 @@ struct Slot {
 struct GfoEngine {
     std::mutex mu;
     std::condition_variable cv;   // callers that cannot join or open a batch, leaders waiting for room on the device
-    int inflight = 2;
+    int inflight = 2, nslot = 4;
     int device = 0, w = 0, h = 0;
     gfo_params prm{};
     int cap_images = 32;      // images per batch (GFO_COMBINE_MAX)
@@ -90,6 +90,7 @@ std::shared_ptr<GfoEngine> engine_for(gfo_ctx* c, int w, int h)
             const int v = atoi(m);
             if (v >= 1 && v <= NSLOT - 2) e->inflight = v;
         }
+        e->nslot = e->inflight + 2;
         g_engines[key] = e;
     }
     c->engine = e;
@@ -158,12 +159,16 @@ int gfo_combined_extract(gfo_ctx* c, int kind, const uint8_t* const* imgs, int w
                 break;
             }
         } else {
-            for (int i = 0; i < NSLOT && si < 0; i++)
+            // every slot the engine will ever use is prepared by its first request: nothing is created or planned once the
+            // streams are running (gfo_contexts_created / gfo_arenas_planned stay put in steady state)
+            for (int i = 0; i < e->nslot; i++) {
+                const int rc = slot_prepare(e, e->slot[i], c);
+                if (rc) return rc;
+            }
+            for (int i = 0; i < e->nslot && si < 0; i++)
                 if (e->slot[i].state == SLOT_FREE) si = i;
             if (si >= 0) {
                 Slot& f = e->slot[si];
-                const int rc = slot_prepare(e, f, c);
-                if (rc) return rc;
                 if (sp && (sp->n_rows < 1 || sp->n_rows > f.bc->st_rows_cap))
                     return gfo_fail(c, GFO_ERR_INVALID, "n_rows %d exceeds the planned %d", sp->n_rows, f.bc->st_rows_cap);
                 f.state = SLOT_FORMING; f.kind = kind; f.n = 1; f.staged = 0; f.readers = 0; f.rc = 0;
@@ -183,7 +188,9 @@ int gfo_combined_extract(gfo_ctx* c, int kind, const uint8_t* const* imgs, int w
 
     // every caller stages its own frame, in parallel, and sends it on its way at once: the copy is queued on the SLOT's
     // stream (idle since the slot's previous batch was collected), so it runs while later joiners are still copying and
-    // while the leader waits for room on the device; the batch's kernels are queued behind all of them
+    // while the leader waits for room on the device; the batch's kernels are queued behind all of them.  ONE copy per
+    // request: splitting a stereo frame into two copies (left image on the link while the right one is staged) measured
+    // 13-17 % slower at K = 8 / 16 -- a copy costs the DMA engine ~10 us whatever its size, and the copies serialise
     int crc = GFO_OK;
     for (int k = 0; k < kind; k++) gfo_small_stage(s.bc, s.L, idx * kind + k, imgs[k], w, h, stride);
     if (hipSetDevice(e->device) != hipSuccess ||

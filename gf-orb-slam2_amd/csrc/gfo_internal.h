@@ -231,6 +231,11 @@ struct gfo_ctx {
     hipGraphExec_t graph_exec = nullptr;
     struct GraphKey { const void* base; const void* pack_dst; long long pitch, img_stride; int nimg, stereo; gfo_stereo_params sp; int plan_gen; } graph_key{};
     int plan_gen = 0;
+    // gfo_batch_deliver: D2H of a batch's results on a stream of its own; the next extraction waits for it before
+    // k_orient_desc overwrites the outputs
+    hipStream_t copy_stream = nullptr;
+    hipEvent_t ev_results = nullptr, ev_delivered = nullptr;
+    bool deliver_pending = false;
     // frame combiner (gfo_ctx_set_combining): per-frame host calls of this context may run inside a shared device batch
     bool combining = false;
     std::shared_ptr<GfoEngine> engine;

@@ -168,6 +168,34 @@ class ORBextractor:
         check(self._L, self._ctx, self._L.gfo_batch_fetch(self._ctx, image, ptr(kp), ptr(desc), cap, C.byref(n)))
         return kp[:n.value].copy(), desc[:n.value].copy()
 
+    def batch_deliver(self, host_ptr=None, host_bytes=0):
+        """gfo_batch_deliver: queue the copy of everything the last batch produced (counts, keypoints, descriptors, stereo
+        outputs) into ONE pinned host block; returns its layout.  host_ptr=None: layout only (`bytes` = size to allocate).
+        Asynchronous: deliver_wait() blocks until the block is complete."""
+        from ._lib import DeliveryC
+        lay = DeliveryC()
+        check(self._L, self._ctx, self._L.gfo_batch_deliver(self._ctx, C.c_void_p(host_ptr) if host_ptr else None, host_bytes, C.byref(lay)))
+        return lay
+
+    def deliver_wait(self):
+        check(self._L, self._ctx, self._L.gfo_deliver_wait(self._ctx))
+
+    @staticmethod
+    def delivered_views(block, lay):
+        """numpy views into a delivered block (a uint8 array over the pinned memory): counts, keypoints [nimg][stride],
+        descriptors [nimg][stride][32] and, when the batch was stereo-matched, (u_right, depth, best_dist, best_idx, nmatched)"""
+        n, ks, npair = lay.nimg, lay.kp_stride, lay.nimg // 2
+        def arr(off, dtype, shape):
+            cnt = int(np.prod(shape))
+            return block[off:off + cnt * np.dtype(dtype).itemsize].view(dtype).reshape(shape)
+        out = {"flags": arr(lay.off_flags, np.int32, (4,)), "counts": arr(lay.off_counts, np.int32, (n,)),
+               "kp": arr(lay.off_kp, KEYPOINT_DTYPE, (n, ks)), "desc": arr(lay.off_desc, np.uint8, (n, ks, 32))}
+        if lay.stereo:
+            out.update(u_right=arr(lay.off_u_right, np.float32, (npair, ks)), depth=arr(lay.off_depth, np.float32, (npair, ks)),
+                       best_dist=arr(lay.off_best_dist, np.int32, (npair, ks)), best_idx=arr(lay.off_best_idx, np.int32, (npair, ks)),
+                       nmatched=arr(lay.off_nmatched, np.int32, (npair,)))
+        return out
+
     # ComputePyramid / mvImagePyramid, ORBextractor.h:127-132
     def ComputePyramid(self, image):
         image = np.ascontiguousarray(image, dtype=np.uint8)

@@ -136,6 +136,22 @@ int gfo_batch_fetch(gfo_ctx* ctx, int image, gfo_keypoint* kp, uint8_t* desc, in
 int gfo_batch_device_views(gfo_ctx* ctx, const gfo_keypoint** d_kp, const uint8_t** d_desc,
                            const int32_t** d_counts, int* kp_stride);
 
+/* Delivery of a device-resident batch to the host: ORBextractor::operator() ends with its results in host containers
+ * (src/ORBextractor.cc:1137-1173: _descriptors.create, the keypoint vector) and the stereo Frame constructor with mvuRight /
+ * mvDepth (src/Frame.cc:1167-1316).  gfo_batch_deliver queues the copy of EVERYTHING the last batch produced -- overflow
+ * flags, counts, keypoints, descriptors and, after gfo_stereo_match_batch, the four stereo arrays and nmatched -- into ONE
+ * pinned host block `host_dst` laid out as `layout` says, on a copy stream of the context: the call returns at once, the
+ * copies run behind the batch's kernels and beside whatever is submitted next (the next extraction on this context only
+ * waits for them before it overwrites the outputs), gfo_deliver_wait blocks until the block is complete.
+ * host_dst = NULL only fills `layout` (bytes = size to allocate: hipHostMalloc / a pinned torch tensor).  Arrays keep the
+ * arena's strides: keypoints [nimg][kp_stride], descriptors [nimg][kp_stride][32], stereo arrays [nimg/2][kp_stride]. */
+typedef struct {
+    int32_t nimg, kp_stride, stereo;
+    size_t off_flags, off_counts, off_kp, off_desc, off_u_right, off_depth, off_best_dist, off_best_idx, off_nmatched, bytes;
+} gfo_delivery;
+int gfo_batch_deliver(gfo_ctx* ctx, void* host_dst, size_t host_bytes, gfo_delivery* layout);
+int gfo_deliver_wait(gfo_ctx* ctx);
+
 /* ORBextractor::ComputePyramid + public member mvImagePyramid (include/ORBextractor.h:127-132,
  * src/ORBextractor.cc:1176-1201).  Copies level `level` of image `image` of the last batch
  * to host.  border = 0: the w_l x h_l level; border = 19: with the BORDER_REFLECT_101 frame

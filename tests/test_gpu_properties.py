@@ -107,6 +107,81 @@ def test_full_batch_stereo_properties(batch, oracle):
         assert a.tobytes() == b.tobytes()
 
 
+@pytest.fixture(scope="module")
+def oracle_refs(batch, oracle):
+    """the 16 distinct images (8 pairs) of the batch through the oracle, once per session"""
+    _, _, imgs = batch
+    oe = oracle.OracleExtractor(2000, 1.2, 8, 20, 7)
+    ext_refs = [oe(imgs[i]) for i in range(16)]
+    sf = oe.scale_factors
+    st_refs = [oracle.stereo_match(ext_refs[2 * p][0], ext_refs[2 * p][1], ext_refs[2 * p + 1][0], ext_refs[2 * p + 1][1], sf, 480,
+                                   47.90639384423901, 47.90639384423901 / 435.2046959714599, 0.0) for p in range(8)]
+    return ext_refs, st_refs
+
+
+def test_headline_configuration_against_the_oracle(batch, oracle_refs):
+    """bench.py's exact headline shape: 128 images per step, TWO contexts chained behind each
+    other's pyramid (gfo_ctx_chain), four alternating steps submitted without a synchronisation in between, stereo
+    association of the 64 pairs -- then, per context, 16 images (every distinct image once, at positions spread over
+    the batch) and 8 pairs compared with the oracle bit for bit, read back through gfo_batch_deliver (the delivery
+    path bench.py's `value_delivered` uses) and cross-checked against gfo_batch_fetch / gfo_stereo_fetch."""
+    import torch
+    import gf_orb_slam2_amd as G
+    _, t, imgs = batch
+    ext_refs, st_refs = oracle_refs
+    # a second input batch with the 8 pairs in another order, so that a frame's slot differs between the inputs
+    perm = np.concatenate([[2 * ((p * 5 + 3) % 64), 2 * ((p * 5 + 3) % 64) + 1] for p in range(64)])
+    t2 = t[torch.from_numpy(perm).cuda()].contiguous()
+    inputs, ident = [t, t2], [np.arange(B) % 16, perm % 16]
+    prm = G.StereoParams(480, 47.90639384423901, 47.90639384423901 / 435.2046959714599, 0.0)
+    exts = [G.ORBextractor(2000, 1.2, 8, 20, 7, max_batch=B) for _ in range(2)]
+    ms = [G.ORBmatcher(0.8, True, extractor=e) for e in exts]
+    exts[0].chain_after(exts[1], exts[0].STAGE_PYRAMID)
+    exts[1].chain_after(exts[0], exts[1].STAGE_PYRAMID)
+    lay = None
+    blocks = []
+    for step in range(4):                          # ctx 0: inputs 0, 0 ; ctx 1: inputs 1, 1 -- then swapped roles below
+        k = step & 1
+        src = (step + (step >> 1)) & 1             # 0, 1, 1, 0: each context sees both inputs
+        exts[k].extract_batch_device(inputs[src].data_ptr(), B, 752, 480)
+        ms[k].stereo_match_batch(prm)
+        if step >= 2:
+            if lay is None:
+                lay = exts[k].batch_deliver()
+            blk = torch.empty(lay.bytes, dtype=torch.uint8).pin_memory()
+            exts[k].batch_deliver(blk.data_ptr(), lay.bytes)
+            blocks.append((k, src, blk))
+    for k, src, blk in blocks:
+        exts[k].deliver_wait()
+        v = G.ORBextractor.delivered_views(blk.numpy(), lay)
+        assert v["flags"][0] == 0 and lay.stereo == 1 and lay.nimg == B
+        slots = [next(i for i in range((7 * j) % B, B + (7 * j) % B) if ident[src][i % B] == j) % B for j in range(16)]   # image j somewhere past 7j
+        for j, i in enumerate(slots):
+            n = int(v["counts"][i])
+            ok, od = ext_refs[j]
+            assert n == len(ok) and v["kp"][i, :n].tobytes() == ok.tobytes() and (v["desc"][i, :n] == od).all(), f"ctx {k} image slot {i}"
+        pairs = sorted({i // 2 for i in slots})[:8] if len({i // 2 for i in slots}) >= 8 else list(range(0, 64, 8))
+        seen = set()
+        for pr in pairs + list(range(64)):
+            j = int(ident[src][2 * pr]) // 2
+            if j in seen:
+                continue
+            seen.add(j)
+            nl = int(v["counts"][2 * pr])
+            nm, u, dp, bd, bi = st_refs[j]
+            assert int(v["nmatched"][pr]) == nm
+            for a, b_ in ((v["u_right"][pr, :nl], u), (v["depth"][pr, :nl], dp), (v["best_dist"][pr, :nl], bd), (v["best_idx"][pr, :nl], bi)):
+                assert a.tobytes() == b_.tobytes(), f"ctx {k} pair {pr}"
+        assert len(seen) == 8
+        # the delivered block equals what the fetch entry points hand out
+        kf, df = exts[k].batch_fetch(slots[5])
+        assert kf.tobytes() == v["kp"][slots[5], :len(kf)].tobytes() and (df == v["desc"][slots[5], :len(kf)]).all()
+        g = ms[k].stereo_fetch(3, int(v["counts"][6]))
+        assert g[0] == int(v["nmatched"][3]) and g[1].tobytes() == v["u_right"][3, :len(g[1])].tobytes()
+    for e in exts:
+        e.close()
+
+
 def test_count_all_gather_over_rccl_single_rank():
     """bench.py's only collective, on the real backend: torch.distributed 'nccl' (= RCCL) all-gathering the per-image
     keypoint counts straight out of the arena (the int32 vector is aliased through __cuda_array_interface__, no

@@ -8,7 +8,7 @@ D=/tmp/gfo_dbg; rm -rf $D; mkdir -p $D/pkg; cp -r $R/include $D/include; cp -r $
 export GFO_LIB=/tmp/libgfo_dbg.so
 for s in 1 2 3 4 0; do
   export GFO_FAST_STOP=$s
-  sleep 2; timeout -k 10 150 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES --output-format csv -d $OUT/s$s -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-other-configs --profile-steps 1 --streams 1 > $OUT/s$s.log 2>&1
+  timeout -k 10 150 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES --output-format csv -d $OUT/s$s -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-other-configs --profile-steps 1 --streams 1 > $OUT/s$s.log 2>&1
 done
 python3 - <<'PY'
 import csv, glob, os, collections

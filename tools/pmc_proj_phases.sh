@@ -8,7 +8,7 @@ D=/tmp/gfo_dbg; rm -rf $D; mkdir -p $D/pkg; cp -r $R/include $D/include; cp -r $
 export GFO_LIB=/tmp/libgfo_dbg.so
 for s in 1 2 0; do
   export GFO_PROJ_STOP=$s
-  sleep 2; timeout -k 10 150 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES --output-format csv -d $OUT/s$s -- python3 tools/proj_diag.py 128 > $OUT/s$s.log 2>&1
+  timeout -k 10 150 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES --output-format csv -d $OUT/s$s -- python3 tools/proj_diag.py 128 > $OUT/s$s.log 2>&1
   rocprofv3 --kernel-trace --output-format csv -d $OUT/t$s -- python3 tools/proj_diag.py 128 > $OUT/t$s.log 2>&1
 done
 python3 - <<'PY'

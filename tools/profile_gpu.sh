@@ -11,7 +11,7 @@ OUT=$R/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd $R
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 bench.py $ARGS > $OUT/bench_trace.log 2>&1 || exit 1
-sleep 2; timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 bench.py --pmc-child --steps 6 --warmup 2 --streams 1 > $OUT/bench_fetch.log 2>&1 || exit 2
-sleep 2; timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 bench.py --pmc-child --steps 6 --warmup 2 --streams 1 > $OUT/bench_write.log 2>&1 || exit 3
+timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 bench.py --pmc-child --steps 6 --warmup 2 --streams 1 > $OUT/bench_fetch.log 2>&1 || exit 2
+timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 bench.py --pmc-child --steps 6 --warmup 2 --streams 1 > $OUT/bench_write.log 2>&1 || exit 3
 find $OUT -name "*.csv" | head -20
 python3 tools/summarize_profile.py $OUT $TAG || exit 4
