@@ -44,6 +44,33 @@ struct orc_extractor {
     int nkp[MAX_LEVELS];
 };
 
+/* ------------------------------------------------------------------------------------------
+ * [OCV] variant table.  Every piece of OpenCV 3.4.1 arithmetic this file restates from memory of the published
+ * sources is a SINGLE switch here, so that whoever can run cv2 3.4.x (tests/golden/check_against_cv2.py does the
+ * comparison stage by stage and names the switch) turns a mismatch into a one-line change of
+ * oracle/ocv_variants.json followed by tests/golden/make_golden.py.  The defaults are the variants the golden vectors
+ * and the GPU kernels use; "parity unpinned" (orb_oracle.h) stays until that script has run green once.
+ *   ORC_OCV_RESIZE      0 = 11-bit fixed-point bilinear (the generic resizeGeneric_ path; default)
+ *                       1 = float bilinear, rounded half to even (what an IPP-backed build computes to within 1 LSB)
+ *   ORC_OCV_ATAN_FMA    0 = polynomial in separate multiplies and adds (default)   1 = Horner steps fused (v_fma builds)
+ *   ORC_OCV_BLUR_ROUND  0 = exact accumulation, one (v + 2^15) >> 16 at the end (default; the classic int path and
+ *                           the 8.8 fixed-point path agree on it)
+ *                       1 = horizontal pass rounded to 8 bits first ((v + 128) >> 8), then the vertical pass likewise
+ *   Gaussian taps       orc_set_gauss_taps(): seven integers, scale 256 ({18,34,49,55,49,34,18}, sum 257, = round(256 k);
+ *                           a build whose fixed-point kernel is renormalised to sum 256 needs another centre tap)
+ * ---------------------------------------------------------------------------------------- */
+static int g_ocv[ORC_OCV_COUNT] = {0, 0, 0};
+static int g_gauss7[7] = {18, 34, 49, 55, 49, 34, 18};
+int orc_set_ocv_variant(int key, int value)
+{
+    if (key < 0 || key >= ORC_OCV_COUNT) return -1;
+    g_ocv[key] = value;
+    return 0;
+}
+int orc_get_ocv_variant(int key) { return key < 0 || key >= ORC_OCV_COUNT ? -1 : g_ocv[key]; }
+void orc_set_gauss_taps(const int* taps7) { memcpy(g_gauss7, taps7, sizeof g_gauss7); }
+void orc_get_gauss_taps(int* taps7) { memcpy(taps7, g_gauss7, sizeof g_gauss7); }
+
 /* array forms for the sweep tests (tests/test_oracle.py) */
 void orc_fast_atan2_n(const float* y, const float* x, int n, float* out)
 {
@@ -74,7 +101,9 @@ float orc_fast_atan2(float y, float x)
     const int steep = !(mx >= my);                      /* ax >= ay takes the first branch, NaNs included */
     const float num = steep ? mx : my, den = (steep ? my : mx) + tiny;
     const float r = num / den, r2 = r * r;
-    float deg = (((q7 * r2 + q5) * r2 + q3) * r2 + q1) * r;
+    float deg;
+    if (g_ocv[ORC_OCV_ATAN_FMA]) deg = fmaf(fmaf(fmaf(q7, r2, q5), r2, q3), r2, q1) * r;
+    else deg = (((q7 * r2 + q5) * r2 + q3) * r2 + q1) * r;
     if (steep) deg = 90.f - deg;
     if (x < 0) deg = 180.f - deg;
     if (y < 0) deg = 360.f - deg;
@@ -195,9 +224,39 @@ static void resize_axis_tables(int ssize, int dsize, int* ofs, short* coef, int 
     }
 }
 
+/* variant 1: the same sample positions, interpolated in float and rounded once */
+static void resize_linear_float_u8(const uint8_t* src, int sw, int sh, int sstride, uint8_t* dst, int dw, int dh, int dstride)
+{
+    const double sx_ = 1. / ((double)dw / sw), sy_ = 1. / ((double)dh / sh);
+    for (int dy = 0; dy < dh; dy++) {
+        float fy = (float)((dy + 0.5) * sy_ - 0.5);
+        int y0 = (int)floorf(fy);
+        fy -= y0;
+        if (y0 < 0) { y0 = 0; fy = 0; }
+        if (y0 >= sh - 1) { y0 = sh - 1; fy = 0; }
+        const int y1 = y0 + 1 < sh ? y0 + 1 : y0;
+        for (int dx = 0; dx < dw; dx++) {
+            float fx = (float)((dx + 0.5) * sx_ - 0.5);
+            int x0 = (int)floorf(fx);
+            fx -= x0;
+            if (x0 < 0) { x0 = 0; fx = 0; }
+            if (x0 >= sw - 1) { x0 = sw - 1; fx = 0; }
+            const int x1 = x0 + 1 < sw ? x0 + 1 : x0;
+            const float top = src[(size_t)y0 * sstride + x0] * (1.f - fx) + src[(size_t)y0 * sstride + x1] * fx;
+            const float bot = src[(size_t)y1 * sstride + x0] * (1.f - fx) + src[(size_t)y1 * sstride + x1] * fx;
+            const int v = orc_cv_round(top * (1.f - fy) + bot * fy);
+            dst[(size_t)dy * dstride + dx] = (uint8_t)(v < 0 ? 0 : v > 255 ? 255 : v);
+        }
+    }
+}
+
 void orc_resize_linear_u8(const uint8_t* src, int sw, int sh, int sstride,
                           uint8_t* dst, int dw, int dh, int dstride)
 {
+    if (g_ocv[ORC_OCV_RESIZE] == 1) {
+        resize_linear_float_u8(src, sw, sh, sstride, dst, dw, dh, dstride);
+        return;
+    }
     int* xofs = (int*)malloc(sizeof(int) * dw);
     int* yofs = (int*)malloc(sizeof(int) * dh);
     short* alpha = (short*)malloc(sizeof(short) * 2 * dw);
@@ -293,24 +352,25 @@ void orc_get_level_padded(const orc_extractor* e, int level, uint8_t* out, int o
  * exactly (no intermediate rounding) and finish with (v + 2^15) >> 16 saturated to 255, so the
  * two give the same bytes.
  * ---------------------------------------------------------------------------------------- */
-static const int k_gauss7[7] = {18, 34, 49, 55, 49, 34, 18};
-
 void orc_gaussian_blur7_u8(const uint8_t* src, int w, int h, int sstride, uint8_t* dst, int dstride)
 {
+    const int* taps = g_gauss7;                              /* the variant table, default {18,34,49,55,49,34,18} */
+    const int per_pass = g_ocv[ORC_OCV_BLUR_ROUND] == 1;
     int* tmp = (int*)malloc(sizeof(int) * (size_t)w * h);
     for (int y = 0; y < h; y++) {
         const uint8_t* S = src + (size_t)y * sstride;
         for (int x = 0; x < w; x++) {
             int acc = 0;
-            for (int k = -3; k <= 3; k++) acc += k_gauss7[k + 3] * S[reflect101(x + k, w)];
+            for (int k = -3; k <= 3; k++) acc += taps[k + 3] * S[reflect101(x + k, w)];
+            if (per_pass) { acc = (acc + 128) >> 8; acc = acc > 255 ? 255 : acc; }
             tmp[(size_t)y * w + x] = acc;
         }
     }
     for (int y = 0; y < h; y++) {
         for (int x = 0; x < w; x++) {
             unsigned acc = 0;
-            for (int k = -3; k <= 3; k++) acc += (unsigned)k_gauss7[k + 3] * (unsigned)tmp[(size_t)reflect101(y + k, h) * w + x];
-            unsigned v = (acc + 32768u) >> 16;
+            for (int k = -3; k <= 3; k++) acc += (unsigned)taps[k + 3] * (unsigned)tmp[(size_t)reflect101(y + k, h) * w + x];
+            unsigned v = per_pass ? (acc + 128u) >> 8 : (acc + 32768u) >> 16;
             dst[(size_t)y * dstride + x] = (uint8_t)(v > 255 ? 255 : v);
         }
     }

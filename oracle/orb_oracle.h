@@ -39,6 +39,15 @@ enum {
     ORC_ROT_FMA = 1      /* fmaf(x, b, y*a): what gcc -O3 -march=native may contract to  */
 };
 
+/* [OCV] variant table (process-wide; orb_oracle.c documents each value).  tests/golden/check_against_cv2.py compares
+ * every stage with cv2 3.4.x where that exists and names the switch to flip; oracle/ocv_variants.json holds the values
+ * the Python binding applies at load. */
+enum { ORC_OCV_RESIZE = 0, ORC_OCV_ATAN_FMA = 1, ORC_OCV_BLUR_ROUND = 2, ORC_OCV_COUNT = 3 };
+int orc_set_ocv_variant(int key, int value);
+int orc_get_ocv_variant(int key);
+void orc_set_gauss_taps(const int* taps7);
+void orc_get_gauss_taps(int* taps7);
+
 orc_extractor* orc_create(int nfeatures, float scale_factor, int nlevels, int ini_th, int min_th);
 void orc_destroy(orc_extractor* e);
 void orc_set_variant(orc_extractor* e, int trig_mode, int rot_mode);

@@ -19,6 +19,8 @@ MAP_POINT_DTYPE = np.dtype([("proj_x", "<f4"), ("proj_y", "<f4"), ("proj_xr", "<
 PROJ_QUERY_DTYPE = np.dtype([("u", "<f4"), ("v", "<f4"), ("ur", "<f4"), ("radius", "<f4"), ("min_level", "<i4"),
                              ("max_level", "<i4"), ("angle", "<f4"), ("flags", "<i4")])
 
+_VARIANTS_PATH = os.path.join(_HERE, "ocv_variants.json")
+OCV_KEYS = {"resize": 0, "atan_fma": 1, "blur_round": 2}     # ORC_OCV_* of orb_oracle.h
 TRIG_SHARED, TRIG_LIBM = 0, 1
 ROT_UNFUSED, ROT_FMA = 0, 1
 
@@ -34,7 +36,7 @@ class FrameBounds(C.Structure):
 def build(force=False):
     if force or not os.path.exists(_LIB_PATH) or any(
             os.path.getmtime(os.path.join(_HERE, f)) > os.path.getmtime(_LIB_PATH)
-            for f in ("orb_oracle.c", "orb_oracle.h")):
+            for f in ("orb_oracle.c", "orb_oracle.h", "Makefile")):
         subprocess.check_call(["make", "-C", _HERE, "-s"] + (["-B"] if force else []))
     return _LIB_PATH
 
@@ -80,8 +82,40 @@ def lib():
         L.orc_stereo_match.argtypes = [vp, vp, i, vp, vp, i, vp, C.POINTER(StereoParams), vp, vp, vp, vp, vp, vp]
         L.orc_search_by_projection.argtypes = [vp, vp, vp, i, vp, C.POINTER(FrameBounds), vp, vp, i, f, f, vp, vp, vp]
         L.orc_features_in_area.argtypes = [vp, i, C.POINTER(FrameBounds), f, f, f, i, i, vp, i]
+        L.orc_set_ocv_variant.argtypes = [i, i]
+        L.orc_get_ocv_variant.argtypes = [i]
+        L.orc_set_gauss_taps.argtypes = [vp]
+        L.orc_get_gauss_taps.argtypes = [vp]
         _lib = L
+        set_ocv_variants(**load_ocv_variants())      # oracle/ocv_variants.json: the committed [OCV] choices
     return _lib
+
+
+def load_ocv_variants(path=None):
+    import json
+    j = json.load(open(path or _VARIANTS_PATH))
+    return {k: j[k] for k in ("resize", "atan_fma", "blur_round", "gauss_taps")}
+
+
+def set_ocv_variants(resize=None, atan_fma=None, blur_round=None, gauss_taps=None):
+    """Switch the [OCV] variant table of the C oracle (process-wide).  None leaves a switch as it is."""
+    L = lib() if _lib is None else _lib
+    for name, v in (("resize", resize), ("atan_fma", atan_fma), ("blur_round", blur_round)):
+        if v is not None and L.orc_set_ocv_variant(OCV_KEYS[name], int(v)) != 0:
+            raise ValueError(name)
+    if gauss_taps is not None:
+        t = np.ascontiguousarray(gauss_taps, np.int32)
+        assert t.shape == (7,)
+        L.orc_set_gauss_taps(_p(t))
+
+
+def get_ocv_variants():
+    L = lib()
+    t = np.zeros(7, np.int32)
+    L.orc_get_gauss_taps(_p(t))
+    out = {name: L.orc_get_ocv_variant(k) for name, k in OCV_KEYS.items()}
+    out["gauss_taps"] = [int(x) for x in t]
+    return out
 
 
 def _p(a):

@@ -3,8 +3,10 @@
 
 The reference holds no golden keypoints / descriptors / matches, and its own code
 cannot be built here (no OpenCV), so these vectors pin THE ORACLE, variant
-  blur   : integer taps {18,34,49,55,49,34,18}, (v + 2^15) >> 16
-  sincos : include/gfo_sincos.h (double-evaluated, rounded once), rotation un-fused
+  [OCV] table : oracle/ocv_variants.json as committed (resize 11-bit fixed point; Gaussian taps {18,34,49,55,49,34,18},
+                exact accumulation, (v + 2^15) >> 16; fastAtan2 un-fused) -- written into variants.json next to the
+                vectors; tests/golden/check_against_cv2.py is what decides whether that table is the reference's
+  sincos : correctly rounded (long double, rounded once), rotation un-fused
   quadtree tie-break : equal-sized nodes split newest first
 against accidental change, and give the GPU tests a reference that needs no oracle run.
 Inputs: the reference's own test images test/EuRoC_l.png / EuRoC_r.png (raw dumps).
@@ -59,7 +61,10 @@ def make_projection_case(kp, desc, seed=7, m=5000):
 
 
 def main():
+    import json
     oe = O.OracleExtractor(2000, 1.2, 8, 20, 7)
+    with open(os.path.join(HERE, "variants.json"), "w") as f:      # the table the vectors below were made under
+        json.dump({"ocv": O.get_ocv_variants(), "sincos": "correctly rounded", "rotation": "un-fused", "quadtree_ties": "newest first"}, f, indent=1)
     out = {}
     for side in ("l", "r"):
         img = np.fromfile(os.path.join(HERE, f"EuRoC_{side}_752x480.u8"), np.uint8).reshape(480, 752)

@@ -398,3 +398,104 @@ def test_bow_oracle_against_python_statement(oracle):
         np.testing.assert_array_equal(got[1], ref[1])
     assert oracle.three_maxima([5, 1, 9, 0, 9, 3]) == (2, 4, 0)
     assert oracle.three_maxima([100, 5, 3] + [0] * 27) == (0, -1, -1)
+
+
+def test_ocv_variant_switches_are_single_and_restorable(oracle):
+    """oracle/ocv_variants.json is what the binding applies at load; every [OCV] switch changes its block and nothing
+    else, and restoring the committed table restores the bytes (the golden vectors are made under it)."""
+    committed = oracle.load_ocv_variants()
+    assert oracle.get_ocv_variants() == committed == {"resize": 0, "atan_fma": 0, "blur_round": 0, "gauss_taps": [18, 34, 49, 55, 49, 34, 18]}
+    img = synth_frame(320, 240, 2)
+    base = (oracle.resize_linear(img, 267, 200), oracle.gaussian_blur7(img))
+    y = np.arange(-500, 500, dtype=np.float32) * 37.0
+    x = np.arange(1000, dtype=np.float32)[::-1] * 11.0 - 3000.0
+    a0 = oracle.fast_atan2_n(y, x)
+    try:
+        oracle.set_ocv_variants(resize=1)
+        r1 = oracle.resize_linear(img, 267, 200)
+        assert (r1 != base[0]).any() and np.abs(r1.astype(int) - base[0]).max() == 1      # float vs 11-bit fixed point: one grey level
+        assert (oracle.gaussian_blur7(img) == base[1]).all()                                # ... and nothing else moved
+        oracle.set_ocv_variants(resize=0, blur_round=1)
+        assert (oracle.gaussian_blur7(img) != base[1]).any() and (oracle.resize_linear(img, 267, 200) == base[0]).all()
+        oracle.set_ocv_variants(blur_round=0, gauss_taps=[18, 34, 49, 54, 49, 34, 18])     # a kernel renormalised to sum 256
+        assert (oracle.gaussian_blur7(img) != base[1]).mean() > 0.3
+        oracle.set_ocv_variants(gauss_taps=committed["gauss_taps"], atan_fma=1)
+        a1 = oracle.fast_atan2_n(y, x)
+        assert (a1.view(np.uint32) != a0.view(np.uint32)).any() and np.abs(a1 - a0).max() < 1e-4
+    finally:
+        oracle.set_ocv_variants(**committed)
+    assert (oracle.resize_linear(img, 267, 200) == base[0]).all() and (oracle.gaussian_blur7(img) == base[1]).all()
+    assert (oracle.fast_atan2_n(y, x).view(np.uint32) == a0.view(np.uint32)).all()
+
+
+def _run_cv2_check(extra_path=None):
+    import subprocess
+    import sys
+    env = dict(os.environ)
+    if extra_path:
+        env["PYTHONPATH"] = extra_path + os.pathsep + env.get("PYTHONPATH", "")
+    return subprocess.run([sys.executable, os.path.join(GOLDEN, "check_against_cv2.py")], capture_output=True, text=True, env=env, timeout=600)
+
+
+def test_cv2_pin_script_skips_cleanly_without_opencv():
+    """tests/golden/check_against_cv2.py is the one-command pin for whoever has cv2 3.4.x.  Here
+    OpenCV is absent: it must say so and exit 0, comparing nothing."""
+    try:
+        import cv2  # noqa: F401
+        pytest.skip("cv2 is importable here: run tests/golden/check_against_cv2.py itself, it is the pin")
+    except ImportError:
+        pass
+    r = _run_cv2_check()
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "cv2 absent" in r.stdout and "parity unpinned" in r.stdout
+
+
+def test_cv2_pin_script_control_flow_against_a_mock(oracle, tmp_path):
+    """The script cannot meet a real cv2 in this image, so its CONTROL FLOW is exercised with a mock module named cv2 that
+    answers every call from the oracle itself -- once under the committed variant table (every stage must come out equal),
+    once under a deliberately different one (Gaussian centre tap 54, fused atan2 Horner steps: the stages must come out
+    DIFFERS, name the matching candidate and exit 1).  The mock pins NOTHING (its version string makes the script say so);
+    it only guarantees that the day a real cv2 is present the script runs instead of dying on a typo."""
+    mock = tmp_path / "cv2.py"
+    mock.write_text('''
+import os, sys, numpy as np
+sys.path.insert(0, %r)
+from oracle import orb_oracle as O
+__version__ = "0.0-mock"
+INTER_LINEAR = 1; BORDER_REFLECT_101 = 4; FAST_FEATURE_DETECTOR_TYPE_9_16 = 2
+_ALT = os.environ.get("MOCK_CV2_ALT") == "1"
+def _with(fn, **kw):
+    cur = O.get_ocv_variants()
+    O.set_ocv_variants(**kw)
+    try: return fn()
+    finally: O.set_ocv_variants(**cur)
+def resize(src, size, interpolation=None): return _with(lambda: O.resize_linear(src, size[0], size[1]), resize=0)
+def copyMakeBorder(a, t, b, l, r, kind): return np.pad(a, ((t, b), (l, r)), mode="reflect")
+def getGaussianKernel(n, s):
+    x = np.arange(n) - (n - 1) / 2.0; k = np.exp(-x * x / (2 * s * s)); return (k / k.sum()).reshape(-1, 1)
+def GaussianBlur(a, ks, sx, sy, borderType=None):
+    return _with(lambda: O.gaussian_blur7(a), blur_round=0, gauss_taps=[18, 34, 49, 54 if _ALT else 55, 49, 34, 18])
+class _KP:
+    def __init__(s, x, y, r): s.pt = (float(x), float(y)); s.response = float(r)
+class _Det:
+    def __init__(s, t): s.t = t
+    def detect(s, img, mask): return [_KP(*r) for r in O.fast9_nms(img, s.t).tolist()]
+def FastFeatureDetector_create(threshold=10, nonmaxSuppression=True, type=2): return _Det(threshold)
+def fastAtan2(y, x): return float(_with(lambda: O.fast_atan2_n(np.float32([y]), np.float32([x]))[0], atan_fma=1 if _ALT else 0))
+def phase(x, y, angleInDegrees=False): return _with(lambda: O.fast_atan2_n(y, x), atan_fma=1 if _ALT else 0)
+''' % ROOT)
+    r = _run_cv2_check(str(tmp_path))
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert "EQUAL (but cv2 is not 3.4.x)" in r.stdout and "DIFFERS" not in r.stdout
+    os.environ["MOCK_CV2_ALT"] = "1"
+    try:
+        r = _run_cv2_check(str(tmp_path))
+    finally:
+        del os.environ["MOCK_CV2_ALT"]
+    assert r.returncode == 1, r.stdout[-3000:] + r.stderr[-3000:]
+    assert "[DIFFERS] blur/EuRoC_l" in r.stdout and "round=0 centre=54" in r.stdout
+    assert "[DIFFERS] fastAtan2/scalar" in r.stdout and '"atan_fma": 1' in r.stdout
+    assert "[ok] resize/EuRoC_l" in r.stdout and "NOT PINNED" in r.stdout
+    rep = os.path.join(GOLDEN, "cv2_pin_report.json")
+    if os.path.exists(rep):
+        os.remove(rep)       # a mock's report must not be mistaken for a pin
