@@ -407,7 +407,7 @@ int gfo_plan(gfo_ctx* c, int w, int h, int batch)
     }
     const size_t B = (size_t)batch;
     HIP_TRY(c, hipMalloc(&c->d_geom, sizeof(GfoGeom)));
-    HIP_TRY(c, hipMalloc(&c->d_input, B * g.lv[0].pitch * (size_t)h));
+    HIP_TRY(c, hipMalloc(&c->d_input, B * g.lv[0].pitch * (size_t)h + 64));   // +64: the resize row window may look past a row (never past the last row of a caller's image)
     HIP_TRY(c, hipMalloc(&c->d_pyr, B * (size_t)(g.pyr_img_stride > 0 ? g.pyr_img_stride : 256) + 256));
     HIP_TRY(c, hipMalloc(&c->d_blur, B * (size_t)g.blur_img_stride + 256));  // +256: window staging may read 3 B past a row end
     HIP_TRY(c, hipMalloc(&c->d_cand, B * (size_t)(g.cand_img_stride + 64) * sizeof(uint32_t)));

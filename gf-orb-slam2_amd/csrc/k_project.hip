@@ -309,7 +309,11 @@ __device__ __forceinline__ void scan_candidates(const ProjB& a, int f, int n, in
     }
 }
 
-// cached form of a candidate: dist << 23 | octave << 16 | index (-1 = none)
+// cached form of a candidate: dist << 23 | octave << 16 | index (-1 = none).  A distance of 256 -- every bit differs --
+// sets bit 31 and so reads as "none" too (every consumer tests `< 0`).  That is the reference's behaviour, not an
+// accident of the packing: bestDist and bestDist2 START at 256 and are replaced on strict `<` only (ORBmatcher.cc:186-224),
+// so a candidate at distance 256 becomes neither best nor second-best and the ratio test never sees its level
+// (tests/test_gpu_projection.py::test_candidate_at_distance_256_is_no_candidate).
 __device__ __forceinline__ int key_entry(unsigned long long key)
 {
     if (key == ~0ull) return -1;

@@ -92,9 +92,11 @@ __device__ __forceinline__ void resize_block(const uint8_t* __restrict__ src, in
     // over_mode 1 = the source is a pyramid plane of the arena (256 bytes of slack behind the last one), 2 = the source
     // is the caller's image: allowed unless one of the rows this block loads is the image's last, 0 = never (LDS bands).
     // Without this the last quads take the byte path, and a wave holding one of them (one in two or three) runs BOTH.
-    const bool over = over_mode == 1 || (over_mode == 2 && r_first + RS_MAXR - 1 < sh - 1);
-    const bool fast = (sx[3] + 1 - sx[0]) < 8 && (base_x + 12 <= sw || over);
+    // (the last row this block loads is r_first + RS_MAXR - 1 in the six-row path and r_last in the row-by-row path of
+    //  steep scale factors: both must stay clear of the image's last row)
     const int r_last = min(max(syv[dy1 - dy0 - 1] + 1, 0), sh - 1);
+    const bool over = over_mode == 1 || (over_mode == 2 && max(r_first + RS_MAXR - 1, r_last) < sh - 1);
+    const bool fast = (sx[3] + 1 - sx[0]) < 8 && (base_x + 12 <= sw || over);
     src -= (long long)srow0 * spitch;
     if (r_last - r_first < RS_MAXR) {
         // all source rows of the block in flight together

@@ -123,8 +123,12 @@ __global__ __launch_bounds__(1024) void k_stereo_bucket(StereoArgs a)
         a.sx[so + pos] = k.x;
         // the row band of this right keypoint (Frame.h:248-256), once here instead of once per left keypoint that visits it
         const float rr = 2.0f * a.scale[k.octave];
-        const int maxr = (int)fminf((float)(nRows - 1), ceilf(k.y + rr));
-        const int minr = (int)fmaxf(0.0f, floorf(k.y - rr));
+        int maxr = (int)fminf((float)(nRows - 1), ceilf(k.y + rr));
+        int minr = (int)fmaxf(0.0f, floorf(k.y - rr));
+        // a keypoint whose band misses the image (host arrays may carry any y: maxr < 0 or minr > nRows - 1) enters no
+        // row in the reference -- `for (yi = minr; yi <= maxr; yi++)` does not run, Frame.h:256 -- and must not wrap
+        // around in the packed form: stored as the empty band (1, 0)
+        if (minr > maxr) { minr = 1; maxr = 0; }
         a.sband[so + pos] = (unsigned)minr | ((unsigned)maxr << 16);   // n_rows <= 65535 (checked by the launcher)
         a.soi[so + pos] = ((unsigned)k.octave << 16) | (unsigned)i;
         a.sdesc[2 * (so + pos)] = dr[2 * i];

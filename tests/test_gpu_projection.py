@@ -217,3 +217,31 @@ def test_more_keypoints_than_fit_the_lds_tables(ext, oracle):
         assert got[0] == ref[0] and ref[0] > 5000
         np.testing.assert_array_equal(got[1], ref[1])
         np.testing.assert_array_equal(got[2][got[1] >= 0], ref[2][ref[1] >= 0])
+
+
+def test_candidate_at_distance_256_is_no_candidate(ext, oracle):
+    """ADVICE r2 asked about k_project.hip's key_entry: a candidate whose descriptor differs in all 256 bits packs as
+    dist << 23 with bit 31 set and reads as "none".  That IS the reference: bestDist / bestDist2 start at 256 and are
+    replaced on strict `<` only (ORBmatcher.cc:186-224), so such a candidate is never second-best and the ratio test
+    (:228-231) does not see it.  Two keypoints of one level inside the window, the query 200 bits from the first;
+    threshold 255, ratio 0.6: with the second 256 bits away the match is ACCEPTED (no second candidate), with the second
+    255 bits away it is rejected (200 > 0.6 * 255)."""
+    import gf_orb_slam2_amd as G
+    kp = np.zeros(2, oracle.KEYPOINT_DTYPE)
+    kp["x"] = [100.0, 103.0]; kp["y"] = [100.0, 101.0]; kp["octave"] = 0; kp["size"] = 31.0; kp["angle"] = 0.0
+    qd = np.zeros((1, 32), np.uint8)
+    d0 = np.zeros(32, np.uint8); d0[:25] = 0xFF                  # 200 bits from the query
+    for second_bits, accepted in ((256, True), (255, False)):
+        d1 = np.full(32, 0xFF, np.uint8)
+        if second_bits == 255:
+            d1[31] = 0x7F
+        desc = np.stack([d0, d1])
+        q = np.zeros(1, oracle.PROJ_QUERY_DTYPE)
+        q["u"] = 101.0; q["v"] = 100.0; q["radius"] = 10.0; q["min_level"] = -1; q["max_level"] = -1; q["flags"] = 1 | 4
+        b = (0.0, 0.0, 752.0, 480.0)
+        ref = oracle.search_by_projection_queries(kp, desc, None, kp["angle"], b, q, qd, True, 0.6, 255, False, None)
+        got = G.ORBmatcher(0.6, False, extractor=ext).SearchByProjectionQueries(kp, desc, None, kp["angle"], b, q, qd, use_ratio=True,
+                                                                               th_dist=255)
+        assert ref[0] == (1 if accepted else 0), "the oracle itself must follow :186-231"
+        assert got[0] == ref[0]
+        np.testing.assert_array_equal(got[1], ref[1]); np.testing.assert_array_equal(got[2], ref[2])

@@ -90,6 +90,32 @@ def test_stereo_edge_cases(ext, oracle):
     _cmp_stereo(got, ref)
 
 
+def test_right_keypoints_whose_row_band_misses_the_image(ext, oracle):
+    """ADVICE r2 (k_stereo.hip row bands): host arrays may carry right keypoints far above or below the image.  The
+    reference's row loop does not run for them (Frame.h:248-256: maxr < 0, or minr > nRows - 1), so they are nobody's
+    candidate -- packed as min | max << 16 a negative maxr used to read as 65535 = "every row"."""
+    import gf_orb_slam2_amd as G
+    m = G.ORBmatcher(0.8, True, extractor=ext)
+    sf = np.array([1.0, 1.2, 1.44], np.float32)
+    p = _params()
+    kd = oracle.KEYPOINT_DTYPE
+    rng = np.random.default_rng(23)
+    n = 64
+    kl = np.zeros(n, kd); kr = np.zeros(3 * n, kd)
+    kl["x"] = rng.uniform(200, 700, n).astype(np.float32); kl["y"] = rng.uniform(5, 470, n).astype(np.float32)
+    dl = rng.integers(0, 256, (n, 32), dtype=np.uint8)
+    # three right copies of every left keypoint with the SAME descriptor and a valid disparity: one far above the image,
+    # one far below it, one in place -- only the last may ever be matched
+    for j, dy in enumerate((-700.0, +900.0, 0.5)):
+        kr["x"][j * n:(j + 1) * n] = kl["x"] - 20.0
+        kr["y"][j * n:(j + 1) * n] = kl["y"] + dy
+    dr = np.tile(dl, (3, 1))
+    got = m.ComputeStereoMatches(kl, dl, kr, dr, sf, p)
+    ref = oracle.stereo_match(kl, dl, kr, dr, sf, p.n_rows, p.mbf, p.mb, p.min_x)
+    _cmp_stereo(got, ref)
+    assert (ref[4][ref[4] >= 0] >= 2 * n).all() and (ref[4] >= 2 * n).sum() > n // 2     # every accepted match is an in-place copy
+
+
 def test_chained_extract_and_match_on_device(ext, oracle, euroc_l, euroc_r):
     import torch
     import gf_orb_slam2_amd as G
