@@ -251,6 +251,20 @@ def per_frame_boundary(seconds=1.0):
         return {"error": repr(ex)}
 
 
+def real_image():
+    """The headline pipeline on the reference's own EuRoC images instead of the synthetic stream (tools/bench_real_image.py,
+    a process of its own): real imagery sends half of the FAST cells through the second, minThFAST, round."""
+    import subprocess
+    try:
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "bench_real_image.py")], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=240)
+        lines = [l for l in r.stdout.decode(errors="replace").splitlines() if l.startswith("{\"")]
+        if r.returncode != 0 or not lines:
+            return {"error": f"child process failed (rc {r.returncode})"}
+        return json.loads(lines[-1])
+    except Exception as ex:      # a failing side measurement must not lose the headline line
+        return {"error": repr(ex)}
+
+
 def host_cores():
     try:
         return len(os.sched_getaffinity(0))
@@ -674,6 +688,7 @@ def main():
             ob = 64 if WORKLOADS[name][0] > 1000 else B
             others.append(side_config(name, ob, args.streams))
         line["other_configs"] = others
+        line["real_image"] = real_image()
 
     if rank == 0 and world == 1 and not args.no_boundary and not under_profiler():
         line["per_frame_boundary"] = per_frame_boundary()

@@ -16,6 +16,19 @@
 // Fast_gpu.cu:196-219), and a neighbour can suppress a corner only if its S is >= the corner's,
 // so "compare against the score buffer of corners at threshold t" (FAST_NEON.cc:268-285) is
 // "strict local maximum of S" -- one suppression pass serves both thresholds (FAST).
+// A cell that finds no maximum at iniThFAST repeats the WHOLE cascade at minThFAST -- half the cells of real indoor
+// imagery do (the reference's EuRoC frames: k_fast 198 us per 128 images against 156 on the synthetic stream).  Two ways
+// of sparing such a cell work were built in round 3, parity-green, and measured slower on BOTH streams (same-box A/B,
+// tools/ab_fast.sh):
+//   * both thresholds tested in the one stage-A pass, the minThFAST-only pass bits kept as an LDS bitmap that the second
+//     round merely compacts: +8 vector instructions per stage-A iteration for EVERY cell and 1.5 KB more LDS per wave
+//     (27 -> 21 waves per CU): synthetic 156 -> 176 us, EuRoC 198 -> 200 us;
+//   * second round's stage A dropping the pixels the first round scored (scores taken with the polarity rule at
+//     minThFAST are exact above it and were kept): synthetic 156 -> 164 us (the first round's suppression walks the
+//     pixels with minTh < S <= iniTh too), EuRoC 198 -> 205 us.
+// The premise was wrong: a cell repeats BECAUSE it has next to no pixels that pass at iniThFAST, so there is nothing to
+// avoid re-scoring -- its cost is the second round's own work on ~290 weak candidates (25 % of its pixels pass the
+// compass test at threshold 7), which no bookkeeping in the first round reduces.
 // Queue entries are 16 bit: px | py << 6, the local-maximum flag in bit 15.
 // One cell per (single-wave) workgroup -- a cell's slot is free again the moment its wave ends; all levels of all
 // images are ONE launch.

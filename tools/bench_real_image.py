@@ -1,12 +1,16 @@
 """Extraction throughput on the reference's own EuRoC test images (tests/golden/EuRoC_{l,r}_752x480.u8) instead of
 the synthetic stream: real indoor imagery sends about half of the FAST cells into the second (minThFAST) round, which
 the synthetic frames hardly exercise.  Prints frames/s and the per-kernel device times."""
+import json
+import os
 import sys
 import time
 
 import numpy as np
 
-sys.path.insert(0, ".")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+os.chdir(ROOT)
 import torch
 
 import gf_orb_slam2_amd as G
@@ -39,8 +43,8 @@ for steps in (30, 300):
         m.stereo_match_batch(sp)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-print(f"EuRoC images, stereo752 pipeline: {B * steps / dt:.0f} frames/s, {dt / steps * 1e3:.3f} ms per {B} images; "
-      f"mean keypoints {exts[0][0].batch_counts(B).mean():.0f}")
+value, ms_step, mean_kp = B * steps / dt, dt / steps * 1e3, float(exts[0][0].batch_counts(B).mean())
+print(f"EuRoC images, stereo752 pipeline: {value:.0f} frames/s, {ms_step:.3f} ms per {B} images; mean keypoints {mean_kp:.0f}")
 e = exts[0][0]
 for _ in range(30):
     e.extract_batch_device(d.data_ptr(), B, 752, 480)
@@ -48,4 +52,11 @@ e.profile_enable(True)
 for _ in range(10):
     e.extract_batch_device(d.data_ptr(), B, 752, 480)
 torch.cuda.synchronize()
-print({k: round(v[0] / 10 * 1e3, 1) for k, v in e.profile_read().items() if v[1]})
+stage_us = {k: round(v[0] / 10 * 1e3, 1) for k, v in e.profile_read().items() if v[1]}
+print(stage_us)
+# last line: what bench.py folds into its own line as `real_image`
+print(json.dumps({"workload": "stereo752 pipeline on the reference's EuRoC test pair (tests/golden/EuRoC_{l,r}_752x480.u8, 64 shifted copies of the pair per step)",
+                  "value": round(value, 1), "unit": "frames/s", "ms_per_step": round(ms_step, 4), "images_per_step": B, "contexts": NCTX,
+                  "mean_keypoints_per_image": round(mean_kp, 1), "stage_us_per_step_one_context": stage_us, "k_fast_us": stage_us.get("fast"),
+                  "note": "about half of the FAST cells of real indoor imagery find no corner at iniThFAST and repeat the cascade at minThFAST "
+                          "(ORBextractor.cc:811-818); the synthetic stream of the headline hardly exercises that"}))
