@@ -143,7 +143,7 @@ static void free_arena(gfo_ctx* c)
     void* ptrs[] = {c->d_geom, c->d_input, c->d_pyr, c->d_blur, c->d_cand, c->d_cand_cnt, c->d_node_of, c->d_sel,
                     c->d_sel_cnt, c->d_kp, c->d_desc, c->d_kp_cnt, c->d_flags, c->d_xofs, c->d_xcoef, c->d_yofs, c->d_band, c->d_cell_tab, c->d_qt_scratch,
                     c->d_ycoef, c->st.u_right, c->st.depth, c->st.best_dist, c->st.best_idx, c->st.nmatched, c->st.counted,
-                    c->d_scale, c->d_inv_scale, c->st_sort.sx, c->st_sort.sy, c->st_sort.soi, c->st_sort.sdesc, c->st_sort.row_start};
+                    c->d_scale, c->d_inv_scale, c->st_sort.sx, c->st_sort.sy, c->st_sort.soi, c->st_sort.sdesc, c->st_sort.row_start, c->st_sort.lorder, c->st_sort.lrow_start};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     c->d_geom = nullptr; c->d_input = c->d_pyr = c->d_blur = nullptr; c->d_cand = nullptr; c->d_cand_cnt = nullptr;
@@ -460,6 +460,8 @@ int gfo_plan(gfo_ctx* c, int w, int h, int batch)
     HIP_TRY(c, hipMalloc(&c->st_sort.sdesc, P * g.kp_stride * 32));
     c->st_rows_cap = h + 64;
     HIP_TRY(c, hipMalloc(&c->st_sort.row_start, P * (size_t)(c->st_rows_cap + 1) * sizeof(int)));
+    HIP_TRY(c, hipMalloc(&c->st_sort.lrow_start, P * (size_t)(c->st_rows_cap + 1) * sizeof(int)));
+    HIP_TRY(c, hipMalloc(&c->st_sort.lorder, P * g.kp_stride * sizeof(int)));
     HIP_TRY(c, hipMemcpy(c->d_geom, &g, sizeof g, hipMemcpyHostToDevice));
     HIP_TRY(c, hipMemcpy(c->d_xofs, xtabv.data(), xtabv.size() * sizeof(int), hipMemcpyHostToDevice));
     HIP_TRY(c, hipMemcpy(c->d_yofs, ytabv.data(), ytabv.size() * sizeof(int), hipMemcpyHostToDevice));
@@ -1362,7 +1364,8 @@ extern "C" int gfo_stereo_match(gfo_ctx* c, const gfo_keypoint* kl, const uint8_
     const size_t out_bytes = off - in_bytes;
     const size_t o_ct = take(nl);
     const size_t o_sx = take(4 * (size_t)nr1), o_sy = take(4 * (size_t)nr1), o_soi = take(4 * (size_t)nr1),
-                 o_sd = take(32 * (size_t)nr1), o_rs = take(4 * (size_t)(p->n_rows + 1));
+                 o_sd = take(32 * (size_t)nr1), o_rs = take(4 * (size_t)(p->n_rows + 1)), o_lo = take(4 * (size_t)nl),
+                 o_lrs = take(4 * (size_t)(p->n_rows + 1));
     int rc = scratch(c, off);
     if (rc) return rc;
     rc = pinned(c, &c->h_in, &c->h_in_bytes, in_bytes);
@@ -1395,7 +1398,7 @@ extern "C" int gfo_stereo_match(gfo_ctx* c, const gfo_keypoint* kl, const uint8_
     sl.min_d = win ? (const float*)(S + o_min) : nullptr;
     sl.max_d = win ? (const float*)(S + o_max) : nullptr;
     sl.out = out; sl.out_stride = nl;
-    sl.sort = GfoStereoSort{(float*)(S + o_sx), (float*)(S + o_sy), (unsigned*)(S + o_soi), S + o_sd, (int*)(S + o_rs)};
+    sl.sort = GfoStereoSort{(float*)(S + o_sx), (float*)(S + o_sy), (unsigned*)(S + o_soi), S + o_sd, (int*)(S + o_rs), (int*)(S + o_lo), (int*)(S + o_lrs)};
     sl.sort_stride = nr1;
     sl.window = gfo_stereo_window(sf, nlevels);
     gfo_launch_stereo(c, sl);

@@ -100,6 +100,8 @@ struct GfoStereoSort {
     unsigned* soi;      // octave << 16 | original index
     uint8_t* sdesc;     // 32 B per keypoint
     int* row_start;     // [pairs][n_rows + 1]
+    int* lorder;        // LEFT keypoints whose row is inside the image, counting-sorted by (int)y: original indices [pairs][stride]
+    int* lrow_start;    // [pairs][n_rows + 1]
 };
 
 struct GfoStereoLaunch {

@@ -9,10 +9,19 @@
 //   k_stereo_bucket : one workgroup per pair counting-sorts the right keypoints by floor(y)
 //                     (LDS histogram + scan) and writes them as a compact SoA in bucket order
 //                     (x, y, octave|iR, 32-byte descriptor), so the matcher reads contiguous memory;
-//   k_stereo_match  : one 32-lane half-wave per left keypoint sweeps the buckets [row-W, row+W]
-//                     (W = ceil(2*max scale)+1 covers every band that can contain `row`), applies the
-//                     exact band / octave / disparity-window predicates, takes the 256-bit Hamming
-//                     distance with v_bcnt and wave-reduces min(dist << 16 | iR);
+//   k_stereo_match_rows : the association around ROWS (round 3).  k_stereo_bucket also counting-sorts the LEFT keypoints
+//                     by their row; a workgroup owns a band of R rows of one pair, stages -- once, coalesced -- the
+//                     right-side records of rows [r0 - W, r1 + W] (band, octave | iR, x, 32-byte descriptor) and the
+//                     left keypoints of its rows in LDS, and every 32-lane half-wave then sweeps LDS for one left
+//                     keypoint at a time, in two phases: the cheap predicates (band, octave, disparity window: one
+//                     16-byte LDS read) compact the ~10 % survivors into a small ring, and the 256-bit Hamming distance
+//                     (v_bcnt) runs on full lanes of survivors only; half-wave reduction of min(dist << 16 | iR)
+//                     (W = ceil(2 * max scale) + 1 covers every band that can contain a row).  Before, left keypoints
+//                     arrived in level / list order, every half-wave chased four dependent global loads per candidate
+//                     and shared nothing with its neighbours: 80 % of the wave cycles were waits and the kernel moved
+//                     1.9 x its algorithmic bytes;
+//   k_stereo_match  : that earlier form -- one half-wave per left keypoint straight from the bucketed arrays -- kept
+//                     for windows too wide for the LDS row table and as GFO_STEREO_ROWS=0;
 //   k_stereo_cut    : the outlier cut (:1290-1313) needs only the (ndi/2)-th order statistic of the
 //                     accepted distances: a 128-bin LDS histogram gives it exactly (no sort).
 #include "gfo_internal.h"
@@ -47,6 +56,8 @@ struct StereoArgs {
     unsigned* soi;            // octave << 16 | iR
     uint4* sdesc;             // 2 x uint4 per keypoint
     int* row_start;           // [pairs][n_rows + 1]
+    int* lorder;              // left keypoints with a row inside the image, sorted by row: original indices
+    int* lrow_start;          // [pairs][n_rows + 1]
     int sort_stride;
     int window;               // W
 };
@@ -134,6 +145,44 @@ __global__ __launch_bounds__(1024) void k_stereo_bucket(StereoArgs a)
         a.sdesc[2 * (so + pos)] = dr[2 * i];
         a.sdesc[2 * (so + pos) + 1] = dr[2 * i + 1];
     }
+    if (!a.lorder) return;     // (the SAD variant and the per-keypoint form sweep the left keypoints in list order)
+    // ---- the LEFT keypoints by row (Frame.cc:1204-1211: row = (int)vL, keypoints with vL outside [0, nRows - 1] are
+    //      skipped and keep the defaults written here) ----
+    __syncthreads();
+    const int nl = a.cnt_dev ? a.cnt_dev[2 * pair] : a.nl_host;
+    const gfo_keypoint* kl = a.kl + pair * a.pair_stride;
+    for (int r = tid; r < nRows; r += NT) s_hist[r] = 0;
+    __syncthreads();
+    const long long oo = (long long)pair * a.out_stride;
+    for (int i = tid; i < nl; i += NT) {
+        const float vL = kl[i].y;
+        if (vL < 0 || vL > (float)(nRows - 1)) {
+            a.out.u_right[oo + i] = -1.0f;
+            a.out.depth[oo + i] = -1.0f;
+            a.out.best_dist[oo + i] = -1;
+            a.out.best_idx[oo + i] = -1;
+            a.out.counted[oo + i] = 0;
+        } else {
+            atomicAdd(&s_hist[(int)vL], 1);
+        }
+    }
+    __syncthreads();
+    s = 0;
+    for (int r = b0; r < e0; r++) s += s_hist[r];
+    run = st_block_incl_scan(s, s_part, &total) - s;
+    int* lrs = a.lrow_start + (long long)pair * (nRows + 1);
+    for (int r = b0; r < e0; r++) {
+        const int v = s_hist[r];
+        lrs[r] = run;
+        s_hist[r] = run;
+        run += v;
+    }
+    if (tid == 0) lrs[nRows] = total;
+    __syncthreads();
+    for (int i = tid; i < nl; i += NT) {
+        const float vL = kl[i].y;
+        if (!(vL < 0 || vL > (float)(nRows - 1))) a.lorder[so + atomicAdd(&s_hist[(int)vL], 1)] = i;
+    }
 }
 
 // Two left keypoints per wavefront, one per 32-lane half: the work per keypoint is a short chain of
@@ -216,6 +265,176 @@ __global__ __launch_bounds__(256) void k_stereo_match(StereoArgs a)
         a.out.best_dist[o] = res_dist;
         a.out.best_idx[o] = res_idx;
         a.out.counted[o] = (unsigned char)counted;  // summed per pair by k_stereo_cut (no same-line atomics)
+    }
+}
+
+// ---- the association around rows ----
+#define SR_ROWS 72    // rows of the row table a workgroup needs: R + 2 W + 2
+#define SR_CL 64      // left records per pass (a band of 8 rows holds ~35)
+#ifndef SR_THREADS
+#define SR_THREADS 256   // (128: 52 us, 512: 49 us against 38 per 64 pairs)
+#endif
+
+// LDS operations of one wave execute in issue order: between a half-wave's writes to its ring and its reads of it a
+// compiler-level fence is all that is needed
+__device__ __forceinline__ void sr_wave_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// cr = right records the workgroup can stage (dynamic LDS: 48 bytes each); a band whose buckets hold more is read in place
+__global__ __launch_bounds__(SR_THREADS) void k_stereo_match_rows(StereoArgs a, int R, int cr)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t sr_lds[];
+    uint4* r_rec = reinterpret_cast<uint4*>(sr_lds);    // {row band, octave << 16 | iR, x, -}: the three filters from ONE 16-byte read
+    uint4* r_d0 = r_rec + cr;                           // descriptor halves apart: 16-byte reads of consecutive records, no bank conflicts
+    uint4* r_d1 = r_d0 + cr;
+    __shared__ float l_x[SR_CL], l_minD[SR_CL], l_maxD[SR_CL];
+    __shared__ int l_ro[SR_CL], l_i[SR_CL];             // row | octave << 16, original index
+    __shared__ uint4 l_d0[SR_CL], l_d1[SR_CL];
+    __shared__ int s_rs[SR_ROWS];
+    __shared__ unsigned short s_ring[SR_THREADS / 32][64];   // per half-wave: the candidates that passed the cheap predicates
+    const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, hl = lane & 31, hw = tid >> 5;
+    const int pair = blockIdx.y;
+    const int nRows = a.p.n_rows, W = a.window;
+    const int r0 = blockIdx.x * R, r1 = min(r0 + R, nRows);
+    if (r0 >= nRows) return;
+    const int* lrs = a.lrow_start + (long long)pair * (nRows + 1);
+    const int lb = lrs[r0], le = lrs[r1];
+    if (lb == le) return;                               // no left keypoint in these rows (workgroup-uniform)
+    const int* rs = a.row_start + (long long)pair * (nRows + 1);
+    const int rlo = max(r0 - W, 0), rhi = min(r1 + W, nRows);      // right buckets [rlo, rhi) can hold candidates of rows [r0, r1)
+    for (int t = tid; t <= rhi - rlo; t += SR_THREADS) s_rs[t] = rs[rlo + t];
+    const int jb0 = rs[rlo], nR = rs[rhi] - jb0;
+    const bool staged = nR <= cr;
+    const long long so = (long long)pair * a.sort_stride;
+    if (staged) {
+        for (int t = tid; t < nR; t += SR_THREADS) {
+            const long long j = so + jb0 + t;
+            r_rec[t] = make_uint4(a.sband[j], a.soi[j], __float_as_uint(a.sx[j]), 0u);
+            r_d0[t] = a.sdesc[2 * j];
+            r_d1[t] = a.sdesc[2 * j + 1];
+        }
+    }
+    const gfo_keypoint* kl = a.kl + pair * a.pair_stride;
+    const uint4* dl = reinterpret_cast<const uint4*>(a.dl + pair * a.pair_stride * 32);
+    const bool win = a.min_d && a.max_d;
+    const float maxD0 = a.p.mbf / a.p.mb;               // Frame.cc:1199-1200 (minZ = mb)
+    unsigned short* ring = s_ring[hw];
+    const unsigned lt_mask = (1u << hl) - 1u;
+    for (int c0 = lb; c0 < le; c0 += SR_CL) {
+        const int nc = min(SR_CL, le - c0);
+        __syncthreads();                                // the previous pass has been consumed
+        for (int t = tid; t < nc; t += SR_THREADS) {
+            const int iL = a.lorder[so + c0 + t];
+            const gfo_keypoint* L = kl + iL;
+            l_x[t] = L->x;
+            l_ro[t] = (int)L->y | (L->octave << 16);    // 0 <= (int)y < nRows <= 65535
+            l_i[t] = iL;
+            l_minD[t] = win ? a.min_d[iL] : 0.f;        // :1220-1231 flattened by the adapter
+            l_maxD[t] = win ? a.max_d[iL] : maxD0;
+            l_d0[t] = dl[2 * iL];
+            l_d1[t] = dl[2 * iL + 1];
+        }
+        __syncthreads();
+        for (int t = hw; t < nc; t += SR_THREADS / 32) {   // one half-wave per left keypoint
+            const int ro = l_ro[t], row = ro & 0xFFFF, octL = ro >> 16;
+            const float uL = l_x[t], minD = l_minD[t], maxD = l_maxD[t];
+            const float minU = uL - maxD, maxU = uL - minD;
+            const uint4 a0 = l_d0[t], a1 = l_d1[t];
+            const int jb = s_rs[max(row - W, 0) - rlo] - jb0, je = s_rs[min(row + W + 1, nRows) - rlo] - jb0;
+            unsigned best = ((unsigned)TH_HIGH << 16);  // bestDist = TH_HIGH, iR = 0: only dist < TH_HIGH replaces it
+            float bx = 0.f;
+            bool any = false;
+            if (staged) {
+                // phase 1: band / octave / disparity-window tests (ORBmatcher-free: Frame.cc:1244-1255) on every candidate, the
+                // survivors' positions into the half-wave's ring; phase 2 whenever 32 are waiting, and once at the end:
+                // Hamming distances on full lanes (most candidates fail phase 1: testing and scoring in ONE loop runs the
+                // scoring instructions for two or three live lanes per trip)
+                int head = 0, tail = 0;                 // uniform inside the half
+                for (int j0 = jb; j0 < je; j0 += 32) {
+                    const int j = j0 + hl;
+                    bool pass = false;
+                    if (j < je) {
+                        const uint4 rec = r_rec[j];
+                        if (!(row < (int)(rec.x & 0xFFFF) || row > (int)(rec.x >> 16))) {
+                            any = true;
+                            const int oct = (int)(rec.y >> 16);
+                            const float rx = __uint_as_float(rec.z);
+                            pass = !(oct < octL - 1 || oct > octL + 1) && rx >= minU && rx <= maxU;   // :1250, :1255
+                        }
+                    }
+                    const unsigned mh = (unsigned)(__builtin_amdgcn_ballot_w64(pass) >> (32 * half));
+                    if (pass) ring[(tail + __popc(mh & lt_mask)) & 63] = (unsigned short)j;
+                    tail += __popc(mh);
+                    const bool last = j0 + 32 >= je;
+                    while (tail - head >= 32 || (last && tail > head)) {
+                        sr_wave_sync();
+                        if (head + hl < tail) {
+                            const int jj = ring[(head + hl) & 63];
+                            const uint4 rec = r_rec[jj];
+                            const unsigned key = ((unsigned)hamming256(a0, a1, r_d0[jj], r_d1[jj]) << 16) | (rec.y & 0xFFFF);
+                            if (key < best) { best = key; bx = __uint_as_float(rec.z); }   // first minimum in iR order (:1260)
+                        }
+                        head += 32;
+                        if (head > tail) head = tail;
+                        sr_wave_sync();
+                    }
+                }
+            } else {
+                for (int j = jb + hl; j < je; j += 32) {
+                    const long long g = so + jb0 + j;
+                    const unsigned band = a.sband[g], oi = a.soi[g];
+                    if (row < (int)(band & 0xFFFF) || row > (int)(band >> 16)) continue;
+                    any = true;
+                    const int oct = (int)(oi >> 16);
+                    if (oct < octL - 1 || oct > octL + 1) continue;
+                    const float rx = a.sx[g];
+                    if (rx >= minU && rx <= maxU) {
+                        const unsigned key = ((unsigned)hamming256(a0, a1, a.sdesc[2 * g], a.sdesc[2 * g + 1]) << 16) | (oi & 0xFFFF);
+                        if (key < best) { best = key; bx = rx; }
+                    }
+                }
+            }
+            const unsigned long long anym = __builtin_amdgcn_ballot_w64(any);
+            const bool have_cands = ((anym >> (32 * half)) & 0xFFFFFFFFull) != 0;
+            unsigned red = best;
+#pragma unroll
+            for (int s = 16; s > 0; s >>= 1) red = min(red, (unsigned)__shfl_xor((int)red, s));  // inside the half
+            // the x of the winner: keys are distinct (iR is part of them), so exactly one lane of the half holds it
+            const unsigned long long own = __builtin_amdgcn_ballot_w64(best == red && red < ((unsigned)TH_HIGH << 16));
+            const unsigned ownh = (unsigned)(own >> (32 * half));
+            float bestuR = __shfl(bx, 32 * half + (ownh ? __ffs((int)ownh) - 1 : 0));
+            float res_u = -1.0f, res_depth = -1.0f;
+            int res_dist = -1, res_idx = -1, counted = 0;
+            if (have_cands && !(maxU < a.p.min_x)) {     // :1213, :1236 (the row is inside the image: the keypoint is in lorder)
+                counted = 1;
+                const int bestDist = (int)(red >> 16);
+                if (bestDist < (TH_HIGH + TH_LOW) / 2) {  // :1269
+                    float disparity = uL - bestuR;
+                    if (disparity >= minD && disparity < maxD) {
+                        if (disparity <= 0) {
+                            disparity = 0.01f;
+                            bestuR = (float)((double)uL - 0.01);   // `uL-0.01` is double arithmetic in the reference (Frame.cc:1278)
+                        }
+                        res_depth = a.p.mbf / disparity;
+                        res_u = bestuR;
+                        res_dist = bestDist;
+                        res_idx = (int)(red & 0xFFFF);
+                    }
+                }
+            }
+            if (hl == 0) {
+                const long long o = (long long)pair * a.out_stride + l_i[t];
+                a.out.u_right[o] = res_u;
+                a.out.depth[o] = res_depth;
+                a.out.best_dist[o] = res_dist;
+                a.out.best_idx[o] = res_idx;
+                a.out.counted[o] = (unsigned char)counted;  // summed per pair by k_stereo_cut (no same-line atomics)
+            }
+        }
     }
 }
 
@@ -463,6 +682,7 @@ void gfo_launch_stereo_sad(gfo_ctx* c, const GfoStereoLaunch& s, const GfoInput&
     a.out = s.out; a.out_stride = s.out_stride;
     a.sx = s.sort.sx; a.sband = reinterpret_cast<unsigned*>(s.sort.sy); a.soi = s.sort.soi; a.sdesc = reinterpret_cast<uint4*>(s.sort.sdesc);
     a.row_start = s.sort.row_start;
+    a.lorder = nullptr; a.lrow_start = nullptr;      // this variant sweeps per left keypoint in list order
     a.sort_stride = s.sort_stride;
     a.window = s.window;
     A.g = c->d_geom;
@@ -506,14 +726,32 @@ void gfo_launch_stereo(gfo_ctx* c, const GfoStereoLaunch& s)
         (void)hipMemsetAsync(s.out.nmatched, 0, sizeof(int) * s.npairs, c->stream);
         return;
     }
+    // rows per workgroup of the row form (64 pairs of 480 rows: 2 / 4 / 6 / 8 / 16 / 32 rows -> 51 / 40 / 39 / 38 / 42 / 51 us);
+    // a single pair -- the per-frame path -- gets narrower bands so that the launch still spreads over the chip
+    static const int rows_env = getenv("GFO_STEREO_ROWS") ? atoi(getenv("GFO_STEREO_ROWS")) : -1;   // 0 = the per-keypoint form, R > 0 = that many rows
+    int R = rows_env > 0 ? rows_env : (s.npairs >= 4 ? 8 : 4);
+    if (R > 32) R = 32;
+    const bool rows_form = rows_env != 0 && s.sort.lorder && s.p.n_rows <= 65535 && R + 2 * s.window + 2 <= SR_ROWS;
+    a.lorder = rows_form ? s.sort.lorder : nullptr;
+    a.lrow_start = rows_form ? s.sort.lrow_start : nullptr;
     gfo_prof_begin(c, ST_STEREO_BUCKET);
     GFO_LAUNCH(c, k_stereo_bucket, dim3(s.npairs), dim3(1024), (size_t)(s.p.n_rows + 256) * sizeof(int), c->stream, a);
     gfo_prof_end(c);
-    static const int snw_env = getenv("GFO_STEREO_WAVES") ? atoi(getenv("GFO_STEREO_WAVES")) : 4;   // waves per workgroup, 2 left keypoints each
-    const int snw = snw_env < 1 ? 1 : (snw_env > 4 ? 4 : snw_env);                                     // the kernel is built for <= 256 threads
-    dim3 grid((max_nl + 2 * snw - 1) / (2 * snw), s.npairs);
     gfo_prof_begin(c, ST_STEREO);
-    GFO_LAUNCH(c, k_stereo_match, grid, dim3(64 * snw), 0, c->stream, a);
+    if (rows_form) {
+        // right records staged per workgroup: twice what an even spread of the keypoints over the rows puts into R + 2 W buckets
+        // (128: most bands overflow into the read-in-place path, 53 us; 512: 41 us -- LDS nobody needs)
+        static const int cr_env = getenv("GFO_STEREO_CR") ? atoi(getenv("GFO_STEREO_CR")) : 0;
+        const int per_row8 = (8 * max_nl + s.p.n_rows - 1) / s.p.n_rows;      // keypoints per 8 rows
+        int cr = cr_env > 0 ? cr_env : ((2 * per_row8 * (R + 2 * s.window) / 8 + 63) & ~63);
+        cr = cr < 64 ? 64 : (cr > 1024 ? 1024 : cr);
+        GFO_LAUNCH(c, k_stereo_match_rows, dim3((s.p.n_rows + R - 1) / R, s.npairs), dim3(SR_THREADS), (size_t)cr * 48, c->stream, a, R, cr);
+    } else {
+        static const int snw_env = getenv("GFO_STEREO_WAVES") ? atoi(getenv("GFO_STEREO_WAVES")) : 4;   // waves per workgroup, 2 left keypoints each
+        const int snw = snw_env < 1 ? 1 : (snw_env > 4 ? 4 : snw_env);                                     // the kernel is built for <= 256 threads
+        dim3 grid((max_nl + 2 * snw - 1) / (2 * snw), s.npairs);
+        GFO_LAUNCH(c, k_stereo_match, grid, dim3(64 * snw), 0, c->stream, a);
+    }
     gfo_prof_end(c);
     gfo_prof_begin(c, ST_STEREO_CUT);
     GFO_LAUNCH(c, k_stereo_cut, dim3(s.npairs), dim3(1024), 0, c->stream, s.cnt_dev, s.nl_host, s.out, s.out_stride);
