@@ -13,9 +13,9 @@
 //                     by their row; a workgroup owns a band of R rows of one pair, stages -- once, coalesced -- the
 //                     right-side records of rows [r0 - W, r1 + W] (band, octave | iR, x, 32-byte descriptor) and the
 //                     left keypoints of its rows in LDS, and every 32-lane half-wave then sweeps LDS for one left
-//                     keypoint at a time, in two phases: the cheap predicates (band, octave, disparity window: one
-//                     16-byte LDS read) compact the ~10 % survivors into a small ring, and the 256-bit Hamming distance
-//                     (v_bcnt) runs on full lanes of survivors only; half-wave reduction of min(dist << 16 | iR)
+//                     keypoint at a time: band / octave / disparity-window predicates from one 16-byte LDS read per
+//                     candidate, the 256-bit Hamming distance (v_bcnt) of the survivors, half-wave reduction of
+//                     min(dist << 16 | iR)
 //                     (W = ceil(2 * max scale) + 1 covers every band that can contain a row).  Before, left keypoints
 //                     arrived in level / list order, every half-wave chased four dependent global loads per candidate
 //                     and shared nothing with its neighbours: 80 % of the wave cycles were waits and the kernel moved
@@ -92,22 +92,37 @@ __device__ __forceinline__ int st_block_incl_scan(int v, int* s_part, int* total
     return base + incl;
 }
 
+// blockIdx.y = 0: the right keypoints of the pair by floor(y); blockIdx.y = 1 (row form only): the left ones by row.
+// The two counting sorts are independent -- a workgroup each, side by side (one after the other in one workgroup: 20 us
+// per 64 pairs instead of 16 for the right side alone; the launch is 64 workgroups of latency chains either way).
 __global__ __launch_bounds__(1024) void k_stereo_bucket(StereoArgs a)
 {
     extern __shared__ int s_hist[];  // n_rows + 256
     const int pair = blockIdx.x, tid = threadIdx.x;
+    const bool left = blockIdx.y == 1;
     const int nRows = a.p.n_rows;
     int* s_part = s_hist + nRows;
-    const int nr = a.cnt_dev ? a.cnt_dev[2 * pair + 1] : a.nr_host;
-    const gfo_keypoint* kr = a.kr + pair * a.pair_stride;
-    const uint4* dr = reinterpret_cast<const uint4*>(a.dr + pair * a.pair_stride * 32);
+    const int n = a.cnt_dev ? a.cnt_dev[2 * pair + (left ? 0 : 1)] : (left ? a.nl_host : a.nr_host);
+    const gfo_keypoint* kp = (left ? a.kl : a.kr) + pair * a.pair_stride;
     const int NT = blockDim.x;   // 1024: the count / scatter loops are chains of dependent global loads, so more
                                  // threads means fewer serial round trips (8 -> 2 for 2000 keypoints)
     for (int r = tid; r < nRows; r += NT) s_hist[r] = 0;
     __syncthreads();
-    for (int i = tid; i < nr; i += NT) {
-        const int b = min(max((int)floorf(kr[i].y), 0), nRows - 1);
-        atomicAdd(&s_hist[b], 1);
+    const long long oo = (long long)pair * a.out_stride;
+    for (int i = tid; i < n; i += NT) {
+        const float y = kp[i].y;
+        if (!left) {
+            atomicAdd(&s_hist[min(max((int)floorf(y), 0), nRows - 1)], 1);
+        } else if (y < 0 || y > (float)(nRows - 1)) {
+            // Frame.cc:1204-1211: row = (int)vL, a left keypoint with vL outside [0, nRows - 1] is skipped: the defaults
+            a.out.u_right[oo + i] = -1.0f;
+            a.out.depth[oo + i] = -1.0f;
+            a.out.best_dist[oo + i] = -1;
+            a.out.best_idx[oo + i] = -1;
+            a.out.counted[oo + i] = 0;
+        } else {
+            atomicAdd(&s_hist[(int)y], 1);
+        }
     }
     __syncthreads();
     // exclusive scan over nRows entries
@@ -117,7 +132,7 @@ __global__ __launch_bounds__(1024) void k_stereo_bucket(StereoArgs a)
     for (int r = b0; r < e0; r++) s += s_hist[r];
     int total;
     int run = st_block_incl_scan(s, s_part, &total) - s;
-    int* rs = a.row_start + (long long)pair * (nRows + 1);
+    int* rs = (left ? a.lrow_start : a.row_start) + (long long)pair * (nRows + 1);
     for (int r = b0; r < e0; r++) {
         const int v = s_hist[r];
         rs[r] = run;
@@ -127,8 +142,16 @@ __global__ __launch_bounds__(1024) void k_stereo_bucket(StereoArgs a)
     if (tid == 0) rs[nRows] = total;
     __syncthreads();
     const long long so = (long long)pair * a.sort_stride;
-    for (int i = tid; i < nr; i += NT) {
-        const gfo_keypoint k = kr[i];
+    if (left) {
+        for (int i = tid; i < n; i += NT) {
+            const float y = kp[i].y;
+            if (!(y < 0 || y > (float)(nRows - 1))) a.lorder[so + atomicAdd(&s_hist[(int)y], 1)] = i;
+        }
+        return;
+    }
+    const uint4* dr = reinterpret_cast<const uint4*>(a.dr + pair * a.pair_stride * 32);
+    for (int i = tid; i < n; i += NT) {
+        const gfo_keypoint k = kp[i];
         const int b = min(max((int)floorf(k.y), 0), nRows - 1);
         const int pos = atomicAdd(&s_hist[b], 1);
         a.sx[so + pos] = k.x;
@@ -144,44 +167,6 @@ __global__ __launch_bounds__(1024) void k_stereo_bucket(StereoArgs a)
         a.soi[so + pos] = ((unsigned)k.octave << 16) | (unsigned)i;
         a.sdesc[2 * (so + pos)] = dr[2 * i];
         a.sdesc[2 * (so + pos) + 1] = dr[2 * i + 1];
-    }
-    if (!a.lorder) return;     // (the SAD variant and the per-keypoint form sweep the left keypoints in list order)
-    // ---- the LEFT keypoints by row (Frame.cc:1204-1211: row = (int)vL, keypoints with vL outside [0, nRows - 1] are
-    //      skipped and keep the defaults written here) ----
-    __syncthreads();
-    const int nl = a.cnt_dev ? a.cnt_dev[2 * pair] : a.nl_host;
-    const gfo_keypoint* kl = a.kl + pair * a.pair_stride;
-    for (int r = tid; r < nRows; r += NT) s_hist[r] = 0;
-    __syncthreads();
-    const long long oo = (long long)pair * a.out_stride;
-    for (int i = tid; i < nl; i += NT) {
-        const float vL = kl[i].y;
-        if (vL < 0 || vL > (float)(nRows - 1)) {
-            a.out.u_right[oo + i] = -1.0f;
-            a.out.depth[oo + i] = -1.0f;
-            a.out.best_dist[oo + i] = -1;
-            a.out.best_idx[oo + i] = -1;
-            a.out.counted[oo + i] = 0;
-        } else {
-            atomicAdd(&s_hist[(int)vL], 1);
-        }
-    }
-    __syncthreads();
-    s = 0;
-    for (int r = b0; r < e0; r++) s += s_hist[r];
-    run = st_block_incl_scan(s, s_part, &total) - s;
-    int* lrs = a.lrow_start + (long long)pair * (nRows + 1);
-    for (int r = b0; r < e0; r++) {
-        const int v = s_hist[r];
-        lrs[r] = run;
-        s_hist[r] = run;
-        run += v;
-    }
-    if (tid == 0) lrs[nRows] = total;
-    __syncthreads();
-    for (int i = tid; i < nl; i += NT) {
-        const float vL = kl[i].y;
-        if (!(vL < 0 || vL > (float)(nRows - 1))) a.lorder[so + atomicAdd(&s_hist[(int)vL], 1)] = i;
     }
 }
 
@@ -275,15 +260,6 @@ __global__ __launch_bounds__(256) void k_stereo_match(StereoArgs a)
 #define SR_THREADS 256   // (128: 52 us, 512: 49 us against 38 per 64 pairs)
 #endif
 
-// LDS operations of one wave execute in issue order: between a half-wave's writes to its ring and its reads of it a
-// compiler-level fence is all that is needed
-__device__ __forceinline__ void sr_wave_sync()
-{
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
-
 // cr = right records the workgroup can stage (dynamic LDS: 48 bytes each); a band whose buckets hold more is read in place
 __global__ __launch_bounds__(SR_THREADS) void k_stereo_match_rows(StereoArgs a, int R, int cr)
 {
@@ -295,7 +271,6 @@ __global__ __launch_bounds__(SR_THREADS) void k_stereo_match_rows(StereoArgs a, 
     __shared__ int l_ro[SR_CL], l_i[SR_CL];             // row | octave << 16, original index
     __shared__ uint4 l_d0[SR_CL], l_d1[SR_CL];
     __shared__ int s_rs[SR_ROWS];
-    __shared__ unsigned short s_ring[SR_THREADS / 32][64];   // per half-wave: the candidates that passed the cheap predicates
     const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, hl = lane & 31, hw = tid >> 5;
     const int pair = blockIdx.y;
     const int nRows = a.p.n_rows, W = a.window;
@@ -318,12 +293,13 @@ __global__ __launch_bounds__(SR_THREADS) void k_stereo_match_rows(StereoArgs a, 
             r_d1[t] = a.sdesc[2 * j + 1];
         }
     }
+#if defined(SR_STOP) && SR_STOP == 1
+    if (nR != 123456) return;
+#endif
     const gfo_keypoint* kl = a.kl + pair * a.pair_stride;
     const uint4* dl = reinterpret_cast<const uint4*>(a.dl + pair * a.pair_stride * 32);
     const bool win = a.min_d && a.max_d;
     const float maxD0 = a.p.mbf / a.p.mb;               // Frame.cc:1199-1200 (minZ = mb)
-    unsigned short* ring = s_ring[hw];
-    const unsigned lt_mask = (1u << hl) - 1u;
     for (int c0 = lb; c0 < le; c0 += SR_CL) {
         const int nc = min(SR_CL, le - c0);
         __syncthreads();                                // the previous pass has been consumed
@@ -339,6 +315,9 @@ __global__ __launch_bounds__(SR_THREADS) void k_stereo_match_rows(StereoArgs a, 
             l_d1[t] = dl[2 * iL + 1];
         }
         __syncthreads();
+#if defined(SR_STOP) && SR_STOP == 2
+        if (nR != 123456) return;
+#endif
         for (int t = hw; t < nc; t += SR_THREADS / 32) {   // one half-wave per left keypoint
             const int ro = l_ro[t], row = ro & 0xFFFF, octL = ro >> 16;
             const float uL = l_x[t], minD = l_minD[t], maxD = l_maxD[t];
@@ -349,38 +328,28 @@ __global__ __launch_bounds__(SR_THREADS) void k_stereo_match_rows(StereoArgs a, 
             float bx = 0.f;
             bool any = false;
             if (staged) {
-                // phase 1: band / octave / disparity-window tests (ORBmatcher-free: Frame.cc:1244-1255) on every candidate, the
-                // survivors' positions into the half-wave's ring; phase 2 whenever 32 are waiting, and once at the end:
-                // Hamming distances on full lanes (most candidates fail phase 1: testing and scoring in ONE loop runs the
-                // scoring instructions for two or three live lanes per trip)
-                int head = 0, tail = 0;                 // uniform inside the half
-                for (int j0 = jb; j0 < je; j0 += 32) {
-                    const int j = j0 + hl;
-                    bool pass = false;
-                    if (j < je) {
-                        const uint4 rec = r_rec[j];
-                        if (!(row < (int)(rec.x & 0xFFFF) || row > (int)(rec.x >> 16))) {
-                            any = true;
-                            const int oct = (int)(rec.y >> 16);
-                            const float rx = __uint_as_float(rec.z);
-                            pass = !(oct < octL - 1 || oct > octL + 1) && rx >= minU && rx <= maxU;   // :1250, :1255
-                        }
+                // two candidates per lane and trip: both records are requested before either is looked at (a trip is one LDS
+                // round trip instead of two; the kernel is bound by those chains, not by instruction issue).
+                // Measured and dropped: testing first and scoring the compacted survivors on full lanes (a ring per half-wave:
+                // 48 us against 38 -- the ring's own LDS round trips lengthen the chain it was meant to shorten).
+                for (int j0 = jb + hl; j0 < je; j0 += 64) {
+                    const int j1 = j0 + 32;
+                    const bool in1 = j1 < je;
+                    const uint4 rec0 = r_rec[j0], rec1 = r_rec[in1 ? j1 : j0];
+                    const bool band0 = !(row < (int)(rec0.x & 0xFFFF) || row > (int)(rec0.x >> 16));
+                    const bool band1 = in1 && !(row < (int)(rec1.x & 0xFFFF) || row > (int)(rec1.x >> 16));
+                    any = any || band0 || band1;
+                    const int oct0 = (int)(rec0.y >> 16), oct1 = (int)(rec1.y >> 16);
+                    const float rx0 = __uint_as_float(rec0.z), rx1 = __uint_as_float(rec1.z);
+                    const bool pass0 = band0 && !(oct0 < octL - 1 || oct0 > octL + 1) && rx0 >= minU && rx0 <= maxU;   // :1250, :1255
+                    const bool pass1 = band1 && !(oct1 < octL - 1 || oct1 > octL + 1) && rx1 >= minU && rx1 <= maxU;
+                    if (pass0) {
+                        const unsigned key = ((unsigned)hamming256(a0, a1, r_d0[j0], r_d1[j0]) << 16) | (rec0.y & 0xFFFF);
+                        if (key < best) { best = key; bx = rx0; }            // first minimum in iR order (:1260)
                     }
-                    const unsigned mh = (unsigned)(__builtin_amdgcn_ballot_w64(pass) >> (32 * half));
-                    if (pass) ring[(tail + __popc(mh & lt_mask)) & 63] = (unsigned short)j;
-                    tail += __popc(mh);
-                    const bool last = j0 + 32 >= je;
-                    while (tail - head >= 32 || (last && tail > head)) {
-                        sr_wave_sync();
-                        if (head + hl < tail) {
-                            const int jj = ring[(head + hl) & 63];
-                            const uint4 rec = r_rec[jj];
-                            const unsigned key = ((unsigned)hamming256(a0, a1, r_d0[jj], r_d1[jj]) << 16) | (rec.y & 0xFFFF);
-                            if (key < best) { best = key; bx = __uint_as_float(rec.z); }   // first minimum in iR order (:1260)
-                        }
-                        head += 32;
-                        if (head > tail) head = tail;
-                        sr_wave_sync();
+                    if (pass1) {
+                        const unsigned key = ((unsigned)hamming256(a0, a1, r_d0[j1], r_d1[j1]) << 16) | (rec1.y & 0xFFFF);
+                        if (key < best) { best = key; bx = rx1; }
                     }
                 }
             } else {
@@ -426,6 +395,9 @@ __global__ __launch_bounds__(SR_THREADS) void k_stereo_match_rows(StereoArgs a, 
                     }
                 }
             }
+#if defined(SR_STOP) && SR_STOP == 3
+            if (res_dist != 123456) continue;
+#endif
             if (hl == 0) {
                 const long long o = (long long)pair * a.out_stride + l_i[t];
                 a.out.u_right[o] = res_u;
@@ -726,16 +698,17 @@ void gfo_launch_stereo(gfo_ctx* c, const GfoStereoLaunch& s)
         (void)hipMemsetAsync(s.out.nmatched, 0, sizeof(int) * s.npairs, c->stream);
         return;
     }
-    // rows per workgroup of the row form (64 pairs of 480 rows: 2 / 4 / 6 / 8 / 16 / 32 rows -> 51 / 40 / 39 / 38 / 42 / 51 us);
-    // a single pair -- the per-frame path -- gets narrower bands so that the launch still spreads over the chip
-    static const int rows_env = getenv("GFO_STEREO_ROWS") ? atoi(getenv("GFO_STEREO_ROWS")) : -1;   // 0 = the per-keypoint form, R > 0 = that many rows
-    int R = rows_env > 0 ? rows_env : (s.npairs >= 4 ? 8 : 4);
+    // rows per workgroup of the row form (64 pairs of 480 rows: 2 / 4 / 6 / 8 / 16 / 32 rows -> 51 / 40 / 39 / 38 / 42 / 51 us)
+    const int rows_env = getenv("GFO_STEREO_ROWS") ? atoi(getenv("GFO_STEREO_ROWS")) : -1;   // 0 = the per-keypoint form, R > 0 = that many rows (read per call: the tests run both forms in one process)
+    int R = rows_env > 0 ? rows_env : 8;
     if (R > 32) R = 32;
-    const bool rows_form = rows_env != 0 && s.sort.lorder && s.p.n_rows <= 65535 && R + 2 * s.window + 2 <= SR_ROWS;
+    // from four pairs on; one to three pairs -- the per-frame path -- spread better as one half-wave per left keypoint
+    // (a stereo frame: 0.207 ms against 0.212 with 120 row workgroups)
+    const bool rows_form = rows_env != 0 && (s.npairs >= 4 || rows_env > 0) && s.sort.lorder && s.p.n_rows <= 65535 && R + 2 * s.window + 2 <= SR_ROWS;
     a.lorder = rows_form ? s.sort.lorder : nullptr;
     a.lrow_start = rows_form ? s.sort.lrow_start : nullptr;
     gfo_prof_begin(c, ST_STEREO_BUCKET);
-    GFO_LAUNCH(c, k_stereo_bucket, dim3(s.npairs), dim3(1024), (size_t)(s.p.n_rows + 256) * sizeof(int), c->stream, a);
+    GFO_LAUNCH(c, k_stereo_bucket, dim3(s.npairs, rows_form ? 2 : 1), dim3(1024), (size_t)(s.p.n_rows + 256) * sizeof(int), c->stream, a);
     gfo_prof_end(c);
     gfo_prof_begin(c, ST_STEREO);
     if (rows_form) {

@@ -11,6 +11,18 @@ pytestmark = pytest.mark.gpu
 FX, BF = 435.2046959714599, 47.90639384423901   # EuRoC.yaml of ORB-SLAM2 (Camera.fx, Camera.bf)
 
 
+@pytest.fixture(autouse=True, params=["default", "rows", "keypoints"])
+def association_form(request, monkeypatch):
+    """Every test of this module runs three times: the library's own choice (row form from four pairs on), the row
+    form forced (GFO_STEREO_ROWS=5: k_stereo_match_rows also for a single pair, with a band height that does not divide
+    the image) and the per-keypoint form forced (GFO_STEREO_ROWS=0: k_stereo_match)."""
+    if request.param == "rows":
+        monkeypatch.setenv("GFO_STEREO_ROWS", "5")
+    elif request.param == "keypoints":
+        monkeypatch.setenv("GFO_STEREO_ROWS", "0")
+    return request.param
+
+
 @pytest.fixture(scope="module")
 def ext():
     import gf_orb_slam2_amd as G
