@@ -77,7 +77,7 @@ SYMBOLS = [
     "gfo_map_upload", "gfo_search_by_projection_batch", "gfo_projection_fetch", "gfo_projection_device_views", "gfo_search_by_bow", "gfo_vocabulary_upload", "gfo_bow_transform", "gfo_compute_bow", "gfo_profile_enable",
     "gfo_profile_read", "gfo_debug_blurred_level", "gfo_debug_level_candidates",
     "gfo_contexts_created", "gfo_arenas_planned", "gfo_ctx_id", "gfo_vocabulary_nodes", "gfo_ctx_set_combining", "gfo_combiner_stats",
-    "gfo_batch_deliver", "gfo_deliver_wait",
+    "gfo_batch_deliver", "gfo_deliver_wait", "gfo_host_register", "gfo_host_unregister",
 ]
 
 
@@ -198,6 +198,8 @@ def load_library():
     L.gfo_debug_level_candidates.argtypes = [vp, i, i, vp, i, ip]
     L.gfo_batch_deliver.argtypes = [vp, vp, sz, C.POINTER(DeliveryC)]
     L.gfo_deliver_wait.argtypes = [vp]
+    L.gfo_host_register.argtypes = [vp, sz]
+    L.gfo_host_unregister.argtypes = [vp]
     L.gfo_contexts_created.restype = i
     L.gfo_arenas_planned.restype = i
     L.gfo_ctx_id.argtypes = [vp]

@@ -191,14 +191,8 @@ int gfo_combined_extract(gfo_ctx* c, int kind, const uint8_t* const* imgs, int w
     // while the leader waits for room on the device; the batch's kernels are queued behind all of them.  ONE copy per
     // request: splitting a stereo frame into two copies (left image on the link while the right one is staged) measured
     // 13-17 % slower at K = 8 / 16 -- a copy costs the DMA engine ~10 us whatever its size, and the copies serialise
-    int crc = GFO_OK;
-    for (int k = 0; k < kind; k++) gfo_small_stage(s.bc, s.L, idx * kind + k, imgs[k], w, h, stride);
-    if (hipSetDevice(e->device) != hipSuccess ||
-        hipMemcpyAsync(s.bc->d_input + (size_t)idx * kind * s.L.img_bytes, s.bc->h_in + (size_t)idx * kind * s.L.img_bytes,
-                       (size_t)kind * s.L.img_bytes, hipMemcpyHostToDevice, s.bc->stream) != hipSuccess) {
-        (void)hipGetLastError();
-        crc = GFO_ERR_DEVICE;
-    }
+    int crc = hipSetDevice(e->device) == hipSuccess ? GFO_OK : GFO_ERR_DEVICE;
+    if (!crc) crc = gfo_small_upload(s.bc, s.L, idx * kind, kind, imgs, w, h, stride, s.bc->stream) ? GFO_ERR_DEVICE : GFO_OK;
 
     lk.lock();
     s.staged++;

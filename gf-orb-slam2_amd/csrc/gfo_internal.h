@@ -274,11 +274,13 @@ int gfo_fail(gfo_ctx* c, int code, const char* fmt, ...);
 int gfo_plan(gfo_ctx* c, int w, int h, int batch);
 struct GfoSmallLayout {
     int nimg_cap;
+    int pitch;            // of the staged images: the width when that keeps rows 16-byte aligned (one memcpy / one DMA per image), else the arena's
     size_t img_bytes;
     size_t o_fl, o_cnt, o_kp, o_ds, o_ur, o_dp, o_bd, o_bi, o_nm;   // offsets into the pinned result buffer
 };
 int gfo_small_prepare(gfo_ctx* c, int nimg_cap, GfoSmallLayout* L);
-void gfo_small_stage(gfo_ctx* c, const GfoSmallLayout& L, int i, const uint8_t* img, int w, int h, int stride);
+int gfo_small_upload(gfo_ctx* c, const GfoSmallLayout& L, int first, int count, const uint8_t* const* imgs, int w, int h, int stride,
+                     hipStream_t st);
 int gfo_small_submit(gfo_ctx* c, const GfoSmallLayout& L, int nimg, const gfo_stereo_params* sp, bool copy_in);
 int gfo_small_collect(gfo_ctx* c, const GfoSmallLayout& L, int i, gfo_keypoint* kp, uint8_t* desc, int cap, int* n);
 void gfo_small_collect_stereo(gfo_ctx* c, const GfoSmallLayout& L, int pair, int n_left, int cap, float* u_right, float* depth,

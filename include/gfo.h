@@ -115,6 +115,15 @@ int gfo_ctx_max_keypoints(const gfo_ctx* ctx);
 int gfo_extract(gfo_ctx* ctx, const uint8_t* img, int w, int h, int stride,
                 gfo_keypoint* kp, uint8_t* desc, int cap, int* n);
 
+/* Optional: pin the buffers frames are handed over in.  The per-frame entry points (gfo_extract, gfo_extract_stereo,
+ * small gfo_extract_batch) copy every image into pinned staging before the DMA engine can take it (~35 us of host memcpy
+ * per 752x480 stereo frame); an image that lies entirely inside a range registered here, with stride == width, goes to
+ * the device straight from the caller's memory instead (left and right image contiguous in one buffer: one copy).
+ * gfo_host_register page-locks [p, p + bytes) (hipHostRegister); the range must stay valid until gfo_host_unregister.
+ * Results are unaffected.  Callers that cannot pin anything -- cv::Mat from imread, ROS messages -- simply do not call it. */
+int gfo_host_register(void* p, size_t bytes);
+int gfo_host_unregister(void* p);
+
 /* Batched form: `nimg` host images of identical size (one arena pass, every stage one
  * launch over all images).  imgs[i] points at image i.  kp/desc are [nimg][cap] arrays. */
 int gfo_extract_batch(gfo_ctx* ctx, const uint8_t* const* imgs, int nimg, int w, int h, int stride,

@@ -160,3 +160,32 @@ def test_context_ids_and_vocabulary_residency(oracle):
     assert e2.ctx_id != id1 and e2.ctx_id > 0
     assert L.gfo_vocabulary_nodes(e2.handle) == 0, f"fresh context (same address: {e2.handle.value == addr1}) claims a vocabulary"
     e2.close()
+
+
+def test_frames_from_buffers_the_caller_pinned(oracle, euroc_l, euroc_r):
+    """gfo_host_register: images inside a pinned range, tight rows, skip the staging copy (left | right contiguous: one DMA
+    copy; apart: one each; a pageable image beside a pinned one: staged) -- same bits on the direct and the combining path."""
+    import ctypes as C
+    import gf_orb_slam2_amd as G
+    L = G.load_library()
+    oe = oracle.OracleExtractor(2000, 1.2, 8, 20, 7)
+    okl, odl = oe(euroc_l)
+    okr, odr = oe(euroc_r)
+    prm = G.StereoParams(480, BF, BF / FX, 0.0)
+    ref = oracle.stereo_match(okl, odl, okr, odr, oe.scale_factors, prm.n_rows, prm.mbf, prm.mb, prm.min_x)
+    buf = np.zeros((3, 480, 752), np.uint8)          # left | right contiguous, a third image apart from the first
+    buf[0], buf[1], buf[2] = euroc_l, euroc_r, euroc_r
+    assert L.gfo_host_register(C.c_void_p(buf.ctypes.data), buf.nbytes) == 0
+    try:
+        for combining in (False, True):
+            e = G.ORBextractor(2000, 1.2, 8, 20, 7, max_batch=2, combining=combining)
+            for l, r in ((buf[0], buf[1]), (buf[0], buf[2]), (buf[0], euroc_r.copy())):    # one copy / two copies / staged
+                kl, dl, kr, dr, nm, u, dp, bd, bi = e.extract_stereo(l, r, prm)
+                assert kl.tobytes() == okl.tobytes() and kr.tobytes() == okr.tobytes() and (dl == odl).all() and (dr == odr).all()
+                assert nm == ref[0] and u.tobytes() == ref[1].tobytes() and bi.tobytes() == ref[4].tobytes()
+            k1, d1 = e(buf[1])
+            assert k1.tobytes() == okr.tobytes() and (d1 == odr).all()
+            e.close()
+    finally:
+        assert L.gfo_host_unregister(C.c_void_p(buf.ctypes.data)) == 0
+    assert L.gfo_host_unregister(C.c_void_p(buf.ctypes.data)) != 0      # not registered any more

@@ -13,8 +13,10 @@
  * steady state must create nothing.
  *
  * Build: gcc -O2 -I include tools/c/boundary_throughput.c -o /tmp/boundary_throughput -ldl -lpthread -lm
- * Usage: boundary_throughput <libgfo.so> <golden dir> <seconds per point> <stereo|adapter|both> <K list, e.g. 1,2,4,8,16> [combine 0|1]
- * combine = 1 (default): every context opts into the frame combiner (gfo_ctx_set_combining), as the drop-in adapter does. */
+ * Usage: boundary_throughput <libgfo.so> <golden dir> <seconds per point> <stereo|adapter|both> <K list, e.g. 1,2,4,8,16> [combine 0|1] [pin 0|1]
+ * combine = 1 (default): every context opts into the frame combiner (gfo_ctx_set_combining), as the drop-in adapter does.
+ * pin = 1: the image pair the streams submit is page-locked with gfo_host_register (an application that owns its frame
+ * buffers can do that once); default 0 = pageable memory, as cv::imread / a ROS message hand it over. */
 #define _GNU_SOURCE
 #include <dlfcn.h>
 #include <pthread.h>
@@ -53,10 +55,13 @@ static struct {
     __typeof__(&gfo_arenas_planned) arenas_planned;
     __typeof__(&gfo_ctx_set_combining) set_combining;
     __typeof__(&gfo_combiner_stats) combiner_stats;
+    __typeof__(&gfo_host_register) host_register;
 } G;
-static int g_combine;
+static int g_combine, g_pin;
 
-static uint8_t IML[W * H], IMR[W * H];
+static uint8_t IMGS[2 * W * H] __attribute__((aligned(4096)));   /* left | right, one buffer: a pinned pair is ONE copy */
+#define IML (IMGS)
+#define IMR (IMGS + W * H)
 static volatile int g_stop, g_go;
 static uint64_t g_ref_sum;
 static volatile int g_have_ref;
@@ -206,10 +211,10 @@ static int run_point(int mode, int K, double seconds, int first)
     for (int k = 0; k < K; k++) { memcpy(all + q, S[k].lat, sizeof(double) * S[k].nlat); q += S[k].nlat; }
     qsort(all, nl, sizeof(double), cmp_d);
     const double wall = (t1 - t0) * 1e-3;
-    printf("%s  {\"path\": \"%s\", \"combining\": %s, \"frames_per_device_batch\": %.2f, \"streams\": %d, \"host_threads\": %d, \"contexts\": %d, \"seconds\": %.2f, \"stereo_frames\": %ld, "
+    printf("%s  {\"path\": \"%s\", \"caller_buffers_pinned\": %s, \"combining\": %s, \"frames_per_device_batch\": %.2f, \"streams\": %d, \"host_threads\": %d, \"contexts\": %d, \"seconds\": %.2f, \"stereo_frames\": %ld, "
            "\"images_per_s\": %.0f, \"stereo_frames_per_s\": %.0f, \"latency_ms\": {\"p50\": %.4f, \"p90\": %.4f, \"p99\": %.4f, \"max\": %.4f}, "
            "\"keypoints\": [%d, %d], \"stereo_candidates\": %d, \"frames_checksummed\": %ld, \"result_mismatches\": %d, \"errors\": %d, \"contexts_created_in_timed_region\": %d, \"arenas_planned_in_timed_region\": %d}",
-           first ? "" : ",\n", mode == 0 ? "gfo_extract_stereo" : "adapter: 2 x gfo_extract on two threads + gfo_stereo_match", g_combine ? "true" : "false",
+           first ? "" : ",\n", mode == 0 ? "gfo_extract_stereo" : "adapter: 2 x gfo_extract on two threads + gfo_stereo_match", g_pin ? "true" : "false", g_combine ? "true" : "false",
            cb > 0 ? (double)cr / cb / (mode == 0 ? 1 : 2) : 1.0, K, mode == 0 ? K : 2 * K,
            mode == 0 ? K : 2 * K, wall, frames, 2.0 * frames / wall, frames / wall, nl ? all[nl / 2] : 0.0, nl ? all[(long)nl * 9 / 10] : 0.0,
            nl ? all[(long)nl * 99 / 100] : 0.0, nl ? all[nl - 1] : 0.0, g_nl, g_nr, g_nm, checked, mism, errs, created1 - created0, planned1 - planned0);
@@ -239,15 +244,18 @@ int main(int argc, char** argv)
     SYM(contexts_created, gfo_contexts_created) SYM(arenas_planned, gfo_arenas_planned)
     SYM(set_combining, gfo_ctx_set_combining) SYM(combiner_stats, gfo_combiner_stats)
     g_combine = argc > 6 ? atoi(argv[6]) : 1;
+    g_pin = argc > 7 ? atoi(argv[7]) : 0;
+    SYM(host_register, gfo_host_register)
     char path[512];
     snprintf(path, sizeof path, "%s/EuRoC_l_752x480.u8", dir);
     FILE* f = fopen(path, "rb");
-    if (!f || fread(IML, 1, sizeof IML, f) != sizeof IML) { fprintf(stderr, "cannot read %s\n", path); return 2; }
+    if (!f || fread(IML, 1, W * H, f) != W * H) { fprintf(stderr, "cannot read %s\n", path); return 2; }
     fclose(f);
     snprintf(path, sizeof path, "%s/EuRoC_r_752x480.u8", dir);
     f = fopen(path, "rb");
-    if (!f || fread(IMR, 1, sizeof IMR, f) != sizeof IMR) { fprintf(stderr, "cannot read %s\n", path); return 2; }
+    if (!f || fread(IMR, 1, W * H, f) != W * H) { fprintf(stderr, "cannot read %s\n", path); return 2; }
     fclose(f);
+    if (g_pin && G.host_register(IMGS, sizeof IMGS)) { fprintf(stderr, "gfo_host_register: %s\n", G.last_error(NULL)); return 2; }
     int bad = 0, first = 1;
     printf("{\"workload\": \"EuRoC stereo pair 752x480 @2000, one frame per call, K independent streams\", \"points\": [\n");
     for (int mode = 0; mode < 2; mode++) {
