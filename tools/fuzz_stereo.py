@@ -26,6 +26,17 @@ for it in range(cases):
     bf = float(rng.uniform(5.0, 80.0))
     fx = float(rng.uniform(200.0, 600.0))
     min_x = float(rng.choice([0.0, 0.0, -20.0, 15.0]))
+    # the association's form: the library's choice, the per-keypoint form, or the row form with a random band height
+    import os
+    form = int(rng.choice([-1, 0, 2, 3, 5, 8, 13, 16, 32]))
+    if form < 0:
+        os.environ.pop("GFO_STEREO_ROWS", None)
+    else:
+        os.environ["GFO_STEREO_ROWS"] = str(form)
+    if rng.random() < 0.3:
+        os.environ["GFO_STEREO_CR"] = str(int(rng.choice([64, 128, 1024])))     # staging too small (read in place) / ample
+    else:
+        os.environ.pop("GFO_STEREO_CR", None)
     ext = G.ORBextractor(nf, 1.2, 8, 20, 7, max_batch=2)
     m = G.ORBmatcher(0.8, True, extractor=ext)
     (kl, kr), (dl, dr) = ext.extract_batch([l, r])
