@@ -700,7 +700,7 @@ static GfoStereoLaunch stereo_batch_launch(gfo_ctx* c, const gfo_stereo_params& 
     sl.pair_stride_kp = 2LL * c->g.kp_stride; sl.npairs = c->last_nimg / 2;
     sl.d_scale = c->d_scale;
     sl.p = p;
-    sl.min_d = nullptr; sl.max_d = nullptr;
+    sl.min_d = nullptr; sl.max_d = nullptr; sl.win_stride = 0;
     sl.out = c->st; sl.out_stride = c->g.kp_stride;
     sl.sort = c->st_sort; sl.sort_stride = c->g.kp_stride;
     sl.window = gfo_stereo_window(c->scale.data(), c->g.nlevels);
@@ -1204,6 +1204,75 @@ void gfo_small_collect_stereo(gfo_ctx* c, const GfoSmallLayout& L, int pair, int
     *nmatched = reinterpret_cast<const int*>(H + L.o_nm)[pair];
 }
 
+GfoPairBlock gfo_pair_block(int ks)
+{
+    GfoPairBlock b;
+    size_t off = 16;
+    auto take = [&](size_t bytes) { size_t o = off; off = (size_t)align_up((long long)(off + bytes), 16); return o; };
+    b.o_kl = take(sizeof(gfo_keypoint) * (size_t)ks); b.o_dl = take(32 * (size_t)ks);
+    b.o_kr = take(sizeof(gfo_keypoint) * (size_t)ks); b.o_dr = take(32 * (size_t)ks);
+    b.o_min = take(4 * (size_t)ks); b.o_max = take(4 * (size_t)ks);
+    b.bytes = (size_t)align_up((long long)off, 256);
+    return b;
+}
+
+// pair k's staged block -> the arena's batch layout (images 2k, 2k + 1 = its left / right keypoints and descriptors, counts)
+__global__ __launch_bounds__(256) void k_unpack_pairs(const uint8_t* __restrict__ stage, GfoPairBlock b, gfo_keypoint* __restrict__ d_kp,
+                                                      uint8_t* __restrict__ d_desc, int* __restrict__ d_cnt, int ks)
+{
+    const int pair = blockIdx.y;
+    const uint8_t* S = stage + (size_t)pair * b.bytes;
+    const int nl = reinterpret_cast<const int*>(S)[0], nr = reinterpret_cast<const int*>(S)[1];
+    if (blockIdx.x == 0 && threadIdx.x == 0) { d_cnt[2 * pair] = nl; d_cnt[2 * pair + 1] = nr; }
+    const int t = blockIdx.x * 256 + threadIdx.x, stride = gridDim.x * 256;
+    // 16-byte units; the keypoint arrays are 28-byte records: nl * 28 bytes rounded up stays inside the ks-sized part
+    uint4* kpl = reinterpret_cast<uint4*>(d_kp + (size_t)(2 * pair) * ks);
+    uint4* kpr = reinterpret_cast<uint4*>(d_kp + (size_t)(2 * pair + 1) * ks);
+    uint4* dl = reinterpret_cast<uint4*>(d_desc + (size_t)(2 * pair) * ks * 32);
+    uint4* dr = reinterpret_cast<uint4*>(d_desc + (size_t)(2 * pair + 1) * ks * 32);
+    const uint4* skl = reinterpret_cast<const uint4*>(S + b.o_kl); const uint4* skr = reinterpret_cast<const uint4*>(S + b.o_kr);
+    const uint4* sdl = reinterpret_cast<const uint4*>(S + b.o_dl); const uint4* sdr = reinterpret_cast<const uint4*>(S + b.o_dr);
+    for (int i = t; i < (nl * 28 + 15) / 16; i += stride) kpl[i] = skl[i];
+    for (int i = t; i < (nr * 28 + 15) / 16; i += stride) kpr[i] = skr[i];
+    for (int i = t; i < 2 * nl; i += stride) dl[i] = sdl[i];
+    for (int i = t; i < 2 * nr; i += stride) dr[i] = sdr[i];
+}
+
+// The frame combiner's host-array stereo batch: the pairs' blocks are in d_stage (each joiner copied its own); unpack, the
+// three association kernels over all pairs, the results into the pinned result buffer, one synchronisation.
+int gfo_small_submit_pairs(gfo_ctx* c, const GfoSmallLayout& L, int npairs, const gfo_stereo_params* sp, const uint8_t* d_stage)
+{
+    const int ks = c->g.kp_stride;
+    const GfoPairBlock b = gfo_pair_block(ks);
+    hipStream_t st = c->stream;
+    hipLaunchKernelGGL(k_unpack_pairs, dim3(8, npairs), dim3(256), 0, st, d_stage, b, c->d_kp, c->d_desc, c->d_kp_cnt, ks);
+    HIP_TRY(c, hipGetLastError());
+    c->last_nimg = 2 * npairs;
+    GfoStereoLaunch sl = stereo_batch_launch(c, *sp);
+    sl.min_d = reinterpret_cast<const float*>(d_stage + b.o_min);
+    sl.max_d = reinterpret_cast<const float*>(d_stage + b.o_max);
+    sl.win_stride = (long long)(b.bytes / 4);
+    gfo_launch_stereo(c, sl);
+    if (int lrc = gfo_take_launch_err(c)) return lrc;
+    uint8_t* H = c->h_out;
+    GfoPack pk{};
+    auto seg = [&](const void* src, size_t dst_off, size_t bytes) {
+        pk.src[pk.nseg] = (const uint4*)src; pk.dst[pk.nseg] = (uint4*)(H + dst_off); pk.n16[pk.nseg] = (int)((bytes + 15) / 16); pk.nseg++;
+    };
+    seg(c->st.u_right, L.o_ur, 4 * (size_t)ks * npairs);
+    seg(c->st.depth, L.o_dp, 4 * (size_t)ks * npairs);
+    seg(c->st.best_dist, L.o_bd, 4 * (size_t)ks * npairs);
+    seg(c->st.best_idx, L.o_bi, 4 * (size_t)ks * npairs);
+    seg(c->st.nmatched, L.o_nm, 4 * (size_t)npairs);
+    int total = 0;
+    for (int s_ = 0; s_ < pk.nseg; s_++) total += pk.n16[s_];
+    hipLaunchKernelGGL(k_pack_results, dim3((total + 1023) / 1024 > 0 ? (total + 1023) / 1024 : 1), dim3(256), 0, st, pk);
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipStreamSynchronize(st));
+    c->have_batch = c->have_stereo = false;     // the arena holds unpacked host arrays, not an extraction
+    return GFO_OK;
+}
+
 static int extract_small(gfo_ctx* c, const uint8_t* const* imgs, int nimg, int w, int h, int stride, const gfo_stereo_params* sp,
                          gfo_keypoint* const* kp, uint8_t* const* desc, int cap, int* n, float* u_right, float* depth,
                          int32_t* best_dist, int32_t* best_idx_r, int* nmatched)
@@ -1414,8 +1483,13 @@ extern "C" int gfo_stereo_match(gfo_ctx* c, const gfo_keypoint* kl, const uint8_
         if (kl[i].octave < 0 || kl[i].octave >= nlevels) return fail(c, GFO_ERR_INVALID, "left keypoint %d: octave %d outside 0..%d", i, kl[i].octave, nlevels - 1);
     for (int i = 0; i < nr; i++)
         if (kr[i].octave < 0 || kr[i].octave >= nlevels) return fail(c, GFO_ERR_INVALID, "right keypoint %d: octave %d outside 0..%d", i, kr[i].octave, nlevels - 1);
-    HIP_TRY(c, hipSetDevice(c->device));
     if (p->n_rows < 1 || p->n_rows > 8192) return fail(c, GFO_ERR_INVALID, "n_rows must be 1..8192");
+    if (c->combining) {    // the pairs several threads associate at once share one launch (gfo_combine.hip); 1 = not eligible
+        int status = GFO_OK;
+        if (gfo_combined_stereo_match(c, kl, dl, nl, kr, dr, nr, sf, nlevels, p, min_d, max_d, u_right, depth, best_dist, best_idx_r, nmatched, &status) == 0)
+            return status;
+    }
+    HIP_TRY(c, hipSetDevice(c->device));
     // scratch layout: inputs first, outputs next, work buffers last -- the input and output regions are mirrored in
     // pinned host memory, so the call is one H2D copy, three kernels, one D2H copy and one synchronisation
     size_t off = 0;

@@ -112,7 +112,7 @@ struct GfoStereoLaunch {
     int npairs;
     const float* d_scale;
     gfo_stereo_params p;
-    const float* min_d; const float* max_d;
+    const float* min_d; const float* max_d; long long win_stride;   // per-keypoint disparity windows, floats between pairs
     GfoStereoDev out; int out_stride;
     GfoStereoSort sort; int sort_stride;
     int window;
@@ -285,11 +285,20 @@ int gfo_small_submit(gfo_ctx* c, const GfoSmallLayout& L, int nimg, const gfo_st
 int gfo_small_collect(gfo_ctx* c, const GfoSmallLayout& L, int i, gfo_keypoint* kp, uint8_t* desc, int cap, int* n);
 void gfo_small_collect_stereo(gfo_ctx* c, const GfoSmallLayout& L, int pair, int n_left, int cap, float* u_right, float* depth,
                               int32_t* best_dist, int32_t* best_idx_r, int* nmatched);
+// host-array stereo association of several pairs as one device batch (the frame combiner's kind 3)
+struct GfoPairBlock {      // one pair's inputs, staged contiguously: {nl, nr, -, -} | kl | dl | kr | dr | min_d | max_d, every part 16-byte aligned
+    size_t bytes, o_kl, o_dl, o_kr, o_dr, o_min, o_max;
+};
+GfoPairBlock gfo_pair_block(int kp_stride);
+int gfo_small_submit_pairs(gfo_ctx* c, const GfoSmallLayout& L, int npairs, const gfo_stereo_params* sp, const uint8_t* d_stage);
 
 // gfo_combine.hip
 int gfo_combined_extract(gfo_ctx* c, int kind, const uint8_t* const* imgs, int w, int h, int stride, const gfo_stereo_params* sp,
                          gfo_keypoint* const* kp, uint8_t* const* desc, int cap, int* n, float* u_right, float* depth,
                          int32_t* best_dist, int32_t* best_idx_r, int* nmatched);
+int gfo_combined_stereo_match(gfo_ctx* c, const gfo_keypoint* kl, const uint8_t* dl, int nl, const gfo_keypoint* kr, const uint8_t* dr, int nr,
+                              const float* sf, int nlevels, const gfo_stereo_params* p, const float* min_d, const float* max_d,
+                              float* u_right, float* depth, int32_t* best_dist, int32_t* best_idx_r, int* nmatched, int* status);
 void gfo_engine_release(gfo_ctx* c);
 
 // profiling helpers (gfo_api.hip)

@@ -48,6 +48,7 @@ struct StereoArgs {
     gfo_stereo_params p;
     const float* min_d;
     const float* max_d;
+    long long win_stride;     // floats between consecutive pairs in min_d / max_d (0: one pair)
     GfoStereoDev out;
     int out_stride;
     // bucketed right side, [pairs][sort_stride]
@@ -197,8 +198,8 @@ __global__ __launch_bounds__(256) void k_stereo_match(StereoArgs a)
     const int row = in_rows ? (int)vL : 0;
     float minD = 0.f, maxD = a.p.mbf / a.p.mb;  // :1199-1200 (minZ = mb)
     if (a.min_d && a.max_d) {                  // :1220-1231 flattened by the adapter
-        minD = a.min_d[iL];
-        maxD = a.max_d[iL];
+        minD = a.min_d[pair * a.win_stride + iL];
+        maxD = a.max_d[pair * a.win_stride + iL];
     }
     const float minU = uL - maxD, maxU = uL - minD;
     const uint4* dlp = reinterpret_cast<const uint4*>(dl + (long long)iL * 32);
@@ -309,8 +310,8 @@ __global__ __launch_bounds__(SR_THREADS) void k_stereo_match_rows(StereoArgs a, 
             l_x[t] = L->x;
             l_ro[t] = (int)L->y | (L->octave << 16);    // 0 <= (int)y < nRows <= 65535
             l_i[t] = iL;
-            l_minD[t] = win ? a.min_d[iL] : 0.f;        // :1220-1231 flattened by the adapter
-            l_maxD[t] = win ? a.max_d[iL] : maxD0;
+            l_minD[t] = win ? a.min_d[pair * a.win_stride + iL] : 0.f;        // :1220-1231 flattened by the adapter
+            l_maxD[t] = win ? a.max_d[pair * a.win_stride + iL] : maxD0;
             l_d0[t] = dl[2 * iL];
             l_d1[t] = dl[2 * iL + 1];
         }
@@ -650,7 +651,7 @@ void gfo_launch_stereo_sad(gfo_ctx* c, const GfoStereoLaunch& s, const GfoInput&
     a.pair_stride = s.pair_stride_kp;
     a.scale = s.d_scale;
     a.p = s.p;
-    a.min_d = nullptr; a.max_d = nullptr;
+    a.min_d = nullptr; a.max_d = nullptr; a.win_stride = 0;
     a.out = s.out; a.out_stride = s.out_stride;
     a.sx = s.sort.sx; a.sband = reinterpret_cast<unsigned*>(s.sort.sy); a.soi = s.sort.soi; a.sdesc = reinterpret_cast<uint4*>(s.sort.sdesc);
     a.row_start = s.sort.row_start;
@@ -687,7 +688,7 @@ void gfo_launch_stereo(gfo_ctx* c, const GfoStereoLaunch& s)
     a.pair_stride = s.pair_stride_kp;
     a.scale = s.d_scale;
     a.p = s.p;
-    a.min_d = s.min_d; a.max_d = s.max_d;
+    a.min_d = s.min_d; a.max_d = s.max_d; a.win_stride = s.win_stride;
     a.out = s.out; a.out_stride = s.out_stride;
     a.sx = s.sort.sx; a.sband = reinterpret_cast<unsigned*>(s.sort.sy); a.soi = s.sort.soi; a.sdesc = reinterpret_cast<uint4*>(s.sort.sdesc);
     a.row_start = s.sort.row_start;

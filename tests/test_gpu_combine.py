@@ -189,3 +189,58 @@ def test_frames_from_buffers_the_caller_pinned(oracle, euroc_l, euroc_r):
     finally:
         assert L.gfo_host_unregister(C.c_void_p(buf.ctypes.data)) == 0
     assert L.gfo_host_unregister(C.c_void_p(buf.ctypes.data)) != 0      # not registered any more
+
+
+def test_adapter_pattern_end_to_end_from_many_threads(oracle, euroc_l, euroc_r):
+    """The drop-in adapter's whole per-frame pattern from six rigs at once: left and right extractor on two threads
+    (gfo_extract, one image each), then Frame::ComputeStereoMatches_Undistorted on the LEFT extractor's context
+    (gfo_stereo_match on host arrays) -- which a combining context now also runs as part of a shared device batch (one
+    launch of the association kernels for all pairs in flight).  Rigs differ in images, calibration (two parameter sets:
+    separate batches) and in whether they pass per-keypoint disparity windows (Frame.cc:1220-1231)."""
+    import gf_orb_slam2_amd as G
+    RIGS, REPS = 6, 5
+    oe = oracle.OracleExtractor(1500, 1.2, 8, 20, 7)
+    sf = oe.scale_factors
+    pairs = [(euroc_l, euroc_r), (synth_frame(752, 480, 40), synth_frame(752, 480, 41)), (euroc_r, euroc_l)]
+    ext_refs = [(oe(l), oe(r)) for l, r in pairs]
+    calib = [G.StereoParams(480, BF, BF / FX, 0.0), G.StereoParams(480, 30.0, 0.12, 5.0)]
+    rng = np.random.default_rng(3)
+    cases = []
+    for rig in range(RIGS):
+        (kl, dl), (kr, dr) = ext_refs[rig % 3]
+        prm = calib[rig % 2]
+        win = None
+        if rig % 3 != 1:     # two rigs in three track map points: windows around a guessed disparity
+            d0 = rng.uniform(0, 60, len(kl)).astype(np.float32)
+            win = (np.maximum(d0 - 8, 0).astype(np.float32), np.minimum(d0 + 8, np.float32(prm.mbf / prm.mb)).astype(np.float32))
+        ref = oracle.stereo_match(kl, dl, kr, dr, sf, prm.n_rows, prm.mbf, prm.mb, prm.min_x, *(win or (None, None)))
+        cases.append((rig % 3, prm, win, ref))
+    exts = [(G.ORBextractor(1500, 1.2, 8, 20, 7, combining=True), G.ORBextractor(1500, 1.2, 8, 20, 7, combining=True)) for _ in range(RIGS)]
+    matchers = [G.ORBmatcher(0.8, True, extractor=el) for el, _ in exts]
+    bad = []
+
+    def rig_thread(rig):
+        pi, prm, win, ref = cases[rig]
+        l, r = pairs[pi]
+        (okl, odl), (okr, odr) = ext_refs[pi]
+        for _ in range(REPS):
+            out = {}
+            t = threading.Thread(target=lambda: out.__setitem__("r", exts[rig][1](r)))
+            t.start()
+            kl, dl = exts[rig][0](l)
+            t.join()
+            kr, dr = out["r"]
+            if not (kl.tobytes() == okl.tobytes() and kr.tobytes() == okr.tobytes() and (dl == odl).all() and (dr == odr).all()):
+                bad.append((rig, "extract"))
+                return
+            got = matchers[rig].ComputeStereoMatches(kl, dl, kr, dr, sf, prm, *(win or (None, None)))
+            if not (got[0] == ref[0] and all(a.tobytes() == b.tobytes() for a, b in zip(got[1:], ref[1:]))):
+                bad.append((rig, "stereo"))
+
+    _run_threads([lambda rig=rig: rig_thread(rig) for rig in range(RIGS)])
+    assert not bad, bad
+    b, r = exts[0][0].combiner_stats()
+    assert r == RIGS * REPS * 3 and b < r      # three requests per frame: two images and one association; batches were shared
+    for el, er in exts:
+        el.close()
+        er.close()
