@@ -39,6 +39,7 @@ for rd in range(rounds):
     K = int(rng.integers(2, 13))
     plan = [(int(rng.integers(0, len(PARAMS))), int(rng.integers(0, len(SIZES))), int(rng.integers(3, 12)), int(rng.integers(0, 1 << 30))) for _ in range(K)]
     exts = [G.ORBextractor(*PARAMS[pi], max_batch=2, combining=True) for pi, _, _, _ in plan]
+    matchers = [G.ORBmatcher(0.8, True, extractor=e) for e in exts]
 
     def work(t):
         pi, si, n, seed = plan[t]
@@ -46,7 +47,20 @@ for rd in range(rounds):
         w, h = SIZES[si]
         sp = G.StereoParams(h, BF, BF / FX, 0.0)
         for _ in range(n):
-            if r.random() < 0.5:
+            u = r.random()
+            if u < 0.25:     # the adapter's third call: the host-array association on this extractor's context, with or without windows
+                k = int(r.choice([0, 2]))
+                (kl, dl), (kr, dr) = refs[(pi, si, k)], refs[(pi, si, k + 1)]
+                sfac = O.OracleExtractor(*PARAMS[pi]).scale_factors
+                win = (None, None)
+                if r.random() < 0.5:
+                    d0 = r.uniform(0, 50, len(kl)).astype(np.float32)
+                    win = (np.maximum(d0 - 6, 0).astype(np.float32), (d0 + 6).astype(np.float32))
+                ref = refs[(pi, si, k, "st")] if win[0] is None else O.stereo_match(kl, dl, kr, dr, sfac, h, BF, BF / FX, 0.0, *win)
+                got = matchers[t].ComputeStereoMatches(kl, dl, kr, dr, sfac, sp, *win)
+                if not (got[0] == ref[0] and all(a.tobytes() == b.tobytes() for a, b in zip(got[1:], ref[1:]))):
+                    bad.append((rd, t, "assoc", pi, si, k))
+            elif u < 0.6:
                 k = int(r.integers(0, 4))
                 kp, d = exts[t](imgs[(si, k)])
                 ok, od = refs[(pi, si, k)]
