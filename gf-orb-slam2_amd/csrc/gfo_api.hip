@@ -1114,7 +1114,9 @@ int gfo_small_prepare(gfo_ctx* c, int nimg_cap, GfoSmallLayout* L)
 //   every image pinned by the caller (gfo_host_register), tight rows, one behind the other in memory -> ONE copy, no staging;
 //   pinned but apart -> one copy each, no staging;
 //   otherwise -> memcpy into the context's pinned staging (one memcpy per image when the rows are tight), ONE copy.
-int gfo_small_upload(gfo_ctx* c, const GfoSmallLayout& L, int first, int count, const uint8_t* const* imgs, int w, int h, int stride,
+// `ec` takes the error message: the context of the CALLING thread (in the combiner several callers upload into one batch
+// context at once -- its error string is not theirs to write).
+int gfo_small_upload(gfo_ctx* c, gfo_ctx* ec, const GfoSmallLayout& L, int first, int count, const uint8_t* const* imgs, int w, int h, int stride,
                      hipStream_t st)
 {
     uint8_t* dst = c->d_input + (size_t)first * L.img_bytes;
@@ -1125,9 +1127,9 @@ int gfo_small_upload(gfo_ctx* c, const GfoSmallLayout& L, int first, int count, 
         bool contiguous = true;
         for (int i = 1; i < count; i++) contiguous = contiguous && imgs[i] == imgs[i - 1] + L.img_bytes;
         if (contiguous) {
-            HIP_TRY(c, hipMemcpyAsync(dst, imgs[0], L.img_bytes * count, hipMemcpyHostToDevice, st));
+            HIP_TRY(ec, hipMemcpyAsync(dst, imgs[0], L.img_bytes * count, hipMemcpyHostToDevice, st));
         } else {
-            for (int i = 0; i < count; i++) HIP_TRY(c, hipMemcpyAsync(dst + (size_t)i * L.img_bytes, imgs[i], L.img_bytes, hipMemcpyHostToDevice, st));
+            for (int i = 0; i < count; i++) HIP_TRY(ec, hipMemcpyAsync(dst + (size_t)i * L.img_bytes, imgs[i], L.img_bytes, hipMemcpyHostToDevice, st));
         }
         return GFO_OK;
     }
@@ -1138,7 +1140,7 @@ int gfo_small_upload(gfo_ctx* c, const GfoSmallLayout& L, int first, int count, 
         else
             for (int y = 0; y < h; y++) memcpy(d + (size_t)y * L.pitch, imgs[i] + (size_t)y * stride, w);
     }
-    HIP_TRY(c, hipMemcpyAsync(dst, stage, L.img_bytes * count, hipMemcpyHostToDevice, st));
+    HIP_TRY(ec, hipMemcpyAsync(dst, stage, L.img_bytes * count, hipMemcpyHostToDevice, st));
     return GFO_OK;
 }
 
@@ -1280,7 +1282,7 @@ static int extract_small(gfo_ctx* c, const uint8_t* const* imgs, int nimg, int w
     GfoSmallLayout L;
     int rc = gfo_small_prepare(c, nimg, &L);
     if (rc) return rc;
-    rc = gfo_small_upload(c, L, 0, nimg, imgs, w, h, stride, c->stream);
+    rc = gfo_small_upload(c, c, L, 0, nimg, imgs, w, h, stride, c->stream);
     if (rc) return rc;
     rc = gfo_small_submit(c, L, nimg, sp, false);
     if (rc) return rc;

@@ -264,7 +264,7 @@ int gfo_combined_extract(gfo_ctx* c, int kind, const uint8_t* const* imgs, int w
     int over = 0;
     const int rc = run_request(
         c, eh.get(), kind, kind, sp,
-        [&](Slot& s, int idx) { return gfo_small_upload(s.bc, s.L, idx * kind, kind, imgs, w, h, stride, s.bc->stream); },
+        [&](Slot& s, int idx) { return gfo_small_upload(s.bc, c, s.L, idx * kind, kind, imgs, w, h, stride, s.bc->stream); },
         [&](Slot& s, int nb) { return gfo_small_submit(s.bc, s.L, nb * kind, kind == 2 ? &s.sp : nullptr, false); },
         [&](Slot& s, int idx) {
             int o = 0;

@@ -279,7 +279,7 @@ struct GfoSmallLayout {
     size_t o_fl, o_cnt, o_kp, o_ds, o_ur, o_dp, o_bd, o_bi, o_nm;   // offsets into the pinned result buffer
 };
 int gfo_small_prepare(gfo_ctx* c, int nimg_cap, GfoSmallLayout* L);
-int gfo_small_upload(gfo_ctx* c, const GfoSmallLayout& L, int first, int count, const uint8_t* const* imgs, int w, int h, int stride,
+int gfo_small_upload(gfo_ctx* c, gfo_ctx* ec, const GfoSmallLayout& L, int first, int count, const uint8_t* const* imgs, int w, int h, int stride,
                      hipStream_t st);
 int gfo_small_submit(gfo_ctx* c, const GfoSmallLayout& L, int nimg, const gfo_stereo_params* sp, bool copy_in);
 int gfo_small_collect(gfo_ctx* c, const GfoSmallLayout& L, int i, gfo_keypoint* kp, uint8_t* desc, int cap, int* n);
