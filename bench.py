@@ -621,15 +621,15 @@ def main():
     if world == 1:
         # PCIe-inclusive rate (never `value`): every step first copies its batch from pinned host memory
         pinned = torch.from_numpy(job.host_batches[0]).pin_memory()
-        n_h = max(5, min(args.steps, 30))
+        n_h = max(20, min(args.steps, 60))    # (30 steps = 33 ms were too short a region: one hiccup halved the delivered rate once)
         job.chain(False)      # the copies already pace the contexts; chained on top of that they serialise (77k against 111k)
-        dth = job.timed(n_h, 2, h2d_from=pinned)
+        dth = job.timed(n_h, 4, h2d_from=pinned)
         job.chain(True)
         extra["value_with_h2d"] = round(B * n_h / dth, 1)
         # ... and the results out: every step also lands counts, keypoints, descriptors (and the stereo outputs) of its batch in
         # pinned host memory, where ORBextractor::operator() leaves them (ORBextractor.cc:1137-1173).  Opposite directions of
         # a full-duplex link: the ceiling stays the input copy
-        dtd = job.timed(n_h, 2, h2d_from=pinned, deliver=True)
+        dtd = job.timed(n_h, 6, h2d_from=pinned, deliver=True)    # (the first deliveries touch the pinned result blocks for the first time)
         lay = job.deliver_layout
         extra["value_delivered"] = round(B * n_h / dtd, 1)
         extra["delivery"] = {"host_bytes_in_per_step": int(B * job.w * job.h), "host_bytes_out_per_step": int(lay.bytes),
