@@ -50,6 +50,8 @@ __device__ __forceinline__ void wave_sync()
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+#define FAST_XOFF 1   // the tile starts this many bytes left of the cell: scan column 0 at tile column 4 (k_fast, tile load)
+
 typedef short __attribute__((ext_vector_type(2))) s16x2;
 __device__ __forceinline__ unsigned pmin(unsigned a, unsigned b)
 {
@@ -81,70 +83,73 @@ __device__ __forceinline__ unsigned rot16(unsigned a)
 // above t, a bright arc the mirror image.  Where both hold, the all-eight-pairs test picks the one polarity that
 // can still be a corner (below).
 template <int TP>
-__device__ __forceinline__ int corner_score(const uint8_t* __restrict__ c, int tq)
+__device__ __forceinline__ int corner_score(const uint8_t* __restrict__ tl, int tq, unsigned long long& m_run)
 {
-    const unsigned v = c[0];
-    const unsigned r[16] = {c[3 * TP], c[3 * TP + 1], c[2 * TP + 2], c[TP + 3], c[3], c[-TP + 3], c[-2 * TP + 2], c[-3 * TP + 1],
-                            c[-3 * TP], c[-3 * TP - 1], c[-2 * TP - 2], c[-TP - 3], c[-3], c[TP - 3], c[2 * TP - 2], c[3 * TP - 1]};
-    const s16x2 v2 = __builtin_bit_cast(s16x2, v | (v << 16));
-    s16x2 D[8];
+    // LDS offsets are unsigned immediates: the ring is addressed from `tl`, one byte left of its top-left corner (so that the
+    // caller's address is tile + py * TP + px, nothing added), the centre sits RB bytes further
+    constexpr int RB = 3 * TP + 3 + FAST_XOFF;
+    const unsigned v = tl[RB];
+    const unsigned v2 = v | (v << 16);
+    // ring words Q[k] = (r[k], r[k+8]).  (ds_read_u8_d16 / _d16_hi would deliver the pair packed, but with SRAM ECC on -- as
+    // on every MI300 / MI355 -- a d16 load clears the other half of its register instead of preserving it: tried in round 3,
+    // twice the candidates of the oracle.  One v_lshl_or per word it is.)
+    const unsigned r[16] = {tl[RB + 3 * TP], tl[RB + 3 * TP + 1], tl[RB + 2 * TP + 2], tl[RB + TP + 3], tl[RB + 3], tl[RB - TP + 3], tl[RB - 2 * TP + 2], tl[RB - 3 * TP + 1],
+                            tl[RB - 3 * TP], tl[RB - 3 * TP - 1], tl[RB - 2 * TP - 2], tl[RB - TP - 3], tl[RB - 3], tl[RB + TP - 3], tl[RB + 2 * TP - 2], tl[RB + 3 * TP - 1]};
+    unsigned Q[8];
 #pragma unroll
-    for (int k = 0; k < 8; k++) D[k] = v2 - __builtin_bit_cast(s16x2, r[k] | (r[k + 8] << 16));   // (d[k], d[k+8])
-    // compass: per opposite pair the larger / smaller difference, both halves of a register at once
-    const s16x2 hi08 = __builtin_elementwise_max(D[0], __builtin_bit_cast(s16x2, rot16(__builtin_bit_cast(unsigned, D[0]))));
-    const s16x2 hi4c = __builtin_elementwise_max(D[4], __builtin_bit_cast(s16x2, rot16(__builtin_bit_cast(unsigned, D[4]))));
-    const s16x2 lo08 = __builtin_elementwise_min(D[0], __builtin_bit_cast(s16x2, rot16(__builtin_bit_cast(unsigned, D[0]))));
-    const s16x2 lo4c = __builtin_elementwise_min(D[4], __builtin_bit_cast(s16x2, rot16(__builtin_bit_cast(unsigned, D[4]))));
-    const int s_hi = (int)(short)(__builtin_bit_cast(unsigned, __builtin_elementwise_min(hi08, hi4c)) & 0xFFFF);
-    const int s_lo = (int)(short)(__builtin_bit_cast(unsigned, __builtin_elementwise_max(lo08, lo4c)) & 0xFFFF);
-    const bool dark = s_hi > tq, bright = s_lo < -tq;
+    for (int k = 0; k < 8; k++) Q[k] = r[k] | (r[k + 8] << 16);
+    // compass, on the ring words themselves (no differences yet -- their sign is not known): both halves of A / B are alike,
+    //   both pairs (0,8), (4,12) hold a pixel darker than v - t    <=>  max(min(r0, r8), min(r4, r12)) < v - t
+    //   both pairs hold a brighter one                              <=>  min(max(r0, r8), max(r4, r12)) > v + t
+    // and words with equal halves compare like their halves (x * 0x10001 is monotone, no overflow for 9-bit values)
+    const unsigned tq2 = (unsigned)tq * 0x10001u;
+    const unsigned A = pmax(pmin(Q[0], rot16(Q[0])), pmin(Q[4], rot16(Q[4])));
+    const unsigned B = pmin(pmax(Q[0], rot16(Q[0])), pmax(Q[4], rot16(Q[4])));
+    const int vmt = (int)(v2 - tq2), vpt = (int)(v2 + tq2);
+    const bool dark = (int)A < vmt, bright = (int)B > vpt;
     // ONE polarity is scored per pixel.  A dark and a bright 9-arc cannot coexist (18 > 16 ring pixels), so a pixel
     // whose compass pixels allow both (saddles, edge crossings: ~5 % of the survivors, i.e. nearly every wave holds
     // one) only needs the polarity that can still be a corner: a dark 9-arc covers at least one member of EVERY
     // opposite pair (k, k+8), so "all eight pairs hold a pixel darker than v - t" is necessary for it -- and when both
     // polarities pass that test no pair has two members of one sign, so neither has a 9-arc and either choice scores
-    // <= t.  18 packed ops for the whole wave instead of a second scoring pass (~100).
+    // <= t.  12 packed ops for the whole wave instead of a second scoring pass.
     // (lane masks in scalar registers from here on: as per-lane bools the compiler carried them through the branch as 0 / 1
     //  integers and paid half a dozen vector selects and compares to turn them back into masks)
     const unsigned long long m_dark = __builtin_amdgcn_ballot_w64(dark), m_bright = __builtin_amdgcn_ballot_w64(bright);
     unsigned long long m_neg = ~m_dark;
     if ((m_dark & m_bright) != 0) {
-        unsigned m8 = __builtin_bit_cast(unsigned, __builtin_elementwise_min(hi08, hi4c));   // pairs 0 and 4, both halves alike
-#pragma unroll
-        for (int k = 1; k < 8; k++) {
-            if (k == 4) continue;
-            const unsigned dk = __builtin_bit_cast(unsigned, D[k]);
-            m8 = pmin(m8, pmax(dk, rot16(dk)));
-        }
-        const unsigned long long m_all8 = __builtin_amdgcn_ballot_w64((int)(short)(m8 & 0xFFFF) > tq);
+        // (a tree, not a chain: dependent packed operations back to back cost a wait state each)
+        const unsigned e1 = pmin(Q[1], rot16(Q[1])), e2 = pmin(Q[2], rot16(Q[2])), e3 = pmin(Q[3], rot16(Q[3]));
+        const unsigned e5 = pmin(Q[5], rot16(Q[5])), e6 = pmin(Q[6], rot16(Q[6])), e7 = pmin(Q[7], rot16(Q[7]));
+        const unsigned m8 = pmax(pmax(pmax(e1, e2), pmax(e3, e5)), pmax(pmax(e6, e7), A));   // A: pairs 0 and 4
+        const unsigned long long m_all8 = __builtin_amdgcn_ballot_w64((int)m8 < vmt);
         m_neg |= m_bright & ~m_all8;       // dark && bright: bright polarity unless all eight pairs can still be dark
     }
     const bool neg = __builtin_amdgcn_inverse_ballot_w64(m_neg);
-    const bool run = __builtin_amdgcn_inverse_ballot_w64(m_dark | m_bright);
+    m_run = m_dark | m_bright;   // lanes whose compass pixels allow an arc at all: the others' result is meaningless
     int best = 0;
     {
-        const s16x2 sg = __builtin_bit_cast(s16x2, neg ? 0xFFFFFFFFu : 0x00010001u);
-        unsigned P[8], R[8];
+        // signed differences straight from the ring words: p[k] = sg * (v - r[k]) = (-sg) * r[k] + sg * v is ONE packed
+        // multiply-add per ring word (round 2 formed v - r and multiplied by the sign: two)
+        const s16x2 nsg = __builtin_bit_cast(s16x2, neg ? 0x00010001u : 0xFFFFFFFFu);
+        const s16x2 sv = __builtin_bit_cast(s16x2, v2) * __builtin_bit_cast(s16x2, neg ? 0xFFFFFFFFu : 0x00010001u);
+        unsigned P[8];
 #pragma unroll
-        for (int k = 0; k < 8; k++) {
-            P[k] = __builtin_bit_cast(unsigned, D[k] * sg);
-            R[k] = rot16(P[k]);
-        }
-        unsigned X2[10], X4[12];
-#pragma unroll
-        for (int k = 0; k < 7; k++) X2[k] = pmin(P[k], P[k + 1]);
-        X2[7] = pmin(P[7], R[0]);
-        X2[8] = rot16(X2[0]);
-        X2[9] = rot16(X2[1]);
-#pragma unroll
-        for (int k = 0; k < 8; k++) X4[k] = pmin(X2[k], X2[k + 2]);
-#pragma unroll
-        for (int k = 0; k < 4; k++) X4[8 + k] = rot16(X4[k]);
-        unsigned bst = 0x80008000u;  // (-32768, -32768)
-#pragma unroll
-        for (int k = 0; k < 8; k++) bst = pmax(bst, pmin(pmin(X4[k], X4[k + 4]), R[k]));
-        const int b0 = (int)(short)(bst & 0xFFFF), b1 = (int)(short)(bst >> 16);
-        if (run) best = max(b0, b1);
+        for (int k = 0; k < 8; k++) P[k] = __builtin_bit_cast(unsigned, __builtin_bit_cast(s16x2, Q[k]) * nsg + sv);   // (p[k], p[k+8])
+        // S = max over the sixteen 9-arcs of their minimum.  The arcs starting at s-1 and at s share the eight entries
+        // s..s+7 (m8(s)), and max(min(p[s-1], m8), min(m8, p[s+8])) = min(m8, max(p[s-1], p[s+8])): only the EIGHT runs with odd
+        // start are needed -- four packed registers (starts s and s+8 in the two halves), built by doubling: 4 + 4 + 4 packed
+        // minima, then 3 ops per register (round 2 built all sixteen 4-runs and three ops per arc pair: 40 against 23).
+        // rot16() of an operand folds into the op_sel bits of the consuming instruction.
+        const unsigned a1 = pmin(P[1], P[2]), a3 = pmin(P[3], P[4]), a5 = pmin(P[5], P[6]), a7 = pmin(P[7], rot16(P[0]));   // 2-runs from 1, 3, 5, 7
+        const unsigned b1 = pmin(a1, a3), b3 = pmin(a3, a5), b5 = pmin(a5, a7), b7 = pmin(a7, rot16(a1));                     // 4-runs
+        const unsigned c1 = pmin(b1, b5), c3 = pmin(b3, b7), c5 = pmin(b5, rot16(b1)), c7 = pmin(b7, rot16(b3));               // 8-runs
+        unsigned bst = pmin(c1, pmax(P[0], rot16(P[1])));
+        bst = pmax(bst, pmin(c3, pmax(P[2], rot16(P[3]))));
+        bst = pmax(bst, pmin(c5, pmax(P[4], rot16(P[5]))));
+        bst = pmax(bst, pmin(c7, pmax(P[6], rot16(P[7]))));
+        const int b0 = (int)(short)(bst & 0xFFFF), b1s = (int)(short)(bst >> 16);
+        best = max(b0, b1s);
     }
     return best;
 }
@@ -195,16 +200,22 @@ __global__ __launch_bounds__(256) void k_fast(const GfoGeom* __restrict__ gp, Gf
     const int cw = maxX - iniX, ch = maxY - iniY;
     const int sw = cw - 6, sh = ch - 6;
     if (sw <= 0 || sh <= 0) return;
-    const int x_al = iniX & ~3;
-    const int xoff = iniX - x_al;
+    // The tile starts ONE byte left of the cell, so that scan column 0 (cell column 3) sits at tile column 4: every lane of
+    // stage A then owns four scan pixels of an aligned LDS dword, a 30..32-px cell is 8 dwords wide and 8 rows of it fill the
+    // wave -- four stage-A passes for a 30x30 cell.  (Round 2 started the tile at the aligned dword left of the cell: the scan
+    // columns began at byte 1 or 3 of a dword, 9 dwords per row, 7 rows per pass, five passes -- 5.05 on average at 752x480,
+    // 4.16 now.)  The price is global loads at odd addresses, which the memory pipeline takes: the 16-byte loads below are
+    // declared unaligned.
+    constexpr int xoff = FAST_XOFF;
+    struct __attribute__((packed)) seg16 { uint32_t a, b, c, d; };
     {
         int pitch;
         const uint8_t* src = gfo_level_ptr(g, in, pyr, level, img, &pitch);
-        src += (long long)iniY * pitch + x_al;
+        src += (long long)iniY * pitch + (iniX - xoff);
         // 16-byte row segments: TP is a multiple of 16, every lane issues its (<= 4) wide loads before the
         // first LDS store; the segment right of the cell may run a few bytes past maxX but stays inside the
         // image row (maxX <= w - 16)
-        const int spr = (xoff + cw + 15) >> 4;  // 16-byte segments per tile row (3 for a 30-px cell, at most 6)
+        const int spr = (xoff + cw + 15) >> 4;  // 16-byte segments per tile row (3 for a 30-px cell, at most 5)
         // fixed lane -> (row of the step, segment) map: 64 / spr rows per step, so a load is a pointer increment
         // (two steps for a 30-px cell); all loads of a lane are issued before its first LDS store
         const int rps = 64 / spr;
@@ -218,10 +229,9 @@ __global__ __launch_bounds__(256) void k_fast(const GfoGeom* __restrict__ gp, Gf
         // rows past the cell's last one are clamped to it (loaded, not stored)
         const uint8_t* p_last = lp + (long long)(ch - 1 - min(lr, ch - 1)) * pitch;
         if (2 * rps >= ch) {   // the usual cell: two steps, no per-step bookkeeping (wave-uniform branch)
-            const uint32_t* pa = reinterpret_cast<const uint32_t*>(lr < ch ? lp : p_last);
-            const uint32_t* pb = reinterpret_cast<const uint32_t*>(rps + lr < ch ? lp + gstep : p_last);
-            // 4-byte aligned (x_al), not 16: four dword loads the compiler may merge into one dwordx4
-            const uint4 va = make_uint4(pa[0], pa[1], pa[2], pa[3]), vb = make_uint4(pb[0], pb[1], pb[2], pb[3]);
+            const seg16 sa = *reinterpret_cast<const seg16*>(lr < ch ? lp : p_last);
+            const seg16 sb = *reinterpret_cast<const seg16*>(rps + lr < ch ? lp + gstep : p_last);
+            const uint4 va = make_uint4(sa.a, sa.b, sa.c, sa.d), vb = make_uint4(sb.a, sb.b, sb.c, sb.d);
             if (ld_on && lr < ch) t128[0] = va;
             if (ld_on && rps + lr < ch) t128[lstep] = vb;
         } else {
@@ -229,8 +239,8 @@ __global__ __launch_bounds__(256) void k_fast(const GfoGeom* __restrict__ gp, Gf
 #pragma unroll
             for (int k = 0; k < 6; k++) {
                 if (k * rps < ch) {   // wave-uniform
-                    const uint32_t* p32 = reinterpret_cast<const uint32_t*>(k * rps + lr < ch ? lp + k * gstep : p_last);
-                    v[k] = make_uint4(p32[0], p32[1], p32[2], p32[3]);
+                    const seg16 sk = *reinterpret_cast<const seg16*>(k * rps + lr < ch ? lp + k * gstep : p_last);
+                    v[k] = make_uint4(sk.a, sk.b, sk.c, sk.d);
                 }
             }
 #pragma unroll
@@ -245,7 +255,6 @@ __global__ __launch_bounds__(256) void k_fast(const GfoGeom* __restrict__ gp, Gf
 #ifdef GFO_FAST_DEBUG
     if (dbg_stop == 1) return;
 #endif
-    const uint8_t* t0 = tile + 3 * TP + xoff + 3;  // scan pixel (0,0)
     // The cascade runs at iniThFAST first; only a cell that yields no maximum there repeats it at
     // minThFAST (ORBextractor.cc:811-818).  Scores left in the map by the first round are true S values,
     // so the second round needs no re-initialisation (a stored S <= threshold never suppresses a corner).
@@ -261,29 +270,29 @@ __global__ __launch_bounds__(256) void k_fast(const GfoGeom* __restrict__ gp, Gf
     {
         const uint32_t* t32 = reinterpret_cast<const uint32_t*>(tile);
         const int tp4 = TP >> 2;
-        const int X0 = xoff + 3;                       // tile column of scan pixel 0
-        const int q_lo = X0 >> 2, q_hi = (X0 + sw - 1) >> 2;
-        const int nq = q_hi - q_lo + 1;
+        // scan pixel 0 is tile column 4: the row's dwords 1 .. nq hold the scan pixels, only the last one may run past them
+        const int nq = (sw + 3) >> 2;
         // lane -> (row lr of the iteration, dword lq of the row), fixed for the cell: 64 / nq rows per iteration,
         // so the loop body has no index arithmetic beyond one add
-        const int rpi = 64 / nq;                       // nq <= 18 (cells up to 64 px)
+        const int rpi = 64 / nq;                       // nq <= 16 (cells up to 64 px)
         const int lr = (int)(((float)lane + 0.5f) * (1.0f / (float)nq));
         const int lq = lane - lr * nq;
         const bool lane_on = lr < rpi;
-        const int q = q_lo + lq;
-        const int c0 = 4 * q - X0;                     // scan column of pixel 0 of the dword (may be negative)
+        const int c0 = 4 * lq;                         // scan column of pixel 0 of the dword
+        // A pixel right of scan column sw-1 (last dword of a row) must not pass: its threshold is 0x7FFF, which no difference
+        // exceeds -- validity costs nothing inside the loop.  Packed per pixel pair: (pixel 0, pixel 2) and (pixel 1, pixel 3).
         const unsigned tq2 = (unsigned)tq | ((unsigned)tq << 16);
-        const unsigned valid_lo = (0xFu << (X0 & 3)) & 0xFu;                 // first dword: pixels left of scan column 0 drop out
-        const unsigned valid_hi = 0xFu >> (3 - ((X0 + sw - 1) & 3));        // last dword: pixels right of scan column sw-1
-        // only the first and the last dword of a row can hold pixels outside the scan columns
-        const unsigned valid = (q == q_lo ? valid_lo : 0xFu) & (q == q_hi ? valid_hi : 0xFu);
-        // the same four bits at the positions the compass test leaves its results in (14, 15, 30, 31)
-        const unsigned valid_sign = ((valid & 3u) << 14) | ((valid & 12u) << 28);
-        int idx = (lr + 3) * tp4 + q;
-        for (int y0 = 0; y0 < sh; y0 += rpi, idx += rpi * tp4) {
-            const int py = y0 + lr;
-            unsigned sign = 0;      // pixel0 -> bit 14, pixel1 -> bit 15, pixel2 -> bit 30, pixel3 -> bit 31: the pixel passes
-            if (lane_on && py < sh) {
+        const int nv = sw - c0;                        // valid pixels of this lane's dword (>= 4: all)
+        const unsigned tq_e = (nv > 0 ? (unsigned)tq : 0x7FFFu) | ((nv > 2 ? (unsigned)tq : 0x7FFFu) << 16);
+        const unsigned tq_o = (nv > 1 ? (unsigned)tq : 0x7FFFu) | ((nv > 3 ? (unsigned)tq : 0x7FFFu) << 16);
+        (void)tq2;
+        int idx = (lr + 3) * tp4 + 1 + lq;
+        int p0 = (lr << 6) + c0;                       // queue entry of the dword's pixel 0: px | py << 6 (cells are at most 64 px wide)
+        for (int y0 = 0; y0 < sh; y0 += rpi, idx += rpi * tp4, p0 += rpi << 6) {
+            // the pass bits stay where the packed arithmetic leaves them: the sign bits of the two halves of t_e (pixels 0, 2)
+            // and of t_o (pixels 1, 3) -- round 2 gathered them into one word first (mask, shift, or, mask: six operations)
+            unsigned t_e = 0, t_o = 0;
+            if (lane_on && lr < sh - y0) {
                 const unsigned C = t32[idx], Wm = t32[idx - 1], Wp = t32[idx + 1];
                 const unsigned U = t32[idx + 3 * tp4], D = t32[idx - 3 * tp4];
                 const unsigned Lw = __builtin_amdgcn_alignbyte(C, Wm, 1);   // pixels at column-3
@@ -302,26 +311,23 @@ __global__ __launch_bounds__(256) void k_fast(const GfoGeom* __restrict__ gp, Gf
                     // both pairs hold a brighter one  <=>  min(max(U, D), max(R, L)) - v > t   (12 packed ops per pixel pair)
                     const s16x2 dk = vc - __builtin_elementwise_max(__builtin_elementwise_min(pu, pd), __builtin_elementwise_min(pr, pl));
                     const s16x2 br = __builtin_elementwise_min(__builtin_elementwise_max(pu, pd), __builtin_elementwise_max(pr, pl)) - vc;
-                    // sign bit set <=> max(dk, br) > tq
-                    const s16x2 t1 = __builtin_bit_cast(s16x2, tq2) - __builtin_elementwise_max(dk, br);
-                    const unsigned sg = __builtin_bit_cast(unsigned, t1) & 0x80008000u;
-                    sign |= sg >> (h ? 0 : 1);  // h=0 -> bits 14,30 ; h=1 -> bits 15,31
+                    // sign bit set <=> max(dk, br) > threshold
+                    const unsigned t1 = __builtin_bit_cast(unsigned, __builtin_bit_cast(s16x2, h ? tq_o : tq_e) - __builtin_elementwise_max(dk, br));
+                    if (h) t_o = t1; else t_e = t1;
                 }
-                sign &= valid_sign;   // pixels of the first / last dword that lie outside the scan columns
             }
             // (measured alternative: gathering the pass bits of all iterations per lane and letting every lane pop its
             //  lowest set bit per round -- survivors cluster, the busiest lane holds 8-12 of them, and the rounds cost
             //  more than these four ballots per iteration: 386 vs 373 vector instructions per cell for stage A)
-            const int p0 = (py << 6) + c0;   // queue entry: px | py << 6 (cells are at most 64 px wide)
-            // The four pass bits are tested where they are -- bits 31 and 15 are the sign bits of the word and of its low half,
-            // bits 30 and 14 those of the word shifted left by one: four compares instead of compressing them into a nibble
-            // and extracting them again.  The slot is the count of passing lanes below this one (v_mbcnt) behind a queue
-            // pointer that advances in a scalar register.
-            const unsigned sign1 = sign << 1;
+            // Four compares on the sign bits of the words and of their low halves (the 16-bit compare is written out: the
+            // compiler turns the C form into a bit-field extract and a compare).  The slot is the count of passing lanes
+            // below this one (v_mbcnt) behind a queue pointer that advances in a scalar register.
 #pragma unroll
             for (int j = 0; j < 4; j++) {
-                const bool pass = j == 3 ? (int)sign < 0 : j == 1 ? (short)(sign & 0xFFFFu) < 0 : j == 2 ? (int)sign1 < 0 : (short)(sign1 & 0xFFFFu) < 0;
-                const unsigned long long m = __builtin_amdgcn_ballot_w64(pass);
+                const unsigned tw = (j & 1) ? t_o : t_e;
+                unsigned long long m;
+                if (j & 2) m = __builtin_amdgcn_ballot_w64((int)tw < 0);
+                else asm("v_cmp_gt_i16_e64 %0, 0, %1" : "=s"(m) : "v"(tw));
                 unsigned short* qj = qa + na;
                 if (__builtin_amdgcn_inverse_ballot_w64(m)) qj[__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u))] = (unsigned short)(p0 + j);
                 na += __popcll(m);
@@ -336,17 +342,22 @@ __global__ __launch_bounds__(256) void k_fast(const GfoGeom* __restrict__ gp, Gf
     //         are compacted into qb ----
     nb = 0;
     {
-        for (int i0 = 0; i0 < na; i0 += 64) {
-            const int i = i0 + lane;
-            int p = 0, sc = 0;
-            if (i < na) p = qa[i];
+        const unsigned short* qr = qa + lane;
+        for (int i0 = 0; i0 < na; i0 += 64, qr += 64) {
+            // which lanes hold a queue entry is known to the scalar unit
+            const int rem = na - i0;
+            const unsigned long long m_in = rem >= 64 ? ~0ull : (1ull << rem) - 1ull;
+            int p = 0;
+            if (__builtin_amdgcn_inverse_ballot_w64(m_in)) p = *qr;
             const int py = p >> 6, px = p & 63;
-            sc = corner_score<TP>(t0 + py * TP + px, tq);   // every lane (idle ones re-score entry 0's pixel: wave votes inside)
-            const bool corner = i < na && sc > tq;
-            if (corner) smap[(py + 1) * SP + px + 1] = (uint8_t)sc;
-            const unsigned long long m = __builtin_amdgcn_ballot_w64(corner);   // (the mask itself: __ballot goes through a 0 / 1 integer)
-            if (__builtin_amdgcn_inverse_ballot_w64(m))
-                qb[__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, (unsigned)nb))] = (unsigned short)p;
+            unsigned long long m_run;
+            const int sc = corner_score<TP>(tile + py * TP + px, tq, m_run);   // every lane (idle ones re-score pixel 0: wave votes inside)
+            const unsigned long long m = __builtin_amdgcn_ballot_w64(sc > tq) & m_in & m_run;   // corners
+            unsigned short* qw = qb + nb;
+            if (__builtin_amdgcn_inverse_ballot_w64(m)) {
+                smap[(py + 1) * SP + px + 1] = (uint8_t)sc;
+                qw[__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u))] = (unsigned short)p;
+            }
             nb += __popcll(m);
         }
     }
@@ -361,24 +372,24 @@ __global__ __launch_bounds__(256) void k_fast(const GfoGeom* __restrict__ gp, Gf
     //         untouched for the second round) ----
     int n_max = 0;
     uint32_t* keyq = reinterpret_cast<uint32_t*>(tile);
-    for (int i0 = 0; i0 < nb; i0 += 64) {
-        const int i = i0 + lane;
-        bool mx = false;
-        uint32_t key = 0;
-        if (i < nb) {
-            const int p = qb[i];
-            const int py = p >> 6, px = p & 63;
-            const uint8_t* q = smap + (py + 1) * SP + px + 1;
-            const int s = q[0];
-            const int nmax = max(max(max(max((int)q[-1], (int)q[1]), max((int)q[-SP - 1], (int)q[-SP])),
-                                     max(max((int)q[-SP + 1], (int)q[SP - 1]), max((int)q[SP], (int)q[SP + 1]))), tq);
-            mx = s > nmax;   // strictly above the eight neighbours and above the threshold (S >= 2 follows: tq >= 1)
-            const int x = px + 3 + cj * wcell, y = py + 3 + ci * hcell;  // ORBextractor.cc:824-825
-            key = (uint32_t)x | ((uint32_t)y << 12) | ((uint32_t)(s - 1) << 24);
-        }
-        const unsigned long long m = __builtin_amdgcn_ballot_w64(mx);
-        if (__builtin_amdgcn_inverse_ballot_w64(m))
-            keyq[__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, (unsigned)n_max))] = key;
+    const unsigned short* qn = qb + lane;
+    for (int i0 = 0; i0 < nb; i0 += 64, qn += 64) {
+        const int rem = nb - i0;
+        const unsigned long long m_in = rem >= 64 ? ~0ull : (1ull << rem) - 1ull;
+        int p = 0;
+        if (__builtin_amdgcn_inverse_ballot_w64(m_in)) p = *qn;
+        // every lane (idle ones look at pixel 0): no branch around the body, the vote is masked in the scalar unit
+        const int py = p >> 6, px = p & 63;
+        const uint8_t* q = smap + (py + 1) * SP + px + 1;
+        const int s = q[0];
+        const int nmax = max(max(max(max((int)q[-1], (int)q[1]), max((int)q[-SP - 1], (int)q[-SP])),
+                                 max(max((int)q[-SP + 1], (int)q[SP - 1]), max((int)q[SP], (int)q[SP + 1]))), tq);
+        // strictly above the eight neighbours and above the threshold (S >= 2 follows: tq >= 1)
+        const unsigned long long m = __builtin_amdgcn_ballot_w64(s > nmax) & m_in;
+        const int x = px + 3 + cj * wcell, y = py + 3 + ci * hcell;  // ORBextractor.cc:824-825
+        const uint32_t key = (uint32_t)x | ((uint32_t)y << 12) | ((uint32_t)(s - 1) << 24);
+        uint32_t* kw = keyq + n_max;
+        if (__builtin_amdgcn_inverse_ballot_w64(m)) kw[__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u))] = key;
         n_max += __popcll(m);
     }
     wave_sync();
