@@ -422,10 +422,34 @@ int gfo_plan(gfo_ctx* c, int w, int h, int batch)
     HIP_TRY(c, hipMalloc(&c->d_xofs, xtabv.size() * sizeof(int) + 64));
     HIP_TRY(c, hipMalloc(&c->d_yofs, ytabv.size() * sizeof(int) + 64));
     {
-        std::vector<int> cells((size_t)g.total_cells + 4, 0);
+        // FAST cell table, four ints per cell: {level | row << 4 | column << 16, tile-load map, stage-A map, 0}.  The two maps
+        // are the lane -> (row, column) decompositions k_fast uses, which depend on the cell's clipped size only: dividing a
+        // lane index by a wave-uniform count costs a wave ~25 vector instructions (no scalar division, no scalar float unit),
+        // a multiplication by ceil(4096 / n) and a shift cost two (exact for lanes 0..63 and n <= 16, checked below).
+        //   map = n | (64 / n) << 5 | ceil(4096 / n) << 12      n = 16-byte segments per tile row / dwords per scan row
+        std::vector<int> cells(4 * ((size_t)g.total_cells + 4), 0);
+        auto lane_map = [&](int n) -> int {
+            if (n < 1 || n > 16) return 0;   // (cells beyond 64 px are refused above)
+            const int m = (4096 + n - 1) / n;
+            for (int lane = 0; lane < 64; lane++)
+                if (((lane * m) >> 12) != lane / n) return 0;
+            return n | ((64 / n) << 5) | (m << 12);
+        };
         for (int l = 0; l < g.nlevels; l++)
             for (int i = 0; i < g.lv[l].nrows; i++)
-                for (int j = 0; j < g.lv[l].ncols; j++) cells[(size_t)g.lv[l].cell_base + i * g.lv[l].ncols + j] = l | (i << 4) | (j << 16);
+                for (int j = 0; j < g.lv[l].ncols; j++) {
+                    const GfoLevel& L = g.lv[l];
+                    const int iniX = GFO_MIN_BORDER + j * L.wcell;
+                    const int maxX = iniX + L.wcell + 6 < L.max_bx ? iniX + L.wcell + 6 : L.max_bx;
+                    const int cw = maxX - iniX;          // as k_fast computes it (a cell with cw <= 6 is skipped there)
+                    int* e = &cells[4 * ((size_t)L.cell_base + i * L.ncols + j)];
+                    e[0] = l | (i << 4) | (j << 16);
+                    if (cw > 6) {
+                        e[1] = lane_map((GFO_FAST_XOFF + cw + 15) >> 4);
+                        e[2] = lane_map((cw - 6 + 3) >> 2);
+                        if (!e[1] || !e[2]) return fail(c, GFO_ERR_INVALID, "FAST cell of %d px exceeds the per-wave plan", cw - 6);
+                    }
+                }
         HIP_TRY(c, hipMalloc(&c->d_cell_tab, cells.size() * sizeof(int)));
         HIP_TRY(c, hipMemcpy(c->d_cell_tab, cells.data(), cells.size() * sizeof(int), hipMemcpyHostToDevice));
     }

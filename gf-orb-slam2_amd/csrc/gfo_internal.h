@@ -15,6 +15,7 @@
 #define GFO_HALF_PATCH 15    // HALF_PATCH_SIZE, ORBextractor.cc:73
 #define GFO_PATCH 31         // PATCH_SIZE, ORBextractor.cc:72
 #define GFO_MIN_BORDER 16    // EDGE_THRESHOLD-3, ORBextractor.cc:775
+#define GFO_FAST_XOFF 1       // k_fast: the LDS tile starts this many bytes left of the cell (scan column 0 at tile column 4)
 #define GFO_CELL_W 30        // W, ORBextractor.cc:771
 #define GFO_CNT_STRIDE 32     // ints between per-(image,level) candidate counters: one 128-B line each,
                              // so the per-cell atomicAdds of different levels/images never share a line
@@ -192,7 +193,7 @@ struct gfo_ctx {
     uint8_t* d_qt_scratch = nullptr;   // quadtree state in HBM, only when a level's state exceeds LDS
     size_t qt_scratch_stride = 0;      // bytes per (image, level) workgroup
     size_t qt_lds_granted = 0;         // dynamic LDS limit already raised for k_quadtree on this context's device
-    int* d_cell_tab = nullptr;    // FAST: cell -> level | row << 4 | column << 16
+    int* d_cell_tab = nullptr;    // FAST: four ints per cell: level | row << 4 | column << 16, the two lane maps (plan())
     int* d_band = nullptr;        // per group: int4 [nb][nlevels] = {c0, c1, o0, o1}
     GfoBandGroup band_groups[GFO_MAX_LEVELS];   // nb == 0: a single level launched as k_resize
     int n_band_groups = 0, band_threads = 0;

@@ -50,8 +50,6 @@ __device__ __forceinline__ void wave_sync()
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-#define FAST_XOFF 1   // the tile starts this many bytes left of the cell: scan column 0 at tile column 4 (k_fast, tile load)
-
 typedef short __attribute__((ext_vector_type(2))) s16x2;
 __device__ __forceinline__ unsigned pmin(unsigned a, unsigned b)
 {
@@ -87,7 +85,7 @@ __device__ __forceinline__ int corner_score(const uint8_t* __restrict__ tl, int 
 {
     // LDS offsets are unsigned immediates: the ring is addressed from `tl`, one byte left of its top-left corner (so that the
     // caller's address is tile + py * TP + px, nothing added), the centre sits RB bytes further
-    constexpr int RB = 3 * TP + 3 + FAST_XOFF;
+    constexpr int RB = 3 * TP + 3 + GFO_FAST_XOFF;
     const unsigned v = tl[RB];
     const unsigned v2 = v | (v << 16);
     // ring words Q[k] = (r[k], r[k+8]).  (ds_read_u8_d16 / _d16_hi would deliver the pair packed, but with SRAM ECC on -- as
@@ -190,7 +188,10 @@ __global__ __launch_bounds__(256) void k_fast(const GfoGeom* __restrict__ gp, Gf
     if (cell >= g.total_cells) return;
     // cell -> (level, row, column) through the table plan() uploads: one scalar load instead of a search over the
     // level prefix table and an integer division
-    const int ce = __builtin_amdgcn_readfirstlane(cell_tab[cell]);
+    const int4 ct = reinterpret_cast<const int4*>(cell_tab)[cell];
+    const int ce = __builtin_amdgcn_readfirstlane(ct.x);
+    // lane -> (row, column) maps of the tile load and of stage A: n | (64 / n) << 5 | ceil(4096 / n) << 12, from plan()
+    const int map_ld = __builtin_amdgcn_readfirstlane(ct.y), map_a = __builtin_amdgcn_readfirstlane(ct.z);
     const int level = ce & 15, ci = (ce >> 4) & 0xFFF, cj = ce >> 16;
     const GfoLevel& L = g.lv[level];
     const int wcell = L.wcell, hcell = L.hcell;
@@ -206,31 +207,31 @@ __global__ __launch_bounds__(256) void k_fast(const GfoGeom* __restrict__ gp, Gf
     // columns began at byte 1 or 3 of a dword, 9 dwords per row, 7 rows per pass, five passes -- 5.05 on average at 752x480,
     // 4.16 now.)  The price is global loads at odd addresses, which the memory pipeline takes: the 16-byte loads below are
     // declared unaligned.
-    constexpr int xoff = FAST_XOFF;
+    constexpr int xoff = GFO_FAST_XOFF;
     struct __attribute__((packed)) seg16 { uint32_t a, b, c, d; };
     {
         int pitch;
         const uint8_t* src = gfo_level_ptr(g, in, pyr, level, img, &pitch);
-        src += (long long)iniY * pitch + (iniX - xoff);
+        src += (long long)iniY * pitch + (iniX - xoff);   // wave-uniform: the loads below are scalar base + 32-bit lane offset
         // 16-byte row segments: TP is a multiple of 16, every lane issues its (<= 4) wide loads before the
         // first LDS store; the segment right of the cell may run a few bytes past maxX but stays inside the
         // image row (maxX <= w - 16)
-        const int spr = (xoff + cw + 15) >> 4;  // 16-byte segments per tile row (3 for a 30-px cell, at most 5)
-        // fixed lane -> (row of the step, segment) map: 64 / spr rows per step, so a load is a pointer increment
+        const int spr = map_ld & 31;  // 16-byte segments per tile row (3 for a 30-px cell, at most 5)
+        // fixed lane -> (row of the step, segment) map: 64 / spr rows per step, so a load is an offset increment
         // (two steps for a 30-px cell); all loads of a lane are issued before its first LDS store
-        const int rps = 64 / spr;
-        const int lr = (int)(((float)lane + 0.5f) * (1.0f / (float)spr));
+        const int rps = (map_ld >> 5) & 127;
+        const int lr = (lane * (map_ld >> 12)) >> 12;      // lane / spr
         const int lc = lane - lr * spr;
         const bool ld_on = lr < rps;
-        const uint8_t* lp = src + (long long)min(lr, ch - 1) * pitch + 16 * lc;
-        uint4* t128 = reinterpret_cast<uint4*>(tile) + lr * (TP >> 4) + lc;
-        const long long gstep = (long long)rps * pitch;
-        const int lstep = rps * (TP >> 4);
         // rows past the cell's last one are clamped to it (loaded, not stored)
-        const uint8_t* p_last = lp + (long long)(ch - 1 - min(lr, ch - 1)) * pitch;
+        const unsigned o_last = (unsigned)((ch - 1) * pitch + 16 * lc);
+        const unsigned o_first = (unsigned)(min(lr, ch - 1) * pitch + 16 * lc);
+        const unsigned gstep = (unsigned)(rps * pitch);
+        uint4* t128 = reinterpret_cast<uint4*>(tile) + lr * (TP >> 4) + lc;
+        const int lstep = rps * (TP >> 4);
         if (2 * rps >= ch) {   // the usual cell: two steps, no per-step bookkeeping (wave-uniform branch)
-            const seg16 sa = *reinterpret_cast<const seg16*>(lr < ch ? lp : p_last);
-            const seg16 sb = *reinterpret_cast<const seg16*>(rps + lr < ch ? lp + gstep : p_last);
+            const seg16 sa = *reinterpret_cast<const seg16*>(src + o_first);
+            const seg16 sb = *reinterpret_cast<const seg16*>(src + (rps + lr < ch ? o_first + gstep : o_last));
             const uint4 va = make_uint4(sa.a, sa.b, sa.c, sa.d), vb = make_uint4(sb.a, sb.b, sb.c, sb.d);
             if (ld_on && lr < ch) t128[0] = va;
             if (ld_on && rps + lr < ch) t128[lstep] = vb;
@@ -239,7 +240,7 @@ __global__ __launch_bounds__(256) void k_fast(const GfoGeom* __restrict__ gp, Gf
 #pragma unroll
             for (int k = 0; k < 6; k++) {
                 if (k * rps < ch) {   // wave-uniform
-                    const seg16 sk = *reinterpret_cast<const seg16*>(k * rps + lr < ch ? lp + k * gstep : p_last);
+                    const seg16 sk = *reinterpret_cast<const seg16*>(src + (k * rps + lr < ch ? o_first + k * gstep : o_last));
                     v[k] = make_uint4(sk.a, sk.b, sk.c, sk.d);
                 }
             }
@@ -271,11 +272,11 @@ __global__ __launch_bounds__(256) void k_fast(const GfoGeom* __restrict__ gp, Gf
         const uint32_t* t32 = reinterpret_cast<const uint32_t*>(tile);
         const int tp4 = TP >> 2;
         // scan pixel 0 is tile column 4: the row's dwords 1 .. nq hold the scan pixels, only the last one may run past them
-        const int nq = (sw + 3) >> 2;
+        const int nq = map_a & 31;                     // (sw + 3) >> 2
         // lane -> (row lr of the iteration, dword lq of the row), fixed for the cell: 64 / nq rows per iteration,
         // so the loop body has no index arithmetic beyond one add
-        const int rpi = 64 / nq;                       // nq <= 16 (cells up to 64 px)
-        const int lr = (int)(((float)lane + 0.5f) * (1.0f / (float)nq));
+        const int rpi = (map_a >> 5) & 127;            // 64 / nq; nq <= 16 (cells up to 64 px)
+        const int lr = (lane * (map_a >> 12)) >> 12;   // lane / nq
         const int lq = lane - lr * nq;
         const bool lane_on = lr < rpi;
         const int c0 = 4 * lq;                         // scan column of pixel 0 of the dword
