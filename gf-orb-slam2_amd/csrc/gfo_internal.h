@@ -194,6 +194,8 @@ struct gfo_ctx {
     size_t qt_scratch_stride = 0;      // bytes per (image, level) workgroup
     size_t qt_lds_granted = 0;         // dynamic LDS limit already raised for k_quadtree on this context's device
     int* d_cell_tab = nullptr;    // FAST: four ints per cell: level | row << 4 | column << 16, the two lane maps (plan())
+    int* d_od_tab = nullptr;      // k_orient_desc: level | pair << 4 per wavefront of an image (inside d_cell_tab's allocation)
+    int od_pairs = 0;             // its length
     int* d_band = nullptr;        // per group: int4 [nb][nlevels] = {c0, c1, o0, o1}
     GfoBandGroup band_groups[GFO_MAX_LEVELS];   // nb == 0: a single level launched as k_resize
     int n_band_groups = 0, band_threads = 0;

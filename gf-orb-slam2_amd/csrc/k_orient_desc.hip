@@ -49,8 +49,8 @@ __global__ __launch_bounds__(64 * OD_WAVES) void k_orient_desc(const GfoGeom* __
                                                      const uint8_t* __restrict__ pyr, const uint8_t* __restrict__ blur,
                                                      const uint32_t* __restrict__ sel, const int* __restrict__ sel_cnt,
                                                      gfo_keypoint* __restrict__ kp_out, uint8_t* __restrict__ desc_out,
-                                                     int* __restrict__ kp_cnt, int* __restrict__ flags, int nimg,
-                                                     int blocks_per_img)
+                                                     int* __restrict__ kp_cnt, int* __restrict__ flags, const int* __restrict__ od_tab,
+                                                     int nimg)
 {
     // ONE LDS region per keypoint, used twice: first the 31-row patch (angle), then -- once the angle's reads are done --
     // the 37-row window, whose bytes wait in registers meanwhile.  14 KB per workgroup instead of 26 KB: LDS no longer
@@ -76,32 +76,35 @@ __global__ __launch_bounds__(64 * OD_WAVES) void k_orient_desc(const GfoGeom* __
 #else
     const int img = nimg - 1 - img_fwd;
 #endif
-    // per-level counts (wave-uniform): a slot's level follows from their prefix; output rows are level by
-    // level, list order inside a level (:1144-1161)
-    int total = 0;
+    // A wave owns the selection slots (2 * pair, 2 * pair + 1) of ONE level (table of plan(): level | pair << 4), so the
+    // level and everything derived from it -- plane pointers, pitch, scale, the output row of slot 0 -- live in scalar
+    // registers.  (Round 2 walked the compacted output rows and let each half of the wave search its level in the count
+    // prefix: 8 levels x 4 selects per wave, and every address 64-bit per lane.)
+    const int pe = __builtin_amdgcn_readfirstlane(od_tab[blk * OD_WAVES + wave]);
+    const int level = pe & 15, pair = pe >> 4;
+    // per-level counts (wave-uniform); output rows are level by level, list order inside a level (:1144-1161)
     // (counts are clamped to the slots a level owns: a selection that was never written cannot send this kernel
     //  outside its buffers)
-    for (int l = 0; l < g.nlevels; l++) total += min(max(sel_cnt[img * g.nlevels + l], 0), g.lv[l].sel_cap);
+    int total = 0, prefix = 0, cnt = 0;
+    for (int l = 0; l < g.nlevels; l++) {
+        const int c = min(max(sel_cnt[img * g.nlevels + l], 0), g.lv[l].sel_cap);
+        prefix += l < level ? c : 0;
+        cnt = l == level ? c : cnt;
+        total += c;
+    }
     if (blk == 0 && wave == 0 && lane == 0) {
         kp_cnt[img] = min(total, g.kp_stride);
         if (total > g.kp_stride) atomicOr(&flags[0], 8);
     }
     const int nkp = min(total, g.kp_stride);
-    const int slot0 = (blk * OD_WAVES + wave) * 2;
-    if (slot0 >= nkp) return;                      // wave-uniform
-    const bool act = slot0 + half < nkp;           // the second half may run past the end: it redoes the last keypoint
-    const int slot = min(slot0 + half, nkp - 1);
-    int level = 0, idx = slot, acc = 0;
-    for (int l = 0; l < g.nlevels; l++) {
-        const int c = min(max(sel_cnt[img * g.nlevels + l], 0), g.lv[l].sel_cap);
-        if (slot >= acc && slot < acc + c) {
-            level = l;
-            idx = slot - acc;
-        }
-        acc += c;
-    }
+    const int i0 = 2 * pair;
+    if (pe < 0 || i0 >= cnt || prefix + i0 >= nkp) return;   // wave-uniform
+    const bool act = i0 + half < cnt && prefix + i0 + half < nkp;   // an odd count leaves the last wave's second half idle: it redoes the first keypoint
+    const unsigned idx = act ? i0 + half : i0;
+    const int slot = prefix + (int)idx;
     const GfoLevel& L = g.lv[level];
-    const uint32_t key = sel[(long long)img * g.total_sel_cap + L.sel_off + idx];
+    const uint32_t* selb = sel + (long long)img * g.total_sel_cap + L.sel_off;   // uniform base, 32-bit lane offset
+    const uint32_t key = selb[idx];
     const int x = (int)(key & 0xFFF) + GFO_MIN_BORDER, y = (int)((key >> 12) & 0xFFF) + GFO_MIN_BORDER;  // :845-846
     const int score = (int)(key >> 24);
 
@@ -109,17 +112,18 @@ __global__ __launch_bounds__(64 * OD_WAVES) void k_orient_desc(const GfoGeom* __
     // A row of either window is three 16-byte segments from the aligned dword left of it (31 + 3 and 37 + 3
     // bytes fit in 48; the bytes past the window belong to the same row or, at the right image border, to the
     // next row, which exists because keypoints keep 19 px from every edge).  The lane -> (row, segment) map is
-    // fixed -- 10 rows x 3 segments per step -- so a load or store costs a pointer increment, not an index
+    // fixed -- 10 rows x 3 segments per step -- so a load or store costs an offset increment, not an index
     // decomposition.
     int pitch;
-    const uint8_t* lv = gfo_level_ptr(g, in, pyr, level, img, &pitch);
+    const uint8_t* lv = gfo_level_ptr(g, in, pyr, level, img, &pitch);   // wave-uniform
+    const uint8_t* bl = blur + (long long)img * g.blur_img_stride + L.blur_off;
     const int ox_al = (x - GFO_HALF_PATCH) & ~3, ooff = (x - GFO_HALF_PATCH) - ox_al;
     const int wx_al = (x - 18) & ~3, woff = (x - 18) - wx_al;
     const int lpitch = L.pitch;
     const int rw = (hl * 11) >> 5, seg = hl - 3 * rw;   // hl / 3, hl % 3 for hl < 32; rw == 10: idle lanes
     const bool ld_on = rw < 10;
-    const uint8_t* psrc = lv + (long long)(y - GFO_HALF_PATCH + rw) * pitch + (ox_al + 16 * seg);
-    const uint8_t* wsrc = blur + (long long)img * g.blur_img_stride + L.blur_off + (long long)(y - 18 + rw) * lpitch + (wx_al + 16 * seg);
+    const unsigned po = (unsigned)((y - GFO_HALF_PATCH) * pitch + ox_al + 16 * seg);     // row 0 of the patch, this lane's segment
+    const unsigned wo = (unsigned)((y - 18) * lpitch + wx_al + 16 * seg);                // row 0 of the window
     uint8_t* win = s_win[wave * 2 + half];
     uint8_t* pat = win;   // same bytes, earlier in time
     uint4 vw0, vw1, vw2, vw3;   // the window's bytes, in registers until the patch has been consumed
@@ -128,12 +132,12 @@ __global__ __launch_bounds__(64 * OD_WAVES) void k_orient_desc(const GfoGeom* __
 #pragma unroll
         for (int k = 0; k < OD_STEPS; k++) {
             const int rp = min(10 * k + rw, OW - 1);   // clamped: idle lanes re-read a valid row
-            vp[k] = *reinterpret_cast<const uint4*>(psrc + (long long)(rp - rw) * pitch);
+            vp[k] = *reinterpret_cast<const uint4*>(lv + (po + (unsigned)(rp * pitch)));
         }
-        vw0 = *reinterpret_cast<const uint4*>(wsrc);
-        vw1 = *reinterpret_cast<const uint4*>(wsrc + (long long)(min(10 + rw, DW - 1) - rw) * lpitch);
-        vw2 = *reinterpret_cast<const uint4*>(wsrc + (long long)(min(20 + rw, DW - 1) - rw) * lpitch);
-        vw3 = *reinterpret_cast<const uint4*>(wsrc + (long long)(min(30 + rw, DW - 1) - rw) * lpitch);
+        vw0 = *reinterpret_cast<const uint4*>(bl + (wo + (unsigned)(rw * lpitch)));
+        vw1 = *reinterpret_cast<const uint4*>(bl + (wo + (unsigned)(min(10 + rw, DW - 1) * lpitch)));
+        vw2 = *reinterpret_cast<const uint4*>(bl + (wo + (unsigned)(min(20 + rw, DW - 1) * lpitch)));
+        vw3 = *reinterpret_cast<const uint4*>(bl + (wo + (unsigned)(min(30 + rw, DW - 1) * lpitch)));
         uint4* pl = reinterpret_cast<uint4*>(pat + rw * OWP + 16 * seg);
         // steps 0-2 store unconditionally: every row they touch exists, and the two idle lanes (rw == 10) hold
         // exactly the bytes that lane rw == 0 of the next step writes to the same place; only the last step is
@@ -198,7 +202,7 @@ __global__ __launch_bounds__(64 * OD_WAVES) void k_orient_desc(const GfoGeom* __
     // more operations per coordinate)
     const float magic = 12582912.0f;
     const unsigned wbase = (unsigned)(18 * DWP + woff + 18) - 0x4B400000u * (unsigned)(DWP + 1);   // mod 2^32
-    unsigned word = 0;
+    unsigned long long mk[8];
 #pragma unroll
     for (int r = 0; r < 8; r++) {
         const PatQuad p = k_pattern[r * 32 + hl];
@@ -209,8 +213,23 @@ __global__ __launch_bounds__(64 * OD_WAVES) void k_orient_desc(const GfoGeom* __
         const unsigned iy0 = __float_as_uint(fy.x), ix0 = __float_as_uint(fx.x), iy1 = __float_as_uint(fy.y), ix1 = __float_as_uint(fx.y);
         const int t0 = win[iy0 * (unsigned)DWP + ix0 + wbase], t1 = win[iy1 * (unsigned)DWP + ix1 + wbase];   // u32 arithmetic: the biases cancel
         const unsigned long long m = __builtin_amdgcn_ballot_w64(t0 < t1);
-        word = hl == r ? (unsigned)(m >> (32 * half)) : word;  // tests 32r..32r+31 of THIS half's keypoint
+        mk[r] = m;
     }
+    // Tests 32r..32r+31 of each half's keypoint go to lane r of that half: sixteen v_writelane from the scalar masks, after
+    // the last round (as a per-lane select of a 64-bit shift of the mask this cost five vector instructions a round).  The
+    // instructions are written out (this compiler has no builtin for them), so the hazard between a vector compare that
+    // writes a scalar register and a v_writelane that reads it is this code's to keep: the wait states stand in front.
+    unsigned word = 0;
+    asm volatile("s_nop 4\n\t"
+                 "v_writelane_b32 %0, %1, 0\n\tv_writelane_b32 %0, %2, 1\n\tv_writelane_b32 %0, %3, 2\n\tv_writelane_b32 %0, %4, 3\n\t"
+                 "v_writelane_b32 %0, %5, 4\n\tv_writelane_b32 %0, %6, 5\n\tv_writelane_b32 %0, %7, 6\n\tv_writelane_b32 %0, %8, 7\n\t"
+                 "v_writelane_b32 %0, %9, 32\n\tv_writelane_b32 %0, %10, 33\n\tv_writelane_b32 %0, %11, 34\n\tv_writelane_b32 %0, %12, 35\n\t"
+                 "v_writelane_b32 %0, %13, 36\n\tv_writelane_b32 %0, %14, 37\n\tv_writelane_b32 %0, %15, 38\n\tv_writelane_b32 %0, %16, 39"
+                 : "+v"(word)
+                 : "s"((unsigned)mk[0]), "s"((unsigned)mk[1]), "s"((unsigned)mk[2]), "s"((unsigned)mk[3]),
+                   "s"((unsigned)mk[4]), "s"((unsigned)mk[5]), "s"((unsigned)mk[6]), "s"((unsigned)mk[7]),
+                   "s"((unsigned)(mk[0] >> 32)), "s"((unsigned)(mk[1] >> 32)), "s"((unsigned)(mk[2] >> 32)), "s"((unsigned)(mk[3] >> 32)),
+                   "s"((unsigned)(mk[4] >> 32)), "s"((unsigned)(mk[5] >> 32)), "s"((unsigned)(mk[6] >> 32)), "s"((unsigned)(mk[7] >> 32)));
     if (!act) return;
     const long long o = (long long)img * g.kp_stride + slot;
     if (hl < 8) reinterpret_cast<unsigned*>(desc_out + o * 32)[hl] = word;
@@ -233,10 +252,10 @@ __global__ __launch_bounds__(64 * OD_WAVES) void k_orient_desc(const GfoGeom* __
 
 void gfo_launch_orient_desc(gfo_ctx* c, const GfoInput& in, int nimg)
 {
-    const int bpi = (c->g.kp_stride + 2 * OD_WAVES - 1) / (2 * OD_WAVES);  // OD_WAVES waves x 2 keypoints per workgroup
+    const int bpi = (c->od_pairs + OD_WAVES - 1) / OD_WAVES;  // OD_WAVES waves x 2 keypoints per workgroup (the table is padded with -1)
     dim3 grid((unsigned)bpi * 8u, (unsigned)(nimg + 7) / 8u);
     gfo_prof_begin(c, ST_ORIENT_DESC);
     GFO_LAUNCH(c, k_orient_desc, grid, dim3(64 * OD_WAVES), 0, c->stream, c->d_geom, in, c->d_pyr, c->d_blur, c->d_sel,
-                       c->d_sel_cnt, c->d_kp, c->d_desc, c->d_kp_cnt, c->d_flags, nimg, bpi);
+                       c->d_sel_cnt, c->d_kp, c->d_desc, c->d_kp_cnt, c->d_flags, c->d_od_tab, nimg);
     gfo_prof_end(c);
 }

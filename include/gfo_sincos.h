@@ -76,16 +76,13 @@ GFO_HD float gfo_fast_atan2f(float y, float x)
     const float p7 = -0.04432655554792128f * scale;
     const float eps = (float)2.2204460492503131e-016; /* (float)DBL_EPSILON */
     const float ax = fabsf(x), ay = fabsf(y);
-    float a, c, c2;
-    if (ax >= ay) {
-        c = ay / (ax + eps);
-        c2 = c * c;
-        a = (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
-    } else {
-        c = ax / (ay + eps);
-        c2 = c * c;
-        a = 90.f - (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
-    }
+    /* the smaller over the larger magnitude: one division serves both octant cases (the operands and the operations are those
+     * of the two-branch form, so are the bits) */
+    const int steep = !(ax >= ay);
+    const float c = (steep ? ax : ay) / ((steep ? ay : ax) + eps);
+    const float c2 = c * c;
+    const float pa = (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
+    float a = steep ? 90.f - pa : pa;
     if (x < 0) a = 180.f - a;
     if (y < 0) a = 360.f - a;
     return a;
