@@ -17,6 +17,12 @@
 // No workgroup barrier is used: each wave owns its LDS window (LDS operations of one wave
 // execute in issue order), so trailing waves may exit early.
 #include "gfo_internal.h"
+// The double-precision coefficients of gfo_sincosf come from a table in memory (scalar loads into register pairs that the
+// fma takes directly) instead of 64-bit literals, each of which is two v_mov per wave: 15 constants, 24 vector instructions.
+// Not const on purpose: a const table's loads fold back into the literals.
+#include "../../include/gfo_sincos_coef.h"
+__device__ double k_sincos_coef[GFO_SINCOS_NCOEF] = {GFO_SINCOS_COEF_LIST};
+#define GFO_SINCOS_TABLE k_sincos_coef
 #include "../../include/gfo_sincos.h"
 
 // the 256 test pairs as floats (one 16-byte load per lane and round, no integer -> float conversion in the loop)
@@ -34,13 +40,48 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 __device__ const PatQuad k_pattern[256] = {
 #include "../../include/gfo_pattern.inc"
 };
-__device__ const int k_umax[16] = {15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3};  // ORBextractor.cc:451-468
+// ORBextractor.cc:451-468: umax[|v|], the half-width of the orientation disc in row v
+#define GFO_UMAX_LIST 15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3
+// Row weights of the disc for v_dot4_u32_u8: row r = v + 15 (r = 31: an idle lane's all-zero row) as 32 bytes for the columns
+// u = -15 .. 16, first the moment weights (u + 16 inside the disc, 0 outside: unsigned, the bias comes off as 16 * the row
+// sum), then the membership bytes (1 / 0) -- eight dwords each.
+struct AngleRows {
+    uint32_t w[32][16];
+    constexpr AngleRows() : w()
+    {
+        const int umax[16] = {GFO_UMAX_LIST};
+        for (int r = 0; r < 31; r++) {
+            const int av = r < 15 ? 15 - r : r - 15;
+            for (int i = 0; i < 32; i++) {
+                const int u = i - 15, au = u < 0 ? -u : u;
+                if (au <= umax[av]) {
+                    w[r][i >> 2] |= (uint32_t)(u + 16) << (8 * (i & 3));
+                    w[r][8 + (i >> 2)] |= 1u << (8 * (i & 3));
+                }
+            }
+        }
+    }
+};
+__device__ const AngleRows k_angle_rows = AngleRows();
 
 #define DW 37          // descriptor window (blurred level), rows
 #define DWP 48         // its LDS pitch: three 16-byte segments cover 37 px + up to 3 px of alignment slack
 #define OW 31          // orientation patch (unblurred level), rows
 #define OWP 48         // its LDS pitch: three 16-byte segments
 #define OD_STEPS 4     // 10 rows per step: 4 steps cover the 31-row patch and the 37-row window
+
+// Sum over the 32 lanes of a half, left in every lane: four DPP steps inside the 16-lane rows (lane ^ 1, lane ^ 2, the other
+// quad of the eight, the other eight of the row -- each folds into its v_add) and one ds_swizzle across the two rows.
+// (__shfl_xor is a ds_bpermute with its address arithmetic: six vector instructions and an LDS round trip per step.)
+__device__ __forceinline__ int half_sum(int v)
+{
+    v += __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, true);    // quad_perm:[1,0,3,2]
+    v += __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xF, 0xF, true);    // quad_perm:[2,3,0,1]
+    v += __builtin_amdgcn_update_dpp(0, v, 0x141, 0xF, 0xF, true);   // row_half_mirror
+    v += __builtin_amdgcn_update_dpp(0, v, 0x140, 0xF, 0xF, true);   // row_mirror
+    v += __builtin_amdgcn_ds_swizzle(v, 0x401F);                     // bit mode: lane ^ 16
+    return v;
+}
 
 #ifndef OD_WAVES
 #define OD_WAVES 4   // waves per workgroup, 2 keypoints each (2-wave workgroups measured 5 % slower)
@@ -57,6 +98,23 @@ __global__ __launch_bounds__(64 * OD_WAVES) void k_orient_desc(const GfoGeom* __
     // caps the kernel at 6 waves per SIMD (the registers allow 8), and the chain of dependent loads at the head of
     // every wave is what the extra waves hide.
     __shared__ __attribute__((aligned(16))) uint8_t s_win[2 * OD_WAVES][DW * DWP];   // [wave*2 + half]
+    // The two tables every wave needs -- the 256 test pairs (4 KB) and the disc's row weights (2 KB) -- are brought into LDS
+    // ONCE per workgroup, 16 bytes per thread, instead of twelve 16-byte loads per lane and wave: this kernel is bound by the
+    // rate at which a CU's texture path takes vector memory instructions (22 per wave were 62 % of its time; with the row
+    // weights fetched per lane as well it went from 128 to 144 us), not by arithmetic.  20.3 KB per workgroup: eight still fit.
+    __shared__ __attribute__((aligned(16))) float s_pat[256][4];   // PatQuad rows
+    __shared__ __attribute__((aligned(16))) uint32_t s_aw[32][16];
+    static_assert(sizeof(PatQuad) == 16 && sizeof(s_pat) == 4096 && sizeof(k_pattern) == 4096, "pattern table layout");
+    uint4 tab_p = make_uint4(0, 0, 0, 0), tab_w = make_uint4(0, 0, 0, 0);
+    {
+        constexpr int NT = 64 * OD_WAVES;
+        static_assert(NT == 256 || NT == 128 || NT == 64, "table staging assumes 64 / 128 / 256 threads");
+        // issued first, stored to LDS in front of the first possible exit (every wave of the workgroup must contribute)
+        if (NT == 256) {
+            tab_p = reinterpret_cast<const uint4*>(k_pattern)[threadIdx.x];
+            if (threadIdx.x < 128) tab_w = reinterpret_cast<const uint4*>(k_angle_rows.w)[threadIdx.x];
+        }
+    }
     const GfoGeom& g = *gp;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;  // uniform: keep it scalar
     const int half = lane >> 5, hl = lane & 31;
@@ -91,6 +149,13 @@ __global__ __launch_bounds__(64 * OD_WAVES) void k_orient_desc(const GfoGeom* __
         prefix += l < level ? c : 0;
         cnt = l == level ? c : cnt;
         total += c;
+    }
+    if (64 * OD_WAVES == 256) {
+        reinterpret_cast<uint4*>(s_pat)[threadIdx.x] = tab_p;
+        if (threadIdx.x < 128) reinterpret_cast<uint4*>(&s_aw[0][0])[threadIdx.x] = tab_w;
+    } else {
+        for (int t = threadIdx.x; t < 256; t += 64 * OD_WAVES) reinterpret_cast<uint4*>(s_pat)[t] = reinterpret_cast<const uint4*>(k_pattern)[t];
+        for (int t = threadIdx.x; t < 128; t += 64 * OD_WAVES) reinterpret_cast<uint4*>(&s_aw[0][0])[t] = reinterpret_cast<const uint4*>(k_angle_rows.w)[t];
     }
     if (blk == 0 && wave == 0 && lane == 0) {
         kp_cnt[img] = min(total, g.kp_stride);
@@ -150,33 +215,41 @@ __global__ __launch_bounds__(64 * OD_WAVES) void k_orient_desc(const GfoGeom* __
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
-    // ---- IC_Angle on the unblurred patch: lane = column u, one disc row per step ----
-    // Every lane reads its column of every row (the read stays inside the staged 48-byte row) and the disc
-    // is applied as a select on |u| <= umax(|v|): no divergent branch, so no exec-mask bookkeeping per row.
-    // Lane 31 (u = 16) lies outside every row of the disc and contributes zeros.
-    const uint8_t* center = pat + GFO_HALF_PATCH * OWP + ooff + GFO_HALF_PATCH;
-    const int u = hl - GFO_HALF_PATCH;
-    const int au = u < 0 ? -u : u;
-    // rows +v and -v share umax(v) (the reference pairs them the same way, ORBextractor.cc:88-100): one select
-    // per pair, m10 takes u * (sum), m01 takes v * (difference); integer sums, so the order is immaterial
-    int m10, m01 = 0;
+    // ---- IC_Angle on the unblurred patch: lane = disc row v, the row's 31 pixels as eight dwords against the row's weight
+    //      bytes -- v_dot4_u32_u8 takes four pixels a time, twice (moment and plain sum): 8 byte shifts + 16 dot products per
+    //      row instead of the 90 vector instructions of a column per lane (2 byte adds, 2 selects, 2 multiply-adds per row
+    //      pair).  m10 = sum of u * I = sum of (u + 16) * I - 16 * sum of I; m01 = sum over the rows of v * (row sum); integer
+    //      sums, so the order is immaterial (the reference pairs rows +v / -v, ORBextractor.cc:88-100).  Lane 31 of a half
+    //      reads the region's row 31 (not the patch's) against an all-zero weight row.
+    // the tables are complete once every wave that is still running has passed here (a wave that left early stored its
+    // share first; finished waves do not count at the barrier)
+    __syncthreads();
+    int m10, m01;
     {
-        const int val = center[u];
-        m10 = u * (au <= GFO_HALF_PATCH ? val : 0);
-    }
+        uint32_t aw[16];
+        {
+            const uint4* awp = reinterpret_cast<const uint4*>(s_aw[hl]);
+            const uint4 a0 = awp[0], a1 = awp[1], a2 = awp[2], a3 = awp[3];
+            aw[0] = a0.x; aw[1] = a0.y; aw[2] = a0.z; aw[3] = a0.w; aw[4] = a1.x; aw[5] = a1.y; aw[6] = a1.z; aw[7] = a1.w;
+            aw[8] = a2.x; aw[9] = a2.y; aw[10] = a2.z; aw[11] = a2.w; aw[12] = a3.x; aw[13] = a3.y; aw[14] = a3.z; aw[15] = a3.w;
+        }
+        const uint4* prow = reinterpret_cast<const uint4*>(pat + hl * OWP);
+        const uint4 q0 = prow[0], q1 = prow[1];
+        const uint32_t q2 = reinterpret_cast<const uint32_t*>(prow)[8];
+        // the row starts at byte `ooff` of the staged segment: shift it down (the shift count is the same for the whole half)
+        const uint32_t d[9] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2};
+        uint32_t s1 = 0, s0 = 0;
 #pragma unroll
-    for (int v = 1; v <= GFO_HALF_PATCH; v++) {
-        const int d = k_umax[v];
-        const int vp = center[v * OWP + u], vm = center[-v * OWP + u];
-        const bool in = au <= d;
-        m10 += u * (in ? vp + vm : 0);
-        m01 += v * (in ? vp - vm : 0);
+        for (int k = 0; k < 8; k++) {
+            const uint32_t px = __builtin_amdgcn_alignbyte(d[k + 1], d[k], (uint32_t)ooff);
+            s1 = __builtin_amdgcn_udot4(px, aw[k], s1, false);
+            s0 = __builtin_amdgcn_udot4(px, aw[8 + k], s0, false);
+        }
+        m10 = (int)s1 - 16 * (int)s0;
+        m01 = (hl - GFO_HALF_PATCH) * (int)s0;
     }
-#pragma unroll
-    for (int o = 16; o > 0; o >>= 1) {  // stays inside the 32-lane half
-        m10 += __shfl_xor(m10, o);
-        m01 += __shfl_xor(m01, o);
-    }
+    m10 = half_sum(m10);
+    m01 = half_sum(m01);
     const float angle = gfo_fast_atan2f((float)m01, (float)m10);
 
     // ---- the patch has been read (LDS operations of a wave execute in issue order): the window takes its place ----
@@ -205,7 +278,7 @@ __global__ __launch_bounds__(64 * OD_WAVES) void k_orient_desc(const GfoGeom* __
     unsigned long long mk[8];
 #pragma unroll
     for (int r = 0; r < 8; r++) {
-        const PatQuad p = k_pattern[r * 32 + hl];
+        const PatQuad p = *reinterpret_cast<const PatQuad*>(s_pat[r * 32 + hl]);
         // both points of the pair at once: packed-fp32 multiply / add (v_pk_mul_f32, v_pk_add_f32), each lane op
         // still the plain IEEE single operation of the scalar form (no contraction: -ffp-contract=off)
         const f32x2 px = {p.x0, p.x1}, py = {p.y0, p.y1};

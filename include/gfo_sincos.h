@@ -19,6 +19,27 @@
 #define GFO_SINCOS_H
 
 #include <math.h>
+#include "gfo_sincos_coef.h"
+
+/* the constants: literals, or -- where the includer defines GFO_SINCOS_TABLE (the HIP kernel) -- entries of a table in memory */
+#ifdef GFO_SINCOS_TABLE
+#define GFO_SC(i, lit) (GFO_SINCOS_TABLE[i])
+#else
+#define GFO_SC(i, lit) (lit)
+#endif
+/* fma(a, b, c) with a constant addend c.  In the HIP kernel c sits in a scalar register pair (loaded from the table) and the
+ * three-operand v_fma_f64 reads it there; left to itself the compiler picks the accumulating form, which wants the addend in
+ * the destination and pays two v_mov per constant.  Same IEEE operation either way. */
+#if defined(__HIP_DEVICE_COMPILE__) && defined(GFO_SINCOS_TABLE)
+static __device__ __forceinline__ double gfo_fma_c(double a, double b, double c)
+{
+    double d;
+    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "s"(c));
+    return d;
+}
+#else
+#define gfo_fma_c(a, b, c) fma((a), (b), (c))
+#endif
 
 #ifdef __HIPCC__
 #define GFO_HD __host__ __device__ static inline
@@ -30,38 +51,40 @@
 GFO_HD void gfo_sincosf(float t, float* s_out, float* c_out)
 {
     const double x = (double)t;
-    const double two_over_pi = 6.36619772367581382433e-01;
-    const double pio2_hi = 1.57079632679489655800e+00; /* 0x3FF921FB54442D18 */
-    const double pio2_lo = 6.12323399573676603587e-17; /* 0x3C91A62633145C07 */
+    const double two_over_pi = GFO_SC(0, GFO_SC_2OPI);
+    const double pio2_hi = GFO_SC(1, GFO_SC_PIO2_HI);
+    const double pio2_lo = GFO_SC(2, GFO_SC_PIO2_LO);
     const double kd = rint(x * two_over_pi);
     const int k = (int)kd;
     double r = fma(-kd, pio2_hi, x);
     r = fma(-kd, pio2_lo, r);
     const double z = r * r;
     /* minimax polynomials on [-pi/4, pi/4] (the classic fdlibm kernel coefficients) */
-    double ps = 1.58969099521155010221e-10;
-    ps = fma(ps, z, -2.50507602534068634195e-08);
-    ps = fma(ps, z, 2.75573137070700676789e-06);
-    ps = fma(ps, z, -1.98412698298579493134e-04);
-    ps = fma(ps, z, 8.33333333332248946124e-03);
-    ps = fma(ps, z, -1.66666666666666324348e-01);
+    double ps = GFO_SC(3, GFO_SC_S6);
+    ps = gfo_fma_c(ps, z, GFO_SC(4, GFO_SC_S5));
+    ps = gfo_fma_c(ps, z, GFO_SC(5, GFO_SC_S4));
+    ps = gfo_fma_c(ps, z, GFO_SC(6, GFO_SC_S3));
+    ps = gfo_fma_c(ps, z, GFO_SC(7, GFO_SC_S2));
+    ps = gfo_fma_c(ps, z, GFO_SC(8, GFO_SC_S1));
     const double sn = fma(r * z, ps, r);
-    double pc = -1.13596475577881948265e-11;
-    pc = fma(pc, z, 2.08757232129817482790e-09);
-    pc = fma(pc, z, -2.75573143513906633035e-07);
-    pc = fma(pc, z, 2.48015872894767294178e-05);
-    pc = fma(pc, z, -1.38888888888741095749e-03);
-    pc = fma(pc, z, 4.16666666666666019037e-02);
+    double pc = GFO_SC(9, GFO_SC_C6);
+    pc = gfo_fma_c(pc, z, GFO_SC(10, GFO_SC_C5));
+    pc = gfo_fma_c(pc, z, GFO_SC(11, GFO_SC_C4));
+    pc = gfo_fma_c(pc, z, GFO_SC(12, GFO_SC_C3));
+    pc = gfo_fma_c(pc, z, GFO_SC(13, GFO_SC_C2));
+    pc = gfo_fma_c(pc, z, GFO_SC(14, GFO_SC_C1));
     const double cs = fma(z * z, pc, fma(z, -0.5, 1.0));
-    double s, c;
-    switch (k & 3) {
-    case 0: s = sn; c = cs; break;
-    case 1: s = cs; c = -sn; break;
-    case 2: s = -sn; c = -cs; break;
-    default: s = -cs; c = sn; break;
+    /* quadrant: (s, c) = (sn, cs), (cs, -sn), (-sn, -cs), (-cs, sn).  Rounding commutes with negation and with the choice, so
+     * both are done on the rounded floats (two conversions, 32-bit selects) instead of on the doubles. */
+    {
+        const float snf = (float)sn, csf = (float)cs;
+        float s = (k & 1) ? csf : snf;
+        float c = (k & 1) ? snf : csf;
+        if (k & 2) s = -s;
+        if ((k + 1) & 2) c = -c;
+        *s_out = s;
+        *c_out = c;
     }
-    *s_out = (float)s;
-    *c_out = (float)c;
 }
 
 /* OpenCV 3.4.x cv::fastAtan2(y, x) restated (scalar path of modules/core mathfuncs_core):
