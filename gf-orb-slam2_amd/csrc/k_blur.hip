@@ -24,20 +24,20 @@ struct HRow {
     unsigned lo, hi;  // four u16 horizontal sums: (x0, x0+1), (x0+2, x0+3)
 };
 
-// Horizontal pass of 4 pixels as v_dot4_u32_u8: output j (pixel x0+j) = B[j+1..j+4] . (18,34,49,55) +
-// B[j+5..j+8] . (49,34,18,0) over the 12 loaded bytes B = pixels x0-4 .. x0+7; the 4-byte windows are cut
-// out of the three dwords with v_alignbyte, so no byte is unpacked.
+// Horizontal pass of 4 pixels as v_dot4_u32_u8 over the 12 loaded bytes B = pixels x0-4 .. x0+7: output j (pixel x0+j) is
+// B[j+1 .. j+7] . (18,34,49,55,49,34,18).  The dwords are used where they lie and the TAPS are shifted instead -- a tap
+// vector per (output, dword) with zeros where the window does not reach: 2 + 3 + 3 + 2 dot products, all against scalar
+// constants.  (Round 2 cut byte-shifted windows out of the dwords first: 6 v_alignbyte + 8 dot products.)
 __device__ __forceinline__ HRow hpass_dot(unsigned d0, unsigned d1, unsigned d2)
 {
-    const unsigned klo = 18u | (34u << 8) | (49u << 16) | (55u << 24);
-    const unsigned khi = 49u | (34u << 8) | (18u << 16);
-    const unsigned s0 = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d2, d1, 1), khi,
-                                               __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d1, d0, 1), klo, 0u, false), false);
-    const unsigned s1 = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d2, d1, 2), khi,
-                                               __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d1, d0, 2), klo, 0u, false), false);
-    const unsigned s2 = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d2, d1, 3), khi,
-                                               __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d1, d0, 3), klo, 0u, false), false);
-    const unsigned s3 = __builtin_amdgcn_udot4(d2, khi, __builtin_amdgcn_udot4(d1, klo, 0u, false), false);
+#define GFO_T4(a, b, c, d) ((unsigned)(a) | ((unsigned)(b) << 8) | ((unsigned)(c) << 16) | ((unsigned)(d) << 24))
+    const unsigned s0 = __builtin_amdgcn_udot4(d1, GFO_T4(55, 49, 34, 18), __builtin_amdgcn_udot4(d0, GFO_T4(0, 18, 34, 49), 0u, false), false);
+    const unsigned s1 = __builtin_amdgcn_udot4(d2, GFO_T4(18, 0, 0, 0), __builtin_amdgcn_udot4(d1, GFO_T4(49, 55, 49, 34),
+                                               __builtin_amdgcn_udot4(d0, GFO_T4(0, 0, 18, 34), 0u, false), false), false);
+    const unsigned s2 = __builtin_amdgcn_udot4(d2, GFO_T4(34, 18, 0, 0), __builtin_amdgcn_udot4(d1, GFO_T4(34, 49, 55, 49),
+                                               __builtin_amdgcn_udot4(d0, GFO_T4(0, 0, 0, 18), 0u, false), false), false);
+    const unsigned s3 = __builtin_amdgcn_udot4(d2, GFO_T4(49, 34, 18, 0), __builtin_amdgcn_udot4(d1, GFO_T4(18, 34, 49, 55), 0u, false), false);
+#undef GFO_T4
     HRow r;
     r.lo = s0 | (s1 << 16);  // each sum <= 257 * 255 = 65535
     r.hi = s2 | (s3 << 16);
@@ -191,9 +191,13 @@ __device__ __forceinline__ void blur_body(const GfoGeom& g, const GfoInput& in, 
     // and one load per lane with the neighbour dwords fetched by lane shuffle (the ds_bpermute traffic costs
     // more than the L1-served overlapping loads).
     RawRow nxt = load_row<BORDER>(src + (long long)gfo_reflect101(y0 + 3, h) * pitch, x0, w, bs);
+    const int h2 = 2 * h - 2;
     for (int y = y0; y < y1; y++) {
         const RawRow cur = nxt;
-        nxt = load_row<BORDER>(src + (long long)gfo_reflect101(y + 4, h) * pitch, x0, w, bs);
+        // row y + 4 reflected: it is never above the image, so BORDER_REFLECT_101 is min(a, 2h - 2 - a), and the clamp for
+        // images of a few rows adds max(., 0): three operations instead of the general form's eight
+        const int ya = y + 4;
+        nxt = load_row<BORDER>(src + (long long)max(min(ya, h2 - ya), 0) * pitch, x0, w, bs);
         r6 = hpass_dot(cur.d0, cur.d1, cur.d2);
         const unsigned o0 = vcol<false>(r0.lo, r1.lo, r2.lo, r3.lo, r4.lo, r5.lo, r6.lo);
         const unsigned o1 = vcol<true>(r0.lo, r1.lo, r2.lo, r3.lo, r4.lo, r5.lo, r6.lo);

@@ -178,7 +178,9 @@ __global__ __launch_bounds__(64 * OD_WAVES) void k_orient_desc(const GfoGeom* __
     // bytes fit in 48; the bytes past the window belong to the same row or, at the right image border, to the
     // next row, which exists because keypoints keep 19 px from every edge).  The lane -> (row, segment) map is
     // fixed -- 10 rows x 3 segments per step -- so a load or store costs an offset increment, not an index
-    // decomposition.
+    // decomposition.  (Round 3 tried both windows from their exact first byte, loads declared unaligned: the patch is then
+    // two segments a row, six vector memory instructions per wave instead of eight -- and the kernel went from 114 to 145 us:
+    // a 16-byte load at an odd address costs the texture path about twice an aligned one.)
     int pitch;
     const uint8_t* lv = gfo_level_ptr(g, in, pyr, level, img, &pitch);   // wave-uniform
     const uint8_t* bl = blur + (long long)img * g.blur_img_stride + L.blur_off;
