@@ -42,21 +42,21 @@ __device__ const PatQuad k_pattern[256] = {
 };
 // ORBextractor.cc:451-468: umax[|v|], the half-width of the orientation disc in row v
 #define GFO_UMAX_LIST 15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3
-// Row weights of the disc for v_dot4_u32_u8: row r = v + 15 (r = 31: an idle lane's all-zero row) as 32 bytes for the columns
-// u = -15 .. 16, first the moment weights (u + 16 inside the disc, 0 outside: unsigned, the bias comes off as 16 * the row
-// sum), then the membership bytes (1 / 0) -- eight dwords each.
+// Row weights of the disc for v_dot4_u32_u8: one row per |v| = 0 .. 15 (rows +v and -v share umax) and an all-zero row 16 for
+// the idle lane, each as 32 bytes for the columns u = -15 .. 16: first the moment weights (u + 16 inside the disc, 0 outside:
+// unsigned, the bias comes off as 16 * the row sum), then the membership bytes (1 / 0) -- eight dwords each.
+#define OD_AW_ROWS 17
 struct AngleRows {
-    uint32_t w[32][16];
+    uint32_t w[OD_AW_ROWS][16];
     constexpr AngleRows() : w()
     {
         const int umax[16] = {GFO_UMAX_LIST};
-        for (int r = 0; r < 31; r++) {
-            const int av = r < 15 ? 15 - r : r - 15;
+        for (int av = 0; av < 16; av++) {
             for (int i = 0; i < 32; i++) {
                 const int u = i - 15, au = u < 0 ? -u : u;
                 if (au <= umax[av]) {
-                    w[r][i >> 2] |= (uint32_t)(u + 16) << (8 * (i & 3));
-                    w[r][8 + (i >> 2)] |= 1u << (8 * (i & 3));
+                    w[av][i >> 2] |= (uint32_t)(u + 16) << (8 * (i & 3));
+                    w[av][8 + (i >> 2)] |= 1u << (8 * (i & 3));
                 }
             }
         }
@@ -98,12 +98,12 @@ __global__ __launch_bounds__(64 * OD_WAVES) void k_orient_desc(const GfoGeom* __
     // caps the kernel at 6 waves per SIMD (the registers allow 8), and the chain of dependent loads at the head of
     // every wave is what the extra waves hide.
     __shared__ __attribute__((aligned(16))) uint8_t s_win[2 * OD_WAVES][DW * DWP];   // [wave*2 + half]
-    // The two tables every wave needs -- the 256 test pairs (4 KB) and the disc's row weights (2 KB) -- are brought into LDS
+    // The two tables every wave needs -- the 256 test pairs (4 KB) and the disc's row weights (1.1 KB) -- are brought into LDS
     // ONCE per workgroup, 16 bytes per thread, instead of twelve 16-byte loads per lane and wave: this kernel is bound by the
     // rate at which a CU's texture path takes vector memory instructions (22 per wave were 62 % of its time; with the row
-    // weights fetched per lane as well it went from 128 to 144 us), not by arithmetic.  20.3 KB per workgroup: eight still fit.
+    // weights fetched per lane as well it went from 128 to 144 us), not by arithmetic.  19.7 KB per workgroup: eight still fit.
     __shared__ __attribute__((aligned(16))) float s_pat[256][4];   // PatQuad rows
-    __shared__ __attribute__((aligned(16))) uint32_t s_aw[32][16];
+    __shared__ __attribute__((aligned(16))) uint32_t s_aw[OD_AW_ROWS][20];   // rows padded to 80 B: 16-byte reads of eight consecutive rows then hit all 32 banks once (64-B rows: four ways)
     static_assert(sizeof(PatQuad) == 16 && sizeof(s_pat) == 4096 && sizeof(k_pattern) == 4096, "pattern table layout");
     uint4 tab_p = make_uint4(0, 0, 0, 0), tab_w = make_uint4(0, 0, 0, 0);
     {
@@ -112,7 +112,7 @@ __global__ __launch_bounds__(64 * OD_WAVES) void k_orient_desc(const GfoGeom* __
         // issued first, stored to LDS in front of the first possible exit (every wave of the workgroup must contribute)
         if (NT == 256) {
             tab_p = reinterpret_cast<const uint4*>(k_pattern)[threadIdx.x];
-            if (threadIdx.x < 128) tab_w = reinterpret_cast<const uint4*>(k_angle_rows.w)[threadIdx.x];
+            if (threadIdx.x < 4 * OD_AW_ROWS) tab_w = reinterpret_cast<const uint4*>(k_angle_rows.w)[threadIdx.x];
         }
     }
     const GfoGeom& g = *gp;
@@ -152,10 +152,10 @@ __global__ __launch_bounds__(64 * OD_WAVES) void k_orient_desc(const GfoGeom* __
     }
     if (64 * OD_WAVES == 256) {
         reinterpret_cast<uint4*>(s_pat)[threadIdx.x] = tab_p;
-        if (threadIdx.x < 128) reinterpret_cast<uint4*>(&s_aw[0][0])[threadIdx.x] = tab_w;
+        if (threadIdx.x < 4 * OD_AW_ROWS) *reinterpret_cast<uint4*>(&s_aw[threadIdx.x >> 2][4 * (threadIdx.x & 3)]) = tab_w;
     } else {
         for (int t = threadIdx.x; t < 256; t += 64 * OD_WAVES) reinterpret_cast<uint4*>(s_pat)[t] = reinterpret_cast<const uint4*>(k_pattern)[t];
-        for (int t = threadIdx.x; t < 128; t += 64 * OD_WAVES) reinterpret_cast<uint4*>(&s_aw[0][0])[t] = reinterpret_cast<const uint4*>(k_angle_rows.w)[t];
+        for (int t = threadIdx.x; t < 4 * OD_AW_ROWS; t += 64 * OD_WAVES) *reinterpret_cast<uint4*>(&s_aw[t >> 2][4 * (t & 3)]) = reinterpret_cast<const uint4*>(k_angle_rows.w)[t];
     }
     if (blk == 0 && wave == 0 && lane == 0) {
         kp_cnt[img] = min(total, g.kp_stride);
@@ -222,7 +222,7 @@ __global__ __launch_bounds__(64 * OD_WAVES) void k_orient_desc(const GfoGeom* __
     //      row instead of the 90 vector instructions of a column per lane (2 byte adds, 2 selects, 2 multiply-adds per row
     //      pair).  m10 = sum of u * I = sum of (u + 16) * I - 16 * sum of I; m01 = sum over the rows of v * (row sum); integer
     //      sums, so the order is immaterial (the reference pairs rows +v / -v, ORBextractor.cc:88-100).  Lane 31 of a half
-    //      reads the region's row 31 (not the patch's) against an all-zero weight row.
+    //      reads the region's row 31 (not the patch's) against the all-zero weight row.
     // the tables are complete once every wave that is still running has passed here (a wave that left early stored its
     // share first; finished waves do not count at the barrier)
     __syncthreads();
@@ -230,7 +230,8 @@ __global__ __launch_bounds__(64 * OD_WAVES) void k_orient_desc(const GfoGeom* __
     {
         uint32_t aw[16];
         {
-            const uint4* awp = reinterpret_cast<const uint4*>(s_aw[hl]);
+            const int av = hl < GFO_HALF_PATCH ? GFO_HALF_PATCH - hl : hl - GFO_HALF_PATCH;   // |v|; 16 for the idle lane
+            const uint4* awp = reinterpret_cast<const uint4*>(s_aw[av]);
             const uint4 a0 = awp[0], a1 = awp[1], a2 = awp[2], a3 = awp[3];
             aw[0] = a0.x; aw[1] = a0.y; aw[2] = a0.z; aw[3] = a0.w; aw[4] = a1.x; aw[5] = a1.y; aw[6] = a1.z; aw[7] = a1.w;
             aw[8] = a2.x; aw[9] = a2.y; aw[10] = a2.z; aw[11] = a2.w; aw[12] = a3.x; aw[13] = a3.y; aw[14] = a3.z; aw[15] = a3.w;
