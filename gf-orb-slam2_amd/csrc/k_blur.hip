@@ -6,7 +6,8 @@
 // GFO_BLUR_STRIP-row (24) strip.  Per row it loads the 12 bytes [x-4, x+8) as three coalesced dwords (the lanes of a
 // wave read one contiguous 256-B run three times, shifted by 4 B: served by L1), forms the four
 // horizontal sums with two v_dot4_u32_u8 each (no byte unpacking; max 257*255 = 65535 fits u16 exactly),
-// keeps the last seven rows of sums packed in registers, and emits one dword of output per row.
+// keeps the sums of the last four row PAIRS in registers (a column's even and odd row share a register: the vertical pass is
+// then four v_dot2_u32_u16 per output instead of seven), and emits two rows of output per step.
 // Vertical halo: 6 extra rows per strip (32-row strips measured 4 % slower alone, 16-row ones 2 % slower in the pipeline).
 // All levels of all images are one launch (block index -> level through the prefix table).
 #include "gfo_internal.h"
@@ -128,21 +129,41 @@ __device__ __forceinline__ HRow hrow(const RawRow& r) { return hpass_dot(r.d0, r
 
 typedef unsigned short gfo_bu16x2 __attribute__((ext_vector_type(2)));
 
-// Vertical pass of one column: the seven rows' u16 sums sit in the low (HI = false) or high half of their
-// registers; v_dot2_u32_u16 against {tap, 0} (or {0, tap}) multiplies the wanted half and adds it to the
-// running sum without unpacking anything.  u32 accumulation (257 * 65535 + 2^15 < 2^32), one rounding.
-template <bool HI>
-__device__ __forceinline__ unsigned vcol(unsigned a0, unsigned a1, unsigned a2, unsigned a3, unsigned a4, unsigned a5, unsigned a6)
+// Vertical pass.  The window holds ROW PAIRS: a register carries one column's horizontal sums of rows (2k, 2k+1) in its two
+// halves, so v_dot2_u32_u16 against a pair of taps does two useful multiply-adds -- an output row is FOUR dot products over
+// four pairs (the seven taps and a zero), where a window of single rows packed by column pair needed seven, each with one
+// tap wasted on the neighbour column.  u32 accumulation (257 * 65535 + 2^15 < 2^32), one rounding.
+struct HPair {
+    unsigned c0, c1, c2, c3;   // column j: sums of the pair's even row | odd row << 16
+};
+
+__device__ __forceinline__ HPair hpair(const HRow& e, const HRow& o)
 {
-#define GFO_TAP(v, k, acc) __builtin_amdgcn_udot2(__builtin_bit_cast(gfo_bu16x2, v), __builtin_bit_cast(gfo_bu16x2, (unsigned)(HI ? ((k) << 16) : (k))), acc, false)
-    unsigned acc = GFO_TAP(a0, 18u, 32768u);
-    acc = GFO_TAP(a6, 18u, acc);
-    acc = GFO_TAP(a1, 34u, acc);
-    acc = GFO_TAP(a5, 34u, acc);
-    acc = GFO_TAP(a2, 49u, acc);
-    acc = GFO_TAP(a4, 49u, acc);
-    acc = GFO_TAP(a3, 55u, acc);
-#undef GFO_TAP
+    HPair p;   // (the four v_perm / v_lshl_or that re-pack two rows of column pairs into four columns of row pairs)
+    p.c0 = __builtin_amdgcn_perm(o.lo, e.lo, 0x05040100u);   // e.lo low half | o.lo low half << 16
+    p.c1 = __builtin_amdgcn_perm(o.lo, e.lo, 0x07060302u);   // the high halves
+    p.c2 = __builtin_amdgcn_perm(o.hi, e.hi, 0x05040100u);
+    p.c3 = __builtin_amdgcn_perm(o.hi, e.hi, 0x07060302u);
+    return p;
+}
+
+#define GFO_DOT2(v, klo, khi, acc) __builtin_amdgcn_udot2(__builtin_bit_cast(gfo_bu16x2, (unsigned)(v)), __builtin_bit_cast(gfo_bu16x2, (unsigned)((klo) | ((khi) << 16))), acc, false)
+// output row y (even) of one column from the pairs (y-4, y-3), (y-2, y-1), (y, y+1), (y+2, y+3)
+__device__ __forceinline__ unsigned vcol_even(unsigned m2, unsigned m1, unsigned p0, unsigned p1)
+{
+    unsigned acc = GFO_DOT2(m2, 0u, 18u, 32768u);
+    acc = GFO_DOT2(m1, 34u, 49u, acc);
+    acc = GFO_DOT2(p0, 55u, 49u, acc);
+    acc = GFO_DOT2(p1, 34u, 18u, acc);
+    return min(acc >> 16, 255u);
+}
+// output row y + 1 from the pairs (y-2, y-1), (y, y+1), (y+2, y+3), (y+4, y+5)
+__device__ __forceinline__ unsigned vcol_odd(unsigned m1, unsigned p0, unsigned p1, unsigned p2)
+{
+    unsigned acc = GFO_DOT2(m1, 18u, 34u, 32768u);
+    acc = GFO_DOT2(p0, 49u, 55u, acc);
+    acc = GFO_DOT2(p1, 49u, 34u, acc);
+    acc = GFO_DOT2(p2, 18u, 0u, acc);
     return min(acc >> 16, 255u);
 }
 
@@ -179,34 +200,43 @@ __device__ __forceinline__ void blur_body(const GfoGeom& g, const GfoInput& in, 
     if (BORDER) bs = border_sel(x0, w);
     const int y1 = min(y0 + BLUR_STRIP, h);
 
-    HRow r0, r1, r2, r3, r4, r5, r6;
-    r0 = hrow(load_row<BORDER>(src + (long long)gfo_reflect101(y0 - 3, h) * pitch, x0, w, bs));
-    r1 = hrow(load_row<BORDER>(src + (long long)gfo_reflect101(y0 - 2, h) * pitch, x0, w, bs));
-    r2 = hrow(load_row<BORDER>(src + (long long)gfo_reflect101(y0 - 1, h) * pitch, x0, w, bs));
-    r3 = hrow(load_row<BORDER>(src + (long long)y0 * pitch, x0, w, bs));
-    r4 = hrow(load_row<BORDER>(src + (long long)gfo_reflect101(y0 + 1, h) * pitch, x0, w, bs));
-    r5 = hrow(load_row<BORDER>(src + (long long)gfo_reflect101(y0 + 2, h) * pitch, x0, w, bs));
-    // the raw dwords of row y+4 are requested one step before they are filtered (two rows of loads in flight
+    // strips start at even rows (GFO_BLUR_STRIP is even): the pairs are (y0 + 2k, y0 + 2k + 1)
+    static_assert(BLUR_STRIP % 2 == 0, "row pairs need an even strip height");
+#define GFO_BLUR_ROW(yy) hrow(load_row<BORDER>(src + (long long)gfo_reflect101((yy), h) * pitch, x0, w, bs))
+    HPair m2 = hpair(GFO_BLUR_ROW(y0 - 4), GFO_BLUR_ROW(y0 - 3));
+    HPair m1 = hpair(GFO_BLUR_ROW(y0 - 2), GFO_BLUR_ROW(y0 - 1));
+    HPair p0 = hpair(GFO_BLUR_ROW(y0), GFO_BLUR_ROW(y0 + 1));
+    HPair p1 = hpair(GFO_BLUR_ROW(y0 + 2), GFO_BLUR_ROW(y0 + 3));
+#undef GFO_BLUR_ROW
+    // the raw dwords of rows y+4, y+5 are requested one step before they are filtered (two rows of loads in flight
     // per thread).  Measured alternatives that were slower: a 7-row unrolled window (106 VGPRs, 4 waves/SIMD),
     // and one load per lane with the neighbour dwords fetched by lane shuffle (the ds_bpermute traffic costs
     // more than the L1-served overlapping loads).
-    RawRow nxt = load_row<BORDER>(src + (long long)gfo_reflect101(y0 + 3, h) * pitch, x0, w, bs);
+    RawRow nxe = load_row<BORDER>(src + (long long)gfo_reflect101(y0 + 4, h) * pitch, x0, w, bs);
+    RawRow nxo = load_row<BORDER>(src + (long long)gfo_reflect101(y0 + 5, h) * pitch, x0, w, bs);
     const int h2 = 2 * h - 2;
-    for (int y = y0; y < y1; y++) {
-        const RawRow cur = nxt;
-        // row y + 4 reflected: it is never above the image, so BORDER_REFLECT_101 is min(a, 2h - 2 - a), and the clamp for
+    for (int y = y0; y < y1; y += 2) {
+        const RawRow ce = nxe, co = nxo;
+        // rows y + 6, y + 7 reflected: never above the image, so BORDER_REFLECT_101 is min(a, 2h - 2 - a), and the clamp for
         // images of a few rows adds max(., 0): three operations instead of the general form's eight
-        const int ya = y + 4;
-        nxt = load_row<BORDER>(src + (long long)max(min(ya, h2 - ya), 0) * pitch, x0, w, bs);
-        r6 = hpass_dot(cur.d0, cur.d1, cur.d2);
-        const unsigned o0 = vcol<false>(r0.lo, r1.lo, r2.lo, r3.lo, r4.lo, r5.lo, r6.lo);
-        const unsigned o1 = vcol<true>(r0.lo, r1.lo, r2.lo, r3.lo, r4.lo, r5.lo, r6.lo);
-        const unsigned o2 = vcol<false>(r0.hi, r1.hi, r2.hi, r3.hi, r4.hi, r5.hi, r6.hi);
-        const unsigned o3 = vcol<true>(r0.hi, r1.hi, r2.hi, r3.hi, r4.hi, r5.hi, r6.hi);
-        *reinterpret_cast<unsigned*>(dst + (long long)y * L.pitch + x0) = o0 | (o1 << 8) | (o2 << 16) | (o3 << 24);
-        r0 = r1; r1 = r2; r2 = r3; r3 = r4; r4 = r5; r5 = r6;
+        const int ya = y + 6, yb = y + 7;
+        nxe = load_row<BORDER>(src + (long long)max(min(ya, h2 - ya), 0) * pitch, x0, w, bs);
+        nxo = load_row<BORDER>(src + (long long)max(min(yb, h2 - yb), 0) * pitch, x0, w, bs);
+        const HPair p2 = hpair(hpass_dot(ce.d0, ce.d1, ce.d2), hpass_dot(co.d0, co.d1, co.d2));
+        {
+            const unsigned o0 = vcol_even(m2.c0, m1.c0, p0.c0, p1.c0), o1 = vcol_even(m2.c1, m1.c1, p0.c1, p1.c1);
+            const unsigned o2 = vcol_even(m2.c2, m1.c2, p0.c2, p1.c2), o3 = vcol_even(m2.c3, m1.c3, p0.c3, p1.c3);
+            *reinterpret_cast<unsigned*>(dst + (long long)y * L.pitch + x0) = o0 | (o1 << 8) | (o2 << 16) | (o3 << 24);
+        }
+        if (y + 1 < y1) {
+            const unsigned o0 = vcol_odd(m1.c0, p0.c0, p1.c0, p2.c0), o1 = vcol_odd(m1.c1, p0.c1, p1.c1, p2.c1);
+            const unsigned o2 = vcol_odd(m1.c2, p0.c2, p1.c2, p2.c2), o3 = vcol_odd(m1.c3, p0.c3, p1.c3, p2.c3);
+            *reinterpret_cast<unsigned*>(dst + (long long)(y + 1) * L.pitch + x0) = o0 | (o1 << 8) | (o2 << 16) | (o3 << 24);
+        }
+        m2 = m1; m1 = p0; p0 = p1; p1 = p2;
     }
 }
+#undef GFO_DOT2
 
 // One launch: the first blur_total_b blocks of every image are its border blocks (long, thin chains of
 // scattered rows -- dispatched first so they run underneath the streaming bulk), the rest the interior.
@@ -215,7 +245,7 @@ __device__ __forceinline__ void blur_body(const GfoGeom& g, const GfoInput& in, 
 // there every register it does not hold is a wave of somebody else: 194.0k -> 201.3k frames/s for the whole pipeline
 // (same-box A/B, tools/ab_variant.sh; DESIGN.md "footprint").
 #ifndef GFO_BLUR_WAVES
-#define GFO_BLUR_WAVES 8
+#define GFO_BLUR_WAVES 6
 #endif
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(GFO_BLUR_WAVES, GFO_BLUR_WAVES))) void k_blur(const GfoGeom* __restrict__ gp, GfoInput in,
                                               const uint8_t* __restrict__ pyr, uint8_t* __restrict__ blur)
