@@ -549,7 +549,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--batch", type=int, default=128, help="images per GPU per step (even)")
+    ap.add_argument("--batch", type=int, default=256, help="images per GPU per step (even); 256 is where the rate levels off on MI355X (64 / 128 / 256 / 384 / 1024: 237k / 260k / 274k / 275k / 275k frames/s, profiles/batch_sweep_r03.txt)")
     ap.add_argument("--workload", default="stereo752", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-other-configs", action="store_true", help="skip the short passes over the other BASELINE configs")

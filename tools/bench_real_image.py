@@ -15,7 +15,7 @@ import torch
 
 import gf_orb_slam2_amd as G
 
-B = 128
+B = int(os.environ.get("GFO_REAL_BATCH", "256"))   # as bench.py's default batch
 l = np.fromfile("tests/golden/EuRoC_l_752x480.u8", np.uint8).reshape(480, 752)
 r = np.fromfile("tests/golden/EuRoC_r_752x480.u8", np.uint8).reshape(480, 752)
 # 64 "pairs": the two images under small integer shifts (np.roll), so the batch is not 64 identical copies
