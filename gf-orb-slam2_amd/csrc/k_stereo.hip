@@ -63,6 +63,38 @@ struct StereoArgs {
     int window;               // W
 };
 
+// Minimum / sum over the 32 lanes of a half (or all 64), left in every lane: DPP steps inside the 16-lane rows (lane ^ 1,
+// lane ^ 2, the other quad of the eight, the other eight of the row -- each folds into its v_min / v_add) and a ds_swizzle
+// (lane ^ 16) / a v_readlane pair across rows.  (__shfl_xor is a ds_bpermute with its address arithmetic: six vector
+// instructions and an LDS round trip per step, five or six steps per keypoint.)
+__device__ __forceinline__ unsigned st_row_min(unsigned v)
+{
+    v = min(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, true));    // quad_perm:[1,0,3,2]
+    v = min(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, true));    // quad_perm:[2,3,0,1]
+    v = min(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xF, 0xF, true));   // row_half_mirror
+    v = min(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x140, 0xF, 0xF, true));   // row_mirror
+    return v;
+}
+__device__ __forceinline__ unsigned st_half_min(unsigned v)
+{
+    v = st_row_min(v);
+    return min(v, (unsigned)__builtin_amdgcn_ds_swizzle((int)v, 0x401F));                  // bit mode: lane ^ 16
+}
+__device__ __forceinline__ unsigned st_wave_min(unsigned v)
+{
+    v = st_half_min(v);
+    return min((unsigned)__builtin_amdgcn_readlane((int)v, 0), (unsigned)__builtin_amdgcn_readlane((int)v, 32));
+}
+__device__ __forceinline__ int st_wave_sum(int v)
+{
+    v += __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, true);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xF, 0xF, true);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x141, 0xF, 0xF, true);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x140, 0xF, 0xF, true);
+    v += __builtin_amdgcn_ds_swizzle(v, 0x401F);
+    return __builtin_amdgcn_readlane(v, 0) + __builtin_amdgcn_readlane(v, 32);
+}
+
 // inclusive scan over the 64 lanes in the DPP network (see k_quadtree.hip)
 __device__ __forceinline__ int st_wave_incl_scan(int v)
 {
@@ -224,8 +256,7 @@ __global__ __launch_bounds__(256) void k_stereo_match(StereoArgs a)
     }
     const unsigned long long anym = __builtin_amdgcn_ballot_w64(any);
     const bool have_cands = ((anym >> (32 * half)) & 0xFFFFFFFFull) != 0;
-#pragma unroll
-    for (int s = 16; s > 0; s >>= 1) best = min(best, (unsigned)__shfl_xor((int)best, s));  // inside the half
+    best = st_half_min(best);   // inside the half
     if (in_rows && have_cands && !(maxU < a.p.min_x)) {  // :1213, :1236
         counted = 1;
         const int bestDist = (int)(best >> 16);
@@ -371,8 +402,7 @@ __global__ __launch_bounds__(SR_THREADS) void k_stereo_match_rows(StereoArgs a, 
             const unsigned long long anym = __builtin_amdgcn_ballot_w64(any);
             const bool have_cands = ((anym >> (32 * half)) & 0xFFFFFFFFull) != 0;
             unsigned red = best;
-#pragma unroll
-            for (int s = 16; s > 0; s >>= 1) red = min(red, (unsigned)__shfl_xor((int)red, s));  // inside the half
+            red = st_half_min(red);   // inside the half
             // the x of the winner: keys are distinct (iR is part of them), so exactly one lane of the half holds it
             const unsigned long long own = __builtin_amdgcn_ballot_w64(best == red && red < ((unsigned)TH_HIGH << 16));
             const unsigned ownh = (unsigned)(own >> (32 * half));
@@ -514,8 +544,7 @@ __global__ __launch_bounds__(256) void k_stereo_match_sad(SadArgs A)
                 best = min(best, (dist << 16) | (oi & 0xFFFF));
             }
         }
-#pragma unroll
-        for (int s = 32; s > 0; s >>= 1) best = min(best, (unsigned)__shfl_xor((int)best, s));
+        best = st_wave_min(best);
         const int bestDist = (int)(best >> 16), bestIdxR = (int)(best & 0xFFFF);
         if (bestDist < (TH_HIGH + TH_LOW) / 2) {  // :973
             const int lvl = L.octave;
@@ -548,9 +577,7 @@ __global__ __launch_bounds__(256) void k_stereo_match_sad(SadArgs A)
                     }
                 }
 #pragma unroll
-                for (int k = 0; k < 11; k++)
-#pragma unroll
-                    for (int s = 32; s > 0; s >>= 1) acc[k] += __shfl_xor(acc[k], s);
+                for (int k = 0; k < 11; k++) acc[k] = st_wave_sum(acc[k]);
                 int sadBest = 2147483647, bestinc = 0;
 #pragma unroll
                 for (int k = 0; k < 11; k++)
