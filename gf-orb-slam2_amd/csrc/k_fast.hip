@@ -3,8 +3,9 @@
 // cv::FAST / FAST_t<16> (in-tree mirror: FAST_NEON.cc:91-287).
 //
 // One wavefront owns one 30-px cell (+6 px overlap, +3 px ring halo): the cell's pixels are
-// staged in LDS once (aligned dword loads) and the wave runs a filter cascade with WAVE-LEVEL
-// COMPACTION between the stages, so the expensive stages run with all 64 lanes busy:
+// staged in LDS once (the tile starts one byte left of the cell, so that the scan columns fall on aligned LDS dwords) and
+// the wave runs a filter cascade with WAVE-LEVEL COMPACTION between the stages, so the expensive stages run with all 64
+// lanes busy:
 //   A  every pixel      : compass test -- a 9-arc of the 16-ring holds a pixel of every opposite pair, so
 //                         (ring 0 or 8) and (ring 4 or 12) must both be beyond the threshold (5 LDS reads)
 //   B  survivors of A   : the score S = max over the sixteen 9-arcs of min |v - ring| (common sign); a pixel
@@ -17,9 +18,9 @@
 // so "compare against the score buffer of corners at threshold t" (FAST_NEON.cc:268-285) is
 // "strict local maximum of S" -- one suppression pass serves both thresholds (FAST).
 // A cell that finds no maximum at iniThFAST repeats the WHOLE cascade at minThFAST -- half the cells of real indoor
-// imagery do (the reference's EuRoC frames: k_fast 198 us per 128 images against 156 on the synthetic stream).  Two ways
-// of sparing such a cell work were built in round 3, parity-green, and measured slower on BOTH streams (same-box A/B,
-// tools/ab_fast.sh):
+// imagery do (the reference's EuRoC frames: k_fast 166 us per 128 images against 140 on the synthetic stream; 198 against
+// 156 before the round-3 instruction cuts below, which pay twice in a repeating cell).  Two ways of sparing such a cell work
+// were built earlier in round 3, parity-green, and measured slower on BOTH streams (same-box A/B, tools/ab_fast.sh):
 //   * both thresholds tested in the one stage-A pass, the minThFAST-only pass bits kept as an LDS bitmap that the second
 //     round merely compacts: +8 vector instructions per stage-A iteration for EVERY cell and 1.5 KB more LDS per wave
 //     (27 -> 21 waves per CU): synthetic 156 -> 176 us, EuRoC 198 -> 200 us;
@@ -28,7 +29,11 @@
 //     pixels with minTh < S <= iniTh too), EuRoC 198 -> 205 us.
 // The premise was wrong: a cell repeats BECAUSE it has next to no pixels that pass at iniThFAST, so there is nothing to
 // avoid re-scoring -- its cost is the second round's own work on ~290 weak candidates (25 % of its pixels pass the
-// compass test at threshold 7), which no bookkeeping in the first round reduces.
+// compass test at threshold 7), which no bookkeeping in the first round reduces; what does reduce it is a cheaper cascade.
+// Round 3's cuts (674 -> 514 vector instructions per cell, 156 -> 140 us per 128 images): aligned scan columns (4 stage-A
+// passes per cell instead of 5), pass bits tested where the packed arithmetic leaves them, the score from the eight odd
+// 8-runs (23 packed operations instead of 40), signed differences by one packed multiply-add per ring word, vote masks kept
+// scalar, and the lane -> (row, column) maps precomputed per cell by plan() instead of divided out by every wave.
 // Queue entries are 16 bit: px | py << 6, the local-maximum flag in bit 15.
 // One cell per (single-wave) workgroup -- a cell's slot is free again the moment its wave ends; all levels of all
 // images are ONE launch.
@@ -72,13 +77,12 @@ __device__ __forceinline__ unsigned rot16(unsigned a)
 }
 
 // Score of a pixel = max over the sixteen 9-arcs of min(sign * d) (sign = +1 dark, -1 bright), computed with two
-// ring positions (k, k+8) per register in packed i16: the arc minima for k and k+8 come out of one op.  The
-// differences are formed packed as well: (r[k], r[k+8]) is one v_lshl_or, centre minus ring one v_pk_sub, and
-// the polarity one v_pk_mul by (+-1, +-1).
+// ring positions (k, k+8) per register in packed i16: the arc minima for k and k+8 come out of one op.  The ring word
+// (r[k], r[k+8]) is one v_lshl_or; the signed difference sign * (v - r) one packed multiply-add.
 // Survivors of the compass test: score directly.  corner(t) <=> S > t, so the exact 9-contiguous test and the
 // score are one computation (the packed arc minima); the polarity to score comes from the compass pixels
-// themselves -- a 9-arc holds a pixel of each opposite pair, so a dark arc needs (d0 or d8) and (d4 or d12)
-// above t, a bright arc the mirror image.  Where both hold, the all-eight-pairs test picks the one polarity that
+// themselves -- a 9-arc holds a pixel of each opposite pair, so a dark arc needs (r0 or r8) and (r4 or r12)
+// below v - t, a bright arc the mirror image.  Where both hold, the all-eight-pairs test picks the one polarity that
 // can still be a corner (below).
 template <int TP>
 __device__ __forceinline__ int corner_score(const uint8_t* __restrict__ tl, int tq, unsigned long long& m_run)
