@@ -272,6 +272,11 @@ int gfo_plan(gfo_ctx* c, int w, int h, int batch)
     // k_fast is instantiated for (48/44, 64/60, 80/76: tile / score-map pitch).
     g.fast_tile_pitch = max_cw <= 45 ? 48 : (max_cw <= 61 ? 64 : 80);
     g.fast_npx_max = (int)align_up((long long)(max_cw - 6) * (max_ch - 6), 8);
+    {
+        const int qcap_env = getenv("GFO_FAST_QCAP") ? atoi(getenv("GFO_FAST_QCAP")) : 0;   // read per plan: tests force a small queue (>= 264) to reach the overflow paths
+        const int qc = qcap_env >= 264 ? (qcap_env & ~7) : GFO_FAST_QCAP;   // (264: a pass of 256 pixels must fit; at that size nearly every cell takes the dense pass)
+        g.fast_q_cap = g.fast_npx_max < qc ? g.fast_npx_max : qc;
+    }
     g.fast_tile_rows = max_ch;
     g.fast_smap_pitch = g.fast_tile_pitch - 4;
     g.fast_smap_rows = (int)align_up((long long)(max_ch - 6 + 2) * g.fast_smap_pitch, 16) / g.fast_smap_pitch + 1;  // zeroed in 16-B steps

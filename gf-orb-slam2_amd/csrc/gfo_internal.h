@@ -15,6 +15,9 @@
 #define GFO_HALF_PATCH 15    // HALF_PATCH_SIZE, ORBextractor.cc:73
 #define GFO_PATCH 31         // PATCH_SIZE, ORBextractor.cc:72
 #define GFO_MIN_BORDER 16    // EDGE_THRESHOLD-3, ORBextractor.cc:775
+#ifndef GFO_FAST_QCAP
+#define GFO_FAST_QCAP 768       // k_fast: queue entries per wave (a stage-A pass adds up to 256)
+#endif
 #define GFO_FAST_XOFF 1       // k_fast: the LDS tile starts this many bytes left of the cell (scan column 0 at tile column 4)
 #define GFO_CELL_W 30        // W, ORBextractor.cc:771
 #define GFO_CNT_STRIDE 32     // ints between per-(image,level) candidate counters: one 128-B line each,
@@ -67,7 +70,8 @@ struct GfoGeom {
     int kp_stride;            // per image output capacity (>= total_sel_cap)
     int ini_th, min_th;
     int fast_tile_pitch, fast_tile_rows, fast_smap_pitch, fast_smap_rows; // LDS plan per wave
-    int fast_npx_max;         // largest scan area of a cell (queue capacity), multiple of 8
+    int fast_npx_max;         // largest scan area of a cell, multiple of 8
+    int fast_q_cap;           // entries of a wave's survivor / corner queue: min(fast_npx_max, GFO_FAST_QCAP)
     long long pyr_img_stride;   // bytes per image of levels 1..L-1
     long long blur_img_stride;  // bytes per image of blurred levels 0..L-1
     long long cand_img_stride;  // u32 elements per image

@@ -183,7 +183,14 @@ __global__ __launch_bounds__(256) void k_fast(const GfoGeom* __restrict__ gp, Gf
     if (XCD8 && img >= nimg) return;   // the last group of 8 may be partly empty
     const int cell = (int)(XCD8 ? blockIdx.x >> 3 : blockIdx.x) * (int)(blockDim.x >> 6) + wave;
     const int tile_bytes = TP * g.fast_tile_rows, smap_bytes = (SP * g.fast_smap_rows + 15) & ~15;
-    const int per_wave = tile_bytes + smap_bytes + 2 * g.fast_npx_max;  // one u16 queue, compacted in place
+    // one u16 queue, compacted in place.  It holds fast_q_cap entries, not the cell's whole scan area: 768 instead of up to
+    // 1224 is what lets 32 waves instead of 27 share a CU's LDS (the kernel is bound by wave latency x occupancy: truncated
+    // after the tile load it still takes a third of its time, tools/fast_phase_times.sh).  A cell that would overflow it
+    // (noise-like imagery) scores what it has queued before it queues more, and drops the corner list for a dense pass over
+    // the score map if even the corners do not fit (below).
+    const int q_cap = g.fast_q_cap;
+    const bool q_capped = q_cap < g.fast_npx_max;                        // wave-uniform
+    const int per_wave = tile_bytes + smap_bytes + 2 * q_cap;
     uint8_t* tile = lds + wave * per_wave;
     uint8_t* smap = tile + tile_bytes;
     unsigned short* qa = reinterpret_cast<unsigned short*>(smap + smap_bytes);
@@ -266,12 +273,36 @@ __global__ __launch_bounds__(256) void k_fast(const GfoGeom* __restrict__ gp, Gf
     int total = 0, nb = 0;
     for (int round = 0; round < 2; round++) {
     const int tq = round == 0 ? g.ini_th : g.min_th;
+    int na = 0;
+    bool dense = false;   // wave-uniform: the corner list was dropped (it outgrew the queue); the suppression pass reads the score map densely
+    nb = 0;
+    // ---- B: score S of the queued survivors [from, na) (corner <=> S > threshold), written to the cell's score map; the corners
+    //         are compacted into qb behind the corners already there ----
+    auto score_queued = [&](int from) {
+        const unsigned short* qr = qa + from + lane;
+        for (int i0 = from; i0 < na; i0 += 64, qr += 64) {
+            // which lanes hold a queue entry is known to the scalar unit
+            const int rem = na - i0;
+            const unsigned long long m_in = rem >= 64 ? ~0ull : (1ull << rem) - 1ull;
+            int p = 0;
+            if (__builtin_amdgcn_inverse_ballot_w64(m_in)) p = *qr;
+            const int py = p >> 6, px = p & 63;
+            unsigned long long m_run;
+            const int sc = corner_score<TP>(tile + py * TP + px, tq, m_run);   // every lane (idle ones re-score pixel 0: wave votes inside)
+            const unsigned long long m = __builtin_amdgcn_ballot_w64(sc > tq) & m_in & m_run;   // corners
+            unsigned short* qw = qb + nb;
+            if (__builtin_amdgcn_inverse_ballot_w64(m)) {
+                smap[(py + 1) * SP + px + 1] = (uint8_t)sc;
+                if (!dense) qw[__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u))] = (unsigned short)p;
+            }
+            nb += __popcll(m);
+        }
+    };
     // ---- A: compass test over every scan pixel, compacted into qa ----
     // A lane takes one aligned dword (4 pixels) of a tile row: centre, the rows 3 above/below and the
     // dwords left/right come in as five LDS dword reads, and the "second largest / second smallest of the
     // four compass differences" network runs on packed i16 (even and odd bytes of the dword), so four
     // pixels cost ~40 VALU operations instead of ~100.
-    int na = 0;
     {
         const uint32_t* t32 = reinterpret_cast<const uint32_t*>(tile);
         const int tp4 = TP >> 2;
@@ -294,6 +325,19 @@ __global__ __launch_bounds__(256) void k_fast(const GfoGeom* __restrict__ gp, Gf
         int idx = (lr + 3) * tp4 + 1 + lq;
         int p0 = (lr << 6) + c0;                       // queue entry of the dword's pixel 0: px | py << 6 (cells are at most 64 px wide)
         for (int y0 = 0; y0 < sh; y0 += rpi, idx += rpi * tp4, p0 += rpi << 6) {
+            if (q_capped && na + 256 > q_cap) {
+                // a pass queues up to 256 pixels: make room first -- score what is queued (its corners stay, compacted, at the
+                // front), and if the corners alone leave no room either, drop the list: the score map holds everything the
+                // suppression pass needs, at the price of walking it pixel by pixel
+                wave_sync();
+                score_queued(dense ? 0 : nb);
+                wave_sync();
+                na = dense ? 0 : nb;
+                if (!dense && nb + 256 > q_cap) {
+                    dense = true;
+                    na = 0;
+                }
+            }
             // the pass bits stay where the packed arithmetic leaves them: the sign bits of the two halves of t_e (pixels 0, 2)
             // and of t_o (pixels 1, 3) -- round 2 gathered them into one word first (mask, shift, or, mask: six operations)
             unsigned t_e = 0, t_o = 0;
@@ -343,29 +387,7 @@ __global__ __launch_bounds__(256) void k_fast(const GfoGeom* __restrict__ gp, Gf
 #ifdef GFO_FAST_DEBUG
     if (dbg_stop == 2) { if (na == 12345) flags[1] = 1; return; }
 #endif
-    // ---- B: score S of the survivors (corner <=> S > threshold), written to the cell's score map; the corners
-    //         are compacted into qb ----
-    nb = 0;
-    {
-        const unsigned short* qr = qa + lane;
-        for (int i0 = 0; i0 < na; i0 += 64, qr += 64) {
-            // which lanes hold a queue entry is known to the scalar unit
-            const int rem = na - i0;
-            const unsigned long long m_in = rem >= 64 ? ~0ull : (1ull << rem) - 1ull;
-            int p = 0;
-            if (__builtin_amdgcn_inverse_ballot_w64(m_in)) p = *qr;
-            const int py = p >> 6, px = p & 63;
-            unsigned long long m_run;
-            const int sc = corner_score<TP>(tile + py * TP + px, tq, m_run);   // every lane (idle ones re-score pixel 0: wave votes inside)
-            const unsigned long long m = __builtin_amdgcn_ballot_w64(sc > tq) & m_in & m_run;   // corners
-            unsigned short* qw = qb + nb;
-            if (__builtin_amdgcn_inverse_ballot_w64(m)) {
-                smap[(py + 1) * SP + px + 1] = (uint8_t)sc;
-                qw[__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u))] = (unsigned short)p;
-            }
-            nb += __popcll(m);
-        }
-    }
+    score_queued(dense ? 0 : nb);   // (after a flush the corners so far sit in [0, nb), the unscored survivors behind them)
     wave_sync();
 #ifdef GFO_FAST_DEBUG
     if (dbg_stop == 3) { if (nb == 12345) flags[1] = 1; return; }
@@ -378,11 +400,20 @@ __global__ __launch_bounds__(256) void k_fast(const GfoGeom* __restrict__ gp, Gf
     int n_max = 0;
     uint32_t* keyq = reinterpret_cast<uint32_t*>(tile);
     const unsigned short* qn = qb + lane;
-    for (int i0 = 0; i0 < nb; i0 += 64, qn += 64) {
-        const int rem = nb - i0;
-        const unsigned long long m_in = rem >= 64 ? ~0ull : (1ull << rem) - 1ull;
+    // list form: the corners are in qb; dense form (the list was dropped): one scan row per step, lane = column (sw <= 64),
+    // a pixel takes part if its stored score is above the threshold
+    const int n_steps = dense ? 64 * sh : nb;
+    for (int i0 = 0; i0 < n_steps; i0 += 64, qn += 64) {
+        unsigned long long m_in;
         int p = 0;
-        if (__builtin_amdgcn_inverse_ballot_w64(m_in)) p = *qn;
+        if (dense) {
+            p = ((i0 >> 6) << 6) | min(lane, sw - 1);
+            m_in = sw >= 64 ? ~0ull : (1ull << sw) - 1ull;
+        } else {
+            const int rem = nb - i0;
+            m_in = rem >= 64 ? ~0ull : (1ull << rem) - 1ull;
+            if (__builtin_amdgcn_inverse_ballot_w64(m_in)) p = *qn;
+        }
         // every lane (idle ones look at pixel 0): no branch around the body, the vote is masked in the scalar unit
         const int py = p >> 6, px = p & 63;
         const uint8_t* q = smap + (py + 1) * SP + px + 1;
@@ -425,7 +456,7 @@ void gfo_launch_fast(gfo_ctx* c, const GfoInput& in, int nimg)
     // A/B: they leave more of a CU to the other contexts' kernels); not worth 6 us of the kernel's own time.
     static const int nw_env = getenv("GFO_FAST_WAVES") ? atoi(getenv("GFO_FAST_WAVES")) : 0;
     const int nw = nw_env >= 1 && nw_env <= 4 ? nw_env : 1;
-    const size_t lds = nw * (size_t)(g.fast_tile_pitch * g.fast_tile_rows + ((g.fast_smap_pitch * g.fast_smap_rows + 15) & ~15) + 2 * g.fast_npx_max);
+    const size_t lds = nw * (size_t)(g.fast_tile_pitch * g.fast_tile_rows + ((g.fast_smap_pitch * g.fast_smap_rows + 15) & ~15) + 2 * g.fast_q_cap);
     const int cell_blocks = (g.total_cells + nw - 1) / nw;
     // one image per XCD from 8 images up (below that, 7 of 8 workgroups would be empty: plain grid)
     static const int xcd_env = getenv("GFO_FAST_XCD") ? atoi(getenv("GFO_FAST_XCD")) : 1;

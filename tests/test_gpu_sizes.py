@@ -220,3 +220,30 @@ def test_large_level_quota_runs_from_global_memory(oracle, nf, nl, w, h):
     assert n > 500
     _same(ext, oracle.OracleExtractor(nf, 1.2, nl, 20, 7), synth_frame(w, h, 77))
     ext.close()
+
+
+@pytest.mark.parametrize("qcap", [None, 512, 264])
+def test_fast_queue_overflow_paths(oracle, monkeypatch, qcap):
+    """k_fast keeps fewer queue entries than a cell has pixels (768, or GFO_FAST_QCAP read when the arena is planned): a cell
+    of noise-like imagery must score what it has queued before it queues more (flush), and drop the corner list for the
+    dense suppression pass when even its corners do not fit.  White noise at thresholds 1 / 1 passes most pixels through the
+    compass test; saturated blocks add plateaus of equal scores.  A queue of 512 entries forces the flush in most cells, one of
+    264 (a single pass of 256 pixels) the dense pass in nearly all of them."""
+    import gf_orb_slam2_amd as G
+    if qcap:
+        monkeypatch.setenv("GFO_FAST_QCAP", str(qcap))
+    rng = np.random.default_rng(123)
+    noise = rng.integers(0, 256, (300, 420), dtype=np.uint8)
+    blocks = noise.copy()
+    blocks[40:120, 60:200] = 255
+    blocks[150:260, 220:400] = rng.integers(120, 136, (110, 180), dtype=np.uint8)
+    for ini, mn in ((1, 1), (7, 2), (40, 3)):
+        ext = G.ORBextractor(3000, 1.2, 6, ini, mn)
+        oe = oracle.OracleExtractor(3000, 1.2, 6, ini, mn)
+        assert _same(ext, oe, noise) > 0
+        _same(ext, oe, blocks)
+        for l in range(6):
+            oc = sorted(map(tuple, oe.level_candidates(l).tolist()))
+            gc = sorted(map(tuple, ext.debug_level_candidates(l).tolist()))
+            assert gc == oc, f"FAST candidates differ at level {l} (thresholds {ini}/{mn}, queue {qcap})"
+        ext.close()
