@@ -455,14 +455,18 @@ int gfo_plan(gfo_ctx* c, int w, int h, int batch)
                         if (!e[1] || !e[2]) return fail(c, GFO_ERR_INVALID, "FAST cell of %d px exceeds the per-wave plan", cw - 6);
                     }
                 }
-        // behind the cells: the keypoint-pair table of k_orient_desc, one int per wavefront of an image: level | pair << 4 --
+        // behind the cells: the keypoint-pair table of k_orient_desc, two ints per wavefront of an image: level | pair << 4 and the level's sel_off --
         // a wave owns selection slots (2 * pair, 2 * pair + 1) of ONE level, so everything that depends on the level is
         // wave-uniform there; -1 pads the table to whole workgroups
+        if (cells.size() & 1) cells.push_back(0);   // (the pair table is read as int2)
         const size_t od_base = cells.size();
         for (int l = 0; l < g.nlevels; l++)
-            for (int pr = 0; pr < (g.lv[l].sel_cap + 1) / 2; pr++) cells.push_back(l | (pr << 4));
-        c->od_pairs = (int)(cells.size() - od_base);
-        for (int k = 0; k < 16; k++) cells.push_back(-1);
+            for (int pr = 0; pr < (g.lv[l].sel_cap + 1) / 2; pr++) {
+                cells.push_back(l | (pr << 4));
+                cells.push_back(g.lv[l].sel_off);    // the level's first selection slot: the kernel requests a pair's selection words without looking the level up
+            }
+        c->od_pairs = (int)((cells.size() - od_base) / 2);
+        for (int k = 0; k < 16; k++) { cells.push_back(-1); cells.push_back(0); }
         HIP_TRY(c, hipMalloc(&c->d_cell_tab, cells.size() * sizeof(int)));
         HIP_TRY(c, hipMemcpy(c->d_cell_tab, cells.data(), cells.size() * sizeof(int), hipMemcpyHostToDevice));
         c->d_od_tab = c->d_cell_tab + od_base;

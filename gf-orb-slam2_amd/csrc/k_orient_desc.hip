@@ -86,7 +86,17 @@ __device__ __forceinline__ int half_sum(int v)
 #ifndef OD_WAVES
 #define OD_WAVES 4   // waves per workgroup, 2 keypoints each (2-wave workgroups measured 5 % slower)
 #endif
-__global__ __launch_bounds__(64 * OD_WAVES) void k_orient_desc(const GfoGeom* __restrict__ gp, GfoInput in,
+// What the head of a wave needs before its first pixel load, BY VALUE in the kernel arguments (one scalar round trip): truncated
+// after its selection word the kernel still took 97 of its 240 us per 256 images -- the per-level counts were read one dependent
+// scalar load after the other through the geometry pointer, and the 16-byte table loads had to land in LDS before the selection
+// word was even requested (tools: -DOD_STOP=n, profiles/orient_phase_times_r03.txt).
+struct OdK {
+    int nlevels, kp_stride;
+    long long total_sel_cap;
+    int sel_cap[GFO_MAX_LEVELS];
+};
+
+__global__ __launch_bounds__(64 * OD_WAVES) void k_orient_desc(const GfoGeom* __restrict__ gp, OdK ok, GfoInput in,
                                                      const uint8_t* __restrict__ pyr, const uint8_t* __restrict__ blur,
                                                      const uint32_t* __restrict__ sel, const int* __restrict__ sel_cnt,
                                                      gfo_keypoint* __restrict__ kp_out, uint8_t* __restrict__ desc_out,
@@ -138,38 +148,60 @@ __global__ __launch_bounds__(64 * OD_WAVES) void k_orient_desc(const GfoGeom* __
     // level and everything derived from it -- plane pointers, pitch, scale, the output row of slot 0 -- live in scalar
     // registers.  (Round 2 walked the compacted output rows and let each half of the wave search its level in the count
     // prefix: 8 levels x 4 selects per wave, and every address 64-bit per lane.)
-    const int pe = __builtin_amdgcn_readfirstlane(od_tab[blk * OD_WAVES + wave]);
+    // table of plan(), two ints per wave: level | pair << 4, and the level's first selection slot (sel_off): the selection word
+    // can be requested as soon as these and the counts are there, without a look at the level's geometry entry
+    const int2 pe2 = reinterpret_cast<const int2*>(od_tab)[blk * OD_WAVES + wave];
+    const int pe = __builtin_amdgcn_readfirstlane(pe2.x), sel_off = __builtin_amdgcn_readfirstlane(pe2.y);
     const int level = pe & 15, pair = pe >> 4;
     // per-level counts (wave-uniform); output rows are level by level, list order inside a level (:1144-1161)
     // (counts are clamped to the slots a level owns: a selection that was never written cannot send this kernel
-    //  outside its buffers)
+    //  outside its buffers).  All of them are requested together (a loop over g.nlevels compiled into one dependent scalar
+    //  load per level: ~2 us at the head of every wave).
     int total = 0, prefix = 0, cnt = 0;
-    for (int l = 0; l < g.nlevels; l++) {
-        const int c = min(max(sel_cnt[img * g.nlevels + l], 0), g.lv[l].sel_cap);
-        prefix += l < level ? c : 0;
-        cnt = l == level ? c : cnt;
-        total += c;
-    }
-    if (64 * OD_WAVES == 256) {
-        reinterpret_cast<uint4*>(s_pat)[threadIdx.x] = tab_p;
-        if (threadIdx.x < 4 * OD_AW_ROWS) *reinterpret_cast<uint4*>(&s_aw[threadIdx.x >> 2][4 * (threadIdx.x & 3)]) = tab_w;
-    } else {
-        for (int t = threadIdx.x; t < 256; t += 64 * OD_WAVES) reinterpret_cast<uint4*>(s_pat)[t] = reinterpret_cast<const uint4*>(k_pattern)[t];
-        for (int t = threadIdx.x; t < 4 * OD_AW_ROWS; t += 64 * OD_WAVES) *reinterpret_cast<uint4*>(&s_aw[t >> 2][4 * (t & 3)]) = reinterpret_cast<const uint4*>(k_angle_rows.w)[t];
+    {
+        const int nl = ok.nlevels;
+        const int* sc = sel_cnt + img * nl;
+        int craw[GFO_MAX_LEVELS];
+#pragma unroll
+        for (int l = 0; l < GFO_MAX_LEVELS; l++) craw[l] = sc[min(l, nl - 1)];   // (clamped index: never past the image's entries)
+#pragma unroll
+        for (int l = 0; l < GFO_MAX_LEVELS; l++) {
+            const int c = l < nl ? min(max(craw[l], 0), ok.sel_cap[l]) : 0;
+            prefix += l < level ? c : 0;
+            cnt = l == level ? c : cnt;
+            total += c;
+        }
     }
     if (blk == 0 && wave == 0 && lane == 0) {
-        kp_cnt[img] = min(total, g.kp_stride);
-        if (total > g.kp_stride) atomicOr(&flags[0], 8);
+        kp_cnt[img] = min(total, ok.kp_stride);
+        if (total > ok.kp_stride) atomicOr(&flags[0], 8);
     }
-    const int nkp = min(total, g.kp_stride);
+    const int nkp = min(total, ok.kp_stride);
     const int i0 = 2 * pair;
-    if (pe < 0 || i0 >= cnt || prefix + i0 >= nkp) return;   // wave-uniform
+    // the tables' share of this thread goes to LDS: in front of an early exit (every wave of the workgroup must contribute),
+    // otherwise not before this wave's own loads are under way
+    auto store_tables = [&]() {
+        if (64 * OD_WAVES == 256) {
+            reinterpret_cast<uint4*>(s_pat)[threadIdx.x] = tab_p;
+            if (threadIdx.x < 4 * OD_AW_ROWS) *reinterpret_cast<uint4*>(&s_aw[threadIdx.x >> 2][4 * (threadIdx.x & 3)]) = tab_w;
+        } else {
+            for (int t = threadIdx.x; t < 256; t += 64 * OD_WAVES) reinterpret_cast<uint4*>(s_pat)[t] = reinterpret_cast<const uint4*>(k_pattern)[t];
+            for (int t = threadIdx.x; t < 4 * OD_AW_ROWS; t += 64 * OD_WAVES) *reinterpret_cast<uint4*>(&s_aw[t >> 2][4 * (t & 3)]) = reinterpret_cast<const uint4*>(k_angle_rows.w)[t];
+        }
+    };
+    if (pe < 0 || i0 >= cnt || prefix + i0 >= nkp) {   // wave-uniform
+        store_tables();
+        return;
+    }
     const bool act = i0 + half < cnt && prefix + i0 + half < nkp;   // an odd count leaves the last wave's second half idle: it redoes the first keypoint
     const unsigned idx = act ? i0 + half : i0;
     const int slot = prefix + (int)idx;
-    const GfoLevel& L = g.lv[level];
-    const uint32_t* selb = sel + (long long)img * g.total_sel_cap + L.sel_off;   // uniform base, 32-bit lane offset
+    const uint32_t* selb = sel + (long long)img * ok.total_sel_cap + sel_off;   // uniform base, 32-bit lane offset
     const uint32_t key = selb[idx];
+    const GfoLevel& L = g.lv[level];
+#if defined(OD_STOP) && OD_STOP == 1   // tools/ab_variant.sh "-DOD_STOP=n": truncate after a phase (results are wrong by construction)
+    if (key != 0x12345678u) return;
+#endif
     const int x = (int)(key & 0xFFF) + GFO_MIN_BORDER, y = (int)((key >> 12) & 0xFFF) + GFO_MIN_BORDER;  // :845-846
     const int score = (int)(key >> 24);
 
@@ -205,6 +237,7 @@ __global__ __launch_bounds__(64 * OD_WAVES) void k_orient_desc(const GfoGeom* __
         vw1 = *reinterpret_cast<const uint4*>(bl + (wo + (unsigned)(min(10 + rw, DW - 1) * lpitch)));
         vw2 = *reinterpret_cast<const uint4*>(bl + (wo + (unsigned)(min(20 + rw, DW - 1) * lpitch)));
         vw3 = *reinterpret_cast<const uint4*>(bl + (wo + (unsigned)(min(30 + rw, DW - 1) * lpitch)));
+        store_tables();   // (their loads were the first of the kernel: long landed)
         uint4* pl = reinterpret_cast<uint4*>(pat + rw * OWP + 16 * seg);
         // steps 0-2 store unconditionally: every row they touch exists, and the two idle lanes (rw == 10) hold
         // exactly the bytes that lane rw == 0 of the next step writes to the same place; only the last step is
@@ -226,6 +259,9 @@ __global__ __launch_bounds__(64 * OD_WAVES) void k_orient_desc(const GfoGeom* __
     // the tables are complete once every wave that is still running has passed here (a wave that left early stored its
     // share first; finished waves do not count at the barrier)
     __syncthreads();
+#if defined(OD_STOP) && OD_STOP == 2
+    if (key != 0x12345678u) return;
+#endif
     int m10, m01;
     {
         uint32_t aw[16];
@@ -254,6 +290,9 @@ __global__ __launch_bounds__(64 * OD_WAVES) void k_orient_desc(const GfoGeom* __
     m10 = half_sum(m10);
     m01 = half_sum(m01);
     const float angle = gfo_fast_atan2f((float)m01, (float)m10);
+#if defined(OD_STOP) && OD_STOP == 3
+    if (angle != 12345.f) return;
+#endif
 
     // ---- the patch has been read (LDS operations of a wave execute in issue order): the window takes its place ----
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -306,8 +345,11 @@ __global__ __launch_bounds__(64 * OD_WAVES) void k_orient_desc(const GfoGeom* __
                    "s"((unsigned)mk[4]), "s"((unsigned)mk[5]), "s"((unsigned)mk[6]), "s"((unsigned)mk[7]),
                    "s"((unsigned)(mk[0] >> 32)), "s"((unsigned)(mk[1] >> 32)), "s"((unsigned)(mk[2] >> 32)), "s"((unsigned)(mk[3] >> 32)),
                    "s"((unsigned)(mk[4] >> 32)), "s"((unsigned)(mk[5] >> 32)), "s"((unsigned)(mk[6] >> 32)), "s"((unsigned)(mk[7] >> 32)));
+#if defined(OD_STOP) && OD_STOP == 4
+    if (word != 0x12345678u) return;
+#endif
     if (!act) return;
-    const long long o = (long long)img * g.kp_stride + slot;
+    const long long o = (long long)img * ok.kp_stride + slot;
     if (hl < 8) reinterpret_cast<unsigned*>(desc_out + o * 32)[hl] = word;
     if (hl == 0) {
         gfo_keypoint q;
@@ -331,7 +373,10 @@ void gfo_launch_orient_desc(gfo_ctx* c, const GfoInput& in, int nimg)
     const int bpi = (c->od_pairs + OD_WAVES - 1) / OD_WAVES;  // OD_WAVES waves x 2 keypoints per workgroup (the table is padded with -1)
     dim3 grid((unsigned)bpi * 8u, (unsigned)(nimg + 7) / 8u);
     gfo_prof_begin(c, ST_ORIENT_DESC);
-    GFO_LAUNCH(c, k_orient_desc, grid, dim3(64 * OD_WAVES), 0, c->stream, c->d_geom, in, c->d_pyr, c->d_blur, c->d_sel,
+    OdK ok{};
+    ok.nlevels = c->g.nlevels; ok.kp_stride = c->g.kp_stride; ok.total_sel_cap = c->g.total_sel_cap;
+    for (int l = 0; l < c->g.nlevels; l++) ok.sel_cap[l] = c->g.lv[l].sel_cap;
+    GFO_LAUNCH(c, k_orient_desc, grid, dim3(64 * OD_WAVES), 0, c->stream, c->d_geom, ok, in, c->d_pyr, c->d_blur, c->d_sel,
                        c->d_sel_cnt, c->d_kp, c->d_desc, c->d_kp_cnt, c->d_flags, c->d_od_tab, nimg);
     gfo_prof_end(c);
 }
