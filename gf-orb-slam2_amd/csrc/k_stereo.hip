@@ -736,7 +736,15 @@ void gfo_launch_stereo(gfo_ctx* c, const GfoStereoLaunch& s)
     a.lorder = rows_form ? s.sort.lorder : nullptr;
     a.lrow_start = rows_form ? s.sort.lrow_start : nullptr;
     gfo_prof_begin(c, ST_STEREO_BUCKET);
-    GFO_LAUNCH(c, k_stereo_bucket, dim3(s.npairs, rows_form ? 2 : 1), dim3(1024), (size_t)(s.p.n_rows + 256) * sizeof(int), c->stream, a);
+    // threads of the two small per-pair kernels (bucket, cut): 1024 alone is fastest (fewer serial round trips), but a
+    // 1024-thread workgroup needs sixteen free wave slots in ONE CU at once, and in the running pipeline it waits for them behind
+    // the other context's kernels (the launches stretch 4-6 x, profiles/overlap_trace_r03.txt): 512 / 256 threads from 32 pairs on
+    // (1024 / 1024: 278-280 k frames/s, 512 / 256: 281-281.5 k, 256 / 256: 276.5 k; a stereo frame alone keeps 1024)
+    static const int bt_env = getenv("GFO_STEREO_BUCKET_THREADS") ? atoi(getenv("GFO_STEREO_BUCKET_THREADS")) : 0;
+    static const int ct_env = getenv("GFO_STEREO_CUT_THREADS") ? atoi(getenv("GFO_STEREO_CUT_THREADS")) : 0;
+    const int bucket_threads = bt_env == 256 || bt_env == 512 || bt_env == 1024 ? bt_env : (s.npairs >= 32 ? 512 : 1024);
+    const int cut_threads = ct_env == 256 || ct_env == 512 || ct_env == 1024 ? ct_env : (s.npairs >= 32 ? 256 : 1024);
+    GFO_LAUNCH(c, k_stereo_bucket, dim3(s.npairs, rows_form ? 2 : 1), dim3(bucket_threads), (size_t)(s.p.n_rows + 256) * sizeof(int), c->stream, a);
     gfo_prof_end(c);
     gfo_prof_begin(c, ST_STEREO);
     if (rows_form) {
@@ -755,6 +763,6 @@ void gfo_launch_stereo(gfo_ctx* c, const GfoStereoLaunch& s)
     }
     gfo_prof_end(c);
     gfo_prof_begin(c, ST_STEREO_CUT);
-    GFO_LAUNCH(c, k_stereo_cut, dim3(s.npairs), dim3(1024), 0, c->stream, s.cnt_dev, s.nl_host, s.out, s.out_stride);
+    GFO_LAUNCH(c, k_stereo_cut, dim3(s.npairs), dim3(cut_threads), 0, c->stream, s.cnt_dev, s.nl_host, s.out, s.out_stride);
     gfo_prof_end(c);
 }
