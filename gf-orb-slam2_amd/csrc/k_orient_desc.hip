@@ -1,21 +1,26 @@
 // k_orient_desc.hip -- IC_Angle (ORBextractor.cc:76-103), computeOrbDescriptor (:107-146) and
 // the keypoint bookkeeping of ComputeKeyPointsOctTree / operator() (:839-849, 1144-1172).
 //
-// TWO keypoints per wavefront, one per 32-lane half.  The per-keypoint work is a chain of dependent
-// memory accesses (selection word -> window addresses -> window bytes), so the kernel is latency-bound;
-// two independent chains per wave halve the number of waves the same occupancy has to retire.
+// TWO keypoints per wavefront, one per 32-lane half, both of ONE pyramid level (pair table of plan()): level, plane
+// pointers, pitch and the output row's prefix are scalar.  Where the time goes (profiles/orient_phase_times_r03.txt,
+// profiles/vmem_rate_r03.txt): the eight 16-byte window loads per lane -- a vector load costs the texture path ~2.2 clocks
+// per distinct 64-byte chunk it touches, and 68 window rows per keypoint are ~120 of them -- and the rate at which the
+// chip starts waves; the arithmetic below is a tenth of the kernel.
+//   tables     : the 256 test pairs and the disc's row weights enter LDS once per workgroup (16 bytes per thread);
 //   staging    : the 31x31 patch of the level and the 37x37 window of the BLURRED level (the rotated
-//                pattern reaches 18 px) go to LDS as aligned dwords, all loads of a
-//                lane in flight before the first LDS store;
-//   angle      : one disc row per step, 31 lanes of the half; the int32 moments are reduced inside
-//                the half with lane shuffles; fastAtan2 is the shared plain-fp32 polynomial of
-//                include/gfo_sincos.h;
+//                pattern reaches 18 px) go to LDS as aligned 16-byte segments, all loads of a
+//                lane in flight before the first LDS store; patch and window share one LDS region, the window's
+//                bytes wait in registers while the patch is consumed;
+//   angle      : a lane owns a disc ROW: v_dot4_u32_u8 of the row's eight dwords against its moment weights and
+//                membership bytes; the two int32 moments are summed over the half by DPP steps and a ds_swizzle;
+//                fastAtan2 is the plain-fp32 polynomial of include/gfo_sincos.h, sin / cos its double evaluation;
 //   descriptor : each lane evaluates 8 of the 256 pair tests; the half of the wave ballot that belongs
-//                to a keypoint in round r IS its descriptor bytes 4r..4r+3, so the 32 bytes leave as
-//                eight 32-bit words without any bit shuffling.
+//                to a keypoint in round r IS its descriptor bytes 4r..4r+3 -- sixteen v_writelane move the
+//                scalar masks into lanes 0..7 of each half, and the 32 bytes leave as eight 32-bit words.
 // Output rows are laid out level by level, inside a level in list order (:1144-1161).
-// No workgroup barrier is used: each wave owns its LDS window (LDS operations of one wave
-// execute in issue order), so trailing waves may exit early.
+// One workgroup barrier (the tables must be complete before the first wave reads them); otherwise each wave owns its
+// LDS window (LDS operations of one wave execute in issue order), and a wave without work stores its share of the
+// tables and leaves.
 #include "gfo_internal.h"
 // The double-precision coefficients of gfo_sincosf come from a table in memory (scalar loads into register pairs that the
 // fma takes directly) instead of 64-bit literals, each of which is two v_mov per wave: 15 constants, 24 vector instructions.

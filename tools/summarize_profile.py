@@ -76,7 +76,14 @@ def main():
                     # 64 B -- the doubled figure is the upper bound for kernels that load 16 B per lane
                     traffic_x2[st] = traffic_x2.get(st, 0) + (2 * b if cname == "FETCH_SIZE" else b)
                     break
-    meta = {"tag": tag, "workload": os.environ.get("GFO_PROF_WORKLOAD", "stereo752"), "batch": int(os.environ.get("GFO_PROF_BATCH", "128")),
+    # images per launch: what the traced bench line says (bench.py compares it with its own batch before it uses the file)
+    batch = int(os.environ.get("GFO_PROF_BATCH", "256"))
+    try:
+        bl = [l for l in open(os.path.join(src, "bench_trace.log")).read().splitlines() if l.startswith("{")]
+        batch = int(json.loads(bl[-1])["config"]["images_per_step_per_gpu"])
+    except Exception:
+        pass
+    meta = {"tag": tag, "workload": os.environ.get("GFO_PROF_WORKLOAD", "stereo752"), "batch": batch,
             "hbm_bytes_per_launch": traffic, "hbm_bytes_per_launch_fetch_x2": traffic_x2,
             "note": "FETCH_SIZE+WRITE_SIZE (KiB) x 1024, separate --pmc passes, averaged per launch; *_fetch_x2 doubles FETCH_SIZE "
                     "(gfx950 counts a 16-B-per-lane streaming read at half its bytes: k_fast and k_orient_desc load 16 B per lane)"}
