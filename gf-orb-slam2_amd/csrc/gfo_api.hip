@@ -148,7 +148,7 @@ static void free_arena(gfo_ctx* c)
         if (p) (void)hipFree(p);
     c->d_geom = nullptr; c->d_input = c->d_pyr = c->d_blur = nullptr; c->d_cand = nullptr; c->d_cand_cnt = nullptr;
     c->d_node_of = nullptr; c->d_sel = nullptr; c->d_sel_cnt = nullptr; c->d_kp = nullptr; c->d_desc = nullptr;
-    c->d_kp_cnt = nullptr; c->d_flags = nullptr; c->d_xofs = nullptr; c->d_xcoef = nullptr; c->d_yofs = nullptr; c->d_band = nullptr; c->d_cell_tab = nullptr; c->d_qt_scratch = nullptr;
+    c->d_kp_cnt = nullptr; c->d_flags = nullptr; c->d_xofs = nullptr; c->d_xcoef = nullptr; c->d_yofs = nullptr; c->d_band = nullptr; c->d_cell_tab = nullptr; c->d_od_tab = nullptr; c->od_pairs = 0; c->d_qt_scratch = nullptr;
     c->d_ycoef = nullptr; c->st = GfoStereoDev{}; c->d_scale = nullptr; c->d_inv_scale = nullptr; c->st_sort = GfoStereoSort{}; c->st_rows_cap = 0;
     c->planned = false;
     c->have_batch = c->have_pyramid = c->have_stereo = false;
