@@ -3,6 +3,7 @@
 kernel and the CPU oracle timed beside it.
 
   python bench.py --gpus 1 --steps 20 --warmup 3
+  python bench.py --gpus 8 --steps 20 --warmup 3        (no launcher: this process starts the 8 ranks itself, spawn_ranks())
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
          --master-port P bench.py --gpus N --steps K --warmup W
 
@@ -335,6 +336,80 @@ def cpu_baseline(w, h, nfeatures, stereo, budget_s=10.0):
             "reference_published": "13.7-22.2 ms per stereo frame on unstated hardware (README.md:7-16) = 90-146 images/s"}
 
 
+def spawn_ranks(n, argv, selftest=False):
+    """`python bench.py --gpus N` without a launcher (no WORLD_SIZE in the environment): this process -- which has not
+    imported torch and never touches the GPU -- starts N fresh child processes of this same command, one per GPU, with
+    RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT set (what torch.distributed.run would have set), relays
+    rank 0's single JSON line, and exits non-zero if any rank does.  No exec anywhere: the children are ordinary
+    subprocesses, each a session of its own so that the whole rank can be killed as a group when a bound is hit
+    (GFO_BENCH_SPAWN_TIMEOUT seconds, default 900) or when a sibling has failed (the survivors would otherwise wait in
+    a collective forever)."""
+    import signal
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    bound = float(os.environ.get("GFO_BENCH_SPAWN_TIMEOUT", "900"))
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), GROUP_RANK="0",
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), GFO_BENCH_SPAWNED="1")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: RCCL across processes needs it on this driver
+        cmd = [sys.executable, os.path.abspath(__file__)] + list(argv) + (["--spawn-selftest"] if selftest else [])
+        # rank 0's stdout carries the line; the other ranks print nothing on stdout by contract, and if they do it goes to stderr
+        procs.append(subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE if r == 0 else sys.stderr, start_new_session=True))
+
+    def kill_all():
+        for p in procs:
+            if p.poll() is None:
+                try:
+                    os.killpg(p.pid, signal.SIGKILL)
+                except OSError:
+                    pass
+        for p in procs:
+            try:
+                p.wait(timeout=10)
+            except Exception:
+                pass
+
+    import threading
+    out0 = []
+    reader = threading.Thread(target=lambda: out0.extend(procs[0].stdout.read().decode(errors="replace").splitlines()), daemon=True)
+    reader.start()
+    t0, failed = time.monotonic(), None
+    try:
+        while any(p.poll() is None for p in procs):
+            bad = [(r, p.returncode) for r, p in enumerate(procs) if p.poll() is not None and p.returncode != 0]
+            if bad:
+                failed = f"rank {bad[0][0]} exited with code {bad[0][1]}"
+                break
+            if time.monotonic() - t0 > bound:
+                failed = f"ranks still running after {bound:.0f} s (GFO_BENCH_SPAWN_TIMEOUT)"
+                break
+            time.sleep(0.05)
+    finally:
+        if failed or any(p.poll() is None for p in procs):
+            kill_all()
+    reader.join(timeout=10)
+    bad = [(r, p.returncode) for r, p in enumerate(procs) if p.returncode != 0]
+    if failed is None and bad:
+        failed = f"rank {bad[0][0]} exited with code {bad[0][1]}"
+    lines = [l for l in out0 if l.startswith("{")]
+    for l in lines:
+        print(l, flush=True)
+    if os.environ.get("GFO_BENCH_PARENT_REPORT"):      # tests: what this launcher process itself has loaded
+        print("parent_modules " + json.dumps(sorted(m for m in sys.modules if m.split(".")[0] in ("torch", "gf_orb_slam2_amd", "oracle"))),
+              file=sys.stderr, flush=True)
+    if failed:
+        print(f"bench.py --gpus {n}: {failed}", file=sys.stderr, flush=True)
+        return 1
+    if len(lines) != 1:
+        print(f"bench.py --gpus {n}: rank 0 printed {len(lines)} JSON lines, expected 1", file=sys.stderr, flush=True)
+        return 1
+    return 0
+
+
 class Job:
     """One workload on this rank: input batches resident in HBM, `nctx` independent contexts (arena + HIP stream)
     the steps alternate between, so the tail of one batch overlaps the head of the next."""
@@ -566,7 +641,25 @@ def main():
                          "0 = never -- separates straggler coupling between ranks from kernel time on a real node)")
     ap.add_argument("--no-boundary", action="store_true", help="skip the per-frame boundary harness (per_frame_boundary)")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)   # internal: the pass live_traffic() profiles
+    ap.add_argument("--spawn-selftest", action="store_true", help=argparse.SUPPRESS)   # tests: ranks report their environment and exit (no GPU)
     args = ap.parse_args()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and "RANK" not in os.environ and args.gpus > 1:
+        # no launcher around this command: be the launcher (before torch is imported, before anything touches the GPU)
+        argv = [a for a in sys.argv[1:] if a != "--spawn-selftest"]
+        sys.exit(spawn_ranks(args.gpus, argv, selftest=args.spawn_selftest))
+    if args.spawn_selftest:
+        info = {"spawn_selftest": True, "rank": int(os.environ.get("RANK", "0")), "local_rank": int(os.environ.get("LOCAL_RANK", "0")),
+                "world": int(os.environ.get("WORLD_SIZE", "1")), "master": f"{os.environ.get('MASTER_ADDR')}:{os.environ.get('MASTER_PORT')}",
+                "gpus_arg": args.gpus, "torch_loaded": "torch" in sys.modules}
+        if os.environ.get("GFO_BENCH_SELFTEST_FAIL_RANK") == os.environ.get("RANK", "0"):
+            sys.exit(7)
+        if info["rank"] == 0:
+            print(json.dumps(info), flush=True)
+        else:
+            print(json.dumps(info), file=sys.stderr, flush=True)
+        return
     if os.environ.get("GFO_BENCH_WATCHDOG"):      # diagnosis of a stalled run: dump every thread's stack after N seconds and exit
         import faulthandler
         faulthandler.dump_traceback_later(float(os.environ["GFO_BENCH_WATCHDOG"]), exit=True)
@@ -574,6 +667,8 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world} in the environment: running {world} ranks (n_gpus reports {world})", file=sys.stderr)
     # the PMC passes run first, as children, while this process has not touched the GPU yet
     live, live_note = None, "live measurement off (opt in with --live-traffic)"
     if world == 1 and args.live_traffic and not args.pmc_child:
@@ -654,11 +749,20 @@ def main():
     if rank == 0:
         n_kp_img, roof = job.roofline(prof, args.profile_steps, value / world, args.workload, live, live_note)
         stereo = job.matcher == "stereo"
+        # did the collective see N ranks?  the output of the LAST count all-gather of the timed region, cut into B-sized
+        # segments (one per rank, zero-initialised): a rank that did not take part leaves its segment at zero
+        coll = None
+        if world > 1:
+            segs = [int((g.view(world, B) != 0).any(dim=1).sum().item()) for g in job.gathered if g is not None]
+            coll = {"backend": dist.get_backend(), "world_size": dist.get_world_size(), "gathered_elements": int(job.gathered[0].numel()),
+                    "elements_per_rank": B, "ranks_with_counts": min(segs) if args.gather_every else None,
+                    "launcher": "bench.py spawn_ranks" if os.environ.get("GFO_BENCH_SPAWNED") else "external (torch.distributed.run)"}
         line = {
             "metric": "frames/sec ORB extract+match, 752x480 @2000 kp" if args.workload == "stereo752" else f"frames/sec ORB {args.workload}",
             "value": round(value, 1), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+            "rccl_ranks": (coll["ranks_with_counts"] if coll else 1), "collective": coll,
             "config": {"workload": job.cfg_name, "frame": "one camera image (a stereo pair = 2 frames + 1 association)",
                        "images_per_step_per_gpu": B, "stereo_pairs_per_s": round(value / 2, 1) if stereo else None,
                        "width": job.w, "height": job.h, "nfeatures": job.nfeat, "levels": 8, "scale_factor": 1.2, "fast_th": [20, 7],

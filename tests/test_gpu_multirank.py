@@ -33,3 +33,21 @@ def test_two_ranks_rehearsal():
     # whole-job aggregate: 2 ranks x 16 images x 6 steps over the max-over-ranks time
     assert abs(d["value"] - 2 * 16 * 6 / (d["ms_per_step"] * 6 * 1e-3)) / d["value"] < 0.01
     assert "roofline" in d and "cpu_baseline" not in d and "other_configs" not in d
+    assert d["rccl_ranks"] == 2 and d["collective"]["launcher"].startswith("external")
+
+
+def test_plain_gpus_2_launches_two_ranks_by_itself():
+    """The driver's recorded command form, `python3 bench.py --gpus N ...` with no launcher: bench.py starts the N ranks
+    itself (spawn_ranks) and the count all-gather of the timed region holds counts of N ranks."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+    env["GFO_BENCH_REHEARSAL"] = "1"
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "2", "--batch", "16", "--profile-steps", "2"]
+    r = subprocess.run(cmd, capture_output=True, text=True, env=env, cwd=ROOT, timeout=170)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 == d["rccl_ranks"], (d["n_gpus"], d["rccl_ranks"])
+    assert d["collective"]["world_size"] == 2 and d["collective"]["gathered_elements"] == 2 * 16
+    assert d["collective"]["launcher"] == "bench.py spawn_ranks"
+    assert abs(d["value"] - 2 * 16 * 6 / (d["ms_per_step"] * 6 * 1e-3)) / d["value"] < 0.01

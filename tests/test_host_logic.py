@@ -174,3 +174,35 @@ def test_adapter_context_table_keeps_live_extractors_and_retires_dead_ones():
     assert r.returncode == 0, r.stderr[-3000:]
     r = subprocess.run([exe], capture_output=True, text=True)
     assert r.returncode == 0 and r.stdout.startswith("OK"), r.stdout + r.stderr
+
+
+def test_bench_gpus_n_is_its_own_launcher_and_stays_off_the_gpu():
+    """`python bench.py --gpus N` with no launcher around it (the driver's recorded command form) starts N ranks itself
+    (bench.spawn_ranks): every rank gets RANK / LOCAL_RANK / WORLD_SIZE and one shared MASTER_ADDR:PORT on 127.0.0.1, rank 0's
+    single JSON line is relayed, and the launcher process never imports torch (so it cannot have initialised a GPU) nor the
+    product nor the oracle.  A failing rank fails the command."""
+    import json
+    import subprocess
+    import sys
+    bench = os.path.join(ROOT, "bench.py")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+    env["GFO_BENCH_PARENT_REPORT"] = "1"
+    r = subprocess.run([sys.executable, bench, "--gpus", "3", "--steps", "2", "--spawn-selftest"], capture_output=True, text=True, env=env, timeout=120)
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(out) == 1 and out[0]["rank"] == 0 and out[0]["world"] == 3 and out[0]["gpus_arg"] == 3
+    others = [json.loads(l) for l in r.stderr.splitlines() if l.startswith("{")]
+    assert sorted(o["rank"] for o in others) == [1, 2] and all(o["local_rank"] == o["rank"] and o["world"] == 3 for o in others)
+    assert {o["master"] for o in others + out} == {out[0]["master"]} and out[0]["master"].startswith("127.0.0.1:")
+    assert not any(o["torch_loaded"] for o in others + out)
+    parent = [l for l in r.stderr.splitlines() if l.startswith("parent_modules ")]
+    assert parent == ["parent_modules []"], parent
+    # one rank dies: the command fails and says which
+    env["GFO_BENCH_SELFTEST_FAIL_RANK"] = "1"
+    r = subprocess.run([sys.executable, bench, "--gpus", "3", "--spawn-selftest"], capture_output=True, text=True, env=env, timeout=120)
+    assert r.returncode != 0 and "rank 1 exited with code 7" in r.stderr
+    # under a launcher (WORLD_SIZE set) the command is a rank, not a launcher
+    env.pop("GFO_BENCH_SELFTEST_FAIL_RANK")
+    env.update(RANK="1", LOCAL_RANK="1", WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT="1")
+    r = subprocess.run([sys.executable, bench, "--gpus", "2", "--spawn-selftest"], capture_output=True, text=True, env=env, timeout=120)
+    assert r.returncode == 0 and r.stdout.strip() == "" and '"rank": 1' in r.stderr
