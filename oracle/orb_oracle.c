@@ -1395,33 +1395,37 @@ void orc_bow_transform(const orc_vocabulary* voc, const uint8_t* desc, int n, in
     }
 }
 
-int orc_compute_bow(const orc_vocabulary* voc, const uint8_t* desc, int n, int levelsup, int weighting, int norm,
-                    uint32_t* bow_words, double* bow_values, uint32_t* fv_node_ids, int32_t* fv_start, uint32_t* fv_items,
-                    int* n_fv_nodes)
+/* The fold half of TemplatedVocabulary::transform(features, BowVector&, FeatureVector&, levelsup) --
+ * TemplatedVocabulary.h:1161-1212 -- on the per-feature (word, weight, node) stream the descent produced: BowVector::addWeight /
+ * addIfNotExist / normalize (BowVector.cpp:34-84) and FeatureVector::addFeature (FeatureVector.cpp:31-46), the two std::maps kept
+ * as sorted arrays.  This is the one piece of the path with a reference-compiled pin: oracle/_ref/libdbow2_fold.so is the
+ * reference's own BowVector.cpp / FeatureVector.cpp, and tests/test_oracle.py compares the two bit for bit. */
+int orc_bow_fold(const uint32_t* word, const double* weight, const uint32_t* node, int n, int weighting, int norm,
+                 uint32_t* bow_words, double* bow_values, uint32_t* fv_node_ids, int32_t* fv_start, uint32_t* fv_items,
+                 int* n_fv_nodes)
 {
-    /* the two maps as sorted arrays; fv: per node a growing list (kept as (node, feature) pairs, stable) */
+    /* fv: per node a growing list (kept as (node, feature) pairs, stable) */
     int nw = 0, npairs = 0;
     uint32_t* pn = (uint32_t*)malloc(sizeof(uint32_t) * (n > 0 ? n : 1));
     uint32_t* pf = (uint32_t*)malloc(sizeof(uint32_t) * (n > 0 ? n : 1));
     const int tf = weighting == 0 || weighting == 1;
     for (int i = 0; i < n; i++) { /* :1161-1176 / :1187-1202 */
-        int id, nid;
-        double w;
-        bow_descend(voc, desc + (size_t)i * 32, levelsup, &id, &w, &nid);
+        const uint32_t id = word[i];
+        const double w = weight[i];
         if (!(w > 0)) continue; /* stopped */
         /* lower_bound in the BowVector */
         int lo = 0, hi = nw;
-        while (lo < hi) { const int mid = (lo + hi) / 2; if (bow_words[mid] < (uint32_t)id) lo = mid + 1; else hi = mid; }
-        if (lo < nw && bow_words[lo] == (uint32_t)id) {
+        while (lo < hi) { const int mid = (lo + hi) / 2; if (bow_words[mid] < id) lo = mid + 1; else hi = mid; }
+        if (lo < nw && bow_words[lo] == id) {
             if (tf) bow_values[lo] += w; /* addWeight; addIfNotExist leaves the first value */
         } else {
             memmove(bow_words + lo + 1, bow_words + lo, sizeof(uint32_t) * (size_t)(nw - lo));
             memmove(bow_values + lo + 1, bow_values + lo, sizeof(double) * (size_t)(nw - lo));
-            bow_words[lo] = (uint32_t)id;
+            bow_words[lo] = id;
             bow_values[lo] = w;
             nw++;
         }
-        pn[npairs] = (uint32_t)nid; /* fv.addFeature(nid, i_feature) */
+        pn[npairs] = node[i]; /* fv.addFeature(nid, i_feature) */
         pf[npairs] = (uint32_t)i;
         npairs++;
     }
@@ -1457,6 +1461,31 @@ int orc_compute_bow(const orc_vocabulary* voc, const uint8_t* desc, int n, int l
     fv_start[nseg] = pos;
     *n_fv_nodes = nseg;
     free(pn); free(pf); free(used);
+    return nw;
+}
+
+/* the per-feature stream of the descent with the weight as DBoW2 holds it (WordValue = double): the input of orc_bow_fold */
+void orc_bow_stream(const orc_vocabulary* voc, const uint8_t* desc, int n, int levelsup, uint32_t* word, double* weight, uint32_t* node)
+{
+    for (int i = 0; i < n; i++) {
+        int id, nid;
+        double w;
+        bow_descend(voc, desc + (size_t)i * 32, levelsup, &id, &w, &nid);
+        word[i] = (uint32_t)id; weight[i] = w; node[i] = (uint32_t)nid;
+    }
+}
+
+int orc_compute_bow(const orc_vocabulary* voc, const uint8_t* desc, int n, int levelsup, int weighting, int norm,
+                    uint32_t* bow_words, double* bow_values, uint32_t* fv_node_ids, int32_t* fv_start, uint32_t* fv_items,
+                    int* n_fv_nodes)
+{
+    const size_t m = (size_t)(n > 0 ? n : 1);
+    uint32_t* word = (uint32_t*)malloc(sizeof(uint32_t) * m);
+    uint32_t* node = (uint32_t*)malloc(sizeof(uint32_t) * m);
+    double* weight = (double*)malloc(sizeof(double) * m);
+    orc_bow_stream(voc, desc, n, levelsup, word, weight, node);
+    const int nw = orc_bow_fold(word, weight, node, n, weighting, norm, bow_words, bow_values, fv_node_ids, fv_start, fv_items, n_fv_nodes);
+    free(word); free(node); free(weight);
     return nw;
 }
 

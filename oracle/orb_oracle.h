@@ -209,6 +209,13 @@ void orc_bow_transform(const orc_vocabulary* voc, const uint8_t* desc, int n, in
 int orc_compute_bow(const orc_vocabulary* voc, const uint8_t* desc, int n, int levelsup, int weighting, int norm,
                     uint32_t* bow_words, double* bow_values, uint32_t* fv_node_ids, int32_t* fv_start, uint32_t* fv_items,
                     int* n_fv_nodes);
+/* the two halves of orc_compute_bow: the per-feature (word, double weight, node) stream of the descent, and the fold of such a
+ * stream into the two maps.  The fold is what oracle/_ref/libdbow2_fold.so (the reference's own BowVector.cpp / FeatureVector.cpp
+ * behind the same signature, ref_bow_fold) pins. */
+void orc_bow_stream(const orc_vocabulary* voc, const uint8_t* desc, int n, int levelsup, uint32_t* word, double* weight, uint32_t* node);
+int orc_bow_fold(const uint32_t* word, const double* weight, const uint32_t* node, int n, int weighting, int norm,
+                 uint32_t* bow_words, double* bow_values, uint32_t* fv_node_ids, int32_t* fv_start, uint32_t* fv_items,
+                 int* n_fv_nodes);
 
 #ifdef __cplusplus
 }

@@ -390,6 +390,76 @@ def compute_bow(voc, desc, levelsup=4, weighting=0, norm=1):
     return bw[:nw].copy(), bv[:nw].copy(), fn[:nf.value].copy(), fs[:nf.value + 1].copy(), fi[:fs[nf.value]].copy()
 
 
+def _voc_c(voc):
+    arrs = [np.ascontiguousarray(voc[k]) for k in ("first_child", "n_children", "descriptors", "word_id", "weight")]
+    w64 = np.ascontiguousarray(voc["weight64"], np.float64) if "weight64" in voc else None
+    return VocabularyC(*[a.ctypes.data for a in arrs], len(arrs[0]), voc["depth"], None if w64 is None else w64.ctypes.data), (arrs, w64)
+
+
+def bow_stream(voc, desc, levelsup=4):
+    """The per-feature stream of the descent as DBoW2 holds it: (word u32, weight f64, node u32) -- the input of bow_fold."""
+    desc = np.ascontiguousarray(desc, np.uint8)
+    n = len(desc)
+    v, keep = _voc_c(voc)
+    m = max(n, 1)
+    word = np.zeros(m, np.uint32); wt = np.zeros(m, np.float64); node = np.zeros(m, np.uint32)
+    L = lib()
+    L.orc_bow_stream.argtypes = [C.POINTER(VocabularyC), C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.orc_bow_stream.restype = None
+    L.orc_bow_stream(C.byref(v), _p(desc), n, levelsup, _p(word), _p(wt), _p(node))
+    return word[:n], wt[:n], node[:n]
+
+
+def _fold(fn, word, weight, node, weighting, norm):
+    word = np.ascontiguousarray(word, np.uint32); weight = np.ascontiguousarray(weight, np.float64); node = np.ascontiguousarray(node, np.uint32)
+    n = len(word)
+    m = max(n, 1)
+    bw = np.zeros(m, np.uint32); bv = np.zeros(m, np.float64); fnn = np.zeros(m, np.uint32); fs = np.zeros(m + 1, np.int32)
+    fi = np.zeros(m, np.uint32); nf = C.c_int()
+    vp = C.c_void_p
+    fn.argtypes = [vp, vp, vp, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp, C.POINTER(C.c_int)]
+    fn.restype = C.c_int
+    nw = fn(_p(word), _p(weight), _p(node), n, weighting, norm, _p(bw), _p(bv), _p(fnn), _p(fs), _p(fi), C.byref(nf))
+    return bw[:nw].copy(), bv[:nw].copy(), fnn[:nf.value].copy(), fs[:nf.value + 1].copy(), fi[:fs[nf.value]].copy()
+
+
+def bow_fold(word, weight, node, weighting=0, norm=1):
+    """orc_bow_fold: the fold of a (word, weight, node) stream into BowVector / FeatureVector (the oracle's restatement).
+    weighting: 0 TF_IDF, 1 TF, 2 IDF, 3 BINARY; norm: 0 none, 1 L1, 2 L2."""
+    return _fold(lib().orc_bow_fold, word, weight, node, weighting, norm)
+
+
+_REF_DIR = os.path.join(_HERE, "_ref")
+_REF_FOLD = os.path.join(_REF_DIR, "libdbow2_fold.so")
+REFERENCE_ROOT = os.environ.get("GFO_REFERENCE_ROOT", "/root/reference")
+
+
+def build_ref():
+    """oracle/_ref/libdbow2_fold.so from the reference's own DBoW2 BowVector.cpp / FeatureVector.cpp, compiled unmodified where they
+    lie (oracle/Makefile, target ref).  Only where the reference tree exists (the build container); returns the path or None."""
+    if not os.path.exists(os.path.join(REFERENCE_ROOT, "Thirdparty", "DBoW2", "DBoW2", "BowVector.cpp")):
+        return _REF_FOLD if os.path.exists(_REF_FOLD) else None
+    subprocess.check_call(["make", "-C", _HERE, "-s", "ref", f"REFERENCE={REFERENCE_ROOT}"])
+    return _REF_FOLD
+
+
+_ref_lib = None
+
+
+def ref_available():
+    return os.path.exists(_REF_FOLD)
+
+
+def ref_bow_fold(word, weight, node, weighting=0, norm=1):
+    """The same fold through the reference's compiled std::map classes (oracle/_ref); raises FileNotFoundError without the build."""
+    global _ref_lib
+    if _ref_lib is None:
+        if not os.path.exists(_REF_FOLD):
+            raise FileNotFoundError(_REF_FOLD)
+        _ref_lib = C.CDLL(_REF_FOLD)
+    return _fold(_ref_lib.ref_bow_fold, word, weight, node, weighting, norm)
+
+
 class ProjMode(C.Structure):
     _fields_ = [("use_ratio", C.c_int32), ("nn_ratio", C.c_float), ("th_dist", C.c_int32), ("check_orientation", C.c_int32)]
 

@@ -122,3 +122,33 @@ def test_compute_bow_folds_both_maps_on_the_device(oracle, weighting, norm):
         V.compute_bow(np.zeros((8193, 32), np.uint8))
     assert e.value.code == -3
     ext.close()
+
+
+def test_compute_bow_fold_against_the_reference_compiled_fixtures(oracle):
+    """gfo_compute_bow against tests/golden/bow_fold.npz -- the outputs of the reference's own BowVector.cpp / FeatureVector.cpp
+    (oracle/_ref, compiled unmodified) on the stream of each stored descriptor set: the device descent must reproduce the stored
+    (word, weight, node) stream and the device fold the reference's maps, WordValues bit for bit, for 4 weightings x 3 norms."""
+    import gf_orb_slam2_amd as G
+    fx = np.load(os.path.join(GOLDEN, "bow_fold.npz"))
+    ext = G.ORBextractor(500, 1.2, 8, 20, 7)
+    cases = 0
+    for name in sorted({k.split(".")[0] for k in fx.files if k.startswith("voc")}):
+        seed, k, depth, n, levelsup = (int(x) for x in fx[f"{name}.params"])
+        voc = oracle.make_vocabulary(k, depth, seed=seed, p_stop=0.1)
+        desc = fx[f"{name}.desc"]
+        V = G.ORBVocabulary(voc, ext)
+        wid, wt, nid = V.transform_raw(desc, levelsup)
+        np.testing.assert_array_equal(wid.astype(np.uint32), fx[f"{name}.word"])
+        np.testing.assert_array_equal(nid.astype(np.uint32), fx[f"{name}.node"])
+        for wn in ("TF_IDF", "TF", "IDF", "BINARY"):
+            for nn in (None, "L1", "L2"):
+                (bw, bv), (fn, fs, fi) = V.compute_bow(desc, levelsup, wn, nn)
+                pre = f"{name}.{wn}.{nn or 'none'}."
+                np.testing.assert_array_equal(bw, fx[pre + "bow_words"])
+                assert bv.tobytes() == fx[pre + "bow_values"].tobytes(), pre
+                np.testing.assert_array_equal(fn, fx[f"{name}.fv_nodes"])
+                np.testing.assert_array_equal(fs, fx[f"{name}.fv_start"])
+                np.testing.assert_array_equal(fi, fx[f"{name}.fv_items"])
+                cases += 1
+    assert cases == 60
+    ext.close()

@@ -499,3 +499,74 @@ def phase(x, y, angleInDegrees=False): return _with(lambda: O.fast_atan2_n(y, x)
     rep = os.path.join(GOLDEN, "cv2_pin_report.json")
     if os.path.exists(rep):
         os.remove(rep)       # a mock's report must not be mistaken for a pin
+
+
+# ---- the one reference-compiled pin of the path: DBoW2's BowVector / FeatureVector (oracle/_ref) ----
+BOW_W = {"TF_IDF": 0, "TF": 1, "IDF": 2, "BINARY": 3}
+BOW_N = {"none": 0, "L1": 1, "L2": 2}
+
+
+def _bow_fixture():
+    return np.load(os.path.join(GOLDEN, "bow_fold.npz"))
+
+
+def test_bow_fold_equals_the_reference_compiled_fixtures(oracle):
+    """tests/golden/bow_fold.npz holds outputs of the REFERENCE's own BowVector.cpp / FeatureVector.cpp (compiled unmodified into
+    oracle/_ref/libdbow2_fold.so by tests/golden/make_bow_fold_golden.py): the oracle's fold must give the same maps -- word ids,
+    node ids, index lists, and every WordValue bit for bit -- for the 4 weightings x 3 norms on every stream, including empty and
+    one-feature streams, stop words, negative / NaN / denormal weights."""
+    fx = _bow_fixture()
+    streams = sorted({k.split(".")[0] for k in fx.files})
+    assert len(streams) == 10
+    cases = 0
+    for name in streams:
+        word, weight, node = fx[f"{name}.word"], fx[f"{name}.weight"], fx[f"{name}.node"]
+        for wn, w in BOW_W.items():
+            for nn, nm in BOW_N.items():
+                bw, bv, fn, fs, fi = oracle.bow_fold(word, weight, node, w, nm)
+                pre = f"{name}.{wn}.{nn}."
+                np.testing.assert_array_equal(bw, fx[pre + "bow_words"])
+                assert bv.tobytes() == fx[pre + "bow_values"].tobytes(), pre
+                np.testing.assert_array_equal(fn, fx[f"{name}.fv_nodes"])
+                np.testing.assert_array_equal(fs, fx[f"{name}.fv_start"])
+                np.testing.assert_array_equal(fi, fx[f"{name}.fv_items"])
+                cases += 1
+    assert cases == 120
+
+
+def test_bow_fixture_streams_are_what_the_descent_gives(oracle):
+    """the "voc" streams of the fixture are the oracle's descent on the stored descriptors: regenerate and compare (drift guard;
+    the descent itself has no reference pin, which is why the streams are stored)."""
+    fx = _bow_fixture()
+    for name in sorted({k.split(".")[0] for k in fx.files if k.startswith("voc")}):
+        seed, k, depth, n, levelsup = (int(x) for x in fx[f"{name}.params"])
+        voc = oracle.make_vocabulary(k, depth, seed=seed, p_stop=0.1)
+        word, weight, node = oracle.bow_stream(voc, fx[f"{name}.desc"], levelsup)
+        np.testing.assert_array_equal(word, fx[f"{name}.word"])
+        assert weight.tobytes() == fx[f"{name}.weight"].tobytes()
+        np.testing.assert_array_equal(node, fx[f"{name}.node"])
+        # and compute_bow = stream + fold
+        got = oracle.compute_bow(voc, fx[f"{name}.desc"], levelsup, 0, 1)
+        ref = oracle.bow_fold(word, weight, node, 0, 1)
+        for a, b in zip(got, ref):
+            assert a.tobytes() == b.tobytes()
+
+
+def test_bow_fold_against_the_reference_build_live(oracle):
+    """where oracle/_ref exists (built by __graft_entry__.build() in the build container, shipped as a .so to the GPU box): fresh
+    random streams through both, bit for bit."""
+    if not oracle.ref_available():
+        pytest.skip("oracle/_ref/libdbow2_fold.so not built (no reference tree on this machine)")
+    rng = np.random.default_rng(99)
+    for trial in range(40):
+        n = int(rng.integers(0, 3000))
+        nwords = int(rng.integers(1, 400))
+        word = rng.integers(0, nwords, n).astype(np.uint32)
+        weight = np.where(rng.random(n) < 0.1, 0.0, np.log(rng.uniform(1.01, 1e4, n)))
+        node = rng.integers(0, int(rng.integers(1, 60)), n).astype(np.uint32)
+        for w in range(4):
+            for nm in range(3):
+                a = oracle.bow_fold(word, weight, node, w, nm)
+                b = oracle.ref_bow_fold(word, weight, node, w, nm)
+                for x, y in zip(a, b):
+                    assert x.tobytes() == y.tobytes(), (trial, w, nm)
