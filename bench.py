@@ -58,6 +58,8 @@ CONTEXTS = {"stereo752": 2, "extract752": 2, "extract1080": 3, "proj1080": 2}
 # (241k against 232k chained); the 1080p workloads do not care.
 CHAIN_STAGE = {"stereo752": 1, "extract752": 0, "extract1080": 0, "proj1080": 0}
 FX, BF = 435.2046959714599, 47.90639384423901
+ISSUE_CYCLES, N_SIMDS, CLOCK_HZ = 4, 1024, 2.4e9   # MI355X_MICROARCH.md: vector-instruction issue cost, 256 CUs x 4 SIMDs, max clock
+HEADLINE_BATCH = 256   # == gf_orb_slam2_amd.HEADLINE_BATCH (checked in main(); the launcher process must not import the product)
 MAP_POINTS = 50000
 
 
@@ -205,7 +207,7 @@ def side_config(name, batch, streams):
     249k, proj1080 46.5k against 51.2k frames/s, measured both ways)."""
     import subprocess
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--workload", name, "--batch", str(batch), "--steps", "400", "--warmup", "30",
-           "--streams", str(streams), "--no-other-configs", "--no-cpu-baseline", "--no-boundary", "--profile-steps", "5"]
+           "--streams", str(streams), "--no-other-configs", "--no-cpu-baseline", "--no-boundary", "--profile-steps", "5"]   # (each verifies its own last step)
     try:
         r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=240)
         lines = [l for l in r.stdout.decode(errors="replace").splitlines() if l.startswith("{")]
@@ -267,29 +269,113 @@ def real_image():
 
 
 def host_cores():
+    """(cores this process may be scheduled on, cores' worth of CPU time its cgroup grants, or None).  A GPU box shows all 256
+    hardware threads in the affinity mask while the container's cgroup grants a fraction of them (cpu.max): a pool sized by the
+    mask alone is throttled by the quota -- round 3's "256 threads = 12.5 x one thread"."""
     try:
-        return len(os.sched_getaffinity(0))
+        aff = len(os.sched_getaffinity(0))
     except AttributeError:
-        return os.cpu_count() or 1
+        aff = os.cpu_count() or 1
+    quota = None
+    try:
+        cg = open("/proc/self/cgroup").read().strip().splitlines()
+        rel = [l.split(":", 2)[2] for l in cg if l.startswith("0::")]
+        paths = (["/sys/fs/cgroup" + rel[0].rstrip("/") + "/cpu.max"] if rel else []) + ["/sys/fs/cgroup/cpu.max"]
+        for path in paths:
+            if os.path.exists(path):
+                q, per = open(path).read().split()[:2]
+                if q != "max":
+                    quota = float(q) / float(per)
+                break
+        if quota is None and os.path.exists("/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+            q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                quota = q / per
+    except Exception:
+        quota = None
+    return aff, quota
+
+
+def cpu_model():
+    try:
+        for l in open("/proc/cpuinfo"):
+            if l.startswith("model name"):
+                return l.split(":", 1)[1].strip()
+    except Exception:
+        pass
+    return "unknown"
+
+
+def _cpu_inputs(w, h, euroc):
+    from gf_orb_slam2_amd.synth import synth_stereo_pair
+    if euroc:
+        gold = os.path.join(ROOT, "tests", "golden")
+        l = np.fromfile(os.path.join(gold, "EuRoC_l_752x480.u8"), np.uint8).reshape(480, 752)
+        r = np.fromfile(os.path.join(gold, "EuRoC_r_752x480.u8"), np.uint8).reshape(480, 752)
+        return [(l, r)]
+    return [synth_stereo_pair(w, h, 1000 + i) for i in range(8)]
+
+
+def cpu_worker(argv):
+    """One CPU-baseline worker process (bench.py --cpu-worker w h nfeatures stereo euroc n_pairs start_epoch): a process of its
+    own per core -- no GIL, no shared allocator, never touches the GPU -- that waits for the common start time, runs n_pairs
+    stereo pairs through the oracle and prints its start and end times."""
+    w, h, nfeat, stereo, euroc, n_pairs = (int(x) for x in argv[:6])
+    t_start = float(argv[6])
+    from oracle import orb_oracle as O
+    pairs = _cpu_inputs(w, h, euroc)
+    oe_l, oe_r = O.OracleExtractor(nfeat, 1.2, 8, 20, 7), O.OracleExtractor(nfeat, 1.2, 8, 20, 7)
+    sf = oe_l.scale_factors
+    oe_l(pairs[0][0])                      # first touch of the library and its buffers, untimed
+    while time.time() < t_start:
+        time.sleep(0.001)
+    t0 = time.time()
+    for i in range(n_pairs):
+        l, r = pairs[i % len(pairs)]
+        kl, dl = oe_l(l)
+        kr, dr = oe_r(r)
+        if stereo:
+            O.stereo_match(kl, dl, kr, dr, sf, h, BF, BF / FX, 0.0)
+    print(json.dumps({"t0": t0, "t1": time.time(), "late": t0 - t_start}), flush=True)
+
+
+def cpu_processes(w, h, nfeat, stereo, euroc, nproc, n_pairs):
+    """nproc worker processes, one stereo pair stream each, started together; images/s over the span first start .. last end"""
+    import subprocess
+    t_start = time.time() + 4.0 + 0.02 * nproc        # interpreter + numpy + inputs of every worker are up by then (checked: `late`)
+    cmd = [sys.executable, os.path.abspath(__file__), "--cpu-worker"] + [str(x) for x in (w, h, nfeat, int(stereo), int(euroc), n_pairs, t_start)]
+    procs = [subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL) for _ in range(nproc)]
+    outs = []
+    for p in procs:
+        try:
+            o, _ = p.communicate(timeout=180)
+            outs.append(json.loads(o.decode().strip().splitlines()[-1]))
+        except Exception:
+            p.kill()
+    if len(outs) != nproc:
+        return None
+    span = max(o["t1"] for o in outs) - min(o["t0"] for o in outs)
+    return {"processes": nproc, "value": round(2 * n_pairs * nproc / span, 2), "pairs_per_process": n_pairs,
+            "max_start_delay_s": round(max(o["late"] for o in outs), 3)}
 
 
 def cpu_baseline(w, h, nfeatures, stereo, budget_s=10.0):
     """The CPU oracle (oracle/, kind 'port') on a bounded sample of the same synthetic stream, on this host:
     one thread (the headline `value`), two threads (the reference's own left/right arrangement, Frame.cc:84-87)
-    and every core this process may run on, one stereo pair per thread.  ctypes releases
-    the GIL, so the threads run the C oracle concurrently."""
+    and every core this process is GRANTED -- min(affinity mask, cgroup quota) -- as one process per core with one stereo pair
+    stream each.  The same three on the reference's own EuRoC pair ("euroc": BASELINE configs[0]: the CPU
+    extractor on test/EuRoC_l.png).  ctypes releases the GIL, so the two threads run the C oracle concurrently."""
     from concurrent.futures import ThreadPoolExecutor
-    from gf_orb_slam2_amd.synth import synth_stereo_pair
     from oracle import orb_oracle as O
     O.build()
 
     def make():
         return O.OracleExtractor(nfeatures, 1.2, 8, 20, 7)
 
-    pairs = [synth_stereo_pair(w, h, 1000 + i) for i in range(8)]
     sf = make().scale_factors
 
-    def one_pair(oe_l, oe_r, idx, two_threads=None):
+    def one_pair(pairs, oe_l, oe_r, idx, two_threads=None, match=stereo):
         l, r = pairs[idx % len(pairs)]
         if two_threads is not None:
             fl = two_threads.submit(oe_l, l)
@@ -298,42 +384,59 @@ def cpu_baseline(w, h, nfeatures, stereo, budget_s=10.0):
         else:
             kl, dl = oe_l(l)
             kr, dr = oe_r(r)
-        if stereo:
+        if match:
             O.stereo_match(kl, dl, kr, dr, sf, h, BF, BF / FX, 0.0)
 
-    oe_l, oe_r = make(), make()
-    t0 = time.perf_counter()
-    one_pair(oe_l, oe_r, 0)
-    t_first = time.perf_counter() - t0
-    n1 = int(max(3, min(60, budget_s / max(t_first, 1e-3))))
-    t0 = time.perf_counter()
-    for i in range(n1):
-        one_pair(oe_l, oe_r, i)
-    v1 = 2 * n1 / (time.perf_counter() - t0)
-    # two threads: left and right image extracted concurrently
-    n2 = max(3, n1 // 2)
-    with ThreadPoolExecutor(1) as side:
+    def one_and_two(pairs, budget):
+        oe_l, oe_r = make(), make()
         t0 = time.perf_counter()
-        for i in range(n2):
-            one_pair(oe_l, oe_r, i, side)
-        v2 = 2 * n2 / (time.perf_counter() - t0)
-    # all cores this process may use: one pair per thread
-    nt = max(1, host_cores())
-    exts = [(make(), make()) for _ in range(nt)]
-    per = max(2, n1 // 4)
+        one_pair(pairs, oe_l, oe_r, 0)
+        t_first = time.perf_counter() - t0
+        n1 = int(max(3, min(60, budget / max(t_first, 1e-3))))
+        t0 = time.perf_counter()
+        for i in range(n1):
+            one_pair(pairs, oe_l, oe_r, i)
+        v1 = 2 * n1 / (time.perf_counter() - t0)
+        n2 = max(3, n1 // 2)       # two threads: left and right image extracted concurrently
+        with ThreadPoolExecutor(1) as side:
+            t0 = time.perf_counter()
+            for i in range(n2):
+                one_pair(pairs, oe_l, oe_r, i, side)
+            v2 = 2 * n2 / (time.perf_counter() - t0)
+        return n1, v1, v2
 
-    def worker(k):
-        for i in range(per):
-            one_pair(exts[k][0], exts[k][1], k * per + i)
-    with ThreadPoolExecutor(nt) as pool:
+    aff, quota = host_cores()
+    granted = max(1, min(aff, int(quota + 0.5)) if quota else aff)
+    pairs = _cpu_inputs(w, h, False)
+    n1, v1, v2 = one_and_two(pairs, budget_s * 0.35)
+    per = max(2, n1 // 4)
+    vn = cpu_processes(w, h, nfeatures, stereo, False, granted, per)
+    out = {"value": round(v1, 2), "unit": "frames/s", "cores": 1, "kind": "port", "cpu_model": cpu_model(),
+           "sample": f"{n1} stereo pairs ({2 * n1} images) of the same {w}x{h} synthetic stream, oracle/orb_oracle.c, "
+                     f"single thread; {os.cpu_count()} hardware threads present, {aff} in this process's affinity mask, "
+                     f"cgroup CPU quota {('%.1f cores' % quota) if quota else 'none'} -> {granted} granted",
+           "threads_2": round(v2, 2), "all_granted_cores": vn,
+           "scaling_vs_one_thread": round(vn["value"] / v1 / granted, 3) if vn else None,
+           "reference_published": "13.7-22.2 ms per stereo frame on unstated hardware (README.md:7-16) = 90-146 images/s"}
+    if (w, h) == (752, 480):
+        # BASELINE configs[0]: the CPU ORBextractor on the reference's test/EuRoC_l.png (752x480, 8 levels, 2000 features);
+        # committed here as tests/golden/EuRoC_l_752x480.u8 (raw pixels of that PNG)
+        ep = _cpu_inputs(w, h, True)
+        oe = make()
         t0 = time.perf_counter()
-        list(pool.map(worker, range(nt)))
-        vn = 2 * per * nt / (time.perf_counter() - t0)
-    return {"value": round(v1, 2), "unit": "frames/s", "cores": 1, "kind": "port",
-            "sample": f"{n1} stereo pairs ({2 * n1} images) of the same {w}x{h} synthetic stream, oracle/orb_oracle.c, "
-                      f"single thread; {os.cpu_count()} host cores present, {nt} usable by this process",
-            "threads_2": round(v2, 2), "threads_n": {"threads": nt, "value": round(vn, 2)},
-            "reference_published": "13.7-22.2 ms per stereo frame on unstated hardware (README.md:7-16) = 90-146 images/s"}
+        oe(ep[0][0])
+        ne = int(max(5, min(100, 0.1 * budget_s / max(time.perf_counter() - t0, 1e-3))))
+        t0 = time.perf_counter()
+        for _ in range(ne):
+            oe(ep[0][0])
+        v_l = ne / (time.perf_counter() - t0)
+        ne1, ve1, ve2 = one_and_two(ep, budget_s * 0.15)
+        ven = cpu_processes(w, h, nfeatures, stereo, True, granted, max(2, ne1 // 4))
+        out["euroc"] = {"config": "BASELINE configs[0]: CPU ORBextractor on test/EuRoC_l.png, 752x480, 8 levels, 2000 features",
+                        "extract_only_left_image": {"value": round(v_l, 2), "unit": "frames/s", "cores": 1, "images": ne},
+                        "stereo_pair_extract_and_match": {"value": round(ve1, 2), "threads_2": round(ve2, 2), "unit": "frames/s", "pairs": ne1,
+                                                          "all_granted_cores": ven}}
+    return out
 
 
 def spawn_ranks(n, argv, selftest=False):
@@ -458,6 +561,7 @@ class Job:
         if self.matcher == "project":
             kp0, desc0 = self.exts[0].batch_fetch(0)
             mpd, mps = synth_local_map(kp0, desc0, offs, w, h, MAP_POINTS, 4000, seed=7)
+            self.mpd, self.mps = mpd, mps                                              # host copies: verify() hands them to the oracle
             self.d_mps = torch.from_numpy(mps.view(np.uint8).reshape(B, -1)).cuda()   # [B][M] projections, resident
             for m in self.matchers:
                 m.map_upload(mpd)                                                      # one resident map per context
@@ -548,6 +652,44 @@ class Job:
             dt = float(tt.item())
         return dt
 
+    def verify(self, n_images=4, n_pairs=2):
+        """The checker role of the oracle, outside every timed region: results of the LAST step submitted (still in that context's
+        arena) -- n_images images (first pair and last pair of the batch) and n_pairs matcher units (stereo pairs / projected
+        frames) -- compared with the CPU oracle on the same host images, bit for bit.  Call right after timed()."""
+        from oracle import orb_oracle as O
+        O.build()
+        self.torch.cuda.synchronize()
+        k = (self.step_no - 1) % self.nctx
+        host = self.host_batches[(self.step_no - 1) % len(self.d_inputs)]
+        ext, m = self.exts[k], self.matchers[k]
+        B = self.B
+        slots = ([0, 1] + [B - 2, B - 1] + list(range(2, B - 2)))[:max(2, n_images)]
+        oe = O.OracleExtractor(self.nfeat, 1.2, 8, 20, 7)
+        sf = oe.scale_factors
+        bad, ref = 0, {}
+        for i in slots:
+            ok, od = oe(host[i])
+            gk, gd = ext.batch_fetch(i)
+            ref[i] = (ok, od)
+            bad += int(not (gk.tobytes() == ok.tobytes() and gd.tobytes() == od.tobytes()))
+        pairs = 0
+        if self.matcher == "stereo":
+            for pr in [s_ // 2 for s_ in slots[::2]][:n_pairs]:
+                (kl, dl), (kr, dr) = ref[2 * pr], ref[2 * pr + 1]
+                o = O.stereo_match(kl, dl, kr, dr, sf, self.h, BF, BF / FX, 0.0)
+                g = m.stereo_fetch(pr, len(kl))
+                bad += int(not (g[0] == o[0] and all(a.tobytes() == b.tobytes() for a, b in zip(g[1:], o[1:]))))
+                pairs += 1
+        elif self.matcher == "project":
+            for f in slots[:n_pairs]:
+                kp, desc = ref[f]
+                o = O.search_by_projection(kp, desc, None, sf, self.bounds, self.mps[f], self.mpd, 3.0, 0.8, None)
+                nm, out_mp, out_sc = m.projection_fetch(f, len(kp))
+                bad += int(not (nm == o[0] and (out_mp[:len(kp)] == o[1]).all() and (out_sc[:len(kp)] == o[2]).all()))
+                pairs += 1
+        return {"images": len(slots), "pairs": pairs, "mismatches": bad, "context": k, "slots": slots,
+                "against": "oracle/orb_oracle.c on the same host images, bit for bit; the last step of the timed region, outside it"}
+
     def profile(self, nsteps):
         """per-kernel device time from HIP events on the launch stream, context 0 alone (clean per-kernel durations)"""
         ext = self.exts[0]
@@ -596,6 +738,24 @@ class Job:
                 tj_all = {}
         if dom in tj_all:
             traffic = int(tj_all[dom] / max(launches_per_step, 1e-9))
+        # The roofline that BINDS.  These kernels are integer / byte work whose wall is vector-instruction issue, not HBM: a
+        # wave-instruction occupies its SIMD for ISSUE_CYCLES cycles (MI355X_MICROARCH.md, 'vector-instruction ISSUE cost': 4;
+        # tools/c/valu_rate.hip measured 4.2 for the packed-integer mix these kernels are made of) and the chip has 1024 SIMDs at
+        # <= 2.4 GHz, so issue_frac = SQ_INSTS_VALU x 4 / (1024 x 2.4e9 x duration).  SQ_INSTS_VALU per stage and step comes from
+        # the committed counter pass of this command (profiles/sq_counters_latest.json, tools/pmc_sq.sh) -- instruction counts
+        # do not vary from run to run; the duration is this run's.
+        issue_all, issue_src = {}, None
+        try:
+            sj = json.load(open(os.path.join(ROOT, "profiles", "sq_counters_latest.json")))
+            if sj.get("workload") == traffic_workload and sj.get("batch") == self.B:
+                issue_all = {k: v.get("SQ_INSTS_VALU") for k, v in sj["per_stage_per_step"].items()}
+                issue_src = f"profiles/sq_counters_{sj.get('tag')}.txt (rocprofv3 --pmc SQ_INSTS_VALU pass of this command, tools/pmc_sq.sh); duration measured in this run"
+        except Exception:
+            issue_all = {}
+
+        def issue_frac(stage, ms_per_step):
+            n = issue_all.get(stage)
+            return round(n * ISSUE_CYCLES / (N_SIMDS * CLOCK_HZ * ms_per_step * 1e-3), 4) if n and ms_per_step > 0 else None
         per_stage = {}
         for k, ms in stage_ms.items():
             lps = prof[k][1] / max(1, nsteps)
@@ -603,10 +763,20 @@ class Job:
             al = prof[k][0] / prof[k][1]
             per_stage[k] = {"avg_launch_ms": round(al, 4), "launches_per_step": round(lps, 2), "algorithmic_bytes_per_launch": int(bpl),
                             "achieved_GBps": round(bpl / (al * 1e-3) / 1e9, 1), "frac": round(bpl / (al * 1e-3) / 8e12, 5),
+                            "issue_frac": issue_frac(k, ms),
                             "traffic_per_step": tj_all.get(k), "traffic_counters_per_step": raw_all.get(k)}
+        dom_issue = issue_frac(dom, stage_ms[dom])
+        hbm_frac = round(achieved / 8000.0, 5)
+        for k, v in per_stage.items():
+            v["bound"] = "valu-issue" if (v["issue_frac"] or 0) > v["frac"] else "hbm"
         return n_kp_img, {
-            "bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": 8000.0, "unit": "GB/s",
-            "frac": round(achieved / 8000.0, 5), "traffic": traffic, "traffic_source": traffic_source,
+            # `bound` names the wall the dominant kernel actually sits against: whichever of the two fractions is larger.
+            # achieved / peak / frac stay the HBM figures the contract defines; issue_frac is the other roofline.
+            "bound": "valu-issue" if (dom_issue or 0) > hbm_frac else "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": 8000.0, "unit": "GB/s",
+            "frac": hbm_frac, "issue_frac": dom_issue,
+            "issue_model": {"valu_instructions_per_launch": int(issue_all[dom] / max(launches_per_step, 1e-9)) if issue_all.get(dom) else None,
+                            "cycles_per_wave_instruction": ISSUE_CYCLES, "simds": N_SIMDS, "clock_ghz": CLOCK_HZ / 1e9, "source": issue_src},
+            "traffic": traffic, "traffic_measured": bool(live), "traffic_source": traffic_source,
             "avg_launch_ms": round(avg_launch_ms, 4), "algorithmic_bytes_per_launch": int(bytes_per_launch),
             "pipeline_frac_hbm": round(value_per_gpu * survey_total / 8e12, 5),
             "stage_ms_per_step": {k: round(v, 4) for k, v in stage_ms.items()},
@@ -624,7 +794,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--batch", type=int, default=256, help="images per GPU per step (even); 256 is where the rate levels off on MI355X (64 / 128 / 256 / 384 / 1024: 237k / 260k / 274k / 275k / 275k frames/s, profiles/batch_sweep_r03.txt)")
+    ap.add_argument("--batch", type=int, default=HEADLINE_BATCH, help="images per GPU per step (even); 256 is where the rate levels off on MI355X (64 / 128 / 256 / 384 / 1024: 237k / 260k / 274k / 275k / 275k frames/s, profiles/batch_sweep_r03.txt)")
     ap.add_argument("--workload", default="stereo752", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-other-configs", action="store_true", help="skip the short passes over the other BASELINE configs")
@@ -639,6 +809,7 @@ def main():
     ap.add_argument("--gather-every", type=int, default=1,
                     help="N > 1 GPUs: all-gather the keypoint counts every this many steps (1 = every step, as north_star names it; "
                          "0 = never -- separates straggler coupling between ranks from kernel time on a real node)")
+    ap.add_argument("--no-verify", action="store_true", help="skip the oracle check of the last timed step (4 images + 2 matcher units)")
     ap.add_argument("--no-boundary", action="store_true", help="skip the per-frame boundary harness (per_frame_boundary)")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)   # internal: the pass live_traffic() profiles
     ap.add_argument("--spawn-selftest", action="store_true", help=argparse.SUPPRESS)   # tests: ranks report their environment and exit (no GPU)
@@ -693,6 +864,7 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     import gf_orb_slam2_amd as G
+    assert G.HEADLINE_BATCH == HEADLINE_BATCH, "bench.py and the package disagree on the headline batch size"
 
     B = args.batch - (args.batch & 1)
     nctx = args.streams if args.streams >= 1 else CONTEXTS[args.workload]   # 0: the workload's default
@@ -704,6 +876,7 @@ def main():
     dt = job.timed(args.steps, args.warmup)
     total_frames = world * B * args.steps
     value = total_frames / dt
+    verified = job.verify() if rank == 0 and not args.no_verify else None
 
     # a timed region shorter than half a second says little about a sustained rate: repeat for >= 1 s
     sustained = None
@@ -762,7 +935,7 @@ def main():
             "value": round(value, 1), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-            "rccl_ranks": (coll["ranks_with_counts"] if coll else 1), "collective": coll,
+            "rccl_ranks": (coll["ranks_with_counts"] if coll else 1), "collective": coll, "verified": verified,
             "config": {"workload": job.cfg_name, "frame": "one camera image (a stereo pair = 2 frames + 1 association)",
                        "images_per_step_per_gpu": B, "stereo_pairs_per_s": round(value / 2, 1) if stereo else None,
                        "width": job.w, "height": job.h, "nfeatures": job.nfeat, "levels": 8, "scale_factor": 1.2, "fast_th": [20, 7],
@@ -807,4 +980,7 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "--cpu-worker":
+        cpu_worker(sys.argv[2:])
+    else:
+        main()

@@ -9,5 +9,9 @@ from .extractor import ORBextractor  # noqa: F401
 from .matcher import ORBmatcher, ORBVocabulary, StereoParams, FrameBounds  # noqa: F401
 from .build import build_library  # noqa: F401
 
-__all__ = ["ORBextractor", "ORBmatcher", "ORBVocabulary", "StereoParams", "FrameBounds", "GfoError", "KEYPOINT_DTYPE",
+# images per GPU per step of bench.py's headline workload AND of the parity test at that shape (tests/test_gpu_properties.py):
+# one constant, so that what is timed is what is compared with the oracle
+HEADLINE_BATCH = 256
+
+__all__ = ["HEADLINE_BATCH", "ORBextractor", "ORBmatcher", "ORBVocabulary", "StereoParams", "FrameBounds", "GfoError", "KEYPOINT_DTYPE",
            "MAP_POINT_DTYPE", "build_library", "load_library", "lib_path"]

@@ -523,6 +523,39 @@ extern "C" int gfo_version(void) { return GFO_VERSION; }
 
 extern "C" const char* gfo_last_error(const gfo_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_err.c_str(); }
 
+// The HIP runtime loads a translation unit's code object and registers each kernel on the FIRST launch that needs it.
+// Round 3 saw eight host threads reach their first k_pack_results launch together and one of them fault inside the runtime
+// (under rocprofv3, which hooks exactly that code-object load; profiles/boundary_trace_r04.txt).  Whatever the runtime's own
+// locking is worth there, this library no longer depends on it: the first gfo_ctx_create on a device resolves every kernel
+// of every translation unit (hipFuncGetAttributes = load + register, no launch) under one mutex, and later contexts find
+// the device marked.  GFO_PRELOAD=0 restores the lazy behaviour (experiments only).
+struct GfoPack;
+static void gfo_kernels_api(std::vector<const void*>& v);
+static std::mutex g_preload_mu;
+static uint64_t g_preloaded_devices = 0;
+static std::atomic<int> g_kernels_preloaded{0};
+static int gfo_preload_kernels(int device)
+{
+    std::lock_guard<std::mutex> lk(g_preload_mu);
+    if (device < 64 && (g_preloaded_devices >> device & 1)) return GFO_OK;
+    if (const char* e = getenv("GFO_PRELOAD")) if (atoi(e) == 0) return GFO_OK;
+    std::vector<const void*> ks;
+    gfo_kernels_pyramid(ks); gfo_kernels_blur(ks); gfo_kernels_fast(ks); gfo_kernels_quadtree(ks); gfo_kernels_orient_desc(ks);
+    gfo_kernels_stereo(ks); gfo_kernels_project(ks); gfo_kernels_bow(ks); gfo_kernels_api(ks);
+    for (const void* k : ks) {
+        hipFuncAttributes fa;
+        const hipError_t e = hipFuncGetAttributes(&fa, k);
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            return fail(nullptr, GFO_ERR_DEVICE, "kernel %d of %d did not load on device %d: %s", (int)(&k - ks.data()), (int)ks.size(), device, hipGetErrorString(e));
+        }
+    }
+    g_kernels_preloaded += (int)ks.size();
+    if (device < 64) g_preloaded_devices |= 1ull << device;
+    return GFO_OK;
+}
+extern "C" int gfo_kernels_preloaded(void) { return g_kernels_preloaded.load(); }
+
 extern "C" int gfo_ctx_create(const gfo_params* p, int device, gfo_ctx** out)
 {
     if (!p || !out) return fail(nullptr, GFO_ERR_INVALID, "null argument");
@@ -540,6 +573,7 @@ extern "C" int gfo_ctx_create(const gfo_params* p, int device, gfo_ctx** out)
     if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
         return fail(nullptr, GFO_ERR_DEVICE, "device %d is %s; libgfo is built for gfx950 only", device, prop.gcnArchName);
     HIP_TRY(nullptr, hipSetDevice(device));
+    if (const int prc = gfo_preload_kernels(device)) return prc;
     gfo_ctx* c = new gfo_ctx();
     c->prm = *p;
     if (c->prm.max_batch < 1) c->prm.max_batch = 1;
@@ -1728,4 +1762,9 @@ extern "C" int gfo_debug_level_candidates(gfo_ctx* c, int image, int level, int3
         }
     }
     return GFO_OK;
+}
+
+static void gfo_kernels_api(std::vector<const void*>& v)
+{
+    v.push_back((const void*)k_pack_results); v.push_back((const void*)k_unpack_pairs);
 }

@@ -262,6 +262,15 @@ inline int* gfo_take_zero_cnt(gfo_ctx* c)
     c->zero_cnt_pending = false;
     return c->d_cand_cnt;
 }
+// every kernel of a translation unit (for gfo_preload_kernels, gfo_api.hip)
+void gfo_kernels_fast(std::vector<const void*>& v);
+void gfo_kernels_pyramid(std::vector<const void*>& v);
+void gfo_kernels_blur(std::vector<const void*>& v);
+void gfo_kernels_quadtree(std::vector<const void*>& v);
+void gfo_kernels_orient_desc(std::vector<const void*>& v);
+void gfo_kernels_stereo(std::vector<const void*>& v);
+void gfo_kernels_project(std::vector<const void*>& v);
+void gfo_kernels_bow(std::vector<const void*>& v);
 void gfo_launch_resize(gfo_ctx* c, const GfoInput& in, int level, int nimg);
 void gfo_launch_resize_tail(gfo_ctx* c, const GfoInput& in, int level_begin, int nimg);
 size_t gfo_quadtree_lds_bytes(int ncap, int klds);

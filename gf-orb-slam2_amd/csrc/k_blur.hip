@@ -266,3 +266,8 @@ void gfo_launch_blur(gfo_ctx* c, const GfoInput& in, int nimg)
                            c->d_pyr, c->d_blur);
     gfo_prof_end(c);
 }
+
+// Every __global__ of this translation unit, for gfo_preload_kernels (gfo_api.hip): the runtime loads a code object and
+// registers a kernel lazily, on the first launch that needs it; gfo_ctx_create resolves them all once per device under a
+// mutex so that no two host threads ever race through that first-launch path (round 3: eight threads, first k_pack_results).
+void gfo_kernels_blur(std::vector<const void*>& v) { v.push_back((const void*)k_blur); }

@@ -576,3 +576,12 @@ extern "C" int gfo_compute_bow(gfo_ctx* c, const uint8_t* desc, int n, int level
     *n_fv_nodes = cnt[1];
     return GFO_OK;
 }
+
+// Every __global__ of this translation unit, for gfo_preload_kernels (gfo_api.hip): the runtime loads a code object and
+// registers a kernel lazily, on the first launch that needs it; gfo_ctx_create resolves them all once per device under a
+// mutex so that no two host threads ever race through that first-launch path (round 3: eight threads, first k_pack_results).
+void gfo_kernels_bow(std::vector<const void*>& v)
+{
+    v.push_back((const void*)k_bow_match); v.push_back((const void*)k_bow_rotation); v.push_back((const void*)k_bow_transform);
+    v.push_back((const void*)k_bow_fold);
+}

@@ -485,3 +485,17 @@ void gfo_launch_fast(gfo_ctx* c, const GfoInput& in, int nimg)
 #undef GFO_FAST_DBG_ARG
     gfo_prof_end(c);
 }
+
+// Every __global__ of this translation unit, for gfo_preload_kernels (gfo_api.hip): the runtime loads a code object and
+// registers a kernel lazily, on the first launch that needs it; gfo_ctx_create resolves them all once per device under a
+// mutex so that no two host threads ever race through that first-launch path (round 3: eight threads, first k_pack_results).
+void gfo_kernels_fast(std::vector<const void*>& v)
+{
+#ifndef GFO_FAST_DEBUG
+    v.push_back((const void*)k_fast<48, 44, true>); v.push_back((const void*)k_fast<48, 44, false>);
+    v.push_back((const void*)k_fast<64, 60, true>); v.push_back((const void*)k_fast<64, 60, false>);
+    v.push_back((const void*)k_fast<80, 76, true>); v.push_back((const void*)k_fast<80, 76, false>);
+#else
+    (void)v;
+#endif
+}

@@ -888,3 +888,12 @@ extern "C" int gfo_projection_device_views(gfo_ctx* c, const int32_t** d_out_mp,
     if (counters_stride) *counters_stride = PJ_CNT;
     return GFO_OK;
 }
+
+// Every __global__ of this translation unit, for gfo_preload_kernels (gfo_api.hip): the runtime loads a code object and
+// registers a kernel lazily, on the first launch that needs it; gfo_ctx_create resolves them all once per device under a
+// mutex so that no two host threads ever race through that first-launch path (round 3: eight threads, first k_pack_results).
+void gfo_kernels_project(std::vector<const void*>& v)
+{
+    v.push_back((const void*)k_proj_grid); v.push_back((const void*)k_proj_round0<true>); v.push_back((const void*)k_proj_round0<false>);
+    v.push_back((const void*)k_proj_resolve<true>); v.push_back((const void*)k_proj_resolve<false>);
+}

@@ -386,3 +386,11 @@ int gfo_pyramid_bands_prepare(int lds_bytes)
     if (lds_bytes <= 64 * 1024) return 0;
     return (int)hipFuncSetAttribute(reinterpret_cast<const void*>(k_pyramid_bands), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
 }
+
+// Every __global__ of this translation unit, for gfo_preload_kernels (gfo_api.hip): the runtime loads a code object and
+// registers a kernel lazily, on the first launch that needs it; gfo_ctx_create resolves them all once per device under a
+// mutex so that no two host threads ever race through that first-launch path (round 3: eight threads, first k_pack_results).
+void gfo_kernels_pyramid(std::vector<const void*>& v)
+{
+    v.push_back((const void*)k_resize); v.push_back((const void*)k_resize_tail); v.push_back((const void*)k_pyramid_bands);
+}

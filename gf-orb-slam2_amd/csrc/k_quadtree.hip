@@ -199,3 +199,11 @@ void gfo_launch_quadtree(gfo_ctx* c, int nimg)
     }
     gfo_prof_end(c);
 }
+
+// Every __global__ of this translation unit, for gfo_preload_kernels (gfo_api.hip): the runtime loads a code object and
+// registers a kernel lazily, on the first launch that needs it; gfo_ctx_create resolves them all once per device under a
+// mutex so that no two host threads ever race through that first-launch path (round 3: eight threads, first k_pack_results).
+void gfo_kernels_quadtree(std::vector<const void*>& v)
+{
+    v.push_back((const void*)k_quadtree); v.push_back((const void*)k_quadtree_gmem);
+}

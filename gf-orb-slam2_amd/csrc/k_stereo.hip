@@ -766,3 +766,12 @@ void gfo_launch_stereo(gfo_ctx* c, const GfoStereoLaunch& s)
     GFO_LAUNCH(c, k_stereo_cut, dim3(s.npairs), dim3(cut_threads), 0, c->stream, s.cnt_dev, s.nl_host, s.out, s.out_stride);
     gfo_prof_end(c);
 }
+
+// Every __global__ of this translation unit, for gfo_preload_kernels (gfo_api.hip): the runtime loads a code object and
+// registers a kernel lazily, on the first launch that needs it; gfo_ctx_create resolves them all once per device under a
+// mutex so that no two host threads ever race through that first-launch path (round 3: eight threads, first k_pack_results).
+void gfo_kernels_stereo(std::vector<const void*>& v)
+{
+    v.push_back((const void*)k_stereo_bucket); v.push_back((const void*)k_stereo_match); v.push_back((const void*)k_stereo_match_rows);
+    v.push_back((const void*)k_stereo_cut); v.push_back((const void*)k_stereo_match_sad); v.push_back((const void*)k_stereo_cut_sad);
+}

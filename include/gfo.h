@@ -387,6 +387,11 @@ int gfo_profile_read(gfo_ctx* ctx, gfo_stage_time* out, int cap, int* nstages, i
  * (tools/c/boundary_throughput.c and the adapter's context table assert it). */
 int gfo_contexts_created(void);
 int gfo_arenas_planned(void);
+/* Kernels resolved ahead of their first launch.  The first gfo_ctx_create on a device loads every code object of the library and
+ * registers every kernel, serialised under one mutex, so that K host threads issuing their first frames at once (the reference's
+ * K Frame constructors, Frame.cc:84-87) never race through the HIP runtime's lazy first-launch path.  Returns the number resolved
+ * so far (kernels x devices used); a per-frame loop leaves it unchanged. */
+int gfo_kernels_preloaded(void);
 
 /* ---- inspection hooks for the parity tests (device -> host copies of intermediates) ------ */
 int gfo_debug_blurred_level(gfo_ctx* ctx, int image, int level, uint8_t* out, int out_stride);

@@ -1,4 +1,5 @@
-"""Size-independent properties at the bench's full batch size (128 images, 752x480, 2000 features): the oracle
+"""Size-independent properties at the bench's full batch size (gf_orb_slam2_amd.HEADLINE_BATCH = bench.py's --batch default:
+256 images, 752x480, 2000 features): the oracle
 is too slow to check every image of every batch, so these pin the batched device path against itself and
 against invariants of the reference algorithm."""
 import numpy as np
@@ -6,7 +7,7 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 
-B = 128
+from gf_orb_slam2_amd import HEADLINE_BATCH as B      # the constant bench.py's --batch defaults to
 
 
 @pytest.fixture(scope="module")
@@ -15,7 +16,7 @@ def batch():
     import gf_orb_slam2_amd as G
     from gf_orb_slam2_amd.synth import synth_stereo_pair
     frames = []
-    for p in range(8):                       # 8 distinct pairs tiled to 128 images
+    for p in range(8):                       # 8 distinct pairs tiled to B images
         l, r = synth_stereo_pair(752, 480, 500 + p)
         frames += [l, r]
     imgs = np.stack([frames[i % 16] for i in range(B)])
@@ -46,8 +47,8 @@ def test_full_batch_is_deterministic_and_position_independent(batch, oracle):
         k, d = ext.batch_fetch(i)
         fk, fd = first[i % 16]
         assert k.tobytes() == fk.tobytes() and (d == fd).all()
-    # two of the 128 against the oracle
-    for i in (3, 77):
+    # two of the batch against the oracle
+    for i in (3, B - 51):
         ok, od = oracle.OracleExtractor(2000, 1.2, 8, 20, 7)(imgs[i])
         k, d = ext.batch_fetch(i)
         assert k.tobytes() == ok.tobytes() and (d == od).all()
@@ -120,9 +121,10 @@ def oracle_refs(batch, oracle):
 
 
 def test_headline_configuration_against_the_oracle(batch, oracle_refs):
-    """bench.py's exact headline shape: 128 images per step, TWO contexts chained behind each
-    other's pyramid (gfo_ctx_chain), four alternating steps submitted without a synchronisation in between, stereo
-    association of the 64 pairs -- then, per context, 16 images (every distinct image once, at positions spread over
+    """bench.py's exact headline shape: HEADLINE_BATCH = 256 images per step (the XCD8 grids with
+    32 image groups, 128-pair stereo launches, the 512- / 256-thread bucket / cut kernels, the 256-image delivery layout), TWO
+    contexts chained behind each other's pyramid (gfo_ctx_chain), four alternating steps submitted without a synchronisation in
+    between, stereo association of the B/2 pairs -- then, per context, 16 images (every distinct image once, at positions spread over
     the batch) and 8 pairs compared with the oracle bit for bit, read back through gfo_batch_deliver (the delivery
     path bench.py's `value_delivered` uses) and cross-checked against gfo_batch_fetch / gfo_stereo_fetch."""
     import torch
@@ -130,7 +132,8 @@ def test_headline_configuration_against_the_oracle(batch, oracle_refs):
     _, t, imgs = batch
     ext_refs, st_refs = oracle_refs
     # a second input batch with the 8 pairs in another order, so that a frame's slot differs between the inputs
-    perm = np.concatenate([[2 * ((p * 5 + 3) % 64), 2 * ((p * 5 + 3) % 64) + 1] for p in range(64)])
+    NP = B // 2
+    perm = np.concatenate([[2 * ((p * 5 + 3) % NP), 2 * ((p * 5 + 3) % NP) + 1] for p in range(NP)])
     t2 = t[torch.from_numpy(perm).cuda()].contiguous()
     inputs, ident = [t, t2], [np.arange(B) % 16, perm % 16]
     prm = G.StereoParams(480, 47.90639384423901, 47.90639384423901 / 435.2046959714599, 0.0)
@@ -160,9 +163,9 @@ def test_headline_configuration_against_the_oracle(batch, oracle_refs):
             n = int(v["counts"][i])
             ok, od = ext_refs[j]
             assert n == len(ok) and v["kp"][i, :n].tobytes() == ok.tobytes() and (v["desc"][i, :n] == od).all(), f"ctx {k} image slot {i}"
-        pairs = sorted({i // 2 for i in slots})[:8] if len({i // 2 for i in slots}) >= 8 else list(range(0, 64, 8))
+        pairs = sorted({i // 2 for i in slots})[:8] if len({i // 2 for i in slots}) >= 8 else list(range(0, NP, NP // 8))
         seen = set()
-        for pr in pairs + list(range(64)):
+        for pr in pairs + list(range(NP)):
             j = int(ident[src][2 * pr]) // 2
             if j in seen:
                 continue

@@ -256,6 +256,22 @@ int main(int argc, char** argv)
     if (!f || fread(IMR, 1, W * H, f) != W * H) { fprintf(stderr, "cannot read %s\n", path); return 2; }
     fclose(f);
     if (g_pin && G.host_register(IMGS, sizeof IMGS)) { fprintf(stderr, "gfo_host_register: %s\n", G.last_error(NULL)); return 2; }
+    if (getenv("GFO_DUMP_MAPS") && atoi(getenv("GFO_DUMP_MAPS"))) {
+        /* so that an abort in this process is symbolisable afterwards: one context created (the HIP / HSA runtimes, and under a
+         * profiler its tool libraries, are mapped by then), then the process's address map to stderr */
+        gfo_params p0 = {2000, 1.2f, 8, 20, 7, 2};
+        gfo_ctx* c0 = NULL;
+        if (G.ctx_create(&p0, 0, &c0) == 0) G.ctx_destroy(c0);
+        FILE* m = fopen("/proc/self/maps", "r");
+        if (m) {
+            char line[1024];
+            fprintf(stderr, "---- /proc/self/maps (GFO_DUMP_MAPS) ----\n");
+            while (fgets(line, sizeof line, m))
+                if (strstr(line, " r-xp ") || strstr(line, ".so")) fputs(line, stderr);
+            fprintf(stderr, "---- end of maps ----\n");
+            fclose(m);
+        }
+    }
     int bad = 0, first = 1;
     printf("{\"workload\": \"EuRoC stereo pair 752x480 @2000, one frame per call, K independent streams\", \"points\": [\n");
     for (int mode = 0; mode < 2; mode++) {

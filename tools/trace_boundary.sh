@@ -7,7 +7,7 @@ TAG=$1; K=${2:-8}; MODE=${3:-stereo}; API=${4:-1}; CMB=${5:-1}
 R=$GRAFT_REPO_ROOT; OUT=$R/gpurun_out/trace_boundary_$TAG; rm -rf $OUT; mkdir -p $OUT; cd $R
 gcc -O2 -I include tools/c/boundary_throughput.c -o /tmp/boundary_throughput -ldl -lpthread -lm || exit 1
 EXTRA=""; [ "$API" = "1" ] && EXTRA="--hip-runtime-trace"
-timeout -k 10 240 rocprofv3 --kernel-trace --memory-copy-trace $EXTRA --output-format csv -d $OUT -- /tmp/boundary_throughput gf-orb-slam2_amd/libgfo.so tests/golden 0.5 $MODE $K $CMB > $OUT/log.txt 2>&1
+GFO_DUMP_MAPS=1 timeout -k 10 240 rocprofv3 --kernel-trace --memory-copy-trace $EXTRA --output-format csv -d $OUT -- /tmp/boundary_throughput gf-orb-slam2_amd/libgfo.so tests/golden 0.5 $MODE $K $CMB > $OUT/log.txt 2>&1
 grep -v amdgpu.ids $OUT/log.txt | tail -4 | cut -c1-330
 python3 - "$OUT" <<'PY' | tee $R/gpurun_out/trace_boundary_$TAG.txt
 import csv, glob, os, sys, collections
