@@ -243,7 +243,7 @@ def per_frame_boundary(seconds=1.0):
             j = json.loads(r.stdout.decode(errors="replace"))
             for p in j["points"]:
                 pts.append({k: p[k] for k in ("path", "combining", "streams", "host_threads", "images_per_s", "stereo_frames_per_s",
-                                              "frames_per_device_batch", "latency_ms", "result_mismatches", "errors",
+                                              "frames_per_device_batch", "latency_ms", "stereo_rig", "result_mismatches", "errors",
                                               "contexts_created_in_timed_region", "arenas_planned_in_timed_region")})
             if r.returncode != 0:
                 return {"error": f"harness rc {r.returncode}", "points": pts}

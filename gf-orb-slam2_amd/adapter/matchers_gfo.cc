@@ -117,6 +117,10 @@ int Frame::ComputeStereoMatches_Undistorted(bool /*isOnline*/)
     int nmatched = 0;
     cv::Mat keepL, keepR;
     gfo_ctx* c = gfo_context_of(mpORBextractorLeft);
+    // the two extractors are one stereo rig with this calibration: from the next frame on their two operator() calls go to the
+    // device as one stereo submission that also computes this association, and the call below -- on rectified input, where
+    // mvKeysUn == mvKeys -- is answered from it (gfo_ctx_pair: a hint, idempotent, a few nanoseconds when nothing changed)
+    if (mpORBextractorRight) (void)gfo_ctx_pair(c, gfo_context_of(mpORBextractorRight), &p);
     const int rc = gfo_stereo_match(c, as_gfo(mvKeysUn), rows32(mDescriptors, keepL), N, as_gfo(mvKeysRightUn),
                                     rows32(mDescriptorsRight, keepR), (int)mvKeysRightUn.size(), mvScaleFactors.data(),
                                     (int)mvScaleFactors.size(), &p, windows ? minD.data() : NULL, windows ? maxD.data() : NULL,

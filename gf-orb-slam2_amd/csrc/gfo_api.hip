@@ -618,6 +618,7 @@ extern "C" void gfo_ctx_destroy(gfo_ctx* c)
         for (gfo_ctx* o : g_ctx_live)
             if (o->chain_after == c) o->chain_after = nullptr;
     }
+    gfo_pair_release(c);     // a stereo rig this context was declared part of (gfo_ctx_pair)
     gfo_engine_release(c);   // the combiner's engine (and its batch contexts) goes with its last member
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
@@ -1158,6 +1159,18 @@ extern "C" int gfo_host_unregister(void* p)
     return GFO_OK;
 }
 
+// pinned memory of the library's own that images are staged in (the stereo rigs of gfo_combine.hip): same registry
+void gfo_note_pinned(const uint8_t* p, size_t bytes, bool add)
+{
+    std::lock_guard<std::mutex> lk(g_pin_mu);
+    if (add) {
+        g_pinned.push_back({p, p + bytes});
+        return;
+    }
+    for (size_t i = 0; i < g_pinned.size(); i++)
+        if (g_pinned[i].first == p) { g_pinned.erase(g_pinned.begin() + i); break; }
+}
+
 static bool host_pinned(const uint8_t* p, size_t bytes)
 {
     std::lock_guard<std::mutex> lk(g_pin_mu);
@@ -1381,7 +1394,13 @@ extern "C" int gfo_extract_batch(gfo_ctx* c, const uint8_t* const* imgs, int nim
         gfo_keypoint* kps[1] = {kp};
         uint8_t* ds[1] = {desc};
         c->have_batch = c->have_pyramid = c->have_stereo = false;   // the device-side state lives in the combiner's arena
-        return gfo_combined_extract(c, 1, imgs, w, h, stride, nullptr, kps, ds, cap, n, nullptr, nullptr, nullptr, nullptr, nullptr);
+        if (c->pair) {      // one camera of a declared stereo rig: this frame and its partner's go down as ONE stereo request
+            const int prc = gfo_pair_extract(c, imgs[0], w, h, stride, kp, desc, cap, n);
+            if (prc != GFO_COMBINE_DIRECT) return prc;
+        }
+        const int crc = gfo_combined_extract(c, 1, imgs, w, h, stride, nullptr, kps, ds, cap, n, nullptr, nullptr, nullptr, nullptr, nullptr);
+        if (crc != GFO_COMBINE_DIRECT) return crc;
+        // the engine cannot serve this frame (no slot could be prepared, or its batch failed as a whole): alone, below
     }
     HIP_TRY(c, hipSetDevice(c->device));
     int rc = gfo_plan(c, w, h, nimg);
@@ -1431,9 +1450,12 @@ extern "C" int gfo_extract_stereo(gfo_ctx* c, const uint8_t* img_l, const uint8_
     if (c->combining) {
         c->have_batch = c->have_pyramid = c->have_stereo = false;
         const int crc = gfo_combined_extract(c, 2, imgs, w, h, stride, p, kps, ds, cap, n, u_right, depth, best_dist, best_idx_r, nmatched);
-        *n_l = n[0];
-        *n_r = n[1];
-        return crc;
+        if (crc != GFO_COMBINE_DIRECT) {
+            *n_l = n[0];
+            *n_r = n[1];
+            return crc;
+        }
+        n[0] = n[1] = 0;      // the engine cannot serve this frame: alone, below
     }
     HIP_TRY(c, hipSetDevice(c->device));
     int rc = gfo_plan(c, w, h, 2);
@@ -1562,6 +1584,9 @@ extern "C" int gfo_stereo_match(gfo_ctx* c, const gfo_keypoint* kl, const uint8_
     for (int i = 0; i < nr; i++)
         if (kr[i].octave < 0 || kr[i].octave >= nlevels) return fail(c, GFO_ERR_INVALID, "right keypoint %d: octave %d outside 0..%d", i, kr[i].octave, nlevels - 1);
     if (p->n_rows < 1 || p->n_rows > 8192) return fail(c, GFO_ERR_INVALID, "n_rows must be 1..8192");
+    // a declared stereo rig (gfo_ctx_pair) whose last frame these arrays are: the association was computed with that frame
+    if (c->pair && gfo_pair_lookup(c, kl, dl, nl, kr, dr, nr, sf, nlevels, p, min_d, max_d, u_right, depth, best_dist, best_idx_r, nmatched) == 0)
+        return GFO_OK;
     if (c->combining) {    // the pairs several threads associate at once share one launch (gfo_combine.hip); 1 = not eligible
         int status = GFO_OK;
         if (gfo_combined_stereo_match(c, kl, dl, nl, kr, dr, nr, sf, nlevels, p, min_d, max_d, u_right, depth, best_dist, best_idx_r, nmatched, &status) == 0)

@@ -23,6 +23,7 @@
 // (tests/test_gpu_combine.py, and the checksums of tools/c/boundary_throughput.c under load).
 #include "gfo_internal.h"
 
+#include <chrono>
 #include <condition_variable>
 #include <map>
 #include <memory>
@@ -61,12 +62,57 @@ struct GfoEngine {
     int forming[4] = {-1, -1, -1, -1};   // per kind of request: the slot that accepts joiners (an extraction batch that is forming
                                          // must not hold up the association calls of the threads that are a phase ahead, and vice versa)
     int running = 0;          // batches submitted and not yet complete
-    long batches = 0, requests = 0;
+    int prepared = 0;         // slots that have their batch context (prepared lazily: two by the first request, one more whenever
+                              // a caller finds every prepared slot busy -- concurrent callers observed -- up to nslot)
+    int fail_prepare_from = -1, fail_batch_every = 0;   // tests only: injected failures (slot_prepare, run_request)
+    bool grow_failed = false; // a later slot could not be prepared: the engine keeps the slots it has
+    bool broken = false;      // a slot could not be prepared (out of memory) and none exists: every caller takes the direct path
+    long batches = 0, requests = 0, redone = 0;
     ~GfoEngine()
     {
         for (Slot& s : slot) {
             if (s.d_pairs) (void)hipFree(s.d_pairs);
             if (s.bc) gfo_ctx_destroy(s.bc);
+        }
+    }
+};
+
+// Two extractor contexts that the caller declared to be the left and right camera of one stereo rig (gfo_ctx_pair): the
+// reference's mpORBextractorLeft / mpORBextractorRight, called from two threads per frame (Frame.cc:84-87), followed by
+// Frame::ComputeStereoMatches on the arrays the two calls returned (Frame.cc:100).  The two gfo_extract calls of a frame meet
+// here, go to the engine as ONE stereo request (what gfo_extract_stereo would have submitted), and the association the third
+// call is going to ask for is computed in the same submission and kept; gfo_stereo_match then only has to establish that it is
+// being asked about exactly those arrays.
+struct GfoPair {
+    std::mutex mu;
+    std::condition_variable cv;
+    gfo_ctx* ctx[2] = {nullptr, nullptr};
+    gfo_stereo_params sp{};
+    struct Req {
+        const uint8_t* img = nullptr;
+        int w = 0, h = 0;
+        gfo_keypoint* kp = nullptr;
+        uint8_t* desc = nullptr;
+        int cap = 0, rc = 0;
+        int* n = nullptr;
+        bool arrived = false, staged = false;
+    } req[2];
+    int state = 0;            // 0 idle, 1 one side waiting for its partner, 2 the second arrival is executing the frame, 3 done: the waiter picks up
+    uint8_t* h_pair = nullptr;   // pinned: left image | right image, tight rows -- each side copies its own half, ONE copy takes both down
+    int w = 0, h = 0;
+    // the frame delivered last: what the two calls returned (for the identity check) and its association
+    bool valid = false, batch_ok = false, other_kept = false;
+    int nl = 0, nr = 0, nm = 0;
+    std::vector<gfo_keypoint> rk[2];
+    std::vector<uint8_t> rd[2];
+    std::vector<float> ur, dp;
+    std::vector<int32_t> bd, bi;
+    long speculated = 0, served = 0, solo = 0;
+    ~GfoPair()
+    {
+        if (h_pair) {
+            gfo_note_pinned(h_pair, 0, false);
+            (void)hipHostFree(h_pair);
         }
     }
 };
@@ -95,6 +141,8 @@ std::shared_ptr<GfoEngine> engine_for(gfo_ctx* c, int w, int h)
             if (v >= 1 && v <= NSLOT - 4) e->inflight = v;
         }
         e->nslot = e->inflight + 4 <= NSLOT ? e->inflight + 4 : NSLOT;
+        if (const char* m = getenv("GFO_COMBINE_FAIL_PREPARE")) e->fail_prepare_from = atoi(m);
+        if (const char* m = getenv("GFO_COMBINE_FAIL_BATCH")) e->fail_batch_every = atoi(m);
         g_engines[key] = e;
     }
     c->engine = e;
@@ -105,6 +153,9 @@ std::shared_ptr<GfoEngine> engine_for(gfo_ctx* c, int w, int h)
 int slot_prepare(GfoEngine* e, Slot& s, gfo_ctx* c)
 {
     if (s.bc) return GFO_OK;
+    // tests only (tests/test_gpu_combine.py): GFO_COMBINE_FAIL_PREPARE=k makes the k-th and every later slot preparation of an
+    // engine fail as an out-of-memory would (k = 0: the engine never gets a slot and its callers take the direct path)
+    if (e->fail_prepare_from >= 0 && e->prepared >= e->fail_prepare_from) return gfo_fail(c, GFO_ERR_DEVICE, "combiner: slot preparation failed (injected)");
     gfo_params p = e->prm;
     p.max_batch = e->cap_images;
     int rc = gfo_ctx_create(&p, e->device, &s.bc);
@@ -152,6 +203,22 @@ extern "C" int gfo_combiner_stats(const gfo_ctx* c, int64_t* batches, int64_t* r
     return GFO_OK;
 }
 
+extern "C" int gfo_combiner_counters(const gfo_ctx* c, int64_t* out, int n)
+{
+    if (!c || !out || n < 1) return GFO_ERR_INVALID;
+    int64_t v[GFO_COMBINER_COUNTERS] = {0};
+    if (std::shared_ptr<GfoEngine> e = c->engine) {
+        std::lock_guard<std::mutex> lk(e->mu);
+        v[0] = e->batches; v[1] = e->requests; v[2] = e->redone; v[3] = e->prepared; v[4] = e->broken ? 1 : 0;
+    }
+    if (std::shared_ptr<GfoPair> P = c->pair) {
+        std::lock_guard<std::mutex> lk(P->mu);
+        v[5] = P->speculated; v[6] = P->served; v[7] = P->solo;
+    }
+    for (int i = 0; i < n && i < GFO_COMBINER_COUNTERS; i++) out[i] = v[i];
+    return GFO_OK;
+}
+
 // One request of one caller through the engine's slots.  kind 1: one image (gfo_extract); 2: a stereo frame
 // (gfo_extract_stereo); 3: the host-array stereo association of one pair (gfo_stereo_match -- the third call of the adapter's
 // pattern).  `units` = images of the batch capacity a request takes.  upload(slot, idx): the caller's own inputs on their
@@ -173,14 +240,32 @@ static int run_request(gfo_ctx* c, GfoEngine* e, int kind, int units, const gfo_
                 break;
             }
         } else {
-            // every slot the engine will ever use is prepared by its first request: nothing is created or planned once the
-            // streams are running (gfo_contexts_created / gfo_arenas_planned stay put in steady state)
-            for (int i = 0; i < e->nslot; i++) {
-                const int rc = slot_prepare(e, e->slot[i], c);
-                if (rc) return rc;
-            }
-            for (int i = 0; i < e->nslot && si < 0; i++)
+            // Slots are prepared as concurrency shows: a slot is an arena for cap_images images plus pinned buffers --
+            // ~130 MB at 752x480, several hundred MB at 1080p -- and a single-threaded caller needs two (one batch collected while
+            // the next forms).  The first request prepares two; a caller that finds every prepared slot busy prepares one more,
+            // up to nslot.  K concurrent streams have theirs by the end of their first frames: gfo_contexts_created /
+            // gfo_arenas_planned then stay put.  A slot that cannot be prepared (out of memory) is not fatal: with another slot
+            // there the caller waits for it, with none the engine is marked broken and every caller takes the direct path.
+            if (e->broken) return GFO_COMBINE_DIRECT;
+            for (int i = 0; i < e->prepared && si < 0; i++)
                 if (e->slot[i].state == SLOT_FREE) si = i;
+            if (si < 0 && e->prepared < e->nslot && !e->grow_failed) {
+                const int want = e->prepared == 0 ? (e->nslot < 2 ? e->nslot : 2) : e->prepared + 1;
+                while (e->prepared < want) {
+                    if (slot_prepare(e, e->slot[e->prepared], c)) {
+                        e->grow_failed = true;
+                        break;
+                    }
+                    e->prepared++;
+                }
+                if (e->prepared == 0) {
+                    e->broken = true;
+                    e->cv.notify_all();
+                    return GFO_COMBINE_DIRECT;
+                }
+                for (int i = 0; i < e->prepared && si < 0; i++)
+                    if (e->slot[i].state == SLOT_FREE) si = i;
+            }
             if (si >= 0) {
                 Slot& f = e->slot[si];
                 if (sp && (sp->n_rows < 1 || sp->n_rows > f.bc->st_rows_cap))
@@ -222,9 +307,11 @@ static int run_request(gfo_ctx* c, GfoEngine* e, int kind, int units, const gfo_
         e->running++;
         e->batches++;
         int rc = s.rc;
+        const bool inject = e->fail_batch_every > 0 && nb > 1 && e->batches % e->fail_batch_every == 0;   // tests only
         lk.unlock();
         if (!rc) rc = submit(s, nb);
         else (void)hipStreamSynchronize(s.bc->stream);
+        if (!rc && inject) rc = gfo_fail(s.bc, GFO_ERR_OVERFLOW, "batch failure (injected)");
         lk.lock();
         e->running--;
         s.rc = rc;
@@ -237,8 +324,17 @@ static int run_request(gfo_ctx* c, GfoEngine* e, int kind, int units, const gfo_
         if (s.state == SLOT_CLOSED && s.staged == s.n) s.cv.notify_all();   // the leader is waiting for this copy
         while (!(s.gen == my_gen && s.state == SLOT_DRAINING)) s.cv.wait(lk);
     }
-    const int brc = s.rc;
-    if (brc) gfo_fail(c, brc, "combined batch: %s", s.err.c_str());
+    int brc = s.rc;
+    if (brc && s.n > 1) {
+        // a batch-level failure is not every member's failure: one frame that trips the shared overflow flags, or
+        // one caller's failed upload, must not fail the other callers' frames -- "a combined call returns what the direct
+        // call returns".  Every member of a failed batch of several re-runs its own request alone on the direct path; only the
+        // frame that really fails reports the error, from its own context.
+        brc = GFO_COMBINE_DIRECT;
+        e->redone++;
+    } else if (brc) {
+        gfo_fail(c, brc, "combined batch: %s", s.err.c_str());
+    }
     lk.unlock();
 
     *truncated = 0;
@@ -273,7 +369,7 @@ int gfo_combined_extract(gfo_ctx* c, int kind, const uint8_t* const* imgs, int w
             return o;
         },
         &over);
-    if (rc) return rc;
+    if (rc) return rc;      // (GFO_COMBINE_DIRECT: the caller takes the direct path)
     return over ? gfo_fail(c, GFO_ERR_CAPACITY, "an image produced more keypoints than the caller capacity %d", cap) : GFO_OK;
 }
 
@@ -291,7 +387,7 @@ int gfo_combined_stereo_match(gfo_ctx* c, const gfo_keypoint* kl, const uint8_t*
     int ks = 0, rows_cap = 0;
     {
         std::lock_guard<std::mutex> lk(e->mu);
-        if (!e->slot[0].bc || !e->slot[0].d_pairs) return 1;
+        if (e->broken || !e->slot[0].bc || !e->slot[0].d_pairs) return 1;
         ks = e->slot[0].bc->g.kp_stride;
         rows_cap = e->slot[0].bc->st_rows_cap;
     }
@@ -329,5 +425,200 @@ int gfo_combined_stereo_match(gfo_ctx* c, const gfo_keypoint* kl, const uint8_t*
             return 0;
         },
         &trunc);
+    return *status == GFO_COMBINE_DIRECT ? 1 : 0;      // the engine could not serve it (or its batch failed as a whole): direct path
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// stereo rigs: gfo_ctx_pair
+// ---------------------------------------------------------------------------------------------------------------------
+extern "C" int gfo_ctx_pair(gfo_ctx* left, gfo_ctx* right, const gfo_stereo_params* p)
+{
+    if (!left) return GFO_ERR_INVALID;
+    if (!right || !p) {      // dissolve
+        gfo_pair_release(left);
+        return GFO_OK;
+    }
+    if (left == right) return gfo_fail(left, GFO_ERR_INVALID, "a context cannot be its own stereo partner");
+    if (left->device != right->device || memcmp(&left->prm, &right->prm, offsetof(gfo_params, max_batch)) != 0)
+        return gfo_fail(left, GFO_ERR_INVALID, "stereo partners need equal extractor parameters and one device");
+    if (std::shared_ptr<GfoPair> P = left->pair) {      // the usual call: once per frame, nothing changes
+        std::lock_guard<std::mutex> lk(P->mu);
+        if (P == right->pair && P->ctx[0] == left && P->ctx[1] == right) {
+            if (memcmp(&P->sp, p, sizeof *p) != 0) {
+                P->sp = *p;
+                P->valid = false;
+            }
+            return GFO_OK;
+        }
+    }
+    gfo_pair_release(left);
+    gfo_pair_release(right);
+    std::shared_ptr<GfoPair> P = std::make_shared<GfoPair>();
+    P->ctx[0] = left; P->ctx[1] = right; P->sp = *p;
+    left->pair = P; left->pair_side = 0;
+    right->pair = P; right->pair_side = 1;
+    return GFO_OK;
+}
+
+void gfo_pair_release(gfo_ctx* c)
+{
+    std::shared_ptr<GfoPair> P = c->pair;
+    if (!P) return;
+    {
+        std::unique_lock<std::mutex> lk(P->mu);
+        while (P->state >= 2) P->cv.wait(lk);      // a frame is being executed for both sides: let it finish
+        P->ctx[c->pair_side] = nullptr;
+        P->valid = false;
+        P->cv.notify_all();
+    }
+    c->pair.reset();
+}
+
+// gfo_extract of a paired, combining context.  Returns GFO_COMBINE_DIRECT when the frame is not taken here (no partner, the
+// partner does not show up, other geometry): the caller goes on as if there were no pair.
+int gfo_pair_extract(gfo_ctx* c, const uint8_t* img, int w, int h, int stride, gfo_keypoint* kp, uint8_t* desc, int cap, int* n)
+{
+    std::shared_ptr<GfoPair> P = c->pair;
+    if (!P || (w & 15) != 0) return GFO_COMBINE_DIRECT;      // (tight rows of the staged pair must stay 16-byte aligned)
+    const int side = c->pair_side;
+    static const long wait_us = getenv("GFO_PAIR_WAIT_US") ? atol(getenv("GFO_PAIR_WAIT_US")) : 2000;
+    if (wait_us <= 0) return GFO_COMBINE_DIRECT;
+    std::unique_lock<std::mutex> lk(P->mu);
+    GfoPair::Req& me = P->req[side];
+    GfoPair::Req& other = P->req[side ^ 1];
+    gfo_ctx* partner = P->ctx[side ^ 1];
+    if (!partner || !partner->combining || me.arrived || P->state >= 2) return GFO_COMBINE_DIRECT;
+    if (P->sp.n_rows < 1 || P->sp.n_rows > h + 64) return GFO_COMBINE_DIRECT;      // an association no arena of this size is planned for: no speculation
+    if (other.arrived && (other.w != w || other.h != h)) return GFO_COMBINE_DIRECT;
+    const size_t img_bytes = (size_t)w * h;
+    if (!P->h_pair || P->w != w || P->h != h) {
+        if (other.arrived) return GFO_COMBINE_DIRECT;
+        if (P->h_pair) {
+            gfo_note_pinned(P->h_pair, 0, false);
+            (void)hipHostFree(P->h_pair);
+            P->h_pair = nullptr;
+        }
+        if (hipSetDevice(c->device) != hipSuccess || hipHostMalloc((void**)&P->h_pair, 2 * img_bytes, hipHostMallocDefault) != hipSuccess) {
+            (void)hipGetLastError();
+            P->h_pair = nullptr;
+            return GFO_COMBINE_DIRECT;
+        }
+        gfo_note_pinned(P->h_pair, 2 * img_bytes, true);
+        P->w = w; P->h = h;
+    }
+    me.img = img; me.w = w; me.h = h; me.kp = kp; me.desc = desc; me.cap = cap; me.n = n; me.rc = 0;
+    me.arrived = true; me.staged = false;
+    const bool first = !other.arrived;
+    if (first) P->state = 1;
+    else P->state = 2;            // the second arrival executes the frame for both
+    P->cv.notify_all();
+    lk.unlock();
+
+    // each side stages its own image, in parallel with the other
+    uint8_t* dst = P->h_pair + (size_t)side * img_bytes;
+    if (stride == w) memcpy(dst, img, img_bytes);
+    else
+        for (int y = 0; y < h; y++) memcpy(dst + (size_t)y * w, img + (size_t)y * stride, w);
+
+    auto retain = [&](int sd, const gfo_keypoint* k, const uint8_t* d, int cnt) {
+        P->rk[sd].assign(k, k + cnt);
+        P->rd[sd].assign(d, d + 32 * (size_t)cnt);
+    };
+    lk.lock();
+    me.staged = true;
+    P->cv.notify_all();
+    if (first) {
+        const auto deadline = std::chrono::steady_clock::now() + std::chrono::microseconds(wait_us);
+        while (!other.arrived) {
+            if (P->cv.wait_until(lk, deadline) == std::cv_status::timeout && !other.arrived) {
+                // nobody came for the other image: this frame is not a stereo frame after all
+                me.arrived = me.staged = false;
+                P->state = 0;
+                P->valid = false;
+                P->solo++;
+                return GFO_COMBINE_DIRECT;
+            }
+        }
+        while (P->state != 3) P->cv.wait(lk);
+        const int rc = me.rc;
+        const bool keep = P->batch_ok && kp && desc;
+        const int cnt = keep ? (side == 0 ? P->nl : P->nr) : 0;
+        lk.unlock();
+        if (keep) retain(side, kp, desc, cnt);      // my half of what the identity check of gfo_stereo_match compares against
+        lk.lock();
+        me.arrived = me.staged = false;
+        other.arrived = other.staged = false;
+        P->valid = P->batch_ok && keep && P->other_kept;
+        P->state = 0;
+        P->cv.notify_all();
+        return rc;
+    }
+    // executor: both images are (about to be) staged; ONE stereo request for the frame
+    while (!other.staged) P->cv.wait(lk);
+    const gfo_stereo_params sp = P->sp;
+    lk.unlock();
+    std::shared_ptr<GfoEngine> eh = engine_for(c, w, h);
+    const uint8_t* imgs[2] = {P->h_pair, P->h_pair + img_bytes};
+    int cnt[2] = {0, 0}, nm = 0, over[2] = {0, 0}, dummy = 0;
+    const int rc = run_request(
+        c, eh.get(), 2, 2, &sp,
+        [&](Slot& s, int idx) { return gfo_small_upload(s.bc, c, s.L, idx * 2, 2, imgs, w, h, w, s.bc->stream); },
+        [&](Slot& s, int nb) { return gfo_small_submit(s.bc, s.L, nb * 2, &s.sp, false); },
+        [&](Slot& s, int idx) {
+            for (int k = 0; k < 2; k++) over[k] = gfo_small_collect(s.bc, s.L, idx * 2 + k, P->req[k].kp, P->req[k].desc, P->req[k].cap, &cnt[k]);
+            const int ks = s.bc->g.kp_stride;
+            P->ur.resize(ks); P->dp.resize(ks); P->bd.resize(ks); P->bi.resize(ks);
+            gfo_small_collect_stereo(s.bc, s.L, idx, cnt[0], ks, P->ur.data(), P->dp.data(), P->bd.data(), P->bi.data(), &nm);
+            return 0;
+        },
+        &dummy);
+    const bool ok = rc == GFO_OK && !over[0] && !over[1];
+    const bool keep = ok && kp && desc && P->req[side ^ 1].kp && P->req[side ^ 1].desc;
+    if (keep) retain(side, kp, desc, cnt[side]);
+    lk.lock();
+    int my_rc = rc;
+    for (int k = 0; k < 2; k++) {
+        int r = rc;
+        if (rc == GFO_COMBINE_DIRECT) r = GFO_COMBINE_DIRECT;      // the engine could not serve the frame: both sides go on alone
+        else if (rc == GFO_OK) {
+            *P->req[k].n = cnt[k];
+            if (over[k]) r = gfo_fail(P->ctx[k] ? P->ctx[k] : c, GFO_ERR_CAPACITY, "an image produced more keypoints than the caller capacity %d", P->req[k].cap);
+        } else if (k != side && P->ctx[k]) {
+            gfo_fail(P->ctx[k], rc, "%s", gfo_last_error(c));
+        }
+        P->req[k].rc = r;
+        if (k == side) my_rc = r;
+    }
+    P->batch_ok = ok;
+    P->other_kept = keep;
+    P->nl = cnt[0]; P->nr = cnt[1]; P->nm = nm;
+    if (ok) P->speculated++;
+    P->valid = false;          // until the waiter has retained its half
+    P->state = 3;
+    P->cv.notify_all();
+    return my_rc;
+}
+
+// gfo_stereo_match on the left context of a pair: if the arrays are, bit for bit, what the pair's last two gfo_extract calls
+// returned, the calibration is the declared one and no disparity windows are given, the association computed with that frame
+// IS the answer (same kernels, same inputs).  Returns 0 when served, 1 otherwise (the caller computes it).
+int gfo_pair_lookup(gfo_ctx* c, const gfo_keypoint* kl, const uint8_t* dl, int nl, const gfo_keypoint* kr, const uint8_t* dr, int nr,
+                    const float* sf, int nlevels, const gfo_stereo_params* p, const float* min_d, const float* max_d,
+                    float* u_right, float* depth, int32_t* best_dist, int32_t* best_idx_r, int* nmatched)
+{
+    std::shared_ptr<GfoPair> P = c->pair;
+    if (!P || c->pair_side != 0 || min_d || max_d) return 1;
+    if (nlevels != c->prm.nlevels || memcmp(sf, c->scale.data(), sizeof(float) * nlevels) != 0) return 1;
+    std::lock_guard<std::mutex> lk(P->mu);
+    if (!P->valid || P->state != 0 || nl != P->nl || nr != P->nr || memcmp(p, &P->sp, sizeof *p) != 0) return 1;
+    if ((int)P->rk[0].size() != nl || (int)P->rk[1].size() != nr) return 1;
+    if (memcmp(kl, P->rk[0].data(), sizeof(gfo_keypoint) * (size_t)nl) != 0 || memcmp(dl, P->rd[0].data(), 32 * (size_t)nl) != 0) return 1;
+    if (nr > 0 && (memcmp(kr, P->rk[1].data(), sizeof(gfo_keypoint) * (size_t)nr) != 0 || memcmp(dr, P->rd[1].data(), 32 * (size_t)nr) != 0)) return 1;
+    memcpy(u_right, P->ur.data(), 4 * (size_t)nl);
+    memcpy(depth, P->dp.data(), 4 * (size_t)nl);
+    if (best_dist) memcpy(best_dist, P->bd.data(), 4 * (size_t)nl);
+    if (best_idx_r) memcpy(best_idx_r, P->bi.data(), 4 * (size_t)nl);
+    *nmatched = P->nm;
+    P->served++;
     return 0;
 }

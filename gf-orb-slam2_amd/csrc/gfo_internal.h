@@ -147,6 +147,7 @@ enum GfoStage {
 };
 
 struct GfoEngine;   // gfo_combine.hip
+struct GfoPair;     // gfo_combine.hip: two contexts declared the left / right extractor of one stereo rig (gfo_ctx_pair)
 
 struct gfo_ctx {
     gfo_params prm{};
@@ -248,6 +249,8 @@ struct gfo_ctx {
     // frame combiner (gfo_ctx_set_combining): per-frame host calls of this context may run inside a shared device batch
     bool combining = false;
     std::shared_ptr<GfoEngine> engine;
+    std::shared_ptr<GfoPair> pair;      // gfo_ctx_pair
+    int pair_side = 0;                  // 0 left, 1 right
     // resident vocabulary tree (gfo_vocabulary_upload)
     void* d_voc = nullptr;
     size_t voc_desc_off = 0, voc_fc_off = 0, voc_nc_off = 0, voc_wid_off = 0, voc_w_off = 0, voc_w64_off = 0;
@@ -309,6 +312,8 @@ GfoPairBlock gfo_pair_block(int kp_stride);
 int gfo_small_submit_pairs(gfo_ctx* c, const GfoSmallLayout& L, int npairs, const gfo_stereo_params* sp, const uint8_t* d_stage);
 
 // gfo_combine.hip
+#define GFO_COMBINE_DIRECT 1   // (positive: never an ABI status) the engine cannot serve this request -- no slot could be prepared, or the
+                               // batch it joined failed as a whole: the caller runs it alone on the direct path
 int gfo_combined_extract(gfo_ctx* c, int kind, const uint8_t* const* imgs, int w, int h, int stride, const gfo_stereo_params* sp,
                          gfo_keypoint* const* kp, uint8_t* const* desc, int cap, int* n, float* u_right, float* depth,
                          int32_t* best_dist, int32_t* best_idx_r, int* nmatched);
@@ -316,6 +321,13 @@ int gfo_combined_stereo_match(gfo_ctx* c, const gfo_keypoint* kl, const uint8_t*
                               const float* sf, int nlevels, const gfo_stereo_params* p, const float* min_d, const float* max_d,
                               float* u_right, float* depth, int32_t* best_dist, int32_t* best_idx_r, int* nmatched, int* status);
 void gfo_engine_release(gfo_ctx* c);
+#define GFO_COMBINER_COUNTERS 8
+void gfo_pair_release(gfo_ctx* c);
+int gfo_pair_extract(gfo_ctx* c, const uint8_t* img, int w, int h, int stride, gfo_keypoint* kp, uint8_t* desc, int cap, int* n);
+int gfo_pair_lookup(gfo_ctx* c, const gfo_keypoint* kl, const uint8_t* dl, int nl, const gfo_keypoint* kr, const uint8_t* dr, int nr,
+                    const float* sf, int nlevels, const gfo_stereo_params* p, const float* min_d, const float* max_d,
+                    float* u_right, float* depth, int32_t* best_dist, int32_t* best_idx_r, int* nmatched);
+void gfo_note_pinned(const uint8_t* p, size_t bytes, bool add);   // gfo_api.hip: the registry gfo_small_upload consults
 
 // profiling helpers (gfo_api.hip)
 void gfo_prof_begin(gfo_ctx* c, int stage);

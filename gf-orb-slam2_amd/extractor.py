@@ -73,6 +73,18 @@ class ORBextractor:
         check(self._L, self._ctx, self._L.gfo_combiner_stats(self._ctx, C.byref(b), C.byref(r)))
         return b.value, r.value
 
+    def combiner_counters(self):
+        """gfo_combiner_counters as a dict (frame combiner engine + this context's stereo rig)"""
+        v = (C.c_int64 * 8)()
+        check(self._L, self._ctx, self._L.gfo_combiner_counters(self._ctx, v, 8))
+        names = ("batches", "requests", "batches_redone", "slots_prepared", "engine_broken", "rig_frames", "rig_served", "rig_alone")
+        return dict(zip(names, (int(x) for x in v)))
+
+    def pair_with(self, right, params):
+        """gfo_ctx_pair: this extractor and `right` are the left / right extractor of one stereo rig (None dissolves it)"""
+        rc = self._L.gfo_ctx_pair(self._ctx, right._ctx if right is not None else None, C.byref(params) if params is not None else None)
+        check(self._L, self._ctx, rc)
+
     def max_keypoints(self):
         return self._L.gfo_ctx_max_keypoints(self._ctx)
 

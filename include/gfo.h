@@ -382,6 +382,23 @@ typedef struct {
 } gfo_stage_time;
 int gfo_profile_enable(gfo_ctx* ctx, int on);
 int gfo_profile_read(gfo_ctx* ctx, gfo_stage_time* out, int cap, int* nstages, int reset);
+/* Declares `left` and `right` the two extractors of ONE stereo rig -- the reference's mpORBextractorLeft / mpORBextractorRight, which
+ * Frame::Frame calls from two threads per frame (Frame.cc:84-87) before Frame::ComputeStereoMatches works on what they returned
+ * (Frame.cc:100) -- and `p` the calibration that association will be asked for with.  A HINT: no call returns anything else than
+ * without it.  With both contexts combining (gfo_ctx_set_combining), the two gfo_extract calls of a frame meet inside the library
+ * and go to the device as ONE stereo submission (what gfo_extract_stereo issues: one input copy, one launch chain), which also
+ * computes the frame's association; a gfo_stereo_match on `left` that passes, bit for bit, the keypoints and descriptors those two
+ * calls returned, the same `p`, the context's own scale factors and no disparity windows is then answered from that result without
+ * touching the device (the arrays are compared in full: rectified input, where the reference's mvKeysUn equals mvKeys, qualifies;
+ * anything else is computed as before).  A side whose partner does not call within GFO_PAIR_WAIT_US (2000) extracts alone.
+ * Both contexts need equal extractor parameters and one device.  right == NULL or p == NULL dissolves the rig; destroying either
+ * context does too.  The adapter declares the rig from Frame::ComputeStereoMatches_Undistorted (adapter/matchers_gfo.cc). */
+int gfo_ctx_pair(gfo_ctx* left, gfo_ctx* right, const gfo_stereo_params* p);
+/* Counters of the frame combiner and of a context's stereo rig, for tests and harnesses: out[0] device batches, [1] requests,
+ * [2] batches whose members were re-run alone after a batch-level failure, [3] batch slots prepared, [4] 1 if the engine could
+ * prepare no slot and its callers take the direct path, [5] stereo frames extracted as one submission through gfo_ctx_pair,
+ * [6] gfo_stereo_match calls answered from such a frame, [7] frames whose partner did not show up.  n <= 8 entries are written. */
+int gfo_combiner_counters(const gfo_ctx* ctx, int64_t* out, int n);
 /* Process-wide monotonic counters: contexts created by gfo_ctx_create and arenas (re)planned -- hipMalloc of a whole
  * arena -- since the library was loaded.  A steady-state per-frame loop must leave both unchanged
  * (tools/c/boundary_throughput.c and the adapter's context table assert it). */

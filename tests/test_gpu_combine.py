@@ -244,3 +244,187 @@ def test_adapter_pattern_end_to_end_from_many_threads(oracle, euroc_l, euroc_r):
     for el, er in exts:
         el.close()
         er.close()
+
+
+def _rig_frame(el, er, m, l, r, sf, prm, win=(None, None)):
+    """the adapter's per-frame pattern: right image on a thread of its own, left on this one, then the association"""
+    out = {}
+    t = threading.Thread(target=lambda: out.__setitem__("r", er(r)))
+    t.start()
+    kl, dl = el(l)
+    t.join()
+    kr, dr = out["r"]
+    return (kl, dl, kr, dr), m.ComputeStereoMatches(kl, dl, kr, dr, sf, prm, *win)
+
+
+def test_declared_stereo_rig_extracts_as_one_submission_and_answers_the_association(oracle, euroc_l, euroc_r):
+    """gfo_ctx_pair: the adapter's three calls per frame on a declared rig -- the two gfo_extract calls meet
+    and run as ONE stereo submission, gfo_stereo_match on the arrays they returned is answered from it -- must return exactly what
+    the undeclared pattern returns (= the oracle), frame after frame with CHANGING images; and every way of leaving the fast path
+    must fall back to the computed answer: other calibration, disparity windows, modified arrays, a frame of one image only."""
+    import gf_orb_slam2_amd as G
+    oe = oracle.OracleExtractor(1990, 1.2, 8, 20, 7)
+    sf = oe.scale_factors
+    frames = [(euroc_l, euroc_r), (synth_frame(752, 480, 40), synth_frame(752, 480, 41)), (euroc_r, euroc_l), (euroc_l, euroc_r)]
+    refs = [(oe(l), oe(r)) for l, r in frames]
+    prm = G.StereoParams(480, BF, BF / FX, 0.0)
+    el, er = G.ORBextractor(1990, 1.2, 8, 20, 7, combining=True), G.ORBextractor(1990, 1.2, 8, 20, 7, combining=True)
+    m = G.ORBmatcher(0.8, True, extractor=el)
+    el.pair_with(er, prm)
+
+    def check_frame(i, prm_i=prm, win=(None, None)):
+        (okl, odl), (okr, odr) = refs[i]
+        (kl, dl, kr, dr), got = _rig_frame(el, er, m, *frames[i], sf, prm_i, win)
+        assert kl.tobytes() == okl.tobytes() and kr.tobytes() == okr.tobytes() and (dl == odl).all() and (dr == odr).all(), f"frame {i}"
+        ref = oracle.stereo_match(okl, odl, okr, odr, sf, prm_i.n_rows, prm_i.mbf, prm_i.mb, prm_i.min_x, *win)
+        assert got[0] == ref[0] and all(a.tobytes() == b.tobytes() for a, b in zip(got[1:], ref[1:])), f"frame {i}"
+        return kl, dl, kr, dr
+
+    for rep in range(3):
+        for i in range(len(frames)):
+            check_frame(i)
+    c = el.combiner_counters()
+    assert c["rig_frames"] == 12 and c["rig_served"] == 12 and c["rig_alone"] == 0, c
+    assert c["requests"] == 12        # ONE engine request per stereo frame: no separate right image, no association request
+    # another calibration than the declared one: computed, not served
+    other = G.StereoParams(480, 30.0, 0.12, 5.0)
+    check_frame(1, other)
+    assert el.combiner_counters()["rig_served"] == 12
+    # disparity windows: computed
+    (okl, _), _ = refs[2]
+    d0 = np.random.default_rng(1).uniform(0, 60, len(okl)).astype(np.float32)
+    win = (np.maximum(d0 - 8, 0).astype(np.float32), np.minimum(d0 + 8, np.float32(prm.mbf / prm.mb)).astype(np.float32))
+    check_frame(2, prm, win)
+    assert el.combiner_counters()["rig_served"] == 12
+    # arrays that are NOT what the two calls returned (one descriptor bit flipped; keypoints as an undistortion would move them)
+    kl, dl, kr, dr = check_frame(0)
+    served = el.combiner_counters()["rig_served"]
+    assert served == 13
+    dl2 = dl.copy(); dl2[7, 3] ^= 1
+    got = m.ComputeStereoMatches(kl, dl2, kr, dr, sf, prm)
+    ref = oracle.stereo_match(kl, dl2, kr, dr, sf, prm.n_rows, prm.mbf, prm.mb, prm.min_x)
+    assert got[0] == ref[0] and all(a.tobytes() == b.tobytes() for a, b in zip(got[1:], ref[1:]))
+    kr2 = kr.copy(); kr2["x"][5] += np.float32(0.25)
+    got = m.ComputeStereoMatches(kl, dl, kr2, dr, sf, prm)
+    ref = oracle.stereo_match(kl, dl, kr2, dr, sf, prm.n_rows, prm.mbf, prm.mb, prm.min_x)
+    assert got[0] == ref[0] and all(a.tobytes() == b.tobytes() for a, b in zip(got[1:], ref[1:]))
+    assert el.combiner_counters()["rig_served"] == served
+    # the same untouched arrays again: served again (the stored frame is still the last one)
+    got = m.ComputeStereoMatches(kl, dl, kr, dr, sf, prm)
+    assert el.combiner_counters()["rig_served"] == served + 1
+    # a frame of ONE image (the left extractor used alone): extracted alone after the wait, correct, nothing served from it
+    k0, d0_ = el(frames[1][0])
+    assert k0.tobytes() == refs[1][0][0].tobytes() and (d0_ == refs[1][0][1]).all()
+    assert el.combiner_counters()["rig_alone"] == 1
+    got = m.ComputeStereoMatches(kl, dl, kr, dr, sf, prm)      # the stored frame is gone: computed
+    assert el.combiner_counters()["rig_served"] == served + 1 and got[0] == oracle.stereo_match(kl, dl, kr, dr, sf, prm.n_rows, prm.mbf, prm.mb, prm.min_x)[0]
+    # dissolved: the plain pattern
+    el.pair_with(None, None)
+    check_frame(3)
+    assert el.combiner_counters()["rig_frames"] == 0      # (the rig's counters went with it)
+    el.close()
+    er.close()
+
+
+def test_rigs_from_many_threads_and_a_partner_destroyed_mid_stream(oracle, euroc_l, euroc_r):
+    """six declared rigs at once (their stereo requests share device batches), then a rig whose right extractor is destroyed and
+    re-created (Tracking::updateORBExtractor, src/Tracking.cc:298-320): the left side extracts alone until the rig is declared again"""
+    import gf_orb_slam2_amd as G
+    RIGS, REPS = 6, 6
+    oe = oracle.OracleExtractor(1500, 1.2, 8, 20, 7)
+    sf = oe.scale_factors
+    pairs = [(euroc_l, euroc_r), (synth_frame(752, 480, 40), synth_frame(752, 480, 41)), (euroc_r, euroc_l)]
+    refs = [(oe(l), oe(r)) for l, r in pairs]
+    calib = [G.StereoParams(480, BF, BF / FX, 0.0), G.StereoParams(480, 30.0, 0.12, 5.0)]
+    exts = [(G.ORBextractor(1500, 1.2, 8, 20, 7, combining=True), G.ORBextractor(1500, 1.2, 8, 20, 7, combining=True)) for _ in range(RIGS)]
+    ms = [G.ORBmatcher(0.8, True, extractor=el) for el, _ in exts]
+    bad = []
+
+    def rig_thread(rig):
+        el, er = exts[rig]
+        prm = calib[rig % 2]
+        for rep in range(REPS):
+            pi = (rig + rep) % 3
+            (okl, odl), (okr, odr) = refs[pi]
+            el.pair_with(er, prm)                  # what the adapter does every frame
+            (kl, dl, kr, dr), got = _rig_frame(el, er, ms[rig], *pairs[pi], sf, prm)
+            ref = oracle.stereo_match(okl, odl, okr, odr, sf, prm.n_rows, prm.mbf, prm.mb, prm.min_x)
+            if not (kl.tobytes() == okl.tobytes() and kr.tobytes() == okr.tobytes() and (dl == odl).all() and (dr == odr).all()
+                    and got[0] == ref[0] and all(a.tobytes() == b.tobytes() for a, b in zip(got[1:], ref[1:]))):
+                bad.append((rig, rep))
+
+    _run_threads([lambda rig=rig: rig_thread(rig) for rig in range(RIGS)])
+    assert not bad, bad
+    tot = [e[0].combiner_counters() for e in exts]
+    assert sum(t["rig_frames"] for t in tot) >= RIGS * (REPS - 1) and sum(t["rig_served"] for t in tot) >= RIGS * (REPS - 1), tot
+    # the right extractor of rig 0 goes away: the left one keeps working, alone
+    el, er = exts[0]
+    er.close()
+    k, d = el(pairs[0][0])
+    assert k.tobytes() == refs[0][0][0].tobytes()
+    er2 = G.ORBextractor(1500, 1.2, 8, 20, 7, combining=True)
+    el.pair_with(er2, calib[0])
+    (kl, dl, kr, dr), got = _rig_frame(el, er2, ms[0], *pairs[1], sf, calib[0])
+    ref = oracle.stereo_match(*refs[1][0], *refs[1][1], sf, 480, calib[0].mbf, calib[0].mb, calib[0].min_x)
+    assert kl.tobytes() == refs[1][0][0].tobytes() and got[0] == ref[0] and got[1].tobytes() == ref[1].tobytes()
+    exts[0] = (el, er2)
+    for a, b in exts:
+        a.close()
+        b.close()
+
+
+def _combine_subprocess(env_extra, body):
+    """a fresh process (the combiner's test hooks are read when an engine is created)"""
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    code = "import sys, threading, numpy as np\nsys.path.insert(0, %r)\nimport gf_orb_slam2_amd as G\nfrom oracle import orb_oracle as O\n" % ROOT + body
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=dict(os.environ, **env_extra), cwd=ROOT, timeout=170)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+    return r.stdout
+
+
+_COMBINE_BODY = """
+gold = 'tests/golden/'
+l = np.fromfile(gold + 'EuRoC_l_752x480.u8', np.uint8).reshape(480, 752); r = np.fromfile(gold + 'EuRoC_r_752x480.u8', np.uint8).reshape(480, 752)
+oe = O.OracleExtractor(1000, 1.2, 8, 20, 7)
+refs = [oe(l), oe(r)]
+exts = [G.ORBextractor(1000, 1.2, 8, 20, 7, combining=True) for _ in range(6)]
+bad = []
+def work(i):
+    for rep in range(6):
+        k, d = exts[i]([l, r][(i + rep) & 1])
+        ok, od = refs[(i + rep) & 1]
+        if k.tobytes() != ok.tobytes() or not (d == od).all(): bad.append((i, rep))
+ts = [threading.Thread(target=work, args=(i,)) for i in range(6)]
+[t.start() for t in ts]; [t.join() for t in ts]
+assert not bad, bad
+print('COUNTERS', exts[0].combiner_counters())
+"""
+
+
+def test_combiner_prepares_slots_as_concurrency_shows_and_survives_allocation_failures():
+    """(1) one caller alone prepares two batch slots, not all six; (2) a slot that cannot be prepared later leaves the
+    engine with the slots it has; (3) an engine that can prepare none sends every caller down the direct path -- same results;
+    (4) a batch that fails as a whole is re-run member by member on the direct path, so nobody inherits another frame's failure."""
+    import ast
+    import gf_orb_slam2_amd as G
+    e = G.ORBextractor(1000, 1.2, 8, 20, 7, combining=True)
+    img = synth_frame(752, 480, 3)
+    for _ in range(4):
+        e(img)
+    c = e.combiner_counters()
+    assert c["slots_prepared"] == 2 and c["engine_broken"] == 0 and c["batches"] == 4, c
+    e.close()
+
+    def counters(out):
+        return ast.literal_eval(out.split("COUNTERS", 1)[1].strip())
+    c = counters(_combine_subprocess({}, _COMBINE_BODY))
+    assert 2 <= c["slots_prepared"] <= 6 and c["requests"] == 36 and c["batches"] < 36 and c["batches_redone"] == 0, c
+    c = counters(_combine_subprocess({"GFO_COMBINE_FAIL_PREPARE": "2"}, _COMBINE_BODY))
+    assert c["slots_prepared"] == 2 and c["engine_broken"] == 0 and c["requests"] == 36, c
+    c = counters(_combine_subprocess({"GFO_COMBINE_FAIL_PREPARE": "0"}, _COMBINE_BODY))
+    assert c["slots_prepared"] == 0 and c["engine_broken"] == 1 and c["batches"] == 0, c
+    c = counters(_combine_subprocess({"GFO_COMBINE_FAIL_BATCH": "2"}, _COMBINE_BODY))
+    assert c["batches_redone"] >= 1 and c["requests"] == 36, c

@@ -13,7 +13,9 @@
  * steady state must create nothing.
  *
  * Build: gcc -O2 -I include tools/c/boundary_throughput.c -o /tmp/boundary_throughput -ldl -lpthread -lm
- * Usage: boundary_throughput <libgfo.so> <golden dir> <seconds per point> <stereo|adapter|both> <K list, e.g. 1,2,4,8,16> [combine 0|1] [pin 0|1]
+ * Usage: boundary_throughput <libgfo.so> <golden dir> <seconds per point> <stereo|adapter|both> <K list, e.g. 1,2,4,8,16> [combine 0|1] [pin 0|1] [pair 0|1]
+ * pair = 1 (default): in adapter mode the two contexts of a stream are declared a stereo rig (gfo_ctx_pair) before every association,
+ * as adapter/matchers_gfo.cc does.
  * combine = 1 (default): every context opts into the frame combiner (gfo_ctx_set_combining), as the drop-in adapter does.
  * pin = 1: the image pair the streams submit is page-locked with gfo_host_register (an application that owns its frame
  * buffers can do that once); default 0 = pageable memory, as cv::imread / a ROS message hand it over. */
@@ -56,8 +58,10 @@ static struct {
     __typeof__(&gfo_ctx_set_combining) set_combining;
     __typeof__(&gfo_combiner_stats) combiner_stats;
     __typeof__(&gfo_host_register) host_register;
+    __typeof__(&gfo_ctx_pair) ctx_pair;
+    __typeof__(&gfo_combiner_counters) combiner_counters;
 } G;
-static int g_combine, g_pin;
+static int g_combine, g_pin, g_pair = 1;
 
 static uint8_t IMGS[2 * W * H] __attribute__((aligned(4096)));   /* left | right, one buffer: a pinned pair is ONE copy */
 #define IML (IMGS)
@@ -124,6 +128,7 @@ static int one_frame(stream_t* s)
         pthread_join(th, NULL);
         if (jl.rc || jr.rc) { fprintf(stderr, "stream %d: %s / %s\n", s->id, G.last_error(s->cl), G.last_error(s->cr)); return -1; }
         nl = jl.n; nr = jr.n;
+        if (g_pair) G.ctx_pair(s->cl, s->cr, &sp);   /* what the adapter's ComputeStereoMatches does before the association (idempotent) */
         rc = G.stereo_match(s->cl, s->kp, s->desc, nl, s->kp + CAP, s->desc + 32 * (size_t)CAP, nr, s->sf, 8, &sp, NULL, NULL, s->ur, s->dp,
                             s->bd, s->bi, &nm);
         if (rc) { fprintf(stderr, "stream %d: %s\n", s->id, G.last_error(s->cl)); return rc; }
@@ -204,6 +209,8 @@ static int run_point(int mode, int K, double seconds, int first)
     int64_t cb = 0, cr = 0;
     G.combiner_stats(S[0].cl, &cb, &cr);
     cb -= cb0; cr -= cr0;
+    int64_t rig[8] = {0}, rig_sum[3] = {0, 0, 0};
+    for (int k = 0; k < K; k++) { G.combiner_counters(S[k].cl, rig, 8); rig_sum[0] += rig[5]; rig_sum[1] += rig[6]; rig_sum[2] += rig[7]; }
     long frames = 0, checked = 0; int mism = 0, errs = 0, nl = 0;
     for (int k = 0; k < K; k++) { frames += S[k].frames; checked += S[k].checked; mism += S[k].mismatches; errs += S[k].errors; nl += S[k].nlat; }
     double* all = (double*)malloc(sizeof(double) * (nl > 0 ? nl : 1));
@@ -213,11 +220,11 @@ static int run_point(int mode, int K, double seconds, int first)
     const double wall = (t1 - t0) * 1e-3;
     printf("%s  {\"path\": \"%s\", \"caller_buffers_pinned\": %s, \"combining\": %s, \"frames_per_device_batch\": %.2f, \"streams\": %d, \"host_threads\": %d, \"contexts\": %d, \"seconds\": %.2f, \"stereo_frames\": %ld, "
            "\"images_per_s\": %.0f, \"stereo_frames_per_s\": %.0f, \"latency_ms\": {\"p50\": %.4f, \"p90\": %.4f, \"p99\": %.4f, \"max\": %.4f}, "
-           "\"keypoints\": [%d, %d], \"stereo_candidates\": %d, \"frames_checksummed\": %ld, \"result_mismatches\": %d, \"errors\": %d, \"contexts_created_in_timed_region\": %d, \"arenas_planned_in_timed_region\": %d}",
+           "\"stereo_rig\": {\"declared\": %s, \"frames_as_one_submission\": %ld, \"associations_answered_from_them\": %ld, \"frames_alone\": %ld}, \"keypoints\": [%d, %d], \"stereo_candidates\": %d, \"frames_checksummed\": %ld, \"result_mismatches\": %d, \"errors\": %d, \"contexts_created_in_timed_region\": %d, \"arenas_planned_in_timed_region\": %d}",
            first ? "" : ",\n", mode == 0 ? "gfo_extract_stereo" : "adapter: 2 x gfo_extract on two threads + gfo_stereo_match", g_pin ? "true" : "false", g_combine ? "true" : "false",
            cb > 0 ? (double)cr / cb / (mode == 0 ? 1 : 2) : 1.0, K, mode == 0 ? K : 2 * K,
            mode == 0 ? K : 2 * K, wall, frames, 2.0 * frames / wall, frames / wall, nl ? all[nl / 2] : 0.0, nl ? all[(long)nl * 9 / 10] : 0.0,
-           nl ? all[(long)nl * 99 / 100] : 0.0, nl ? all[nl - 1] : 0.0, g_nl, g_nr, g_nm, checked, mism, errs, created1 - created0, planned1 - planned0);
+           nl ? all[(long)nl * 99 / 100] : 0.0, nl ? all[nl - 1] : 0.0, (mode == 1 && g_pair) ? "true" : "false", (long)rig_sum[0], (long)rig_sum[1], (long)rig_sum[2], g_nl, g_nr, g_nm, checked, mism, errs, created1 - created0, planned1 - planned0);
     fflush(stdout);
     for (int k = 0; k < K; k++) {
         G.ctx_destroy(S[k].cl);
@@ -245,7 +252,8 @@ int main(int argc, char** argv)
     SYM(set_combining, gfo_ctx_set_combining) SYM(combiner_stats, gfo_combiner_stats)
     g_combine = argc > 6 ? atoi(argv[6]) : 1;
     g_pin = argc > 7 ? atoi(argv[7]) : 0;
-    SYM(host_register, gfo_host_register)
+    SYM(host_register, gfo_host_register) SYM(ctx_pair, gfo_ctx_pair) SYM(combiner_counters, gfo_combiner_counters)
+    g_pair = argc > 8 ? atoi(argv[8]) : 1;
     char path[512];
     snprintf(path, sizeof path, "%s/EuRoC_l_752x480.u8", dir);
     FILE* f = fopen(path, "rb");
