@@ -1578,15 +1578,16 @@ extern "C" int gfo_stereo_match(gfo_ctx* c, const gfo_keypoint* kl, const uint8_
     if (nr > 65535) return fail(c, GFO_ERR_INVALID, "more than 65535 right keypoints");
     *nmatched = 0;
     if (nl == 0) return GFO_OK;
+    // a declared stereo rig (gfo_ctx_pair) whose last frame these arrays are, bit for bit: the association was computed with that
+    // frame (and arrays this library delivered need no validation)
+    if (c->pair && gfo_pair_lookup(c, kl, dl, nl, kr, dr, nr, sf, nlevels, p, min_d, max_d, u_right, depth, best_dist, best_idx_r, nmatched) == 0)
+        return GFO_OK;
     // the kernels index scale[octave] (Frame.h:244, Frame.cc:1204-1206 do the same, unchecked): refuse what would read past it
     for (int i = 0; i < nl; i++)
         if (kl[i].octave < 0 || kl[i].octave >= nlevels) return fail(c, GFO_ERR_INVALID, "left keypoint %d: octave %d outside 0..%d", i, kl[i].octave, nlevels - 1);
     for (int i = 0; i < nr; i++)
         if (kr[i].octave < 0 || kr[i].octave >= nlevels) return fail(c, GFO_ERR_INVALID, "right keypoint %d: octave %d outside 0..%d", i, kr[i].octave, nlevels - 1);
     if (p->n_rows < 1 || p->n_rows > 8192) return fail(c, GFO_ERR_INVALID, "n_rows must be 1..8192");
-    // a declared stereo rig (gfo_ctx_pair) whose last frame these arrays are: the association was computed with that frame
-    if (c->pair && gfo_pair_lookup(c, kl, dl, nl, kr, dr, nr, sf, nlevels, p, min_d, max_d, u_right, depth, best_dist, best_idx_r, nmatched) == 0)
-        return GFO_OK;
     if (c->combining) {    // the pairs several threads associate at once share one launch (gfo_combine.hip); 1 = not eligible
         int status = GFO_OK;
         if (gfo_combined_stereo_match(c, kl, dl, nl, kr, dr, nr, sf, nlevels, p, min_d, max_d, u_right, depth, best_dist, best_idx_r, nmatched, &status) == 0)

@@ -62,6 +62,7 @@ struct GfoEngine {
     int forming[4] = {-1, -1, -1, -1};   // per kind of request: the slot that accepts joiners (an extraction batch that is forming
                                          // must not hold up the association calls of the threads that are a phase ahead, and vice versa)
     int running = 0;          // batches submitted and not yet complete
+    int members = 0;          // contexts that have attached to this engine so far (engine_for)
     int prepared = 0;         // slots that have their batch context (prepared lazily: two by the first request, one more whenever
                               // a caller finds every prepared slot busy -- concurrent callers observed -- up to nslot)
     int fail_prepare_from = -1, fail_batch_every = 0;   // tests only: injected failures (slot_prepare, run_request)
@@ -97,11 +98,16 @@ struct GfoPair {
         int* n = nullptr;
         bool arrived = false, staged = false;
     } req[2];
-    int state = 0;            // 0 idle, 1 one side waiting for its partner, 2 the second arrival is executing the frame, 3 done: the waiter picks up
+    int state = 0;            // 0 idle, 1 one side waits for its partner, 2 the second arrival is executing the frame, 4 the batch is
+                              // complete: the waiting side copies its arrays out of the result block (pick_*), 3 the batch failed:
+                              // the waiting side takes its status
+    gfo_ctx* pick_bc = nullptr;
+    const GfoSmallLayout* pick_L = nullptr;
+    int pick_image = 0, picked = -1;
     uint8_t* h_pair = nullptr;   // pinned: left image | right image, tight rows -- each side copies its own half, ONE copy takes both down
     int w = 0, h = 0;
     // the frame delivered last: what the two calls returned (for the identity check) and its association
-    bool valid = false, batch_ok = false, other_kept = false;
+    bool valid = false;
     int nl = 0, nr = 0, nm = 0;
     std::vector<gfo_keypoint> rk[2];
     std::vector<uint8_t> rd[2];
@@ -144,6 +150,10 @@ std::shared_ptr<GfoEngine> engine_for(gfo_ctx* c, int w, int h)
         if (const char* m = getenv("GFO_COMBINE_FAIL_PREPARE")) e->fail_prepare_from = atoi(m);
         if (const char* m = getenv("GFO_COMBINE_FAIL_BATCH")) e->fail_batch_every = atoi(m);
         g_engines[key] = e;
+    }
+    {
+        std::lock_guard<std::mutex> lk2(e->mu);
+        e->members++;
     }
     c->engine = e;
     return e;
@@ -241,16 +251,19 @@ static int run_request(gfo_ctx* c, GfoEngine* e, int kind, int units, const gfo_
             }
         } else {
             // Slots are prepared as concurrency shows: a slot is an arena for cap_images images plus pinned buffers --
-            // ~130 MB at 752x480, several hundred MB at 1080p -- and a single-threaded caller needs two (one batch collected while
-            // the next forms).  The first request prepares two; a caller that finds every prepared slot busy prepares one more,
-            // up to nslot.  K concurrent streams have theirs by the end of their first frames: gfo_contexts_created /
-            // gfo_arenas_planned then stay put.  A slot that cannot be prepared (out of memory) is not fatal: with another slot
-            // there the caller waits for it, with none the engine is marked broken and every caller takes the direct path.
+            // ~130 MB at 752x480, several hundred MB at 1080p.  An engine that only ever served one or two contexts (one camera:
+            // the left and right extractor, or one monocular extractor) gets two -- one batch collected while the next forms -- and
+            // one more whenever a caller finds every prepared slot busy.  As soon as a third context has attached (several cameras:
+            // the case the combiner exists for) the next request prepares all nslot, so that nothing is created or planned once the
+            // streams run (gfo_contexts_created / gfo_arenas_planned stay put in steady state).  A slot that cannot be prepared
+            // (out of memory) is not fatal: with another slot there the caller waits for it, with none the engine is marked broken
+            // and every caller takes the direct path.
             if (e->broken) return GFO_COMBINE_DIRECT;
-            for (int i = 0; i < e->prepared && si < 0; i++)
+            const bool want_all = e->members > 2 && e->prepared < e->nslot && !e->grow_failed;
+            for (int i = 0; i < e->prepared && si < 0 && !want_all; i++)
                 if (e->slot[i].state == SLOT_FREE) si = i;
             if (si < 0 && e->prepared < e->nslot && !e->grow_failed) {
-                const int want = e->prepared == 0 ? (e->nslot < 2 ? e->nslot : 2) : e->prepared + 1;
+                const int want = want_all ? e->nslot : (e->prepared == 0 ? (e->nslot < 2 ? e->nslot : 2) : e->prepared + 1);
                 while (e->prepared < want) {
                     if (slot_prepare(e, e->slot[e->prepared], c)) {
                         e->grow_failed = true;
@@ -509,8 +522,7 @@ int gfo_pair_extract(gfo_ctx* c, const uint8_t* img, int w, int h, int stride, g
     me.img = img; me.w = w; me.h = h; me.kp = kp; me.desc = desc; me.cap = cap; me.n = n; me.rc = 0;
     me.arrived = true; me.staged = false;
     const bool first = !other.arrived;
-    if (first) P->state = 1;
-    else P->state = 2;            // the second arrival executes the frame for both
+    P->state = first ? 1 : 2;            // the second arrival executes the frame for both
     P->cv.notify_all();
     lk.unlock();
 
@@ -520,9 +532,15 @@ int gfo_pair_extract(gfo_ctx* c, const uint8_t* img, int w, int h, int stride, g
     else
         for (int y = 0; y < h; y++) memcpy(dst + (size_t)y * w, img + (size_t)y * stride, w);
 
-    auto retain = [&](int sd, const gfo_keypoint* k, const uint8_t* d, int cnt) {
-        P->rk[sd].assign(k, k + cnt);
-        P->rd[sd].assign(d, d + 32 * (size_t)cnt);
+    // a side's own results out of the batch's pinned result block, and its half of what gfo_stereo_match will compare against
+    auto take_mine = [&](gfo_ctx* bc, const GfoSmallLayout& L, int image, int* cnt_out) {
+        const int over = gfo_small_collect(bc, L, image, kp, desc, cap, cnt_out);
+        const bool keep = !over && kp && desc;
+        if (keep) {
+            P->rk[side].assign(kp, kp + *cnt_out);
+            P->rd[side].assign(desc, desc + 32 * (size_t)*cnt_out);
+        }
+        return over ? 2 : (keep ? 1 : 0);      // 2 truncated, 1 kept, 0 delivered but not kept (no output arrays)
     };
     lk.lock();
     me.staged = true;
@@ -539,16 +557,25 @@ int gfo_pair_extract(gfo_ctx* c, const uint8_t* img, int w, int h, int stride, g
                 return GFO_COMBINE_DIRECT;
             }
         }
-        while (P->state != 3) P->cv.wait(lk);
+        // the partner executes the frame; it calls this side to the result block as soon as the batch is complete (state 4), so
+        // that both sides copy their own arrays at the same time; a failed batch skips that (state 3)
+        while (P->state != 3 && P->state != 4) P->cv.wait(lk);
+        if (P->state == 4) {
+            gfo_ctx* bc = P->pick_bc;
+            const GfoSmallLayout L = *P->pick_L;
+            const int image = P->pick_image + side;
+            lk.unlock();
+            int cnt = 0;
+            const int got = take_mine(bc, L, image, &cnt);
+            lk.lock();
+            *n = cnt;
+            P->picked = got;
+            P->cv.notify_all();
+            return got == 2 ? gfo_fail(c, GFO_ERR_CAPACITY, "an image produced more keypoints than the caller capacity %d", cap) : GFO_OK;
+        }
         const int rc = me.rc;
-        const bool keep = P->batch_ok && kp && desc;
-        const int cnt = keep ? (side == 0 ? P->nl : P->nr) : 0;
-        lk.unlock();
-        if (keep) retain(side, kp, desc, cnt);      // my half of what the identity check of gfo_stereo_match compares against
-        lk.lock();
         me.arrived = me.staged = false;
         other.arrived = other.staged = false;
-        P->valid = P->batch_ok && keep && P->other_kept;
         P->state = 0;
         P->cv.notify_all();
         return rc;
@@ -559,42 +586,51 @@ int gfo_pair_extract(gfo_ctx* c, const uint8_t* img, int w, int h, int stride, g
     lk.unlock();
     std::shared_ptr<GfoEngine> eh = engine_for(c, w, h);
     const uint8_t* imgs[2] = {P->h_pair, P->h_pair + img_bytes};
-    int cnt[2] = {0, 0}, nm = 0, over[2] = {0, 0}, dummy = 0;
+    int cnt_mine = 0, nm = 0, got_mine = 0, got_other = 0, cnt_other = 0, dummy = 0;
     const int rc = run_request(
         c, eh.get(), 2, 2, &sp,
         [&](Slot& s, int idx) { return gfo_small_upload(s.bc, c, s.L, idx * 2, 2, imgs, w, h, w, s.bc->stream); },
         [&](Slot& s, int nb) { return gfo_small_submit(s.bc, s.L, nb * 2, &s.sp, false); },
         [&](Slot& s, int idx) {
-            for (int k = 0; k < 2; k++) over[k] = gfo_small_collect(s.bc, s.L, idx * 2 + k, P->req[k].kp, P->req[k].desc, P->req[k].cap, &cnt[k]);
+            {   // call the waiting side to the result block
+                std::lock_guard<std::mutex> g(P->mu);
+                P->pick_bc = s.bc; P->pick_L = &s.L; P->pick_image = idx * 2; P->picked = -1;
+                P->state = 4;
+                P->cv.notify_all();
+            }
+            got_mine = take_mine(s.bc, s.L, idx * 2 + side, &cnt_mine);
             const int ks = s.bc->g.kp_stride;
             P->ur.resize(ks); P->dp.resize(ks); P->bd.resize(ks); P->bi.resize(ks);
-            gfo_small_collect_stereo(s.bc, s.L, idx, cnt[0], ks, P->ur.data(), P->dp.data(), P->bd.data(), P->bi.data(), &nm);
+            const int nl = reinterpret_cast<const int*>(s.bc->h_out + s.L.o_cnt)[idx * 2];
+            gfo_small_collect_stereo(s.bc, s.L, idx, nl, ks, P->ur.data(), P->dp.data(), P->bd.data(), P->bi.data(), &nm);
+            cnt_other = reinterpret_cast<const int*>(s.bc->h_out + s.L.o_cnt)[idx * 2 + (side ^ 1)];
+            std::unique_lock<std::mutex> g(P->mu);
+            while (P->picked < 0) P->cv.wait(g);       // the slot's block stays ours until the other side has its arrays
+            got_other = P->picked;
             return 0;
         },
         &dummy);
-    const bool ok = rc == GFO_OK && !over[0] && !over[1];
-    const bool keep = ok && kp && desc && P->req[side ^ 1].kp && P->req[side ^ 1].desc;
-    if (keep) retain(side, kp, desc, cnt[side]);
     lk.lock();
     int my_rc = rc;
-    for (int k = 0; k < 2; k++) {
-        int r = rc;
-        if (rc == GFO_COMBINE_DIRECT) r = GFO_COMBINE_DIRECT;      // the engine could not serve the frame: both sides go on alone
-        else if (rc == GFO_OK) {
-            *P->req[k].n = cnt[k];
-            if (over[k]) r = gfo_fail(P->ctx[k] ? P->ctx[k] : c, GFO_ERR_CAPACITY, "an image produced more keypoints than the caller capacity %d", P->req[k].cap);
-        } else if (k != side && P->ctx[k]) {
-            gfo_fail(P->ctx[k], rc, "%s", gfo_last_error(c));
-        }
-        P->req[k].rc = r;
-        if (k == side) my_rc = r;
+    if (rc == GFO_OK) {
+        *n = cnt_mine;
+        if (got_mine == 2) my_rc = gfo_fail(c, GFO_ERR_CAPACITY, "an image produced more keypoints than the caller capacity %d", cap);
+        P->nl = side == 0 ? cnt_mine : cnt_other;
+        P->nr = side == 0 ? cnt_other : cnt_mine;
+        P->nm = nm;
+        P->valid = got_mine == 1 && got_other == 1;
+        P->speculated++;
+        me.arrived = me.staged = false;
+        other.arrived = other.staged = false;
+        P->state = 0;
+    } else {
+        // the batch failed (or the engine could not take it: GFO_COMBINE_DIRECT, both sides then go on alone)
+        other.rc = rc;
+        if (rc != GFO_COMBINE_DIRECT && P->ctx[side ^ 1]) gfo_fail(P->ctx[side ^ 1], rc, "%s", gfo_last_error(c));
+        P->valid = false;
+        me.arrived = me.staged = false;
+        P->state = 3;          // the waiter takes its status and resets the rendezvous
     }
-    P->batch_ok = ok;
-    P->other_kept = keep;
-    P->nl = cnt[0]; P->nr = cnt[1]; P->nm = nm;
-    if (ok) P->speculated++;
-    P->valid = false;          // until the waiter has retained its half
-    P->state = 3;
     P->cv.notify_all();
     return my_rc;
 }

@@ -82,7 +82,9 @@ class ORBextractor:
 
     def pair_with(self, right, params):
         """gfo_ctx_pair: this extractor and `right` are the left / right extractor of one stereo rig (None dissolves it)"""
-        rc = self._L.gfo_ctx_pair(self._ctx, right._ctx if right is not None else None, C.byref(params) if params is not None else None)
+        from ._lib import StereoParamsC
+        p = StereoParamsC(*params) if params is not None else None
+        rc = self._L.gfo_ctx_pair(self._ctx, right._ctx if right is not None else None, C.byref(p) if p is not None else None)
         check(self._L, self._ctx, rc)
 
     def max_keypoints(self):
