@@ -293,7 +293,15 @@ __global__ __launch_bounds__(256) void k_stereo_match(StereoArgs a)
 #endif
 
 // cr = right records the workgroup can stage (dynamic LDS: 48 bytes each); a band whose buckets hold more is read in place
-__global__ __launch_bounds__(SR_THREADS) void k_stereo_match_rows(StereoArgs a, int R, int cr)
+// xcd8: the grid is (8 * bands, ceil(pairs / 8)) and blockIdx.x & 7 picks the pair inside a group of eight, so that ALL bands of a
+// pair run on ONE XCD (workgroups are dealt round-robin over the eight XCDs by their linear index, as in k_fast): the five 4-byte
+// result stores per left keypoint -- scattered over the pair's output arrays, because the bands walk the keypoints in row order and the
+// arrays are in the extractor's order -- then meet in one L2, which merges them into whole lines before they leave for memory.  With
+// the plain (bands, pairs) grid a pair's bands sat on all eight XCDs, every L2 held a few dirty bytes of every line and wrote its own
+// 32-byte sector: 12 MB of write traffic per 64 pairs for 2.2 MB of results (profiles/traffic_r03.json: 2.1-3.4 x the algorithmic
+// bytes).  The overlapping right-side records that neighbouring bands stage are fetched through the fabric once instead of up to
+// eight times, too.  k_stereo_bucket and k_stereo_cut handle pair p in workgroup p: the same XCD when pairs come in multiples of 8.
+__global__ __launch_bounds__(SR_THREADS) void k_stereo_match_rows(StereoArgs a, int R, int cr, int xcd8, int npairs)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t sr_lds[];
     uint4* r_rec = reinterpret_cast<uint4*>(sr_lds);    // {row band, octave << 16 | iR, x, -}: the three filters from ONE 16-byte read
@@ -304,9 +312,10 @@ __global__ __launch_bounds__(SR_THREADS) void k_stereo_match_rows(StereoArgs a, 
     __shared__ uint4 l_d0[SR_CL], l_d1[SR_CL];
     __shared__ int s_rs[SR_ROWS];
     const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, hl = lane & 31, hw = tid >> 5;
-    const int pair = blockIdx.y;
+    const int pair = xcd8 ? (int)(blockIdx.y * 8 + (blockIdx.x & 7)) : (int)blockIdx.y;
+    if (pair >= npairs) return;                         // the last group of eight may be partly empty
     const int nRows = a.p.n_rows, W = a.window;
-    const int r0 = blockIdx.x * R, r1 = min(r0 + R, nRows);
+    const int r0 = (int)(xcd8 ? blockIdx.x >> 3 : blockIdx.x) * R, r1 = min(r0 + R, nRows);
     if (r0 >= nRows) return;
     const int* lrs = a.lrow_start + (long long)pair * (nRows + 1);
     const int lb = lrs[r0], le = lrs[r1];
@@ -754,7 +763,11 @@ void gfo_launch_stereo(gfo_ctx* c, const GfoStereoLaunch& s)
         const int per_row8 = (8 * max_nl + s.p.n_rows - 1) / s.p.n_rows;      // keypoints per 8 rows
         int cr = cr_env > 0 ? cr_env : ((2 * per_row8 * (R + 2 * s.window) / 8 + 63) & ~63);
         cr = cr < 64 ? 64 : (cr > 1024 ? 1024 : cr);
-        GFO_LAUNCH(c, k_stereo_match_rows, dim3((s.p.n_rows + R - 1) / R, s.npairs), dim3(SR_THREADS), (size_t)cr * 48, c->stream, a, R, cr);
+        static const int xcd_env = getenv("GFO_STEREO_XCD") ? atoi(getenv("GFO_STEREO_XCD")) : 1;
+        const int xcd8 = xcd_env && s.npairs >= 8 ? 1 : 0;      // below eight pairs seven of eight workgroups would be empty
+        const unsigned bands = (unsigned)((s.p.n_rows + R - 1) / R);
+        const dim3 grid = xcd8 ? dim3(bands * 8u, (unsigned)(s.npairs + 7) / 8u) : dim3(bands, (unsigned)s.npairs);
+        GFO_LAUNCH(c, k_stereo_match_rows, grid, dim3(SR_THREADS), (size_t)cr * 48, c->stream, a, R, cr, xcd8, s.npairs);
     } else {
         static const int snw_env = getenv("GFO_STEREO_WAVES") ? atoi(getenv("GFO_STEREO_WAVES")) : 4;   // waves per workgroup, 2 left keypoints each
         const int snw = snw_env < 1 ? 1 : (snw_env > 4 ? 4 : snw_env);                                     // the kernel is built for <= 256 threads
