@@ -11,6 +11,7 @@
 // Vertical halo: 6 extra rows per strip (32-row strips measured 4 % slower alone, 16-row ones 2 % slower in the pipeline).
 // All levels of all images are one launch (block index -> level through the prefix table).
 #include "gfo_internal.h"
+#include <stdlib.h>
 
 #define BLUR_STRIP GFO_BLUR_STRIP
 
@@ -248,22 +249,32 @@ __device__ __forceinline__ void blur_body(const GfoGeom& g, const GfoInput& in, 
 #define GFO_BLUR_WAVES 6
 #endif
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(GFO_BLUR_WAVES, GFO_BLUR_WAVES))) void k_blur(const GfoGeom* __restrict__ gp, GfoInput in,
-                                              const uint8_t* __restrict__ pyr, uint8_t* __restrict__ blur)
+                                              const uint8_t* __restrict__ pyr, uint8_t* __restrict__ blur, int xcd8, int nimg)
 {
     const GfoGeom& g = *gp;
     const int nb = g.blur_total_b;
-    if ((int)blockIdx.x < nb)
-        blur_body<true>(g, in, pyr, blur, blockIdx.x, blockIdx.y);
+    // xcd8: grid (8 * blocks, ceil(images / 8)), blockIdx.x & 7 picks the image inside a group of eight -- all blocks of an image
+    // on ONE XCD (as in k_fast), so that the three halo rows a strip shares with the strips above and below it are fetched through
+    // the fabric once instead of by two XCDs
+    const int img = xcd8 ? (int)(blockIdx.y * 8 + (blockIdx.x & 7)) : (int)blockIdx.y;
+    if (img >= nimg) return;
+    const int bx = xcd8 ? (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+    if (bx < nb)
+        blur_body<true>(g, in, pyr, blur, bx, img);
     else
-        blur_body<false>(g, in, pyr, blur, blockIdx.x - nb, blockIdx.y);
+        blur_body<false>(g, in, pyr, blur, bx - nb, img);
 }
 
 void gfo_launch_blur(gfo_ctx* c, const GfoInput& in, int nimg)
 {
     gfo_prof_begin(c, ST_BLUR);
-    if (c->g.total_tiles + c->g.blur_total_b > 0)
-        GFO_LAUNCH(c, k_blur, dim3(c->g.total_tiles + c->g.blur_total_b, nimg), dim3(256), 0, c->stream, c->d_geom, in,
-                           c->d_pyr, c->d_blur);
+    if (c->g.total_tiles + c->g.blur_total_b > 0) {
+        static const int xcd_env = getenv("GFO_BLUR_XCD") ? atoi(getenv("GFO_BLUR_XCD")) : 1;
+        const int xcd8 = xcd_env && nimg >= 8 ? 1 : 0;
+        const unsigned blocks = (unsigned)(c->g.total_tiles + c->g.blur_total_b);
+        const dim3 grid = xcd8 ? dim3(blocks * 8u, (unsigned)(nimg + 7) / 8u) : dim3(blocks, (unsigned)nimg);
+        GFO_LAUNCH(c, k_blur, grid, dim3(256), 0, c->stream, c->d_geom, in, c->d_pyr, c->d_blur, xcd8, nimg);
+    }
     gfo_prof_end(c);
 }
 
