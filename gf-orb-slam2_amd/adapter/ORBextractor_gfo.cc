@@ -59,15 +59,17 @@ struct Table : gfo_adapter::ContextTable {
     Table() { on_create = configure_context; }
 } g_tab;
 
-gfo_ctx* ctx_of(const ORBextractor* self) { return g_tab.get(self); }
+typedef gfo_adapter::ContextTable::Use Use;   // a context pinned for the duration of one call (reclaim() on another thread skips it)
 
 struct AtExit {
     ~AtExit() { g_tab.destroy_all(); }
 } g_at_exit;
 }  // namespace
 
-// used by the matcher adapters (matchers_gfo.cc) to reach the device context of a frame's extractor
-gfo_ctx* gfo_context_of(const ORBextractor* e) { return ctx_of(e); }
+// used by the matcher adapters (matchers_gfo.cc) to reach the device context of a frame's extractor: pinned while the matcher
+// call is inside the library (GfoUse there), released afterwards
+gfo_ctx* gfo_context_pin(const ORBextractor* e) { return g_tab.acquire(e); }
+void gfo_context_unpin(const ORBextractor* e, gfo_ctx* c) { if (c) g_tab.release(e, c); }
 
 ORBextractor::ORBextractor(int _nfeatures, float _scaleFactor, int _nlevels, int _iniThFAST, int _minThFAST)
     : nfeatures(_nfeatures), scaleFactor(_scaleFactor), nlevels(_nlevels), iniThFAST(_iniThFAST), minThFAST(_minThFAST)
@@ -86,7 +88,8 @@ ORBextractor::ORBextractor(int _nfeatures, float _scaleFactor, int _nlevels, int
     mvInvLevelSigma2.resize(nlevels);
     mnFeaturesPerLevel.resize(nlevels);
     mvImagePyramid.resize(nlevels);
-    if (gfo_ctx* c = ctx_of(this))
+    Use use(g_tab, this);
+    if (gfo_ctx* c = use.ctx())
         gfo_ctx_tables(c, mvScaleFactor.data(), mvInvScaleFactor.data(), mvLevelSigma2.data(), mvInvLevelSigma2.data(),
                        mnFeaturesPerLevel.data());
 }
@@ -109,7 +112,8 @@ static void fetch_pyramid(gfo_ctx* c, std::vector<cv::Mat>& pyr, const std::vect
 
 void ORBextractor::ComputePyramid(cv::Mat image)
 {
-    gfo_ctx* c = ctx_of(this);
+    Use use(g_tab, this);
+    gfo_ctx* c = use.ctx();
     if (!c || image.empty()) return;
     if (gfo_compute_pyramid(c, image.data, image.cols, image.rows, (int)image.step) != GFO_OK) {
         fprintf(stderr, "[gfo] ComputePyramid: %s\n", gfo_last_error(c));
@@ -124,7 +128,8 @@ void ORBextractor::operator()(cv::InputArray _image, cv::InputArray /*_mask*/, s
     if (_image.empty()) return;
     cv::Mat image = _image.getMat();
     assert(image.type() == CV_8UC1);
-    gfo_ctx* c = ctx_of(this);
+    Use use(g_tab, this);
+    gfo_ctx* c = use.ctx();
     static_assert(sizeof(cv::KeyPoint) == sizeof(gfo_keypoint), "gfo_keypoint must mirror cv::KeyPoint");
     int n = 0;
     int cap = c ? gfo_ctx_max_keypoints(c) : 0;

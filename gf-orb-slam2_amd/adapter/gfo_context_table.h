@@ -7,6 +7,11 @@
 //   * an extractor that is in use is never evicted, however many there are: a context is only reclaimed when its owner
 //     has not called for `idle_limit()` table lookups (64 x the number of live contexts, at least 4096) -- a rig of K
 //     cameras calling round-robin touches every context once per ~K lookups, three orders of magnitude inside the limit;
+//   * a context is PINNED while a call is inside the library with it (ContextTable::Use, the only way the adapters obtain a
+//     context): reclaim() -- run from whichever thread has just created a context -- skips pinned entries, so neither the LRU
+//     ceiling nor the idle rule can destroy a context under a thread that is using it (get() used to hand out a raw
+//     pointer and drop the lock); a constructor at the address of a pinned entry defers the old context's destruction to the
+//     moment its last user leaves;
 //   * a constructor at an address the table already knows means the old object is gone (Tracking::updateORBExtractor,
 //     src/Tracking.cc:298-320, deletes and re-creates both extractors; glibc hands `new` the block `delete` just freed):
 //     its context is destroyed at once and the new object gets a NEW context -- nothing cached "per address"
@@ -39,6 +44,24 @@ public:
         gfo_params prm;
         gfo_ctx* ctx;
         unsigned long stamp;
+        int in_use;            // calls inside the library with `ctx` (or `retired`) right now
+        gfo_ctx* retired;      // the context of a dead object at this address that still had a user when the new object was declared
+    };
+
+    // A context for the duration of one call: pins the entry so that reclaim() on another thread cannot destroy it.
+    //   ContextTable::Use u(table, this);  if (gfo_ctx* c = u.ctx()) gfo_extract(c, ...);
+    class Use
+    {
+    public:
+        Use(ContextTable& t, const void* key) : t_(t), key_(key), ctx_(t.acquire(key)) {}
+        ~Use() { if (ctx_) t_.release(key_, ctx_); }
+        gfo_ctx* ctx() const { return ctx_; }
+    private:
+        Use(const Use&);
+        Use& operator=(const Use&);
+        ContextTable& t_;
+        const void* key_;
+        gfo_ctx* ctx_;
     };
 
     // the constructor of an extractor: remembers its arguments; a context the address still owns belongs to a dead object
@@ -46,21 +69,99 @@ public:
     {
         std::lock_guard<std::mutex> lk(mu_);
         std::map<const void*, Entry>::iterator it = tab_.find(key);
-        if (it != tab_.end() && it->second.ctx) {
-            gfo_ctx_destroy(it->second.ctx);
-            destroyed_++;
-        }
         Entry e;
         e.prm = prm;
         e.ctx = NULL;
         e.stamp = ++clock_;
+        e.in_use = 0;
+        e.retired = NULL;
+        if (it != tab_.end()) {
+            Entry& old = it->second;
+            if (old.ctx && old.in_use > 0 && !old.retired) {
+                // somebody is still inside a call with the dead object's context (the caller's bug, but not ours to crash on):
+                // it is destroyed when that call returns
+                e.retired = old.ctx;
+                e.in_use = old.in_use;
+            } else if (old.ctx) {
+                gfo_ctx_destroy(old.ctx);
+                destroyed_++;
+            }
+            if (old.retired) {       // (a second re-declaration while the first dead context is still in use: keep waiting for it)
+                e.retired = old.retired;
+                e.in_use = old.in_use;
+            }
+        }
         tab_[key] = e;
     }
 
-    // the context of a live extractor, created on first use; NULL (and a message) when the device refuses
+    // pin + get: the context of a live extractor for the duration of a call (see Use); release() with what acquire() returned
+    gfo_ctx* acquire(const void* key)
+    {
+        std::lock_guard<std::mutex> lk(mu_);
+        gfo_ctx* c = get_locked(key);
+        if (c) tab_[key].in_use++;
+        return c;
+    }
+
+    void release(const void* key, gfo_ctx* c)
+    {
+        std::lock_guard<std::mutex> lk(mu_);
+        std::map<const void*, Entry>::iterator it = tab_.find(key);
+        if (it == tab_.end()) return;
+        Entry& e = it->second;
+        if (e.in_use > 0) e.in_use--;
+        if (e.in_use == 0 && e.retired) {      // the last user of a dead object's context has left
+            if (e.retired != e.ctx) {
+                gfo_ctx_destroy(e.retired);
+                destroyed_++;
+            }
+            e.retired = NULL;
+        }
+        (void)c;
+    }
+
+    // the context of a live extractor, created on first use; NULL (and a message) when the device refuses.  UNPINNED: for
+    // single-threaded callers and the tests; the adapters go through Use.
     gfo_ctx* get(const void* key)
     {
         std::lock_guard<std::mutex> lk(mu_);
+        return get_locked(key);
+    }
+
+    void destroy_all()
+    {
+        std::lock_guard<std::mutex> lk(mu_);
+        for (std::map<const void*, Entry>::iterator it = tab_.begin(); it != tab_.end(); ++it) {
+            if (it->second.ctx) {
+                gfo_ctx_destroy(it->second.ctx);
+                it->second.ctx = NULL;
+                destroyed_++;
+            }
+            if (it->second.retired) {
+                gfo_ctx_destroy(it->second.retired);
+                it->second.retired = NULL;
+                destroyed_++;
+            }
+        }
+    }
+
+    int alive()
+    {
+        std::lock_guard<std::mutex> lk(mu_);
+        return alive_locked();
+    }
+    unsigned long created() const { return created_; }
+    unsigned long destroyed() const { return destroyed_; }
+
+    static int max_contexts()
+    {
+        static const int n = getenv("GFO_MAX_CONTEXTS") ? atoi(getenv("GFO_MAX_CONTEXTS")) : 64;
+        return n < 2 ? 2 : n;
+    }
+
+private:
+    gfo_ctx* get_locked(const void* key)
+    {
         std::map<const void*, Entry>::iterator it = tab_.find(key);
         if (it == tab_.end()) return NULL;   // not constructed through the adapter
         Entry& e = it->second;
@@ -80,32 +181,6 @@ public:
         return e.ctx;
     }
 
-    void destroy_all()
-    {
-        std::lock_guard<std::mutex> lk(mu_);
-        for (std::map<const void*, Entry>::iterator it = tab_.begin(); it != tab_.end(); ++it)
-            if (it->second.ctx) {
-                gfo_ctx_destroy(it->second.ctx);
-                it->second.ctx = NULL;
-                destroyed_++;
-            }
-    }
-
-    int alive()
-    {
-        std::lock_guard<std::mutex> lk(mu_);
-        return alive_locked();
-    }
-    unsigned long created() const { return created_; }
-    unsigned long destroyed() const { return destroyed_; }
-
-    static int max_contexts()
-    {
-        static const int n = getenv("GFO_MAX_CONTEXTS") ? atoi(getenv("GFO_MAX_CONTEXTS")) : 64;
-        return n < 2 ? 2 : n;
-    }
-
-private:
     int alive_locked() const
     {
         int n = 0;
@@ -121,7 +196,7 @@ private:
             const unsigned long idle_limit = 64ul * (unsigned long)alive > 4096ul ? 64ul * (unsigned long)alive : 4096ul;
             std::map<const void*, Entry>::iterator oldest = tab_.end();
             for (std::map<const void*, Entry>::iterator it = tab_.begin(); it != tab_.end(); ++it) {
-                if (!it->second.ctx || it->first == keep) continue;
+                if (!it->second.ctx || it->first == keep || it->second.in_use > 0) continue;   // never the caller's own, never one in use
                 if (oldest == tab_.end() || it->second.stamp < oldest->second.stamp) oldest = it;
             }
             if (oldest == tab_.end()) return;

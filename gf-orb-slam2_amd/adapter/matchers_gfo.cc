@@ -17,7 +17,7 @@
 // no status): a gfo error is reported on stderr and the function returns "nothing matched".
 //
 // The device context of a frame is the one its left extractor owns (adapter/ORBextractor_gfo.cc keeps it in a side
-// table because include/ORBextractor.h cannot carry a new member): gfo_context_of().
+// table because include/ORBextractor.h cannot carry a new member): gfo_context_pin() / GfoUse.
 #ifdef GFO_ADAPTER_ALL
 #define GFO_ADAPTER_STEREO
 #define GFO_ADAPTER_PROJECTION
@@ -46,11 +46,24 @@
 namespace ORB_SLAM2
 {
 
-gfo_ctx* gfo_context_of(const ORBextractor* e);   // adapter/ORBextractor_gfo.cc
+gfo_ctx* gfo_context_pin(const ORBextractor* e);   // adapter/ORBextractor_gfo.cc
+void gfo_context_unpin(const ORBextractor* e, gfo_ctx* c);
 
 namespace
 {
 static_assert(sizeof(cv::KeyPoint) == sizeof(gfo_keypoint), "gfo_keypoint must mirror cv::KeyPoint");
+
+// the device context of an extractor, pinned in the adapter's table for the duration of one matcher call (another thread that
+// creates a context may reclaim idle ones meanwhile: never one that is in use)
+struct GfoUse {
+    const ORBextractor* e;
+    gfo_ctx* c;
+    explicit GfoUse(const ORBextractor* e_) : e(e_), c(e_ ? gfo_context_pin(e_) : NULL) {}
+    ~GfoUse() { gfo_context_unpin(e, c); }
+private:
+    GfoUse(const GfoUse&);
+    GfoUse& operator=(const GfoUse&);
+};
 
 inline const gfo_keypoint* as_gfo(const std::vector<cv::KeyPoint>& v) { return reinterpret_cast<const gfo_keypoint*>(v.data()); }
 
@@ -116,11 +129,12 @@ int Frame::ComputeStereoMatches_Undistorted(bool /*isOnline*/)
     std::vector<int32_t> bestDist(N), bestIdx(N);
     int nmatched = 0;
     cv::Mat keepL, keepR;
-    gfo_ctx* c = gfo_context_of(mpORBextractorLeft);
+    GfoUse use(mpORBextractorLeft), use_r(mpORBextractorRight);
+    gfo_ctx* c = use.c;
     // the two extractors are one stereo rig with this calibration: from the next frame on their two operator() calls go to the
     // device as one stereo submission that also computes this association, and the call below -- on rectified input, where
     // mvKeysUn == mvKeys -- is answered from it (gfo_ctx_pair: a hint, idempotent, a few nanoseconds when nothing changed)
-    if (mpORBextractorRight) (void)gfo_ctx_pair(c, gfo_context_of(mpORBextractorRight), &p);
+    if (c && use_r.c) (void)gfo_ctx_pair(c, use_r.c, &p);
     const int rc = gfo_stereo_match(c, as_gfo(mvKeysUn), rows32(mDescriptors, keepL), N, as_gfo(mvKeysRightUn),
                                     rows32(mDescriptorsRight, keepR), (int)mvKeysRightUn.size(), mvScaleFactors.data(),
                                     (int)mvScaleFactors.size(), &p, windows ? minD.data() : NULL, windows ? maxD.data() : NULL,
@@ -157,7 +171,8 @@ int ORBmatcher::SearchByProjection(Frame& F, const std::vector<MapPoint*>& vpMap
     std::vector<int32_t> outMp(N), outScore(N);
     int nmatches = 0;
     cv::Mat keep;
-    gfo_ctx* c = gfo_context_of(F.mpORBextractorLeft);
+    GfoUse use(F.mpORBextractorLeft);
+    gfo_ctx* c = use.c;
     const int rc = gfo_search_by_projection(c, as_gfo(F.mvKeysUn), rows32(F.mDescriptors, keep), F.mvuRight.data(), N,
                                             F.mvScaleFactors.data(), (int)F.mvScaleFactors.size(), &fb, mps.data(), mpDesc.data, M,
                                             th, mfNNratio, taken.data(), outMp.data(), outScore.data(), &nmatches);
@@ -239,7 +254,8 @@ int ORBmatcher::SearchByProjection(Frame& CurrentFrame, const Frame& LastFrame, 
     std::vector<int32_t> outQ(N), outScore(N);
     int nmatches = 0;
     cv::Mat keep;
-    gfo_ctx* c = gfo_context_of(CurrentFrame.mpORBextractorLeft);
+    GfoUse use(CurrentFrame.mpORBextractorLeft);
+    gfo_ctx* c = use.c;
     const int rc = gfo_search_by_projection_queries(c, as_gfo(CurrentFrame.mvKeysUn), rows32(CurrentFrame.mDescriptors, keep),
                                                     CurrentFrame.mvuRight.data(), angle.data(), N, &fb, q.data(), qDesc.data, M, &mode,
                                                     taken.data(), outQ.data(), outScore.data(), &nmatches);
@@ -316,7 +332,8 @@ int ORBmatcher::SearchByProjection(Frame& CurrentFrame, KeyFrame* pKF, const std
     std::vector<int32_t> outQ(N), outScore(N);
     int nmatches = 0;
     cv::Mat keep;
-    gfo_ctx* c = gfo_context_of(CurrentFrame.mpORBextractorLeft);
+    GfoUse use(CurrentFrame.mpORBextractorLeft);
+    gfo_ctx* c = use.c;
     const int rc = gfo_search_by_projection_queries(c, as_gfo(CurrentFrame.mvKeysUn), rows32(CurrentFrame.mDescriptors, keep), NULL,
                                                     angle.data(), N, &fb, q.data(), qDesc.data, M, &mode, taken.data(), outQ.data(),
                                                     outScore.data(), &nmatches);
@@ -351,7 +368,8 @@ int ORBmatcher::SearchByBoW(KeyFrame* pKF, Frame& F, std::vector<MapPoint*>& vpM
     std::vector<int32_t> out(nF > 0 ? nF : 1);
     int nmatches = 0;
     cv::Mat keepK, keepF;
-    gfo_ctx* c = gfo_context_of(F.mpORBextractorLeft);
+    GfoUse use(F.mpORBextractorLeft);
+    gfo_ctx* c = use.c;
     const int rc = gfo_search_by_bow(c, rows32(pKF->mDescriptors, keepK), kfAngle.data(), valid.data(), nKF, &kfv.view,
                                      rows32(F.mDescriptors, keepF), fAngle.data(), nF, &ffv.view, mfNNratio,
                                      mbCheckOrientation ? 1 : 0, out.data(), &nmatches);
@@ -420,7 +438,8 @@ void Frame::ComputeBoW()
     if (!mBowVec.empty()) return;
     mFeatVec.clear();
     if (mpORBvocabulary->empty() || N == 0) return;
-    gfo_ctx* c = gfo_context_of(mpORBextractorLeft);
+    GfoUse use(mpORBextractorLeft);
+    gfo_ctx* c = use.c;
     if (!c) return;
     const VocabularyView::Flat* flat;
     {

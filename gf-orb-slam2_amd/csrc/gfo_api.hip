@@ -423,7 +423,7 @@ int gfo_plan(gfo_ctx* c, int w, int h, int batch)
     HIP_TRY(c, hipMalloc(&c->d_kp, B * (size_t)g.kp_stride * sizeof(gfo_keypoint)));
     HIP_TRY(c, hipMalloc(&c->d_desc, B * (size_t)g.kp_stride * 32));
     HIP_TRY(c, hipMalloc(&c->d_kp_cnt, B * sizeof(int) + 16));   // +16: k_pack_results copies in 16-byte units
-    HIP_TRY(c, hipMalloc(&c->d_flags, 4 * sizeof(int)));
+    HIP_TRY(c, hipMalloc(&c->d_flags, 8 * sizeof(int)));   // [0..3] the live flags the kernels OR into, [4..7] the snapshot gfo_batch_deliver hands out
     HIP_TRY(c, hipMalloc(&c->d_xofs, xtabv.size() * sizeof(int) + 64));
     HIP_TRY(c, hipMalloc(&c->d_yofs, ytabv.size() * sizeof(int) + 64));
     {
@@ -509,7 +509,7 @@ int gfo_plan(gfo_ctx* c, int w, int h, int batch)
     HIP_TRY(c, hipMemcpy(c->d_yofs, ytabv.data(), ytabv.size() * sizeof(int), hipMemcpyHostToDevice));
     HIP_TRY(c, hipMemcpy(c->d_scale, c->scale.data(), g.nlevels * sizeof(float), hipMemcpyHostToDevice));
     HIP_TRY(c, hipMemcpy(c->d_inv_scale, c->inv_scale.data(), g.nlevels * sizeof(float), hipMemcpyHostToDevice));
-    HIP_TRY(c, hipMemset(c->d_flags, 0, 4 * sizeof(int)));
+    HIP_TRY(c, hipMemset(c->d_flags, 0, 8 * sizeof(int)));
     c->cap_batch = batch;
     c->planned = true;
     g_arenas_planned++;
@@ -923,6 +923,7 @@ static int run_extract(gfo_ctx* c, const GfoInput& in, int nimg, const gfo_stere
         return gfo_take_launch_err(c);
     }
     HIP_TRY(c, hipGetLastError());
+    c->flags_snapshot = false;      // a new batch: its flags are in the live word
     c->last_in = in;
     c->last_nimg = nimg;
     c->have_pyramid = true;
@@ -934,9 +935,10 @@ static int run_extract(gfo_ctx* c, const GfoInput& in, int nimg, const gfo_stere
 
 static int check_flags(gfo_ctx* c)
 {
-    int f[4] = {0, 0, 0, 0};
+    int f[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     HIP_TRY(c, hipMemcpyAsync(f, c->d_flags, sizeof f, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (c->flags_snapshot) f[0] |= f[4];    // gfo_batch_deliver moved this batch's flags into the snapshot word
 #ifdef GFO_FAST_DEBUG
     if (getenv("GFO_FAST_STOP") && atoi(getenv("GFO_FAST_STOP")) == 9) {
         fprintf(stderr, "[gfo] FAST selectivity: scan px %d, after compass %d, after pair test %d\n", f[1], f[2], f[3]);
@@ -945,6 +947,7 @@ static int check_flags(gfo_ctx* c)
 #endif
     if (f[0]) {
         (void)hipMemsetAsync(c->d_flags, 0, sizeof f, c->stream);
+        c->flags_snapshot = false;
         return fail(c, GFO_ERR_OVERFLOW, "internal buffer overflow (flags 0x%x: 1 candidates, 2 quadtree nodes, 4 selection, 8 keypoints)", f[0]);
     }
     return GFO_OK;
@@ -1046,6 +1049,14 @@ extern "C" int gfo_batch_deliver(gfo_ctx* c, void* host_dst, size_t host_bytes, 
     }
     uint8_t* H = (uint8_t*)host_dst;
     hipStream_t cs = c->copy_stream;
+    // The overflow flags of THIS batch, frozen on the main stream before the copy stream may run beside the next extraction
+    // (ADVICE r3): that extraction's k_fast / k_quadtree OR into the live word while this batch is still being delivered, and the
+    // live word was never cleared on this path -- batch N could report batch N+1's overflow, and one overflow stuck to every later
+    // delivery.  Snapshot, then clear; the snapshot is what is delivered.  (The next snapshot is written after the next
+    // extraction's k_orient_desc, which waits for ev_delivered: the copy stream has read this one by then.)
+    HIP_TRY(c, hipMemcpyAsync(c->d_flags + 4, c->d_flags, 16, hipMemcpyDeviceToDevice, c->stream));
+    HIP_TRY(c, hipMemsetAsync(c->d_flags, 0, 16, c->stream));
+    c->flags_snapshot = true;
     HIP_TRY(c, hipEventRecord(c->ev_results, c->stream));
     HIP_TRY(c, hipStreamWaitEvent(cs, c->ev_results, 0));
     // Pinned memory the device can address (hipHostMalloc, a pinned torch tensor, hipHostRegister'ed pages) is written by
@@ -1060,7 +1071,7 @@ extern "C" int gfo_batch_deliver(gfo_ctx* c, void* host_dst, size_t host_bytes, 
         auto seg = [&](const void* src, size_t dst_off, size_t bytes) {
             pk.src[pk.nseg] = (const uint4*)src; pk.dst[pk.nseg] = (uint4*)(D + dst_off); pk.n16[pk.nseg] = (int)((bytes + 15) / 16); pk.nseg++;
         };
-        seg(c->d_flags, L->off_flags, 16);
+        seg(c->d_flags + 4, L->off_flags, 16);
         seg(c->d_kp_cnt, L->off_counts, 4 * (size_t)nimg);
         seg(c->d_kp, L->off_kp, sizeof(gfo_keypoint) * (size_t)ks * nimg);
         seg(c->d_desc, L->off_desc, 32 * (size_t)ks * nimg);
@@ -1078,7 +1089,7 @@ extern "C" int gfo_batch_deliver(gfo_ctx* c, void* host_dst, size_t host_bytes, 
         HIP_TRY(c, hipGetLastError());
     } else {
         (void)hipGetLastError();
-        HIP_TRY(c, hipMemcpyAsync(H + L->off_flags, c->d_flags, 16, hipMemcpyDeviceToHost, cs));
+        HIP_TRY(c, hipMemcpyAsync(H + L->off_flags, c->d_flags + 4, 16, hipMemcpyDeviceToHost, cs));
         HIP_TRY(c, hipMemcpyAsync(H + L->off_counts, c->d_kp_cnt, 4 * (size_t)nimg, hipMemcpyDeviceToHost, cs));
         HIP_TRY(c, hipMemcpyAsync(H + L->off_kp, c->d_kp, sizeof(gfo_keypoint) * (size_t)ks * nimg, hipMemcpyDeviceToHost, cs));
         HIP_TRY(c, hipMemcpyAsync(H + L->off_desc, c->d_desc, 32 * (size_t)ks * nimg, hipMemcpyDeviceToHost, cs));

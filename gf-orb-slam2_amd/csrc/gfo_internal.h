@@ -247,6 +247,7 @@ struct gfo_ctx {
     hipEvent_t ev_results = nullptr, ev_delivered = nullptr;
     bool deliver_pending = false;
     // frame combiner (gfo_ctx_set_combining): per-frame host calls of this context may run inside a shared device batch
+    bool flags_snapshot = false;        // the last batch's overflow flags were moved to d_flags[4..7] by gfo_batch_deliver
     bool combining = false;
     std::shared_ptr<GfoEngine> engine;
     std::shared_ptr<GfoPair> pair;      // gfo_ctx_pair

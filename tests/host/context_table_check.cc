@@ -78,6 +78,37 @@ int main()
         t.destroy_all();
         CHECK(g_live.empty());
     }
+    // (e) ADVICE r3: a context that is IN USE is never reclaimed -- neither by the ceiling nor by the idle rule -- while another
+    //     thread's first call creates contexts; and a constructor at the address of an object that still has a call in flight
+    //     defers the old context's destruction to the end of that call
+    {
+        setenv("GFO_MAX_CONTEXTS", "64", 1);
+        gfo_adapter::ContextTable t;
+        std::vector<char> objs(80);
+        t.declare(&objs[0], prm);
+        gfo_ctx* held;
+        {
+            gfo_adapter::ContextTable::Use use(t, &objs[0]);       // "inside gfo_extract" with objs[0]'s context, the oldest of all
+            held = use.ctx();
+            CHECK(held != NULL);
+            for (size_t i = 1; i < objs.size(); i++) { t.declare(&objs[i], prm); CHECK(t.get(&objs[i]) != NULL); }   // 79 creations, ceiling 64
+            for (int it = 0; it < 6000; it++) CHECK(t.get(&objs[79]) != NULL);                                        // ... and 6000 lookups: objs[0] is "idle"
+            char late;
+            t.declare(&late, prm);
+            CHECK(t.get(&late) != NULL);
+            CHECK(g_live.count(held) == 1);                          // still alive: it is pinned
+            CHECK(t.alive() <= 65);
+            // the object is re-created at the same address while the call is still inside
+            const int d0 = g_destroyed;
+            t.declare(&objs[0], prm);
+            CHECK(g_live.count(held) == 1 && g_destroyed == d0);     // not yet
+            gfo_ctx* fresh = t.get(&objs[0]);
+            CHECK(fresh != NULL && fresh != held);
+        }                                                            // the call returns: now the dead object's context goes
+        CHECK(g_live.count(held) == 0);
+        t.destroy_all();
+        CHECK(g_live.empty());
+    }
     printf("OK created %d destroyed %d\n", g_created, g_destroyed);
     return 0;
 }
