@@ -1,0 +1,27 @@
+// Declarations with the reference's names and signatures (include/Frame.h:267, include/ORBmatcher.h:64,259-272), nothing else of
+// the classes: a mangled name depends on the names in a signature only.  tests/test_adapter_compiles.py checks that the symbols
+// this miniature defines ARE the ones in adapter/weaken_symbols.txt.
+#include <set>
+#include <vector>
+namespace ORB_SLAM2
+{
+class MapPoint;
+class KeyFrame;
+class Frame
+{
+public:
+    int ComputeStereoMatches_Undistorted(bool isOnline);
+    void ComputeBoW();
+    int construct();   // stands for Frame::Frame, which calls ComputeStereoMatches_Undistorted from inside Frame.o (Frame.cc:100)
+    int bow = 0;
+};
+class ORBmatcher
+{
+public:
+    int SearchByProjection(Frame& F, const std::vector<MapPoint*>& vpMapPoints, const float th);
+    int SearchByProjection(Frame& CurrentFrame, const Frame& LastFrame, const float th, const bool bMono, double& numVisibleMpt);
+    int SearchByProjection(Frame& CurrentFrame, KeyFrame* pKF, const std::set<MapPoint*>& sAlreadyFound, const float th, const int ORBdist);
+    int SearchByBoW(KeyFrame* pKF, Frame& F, std::vector<MapPoint*>& vpMapPointMatches);
+    int untouched();   // a member the adapter does not replace
+};
+}  // namespace ORB_SLAM2

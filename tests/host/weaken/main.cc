@@ -1,0 +1,16 @@
+// stands for Tracking.cc: calls through the unchanged public signatures
+#include <cstdio>
+#include "decl.h"
+using namespace ORB_SLAM2;
+int main()
+{
+    Frame f, g;
+    ORBmatcher m;
+    std::vector<MapPoint*> v;
+    std::set<MapPoint*> s;
+    double nv = 0;
+    f.ComputeBoW();
+    printf("%d %d %d %d %d %d %d %d\n", f.ComputeStereoMatches_Undistorted(false), f.construct(), f.bow, m.SearchByProjection(f, v, 3.f),
+           m.SearchByProjection(f, g, 3.f, false, nv), m.SearchByProjection(f, (KeyFrame*)0, s, 3.f, 100), m.SearchByBoW((KeyFrame*)0, f, v), m.untouched());
+    return 0;
+}

@@ -37,3 +37,60 @@ def test_matcher_adapters_match_reference_headers(guard):
            "-I", REF_INC, "-I", os.path.dirname(REF_INC), "-I", os.path.join(ROOT, "include"), src]
     r = subprocess.run(cmd, capture_output=True, text=True)
     assert r.returncode == 0, r.stderr[-3000:]
+
+
+@pytest.mark.skipif(not os.path.exists(os.path.join(REF_INC, "ORBmatcher.h")), reason="reference headers not mounted")
+@pytest.mark.skipif(shutil.which("g++") is None, reason="g++ missing")
+def test_weaken_list_is_what_the_adapter_defines():
+    """adapter/weaken_symbols.txt (committed) = the Frame:: / ORBmatcher:: text symbols of matchers_gfo.cc compiled against the
+    reference's unchanged headers (tools/make_weaken_list.py --print): six members, the names a maintainer weakens in Frame.o /
+    ORBmatcher.o."""
+    import sys
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "make_weaken_list.py"), "--print"], capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr[-2000:]
+    committed = open(os.path.join(ROOT, "gf-orb-slam2_amd", "adapter", "weaken_symbols.txt")).read()
+    assert out.stdout == committed
+    assert len([l for l in committed.splitlines() if l and not l.startswith("#")]) == 6
+
+
+@pytest.mark.skipif(shutil.which("g++") is None or shutil.which("objcopy") is None, reason="g++ / objcopy missing")
+@pytest.mark.parametrize("shared", [False, True])
+def test_link_time_swap_of_the_matcher_bodies(tmp_path, shared):
+    """"Tracking.cc and Frame.cc link unchanged", literally.  A two-TU miniature with the REAL mangled names:
+    reference_side.cc (stands for src/Frame.cc + src/ORBmatcher.cc, bodies answer 1) and adapter_side.cc (stands for
+    adapter/matchers_gfo.cc, bodies answer 2) both define the six members.  Untouched, the link fails (duplicate definitions);
+    after tools/weaken_reference_objects.sh on the reference-side object it succeeds and EVERY call reaches the adapter's body --
+    from outside (main.cc = Tracking.cc) and from inside the reference's own object (Frame::construct = Frame::Frame calling
+    ComputeStereoMatches_Undistorted, Frame.cc:100) -- while a member the adapter does not define keeps the reference's body.
+    Both as a plain executable and the way the reference links: -fPIC objects into one shared library (CMakeLists.txt:260)."""
+    d = os.path.join(ROOT, "tests", "host", "weaken")
+    objs = {}
+    for name in ("reference_side", "adapter_side", "main"):
+        objs[name] = str(tmp_path / (name + ".o"))
+        r = subprocess.run(["g++", "-std=c++11", "-O3", "-fPIC", "-c", os.path.join(d, name + ".cc"), "-o", objs[name]], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr[-2000:]
+    want = [l for l in open(os.path.join(ROOT, "gf-orb-slam2_amd", "adapter", "weaken_symbols.txt")).read().splitlines() if l and not l.startswith("#")]
+    defined = subprocess.run(["nm", "--defined-only", objs["reference_side"]], capture_output=True, text=True).stdout
+    for sym in want:                      # the miniature uses the real names
+        assert f" T {sym}" in defined, sym
+    exe, lib = str(tmp_path / "swap"), str(tmp_path / "libORB_SLAM2_mini.so")
+
+    def link():
+        if shared:
+            r = subprocess.run(["g++", "-shared", "-o", lib, objs["reference_side"], objs["adapter_side"]], capture_output=True, text=True)
+            if r.returncode:
+                return r
+            return subprocess.run(["g++", "-o", exe, objs["main"], lib, "-Wl,-rpath," + str(tmp_path)], capture_output=True, text=True)
+        return subprocess.run(["g++", "-o", exe, objs["main"], objs["reference_side"], objs["adapter_side"]], capture_output=True, text=True)
+    r = link()
+    assert r.returncode != 0 and "multiple definition" in r.stderr        # untouched objects: both define the members
+    r = subprocess.run([os.path.join(ROOT, "tools", "weaken_reference_objects.sh"), objs["reference_side"]], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    after = subprocess.run(["nm", "--defined-only", objs["reference_side"]], capture_output=True, text=True).stdout
+    for sym in want:
+        assert f" W {sym}" in after, sym
+    assert " T _ZN9ORB_SLAM210ORBmatcher9untouchedEv" in after             # nothing else was touched
+    r = link()
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = subprocess.run([exe], capture_output=True, text=True)
+    assert out.returncode == 0 and out.stdout.split() == ["2", "2", "2", "2", "2", "2", "2", "7"], out.stdout
