@@ -23,6 +23,6 @@ for k in ("pageable", "pinned", "nocombine"):
     runs[k] = {"what": old["runs"][k]["what"], "points": j["points"]}
 json.dump({"workload": old["workload"], "runs": runs}, open(os.path.join(P, f"boundary_throughput_{tag}.json"), "w"), indent=1)
 for src, dst in ((f"bench_default_{tag}.json", f"bench_default_{tag}.json"), (f"latency_pair_{tag}.json", f"latency_pair_{tag}.json"),
-                 (f"sq_counters_{tag}.txt", f"sq_counters_{tag}.txt"), (f"trace_boundary_{tag}_k8_combined.txt", f"boundary_trace_{tag}.txt")):
+                 (f"sq_counters_{tag}.txt", f"sq_counters_{tag}.txt"), (f"trace_boundary_{tag}_k8_combined.txt", f"boundary_trace_{tag}_k8_combined.txt")):
     shutil.copy(os.path.join(G, src), os.path.join(P, dst))
 print("profiles/", tag, "refreshed")
