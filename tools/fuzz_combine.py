@@ -39,6 +39,7 @@ for rd in range(rounds):
     K = int(rng.integers(2, 13))
     plan = [(int(rng.integers(0, len(PARAMS))), int(rng.integers(0, len(SIZES))), int(rng.integers(3, 12)), int(rng.integers(0, 1 << 30))) for _ in range(K)]
     exts = [G.ORBextractor(*PARAMS[pi], max_batch=2, combining=True) for pi, _, _, _ in plan]
+    rights = [G.ORBextractor(*PARAMS[pi], max_batch=2, combining=True) for pi, _, _, _ in plan]     # the right extractor of thread t's rig
     matchers = [G.ORBmatcher(0.8, True, extractor=e) for e in exts]
 
     def work(t):
@@ -60,7 +61,29 @@ for rd in range(rounds):
                 got = matchers[t].ComputeStereoMatches(kl, dl, kr, dr, sfac, sp, *win)
                 if not (got[0] == ref[0] and all(a.tobytes() == b.tobytes() for a, b in zip(got[1:], ref[1:]))):
                     bad.append((rd, t, "assoc", pi, si, k))
-            elif u < 0.6:
+            elif u < 0.45:
+                # the adapter's whole pattern on a declared rig (gfo_ctx_pair): right image on a thread of its own, left here, then the
+                # association -- answered from the frame's one submission, or computed when windows are passed
+                k = int(r.choice([0, 2]))
+                exts[t].pair_with(rights[t], sp)
+                out = {}
+                th = threading.Thread(target=lambda: out.__setitem__("r", rights[t](imgs[(si, k + 1)])))
+                th.start()
+                kl, dl = exts[t](imgs[(si, k)])
+                th.join()
+                kr, dr = out["r"]
+                (okl, odl), (okr, odr) = refs[(pi, si, k)], refs[(pi, si, k + 1)]
+                sfac = O.OracleExtractor(*PARAMS[pi]).scale_factors
+                win = (None, None)
+                if r.random() < 0.3:
+                    d0 = r.uniform(0, 50, len(okl)).astype(np.float32)
+                    win = (np.maximum(d0 - 6, 0).astype(np.float32), (d0 + 6).astype(np.float32))
+                ref = refs[(pi, si, k, "st")] if win[0] is None else O.stereo_match(okl, odl, okr, odr, sfac, h, BF, BF / FX, 0.0, *win)
+                got = matchers[t].ComputeStereoMatches(kl, dl, kr, dr, sfac, sp, *win)
+                if not (kl.tobytes() == okl.tobytes() and kr.tobytes() == okr.tobytes() and (dl == odl).all() and (dr == odr).all()
+                        and got[0] == ref[0] and all(a.tobytes() == b.tobytes() for a, b in zip(got[1:], ref[1:]))):
+                    bad.append((rd, t, "rig", pi, si, k))
+            elif u < 0.7:
                 k = int(r.integers(0, 4))
                 kp, d = exts[t](imgs[(si, k)])
                 ok, od = refs[(pi, si, k)]
@@ -79,8 +102,11 @@ for rd in range(rounds):
     for t in ts:
         t.join()
     frames += sum(p[2] for p in plan)
-    for e in exts:
+    rig_frames = sum(e.combiner_counters()["rig_frames"] for e in exts)
+    rig_served = sum(e.combiner_counters()["rig_served"] for e in exts)
+    for e in exts + rights:
         e.close()
+    print(f"[rigs: {rig_frames} frames as one submission, {rig_served} associations answered from them] ", end="")
     print(f"round {rd + 1}: {K} threads, {frames} calls so far, {len(bad)} mismatches, {time.time() - t0:.0f} s", flush=True)
 print(f"done: {rounds} rounds, {frames} calls, {len(bad)} mismatches", bad[:5])
 sys.exit(1 if bad else 0)

@@ -37,6 +37,28 @@ for it in range(cases):
         os.environ["GFO_STEREO_CR"] = str(int(rng.choice([64, 128, 1024])))     # staging too small (read in place) / ample
     else:
         os.environ.pop("GFO_STEREO_CR", None)
+    if rng.random() < 0.25 and w * h < 400 * 300:
+        # a batch of P pairs (P >= 8: all row bands of a pair on one XCD, the last group of eight partly empty when P is not a
+        # multiple of 8): every pair against the oracle
+        P = int(rng.choice([8, 9, 13, 16, 19]))
+        pairs = [synth_stereo_pair(w, h, int(rng.integers(0, 1 << 20))) for _ in range(P)]
+        extb = G.ORBextractor(nf, 1.2, 8, 20, 7, max_batch=2 * P)
+        mb = G.ORBmatcher(0.8, True, extractor=extb)
+        kps, descs = extb.extract_batch([im for pr in pairs for im in pr])
+        prm = G.StereoParams(h, bf, bf / fx, min_x)
+        mb.stereo_match_batch(prm)
+        sfb = extb.GetScaleFactors()
+        for q in range(P):
+            kl, dl, kr, dr = kps[2 * q], descs[2 * q], kps[2 * q + 1], descs[2 * q + 1]
+            ref = O.stereo_match(kl, dl, kr, dr, sfb, prm.n_rows, prm.mbf, prm.mb, prm.min_x)
+            got = mb.stereo_fetch(q, max(len(kl), 1))
+            tot_kp += len(kl)
+            tot_m += int(ref[0])
+            if not (got[0] == ref[0] and all(a[:len(kl)].tobytes() == b.tobytes() for a, b in zip(got[1:], ref[1:]))):
+                bad += 1
+                print(f"MISMATCH case {it} (batch of {P}, pair {q}): {w}x{h} nf={nf} form={form}", flush=True)
+        extb.close()
+        continue
     ext = G.ORBextractor(nf, 1.2, 8, 20, 7, max_batch=2)
     m = G.ORBmatcher(0.8, True, extractor=ext)
     (kl, kr), (dl, dr) = ext.extract_batch([l, r])
