@@ -114,6 +114,8 @@ struct GfoPair {
     std::vector<float> ur, dp;
     std::vector<int32_t> bd, bi;
     long speculated = 0, served = 0, solo = 0;
+    int solo_streak = 0;      // frames in a row whose partner did not show up: after three the rig sleeps (no more waiting) until it is
+    bool dormant = false;     // declared again -- which the adapter does at every ComputeStereoMatches, i.e. as soon as stereo frames are back
     ~GfoPair()
     {
         if (h_pair) {
@@ -461,6 +463,8 @@ extern "C" int gfo_ctx_pair(gfo_ctx* left, gfo_ctx* right, const gfo_stereo_para
                 P->sp = *p;
                 P->valid = false;
             }
+            P->dormant = false;
+            P->solo_streak = 0;
             return GFO_OK;
         }
     }
@@ -500,7 +504,7 @@ int gfo_pair_extract(gfo_ctx* c, const uint8_t* img, int w, int h, int stride, g
     GfoPair::Req& me = P->req[side];
     GfoPair::Req& other = P->req[side ^ 1];
     gfo_ctx* partner = P->ctx[side ^ 1];
-    if (!partner || !partner->combining || me.arrived || P->state >= 2) return GFO_COMBINE_DIRECT;
+    if (!partner || !partner->combining || me.arrived || P->state >= 2 || P->dormant) return GFO_COMBINE_DIRECT;
     if (P->sp.n_rows < 1 || P->sp.n_rows > h + 64) return GFO_COMBINE_DIRECT;      // an association no arena of this size is planned for: no speculation
     if (other.arrived && (other.w != w || other.h != h)) return GFO_COMBINE_DIRECT;
     const size_t img_bytes = (size_t)w * h;
@@ -554,6 +558,7 @@ int gfo_pair_extract(gfo_ctx* c, const uint8_t* img, int w, int h, int stride, g
                 P->state = 0;
                 P->valid = false;
                 P->solo++;
+                if (++P->solo_streak >= 3) P->dormant = true;      // this extractor is being used on its own: stop waiting for a partner
                 return GFO_COMBINE_DIRECT;
             }
         }
@@ -620,6 +625,7 @@ int gfo_pair_extract(gfo_ctx* c, const uint8_t* img, int w, int h, int stride, g
         P->nm = nm;
         P->valid = got_mine == 1 && got_other == 1;
         P->speculated++;
+        P->solo_streak = 0;
         me.arrived = me.staged = false;
         other.arrived = other.staged = false;
         P->state = 0;

@@ -390,7 +390,8 @@ int gfo_profile_read(gfo_ctx* ctx, gfo_stage_time* out, int cap, int* nstages, i
  * computes the frame's association; a gfo_stereo_match on `left` that passes, bit for bit, the keypoints and descriptors those two
  * calls returned, the same `p`, the context's own scale factors and no disparity windows is then answered from that result without
  * touching the device (the arrays are compared in full: rectified input, where the reference's mvKeysUn equals mvKeys, qualifies;
- * anything else is computed as before).  A side whose partner does not call within GFO_PAIR_WAIT_US (2000) extracts alone.
+ * anything else is computed as before).  A side whose partner does not call within GFO_PAIR_WAIT_US (2000) extracts alone; after
+ * three such frames in a row the rig stops waiting altogether until it is declared again (the extractor is being used on its own).
  * Both contexts need equal extractor parameters and one device.  right == NULL or p == NULL dissolves the rig; destroying either
  * context does too.  The adapter declares the rig from Frame::ComputeStereoMatches_Undistorted (adapter/matchers_gfo.cc). */
 int gfo_ctx_pair(gfo_ctx* left, gfo_ctx* right, const gfo_stereo_params* p);

@@ -318,6 +318,19 @@ def test_declared_stereo_rig_extracts_as_one_submission_and_answers_the_associat
     assert el.combiner_counters()["rig_alone"] == 1
     got = m.ComputeStereoMatches(kl, dl, kr, dr, sf, prm)      # the stored frame is gone: computed
     assert el.combiner_counters()["rig_served"] == served + 1 and got[0] == oracle.stereo_match(kl, dl, kr, dr, sf, prm.n_rows, prm.mbf, prm.mb, prm.min_x)[0]
+    # the left extractor used on its own for a while: after three frames the rig stops waiting for a partner (no 2-ms stalls), and
+    # the next declaration -- the adapter's, at the next stereo frame's association -- wakes it
+    import time
+    for _ in range(3):          # (the one-image frame above was the first of the streak: two more waits, then the rig sleeps)
+        el(frames[1][0])
+    assert el.combiner_counters()["rig_alone"] == 3
+    t0 = time.perf_counter()
+    for _ in range(5):
+        el(frames[1][0])
+    assert el.combiner_counters()["rig_alone"] == 3 and (time.perf_counter() - t0) / 5 < 0.0015      # asleep: nobody waited
+    el.pair_with(er, prm)
+    check_frame(2)
+    assert el.combiner_counters()["rig_frames"] == 16
     # dissolved: the plain pattern
     el.pair_with(None, None)
     check_frame(3)

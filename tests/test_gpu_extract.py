@@ -94,6 +94,39 @@ def test_two_contexts_from_two_threads(oracle, euroc_l, euroc_r):
     assert not errors, errors
 
 
+def test_kernels_are_resolved_before_any_thread_launches_and_eight_first_frames_at_once():
+    """gfo_ctx_create resolves every kernel of the library once per device under a mutex (gfo_kernels_preloaded), so that threads
+    issuing their FIRST frames at the same moment never race through the runtime's lazy code-object loading (round 3: eight threads,
+    first k_pack_results launch, an abort under rocprofv3 -- profiles/boundary_trace_r04.txt).  In a FRESH process (this one has
+    launched everything long ago): the count is complete after the first context and does not move with use; then the C harness'
+    own scenario, eight threads x gfo_extract_stereo from a cold start, combiner off, checksums equal."""
+    import os
+    import shutil
+    import subprocess
+    import sys
+    from conftest import ROOT
+    code = ("import sys; sys.path.insert(0, %r)\nimport numpy as np\nimport gf_orb_slam2_amd as G\n"
+            "L = G.load_library()\nassert L.gfo_kernels_preloaded() == 0\n"
+            "e = G.ORBextractor(500, 1.2, 8, 20, 7)\nn = L.gfo_kernels_preloaded()\nassert n >= 30, n\n"
+            "e2 = G.ORBextractor(700, 1.2, 8, 20, 7)\nassert L.gfo_kernels_preloaded() == n\n"
+            "im = np.random.default_rng(0).integers(0, 256, (240, 320), dtype=np.uint8)\nk, d = e(im); k2, d2 = e2(im)\n"
+            "assert L.gfo_kernels_preloaded() == n and len(k) > 0\nprint('PRELOADED', n)\n") % ROOT
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=ROOT, timeout=170)
+    assert r.returncode == 0 and "PRELOADED" in r.stdout, r.stdout[-1000:] + r.stderr[-3000:]
+    cc = shutil.which("gcc") or shutil.which("cc")
+    if cc is None:
+        pytest.skip("no C compiler for the harness")
+    exe = "/tmp/gfo_bt_first_frames"
+    subprocess.run([cc, "-O2", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tools", "c", "boundary_throughput.c"), "-o", exe,
+                    "-ldl", "-lpthread", "-lm"], check=True, capture_output=True, timeout=120)
+    import json
+    from gf_orb_slam2_amd._lib import lib_path
+    r = subprocess.run([exe, lib_path(), os.path.join(ROOT, "tests", "golden"), "0.3", "stereo", "8", "0"], capture_output=True, text=True, timeout=170)
+    assert r.returncode == 0, r.stderr[-3000:]
+    p = json.loads(r.stdout)["points"][0]
+    assert p["streams"] == 8 and p["errors"] == 0 and p["result_mismatches"] == 0 and p["stereo_frames"] > 100, p
+
+
 def test_two_threads_replanning_against_each_other(oracle):
     """The reference runs its left and right extractor on two host threads (Frame.cc:84-87): one thread may be planning
     an arena (hipMalloc / hipMemcpy) while the other is mid-pipeline.  Both alternate between two image sizes here, so
