@@ -97,41 +97,6 @@ __device__ int2 qt_scan2(int* a, int* b2, int n, int* part)
     return make_int2((int)(total & 0xFFFFu), (int)(total >> 16));
 }
 
-// The breadth pass's two per-node values -- children a split creates (nch) and "stays as it is" (single) -- computed in the scan's
-// own first sweep instead of a pass of their own (one barrier less per pass): a thread sweeps the same chunk in both halves of the
-// scan, so what it stashes in a[] in the first half it finds there in the second.  Packed scan (totals < 2^16: the caller checks).
-__device__ int2 qt_scan2_nodes(const int* cnt, const int* cc, int* a, int* b2, int n, int* part)
-{
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int chunk = (n + QT_THREADS - 1) / QT_THREADS;
-    const int b = tid * chunk, e = min(b + chunk, n);
-    unsigned s = 0;
-    for (int i = b; i < e; i++) {
-        unsigned v = 1u << 16;                 // a node with one key: kept
-        if (cnt[i] > 1) v = (unsigned)((cc[4 * i] > 0) + (cc[4 * i + 1] > 0) + (cc[4 * i + 2] > 0) + (cc[4 * i + 3] > 0));
-        a[i] = (int)v;
-        s += v;
-    }
-    const unsigned incl = (unsigned)qt_wave_incl_scan((int)s);
-    if (lane == 63) part[wave] = (int)incl;
-    __syncthreads();
-    unsigned wbase = 0, total = 0;
-    for (int w = 0; w < QT_THREADS / 64; w++) {
-        const unsigned t = (unsigned)part[w];
-        if (w < wave) wbase += t;
-        total += t;
-    }
-    unsigned run = wbase + incl - s;
-    for (int i = b; i < e; i++) {
-        const unsigned v = (unsigned)a[i];
-        a[i] = (int)(run & 0xFFFFu);
-        b2[i] = (int)(run >> 16);
-        run += v;
-    }
-    __syncthreads();
-    return make_int2((int)(total & 0xFFFFu), (int)(total >> 16));
-}
-
 __device__ __forceinline__ int qt_quadrant(uint32_t key, QtBox b)
 {
     // ExtractorNode::DivideNode, ORBextractor.cc:483-484,515-525
