@@ -304,7 +304,7 @@ __global__ __launch_bounds__(256) void k_stereo_match(StereoArgs a)
 __global__ __launch_bounds__(SR_THREADS) void k_stereo_match_rows(StereoArgs a, int R, int cr, int xcd8, int npairs)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t sr_lds[];
-    uint4* r_rec = reinterpret_cast<uint4*>(sr_lds);    // {row band, octave << 16 | iR, x, -}: the three filters from ONE 16-byte read
+    uint4* r_rec = reinterpret_cast<uint4*>(sr_lds);    // {first row of the band, octave << 16 | iR, x, band height | 1 << (16 + octave)}: the three filters from ONE 16-byte read
     uint4* r_d0 = r_rec + cr;                           // descriptor halves apart: 16-byte reads of consecutive records, no bank conflicts
     uint4* r_d1 = r_d0 + cr;
     __shared__ float l_x[SR_CL], l_minD[SR_CL], l_maxD[SR_CL];
@@ -329,7 +329,12 @@ __global__ __launch_bounds__(SR_THREADS) void k_stereo_match_rows(StereoArgs a, 
     if (staged) {
         for (int t = tid; t < nR; t += SR_THREADS) {
             const long long j = so + jb0 + t;
-            r_rec[t] = make_uint4(a.sband[j], a.soi[j], __float_as_uint(a.sx[j]), 0u);
+            // the band as (first row, height) and the octave as a bit: "row inside the band" is one subtraction and one unsigned
+            // compare, "octave within one of the left keypoint's" one AND against the left keypoint's three-bit mask -- 5 vector
+            // operations per candidate where the (lo, hi) / octave-number form took 9; computed once per staged record, used by every
+            // left keypoint whose window holds it (round 4: 59 -> 55 us came from the XCD placement, 55 -> see DESIGN from this)
+            const unsigned band = a.sband[j], oi = a.soi[j];
+            r_rec[t] = make_uint4(band & 0xFFFFu, oi, __float_as_uint(a.sx[j]), ((band >> 16) - (band & 0xFFFFu)) | (0x10000u << (oi >> 16)));
             r_d0[t] = a.sdesc[2 * j];
             r_d1[t] = a.sdesc[2 * j + 1];
         }
@@ -364,6 +369,7 @@ __global__ __launch_bounds__(SR_THREADS) void k_stereo_match_rows(StereoArgs a, 
             const float uL = l_x[t], minD = l_minD[t], maxD = l_maxD[t];
             const float minU = uL - maxD, maxU = uL - minD;
             const uint4 a0 = l_d0[t], a1 = l_d1[t];
+            const unsigned octm = ((7u << octL) >> 1) << 16;      // octaves octL - 1 .. octL + 1 (:1250), in the upper half like the records' bit
             const int jb = s_rs[max(row - W, 0) - rlo] - jb0, je = s_rs[min(row + W + 1, nRows) - rlo] - jb0;
             unsigned best = ((unsigned)TH_HIGH << 16);  // bestDist = TH_HIGH, iR = 0: only dist < TH_HIGH replaces it
             float bx = 0.f;
@@ -377,13 +383,12 @@ __global__ __launch_bounds__(SR_THREADS) void k_stereo_match_rows(StereoArgs a, 
                     const int j1 = j0 + 32;
                     const bool in1 = j1 < je;
                     const uint4 rec0 = r_rec[j0], rec1 = r_rec[in1 ? j1 : j0];
-                    const bool band0 = !(row < (int)(rec0.x & 0xFFFF) || row > (int)(rec0.x >> 16));
-                    const bool band1 = in1 && !(row < (int)(rec1.x & 0xFFFF) || row > (int)(rec1.x >> 16));
+                    const bool band0 = (unsigned)(row - (int)rec0.x) <= (rec0.w & 0xFFFFu);
+                    const bool band1 = in1 && (unsigned)(row - (int)rec1.x) <= (rec1.w & 0xFFFFu);
                     any = any || band0 || band1;
-                    const int oct0 = (int)(rec0.y >> 16), oct1 = (int)(rec1.y >> 16);
                     const float rx0 = __uint_as_float(rec0.z), rx1 = __uint_as_float(rec1.z);
-                    const bool pass0 = band0 && !(oct0 < octL - 1 || oct0 > octL + 1) && rx0 >= minU && rx0 <= maxU;   // :1250, :1255
-                    const bool pass1 = band1 && !(oct1 < octL - 1 || oct1 > octL + 1) && rx1 >= minU && rx1 <= maxU;
+                    const bool pass0 = band0 && (rec0.w & octm) != 0 && rx0 >= minU && rx0 <= maxU;   // :1250, :1255
+                    const bool pass1 = band1 && (rec1.w & octm) != 0 && rx1 >= minU && rx1 <= maxU;
                     if (pass0) {
                         const unsigned key = ((unsigned)hamming256(a0, a1, r_d0[j0], r_d1[j0]) << 16) | (rec0.y & 0xFFFF);
                         if (key < best) { best = key; bx = rx0; }            // first minimum in iR order (:1260)
