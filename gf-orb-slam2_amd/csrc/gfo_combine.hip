@@ -588,6 +588,8 @@ int gfo_pair_extract(gfo_ctx* c, const uint8_t* img, int w, int h, int stride, g
     // executor: both images are (about to be) staged; ONE stereo request for the frame
     while (!other.staged) P->cv.wait(lk);
     const gfo_stereo_params sp = P->sp;
+    P->valid = false;      // the stored frame is about to be overwritten (both sides write their halves without the lock): a
+                           // gfo_stereo_match of another thread that is still asking about the previous frame computes its answer
     lk.unlock();
     std::shared_ptr<GfoEngine> eh = engine_for(c, w, h);
     const uint8_t* imgs[2] = {P->h_pair, P->h_pair + img_bytes};
