@@ -192,13 +192,20 @@ int slot_prepare(GfoEngine* e, Slot& s, gfo_ctx* c)
 }
 }  // namespace
 
-void gfo_engine_release(gfo_ctx* c) { c->engine.reset(); }
+void gfo_engine_release(gfo_ctx* c)
+{
+    if (std::shared_ptr<GfoEngine> e = c->engine) {
+        std::lock_guard<std::mutex> lk(e->mu);
+        if (e->members > 0) e->members--;      // (a pair of extractors that is deleted and re-created -- Tracking::updateORBExtractor -- stays "one camera")
+    }
+    c->engine.reset();
+}
 
 extern "C" int gfo_ctx_set_combining(gfo_ctx* c, int on)
 {
     if (!c) return GFO_ERR_INVALID;
     c->combining = on != 0;
-    if (!on) c->engine.reset();
+    if (!on) gfo_engine_release(c);
     return GFO_OK;
 }
 
