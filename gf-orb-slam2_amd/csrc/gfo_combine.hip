@@ -23,6 +23,7 @@
 // (tests/test_gpu_combine.py, and the checksums of tools/c/boundary_throughput.c under load).
 #include "gfo_internal.h"
 
+#include <atomic>
 #include <chrono>
 #include <condition_variable>
 #include <map>
@@ -30,6 +31,13 @@
 #include <mutex>
 #include <string.h>
 #include <tuple>
+
+// a polite spin-wait step of the host CPU (this file is also parsed for the device, where the x86 builtin does not exist)
+#if defined(__HIP_DEVICE_COMPILE__) || !(defined(__x86_64__) || defined(__i386__))
+#define GFO_CPU_RELAX() ((void)0)
+#else
+#define GFO_CPU_RELAX() __builtin_ia32_pause()
+#endif
 
 namespace
 {
@@ -101,6 +109,8 @@ struct GfoPair {
     int state = 0;            // 0 idle, 1 one side waits for its partner, 2 the second arrival is executing the frame, 4 the batch is
                               // complete: the waiting side copies its arrays out of the result block (pick_*), 3 the batch failed:
                               // the waiting side takes its status
+    std::atomic<int> state_seen{0};   // mirror of `state` for the waiting side's short spin (below): written under mu, read without
+    bool spin_ok = false;     // one camera on this engine: the waiting side may spin for the result instead of sleeping
     gfo_ctx* pick_bc = nullptr;
     const GfoSmallLayout* pick_L = nullptr;
     int pick_image = 0, picked = -1;
@@ -534,6 +544,7 @@ int gfo_pair_extract(gfo_ctx* c, const uint8_t* img, int w, int h, int stride, g
     me.arrived = true; me.staged = false;
     const bool first = !other.arrived;
     P->state = first ? 1 : 2;            // the second arrival executes the frame for both
+    P->state_seen.store(P->state, std::memory_order_release);
     P->cv.notify_all();
     lk.unlock();
 
@@ -570,7 +581,23 @@ int gfo_pair_extract(gfo_ctx* c, const uint8_t* img, int w, int h, int stride, g
             }
         }
         // the partner executes the frame; it calls this side to the result block as soon as the batch is complete (state 4), so
-        // that both sides copy their own arrays at the same time; a failed batch skips that (state 3)
+        // that both sides copy their own arrays at the same time; a failed batch skips that (state 3).
+        // One camera alone (the engine serves nobody else): this thread has nothing else to do for the ~0.17 ms the frame takes --
+        // in the reference it would be extracting the left image itself -- and a sleeping thread's wake-up costs 5-15 us of the
+        // frame's latency: it watches the state for up to GFO_PAIR_SPIN_US (400) before it goes to sleep on the condition
+        // variable.  With several cameras the waiting sides sleep at once (their cores belong to the other cameras' threads).
+        if (P->spin_ok) {
+            static const long spin_us = getenv("GFO_PAIR_SPIN_US") ? atol(getenv("GFO_PAIR_SPIN_US")) : 400;
+            lk.unlock();
+            const auto until = std::chrono::steady_clock::now() + std::chrono::microseconds(spin_us);
+            for (int it = 0;; it++) {
+                const int st = P->state_seen.load(std::memory_order_acquire);
+                if (st == 3 || st == 4) break;
+                GFO_CPU_RELAX();
+                if ((it & 63) == 63 && std::chrono::steady_clock::now() >= until) break;
+            }
+            lk.lock();
+        }
         while (P->state != 3 && P->state != 4) P->cv.wait(lk);
         if (P->state == 4) {
             gfo_ctx* bc = P->pick_bc;
@@ -599,6 +626,15 @@ int gfo_pair_extract(gfo_ctx* c, const uint8_t* img, int w, int h, int stride, g
                            // gfo_stereo_match of another thread that is still asking about the previous frame computes its answer
     lk.unlock();
     std::shared_ptr<GfoEngine> eh = engine_for(c, w, h);
+    bool alone_on_engine;
+    {
+        std::lock_guard<std::mutex> g(eh->mu);
+        alone_on_engine = eh->members <= 2;
+    }
+    {
+        std::lock_guard<std::mutex> g(P->mu);
+        P->spin_ok = alone_on_engine;
+    }
     const uint8_t* imgs[2] = {P->h_pair, P->h_pair + img_bytes};
     int cnt_mine = 0, nm = 0, got_mine = 0, got_other = 0, cnt_other = 0, dummy = 0;
     const int rc = run_request(
@@ -610,6 +646,7 @@ int gfo_pair_extract(gfo_ctx* c, const uint8_t* img, int w, int h, int stride, g
                 std::lock_guard<std::mutex> g(P->mu);
                 P->pick_bc = s.bc; P->pick_L = &s.L; P->pick_image = idx * 2; P->picked = -1;
                 P->state = 4;
+                P->state_seen.store(4, std::memory_order_release);
                 P->cv.notify_all();
             }
             got_mine = take_mine(s.bc, s.L, idx * 2 + side, &cnt_mine);
@@ -645,6 +682,7 @@ int gfo_pair_extract(gfo_ctx* c, const uint8_t* img, int w, int h, int stride, g
         P->valid = false;
         me.arrived = me.staged = false;
         P->state = 3;          // the waiter takes its status and resets the rendezvous
+        P->state_seen.store(3, std::memory_order_release);
     }
     P->cv.notify_all();
     return my_rc;
