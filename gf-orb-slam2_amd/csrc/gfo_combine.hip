@@ -125,7 +125,10 @@ struct GfoPair {
     std::vector<int32_t> bd, bi;
     long speculated = 0, served = 0, solo = 0;
     int solo_streak = 0;      // frames in a row whose partner did not show up: after three the rig sleeps (no more waiting) until it is
-    bool dormant = false;     // declared again -- which the adapter does at every ComputeStereoMatches, i.e. as soon as stereo frames are back
+    bool dormant = false;     // declared again -- which the adapter does at every ComputeStereoMatches, i.e. as soon as stereo frames are back.
+    int wake_need = 1, wake_target = 1, wake_count = 0;   // A caller that extracts left and right on ONE thread declares the rig every frame
+                              // and never meets its partner: every time the rig falls asleep again without a frame in between that
+                              // did pair, it takes twice as many declarations to wake it (1, 2, 4 ... 1024), so the 2-ms waits die out
     ~GfoPair()
     {
         if (h_pair) {
@@ -480,8 +483,10 @@ extern "C" int gfo_ctx_pair(gfo_ctx* left, gfo_ctx* right, const gfo_stereo_para
                 P->sp = *p;
                 P->valid = false;
             }
-            P->dormant = false;
-            P->solo_streak = 0;
+            if (P->dormant && ++P->wake_count >= P->wake_target) {
+                P->dormant = false;
+                P->solo_streak = 0;
+            }
             return GFO_OK;
         }
     }
@@ -576,7 +581,12 @@ int gfo_pair_extract(gfo_ctx* c, const uint8_t* img, int w, int h, int stride, g
                 P->state = 0;
                 P->valid = false;
                 P->solo++;
-                if (++P->solo_streak >= 3) P->dormant = true;      // this extractor is being used on its own: stop waiting for a partner
+                if (++P->solo_streak >= 3 && !P->dormant) {      // this extractor is being used on its own: stop waiting for a partner
+                    P->dormant = true;
+                    P->wake_count = 0;
+                    P->wake_target = P->wake_need;
+                    P->wake_need = P->wake_need < 1024 ? 2 * P->wake_need : 1024;
+                }
                 return GFO_COMBINE_DIRECT;
             }
         }
@@ -672,6 +682,7 @@ int gfo_pair_extract(gfo_ctx* c, const uint8_t* img, int w, int h, int stride, g
         P->valid = got_mine == 1 && got_other == 1;
         P->speculated++;
         P->solo_streak = 0;
+        P->wake_need = 1;
         me.arrived = me.staged = false;
         other.arrived = other.staged = false;
         P->state = 0;

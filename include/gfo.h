@@ -391,7 +391,9 @@ int gfo_profile_read(gfo_ctx* ctx, gfo_stage_time* out, int cap, int* nstages, i
  * calls returned, the same `p`, the context's own scale factors and no disparity windows is then answered from that result without
  * touching the device (the arrays are compared in full: rectified input, where the reference's mvKeysUn equals mvKeys, qualifies;
  * anything else is computed as before).  A side whose partner does not call within GFO_PAIR_WAIT_US (2000) extracts alone; after
- * three such frames in a row the rig stops waiting altogether until it is declared again (the extractor is being used on its own).
+ * three such frames in a row the rig stops waiting altogether until it is declared again (the extractor is being used on its own;
+ * a caller that keeps declaring a rig whose two sides never meet -- left and right extracted on one thread -- wakes it ever more
+ * rarely: 1, 2, 4 ... 1024 declarations).
  * Both contexts need equal extractor parameters and one device.  right == NULL or p == NULL dissolves the rig; destroying either
  * context does too.  The adapter declares the rig from Frame::ComputeStereoMatches_Undistorted (adapter/matchers_gfo.cc). */
 int gfo_ctx_pair(gfo_ctx* left, gfo_ctx* right, const gfo_stereo_params* p);

@@ -331,6 +331,18 @@ def test_declared_stereo_rig_extracts_as_one_submission_and_answers_the_associat
     el.pair_with(er, prm)
     check_frame(2)
     assert el.combiner_counters()["rig_frames"] == 16
+    # left and right extracted on ONE thread, the rig declared at every frame (what a single-threaded caller of the adapter would do):
+    # the sides never meet; the waits die out -- three per dormancy, and every dormancy takes twice as many declarations to end
+    waits0 = el.combiner_counters()["rig_alone"]
+    t0 = time.perf_counter()
+    for _ in range(40):
+        el.pair_with(er, prm)
+        kl, dl = el(frames[0][0])
+        kr, dr = er(frames[0][1])
+        assert kl.tobytes() == refs[0][0][0].tobytes() and kr.tobytes() == refs[0][1][0].tobytes()
+    waits = el.combiner_counters()["rig_alone"] - waits0
+    assert waits <= 3 * 6, waits              # dormancies end after 1, 2, 4, 8, 16 declarations: at most 6 of them in 40 frames
+    el.pair_with(er, prm)
     # dissolved: the plain pattern
     el.pair_with(None, None)
     check_frame(3)
