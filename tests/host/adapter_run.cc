@@ -1,0 +1,439 @@
+// adapter_run.cc -- EXECUTES the drop-in adapters (gf-orb-slam2_amd/adapter/ORBextractor_gfo.cc, matchers_gfo.cc) on the GPU box,
+// through the reference's unchanged headers (include/ORBextractor.h, Frame.h, MapPoint.h, ORBmatcher.h), the way the reference's
+// own callers use them:
+//   A. Frame::Frame's pattern (src/Frame.cc:84-100): two ORBextractor objects, operator() on two threads, then
+//      Frame::ComputeStereoMatches_Undistorted -- 20 frames; from the second frame on the two calls meet in the library as one rig
+//      submission and the association is answered from it (gfo_combiner_counters);
+//   B. ORBextractor::ComputePyramid (Frame.cc:182-183) and the 19-px framed levels behind mvImagePyramid;
+//   C. delete + new at one address (Tracking::updateORBExtractor, src/Tracking.cc:298-320), an empty image (ORBextractor.cc:1115-1116),
+//      an image without a corner (:1133-1134);
+//   D. the disparity-window form of the stereo association (Frame.cc:1220-1231: frames that carry map points);
+//   E. ORBmatcher::SearchByProjection(Frame&, vector<MapPoint*>&, th) (ORBmatcher.cc:155-241);
+//   F. ORBmatcher::SearchByProjection(CurrentFrame, LastFrame, th, bMono, numVisible) (ORBmatcher.cc:1440-1593), including the
+//      host-side projection the adapter keeps (:1451-1502).
+// Inputs come from tests/test_gpu_adapter_run.py (which builds them from the oracle's keypoints), every result is written to
+// <out_dir> as raw arrays and compared THERE with the oracle, bit for bit.  This program only checks what needs no oracle
+// (sizes, untouched outputs, context counts) and exits non-zero when one of those fails.
+// Built by __graft_entry__.build() with g++ where the reference headers exist; cv::Mat is tests/cv_standin (a container, no OpenCV
+// arithmetic), the handful of out-of-line reference members the link needs are tests/host/adapter_link_support.cc.
+#include "Frame.h"
+#include "MapPoint.h"
+#include "ORBmatcher.h"
+#include "ORBextractor.h"
+
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "gfo.h"
+
+namespace ORB_SLAM2
+{
+gfo_ctx* gfo_context_pin(const ORBextractor* e);   // adapter/ORBextractor_gfo.cc
+void gfo_context_unpin(const ORBextractor* e, gfo_ctx* c);
+}
+
+using namespace ORB_SLAM2;
+
+static std::string g_in, g_out;
+static int g_fail = 0;
+static FILE* g_rep = NULL;
+
+#define CHECK(cond, ...)                                                        \
+    do {                                                                        \
+        if (!(cond)) {                                                          \
+            fprintf(stderr, "[adapter_run] CHECK FAILED %s:%d: ", __FILE__, __LINE__); \
+            fprintf(stderr, __VA_ARGS__);                                       \
+            fprintf(stderr, "\n");                                              \
+            g_fail++;                                                           \
+        }                                                                       \
+    } while (0)
+
+static void report(const char* key, long long v) { fprintf(g_rep, "%s %lld\n", key, v); fflush(g_rep); }
+
+static void dump(const std::string& name, const void* p, size_t bytes)
+{
+    FILE* f = fopen((g_out + "/" + name).c_str(), "wb");
+    if (!f) { fprintf(stderr, "[adapter_run] cannot write %s\n", name.c_str()); exit(3); }
+    if (bytes) fwrite(p, 1, bytes, f);
+    fclose(f);
+}
+
+static std::vector<uint8_t> slurp(const std::string& path, bool must = true)
+{
+    std::vector<uint8_t> v;
+    FILE* f = fopen(path.c_str(), "rb");
+    if (!f) {
+        if (must) { fprintf(stderr, "[adapter_run] cannot read %s\n", path.c_str()); exit(3); }
+        return v;
+    }
+    fseek(f, 0, SEEK_END);
+    long n = ftell(f);
+    fseek(f, 0, SEEK_SET);
+    v.resize((size_t)n);
+    if (n && fread(v.data(), 1, (size_t)n, f) != (size_t)n) exit(3);
+    fclose(f);
+    return v;
+}
+
+static std::string tag(const char* base, int f, const char* what)
+{
+    char b[96];
+    snprintf(b, sizeof b, "%s_f%02d_%s.bin", base, f, what);
+    return b;
+}
+
+static void dump_desc(const std::string& name, const cv::Mat& d)
+{
+    std::vector<uint8_t> flat((size_t)d.rows * 32);
+    for (int i = 0; i < d.rows; i++) memcpy(&flat[(size_t)i * 32], d.ptr<uint8_t>(i), 32);
+    dump(name, flat.data(), flat.size());
+}
+
+// frame f of the stream = the EuRoC image rotated left by 3 f columns (the Python side makes the same frames)
+static cv::Mat roll(const cv::Mat& src, int shift, int pad)
+{
+    cv::Mat whole(src.rows, src.cols + pad, CV_8UC1, cv::Scalar(0x5a));
+    cv::Mat dst = pad ? whole(cv::Rect(pad / 2, 0, src.cols, src.rows)) : whole;     // pad > 0: a view with step != cols
+    for (int y = 0; y < src.rows; y++)
+        for (int x = 0; x < src.cols; x++) dst.at<uint8_t>(y, x) = src.at<uint8_t>(y, (x + shift) % src.cols);
+    return dst;
+}
+
+struct TestMP : public MapPoint {   // MapPoint() is the header's own "for unit test only" constructor (include/MapPoint.h:57)
+    TestMP()
+    {
+        nObs = 0; mbBad = false; mbTrackInView = false; mTrackProjX = mTrackProjY = mTrackProjXR = 0.f;
+        mnTrackScaleLevel = 0; mTrackViewCos = 1.f; mpReplaced = NULL; mpRefKF = NULL; mpMap = NULL;
+    }
+    void world(const float* p)
+    {
+        mWorldPos = cv::Mat(3, 1, CV_32F);
+        for (int i = 0; i < 3; i++) mWorldPos.at<float>(i) = p[i];
+    }
+    void descriptor(const uint8_t* d)
+    {
+        mDescriptor = cv::Mat(1, 32, CV_8U);
+        memcpy(mDescriptor.data, d, 32);
+    }
+    void bad(bool b) { mbBad = b; }
+};
+
+static const float MBF = 47.906f, MB = 47.906f / 435.2f;
+
+static void fill_frame(Frame& F, ORBextractor* L, ORBextractor* R, const std::vector<cv::KeyPoint>& kl, const cv::Mat& dl,
+                       const std::vector<cv::KeyPoint>& kr, const cv::Mat& dr)
+{
+    F.mpORBextractorLeft = L;
+    F.mpORBextractorRight = R;
+    F.mpORBvocabulary = NULL;
+    F.N = (int)kl.size();
+    F.mvKeys = kl; F.mvKeysUn = kl;            // rectified input: the undistorted keypoints ARE the keypoints (Frame.cc, stereo case)
+    F.mvKeysRight = kr; F.mvKeysRightUn = kr;
+    F.mDescriptors = dl; F.mDescriptorsRight = dr;
+    F.mvScaleFactors = L->GetScaleFactors();
+    F.mvInvScaleFactors = L->GetInverseScaleFactors();
+    F.mnScaleLevels = L->GetLevels();
+    F.mbf = MBF; F.mb = MB;
+    F.mvpMapPoints.assign(F.N, static_cast<MapPoint*>(NULL));
+    F.mvpMatchScore.assign(F.N, 0);
+    F.mvbOutlier.assign(F.N, false);
+    F.mpReferenceKF = NULL;
+}
+
+static void dump_stereo(const char* base, int f, Frame& F, int ns)
+{
+    dump(tag(base, f, "uright"), F.mvuRight.data(), F.mvuRight.size() * 4);
+    dump(tag(base, f, "depth"), F.mvDepth.data(), F.mvDepth.size() * 4);
+    std::vector<int32_t> di;
+    for (size_t i = 0; i < F.mvDistIdx.size(); i++) { di.push_back(F.mvDistIdx[i].first); di.push_back(F.mvDistIdx[i].second); }
+    dump(tag(base, f, "distidx"), di.data(), di.size() * 4);
+    int32_t n = ns;
+    dump(tag(base, f, "nstereo"), &n, 4);
+}
+
+static cv::Mat mat4(const float* p)
+{
+    cv::Mat T(4, 4, CV_32F);
+    for (int i = 0; i < 4; i++) for (int j = 0; j < 4; j++) T.at<float>(i, j) = p[i * 4 + j];
+    return T;
+}
+
+int main(int argc, char** argv)
+{
+    if (argc < 4) { fprintf(stderr, "usage: adapter_run <golden_dir> <in_dir> <out_dir> [frames]\n"); return 2; }
+    const std::string gold = argv[1];
+    g_in = argv[2];
+    g_out = argv[3];
+    const int NF = argc > 4 ? atoi(argv[4]) : 20;
+    g_rep = fopen((g_out + "/report.txt").c_str(), "w");
+    if (!g_rep) return 3;
+    const int W = 752, H = 480;
+    std::vector<uint8_t> rawl = slurp(gold + "/EuRoC_l_752x480.u8"), rawr = slurp(gold + "/EuRoC_r_752x480.u8");
+    CHECK(rawl.size() == (size_t)W * H && rawr.size() == (size_t)W * H, "golden images have the wrong size");
+    cv::Mat imL(H, W, CV_8UC1, rawl.data()), imR(H, W, CV_8UC1, rawr.data());
+    Frame::mnMinX = 0.f; Frame::mnMinY = 0.f; Frame::mnMaxX = (float)W; Frame::mnMaxY = (float)H;
+
+    // ------------------------------------------------------------------------------------------------------------------
+    // A. the Frame constructor's pattern, NF frames
+    // gfo_contexts_created counts every gfo_ctx_create of the process: one per extractor (the adapter's constructor creates it to
+    // read the tables) plus the batch slots the frame combiner's engine prepares on the first frames -- and nothing afterwards
+    const uint64_t created_before = gfo_contexts_created();
+    ORBextractor* L = new ORBextractor(2000, 1.2f, 8, 20, 7);
+    ORBextractor* R = new ORBextractor(2000, 1.2f, 8, 20, 7);
+    CHECK(gfo_contexts_created() - created_before == 2, "two extractors own two contexts, %llu were created", (unsigned long long)(gfo_contexts_created() - created_before));
+    CHECK(L->GetLevels() == 8 && L->GetScaleFactors().size() == 8, "getters");
+    {
+        std::vector<float> t = L->GetScaleFactors(), u = L->GetInverseScaleFactors(), v = L->GetScaleSigmaSquares(), w = L->GetInverseScaleSigmaSquares();
+        t.insert(t.end(), u.begin(), u.end()); t.insert(t.end(), v.begin(), v.end()); t.insert(t.end(), w.begin(), w.end());
+        dump("A_tables.bin", t.data(), t.size() * 4);
+    }
+    uint64_t created_mid = 0;
+    std::vector<Frame*> kept;
+    for (int f = 0; f < NF; f++) {
+        if (f == NF / 2) created_mid = gfo_contexts_created();
+        const cv::Mat fl = roll(imL, 3 * f, f == NF - 1 ? 48 : 0), fr = roll(imR, 3 * f, f == NF - 1 ? 48 : 0);
+        std::vector<cv::KeyPoint> kl, kr;
+        cv::Mat dl, dr;
+        std::thread tl([&] { (*L)(fl, cv::Mat(), kl, dl); });          // Frame.cc:84-87
+        std::thread tr([&] { (*R)(fr, cv::Mat(), kr, dr); });
+        tl.join();
+        tr.join();
+        CHECK(dl.rows == (int)kl.size() && dr.rows == (int)kr.size() && dl.cols == 32, "descriptor rows %d / keypoints %zu", dl.rows, kl.size());
+        CHECK(L->mvImagePyramid.size() == 8 && L->mvImagePyramid[0].rows == H && L->mvImagePyramid[0].cols == W, "mvImagePyramid[0] %d x %d",
+              L->mvImagePyramid[0].cols, L->mvImagePyramid[0].rows);
+        CHECK(R->mvImagePyramid[0].rows == H, "right mvImagePyramid[0].rows");
+        dump(tag("A", f, "kl"), kl.data(), kl.size() * sizeof(cv::KeyPoint));
+        dump(tag("A", f, "kr"), kr.data(), kr.size() * sizeof(cv::KeyPoint));
+        dump_desc(tag("A", f, "dl"), dl);
+        dump_desc(tag("A", f, "dr"), dr);
+        Frame* F = new Frame();
+        fill_frame(*F, L, R, kl, dl, kr, dr);
+        const int ns = F->ComputeStereoMatches_Undistorted(false);     // Frame.cc:100
+        dump_stereo("A", f, *F, ns);
+        if (f < 3) kept.push_back(F); else delete F;
+    }
+    {
+        std::vector<int32_t> sz;
+        for (int l = 0; l < 8; l++) { sz.push_back(L->mvImagePyramid[l].cols); sz.push_back(L->mvImagePyramid[l].rows); }
+        dump("A_level_sizes.bin", sz.data(), sz.size() * 4);
+    }
+    report("contexts_created_by_two_extractors_and_their_engine", (long long)(gfo_contexts_created() - created_before));
+    report("contexts_created_in_steady_state", (long long)(gfo_contexts_created() - created_mid));
+    CHECK(gfo_contexts_created() == created_mid, "the second half of the stream created %llu contexts", (unsigned long long)(gfo_contexts_created() - created_mid));
+    {
+        gfo_ctx* c = gfo_context_pin(L);
+        int64_t cnt[8] = {0};
+        CHECK(c && gfo_combiner_counters(c, cnt, 8) == GFO_OK, "combiner counters");
+        gfo_context_unpin(L, c);
+        const char* names[8] = {"batches", "requests", "redone", "slots", "broken", "rig_frames", "rig_answers", "rig_solo"};
+        for (int i = 0; i < 8; i++) report((std::string("combiner_") + names[i]).c_str(), cnt[i]);
+    }
+
+    // ------------------------------------------------------------------------------------------------------------------
+    // B. ComputePyramid: the levels as views into their 19-px framed buffers (ORBextractor.cc:1182-1197)
+    {
+        L->ComputePyramid(imL);
+        for (int l = 0; l < 8; l++) {
+            const cv::Mat& m = L->mvImagePyramid[l];
+            CHECK(!m.empty() && m.step == (size_t)m.cols + 38, "level %d is not a view into a framed buffer (step %zu, cols %d)", l, m.step, m.cols);
+            if (m.empty()) continue;
+            const uint8_t* whole = m.data - 19 * m.step - 19;
+            char nm[64];
+            snprintf(nm, sizeof nm, "B_level%d_framed_%dx%d.bin", l, m.cols + 38, m.rows + 38);
+            dump(nm, whole, (size_t)(m.rows + 38) * m.step);
+        }
+        // operator() afterwards still works on the same object and publishes sized headers again
+        std::vector<cv::KeyPoint> k;
+        cv::Mat d;
+        (*L)(imL, cv::Mat(), k, d);
+        dump("B_after_kl.bin", k.data(), k.size() * sizeof(cv::KeyPoint));
+        dump_desc("B_after_dl.bin", d);
+        CHECK(L->mvImagePyramid[0].rows == H, "mvImagePyramid[0].rows after ComputePyramid + operator()");
+    }
+
+    // ------------------------------------------------------------------------------------------------------------------
+    // C. an extractor re-created at the address of a deleted one (Tracking.cc:298-320); empty image; image without a corner
+    {
+        alignas(ORBextractor) static unsigned char slot[sizeof(ORBextractor)];
+        const uint64_t c0 = gfo_contexts_created();
+        ORBextractor* E = new (slot) ORBextractor(1000, 1.2f, 8, 20, 7);
+        CHECK(gfo_contexts_created() - c0 == 1, "the constructor creates one context");
+        std::vector<cv::KeyPoint> k;
+        cv::Mat d;
+        (*E)(imL, cv::Mat(), k, d);
+        dump("C_first_kl.bin", k.data(), k.size() * sizeof(cv::KeyPoint));
+        dump_desc("C_first_dl.bin", d);
+        E->~ORBextractor();
+        const uint64_t c1 = gfo_contexts_created();
+        E = new (slot) ORBextractor(1500, 1.2f, 8, 12, 5);             // other parameters at the same address
+        report("contexts_created_by_reconstruction", (long long)(gfo_contexts_created() - c1));
+        CHECK(gfo_contexts_created() - c1 == 1, "re-construction at one address creates exactly one new context (%llu)", (unsigned long long)(gfo_contexts_created() - c1));
+        (*E)(imR, cv::Mat(), k, d);                                    // (new parameters: the combiner prepares an engine for them)
+        const uint64_t c2 = gfo_contexts_created();
+        (*E)(imR, cv::Mat(), k, d);
+        CHECK(gfo_contexts_created() == c2, "the second frame of the re-constructed extractor created a context");
+        dump("C_second_kl.bin", k.data(), k.size() * sizeof(cv::KeyPoint));
+        dump_desc("C_second_dl.bin", d);
+        {
+            std::vector<float> t = E->GetScaleFactors();
+            CHECK(t.size() == 8 && t[1] == 1.2f, "tables of the re-constructed extractor");
+        }
+        // empty image: outputs untouched (ORBextractor.cc:1115-1116)
+        std::vector<cv::KeyPoint> k3(3, cv::KeyPoint(1.f, 2.f, 3.f));
+        cv::Mat d3(3, 32, CV_8U, cv::Scalar(0xab));
+        const uint8_t* before = d3.data;
+        (*E)(cv::Mat(), cv::Mat(), k3, d3);
+        bool same = k3.size() == 3 && d3.rows == 3 && d3.data == before && k3[2].pt.y == 2.f;
+        for (int i = 0; same && i < 96; i++) same = d3.data[i] == 0xab;
+        CHECK(same, "an empty image must leave the outputs untouched");
+        // no corner anywhere: zero keypoints, descriptors released (:1133-1134)
+        cv::Mat flat(H, W, CV_8UC1, cv::Scalar(128));
+        (*E)(flat, cv::Mat(), k3, d3);
+        CHECK(k3.empty() && d3.empty(), "a flat image: %zu keypoints, descriptors %s", k3.size(), d3.empty() ? "released" : "kept");
+        // and the extractor keeps working afterwards
+        (*E)(imL, cv::Mat(), k, d);
+        dump("C_third_kl.bin", k.data(), k.size() * sizeof(cv::KeyPoint));
+        dump_desc("C_third_dl.bin", d);
+        E->~ORBextractor();
+    }
+
+    // ------------------------------------------------------------------------------------------------------------------
+    // D. the association of a frame that carries map points: per-keypoint disparity windows (Frame.cc:1220-1231)
+    std::vector<TestMP*> owned;
+    if (kept.size() >= 3) {
+        Frame& F = *kept[2];
+        struct Rec { int32_t has, bad; float p[3]; };
+        std::vector<uint8_t> raw = slurp(g_in + "/D_windows.bin");
+        std::vector<uint8_t> pose = slurp(g_in + "/D_pose.bin");
+        const int n = (int)(raw.size() / sizeof(Rec));
+        CHECK(n == F.N && pose.size() == 64, "D: %d records for %d keypoints", n, F.N);
+        if (n == F.N && pose.size() == 64) {
+            const Rec* r = reinterpret_cast<const Rec*>(raw.data());
+            F.SetPose(mat4(reinterpret_cast<const float*>(pose.data())));
+            for (int i = 0; i < n; i++) {
+                if (!r[i].has) continue;
+                TestMP* mp = new TestMP();
+                mp->world(r[i].p);
+                mp->bad(r[i].bad != 0);
+                owned.push_back(mp);
+                F.mvpMapPoints[i] = mp;
+            }
+            const int ns = F.ComputeStereoMatches_Undistorted(false);
+            dump_stereo("D", 2, F, ns);
+        }
+    }
+
+    // ------------------------------------------------------------------------------------------------------------------
+    // E. SearchByProjection(F, local map, th) on frame 1 (ORBmatcher.cc:155-241)
+    if (kept.size() >= 2) {
+        Frame& F = *kept[1];
+        std::vector<uint8_t> raw = slurp(g_in + "/E_map.bin"), dsc = slurp(g_in + "/E_map_desc.bin"), tk = slurp(g_in + "/E_taken.bin");
+        const int M = (int)(raw.size() / sizeof(gfo_map_point));
+        CHECK((int)tk.size() == F.N && dsc.size() == (size_t)M * 32, "E: %zu slots for %d keypoints", tk.size(), F.N);
+        if ((int)tk.size() == F.N) {
+            const gfo_map_point* mp = reinterpret_cast<const gfo_map_point*>(raw.data());
+            std::vector<MapPoint*> map(M);
+            for (int i = 0; i < M; i++) {
+                TestMP* p = new TestMP();
+                p->mTrackProjX = mp[i].proj_x; p->mTrackProjY = mp[i].proj_y; p->mTrackProjXR = mp[i].proj_xr;
+                p->mTrackViewCos = mp[i].view_cos; p->mnTrackScaleLevel = mp[i].level;
+                p->mbTrackInView = (mp[i].flags & 1) != 0;
+                p->bad((mp[i].flags & 2) != 0);
+                p->nObs = (mp[i].flags & 4) ? 3 : 0;
+                p->descriptor(&dsc[(size_t)i * 32]);
+                owned.push_back(p);
+                map[i] = p;
+            }
+            for (int i = 0; i < F.N; i++) {
+                if (!tk[i]) continue;
+                TestMP* p = new TestMP();                  // a slot that already holds a map point: with (1) / without (2) observations
+                p->nObs = tk[i] == 1 ? 2 : 0;
+                owned.push_back(p);
+                F.mvpMapPoints[i] = p;
+            }
+            std::vector<MapPoint*> before = F.mvpMapPoints;
+            ORBmatcher matcher(0.8f);
+            const int nm = matcher.SearchByProjection(F, map, 3);
+            std::vector<int32_t> idx(F.N, -1);
+            for (int i = 0; i < F.N; i++) {
+                if (F.mvpMapPoints[i] == before[i]) continue;     // untouched slot
+                idx[i] = -3;
+                for (int j = 0; j < M; j++) if (map[j] == F.mvpMapPoints[i]) { idx[i] = j; break; }
+            }
+            dump("E_out_mp.bin", idx.data(), idx.size() * 4);
+            dump("E_out_score.bin", F.mvpMatchScore.data(), F.mvpMatchScore.size() * 4);
+            int32_t n32 = nm;
+            dump("E_nmatches.bin", &n32, 4);
+        }
+    }
+
+    // ------------------------------------------------------------------------------------------------------------------
+    // F. SearchByProjection(CurrentFrame = frame 1, LastFrame = frame 0, th, bMono = false, numVisible) (ORBmatcher.cc:1440-1593);
+    //    variants F0, F1, ... as long as the Python side provides inputs (neutral / forward / backward motion, orientation check off)
+    for (int v = 0; kept.size() >= 2; v++) {
+        char pre[16];
+        snprintf(pre, sizeof pre, "F%d", v);
+        std::vector<uint8_t> cal = slurp(g_in + "/" + pre + "_calib.bin", false);
+        if (cal.empty()) break;
+        Frame& Last = *kept[0];
+        Frame* CurP = new Frame();
+        Frame& Cur = *CurP;
+        fill_frame(Cur, L, R, kept[1]->mvKeys, kept[1]->mDescriptors, kept[1]->mvKeysRight, kept[1]->mDescriptorsRight);
+        Cur.mvuRight = kept[1]->mvuRight;      // the association of part A
+        Cur.mvDepth = kept[1]->mvDepth;
+        struct Rec { int32_t has, outlier, obs; float p[3]; };
+        std::vector<uint8_t> raw = slurp(g_in + "/" + pre + "_last.bin"), dsc = slurp(g_in + "/" + pre + "_last_desc.bin");
+        const int n = (int)(raw.size() / sizeof(Rec));
+        CHECK(n == Last.N && cal.size() == (2 * 16 + 6) * 4, "%s: %d records for %d keypoints", pre, n, Last.N);
+        if (n == Last.N && cal.size() == (2 * 16 + 6) * 4) {
+            const float* c = reinterpret_cast<const float*>(cal.data());
+            Cur.mTcw = mat4(c);
+            Last.mTcw = mat4(c + 16);
+            Frame::fx = c[32]; Frame::fy = c[33]; Frame::cx = c[34]; Frame::cy = c[35];
+            const float th = c[36];
+            const bool ori = c[37] != 0.f;
+            const Rec* r = reinterpret_cast<const Rec*>(raw.data());
+            std::vector<MapPoint*> of_last(n, static_cast<MapPoint*>(NULL));
+            Last.mvpMapPoints.assign(n, static_cast<MapPoint*>(NULL));
+            for (int i = 0; i < n; i++) {
+                Last.mvbOutlier[i] = r[i].outlier != 0;
+                if (!r[i].has) continue;
+                TestMP* p = new TestMP();
+                p->world(r[i].p);
+                p->nObs = r[i].obs;
+                p->descriptor(&dsc[(size_t)i * 32]);
+                owned.push_back(p);
+                Last.mvpMapPoints[i] = p;
+                of_last[i] = p;
+            }
+            ORBmatcher matcher(0.9f, ori);
+            double visible = 0;
+            const int nm = matcher.SearchByProjection(Cur, Last, th, false, visible);
+            std::vector<int32_t> idx(Cur.N, -1);        // index of the LAST-frame keypoint whose map point sits in each slot
+            for (int i = 0; i < Cur.N; i++) {
+                if (!Cur.mvpMapPoints[i]) continue;
+                idx[i] = -3;
+                for (int j = 0; j < n; j++) if (of_last[j] == Cur.mvpMapPoints[i]) { idx[i] = j; break; }
+            }
+            dump(std::string(pre) + "_out_last_idx.bin", idx.data(), idx.size() * 4);
+            int32_t two[2] = {nm, (int32_t)visible};
+            dump(std::string(pre) + "_nmatches_visible.bin", two, 8);
+        }
+        delete CurP;
+    }
+
+    for (size_t i = 0; i < kept.size(); i++) delete kept[i];
+    for (size_t i = 0; i < owned.size(); i++) delete owned[i];
+    delete L;
+    delete R;
+    report("check_failures", g_fail);
+    fclose(g_rep);
+    fprintf(stderr, "[adapter_run] %s (%d check failures)\n", g_fail ? "FAILED" : "ok", g_fail);
+    return g_fail ? 1 : 0;
+}

@@ -1,0 +1,320 @@
+"""The C++ drop-in adapters EXECUTED on the GPU: tests/_build/adapter_run = adapter/ORBextractor_gfo.cc +
+adapter/matchers_gfo.cc compiled against the reference's UNCHANGED headers (include/ORBextractor.h, Frame.h, MapPoint.h,
+ORBmatcher.h), linked with libgfo.so, driven the way Frame.cc / Tracking.cc drive the reference's classes
+(tests/host/adapter_run.cc lists the scenarios).  This file makes its inputs from the oracle's keypoints, runs the program once
+and compares everything it wrote with the oracle, bit for bit.
+
+The binary is built by __graft_entry__.build() where the reference headers are mounted (the build container) and travels to the
+GPU box with the snapshot, like libgfo.so."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, GOLDEN
+
+pytestmark = pytest.mark.gpu
+
+EXE = os.path.join(ROOT, "tests", "_build", "adapter_run")
+FX, FY, CX, CY = 435.2046959714599, 435.2046959714599, 367.4517211914062, 252.2008514404297
+MBF = np.float32(47.906)
+MB = np.float32(np.float32(47.906) / np.float32(435.2))
+NF = 20
+f32 = np.float32
+
+
+def _frames(img, f):
+    return np.ascontiguousarray(np.roll(img, -3 * f, axis=1))
+
+
+def _mm(R, X):
+    """(3x3) x (n x 3)^T as the plain float loops of the cv stand-in: s = 0; s += R[i,k] * x[k] for k = 0, 1, 2."""
+    out = np.zeros((len(X), 3), f32)
+    for i in range(3):
+        s = np.zeros(len(X), f32)
+        for k in range(3):
+            s = (s + (f32(R[i, k]) * X[:, k]).astype(f32)).astype(f32)
+        out[:, i] = s
+    return out
+
+
+def _pose(rx, ry, rz, t):
+    cx_, sx = np.cos(rx), np.sin(rx)
+    cy_, sy = np.cos(ry), np.sin(ry)
+    cz, sz = np.cos(rz), np.sin(rz)
+    Rx = np.array([[1, 0, 0], [0, cx_, -sx], [0, sx, cx_]])
+    Ry = np.array([[cy_, 0, sy], [0, 1, 0], [-sy, 0, cy_]])
+    Rz = np.array([[cz, -sz, 0], [sz, cz, 0], [0, 0, 1]])
+    T = np.eye(4)
+    T[:3, :3] = Rz @ Ry @ Rx
+    T[:3, 3] = t
+    return T.astype(f32)
+
+
+@pytest.fixture(scope="module")
+def run(tmp_path_factory, oracle, euroc_l, euroc_r):
+    if not os.path.exists(EXE):
+        if os.path.exists("/root/reference/include/ORBextractor.h"):
+            subprocess.check_call(["make", "-C", os.path.join(ROOT, "tests", "host")])
+        else:
+            pytest.fail("tests/_build/adapter_run is missing: __graft_entry__.build() makes it in the build container")
+    ind, outd = tmp_path_factory.mktemp("adapter_in"), tmp_path_factory.mktemp("adapter_out")
+    oe = oracle.OracleExtractor(2000, 1.2, 8, 20, 7)
+    sf = oe.scale_factors
+    ref = {"sf": sf, "frames": []}
+    for f in range(NF):
+        kl, dl = oe(_frames(euroc_l, f))
+        kr, dr = oe(_frames(euroc_r, f))
+        st = oracle.stereo_match(kl, dl, kr, dr, sf, 480, MBF, MB, 0.0)
+        ref["frames"].append((kl, dl, kr, dr, st))
+    rng = np.random.default_rng(5)
+
+    # D: frame 2 carries map points -> per-keypoint disparity windows (Frame.cc:1220-1231)
+    kl, dl, kr, dr, st = ref["frames"][2]
+    n = len(kl)
+    T = _pose(0.01, -0.02, 0.015, [0.05, -0.03, 0.1])
+    has = rng.random(n) < 0.5
+    bad = has & (rng.random(n) < 0.1)
+    disp = rng.uniform(1.0, 130.0, n)
+    z = (47.906 / disp)
+    z[rng.random(n) < 0.05] *= -1                     # behind the camera: WorldToCameraPoint says no, the default window stays
+    pw = np.stack([rng.uniform(-2, 2, n), rng.uniform(-1, 1, n), z], 1).astype(f32)
+    rec = np.zeros(n, np.dtype([("has", "<i4"), ("bad", "<i4"), ("p", "<f4", 3)]))
+    rec["has"], rec["bad"], rec["p"] = has, bad, pw
+    rec.tofile(ind / "D_windows.bin")
+    T.tofile(ind / "D_pose.bin")
+    pc = (_mm(T[:3, :3], pw) + T[:3, 3][None, :]).astype(f32)          # mRcw * Pw + mtcw
+    min_d = np.zeros(n, f32)
+    max_d = np.full(n, MBF / MB, f32)
+    ok = has & ~bad & (pc[:, 2] > 0)
+    d = (MBF / pc[:, 2]).astype(f32)
+    min_d[ok] = np.maximum((d - f32(50.0)).astype(f32), f32(0))[ok]
+    max_d[ok] = np.minimum((d + f32(50.0)).astype(f32), f32(MBF / MB))[ok]
+    ref["D"] = oracle.stereo_match(kl, dl, kr, dr, sf, 480, MBF, MB, 0.0, min_d, max_d)
+    ref["D_windows_used"] = int(ok.sum())
+
+    # E: SearchByProjection(F, local map, 3) on frame 1
+    kl, dl, kr, dr, st = ref["frames"][1]
+    n, m = len(kl), 3000
+    mps = np.zeros(m, oracle.MAP_POINT_DTYPE)
+    src = rng.integers(0, n, m)
+    mpd = dl[src].copy()
+    nflip = rng.integers(0, 40, m)
+    for j in range(m):
+        for b in rng.integers(0, 256, nflip[j]):
+            mpd[j, b >> 3] ^= np.uint8(1 << (b & 7))
+    mpd[2500:] = rng.integers(0, 256, (500, 32), dtype=np.uint8)
+    mps["proj_x"] = kl["x"][src] + rng.normal(0, 2, m)
+    mps["proj_y"] = kl["y"][src] + rng.normal(0, 2, m)
+    mps["proj_xr"] = np.where(st[1][src] >= 0, st[1][src] + rng.normal(0, 1.5, m), mps["proj_x"] - 10)
+    mps["level"] = np.clip(kl["octave"][src] + rng.integers(-1, 2, m), 0, 7)
+    mps["view_cos"] = rng.choice([1.0, 0.9985, 0.99], m)
+    fl = np.full(m, 1 | 4, np.int32)
+    fl[rng.random(m) < 0.05] = 4
+    fl[rng.random(m) < 0.04] |= 2
+    fl[rng.random(m) < 0.2] &= ~4
+    mps["flags"] = fl
+    tk = np.zeros(n, np.uint8)
+    r = rng.random(n)
+    tk[r < 0.08] = 1
+    tk[(r >= 0.08) & (r < 0.12)] = 2
+    mps.tofile(ind / "E_map.bin")
+    mpd.tofile(ind / "E_map_desc.bin")
+    tk.tofile(ind / "E_taken.bin")
+    ref["E"] = oracle.search_by_projection(kl, dl, st[1], sf, (0.0, 0.0, 752.0, 480.0), mps, mpd, 3.0, 0.8, (tk == 1).astype(np.uint8))
+
+    # F: SearchByProjection(Cur = frame 1, Last = frame 0): the adapter projects on the host (ORBmatcher.cc:1451-1502), so this side
+    # states the same float expressions independently
+    kl0, dl0 = ref["frames"][0][0], ref["frames"][0][1]
+    kl1, dl1, _, _, st1 = ref["frames"][1]
+    n0 = len(kl0)
+    ref["F"] = []
+    variants = [(7.0, 1.0, [0.0, 0.0, 0.0]), (7.0, 1.0, [0.0, 0.0, 0.5]), (15.0, 1.0, [0.0, 0.0, -0.5]), (7.0, 0.0, [0.02, 0.0, 0.01])]
+    for v, (th, ori, dt) in enumerate(variants):
+        Tc = _pose(0.004, -0.006, 0.003, [0.01, -0.02, 0.03])
+        Tl = Tc.copy()
+        Tl[:3, 3] = (Tl[:3, 3] + np.asarray(dt, f32)).astype(f32)
+        has = rng.random(n0) < 0.7
+        outl = rng.random(n0) < 0.06
+        obs = np.where(rng.random(n0) < 0.85, 3, 0).astype(np.int32)
+        zc = rng.uniform(1.5, 25.0, n0)
+        zc[rng.random(n0) < 0.03] *= -1
+        # world points that project near where the keypoint moved to in frame 1 (the image rotates left by 3 columns)
+        uc = kl0["x"] - 3.0 + rng.normal(0, 1.5, n0)
+        vc = kl0["y"] + rng.normal(0, 1.5, n0)
+        uc[rng.random(n0) < 0.03] += 900.0            # outside the image bounds
+        pcam = np.stack([(uc - CX) / FX * zc, (vc - CY) / FY * zc, zc], 1)
+        Rc, tc = Tc[:3, :3].astype(np.float64), Tc[:3, 3].astype(np.float64)
+        pw = ((pcam - tc[None, :]) @ Rc).astype(f32)                       # Rc^T (pc - tc)
+        qd = dl0.copy()
+        for j in range(n0):
+            for b in rng.integers(0, 256, rng.integers(0, 50)):
+                qd[j, b >> 3] ^= np.uint8(1 << (b & 7))
+        rec = np.zeros(n0, np.dtype([("has", "<i4"), ("outlier", "<i4"), ("obs", "<i4"), ("p", "<f4", 3)]))
+        rec["has"], rec["outlier"], rec["obs"], rec["p"] = has, outl, obs, pw
+        rec.tofile(ind / f"F{v}_last.bin")
+        qd.tofile(ind / f"F{v}_last_desc.bin")
+        np.concatenate([Tc.ravel(), Tl.ravel(), np.array([FX, FY, CX, CY, th, ori], f32)]).astype(f32).tofile(ind / f"F{v}_calib.bin")
+        # --- what the adapter computes on the host, restated (every operation rounded to float like the C++ expressions)
+        Rcw, tcw = Tc[:3, :3], Tc[:3, 3]
+        Rlw, tlw = Tl[:3, :3], Tl[:3, 3]
+        twc = _mm((-(Rcw.T)).astype(f32), tcw[None, :])[0]                   # -Rcw.t() * tcw
+        tlc = (_mm(Rlw, twc[None, :])[0] + tlw).astype(f32)
+        fwd, bwd = bool(tlc[2] > MB), bool(-tlc[2] > MB)
+        x3 = (_mm(Rcw, pw) + tcw[None, :]).astype(f32)
+        with np.errstate(divide="ignore"):
+            invz = (1.0 / x3[:, 2].astype(np.float64)).astype(f32)
+        fx, fy, cx, cy = f32(FX), f32(FY), f32(CX), f32(CY)
+        u = ((((fx * x3[:, 0]).astype(f32)) * invz).astype(f32) + cx).astype(f32)
+        vv = ((((fy * x3[:, 1]).astype(f32)) * invz).astype(f32) + cy).astype(f32)
+        keep = has & ~outl & ~(invz < 0) & ~(u < 0) & ~(u > 752) & ~(vv < 0) & ~(vv > 480)
+        qi = np.nonzero(keep)[0]
+        q = np.zeros(len(qi), oracle.PROJ_QUERY_DTYPE)
+        octv = kl0["octave"][qi]
+        q["u"], q["v"] = u[qi], vv[qi]
+        q["ur"] = (u[qi] - (MBF * invz[qi]).astype(f32)).astype(f32)
+        q["radius"] = (f32(th) * sf[octv]).astype(f32)
+        if fwd:
+            q["min_level"], q["max_level"] = octv, -1
+        elif bwd:
+            q["min_level"], q["max_level"] = 0, octv
+        else:
+            q["min_level"], q["max_level"] = octv - 1, octv + 1
+        q["angle"] = kl0["angle"][qi]
+        q["flags"] = 1 | np.where(obs[qi] > 0, 4, 0)
+        nm, out_q, _ = oracle.search_by_projection_queries(kl1, dl1, st1[1], kl1["angle"], (0.0, 0.0, 752.0, 480.0), q, qd[qi], False, 0.0,
+                                                           100, bool(ori), np.zeros(len(kl1), np.uint8))
+        ref["F"].append({"nm": nm, "idx": np.where(out_q >= 0, qi[np.maximum(out_q, 0)], -1).astype(np.int32), "visible": len(qi),
+                         "fwd": fwd, "bwd": bwd})
+    env = dict(os.environ)
+    env.pop("GFO_COMBINE", None)
+    env.pop("GFO_FULL_PYRAMID", None)
+    p = subprocess.run([EXE, GOLDEN, str(ind), str(outd), str(NF)], capture_output=True, text=True, timeout=600, env=env)
+    ref["rc"], ref["stderr"], ref["out"] = p.returncode, p.stderr, outd
+    ref["report"] = dict(l.split() for l in open(outd / "report.txt").read().splitlines() if l.strip()) if (outd / "report.txt").exists() else {}
+    ref["oracle"] = oracle
+    keep = os.path.join(ROOT, "gpurun_out")          # on the GPU box: the program's own report comes back with the call
+    if os.path.isdir(keep) and (outd / "report.txt").exists():
+        with open(os.path.join(keep, "adapter_run_report.txt"), "w") as fh:
+            fh.write(open(outd / "report.txt").read() + "--- stderr ---\n" + p.stderr[-4000:])
+    return ref
+
+
+def _rd(run, name, dtype):
+    return np.fromfile(run["out"] / name, dtype)
+
+
+def test_adapter_program_ran_clean(run):
+    """the checks that need no oracle: sizes of mvImagePyramid, context counts, untouched outputs on an empty image, released
+    descriptors on a cornerless one (tests/host/adapter_run.cc CHECK lines)"""
+    assert run["rc"] == 0, run["stderr"][-4000:]
+    assert run["report"].get("check_failures") == "0"
+    assert run["report"]["contexts_created_in_steady_state"] == "0"
+    assert run["report"]["contexts_created_by_reconstruction"] == "1"
+    assert "[gfo]" not in run["stderr"], run["stderr"][-2000:]         # no library error was reported and swallowed
+
+
+def test_operator_call_on_two_threads_equals_the_oracle(run):
+    """ORBextractor::operator() (ORBextractor.h:89-91) called like Frame.cc:84-87 for 20 frames: keypoints (28-byte cv::KeyPoint)
+    and descriptor rows, both cameras, bit for bit; the last frame is a non-continuous cv::Mat view (step != cols)"""
+    kd = run["oracle"].KEYPOINT_DTYPE
+    for f, (kl, dl, kr, dr, st) in enumerate(run["frames"]):
+        for side, k, d in (("l", kl, dl), ("r", kr, dr)):
+            gk = _rd(run, f"A_f{f:02d}_k{side}.bin", kd)
+            gd = _rd(run, f"A_f{f:02d}_d{side}.bin", np.uint8).reshape(-1, 32)
+            assert gk.tobytes() == k.tobytes(), f"frame {f} {side}: keypoints"
+            assert gd.tobytes() == d.tobytes(), f"frame {f} {side}: descriptors"
+    sz = _rd(run, "A_level_sizes.bin", np.int32).reshape(8, 2)
+    oe = run["oracle"].OracleExtractor(2000, 1.2, 8, 20, 7)
+    oe.compute_pyramid(np.zeros((480, 752), np.uint8))
+    assert [tuple(s) for s in sz] == [tuple(oe.level_size(l)) for l in range(8)]
+    tabs = _rd(run, "A_tables.bin", np.float32).reshape(4, 8)
+    for got, want in zip(tabs, (oe.scale_factors, oe.inv_scale_factors, oe.level_sigma2, oe.inv_level_sigma2)):
+        assert got.tobytes() == np.asarray(want, np.float32).tobytes()
+
+
+def test_stereo_association_member_equals_the_oracle_and_uses_the_rig(run):
+    """Frame::ComputeStereoMatches_Undistorted (Frame.cc:1167-1316) as swapped in by adapter/matchers_gfo.cc: mvuRight, mvDepth,
+    mvDistIdx and the return value of every frame; from the second frame on the two operator() calls went to the device as one
+    rig submission and the member was answered from it"""
+    for f, (kl, dl, kr, dr, st) in enumerate(run["frames"]):
+        nm, ur, dp, bd, bi = st
+        assert _rd(run, f"A_f{f:02d}_uright.bin", np.float32).tobytes() == ur.tobytes(), f
+        assert _rd(run, f"A_f{f:02d}_depth.bin", np.float32).tobytes() == dp.tobytes(), f
+        want = sorted((int(bd[i]), i) for i in range(len(bd)) if bd[i] >= 0)
+        got = _rd(run, f"A_f{f:02d}_distidx.bin", np.int32).reshape(-1, 2)
+        assert [tuple(x) for x in got.tolist()] == want, f
+        assert int(_rd(run, f"A_f{f:02d}_nstereo.bin", np.int32)[0]) == nm
+    rep = run["report"]
+    assert int(rep["combiner_rig_frames"]) >= NF - 3, rep            # the first frame declares the rig; a partner may miss its window once
+    assert int(rep["combiner_rig_answers"]) >= NF - 3, rep
+    assert int(rep["combiner_broken"]) == 0
+
+
+def test_compute_pyramid_levels_with_their_frames(run):
+    """ORBextractor::ComputePyramid (ORBextractor.h:132, .cc:1176-1201): every level a view into its (w+38) x (h+38) buffer whose
+    19-px frame is the reflect-101 border"""
+    oe = run["oracle"].OracleExtractor(2000, 1.2, 8, 20, 7)
+    img = np.fromfile(os.path.join(GOLDEN, "EuRoC_l_752x480.u8"), np.uint8).reshape(480, 752)
+    oe.compute_pyramid(img)
+    for l in range(8):
+        w, h = oe.level_size(l)
+        got = _rd(run, f"B_level{l}_framed_{w + 38}x{h + 38}.bin", np.uint8).reshape(h + 38, w + 38)
+        assert got.tobytes() == oe.level(l, padded=True).tobytes(), l
+    kd = run["oracle"].KEYPOINT_DTYPE
+    kl, dl = run["frames"][0][0], run["frames"][0][1]
+    assert _rd(run, "B_after_kl.bin", kd).tobytes() == kl.tobytes()
+    assert _rd(run, "B_after_dl.bin", np.uint8).tobytes() == dl.tobytes()
+
+
+def test_extractor_recreated_at_one_address(run, euroc_l, euroc_r):
+    """Tracking::updateORBExtractor (Tracking.cc:298-320): other parameters at the same address -> the new object's results"""
+    O = run["oracle"]
+    kd = O.KEYPOINT_DTYPE
+    k, d = O.OracleExtractor(1000, 1.2, 8, 20, 7)(euroc_l)
+    assert _rd(run, "C_first_kl.bin", kd).tobytes() == k.tobytes() and _rd(run, "C_first_dl.bin", np.uint8).tobytes() == d.tobytes()
+    assert _rd(run, "C_third_kl.bin", kd).size > 0
+    e2 = O.OracleExtractor(1500, 1.2, 8, 12, 5)
+    k, d = e2(euroc_r)
+    assert _rd(run, "C_second_kl.bin", kd).tobytes() == k.tobytes() and _rd(run, "C_second_dl.bin", np.uint8).tobytes() == d.tobytes()
+    k, d = e2(euroc_l)
+    assert _rd(run, "C_third_kl.bin", kd).tobytes() == k.tobytes() and _rd(run, "C_third_dl.bin", np.uint8).tobytes() == d.tobytes()
+
+
+def test_stereo_member_with_map_point_windows(run):
+    """Frame.cc:1220-1231: the adapter flattens MapPoint::isBad / GetWorldPos / Frame::WorldToCameraPoint into minD / maxD"""
+    nm, ur, dp, bd, bi = run["D"]
+    assert run["D_windows_used"] > 300
+    assert _rd(run, "D_f02_uright.bin", np.float32).tobytes() == ur.tobytes()
+    assert _rd(run, "D_f02_depth.bin", np.float32).tobytes() == dp.tobytes()
+    want = sorted((int(bd[i]), i) for i in range(len(bd)) if bd[i] >= 0)
+    assert [tuple(x) for x in _rd(run, "D_f02_distidx.bin", np.int32).reshape(-1, 2).tolist()] == want
+    assert int(_rd(run, "D_f02_nstereo.bin", np.int32)[0]) == nm
+    assert ur.tobytes() != run["frames"][2][4][1].tobytes()          # the windows changed the association
+
+
+def test_search_by_projection_member(run):
+    """ORBmatcher::SearchByProjection(Frame&, const vector<MapPoint*>&, th) (ORBmatcher.h:64, .cc:155-241) through MapPoint objects:
+    which map point ends in which mvpMapPoints slot, mvpMatchScore, the count"""
+    nm, out_mp, out_sc = run["E"]
+    assert nm > 300
+    got = _rd(run, "E_out_mp.bin", np.int32)
+    np.testing.assert_array_equal(got, out_mp)
+    sc = _rd(run, "E_out_score.bin", np.int32)
+    np.testing.assert_array_equal(sc[out_mp >= 0], out_sc[out_mp >= 0])
+    assert (sc[out_mp < 0] == 0).all()
+    assert int(_rd(run, "E_nmatches.bin", np.int32)[0]) == nm
+
+
+def test_search_by_projection_last_frame_member(run):
+    """ORBmatcher::SearchByProjection(CurrentFrame, LastFrame, th, bMono, numVisible) (ORBmatcher.cc:1440-1593): the adapter's
+    host-side projection (:1451-1502) + the device search, neutral / forward / backward motion and the orientation check off"""
+    assert [(v["fwd"], v["bwd"]) for v in run["F"]] == [(False, False), (True, False), (False, True), (False, False)]
+    for v, want in enumerate(run["F"]):
+        got = _rd(run, f"F{v}_out_last_idx.bin", np.int32)
+        nm, vis = _rd(run, f"F{v}_nmatches_visible.bin", np.int32)
+        assert vis == want["visible"], v
+        np.testing.assert_array_equal(got, want["idx"], err_msg=f"variant {v}")
+        assert nm == want["nm"], v
+        assert want["nm"] > 200, (v, want["nm"])
