@@ -207,14 +207,15 @@ def side_config(name, batch, streams):
     249k, proj1080 46.5k against 51.2k frames/s, measured both ways)."""
     import subprocess
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--workload", name, "--batch", str(batch), "--steps", "400", "--warmup", "30",
-           "--streams", str(streams), "--no-other-configs", "--no-cpu-baseline", "--no-boundary", "--profile-steps", "5"]   # (each verifies its own last step)
+           "--streams", str(streams), "--no-other-configs", "--no-cpu-baseline", "--no-boundary", "--no-live-traffic", "--profile-steps", "5"]   # (each verifies its own last step)
     try:
         r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=240)
         lines = [l for l in r.stdout.decode(errors="replace").splitlines() if l.startswith("{")]
-        if r.returncode != 0 or not lines:
+        if r.returncode not in (0, 4) or not lines:      # (4: the child printed its line and failed on verified.mismatches)
             return {"name": name, "error": f"child process failed (rc {r.returncode})"}
         j = json.loads(lines[-1])
         return {"workload": j["config"]["workload"], "name": name, "value": j["value"], "unit": "frames/s", "images_per_step": batch,
+                "verified": j["config"].get("verified"),
                 "contexts": j["config"]["contexts_per_gpu"], "steps": j["steps"], "ms_per_step": j["ms_per_step"],
                 "process": "its own (same command with --workload)", "roofline": j["roofline"]}
     except Exception as ex:      # a failing side measurement must not lose the headline line
@@ -224,8 +225,8 @@ def side_config(name, batch, streams):
 def per_frame_boundary(seconds=1.0):
     """The reference's own call pattern through the C ABI: one stereo frame per call, K host threads (K camera streams),
     tools/c/boundary_throughput.c built with the host compiler and run as a child process (it initialises the GPU itself).
-    gfo_extract_stereo at K = 1, 4, 8, 16 and the adapter's two-context pattern at K = 4, 8, contexts combining as the
-    adapter sets them (gfo_ctx_set_combining)."""
+    gfo_extract_stereo at K = 1, 4, 8, 16 and the adapter's two-context pattern at K = 1 (the one configuration GF-ORB-SLAM2
+    itself runs: one stereo camera), 4, 8, contexts combining as the adapter sets them (gfo_ctx_set_combining)."""
     import shutil
     import subprocess
     cc = shutil.which("gcc") or shutil.which("cc")
@@ -237,7 +238,7 @@ def per_frame_boundary(seconds=1.0):
                         "-ldl", "-lpthread", "-lm"], check=True, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120)
         from gf_orb_slam2_amd._lib import lib_path
         pts = []
-        for mode, ks in (("stereo", "1,4,8,16"), ("adapter", "4,8")):
+        for mode, ks in (("stereo", "1,4,8,16"), ("adapter", "1,4,8")):
             r = subprocess.run([exe, lib_path(), os.path.join(ROOT, "tests", "golden"), str(seconds), mode, ks, "1"], stdout=subprocess.PIPE,
                                stderr=subprocess.DEVNULL, timeout=180)
             j = json.loads(r.stdout.decode(errors="replace"))
@@ -458,7 +459,7 @@ def spawn_ranks(n, argv, selftest=False):
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), GROUP_RANK="0",
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), GFO_BENCH_SPAWNED="1")
-        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: RCCL across processes needs it on this driver
+        # (HSA_ENABLE_IPC_MODE_LEGACY: see main() -- every rank sets it for itself, whichever launcher started it)
         cmd = [sys.executable, os.path.abspath(__file__)] + list(argv) + (["--spawn-selftest"] if selftest else [])
         # rank 0's stdout carries the line; the other ranks print nothing on stdout by contract, and if they do it goes to stderr
         procs.append(subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE if r == 0 else sys.stderr, start_new_session=True))
@@ -687,6 +688,8 @@ class Job:
                 nm, out_mp, out_sc = m.projection_fetch(f, len(kp))
                 bad += int(not (nm == o[0] and (out_mp[:len(kp)] == o[1]).all() and (out_sc[:len(kp)] == o[2]).all()))
                 pairs += 1
+        if os.environ.get("GFO_BENCH_INJECT_MISMATCH"):      # tests only: the self-policing exit must be reachable
+            bad += 1
         return {"images": len(slots), "pairs": pairs, "mismatches": bad, "context": k, "slots": slots,
                 "against": "oracle/orb_oracle.c on the same host images, bit for bit; the last step of the timed region, outside it"}
 
@@ -745,13 +748,16 @@ class Job:
         # the committed counter pass of this command (profiles/sq_counters_latest.json, tools/pmc_sq.sh) -- instruction counts
         # do not vary from run to run; the duration is this run's.
         issue_all, issue_src = {}, None
-        try:
-            sj = json.load(open(os.path.join(ROOT, "profiles", "sq_counters_latest.json")))
-            if sj.get("workload") == traffic_workload and sj.get("batch") == self.B:
-                issue_all = {k: v.get("SQ_INSTS_VALU") for k, v in sj["per_stage_per_step"].items()}
-                issue_src = f"profiles/sq_counters_{sj.get('tag')}.txt (rocprofv3 --pmc SQ_INSTS_VALU pass of this command, tools/pmc_sq.sh); duration measured in this run"
-        except Exception:
-            issue_all = {}
+        for cand in (f"sq_counters_{traffic_workload}_latest.json", "sq_counters_latest.json"):
+            try:
+                sj = json.load(open(os.path.join(ROOT, "profiles", cand)))
+                if sj.get("workload") == traffic_workload and sj.get("batch") == self.B:
+                    issue_all = {k: v.get("SQ_INSTS_VALU") for k, v in sj["per_stage_per_step"].items()}
+                    issue_src = (f"profiles/{cand} = sq_counters_{sj.get('tag')} (rocprofv3 --pmc SQ_INSTS_VALU pass of this command, "
+                                 "tools/pmc_sq.sh); duration measured in this run")
+                    break
+            except Exception:
+                pass
 
         def issue_frac(stage, ms_per_step):
             n = issue_all.get(stage)
@@ -767,12 +773,14 @@ class Job:
                             "traffic_per_step": tj_all.get(k), "traffic_counters_per_step": raw_all.get(k)}
         dom_issue = issue_frac(dom, stage_ms[dom])
         hbm_frac = round(achieved / 8000.0, 5)
+        def bound_of(issue, hbm):      # no instruction count for this workload / stage: no claim about which wall binds
+            return None if issue is None else ("valu-issue" if issue > hbm else "hbm")
         for k, v in per_stage.items():
-            v["bound"] = "valu-issue" if (v["issue_frac"] or 0) > v["frac"] else "hbm"
+            v["bound"] = bound_of(v["issue_frac"], v["frac"])
         return n_kp_img, {
             # `bound` names the wall the dominant kernel actually sits against: whichever of the two fractions is larger.
             # achieved / peak / frac stay the HBM figures the contract defines; issue_frac is the other roofline.
-            "bound": "valu-issue" if (dom_issue or 0) > hbm_frac else "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": 8000.0, "unit": "GB/s",
+            "bound": bound_of(dom_issue, hbm_frac), "kernel": dom, "achieved": round(achieved, 2), "peak": 8000.0, "unit": "GB/s",
             "frac": hbm_frac, "issue_frac": dom_issue,
             "issue_model": {"valu_instructions_per_launch": int(issue_all[dom] / max(launches_per_step, 1e-9)) if issue_all.get(dom) else None,
                             "cycles_per_wave_instruction": ISSUE_CYCLES, "simds": N_SIMDS, "clock_ghz": CLOCK_HZ / 1e9, "source": issue_src},
@@ -802,10 +810,11 @@ def main():
     ap.add_argument("--streams", type=int, default=0,
                     help="independent contexts (arena + HIP stream) the steps alternate between, so the tail of one "
                          "batch overlaps the head of the next (0 = the workload's measured best, CONTEXTS)")
-    ap.add_argument("--live-traffic", action="store_true",
-                    help="measure roofline.traffic in this run: two rocprofv3 --pmc child passes (FETCH_SIZE, WRITE_SIZE) before the GPU is "
-                         "initialised (+10 s).  Default: the committed profiles/traffic_latest.json, labelled as such")
-    ap.add_argument("--no-live-traffic", action="store_true", help=argparse.SUPPRESS)   # the round-2 spelling of the default
+    ap.add_argument("--live-traffic", action="store_true", help=argparse.SUPPRESS)   # (the default since round 5)
+    ap.add_argument("--no-live-traffic", action="store_true",
+                    help="do not measure roofline.traffic in this run.  Default (N = 1, rocprofv3 present, not under a profiler): two "
+                         "rocprofv3 --pmc child passes (FETCH_SIZE, WRITE_SIZE) of this command, started before this process touches the "
+                         "GPU, 75 s bound each (+10..15 s); if they cannot run the committed profiles/traffic_latest.json is used and labelled")
     ap.add_argument("--gather-every", type=int, default=1,
                     help="N > 1 GPUs: all-gather the keypoint counts every this many steps (1 = every step, as north_star names it; "
                          "0 = never -- separates straggler coupling between ranks from kernel time on a real node)")
@@ -838,11 +847,16 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    # Multi-process GPU work on this pool: the image exports HSA_ENABLE_IPC_MODE_LEGACY=0 here and on the GPU boxes, and its
+    # environment notes say why -- the host driver only supports dmabuf IPC; without it RCCL across processes fails with
+    # `hipIpcGetMemHandle: invalid argument`.  Kept (never overridden) in EVERY rank, before the HIP runtime loads, so that the
+    # spawned form (`bench.py --gpus N`) and the torch.distributed.run form are one and the same on this point.
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     if world != args.gpus:
         print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world} in the environment: running {world} ranks (n_gpus reports {world})", file=sys.stderr)
     # the PMC passes run first, as children, while this process has not touched the GPU yet
-    live, live_note = None, "live measurement off (opt in with --live-traffic)"
-    if world == 1 and args.live_traffic and not args.pmc_child:
+    live, live_note = None, "live measurement off (--no-live-traffic)" if args.no_live_traffic else "N > 1: the counter passes are a single-GPU measurement"
+    if world == 1 and not args.no_live_traffic and not args.pmc_child and "GFO_BENCH_SPAWNED" not in os.environ:
         live, live_note = live_traffic(args.workload, args.batch - (args.batch & 1))
 
     import torch
@@ -938,8 +952,12 @@ def main():
             "value": round(value, 1), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-            "rccl_ranks": (coll["ranks_with_counts"] if coll else 1), "collective": coll, "verified": verified,
-            "config": {"workload": job.cfg_name, "frame": "one camera image (a stereo pair = 2 frames + 1 association)",
+            # ranks whose counts are in the last all-gather's output: `collective_ranks` whatever the backend, `rccl_ranks` only when
+            # the backend IS RCCL ("nccl"); a gloo rehearsal on one GPU reports rccl_ranks null
+            "collective_ranks": (coll["ranks_with_counts"] if coll else 1),
+            "rccl_ranks": ((coll["ranks_with_counts"] if coll["backend"] == "nccl" else None) if coll else 1), "collective": coll, "verified": verified,
+            "config": {"workload": job.cfg_name,
+                       "verified": ({k: verified[k] for k in ("images", "pairs", "mismatches")} if verified else None), "frame": "one camera image (a stereo pair = 2 frames + 1 association)",
                        "images_per_step_per_gpu": B, "stereo_pairs_per_s": round(value / 2, 1) if stereo else None,
                        "width": job.w, "height": job.h, "nfeatures": job.nfeat, "levels": 8, "scale_factor": 1.2, "fast_th": [20, 7],
                        "map_points": MAP_POINTS if job.matcher == "project" else None,
@@ -957,6 +975,29 @@ def main():
     del job
     torch.cuda.empty_cache()
 
+    # ---- N > 1: BASELINE configs[4] in the same line -- one 1920x1080 @4000 stream per GPU (extract + SearchByProjection against the
+    #      50 000-point map), 64 images per rank and step, same ranks, same all-gather of the keypoint counts
+    if world > 1 and not args.no_other_configs and args.workload != "proj1080":
+        b4 = min(64, B)
+        job4 = Job(G, torch, "proj1080", b4, CONTEXTS["proj1080"], local_rank, rank, world, dist, gather_every=args.gather_every)
+        s4 = max(10, min(60, args.steps))
+        dt4 = job4.timed(s4, 5)
+        ver4 = job4.verify(n_images=2, n_pairs=1) if rank == 0 and not args.no_verify else None
+        if rank == 0:
+            segs = [int((g.view(world, b4) != 0).any(dim=1).sum().item()) for g in job4.gathered if g is not None]
+            ranks4 = min(segs) if args.gather_every else None
+            line["other_configs"] = [{"workload": "configs[4]: " + job4.cfg_name + f", one stream per GPU x {world}", "name": "proj1080",
+                                      "value": round(world * b4 * s4 / dt4, 1), "unit": "frames/s", "n_gpus": world, "images_per_step_per_gpu": b4,
+                                      "steps": s4, "ms_per_step": round(dt4 / s4 * 1e3, 4), "scaling": "weak", "collective_ranks": ranks4,
+                                      "rccl_ranks": ranks4 if dist.get_backend() == "nccl" else None,
+                                      "verified": ({k: ver4[k] for k in ("images", "pairs", "mismatches")} if ver4 else None)}]
+            if ver4 and ver4["mismatches"]:
+                verified = dict(verified or {"images": 0, "pairs": 0, "mismatches": 0})
+                verified["mismatches"] += ver4["mismatches"]
+        job4.close()
+        del job4
+        torch.cuda.empty_cache()
+
     # ---- the other BASELINE configs, short passes, same line ----
     if world == 1 and not args.no_other_configs and under_profiler():
         line["other_configs"] = "skipped: this run is under a profiler (they run as child processes of this command)"
@@ -969,6 +1010,10 @@ def main():
             others.append(side_config(name, ob, args.streams))
         line["other_configs"] = others
         line["real_image"] = real_image()
+        side_bad = sum((o.get("verified") or {}).get("mismatches", 0) for o in others)
+        if side_bad:
+            verified = dict(verified or {"images": 0, "pairs": 0, "mismatches": 0})
+            verified["mismatches"] += side_bad
 
     if rank == 0 and world == 1 and not args.no_boundary and not under_profiler():
         line["per_frame_boundary"] = per_frame_boundary()
@@ -980,6 +1025,10 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+    # self-policing: a run whose checked results differ from the oracle's has printed its line (the evidence) and FAILS
+    if rank == 0 and verified and verified["mismatches"] > 0:
+        print(f"bench.py: {verified['mismatches']} of the verified results differ from the oracle: the measurement is void", file=sys.stderr, flush=True)
+        sys.exit(4)
 
 
 if __name__ == "__main__":

@@ -1,0 +1,41 @@
+"""bench.py polices its own line: the oracle check of the last timed step is part of `config` (what the
+driver's record keeps) and a mismatch fails the command AFTER the line -- the evidence -- has been printed."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+CMD = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--batch", "8", "--profile-steps", "1",
+       "--no-other-configs", "--no-cpu-baseline", "--no-boundary", "--no-live-traffic"]
+
+
+def _run(extra_env):
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+    env.update(extra_env)
+    r = subprocess.run(CMD, capture_output=True, text=True, env=env, cwd=ROOT, timeout=300)
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, (r.stdout[-1000:], r.stderr[-2000:])
+    return r, json.loads(lines[0])
+
+
+def test_verified_is_in_config_and_a_clean_run_passes():
+    r, d = _run({})
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert d["config"]["verified"] == {"images": 4, "pairs": 2, "mismatches": 0}
+    assert d["roofline"]["bound"] in ("valu-issue", "hbm", None)
+    # no instruction count is committed for a batch of 8: no claim about the binding wall (never "hbm" by default)
+    assert d["roofline"]["issue_frac"] is None and d["roofline"]["bound"] is None
+    assert all(v["bound"] is None for v in d["roofline"]["all_kernels"].values())
+
+
+def test_a_mismatch_prints_the_line_and_fails_the_command():
+    r, d = _run({"GFO_BENCH_INJECT_MISMATCH": "1"})
+    assert r.returncode == 4, (r.returncode, r.stderr[-2000:])
+    assert d["config"]["verified"]["mismatches"] == 1 and d["value"] > 0
+    assert "differ from the oracle" in r.stderr

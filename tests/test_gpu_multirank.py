@@ -22,7 +22,7 @@ def test_two_ranks_rehearsal():
     env = dict(os.environ, GFO_BENCH_REHEARSAL="1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "2", "--batch", "16",
-           "--profile-steps", "2"]
+           "--profile-steps", "2", "--no-other-configs"]
     r = subprocess.run(cmd, capture_output=True, text=True, env=env, cwd=ROOT, timeout=170)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
@@ -33,21 +33,29 @@ def test_two_ranks_rehearsal():
     # whole-job aggregate: 2 ranks x 16 images x 6 steps over the max-over-ranks time
     assert abs(d["value"] - 2 * 16 * 6 / (d["ms_per_step"] * 6 * 1e-3)) / d["value"] < 0.01
     assert "roofline" in d and "cpu_baseline" not in d and "other_configs" not in d
-    assert d["rccl_ranks"] == 2 and d["collective"]["launcher"].startswith("external")
+    assert d["collective_ranks"] == 2 and d["collective"]["launcher"].startswith("external")
+    assert d["collective"]["backend"] == "gloo" and d["rccl_ranks"] is None      # a gloo rehearsal does not claim RCCL ranks
+    assert d["config"]["verified"] == {"images": 4, "pairs": 2, "mismatches": 0}
 
 
 def test_plain_gpus_2_launches_two_ranks_by_itself():
     """The driver's recorded command form, `python3 bench.py --gpus N ...` with no launcher: bench.py starts the N ranks
-    itself (spawn_ranks) and the count all-gather of the timed region holds counts of N ranks."""
+    itself (spawn_ranks) and the count all-gather of the timed region holds counts of N ranks.  Without --no-other-configs
+    the N > 1 line also carries BASELINE configs[4] (one 1920x1080 @4000 stream per GPU, extract + SearchByProjection against the
+    50 000-point map, same ranks, same all-gather): here 4 images per rank."""
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
     env["GFO_BENCH_REHEARSAL"] = "1"
-    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "2", "--batch", "16", "--profile-steps", "2"]
-    r = subprocess.run(cmd, capture_output=True, text=True, env=env, cwd=ROOT, timeout=170)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "2", "--batch", "4", "--profile-steps", "2"]
+    r = subprocess.run(cmd, capture_output=True, text=True, env=env, cwd=ROOT, timeout=400)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]
     d = json.loads(lines[0])
-    assert d["n_gpus"] == 2 == d["rccl_ranks"], (d["n_gpus"], d["rccl_ranks"])
-    assert d["collective"]["world_size"] == 2 and d["collective"]["gathered_elements"] == 2 * 16
+    assert d["n_gpus"] == 2 == d["collective_ranks"], (d["n_gpus"], d["collective_ranks"])
+    assert d["collective"]["world_size"] == 2 and d["collective"]["gathered_elements"] == 2 * 4
     assert d["collective"]["launcher"] == "bench.py spawn_ranks"
-    assert abs(d["value"] - 2 * 16 * 6 / (d["ms_per_step"] * 6 * 1e-3)) / d["value"] < 0.01
+    assert abs(d["value"] - 2 * 4 * 6 / (d["ms_per_step"] * 6 * 1e-3)) / d["value"] < 0.01
+    (c4,) = d["other_configs"]
+    assert c4["name"] == "proj1080" and c4["workload"].startswith("configs[4]") and c4["n_gpus"] == 2 and c4["images_per_step_per_gpu"] == 4
+    assert c4["collective_ranks"] == 2 and c4["value"] > 0 and c4["verified"]["mismatches"] == 0 and c4["verified"]["pairs"] == 1
+    assert abs(c4["value"] - 2 * 4 * c4["steps"] / (c4["ms_per_step"] * c4["steps"] * 1e-3)) / c4["value"] < 0.01
