@@ -729,16 +729,17 @@ class Job:
             raw_all = {k: {"fetch_raw": v["fetch_raw"], "write": v["write"]} for k, v in live.items()}
             traffic_source = live_note
         else:
-            tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
-            try:
-                tj = json.load(open(tpath))
-                if tj.get("workload") == traffic_workload and tj.get("batch") == self.B:
-                    x2, rw = tj.get("hbm_bytes_per_launch_fetch_x2", {}), tj.get("hbm_bytes_per_launch", {})
-                    tj_all = {k: (x2.get(k, v) if k in WIDE_READ_STAGES else v) for k, v in rw.items()}
-                    traffic_source = (f"profiles/traffic_{tj.get('tag')}.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of an earlier run of "
-                                      f"this command; not measured in this run: {live_note or 'live measurement off'})")
-            except Exception:
-                tj_all = {}
+            for cand in (f"traffic_{traffic_workload}_latest.json", "traffic_latest.json"):
+                try:
+                    tj = json.load(open(os.path.join(ROOT, "profiles", cand)))
+                    if tj.get("workload") == traffic_workload and tj.get("batch") == self.B:
+                        x2, rw = tj.get("hbm_bytes_per_launch_fetch_x2", {}), tj.get("hbm_bytes_per_launch", {})
+                        tj_all = {k: (x2.get(k, v) if k in WIDE_READ_STAGES else v) for k, v in rw.items()}
+                        traffic_source = (f"profiles/{cand} = tag {tj.get('tag')} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of an earlier run of "
+                                          f"this command; not measured in this run: {live_note or 'live measurement off'})")
+                        break
+                except Exception:
+                    pass
         if dom in tj_all:
             traffic = int(tj_all[dom] / max(launches_per_step, 1e-9))
         # The roofline that BINDS.  These kernels are integer / byte work whose wall is vector-instruction issue, not HBM: a

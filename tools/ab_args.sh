@@ -6,7 +6,7 @@ for SPEC in "$@"; do
   i=$((i+1))
   ENVS="${SPEC%%--*}"; ARGS="${SPEC#*--}"
   for rep in 1 2; do
-    env $ENVS python bench.py --steps ${GFO_AB_STEPS:-100} --warmup 30 --no-cpu-baseline --no-other-configs --no-boundary $ARGS > gpurun_out/aa_$i.json 2> gpurun_out/aa_$i.err || { tail -5 gpurun_out/aa_$i.err; exit 1; }
+    env $ENVS python bench.py --steps ${GFO_AB_STEPS:-100} --warmup 30 --no-cpu-baseline --no-other-configs --no-boundary --no-live-traffic $ARGS > gpurun_out/aa_$i.json 2> gpurun_out/aa_$i.err || { tail -5 gpurun_out/aa_$i.err; exit 1; }
     python - "$SPEC" gpurun_out/aa_$i.json <<'PY'
 import json, sys
 j = json.loads(open(sys.argv[2]).read().strip().splitlines()[-1])

@@ -17,7 +17,7 @@ print(f"GFO_BLUR_XCD={sys.argv[3]} {sys.argv[2]} MB per launch: " + "  ".join(f"
 PY
   done
   for rep in 1 2; do
-    python bench.py --steps 100 --warmup 30 --no-cpu-baseline --no-other-configs --no-boundary --no-verify > gpurun_out/abbx.json 2> gpurun_out/abbx.err || { tail -5 gpurun_out/abbx.err; exit 1; }
+    python bench.py --steps 100 --warmup 30 --no-cpu-baseline --no-other-configs --no-boundary --no-live-traffic --no-verify > gpurun_out/abbx.json 2> gpurun_out/abbx.err || { tail -5 gpurun_out/abbx.err; exit 1; }
     python3 - $X <<'PY' | tee -a $OUTF
 import json, sys
 j = json.loads(open('gpurun_out/abbx.json').read().strip().splitlines()[-1])

@@ -5,7 +5,7 @@ R=$GRAFT_REPO_ROOT; cd $R
 for rep in 1 2; do
 for A in "--streams 2" "--streams 3" "--streams 2:GFO_BENCH_CHAIN=2" "--streams 2:GFO_BENCH_CHAIN=0"; do
   ARGS=${A%%:*}; ENVV=${A#*:}; [ "$ENVV" = "$A" ] && ENVV="X=1"
-  env $ENVV python bench.py $ARGS --steps 200 --warmup 30 --no-cpu-baseline --no-other-configs --no-boundary --no-verify 2>/dev/null | python3 -c "
+  env $ENVV python bench.py $ARGS --steps 200 --warmup 30 --no-cpu-baseline --no-other-configs --no-boundary --no-live-traffic --no-verify 2>/dev/null | python3 -c "
 import json,sys; j=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('[$A]', round(j['value']), j.get('sustained',{}).get('value'))"
 done
 done

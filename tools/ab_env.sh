@@ -3,7 +3,7 @@
 R=$GRAFT_REPO_ROOT; cd $R; mkdir -p gpurun_out
 for rep in 1 2; do
 for E in "$@"; do
-  env $E python bench.py --steps 100 --warmup 30 --no-cpu-baseline --no-other-configs --no-boundary ${GFO_AB_ARGS} > gpurun_out/abe.json 2> gpurun_out/abe.err || { tail -5 gpurun_out/abe.err; exit 1; }
+  env $E python bench.py --steps 100 --warmup 30 --no-cpu-baseline --no-other-configs --no-boundary --no-live-traffic ${GFO_AB_ARGS} > gpurun_out/abe.json 2> gpurun_out/abe.err || { tail -5 gpurun_out/abe.err; exit 1; }
   python - "${E:-defaults}" gpurun_out/abe.json <<'PY'
 import json, sys
 j = json.loads(open(sys.argv[2]).read().strip().splitlines()[-1])

@@ -5,7 +5,7 @@ R=$GRAFT_REPO_ROOT; cd $R; mkdir -p gpurun_out
 for rep in 1 2; do
 for LIB in "$@"; do
   if [ -n "$LIB" ]; then export GFO_LIB=$R/$LIB; else unset GFO_LIB; fi
-  python bench.py --steps 100 --warmup 30 --no-cpu-baseline --no-other-configs --no-boundary > gpurun_out/abf.json 2> gpurun_out/abf.err || { tail -5 gpurun_out/abf.err; exit 1; }
+  python bench.py --steps 100 --warmup 30 --no-cpu-baseline --no-other-configs --no-boundary --no-live-traffic > gpurun_out/abf.json 2> gpurun_out/abf.err || { tail -5 gpurun_out/abf.err; exit 1; }
   python - "${LIB:-as built}" gpurun_out/abf.json <<'PY'
 import json, sys
 j = json.loads(open(sys.argv[2]).read().strip().splitlines()[-1])

@@ -19,7 +19,7 @@ print(f"GFO_STEREO_XCD={sys.argv[3]} {sys.argv[2]} MB per launch: " + "  ".join(
 PY
   done
   for rep in 1 2; do
-    python bench.py --steps 100 --warmup 30 --no-cpu-baseline --no-other-configs --no-boundary --no-verify > gpurun_out/absx.json 2> gpurun_out/absx.err || { tail -5 gpurun_out/absx.err; exit 1; }
+    python bench.py --steps 100 --warmup 30 --no-cpu-baseline --no-other-configs --no-boundary --no-live-traffic --no-verify > gpurun_out/absx.json 2> gpurun_out/absx.err || { tail -5 gpurun_out/absx.err; exit 1; }
     python3 - $X <<'PY' | tee -a $OUTF
 import json, sys
 j = json.loads(open('gpurun_out/absx.json').read().strip().splitlines()[-1])

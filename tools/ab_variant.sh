@@ -14,7 +14,7 @@ for FL in "$@"; do
     unset GFO_LIB
   fi
   for rep in 1 2; do
-    python bench.py --steps 100 --warmup 30 --no-cpu-baseline --no-other-configs --no-boundary ${GFO_AB_ARGS} > gpurun_out/ab_$i.json 2> gpurun_out/ab_$i.err || { tail -5 gpurun_out/ab_$i.err; exit 1; }
+    python bench.py --steps 100 --warmup 30 --no-cpu-baseline --no-other-configs --no-boundary --no-live-traffic ${GFO_AB_ARGS} > gpurun_out/ab_$i.json 2> gpurun_out/ab_$i.err || { tail -5 gpurun_out/ab_$i.err; exit 1; }
     python - "$FL" gpurun_out/ab_$i.json <<'PY'
 import json, sys
 j = json.loads(open(sys.argv[2]).read().strip().splitlines()[-1])

@@ -7,7 +7,7 @@ D=/tmp/gfo_dbg; rm -rf $D; mkdir -p $D/pkg; cp -r $R/include $D/include; cp -r $
 ( cd $D/pkg/csrc && rm -f *.o && make -s -j8 EXTRA=-DGFO_FAST_DEBUG OUT=/tmp/libgfo_dbg.so ) || exit 1
 export GFO_LIB=/tmp/libgfo_dbg.so
 for s in 1 2 3 4 0; do
-  GFO_FAST_STOP=$s python bench.py --steps 40 --warmup 10 --streams 1 --no-cpu-baseline --no-other-configs --no-boundary > gpurun_out/fpt.json 2> gpurun_out/fpt.err || { tail -3 gpurun_out/fpt.err; exit 1; }
+  GFO_FAST_STOP=$s python bench.py --steps 40 --warmup 10 --streams 1 --no-cpu-baseline --no-other-configs --no-boundary --no-live-traffic > gpurun_out/fpt.json 2> gpurun_out/fpt.err || { tail -3 gpurun_out/fpt.err; exit 1; }
   python - $s gpurun_out/fpt.json <<'PY'
 import json, sys
 j = json.loads(open(sys.argv[2]).read().strip().splitlines()[-1])
