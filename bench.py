@@ -115,7 +115,7 @@ def under_profiler():
 
 def pmc_bytes_per_step(csv_path, counter):
     """rocprofv3 counter_collection.csv -> ({stage: bytes per step}, steps).  FETCH_SIZE / WRITE_SIZE come in KiB per
-    dispatch; a stage may be several launches per step (the pyramid), a step is one k_quadtree launch."""
+    dispatch; a stage may be several launches per step (the pyramid, the quadtree's level groups), a step is one k_fast launch."""
     import csv
     per, launches = {}, {}
     for row in csv.DictReader(open(csv_path)):
@@ -127,7 +127,7 @@ def pmc_bytes_per_step(csv_path, counter):
                 per[st] = per.get(st, 0.0) + float(row["Counter_Value"]) * 1024.0
                 launches[st] = launches.get(st, 0) + 1
                 break
-    steps = launches.get("quadtree", 0)
+    steps = launches.get("fast", 0)
     return ({st: v / steps for st, v in per.items()} if steps else {}), steps
 
 

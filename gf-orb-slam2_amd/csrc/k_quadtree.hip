@@ -20,6 +20,7 @@
 #include <stdlib.h>
 
 #define QT_MAX_THREADS 1024
+#define QT_PART 32                     // ints of scan scratch: one per wave of the workgroup (<= 16), rounded up
 #define QT_THREADS ((int)blockDim.x)   // 256 (small quotas) or 1024 (large ones): see gfo_launch_quadtree
 
 struct QtBox {
@@ -134,7 +135,7 @@ __device__ __forceinline__ QtBox qt_child_box(QtBox b, int q)
 #undef QT_STATE_BASE
 
 #define QT_KERNEL k_quadtree_gmem
-#define QT_STATE_BASE uint8_t* lds = scratch + ((unsigned long long)blockIdx.y * gridDim.x + blockIdx.x) * scratch_stride;
+#define QT_STATE_BASE uint8_t* lds = scratch + ((unsigned long long)(level0 + blockIdx.y) * gridDim.x + blockIdx.x) * scratch_stride;
 #include "k_quadtree_body.inc"
 #undef QT_KERNEL
 #undef QT_STATE_BASE
@@ -143,51 +144,109 @@ size_t gfo_quadtree_lds_bytes(int ncap, int klds)
 {
     int p2 = 1;
     while (p2 < ncap) p2 <<= 1;
-    return (size_t)p2 * 8 + (size_t)ncap * (2 * sizeof(QtBox) + 2 * 4 + 4 * 4 + 4 * 4 + 3 * 4) + QT_MAX_THREADS * 4 + (size_t)klds * 6 + 64;
+    return (size_t)p2 * 8 + (size_t)ncap * (2 * sizeof(QtBox) + 2 * 4 + 4 * 4 + 4 * 4 + 3 * 4) + QT_PART * 4 + (size_t)klds * 6 + 64;
+}
+
+// Keys a level keeps in LDS (6 B each): seven times its quota, in steps of 512, at most `cap`.  Measured candidate counts per
+// level are 2-6 x the quota (752x480 @2000: level 0 up to 2700 for a quota of 434, level 7 ~550 for 122); a level with more
+// candidates than that runs the same code on its keys in L2.
+static int qt_level_klds(const GfoLevel& L, int cap)
+{
+    int k = ((7 * L.quota > 1024 ? 7 * L.quota : 1024) + 511) & ~511;
+    if (k > L.cand_cap) k = (L.cand_cap + 63) & ~63;
+    return k < cap ? k : cap;
 }
 
 void gfo_launch_quadtree(gfo_ctx* c, int nimg)
 {
+    const int nl = c->g.nlevels;
     int ncap = 0;
-    for (int l = 0; l < c->g.nlevels; l++) ncap = c->g.lv[l].node_cap > ncap ? c->g.lv[l].node_cap : ncap;
-    // keys kept in LDS (6 B each, up to 6144 of them).  Alone, a large batch ran 4 % faster with the keys in L2 (four
-    // workgroups per CU instead of two); in the running pipeline LDS-resident keys win (214.4k -> 219.1k frames/s,
-    // same-box A/B: less L2 traffic next to the other contexts' kernels, and fewer quadtree workgroups per CU leave the
-    // wave slots to kernels that use them).  For a handful of images (the per-frame latency path) the level-0 workgroup IS
-    // the critical path: LDS-resident keys and 1024 threads (0.237 -> 0.214 ms per stereo frame).
+    for (int l = 0; l < nl; l++) ncap = c->g.lv[l].node_cap > ncap ? c->g.lv[l].node_cap : ncap;
+    // Keys kept in LDS (6 B each).  Alone, a large batch ran 4 % faster with the keys in L2 (four workgroups per CU instead
+    // of two); in the running pipeline LDS-resident keys win (214.4k -> 219.1k frames/s, same-box A/B: less L2 traffic next to
+    // the other contexts' kernels).  For a handful of images (the per-frame latency path) the level-0 workgroup IS the critical
+    // path: 6144 keys of LDS and 1024 threads (0.237 -> 0.214 ms per stereo frame).
+    // Round 5: batches keep 7 x quota keys of the LARGEST level instead of 6144 (752x480 @2000: 3072; measured candidate counts
+    // are <= 2700 at level 0, ~2000 below) and the scan scratch is one int per wave instead of per thread: 75 -> 52.7 KB per
+    // workgroup = THREE workgroups per CU instead of two for all eight levels.  k_quadtree alone 163 -> 116 us per 256 images
+    // (profiles/quadtree_occupancy_r05.txt); a level with more candidates than that runs on its keys in L2, same code.
     static const int klds_env = getenv("GFO_QT_KLDS") ? atoi(getenv("GFO_QT_KLDS")) : -1;
     const bool few = nimg <= 8;
-    int klds = klds_env >= 0 ? klds_env : 6144;
+    int klds = klds_env >= 0 ? klds_env : (few ? 6144 : qt_level_klds(c->g.lv[0], 6144));
     while (klds > 0 && gfo_quadtree_lds_bytes(ncap, klds) > 150 * 1024) klds -= 1024;
     const size_t lds = gfo_quadtree_lds_bytes(ncap, klds);
     const bool gmem = lds > 160 * 1024;   // state of the largest level does not fit LDS: scratch in HBM (plan() sized it)
-    if (!gmem && lds > 64 * 1024 && lds > c->qt_lds_granted) {
-        // raised per context (= per device; contexts may be driven from different threads): the grant only grows
-        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_quadtree), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) {
-            (void)hipGetLastError();
-            if (c->launch_err.empty()) c->launch_err = std::string("stage quadtree: cannot raise the dynamic LDS limit: ") + hipGetErrorString(e);
-            return;
-        }
-        c->qt_lds_granted = lds;
-    }
-    dim3 grid(nimg, c->g.nlevels);
     // the per-pass key loops are latency-bound inside a workgroup: large quotas (1080p @4000 features) get
     // 1024 threads per (image, level), the 752x480 @2000 case runs best with 256
     static const int nt_env = getenv("GFO_QT_THREADS") ? atoi(getenv("GFO_QT_THREADS")) : 0;
     const bool nt_ok = nt_env >= 64 && nt_env <= QT_MAX_THREADS && (nt_env & 63) == 0;   // anything else: the default
     // (with LDS-resident keys 128 / 192 / 256 threads give the same pipeline rate, 219k; 256 is the fastest alone: 96 us)
     const int nthreads = nt_ok ? nt_env : (c->g.lv[0].quota >= 600 && nimg < 48 ? 1024 : (few ? 1024 : 256));
+
+    // Level groups (round 5, opt-in: GFO_QT_GROUPS=auto | a,b).  The dynamic LDS of a launch is one figure for all its
+    // workgroups, sized by level 0, although level 7 (122 nodes, ~550 keys) needs 16 KB.  With GFO_QT_GROUPS a batch is launched
+    // as up to three consecutive level ranges, each with the node and key capacity of ITS first (largest) level (`auto`: ranges
+    // cut where the workgroups a CU can hold -- LDS, and 24 waves -- step from <= 3 to 4-5 to >= 6; `a,b`: cut in front of
+    // levels a and b).  MEASURED AND NOT ADOPTED: 136-148 us alone against 116 us for the single launch at three workgroups per
+    // CU -- a launch boundary makes the small levels wait for the slowest level-0 workgroup instead of back-filling behind it --
+    // and the pipeline rate is the same within noise for every form (277.6-281.5k frames/s).  Kept as a knob, parity-tested.
+    struct Grp { int l0, n, ncap, klds; size_t lds; };
+    Grp grp[GFO_MAX_LEVELS];
+    int ngrp = 0;
+    const char* groups_env = getenv("GFO_QT_GROUPS");   // (read per launch: the tests switch it inside one process)
+    const bool auto_groups = groups_env && groups_env[0] == 'a';
+    const bool grouped = !gmem && !few && groups_env && !(groups_env[0] == '0' && groups_env[1] == 0);
+    if (grouped) {
+        int cut_a = -1, cut_b = -1;
+        if (!auto_groups) sscanf(groups_env, "%d,%d", &cut_a, &cut_b);
+        const int wave_wgs = 24 / (nthreads / 64) > 0 ? 24 / (nthreads / 64) : 1;
+        int prev_class = -1;
+        for (int l = 0; l < nl; l++) {
+            const GfoLevel& L = c->g.lv[l];
+            const int kl = qt_level_klds(L, klds);
+            const size_t need = gfo_quadtree_lds_bytes(L.node_cap, kl);
+            int wgs = (int)((size_t)160 * 1024 / ((need + 1279) / 1280 * 1280));
+            if (wgs > wave_wgs) wgs = wave_wgs;
+            const int cls = wgs <= 3 ? 0 : (wgs <= 5 ? 1 : 2);
+            const bool cut = auto_groups ? (cls != prev_class) : (l == cut_a || l == cut_b);
+            if (l == 0 || cut) {
+                grp[ngrp].l0 = l; grp[ngrp].n = 0; grp[ngrp].ncap = L.node_cap; grp[ngrp].klds = kl; grp[ngrp].lds = need;
+                ngrp++;
+            }
+            Grp& G = grp[ngrp - 1];
+            G.n++;
+            if (L.node_cap > G.ncap) G.ncap = L.node_cap;      // (quotas shrink with the level; kept general)
+            if (kl > G.klds) G.klds = kl;
+            G.lds = gfo_quadtree_lds_bytes(G.ncap, G.klds);
+            prev_class = cls;
+        }
+    } else {
+        grp[0].l0 = 0; grp[0].n = nl; grp[0].ncap = ncap; grp[0].klds = klds; grp[0].lds = lds;
+        ngrp = 1;
+    }
+    size_t lds_max = 0;
+    for (int i = 0; i < ngrp; i++) lds_max = grp[i].lds > lds_max ? grp[i].lds : lds_max;
+    if (!gmem && lds_max > 64 * 1024 && lds_max > c->qt_lds_granted) {
+        // raised per context (= per device; contexts may be driven from different threads): the grant only grows
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_quadtree), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max);
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            if (c->launch_err.empty()) c->launch_err = std::string("stage quadtree: cannot raise the dynamic LDS limit: ") + hipGetErrorString(e);
+            return;
+        }
+        c->qt_lds_granted = lds_max;
+    }
     static const bool timing = getenv("GFO_QT_TIMING") != nullptr;
     unsigned long long* d_ts = nullptr;
     if (timing && hipMalloc(&d_ts, 128 * sizeof(unsigned long long)) == hipSuccess) (void)hipMemsetAsync(d_ts, 0, 128 * sizeof(unsigned long long), c->stream);
     gfo_prof_begin(c, ST_QUADTREE);
     if (gmem)
-        GFO_LAUNCH(c, k_quadtree_gmem, grid, dim3(1024), 0, c->stream, c->d_geom, c->d_cand, c->d_cand_cnt, c->d_node_of,
-                           c->d_sel, c->d_sel_cnt, c->d_flags, ncap, 0, d_ts, c->d_qt_scratch, (unsigned long long)c->qt_scratch_stride);
+        GFO_LAUNCH(c, k_quadtree_gmem, dim3(nimg, nl), dim3(1024), 0, c->stream, c->d_geom, c->d_cand, c->d_cand_cnt, c->d_node_of,
+                           c->d_sel, c->d_sel_cnt, c->d_flags, ncap, 0, 0, d_ts, c->d_qt_scratch, (unsigned long long)c->qt_scratch_stride);
     else
-        GFO_LAUNCH(c, k_quadtree, grid, dim3(nthreads), lds, c->stream, c->d_geom, c->d_cand, c->d_cand_cnt, c->d_node_of,
-                           c->d_sel, c->d_sel_cnt, c->d_flags, ncap, klds, d_ts, (uint8_t*)nullptr, 0ull);
+        for (int i = 0; i < ngrp; i++)
+            GFO_LAUNCH(c, k_quadtree, dim3(nimg, grp[i].n), dim3(nthreads), grp[i].lds, c->stream, c->d_geom, c->d_cand, c->d_cand_cnt, c->d_node_of,
+                               c->d_sel, c->d_sel_cnt, c->d_flags, grp[i].ncap, grp[i].klds, grp[i].l0, d_ts, (uint8_t*)nullptr, 0ull);
     if (d_ts) {   // debugging aid: blocks until the kernel is done and prints the phase times of block (0, 0)
         unsigned long long ts[128];
         (void)hipStreamSynchronize(c->stream);

@@ -247,3 +247,28 @@ def test_fast_queue_overflow_paths(oracle, monkeypatch, qcap):
             gc = sorted(map(tuple, ext.debug_level_candidates(l).tolist()))
             assert gc == oc, f"FAST candidates differ at level {l} (thresholds {ini}/{mn}, queue {qcap})"
         ext.close()
+
+
+@pytest.mark.parametrize("groups", ["auto", "2,5", "1,99", "0"])
+def test_quadtree_level_groups_and_key_overflow_to_l2(oracle, monkeypatch, groups):
+    """k_quadtree launched as level ranges with their own node / key capacity (GFO_QT_GROUPS, opt-in: measured, not the default,
+    profiles/quadtree_occupancy_r05.txt) and the batch default of 7 x quota LDS keys: a batch of 12 images (the grouped forms apply
+    from 9 images on) among them noise frames whose level-0 candidate count exceeds the LDS key capacity (those workgroups run on
+    their keys in L2) -- every image equals the oracle."""
+    import gf_orb_slam2_amd as G
+    monkeypatch.setenv("GFO_QT_GROUPS", groups)
+    rng = np.random.default_rng(3)
+    imgs = [synth_frame(752, 480, 60 + i) for i in range(10)]
+    noisy = synth_frame(752, 480, 7).astype(np.int32) + rng.integers(-60, 60, (480, 752))      # many more FAST candidates per level
+    imgs += [np.clip(noisy, 0, 255).astype(np.uint8), rng.integers(0, 256, (480, 752), dtype=np.uint8)]
+    ext = G.ORBextractor(2000, 1.2, 8, 20, 7, max_batch=len(imgs))
+    oe = oracle.OracleExtractor(2000, 1.2, 8, 20, 7)
+    ks, ds = ext.extract_batch(imgs)
+    most = 0
+    for i, img in enumerate(imgs):
+        ok, od = oe(img)
+        most = max(most, max(len(oe.level_candidates(l)) for l in range(8)))
+        assert ks[i].tobytes() == ok.tobytes(), (groups, i)
+        assert ds[i].tobytes() == od.tobytes(), (groups, i)
+    assert most > 3072          # the L2-key path was taken by at least one (image, level)
+    ext.close()

@@ -134,7 +134,7 @@ def test_matcher_on_closed_extractor_raises():
 
 def test_bench_reads_the_pmc_csv_per_stage_and_step(tmp_path):
     """bench.py's reader of rocprofv3's counter_collection.csv: KiB per dispatch -> bytes per stage and step (a step is one
-    k_quadtree launch; the pyramid is several launches per step; the SAD matcher is not the stereo stage)."""
+    k_fast launch; the pyramid and the quadtree are several launches per step; the SAD matcher is not the stereo stage)."""
     import importlib.util
     import os
     spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py"))
@@ -144,7 +144,7 @@ def test_bench_reads_the_pmc_csv_per_stage_and_step(tmp_path):
     for step in range(3):
         rows += [f"{10 * step},k_resize(GfoGeom const*),FETCH_SIZE,100", f"{10 * step + 1},k_resize(GfoGeom const*),FETCH_SIZE,50",
                  f"{10 * step + 2},k_resize_tail(x),FETCH_SIZE,10", f"{10 * step + 3},\"void k_fast<48, 44, true>(x)\",FETCH_SIZE,64",
-                 f"{10 * step + 4},k_quadtree(x),FETCH_SIZE,4", f"{10 * step + 5},k_stereo_match_sad(x),FETCH_SIZE,999",
+                 f"{10 * step + 4},k_quadtree(x),FETCH_SIZE,3", f"{10 * step + 8},k_quadtree(x),FETCH_SIZE,1", f"{10 * step + 5},k_stereo_match_sad(x),FETCH_SIZE,999",
                  f"{10 * step + 6},k_stereo_match(x),FETCH_SIZE,8", f"{10 * step + 7},k_fast(x),WRITE_SIZE,7"]
     p = tmp_path / "counter_collection.csv"
     p.write_text("\n".join(rows) + "\n")
@@ -152,7 +152,7 @@ def test_bench_reads_the_pmc_csv_per_stage_and_step(tmp_path):
     assert steps == 3
     assert per["resize"] == 160 * 1024 and per["fast"] == 64 * 1024 and per["quadtree"] == 4 * 1024 and per["stereo_match"] == 8 * 1024
     per_w, _ = bench.pmc_bytes_per_step(str(p), "WRITE_SIZE")
-    assert per_w == {}            # no quadtree launch carries WRITE_SIZE in this file: no step count, nothing reported
+    assert per_w == {"fast": 7 * 1024}
 
 
 def test_adapter_context_table_keeps_live_extractors_and_retires_dead_ones():

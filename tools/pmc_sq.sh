@@ -19,7 +19,7 @@ for sub in ('a','b'):
         line = k + ' ' + ' '.join(f"{c}={sum(x)/len(x):.4g}" for c,x in sorted(v.items()))
         print(line)
         open(os.path.join(root, 'summary.txt'), 'a').write(line + '\n')
-# per stage and STEP (a step = one k_quadtree launch; the pyramid is several launches per step): what bench.py's issue_frac reads
+# per stage and STEP (a step = one k_fast launch; the pyramid is several launches per step): what bench.py's issue_frac reads
 import json, sys
 sys.path.insert(0, os.environ['GRAFT_REPO_ROOT'])
 from bench import STAGE_OF_KERNEL
@@ -32,7 +32,7 @@ for sub in ('a','b'):
         for pat, st in STAGE_OF_KERNEL:
             if pat in kn and not (pat == 'k_stereo_match' and 'sad' in kn):
                 per[st][row['Counter_Name']] += float(row['Counter_Value'])
-                if st == 'quadtree': steps[row['Counter_Name']] += 1
+                if st == 'fast': steps[row['Counter_Name']] += 1
                 break
 out = {st: {c: v / max(1, steps.get(c, 0) or max(steps.values())) for c, v in cs.items()} for st, cs in per.items()}
 json.dump({"workload": "stereo752", "batch": 256, "per_stage_per_step": out,

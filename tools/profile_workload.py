@@ -91,7 +91,7 @@ def main():
         for pat, st in STAGE_OF_KERNEL:
             if pat in kn and not (pat == "k_stereo_match" and "sad" in kn):
                 acc[st][row["Counter_Name"]] += float(row["Counter_Value"])
-                if st == "quadtree":
+                if st == "fast":
                     nsteps[row["Counter_Name"]] += 1
                 break
     n = max(nsteps.values()) if nsteps else 1

@@ -60,13 +60,13 @@ def main():
     # (4 B per lane): k_fast reads every level exactly once and FETCH_SIZE*1024 comes out at 1.00-1.03x
     # that byte count, so no 2x correction is applied (the gfx950 halving concerns 16 B/lane streams).
     # a stage may be several launches per step (the banded pyramid is two, the per-level fallback up to seven):
-    # stage bytes per step = all bytes of the stage's kernels / steps, steps = launches of k_quadtree (one per step)
+    # stage bytes per step = all bytes of the stage's kernels / steps, steps = launches of k_fast (one per step; the quadtree is up to three level-group launches)
     stage_of = (("k_resize", "resize"), ("k_pyramid_bands", "resize"), ("k_blur", "blur"), ("k_fast", "fast"), ("k_quadtree", "quadtree"),
                 ("k_orient_desc", "orient_desc"), ("k_stereo_bucket", "stereo_bucket"), ("k_stereo_match", "stereo_match"),
                 ("k_stereo_cut", "stereo_cut"))
     traffic, traffic_x2 = {}, {}
     for cname in ("FETCH_SIZE", "WRITE_SIZE"):
-        steps = max([v["launches"] for k, v in out[cname].items() if "k_quadtree" in k] or [1])
+        steps = max([v["launches"] for k, v in out[cname].items() if "k_fast" in k] or [1])
         for k, v in out[cname].items():
             for pat, st in stage_of:
                 if pat in k and not (pat == "k_stereo_match" and "sad" in k):
