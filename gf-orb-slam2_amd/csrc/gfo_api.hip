@@ -529,7 +529,6 @@ extern "C" const char* gfo_last_error(const gfo_ctx* ctx) { return ctx ? ctx->er
 // locking is worth there, this library no longer depends on it: the first gfo_ctx_create on a device resolves every kernel
 // of every translation unit (hipFuncGetAttributes = load + register, no launch) under one mutex, and later contexts find
 // the device marked.  GFO_PRELOAD=0 restores the lazy behaviour (experiments only).
-struct GfoPack;
 static void gfo_kernels_api(std::vector<const void*>& v);
 static std::mutex g_preload_mu;
 static uint64_t g_preloaded_devices = 0;
@@ -750,17 +749,6 @@ static int run_pyramid(gfo_ctx* c, const GfoInput& in, int nimg)
     return GFO_OK;
 }
 
-// Results of a small batch, gathered by ONE kernel straight into the context's pinned host buffer (mapped into the
-// device's address space): nine separate D2H copies cost ~75 us of copy-engine latency on the per-frame path
-// (profiles/latency_timeline_r02.txt), this costs ~10 us of PCIe writes at the end of the captured launch sequence.
-#define GFO_PACK_MAX 10
-struct GfoPack {
-    const uint4* src[GFO_PACK_MAX];
-    uint4* dst[GFO_PACK_MAX];
-    int n16[GFO_PACK_MAX];     // 16-byte units
-    int nseg;
-};
-
 __global__ __launch_bounds__(256) void k_pack_results(GfoPack p)
 {
     const int t = blockIdx.x * 256 + threadIdx.x, stride = gridDim.x * 256;
@@ -781,6 +769,7 @@ static GfoStereoLaunch stereo_batch_launch(gfo_ctx* c, const gfo_stereo_params& 
     sl.out = c->st; sl.out_stride = c->g.kp_stride;
     sl.sort = c->st_sort; sl.sort_stride = c->g.kp_stride;
     sl.window = gfo_stereo_window(c->scale.data(), c->g.nlevels);
+    sl.nlevels = c->g.nlevels;
     return sl;
 }
 
@@ -844,12 +833,18 @@ static int extract_launches(gfo_ctx* c, const GfoInput& in, int nimg, const gfo_
 #undef GFO_PACE_POINT
     if (c->launch_err.empty() && sp) {
         c->last_nimg = nimg;
-        gfo_launch_stereo(c, stereo_batch_launch(c, *sp));
+        GfoStereoLaunch sl = stereo_batch_launch(c, *sp);
+        sl.cut_in_pack = pack && pack->cut_pairs > 0;      // the per-frame path: the pack kernel's first workgroups make the cut
+        gfo_launch_stereo(c, sl);
     }
     if (c->launch_err.empty() && pack) {
-        int total = 0;
-        for (int s_ = 0; s_ < pack->nseg; s_++) total += pack->n16[s_];
-        GFO_LAUNCH(c, k_pack_results, dim3((total + 1023) / 1024 > 0 ? (total + 1023) / 1024 : 1), dim3(256), 0, c->stream, *pack);
+        if (pack->cut_pairs > 0) {
+            gfo_launch_pack_cut(c, *pack, c->stream);
+        } else {
+            int total = 0;
+            for (int s_ = 0; s_ < pack->nseg; s_++) total += pack->n16[s_];
+            GFO_LAUNCH(c, k_pack_results, dim3((total + 1023) / 1024 > 0 ? (total + 1023) / 1024 : 1), dim3(256), 0, c->stream, *pack);
+        }
     }
     return GFO_OK;
 }
@@ -1259,11 +1254,20 @@ int gfo_small_submit(gfo_ctx* c, const GfoSmallLayout& L, int nimg, const gfo_st
     seg(c->d_kp, L.o_kp, sizeof(gfo_keypoint) * (size_t)ks * nimg);
     seg(c->d_desc, L.o_ds, 32 * (size_t)ks * nimg);
     if (sp) {
-        seg(c->st.u_right, L.o_ur, 4 * (size_t)ks * npair);
-        seg(c->st.depth, L.o_dp, 4 * (size_t)ks * npair);
+        // u_right / depth / nmatched reach the host block from the cut itself, made by the pack kernel's first workgroups
+        // (GFO_STEREO_CUT_IN_PACK=0: k_stereo_cut as a launch of its own, then plain copies)
+        static const bool cut_in_pack = !(getenv("GFO_STEREO_CUT_IN_PACK") && getenv("GFO_STEREO_CUT_IN_PACK")[0] == '0');
+        if (cut_in_pack && npair > 0) {
+            pk.cut_pairs = (int)npair; pk.cut_cnt_dev = c->d_kp_cnt; pk.cut_nl_host = 0; pk.cut_out = c->st; pk.cut_out_stride = ks;
+            pk.h_u_right = reinterpret_cast<float*>(H + L.o_ur); pk.h_depth = reinterpret_cast<float*>(H + L.o_dp);
+            pk.h_nmatched = reinterpret_cast<int*>(H + L.o_nm);
+        } else {
+            seg(c->st.u_right, L.o_ur, 4 * (size_t)ks * npair);
+            seg(c->st.depth, L.o_dp, 4 * (size_t)ks * npair);
+            seg(c->st.nmatched, L.o_nm, 4 * npair);             // allocated with 16 bytes of slack (plan)
+        }
         seg(c->st.best_dist, L.o_bd, 4 * (size_t)ks * npair);
         seg(c->st.best_idx, L.o_bi, 4 * (size_t)ks * npair);
-        seg(c->st.nmatched, L.o_nm, 4 * npair);             // allocated with 16 bytes of slack (plan)
     }
     (void)copy_in;   // the images are on their way already (gfo_small_upload)
     GfoInput in{c->d_input, pitch, (long long)L.img_bytes};
@@ -1354,6 +1358,7 @@ int gfo_small_submit_pairs(gfo_ctx* c, const GfoSmallLayout& L, int npairs, cons
     sl.min_d = reinterpret_cast<const float*>(d_stage + b.o_min);
     sl.max_d = reinterpret_cast<const float*>(d_stage + b.o_max);
     sl.win_stride = (long long)(b.bytes / 4);
+    sl.cut_in_pack = true;            // the pack kernel below makes the cut
     gfo_launch_stereo(c, sl);
     if (int lrc = gfo_take_launch_err(c)) return lrc;
     uint8_t* H = c->h_out;
@@ -1361,14 +1366,13 @@ int gfo_small_submit_pairs(gfo_ctx* c, const GfoSmallLayout& L, int npairs, cons
     auto seg = [&](const void* src, size_t dst_off, size_t bytes) {
         pk.src[pk.nseg] = (const uint4*)src; pk.dst[pk.nseg] = (uint4*)(H + dst_off); pk.n16[pk.nseg] = (int)((bytes + 15) / 16); pk.nseg++;
     };
-    seg(c->st.u_right, L.o_ur, 4 * (size_t)ks * npairs);
-    seg(c->st.depth, L.o_dp, 4 * (size_t)ks * npairs);
+    pk.cut_pairs = npairs; pk.cut_cnt_dev = c->d_kp_cnt; pk.cut_nl_host = 0; pk.cut_out = c->st; pk.cut_out_stride = ks;
+    pk.h_u_right = reinterpret_cast<float*>(H + L.o_ur); pk.h_depth = reinterpret_cast<float*>(H + L.o_dp);
+    pk.h_nmatched = reinterpret_cast<int*>(H + L.o_nm);
     seg(c->st.best_dist, L.o_bd, 4 * (size_t)ks * npairs);
     seg(c->st.best_idx, L.o_bi, 4 * (size_t)ks * npairs);
-    seg(c->st.nmatched, L.o_nm, 4 * (size_t)npairs);
-    int total = 0;
-    for (int s_ = 0; s_ < pk.nseg; s_++) total += pk.n16[s_];
-    hipLaunchKernelGGL(k_pack_results, dim3((total + 1023) / 1024 > 0 ? (total + 1023) / 1024 : 1), dim3(256), 0, st, pk);
+    gfo_launch_pack_cut(c, pk, st);
+    if (int lrc = gfo_take_launch_err(c)) return lrc;
     HIP_TRY(c, hipGetLastError());
     HIP_TRY(c, hipStreamSynchronize(st));
     c->have_batch = c->have_stereo = false;     // the arena holds unpacked host arrays, not an extraction
@@ -1657,6 +1661,7 @@ extern "C" int gfo_stereo_match(gfo_ctx* c, const gfo_keypoint* kl, const uint8_
     sl.sort = GfoStereoSort{(float*)(S + o_sx), (float*)(S + o_sy), (unsigned*)(S + o_soi), S + o_sd, (int*)(S + o_rs), (int*)(S + o_lo), (int*)(S + o_lrs)};
     sl.sort_stride = nr1;
     sl.window = gfo_stereo_window(sf, nlevels);
+    sl.nlevels = nlevels;
     gfo_launch_stereo(c, sl);
     if (int lrc = gfo_take_launch_err(c)) return lrc;
     HIP_TRY(c, hipGetLastError());

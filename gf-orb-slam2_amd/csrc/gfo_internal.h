@@ -98,6 +98,28 @@ struct GfoStereoDev {
     unsigned char* counted;  // [pairs][kp_stride] 1 where the reference's loop reaches nmatched++ (Frame.cc:1286)
 };
 
+// Results of a small batch, gathered by ONE kernel straight into the context's pinned host buffer (mapped into the
+// device's address space): nine separate D2H copies cost ~75 us of copy-engine latency on the per-frame path
+// (profiles/latency_timeline_r02.txt), this costs ~10 us of PCIe writes at the end of the launch sequence.
+// cut_pairs > 0 (round 5): the first `cut_pairs` workgroups of the kernel make the outlier cut of one stereo pair each
+// (Frame.cc:1290-1313, what k_stereo_cut does as a launch of its own) and write that pair's final u_right / depth / nmatched
+// to the device arrays AND to the host block; the other workgroups copy the segments (k_pack_results_cut, k_stereo.hip).
+#define GFO_PACK_MAX 10
+struct GfoPack {
+    const uint4* src[GFO_PACK_MAX];
+    uint4* dst[GFO_PACK_MAX];
+    int n16[GFO_PACK_MAX];     // 16-byte units
+    int nseg;
+    int cut_pairs;
+    const int* cut_cnt_dev;
+    int cut_nl_host;
+    GfoStereoDev cut_out;
+    int cut_out_stride;
+    float* h_u_right;          // host (mapped) destinations of the cut's outputs, [pairs][cut_out_stride] / [pairs]
+    float* h_depth;
+    int* h_nmatched;
+};
+
 // right keypoints of a pair counting-sorted by floor(y), compact SoA (k_stereo_bucket)
 struct GfoStereoSort {
     float* sx;
@@ -121,6 +143,8 @@ struct GfoStereoLaunch {
     GfoStereoDev out; int out_stride;
     GfoStereoSort sort; int sort_stride;
     int window;
+    int nlevels;          // entries of d_scale
+    bool cut_in_pack;     // the caller's pack kernel makes the outlier cut (GfoPack::cut_pairs): no k_stereo_cut launch
 };
 
 // work buffers of the batched projection search (k_project.hip), one block per frame
@@ -286,6 +310,7 @@ void gfo_launch_fast(gfo_ctx* c, const GfoInput& in, int nimg);
 void gfo_launch_quadtree(gfo_ctx* c, int nimg);
 void gfo_launch_orient_desc(gfo_ctx* c, const GfoInput& in, int nimg);
 void gfo_launch_stereo(gfo_ctx* c, const GfoStereoLaunch& s);
+void gfo_launch_pack_cut(gfo_ctx* c, const GfoPack& p, hipStream_t st);   // k_pack_results with the stereo cut in it (GfoPack::cut_pairs)
 int gfo_stereo_window(const float* scale, int nlevels);
 void gfo_launch_stereo_sad(gfo_ctx* c, const GfoStereoLaunch& s, const GfoInput& in, const float* d_inv_scale);
 

@@ -61,6 +61,7 @@ struct StereoArgs {
     int* lrow_start;          // [pairs][n_rows + 1]
     int sort_stride;
     int window;               // W
+    int nlevels;              // entries of `scale`
 };
 
 // Minimum / sum over the 32 lanes of a half (or all 64), left in every lane: DPP steps inside the 16-lane rows (lane ^ 1,
@@ -285,6 +286,162 @@ __global__ __launch_bounds__(256) void k_stereo_match(StereoArgs a)
     }
 }
 
+// ---- one to three pairs: the association straight from the extractor's arrays, no bucketing launch (round 5) ----
+// The per-frame path (Frame::Frame: ONE stereo pair per call) is a chain of launches of 7-12 us each; k_stereo_bucket was one of
+// them (9-12 us: two workgroups of latency chains) only to hand k_stereo_match a row-sorted copy.  Here every workgroup first
+// packs ALL right keypoints into LDS as 8-byte records {row band minr | maxr << 16 (Frame.h:248-256), x} -- nr x 28 bytes out
+// of L2, ~15 vector operations per keypoint and thread -- and each wavefront then sweeps that table for its left keypoints:
+// the band test (97 % of the table fails it) costs one 8-byte LDS read and two compares per candidate, octave / disparity
+// window / Hamming only for the band's members, read from the arrays where the extractor left them.  Candidates are visited
+// in iR order by construction (lane j, j + 64, ...; the wave minimum of dist << 16 | iR is the first minimum, :1260).
+// Survivors of band, octave and disparity window are compacted (ballot) into a per-wave list and scored on full lanes, so
+// the sweep itself holds no global load.  Measured per stereo frame (profiles/stereo_direct_r05.txt): staging 4.6 us +
+// sweep and scoring 5.6 us = 10.2 us against 9.2 (bucket) + 7.3 (match); ONE left keypoint per wavefront and eight
+// wavefronts per workgroup: a lone wave per SIMD retires a dependent instruction every ~9 cycles, so instructions per wave --
+// not total work -- set the time (four keypoints per wave, swept together: 24 us; two, one after the other: 20-30 us).
+#define SD_KP 1        // left keypoints per wavefront
+#define SD_WAVES 8     // wavefronts per workgroup (512 threads: 251 workgroups for 2008 left keypoints)
+#define SD_NT (64 * SD_WAVES)
+#define SD_LIST 128    // survivor slots per wavefront and keypoint (flushed when fewer than 64 are free)
+__global__ __launch_bounds__(SD_NT) void k_stereo_match_direct(StereoArgs a)
+{
+    extern __shared__ uint4 s_rec[];   // [nr] {minr | maxr << 16, x, octave, -}
+    __shared__ float s_scale[GFO_MAX_LEVELS];
+    __shared__ unsigned short s_list[SD_WAVES][SD_KP][SD_LIST];
+    const int pair = blockIdx.y, tid = threadIdx.x;
+    const int nl = a.cnt_dev ? a.cnt_dev[2 * pair] : a.nl_host;
+    const int nr = a.cnt_dev ? a.cnt_dev[2 * pair + 1] : a.nr_host;
+    if ((int)blockIdx.x * SD_WAVES * SD_KP >= nl) return;     // workgroup-uniform, before any barrier
+    const int nRows = a.p.n_rows;
+    const gfo_keypoint* kr = a.kr + pair * a.pair_stride;
+    if (tid < GFO_MAX_LEVELS) s_scale[tid] = tid < a.nlevels ? a.scale[tid] : 0.f;
+    // this wave's left keypoints, requested before the staging below so that their round trips overlap it
+    struct LeftKp { int iL; bool valid, in_rows; float vL, uL, minD, maxD; int oct; uint4 a0, a1; } Lv[SD_KP];
+    {
+        const gfo_keypoint* kl = a.kl + pair * a.pair_stride;
+        const uint8_t* dl = a.dl + pair * a.pair_stride * 32;
+        const int w_ = __builtin_amdgcn_readfirstlane(tid >> 6);
+#pragma unroll
+        for (int q = 0; q < SD_KP; q++) {
+            const int iL = ((int)blockIdx.x * SD_WAVES + w_) * SD_KP + q;
+            Lv[q].valid = iL < nl;
+            Lv[q].iL = min(iL, nl - 1);                  // an idle slot redoes the last keypoint, writes nothing
+            const gfo_keypoint L = kl[Lv[q].iL];
+            Lv[q].vL = L.y; Lv[q].uL = L.x; Lv[q].oct = L.octave;
+            Lv[q].in_rows = Lv[q].valid && !(L.y < 0 || L.y > (float)(nRows - 1));  // Frame.cc:1208
+            Lv[q].minD = 0.f; Lv[q].maxD = a.p.mbf / a.p.mb;                         // :1199-1200
+            if (a.min_d && a.max_d) {                                                // :1220-1231 flattened by the adapter
+                Lv[q].minD = a.min_d[pair * a.win_stride + Lv[q].iL];
+                Lv[q].maxD = a.max_d[pair * a.win_stride + Lv[q].iL];
+            }
+            const uint4* dlp = reinterpret_cast<const uint4*>(dl + (long long)Lv[q].iL * 32);
+            Lv[q].a0 = dlp[0]; Lv[q].a1 = dlp[1];
+        }
+    }
+    // the right keypoints' x / y / octave, four per thread in flight (the loop body is a chain of L2 round trips otherwise)
+    for (int j0 = 0; j0 < nr; j0 += 4 * SD_NT) {
+        float kx[4], ky[4];
+        int ko[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int j = min(j0 + u * SD_NT + tid, nr - 1);
+            kx[u] = kr[j].x; ky[u] = kr[j].y; ko[u] = kr[j].octave;
+        }
+        if (j0 == 0) __syncthreads();                   // s_scale
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int j = j0 + u * SD_NT + tid;
+            if (j >= nr) continue;
+            const float rr = 2.0f * s_scale[ko[u] & (GFO_MAX_LEVELS - 1)];
+            int maxr = (int)fminf((float)(nRows - 1), ceilf(ky[u] + rr));
+            int minr = (int)fmaxf(0.0f, floorf(ky[u] - rr));
+            if (minr > maxr) { minr = 1; maxr = 0; }    // a band that misses the image enters no row (Frame.h:256)
+            s_rec[j] = make_uint4((unsigned)minr | ((unsigned)maxr << 16), __float_as_uint(kx[u]), (unsigned)ko[u], 0u);
+        }
+    }
+    __syncthreads();
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    const uint4* dr = reinterpret_cast<const uint4*>(a.dr + pair * a.pair_stride * 32);
+    const unsigned long long lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));     // lanes below this one
+    // the wave's SD_KP left keypoints are swept TOGETHER: one LDS read of a right record serves all of them, and every
+    // dependent access (the record, later the survivors' descriptors) is a round trip paid once per wave, not per keypoint
+    unsigned row[SD_KP], nsurv[SD_KP], best[SD_KP];
+    float minU[SD_KP], maxU[SD_KP];
+    int octL[SD_KP];
+    bool any[SD_KP], inr[SD_KP];
+#pragma unroll
+    for (int q = 0; q < SD_KP; q++) {
+        row[q] = __builtin_amdgcn_readfirstlane(Lv[q].in_rows ? (int)Lv[q].vL : 0);
+        inr[q] = Lv[q].in_rows;
+        minU[q] = Lv[q].uL - Lv[q].maxD; maxU[q] = Lv[q].uL - Lv[q].minD;
+        octL[q] = Lv[q].oct;
+        nsurv[q] = 0; best[q] = ((unsigned)TH_HIGH << 16); any[q] = false;
+    }
+    auto score = [&](int q) {
+        for (unsigned k = lane; k < nsurv[q]; k += 64) {
+            const unsigned j = s_list[wave][q][k];
+            const unsigned dist = (unsigned)hamming256(Lv[q].a0, Lv[q].a1, dr[2 * j], dr[2 * j + 1]);
+            best[q] = min(best[q], (dist << 16) | j);
+        }
+        nsurv[q] = 0;
+    };
+    for (int j = lane; j - lane < nr; j += 64) {
+        uint4 r = make_uint4(1u, 0u, 0u, 0u);          // an empty band: matches no row
+        if (j < nr) r = s_rec[j];
+        const unsigned minr = r.x & 0xFFFFu, maxr = r.x >> 16;
+        const float rx = __uint_as_float(r.y);
+        const int oct = (int)r.z;
+#pragma unroll
+        for (int q = 0; q < SD_KP; q++) {
+            const bool band = inr[q] && !(row[q] < minr || row[q] > maxr);
+            any[q] = any[q] || band;
+            const bool keep = band && !(oct < octL[q] - 1 || oct > octL[q] + 1) && rx >= minU[q] && rx <= maxU[q];   // :1250, :1255
+            const unsigned long long m = __builtin_amdgcn_ballot_w64(keep);
+            if (m) {
+                if (keep) s_list[wave][q][nsurv[q] + __builtin_popcountll(m & lt)] = (unsigned short)j;
+                nsurv[q] += __builtin_popcountll(m);
+                if (nsurv[q] > SD_LIST - 64) score(q);
+            }
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < SD_KP; q++) {
+        if (!Lv[q].valid) continue;                     // wave-uniform
+        if (nsurv[q]) score(q);
+        const long long o = (long long)pair * a.out_stride + Lv[q].iL;
+        float res_u = -1.0f, res_depth = -1.0f;
+        int res_dist = -1, res_idx = -1, counted = 0;
+        const bool have_cands = __builtin_amdgcn_ballot_w64(any[q]) != 0;
+        const unsigned bst = st_wave_min(best[q]);
+        if (inr[q] && have_cands && !(maxU[q] < a.p.min_x)) {  // :1213, :1236
+            counted = 1;
+            const int bestDist = (int)(bst >> 16);
+            const int bestIdxR = (int)(bst & 0xFFFF);
+            if (bestDist < (TH_HIGH + TH_LOW) / 2) {  // :1269
+                float bestuR = __uint_as_float(s_rec[bestIdxR].y);
+                float disparity = Lv[q].uL - bestuR;
+                if (disparity >= Lv[q].minD && disparity < Lv[q].maxD) {
+                    if (disparity <= 0) {
+                        disparity = 0.01f;
+                        bestuR = (float)((double)Lv[q].uL - 0.01);   // `uL-0.01` is double arithmetic in the reference (Frame.cc:1278)
+                    }
+                    res_depth = a.p.mbf / disparity;
+                    res_u = bestuR;
+                    res_dist = bestDist;
+                    res_idx = bestIdxR;
+                }
+            }
+        }
+        if (lane == 0) {
+            a.out.u_right[o] = res_u;
+            a.out.depth[o] = res_depth;
+            a.out.best_dist[o] = res_dist;
+            a.out.best_idx[o] = res_idx;
+            a.out.counted[o] = (unsigned char)counted;
+        }
+    }
+}
+
 // ---- the association around rows ----
 #define SR_ROWS 72    // rows of the row table a workgroup needs: R + 2 W + 2
 #define SR_CL 64      // left records per pass (a band of 8 rows holds ~35)
@@ -455,17 +612,16 @@ __global__ __launch_bounds__(SR_THREADS) void k_stereo_match_rows(StereoArgs a, 
     }
 }
 
-__global__ __launch_bounds__(1024) void k_stereo_cut(const int* __restrict__ cnt_dev, int nl_host, GfoStereoDev out,
-                                                     int out_stride)
+// the outlier cut of one pair by one workgroup (any size); h_* (optional): host-mapped copies of the final outputs
+__device__ __forceinline__ void stereo_cut_pair(const int* __restrict__ cnt_dev, int nl_host, const GfoStereoDev& out, int out_stride, int pair,
+                                                int* hist, int* s_part, int* s_med, int* s_drop, int* s_cnt,
+                                                float* __restrict__ h_u, float* __restrict__ h_d, int* __restrict__ h_nm)
 {
-    __shared__ int hist[128];
-    __shared__ int s_part[16];
-    __shared__ int s_med, s_drop, s_cnt;
-    const int pair = blockIdx.x, tid = threadIdx.x, NT = blockDim.x;
+    const int tid = threadIdx.x, NT = blockDim.x;
     const int nl = cnt_dev ? cnt_dev[2 * pair] : nl_host;
     const long long o = (long long)pair * out_stride;
     if (tid < 128) hist[tid] = 0;
-    if (tid == 0) s_drop = 0, s_cnt = 0, s_med = 1 << 30;
+    if (tid == 0) *s_drop = 0, *s_cnt = 0, *s_med = 1 << 30;
     __syncthreads();
     int mine = 0;
     for (int i = tid; i < nl; i += NT) {
@@ -473,32 +629,80 @@ __global__ __launch_bounds__(1024) void k_stereo_cut(const int* __restrict__ cnt
         if (d >= 0) atomicAdd(&hist[d], 1);
         mine += out.counted[o + i];
     }
-    if (mine) atomicAdd(&s_cnt, mine);
+    if (mine) atomicAdd(s_cnt, mine);
     __syncthreads();
     // median = the distance whose running count first exceeds ndi / 2 (the element of rank ndi/2 in the sorted
     // list, :1297): a workgroup scan over the 128 bins instead of one thread walking them
     int ndi;
-    const int h = tid < 128 ? hist[tid] : 0;
+    int h = 0;
+    h = tid < 128 ? hist[tid] : 0;                // (NT >= 128 everywhere this is launched: one bin per thread)
     const int incl = st_block_incl_scan(h, s_part, &ndi);
-    if (tid < 128 && ndi > 0 && incl > ndi / 2) atomicMin(&s_med, tid);
+    if (tid < 128 && ndi > 0 && incl > ndi / 2) atomicMin(s_med, tid);
     __syncthreads();
     if (ndi == 0) {
-        if (tid == 0) out.nmatched[pair] = s_cnt;
+        if (h_u)
+            for (int i = tid; i < nl; i += NT) { h_u[o + i] = out.u_right[o + i]; h_d[o + i] = out.depth[o + i]; }
+        if (tid == 0) {
+            out.nmatched[pair] = *s_cnt;
+            if (h_nm) h_nm[pair] = *s_cnt;
+        }
         return;
     }
-    const float thDist = 1.5f * 1.4f * (float)s_med;  // :1298
+    const float thDist = 1.5f * 1.4f * (float)*s_med;  // :1298
     int drop = 0;
     for (int i = tid; i < nl; i += NT) {
         const int d = out.best_dist[o + i];
-        if (d >= 0 && !((float)d < thDist)) {
+        const bool cut = d >= 0 && !((float)d < thDist);
+        if (cut) {
             out.u_right[o + i] = -1.0f;
             out.depth[o + i] = -1.0f;
             drop++;
         }
+        if (h_u) {
+            h_u[o + i] = cut ? -1.0f : out.u_right[o + i];
+            h_d[o + i] = cut ? -1.0f : out.depth[o + i];
+        }
     }
-    if (drop) atomicAdd(&s_drop, drop);
+    if (drop) atomicAdd(s_drop, drop);
     __syncthreads();
-    if (tid == 0) out.nmatched[pair] = s_cnt - s_drop;
+    if (tid == 0) {
+        out.nmatched[pair] = *s_cnt - *s_drop;
+        if (h_nm) h_nm[pair] = *s_cnt - *s_drop;
+    }
+}
+
+__global__ __launch_bounds__(1024) void k_stereo_cut(const int* __restrict__ cnt_dev, int nl_host, GfoStereoDev out,
+                                                     int out_stride)
+{
+    __shared__ int hist[128];
+    __shared__ int s_part[16];
+    __shared__ int s_med, s_drop, s_cnt;
+    stereo_cut_pair(cnt_dev, nl_host, out, out_stride, blockIdx.x, hist, s_part, &s_med, &s_drop, &s_cnt, nullptr, nullptr, nullptr);
+}
+
+// k_pack_results with the cut in it (GfoPack::cut_pairs > 0): workgroups [0, cut_pairs) cut one pair each, the others copy
+__global__ __launch_bounds__(1024) void k_pack_results_cut(GfoPack p)
+{
+    if ((int)blockIdx.x < p.cut_pairs) {
+        __shared__ int hist[128];
+        __shared__ int s_part[16];
+        __shared__ int s_med, s_drop, s_cnt;
+        stereo_cut_pair(p.cut_cnt_dev, p.cut_nl_host, p.cut_out, p.cut_out_stride, blockIdx.x, hist, s_part, &s_med, &s_drop, &s_cnt,
+                        p.h_u_right, p.h_depth, p.h_nmatched);
+        return;
+    }
+    const int t = ((int)blockIdx.x - p.cut_pairs) * 1024 + threadIdx.x, stride = ((int)gridDim.x - p.cut_pairs) * 1024;
+    for (int s = 0; s < p.nseg; s++)
+        for (int i = t; i < p.n16[s]; i += stride) p.dst[s][i] = p.src[s][i];
+}
+
+void gfo_launch_pack_cut(gfo_ctx* c, const GfoPack& p, hipStream_t st)
+{
+    int total = 0;
+    for (int s_ = 0; s_ < p.nseg; s_++) total += p.n16[s_];
+    // 1024 threads: the cut is two passes of dependent loads over the pair's ~2000 entries -- two trips per thread instead of eight
+    const int copy_blocks = (total + 4095) / 4096 > 0 ? (total + 4095) / 4096 : 1;
+    GFO_LAUNCH(c, k_pack_results_cut, dim3(p.cut_pairs + copy_blocks), dim3(1024), 0, st, p);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -735,6 +939,7 @@ void gfo_launch_stereo(gfo_ctx* c, const GfoStereoLaunch& s)
     a.row_start = s.sort.row_start;
     a.sort_stride = s.sort_stride;
     a.window = s.window;
+    a.nlevels = s.nlevels;
     const int max_nl = s.cnt_dev ? s.out_stride : s.nl_host;
     if (max_nl <= 0) {
         (void)hipMemsetAsync(s.out.nmatched, 0, sizeof(int) * s.npairs, c->stream);
@@ -747,6 +952,23 @@ void gfo_launch_stereo(gfo_ctx* c, const GfoStereoLaunch& s)
     // from four pairs on; one to three pairs -- the per-frame path -- spread better as one half-wave per left keypoint
     // (a stereo frame: 0.207 ms against 0.212 with 120 row workgroups)
     const bool rows_form = rows_env != 0 && (s.npairs >= 4 || rows_env > 0) && s.sort.lorder && s.p.n_rows <= 65535 && R + 2 * s.window + 2 <= SR_ROWS;
+    // one to three pairs (the per-frame path): no bucketing launch at all, k_stereo_match_direct (GFO_STEREO_DIRECT=0, or any
+    // GFO_STEREO_ROWS setting, keeps the bucketed forms: the tests run all of them in one process)
+    const char* direct_env = getenv("GFO_STEREO_DIRECT");
+    const int max_nr = s.cnt_dev ? s.out_stride : s.nr_host;
+    const bool direct = !rows_form && rows_env < 0 && !(direct_env && direct_env[0] == '0') && s.npairs <= 3 && max_nr > 0 && max_nr <= 4096 && s.nlevels > 0 &&
+                        s.p.n_rows <= 65535;
+    if (direct) {
+        gfo_prof_begin(c, ST_STEREO);
+        GFO_LAUNCH(c, k_stereo_match_direct, dim3((max_nl + SD_WAVES * SD_KP - 1) / (SD_WAVES * SD_KP), s.npairs), dim3(SD_NT), (size_t)max_nr * sizeof(uint4), c->stream, a);
+        gfo_prof_end(c);
+        if (!s.cut_in_pack) {
+            gfo_prof_begin(c, ST_STEREO_CUT);
+            GFO_LAUNCH(c, k_stereo_cut, dim3(s.npairs), dim3(1024), 0, c->stream, s.cnt_dev, s.nl_host, s.out, s.out_stride);
+            gfo_prof_end(c);
+        }
+        return;
+    }
     a.lorder = rows_form ? s.sort.lorder : nullptr;
     a.lrow_start = rows_form ? s.sort.lrow_start : nullptr;
     gfo_prof_begin(c, ST_STEREO_BUCKET);
@@ -780,6 +1002,7 @@ void gfo_launch_stereo(gfo_ctx* c, const GfoStereoLaunch& s)
         GFO_LAUNCH(c, k_stereo_match, grid, dim3(64 * snw), 0, c->stream, a);
     }
     gfo_prof_end(c);
+    if (s.cut_in_pack) return;
     gfo_prof_begin(c, ST_STEREO_CUT);
     GFO_LAUNCH(c, k_stereo_cut, dim3(s.npairs), dim3(cut_threads), 0, c->stream, s.cnt_dev, s.nl_host, s.out, s.out_stride);
     gfo_prof_end(c);
@@ -792,4 +1015,5 @@ void gfo_kernels_stereo(std::vector<const void*>& v)
 {
     v.push_back((const void*)k_stereo_bucket); v.push_back((const void*)k_stereo_match); v.push_back((const void*)k_stereo_match_rows);
     v.push_back((const void*)k_stereo_cut); v.push_back((const void*)k_stereo_match_sad); v.push_back((const void*)k_stereo_cut_sad);
+    v.push_back((const void*)k_stereo_match_direct); v.push_back((const void*)k_pack_results_cut);
 }
