@@ -1409,7 +1409,7 @@ extern "C" int gfo_extract_batch(gfo_ctx* c, const uint8_t* const* imgs, int nim
         gfo_keypoint* kps[1] = {kp};
         uint8_t* ds[1] = {desc};
         c->have_batch = c->have_pyramid = c->have_stereo = false;   // the device-side state lives in the combiner's arena
-        if (c->pair) {      // one camera of a declared stereo rig: this frame and its partner's go down as ONE stereo request
+        if (gfo_has_pair(c)) {      // one camera of a declared stereo rig: this frame and its partner's go down as ONE stereo request
             const int prc = gfo_pair_extract(c, imgs[0], w, h, stride, kp, desc, cap, n);
             if (prc != GFO_COMBINE_DIRECT) return prc;
         }
@@ -1595,7 +1595,7 @@ extern "C" int gfo_stereo_match(gfo_ctx* c, const gfo_keypoint* kl, const uint8_
     if (nl == 0) return GFO_OK;
     // a declared stereo rig (gfo_ctx_pair) whose last frame these arrays are, bit for bit: the association was computed with that
     // frame (and arrays this library delivered need no validation)
-    if (c->pair && gfo_pair_lookup(c, kl, dl, nl, kr, dr, nr, sf, nlevels, p, min_d, max_d, u_right, depth, best_dist, best_idx_r, nmatched) == 0)
+    if (gfo_has_pair(c) && gfo_pair_lookup(c, kl, dl, nl, kr, dr, nr, sf, nlevels, p, min_d, max_d, u_right, depth, best_dist, best_idx_r, nmatched) == 0)
         return GFO_OK;
     // the kernels index scale[octave] (Frame.h:244, Frame.cc:1204-1206 do the same, unchecked): refuse what would read past it
     for (int i = 0; i < nl; i++)

@@ -138,6 +138,14 @@ struct GfoPair {
     }
 };
 
+// A context's rig (gfo_ctx::pair) may be declared, re-declared or dissolved by one thread (gfo_ctx_pair, gfo_ctx_destroy of the
+// partner) while another is entering gfo_extract on that context: the member is read and written through the atomic shared_ptr
+// functions only, and which side a context is on is asked of the rig itself, under its lock (round 5: tests/host/combine_tsan.cc
+// found the plain accesses racing).
+static inline std::shared_ptr<GfoPair> pair_of(const gfo_ctx* c) { return std::atomic_load(&c->pair); }
+static inline void set_pair(gfo_ctx* c, const std::shared_ptr<GfoPair>& P) { std::atomic_store(&c->pair, P); }
+bool gfo_has_pair(const gfo_ctx* c) { return pair_of(c) != nullptr; }
+
 namespace
 {
 typedef std::tuple<int, int, int, int, float, int, int, int> EngineKey;
@@ -243,7 +251,7 @@ extern "C" int gfo_combiner_counters(const gfo_ctx* c, int64_t* out, int n)
         std::lock_guard<std::mutex> lk(e->mu);
         v[0] = e->batches; v[1] = e->requests; v[2] = e->redone; v[3] = e->prepared; v[4] = e->broken ? 1 : 0;
     }
-    if (std::shared_ptr<GfoPair> P = c->pair) {
+    if (std::shared_ptr<GfoPair> P = pair_of(c)) {
         std::lock_guard<std::mutex> lk(P->mu);
         v[5] = P->speculated; v[6] = P->served; v[7] = P->solo;
     }
@@ -476,9 +484,9 @@ extern "C" int gfo_ctx_pair(gfo_ctx* left, gfo_ctx* right, const gfo_stereo_para
     if (left == right) return gfo_fail(left, GFO_ERR_INVALID, "a context cannot be its own stereo partner");
     if (left->device != right->device || memcmp(&left->prm, &right->prm, offsetof(gfo_params, max_batch)) != 0)
         return gfo_fail(left, GFO_ERR_INVALID, "stereo partners need equal extractor parameters and one device");
-    if (std::shared_ptr<GfoPair> P = left->pair) {      // the usual call: once per frame, nothing changes
+    if (std::shared_ptr<GfoPair> P = pair_of(left)) {      // the usual call: once per frame, nothing changes
         std::lock_guard<std::mutex> lk(P->mu);
-        if (P == right->pair && P->ctx[0] == left && P->ctx[1] == right) {
+        if (P == pair_of(right) && P->ctx[0] == left && P->ctx[1] == right) {
             if (memcmp(&P->sp, p, sizeof *p) != 0) {
                 P->sp = *p;
                 P->valid = false;
@@ -494,35 +502,37 @@ extern "C" int gfo_ctx_pair(gfo_ctx* left, gfo_ctx* right, const gfo_stereo_para
     gfo_pair_release(right);
     std::shared_ptr<GfoPair> P = std::make_shared<GfoPair>();
     P->ctx[0] = left; P->ctx[1] = right; P->sp = *p;
-    left->pair = P; left->pair_side = 0;
-    right->pair = P; right->pair_side = 1;
+    set_pair(left, P);
+    set_pair(right, P);
     return GFO_OK;
 }
 
 void gfo_pair_release(gfo_ctx* c)
 {
-    std::shared_ptr<GfoPair> P = c->pair;
+    std::shared_ptr<GfoPair> P = pair_of(c);
     if (!P) return;
     {
         std::unique_lock<std::mutex> lk(P->mu);
         while (P->state >= 2) P->cv.wait(lk);      // a frame is being executed for both sides: let it finish
-        P->ctx[c->pair_side] = nullptr;
+        for (int s = 0; s < 2; s++)
+            if (P->ctx[s] == c) P->ctx[s] = nullptr;
         P->valid = false;
         P->cv.notify_all();
     }
-    c->pair.reset();
+    set_pair(c, std::shared_ptr<GfoPair>());
 }
 
 // gfo_extract of a paired, combining context.  Returns GFO_COMBINE_DIRECT when the frame is not taken here (no partner, the
 // partner does not show up, other geometry): the caller goes on as if there were no pair.
 int gfo_pair_extract(gfo_ctx* c, const uint8_t* img, int w, int h, int stride, gfo_keypoint* kp, uint8_t* desc, int cap, int* n)
 {
-    std::shared_ptr<GfoPair> P = c->pair;
+    std::shared_ptr<GfoPair> P = pair_of(c);
     if (!P || (w & 15) != 0) return GFO_COMBINE_DIRECT;      // (tight rows of the staged pair must stay 16-byte aligned)
-    const int side = c->pair_side;
     static const long wait_us = getenv("GFO_PAIR_WAIT_US") ? atol(getenv("GFO_PAIR_WAIT_US")) : 2000;
     if (wait_us <= 0) return GFO_COMBINE_DIRECT;
     std::unique_lock<std::mutex> lk(P->mu);
+    const int side = P->ctx[1] == c ? 1 : 0;
+    if (P->ctx[side] != c) return GFO_COMBINE_DIRECT;       // this rig was dissolved while the call was on its way in
     GfoPair::Req& me = P->req[side];
     GfoPair::Req& other = P->req[side ^ 1];
     gfo_ctx* partner = P->ctx[side ^ 1];
@@ -706,10 +716,11 @@ int gfo_pair_lookup(gfo_ctx* c, const gfo_keypoint* kl, const uint8_t* dl, int n
                     const float* sf, int nlevels, const gfo_stereo_params* p, const float* min_d, const float* max_d,
                     float* u_right, float* depth, int32_t* best_dist, int32_t* best_idx_r, int* nmatched)
 {
-    std::shared_ptr<GfoPair> P = c->pair;
-    if (!P || c->pair_side != 0 || min_d || max_d) return 1;
+    std::shared_ptr<GfoPair> P = pair_of(c);
+    if (!P || min_d || max_d) return 1;
     if (nlevels != c->prm.nlevels || memcmp(sf, c->scale.data(), sizeof(float) * nlevels) != 0) return 1;
     std::lock_guard<std::mutex> lk(P->mu);
+    if (P->ctx[0] != c) return 1;                            // only the LEFT context of a rig asks for its association
     if (!P->valid || P->state != 0 || nl != P->nl || nr != P->nr || memcmp(p, &P->sp, sizeof *p) != 0) return 1;
     if ((int)P->rk[0].size() != nl || (int)P->rk[1].size() != nr) return 1;
     if (memcmp(kl, P->rk[0].data(), sizeof(gfo_keypoint) * (size_t)nl) != 0 || memcmp(dl, P->rd[0].data(), 32 * (size_t)nl) != 0) return 1;

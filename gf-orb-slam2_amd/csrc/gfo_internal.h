@@ -1,6 +1,9 @@
 // gfo_internal.h -- context, level geometry and kernel launch prototypes of libgfo.so.
 // gfx950 (MI355X) only.  Nothing here is part of the ABI (include/gfo.h is).
-#pragma once
+// (a classic include guard, not #pragma once: tests/host/combine_tsan.cc compiles gfo_combine.hip for the CPU under
+//  ThreadSanitizer against a fake of this header and defines the guard first)
+#ifndef GFO_INTERNAL_H
+#define GFO_INTERNAL_H
 
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
@@ -275,7 +278,6 @@ struct gfo_ctx {
     bool combining = false;
     std::shared_ptr<GfoEngine> engine;
     std::shared_ptr<GfoPair> pair;      // gfo_ctx_pair
-    int pair_side = 0;                  // 0 left, 1 right
     // resident vocabulary tree (gfo_vocabulary_upload)
     void* d_voc = nullptr;
     size_t voc_desc_off = 0, voc_fc_off = 0, voc_nc_off = 0, voc_wid_off = 0, voc_w_off = 0, voc_w64_off = 0;
@@ -349,6 +351,7 @@ int gfo_combined_stereo_match(gfo_ctx* c, const gfo_keypoint* kl, const uint8_t*
 void gfo_engine_release(gfo_ctx* c);
 #define GFO_COMBINER_COUNTERS 8
 void gfo_pair_release(gfo_ctx* c);
+bool gfo_has_pair(const gfo_ctx* c);   // (gfo_ctx::pair is only ever touched through the atomic shared_ptr functions, gfo_combine.hip)
 int gfo_pair_extract(gfo_ctx* c, const uint8_t* img, int w, int h, int stride, gfo_keypoint* kp, uint8_t* desc, int cap, int* n);
 int gfo_pair_lookup(gfo_ctx* c, const gfo_keypoint* kl, const uint8_t* dl, int nl, const gfo_keypoint* kr, const uint8_t* dr, int nr,
                     const float* sf, int nlevels, const gfo_stereo_params* p, const float* min_d, const float* max_d,
@@ -383,3 +386,5 @@ __device__ __forceinline__ const uint8_t* gfo_level_ptr(const GfoGeom& g, const 
     *pitch = g.lv[level].pitch;
     return pyr + (long long)img * g.pyr_img_stride + g.lv[level].plane_off;
 }
+
+#endif  // GFO_INTERNAL_H
