@@ -32,6 +32,20 @@
 #include "MapPoint.h"
 #include "ORBmatcher.h"
 
+// Variants of the reference that these bodies do NOT reproduce are refused at compile time instead of silently ignored:
+//   DELAYED_STEREO_MATCHING (include/Frame.h:40, off by default): the online call of ComputeStereoMatches_Undistorted visits only
+//     keypoints that carry a map point and the offline call only the rest (src/Frame.cc:1186-1199, mvStereoMatched), with
+//     mvDistIdx accumulated across the two calls;
+//   BUDGETING_FEATURE_MATCHING (include/ORBmatcher.h:36, off by default): SearchByBoW / SearchByProjection(Cur, Last) stop after
+//     MAX_NUM_FEATURE_MATCHING accepted matches (src/ORBmatcher.cc:360, 1547-1552) -- an order-dependent early exit.
+// Build those configurations with the reference's own bodies (leave the corresponding GFO_ADAPTER_* guard off).
+#if defined(DELAYED_STEREO_MATCHING) && defined(GFO_ADAPTER_STEREO)
+#error "adapter/matchers_gfo.cc: GFO_ADAPTER_STEREO does not reproduce DELAYED_STEREO_MATCHING (Frame.cc:1186-1199); keep the reference's Frame::ComputeStereoMatches_Undistorted in that build"
+#endif
+#if defined(BUDGETING_FEATURE_MATCHING) && (defined(GFO_ADAPTER_PROJ_LAST) || defined(GFO_ADAPTER_BOW))
+#error "adapter/matchers_gfo.cc: GFO_ADAPTER_PROJ_LAST / GFO_ADAPTER_BOW do not reproduce BUDGETING_FEATURE_MATCHING (ORBmatcher.cc:360, 1547-1552); keep the reference's bodies in that build"
+#endif
+
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
@@ -102,7 +116,10 @@ inline const uint8_t* rows32(const cv::Mat& m, cv::Mat& keep)
 
 // ---------------------------------------------------------------------------------------------------------------
 #ifdef GFO_ADAPTER_STEREO
-int Frame::ComputeStereoMatches_Undistorted(bool /*isOnline*/)
+// isOnline (without DELAYED_STEREO_MATCHING, refused above): the reference's outlier cut is under `if (!isOnline)` (Frame.cc:1290),
+// so an online call keeps every accepted match.  The library always cuts; the entries the cut cleared are restored below with
+// the reference's own expressions (:1271-1281) from the match index the library returns.
+int Frame::ComputeStereoMatches_Undistorted(bool isOnline)
 {
     const int nRows = mpORBextractorLeft->mvImagePyramid[0].rows;
     mvuRight.assign(N, -1.0f);
@@ -143,9 +160,25 @@ int Frame::ComputeStereoMatches_Undistorted(bool /*isOnline*/)
         report(c, "ComputeStereoMatches_Undistorted");
         return 0;
     }
-    for (int iL = 0; iL < N; iL++)             // rebuild mvDistIdx as :1281 fills it, sorted as :1296
+    for (int iL = 0; iL < N; iL++)             // rebuild mvDistIdx as :1281 fills it
         if (bestDist[iL] >= 0) mvDistIdx.push_back(std::pair<int, int>(bestDist[iL], iL));
-    std::sort(mvDistIdx.begin(), mvDistIdx.end());
+    if (isOnline) {
+        for (int iL = 0; iL < N; iL++) {
+            if (bestDist[iL] < 0 || mvuRight[iL] >= 0) continue;          // not accepted, or not cut
+            const float uL = mvKeysUn[iL].pt.x;
+            float bestuR = mvKeysRightUn[bestIdx[iL]].pt.x;                // :1271
+            float disparity = uL - bestuR;
+            if (disparity <= 0) {                                          // :1275-1279
+                disparity = 0.01;
+                bestuR = uL - 0.01;
+            }
+            mvDepth[iL] = mbf / disparity;
+            mvuRight[iL] = bestuR;
+            nmatched++;
+        }
+        return nmatched;                       // (an online call leaves mvDistIdx unsorted, as the reference does)
+    }
+    std::sort(mvDistIdx.begin(), mvDistIdx.end());   // :1296
     return nmatched;
 }
 #endif
@@ -470,44 +503,22 @@ void Frame::ComputeBoW()
     const bool must = voc->m_scoring_object->mustNormalize(norm);
     cv::Mat keep;
     const uint8_t* desc = rows32(mDescriptors, keep);
-    if (N <= 8192) {
-        // descent AND fold on the device: both maps come back flattened in std::map order (TemplatedVocabulary.h:1140-1212)
-        std::vector<uint32_t> bw(N), fn(N), fi(N);
-        std::vector<double> bv(N);
-        std::vector<int32_t> fs(N + 1);
-        int nw = 0, nf = 0;
-        gfo_bow_mode mode = {(int32_t)voc->m_weighting, must ? (norm == DBoW2::L1 ? 1 : 2) : 0};
-        if (gfo_compute_bow(c, desc, N, 4, &mode, bw.data(), bv.data(), &nw, fn.data(), fs.data(), fi.data(), &nf) != GFO_OK) {   // levelsup = 4, Frame.cc:666
-            report(c, "ComputeBoW");
-            return;
-        }
-        for (int k = 0; k < nw; k++) mBowVec.insert(mBowVec.end(), DBoW2::BowVector::value_type((DBoW2::WordId)bw[k], bv[k]));
-        for (int j = 0; j < nf; j++) {
-            std::vector<unsigned int>& items = mFeatVec[(DBoW2::NodeId)flat->orig_id[fn[j]]];
-            items.assign(fi.begin() + fs[j], fi.begin() + fs[j + 1]);
-        }
-        return;
-    }
-    // more descriptors than one fold workgroup sorts: descent on the device, the fold of :1140-1212 here, in feature order
-    std::vector<int32_t> word(N), node(N);
-    std::vector<float> weight(N);
-    if (gfo_bow_transform(c, desc, N, 4, word.data(), weight.data(), node.data()) != GFO_OK) {
+    // descent AND fold on the device, whatever N (beyond 8192 descriptors the fold sorts in device memory instead of LDS): both
+    // maps come back flattened in std::map order (TemplatedVocabulary.h:1140-1212)
+    std::vector<uint32_t> bw(N), fn(N), fi(N);
+    std::vector<double> bv(N);
+    std::vector<int32_t> fs(N + 1);
+    int nw = 0, nf = 0;
+    gfo_bow_mode mode = {(int32_t)voc->m_weighting, must ? (norm == DBoW2::L1 ? 1 : 2) : 0};
+    if (gfo_compute_bow(c, desc, N, 4, &mode, bw.data(), bv.data(), &nw, fn.data(), fs.data(), fi.data(), &nf) != GFO_OK) {   // levelsup = 4, Frame.cc:666
         report(c, "ComputeBoW");
         return;
     }
-    const bool tf = voc->m_weighting == DBoW2::TF || voc->m_weighting == DBoW2::TF_IDF;
-    for (int i = 0; i < N; i++) {
-        if (!(weight[i] > 0)) continue;                                       // stopped word
-        const double w = (double)weight[i];                                    // float table on this path
-        if (tf) mBowVec.addWeight((DBoW2::WordId)word[i], w);
-        else mBowVec.addIfNotExist((DBoW2::WordId)word[i], w);
-        mFeatVec.addFeature((DBoW2::NodeId)flat->orig_id[node[i]], (unsigned int)i);
+    for (int k = 0; k < nw; k++) mBowVec.insert(mBowVec.end(), DBoW2::BowVector::value_type((DBoW2::WordId)bw[k], bv[k]));
+    for (int j = 0; j < nf; j++) {
+        std::vector<unsigned int>& items = mFeatVec[(DBoW2::NodeId)flat->orig_id[fn[j]]];
+        items.assign(fi.begin() + fs[j], fi.begin() + fs[j + 1]);
     }
-    if (tf && !mBowVec.empty() && !must) {
-        const double nd = mBowVec.size();
-        for (DBoW2::BowVector::iterator vit = mBowVec.begin(); vit != mBowVec.end(); vit++) vit->second /= nd;
-    }
-    if (must) mBowVec.normalize(norm);
 }
 #endif
 

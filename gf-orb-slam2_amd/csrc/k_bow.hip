@@ -294,6 +294,7 @@ struct BowFold {
     const int* word; const double* wt; const int* node; int n;
     int weighting, norm;
     unsigned* bow_words; double* bow_values; unsigned* fv_nodes; int* fv_start; unsigned* fv_items; int* counts;   // counts[0] words, [1] fv nodes
+    unsigned long long* gkey; int* gflag;   // k_bow_fold<true>: the sort keys and marks in device memory (more than 8192 descriptors)
 };
 
 __device__ void bow_bitonic(unsigned long long* key, int p2, int tid)
@@ -334,10 +335,15 @@ __device__ int bow_scan(int* v, int n, int* part, int tid)
     return total;
 }
 
+// GMEM = false: keys and marks in LDS (p2 <= 8192: 96 KB), the form every ordinary frame takes.  GMEM = true: the same code on
+// device memory -- one workgroup bitonic-sorting through L2 is slow (milliseconds at 50 000 descriptors) but it lifts the limit:
+// no frame is refused or folded elsewhere (the reference itself has no limit, TemplatedVocabulary.h:1140-1212).
+template <bool GMEM>
 __global__ __launch_bounds__(1024) void k_bow_fold(BowFold a, int p2)
 {
-    extern __shared__ unsigned long long lds_key[];          // p2 keys
-    int* flag = reinterpret_cast<int*>(lds_key + p2);         // p2 ints
+    extern __shared__ unsigned long long lds_dyn[];          // p2 keys + p2 ints (GMEM = false)
+    unsigned long long* lds_key = GMEM ? a.gkey : lds_dyn;
+    int* flag = GMEM ? a.gflag : reinterpret_cast<int*>(lds_dyn + p2);
     __shared__ int part[1024];
     __shared__ int s_nvalid;
     const int tid = threadIdx.x, n = a.n;
@@ -356,7 +362,7 @@ __global__ __launch_bounds__(1024) void k_bow_fold(BowFold a, int p2)
     if (cnt) atomicAdd(&s_nvalid, cnt);
     __syncthreads();
     const int nvalid = s_nvalid;
-    // the scan is exclusive: keep the segment-start marks aside (bit 31 of the key's index half is free: n <= 8192)
+    // the scan is exclusive: keep the segment-start marks aside (bit 31 of the key's index half is free: n <= 2^20)
     for (int i = tid; i < n; i += 1024)
         if (flag[i]) lds_key[i] |= 0x80000000ull;
     __syncthreads();
@@ -526,16 +532,20 @@ extern "C" int gfo_compute_bow(gfo_ctx* c, const uint8_t* desc, int n, int level
     *n_words = *n_fv_nodes = 0;
     fv_start[0] = 0;
     if (n == 0) return GFO_OK;
-    if (n > 8192) {
-        c->err = "gfo_compute_bow: more than 8192 descriptors (use gfo_bow_transform and fold on the host)";
+    if (n > (1 << 20)) {
+        c->err = "gfo_compute_bow: more than 1048576 descriptors in one call";
         return GFO_ERR_CAPACITY;
     }
     BTRY(c, hipSetDevice(c->device));
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = off; off = (off + bytes + 255) / 256 * 256; return o; };
     const size_t N = (size_t)n;
+    int p2 = 1;
+    while (p2 < n) p2 <<= 1;
+    const bool gmem = p2 > 8192;      // keys + marks beyond 96 KB of LDS: sorted in device memory
     const size_t o_d = take(32 * N), o_w = take(4 * N), o_wt = take(8 * N), o_n = take(4 * N), o_bw = take(4 * N), o_bv = take(8 * N),
-                 o_fn = take(4 * N), o_fs = take(4 * (N + 1)), o_fi = take(4 * N), o_ct = take(16);
+                 o_fn = take(4 * N), o_fs = take(4 * (N + 1)), o_fi = take(4 * N), o_ct = take(16), o_gk = take(gmem ? 8 * (size_t)p2 : 0),
+                 o_gf = take(gmem ? 4 * (size_t)p2 : 0);
     if (off > c->scratch_bytes) {
         (void)hipStreamSynchronize(c->stream);
         if (c->d_scratch) (void)hipFree(c->d_scratch);
@@ -553,14 +563,17 @@ extern "C" int gfo_compute_bow(gfo_ctx* c, const uint8_t* desc, int n, int level
     gfo_prof_begin(c, ST_BOW);
     GFO_LAUNCH(c, k_bow_transform, dim3((n + 3) / 4), dim3(256), 0, st, v, S + o_d, n, levelsup, (int*)(S + o_w), (float*)nullptr,
                        (int*)(S + o_n), (double*)(S + o_wt));
-    int p2 = 1;
-    while (p2 < n) p2 <<= 1;
     BowFold f{(const int*)(S + o_w), (const double*)(S + o_wt), (const int*)(S + o_n), n, mode->weighting, mode->norm,
-              (unsigned*)(S + o_bw), (double*)(S + o_bv), (unsigned*)(S + o_fn), (int*)(S + o_fs), (unsigned*)(S + o_fi), (int*)(S + o_ct)};
-    const size_t lds = (size_t)p2 * 12;
-    if (lds > 48 * 1024)
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bow_fold), hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
-    GFO_LAUNCH(c, k_bow_fold, dim3(1), dim3(1024), lds, st, f, p2);
+              (unsigned*)(S + o_bw), (double*)(S + o_bv), (unsigned*)(S + o_fn), (int*)(S + o_fs), (unsigned*)(S + o_fi), (int*)(S + o_ct),
+              gmem ? (unsigned long long*)(S + o_gk) : nullptr, gmem ? (int*)(S + o_gf) : nullptr};
+    if (gmem) {
+        GFO_LAUNCH(c, k_bow_fold<true>, dim3(1), dim3(1024), 0, st, f, p2);
+    } else {
+        const size_t lds = (size_t)p2 * 12;
+        if (lds > 48 * 1024)
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bow_fold<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
+        GFO_LAUNCH(c, k_bow_fold<false>, dim3(1), dim3(1024), lds, st, f, p2);
+    }
     gfo_prof_end(c);
     if (int lrc = gfo_take_launch_err(c)) return lrc;
     BTRY(c, hipGetLastError());
@@ -583,5 +596,5 @@ extern "C" int gfo_compute_bow(gfo_ctx* c, const uint8_t* desc, int n, int level
 void gfo_kernels_bow(std::vector<const void*>& v)
 {
     v.push_back((const void*)k_bow_match); v.push_back((const void*)k_bow_rotation); v.push_back((const void*)k_bow_transform);
-    v.push_back((const void*)k_bow_fold);
+    v.push_back((const void*)k_bow_fold<false>); v.push_back((const void*)k_bow_fold<true>);
 }

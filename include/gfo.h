@@ -361,7 +361,7 @@ int gfo_bow_transform(gfo_ctx* ctx, const uint8_t* desc, int n, int levelsup,
  *   FeatureVector fv_node_ids[j] ascending, fv_items[fv_start[j] .. fv_start[j+1]) = the feature indices of that node,
  *                 ascending (FeatureVector::addFeature appends in feature order).
  * Stopped words (weight <= 0) enter neither map.  bow_* and fv_items / fv_node_ids take n entries, fv_start n + 1.
- * At most 8192 descriptors per call (one workgroup sorts them in LDS). */
+ * Up to 8192 descriptors are folded in LDS; more (up to 2^20 per call) by the same kernel on device memory -- slower, never refused. */
 typedef struct {
     int32_t weighting;   /* DBoW2::WeightingType: 0 TF_IDF, 1 TF, 2 IDF, 3 BINARY (BowVector.h:26-32)  */
     int32_t norm;        /* 0 = the scoring does not normalise, 1 = L1, 2 = L2 (mustNormalize, ScoringObject.h:69-80) */

@@ -879,6 +879,12 @@ static int dist_idx_cmp(const void* a, const void* b)
     return x->il < y->il ? -1 : (x->il > y->il ? 1 : 0);
 }
 
+/* Frame::ComputeStereoMatches_Undistorted(bool isOnline): the outlier cut is under `if (!isOnline)` (Frame.cc:1290), outside every
+ * #ifdef -- an online call keeps every accepted match.  (The reference's default build only ever passes false; with
+ * DELAYED_STEREO_MATCHING the online call also restricts WHICH keypoints are visited, :1186-1199, which is not restated here.) */
+static int g_stereo_online = 0;
+void orc_set_stereo_online(int on) { g_stereo_online = on != 0; }
+
 int orc_stereo_match(const orc_keypoint* kl, const uint8_t* dl, int nl,
                      const orc_keypoint* kr, const uint8_t* dr, int nr,
                      const float* scale_factors, const orc_stereo_params* p,
@@ -956,7 +962,7 @@ int orc_stereo_match(const orc_keypoint* kl, const uint8_t* dl, int nl,
         }
         nmatched++;
     }
-    if (ndi > 0) { /* :1290-1313 */
+    if (ndi > 0 && !g_stereo_online) { /* :1290-1313 */
         qsort(di, ndi, sizeof(dist_idx), dist_idx_cmp);
         const float median = (float)di[ndi / 2].dist;
         const float thDist = 1.5f * 1.4f * median;

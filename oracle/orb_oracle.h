@@ -105,6 +105,8 @@ typedef struct {
     float mbf, mb; /* baseline*fx and baseline                       */
     float min_x;   /* mnMinX                                         */
 } orc_stereo_params;
+/* 1: the call is ComputeStereoMatches_Undistorted(true): no outlier cut (Frame.cc:1290 `if (!isOnline)`); 0 (default): (false) */
+void orc_set_stereo_online(int on);
 int orc_stereo_match(const orc_keypoint* kl, const uint8_t* dl, int nl,
                      const orc_keypoint* kr, const uint8_t* dr, int nr,
                      const float* scale_factors, const orc_stereo_params* p,

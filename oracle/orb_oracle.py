@@ -265,7 +265,8 @@ def sincos_n(t):
     return s, c
 
 
-def stereo_match(kl, dl, kr, dr, scale_factors, n_rows, mbf, mb, min_x=0.0, min_d=None, max_d=None):
+def stereo_match(kl, dl, kr, dr, scale_factors, n_rows, mbf, mb, min_x=0.0, min_d=None, max_d=None, online=False):
+    """Frame::ComputeStereoMatches_Undistorted(isOnline) on arrays; online=True: no outlier cut (Frame.cc:1290)"""
     kl = np.ascontiguousarray(kl, dtype=KEYPOINT_DTYPE)
     kr = np.ascontiguousarray(kr, dtype=KEYPOINT_DTYPE)
     dl = np.ascontiguousarray(dl, dtype=np.uint8)
@@ -280,8 +281,12 @@ def stereo_match(kl, dl, kr, dr, scale_factors, n_rows, mbf, mb, min_x=0.0, min_
     if min_d is not None:
         min_d = np.ascontiguousarray(min_d, np.float32)
         max_d = np.ascontiguousarray(max_d, np.float32)
-    nm = lib().orc_stereo_match(_p(kl), _p(dl), nl, _p(kr), _p(dr), nr, _p(sf), C.byref(p), _p(min_d), _p(max_d),
-                                _p(u_right), _p(depth), _p(best_dist), _p(best_idx))
+    lib().orc_set_stereo_online(1 if online else 0)
+    try:
+        nm = lib().orc_stereo_match(_p(kl), _p(dl), nl, _p(kr), _p(dr), nr, _p(sf), C.byref(p), _p(min_d), _p(max_d),
+                                    _p(u_right), _p(depth), _p(best_dist), _p(best_idx))
+    finally:
+        lib().orc_set_stereo_online(0)
     return nm, u_right[:nl], depth[:nl], best_dist[:nl], best_idx[:nl]
 
 

@@ -8,6 +8,7 @@
 //   C. delete + new at one address (Tracking::updateORBExtractor, src/Tracking.cc:298-320), an empty image (ORBextractor.cc:1115-1116),
 //      an image without a corner (:1133-1134);
 //   D. the disparity-window form of the stereo association (Frame.cc:1220-1231: frames that carry map points);
+//   G. the online form of the association, ComputeStereoMatches_Undistorted(true): no outlier cut (Frame.cc:1290);
 //   E. ORBmatcher::SearchByProjection(Frame&, vector<MapPoint*>&, th) (ORBmatcher.cc:155-241);
 //   F. ORBmatcher::SearchByProjection(CurrentFrame, LastFrame, th, bMono, numVisible) (ORBmatcher.cc:1440-1593), including the
 //      host-side projection the adapter keeps (:1451-1502).
@@ -326,6 +327,27 @@ int main(int argc, char** argv)
             }
             const int ns = F.ComputeStereoMatches_Undistorted(false);
             dump_stereo("D", 2, F, ns);
+        }
+    }
+
+    // ------------------------------------------------------------------------------------------------------------------
+    // G. ComputeStereoMatches_Undistorted(true): an online call keeps every accepted match (`if (!isOnline)`, Frame.cc:1290).
+    //    The pair is the left image against itself shifted by 10 columns: a small median distance, so that the offline call of the
+    //    same arrays does cut (2.1 x median, :1297-1298) and the online call has something to keep.
+    {
+        const cv::Mat gl = roll(imL, 0, 0), gr = roll(imL, 10, 0);
+        std::vector<cv::KeyPoint> kl, kr;
+        cv::Mat dl, dr;
+        std::thread tl([&] { (*L)(gl, cv::Mat(), kl, dl); });
+        std::thread tr([&] { (*R)(gr, cv::Mat(), kr, dr); });
+        tl.join();
+        tr.join();
+        for (int online = 0; online < 2; online++) {
+            Frame* G = new Frame();
+            fill_frame(*G, L, R, kl, dl, kr, dr);
+            const int ns = G->ComputeStereoMatches_Undistorted(online != 0);
+            dump_stereo(online ? "Gon" : "Goff", 0, *G, ns);
+            delete G;
         }
     }
 

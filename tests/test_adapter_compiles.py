@@ -41,6 +41,23 @@ def test_matcher_adapters_match_reference_headers(guard):
 
 @pytest.mark.skipif(not os.path.exists(os.path.join(REF_INC, "ORBmatcher.h")), reason="reference headers not mounted")
 @pytest.mark.skipif(shutil.which("g++") is None, reason="g++ missing")
+@pytest.mark.parametrize("variant,guard", [("DELAYED_STEREO_MATCHING", "GFO_ADAPTER_STEREO"), ("BUDGETING_FEATURE_MATCHING", "GFO_ADAPTER_PROJ_LAST"),
+                                           ("BUDGETING_FEATURE_MATCHING", "GFO_ADAPTER_BOW")])
+def test_unreproduced_variants_are_refused_at_compile_time(variant, guard):
+    """the reference's non-default variants whose bodies the adapter does not reproduce (delayed stereo matching:
+    Frame.cc:1186-1199; budgeted matching: ORBmatcher.cc:360, 1547-1552) stop the build with a message instead of compiling into
+    something that silently behaves differently; the same variant with only unaffected guards still builds."""
+    src = os.path.join(ROOT, "gf-orb-slam2_amd", "adapter", "matchers_gfo.cc")
+    base = ["g++", "-std=c++11", "-fsyntax-only", "-D__SSE2__", "-I", os.path.join(ROOT, "tests", "cv_standin"), "-I", REF_INC, "-I", os.path.dirname(REF_INC),
+            "-I", os.path.join(ROOT, "include")]
+    r = subprocess.run(base + ["-D" + variant, "-D" + guard, src], capture_output=True, text=True)
+    assert r.returncode != 0 and "#error" in r.stderr and variant in r.stderr, r.stderr[-1500:]
+    r = subprocess.run(base + ["-D" + variant, "-DGFO_ADAPTER_PROJECTION", src], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-1500:]
+
+
+@pytest.mark.skipif(not os.path.exists(os.path.join(REF_INC, "ORBmatcher.h")), reason="reference headers not mounted")
+@pytest.mark.skipif(shutil.which("g++") is None, reason="g++ missing")
 def test_weaken_list_is_what_the_adapter_defines():
     """adapter/weaken_symbols.txt (committed) = the Frame:: / ORBmatcher:: text symbols of matchers_gfo.cc compiled against the
     reference's unchanged headers (tools/make_weaken_list.py --print): six members, the names a maintainer weakens in Frame.o /

@@ -94,6 +94,11 @@ def run(tmp_path_factory, oracle, euroc_l, euroc_r):
     ref["D"] = oracle.stereo_match(kl, dl, kr, dr, sf, 480, MBF, MB, 0.0, min_d, max_d)
     ref["D_windows_used"] = int(ok.sum())
 
+    # G: the online call on frame 0 (no outlier cut)
+    kl, dl = ref["frames"][0][0], ref["frames"][0][1]
+    kr, dr = oe(np.ascontiguousarray(np.roll(euroc_l, -10, axis=1)))         # the left image shifted: disparity 10, small distances
+    ref["G"] = [oracle.stereo_match(kl, dl, kr, dr, sf, 480, MBF, MB, 0.0, online=on) for on in (False, True)]
+
     # E: SearchByProjection(F, local map, 3) on frame 1
     kl, dl, kr, dr, st = ref["frames"][1]
     n, m = len(kl), 3000
@@ -292,6 +297,19 @@ def test_stereo_member_with_map_point_windows(run):
     assert [tuple(x) for x in _rd(run, "D_f02_distidx.bin", np.int32).reshape(-1, 2).tolist()] == want
     assert int(_rd(run, "D_f02_nstereo.bin", np.int32)[0]) == nm
     assert ur.tobytes() != run["frames"][2][4][1].tobytes()          # the windows changed the association
+
+
+def test_stereo_member_online_call_keeps_every_accepted_match(run):
+    """ComputeStereoMatches_Undistorted(true): the reference's cut is under `if (!isOnline)` (Frame.cc:1290); the adapter restores
+    what the library's cut cleared with the reference's own expressions (:1271-1281).  Same arrays, offline then online."""
+    for tag, (nm, ur, dp, bd, bi) in zip(("Goff", "Gon"), run["G"]):
+        assert _rd(run, f"{tag}_f00_uright.bin", np.float32).tobytes() == ur.tobytes(), tag
+        assert _rd(run, f"{tag}_f00_depth.bin", np.float32).tobytes() == dp.tobytes(), tag
+        assert int(_rd(run, f"{tag}_f00_nstereo.bin", np.int32)[0]) == nm, tag
+        want = sorted((int(bd[i]), i) for i in range(len(bd)) if bd[i] >= 0)
+        assert sorted(tuple(x) for x in _rd(run, f"{tag}_f00_distidx.bin", np.int32).reshape(-1, 2).tolist()) == want, tag
+    off, on = run["G"]
+    assert on[0] > off[0] + 20 and (on[1] >= 0).sum() > (off[1] >= 0).sum() + 20     # the offline call cut matches the online call keeps
 
 
 def test_search_by_projection_member(run):
