@@ -88,6 +88,20 @@ __device__ __forceinline__ int half_sum(int v)
     return v;
 }
 
+// Round 5: window loads from 16-BYTE-aligned addresses.  A vector load costs the texture path per distinct 64-byte chunk it
+// touches (~2.2 clocks each, profiles/vmem_rate_r03.txt) and a 16-byte load from a dword-aligned address straddles a chunk
+// boundary 3 times in 16: 1.19 chunks per load.  The 31-px patch row fits three segments from ANY 16-byte boundary left of it
+// (15 + 31 <= 48), the 37-px window row from twelve of the sixteen (11 + 37 <= 48; the other four keep the dword-aligned base):
+// 242 -> 209 chunks per keypoint.  The LDS image keeps its layout -- pixel 0 of a row at byte (offset & 3) -- by storing every
+// segment (offset & ~3) bytes further left (4-byte-aligned LDS stores: two ds_write2_b32 instead of one ds_write_b128; the region
+// has 16 bytes of slack in front).  -DGFO_OD_ALIGN16=0: the dword-aligned bases of rounds 2-4.
+// MEASURED (profiles/orient_align16_r05.txt, same-box A/B): 236-237 -> 233 us per 256 images, headline +0.4 % (inside the noise):
+// kept because it is never slower, but the chunk count is NOT this kernel's wall -- 14 % fewer chunks bought 1.5 %.
+#ifndef GFO_OD_ALIGN16
+#define GFO_OD_ALIGN16 1
+#endif
+typedef unsigned int od_u4a4 __attribute__((ext_vector_type(4), aligned(4)));   // a 16-byte value at a 4-byte-aligned LDS address
+
 #ifndef OD_WAVES
 #define OD_WAVES 4   // waves per workgroup, 2 keypoints each (2-wave workgroups measured 5 % slower)
 #endif
@@ -112,7 +126,7 @@ __global__ __launch_bounds__(64 * OD_WAVES) void k_orient_desc(const GfoGeom* __
     // the 37-row window, whose bytes wait in registers meanwhile.  14 KB per workgroup instead of 26 KB: LDS no longer
     // caps the kernel at 6 waves per SIMD (the registers allow 8), and the chain of dependent loads at the head of
     // every wave is what the extra waves hide.
-    __shared__ __attribute__((aligned(16))) uint8_t s_win[2 * OD_WAVES][DW * DWP];   // [wave*2 + half]
+    __shared__ __attribute__((aligned(16))) uint8_t s_win_raw[16 + 2 * OD_WAVES * DW * DWP];   // 16 bytes of slack, then [wave*2 + half][DW * DWP]
     // The two tables every wave needs -- the 256 test pairs (4 KB) and the disc's row weights (1.1 KB) -- are brought into LDS
     // ONCE per workgroup, 16 bytes per thread, instead of twelve 16-byte loads per lane and wave: this kernel is bound by the
     // rate at which a CU's texture path takes vector memory instructions (22 per wave were 62 % of its time; with the row
@@ -221,14 +235,24 @@ __global__ __launch_bounds__(64 * OD_WAVES) void k_orient_desc(const GfoGeom* __
     int pitch;
     const uint8_t* lv = gfo_level_ptr(g, in, pyr, level, img, &pitch);   // wave-uniform
     const uint8_t* bl = blur + (long long)img * g.blur_img_stride + L.blur_off;
-    const int ox_al = (x - GFO_HALF_PATCH) & ~3, ooff = (x - GFO_HALF_PATCH) - ox_al;
-    const int wx_al = (x - 18) & ~3, woff = (x - 18) - wx_al;
+#if GFO_OD_ALIGN16
+    const int ox_al = (x - GFO_HALF_PATCH) & ~15;
+    const int wx_al = ((x - 18) & 15) < 12 ? (x - 18) & ~15 : (x - 18) & ~3;
+#else
+    const int ox_al = (x - GFO_HALF_PATCH) & ~3;
+    const int wx_al = (x - 18) & ~3;
+#endif
+    // pixel 0 of a staged row sits at byte (offset & 3) of its LDS row; the segments are stored (offset & ~3) bytes to the left
+    const int ooff = ((x - GFO_HALF_PATCH) - ox_al) & 3, woff = ((x - 18) - wx_al) & 3;
+#if GFO_OD_ALIGN16
+    const int oshift = ((x - GFO_HALF_PATCH) - ox_al) & ~3, wshift = ((x - 18) - wx_al) & ~3;
+#endif
     const int lpitch = L.pitch;
     const int rw = (hl * 11) >> 5, seg = hl - 3 * rw;   // hl / 3, hl % 3 for hl < 32; rw == 10: idle lanes
     const bool ld_on = rw < 10;
     const unsigned po = (unsigned)((y - GFO_HALF_PATCH) * pitch + ox_al + 16 * seg);     // row 0 of the patch, this lane's segment
     const unsigned wo = (unsigned)((y - 18) * lpitch + wx_al + 16 * seg);                // row 0 of the window
-    uint8_t* win = s_win[wave * 2 + half];
+    uint8_t* win = s_win_raw + 16 + (wave * 2 + half) * (DW * DWP);
     uint8_t* pat = win;   // same bytes, earlier in time
     uint4 vw0, vw1, vw2, vw3;   // the window's bytes, in registers until the patch has been consumed
     {
@@ -243,13 +267,20 @@ __global__ __launch_bounds__(64 * OD_WAVES) void k_orient_desc(const GfoGeom* __
         vw2 = *reinterpret_cast<const uint4*>(bl + (wo + (unsigned)(min(20 + rw, DW - 1) * lpitch)));
         vw3 = *reinterpret_cast<const uint4*>(bl + (wo + (unsigned)(min(30 + rw, DW - 1) * lpitch)));
         store_tables();   // (their loads were the first of the kernel: long landed)
-        uint4* pl = reinterpret_cast<uint4*>(pat + rw * OWP + 16 * seg);
         // steps 0-2 store unconditionally: every row they touch exists, and the two idle lanes (rw == 10) hold
         // exactly the bytes that lane rw == 0 of the next step writes to the same place; only the last step is
         // predicated (row 30)
+#if GFO_OD_ALIGN16
+        od_u4a4* pl = reinterpret_cast<od_u4a4*>(pat + rw * OWP + 16 * seg - oshift);
+#pragma unroll
+        for (int k = 0; k < OD_STEPS - 1; k++) pl[k * (10 * OWP / 16)] = od_u4a4{vp[k].x, vp[k].y, vp[k].z, vp[k].w};
+        if (ld_on && 10 * (OD_STEPS - 1) + rw < OW) pl[(OD_STEPS - 1) * (10 * OWP / 16)] = od_u4a4{vp[OD_STEPS - 1].x, vp[OD_STEPS - 1].y, vp[OD_STEPS - 1].z, vp[OD_STEPS - 1].w};
+#else
+        uint4* pl = reinterpret_cast<uint4*>(pat + rw * OWP + 16 * seg);
 #pragma unroll
         for (int k = 0; k < OD_STEPS - 1; k++) pl[k * (10 * OWP / 16)] = vp[k];
         if (ld_on && 10 * (OD_STEPS - 1) + rw < OW) pl[(OD_STEPS - 1) * (10 * OWP / 16)] = vp[OD_STEPS - 1];
+#endif
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -303,11 +334,19 @@ __global__ __launch_bounds__(64 * OD_WAVES) void k_orient_desc(const GfoGeom* __
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     {
+#if GFO_OD_ALIGN16
+        od_u4a4* wl = reinterpret_cast<od_u4a4*>(win + rw * DWP + 16 * seg - wshift);
+        wl[0] = od_u4a4{vw0.x, vw0.y, vw0.z, vw0.w};
+        wl[10 * DWP / 16] = od_u4a4{vw1.x, vw1.y, vw1.z, vw1.w};
+        wl[2 * (10 * DWP / 16)] = od_u4a4{vw2.x, vw2.y, vw2.z, vw2.w};
+        if (ld_on && 30 + rw < DW) wl[3 * (10 * DWP / 16)] = od_u4a4{vw3.x, vw3.y, vw3.z, vw3.w};
+#else
         uint4* wl = reinterpret_cast<uint4*>(win + rw * DWP + 16 * seg);
         wl[0] = vw0;
         wl[10 * DWP / 16] = vw1;
         wl[2 * (10 * DWP / 16)] = vw2;
         if (ld_on && 30 + rw < DW) wl[3 * (10 * DWP / 16)] = vw3;
+#endif
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
