@@ -16,7 +16,10 @@ for sub in ("trace", "pmc_fetch", "pmc_write"):
 subprocess.check_call([sys.executable, os.path.join(R, "tools", "summarize_profile.py"), os.path.join(G, f"prof_{tag}"), tag],
                       env=dict(os.environ, GFO_PROF_BATCH=batch), stdout=subprocess.DEVNULL)
 shutil.copy(os.path.join(P, f"traffic_{tag}.json"), os.path.join(P, "traffic_latest.json"))
-old = json.load(open(os.path.join(P, f"boundary_throughput_{tag}.json")))
+tmpl = os.path.join(P, f"boundary_throughput_{tag}.json")
+if not os.path.exists(tmpl):      # a new round: the descriptions of the three runs come from the newest earlier file
+    tmpl = sorted(glob.glob(os.path.join(P, "boundary_throughput_r*.json")))[-1]
+old = json.load(open(tmpl))
 runs = {}
 for k in ("pageable", "pinned", "nocombine"):
     j = json.load(open(os.path.join(G, f"boundary_throughput_{tag}_{k}.json")))
