@@ -800,7 +800,26 @@ static int extract_launches(gfo_ctx* c, const GfoInput& in, int nimg, const gfo_
     // fork: the blur (vector-pipe bound) next to FAST and the quadtree (the latter mostly barrier waits); join
     // before the descriptors.  Per-kernel profiling and debug runs keep everything in one stream.
     const bool fork = c->fork_blur && !c->profiling && !c->debug_sync;
-    if (fork) {
+    // per-frame batches: FAST, then quadtree and blur as ONE launch (k_quadtree_blur) -- no second stream, no fork / join events
+    // (GFO_QT_FUSE_BLUR=0: the forked form)
+    static const bool fuse_env = !(getenv("GFO_QT_FUSE_BLUR") && getenv("GFO_QT_FUSE_BLUR")[0] == '0');
+    bool fused_done = false;
+    if (fork && fuse_env && nimg <= 8) {
+        gfo_launch_fast(c, in, nimg);
+        GFO_PACE_POINT(GFO_STAGE_FAST);
+        fused_done = gfo_launch_quadtree_blur(c, in, nimg);
+        if (!fused_done) {      // (shapes that need the HBM-scratch quadtree: the forked form, FAST already launched)
+            hipStream_t main_stream = c->stream;
+            HIP_TRY(c, hipEventRecord(c->ev_fork, main_stream));
+            HIP_TRY(c, hipStreamWaitEvent(c->side_stream, c->ev_fork, 0));
+            gfo_launch_quadtree(c, nimg);
+            c->stream = c->side_stream;
+            gfo_launch_blur(c, in, nimg);
+            c->stream = main_stream;
+            HIP_TRY(c, hipEventRecord(c->ev_join, c->side_stream));
+            HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev_join, 0));
+        }
+    } else if (fork) {
         // FAST first (it fills the vector pipes by itself); the fork point is after it, so that the blur shares the
         // chip with the quadtree, whose workgroups mostly wait at barriers
         hipStream_t main_stream = c->stream;

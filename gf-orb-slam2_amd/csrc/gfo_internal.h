@@ -310,6 +310,7 @@ int gfo_pyramid_bands_prepare(int lds_bytes);
 void gfo_launch_blur(gfo_ctx* c, const GfoInput& in, int nimg);
 void gfo_launch_fast(gfo_ctx* c, const GfoInput& in, int nimg);
 void gfo_launch_quadtree(gfo_ctx* c, int nimg);
+bool gfo_launch_quadtree_blur(gfo_ctx* c, const GfoInput& in, int nimg);   // per-frame batches: quadtree + blur as one launch (false: not applicable, nothing launched)
 void gfo_launch_orient_desc(gfo_ctx* c, const GfoInput& in, int nimg);
 void gfo_launch_stereo(gfo_ctx* c, const GfoStereoLaunch& s);
 void gfo_launch_pack_cut(gfo_ctx* c, const GfoPack& p, hipStream_t st);   // k_pack_results with the stereo cut in it (GfoPack::cut_pairs)

@@ -128,17 +128,57 @@ __device__ __forceinline__ QtBox qt_child_box(QtBox b, int q)
 #else
 #define QT_OCC_ATTR
 #endif
-#define QT_KERNEL k_quadtree
-#define QT_STATE_BASE extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
 #include "k_quadtree_body.inc"
-#undef QT_KERNEL
-#undef QT_STATE_BASE
+#include "k_blur_dev.inc"
 
-#define QT_KERNEL k_quadtree_gmem
-#define QT_STATE_BASE uint8_t* lds = scratch + ((unsigned long long)(level0 + blockIdx.y) * gridDim.x + blockIdx.x) * scratch_stride;
-#include "k_quadtree_body.inc"
-#undef QT_KERNEL
-#undef QT_STATE_BASE
+__global__ __launch_bounds__(QT_MAX_THREADS) QT_OCC_ATTR void k_quadtree(const GfoGeom* __restrict__ gp, const uint32_t* __restrict__ cand,
+                                                                         const int* __restrict__ cand_cnt, uint16_t* __restrict__ node_of_all,
+                                                                         uint32_t* __restrict__ sel, int* __restrict__ sel_cnt, int* __restrict__ flags,
+                                                                         int ncap, int klds, int level0, unsigned long long* __restrict__ dbg_ts)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t qt_lds[];
+    qt_body(gp, cand, cand_cnt, node_of_all, sel, sel_cnt, flags, ncap, klds, dbg_ts, blockIdx.x, level0 + blockIdx.y, qt_lds);
+}
+
+__global__ __launch_bounds__(QT_MAX_THREADS) QT_OCC_ATTR void k_quadtree_gmem(const GfoGeom* __restrict__ gp, const uint32_t* __restrict__ cand,
+                                                                              const int* __restrict__ cand_cnt, uint16_t* __restrict__ node_of_all,
+                                                                              uint32_t* __restrict__ sel, int* __restrict__ sel_cnt, int* __restrict__ flags,
+                                                                              int ncap, unsigned long long* __restrict__ dbg_ts,
+                                                                              uint8_t* __restrict__ scratch, unsigned long long scratch_stride)
+{
+    uint8_t* state = scratch + ((unsigned long long)blockIdx.y * gridDim.x + blockIdx.x) * scratch_stride;
+    qt_body(gp, cand, cand_cnt, node_of_all, sel, sel_cnt, flags, ncap, 0, dbg_ts, blockIdx.x, blockIdx.y, state);
+}
+
+// Quadtree AND blur of a per-frame batch (<= 8 images) as one launch (round 5).  The two are independent (both read the pyramid;
+// the quadtree the FAST candidates) and used to run side by side on two streams: an event fork behind k_fast and a join in front
+// of k_orient_desc, which on the device are ~7 + ~6 us of nothing on the critical path of a 0.19-ms frame
+// (profiles/stereo_direct_r05.txt, the timeline).  Here workgroups [0, nqt) are k_quadtree's, level-major, and the rest are the
+// blur's 256-thread blocks, four to a workgroup: no second stream, no events, and the blur's blocks fill the CUs the sixteen
+// quadtree workgroups leave idle.  (Batches keep the two launches: there the blur wants its own launch shape and XCD placement.)
+__global__ __launch_bounds__(QT_MAX_THREADS) QT_OCC_ATTR void k_quadtree_blur(const GfoGeom* __restrict__ gp, const uint32_t* __restrict__ cand,
+                                                                              const int* __restrict__ cand_cnt, uint16_t* __restrict__ node_of_all,
+                                                                              uint32_t* __restrict__ sel, int* __restrict__ sel_cnt, int* __restrict__ flags,
+                                                                              int ncap, int klds, unsigned long long* __restrict__ dbg_ts, GfoInput in,
+                                                                              const uint8_t* __restrict__ pyr, uint8_t* __restrict__ blur, int nimg, int nqt,
+                                                                              int blur_blocks)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t qt_lds[];
+    const int b = blockIdx.x;
+    if (b < nqt) {
+        qt_body(gp, cand, cand_cnt, node_of_all, sel, sel_cnt, flags, ncap, klds, dbg_ts, b % nimg, b / nimg, qt_lds);
+        return;
+    }
+    const GfoGeom& g = *gp;
+    const int v = (b - nqt) * (QT_MAX_THREADS / 256) + (int)(threadIdx.x >> 8);      // the blur's block index over all images
+    const int img = v / blur_blocks, bx = v - img * blur_blocks;
+    if (img >= nimg) return;
+    const int nb = g.blur_total_b, tid = threadIdx.x & 255;
+    if (bx < nb)
+        blur_body<true>(g, in, pyr, blur, bx, img, tid);
+    else
+        blur_body<false>(g, in, pyr, blur, bx - nb, img, tid);
+}
 
 size_t gfo_quadtree_lds_bytes(int ncap, int klds)
 {
@@ -157,7 +197,7 @@ static int qt_level_klds(const GfoLevel& L, int cap)
     return k < cap ? k : cap;
 }
 
-void gfo_launch_quadtree(gfo_ctx* c, int nimg)
+static bool launch_quadtree(gfo_ctx* c, int nimg, const GfoInput* blur_in)
 {
     const int nl = c->g.nlevels;
     int ncap = 0;
@@ -228,25 +268,35 @@ void gfo_launch_quadtree(gfo_ctx* c, int nimg)
     for (int i = 0; i < ngrp; i++) lds_max = grp[i].lds > lds_max ? grp[i].lds : lds_max;
     if (!gmem && lds_max > 64 * 1024 && lds_max > c->qt_lds_granted) {
         // raised per context (= per device; contexts may be driven from different threads): the grant only grows
-        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_quadtree), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_quadtree), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max);
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_quadtree_blur), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max);
         if (e != hipSuccess) {
             (void)hipGetLastError();
             if (c->launch_err.empty()) c->launch_err = std::string("stage quadtree: cannot raise the dynamic LDS limit: ") + hipGetErrorString(e);
-            return;
+            return true;      // (the error is recorded: the pipeline driver stops before anything consumes the selection)
         }
         c->qt_lds_granted = lds_max;
     }
     static const bool timing = getenv("GFO_QT_TIMING") != nullptr;
     unsigned long long* d_ts = nullptr;
     if (timing && hipMalloc(&d_ts, 128 * sizeof(unsigned long long)) == hipSuccess) (void)hipMemsetAsync(d_ts, 0, 128 * sizeof(unsigned long long), c->stream);
+    // per-frame batches: quadtree and blur as ONE launch (k_quadtree_blur) when the caller asks for it and the shapes allow
+    const int blur_blocks = c->g.total_tiles + c->g.blur_total_b;
+    const bool fused = blur_in && !gmem && ngrp == 1 && nthreads == QT_MAX_THREADS && blur_blocks > 0;
+    if (blur_in && !fused) return false;      // the caller launches the two side by side as before
     gfo_prof_begin(c, ST_QUADTREE);
-    if (gmem)
+    if (fused) {
+        const int nqt = nimg * nl;
+        const int blur_wgs = (nimg * blur_blocks + QT_MAX_THREADS / 256 - 1) / (QT_MAX_THREADS / 256);
+        GFO_LAUNCH(c, k_quadtree_blur, dim3(nqt + blur_wgs), dim3(QT_MAX_THREADS), grp[0].lds, c->stream, c->d_geom, c->d_cand, c->d_cand_cnt, c->d_node_of,
+                           c->d_sel, c->d_sel_cnt, c->d_flags, grp[0].ncap, grp[0].klds, d_ts, *blur_in, c->d_pyr, c->d_blur, nimg, nqt, blur_blocks);
+    } else if (gmem)
         GFO_LAUNCH(c, k_quadtree_gmem, dim3(nimg, nl), dim3(1024), 0, c->stream, c->d_geom, c->d_cand, c->d_cand_cnt, c->d_node_of,
-                           c->d_sel, c->d_sel_cnt, c->d_flags, ncap, 0, 0, d_ts, c->d_qt_scratch, (unsigned long long)c->qt_scratch_stride);
+                           c->d_sel, c->d_sel_cnt, c->d_flags, ncap, d_ts, c->d_qt_scratch, (unsigned long long)c->qt_scratch_stride);
     else
         for (int i = 0; i < ngrp; i++)
             GFO_LAUNCH(c, k_quadtree, dim3(nimg, grp[i].n), dim3(nthreads), grp[i].lds, c->stream, c->d_geom, c->d_cand, c->d_cand_cnt, c->d_node_of,
-                               c->d_sel, c->d_sel_cnt, c->d_flags, grp[i].ncap, grp[i].klds, grp[i].l0, d_ts, (uint8_t*)nullptr, 0ull);
+                               c->d_sel, c->d_sel_cnt, c->d_flags, grp[i].ncap, grp[i].klds, grp[i].l0, d_ts);
     if (d_ts) {   // debugging aid: blocks until the kernel is done and prints the phase times of block (0, 0)
         unsigned long long ts[128];
         (void)hipStreamSynchronize(c->stream);
@@ -257,12 +307,18 @@ void gfo_launch_quadtree(gfo_ctx* c, int nimg)
         fprintf(stderr, "\n");
     }
     gfo_prof_end(c);
+    return true;
 }
+
+void gfo_launch_quadtree(gfo_ctx* c, int nimg) { (void)launch_quadtree(c, nimg, nullptr); }
+
+// quadtree + blur of a per-frame batch in one launch; false (nothing launched) when the configuration does not allow it
+bool gfo_launch_quadtree_blur(gfo_ctx* c, const GfoInput& in, int nimg) { return launch_quadtree(c, nimg, &in); }
 
 // Every __global__ of this translation unit, for gfo_preload_kernels (gfo_api.hip): the runtime loads a code object and
 // registers a kernel lazily, on the first launch that needs it; gfo_ctx_create resolves them all once per device under a
 // mutex so that no two host threads ever race through that first-launch path (round 3: eight threads, first k_pack_results).
 void gfo_kernels_quadtree(std::vector<const void*>& v)
 {
-    v.push_back((const void*)k_quadtree); v.push_back((const void*)k_quadtree_gmem);
+    v.push_back((const void*)k_quadtree); v.push_back((const void*)k_quadtree_gmem); v.push_back((const void*)k_quadtree_blur);
 }
