@@ -7,6 +7,7 @@
 // harness put into the objects -- getters return the member, the constructor does nothing.  They are not restatements of the
 // reference's algorithms, pin nothing and are never part of the product or of the oracle.
 #include "Frame.h"
+#include "KeyFrame.h"
 #include "MapPoint.h"
 #include "ORBmatcher.h"
 
@@ -40,10 +41,33 @@ void Frame::UpdatePoseMatrices()
 long unsigned int MapPoint::nNextId = 0;
 std::mutex MapPoint::mGlobalMutex;
 
+// For the keyframe overload (ORBmatcher.cc:1595-1721) the adapter asks a map point for its distance range and for the pyramid level
+// it predicts at a distance.  The reference computes those from the point's observation history (MapPoint.cc); here they simply
+// hand back what the harness stored in the object -- the adapter's flattening is what is under test, not that arithmetic.
+float MapPoint::GetMinDistanceInvariance() { return mfMinDistance; }
+float MapPoint::GetMaxDistanceInvariance() { return mfMaxDistance; }
+int MapPoint::PredictScale(const float&, Frame*) { return mnTrackScaleLevel; }
+
 cv::Mat MapPoint::GetWorldPos() { return mWorldPos.clone(); }
 cv::Mat MapPoint::GetDescriptor() { return mDescriptor.clone(); }
 int MapPoint::Observations() { return nObs; }
 bool MapPoint::isBad() { return mbBad; }
+
+// ---- KeyFrame: a keyframe is a frame's arrays frozen (include/KeyFrame.h:165-268: const members copied from the Frame) ---------
+long unsigned int KeyFrame::nNextId = 0;
+KeyFrame::KeyFrame(Frame& F, Map* pMap, KeyFrameDatabase* pKFDB)
+    : mnFrameId(F.mnId), mTimeStamp(F.mTimeStamp), mnGridCols(FRAME_GRID_COLS), mnGridRows(FRAME_GRID_ROWS),
+      mfGridElementWidthInv(F.mfGridElementWidthInv), mfGridElementHeightInv(F.mfGridElementHeightInv), fx(F.fx), fy(F.fy), cx(F.cx), cy(F.cy),
+      invfx(F.invfx), invfy(F.invfy), mbf(F.mbf), mb(F.mb), mThDepth(F.mThDepth), N(F.N), mvKeys(F.mvKeys), mvKeysUn(F.mvKeysUn), mvuRight(F.mvuRight),
+      mvDepth(F.mvDepth), mDescriptors(F.mDescriptors.clone()), mBowVec(F.mBowVec), mFeatVec(F.mFeatVec), mnScaleLevels(F.mnScaleLevels),
+      mfScaleFactor(F.mfScaleFactor), mfLogScaleFactor(F.mfLogScaleFactor), mvScaleFactors(F.mvScaleFactors), mvLevelSigma2(F.mvLevelSigma2),
+      mvInvLevelSigma2(F.mvInvLevelSigma2), mnMinX(F.mnMinX), mnMinY(F.mnMinY), mnMaxX(F.mnMaxX), mnMaxY(F.mnMaxY), mK(F.mK),
+      mvpMapPoints(F.mvpMapPoints), mpKeyFrameDB(pKFDB), mpORBvocabulary(F.mpORBvocabulary), mbFirstConnection(true), mpParent(NULL), mbNotErase(false),
+      mbToBeErased(false), mbBad(false), mHalfBaseline(F.mb / 2), mpMap(pMap)
+{
+    mnId = nNextId++;
+}
+std::vector<MapPoint*> KeyFrame::GetMapPointMatches() { return mvpMapPoints; }
 
 // ---- ORBmatcher: constructor and the three public constants (include/ORBmatcher.h:46,294-296) --------------------------------
 const int ORBmatcher::TH_HIGH = 100;

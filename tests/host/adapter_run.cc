@@ -11,13 +11,16 @@
 //   G. the online form of the association, ComputeStereoMatches_Undistorted(true): no outlier cut (Frame.cc:1290);
 //   E. ORBmatcher::SearchByProjection(Frame&, vector<MapPoint*>&, th) (ORBmatcher.cc:155-241);
 //   F. ORBmatcher::SearchByProjection(CurrentFrame, LastFrame, th, bMono, numVisible) (ORBmatcher.cc:1440-1593), including the
-//      host-side projection the adapter keeps (:1451-1502).
+//      host-side projection the adapter keeps (:1451-1502);
+//   H. ORBmatcher::SearchByProjection(CurrentFrame, KeyFrame*, sAlreadyFound, th, ORBdist) (ORBmatcher.cc:1595-1721), relocalisation's;
+//   I. ORBmatcher::SearchByBoW(KeyFrame*, Frame&, vpMapPointMatches) (ORBmatcher.cc:270-404) with real DBoW2::FeatureVector objects.
 // Inputs come from tests/test_gpu_adapter_run.py (which builds them from the oracle's keypoints), every result is written to
 // <out_dir> as raw arrays and compared THERE with the oracle, bit for bit.  This program only checks what needs no oracle
 // (sizes, untouched outputs, context counts) and exits non-zero when one of those fails.
 // Built by __graft_entry__.build() with g++ where the reference headers exist; cv::Mat is tests/cv_standin (a container, no OpenCV
 // arithmetic), the handful of out-of-line reference members the link needs are tests/host/adapter_link_support.cc.
 #include "Frame.h"
+#include "KeyFrame.h"
 #include "MapPoint.h"
 #include "ORBmatcher.h"
 #include "ORBextractor.h"
@@ -123,6 +126,12 @@ struct TestMP : public MapPoint {   // MapPoint() is the header's own "for unit 
         memcpy(mDescriptor.data, d, 32);
     }
     void bad(bool b) { mbBad = b; }
+    void range(float mn, float mx) { mfMinDistance = mn; mfMaxDistance = mx; }
+};
+
+struct TestKF : public KeyFrame {   // a keyframe made of a frame's arrays; the harness fills the (protected) map-point list
+    explicit TestKF(Frame& F) : KeyFrame(F, NULL, NULL) {}
+    void points(const std::vector<MapPoint*>& v) { mvpMapPoints = v; }
 };
 
 static const float MBF = 47.906f, MB = 47.906f / 435.2f;
@@ -448,6 +457,110 @@ int main(int argc, char** argv)
             dump(std::string(pre) + "_nmatches_visible.bin", two, 8);
         }
         delete CurP;
+    }
+
+    // ------------------------------------------------------------------------------------------------------------------
+    // H. SearchByProjection(CurrentFrame = frame 1, KeyFrame = frame 0, sAlreadyFound, th, ORBdist) (ORBmatcher.cc:1595-1721)
+    if (kept.size() >= 2) {
+        struct Rec { int32_t has, bad, found, level; float p[3]; float dmin, dmax; };
+        std::vector<uint8_t> raw = slurp(g_in + "/H_kf.bin", false), dsc = slurp(g_in + "/H_kf_desc.bin", false), cal = slurp(g_in + "/H_calib.bin", false),
+                             tk = slurp(g_in + "/H_taken.bin", false);
+        Frame& F0 = *kept[0];
+        const int n = (int)(raw.size() / sizeof(Rec));
+        if (!raw.empty()) {
+            CHECK(n == F0.N && cal.size() == (16 + 7) * 4 && (int)tk.size() == kept[1]->N, "H: %d records for %d keypoints", n, F0.N);
+            if (n == F0.N && cal.size() == (16 + 7) * 4 && (int)tk.size() == kept[1]->N) {
+                const float* c = reinterpret_cast<const float*>(cal.data());
+                Frame* CurP = new Frame();
+                Frame& Cur = *CurP;
+                fill_frame(Cur, L, R, kept[1]->mvKeys, kept[1]->mDescriptors, kept[1]->mvKeysRight, kept[1]->mDescriptorsRight);
+                Cur.mTcw = mat4(c);
+                Frame::fx = c[16]; Frame::fy = c[17]; Frame::cx = c[18]; Frame::cy = c[19];
+                const float th = c[20];
+                const int orbdist = (int)c[21];
+                const bool ori = c[22] != 0.f;
+                TestKF kf(F0);
+                const Rec* r = reinterpret_cast<const Rec*>(raw.data());
+                std::vector<MapPoint*> kfmp(n, static_cast<MapPoint*>(NULL));
+                std::set<MapPoint*> found;
+                for (int i = 0; i < n; i++) {
+                    if (!r[i].has) continue;
+                    TestMP* p = new TestMP();
+                    p->world(r[i].p);
+                    p->bad(r[i].bad != 0);
+                    p->mnTrackScaleLevel = r[i].level;       // what PredictScale hands back (adapter_link_support.cc)
+                    p->range(r[i].dmin, r[i].dmax);
+                    p->descriptor(&dsc[(size_t)i * 32]);
+                    owned.push_back(p);
+                    kfmp[i] = p;
+                    if (r[i].found) found.insert(p);
+                }
+                kf.points(kfmp);
+                std::vector<TestMP*> pre;
+                for (int i = 0; i < Cur.N; i++)
+                    if (tk[i]) { TestMP* p = new TestMP(); owned.push_back(p); Cur.mvpMapPoints[i] = p; }
+                std::vector<MapPoint*> before = Cur.mvpMapPoints;
+                ORBmatcher matcher(0.9f, ori);
+                const int nm = matcher.SearchByProjection(Cur, &kf, found, th, orbdist);
+                std::vector<int32_t> idx(Cur.N, -1);        // KF keypoint whose map point sits in each slot this call filled; -2: cleared by it
+                for (int i = 0; i < Cur.N; i++) {
+                    if (Cur.mvpMapPoints[i] == before[i]) continue;
+                    idx[i] = Cur.mvpMapPoints[i] ? -3 : -2;
+                    for (int j = 0; j < n && Cur.mvpMapPoints[i]; j++) if (kfmp[j] == Cur.mvpMapPoints[i]) { idx[i] = j; break; }
+                }
+                dump("H_out_kf_idx.bin", idx.data(), idx.size() * 4);
+                int32_t n32 = nm;
+                dump("H_nmatches.bin", &n32, 4);
+                delete CurP;
+            }
+        }
+    }
+
+    // ------------------------------------------------------------------------------------------------------------------
+    // I. SearchByBoW(KeyFrame = frame 0, F = frame 1, vpMapPointMatches) (ORBmatcher.cc:270-404): the DBoW2::FeatureVector objects
+    //    are the reference's own class (oracle/_ref), filled by addFeature in keypoint order as TemplatedVocabulary::transform does
+    if (kept.size() >= 2) {
+        std::vector<uint8_t> kn = slurp(g_in + "/I_kf_nodes.bin", false), fn = slurp(g_in + "/I_f_nodes.bin", false), kv = slurp(g_in + "/I_kf_valid.bin", false);
+        Frame& F0 = *kept[0];
+        if (!kn.empty()) {
+            CHECK((int)(kn.size() / 4) == F0.N && (int)(fn.size() / 4) == kept[1]->N && (int)kv.size() == F0.N, "I: node lists");
+            if ((int)(kn.size() / 4) == F0.N && (int)(fn.size() / 4) == kept[1]->N && (int)kv.size() == F0.N) {
+                const int32_t* knode = reinterpret_cast<const int32_t*>(kn.data());
+                const int32_t* fnode = reinterpret_cast<const int32_t*>(fn.data());
+                F0.mFeatVec.clear();
+                for (int i = 0; i < F0.N; i++) if (knode[i] >= 0) F0.mFeatVec.addFeature((DBoW2::NodeId)knode[i], (unsigned)i);
+                TestKF kf(F0);      // (copies mFeatVec, mDescriptors, mvKeysUn)
+                std::vector<MapPoint*> kfmp(F0.N, static_cast<MapPoint*>(NULL));
+                for (int i = 0; i < F0.N; i++) {
+                    if (kv[i] == 0) continue;               // 0: no map point, 1: a good one, 2: a bad one
+                    TestMP* p = new TestMP();
+                    p->bad(kv[i] == 2);
+                    owned.push_back(p);
+                    kfmp[i] = p;
+                }
+                kf.points(kfmp);
+                Frame* FP = new Frame();
+                Frame& F = *FP;
+                fill_frame(F, L, R, kept[1]->mvKeys, kept[1]->mDescriptors, kept[1]->mvKeysRight, kept[1]->mDescriptorsRight);
+                for (int i = 0; i < F.N; i++) if (fnode[i] >= 0) F.mFeatVec.addFeature((DBoW2::NodeId)fnode[i], (unsigned)i);
+                for (int ori = 0; ori < 2; ori++) {
+                    ORBmatcher matcher(0.7f, ori != 0);
+                    std::vector<MapPoint*> matches;
+                    const int nm = matcher.SearchByBoW(&kf, F, matches);
+                    CHECK((int)matches.size() == F.N, "I: vpMapPointMatches has %zu entries for %d keypoints", matches.size(), F.N);
+                    std::vector<int32_t> idx(F.N, -1);
+                    for (int i = 0; i < F.N && i < (int)matches.size(); i++) {
+                        if (!matches[i]) continue;
+                        idx[i] = -3;
+                        for (int j = 0; j < F0.N; j++) if (kfmp[j] == matches[i]) { idx[i] = j; break; }
+                    }
+                    dump(ori ? "I_out_kf_idx_ori.bin" : "I_out_kf_idx.bin", idx.data(), idx.size() * 4);
+                    int32_t n32 = nm;
+                    dump(ori ? "I_nmatches_ori.bin" : "I_nmatches.bin", &n32, 4);
+                }
+                delete FP;
+            }
+        }
     }
 
     for (size_t i = 0; i < kept.size(); i++) delete kept[i];

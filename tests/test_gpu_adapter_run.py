@@ -192,6 +192,69 @@ def run(tmp_path_factory, oracle, euroc_l, euroc_r):
                                                            100, bool(ori), np.zeros(len(kl1), np.uint8))
         ref["F"].append({"nm": nm, "idx": np.where(out_q >= 0, qi[np.maximum(out_q, 0)], -1).astype(np.int32), "visible": len(qi),
                          "fwd": fwd, "bwd": bwd})
+    # H: SearchByProjection(Cur = frame 1, KeyFrame = frame 0, sAlreadyFound, th, ORBdist): the adapter's host side restated
+    # (ORBmatcher.cc:1607-1650; PredictScale / the distance range hand back what the harness stored, adapter_link_support.cc)
+    th_h, orbdist, ori_h = 10.0, 90, 1.0
+    Tc = _pose(-0.005, 0.004, 0.002, [0.02, 0.01, -0.03])
+    has = rng.random(n0) < 0.75
+    badk = has & (rng.random(n0) < 0.05)
+    foundk = has & (rng.random(n0) < 0.1)
+    zc = rng.uniform(1.5, 25.0, n0)
+    uc = kl0["x"] - 3.0 + rng.normal(0, 2.0, n0)
+    vc = kl0["y"] + rng.normal(0, 2.0, n0)
+    uc[rng.random(n0) < 0.03] -= 900.0
+    pcam = np.stack([(uc - CX) / FX * zc, (vc - CY) / FY * zc, zc], 1)
+    Rc, tc = Tc[:3, :3].astype(np.float64), Tc[:3, 3].astype(np.float64)
+    pw = ((pcam - tc[None, :]) @ Rc).astype(f32)
+    lev = np.clip(kl0["octave"] + rng.integers(-1, 2, n0), 0, 7).astype(np.int32)
+    Rcw, tcw = Tc[:3, :3], Tc[:3, 3]
+    Ow = _mm((-(Rcw.T)).astype(f32), tcw[None, :])[0]                     # -Rcw.t() * tcw
+    PO = (pw - Ow[None, :]).astype(f32)
+    dist3 = np.sqrt((PO.astype(np.float64) ** 2)[:, 0] + (PO.astype(np.float64) ** 2)[:, 1] + (PO.astype(np.float64) ** 2)[:, 2]).astype(f32)   # cv::norm -> float
+    dmin = (dist3 * rng.choice([0.5, 0.9, 1.2], n0, p=[0.5, 0.4, 0.1])).astype(f32)      # some points out of their distance range
+    dmax = (dist3 * rng.choice([2.0, 1.1, 0.8], n0, p=[0.5, 0.4, 0.1])).astype(f32)
+    qd = dl0.copy()
+    for j in range(n0):
+        for b in rng.integers(0, 256, rng.integers(0, 45)):
+            qd[j, b >> 3] ^= np.uint8(1 << (b & 7))
+    rec = np.zeros(n0, np.dtype([("has", "<i4"), ("bad", "<i4"), ("found", "<i4"), ("level", "<i4"), ("p", "<f4", 3), ("dmin", "<f4"), ("dmax", "<f4")]))
+    rec["has"], rec["bad"], rec["found"], rec["level"], rec["p"], rec["dmin"], rec["dmax"] = has, badk, foundk, lev, pw, dmin, dmax
+    rec.tofile(ind / "H_kf.bin")
+    qd.tofile(ind / "H_kf_desc.bin")
+    np.concatenate([Tc.ravel(), np.array([FX, FY, CX, CY, th_h, orbdist, ori_h], f32)]).astype(f32).tofile(ind / "H_calib.bin")
+    n1 = len(kl1)
+    tkh = (rng.random(n1) < 0.1).astype(np.uint8)
+    tkh.tofile(ind / "H_taken.bin")
+    x3 = (_mm(Rcw, pw) + tcw[None, :]).astype(f32)
+    with np.errstate(divide="ignore"):
+        invz = (1.0 / x3[:, 2].astype(np.float64)).astype(f32)
+    fx, fy, cx, cy = f32(FX), f32(FY), f32(CX), f32(CY)
+    u = ((((fx * x3[:, 0]).astype(f32)) * invz).astype(f32) + cx).astype(f32)
+    vv = ((((fy * x3[:, 1]).astype(f32)) * invz).astype(f32) + cy).astype(f32)
+    keep = has & ~badk & ~foundk & ~(u < 0) & ~(u > 752) & ~(vv < 0) & ~(vv > 480) & ~(dist3 < dmin) & ~(dist3 > dmax)
+    qi = np.nonzero(keep)[0]
+    q = np.zeros(len(qi), oracle.PROJ_QUERY_DTYPE)
+    q["u"], q["v"], q["ur"] = u[qi], vv[qi], 0.0
+    q["radius"] = (f32(th_h) * sf[lev[qi]]).astype(f32)
+    q["min_level"], q["max_level"] = lev[qi] - 1, lev[qi] + 1
+    q["angle"] = kl0["angle"][qi]
+    q["flags"] = 1 | 4
+    nm, out_q, _ = oracle.search_by_projection_kf(kl1, dl1, kl1["angle"], (0.0, 0.0, 752.0, 480.0), q, qd[qi], orbdist, bool(ori_h), tkh)
+    ref["H"] = {"nm": nm, "idx": np.where(out_q >= 0, qi[np.maximum(out_q, 0)], -1).astype(np.int32), "queries": len(qi),
+                "cleared": int((out_q == -2).sum())}       # (a slot this call wrote and its rotation check cleared is NULL again: -1)
+
+    # I: SearchByBoW(KeyFrame = frame 0, F = frame 1): feature vectors = a node id per keypoint (similar descriptors share a node)
+    knode = (dl0[:, 0].astype(np.int32) >> 2)                       # 64 "vocabulary nodes" from the descriptors' first bits
+    fnode = (dl1[:, 0].astype(np.int32) >> 2)
+    knode[rng.random(n0) < 0.05] = -1                              # stopped words: not in the vector
+    fnode[rng.random(n1) < 0.05] = -1
+    kvalid = rng.choice([0, 1, 2], n0, p=[0.25, 0.7, 0.05]).astype(np.uint8)    # no map point / a good one / a bad one
+    knode.astype(np.int32).tofile(ind / "I_kf_nodes.bin")
+    fnode.astype(np.int32).tofile(ind / "I_f_nodes.bin")
+    kvalid.tofile(ind / "I_kf_valid.bin")
+    ref["I"] = [oracle.search_by_bow(dl0, kl0["angle"], (kvalid == 1).astype(np.uint8), oracle.make_feature_vector(knode), dl1, kl1["angle"],
+                                     oracle.make_feature_vector(fnode), 0.7, bool(o)) for o in (0, 1)]
+
     env = dict(os.environ)
     env.pop("GFO_COMBINE", None)
     env.pop("GFO_FULL_PYRAMID", None)
@@ -336,3 +399,24 @@ def test_search_by_projection_last_frame_member(run):
         np.testing.assert_array_equal(got, want["idx"], err_msg=f"variant {v}")
         assert nm == want["nm"], v
         assert want["nm"] > 200, (v, want["nm"])
+
+
+def test_search_by_projection_keyframe_member(run):
+    """ORBmatcher::SearchByProjection(CurrentFrame, KeyFrame*, sAlreadyFound, th, ORBdist) (ORBmatcher.cc:1595-1721) through a KeyFrame
+    and MapPoint objects: already-found / bad points skipped, the distance range, the predicted level window, slots that were set
+    before the call untouched"""
+    want = run["H"]
+    assert want["queries"] > 800 and want["nm"] > 150 and want["cleared"] > 10
+    got = _rd(run, "H_out_kf_idx.bin", np.int32)
+    np.testing.assert_array_equal(got, want["idx"])
+    assert int(_rd(run, "H_nmatches.bin", np.int32)[0]) == want["nm"]
+
+
+def test_search_by_bow_member(run):
+    """ORBmatcher::SearchByBoW(KeyFrame*, Frame&, vector<MapPoint*>&) (ORBmatcher.cc:270-404): the adapter flattens two real
+    DBoW2::FeatureVector objects (the reference's own class) and the keyframe's map-point list; with and without the rotation check"""
+    for tag, (nm, out) in zip(("", "_ori"), run["I"]):
+        got = _rd(run, f"I_out_kf_idx{tag}.bin", np.int32)
+        np.testing.assert_array_equal(got, out, err_msg=tag)
+        assert int(_rd(run, f"I_nmatches{tag}.bin", np.int32)[0]) == nm
+        assert nm > 100, (tag, nm)
