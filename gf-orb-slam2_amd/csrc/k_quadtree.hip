@@ -129,6 +129,7 @@ __device__ __forceinline__ QtBox qt_child_box(QtBox b, int q)
 #define QT_OCC_ATTR
 #endif
 #include "k_quadtree_body.inc"
+#include "k_quadtree_wide.inc"
 #include "k_blur_dev.inc"
 
 __global__ __launch_bounds__(QT_MAX_THREADS) QT_OCC_ATTR void k_quadtree(const GfoGeom* __restrict__ gp, const uint32_t* __restrict__ cand,
@@ -156,17 +157,25 @@ __global__ __launch_bounds__(QT_MAX_THREADS) QT_OCC_ATTR void k_quadtree_gmem(co
 // (profiles/stereo_direct_r05.txt, the timeline).  Here workgroups [0, nqt) are k_quadtree's, level-major, and the rest are the
 // blur's 256-thread blocks, four to a workgroup: no second stream, no events, and the blur's blocks fill the CUs the sixteen
 // quadtree workgroups leave idle.  (Batches keep the two launches: there the blur wants its own launch shape and XCD placement.)
-__global__ __launch_bounds__(QT_MAX_THREADS) QT_OCC_ATTR void k_quadtree_blur(const GfoGeom* __restrict__ gp, const uint32_t* __restrict__ cand,
+// (1024-thread workgroups: four waves per SIMD is all a CU can hold of them -- the whole register file of 128 is theirs)
+__global__ __launch_bounds__(QT_MAX_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_quadtree_blur(const GfoGeom* __restrict__ gp, const uint32_t* __restrict__ cand,
                                                                               const int* __restrict__ cand_cnt, uint16_t* __restrict__ node_of_all,
                                                                               uint32_t* __restrict__ sel, int* __restrict__ sel_cnt, int* __restrict__ flags,
                                                                               int ncap, int klds, unsigned long long* __restrict__ dbg_ts, GfoInput in,
                                                                               const uint8_t* __restrict__ pyr, uint8_t* __restrict__ blur, int nimg, int nqt,
-                                                                              int blur_blocks)
+                                                                              int blur_blocks, int wide)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t qt_lds[];
     const int b = blockIdx.x;
     if (b < nqt) {
-        qt_body(gp, cand, cand_cnt, node_of_all, sel, sel_cnt, flags, ncap, klds, dbg_ts, b % nimg, b / nimg, qt_lds);
+        const int img = b % nimg, level = b / nimg;
+        // the one-thread-per-node form (k_quadtree_wide.inc) when the node list fits the workgroup and the level's keys fit LDS
+        const GfoGeom& g0 = *gp;
+        const int kraw = min(cand_cnt[(img * g0.nlevels + level) * GFO_CNT_STRIDE], g0.lv[level].cand_cap);
+        if (wide && kraw <= klds)
+            qt_body_wide(gp, cand, cand_cnt, sel, sel_cnt, flags, ncap, klds, dbg_ts, img, level, qt_lds);
+        else
+            qt_body(gp, cand, cand_cnt, node_of_all, sel, sel_cnt, flags, ncap, klds, dbg_ts, img, level, qt_lds);
         return;
     }
     const GfoGeom& g = *gp;
@@ -288,8 +297,11 @@ static bool launch_quadtree(gfo_ctx* c, int nimg, const GfoInput* blur_in)
     if (fused) {
         const int nqt = nimg * nl;
         const int blur_wgs = (nimg * blur_blocks + QT_MAX_THREADS / 256 - 1) / (QT_MAX_THREADS / 256);
+        // (GFO_QT_WIDE=0: the general body for every workgroup)
+        const char* wide_env = getenv("GFO_QT_WIDE");
+        const int wide = grp[0].ncap <= QT_MAX_THREADS && grp[0].klds > 0 && !(wide_env && wide_env[0] == '0') ? 1 : 0;
         GFO_LAUNCH(c, k_quadtree_blur, dim3(nqt + blur_wgs), dim3(QT_MAX_THREADS), grp[0].lds, c->stream, c->d_geom, c->d_cand, c->d_cand_cnt, c->d_node_of,
-                           c->d_sel, c->d_sel_cnt, c->d_flags, grp[0].ncap, grp[0].klds, d_ts, *blur_in, c->d_pyr, c->d_blur, nimg, nqt, blur_blocks);
+                           c->d_sel, c->d_sel_cnt, c->d_flags, grp[0].ncap, grp[0].klds, d_ts, *blur_in, c->d_pyr, c->d_blur, nimg, nqt, blur_blocks, wide);
     } else if (gmem)
         GFO_LAUNCH(c, k_quadtree_gmem, dim3(nimg, nl), dim3(1024), 0, c->stream, c->d_geom, c->d_cand, c->d_cand_cnt, c->d_node_of,
                            c->d_sel, c->d_sel_cnt, c->d_flags, ncap, d_ts, c->d_qt_scratch, (unsigned long long)c->qt_scratch_stride);
