@@ -14,8 +14,10 @@
 // nodes by (size desc, position asc), prefix-sums how many nodes each split adds, cuts where
 // the total reaches N, and rebuilds the list the same way.
 //
-// One workgroup per (image, level); node tables live in LDS, keys and their node index in HBM
-// scratch (L2-resident: a level holds a few thousand candidates).
+// One workgroup per (image, level); node tables and (up to 7 x quota of) the keys live in LDS, a level with more candidates
+// keeps its keys in L2, a level whose tables exceed LDS runs from an HBM scratch block (k_quadtree_gmem).  Two statements of
+// the algorithm: k_quadtree_body.inc (any workgroup size: batches) and k_quadtree_wide.inc (per-frame batches: 1024 threads,
+// one thread per node, a third of the barriers), launched there together with the blur as k_quadtree_blur.
 #include "gfo_internal.h"
 #include <stdlib.h>
 
