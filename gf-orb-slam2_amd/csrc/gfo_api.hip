@@ -804,7 +804,7 @@ static int extract_launches(gfo_ctx* c, const GfoInput& in, int nimg, const gfo_
     // (GFO_QT_FUSE_BLUR=0: the forked form)
     static const bool fuse_env = !(getenv("GFO_QT_FUSE_BLUR") && getenv("GFO_QT_FUSE_BLUR")[0] == '0');
     bool fused_done = false;
-    if (fork && fuse_env && nimg <= 8) {
+    if (fork && fuse_env && nimg <= gfo_few_max()) {
         gfo_launch_fast(c, in, nimg);
         GFO_PACE_POINT(GFO_STAGE_FAST);
         fused_done = gfo_launch_quadtree_blur(c, in, nimg);

@@ -309,6 +309,9 @@ void gfo_launch_pyramid_bands(gfo_ctx* c, const GfoInput& in, int nimg);
 int gfo_pyramid_bands_prepare(int lds_bytes);
 void gfo_launch_blur(gfo_ctx* c, const GfoInput& in, int nimg);
 void gfo_launch_fast(gfo_ctx* c, const GfoInput& in, int nimg);
+// images up to which a batch counts as a per-frame batch: 1024-thread one-thread-per-node quadtree workgroups, quadtree + blur as one launch
+// (GFO_FEW_MAX; the frame combiner's batches at K = 8 .. 16 camera threads are 16 .. 32 images)
+int gfo_few_max();
 void gfo_launch_quadtree(gfo_ctx* c, int nimg);
 bool gfo_launch_quadtree_blur(gfo_ctx* c, const GfoInput& in, int nimg);   // per-frame batches: quadtree + blur as one launch (false: not applicable, nothing launched)
 void gfo_launch_orient_desc(gfo_ctx* c, const GfoInput& in, int nimg);

@@ -208,6 +208,14 @@ static int qt_level_klds(const GfoLevel& L, int cap)
     return k < cap ? k : cap;
 }
 
+int gfo_few_max()
+{
+    // 16: the frame combiner's batches at K = 8 .. 16 camera threads are 6 .. 16 images (8: 59.1 / 57.2 k images/s at K = 16,
+    // 16: 62.3 / 63.3 k, 32: 59.4 / 68.6 k; K = 4, 8 within the noise -- profiles/stereo_direct_r05.txt)
+    static const int v = getenv("GFO_FEW_MAX") ? atoi(getenv("GFO_FEW_MAX")) : 16;
+    return v < 1 ? 1 : v;
+}
+
 static bool launch_quadtree(gfo_ctx* c, int nimg, const GfoInput* blur_in)
 {
     const int nl = c->g.nlevels;
@@ -222,7 +230,7 @@ static bool launch_quadtree(gfo_ctx* c, int nimg, const GfoInput* blur_in)
     // workgroup = THREE workgroups per CU instead of two for all eight levels.  k_quadtree alone 163 -> 116 us per 256 images
     // (profiles/quadtree_occupancy_r05.txt); a level with more candidates than that runs on its keys in L2, same code.
     static const int klds_env = getenv("GFO_QT_KLDS") ? atoi(getenv("GFO_QT_KLDS")) : -1;
-    const bool few = nimg <= 8;
+    const bool few = nimg <= gfo_few_max();
     int klds = klds_env >= 0 ? klds_env : (few ? 6144 : qt_level_klds(c->g.lv[0], 6144));
     while (klds > 0 && gfo_quadtree_lds_bytes(ncap, klds) > 150 * 1024) klds -= 1024;
     const size_t lds = gfo_quadtree_lds_bytes(ncap, klds);

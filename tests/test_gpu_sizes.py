@@ -252,13 +252,13 @@ def test_fast_queue_overflow_paths(oracle, monkeypatch, qcap):
 @pytest.mark.parametrize("groups", ["auto", "2,5", "1,99", "0"])
 def test_quadtree_level_groups_and_key_overflow_to_l2(oracle, monkeypatch, groups):
     """k_quadtree launched as level ranges with their own node / key capacity (GFO_QT_GROUPS, opt-in: measured, not the default,
-    profiles/quadtree_occupancy_r05.txt) and the batch default of 7 x quota LDS keys: a batch of 12 images (the grouped forms apply
-    from 9 images on) among them noise frames whose level-0 candidate count exceeds the LDS key capacity (those workgroups run on
+    profiles/quadtree_occupancy_r05.txt) and the batch default of 7 x quota LDS keys: a batch of 20 images (the grouped forms apply
+    above GFO_FEW_MAX = 16 images) among them noise frames whose level-0 candidate count exceeds the LDS key capacity (those workgroups run on
     their keys in L2) -- every image equals the oracle."""
     import gf_orb_slam2_amd as G
     monkeypatch.setenv("GFO_QT_GROUPS", groups)
     rng = np.random.default_rng(3)
-    imgs = [synth_frame(752, 480, 60 + i) for i in range(10)]
+    imgs = [synth_frame(752, 480, 60 + i) for i in range(18)]
     noisy = synth_frame(752, 480, 7).astype(np.int32) + rng.integers(-60, 60, (480, 752))      # many more FAST candidates per level
     imgs += [np.clip(noisy, 0, 255).astype(np.uint8), rng.integers(0, 256, (480, 752), dtype=np.uint8)]
     ext = G.ORBextractor(2000, 1.2, 8, 20, 7, max_batch=len(imgs))

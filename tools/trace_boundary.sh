@@ -29,7 +29,7 @@ for t, d in ev:
 wall = t_hi - t_lo
 per = collections.defaultdict(list)
 for s, e, n in win: per[n].append(e - s)
-frames = len(per.get('k_stereo_cut', [])) or 1
+frames = len(per.get("k_stereo_cut", [])) or len(per.get("k_pack_results_cut", [])) or 1   # (round 5: the per-frame path has no k_stereo_cut launch; the pack kernel makes the cut)
 print(f"window {wall/1e6:.1f} ms, {frames} stereo frames -> {wall/1e3/frames:.1f} us per frame; sum of kernel durations per frame {sum(sum(v) for v in per.values())/1e3/frames:.1f} us")
 for d in range(9): print(f"  {d}{'+' if d==8 else ' '} kernels in flight: {100*hist[d]/wall:5.1f} %")
 print("kernel, launches per frame, avg us")
