@@ -956,7 +956,7 @@ void gfo_launch_stereo(gfo_ctx* c, const GfoStereoLaunch& s)
     // GFO_STEREO_ROWS setting, keeps the bucketed forms: the tests run all of them in one process)
     const char* direct_env = getenv("GFO_STEREO_DIRECT");
     const int max_nr = s.cnt_dev ? s.out_stride : s.nr_host;
-    const bool direct = !rows_form && rows_env < 0 && !(direct_env && direct_env[0] == '0') && s.npairs <= 3 && max_nr > 0 && max_nr <= 4096 && s.nlevels > 0 &&
+    const bool direct = !rows_form && rows_env < 0 && !(direct_env && direct_env[0] == '0') && s.npairs <= 3 && max_nr > 0 && max_nr <= 3584 && s.nlevels > 0 &&   /* 16 B per right keypoint + 4 KB of lists: inside the 64 KB a launch gets without asking */
                         s.p.n_rows <= 65535;
     if (direct) {
         gfo_prof_begin(c, ST_STEREO);

@@ -263,3 +263,26 @@ def test_chained_contexts_alternate_stereo_frames(oracle, euroc_l, euroc_r):
             assert a.tobytes() == b.tobytes()
     for e in exts:
         e.close()
+
+
+@pytest.mark.parametrize("nfeat,w,h", [(4000, 1241, 376), (3400, 1241, 376), (8000, 1920, 1080)])
+def test_stereo_frame_with_more_keypoints_than_the_lds_table_holds(oracle, nfeat, w, h):
+    """The per-frame association without a bucketing launch (k_stereo_match_direct) keeps every right keypoint of the pair in LDS
+    (16 bytes each): frames whose keypoint stride exceeds what 64 KB hold (3584) must take the bucketed kernels instead -- 4000
+    features on a KITTI-sized frame and 8000 at 1080p; 3400 stays on the direct form.  One submission, bit for bit as the oracle."""
+    import gf_orb_slam2_amd as G
+    from gf_orb_slam2_amd.synth import synth_stereo_pair
+    l, r = synth_stereo_pair(w, h, 5)
+    ext = G.ORBextractor(nfeat, 1.2, 8, 20, 7, max_batch=2)
+    oe = oracle.OracleExtractor(nfeat, 1.2, 8, 20, 7)
+    prm = G.StereoParams(h, BF, BF / FX, 0.0)
+    okl, odl = oe(l)
+    okr, odr = oe(r)
+    ref = oracle.stereo_match(okl, odl, okr, odr, oe.scale_factors, prm.n_rows, prm.mbf, prm.mb, prm.min_x)
+    for _ in range(2):
+        kl, dl, kr, dr, nm, u, dp, bd, bi = ext.extract_stereo(l, r, prm)
+        assert kl.tobytes() == okl.tobytes() and kr.tobytes() == okr.tobytes() and (dl == odl).all() and (dr == odr).all()
+        assert nm == ref[0] and len(kl) > 0.8 * nfeat
+        for a, b in zip((u, dp, bd, bi), ref[1:]):
+            assert a.tobytes() == b.tobytes()
+    ext.close()
