@@ -119,3 +119,26 @@ def test_link_time_swap_of_the_matcher_bodies(tmp_path, shared, cxx, extra):
     assert r.returncode == 0, r.stderr[-2000:]
     out = subprocess.run([exe], capture_output=True, text=True)
     assert out.returncode == 0 and out.stdout.split() == ["2", "2", "2", "2", "2", "2", "2", "7"], out.stdout
+
+
+@pytest.mark.skipif(not os.path.exists(os.path.join(REF_INC, "ORBextractor.h")), reason="reference headers not mounted")
+@pytest.mark.skipif(shutil.which("g++") is None, reason="g++ missing")
+def test_adapter_program_links_and_fails_loudly_without_a_device(tmp_path):
+    """tests/_build/adapter_run (the adapters compiled against the reference's unchanged headers, linked with libgfo.so and the
+    reference's own DBoW2 objects) builds here, resolves its libraries, and -- on this GPU-less container -- every adapter call
+    reports "no HIP device" and returns the reference's empty result (ORBextractor.cc:1133-1134): no CPU path, no exception, no
+    crash.  The same binary is what tests/test_gpu_adapter_run.py executes on the GPU box."""
+    import torch
+    r = subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "tests", "host")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+    exe = os.path.join(ROOT, "tests", "_build", "adapter_run")
+    ldd = subprocess.run(["ldd", exe], capture_output=True, text=True).stdout
+    assert "libgfo.so" in ldd and "libdbow2_fold.so" in ldd and "not found" not in ldd, ldd
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present: tests/test_gpu_adapter_run.py runs the program for real")
+    out = tmp_path / "out"
+    out.mkdir()
+    p = subprocess.run([exe, os.path.join(ROOT, "tests", "golden"), str(tmp_path), str(out), "2"], capture_output=True, text=True, timeout=120)
+    assert p.returncode in (1, 3), (p.returncode, p.stderr[-2000:])          # check failures / missing inputs -- never a signal
+    assert "no HIP device available (this library has no CPU fallback)" in p.stderr
+    assert os.path.getsize(out / "A_f00_kl.bin") == 0 and os.path.getsize(out / "A_f00_dl.bin") == 0      # zero keypoints, descriptors released
