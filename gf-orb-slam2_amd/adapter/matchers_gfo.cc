@@ -425,6 +425,7 @@ namespace
 // (gfo_vocabulary), keeping the vocabulary's own child order (ties in the descent keep the FIRST minimum, :1251-1260).
 struct VocabularyView : public ORBVocabulary {
     struct Flat {
+        uint64_t print;      // fingerprint() of the vocabulary this copy was made from
         std::vector<int32_t> first_child, n_children, word_id, orig_id;
         std::vector<float> weight;
         std::vector<double> weight64;
@@ -453,6 +454,26 @@ struct VocabularyView : public ORBVocabulary {
             if (i > 0 && nd.descriptor.cols == 32) memcpy(&f.desc[i * 32], nd.descriptor.data, 32);
         }
     }
+    // A cheap identity of the vocabulary's CONTENT: the flattened copy is cached per object address, and an application that deletes
+    // a vocabulary and loads another may get the same address back (round 5: tests/host/adapter_run.cc builds four vocabularies in
+    // one stack slot).  Shape, parameters and a sample of 64 nodes (weight, word id, eight descriptor bytes): a few hundred bytes per
+    // ComputeBoW call, against re-reading a million nodes.
+    uint64_t fingerprint() const
+    {
+        uint64_t hsh = 1469598103934665603ull;
+        auto mix = [&](uint64_t v) { hsh = (hsh ^ v) * 1099511628211ull; };
+        const size_t n = m_nodes.size();
+        mix(n); mix((uint64_t)m_k); mix((uint64_t)m_L); mix((uint64_t)m_weighting); mix((uint64_t)m_scoring); mix(m_words.size());
+        const size_t step = n > 64 ? n / 64 : 1;
+        for (size_t i = 0; i < n; i += step) {
+            const Node& nd = m_nodes[i];
+            uint64_t w;
+            memcpy(&w, &nd.weight, 8);
+            mix(w); mix((uint64_t)nd.word_id); mix(nd.children.size());
+            if (nd.descriptor.cols == 32 && nd.descriptor.data) { uint64_t d8; memcpy(&d8, nd.descriptor.data, 8); mix(d8); }
+        }
+        return hsh;
+    }
     using ORBVocabulary::m_weighting;
     using ORBVocabulary::m_scoring_object;
 };
@@ -477,15 +498,21 @@ void Frame::ComputeBoW()
     const VocabularyView::Flat* flat;
     {
         std::lock_guard<std::mutex> lk(g_voc_mu);
+        const uint64_t print = static_cast<const VocabularyView*>(mpORBvocabulary)->fingerprint();
         std::map<const ORBVocabulary*, VocabularyView::Flat>::iterator it = g_voc_flat.find(mpORBvocabulary);
-        if (it == g_voc_flat.end()) {
-            it = g_voc_flat.insert(std::make_pair(mpORBvocabulary, VocabularyView::Flat())).first;
+        bool fresh = false;
+        if (it == g_voc_flat.end() || it->second.print != print) {      // first sight, or another vocabulary at a known address
+            if (it == g_voc_flat.end()) it = g_voc_flat.insert(std::make_pair(mpORBvocabulary, VocabularyView::Flat())).first;
             static_cast<const VocabularyView*>(mpORBvocabulary)->flatten(it->second);
+            it->second.print = print;
+            fresh = true;
+            for (std::map<uint64_t, const ORBVocabulary*>::iterator o = g_voc_on_ctx.begin(); o != g_voc_on_ctx.end();)   // what the contexts hold of this address is stale
+                if (o->second == mpORBvocabulary) g_voc_on_ctx.erase(o++); else ++o;
         }
         flat = &it->second;
         const uint64_t id = gfo_ctx_id(c);
         std::map<uint64_t, const ORBVocabulary*>::iterator on = g_voc_on_ctx.find(id);
-        const bool resident = on != g_voc_on_ctx.end() && on->second == mpORBvocabulary &&
+        const bool resident = !fresh && on != g_voc_on_ctx.end() && on->second == mpORBvocabulary &&
                               gfo_vocabulary_nodes(c) == (int)flat->first_child.size();
         if (!resident) {
             gfo_vocabulary v = {flat->first_child.data(), flat->n_children.data(), flat->desc.data(), flat->word_id.data(),

@@ -11,6 +11,29 @@
 #include "MapPoint.h"
 #include "ORBmatcher.h"
 
+// ---- DBoW2: an ORBVocabulary OBJECT (the harness builds one for Frame::ComputeBoW) instantiates every virtual member of
+//      TemplatedVocabulary -- create / transform / save / load -- and with them names FORB's descriptor functions (FORB.cpp) and the six
+//      scoring classes' score() (ScoringObject.cpp), neither of which this image can build.  The adapter never calls any of them (the
+//      descent and the fold run on the device); the definitions below exist for the linker and abort if they are ever reached.
+namespace DBoW2
+{
+static void unreachable(const char* what)
+{
+    fprintf(stderr, "[adapter_link_support] %s was called: it is a link stub, not DBoW2\n", what);
+    abort();
+}
+int FORB::distance(const cv::Mat&, const cv::Mat&) { unreachable("FORB::distance"); return 0; }
+void FORB::meanValue(const std::vector<FORB::pDescriptor>&, FORB::TDescriptor&) { unreachable("FORB::meanValue"); }
+std::string FORB::toString(const FORB::TDescriptor&) { unreachable("FORB::toString"); return std::string(); }
+void FORB::fromString(FORB::TDescriptor&, const std::string&) { unreachable("FORB::fromString"); }
+double L1Scoring::score(const BowVector&, const BowVector&) const { unreachable("L1Scoring::score"); return 0; }
+double L2Scoring::score(const BowVector&, const BowVector&) const { unreachable("L2Scoring::score"); return 0; }
+double ChiSquareScoring::score(const BowVector&, const BowVector&) const { unreachable("ChiSquareScoring::score"); return 0; }
+double KLScoring::score(const BowVector&, const BowVector&) const { unreachable("KLScoring::score"); return 0; }
+double BhattacharyyaScoring::score(const BowVector&, const BowVector&) const { unreachable("BhattacharyyaScoring::score"); return 0; }
+double DotProductScoring::score(const BowVector&, const BowVector&) const { unreachable("DotProductScoring::score"); return 0; }
+}  // namespace DBoW2
+
 namespace ORB_SLAM2
 {
 

@@ -13,7 +13,8 @@
 //   F. ORBmatcher::SearchByProjection(CurrentFrame, LastFrame, th, bMono, numVisible) (ORBmatcher.cc:1440-1593), including the
 //      host-side projection the adapter keeps (:1451-1502);
 //   H. ORBmatcher::SearchByProjection(CurrentFrame, KeyFrame*, sAlreadyFound, th, ORBdist) (ORBmatcher.cc:1595-1721), relocalisation's;
-//   I. ORBmatcher::SearchByBoW(KeyFrame*, Frame&, vpMapPointMatches) (ORBmatcher.cc:270-404) with real DBoW2::FeatureVector objects.
+//   I. ORBmatcher::SearchByBoW(KeyFrame*, Frame&, vpMapPointMatches) (ORBmatcher.cc:270-404) with real DBoW2::FeatureVector objects;
+//   J. Frame::ComputeBoW() (Frame.cc:661-668) on an ORBVocabulary object whose tree the harness fills: mBowVec and mFeatVec.
 // Inputs come from tests/test_gpu_adapter_run.py (which builds them from the oracle's keypoints), every result is written to
 // <out_dir> as raw arrays and compared THERE with the oracle, bit for bit.  This program only checks what needs no oracle
 // (sizes, untouched outputs, context counts) and exits non-zero when one of those fails.
@@ -127,6 +128,33 @@ struct TestMP : public MapPoint {   // MapPoint() is the header's own "for unit 
     }
     void bad(bool b) { mbBad = b; }
     void range(float mn, float mx) { mfMinDistance = mn; mfMaxDistance = mx; }
+};
+
+// an ORBVocabulary whose (protected) tree the harness fills from a flattened description: node i's children are
+// [first_child, first_child + n_children), ids are the breadth-first indices
+struct TestVoc : public ORBVocabulary {
+    TestVoc(int k, int L, DBoW2::WeightingType w, DBoW2::ScoringType s) : ORBVocabulary(k, L, w, s) {}
+    void fill(int n, const int32_t* first, const int32_t* nch, const int32_t* word, const double* weight, const uint8_t* desc)
+    {
+        m_nodes.clear();
+        m_nodes.resize(n);
+        int nwords = 0;
+        for (int i = 0; i < n; i++) nwords += nch[i] == 0 && i > 0;
+        m_words.assign(nwords, NULL);
+        for (int i = 0; i < n; i++) {
+            Node& nd = m_nodes[i];
+            nd.id = (DBoW2::NodeId)i;
+            nd.weight = weight[i];
+            nd.word_id = word[i] >= 0 ? (DBoW2::WordId)word[i] : 0;
+            nd.descriptor = cv::Mat(1, 32, CV_8U);
+            memcpy(nd.descriptor.data, desc + (size_t)i * 32, 32);
+            for (int c = 0; c < nch[i]; c++) {
+                nd.children.push_back((DBoW2::NodeId)(first[i] + c));
+                m_nodes[first[i] + c].parent = (DBoW2::NodeId)i;
+            }
+            if (nch[i] == 0 && i > 0 && word[i] >= 0 && word[i] < nwords) m_words[word[i]] = &nd;
+        }
+    }
 };
 
 struct TestKF : public KeyFrame {   // a keyframe made of a frame's arrays; the harness fills the (protected) map-point list
@@ -561,6 +589,49 @@ int main(int argc, char** argv)
                 delete FP;
             }
         }
+    }
+
+    // ------------------------------------------------------------------------------------------------------------------
+    // J. Frame::ComputeBoW() (Frame.cc:661-668 -> TemplatedVocabulary::transform, levelsup 4): vocabularies of several shapes,
+    //    weightings and scorings; the same frame asked twice (the second call returns at once, :663)
+    for (int v = 0; kept.size() >= 2; v++) {
+        char pre[16];
+        snprintf(pre, sizeof pre, "J%d", v);
+        std::vector<uint8_t> hdr = slurp(g_in + "/" + pre + "_voc_hdr.bin", false);
+        if (hdr.empty()) break;
+        const int32_t* h = reinterpret_cast<const int32_t*>(hdr.data());     // n_nodes, k, depth, weighting, scoring
+        const int n = h[0];
+        std::vector<uint8_t> fc = slurp(g_in + "/" + pre + "_first.bin"), nc = slurp(g_in + "/" + pre + "_nch.bin"), wd = slurp(g_in + "/" + pre + "_word.bin"),
+                             wt = slurp(g_in + "/" + pre + "_weight.bin"), ds = slurp(g_in + "/" + pre + "_desc.bin");
+        CHECK(hdr.size() == 20 && (int)fc.size() == 4 * n && (int)nc.size() == 4 * n && (int)wd.size() == 4 * n && (int)wt.size() == 8 * n && (int)ds.size() == 32 * n,
+              "%s: vocabulary files", pre);
+        if (!((int)fc.size() == 4 * n && (int)wt.size() == 8 * n && (int)ds.size() == 32 * n)) continue;
+        TestVoc voc(h[1], h[2], (DBoW2::WeightingType)h[3], (DBoW2::ScoringType)h[4]);
+        voc.fill(n, reinterpret_cast<const int32_t*>(fc.data()), reinterpret_cast<const int32_t*>(nc.data()), reinterpret_cast<const int32_t*>(wd.data()),
+                 reinterpret_cast<const double*>(wt.data()), ds.data());
+        Frame* FP = new Frame();
+        Frame& F = *FP;
+        fill_frame(F, L, R, kept[1]->mvKeys, kept[1]->mDescriptors, kept[1]->mvKeysRight, kept[1]->mDescriptorsRight);
+        F.mpORBvocabulary = &voc;
+        F.ComputeBoW();
+        const size_t nw = F.mBowVec.size();
+        F.ComputeBoW();                                      // "if(mBowVec.empty())": nothing happens the second time
+        CHECK(F.mBowVec.size() == nw, "%s: the second ComputeBoW changed mBowVec", pre);
+        std::vector<uint32_t> bw, fn, fi;
+        std::vector<double> bv;
+        std::vector<int32_t> fs(1, 0);
+        for (DBoW2::BowVector::const_iterator it = F.mBowVec.begin(); it != F.mBowVec.end(); ++it) { bw.push_back(it->first); bv.push_back(it->second); }
+        for (DBoW2::FeatureVector::const_iterator it = F.mFeatVec.begin(); it != F.mFeatVec.end(); ++it) {
+            fn.push_back(it->first);
+            fi.insert(fi.end(), it->second.begin(), it->second.end());
+            fs.push_back((int32_t)fi.size());
+        }
+        dump(std::string(pre) + "_bow_words.bin", bw.data(), bw.size() * 4);
+        dump(std::string(pre) + "_bow_values.bin", bv.data(), bv.size() * 8);
+        dump(std::string(pre) + "_fv_nodes.bin", fn.data(), fn.size() * 4);
+        dump(std::string(pre) + "_fv_start.bin", fs.data(), fs.size() * 4);
+        dump(std::string(pre) + "_fv_items.bin", fi.data(), fi.size() * 4);
+        delete FP;
     }
 
     for (size_t i = 0; i < kept.size(); i++) delete kept[i];

@@ -258,6 +258,20 @@ def run(tmp_path_factory, oracle, euroc_l, euroc_r):
     ref["I"] = [oracle.search_by_bow(dl0, kl0["angle"], (kvalid == 1).astype(np.uint8), oracle.make_feature_vector(knode), dl1, kl1["angle"],
                                      oracle.make_feature_vector(fnode), 0.7, bool(o)) for o in (0, 1)]
 
+    # J: Frame::ComputeBoW() on frame 1 with vocabularies of several shapes / weightings / scorings (levelsup = 4, Frame.cc:666)
+    ref["J"] = []
+    for v, (k, depth, weighting, scoring, norm) in enumerate([(10, 3, 0, 0, 1), (6, 5, 1, 1, 2), (8, 4, 2, 5, 0), (9, 2, 3, 0, 1)]):
+        voc = oracle.make_vocabulary(k, depth, seed=40 + v, p_stop=0.08)
+        voc["weight"] = voc["weight64"].astype(np.float32)           # DBoW2 holds ONE weight per node, a double
+        n = len(voc["first_child"])
+        np.array([n, k, depth, weighting, scoring], np.int32).tofile(ind / f"J{v}_voc_hdr.bin")
+        voc["first_child"].astype(np.int32).tofile(ind / f"J{v}_first.bin")
+        voc["n_children"].astype(np.int32).tofile(ind / f"J{v}_nch.bin")
+        voc["word_id"].astype(np.int32).tofile(ind / f"J{v}_word.bin")
+        voc["weight64"].astype(np.float64).tofile(ind / f"J{v}_weight.bin")
+        voc["descriptors"].astype(np.uint8).tofile(ind / f"J{v}_desc.bin")
+        ref["J"].append(oracle.compute_bow(voc, dl1, 4, weighting, norm))
+
     env = dict(os.environ)
     env.pop("GFO_COMBINE", None)
     env.pop("GFO_FULL_PYRAMID", None)
@@ -423,3 +437,19 @@ def test_search_by_bow_member(run):
         np.testing.assert_array_equal(got, out, err_msg=tag)
         assert int(_rd(run, f"I_nmatches{tag}.bin", np.int32)[0]) == nm
         assert nm > 100, (tag, nm)
+
+
+def test_compute_bow_member(run):
+    """Frame::ComputeBoW() (Frame.cc:661-668) through an ORBVocabulary object: the adapter reads the tree through a derived type,
+    uploads it once per context, and fills mBowVec / mFeatVec from the device's flattened maps -- word ids, WordValues (bit for bit,
+    doubles), node ids and feature index lists equal the oracle's literal statement of TemplatedVocabulary::transform, for four
+    vocabulary shapes x weightings x scorings"""
+    assert len(run["J"]) == 4
+    assert max(len(j[2]) for j in run["J"]) > 3                    # the depth-5 tree spreads the features over several nodes
+    for v, (bw, bv, fn, fs, fi) in enumerate(run["J"]):
+        assert len(bw) > 20 and len(fn) >= 1, v          # (levelsup 4 on a tree of depth <= 4 puts every feature under the root)
+        np.testing.assert_array_equal(_rd(run, f"J{v}_bow_words.bin", np.uint32), bw, err_msg=str(v))
+        assert _rd(run, f"J{v}_bow_values.bin", np.float64).tobytes() == bv.tobytes(), v
+        np.testing.assert_array_equal(_rd(run, f"J{v}_fv_nodes.bin", np.uint32), fn, err_msg=str(v))
+        np.testing.assert_array_equal(_rd(run, f"J{v}_fv_start.bin", np.int32), fs, err_msg=str(v))
+        np.testing.assert_array_equal(_rd(run, f"J{v}_fv_items.bin", np.uint32), fi, err_msg=str(v))
