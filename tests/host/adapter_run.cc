@@ -14,7 +14,10 @@
 //      host-side projection the adapter keeps (:1451-1502);
 //   H. ORBmatcher::SearchByProjection(CurrentFrame, KeyFrame*, sAlreadyFound, th, ORBdist) (ORBmatcher.cc:1595-1721), relocalisation's;
 //   I. ORBmatcher::SearchByBoW(KeyFrame*, Frame&, vpMapPointMatches) (ORBmatcher.cc:270-404) with real DBoW2::FeatureVector objects;
-//   J. Frame::ComputeBoW() (Frame.cc:661-668) on an ORBVocabulary object whose tree the harness fills: mBowVec and mFeatVec.
+//   J. Frame::ComputeBoW() (Frame.cc:661-668) on an ORBVocabulary object whose tree the harness fills: mBowVec and mFeatVec;
+//   K. three stereo cameras at once: six ORBextractor objects, three camera threads each creating a thread for its right image per
+//      frame, associations through the rigs -- every camera's every frame must equal what one camera alone got for those images;
+//   (GFO_FULL_PYRAMID=1 in the environment: part A also dumps mvImagePyramid after operator(), the levels the SAD variant reads.)
 // Inputs come from tests/test_gpu_adapter_run.py (which builds them from the oracle's keypoints), every result is written to
 // <out_dir> as raw arrays and compared THERE with the oracle, bit for bit.  This program only checks what needs no oracle
 // (sizes, untouched outputs, context counts) and exits non-zero when one of those fails.
@@ -260,6 +263,17 @@ int main(int argc, char** argv)
         std::vector<int32_t> sz;
         for (int l = 0; l < 8; l++) { sz.push_back(L->mvImagePyramid[l].cols); sz.push_back(L->mvImagePyramid[l].rows); }
         dump("A_level_sizes.bin", sz.data(), sz.size() * 4);
+    }
+    if (getenv("GFO_FULL_PYRAMID") && getenv("GFO_FULL_PYRAMID")[0] == '1') {
+        // the levels of the LAST frame's left image as operator() left them in mvImagePyramid (Frame.cc:994,1016 read their pixels)
+        for (int l = 0; l < 8; l++) {
+            const cv::Mat& m = L->mvImagePyramid[l];
+            CHECK(!m.empty() && m.step == (size_t)m.cols + 38, "GFO_FULL_PYRAMID: level %d is not a framed view", l);
+            if (m.empty() || m.step != (size_t)m.cols + 38) continue;
+            char nm[64];
+            snprintf(nm, sizeof nm, "A_full_level%d_%dx%d.bin", l, m.cols + 38, m.rows + 38);
+            dump(nm, m.data - 19 * m.step - 19, (size_t)(m.rows + 38) * m.step);
+        }
     }
     report("contexts_created_by_two_extractors_and_their_engine", (long long)(gfo_contexts_created() - created_before));
     report("contexts_created_in_steady_state", (long long)(gfo_contexts_created() - created_mid));
@@ -632,6 +646,54 @@ int main(int argc, char** argv)
         dump(std::string(pre) + "_fv_start.bin", fs.data(), fs.size() * 4);
         dump(std::string(pre) + "_fv_items.bin", fi.data(), fi.size() * 4);
         delete FP;
+    }
+
+    // ------------------------------------------------------------------------------------------------------------------
+    // K. three stereo cameras at once through the adapters (context table pins, combiner batches, one rig per camera)
+    {
+        const int KC = 3, KF_ = 12;
+        std::vector<ORBextractor*> ex;
+        for (int k = 0; k < 2 * KC; k++) ex.push_back(new ORBextractor(2000, 1.2f, 8, 20, 7));
+        std::vector<int> bad(KC, 0), answered(KC, 0);
+        std::vector<std::thread> cams;
+        for (int k = 0; k < KC; k++)
+            cams.emplace_back([&, k] {
+                std::vector<cv::KeyPoint> ref_kl, ref_kr;
+                std::vector<float> ref_ur;
+                for (int f = 0; f < KF_; f++) {
+                    const cv::Mat fl = roll(imL, 3 * (f % 2), 0), fr = roll(imR, 3 * (f % 2), 0);     // frames 0, 1, 0, 1, ...
+                    std::vector<cv::KeyPoint> kl, kr;
+                    cv::Mat dl, dr;
+                    std::thread tr([&] { (*ex[2 * k + 1])(fr, cv::Mat(), kr, dr); });
+                    (*ex[2 * k])(fl, cv::Mat(), kl, dl);
+                    tr.join();
+                    Frame* F = new Frame();
+                    fill_frame(*F, ex[2 * k], ex[2 * k + 1], kl, dl, kr, dr);
+                    const int ns = F->ComputeStereoMatches_Undistorted(false);
+                    // every camera sees the stream of part A: frame f % 2 there
+                    const Frame& want = *kept[f % 2];
+                    const bool same = kl.size() == want.mvKeys.size() && kr.size() == want.mvKeysRight.size() &&
+                                      memcmp(kl.data(), want.mvKeys.data(), kl.size() * sizeof(cv::KeyPoint)) == 0 &&
+                                      memcmp(kr.data(), want.mvKeysRight.data(), kr.size() * sizeof(cv::KeyPoint)) == 0 &&
+                                      memcmp(dl.data, want.mDescriptors.data, (size_t)dl.rows * 32) == 0 &&
+                                      memcmp(dr.data, want.mDescriptorsRight.data, (size_t)dr.rows * 32) == 0 &&
+                                      F->mvuRight == want.mvuRight && F->mvDepth == want.mvDepth && F->mvDistIdx == want.mvDistIdx;
+                    if (!same) bad[k]++;
+                    (void)ns;
+                    delete F;
+                }
+                gfo_ctx* c = gfo_context_pin(ex[2 * k]);
+                int64_t cnt[8] = {0};
+                if (c) gfo_combiner_counters(c, cnt, 8);
+                gfo_context_unpin(ex[2 * k], c);
+                answered[k] = (int)cnt[6];
+            });
+        for (size_t i = 0; i < cams.size(); i++) cams[i].join();
+        for (int k = 0; k < KC; k++) {
+            CHECK(bad[k] == 0, "K: camera %d got %d frames that differ from the single-camera results", k, bad[k]);
+            report((std::string("K_camera") + char('0' + k) + "_rig_answers").c_str(), answered[k]);
+        }
+        for (size_t i = 0; i < ex.size(); i++) delete ex[i];
     }
 
     for (size_t i = 0; i < kept.size(); i++) delete kept[i];

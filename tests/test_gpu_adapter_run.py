@@ -279,6 +279,11 @@ def run(tmp_path_factory, oracle, euroc_l, euroc_r):
     ref["rc"], ref["stderr"], ref["out"] = p.returncode, p.stderr, outd
     ref["report"] = dict(l.split() for l in open(outd / "report.txt").read().splitlines() if l.strip()) if (outd / "report.txt").exists() else {}
     ref["oracle"] = oracle
+    # a second, short run with GFO_FULL_PYRAMID=1: operator() then leaves the levels' PIXELS in mvImagePyramid (what the SAD stereo
+    # variant reads, Frame.cc:994,1016); no frame combiner in that mode (the levels must be in the extractor's own context)
+    outd2 = tmp_path_factory.mktemp("adapter_out_full")
+    p2 = subprocess.run([EXE, GOLDEN, str(ind), str(outd2), "2"], capture_output=True, text=True, timeout=600, env=dict(env, GFO_FULL_PYRAMID="1"))
+    ref["full"] = {"rc": p2.returncode, "stderr": p2.stderr, "out": outd2}
     keep = os.path.join(ROOT, "gpurun_out")          # on the GPU box: the program's own report comes back with the call
     if os.path.isdir(keep) and (outd / "report.txt").exists():
         with open(os.path.join(keep, "adapter_run_report.txt"), "w") as fh:
@@ -453,3 +458,29 @@ def test_compute_bow_member(run):
         np.testing.assert_array_equal(_rd(run, f"J{v}_fv_nodes.bin", np.uint32), fn, err_msg=str(v))
         np.testing.assert_array_equal(_rd(run, f"J{v}_fv_start.bin", np.int32), fs, err_msg=str(v))
         np.testing.assert_array_equal(_rd(run, f"J{v}_fv_items.bin", np.uint32), fi, err_msg=str(v))
+
+
+def test_three_cameras_through_the_adapters(run):
+    """part K of the program: six ORBextractor objects, three camera threads (each creating a thread per right image), one rig per
+    camera -- every frame of every camera equals the single-camera results of part A; the rigs answered associations"""
+    assert run["rc"] == 0, run["stderr"][-3000:]
+    rep = run["report"]
+    answers = [int(rep[f"K_camera{k}_rig_answers"]) for k in range(3)]
+    assert all(a >= 6 for a in answers), answers           # 12 frames per camera; a rig needs a frame or two to form under load
+
+
+def test_full_pyramid_mode_leaves_the_levels_in_mvImagePyramid(run, euroc_l):
+    """GFO_FULL_PYRAMID=1: after operator() every mvImagePyramid[l] is a view into its 19-px framed buffer holding the level's pixels
+    (ORBextractor.cc:1182-1197) -- compared with the oracle's pyramid of the same image; keypoints unchanged by the mode"""
+    full = run["full"]
+    assert full["rc"] == 0, full["stderr"][-3000:]
+    O = run["oracle"]
+    oe = O.OracleExtractor(2000, 1.2, 8, 20, 7)
+    last = _frames(euroc_l, 1)                      # two frames in this run: the last one is frame 1 (padded view input)
+    oe.compute_pyramid(last)
+    for l in range(8):
+        w, h = oe.level_size(l)
+        got = np.fromfile(full["out"] / f"A_full_level{l}_{w + 38}x{h + 38}.bin", np.uint8).reshape(h + 38, w + 38)
+        assert got.tobytes() == oe.level(l, padded=True).tobytes(), l
+    kd = O.KEYPOINT_DTYPE
+    assert np.fromfile(full["out"] / "A_f01_kl.bin", kd).tobytes() == run["frames"][1][0].tobytes()
