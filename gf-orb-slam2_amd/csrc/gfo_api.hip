@@ -628,6 +628,8 @@ extern "C" void gfo_ctx_destroy(gfo_ctx* c)
     if (c->d_voc) (void)hipFree(c->d_voc);
     if (c->h_in) (void)hipHostFree(c->h_in);
     if (c->h_out) (void)hipHostFree(c->h_out);
+    if (c->h_min) (void)hipHostFree(c->h_min);
+    if (c->h_mout) (void)hipHostFree(c->h_mout);
     if (c->pj.base) (void)hipFree(c->pj.base);
     if (c->d_map_desc) (void)hipFree(c->d_map_desc);
     if (c->side_stream) {
@@ -1130,7 +1132,7 @@ extern "C" int gfo_deliver_wait(gfo_ctx* c)
 }
 
 // grow-only pinned host buffers of the latency path
-static int pinned(gfo_ctx* c, uint8_t** buf, size_t* cap, size_t bytes)
+int gfo_pinned(gfo_ctx* c, uint8_t** buf, size_t* cap, size_t bytes)
 {
     if (bytes <= *cap) return GFO_OK;
     HIP_TRY(c, hipStreamSynchronize(c->stream));
@@ -1210,7 +1212,7 @@ int gfo_small_prepare(gfo_ctx* c, int nimg_cap, GfoSmallLayout* L)
     L->nimg_cap = nimg_cap;
     L->pitch = (w & 15) == 0 ? w : c->g.lv[0].pitch;    // 752, 640, 1920, ...: tight rows, the caller's own layout
     L->img_bytes = (size_t)L->pitch * h;
-    int rc = pinned(c, &c->h_in, &c->h_in_bytes, L->img_bytes * nimg_cap);
+    int rc = gfo_pinned(c, &c->h_in, &c->h_in_bytes, L->img_bytes * nimg_cap);
     if (rc) return rc;
     // result layout in the pinned buffer (fixed for a planned geometry and capacity)
     size_t off = 0;
@@ -1220,7 +1222,7 @@ int gfo_small_prepare(gfo_ctx* c, int nimg_cap, GfoSmallLayout* L)
     L->o_ds = take(32 * (size_t)ks * nimg_cap);
     L->o_ur = take(4 * (size_t)ks * npair); L->o_dp = take(4 * (size_t)ks * npair); L->o_bd = take(4 * (size_t)ks * npair);
     L->o_bi = take(4 * (size_t)ks * npair); L->o_nm = take(16 * ((npair + 3) / 4));
-    return pinned(c, &c->h_out, &c->h_out_bytes, off);
+    return gfo_pinned(c, &c->h_out, &c->h_out_bytes, off);
 }
 
 // Images `first .. first + count` of the small batch on their way to the device, on stream `st`, in as few DMA copies as
@@ -1647,9 +1649,9 @@ extern "C" int gfo_stereo_match(gfo_ctx* c, const gfo_keypoint* kl, const uint8_
                  o_lrs = take(4 * (size_t)(p->n_rows + 1));
     int rc = scratch(c, off);
     if (rc) return rc;
-    rc = pinned(c, &c->h_in, &c->h_in_bytes, in_bytes);
+    rc = gfo_pinned(c, &c->h_in, &c->h_in_bytes, in_bytes);
     if (rc) return rc;
-    rc = pinned(c, &c->h_out, &c->h_out_bytes, out_bytes);
+    rc = gfo_pinned(c, &c->h_out, &c->h_out_bytes, out_bytes);
     if (rc) return rc;
     uint8_t* S = (uint8_t*)c->d_scratch;
     uint8_t* HI = c->h_in;

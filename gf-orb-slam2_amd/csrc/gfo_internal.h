@@ -8,6 +8,7 @@
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
 #include <stdint.h>
+#include <string.h>
 #include <memory>
 #include <string>
 #include <vector>
@@ -264,6 +265,10 @@ struct gfo_ctx {
     // hipGraph of the fixed launch sequence
     uint8_t* h_in = nullptr;  size_t h_in_bytes = 0;     // hipHostMalloc
     uint8_t* h_out = nullptr; size_t h_out_bytes = 0;
+    // host-array matcher calls (SearchByProjection / SearchByBoW / ComputeBoW on caller arrays): every input of a call is packed
+    // here and crosses in ONE H2D copy, every output comes back in ONE D2H (a pageable hipMemcpyAsync costs ~16-22 us each)
+    uint8_t* h_min = nullptr;  size_t h_min_bytes = 0;
+    uint8_t* h_mout = nullptr; size_t h_mout_bytes = 0;
     bool graph_ok = false;   // GFO_GRAPH=1 opts in (see run_extract)
     hipGraphExec_t graph_exec = nullptr;
     struct GraphKey { const void* base; const void* pack_dst; long long pitch, img_stride; int nimg, stereo; gfo_stereo_params sp; int plan_gen; } graph_key{};
@@ -316,6 +321,30 @@ void gfo_launch_quadtree(gfo_ctx* c, int nimg);
 bool gfo_launch_quadtree_blur(gfo_ctx* c, const GfoInput& in, int nimg);   // per-frame batches: quadtree + blur as one launch (false: not applicable, nothing launched)
 void gfo_launch_orient_desc(gfo_ctx* c, const GfoInput& in, int nimg);
 void gfo_launch_stereo(gfo_ctx* c, const GfoStereoLaunch& s);
+int gfo_pinned(gfo_ctx* c, uint8_t** buf, size_t* cap, size_t bytes);   // grow-only hipHostMalloc buffer (synchronises the stream when it grows)
+// One host-array call's transfers.  in(): reserve the pinned mirror of the device scratch [0, bytes); put(): memcpy one input to its
+// offset; up(): the ONE H2D.  out()/down(): ONE D2H of a contiguous device range into pinned memory, read after the stream sync.
+struct GfoXfer {
+    gfo_ctx* c;
+    uint8_t* H = nullptr;    // pinned mirror of the inputs
+    uint8_t* HO = nullptr;   // pinned copy of the outputs
+    explicit GfoXfer(gfo_ctx* ctx) : c(ctx) {}
+    int in(size_t bytes)
+    {
+        int rc = bytes <= c->h_min_bytes ? 0 : gfo_pinned(c, &c->h_min, &c->h_min_bytes, bytes + bytes / 2);   // headroom: frames vary
+        H = c->h_min;
+        return rc;
+    }
+    void put(size_t off, const void* src, size_t bytes) const { if (bytes) memcpy(H + off, src, bytes); }
+    hipError_t up(void* d_dst, size_t bytes, hipStream_t st) const { return hipMemcpyAsync(d_dst, H, bytes, hipMemcpyHostToDevice, st); }
+    int out(size_t bytes)
+    {
+        int rc = bytes <= c->h_mout_bytes ? 0 : gfo_pinned(c, &c->h_mout, &c->h_mout_bytes, bytes + bytes / 2);
+        HO = c->h_mout;
+        return rc;
+    }
+    hipError_t down(const void* d_src, size_t bytes, hipStream_t st) const { return hipMemcpyAsync(HO, d_src, bytes, hipMemcpyDeviceToHost, st); }
+};
 void gfo_launch_pack_cut(gfo_ctx* c, const GfoPack& p, hipStream_t st);   // k_pack_results with the stereo cut in it (GfoPack::cut_pairs)
 int gfo_stereo_window(const float* scale, int nlevels);
 void gfo_launch_stereo_sad(gfo_ctx* c, const GfoStereoLaunch& s, const GfoInput& in, const float* d_inv_scale);

@@ -11,6 +11,7 @@
 // three-maxima scan on one lane, then the sweep that clears the other bins.
 // The node intersection (the lower_bound walk, :292-380) is a host-side merge of two sorted id lists.
 #include "gfo_internal.h"
+#include "k_wave.inc"
 
 #define TH_LOW 50        // ORBmatcher.cc:58
 #define HISTO_LENGTH 30  // ORBmatcher.cc:59
@@ -35,14 +36,10 @@ struct BowArgs {
     int* counters;             // [0] nmatches
 };
 
-__global__ __launch_bounds__(256) void k_bow_match(BowArgs a)
+// A node with more frame keypoints than the lanes' registers hold (> 64 * BOW_R): every keyframe keypoint sweeps the node's frame
+// keypoints from memory, `out` carries the taken state (this wave is its only writer: same-wave program order + the fence below).
+__device__ __noinline__ void bow_node_sweep(const BowArgs& a, int kb, int ke, int fb, int fe, int lane)
 {
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;  // uniform: keep it scalar
-    const int pi = blockIdx.x * 4 + wave;
-    if (pi >= a.npairs) return;
-    const int2 pr = a.pairs[pi];
-    const int kb = a.kf_start[pr.x], ke = a.kf_start[pr.x + 1];
-    const int fb = a.f_start[pr.y], fe = a.f_start[pr.y + 1];
     const float factor = 1.0f / HISTO_LENGTH;  // :284 (applied to degrees, as the reference does)
     int accepted = 0;
     for (int ik = kb; ik < ke; ik++) {
@@ -89,6 +86,112 @@ __global__ __launch_bounds__(256) void k_bow_match(BowArgs a)
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        }
+    }
+    if (lane == 0 && accepted) atomicAdd(&a.counters[0], accepted);
+}
+
+
+#define BOW_R 4   // frame keypoints of the node a lane keeps in registers (descriptor, index, angle): nodes up to 256 frame keypoints
+
+// One wavefront per common node.  The node's FRAME side is loaded once into registers (lane l holds positions l, l+64, ...), with a
+// lane-local "still free" bit per slot -- the node's frame keypoints belong to no other node, so nobody else writes them; the
+// KEYFRAME side is loaded 64 keypoints at a time, one per lane, and broadcast keypoint by keypoint with v_readlane.  The walk over
+// the keyframe keypoints stays sequential (it IS, :320,343) but an iteration is ~60 register instructions and two DPP reductions
+// instead of three dependent trips to memory and a fence: 129 us -> see profiles/NOTEBOOK.md for the EuRoC frame over 92 nodes.
+__global__ __launch_bounds__(256) void k_bow_match(BowArgs a)
+{
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;  // uniform: keep it scalar
+    const int pi = blockIdx.x * 4 + wave;
+    if (pi >= a.npairs) return;
+    const int2 pr = a.pairs[pi];
+    const int kb = a.kf_start[pr.x], ke = a.kf_start[pr.x + 1];
+    const int fb = a.f_start[pr.y], fe = a.f_start[pr.y + 1];
+    if (fe - fb > 64 * BOW_R) {
+        bow_node_sweep(a, kb, ke, fb, fe, lane);
+        return;
+    }
+    const float factor = 1.0f / HISTO_LENGTH;  // :284 (applied to degrees, as the reference does)
+    uint4 f0[BOW_R], f1[BOW_R];
+    unsigned fidx[BOW_R];
+    float fang[BOW_R];
+    unsigned free_m = 0;
+#pragma unroll
+    for (int r = 0; r < BOW_R; r++) {
+        const int j = fb + r * 64 + lane;
+        fidx[r] = 0; fang[r] = 0.f;
+        f0[r] = make_uint4(0, 0, 0, 0); f1[r] = f0[r];
+        if (j < fe) {
+            fidx[r] = a.f_items[j];
+            const uint4* df = reinterpret_cast<const uint4*>(a.f_desc + (long long)fidx[r] * 32);
+            f0[r] = df[0]; f1[r] = df[1];
+            if (a.check_ori) fang[r] = a.f_angle[fidx[r]];
+            if (a.out[fidx[r]] < 0) free_m |= 1u << r;   // :320 (cleared by the host; a slot this wave fills clears its bit)
+        }
+    }
+    int accepted = 0;
+    for (int c0 = kb; c0 < ke; c0 += 64) {
+        const int ik = c0 + lane;
+        unsigned kidx = 0;
+        bool kval = false;
+        uint4 k0 = make_uint4(0, 0, 0, 0), k1 = k0;
+        float kang = 0.f;
+        if (ik < ke) {
+            kidx = a.kf_items[ik];
+            kval = a.kf_valid[kidx] != 0;   // :306-310
+            const uint4* dk = reinterpret_cast<const uint4*>(a.kf_desc + (long long)kidx * 32);
+            k0 = dk[0]; k1 = dk[1];
+            if (a.check_ori) kang = a.kf_angle[kidx];
+        }
+        unsigned long long todo = __builtin_amdgcn_ballot_w64(kval);
+        while (todo) {
+            const int i = __builtin_ctzll(todo);   // next valid keyframe keypoint, in the node's order
+            todo &= todo - 1;
+            const unsigned q0 = __builtin_amdgcn_readlane((int)k0.x, i), q1 = __builtin_amdgcn_readlane((int)k0.y, i),
+                           q2 = __builtin_amdgcn_readlane((int)k0.z, i), q3 = __builtin_amdgcn_readlane((int)k0.w, i),
+                           q4 = __builtin_amdgcn_readlane((int)k1.x, i), q5 = __builtin_amdgcn_readlane((int)k1.y, i),
+                           q6 = __builtin_amdgcn_readlane((int)k1.z, i), q7 = __builtin_amdgcn_readlane((int)k1.w, i);
+            unsigned b1 = 0xFFFFFFFFu, b2 = 0xFFFFFFFFu;  // two smallest (dist << 20 | position)
+#pragma unroll
+            for (int r = 0; r < BOW_R; r++) {
+                if (free_m & (1u << r)) {
+                    const unsigned dist = __popc(q0 ^ f0[r].x) + __popc(q1 ^ f0[r].y) + __popc(q2 ^ f0[r].z) + __popc(q3 ^ f0[r].w) +
+                                          __popc(q4 ^ f1[r].x) + __popc(q5 ^ f1[r].y) + __popc(q6 ^ f1[r].z) + __popc(q7 ^ f1[r].w);
+                    const unsigned key = (dist << 20) | (unsigned)(r * 64 + lane);
+                    if (key < b1) { b2 = b1; b1 = key; }
+                    else if (key < b2) b2 = key;
+                }
+            }
+            // the two smallest keys of the wave: keys are distinct (the position is part of them), so the runner-up is the smallest of
+            // "every lane's best that is not the winner, and the winner's lane's second"
+            const unsigned w1 = st_wave_min(b1);
+            if (w1 == 0xFFFFFFFFu) continue;
+            const unsigned w2 = st_wave_min(b1 == w1 ? b2 : b1);
+            const int bestDist1 = (int)(w1 >> 20);
+            const int bestDist2 = w2 == 0xFFFFFFFFu ? 256 : (int)(w2 >> 20);
+            if (bestDist1 <= TH_LOW && (float)bestDist1 < a.nn_ratio * (float)bestDist2) {  // :339-341
+                const int pos = (int)(w1 & 0xFFFFF);
+                const unsigned realIdxKF = (unsigned)__builtin_amdgcn_readlane((int)kidx, i);
+                const float ka = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(kang), i));
+                if (lane == (pos & 63)) {
+                    const int r = pos >> 6;
+                    unsigned bestIdxF = fidx[0];
+                    float fa = fang[0];
+#pragma unroll
+                    for (int t = 1; t < BOW_R; t++)
+                        if (r == t) { bestIdxF = fidx[t]; fa = fang[t]; }
+                    free_m &= ~(1u << r);
+                    a.out[bestIdxF] = (int)realIdxKF;
+                    if (a.check_ori) {
+                        float rot = ka - fa;
+                        if (rot < 0.0f) rot += 360.0f;
+                        int bin = (int)roundf(rot * factor);
+                        if (bin == HISTO_LENGTH) bin = 0;
+                        a.rot_bin[bestIdxF] = bin;
+                    }
+                }
+                accepted++;
+            }
         }
     }
     if (lane == 0 && accepted) atomicAdd(&a.counters[0], accepted);
@@ -182,7 +285,7 @@ extern "C" int gfo_search_by_bow(gfo_ctx* c, const uint8_t* kf_desc, const float
                  o_ks = take(4 * (size_t)(kf_fv->n_nodes + 1)), o_ki = take(4 * (size_t)(nk_items > 0 ? nk_items : 1)),
                  o_fd = take(32 * (size_t)n_f), o_fa = take(4 * (size_t)n_f), o_fs = take(4 * (size_t)(f_fv->n_nodes + 1)),
                  o_fi = take(4 * (size_t)(nf_items > 0 ? nf_items : 1)), o_pr = take(sizeof(int2) * pairs.size()),
-                 o_out = take(4 * (size_t)n_f), o_rb = take(4 * (size_t)n_f), o_cnt = take(16);
+                 o_rb = take(4 * (size_t)n_f), o_out = take(4 * (size_t)n_f), o_cnt = take(16);
     if (off > c->scratch_bytes) {
         (void)hipStreamSynchronize(c->stream);
         if (c->d_scratch) (void)hipFree(c->d_scratch);
@@ -193,19 +296,22 @@ extern "C" int gfo_search_by_bow(gfo_ctx* c, const uint8_t* kf_desc, const float
     }
     uint8_t* S = (uint8_t*)c->d_scratch;
     hipStream_t st = c->stream;
-    BTRY(c, hipMemcpyAsync(S + o_kd, kf_desc, 32 * (size_t)n_kf, hipMemcpyHostToDevice, st));
-    if (kf_angle) BTRY(c, hipMemcpyAsync(S + o_ka, kf_angle, 4 * (size_t)n_kf, hipMemcpyHostToDevice, st));
-    BTRY(c, hipMemcpyAsync(S + o_kv, kf_mp_valid, n_kf, hipMemcpyHostToDevice, st));
-    BTRY(c, hipMemcpyAsync(S + o_ks, kf_fv->node_start, 4 * (size_t)(kf_fv->n_nodes + 1), hipMemcpyHostToDevice, st));
-    if (nk_items) BTRY(c, hipMemcpyAsync(S + o_ki, kf_fv->items, 4 * (size_t)nk_items, hipMemcpyHostToDevice, st));
-    BTRY(c, hipMemcpyAsync(S + o_fd, f_desc, 32 * (size_t)n_f, hipMemcpyHostToDevice, st));
-    if (f_angle) BTRY(c, hipMemcpyAsync(S + o_fa, f_angle, 4 * (size_t)n_f, hipMemcpyHostToDevice, st));
-    BTRY(c, hipMemcpyAsync(S + o_fs, f_fv->node_start, 4 * (size_t)(f_fv->n_nodes + 1), hipMemcpyHostToDevice, st));
-    if (nf_items) BTRY(c, hipMemcpyAsync(S + o_fi, f_fv->items, 4 * (size_t)nf_items, hipMemcpyHostToDevice, st));
-    BTRY(c, hipMemcpyAsync(S + o_pr, pairs.data(), sizeof(int2) * pairs.size(), hipMemcpyHostToDevice, st));
-    BTRY(c, hipMemsetAsync(S + o_out, 0xFF, 4 * (size_t)n_f, st));
-    BTRY(c, hipMemsetAsync(S + o_rb, 0xFF, 4 * (size_t)n_f, st));
-    BTRY(c, hipMemsetAsync(S + o_cnt, 0, 16, st));
+    // ten inputs and the three cleared outputs in ONE copy through the pinned mirror of the scratch layout (GfoXfer)
+    GfoXfer x(c);
+    if (int rc = x.in(off)) return rc;
+    x.put(o_kd, kf_desc, 32 * (size_t)n_kf);
+    if (kf_angle) x.put(o_ka, kf_angle, 4 * (size_t)n_kf);
+    x.put(o_kv, kf_mp_valid, n_kf);
+    x.put(o_ks, kf_fv->node_start, 4 * (size_t)(kf_fv->n_nodes + 1));
+    if (nk_items) x.put(o_ki, kf_fv->items, 4 * (size_t)nk_items);
+    x.put(o_fd, f_desc, 32 * (size_t)n_f);
+    if (f_angle) x.put(o_fa, f_angle, 4 * (size_t)n_f);
+    x.put(o_fs, f_fv->node_start, 4 * (size_t)(f_fv->n_nodes + 1));
+    if (nf_items) x.put(o_fi, f_fv->items, 4 * (size_t)nf_items);
+    x.put(o_pr, pairs.data(), sizeof(int2) * pairs.size());
+    memset(x.H + o_rb, 0xFF, o_cnt - o_rb);   // rot_bin and out = -1
+    memset(x.H + o_cnt, 0, 16);
+    BTRY(c, x.up(S, o_cnt + 16, st));
     BowArgs a{};
     a.kf_desc = S + o_kd; a.kf_angle = (const float*)(S + o_ka); a.kf_valid = S + o_kv;
     a.kf_start = (const int*)(S + o_ks); a.kf_items = (const unsigned*)(S + o_ki);
@@ -220,11 +326,11 @@ extern "C" int gfo_search_by_bow(gfo_ctx* c, const uint8_t* kf_desc, const float
     gfo_prof_end(c);
     if (int lrc = gfo_take_launch_err(c)) return lrc;
     BTRY(c, hipGetLastError());
-    int cnt[4];
-    BTRY(c, hipMemcpyAsync(out_kf_idx, a.out, 4 * (size_t)n_f, hipMemcpyDeviceToHost, st));
-    BTRY(c, hipMemcpyAsync(cnt, a.counters, 16, hipMemcpyDeviceToHost, st));
+    if (int rc = x.out(o_cnt + 16 - o_out)) return rc;
+    BTRY(c, x.down(S + o_out, o_cnt + 16 - o_out, st));   // out and the counters are neighbours in the scratch
     BTRY(c, hipStreamSynchronize(st));
-    *nmatches = cnt[0];
+    memcpy(out_kf_idx, x.HO, 4 * (size_t)n_f);
+    *nmatches = reinterpret_cast<const int*>(x.HO + (o_cnt - o_out))[0];
     return GFO_OK;
 }
 
@@ -297,8 +403,69 @@ struct BowFold {
     unsigned long long* gkey; int* gflag;   // k_bow_fold<true>: the sort keys and marks in device memory (more than 8192 descriptors)
 };
 
+// compare-exchange of the bitonic network for the element at index i: keeps the smaller key when the element is the lower one of an
+// ascending pair (or the upper one of a descending pair)
+__device__ __forceinline__ unsigned long long bow_cx(unsigned long long mine, unsigned long long other, int i, int j, int k2)
+{
+    const bool lower = (i & j) == 0, up = (i & k2) == 0;
+    const bool take_min = lower == up;
+    const bool other_smaller = other < mine;
+    return (take_min == other_smaller) ? other : mine;
+}
+
+// Bitonic sort of p2 keys (ascending) by 1024 threads.  Partners closer than a wavefront (j < 64) are exchanged through the lanes
+// with the keys in registers (slot t of a thread is element t * 1024 + tid, so i ^ j is lane ^ j of the same slot); only the steps
+// with j >= 64 go through the array, one barrier each.  REG = false (keys in device memory, any p2): every step through the array.
+// p2 = 2048: 21 barriers instead of 66.
+template <bool REG>
 __device__ void bow_bitonic(unsigned long long* key, int p2, int tid)
 {
+    if (REG && p2 >= 64) {
+        const int slots = p2 >> 10 ? p2 >> 10 : 1;   // p2 <= 8192: at most 8; p2 < 1024: threads tid >= p2 idle
+        unsigned long long r[8];
+        const bool mine = tid < p2;
+        auto load = [&]() {
+#pragma unroll
+            for (int t = 0; t < 8; t++) if (t < slots && mine) r[t] = key[t * 1024 + tid];
+        };
+        auto store = [&]() {
+#pragma unroll
+            for (int t = 0; t < 8; t++) if (t < slots && mine) key[t * 1024 + tid] = r[t];
+        };
+        auto lanes = [&](int k2, int j_from) {       // the steps j_from, j_from / 2, ..., 1 of stage k2 between lanes
+            for (int j = j_from; j > 0; j >>= 1) {
+#pragma unroll
+                for (int t = 0; t < 8; t++) {
+                    if (t < slots) {
+                        const unsigned lo = (unsigned)__shfl_xor((int)(unsigned)r[t], j), hi = (unsigned)__shfl_xor((int)(unsigned)(r[t] >> 32), j);
+                        r[t] = bow_cx(r[t], ((unsigned long long)hi << 32) | lo, t * 1024 + tid, j, k2);
+                    }
+                }
+            }
+        };
+        load();
+        for (int k2 = 2; k2 <= 64; k2 <<= 1) lanes(k2, k2 >> 1);
+        for (int k2 = 128; k2 <= p2; k2 <<= 1) {
+            store();
+            __syncthreads();
+            for (int j = k2 >> 1; j >= 64; j >>= 1) {
+                for (int i = tid; i < p2; i += 1024) {
+                    const int ixj = i ^ j;
+                    if (ixj > i) {
+                        const unsigned long long a = key[i], b = key[ixj];
+                        const bool up = (i & k2) == 0;
+                        if (up ? a > b : a < b) { key[i] = b; key[ixj] = a; }
+                    }
+                }
+                __syncthreads();
+            }
+            load();
+            lanes(k2, 32);
+        }
+        store();
+        __syncthreads();
+        return;
+    }
     for (int k2 = 2; k2 <= p2; k2 <<= 1)
         for (int j = k2 >> 1; j > 0; j >>= 1) {
             for (int i = tid; i < p2; i += 1024) {
@@ -313,23 +480,16 @@ __device__ void bow_bitonic(unsigned long long* key, int p2, int tid)
         }
 }
 
-// exclusive scan of flag[0..n) (ints in LDS) in place; returns the total.  1024 threads.
+// exclusive scan of flag[0..n) (ints in LDS) in place; returns the total.  1024 threads: a run of the array per thread, the runs'
+// sums scanned in the DPP network (k_wave.inc, two barriers).
 __device__ int bow_scan(int* v, int n, int* part, int tid)
 {
     const int chunk = (n + 1023) / 1024;
     const int b = min(tid * chunk, n), e = min(b + chunk, n);
     int s = 0;
     for (int i = b; i < e; i++) s += v[i];
-    part[tid] = s;
-    __syncthreads();
-    for (int off = 1; off < 1024; off <<= 1) {
-        const int t = tid >= off ? part[tid - off] : 0;
-        __syncthreads();
-        part[tid] += t;
-        __syncthreads();
-    }
-    int run = part[tid] - s;
-    const int total = part[1023];
+    int total;
+    int run = st_block_incl_scan(s, part, &total) - s;
     for (int i = b; i < e; i++) { const int x = v[i]; v[i] = run; run += x; }
     __syncthreads();
     return total;
@@ -338,21 +498,25 @@ __device__ int bow_scan(int* v, int n, int* part, int tid)
 // GMEM = false: keys and marks in LDS (p2 <= 8192: 96 KB), the form every ordinary frame takes.  GMEM = true: the same code on
 // device memory -- one workgroup bitonic-sorting through L2 is slow (milliseconds at 50 000 descriptors) but it lifts the limit:
 // no frame is refused or folded elsewhere (the reference itself has no limit, TemplatedVocabulary.h:1140-1212).
+// TWO workgroups: block 0 folds the FeatureVector, block 1 the BowVector -- the two maps share nothing but the inputs, and a fold is
+// a chain of ~90 workgroup barriers that one CU walks alone (round 5: 162 us for both in one workgroup on the EuRoC frame).
 template <bool GMEM>
 __global__ __launch_bounds__(1024) void k_bow_fold(BowFold a, int p2)
 {
     extern __shared__ unsigned long long lds_dyn[];          // p2 keys + p2 ints (GMEM = false)
-    unsigned long long* lds_key = GMEM ? a.gkey : lds_dyn;
-    int* flag = GMEM ? a.gflag : reinterpret_cast<int*>(lds_dyn + p2);
+    const bool bow_side = blockIdx.x == 1;
+    unsigned long long* lds_key = GMEM ? a.gkey + (bow_side ? p2 : 0) : lds_dyn;
+    int* flag = GMEM ? a.gflag + (bow_side ? p2 : 0) : reinterpret_cast<int*>(lds_dyn + p2);
     __shared__ int part[1024];
     __shared__ int s_nvalid;
     const int tid = threadIdx.x, n = a.n;
-    // ---- FeatureVector: sort the kept features by (node, feature) ----
+    // ---- sort the kept features by (node, feature) / (word, feature): every segment then lists its members in feature order ----
+    const int* id = bow_side ? a.word : a.node;
     for (int i = tid; i < p2; i += 1024)
-        lds_key[i] = i < n && a.wt[i] > 0 ? ((unsigned long long)(unsigned)a.node[i] << 32) | (unsigned)i : ~0ull;   // w > 0: not stopped (:1169)
+        lds_key[i] = i < n && a.wt[i] > 0 ? ((unsigned long long)(unsigned)id[i] << 32) | (unsigned)i : ~0ull;   // w > 0: not stopped (:1169)
     if (tid == 0) s_nvalid = 0;
     __syncthreads();
-    bow_bitonic(lds_key, p2, tid);
+    bow_bitonic<!GMEM>(lds_key, p2, tid);
     int cnt = 0;
     for (int i = tid; i < n; i += 1024) {
         const bool ok = lds_key[i] != ~0ull;
@@ -367,63 +531,102 @@ __global__ __launch_bounds__(1024) void k_bow_fold(BowFold a, int p2)
         if (flag[i]) lds_key[i] |= 0x80000000ull;
     __syncthreads();
     const int nseg = bow_scan(flag, n, part, tid);
-    for (int i = tid; i < nvalid; i += 1024) {
-        const unsigned long long k = lds_key[i];
-        a.fv_items[i] = (unsigned)(k & 0x7FFFFFFFu);
-        if (k & 0x80000000ull) {
-            a.fv_nodes[flag[i]] = (unsigned)(k >> 32);
-            a.fv_start[flag[i]] = i;
+    if (!bow_side) {
+        // ---- FeatureVector ----
+        for (int i = tid; i < nvalid; i += 1024) {
+            const unsigned long long k = lds_key[i];
+            a.fv_items[i] = (unsigned)(k & 0x7FFFFFFFu);
+            if (k & 0x80000000ull) {
+                a.fv_nodes[flag[i]] = (unsigned)(k >> 32);
+                a.fv_start[flag[i]] = i;
+            }
         }
+        if (tid == 0) { a.fv_start[nseg] = nvalid; a.counts[1] = nseg; }
+        return;
     }
-    if (tid == 0) { a.fv_start[nseg] = nvalid; a.counts[1] = nseg; }
-    __syncthreads();
-    // ---- BowVector: sort by (word, feature); one thread per word walks its features in order ----
-    for (int i = tid; i < p2; i += 1024)
-        lds_key[i] = i < n && a.wt[i] > 0 ? ((unsigned long long)(unsigned)a.word[i] << 32) | (unsigned)i : ~0ull;
-    __syncthreads();
-    bow_bitonic(lds_key, p2, tid);
-    for (int i = tid; i < n; i += 1024)
-        flag[i] = i < nvalid && (i == 0 || (lds_key[i] >> 32) != (lds_key[i - 1] >> 32)) ? 1 : 0;
-    __syncthreads();
-    for (int i = tid; i < n; i += 1024)
-        if (flag[i]) lds_key[i] |= 0x80000000ull;
-    __syncthreads();
-    const int nwords = bow_scan(flag, n, part, tid);
+    // ---- BowVector: one thread per word walks its features in order ----
+    const int nwords = nseg;
     const bool tf = a.weighting == 0 || a.weighting == 1;
-    for (int i = tid; i < nvalid; i += 1024) {
-        const unsigned long long k = lds_key[i];
-        if (!(k & 0x80000000ull)) continue;
+    auto word_value = [&](int i, unsigned long long k) {
         const unsigned w = (unsigned)(k >> 32);
         double v = a.wt[(int)(k & 0x7FFFFFFFu)];              // insert(id, v)
         if (tf)                                                // addWeight: += in feature order
             for (int j = i + 1; j < nvalid && (unsigned)(lds_key[j] >> 32) == w; j++) v += a.wt[(int)(lds_key[j] & 0x7FFFFFFFu)];
-        a.bow_words[flag[i]] = w;
-        a.bow_values[flag[i]] = v;
+        return v;
+    };
+    // the values of the words, in word order, where the normalisation below reads them: device memory when the keys are there,
+    // otherwise the key array itself (8 bytes a slot, nwords <= nvalid) once every thread has taken what it needs out of it
+    double* vals = GMEM ? a.bow_values : reinterpret_cast<double*>(lds_key);
+    if (GMEM) {
+        for (int i = tid; i < nvalid; i += 1024) {
+            const unsigned long long k = lds_key[i];
+            if (!(k & 0x80000000ull)) continue;
+            a.bow_words[flag[i]] = (unsigned)(k >> 32);
+            vals[flag[i]] = word_value(i, k);
+        }
+        __syncthreads();
+        __threadfence_block();   // the stores above are read back below by other threads of this workgroup
+        __syncthreads();
+    } else {
+        double v[8];             // p2 <= 8192: at most eight slots a thread
+        int slot[8];
+#pragma unroll
+        for (int t = 0; t < 8; t++) {
+            const int i = tid + t * 1024;
+            slot[t] = -1;
+            v[t] = 0.0;
+            if (i < nvalid) {
+                const unsigned long long k = lds_key[i];
+                if (k & 0x80000000ull) {
+                    slot[t] = flag[i];
+                    a.bow_words[slot[t]] = (unsigned)(k >> 32);
+                    v[t] = word_value(i, k);
+                }
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int t = 0; t < 8; t++)
+            if (slot[t] >= 0) vals[slot[t]] = v[t];
+        __syncthreads();
     }
-    __syncthreads();
-    // the stores above are read back below by other threads of this workgroup
-    __threadfence_block();
-    __syncthreads();
+    double scale = 0.0;   // 0: values leave as they are
+    bool divide = false;
     if (tf && nwords > 0 && a.norm == 0) {                     // "unnecessary when normalizing" (:1177-1183)
-        const double nd = (double)nwords;
-        for (int k = tid; k < nwords; k += 1024) a.bow_values[k] /= nd;
+        scale = (double)nwords;
+        divide = true;
     }
     if (a.norm != 0) {
         __shared__ double s_norm;
-        if (tid == 0) {                                        // BowVector::normalize: one running sum over the map order
+        if (tid == 0) {                                        // BowVector::normalize: ONE running sum over the map order
             double nrm = 0.0;
-            if (a.norm == 1) for (int k = 0; k < nwords; k++) nrm += fabs(a.bow_values[k]);
-            else {
-                for (int k = 0; k < nwords; k++) nrm += a.bow_values[k] * a.bow_values[k];
+            int k = 0;
+            if (a.norm == 1) {
+                for (; k + 8 <= nwords; k += 8) {              // eight loads in flight, the additions in order
+                    const double t0 = vals[k], t1 = vals[k + 1], t2 = vals[k + 2], t3 = vals[k + 3], t4 = vals[k + 4], t5 = vals[k + 5],
+                                 t6 = vals[k + 6], t7 = vals[k + 7];
+                    nrm += fabs(t0); nrm += fabs(t1); nrm += fabs(t2); nrm += fabs(t3);
+                    nrm += fabs(t4); nrm += fabs(t5); nrm += fabs(t6); nrm += fabs(t7);
+                }
+                for (; k < nwords; k++) nrm += fabs(vals[k]);
+            } else {
+                for (; k + 8 <= nwords; k += 8) {
+                    const double t0 = vals[k], t1 = vals[k + 1], t2 = vals[k + 2], t3 = vals[k + 3], t4 = vals[k + 4], t5 = vals[k + 5],
+                                 t6 = vals[k + 6], t7 = vals[k + 7];
+                    nrm += t0 * t0; nrm += t1 * t1; nrm += t2 * t2; nrm += t3 * t3;
+                    nrm += t4 * t4; nrm += t5 * t5; nrm += t6 * t6; nrm += t7 * t7;
+                }
+                for (; k < nwords; k++) nrm += vals[k] * vals[k];
                 nrm = sqrt(nrm);
             }
             s_norm = nrm;
         }
         __syncthreads();
-        const double nrm = s_norm;
-        if (nrm > 0.0)
-            for (int k = tid; k < nwords; k += 1024) a.bow_values[k] /= nrm;
+        scale = s_norm;
+        divide = scale > 0.0;
     }
+    if (!GMEM || divide)
+        for (int k = tid; k < nwords; k += 1024) a.bow_values[k] = divide ? vals[k] / scale : vals[k];
     if (tid == 0) a.counts[0] = nwords;
 }
 
@@ -500,17 +703,23 @@ extern "C" int gfo_bow_transform(gfo_ctx* c, const uint8_t* desc, int n, int lev
     VocDev v{(const int*)(V + c->voc_fc_off), (const int*)(V + c->voc_nc_off), V + c->voc_desc_off,
              (const int*)(V + c->voc_wid_off), (const float*)(V + c->voc_w_off), (const double*)(V + c->voc_w64_off), c->voc_nodes, c->voc_depth};
     hipStream_t st = c->stream;
-    BTRY(c, hipMemcpyAsync(S + o_d, desc, 32 * (size_t)n, hipMemcpyHostToDevice, st));
+    GfoXfer x(c);
+    if (int rc = x.in(32 * (size_t)n)) return rc;
+    x.put(0, desc, 32 * (size_t)n);
+    BTRY(c, x.up(S + o_d, 32 * (size_t)n, st));
     gfo_prof_begin(c, ST_BOW);
     GFO_LAUNCH(c, k_bow_transform, dim3((n + 3) / 4), dim3(256), 0, st, v, S + o_d, n, levelsup, (int*)(S + o_w),
                        (float*)(S + o_wt), (int*)(S + o_n), (double*)nullptr);
     gfo_prof_end(c);
     if (int lrc = gfo_take_launch_err(c)) return lrc;
     BTRY(c, hipGetLastError());
-    BTRY(c, hipMemcpyAsync(word_id, S + o_w, 4 * (size_t)n, hipMemcpyDeviceToHost, st));
-    BTRY(c, hipMemcpyAsync(weight, S + o_wt, 4 * (size_t)n, hipMemcpyDeviceToHost, st));
-    BTRY(c, hipMemcpyAsync(node_id, S + o_n, 4 * (size_t)n, hipMemcpyDeviceToHost, st));
+    const size_t out_bytes = o_n + 4 * (size_t)n - o_w;   // word, weight, node: neighbours in the scratch, one copy back
+    if (int rc = x.out(out_bytes)) return rc;
+    BTRY(c, x.down(S + o_w, out_bytes, st));
     BTRY(c, hipStreamSynchronize(st));
+    memcpy(word_id, x.HO, 4 * (size_t)n);
+    memcpy(weight, x.HO + (o_wt - o_w), 4 * (size_t)n);
+    memcpy(node_id, x.HO + (o_n - o_w), 4 * (size_t)n);
     return GFO_OK;
 }
 
@@ -544,8 +753,8 @@ extern "C" int gfo_compute_bow(gfo_ctx* c, const uint8_t* desc, int n, int level
     while (p2 < n) p2 <<= 1;
     const bool gmem = p2 > 8192;      // keys + marks beyond 96 KB of LDS: sorted in device memory
     const size_t o_d = take(32 * N), o_w = take(4 * N), o_wt = take(8 * N), o_n = take(4 * N), o_bw = take(4 * N), o_bv = take(8 * N),
-                 o_fn = take(4 * N), o_fs = take(4 * (N + 1)), o_fi = take(4 * N), o_ct = take(16), o_gk = take(gmem ? 8 * (size_t)p2 : 0),
-                 o_gf = take(gmem ? 4 * (size_t)p2 : 0);
+                 o_fn = take(4 * N), o_fs = take(4 * (N + 1)), o_fi = take(4 * N), o_ct = take(16), o_gk = take(gmem ? 16 * (size_t)p2 : 0),
+                 o_gf = take(gmem ? 8 * (size_t)p2 : 0);   // (two workgroups, one set each)
     if (off > c->scratch_bytes) {
         (void)hipStreamSynchronize(c->stream);
         if (c->d_scratch) (void)hipFree(c->d_scratch);
@@ -559,7 +768,10 @@ extern "C" int gfo_compute_bow(gfo_ctx* c, const uint8_t* desc, int n, int level
     VocDev v{(const int*)(V + c->voc_fc_off), (const int*)(V + c->voc_nc_off), V + c->voc_desc_off,
              (const int*)(V + c->voc_wid_off), (const float*)(V + c->voc_w_off), (const double*)(V + c->voc_w64_off), c->voc_nodes, c->voc_depth};
     hipStream_t st = c->stream;
-    BTRY(c, hipMemcpyAsync(S + o_d, desc, 32 * N, hipMemcpyHostToDevice, st));
+    GfoXfer x(c);
+    if (int rc = x.in(32 * N)) return rc;
+    x.put(0, desc, 32 * N);
+    BTRY(c, x.up(S + o_d, 32 * N, st));
     gfo_prof_begin(c, ST_BOW);
     GFO_LAUNCH(c, k_bow_transform, dim3((n + 3) / 4), dim3(256), 0, st, v, S + o_d, n, levelsup, (int*)(S + o_w), (float*)nullptr,
                        (int*)(S + o_n), (double*)(S + o_wt));
@@ -567,24 +779,30 @@ extern "C" int gfo_compute_bow(gfo_ctx* c, const uint8_t* desc, int n, int level
               (unsigned*)(S + o_bw), (double*)(S + o_bv), (unsigned*)(S + o_fn), (int*)(S + o_fs), (unsigned*)(S + o_fi), (int*)(S + o_ct),
               gmem ? (unsigned long long*)(S + o_gk) : nullptr, gmem ? (int*)(S + o_gf) : nullptr};
     if (gmem) {
-        GFO_LAUNCH(c, k_bow_fold<true>, dim3(1), dim3(1024), 0, st, f, p2);
+        GFO_LAUNCH(c, k_bow_fold<true>, dim3(2), dim3(1024), 0, st, f, p2);
     } else {
         const size_t lds = (size_t)p2 * 12;
         if (lds > 48 * 1024)
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bow_fold<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
-        GFO_LAUNCH(c, k_bow_fold<false>, dim3(1), dim3(1024), lds, st, f, p2);
+        GFO_LAUNCH(c, k_bow_fold<false>, dim3(2), dim3(1024), lds, st, f, p2);
     }
     gfo_prof_end(c);
     if (int lrc = gfo_take_launch_err(c)) return lrc;
     BTRY(c, hipGetLastError());
-    int cnt[4] = {0, 0, 0, 0};
-    BTRY(c, hipMemcpyAsync(cnt, S + o_ct, 16, hipMemcpyDeviceToHost, st));
-    BTRY(c, hipMemcpyAsync(bow_words, S + o_bw, 4 * N, hipMemcpyDeviceToHost, st));
-    BTRY(c, hipMemcpyAsync(bow_values, S + o_bv, 8 * N, hipMemcpyDeviceToHost, st));
-    BTRY(c, hipMemcpyAsync(fv_node_ids, S + o_fn, 4 * N, hipMemcpyDeviceToHost, st));
-    BTRY(c, hipMemcpyAsync(fv_start, S + o_fs, 4 * (N + 1), hipMemcpyDeviceToHost, st));
-    BTRY(c, hipMemcpyAsync(fv_items, S + o_fi, 4 * N, hipMemcpyDeviceToHost, st));
+    // the two vectors and the counters are neighbours in the scratch (o_bw .. o_ct): one copy back instead of six
+    const size_t out_bytes = o_ct + 16 - o_bw;
+    if (int rc = x.out(out_bytes)) return rc;
+    BTRY(c, x.down(S + o_bw, out_bytes, st));
     BTRY(c, hipStreamSynchronize(st));
+    int cnt[4];
+    memcpy(cnt, x.HO + (o_ct - o_bw), 16);
+    // only what the call produced: n_words entries of the BowVector, n_fv_nodes (+1 offsets) and n items of the FeatureVector
+    const size_t nw = (size_t)(cnt[0] < 0 ? 0 : cnt[0] > n ? n : cnt[0]), nn = (size_t)(cnt[1] < 0 ? 0 : cnt[1] > n ? n : cnt[1]);
+    memcpy(bow_words, x.HO, 4 * nw);
+    memcpy(bow_values, x.HO + (o_bv - o_bw), 8 * nw);
+    memcpy(fv_node_ids, x.HO + (o_fn - o_bw), 4 * nn);
+    memcpy(fv_start, x.HO + (o_fs - o_bw), 4 * (nn + 1));
+    memcpy(fv_items, x.HO + (o_fi - o_bw), 4 * N);
     *n_words = cnt[0];
     *n_fv_nodes = cnt[1];
     return GFO_OK;

@@ -32,6 +32,7 @@
 // (dist, ix, iy, idx): candidates can be scanned in any order with that 64-bit key, and the best /
 // second-best pair is the two smallest keys (a stable sort by distance).
 #include "gfo_internal.h"
+#include "k_wave.inc"
 #include <stdlib.h>
 
 #define GRID_COLS 64   // FRAME_GRID_COLS, Frame.h:92
@@ -51,6 +52,7 @@
 
 enum { PJ_NLIVE = 0, PJ_ROUNDS = 1, PJ_NMATCH = 2, PJ_ERR = 3, PJ_FALLBACK = 4, PJ_CNT = 8 };
 #define PJ_K 7   // cached candidates per live point: 7 entries + 1 header word = 32 bytes
+#define PJ_RR 4  // k_proj_resolve keeps up to 1024 * PJ_RR live points in registers across the rounds
 
 // Everything is [frame][...]: frame f of a per-frame array starts at base + f * stride (stride 0 = shared).
 struct ProjB {
@@ -131,7 +133,7 @@ __device__ __forceinline__ int frame_n(const ProjB& a, int f)
 __global__ __launch_bounds__(1024) void k_proj_grid(ProjB a)
 {
     __shared__ int s_cnt[NSG];
-    __shared__ int s_part[1024];
+    __shared__ int s_part[16];
     const int tid = threadIdx.x, f = blockIdx.x;
     const int n = frame_n(a, f);
     const gfo_keypoint* kp = a.kp + (long long)f * a.kp_stride;
@@ -157,15 +159,8 @@ __global__ __launch_bounds__(1024) void k_proj_grid(ProjB a)
     int loc[NSG / 1024], s = 0;
 #pragma unroll
     for (int k = 0; k < NSG / 1024; k++) { loc[k] = s_cnt[tid * (NSG / 1024) + k]; s += loc[k]; }
-    s_part[tid] = s;
-    __syncthreads();
-    for (int off = 1; off < 1024; off <<= 1) {
-        const int v = tid >= off ? s_part[tid - off] : 0;
-        __syncthreads();
-        s_part[tid] += v;
-        __syncthreads();
-    }
-    int run = s_part[tid] - s;
+    int total_in;
+    int run = st_block_incl_scan(s, s_part, &total_in) - s;   // DPP scan inside the waves, 16 partial sums (k_wave.inc): two barriers
 #pragma unroll
     for (int k = 0; k < NSG / 1024; k++) {
         cell_start[tid * (NSG / 1024) + k] = run;
@@ -408,6 +403,141 @@ __global__ __launch_bounds__(LDSGRID ? 1024 : 256, 8) void k_proj_round0(ProjB a
     }
 }
 
+// Minimum over the wave of a candidate key (44 bits, ~0 = none) in two 32-bit DPP reductions: the upper 21 bits (distance, reference
+// cell), then the lower 23 (index, octave) among the lanes that hold the winning upper part.
+__device__ __forceinline__ unsigned long long pj_wave_min_key(unsigned long long x)
+{
+    const unsigned hi = (unsigned)(x >> 23), lo = (unsigned)x & 0x7FFFFFu;
+    const unsigned mh = st_wave_min(hi);
+    if (mh == 0xFFFFFFFFu) return ~0ull;
+    const unsigned ml = st_wave_min(hi == mh ? lo : 0xFFFFFFFFu);
+    return ((unsigned long long)mh << 23) | ml;
+}
+
+// round 0 for FEW points (frames * m <= 16 384: the call Tracking makes per frame -- a thousand or two map points, or the last
+// frame's tracked points, against ONE frame): a wavefront per projected point.  One thread a point makes the call a chain of
+// dependent ~1 us loads as long as the point's window has items (1500 points at th 7: 105 us on six workgroups); here the lanes
+// take the window's items side by side -- column ranges of the scan grid, flattened over the lanes -- so a point costs four
+// round trips to memory whatever its window holds, and the points spread over every CU.  Same outputs as k_proj_round0: the
+// PJ_K smallest keys in order, the count, the truncation mark, the pick under the entry state.
+// (Sixteen points a workgroup, and ONE atomic on the frame's live counter per workgroup: the L2 retires atomics on one address at
+//  ~20 ns each -- a returning atomic per point made the 16 000-point call 0.42 ms instead of 0.31.)
+#define PJ_WAVES 16
+__global__ __launch_bounds__(64 * PJ_WAVES) void k_proj_round0_wave(ProjB a)
+{
+    __shared__ int s_n, s_base;
+    const int f = blockIdx.y;
+    const int n = frame_n(a, f);
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int iq = blockIdx.x * PJ_WAVES + wave;
+    if (threadIdx.x == 0) s_n = 0;
+    __syncthreads();
+    ProjQ q{};
+    if (iq < a.m && n > 0) q = load_query(a, f, iq);
+    const float rs = q.radius, x = q.u, y = q.v;
+    const bool scan = iq < a.m && n > 0 && q.active && rs > 0.f;   // a zero or NaN radius admits nothing: the window test is strict
+    const int* g_start = a.cell_start + (long long)f * (NSG + 1);
+    const float2* cell_xy = a.cell_xy + (long long)f * a.n_cap;
+    const unsigned* cell_meta = a.cell_meta + (long long)f * a.n_cap;
+    const uint8_t* desc = a.desc + (long long)f * a.kp_stride * 32;
+    const float* u_right = a.u_right ? a.u_right + (long long)f * a.ur_stride : nullptr;
+    const uint8_t* taken0 = a.taken0 ? a.taken0 + (long long)f * a.tk_stride : nullptr;
+    uint4 a0 = make_uint4(0, 0, 0, 0), a1 = a0;
+    if (scan) {
+        const uint4* dq = reinterpret_cast<const uint4*>(a.q_desc + (long long)f * a.qd_stride + (long long)iq * 32);
+        a0 = dq[0]; a1 = dq[1];
+    }
+    // the scan cells the window touches: see scan_candidates
+    const float sgx = (float)(SG_COLS - 1), sgy = (float)(SG_ROWS - 1);
+    const int cx0 = (int)fminf(fmaxf(floorf((x - a.fb.min_x - rs) * a.sinv_w - 0.01f), 0.f), sgx);
+    const int cx1 = scan ? (int)fminf(fmaxf(floorf((x - a.fb.min_x + rs) * a.sinv_w + 0.01f), 0.f), sgx) : cx0 - 1;   // not scanning: no columns
+    const int cy0 = (int)fminf(fmaxf(floorf((y - a.fb.min_y - rs) * a.sinv_h - 0.01f), 0.f), sgy);
+    const int cy1 = (int)fminf(fmaxf(floorf((y - a.fb.min_y + rs) * a.sinv_h + 0.01f), 0.f), sgy);
+    const bool check_levels = (q.min_level > 0) || (q.max_level >= 0);
+    unsigned long long k[PJ_K];   // the PJ_K smallest keys of the point, ascending; the same in every lane
+#pragma unroll
+    for (int s = 0; s < PJ_K; s++) k[s] = ~0ull;
+    int total = 0;
+    for (int cg = cx0; cg <= cx1; cg += 64) {
+        // lane c holds column cg + c: cells (column, cy0..cy1) are contiguous in the CSR
+        const int ncol = min(64, cx1 - cg + 1);
+        int beg = 0, cnt = 0;
+        if (lane < ncol) {
+            beg = g_start[(cg + lane) * SG_ROWS + cy0];
+            cnt = g_start[(cg + lane) * SG_ROWS + cy1 + 1] - beg;
+        }
+        const int incl = st_wave_incl_scan(cnt);
+        const int excl = incl - cnt;
+        const int T = __builtin_amdgcn_readlane(incl, 63);
+        for (int t0 = 0; t0 < T; t0 += 64) {
+            const int t = t0 + lane;
+            int j = -1;
+            for (int cc = 0; cc < ncol; cc++) {
+                const int p = __builtin_amdgcn_readlane(excl, cc), cn = __builtin_amdgcn_readlane(cnt, cc), b = __builtin_amdgcn_readlane(beg, cc);
+                if (t >= p && t < p + cn) j = b + (t - p);
+            }
+            unsigned long long key = ~0ull;
+            if (j >= 0) {
+                const float2 it = cell_xy[j];
+                const unsigned meta = cell_meta[j];
+                bool ok = fabsf(it.x - x) < rs && fabsf(it.y - y) < rs;   // GetFeaturesInArea, Frame.cc:627-640
+                if (ok && check_levels) {
+                    const int oct = (int)((meta >> 16) & 0xF);
+                    ok = !(oct < q.min_level) && !(q.max_level >= 0 && oct > q.max_level);
+                }
+                if (ok) {
+                    const int i = min((int)(meta & 0xFFFF), n - 1);
+                    const uint4* dk = reinterpret_cast<const uint4*>(desc + (long long)i * 32);
+                    const uint4 b0 = dk[0], b1 = dk[1];
+                    const int tk = taken0 ? (int)taken0[i] : 0;            // F.mvpMapPoints[idx] with Observations() > 0, :197-199
+                    const float ur = u_right ? u_right[i] : -1.0f;         // :201-206
+                    if (!(tk || (ur > 0 && fabsf(q.ur - ur) > rs))) {
+                        const unsigned dist = (unsigned)(__popc(a0.x ^ b0.x) + __popc(a0.y ^ b0.y) + __popc(a0.z ^ b0.z) + __popc(a0.w ^ b0.w) +
+                                                         __popc(a1.x ^ b1.x) + __popc(a1.y ^ b1.y) + __popc(a1.z ^ b1.z) + __popc(a1.w ^ b1.w));
+                        key = cand_key(dist, meta);
+                    }
+                }
+            }
+            total += __popcll(__builtin_amdgcn_ballot_w64(key != ~0ull));
+            // at most PJ_K keys of this batch can enter the list: take the batch's minimum while it beats the list's last
+            for (int s = 0; s < PJ_K; s++) {
+                const unsigned long long mk = pj_wave_min_key(key);
+                if (mk >= k[PJ_K - 1]) break;
+                if (key == mk) key = ~0ull;
+                unsigned long long xk = mk;
+#pragma unroll
+                for (int s2 = 0; s2 < PJ_K; s2++) {
+                    const unsigned long long lo = k[s2] < xk ? k[s2] : xk;
+                    xk = k[s2] < xk ? xk : k[s2];
+                    k[s2] = lo;
+                }
+            }
+        }
+    }
+    int pick = -1, dist = 256, rank = 0;
+    bool live = false;
+    if (k[0] != ~0ull) {
+        const int e1 = key_entry(k[0]), e2 = key_entry(k[1]);
+        live = (e1 >> 23) <= a.th_dist;   // :228 / :1536: otherwise it can never match
+        accept_rule(a, e1, e2, &pick, &dist);
+    }
+    if (live && lane == 0) rank = atomicAdd(&s_n, 1);
+    __syncthreads();
+    if (threadIdx.x == 0 && s_n > 0) s_base = atomicAdd(&a.counters[f * PJ_CNT + PJ_NLIVE], s_n);
+    __syncthreads();
+    if (!live || lane != 0) return;
+    const long long slot = (long long)f * a.m + s_base + rank;
+    a.live[slot] = (unsigned)iq | (q.obs ? 0x80000000u : 0u);
+    a.pick[slot] = pick;
+    a.pick_dist[slot] = dist;
+    int e[PJ_K];
+#pragma unroll
+    for (int s = 0; s < PJ_K; s++) e[s] = key_entry(k[s]);
+    const int cnt = total < PJ_K ? total : PJ_K;
+    a.cand[2 * slot] = make_uint4((unsigned)cnt | (total > PJ_K ? 0x100u : 0u), (unsigned)e[0], (unsigned)e[1], (unsigned)e[2]);
+    a.cand[2 * slot + 1] = make_uint4((unsigned)e[3], (unsigned)e[4], (unsigned)e[5], (unsigned)e[6]);
+}
+
 // One workgroup per frame: claim / re-evaluate rounds until nothing changes, then the epilogue:
 //   owner of a keypoint = the LAST accepted point that picked it (:233 overwrites), its distance the score;
 //   rotation consistency (ORBmatcher.cc:1548-1591): bin of every accepted point, histogram, the reference's
@@ -437,7 +567,100 @@ __global__ __launch_bounds__(1024) void k_proj_resolve(ProjB a)
     if (nlive > a.m) nlive = a.m;
     if (tid < 3) s_acc[tid] = 0;
     int rounds = 0, fallbacks = 0;
-    if (nlive > 0) {
+    // one live point under the current claims: the first two candidates of its cached list that no lower point holds.
+    // false: the cached prefix ran out before a best and a second were found and the point has more candidates than the cache
+    // holds -- it needs `rescan` (rare)
+    auto from_cache = [&](int iq, const uint4& c0, const uint4* c1p, int* e1, int* e2) {
+        const int cnt = (int)(c0.x & 0xFF);
+        *e1 = -1; *e2 = -1;
+        auto offer = [&](int s, int ent) {
+            if (s < cnt && *e2 < 0) {
+                const bool free_ = tab_load(&tab[ent & 0xFFFF]) >= iq;   // not claimed by a lower point
+                if (free_) { if (*e1 < 0) *e1 = ent; else *e2 = ent; }
+            }
+        };
+        offer(0, (int)c0.y); offer(1, (int)c0.z); offer(2, (int)c0.w);
+        if (cnt > 3 && *e2 < 0) {   // the second half of the cached list: fetched only by the points that get this far
+            const uint4 c1 = *c1p;
+            offer(3, (int)c1.x); offer(4, (int)c1.y); offer(5, (int)c1.z); offer(6, (int)c1.w);
+        }
+        return !((c0.x & 0x100u) && *e2 < 0);
+    };
+    // full re-evaluation of one point from the grid under the current claims
+    auto rescan = [&](int iq, int* e1, int* e2) {
+        unsigned long long k1 = ~0ull, k2 = ~0ull;
+        const ProjQ q = load_query(a, f, iq);
+        scan_candidates(a, f, n, iq, q, a.cell_start + (long long)f * (NSG + 1), a.cell_xy + (long long)f * a.n_cap,
+                        a.cell_meta + (long long)f * a.n_cap,
+                        [&](int i) { return tab_load(&tab[i]) < iq; },
+                        [&](unsigned long long x) {
+                            const unsigned long long hi = x < k1 ? k1 : x;
+                            k1 = x < k1 ? x : k1;
+                            k2 = hi < k2 ? hi : k2;
+                        });
+        *e1 = key_entry(k1);
+        *e2 = key_entry(k2);
+        fallbacks++;
+    };
+    if (!TABG && nlive > 0 && nlive <= 1024 * PJ_RR) {   // (TABG: more than 12 288 keypoints, the tables are in device memory anyway)
+        // The usual case -- a frame's few thousand live points: every thread keeps its points (index, cached candidates, pick) in
+        // registers for all the rounds, so a round is LDS traffic and three barriers; walking the live arrays in device memory
+        // every round made a lone call's resolve a chain of ~1 us loads (6 rounds over 1721 points: 44 us).
+        unsigned lv[PJ_RR];
+        int pk[PJ_RR], pd[PJ_RR];
+        uint4 c0[PJ_RR];   // header + the first three candidates; the other four stay in memory (from_cache)
+#pragma unroll
+        for (int r = 0; r < PJ_RR; r++) {
+            const int t = tid + r * 1024;
+            lv[r] = 0; pk[r] = -1; pd[r] = 256;
+            c0[r] = make_uint4(0, 0, 0, 0);
+            if (t < nlive) { lv[r] = live[t]; pk[r] = pick[t]; pd[r] = pick_dist[t]; c0[r] = cand[2 * t]; }
+        }
+        for (;;) {
+            rounds++;
+            for (int k = tid; k < n; k += 1024) tab[k] = 0x7FFFFFFF;
+            __syncthreads();
+#pragma unroll
+            for (int r = 0; r < PJ_RR; r++)
+                if ((lv[r] & 0x80000000u) && pk[r] >= 0) atomicMin(&tab[pk[r]], (int)(lv[r] & 0x7FFFFFFFu));
+            __syncthreads();
+            int changed = 0;
+            unsigned redo = 0;   // slots whose cache ran out: rescanned below, ONE inlined copy of the grid scan
+#pragma unroll
+            for (int r = 0; r < PJ_RR; r++) {
+                if (tid + r * 1024 < nlive) {
+                    int e1, e2, np, nd;
+                    if (from_cache((int)(lv[r] & 0x7FFFFFFFu), c0[r], &cand[2 * (tid + r * 1024) + 1], &e1, &e2)) {
+                        accept_rule(a, e1, e2, &np, &nd);
+                        if (np != pk[r] || nd != pd[r]) { changed = 1; pk[r] = np; pd[r] = nd; }
+                    } else redo |= 1u << r;
+                }
+            }
+            while (redo) {
+                const int r = __builtin_ctz(redo);
+                redo &= redo - 1;
+                unsigned e = lv[0];
+#pragma unroll
+                for (int r2 = 1; r2 < PJ_RR; r2++) e = r == r2 ? lv[r2] : e;
+                int e1, e2, np, nd;
+                rescan((int)(e & 0x7FFFFFFFu), &e1, &e2);
+                accept_rule(a, e1, e2, &np, &nd);
+#pragma unroll
+                for (int r2 = 0; r2 < PJ_RR; r2++)
+                    if (r == r2 && (np != pk[r2] || nd != pd[r2])) { changed = 1; pk[r2] = np; pd[r2] = nd; }
+            }
+            if (!__syncthreads_or(changed)) break;
+            if (rounds > nlive + 1) {   // cannot happen (point i is final after rank(i) rounds); never spin
+                if (tid == 0) a.counters[f * PJ_CNT + PJ_ERR] = 1;
+                break;
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < PJ_RR; r++) {   // the epilogue below reads them back with the same thread
+            const int t = tid + r * 1024;
+            if (t < nlive) { pick[t] = pk[r]; pick_dist[t] = pd[r]; }
+        }
+    } else if (nlive > 0) {
         for (;;) {
             rounds++;
             for (int k = tid; k < n; k += 1024) tab[k] = 0x7FFFFFFF;
@@ -451,35 +674,8 @@ __global__ __launch_bounds__(1024) void k_proj_resolve(ProjB a)
             int changed = 0;
             for (int t = tid; t < nlive; t += 1024) {
                 const int iq = (int)(live[t] & 0x7FFFFFFFu);
-                const uint4 c0 = cand[2 * t], c1 = cand[2 * t + 1];
-                const int cnt = (int)(c0.x & 0xFF);
-                const int ent[PJ_K] = {(int)c0.y, (int)c0.z, (int)c0.w, (int)c1.x, (int)c1.y, (int)c1.z, (int)c1.w};
-                int e1 = -1, e2 = -1;
-#pragma unroll
-                for (int s = 0; s < PJ_K; s++) {
-                    if (s < cnt && e2 < 0) {
-                        const bool free_ = tab_load(&tab[ent[s] & 0xFFFF]) >= iq;   // not claimed by a lower point
-                        if (free_) { if (e1 < 0) e1 = ent[s]; else e2 = ent[s]; }
-                    }
-                }
-                int np, nd;
-                if ((c0.x & 0x100u) && e2 < 0) {
-                    // the cached prefix ran out before a best and a second were found, and the point has more
-                    // candidates than the cache holds: full re-evaluation from the grid (rare)
-                    unsigned long long k1 = ~0ull, k2 = ~0ull;
-                    const ProjQ q = load_query(a, f, iq);
-                    scan_candidates(a, f, n, iq, q, a.cell_start + (long long)f * (NSG + 1), a.cell_xy + (long long)f * a.n_cap,
-                                    a.cell_meta + (long long)f * a.n_cap,
-                                    [&](int i) { return tab_load(&tab[i]) < iq; },
-                                    [&](unsigned long long x) {
-                                        const unsigned long long hi = x < k1 ? k1 : x;
-                                        k1 = x < k1 ? x : k1;
-                                        k2 = hi < k2 ? hi : k2;
-                                    });
-                    e1 = key_entry(k1);
-                    e2 = key_entry(k2);
-                    fallbacks++;
-                }
+                int e1, e2, np, nd;
+                if (!from_cache(iq, cand[2 * t], &cand[2 * t + 1], &e1, &e2)) rescan(iq, &e1, &e2);
                 accept_rule(a, e1, e2, &np, &nd);
                 if (np != pick[t] || nd != pick_dist[t]) {
                     changed = 1;
@@ -632,7 +828,11 @@ static int pj_launch(gfo_ctx* c, const ProjB& a, int frames, int n_max)
     // frame as it takes to put ~2 on every CU (each pays the 78 KB copy once, then walks its chunk of the points)
     const size_t grid_bytes = (size_t)a.n_cap * 12 + (NSG + 1) * 2 + 16;
     static const int lds_grid_on = getenv("GFO_PROJ_LDSGRID") ? atoi(getenv("GFO_PROJ_LDSGRID")) : 1;
-    if (lds_grid_on && grid_bytes <= 78 * 1024 && a.m >= 4096) {
+    // few points (the host-array call Tracking makes per frame: a thousand or two against one frame): a WAVEFRONT per point
+    const int wave_on = getenv("GFO_PROJ_WAVE") ? atoi(getenv("GFO_PROJ_WAVE")) : 1;   // read per call: the tests run both forms
+    if (wave_on && (long long)frames * a.m <= 16384) {
+        GFO_LAUNCH(c, k_proj_round0_wave, dim3((a.m + PJ_WAVES - 1) / PJ_WAVES, frames), dim3(64 * PJ_WAVES), 0, st, a);
+    } else if (lds_grid_on && grid_bytes <= 78 * 1024 && a.m >= 4096) {
         int per_frame = (512 + frames - 1) / frames;
         const int max_pf = (a.m + 2047) / 2048;     // at least two passes of 1024 points per workgroup
         if (per_frame > max_pf) per_frame = max_pf;
@@ -694,13 +894,18 @@ extern "C" int gfo_search_by_projection_queries(gfo_ctx* c, const gfo_keypoint* 
     if (int rc = pj_reserve(c, 1, m + m / 2, n + n / 2)) return rc;
     uint8_t* S = (uint8_t*)c->d_scratch;
     hipStream_t st = c->stream;
-    PTRY(c, hipMemcpyAsync(S + o_kp, kp_un, sizeof(gfo_keypoint) * n, hipMemcpyHostToDevice, st));
-    PTRY(c, hipMemcpyAsync(S + o_desc, desc, 32 * (size_t)n, hipMemcpyHostToDevice, st));
-    if (u_right) PTRY(c, hipMemcpyAsync(S + o_ur, u_right, 4 * (size_t)n, hipMemcpyHostToDevice, st));
-    if (kp_taken) PTRY(c, hipMemcpyAsync(S + o_tk, kp_taken, n, hipMemcpyHostToDevice, st));
-    if (kp_angle) PTRY(c, hipMemcpyAsync(S + o_ang, kp_angle, 4 * (size_t)n, hipMemcpyHostToDevice, st));
-    PTRY(c, hipMemcpyAsync(S + o_q, queries, sizeof(gfo_proj_query) * m, hipMemcpyHostToDevice, st));
-    PTRY(c, hipMemcpyAsync(S + o_mpd, q_desc, 32 * (size_t)m, hipMemcpyHostToDevice, st));
+    // the seven input arrays are packed into the pinned mirror of the scratch layout and cross in one copy: seven pageable
+    // hipMemcpyAsync calls cost ~95 us of the call's 190 us (profiles/proj_call_latency_r05.txt)
+    GfoXfer x(c);
+    if (int rc = x.in(off)) return rc;
+    x.put(o_kp, kp_un, sizeof(gfo_keypoint) * n);
+    x.put(o_desc, desc, 32 * (size_t)n);
+    if (u_right) x.put(o_ur, u_right, 4 * (size_t)n);
+    if (kp_taken) x.put(o_tk, kp_taken, n);
+    if (kp_angle) x.put(o_ang, kp_angle, 4 * (size_t)n);
+    x.put(o_q, queries, sizeof(gfo_proj_query) * m);
+    x.put(o_mpd, q_desc, 32 * (size_t)m);
+    PTRY(c, x.up(S, off, st));
     ProjB a{};
     a.kp = (const gfo_keypoint*)(S + o_kp);
     a.desc = S + o_desc;
@@ -723,14 +928,21 @@ extern "C" int gfo_search_by_projection_queries(gfo_ctx* c, const gfo_keypoint* 
     a.check_ori = mode->check_orientation;
     pj_bind(c, &a);
     if (int rc = pj_launch(c, a, 1, n)) return rc;
-    int cnt[PJ_CNT];
-    PTRY(c, hipMemcpyAsync(out_mp, a.out_mp, 4 * (size_t)n, hipMemcpyDeviceToHost, st));
-    PTRY(c, hipMemcpyAsync(out_score, a.out_score, 4 * (size_t)n, hipMemcpyDeviceToHost, st));
-    PTRY(c, hipMemcpyAsync(cnt, a.counters, sizeof cnt, hipMemcpyDeviceToHost, st));
+    // counters, out_mp and out_score are consecutive in the work buffer (pj_reserve): one copy back
+    const uint8_t* d_lo = (const uint8_t*)a.counters;
+    const size_t out_bytes = (size_t)((const uint8_t*)(a.out_score + n) - d_lo);
+    if (int rc = x.out(out_bytes)) return rc;
+    PTRY(c, x.down(d_lo, out_bytes, st));
     PTRY(c, hipStreamSynchronize(st));
+    int cnt[PJ_CNT];
+    memcpy(cnt, x.HO, sizeof cnt);
+    memcpy(out_mp, x.HO + ((const uint8_t*)a.out_mp - d_lo), 4 * (size_t)n);
+    memcpy(out_score, x.HO + ((const uint8_t*)a.out_score - d_lo), 4 * (size_t)n);
     if (cnt[PJ_ERR]) return pj_fail(c, GFO_ERR_STATE, "gfo_search_by_projection: fixed point not reached");
     *nmatches = cnt[PJ_NMATCH];
     c->last_project_rounds = cnt[PJ_ROUNDS];
+    static const bool stats = getenv("GFO_PROJ_STATS") != nullptr;   // diagnosis only: one line per call on stderr
+    if (stats) fprintf(stderr, "[gfo] projection: m %d n %d live %d rounds %d fallbacks %d matches %d\n", m, n, cnt[PJ_NLIVE], cnt[PJ_ROUNDS], cnt[PJ_FALLBACK], cnt[PJ_NMATCH]);
     c->have_projection = false;
     return GFO_OK;
 }
@@ -895,5 +1107,6 @@ extern "C" int gfo_projection_device_views(gfo_ctx* c, const int32_t** d_out_mp,
 void gfo_kernels_project(std::vector<const void*>& v)
 {
     v.push_back((const void*)k_proj_grid); v.push_back((const void*)k_proj_round0<true>); v.push_back((const void*)k_proj_round0<false>);
+    v.push_back((const void*)k_proj_round0_wave);
     v.push_back((const void*)k_proj_resolve<true>); v.push_back((const void*)k_proj_resolve<false>);
 }

@@ -64,67 +64,7 @@ struct StereoArgs {
     int nlevels;              // entries of `scale`
 };
 
-// Minimum / sum over the 32 lanes of a half (or all 64), left in every lane: DPP steps inside the 16-lane rows (lane ^ 1,
-// lane ^ 2, the other quad of the eight, the other eight of the row -- each folds into its v_min / v_add) and a ds_swizzle
-// (lane ^ 16) / a v_readlane pair across rows.  (__shfl_xor is a ds_bpermute with its address arithmetic: six vector
-// instructions and an LDS round trip per step, five or six steps per keypoint.)
-__device__ __forceinline__ unsigned st_row_min(unsigned v)
-{
-    v = min(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, true));    // quad_perm:[1,0,3,2]
-    v = min(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, true));    // quad_perm:[2,3,0,1]
-    v = min(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xF, 0xF, true));   // row_half_mirror
-    v = min(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x140, 0xF, 0xF, true));   // row_mirror
-    return v;
-}
-__device__ __forceinline__ unsigned st_half_min(unsigned v)
-{
-    v = st_row_min(v);
-    return min(v, (unsigned)__builtin_amdgcn_ds_swizzle((int)v, 0x401F));                  // bit mode: lane ^ 16
-}
-__device__ __forceinline__ unsigned st_wave_min(unsigned v)
-{
-    v = st_half_min(v);
-    return min((unsigned)__builtin_amdgcn_readlane((int)v, 0), (unsigned)__builtin_amdgcn_readlane((int)v, 32));
-}
-__device__ __forceinline__ int st_wave_sum(int v)
-{
-    v += __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, true);
-    v += __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xF, 0xF, true);
-    v += __builtin_amdgcn_update_dpp(0, v, 0x141, 0xF, 0xF, true);
-    v += __builtin_amdgcn_update_dpp(0, v, 0x140, 0xF, 0xF, true);
-    v += __builtin_amdgcn_ds_swizzle(v, 0x401F);
-    return __builtin_amdgcn_readlane(v, 0) + __builtin_amdgcn_readlane(v, 32);
-}
-
-// inclusive scan over the 64 lanes in the DPP network (see k_quadtree.hip)
-__device__ __forceinline__ int st_wave_incl_scan(int v)
-{
-    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xF, 0xF, false);  // row_shr:1
-    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xF, 0xF, false);  // row_shr:2
-    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xF, 0xF, false);  // row_shr:4
-    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xF, 0xF, false);  // row_shr:8
-    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xA, 0xF, false);  // row_bcast:15
-    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xC, 0xF, false);  // row_bcast:31
-    return v;
-}
-
-// inclusive scan of one value per thread over the workgroup (s_part: one int per wave); two barriers
-__device__ __forceinline__ int st_block_incl_scan(int v, int* s_part, int* total)
-{
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
-    const int incl = st_wave_incl_scan(v);
-    if (lane == 63) s_part[wave] = incl;
-    __syncthreads();
-    int base = 0, tot = 0;
-    for (int w = 0; w < nw; w++) {
-        const int t = s_part[w];
-        if (w < wave) base += t;
-        tot += t;
-    }
-    __syncthreads();
-    *total = tot;
-    return base + incl;
-}
+#include "k_wave.inc"   // st_row_min / st_half_min / st_wave_min / st_wave_sum / st_wave_incl_scan / st_block_incl_scan
 
 // blockIdx.y = 0: the right keypoints of the pair by floor(y); blockIdx.y = 1 (row form only): the left ones by row.
 // The two counting sorts are independent -- a workgroup each, side by side (one after the other in one workgroup: 20 us

@@ -10,6 +10,14 @@ from conftest import GOLDEN
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(params=["wavefront_per_point", "thread_per_point"], autouse=True)
+def round0_form(request, monkeypatch):
+    """Round 0 has two forms: k_proj_round0_wave when a call brings at most 16 384 points (the per-frame calls of Tracking), the
+    thread-per-point kernels otherwise.  Every case of this module runs under both (GFO_PROJ_WAVE is read on every call)."""
+    monkeypatch.setenv("GFO_PROJ_WAVE", "1" if request.param == "wavefront_per_point" else "0")
+    return request.param
+
+
 @pytest.fixture(scope="module")
 def ext():
     import gf_orb_slam2_amd as G
