@@ -163,6 +163,9 @@ struct GfoProjBuf {
     int* pick_dist = nullptr;
     unsigned* live = nullptr;
     int* rot_bin = nullptr;
+    int* spill_off = nullptr;               // [frames][m] by live slot: start of the point's full candidate list in `spill`, -1 none
+    unsigned long long* spill = nullptr;    // [spill_cap] candidate keys of the points whose list outgrew the cache (k_proj_round0_wave)
+    int spill_cap = 0;
     int* tab_g = nullptr;
     int* counters = nullptr;
     int* out_mp = nullptr;

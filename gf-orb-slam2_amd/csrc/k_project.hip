@@ -50,7 +50,8 @@
 #define TH_HIGH 100    // ORBmatcher.cc:57
 #define HISTO_LENGTH 30  // ORBmatcher.cc:59
 
-enum { PJ_NLIVE = 0, PJ_ROUNDS = 1, PJ_NMATCH = 2, PJ_ERR = 3, PJ_FALLBACK = 4, PJ_CNT = 8 };
+enum { PJ_NLIVE = 0, PJ_ROUNDS = 1, PJ_NMATCH = 2, PJ_ERR = 3, PJ_FALLBACK = 4, PJ_SPILL = 5, PJ_CNT = 8 };
+#define PJ_SPILL_PER_POINT 64   // the spill pool holds this many candidate keys per point of a wavefront-per-point call, on average
 #define PJ_K 7   // cached candidates per live point: 7 entries + 1 header word = 32 bytes
 #define PJ_RR 4  // k_proj_resolve keeps up to 1024 * PJ_RR live points in registers across the rounds
 
@@ -83,6 +84,10 @@ struct ProjB {
     uint4* cand;               // [m][2] by live slot: header (count | truncated << 8) + PJ_K entries
                                //        dist << 23 | octave << 16 | index, in the reference's candidate order
     int* rot_bin;              // [m] by live slot
+    int* spill_off;            // [m] by live slot: where the point's FULL candidate list starts in `spill` (header bits 9.. = its length), -1 none
+    unsigned long long* spill; // [spill_cap], one pool for the frames of a call (cursor: counters[PJ_SPILL] of frame 0): candidate keys, unsorted,
+                               // of the points with more than PJ_K candidates
+    int spill_cap;
     int* tab_g;                // [2 * n_cap] claim / owner and score tables when they do not fit LDS
     int* counters;             // [PJ_CNT]
     int* out_mp; int* out_score;   // [n_cap]
@@ -391,6 +396,7 @@ __global__ __launch_bounds__(LDSGRID ? 1024 : 256, 8) void k_proj_round0(ProjB a
             a.live[slot] = (unsigned)iq | (obs ? 0x80000000u : 0u);
             a.pick[slot] = pick;
             a.pick_dist[slot] = dist;
+            a.spill_off[slot] = -1;
             int e[PJ_K], cnt = 0;
 #pragma unroll
             for (int s = 0; s < PJ_K; s++) {
@@ -425,13 +431,13 @@ __device__ __forceinline__ unsigned long long pj_wave_min_key(unsigned long long
 #define PJ_WAVES 16
 __global__ __launch_bounds__(64 * PJ_WAVES) void k_proj_round0_wave(ProjB a)
 {
-    __shared__ int s_n, s_base;
+    __shared__ int s_n, s_base, s_sp_base;
+    __shared__ int s_want[PJ_WAVES];
     const int f = blockIdx.y;
     const int n = frame_n(a, f);
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int iq = blockIdx.x * PJ_WAVES + wave;
     if (threadIdx.x == 0) s_n = 0;
-    __syncthreads();
     ProjQ q{};
     if (iq < a.m && n > 0) q = load_query(a, f, iq);
     const float rs = q.radius, x = q.u, y = q.v;
@@ -454,18 +460,42 @@ __global__ __launch_bounds__(64 * PJ_WAVES) void k_proj_round0_wave(ProjB a)
     const int cy0 = (int)fminf(fmaxf(floorf((y - a.fb.min_y - rs) * a.sinv_h - 0.01f), 0.f), sgy);
     const int cy1 = (int)fminf(fmaxf(floorf((y - a.fb.min_y + rs) * a.sinv_h + 0.01f), 0.f), sgy);
     const bool check_levels = (q.min_level > 0) || (q.max_level >= 0);
+    // lane c holds column cg + c of a group of up to 64: cells (column, cy0..cy1) are contiguous in the CSR
+    int beg = 0, cnt = 0;
+    auto load_columns = [&](int cg, int ncol) {
+        beg = 0; cnt = 0;
+        if (lane < ncol) {
+            beg = g_start[(cg + lane) * SG_ROWS + cy0];
+            cnt = g_start[(cg + lane) * SG_ROWS + cy1 + 1] - beg;
+        }
+    };
+    load_columns(cx0, min(64, cx1 - cx0 + 1));
+    // Room for the point's FULL candidate list, for k_proj_resolve to fall back on when the point's PJ_K cached candidates are all
+    // taken (contended maps: several points per keypoint, wide windows): the items of the window bound it.  One cursor for the call
+    // (frame 0's counter), advanced once per workgroup.
+    const int items0 = __builtin_amdgcn_readlane(st_wave_incl_scan(cnt), 63);
+    const int want = cx1 - cx0 < 64 && items0 > PJ_K ? items0 : 0;
+    if (lane == 0) s_want[wave] = want;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int sum = 0;
+        for (int w = 0; w < PJ_WAVES; w++) sum += s_want[w];
+        s_sp_base = sum ? atomicAdd(&a.counters[PJ_SPILL], sum) : 0;
+    }
+    __syncthreads();
+    int sp_off = -1;
+    if (want) {
+        int off = s_sp_base;
+        for (int w = 0; w < wave; w++) off += s_want[w];
+        if (off >= 0 && off + want <= a.spill_cap) sp_off = off;   // pool exhausted: the point keeps the grid rescan
+    }
     unsigned long long k[PJ_K];   // the PJ_K smallest keys of the point, ascending; the same in every lane
 #pragma unroll
     for (int s = 0; s < PJ_K; s++) k[s] = ~0ull;
     int total = 0;
     for (int cg = cx0; cg <= cx1; cg += 64) {
-        // lane c holds column cg + c: cells (column, cy0..cy1) are contiguous in the CSR
         const int ncol = min(64, cx1 - cg + 1);
-        int beg = 0, cnt = 0;
-        if (lane < ncol) {
-            beg = g_start[(cg + lane) * SG_ROWS + cy0];
-            cnt = g_start[(cg + lane) * SG_ROWS + cy1 + 1] - beg;
-        }
+        if (cg != cx0) load_columns(cg, ncol);
         const int incl = st_wave_incl_scan(cnt);
         const int excl = incl - cnt;
         const int T = __builtin_amdgcn_readlane(incl, 63);
@@ -498,7 +528,9 @@ __global__ __launch_bounds__(64 * PJ_WAVES) void k_proj_round0_wave(ProjB a)
                     }
                 }
             }
-            total += __popcll(__builtin_amdgcn_ballot_w64(key != ~0ull));
+            const unsigned long long have = __builtin_amdgcn_ballot_w64(key != ~0ull);
+            if (sp_off >= 0 && key != ~0ull) a.spill[sp_off + total + __popcll(have & ((1ull << lane) - 1))] = key;
+            total += __popcll(have);
             // at most PJ_K keys of this batch can enter the list: take the batch's minimum while it beats the list's last
             for (int s = 0; s < PJ_K; s++) {
                 const unsigned long long mk = pj_wave_min_key(key);
@@ -530,11 +562,13 @@ __global__ __launch_bounds__(64 * PJ_WAVES) void k_proj_round0_wave(ProjB a)
     a.live[slot] = (unsigned)iq | (q.obs ? 0x80000000u : 0u);
     a.pick[slot] = pick;
     a.pick_dist[slot] = dist;
+    a.spill_off[slot] = total > PJ_K ? sp_off : -1;
     int e[PJ_K];
 #pragma unroll
     for (int s = 0; s < PJ_K; s++) e[s] = key_entry(k[s]);
-    const int cnt = total < PJ_K ? total : PJ_K;
-    a.cand[2 * slot] = make_uint4((unsigned)cnt | (total > PJ_K ? 0x100u : 0u), (unsigned)e[0], (unsigned)e[1], (unsigned)e[2]);
+    const int ncached = total < PJ_K ? total : PJ_K;
+    // header: cached entries | truncated << 8 | length of the full list << 9 (with spill_off)
+    a.cand[2 * slot] = make_uint4((unsigned)ncached | (total > PJ_K ? 0x100u : 0u) | ((unsigned)total << 9), (unsigned)e[0], (unsigned)e[1], (unsigned)e[2]);
     a.cand[2 * slot + 1] = make_uint4((unsigned)e[3], (unsigned)e[4], (unsigned)e[5], (unsigned)e[6]);
 }
 
@@ -586,18 +620,40 @@ __global__ __launch_bounds__(1024) void k_proj_resolve(ProjB a)
         }
         return !((c0.x & 0x100u) && *e2 < 0);
     };
-    // full re-evaluation of one point from the grid under the current claims
-    auto rescan = [&](int iq, int* e1, int* e2) {
+    // full re-evaluation of live point t (projected point iq) under the current claims: from its full candidate list when round 0
+    // left one (k_proj_round0_wave: the static filters are already applied, what remains is "not claimed by a lower point"),
+    // otherwise from the grid
+    const int* spill_off = a.spill_off + (long long)f * a.m;
+    auto rescan = [&](int t, int iq, unsigned header, int* e1, int* e2) {
         unsigned long long k1 = ~0ull, k2 = ~0ull;
-        const ProjQ q = load_query(a, f, iq);
-        scan_candidates(a, f, n, iq, q, a.cell_start + (long long)f * (NSG + 1), a.cell_xy + (long long)f * a.n_cap,
-                        a.cell_meta + (long long)f * a.n_cap,
-                        [&](int i) { return tab_load(&tab[i]) < iq; },
-                        [&](unsigned long long x) {
-                            const unsigned long long hi = x < k1 ? k1 : x;
-                            k1 = x < k1 ? x : k1;
-                            k2 = hi < k2 ? hi : k2;
-                        });
+        auto two_smallest = [&](unsigned long long x) {
+            const unsigned long long hi = x < k1 ? k1 : x;
+            k1 = x < k1 ? x : k1;
+            k2 = hi < k2 ? hi : k2;
+        };
+        const int so = spill_off[t];
+        if (so >= 0) {
+            const unsigned long long* sp = a.spill + so;
+            const int len = (int)(header >> 9);
+            int j = 0;
+            for (; j + 4 <= len; j += 4) {   // four keys in flight
+                const unsigned long long x0 = sp[j], x1 = sp[j + 1], x2 = sp[j + 2], x3 = sp[j + 3];
+                const int t0 = tab_load(&tab[(x0 >> 7) & 0xFFFFu]), t1 = tab_load(&tab[(x1 >> 7) & 0xFFFFu]),
+                          t2 = tab_load(&tab[(x2 >> 7) & 0xFFFFu]), t3 = tab_load(&tab[(x3 >> 7) & 0xFFFFu]);
+                if (t0 >= iq) two_smallest(x0);
+                if (t1 >= iq) two_smallest(x1);
+                if (t2 >= iq) two_smallest(x2);
+                if (t3 >= iq) two_smallest(x3);
+            }
+            for (; j < len; j++) {
+                const unsigned long long x0 = sp[j];
+                if (tab_load(&tab[(x0 >> 7) & 0xFFFFu]) >= iq) two_smallest(x0);
+            }
+        } else {
+            const ProjQ q = load_query(a, f, iq);
+            scan_candidates(a, f, n, iq, q, a.cell_start + (long long)f * (NSG + 1), a.cell_xy + (long long)f * a.n_cap,
+                            a.cell_meta + (long long)f * a.n_cap, [&](int i) { return tab_load(&tab[i]) < iq; }, two_smallest);
+        }
         *e1 = key_entry(k1);
         *e2 = key_entry(k2);
         fallbacks++;
@@ -639,11 +695,11 @@ __global__ __launch_bounds__(1024) void k_proj_resolve(ProjB a)
             while (redo) {
                 const int r = __builtin_ctz(redo);
                 redo &= redo - 1;
-                unsigned e = lv[0];
+                unsigned e = lv[0], hdr = c0[0].x;
 #pragma unroll
-                for (int r2 = 1; r2 < PJ_RR; r2++) e = r == r2 ? lv[r2] : e;
+                for (int r2 = 1; r2 < PJ_RR; r2++) { e = r == r2 ? lv[r2] : e; hdr = r == r2 ? c0[r2].x : hdr; }
                 int e1, e2, np, nd;
-                rescan((int)(e & 0x7FFFFFFFu), &e1, &e2);
+                rescan(tid + r * 1024, (int)(e & 0x7FFFFFFFu), hdr, &e1, &e2);
                 accept_rule(a, e1, e2, &np, &nd);
 #pragma unroll
                 for (int r2 = 0; r2 < PJ_RR; r2++)
@@ -675,7 +731,8 @@ __global__ __launch_bounds__(1024) void k_proj_resolve(ProjB a)
             for (int t = tid; t < nlive; t += 1024) {
                 const int iq = (int)(live[t] & 0x7FFFFFFFu);
                 int e1, e2, np, nd;
-                if (!from_cache(iq, cand[2 * t], &cand[2 * t + 1], &e1, &e2)) rescan(iq, &e1, &e2);
+                const uint4 c0 = cand[2 * t];
+                if (!from_cache(iq, c0, &cand[2 * t + 1], &e1, &e2)) rescan(t, iq, c0.x, &e1, &e2);
                 accept_rule(a, e1, e2, &np, &nd);
                 if (np != pick[t] || nd != pick_dist[t]) {
                     changed = 1;
@@ -796,11 +853,13 @@ static int pj_reserve(gfo_ctx* c, int frames, int m, int n_cap)
     auto take = [&](size_t bytes) { size_t o = off; off = al256(off + bytes); return o; };
     const size_t o_cs = take(F * (NSG + 1) * 4), o_it = take(F * N * 8), o_me = take(F * N * 4), o_pk = take(F * M * 4),
                  o_pd = take(F * M * 4), o_lv = take(F * M * 4), o_cd = take(F * M * 32), o_rb = take(F * M * 4),
+                 o_so = take(F * M * 4), o_sp = take(8 * (size_t)PJ_SPILL_PER_POINT * (F * M < 16384 ? F * M : 16384)),
                  o_tg = take(F * N * 8), o_ct = take(F * PJ_CNT * 4), o_om = take(F * N * 4), o_os = take(F * N * 4);
     PTRY(c, hipMalloc(&b.base, off));
     uint8_t* S = (uint8_t*)b.base;
     b.cell_start = (int*)(S + o_cs); b.cell_xy = S + o_it; b.cell_meta = (unsigned*)(S + o_me);
     b.pick = (int*)(S + o_pk); b.pick_dist = (int*)(S + o_pd); b.live = (unsigned*)(S + o_lv); b.cand = S + o_cd; b.rot_bin = (int*)(S + o_rb);
+    b.spill_off = (int*)(S + o_so); b.spill = (unsigned long long*)(S + o_sp); b.spill_cap = PJ_SPILL_PER_POINT * (int)(F * M < 16384 ? F * M : 16384);
     b.tab_g = (int*)(S + o_tg); b.counters = (int*)(S + o_ct); b.out_mp = (int*)(S + o_om); b.out_score = (int*)(S + o_os);
     b.frames_cap = (int)F; b.m_cap = (int)M; b.n_cap = (int)N;
     return GFO_OK;
@@ -815,6 +874,11 @@ static void pj_bind(const gfo_ctx* c, ProjB* a)
     a->n_cap = b.n_cap;
     a->cell_start = b.cell_start; a->cell_xy = (float2*)b.cell_xy; a->cell_meta = b.cell_meta;
     a->pick = b.pick; a->pick_dist = b.pick_dist; a->live = b.live; a->cand = (uint4*)b.cand; a->rot_bin = b.rot_bin;
+    a->spill_off = b.spill_off; a->spill = b.spill; a->spill_cap = b.spill_cap;
+    if (const char* e = getenv("GFO_PROJ_SPILL_CAP")) {   // tests: a pool that runs out (read per call)
+        const int cap = atoi(e);
+        if (cap >= 0 && cap < a->spill_cap) a->spill_cap = cap;
+    }
     a->tab_g = b.tab_g; a->counters = b.counters; a->out_mp = b.out_mp; a->out_score = b.out_score;
 }
 

@@ -10,11 +10,15 @@ from conftest import GOLDEN
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(params=["wavefront_per_point", "thread_per_point"], autouse=True)
+@pytest.fixture(params=["wavefront_per_point", "wavefront_per_point_small_pool", "thread_per_point"], autouse=True)
 def round0_form(request, monkeypatch):
     """Round 0 has two forms: k_proj_round0_wave when a call brings at most 16 384 points (the per-frame calls of Tracking), the
-    thread-per-point kernels otherwise.  Every case of this module runs under both (GFO_PROJ_WAVE is read on every call)."""
-    monkeypatch.setenv("GFO_PROJ_WAVE", "1" if request.param == "wavefront_per_point" else "0")
+    thread-per-point kernels otherwise.  Every case of this module runs under both (GFO_PROJ_WAVE is read on every call), and a third
+    time with the wavefront form's pool of full candidate lists cut to 3000 keys, so that some contended points find their list there
+    and the others fall back to the grid rescan inside one resolve."""
+    monkeypatch.setenv("GFO_PROJ_WAVE", "0" if request.param == "thread_per_point" else "1")
+    if request.param == "wavefront_per_point_small_pool":
+        monkeypatch.setenv("GFO_PROJ_SPILL_CAP", "3000")
     return request.param
 
 
@@ -80,6 +84,38 @@ def test_contended_maps(ext, oracle, seed, m, th, ratio):
     np.testing.assert_array_equal(got[1], ref[1])
     np.testing.assert_array_equal(got[2], ref[2])
     assert ref[0] > 100
+
+
+@pytest.mark.parametrize("seed,m,th", [(1, 3000, 3.0), (3, 10000, 3.0), (4, 2000, 5.0), (5, 16000, 1.0)])
+def test_every_point_blocking_with_wide_windows(ext, oracle, seed, m, th):
+    """The scenario of tools/matcher_call_latency.py: every map point has observations (so every accepted match blocks), imitates a
+    random keypoint and projects within a few pixels of it, several points per keypoint, th = 3 / 5 windows.  Hundreds to thousands of
+    points find their seven cached candidates all claimed by lower points (690 of 3000 at th 3) and go to their full candidate list --
+    the spill list k_proj_round0_wave leaves, or the grid rescan when there is none (the other two forms of this module's fixture)."""
+    import gf_orb_slam2_amd as G
+    kl, dl, _ = _frame(oracle)
+    rng = np.random.default_rng(seed)
+    n = len(kl)
+    mps = np.zeros(m, oracle.MAP_POINT_DTYPE)
+    src = rng.integers(0, n, m)
+    mpd = dl[src].copy()
+    fl = rng.integers(0, 256, (m, 8))
+    for j in range(8):
+        mpd[np.arange(m), fl[:, j] >> 3] ^= (1 << (fl[:, j] & 7)).astype(np.uint8)
+    mps["proj_x"] = kl["x"][src] + rng.normal(0, 2, m)
+    mps["proj_y"] = kl["y"][src] + rng.normal(0, 2, m)
+    mps["proj_xr"] = mps["proj_x"] - 5
+    mps["level"] = kl["octave"][src]
+    mps["view_cos"] = 1.0
+    mps["flags"] = 1 | 4
+    u = np.full(n, -1, np.float32)
+    bounds = (0.0, 0.0, 752.0, 480.0)
+    sf = ext.GetScaleFactors()
+    ref = oracle.search_by_projection(kl, dl, u, sf, bounds, mps, mpd, th, 0.8)
+    got = G.ORBmatcher(0.8, True, extractor=ext).SearchByProjection(kl, dl, u, sf, bounds, mps, mpd, th, None)
+    assert got[0] == ref[0] and ref[0] > 1000
+    np.testing.assert_array_equal(got[1], ref[1])
+    np.testing.assert_array_equal(got[2], ref[2])
 
 
 def test_projection_edge_cases(ext, oracle):
