@@ -36,6 +36,8 @@
 #include <new>
 #include <string>
 #include <thread>
+#include <chrono>
+#include <algorithm>
 #include <vector>
 
 #include "gfo.h"
@@ -63,6 +65,22 @@ static FILE* g_rep = NULL;
     } while (0)
 
 static void report(const char* key, long long v) { fprintf(g_rep, "%s %lld\n", key, v); fflush(g_rep); }
+
+// median wall time of `call` over `reps` runs, in microseconds (`reset` puts the objects back before every run, untimed)
+template <class Reset, class Call>
+static long long median_us(int reps, Reset reset, Call call)
+{
+    std::vector<double> t;
+    for (int i = 0; i < reps + 3; i++) {
+        reset();
+        const std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+        call();
+        const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+        if (i >= 3) t.push_back(us);
+    }
+    std::sort(t.begin(), t.end());
+    return (long long)(t[t.size() / 2] + 0.5);
+}
 
 static void dump(const std::string& name, const void* p, size_t bytes)
 {
@@ -443,6 +461,11 @@ int main(int argc, char** argv)
             dump("E_out_score.bin", F.mvpMatchScore.data(), F.mvpMatchScore.size() * 4);
             int32_t n32 = nm;
             dump("E_nmatches.bin", &n32, 4);
+            // what the call costs through the adapter (flattening M MapPoint objects, the library call, writing the slots back)
+            const std::vector<MapPoint*> after = F.mvpMapPoints;
+            report("E_map_points", M);
+            report("E_SearchByProjection_F_MapPoints_us", median_us(20, [&]() { F.mvpMapPoints = before; }, [&]() { matcher.SearchByProjection(F, map, 3); }));
+            F.mvpMapPoints = after;
         }
     }
 
@@ -497,6 +520,13 @@ int main(int argc, char** argv)
             dump(std::string(pre) + "_out_last_idx.bin", idx.data(), idx.size() * 4);
             int32_t two[2] = {nm, (int32_t)visible};
             dump(std::string(pre) + "_nmatches_visible.bin", two, 8);
+            if (v == 0) {
+                const std::vector<MapPoint*> after = Cur.mvpMapPoints;
+                report("F_SearchByProjection_Cur_Last_us",
+                       median_us(20, [&]() { Cur.mvpMapPoints.assign(Cur.N, static_cast<MapPoint*>(NULL)); },
+                                 [&]() { double vis = 0; matcher.SearchByProjection(Cur, Last, th, false, vis); }));
+                Cur.mvpMapPoints = after;
+            }
         }
         delete CurP;
     }
@@ -599,6 +629,10 @@ int main(int argc, char** argv)
                     dump(ori ? "I_out_kf_idx_ori.bin" : "I_out_kf_idx.bin", idx.data(), idx.size() * 4);
                     int32_t n32 = nm;
                     dump(ori ? "I_nmatches_ori.bin" : "I_nmatches.bin", &n32, 4);
+                    if (ori) {
+                        report("I_common_or_not_nodes_kf", (long long)kf.mFeatVec.size());
+                        report("I_SearchByBoW_us", median_us(20, []() {}, [&]() { std::vector<MapPoint*> mm; matcher.SearchByBoW(&kf, F, mm); }));
+                    }
                 }
                 delete FP;
             }
@@ -645,6 +679,12 @@ int main(int argc, char** argv)
         dump(std::string(pre) + "_fv_nodes.bin", fn.data(), fn.size() * 4);
         dump(std::string(pre) + "_fv_start.bin", fs.data(), fs.size() * 4);
         dump(std::string(pre) + "_fv_items.bin", fi.data(), fi.size() * 4);
+        if (v == 0) {
+            DBoW2::BowVector bvec = F.mBowVec;
+            DBoW2::FeatureVector fvec = F.mFeatVec;
+            report("J_ComputeBoW_us", median_us(20, [&]() { F.mBowVec.clear(); F.mFeatVec.clear(); }, [&]() { F.ComputeBoW(); }));
+            CHECK(F.mBowVec == bvec && F.mFeatVec == fvec, "J0: a repeated ComputeBoW gave other vectors");
+        }
         delete FP;
     }
 
