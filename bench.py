@@ -19,14 +19,15 @@ reported in the same line under "other_configs".
 The steps alternate between a few independent contexts (arena + HIP stream; CONTEXTS per workload), for stereo752 two of
 them chained behind each other's pyramid (gfo_ctx_chain).  Setup ends with PRIME_STEPS untimed batches (clock ramp of a
 fresh process, config.priming_steps); --warmup is run as given, untimed, directly in front of the timed steps.
-roofline.traffic: with --live-traffic it is measured in the run itself (N = 1): two short child passes of this command
-under `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` before the process initialises the GPU (live_traffic()); without
-it (the default since round 3: two such passes stalled in round 2 and the cause was never established)
-it is the committed summary of the latest such measurement of this command, profiles/traffic_latest.json, labelled as such.
+roofline.traffic: measured in the run itself at N = 1 (two short child passes of this command under `rocprofv3 --pmc
+FETCH_SIZE` / `--pmc WRITE_SIZE`, started before the process initialises the GPU and bounded at 75 s each: live_traffic());
+--no-live-traffic (and every spawned rank, and a run under a profiler) takes the committed summary of the latest such
+measurement instead, profiles/traffic_latest.json, and says so (`traffic_measured: false`).
 Beside `value` (inputs and results resident in HBM) the line carries `value_with_h2d` (every step's batch copied in from
 pinned host memory), `value_delivered` (copied in AND every result -- counts, keypoints, descriptors, stereo outputs --
-landed in pinned host memory: gfo_batch_deliver) and `per_frame_boundary` (the reference's own call pattern, one stereo
-frame per call from K host threads through the C ABI: tools/c/boundary_throughput.c).
+landed in pinned host memory: gfo_batch_deliver), `per_frame_boundary` (the reference's own call pattern, one stereo
+frame per call from K host threads through the C ABI: tools/c/boundary_throughput.c) and `matcher_calls` (ms per call of the
+host-array matcher calls Tracking makes per frame: tools/matcher_call_latency.py).
 """
 import argparse
 import ctypes
@@ -251,6 +252,24 @@ def per_frame_boundary(seconds=1.0):
         best = max((p for p in pts if p["path"] == "gfo_extract_stereo"), key=lambda p: p["images_per_s"])
         return {"workload": j["workload"], "unit": "images/s", "harness": "tools/c/boundary_throughput.c (C, dlopen of libgfo.so, no Python in the loop)",
                 "seconds_per_point": seconds, "best_images_per_s": best["images_per_s"], "best_at_streams": best["streams"], "points": pts}
+    except Exception as ex:      # a failing side measurement must not lose the headline line
+        return {"error": repr(ex)}
+
+
+def matcher_calls():
+    """The matcher calls Tracking makes on every frame, caller arrays in and out, ms per call (tools/matcher_call_latency.py as a
+    child process: SearchByProjection(F, MapPoints) for three map sizes, SearchByProjection(Cur, Last), ComputeBoW, SearchByBoW on the
+    EuRoC frame).  A side measurement like per_frame_boundary: never the metric."""
+    import subprocess
+    try:
+        env = dict(os.environ, JSON="1")
+        for k in ("TH", "ONLY", "GFO_PROJ_STATS"):
+            env.pop(k, None)
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "matcher_call_latency.py")], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL,
+                           timeout=180, env=env, cwd=ROOT)
+        if r.returncode != 0:
+            return {"error": f"tools/matcher_call_latency.py rc {r.returncode}"}
+        return json.loads(r.stdout.decode(errors="replace").strip().splitlines()[-1])
     except Exception as ex:      # a failing side measurement must not lose the headline line
         return {"error": repr(ex)}
 
@@ -1018,6 +1037,7 @@ def main():
 
     if rank == 0 and world == 1 and not args.no_boundary and not under_profiler():
         line["per_frame_boundary"] = per_frame_boundary()
+        line["matcher_calls"] = matcher_calls()
     if rank == 0:
         if not args.no_cpu_baseline and world == 1:
             w, h, nfeat, matcher, _ = WORKLOADS[args.workload]

@@ -98,3 +98,37 @@ def synth_local_map(kp0, desc0, offs, w, h, m=50000, n_vis=4000, seed=7, nlevels
         p["view_cos"] = 1.0
         p["flags"] = 5
     return mpd, mps
+
+
+def synth_vocabulary(k=10, depth=4, seed=0):
+    """A full k-ary vocabulary tree of the given depth in the flattened form ORBVocabulary takes (breadth first, the children of a node
+    contiguous, leaves = words numbered in tree order): node descriptors are their parent's with 128 >> level random bits flipped, word
+    weights the logarithms DBoW2 stores (double) -- the SHAPE of ORBvoc (k = 10, L = 6; that file is not in the reference repository),
+    not its content.  For bench.py and tools/matcher_call_latency.py; the parity tests use the oracle's ragged generator."""
+    rng = np.random.default_rng(seed)
+    first, nch, desc = [], [], [np.zeros((1, 32), np.uint8)]
+    level_start, n_level = 0, 1
+    for lvl in range(depth + 1):
+        if lvl < depth:
+            first.append(level_start + n_level + k * np.arange(n_level, dtype=np.int32))
+            nch.append(np.full(n_level, k, np.int32))
+            child = np.repeat(desc[-1], k, axis=0)
+            nflip = max(1, 128 >> lvl)
+            bits = rng.integers(0, 256, (len(child), nflip))
+            for j in range(nflip):
+                child[np.arange(len(child)), bits[:, j] >> 3] ^= (1 << (bits[:, j] & 7)).astype(np.uint8)
+            desc.append(child)
+        else:
+            first.append(np.zeros(n_level, np.int32))
+            nch.append(np.zeros(n_level, np.int32))
+        level_start += n_level
+        n_level *= k
+    first, nch, desc = np.concatenate(first), np.concatenate(nch), np.concatenate(desc)
+    n = len(first)
+    leaves = np.nonzero(nch == 0)[0]
+    word = np.full(n, -1, np.int32)
+    word[leaves] = np.arange(len(leaves), dtype=np.int32)
+    w64 = np.zeros(n, np.float64)
+    w64[leaves] = np.log(rng.uniform(1.1, 400.0, len(leaves)))
+    return {"first_child": first, "n_children": nch, "descriptors": desc, "word_id": word, "weight": w64.astype(np.float32), "weight64": w64,
+            "depth": depth}

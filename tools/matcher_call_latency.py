@@ -1,8 +1,11 @@
-"""Per-call latency of the host-array matcher calls Tracking makes on every frame (caller arrays in, caller arrays out, one
+"""(No oracle in here: bench.py runs this file as a child for its `matcher_calls` block.)
+Per-call latency of the host-array matcher calls Tracking makes on every frame (caller arrays in, caller arrays out, one
 synchronisation): SearchByProjection(F, local map) for several map sizes, SearchByProjection(Cur, Last), SearchByBoW(KF, F),
 ComputeBoW(F) -- on the EuRoC frame (2008 keypoints).  Every map point here imitates a random keypoint (8 flipped bits, N(0,2) px
 away), so with M > N several points COMPETE for one keypoint: the ordered resolve runs its worst case, not a typical local map.
-usage (through gpurun): [TH=1|3|5] python tools/matcher_call_latency.py [M ...]     (GFO_PROJ_STATS=1 prints rounds / fallbacks per call)"""
+usage (through gpurun): [TH=1|3|5] [ONLY=map|last|cbow|bow] [JSON=1] python tools/matcher_call_latency.py [M ...]     (GFO_PROJ_STATS=1 prints
+rounds / fallbacks per call; JSON=1: one JSON object on stdout instead of the text lines)"""
+import json
 import os
 import sys
 import time
@@ -11,9 +14,17 @@ import numpy as np
 
 sys.path.insert(0, ".")
 import gf_orb_slam2_amd as G
-from oracle import orb_oracle as O
+from gf_orb_slam2_amd.synth import synth_vocabulary
 
-O.build()
+JSON = os.environ.get("JSON") == "1"
+out = {"frame": "EuRoC_l 752x480, extractor (2000, 1.2, 8, 20, 7)", "unit": "ms per call, median of 50", "calls": []}
+
+
+def say(name, ms, detail, text):
+    out["calls"].append(dict({"call": name, "ms": round(float(ms), 4)}, **detail))
+    if not JSON:
+        print(text, flush=True)
+
 img = np.fromfile("tests/golden/EuRoC_l_752x480.u8", np.uint8).reshape(480, 752)
 ext = G.ORBextractor(2000, 1.2, 8, 20, 7)
 kp, desc = ext(img)
@@ -47,7 +58,7 @@ def median_ms(call, reps=50):
 
 
 for M in ([int(a) for a in sys.argv[1:]] or (1000, 2000, 4000)) if ONLY in ("", "map") else ():
-    mps = np.zeros(M, O.MAP_POINT_DTYPE)
+    mps = np.zeros(M, G.MAP_POINT_DTYPE)
     src = rng.integers(0, n, M)
     mpd = flipped(desc[src], 8)
     mps["proj_x"] = kp["x"][src] + rng.normal(0, 2, M)
@@ -57,12 +68,13 @@ for M in ([int(a) for a in sys.argv[1:]] or (1000, 2000, 4000)) if ONLY in ("", 
     mps["view_cos"] = 1.0
     mps["flags"] = 1 | 4
     ms, r = median_ms(lambda: m.SearchByProjection(kp, desc, u_right, sf, bounds, mps, mpd, TH, None))
-    print(f"SearchByProjection(F, {M} map points, th {TH:g}), {n} keypoints: median {ms:.3f} ms, {r[0]} matches", flush=True)
+    say("SearchByProjection(F, MapPoints)", ms, {"map_points": M, "th": TH, "keypoints": n, "matches": int(r[0])},
+        f"SearchByProjection(F, {M} map points, th {TH:g}), {n} keypoints: median {ms:.3f} ms, {r[0]} matches")
 
 # SearchByProjection(CurrentFrame, LastFrame, th = 7 mono / 15 stereo): one query per tracked point of the last frame (ORBmatcher.cc:1440-1593)
 nq = 1500
 src = rng.choice(n, nq, replace=False)
-q = np.zeros(nq, O.PROJ_QUERY_DTYPE)
+q = np.zeros(nq, G.PROJ_QUERY_DTYPE)
 q["u"] = kp["x"][src] + rng.normal(0, 2, nq)
 q["v"] = kp["y"][src] + rng.normal(0, 2, nq)
 q["ur"] = q["u"] - 5
@@ -74,23 +86,30 @@ q["flags"] = 1 | 4
 qd = flipped(desc[src], 8)
 if ONLY in ("", "last"):
     ms, r = median_ms(lambda: m.SearchByProjectionQueries(kp, desc, u_right, kp["angle"].copy(), bounds, q, qd))
-    print(f"SearchByProjection(Cur, Last): {nq} tracked points, th 7, rotation check: median {ms:.3f} ms, {r[0]} matches", flush=True)
+    say("SearchByProjection(Cur, Last)", ms, {"tracked_points": nq, "th": 7, "keypoints": n, "matches": int(r[0])},
+        f"SearchByProjection(Cur, Last): {nq} tracked points, th 7, rotation check: median {ms:.3f} ms, {r[0]} matches")
 
 if ONLY not in ("", "cbow", "bow"):
     ext.close()
+    if JSON:
+        print(json.dumps(out), flush=True)
     sys.exit(0)
 # Frame::ComputeBoW and SearchByBoW(KF, F): a random 10-ary, 4-level vocabulary (the ORBvoc shape is 10^6 leaves; the tree is not in the repo)
-voc = O.make_vocabulary(10, 4, seed=0, p_stop=0.0)
+voc = synth_vocabulary(10, 4, seed=0)
 V = G.ORBVocabulary(voc, ext)
 fd = flipped(desc, 6)
 ms, r = median_ms(lambda: V.compute_bow(desc, 2, "TF_IDF", "L1"), 50 if ONLY in ("", "cbow") else 1)
 (bw, bv), kfv = r
 if ONLY in ("", "cbow"):
-    print(f"ComputeBoW({n} descriptors, k=10 L=4, levelsup 2): median {ms:.3f} ms, {len(bw)} words, {len(kfv[0])} feature-vector nodes", flush=True)
+    say("ComputeBoW", ms, {"descriptors": n, "k": 10, "L": 4, "levelsup": 2, "words": len(bw), "feature_vector_nodes": len(kfv[0])},
+        f"ComputeBoW({n} descriptors, k=10 L=4, levelsup 2): median {ms:.3f} ms, {len(bw)} words, {len(kfv[0])} feature-vector nodes")
 ffv = V.compute_bow(fd, 2, "TF_IDF", "L1")[1]
 valid = np.ones(n, np.uint8)
 mb = G.ORBmatcher(0.7, True, extractor=ext)
 if ONLY in ("", "bow"):
     ms, r = median_ms(lambda: mb.SearchByBoW(desc, kp["angle"].copy(), valid, kfv, fd, kp["angle"].copy(), ffv))
-    print(f"SearchByBoW(KF, F): {n} x {n} keypoints over {len(kfv[0])} nodes: median {ms:.3f} ms, {r[0]} matches", flush=True)
+    say("SearchByBoW(KF, F)", ms, {"keypoints": n, "nodes": len(kfv[0]), "matches": int(r[0])},
+        f"SearchByBoW(KF, F): {n} x {n} keypoints over {len(kfv[0])} nodes: median {ms:.3f} ms, {r[0]} matches")
 ext.close()
+if JSON:
+    print(json.dumps(out), flush=True)
