@@ -38,7 +38,7 @@ struct BowArgs {
 
 // A node with more frame keypoints than the lanes' registers hold (> 64 * BOW_R): every keyframe keypoint sweeps the node's frame
 // keypoints from memory, `out` carries the taken state (this wave is its only writer: same-wave program order + the fence below).
-__device__ __noinline__ void bow_node_sweep(const BowArgs& a, int kb, int ke, int fb, int fe, int lane)
+__device__ __forceinline__ void bow_node_sweep(const BowArgs& a, int kb, int ke, int fb, int fe, int lane)
 {
     const float factor = 1.0f / HISTO_LENGTH;  // :284 (applied to degrees, as the reference does)
     int accepted = 0;

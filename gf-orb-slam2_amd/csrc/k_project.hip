@@ -663,14 +663,14 @@ __global__ __launch_bounds__(1024) void k_proj_resolve(ProjB a)
         // registers for all the rounds, so a round is LDS traffic and three barriers; walking the live arrays in device memory
         // every round made a lone call's resolve a chain of ~1 us loads (6 rounds over 1721 points: 44 us).
         unsigned lv[PJ_RR];
-        int pk[PJ_RR], pd[PJ_RR];
+        int pk[PJ_RR];     // (the pick's distance is a function of the pick: it goes to pick_dist[] when the pick changes, not in a register)
         uint4 c0[PJ_RR];   // header + the first three candidates; the other four stay in memory (from_cache)
 #pragma unroll
         for (int r = 0; r < PJ_RR; r++) {
             const int t = tid + r * 1024;
-            lv[r] = 0; pk[r] = -1; pd[r] = 256;
+            lv[r] = 0; pk[r] = -1;
             c0[r] = make_uint4(0, 0, 0, 0);
-            if (t < nlive) { lv[r] = live[t]; pk[r] = pick[t]; pd[r] = pick_dist[t]; c0[r] = cand[2 * t]; }
+            if (t < nlive) { lv[r] = live[t]; pk[r] = pick[t]; c0[r] = cand[2 * t]; }
         }
         for (;;) {
             rounds++;
@@ -688,7 +688,7 @@ __global__ __launch_bounds__(1024) void k_proj_resolve(ProjB a)
                     int e1, e2, np, nd;
                     if (from_cache((int)(lv[r] & 0x7FFFFFFFu), c0[r], &cand[2 * (tid + r * 1024) + 1], &e1, &e2)) {
                         accept_rule(a, e1, e2, &np, &nd);
-                        if (np != pk[r] || nd != pd[r]) { changed = 1; pk[r] = np; pd[r] = nd; }
+                        if (np != pk[r]) { changed = 1; pk[r] = np; pick_dist[tid + r * 1024] = nd; }
                     } else redo |= 1u << r;
                 }
             }
@@ -703,7 +703,7 @@ __global__ __launch_bounds__(1024) void k_proj_resolve(ProjB a)
                 accept_rule(a, e1, e2, &np, &nd);
 #pragma unroll
                 for (int r2 = 0; r2 < PJ_RR; r2++)
-                    if (r == r2 && (np != pk[r2] || nd != pd[r2])) { changed = 1; pk[r2] = np; pd[r2] = nd; }
+                    if (r == r2 && np != pk[r2]) { changed = 1; pk[r2] = np; pick_dist[tid + r2 * 1024] = nd; }
             }
             if (!__syncthreads_or(changed)) break;
             if (rounds > nlive + 1) {   // cannot happen (point i is final after rank(i) rounds); never spin
@@ -714,7 +714,7 @@ __global__ __launch_bounds__(1024) void k_proj_resolve(ProjB a)
 #pragma unroll
         for (int r = 0; r < PJ_RR; r++) {   // the epilogue below reads them back with the same thread
             const int t = tid + r * 1024;
-            if (t < nlive) { pick[t] = pk[r]; pick_dist[t] = pd[r]; }
+            if (t < nlive) pick[t] = pk[r];
         }
     } else if (nlive > 0) {
         for (;;) {
