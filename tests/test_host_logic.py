@@ -234,3 +234,26 @@ def test_combiner_under_thread_sanitizer(tmp_path):
     assert r.returncode == 0, r.stderr[-3000:]
     frames = int(r.stdout.split("ok:")[1].split()[0])
     assert frames >= 50000, r.stdout
+
+
+def test_synthetic_vocabulary_has_the_flattened_form_the_library_takes():
+    """synth_vocabulary (bench.py's matcher_calls, tools/matcher_call_latency.py): breadth first, the children of a node one contiguous
+    range BEHIND it (what gfo_vocabulary_upload checks), leaves = words numbered in tree order, every leaf at the stated depth; and the
+    oracle's descent over it ends in a leaf for any descriptor (the same tree both sides walk in the GPU tests)."""
+    from gf_orb_slam2_amd.synth import synth_vocabulary
+    from oracle import orb_oracle as O
+    O.build()
+    v = synth_vocabulary(5, 3, seed=2)
+    n = len(v["first_child"])
+    assert n == 1 + 5 + 25 + 125 and v["depth"] == 3
+    inner = v["n_children"] > 0
+    assert (v["n_children"][inner] == 5).all() and (v["first_child"][inner] > np.nonzero(inner)[0]).all()
+    kids = np.concatenate([np.arange(f, f + c) for f, c in zip(v["first_child"][inner], v["n_children"][inner])])
+    assert sorted(kids.tolist()) == list(range(1, n))                         # every node but the root is the child of exactly one node
+    leaves = np.nonzero(~inner)[0]
+    assert (v["word_id"][leaves] == np.arange(len(leaves))).all() and (v["word_id"][inner] == -1).all()
+    assert (v["weight64"][leaves] > 0).all() and v["descriptors"].shape == (n, 32) and v["descriptors"].dtype == np.uint8
+    rng = np.random.default_rng(0)
+    desc = rng.integers(0, 256, (40, 32), dtype=np.uint8)
+    word, weight, node = O.bow_transform(v, desc, levelsup=1)
+    assert ((word >= 0) & (word < len(leaves))).all() and (node >= 1).all()
