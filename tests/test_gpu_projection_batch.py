@@ -59,9 +59,12 @@ def test_batch_of_1080p_frames_against_50k_map(oracle):
     ext.close()
 
 
-def test_stereo_chain_feeds_the_projection(oracle):
+@pytest.mark.parametrize("M", [12000, 3500])
+def test_stereo_chain_feeds_the_projection(oracle, M):
     """extract (L, R interleaved) -> stereo association -> projection search with mvuRight gating (:201-206) and
-    keypoints taken on entry, contended map (blocking and non-blocking points mixed)"""
+    keypoints taken on entry, contended map (blocking and non-blocking points mixed).  M = 3500: 4 frames x 3500 points is a call of
+    at most 16 384 points, so round 0 is the wavefront-per-point kernel with several frames in one launch (one candidate-list pool for
+    all of them); M = 12 000: the thread-per-point kernels."""
     import torch
     import gf_orb_slam2_amd as G
     from gf_orb_slam2_amd.synth import synth_stereo_pair
@@ -75,7 +78,6 @@ def test_stereo_chain_feeds_the_projection(oracle):
     sp = G.StereoParams(h, BF, BF / FX, 0.0)
     m.stereo_match_batch(sp)
     cap = ext.max_keypoints()
-    M = 12000
     rng = np.random.default_rng(5)
     kd = [ext.batch_fetch(2 * p) for p in range(P)]
     ur = [m.stereo_fetch(p, cap)[1] for p in range(P)]
