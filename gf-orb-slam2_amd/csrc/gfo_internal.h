@@ -8,6 +8,7 @@
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include <string.h>
 #include <memory>
 #include <string>
@@ -348,6 +349,13 @@ struct GfoXfer {
     }
     hipError_t down(const void* d_src, size_t bytes, hipStream_t st) const { return hipMemcpyAsync(HO, d_src, bytes, hipMemcpyDeviceToHost, st); }
 };
+// host-array matcher calls: the last kernel of a call writes the answer into the pinned block itself (1, default) or the block is filled
+// by a copy behind it (GFO_MATCHER_HOST_WRITES=0; same-box A/B in profiles/matcher_call_latency_r05.txt)
+inline bool gfo_matcher_host_writes()
+{
+    static const bool on = !(getenv("GFO_MATCHER_HOST_WRITES") && atoi(getenv("GFO_MATCHER_HOST_WRITES")) == 0);
+    return on;
+}
 void gfo_launch_pack_cut(gfo_ctx* c, const GfoPack& p, hipStream_t st);   // k_pack_results with the stereo cut in it (GfoPack::cut_pairs)
 int gfo_stereo_window(const float* scale, int nlevels);
 void gfo_launch_stereo_sad(gfo_ctx* c, const GfoStereoLaunch& s, const GfoInput& in, const float* d_inv_scale);

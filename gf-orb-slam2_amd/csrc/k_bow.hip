@@ -34,6 +34,8 @@ struct BowArgs {
     int* out;                  // [n_f] keyframe keypoint index or -1
     int* rot_bin;              // [n_f]
     int* counters;             // [0] nmatches
+    int* h_out;                // host-visible pinned copies of `out` / counters[0], written by k_bow_rotation (null: copied back)
+    int* h_count;
 };
 
 // A node with more frame keypoints than the lanes' registers hold (> 64 * BOW_R): every keyframe keypoint sweeps the node's frame
@@ -227,14 +229,19 @@ __global__ __launch_bounds__(256) void k_bow_rotation(BowArgs a)
     int drop = 0;
     for (int i = tid; i < a.n_f; i += 256) {
         const int b = a.rot_bin[i];
+        int o = a.out[i];
         if (b >= 0 && b != keep[0] && b != keep[1] && b != keep[2]) {
-            a.out[i] = -1;
+            a.out[i] = o = -1;
             drop++;
         }
+        if (a.h_out) a.h_out[i] = o;   // the call's answer, straight into the caller-side pinned block
     }
     if (drop) atomicAdd(&s_drop, drop);
     __syncthreads();
-    if (tid == 0) a.counters[0] -= s_drop;
+    if (tid == 0) {
+        a.counters[0] -= s_drop;
+        if (a.h_count) *a.h_count = a.counters[0];
+    }
 }
 
 #define BTRY(c, expr)                                                                             \
@@ -320,14 +327,18 @@ extern "C" int gfo_search_by_bow(gfo_ctx* c, const uint8_t* kf_desc, const float
     a.pairs = (const int2*)(S + o_pr); a.npairs = (int)pairs.size();
     a.n_f = n_f; a.nn_ratio = nn_ratio; a.check_ori = check_orientation ? 1 : 0;
     a.out = (int*)(S + o_out); a.rot_bin = (int*)(S + o_rb); a.counters = (int*)(S + o_cnt);
+    if (int rc = x.out(o_cnt + 16 - o_out)) return rc;
+    // with the rotation check its kernel is the last one and writes the answer into the pinned block itself; without it, one copy back
+    // (out and the counters are neighbours in the scratch)
+    const bool direct = a.check_ori && gfo_matcher_host_writes();
+    if (direct) { a.h_out = (int*)x.HO; a.h_count = (int*)(x.HO + (o_cnt - o_out)); }
     gfo_prof_begin(c, ST_BOW);
     GFO_LAUNCH(c, k_bow_match, dim3((a.npairs + 3) / 4), dim3(256), 0, st, a);
     if (a.check_ori) GFO_LAUNCH(c, k_bow_rotation, dim3(1), dim3(256), 0, st, a);
     gfo_prof_end(c);
     if (int lrc = gfo_take_launch_err(c)) return lrc;
     BTRY(c, hipGetLastError());
-    if (int rc = x.out(o_cnt + 16 - o_out)) return rc;
-    BTRY(c, x.down(S + o_out, o_cnt + 16 - o_out, st));   // out and the counters are neighbours in the scratch
+    if (!direct) BTRY(c, x.down(S + o_out, o_cnt + 16 - o_out, st));
     BTRY(c, hipStreamSynchronize(st));
     memcpy(out_kf_idx, x.HO, 4 * (size_t)n_f);
     *nmatches = reinterpret_cast<const int*>(x.HO + (o_cnt - o_out))[0];
@@ -401,6 +412,8 @@ struct BowFold {
     int weighting, norm;
     unsigned* bow_words; double* bow_values; unsigned* fv_nodes; int* fv_start; unsigned* fv_items; int* counts;   // counts[0] words, [1] fv nodes
     unsigned long long* gkey; int* gflag;   // k_bow_fold<true>: the sort keys and marks in device memory (more than 8192 descriptors)
+    // k_bow_fold<false>: the answer ALSO goes straight into the caller-side pinned block (null: copied back after the kernel)
+    unsigned* h_bow_words; double* h_bow_values; unsigned* h_fv_nodes; int* h_fv_start; unsigned* h_fv_items; int* h_counts;
 };
 
 // compare-exchange of the bitonic network for the element at index i: keeps the smaller key when the element is the lower one of an
@@ -533,15 +546,21 @@ __global__ __launch_bounds__(1024) void k_bow_fold(BowFold a, int p2)
     const int nseg = bow_scan(flag, n, part, tid);
     if (!bow_side) {
         // ---- FeatureVector ----
+        const bool host = !GMEM && a.h_fv_items;
         for (int i = tid; i < nvalid; i += 1024) {
             const unsigned long long k = lds_key[i];
             a.fv_items[i] = (unsigned)(k & 0x7FFFFFFFu);
+            if (host) a.h_fv_items[i] = (unsigned)(k & 0x7FFFFFFFu);
             if (k & 0x80000000ull) {
                 a.fv_nodes[flag[i]] = (unsigned)(k >> 32);
                 a.fv_start[flag[i]] = i;
+                if (host) { a.h_fv_nodes[flag[i]] = (unsigned)(k >> 32); a.h_fv_start[flag[i]] = i; }
             }
         }
-        if (tid == 0) { a.fv_start[nseg] = nvalid; a.counts[1] = nseg; }
+        if (tid == 0) {
+            a.fv_start[nseg] = nvalid; a.counts[1] = nseg;
+            if (host) { a.h_fv_start[nseg] = nvalid; a.h_counts[1] = nseg; }
+        }
         return;
     }
     // ---- BowVector: one thread per word walks its features in order ----
@@ -580,6 +599,7 @@ __global__ __launch_bounds__(1024) void k_bow_fold(BowFold a, int p2)
                 if (k & 0x80000000ull) {
                     slot[t] = flag[i];
                     a.bow_words[slot[t]] = (unsigned)(k >> 32);
+                    if (a.h_bow_words) a.h_bow_words[slot[t]] = (unsigned)(k >> 32);
                     v[t] = word_value(i, k);
                 }
             }
@@ -626,8 +646,15 @@ __global__ __launch_bounds__(1024) void k_bow_fold(BowFold a, int p2)
         divide = scale > 0.0;
     }
     if (!GMEM || divide)
-        for (int k = tid; k < nwords; k += 1024) a.bow_values[k] = divide ? vals[k] / scale : vals[k];
-    if (tid == 0) a.counts[0] = nwords;
+        for (int k = tid; k < nwords; k += 1024) {
+            const double v = divide ? vals[k] / scale : vals[k];
+            a.bow_values[k] = v;
+            if (!GMEM && a.h_bow_values) a.h_bow_values[k] = v;
+        }
+    if (tid == 0) {
+        a.counts[0] = nwords;
+        if (!GMEM && a.h_counts) a.h_counts[0] = nwords;
+    }
 }
 
 extern "C" int gfo_vocabulary_upload(gfo_ctx* c, const gfo_vocabulary* voc)
@@ -775,9 +802,16 @@ extern "C" int gfo_compute_bow(gfo_ctx* c, const uint8_t* desc, int n, int level
     gfo_prof_begin(c, ST_BOW);
     GFO_LAUNCH(c, k_bow_transform, dim3((n + 3) / 4), dim3(256), 0, st, v, S + o_d, n, levelsup, (int*)(S + o_w), (float*)nullptr,
                        (int*)(S + o_n), (double*)(S + o_wt));
+    // the two vectors and the counters are neighbours in the scratch (o_bw .. o_ct); the pinned block has the same layout.  Up to 8192
+    // descriptors the fold writes its answer there itself; beyond (keys in device memory) one copy back instead of six.
+    const size_t out_bytes = o_ct + 16 - o_bw;
+    if (int rc = x.out(out_bytes)) return rc;
+    const bool direct = !gmem && gfo_matcher_host_writes();
+    auto twin = [&](size_t o) { return direct ? x.HO + (o - o_bw) : (uint8_t*)nullptr; };   // the pinned twin of S + o
     BowFold f{(const int*)(S + o_w), (const double*)(S + o_wt), (const int*)(S + o_n), n, mode->weighting, mode->norm,
               (unsigned*)(S + o_bw), (double*)(S + o_bv), (unsigned*)(S + o_fn), (int*)(S + o_fs), (unsigned*)(S + o_fi), (int*)(S + o_ct),
-              gmem ? (unsigned long long*)(S + o_gk) : nullptr, gmem ? (int*)(S + o_gf) : nullptr};
+              gmem ? (unsigned long long*)(S + o_gk) : nullptr, gmem ? (int*)(S + o_gf) : nullptr,
+              (unsigned*)twin(o_bw), (double*)twin(o_bv), (unsigned*)twin(o_fn), (int*)twin(o_fs), (unsigned*)twin(o_fi), (int*)twin(o_ct)};
     if (gmem) {
         GFO_LAUNCH(c, k_bow_fold<true>, dim3(2), dim3(1024), 0, st, f, p2);
     } else {
@@ -789,10 +823,7 @@ extern "C" int gfo_compute_bow(gfo_ctx* c, const uint8_t* desc, int n, int level
     gfo_prof_end(c);
     if (int lrc = gfo_take_launch_err(c)) return lrc;
     BTRY(c, hipGetLastError());
-    // the two vectors and the counters are neighbours in the scratch (o_bw .. o_ct): one copy back instead of six
-    const size_t out_bytes = o_ct + 16 - o_bw;
-    if (int rc = x.out(out_bytes)) return rc;
-    BTRY(c, x.down(S + o_bw, out_bytes, st));
+    if (!direct) BTRY(c, x.down(S + o_bw, out_bytes, st));
     BTRY(c, hipStreamSynchronize(st));
     int cnt[4];
     memcpy(cnt, x.HO + (o_ct - o_bw), 16);

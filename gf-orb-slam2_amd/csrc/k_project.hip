@@ -91,6 +91,9 @@ struct ProjB {
     int* tab_g;                // [2 * n_cap] claim / owner and score tables when they do not fit LDS
     int* counters;             // [PJ_CNT]
     int* out_mp; int* out_score;   // [n_cap]
+    // host-array calls (one frame): the results ALSO go straight to the caller-side pinned block (device-visible host memory) -- a D2H
+    // copy behind the last kernel is ~5 us of copy and ~10 us of hand-over between the compute queue and the copy engine
+    int* h_counters; int* h_out_mp; int* h_out_score;   // null: the batch forms
 #ifdef GFO_PROJ_DEBUG
     int dbg_stop;
 #endif
@@ -809,13 +812,22 @@ __global__ __launch_bounds__(1024) void k_proj_resolve(ProjB a)
     }
     __syncthreads();
     for (int k = tid; k < n; k += 1024) {
-        out_mp[k] = tab_load(&tab[k]);
-        out_score[k] = tab_load(&sc[k]);
+        const int mp = tab_load(&tab[k]), score = tab_load(&sc[k]);
+        out_mp[k] = mp;
+        out_score[k] = score;
+        if (a.h_out_mp) { a.h_out_mp[k] = mp; a.h_out_score[k] = score; }
     }
     if (tid == 0) {
         a.counters[f * PJ_CNT + PJ_NMATCH] = s_acc[0] - s_acc[1];
         a.counters[f * PJ_CNT + PJ_ROUNDS] = rounds + 1;
         a.counters[f * PJ_CNT + PJ_FALLBACK] = s_acc[2];
+        if (a.h_counters) {
+            a.h_counters[PJ_NLIVE] = nlive;
+            a.h_counters[PJ_ROUNDS] = rounds + 1;
+            a.h_counters[PJ_NMATCH] = s_acc[0] - s_acc[1];
+            a.h_counters[PJ_ERR] = a.counters[f * PJ_CNT + PJ_ERR];   // (written by this thread, if at all)
+            a.h_counters[PJ_FALLBACK] = s_acc[2];
+        }
     }
 }
 
@@ -991,17 +1003,26 @@ extern "C" int gfo_search_by_projection_queries(gfo_ctx* c, const gfo_keypoint* 
     a.th_dist = mode->th_dist;
     a.check_ori = mode->check_orientation;
     pj_bind(c, &a);
+    // the resolve kernel writes counters, out_mp and out_score into the pinned block itself (ProjB::h_*): no copy back
+    const size_t o_hm = 256, o_hs = o_hm + al256(4 * (size_t)n);
+    if (int rc = x.out(o_hs + 4 * (size_t)n)) return rc;
+    const bool direct = gfo_matcher_host_writes();
+    if (direct) {
+        a.h_counters = (int*)x.HO;
+        a.h_out_mp = (int*)(x.HO + o_hm);
+        a.h_out_score = (int*)(x.HO + o_hs);
+    }
     if (int rc = pj_launch(c, a, 1, n)) return rc;
-    // counters, out_mp and out_score are consecutive in the work buffer (pj_reserve): one copy back
-    const uint8_t* d_lo = (const uint8_t*)a.counters;
-    const size_t out_bytes = (size_t)((const uint8_t*)(a.out_score + n) - d_lo);
-    if (int rc = x.out(out_bytes)) return rc;
-    PTRY(c, x.down(d_lo, out_bytes, st));
+    if (!direct) {   // three copies into the same places
+        PTRY(c, hipMemcpyAsync(x.HO, a.counters, PJ_CNT * 4, hipMemcpyDeviceToHost, st));
+        PTRY(c, hipMemcpyAsync(x.HO + o_hm, a.out_mp, 4 * (size_t)n, hipMemcpyDeviceToHost, st));
+        PTRY(c, hipMemcpyAsync(x.HO + o_hs, a.out_score, 4 * (size_t)n, hipMemcpyDeviceToHost, st));
+    }
     PTRY(c, hipStreamSynchronize(st));
     int cnt[PJ_CNT];
     memcpy(cnt, x.HO, sizeof cnt);
-    memcpy(out_mp, x.HO + ((const uint8_t*)a.out_mp - d_lo), 4 * (size_t)n);
-    memcpy(out_score, x.HO + ((const uint8_t*)a.out_score - d_lo), 4 * (size_t)n);
+    memcpy(out_mp, x.HO + o_hm, 4 * (size_t)n);
+    memcpy(out_score, x.HO + o_hs, 4 * (size_t)n);
     if (cnt[PJ_ERR]) return pj_fail(c, GFO_ERR_STATE, "gfo_search_by_projection: fixed point not reached");
     *nmatches = cnt[PJ_NMATCH];
     c->last_project_rounds = cnt[PJ_ROUNDS];
