@@ -758,6 +758,17 @@ __global__ __launch_bounds__(256) void k_pack_results(GfoPack p)
         for (int i = t; i < p.n16[s]; i += stride) p.dst[s][i] = p.src[s][i];
 }
 
+// `bytes` (a multiple of 16, both pointers 16-byte aligned) from device-visible pinned host memory to device memory by a kernel of the
+// compute queue instead of the copy engine: for a few hundred KB in front of a kernel chain the engine costs ~8 us of hand-over
+// between the two queues on top of the copy (GfoXfer::up).
+void gfo_launch_copy16(gfo_ctx* c, void* dst, const void* src, size_t bytes, hipStream_t st)
+{
+    GfoPack pk{};
+    pk.src[0] = (const uint4*)src; pk.dst[0] = (uint4*)dst; pk.n16[0] = (int)(bytes / 16); pk.nseg = 1;
+    const int blocks = (pk.n16[0] + 255) / 256;
+    GFO_LAUNCH(c, k_pack_results, dim3(blocks > 0 ? (blocks < 4096 ? blocks : 4096) : 1), dim3(256), 0, st, pk);
+}
+
 static GfoStereoLaunch stereo_batch_launch(gfo_ctx* c, const gfo_stereo_params& p)
 {
     GfoStereoLaunch sl{};

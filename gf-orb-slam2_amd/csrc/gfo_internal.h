@@ -326,6 +326,7 @@ bool gfo_launch_quadtree_blur(gfo_ctx* c, const GfoInput& in, int nimg);   // pe
 void gfo_launch_orient_desc(gfo_ctx* c, const GfoInput& in, int nimg);
 void gfo_launch_stereo(gfo_ctx* c, const GfoStereoLaunch& s);
 int gfo_pinned(gfo_ctx* c, uint8_t** buf, size_t* cap, size_t bytes);   // grow-only hipHostMalloc buffer (synchronises the stream when it grows)
+void gfo_launch_copy16(gfo_ctx* c, void* dst, const void* src, size_t bytes, hipStream_t st);   // gfo_api.hip
 // One host-array call's transfers.  in(): reserve the pinned mirror of the device scratch [0, bytes); put(): memcpy one input to its
 // offset; up(): the ONE H2D.  out()/down(): ONE D2H of a contiguous device range into pinned memory, read after the stream sync.
 struct GfoXfer {
@@ -340,7 +341,16 @@ struct GfoXfer {
         return rc;
     }
     void put(size_t off, const void* src, size_t bytes) const { if (bytes) memcpy(H + off, src, bytes); }
-    hipError_t up(void* d_dst, size_t bytes, hipStream_t st) const { return hipMemcpyAsync(d_dst, H, bytes, hipMemcpyHostToDevice, st); }
+    hipError_t up(void* d_dst, size_t bytes, hipStream_t st) const
+    {
+        // up to 1 MB: a copy KERNEL in front of the call's kernels (the pinned block is device-visible); larger blocks take the copy engine
+        static const long kernel_max = getenv("GFO_MATCHER_UPLOAD_KERNEL_MAX") ? atol(getenv("GFO_MATCHER_UPLOAD_KERNEL_MAX")) : (1L << 20);
+        if ((long)bytes <= kernel_max && (bytes & 15) == 0 && ((uintptr_t)d_dst & 15) == 0) {
+            gfo_launch_copy16(c, d_dst, H, bytes, st);
+            return hipSuccess;   // (a launch error is collected by gfo_take_launch_err with the call's other launches)
+        }
+        return hipMemcpyAsync(d_dst, H, bytes, hipMemcpyHostToDevice, st);
+    }
     int out(size_t bytes)
     {
         int rc = bytes <= c->h_mout_bytes ? 0 : gfo_pinned(c, &c->h_mout, &c->h_mout_bytes, bytes + bytes / 2);
