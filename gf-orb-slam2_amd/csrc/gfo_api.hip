@@ -766,7 +766,8 @@ void gfo_launch_copy16(gfo_ctx* c, void* dst, const void* src, size_t bytes, hip
     GfoPack pk{};
     pk.src[0] = (const uint4*)src; pk.dst[0] = (uint4*)dst; pk.n16[0] = (int)(bytes / 16); pk.nseg = 1;
     const int blocks = (pk.n16[0] + 255) / 256;
-    GFO_LAUNCH(c, k_pack_results, dim3(blocks > 0 ? (blocks < 4096 ? blocks : 4096) : 1), dim3(256), 0, st, pk);
+    (void)c;   // (no per-stage timing events: a transfer is not a stage)
+    hipLaunchKernelGGL(k_pack_results, dim3(blocks > 0 ? (blocks < 4096 ? blocks : 4096) : 1), dim3(256), 0, st, pk);
 }
 
 static GfoStereoLaunch stereo_batch_launch(gfo_ctx* c, const gfo_stereo_params& p)
