@@ -1679,7 +1679,11 @@ extern "C" int gfo_stereo_match(gfo_ctx* c, const gfo_keypoint* kl, const uint8_
         memcpy(HI + o_min, min_d, sizeof(float) * nl);
         memcpy(HI + o_max, max_d, sizeof(float) * nl);
     }
-    HIP_TRY(c, hipMemcpyAsync(S, HI, in_bytes, hipMemcpyHostToDevice, c->stream));
+    // as the other host-array matcher calls (GfoXfer): a few hundred KB in front of and behind three short kernels go by copy KERNELS of
+    // the compute queue -- the copy engine's hand-overs cost more than the copies
+    static const long kernel_max = getenv("GFO_MATCHER_UPLOAD_KERNEL_MAX") ? atol(getenv("GFO_MATCHER_UPLOAD_KERNEL_MAX")) : (1L << 20);
+    if ((long)in_bytes <= kernel_max) gfo_launch_copy16(c, S, HI, in_bytes, c->stream);
+    else HIP_TRY(c, hipMemcpyAsync(S, HI, in_bytes, hipMemcpyHostToDevice, c->stream));
     GfoStereoDev out{(float*)(S + o_u), (float*)(S + o_dp), (int*)(S + o_bd), (int*)(S + o_bi), (int*)(S + o_nm), S + o_ct};
     GfoStereoLaunch sl{};
     sl.kl = (const gfo_keypoint*)(S + o_kl); sl.dl = S + o_dl;
@@ -1699,7 +1703,8 @@ extern "C" int gfo_stereo_match(gfo_ctx* c, const gfo_keypoint* kl, const uint8_
     if (int lrc = gfo_take_launch_err(c)) return lrc;
     HIP_TRY(c, hipGetLastError());
     uint8_t* HO = c->h_out;
-    HIP_TRY(c, hipMemcpyAsync(HO, S + in_bytes, out_bytes, hipMemcpyDeviceToHost, c->stream));
+    if (gfo_matcher_host_writes() && (long)out_bytes <= kernel_max) gfo_launch_copy16(c, HO, S + in_bytes, out_bytes, c->stream);
+    else HIP_TRY(c, hipMemcpyAsync(HO, S + in_bytes, out_bytes, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     memcpy(u_right, HO + (o_u - in_bytes), sizeof(float) * nl);
     memcpy(depth, HO + (o_dp - in_bytes), sizeof(float) * nl);

@@ -42,7 +42,7 @@ def test_a_mismatch_prints_the_line_and_fails_the_command():
 
 
 def test_matcher_calls_block_of_the_line():
-    """`matcher_calls` of the default line = tools/matcher_call_latency.py with JSON=1 (no oracle inside: it runs under bench.py): six
+    """`matcher_calls` of the default line = tools/matcher_call_latency.py with JSON=1 (no oracle inside: it runs under bench.py): seven
     calls, each with a time and matches found."""
     env = {k: v for k, v in os.environ.items() if k not in ("TH", "ONLY", "GFO_PROJ_STATS")}
     env["JSON"] = "1"
@@ -51,7 +51,8 @@ def test_matcher_calls_block_of_the_line():
     assert r.returncode == 0, r.stderr[-2000:]
     d = json.loads(r.stdout.strip().splitlines()[-1])
     names = [c["call"] for c in d["calls"]]
-    assert names == ["SearchByProjection(F, MapPoints)"] * 3 + ["SearchByProjection(Cur, Last)", "ComputeBoW", "SearchByBoW(KF, F)"]
+    assert names == ["SearchByProjection(F, MapPoints)"] * 3 + ["ComputeStereoMatches(host arrays)", "SearchByProjection(Cur, Last)", "ComputeBoW",
+                     "SearchByBoW(KF, F)"]
     assert all(0 < c["ms"] < 50 for c in d["calls"])
     assert all(c.get("matches", c.get("words")) > 100 for c in d["calls"])
     src = open(os.path.join(ROOT, "tools", "matcher_call_latency.py")).read()

@@ -3,7 +3,7 @@ Per-call latency of the host-array matcher calls Tracking makes on every frame (
 synchronisation): SearchByProjection(F, local map) for several map sizes, SearchByProjection(Cur, Last), SearchByBoW(KF, F),
 ComputeBoW(F) -- on the EuRoC frame (2008 keypoints).  Every map point here imitates a random keypoint (8 flipped bits, N(0,2) px
 away), so with M > N several points COMPETE for one keypoint: the ordered resolve runs its worst case, not a typical local map.
-usage (through gpurun): [TH=1|3|5] [ONLY=map|last|cbow|bow] [JSON=1] python tools/matcher_call_latency.py [M ...]     (GFO_PROJ_STATS=1 prints
+usage (through gpurun): [TH=1|3|5] [ONLY=map|stereo|last|cbow|bow] [JSON=1] python tools/matcher_call_latency.py [M ...]     (GFO_PROJ_STATS=1 prints
 rounds / fallbacks per call; JSON=1: one JSON object on stdout instead of the text lines)"""
 import json
 import os
@@ -70,6 +70,15 @@ for M in ([int(a) for a in sys.argv[1:]] or (1000, 2000, 4000)) if ONLY in ("", 
     ms, r = median_ms(lambda: m.SearchByProjection(kp, desc, u_right, sf, bounds, mps, mpd, TH, None))
     say("SearchByProjection(F, MapPoints)", ms, {"map_points": M, "th": TH, "keypoints": n, "matches": int(r[0])},
         f"SearchByProjection(F, {M} map points, th {TH:g}), {n} keypoints: median {ms:.3f} ms, {r[0]} matches")
+
+# Frame::ComputeStereoMatches_Undistorted on caller arrays (what the adapter falls back on when the rig cannot answer from the extraction)
+if ONLY in ("", "stereo"):
+    imr = np.fromfile("tests/golden/EuRoC_r_752x480.u8", np.uint8).reshape(480, 752)
+    kr, dr = ext(imr)
+    prm = G.StereoParams(480, 47.90639384423901, 47.90639384423901 / 435.2046959714599, 0.0)
+    ms, r = median_ms(lambda: m.ComputeStereoMatches(kp, desc, kr, dr, sf, prm))
+    say("ComputeStereoMatches(host arrays)", ms, {"left": n, "right": len(kr), "matches": int(r[0])},
+        f"ComputeStereoMatches on host arrays: {n} x {len(kr)} keypoints: median {ms:.3f} ms, {r[0]} matches")
 
 # SearchByProjection(CurrentFrame, LastFrame, th = 7 mono / 15 stereo): one query per tracked point of the last frame (ORBmatcher.cc:1440-1593)
 nq = 1500
