@@ -327,6 +327,13 @@ void gfo_launch_orient_desc(gfo_ctx* c, const GfoInput& in, int nimg);
 void gfo_launch_stereo(gfo_ctx* c, const GfoStereoLaunch& s);
 int gfo_pinned(gfo_ctx* c, uint8_t** buf, size_t* cap, size_t bytes);   // grow-only hipHostMalloc buffer (synchronises the stream when it grows)
 void gfo_launch_copy16(gfo_ctx* c, void* dst, const void* src, size_t bytes, hipStream_t st);   // gfo_api.hip
+// host-array matcher calls: the last kernel of a call writes the answer into the pinned block itself (1, default) or the block is filled
+// by a copy behind it (GFO_MATCHER_HOST_WRITES=0; same-box A/B in profiles/matcher_call_latency_r05.txt)
+inline bool gfo_matcher_host_writes()
+{
+    static const bool on = !(getenv("GFO_MATCHER_HOST_WRITES") && atoi(getenv("GFO_MATCHER_HOST_WRITES")) == 0);
+    return on;
+}
 // One host-array call's transfers.  in(): reserve the pinned mirror of the device scratch [0, bytes); put(): memcpy one input to its
 // offset; up(): the ONE H2D.  out()/down(): ONE D2H of a contiguous device range into pinned memory, read after the stream sync.
 struct GfoXfer {
@@ -357,15 +364,17 @@ struct GfoXfer {
         HO = c->h_mout;
         return rc;
     }
-    hipError_t down(const void* d_src, size_t bytes, hipStream_t st) const { return hipMemcpyAsync(HO, d_src, bytes, hipMemcpyDeviceToHost, st); }
+    hipError_t down(const void* d_src, size_t bytes, hipStream_t st) const
+    {
+        // (the calls whose last kernel cannot write the answer itself) up to 1 MB: a copy kernel into the pinned block, as in up()
+        static const long kernel_max = getenv("GFO_MATCHER_UPLOAD_KERNEL_MAX") ? atol(getenv("GFO_MATCHER_UPLOAD_KERNEL_MAX")) : (1L << 20);
+        if (gfo_matcher_host_writes() && (long)bytes <= kernel_max && (bytes & 15) == 0 && ((uintptr_t)d_src & 15) == 0) {
+            gfo_launch_copy16(c, HO, d_src, bytes, st);
+            return hipSuccess;
+        }
+        return hipMemcpyAsync(HO, d_src, bytes, hipMemcpyDeviceToHost, st);
+    }
 };
-// host-array matcher calls: the last kernel of a call writes the answer into the pinned block itself (1, default) or the block is filled
-// by a copy behind it (GFO_MATCHER_HOST_WRITES=0; same-box A/B in profiles/matcher_call_latency_r05.txt)
-inline bool gfo_matcher_host_writes()
-{
-    static const bool on = !(getenv("GFO_MATCHER_HOST_WRITES") && atoi(getenv("GFO_MATCHER_HOST_WRITES")) == 0);
-    return on;
-}
 void gfo_launch_pack_cut(gfo_ctx* c, const GfoPack& p, hipStream_t st);   // k_pack_results with the stereo cut in it (GfoPack::cut_pairs)
 int gfo_stereo_window(const float* scale, int nlevels);
 void gfo_launch_stereo_sad(gfo_ctx* c, const GfoStereoLaunch& s, const GfoInput& in, const float* d_inv_scale);
