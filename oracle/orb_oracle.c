@@ -1061,7 +1061,7 @@ int orc_features_in_area(const orc_keypoint* kp_un, int n, const orc_frame_bound
 
 /* ORBmatcher::SearchByProjection(Frame&, vector<MapPoint*>&, th) -- ORBmatcher.cc:155-249 */
 int orc_search_by_projection(const orc_keypoint* kp, const uint8_t* desc, const float* u_right, int n,
-                             const float* sf, const orc_frame_bounds* fb,
+                             const float* sf, int nlevels, const orc_frame_bounds* fb,
                              const orc_map_point* mps, const uint8_t* mp_desc, int m,
                              float th, float nn_ratio, const uint8_t* kp_taken,
                              int* out_mp, int* out_score)
@@ -1083,6 +1083,11 @@ int orc_search_by_projection(const orc_keypoint* kp, const uint8_t* desc, const 
         if (!(mp->flags & 1)) continue; /* mbTrackInView */
         if (mp->flags & 2) continue;    /* isBad()       */
         const int lvl = mp->level;
+        /* The reference indexes F.mvScaleFactors[nPredictedLevel] unchecked (:177-180); MapPoint::PredictScale keeps the level inside the
+           table, so it never reads beside it.  A level outside [0, nlevels) is therefore not a case the reference defines: this statement
+           skips the point -- what the library does -- instead of reading whatever lies beside sf[] (a fuzz run found the oracle's answer
+           changing from run to run on such inputs). */
+        if (lvl < 0 || lvl >= nlevels) continue;
         float r = mp->view_cos > 0.998 ? 2.5f : 4.0f; /* RadiusByViewingCos :243-249 (double compare) */
         if (bFactor) r *= th;
         const float rs = r * sf[lvl];

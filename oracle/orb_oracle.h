@@ -138,10 +138,10 @@ typedef struct {
  * out_mp[n]: index of the map point finally stored in F.mvpMapPoints[i] by this call (-1 none);
  * out_score[n]: F.mvpMatchScore[i] for those.  Returns nmatches. */
 int orc_search_by_projection(const orc_keypoint* kp_un, const uint8_t* desc, const float* u_right, int n,
-                             const float* scale_factors, const orc_frame_bounds* fb,
+                             const float* scale_factors, int nlevels, const orc_frame_bounds* fb,
                              const orc_map_point* mps, const uint8_t* mp_desc, int m,
                              float th, float nn_ratio, const uint8_t* kp_taken,
-                             int* out_mp, int* out_score);
+                             int* out_mp, int* out_score);   /* a map point whose level is outside [0, nlevels) is skipped (see the .c) */
 int orc_features_in_area(const orc_keypoint* kp_un, int n, const orc_frame_bounds* fb,
                          float x, float y, float r, int min_level, int max_level,
                          int* out_idx, int cap);

@@ -80,7 +80,7 @@ def lib():
         L.orc_sincos_n.argtypes = [vp, i, vp, vp]
         L.orc_hamming256.argtypes = [vp, vp]
         L.orc_stereo_match.argtypes = [vp, vp, i, vp, vp, i, vp, C.POINTER(StereoParams), vp, vp, vp, vp, vp, vp]
-        L.orc_search_by_projection.argtypes = [vp, vp, vp, i, vp, C.POINTER(FrameBounds), vp, vp, i, f, f, vp, vp, vp]
+        L.orc_search_by_projection.argtypes = [vp, vp, vp, i, vp, i, C.POINTER(FrameBounds), vp, vp, i, f, f, vp, vp, vp]
         L.orc_features_in_area.argtypes = [vp, i, C.POINTER(FrameBounds), f, f, f, i, i, vp, i]
         L.orc_set_ocv_variant.argtypes = [i, i]
         L.orc_get_ocv_variant.argtypes = [i]
@@ -317,7 +317,7 @@ def search_by_projection(kp_un, desc, u_right, scale_factors, bounds, mps, mp_de
     fb = FrameBounds(*bounds)
     out_mp = np.zeros(max(n, 1), np.int32)
     out_score = np.zeros(max(n, 1), np.int32)
-    nm = lib().orc_search_by_projection(_p(kp_un), _p(desc), _p(u_right), n, _p(sf), C.byref(fb), _p(mps), _p(mp_desc), m,
+    nm = lib().orc_search_by_projection(_p(kp_un), _p(desc), _p(u_right), n, _p(sf), len(sf), C.byref(fb), _p(mps), _p(mp_desc), m,
                                         th, nn_ratio, _p(kp_taken), _p(out_mp), _p(out_score))
     return nm, out_mp[:n], out_score[:n]
 

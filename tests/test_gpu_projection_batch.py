@@ -112,11 +112,8 @@ def test_stereo_chain_feeds_the_projection(oracle, M):
     for p in range(P):
         kp, desc = kd[p]
         n = len(kp)
-        mp_ok = mps[p].copy()
-        bad = (mp_ok["level"] < 0) | (mp_ok["level"] > 7)       # the oracle indexes sf[level] unchecked, as the reference does
-        mp_ok["flags"][bad] &= ~1
-        mp_ok["level"][bad] = 0
-        ref = oracle.search_by_projection(kp, desc, ur[p][:n], sf, bounds, mp_ok, mpd, 5.0, 0.7, taken[p][:n])
+        # (levels -1 and 8 -- outside the scale table -- are skipped by the library and by the oracle alike)
+        ref = oracle.search_by_projection(kp, desc, ur[p][:n], sf, bounds, mps[p], mpd, 5.0, 0.7, taken[p][:n])
         nm, out_mp, out_sc = m.projection_fetch(p, n)
         assert nm == ref[0] and nm > 200, f"pair {p}"
         np.testing.assert_array_equal(out_mp[:n], ref[1])

@@ -96,13 +96,8 @@ for it in range(cases):
             mps["flags"] = fl
             th = float(rng.choice([1.0, 1.0, 3.0, 5.0, 7.0, 15.0]))
             ratio = float(rng.choice([0.6, 0.8, 0.9, 1.0]))
-            # levels -1 and 8 are outside the frame's scale table: the library skips such a point; the oracle indexes sf[level] unchecked,
-            # as the reference does (where PredictScale never produces them) -- it gets the point switched off instead of reading garbage
-            mp_ok = mps.copy()
-            out_of_range = (mp_ok["level"] < 0) | (mp_ok["level"] > 7)
-            mp_ok["flags"][out_of_range] &= ~1
-            mp_ok["level"][out_of_range] = 0
-            ref = O.search_by_projection(kp, desc, u_right, SF, bounds, mp_ok, qd, th, ratio, taken)
+            # (levels -1 and 8 are outside the frame's scale table: library and oracle both skip such a point)
+            ref = O.search_by_projection(kp, desc, u_right, SF, bounds, mps, qd, th, ratio, taken)
             got = G.ORBmatcher(ratio, True, extractor=ext).SearchByProjection(kp, desc, u_right, SF, bounds, mps, qd, th, taken)
         else:
             q = np.zeros(m, O.PROJ_QUERY_DTYPE)
