@@ -1244,8 +1244,13 @@ int gfo_small_prepare(gfo_ctx* c, int nimg_cap, GfoSmallLayout* L)
 //   otherwise -> memcpy into the context's pinned staging (one memcpy per image when the rows are tight), ONE copy.
 // `ec` takes the error message: the context of the CALLING thread (in the combiner several callers upload into one batch
 // context at once -- its error string is not theirs to write).
+// lone_caller: nobody else is feeding this device through the library right now as far as the caller can tell (a context used on its
+// own; in the combiner, an engine that serves ONE camera).  Then a staged upload of up to GFO_UPLOAD_KERNEL_MAX bytes (512 KB: one
+// image of a mono camera) comes over by a copy kernel of the compute queue instead of the copy engine: -4 to -6 us per frame (same-box
+// A/B, profiles/NOTEBOOK.md "Round 5"); a stereo frame's 722 KB gain nothing, and with several cameras the engine's copies run
+// underneath the other batches' kernels where a copy kernel competes with them (-17 % at K = 8).
 int gfo_small_upload(gfo_ctx* c, gfo_ctx* ec, const GfoSmallLayout& L, int first, int count, const uint8_t* const* imgs, int w, int h, int stride,
-                     hipStream_t st)
+                     hipStream_t st, bool lone_caller)
 {
     uint8_t* dst = c->d_input + (size_t)first * L.img_bytes;
     const bool tight = stride == L.pitch;
@@ -1268,7 +1273,9 @@ int gfo_small_upload(gfo_ctx* c, gfo_ctx* ec, const GfoSmallLayout& L, int first
         else
             for (int y = 0; y < h; y++) memcpy(d + (size_t)y * L.pitch, imgs[i] + (size_t)y * stride, w);
     }
-    HIP_TRY(ec, hipMemcpyAsync(dst, stage, L.img_bytes * count, hipMemcpyHostToDevice, st));
+    static const long kernel_max = getenv("GFO_UPLOAD_KERNEL_MAX") ? atol(getenv("GFO_UPLOAD_KERNEL_MAX")) : 512 * 1024;
+    if (lone_caller && (long)(L.img_bytes * count) <= kernel_max && (L.img_bytes & 15) == 0) gfo_launch_copy16(c, dst, stage, L.img_bytes * count, st);
+    else HIP_TRY(ec, hipMemcpyAsync(dst, stage, L.img_bytes * count, hipMemcpyHostToDevice, st));
     return GFO_OK;
 }
 
@@ -1419,7 +1426,7 @@ static int extract_small(gfo_ctx* c, const uint8_t* const* imgs, int nimg, int w
     GfoSmallLayout L;
     int rc = gfo_small_prepare(c, nimg, &L);
     if (rc) return rc;
-    rc = gfo_small_upload(c, c, L, 0, nimg, imgs, w, h, stride, c->stream);
+    rc = gfo_small_upload(c, c, L, 0, nimg, imgs, w, h, stride, c->stream, true);   // a context used on its own (no combiner)
     if (rc) return rc;
     rc = gfo_small_submit(c, L, nimg, sp, false);
     if (rc) return rc;

@@ -401,9 +401,14 @@ int gfo_combined_extract(gfo_ctx* c, int kind, const uint8_t* const* imgs, int w
 {
     std::shared_ptr<GfoEngine> eh = engine_for(c, w, h);
     int over = 0;
+    bool one_camera;   // this context is all the engine serves (a mono camera): see gfo_small_upload
+    {
+        std::lock_guard<std::mutex> g(eh->mu);
+        one_camera = eh->members <= 1;
+    }
     const int rc = run_request(
         c, eh.get(), kind, kind, sp,
-        [&](Slot& s, int idx) { return gfo_small_upload(s.bc, c, s.L, idx * kind, kind, imgs, w, h, stride, s.bc->stream); },
+        [&](Slot& s, int idx) { return gfo_small_upload(s.bc, c, s.L, idx * kind, kind, imgs, w, h, stride, s.bc->stream, one_camera); },
         [&](Slot& s, int nb) { return gfo_small_submit(s.bc, s.L, nb * kind, kind == 2 ? &s.sp : nullptr, false); },
         [&](Slot& s, int idx) {
             int o = 0;

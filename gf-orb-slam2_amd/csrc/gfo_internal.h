@@ -390,7 +390,7 @@ struct GfoSmallLayout {
 };
 int gfo_small_prepare(gfo_ctx* c, int nimg_cap, GfoSmallLayout* L);
 int gfo_small_upload(gfo_ctx* c, gfo_ctx* ec, const GfoSmallLayout& L, int first, int count, const uint8_t* const* imgs, int w, int h, int stride,
-                     hipStream_t st);
+                     hipStream_t st, bool lone_caller = false);
 int gfo_small_submit(gfo_ctx* c, const GfoSmallLayout& L, int nimg, const gfo_stereo_params* sp, bool copy_in);
 int gfo_small_collect(gfo_ctx* c, const GfoSmallLayout& L, int i, gfo_keypoint* kp, uint8_t* desc, int cap, int* n);
 void gfo_small_collect_stereo(gfo_ctx* c, const GfoSmallLayout& L, int pair, int n_left, int cap, float* u_right, float* depth,

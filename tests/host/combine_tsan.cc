@@ -104,7 +104,7 @@ int gfo_small_prepare(gfo_ctx* c, int nimg_cap, GfoSmallLayout* L)
     c->h_out = (uint8_t*)malloc(off);
     return GFO_OK;
 }
-int gfo_small_upload(gfo_ctx* c, gfo_ctx*, const GfoSmallLayout& L, int first, int count, const uint8_t* const* imgs, int w, int h, int stride, hipStream_t)
+int gfo_small_upload(gfo_ctx* c, gfo_ctx*, const GfoSmallLayout& L, int first, int count, const uint8_t* const* imgs, int w, int h, int stride, hipStream_t, bool)
 {
     for (int i = 0; i < count; i++) {
         uint8_t* stage = c->h_in + (size_t)(first + i) * L.img_bytes;
