@@ -94,6 +94,12 @@ struct ProjB {
     // host-array calls (one frame): the results ALSO go straight to the caller-side pinned block (device-visible host memory) -- a D2H
     // copy behind the last kernel is ~5 us of copy and ~10 us of hand-over between the compute queue and the copy engine
     int* h_counters; int* h_out_mp; int* h_out_score;   // null: the batch forms
+    // host-array calls: k_proj_grid ALSO brings the call's inputs over -- workgroups behind the frames' copy cp_n16 16-byte units from
+    // the pinned block to the scratch, while the grid workgroup reads the keypoints from the pinned block itself (kp_grid): one launch
+    // instead of a copy kernel and a grid kernel
+    const uint4* cp_src; uint4* cp_dst; int cp_n16;
+    const gfo_keypoint* kp_grid;   // null: a.kp
+    int grid_frames;               // frames of the launch (the copy workgroups come behind them)
 #ifdef GFO_PROJ_DEBUG
     int dbg_stop;
 #endif
@@ -143,8 +149,13 @@ __global__ __launch_bounds__(1024) void k_proj_grid(ProjB a)
     __shared__ int s_cnt[NSG];
     __shared__ int s_part[16];
     const int tid = threadIdx.x, f = blockIdx.x;
+    if (a.cp_n16 > 0 && (int)blockIdx.x >= a.grid_frames) {   // a copy workgroup (host-array calls)
+        const int t = ((int)blockIdx.x - a.grid_frames) * 1024 + tid, stride = ((int)gridDim.x - a.grid_frames) * 1024;
+        for (int i = t; i < a.cp_n16; i += stride) a.cp_dst[i] = a.cp_src[i];
+        return;
+    }
     const int n = frame_n(a, f);
-    const gfo_keypoint* kp = a.kp + (long long)f * a.kp_stride;
+    const gfo_keypoint* kp = (a.kp_grid ? a.kp_grid : a.kp) + (long long)f * a.kp_stride;
     int* cell_start = a.cell_start + (long long)f * (NSG + 1);
     float2* cell_xy = a.cell_xy + (long long)f * a.n_cap;
     unsigned* cell_meta = a.cell_meta + (long long)f * a.n_cap;
@@ -899,7 +910,12 @@ static int pj_launch(gfo_ctx* c, const ProjB& a, int frames, int n_max)
 {
     hipStream_t st = c->stream;
     gfo_prof_begin(c, ST_PROJECT);
-    GFO_LAUNCH(c, k_proj_grid, dim3(frames), dim3(1024), 0, st, a);
+    {
+        ProjB g = a;
+        g.grid_frames = frames;
+        const int copy_blocks = a.cp_n16 > 0 ? (a.cp_n16 + 1023) / 1024 : 0;
+        GFO_LAUNCH(c, k_proj_grid, dim3(frames + copy_blocks), dim3(1024), 0, st, g);
+    }
     // round 0 against an LDS copy of the grid when it fits twice per CU: workgroups of 1024 threads, as many per
     // frame as it takes to put ~2 on every CU (each pays the 78 KB copy once, then walks its chunk of the points)
     const size_t grid_bytes = (size_t)a.n_cap * 12 + (NSG + 1) * 2 + 16;
@@ -981,8 +997,16 @@ extern "C" int gfo_search_by_projection_queries(gfo_ctx* c, const gfo_keypoint* 
     if (kp_angle) x.put(o_ang, kp_angle, 4 * (size_t)n);
     x.put(o_q, queries, sizeof(gfo_proj_query) * m);
     x.put(o_mpd, q_desc, 32 * (size_t)m);
-    PTRY(c, x.up(S, off, st));
+    // up to 1 MB the inputs travel inside the grid launch (ProjB::cp_*); larger calls take the copy engine first
+    static const long fused_max = getenv("GFO_MATCHER_UPLOAD_KERNEL_MAX") ? atol(getenv("GFO_MATCHER_UPLOAD_KERNEL_MAX")) : (1L << 20);
+    static const bool fuse_ok = !(getenv("GFO_PROJ_FUSED_UPLOAD") && atoi(getenv("GFO_PROJ_FUSED_UPLOAD")) == 0);
+    const bool fused = fuse_ok && (long)off <= fused_max;
+    if (!fused) PTRY(c, x.up(S, off, st));
     ProjB a{};
+    if (fused) {
+        a.cp_src = (const uint4*)x.H; a.cp_dst = (uint4*)S; a.cp_n16 = (int)(off / 16);
+        a.kp_grid = (const gfo_keypoint*)(x.H + o_kp);
+    }
     a.kp = (const gfo_keypoint*)(S + o_kp);
     a.desc = S + o_desc;
     a.u_right = u_right ? (const float*)(S + o_ur) : nullptr;
