@@ -700,6 +700,18 @@ extern "C" int gfo_vocabulary_upload(gfo_ctx* c, const gfo_vocabulary* voc)
     return GFO_OK;
 }
 
+// where k_bow_transform reads the call's descriptors: the pinned block (device-visible; up to 1 MB) or, after a copy, the scratch
+static const uint8_t* bow_desc_source(gfo_ctx* c, const GfoXfer& x, uint8_t* d_scratch, size_t bytes, hipStream_t st)
+{
+    static const bool from_host = !(getenv("GFO_BOW_DESC_FROM_HOST") && atoi(getenv("GFO_BOW_DESC_FROM_HOST")) == 0);
+    if (from_host && bytes <= (1u << 20)) return x.H;
+    if (x.up(d_scratch, bytes, st) != hipSuccess) {
+        c->err = "gfo_compute_bow: copying the descriptors failed";
+        return nullptr;
+    }
+    return d_scratch;
+}
+
 extern "C" int gfo_bow_transform(gfo_ctx* c, const uint8_t* desc, int n, int levelsup, int32_t* word_id, float* weight,
                                  int32_t* node_id)
 {
@@ -733,9 +745,12 @@ extern "C" int gfo_bow_transform(gfo_ctx* c, const uint8_t* desc, int n, int lev
     GfoXfer x(c);
     if (int rc = x.in(32 * (size_t)n)) return rc;
     x.put(0, desc, 32 * (size_t)n);
-    BTRY(c, x.up(S + o_d, 32 * (size_t)n, st));
+    // every wavefront reads its descriptor ONCE (32 bytes): the descent reads them from the pinned block itself -- no copy in
+    // (GFO_BOW_DESC_FROM_HOST=0: a copy into the scratch first)
+    const uint8_t* d_desc = bow_desc_source(c, x, S + o_d, 32 * (size_t)n, st);
+    if (!d_desc) return GFO_ERR_DEVICE;
     gfo_prof_begin(c, ST_BOW);
-    GFO_LAUNCH(c, k_bow_transform, dim3((n + 3) / 4), dim3(256), 0, st, v, S + o_d, n, levelsup, (int*)(S + o_w),
+    GFO_LAUNCH(c, k_bow_transform, dim3((n + 3) / 4), dim3(256), 0, st, v, d_desc, n, levelsup, (int*)(S + o_w),
                        (float*)(S + o_wt), (int*)(S + o_n), (double*)nullptr);
     gfo_prof_end(c);
     if (int lrc = gfo_take_launch_err(c)) return lrc;
@@ -798,9 +813,10 @@ extern "C" int gfo_compute_bow(gfo_ctx* c, const uint8_t* desc, int n, int level
     GfoXfer x(c);
     if (int rc = x.in(32 * N)) return rc;
     x.put(0, desc, 32 * N);
-    BTRY(c, x.up(S + o_d, 32 * N, st));
+    const uint8_t* d_desc = bow_desc_source(c, x, S + o_d, 32 * N, st);   // (see gfo_bow_transform)
+    if (!d_desc) return GFO_ERR_DEVICE;
     gfo_prof_begin(c, ST_BOW);
-    GFO_LAUNCH(c, k_bow_transform, dim3((n + 3) / 4), dim3(256), 0, st, v, S + o_d, n, levelsup, (int*)(S + o_w), (float*)nullptr,
+    GFO_LAUNCH(c, k_bow_transform, dim3((n + 3) / 4), dim3(256), 0, st, v, d_desc, n, levelsup, (int*)(S + o_w), (float*)nullptr,
                        (int*)(S + o_n), (double*)(S + o_wt));
     // the two vectors and the counters are neighbours in the scratch (o_bw .. o_ct); the pinned block has the same layout.  Up to 8192
     // descriptors the fold writes its answer there itself; beyond (keys in device memory) one copy back instead of six.
