@@ -466,6 +466,27 @@ int main(int argc, char** argv)
             report("E_map_points", M);
             report("E_SearchByProjection_F_MapPoints_us", median_us(20, [&]() { F.mvpMapPoints = before; }, [&]() { matcher.SearchByProjection(F, map, 3); }));
             F.mvpMapPoints = after;
+            // ... and what the library call inside it costs on the same inputs, already flattened (a context of the harness's own):
+            // the difference is the adapter's walk over the MapPoint objects through the reference's accessors
+            {
+                gfo_params prm = {2000, 1.2f, 8, 20, 7, 2};
+                gfo_ctx* raw = NULL;
+                if (gfo_ctx_create(&prm, 0, &raw) == GFO_OK) {
+                    std::vector<uint8_t> taken(F.N);
+                    for (int i = 0; i < F.N; i++) taken[i] = before[i] && before[i]->Observations() > 0;
+                    gfo_frame_bounds fb = {Frame::mnMinX, Frame::mnMinY, Frame::mnMaxX, Frame::mnMaxY};
+                    std::vector<int32_t> omp(F.N), osc(F.N);
+                    int nm2 = 0;
+                    const long long us = median_us(20, []() {}, [&]() {
+                        gfo_search_by_projection(raw, reinterpret_cast<const gfo_keypoint*>(F.mvKeysUn.data()), F.mDescriptors.data, F.mvuRight.data(), F.N,
+                                                 F.mvScaleFactors.data(), (int)F.mvScaleFactors.size(), &fb, mp, dsc.data(), M, 3.0f, 0.8f, taken.data(),
+                                                 omp.data(), osc.data(), &nm2);
+                    });
+                    report("E_gfo_search_by_projection_us", us);
+                    CHECK(nm2 == nm, "E: the raw library call found %d matches, the adapter %d", nm2, nm);
+                    gfo_ctx_destroy(raw);
+                }
+            }
         }
     }
 
