@@ -104,6 +104,14 @@ struct FlatFeatVec {
     }
 };
 
+// one map point's descriptor into row i of an M x 32 block (MapPoint::GetDescriptor returns a clone: 1 x 32 CV_8U, continuous)
+inline void descriptor_row(MapPoint* pMP, cv::Mat& block, int i)
+{
+    const cv::Mat d = pMP->GetDescriptor();
+    if (d.data && d.rows * d.cols >= 32 && d.isContinuous()) memcpy(block.data + (size_t)i * 32, d.data, 32);
+    else d.copyTo(block.row(i));
+}
+
 // continuous descriptor rows (mDescriptors is created by the extractor adapter as one N x 32 block; a row view
 // handed in from elsewhere may not be)
 inline const uint8_t* rows32(const cv::Mat& m, cv::Mat& keep)
@@ -190,13 +198,20 @@ int ORBmatcher::SearchByProjection(Frame& F, const std::vector<MapPoint*>& vpMap
     const int M = (int)vpMapPoints.size(), N = F.N;
     std::vector<gfo_map_point> mps(M);
     cv::Mat mpDesc(M > 0 ? M : 1, 32, CV_8U);
+    memset(mpDesc.data, 0, (size_t)(M > 0 ? M : 1) * 32);   // rows of the points that are skipped below
     for (int i = 0; i < M; i++) {
         MapPoint* pMP = vpMapPoints[i];
         gfo_map_point& m = mps[i];
         m.proj_x = pMP->mTrackProjX; m.proj_y = pMP->mTrackProjY; m.proj_xr = pMP->mTrackProjXR;
         m.view_cos = pMP->mTrackViewCos; m.level = pMP->mnTrackScaleLevel;
-        m.flags = (pMP->mbTrackInView ? 1 : 0) | (pMP->isBad() ? 2 : 0) | (pMP->Observations() > 0 ? 4 : 0);
-        pMP->GetDescriptor().copyTo(mpDesc.row(i));
+        // As the reference's loop (:163-168): a point that is not in view, or bad, is skipped before anything else is asked of it --
+        // most of a local map, usually.  Only a point that will be searched pays for GetDescriptor() (a clone under the point's
+        // mutex) and Observations(); the library never looks at the descriptor row or the third flag of the others.
+        m.flags = pMP->mbTrackInView ? 1 : 0;
+        if (!m.flags) continue;
+        if (pMP->isBad()) { m.flags |= 2; continue; }
+        if (pMP->Observations() > 0) m.flags |= 4;
+        descriptor_row(pMP, mpDesc, i);
     }
     std::vector<uint8_t> taken(N);
     for (int i = 0; i < N; i++) taken[i] = F.mvpMapPoints[i] && F.mvpMapPoints[i]->Observations() > 0;
@@ -275,7 +290,7 @@ int ORBmatcher::SearchByProjection(Frame& CurrentFrame, const Frame& LastFrame, 
     }
     const int M = (int)q.size(), N = CurrentFrame.N;
     cv::Mat qDesc(M > 0 ? M : 1, 32, CV_8U);
-    for (int i = 0; i < M; i++) qmp[i]->GetDescriptor().copyTo(qDesc.row(i));
+    for (int i = 0; i < M; i++) descriptor_row(qmp[i], qDesc, i);
     std::vector<uint8_t> taken(N);
     std::vector<float> angle(N);
     for (int i = 0; i < N; i++) {
@@ -353,7 +368,7 @@ int ORBmatcher::SearchByProjection(Frame& CurrentFrame, KeyFrame* pKF, const std
     }
     const int M = (int)q.size(), N = CurrentFrame.N;
     cv::Mat qDesc(M > 0 ? M : 1, 32, CV_8U);
-    for (int i = 0; i < M; i++) qmp[i]->GetDescriptor().copyTo(qDesc.row(i));
+    for (int i = 0; i < M; i++) descriptor_row(qmp[i], qDesc, i);
     std::vector<uint8_t> taken(N);
     std::vector<float> angle(N);
     for (int i = 0; i < N; i++) {
