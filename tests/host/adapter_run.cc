@@ -282,6 +282,36 @@ int main(int argc, char** argv)
         for (int l = 0; l < 8; l++) { sz.push_back(L->mvImagePyramid[l].cols); sz.push_back(L->mvImagePyramid[l].rows); }
         dump("A_level_sizes.bin", sz.data(), sz.size() * 4);
     }
+    {
+        // what a frame costs through the adapters: the two extractions on two threads (Frame.cc:84-87) and the association (:100),
+        // timed apart (the harness's own copying of the vectors into a Frame is not the reference's and stays outside)
+        std::vector<double> te, ta;
+        for (int f = 0; f < 43; f++) {
+            const cv::Mat fl = roll(imL, 2 * f + 1, 0), fr = roll(imR, 2 * f + 1, 0);
+            std::vector<cv::KeyPoint> kl, kr;
+            cv::Mat dl, dr;
+            const std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+            std::thread tl([&] { (*L)(fl, cv::Mat(), kl, dl); });
+            std::thread tr([&] { (*R)(fr, cv::Mat(), kr, dr); });
+            tl.join();
+            tr.join();
+            const std::chrono::steady_clock::time_point t1 = std::chrono::steady_clock::now();
+            Frame* F = new Frame();
+            fill_frame(*F, L, R, kl, dl, kr, dr);
+            const std::chrono::steady_clock::time_point t2 = std::chrono::steady_clock::now();
+            F->ComputeStereoMatches_Undistorted(false);
+            const std::chrono::steady_clock::time_point t3 = std::chrono::steady_clock::now();
+            delete F;
+            if (f >= 3) {
+                te.push_back(std::chrono::duration<double, std::micro>(t1 - t0).count());
+                ta.push_back(std::chrono::duration<double, std::micro>(t3 - t2).count());
+            }
+        }
+        std::sort(te.begin(), te.end());
+        std::sort(ta.begin(), ta.end());
+        report("A_two_extractions_on_two_threads_us", (long long)(te[te.size() / 2] + 0.5));
+        report("A_ComputeStereoMatches_Undistorted_us", (long long)(ta[ta.size() / 2] + 0.5));
+    }
     if (getenv("GFO_FULL_PYRAMID") && getenv("GFO_FULL_PYRAMID")[0] == '1') {
         // the levels of the LAST frame's left image as operator() left them in mvImagePyramid (Frame.cc:994,1016 read their pixels)
         for (int l = 0; l < 8; l++) {
