@@ -282,6 +282,17 @@ int main(int argc, char** argv)
         for (int l = 0; l < 8; l++) { sz.push_back(L->mvImagePyramid[l].cols); sz.push_back(L->mvImagePyramid[l].rows); }
         dump("A_level_sizes.bin", sz.data(), sz.size() * 4);
     }
+    if (getenv("GFO_FULL_PYRAMID") && getenv("GFO_FULL_PYRAMID")[0] == '1') {
+        // the levels of the LAST frame's left image as operator() left them in mvImagePyramid (Frame.cc:994,1016 read their pixels)
+        for (int l = 0; l < 8; l++) {
+            const cv::Mat& m = L->mvImagePyramid[l];
+            CHECK(!m.empty() && m.step == (size_t)m.cols + 38, "GFO_FULL_PYRAMID: level %d is not a framed view", l);
+            if (m.empty() || m.step != (size_t)m.cols + 38) continue;
+            char nm[64];
+            snprintf(nm, sizeof nm, "A_full_level%d_%dx%d.bin", l, m.cols + 38, m.rows + 38);
+            dump(nm, m.data - 19 * m.step - 19, (size_t)(m.rows + 38) * m.step);
+        }
+    }
     {
         // what a frame costs through the adapters: the two extractions on two threads (Frame.cc:84-87) and the association (:100),
         // timed apart (the harness's own copying of the vectors into a Frame is not the reference's and stays outside)
@@ -311,17 +322,6 @@ int main(int argc, char** argv)
         std::sort(ta.begin(), ta.end());
         report("A_two_extractions_on_two_threads_us", (long long)(te[te.size() / 2] + 0.5));
         report("A_ComputeStereoMatches_Undistorted_us", (long long)(ta[ta.size() / 2] + 0.5));
-    }
-    if (getenv("GFO_FULL_PYRAMID") && getenv("GFO_FULL_PYRAMID")[0] == '1') {
-        // the levels of the LAST frame's left image as operator() left them in mvImagePyramid (Frame.cc:994,1016 read their pixels)
-        for (int l = 0; l < 8; l++) {
-            const cv::Mat& m = L->mvImagePyramid[l];
-            CHECK(!m.empty() && m.step == (size_t)m.cols + 38, "GFO_FULL_PYRAMID: level %d is not a framed view", l);
-            if (m.empty() || m.step != (size_t)m.cols + 38) continue;
-            char nm[64];
-            snprintf(nm, sizeof nm, "A_full_level%d_%dx%d.bin", l, m.cols + 38, m.rows + 38);
-            dump(nm, m.data - 19 * m.step - 19, (size_t)(m.rows + 38) * m.step);
-        }
     }
     report("contexts_created_by_two_extractors_and_their_engine", (long long)(gfo_contexts_created() - created_before));
     report("contexts_created_in_steady_state", (long long)(gfo_contexts_created() - created_mid));
