@@ -160,10 +160,11 @@ void ORBextractor::operator()(cv::InputArray _image, cv::InputArray /*_mask*/, s
     if (n == 0) {
         _descriptors.release();
     } else if (n < cap) {
-        cv::Mat exact(n, 32, CV_8U);                       // the reference hands back exactly n rows (:1137)
-        memcpy(exact.data, desc.data, (size_t)n * 32);
+        // the reference hands back exactly n rows (:1137).  `desc` keeps the cap-row block alive (a header sharing its storage) while
+        // create() gives the output its own n-row block: one copy, no temporary
         _descriptors.create(n, 32, CV_8U);
-        memcpy(_descriptors.getMat().data, exact.data, (size_t)n * 32);
+        cv::Mat exact = _descriptors.getMat();
+        if (exact.data != desc.data) memcpy(exact.data, desc.data, (size_t)n * 32);
     }
     if (full_pyramid()) {
         fetch_pyramid(c, mvImagePyramid, mvInvScaleFactor, nlevels, image.cols, image.rows);
