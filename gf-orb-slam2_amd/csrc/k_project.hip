@@ -167,12 +167,26 @@ __global__ __launch_bounds__(1024) void k_proj_grid(ProjB a)
         const int fy = min(max((int)floorf((y - a.fb.min_y) * a.sinv_h), 0), SG_ROWS - 1);
         return fx * SG_ROWS + fy;
     };
-    for (int i = tid; i < n; i += 1024) {
-        // Frame::PosInGrid, Frame.cc:648-658 (round half away from zero): only assigned keypoints can be candidates
-        const int px = (int)roundf((kp[i].x - a.fb.min_x) * a.inv_w);
-        const int py = (int)roundf((kp[i].y - a.fb.min_y) * a.inv_h);
-        if (!(px < 0 || px >= GRID_COLS || py < 0 || py >= GRID_ROWS)) atomicAdd(&s_cnt[scan_cell(kp[i].x, kp[i].y)], 1);
+    // the first 4096 keypoints stay in registers between the counting and the filling pass (four a thread): on a host-array call they
+    // are read from the pinned block over PCIe (kp_grid), and once is enough
+    float kx[4], ky[4];
+    int ko[4];
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        const int i = tid + r * 1024;
+        kx[r] = ky[r] = 0.f; ko[r] = 0;
+        if (i < n) { kx[r] = kp[i].x; ky[r] = kp[i].y; ko[r] = kp[i].octave; }
     }
+    // Frame::PosInGrid, Frame.cc:648-658 (round half away from zero): only assigned keypoints can be candidates
+    auto count_one = [&](float x, float y) {
+        const int px = (int)roundf((x - a.fb.min_x) * a.inv_w);
+        const int py = (int)roundf((y - a.fb.min_y) * a.inv_h);
+        if (!(px < 0 || px >= GRID_COLS || py < 0 || py >= GRID_ROWS)) atomicAdd(&s_cnt[scan_cell(x, y)], 1);
+    };
+#pragma unroll
+    for (int r = 0; r < 4; r++)
+        if (tid + r * 1024 < n) count_one(kx[r], ky[r]);
+    for (int i = tid + 4096; i < n; i += 1024) count_one(kp[i].x, kp[i].y);
     __syncthreads();
     // exclusive scan of 12288 counters: 12 per thread
     int loc[NSG / 1024], s = 0;
@@ -188,16 +202,19 @@ __global__ __launch_bounds__(1024) void k_proj_grid(ProjB a)
     }
     if (tid == 1023) cell_start[NSG] = run;
     __syncthreads();
-    for (int i = tid; i < n; i += 1024) {
-        const gfo_keypoint k = kp[i];
-        const int px = (int)roundf((k.x - a.fb.min_x) * a.inv_w);
-        const int py = (int)roundf((k.y - a.fb.min_y) * a.inv_h);
-        if (px < 0 || px >= GRID_COLS || py < 0 || py >= GRID_ROWS) continue;
-        const int slot = atomicAdd(&s_cnt[scan_cell(k.x, k.y)], 1);
-        cell_xy[slot] = make_float2(k.x, k.y);
+    auto fill_one = [&](int i, float x, float y, int octave) {
+        const int px = (int)roundf((x - a.fb.min_x) * a.inv_w);
+        const int py = (int)roundf((y - a.fb.min_y) * a.inv_h);
+        if (px < 0 || px >= GRID_COLS || py < 0 || py >= GRID_ROWS) return;
+        const int slot = atomicAdd(&s_cnt[scan_cell(x, y)], 1);
+        cell_xy[slot] = make_float2(x, y);
         // octaves outside 0..15 cannot come out of the extractor (GFO_MAX_LEVELS); host arrays are checked at the ABI
-        cell_meta[slot] = (unsigned)i | ((unsigned)(k.octave & 0xF) << 16) | ((unsigned)px << 20) | ((unsigned)py << 26);
-    }
+        cell_meta[slot] = (unsigned)i | ((unsigned)(octave & 0xF) << 16) | ((unsigned)px << 20) | ((unsigned)py << 26);
+    };
+#pragma unroll
+    for (int r = 0; r < 4; r++)
+        if (tid + r * 1024 < n) fill_one(tid + r * 1024, kx[r], ky[r], ko[r]);
+    for (int i = tid + 4096; i < n; i += 1024) fill_one(i, kp[i].x, kp[i].y, kp[i].octave);
 }
 
 __device__ __forceinline__ int hamming_u4(const uint4 a0, const uint4 a1, const uint4* __restrict__ b)
