@@ -1,6 +1,6 @@
 """Randomised parity sweep (not part of the test suite: minutes of GPU + oracle time): random image sizes,
 extractor parameters and image statistics, GPU extraction vs the oracle, bit for bit; both pyramid paths.
-usage: python tools/fuzz_parity.py [cases] [seed]"""
+usage: python tools/fuzz_parity.py [cases] [seed] [max_w max_h]"""
 import os
 import sys
 import time
@@ -15,11 +15,12 @@ from oracle import orb_oracle as O
 O.build()
 cases = int(sys.argv[1]) if len(sys.argv) > 1 else 200
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+MAX_W, MAX_H = (int(sys.argv[3]), int(sys.argv[4])) if len(sys.argv) > 4 else (1300, 900)   # exclusive upper bounds of the image size
 bad = 0
 t0 = time.time()
 for it in range(cases):
-    w = int(rng.integers(64, 1300))
-    h = int(rng.integers(48, 900))
+    w = int(rng.integers(64, MAX_W))
+    h = int(rng.integers(48, MAX_H))
     nf = int(rng.choice([50, 300, 1000, 2000, 4000]))
     sf = float(rng.choice([1.1, 1.2, 1.2, 1.2, 1.3, 1.5, 2.0]))
     nl = int(rng.integers(1, 11 if sf < 1.4 else 5))
