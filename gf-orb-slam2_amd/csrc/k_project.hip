@@ -703,14 +703,20 @@ __global__ __launch_bounds__(1024) void k_proj_resolve(ProjB a)
             c0[r] = make_uint4(0, 0, 0, 0);
             if (t < nlive) { lv[r] = live[t]; pk[r] = pick[t]; c0[r] = cand[2 * t]; }
         }
+        // two claim tables, used in turn (the second one is the score table's place, idle until the epilogue): the table of the next
+        // round is cleared while this round's is being read -- two barriers a round instead of three
+        int* const tab_a = tab;
+        int* const tab_b = sc;
+        for (int k = tid; k < n; k += 1024) tab[k] = 0x7FFFFFFF;
+        __syncthreads();
         for (;;) {
             rounds++;
-            for (int k = tid; k < n; k += 1024) tab[k] = 0x7FFFFFFF;
-            __syncthreads();
 #pragma unroll
             for (int r = 0; r < PJ_RR; r++)
                 if ((lv[r] & 0x80000000u) && pk[r] >= 0) atomicMin(&tab[pk[r]], (int)(lv[r] & 0x7FFFFFFFu));
             __syncthreads();
+            int* const tab_next = tab == tab_a ? tab_b : tab_a;
+            for (int k = tid; k < n; k += 1024) tab_next[k] = 0x7FFFFFFF;
             int changed = 0;
             unsigned redo = 0;   // slots whose cache ran out: rescanned below, ONE inlined copy of the grid scan
 #pragma unroll
@@ -741,7 +747,9 @@ __global__ __launch_bounds__(1024) void k_proj_resolve(ProjB a)
                 if (tid == 0) a.counters[f * PJ_CNT + PJ_ERR] = 1;
                 break;
             }
+            tab = tab_next;
         }
+        tab = tab_a;
 #pragma unroll
         for (int r = 0; r < PJ_RR; r++) {   // the epilogue below reads them back with the same thread
             const int t = tid + r * 1024;
