@@ -39,9 +39,6 @@
 //   BUDGETING_FEATURE_MATCHING (include/ORBmatcher.h:36, off by default): SearchByBoW / SearchByProjection(Cur, Last) stop after
 //     MAX_NUM_FEATURE_MATCHING accepted matches (src/ORBmatcher.cc:360, 1547-1552) -- an order-dependent early exit.
 // Build those configurations with the reference's own bodies (leave the corresponding GFO_ADAPTER_* guard off).
-#if defined(DELAYED_STEREO_MATCHING) && defined(GFO_ADAPTER_STEREO)
-#error "adapter/matchers_gfo.cc: GFO_ADAPTER_STEREO does not reproduce DELAYED_STEREO_MATCHING (Frame.cc:1186-1199); keep the reference's Frame::ComputeStereoMatches_Undistorted in that build"
-#endif
 #if defined(BUDGETING_FEATURE_MATCHING) && (defined(GFO_ADAPTER_PROJ_LAST) || defined(GFO_ADAPTER_BOW))
 #error "adapter/matchers_gfo.cc: GFO_ADAPTER_PROJ_LAST / GFO_ADAPTER_BOW do not reproduce BUDGETING_FEATURE_MATCHING (ORBmatcher.cc:360, 1547-1552); keep the reference's bodies in that build"
 #endif
@@ -124,23 +121,63 @@ inline const uint8_t* rows32(const cv::Mat& m, cv::Mat& keep)
 
 // ---------------------------------------------------------------------------------------------------------------
 #ifdef GFO_ADAPTER_STEREO
-// isOnline (without DELAYED_STEREO_MATCHING, refused above): the reference's outlier cut is under `if (!isOnline)` (Frame.cc:1290),
-// so an online call keeps every accepted match.  The library always cuts; the entries the cut cleared are restored below with
-// the reference's own expressions (:1271-1281) from the match index the library returns.
+// The member keeps state between calls on one frame, as the reference's does: mvuRight / mvDepth / mvStereoMatched / mvDistIdx are
+// reset only by PrepareStereoCandidates, which runs only when `mvRowIndices.size() != nRows` (Frame.cc:1173-1176, Frame.h:230-263).
+//   * first call on a frame (every Frame constructor, Frame.cc:100,198): state reset, the library's answer IS the member's;
+//   * a later call on the same frame (Tracking.cc:941-954 in the default build, after map points narrowed the windows; every call
+//     of a DELAYED_STEREO_MATCHING build after the caller's own PrepareStereoCandidates, Tracking.cc:613,649,681): a keypoint the
+//     call does not match KEEPS what it had, every accepted match is appended to mvDistIdx (:1282), and the outlier cut runs over
+//     the accumulated list (:1290-1313; entries an earlier call cut are still in it, nmatched goes down for each, duplicates
+//     included).  The library answers "this call on a fresh frame" and returns the accepted matches BEFORE its own cut
+//     (best_dist / best_idx); the member's state is derived from those here, with the reference's own expressions (:1271-1281).
+//   * isOnline: no cut at all (`if (!isOnline)`, :1290).
+//   * DELAYED_STEREO_MATCHING (:1186-1199): the online call visits only unvisited keypoints that carry a map point, the offline
+//     call the other unvisited ones; a keypoint that is not visited gets an empty disparity window (nothing can match it and the
+//     library does not count it).
+// mvRowIndices itself is read by nothing else in a build without DELAYED_STEREO_MATCHING (ComputeStereoMatch_OnePoint returns
+// before it, :1086), so it is only SIZED there -- the flag the reference tests; -DGFO_ADAPTER_FULL_ROW_INDEX (implied by
+// DELAYED_STEREO_MATCHING, whose Observability.cc:995,1259 read the lists) runs the reference's own PrepareStereoCandidates instead.
 int Frame::ComputeStereoMatches_Undistorted(bool isOnline)
 {
     const int nRows = mpORBextractorLeft->mvImagePyramid[0].rows;
-    mvuRight.assign(N, -1.0f);
-    mvDepth.assign(N, -1.0f);
-    mvStereoMatched.assign(N, true);
-    mvDistIdx.clear();
+    const bool first = mvRowIndices.size() != (size_t)nRows;     // :1173
+    if (first) {
+#if defined(GFO_ADAPTER_FULL_ROW_INDEX) || defined(DELAYED_STEREO_MATCHING)
+        PrepareStereoCandidates();
+#else
+        mvuRight.assign(N, -1.0f);
+        mvDepth.assign(N, -1.0f);
+        mvStereoMatched.assign(N, false);
+        mvRowIndices.assign(nRows, std::vector<size_t>());
+        mvDistIdx.reserve(N);
+        mvDistIdx.clear();
+#endif
+    }
+    if ((int)mvuRight.size() != N) mvuRight.resize(N, -1.0f);    // (the reference would index past the end)
+    if ((int)mvDepth.size() != N) mvDepth.resize(N, -1.0f);
+    if ((int)mvStereoMatched.size() != N) mvStereoMatched.resize(N, false);
+
     std::vector<float> minD, maxD;
     bool windows = false;                      // Frame.cc:1220-1231: per-keypoint disparity window
+#ifdef DELAYED_STEREO_MATCHING
+    std::vector<uint8_t> visit(N);
+    for (int iL = 0; iL < N; iL++) {           // :1186-1199
+        visit[iL] = isOnline ? (mvpMapPoints[iL] != NULL && !mvStereoMatched[iL]) : !mvStereoMatched[iL];
+        if (!visit[iL]) windows = true;
+    }
+#endif
     for (int iL = 0; iL < N && !windows; iL++) windows = mvpMapPoints[iL] != NULL;
     if (windows) {
         minD.assign(N, 0.f);
         maxD.assign(N, mbf / mb);
         for (int iL = 0; iL < N; iL++) {
+#ifdef DELAYED_STEREO_MATCHING
+            if (!visit[iL]) {                  // uL - minD < mnMinX whatever uL: not visited, not counted (:1235)
+                minD[iL] = 3.0e38f;
+                maxD[iL] = -3.0e38f;
+                continue;
+            }
+#endif
             MapPoint* pMP = mvpMapPoints[iL];
             if (!pMP || pMP->isBad()) continue;
             cv::Mat Pw = pMP->GetWorldPos(), Pc;
@@ -150,6 +187,11 @@ int Frame::ComputeStereoMatches_Undistorted(bool isOnline)
             maxD[iL] = std::min(disp + float(DISPARITY_THRES), float(mbf) / float(mb));
         }
     }
+#ifdef DELAYED_STEREO_MATCHING
+    for (int iL = 0; iL < N; iL++) if (visit[iL]) mvStereoMatched[iL] = true;   // :1203
+#else
+    mvStereoMatched.assign(N, true);
+#endif
     gfo_stereo_params p = {nRows, mbf, mb, mnMinX};
     std::vector<int32_t> bestDist(N), bestIdx(N);
     int nmatched = 0;
@@ -160,34 +202,60 @@ int Frame::ComputeStereoMatches_Undistorted(bool isOnline)
     // device as one stereo submission that also computes this association, and the call below -- on rectified input, where
     // mvKeysUn == mvKeys -- is answered from it (gfo_ctx_pair: a hint, idempotent, a few nanoseconds when nothing changed)
     if (c && use_r.c) (void)gfo_ctx_pair(c, use_r.c, &p);
+    const bool direct = first && !isOnline;    // a fresh frame, offline: the library's arrays are the member's
+    std::vector<float> ur, dp;
+    if (!direct) { ur.resize(N); dp.resize(N); }
+    float* const outU = direct ? mvuRight.data() : ur.data();
+    float* const outD = direct ? mvDepth.data() : dp.data();
     const int rc = gfo_stereo_match(c, as_gfo(mvKeysUn), rows32(mDescriptors, keepL), N, as_gfo(mvKeysRightUn),
                                     rows32(mDescriptorsRight, keepR), (int)mvKeysRightUn.size(), mvScaleFactors.data(),
                                     (int)mvScaleFactors.size(), &p, windows ? minD.data() : NULL, windows ? maxD.data() : NULL,
-                                    mvuRight.data(), mvDepth.data(), bestDist.data(), bestIdx.data(), &nmatched);
+                                    outU, outD, bestDist.data(), bestIdx.data(), &nmatched);
     if (rc != GFO_OK) {
         report(c, "ComputeStereoMatches_Undistorted");
+        if (direct) { mvuRight.assign(N, -1.0f); mvDepth.assign(N, -1.0f); }
         return 0;
     }
-    for (int iL = 0; iL < N; iL++)             // rebuild mvDistIdx as :1281 fills it
-        if (bestDist[iL] >= 0) mvDistIdx.push_back(std::pair<int, int>(bestDist[iL], iL));
-    if (isOnline) {
-        for (int iL = 0; iL < N; iL++) {
-            if (bestDist[iL] < 0 || mvuRight[iL] >= 0) continue;          // not accepted, or not cut
+    if (direct) {
+        for (int iL = 0; iL < N; iL++)         // mvDistIdx as :1282 fills it, :1296 sorts it
+            if (bestDist[iL] >= 0) mvDistIdx.push_back(std::pair<int, int>(bestDist[iL], iL));
+        std::sort(mvDistIdx.begin(), mvDistIdx.end());
+        return nmatched;
+    }
+    // the library counted as the reference does for ONE fresh call: keypoints that reach the end of the loop body (:1287), minus
+    // one per entry of its own cut; the member's count starts from the former
+    for (int iL = 0; iL < N; iL++) {
+        if (bestDist[iL] < 0) continue;        // nothing accepted for this keypoint: it keeps what it had
+        if (dp[iL] >= 0) {                     // accepted and not cut by the library (an accepted match has depth > 0)
+            mvuRight[iL] = ur[iL];
+            mvDepth[iL] = dp[iL];
+        } else {                               // accepted, cleared by the library's cut: :1271-1281
+            nmatched++;
             const float uL = mvKeysUn[iL].pt.x;
-            float bestuR = mvKeysRightUn[bestIdx[iL]].pt.x;                // :1271
+            float bestuR = mvKeysRightUn[bestIdx[iL]].pt.x;
             float disparity = uL - bestuR;
-            if (disparity <= 0) {                                          // :1275-1279
+            if (disparity <= 0) {
                 disparity = 0.01;
                 bestuR = uL - 0.01;
             }
             mvDepth[iL] = mbf / disparity;
             mvuRight[iL] = bestuR;
-            nmatched++;
         }
-        return nmatched;                       // (an online call leaves mvDistIdx unsorted, as the reference does)
+        mvDistIdx.push_back(std::pair<int, int>(bestDist[iL], iL));            // :1282
     }
-    std::sort(mvDistIdx.begin(), mvDistIdx.end());   // :1296
-    return nmatched;
+    if (!isOnline) {                           // :1290-1313 over everything the frame has accumulated
+        if (mvDistIdx.empty()) return nmatched;
+        std::sort(mvDistIdx.begin(), mvDistIdx.end());
+        const float median = mvDistIdx[mvDistIdx.size() / 2].first;
+        const float thDist = 1.5f * 1.4f * median;
+        for (int i = (int)mvDistIdx.size() - 1; i >= 0; i--) {
+            if (mvDistIdx[i].first < thDist) break;
+            mvuRight[mvDistIdx[i].second] = -1;
+            mvDepth[mvDistIdx[i].second] = -1;
+            nmatched--;
+        }
+    }
+    return nmatched;                           // (an online call leaves mvDistIdx unsorted, as the reference does)
 }
 #endif
 

@@ -978,6 +978,167 @@ int orc_stereo_match(const orc_keypoint* kl, const uint8_t* dl, int nl,
 }
 
 /* ------------------------------------------------------------------------------------------
+ * The stereo MEMBERS of one Frame across several calls -- Frame.h:230-263,335-339, Frame.cc:1167-1316.
+ * orc_stereo_match above is one call on a fresh frame.  The reference's member keeps state between calls on one frame:
+ * mvuRight / mvDepth / mvStereoMatched / mvDistIdx are reset ONLY inside PrepareStereoCandidates, which the member runs only
+ * when `mvRowIndices.size() != nRows` (:1173-1176).  Tracking.cc:941-954 (default build: ALTER_STEREO_MATCHING on, DELAYED off,
+ * ORB_SLAM_BASELINE off) calls it a second time on mCurrentFrame after map points narrowed the windows: a keypoint whose narrowed
+ * window rejects its match KEEPS the first call's uRight / depth, every accepted match is appended to mvDistIdx again (:1282), the
+ * list is sorted and cut as a whole (:1296-1313; entries the first call cut are still in it), and nmatched is decremented for
+ * every cut entry, duplicates included.  This object is that state, literally; `delayed` != 0 is the member compiled with
+ * DELAYED_STEREO_MATCHING (:1186-1199: the online call visits only unvisited keypoints that carry a map point, the offline call
+ * the other unvisited ones).
+ * ---------------------------------------------------------------------------------------- */
+struct orc_stereo_frame {
+    int n;                 /* N */
+    float* u_right;        /* mvuRight */
+    float* depth;          /* mvDepth */
+    unsigned char* matched;/* mvStereoMatched */
+    dist_idx* di;          /* mvDistIdx */
+    int ndi, cap_di;
+    int rows;              /* mvRowIndices.size() */
+    int* start;            /* mvRowIndices as CSR: each row keeps insertion order by iR */
+    int* items;
+};
+
+orc_stereo_frame* orc_stereo_frame_new(void) { return (orc_stereo_frame*)calloc(1, sizeof(orc_stereo_frame)); }
+
+void orc_stereo_frame_free(orc_stereo_frame* s)
+{
+    if (!s) return;
+    free(s->u_right); free(s->depth); free(s->matched); free(s->di); free(s->start); free(s->items);
+    free(s);
+}
+
+/* Frame::PrepareStereoCandidates -- Frame.h:230-263 */
+void orc_stereo_frame_prepare(orc_stereo_frame* s, int nl, const orc_keypoint* kr, int nr, const float* scale_factors, int nRows)
+{
+    free(s->u_right); free(s->depth); free(s->matched); free(s->start); free(s->items);
+    s->n = nl;
+    s->u_right = (float*)malloc(sizeof(float) * (nl > 0 ? nl : 1));
+    s->depth = (float*)malloc(sizeof(float) * (nl > 0 ? nl : 1));
+    s->matched = (unsigned char*)calloc((size_t)(nl > 0 ? nl : 1), 1);
+    for (int i = 0; i < nl; i++) { s->u_right[i] = -1.0f; s->depth[i] = -1.0f; }
+    s->rows = nRows;
+    s->start = (int*)calloc((size_t)nRows + 1, sizeof(int));
+    int* minr_a = (int*)malloc(sizeof(int) * (nr > 0 ? nr : 1));
+    int* maxr_a = (int*)malloc(sizeof(int) * (nr > 0 ? nr : 1));
+    for (int iR = 0; iR < nr; iR++) {
+        const float kpY = kr[iR].y;
+        const float r = 2.0f * scale_factors[kr[iR].octave];
+        const float fmaxr = ceilf(kpY + r), fminr = floorf(kpY - r);
+        maxr_a[iR] = (int)((float)(nRows - 1) < fmaxr ? (float)(nRows - 1) : fmaxr);
+        minr_a[iR] = (int)(0.0f > fminr ? 0.0f : fminr);
+        for (int yi = minr_a[iR]; yi <= maxr_a[iR]; yi++) s->start[yi + 1]++;
+    }
+    for (int r = 0; r < nRows; r++) s->start[r + 1] += s->start[r];
+    s->items = (int*)malloc(sizeof(int) * (s->start[nRows] > 0 ? s->start[nRows] : 1));
+    int* fill = (int*)calloc((size_t)(nRows > 0 ? nRows : 1), sizeof(int));
+    for (int iR = 0; iR < nr; iR++)
+        for (int yi = minr_a[iR]; yi <= maxr_a[iR]; yi++) s->items[s->start[yi] + fill[yi]++] = iR;
+    free(fill); free(minr_a); free(maxr_a);
+    s->ndi = 0; /* mvDistIdx.clear() */
+}
+
+/* `mvStereoMatched = vector<bool>(N,false)` of the Frame constructors, AFTER their own association call (Frame.cc:118,216) */
+void orc_stereo_frame_clear_matched(orc_stereo_frame* s)
+{
+    if (s->matched) memset(s->matched, 0, (size_t)(s->n > 0 ? s->n : 1));
+}
+
+static void stereo_frame_push(orc_stereo_frame* s, int dist, int il)
+{
+    if (s->ndi == s->cap_di) {
+        s->cap_di = s->cap_di ? 2 * s->cap_di : 1024;
+        s->di = (dist_idx*)realloc(s->di, sizeof(dist_idx) * (size_t)s->cap_di);
+    }
+    s->di[s->ndi].dist = dist;
+    s->di[s->ndi].il = il;
+    s->ndi++;
+}
+
+/* Frame::ComputeStereoMatches_Undistorted(isOnline) -- Frame.cc:1167-1316.  has_mp[iL] = (mvpMapPoints[iL] != NULL), NULL = none;
+ * min_d / max_d = the window of :1220-1231 per keypoint (NULL = 0 and mbf/mb everywhere), as the adapter flattens it. */
+int orc_stereo_frame_match(orc_stereo_frame* s, const orc_keypoint* kl, const uint8_t* dl, int nl,
+                           const orc_keypoint* kr, const uint8_t* dr, int nr, const float* scale_factors,
+                           const orc_stereo_params* p, const float* min_d_in, const float* max_d_in,
+                           const unsigned char* has_mp, int is_online, int delayed)
+{
+    const int TH_HIGH = 100, TH_LOW = 50;
+    const int thOrbDist = (TH_HIGH + TH_LOW) / 2;
+    const int nRows = p->n_rows;
+    if (s->rows != nRows) orc_stereo_frame_prepare(s, nl, kr, nr, scale_factors, nRows); /* :1173-1176 */
+    const float minZ = p->mb;
+    int nmatched = 0;
+    for (int iL = 0; iL < nl; iL++) {
+        if (delayed) { /* :1186-1199 */
+            if (is_online) {
+                if (!(has_mp && has_mp[iL]) || s->matched[iL]) continue;
+            } else {
+                if (s->matched[iL]) continue;
+            }
+        }
+        float minD = 0;
+        float maxD = p->mbf / minZ;
+        s->matched[iL] = 1;
+        const int levelL = kl[iL].octave;
+        const float vL = kl[iL].y, uL = kl[iL].x;
+        if (vL < 0 || vL > nRows - 1) continue;
+        const int row = (int)vL;
+        const int nC = s->start[row + 1] - s->start[row];
+        if (nC == 0) continue;
+        if (min_d_in && max_d_in) { minD = min_d_in[iL]; maxD = max_d_in[iL]; }
+        const float minU = uL - maxD, maxU = uL - minD;
+        if (maxU < p->min_x) continue;
+        int bestDist = TH_HIGH;
+        int bestIdxR = 0;
+        for (int iC = 0; iC < nC; iC++) {
+            const int iR = s->items[s->start[row] + iC];
+            if (kr[iR].octave < levelL - 1 || kr[iR].octave > levelL + 1) continue;
+            const float uR = kr[iR].x;
+            if (uR >= minU && uR <= maxU) {
+                const int dist = orc_hamming256(dl + (size_t)iL * 32, dr + (size_t)iR * 32);
+                if (dist < bestDist) { bestDist = dist; bestIdxR = iR; }
+            }
+        }
+        if (bestDist < thOrbDist) {
+            float bestuR = kr[bestIdxR].x;
+            float disparity = uL - bestuR;
+            if (disparity >= minD && disparity < maxD) {
+                if (disparity <= 0) { disparity = 0.01f; bestuR = (float)((double)uL - 0.01); }
+                s->depth[iL] = p->mbf / disparity;
+                s->u_right[iL] = bestuR;
+                stereo_frame_push(s, bestDist, iL); /* :1282 */
+            }
+        }
+        nmatched++;
+    }
+    if (!is_online) { /* :1290-1313 */
+        if (s->ndi == 0) return nmatched;
+        qsort(s->di, (size_t)s->ndi, sizeof(dist_idx), dist_idx_cmp);
+        const float median = (float)s->di[s->ndi / 2].dist;
+        const float thDist = 1.5f * 1.4f * median;
+        for (int i = s->ndi - 1; i >= 0; i--) {
+            if ((float)s->di[i].dist < thDist) break;
+            s->u_right[s->di[i].il] = -1;
+            s->depth[s->di[i].il] = -1;
+            nmatched--;
+        }
+    }
+    return nmatched;
+}
+
+int orc_stereo_frame_n(const orc_stereo_frame* s) { return s->n; }
+const float* orc_stereo_frame_uright(const orc_stereo_frame* s) { return s->u_right; }
+const float* orc_stereo_frame_depth(const orc_stereo_frame* s) { return s->depth; }
+const unsigned char* orc_stereo_frame_matched(const orc_stereo_frame* s) { return s->matched; }
+int orc_stereo_frame_dist_idx(const orc_stereo_frame* s, int* pairs, int cap)
+{
+    for (int i = 0; i < s->ndi && i < cap; i++) { pairs[2 * i] = s->di[i].dist; pairs[2 * i + 1] = s->di[i].il; }
+    return s->ndi;
+}
+
+/* ------------------------------------------------------------------------------------------
  * Frame grid -- Frame.cc:461-476 (AssignFeaturesToGrid), :648-658 (PosInGrid),
  * :593-646 (GetFeaturesInArea).  FRAME_GRID_COLS=64, FRAME_GRID_ROWS=48 (Frame.h:92-93).
  * ---------------------------------------------------------------------------------------- */

@@ -113,6 +113,25 @@ int orc_stereo_match(const orc_keypoint* kl, const uint8_t* dl, int nl,
                      const float* min_d, const float* max_d,
                      float* u_right, float* depth, int* best_dist, int* best_idx_r);
 
+/* The stereo members of one Frame ACROSS calls (mvuRight, mvDepth, mvStereoMatched, mvDistIdx, mvRowIndices): state is reset only
+ * by PrepareStereoCandidates, which ComputeStereoMatches_Undistorted runs only when mvRowIndices.size() != nRows (Frame.cc:1173-1176);
+ * a second call on the same frame (Tracking.cc:941-954) keeps what it does not overwrite and cuts over the accumulated mvDistIdx.
+ * delayed != 0: the member as compiled with DELAYED_STEREO_MATCHING (Frame.cc:1186-1199).  See orb_oracle.c. */
+typedef struct orc_stereo_frame orc_stereo_frame;
+orc_stereo_frame* orc_stereo_frame_new(void);
+void orc_stereo_frame_free(orc_stereo_frame* s);
+void orc_stereo_frame_prepare(orc_stereo_frame* s, int nl, const orc_keypoint* kr, int nr, const float* scale_factors, int n_rows);
+void orc_stereo_frame_clear_matched(orc_stereo_frame* s);
+int orc_stereo_frame_match(orc_stereo_frame* s, const orc_keypoint* kl, const uint8_t* dl, int nl,
+                           const orc_keypoint* kr, const uint8_t* dr, int nr, const float* scale_factors,
+                           const orc_stereo_params* p, const float* min_d, const float* max_d,
+                           const unsigned char* has_mp, int is_online, int delayed);
+int orc_stereo_frame_n(const orc_stereo_frame* s);
+const float* orc_stereo_frame_uright(const orc_stereo_frame* s);
+const float* orc_stereo_frame_depth(const orc_stereo_frame* s);
+const unsigned char* orc_stereo_frame_matched(const orc_stereo_frame* s);
+int orc_stereo_frame_dist_idx(const orc_stereo_frame* s, int* pairs, int cap);   /* returns mvDistIdx.size(); pairs = (dist, iL) */
+
 /* Frame::ComputeStereoMatches (the SAD sub-pixel variant, Frame.cc:889-1078; compiled out by
  * ALTER_STEREO_MATCHING in the reference's default build).  el / er hold the pyramids of the left and right
  * image (orc_extract / orc_compute_pyramid was run on them); kl/kr are mvKeys / mvKeysRight.

@@ -290,6 +290,73 @@ def stereo_match(kl, dl, kr, dr, scale_factors, n_rows, mbf, mb, min_x=0.0, min_
     return nm, u_right[:nl], depth[:nl], best_dist[:nl], best_idx[:nl]
 
 
+class StereoFrame:
+    """The stereo members of ONE Frame across calls (orc_stereo_frame, orb_oracle.c): mvuRight, mvDepth, mvStereoMatched, mvDistIdx
+    and the row table, reset only by PrepareStereoCandidates (Frame.h:230-263), which ComputeStereoMatches_Undistorted runs only
+    when mvRowIndices.size() != nRows (Frame.cc:1173-1176)."""
+
+    def __init__(self, kl, dl, kr, dr, scale_factors, n_rows, mbf, mb, min_x=0.0, delayed=False):
+        L = lib()
+        vp, i = C.c_void_p, C.c_int
+        L.orc_stereo_frame_new.restype = vp
+        L.orc_stereo_frame_free.argtypes = [vp]
+        L.orc_stereo_frame_prepare.argtypes = [vp, i, vp, i, vp, i]
+        L.orc_stereo_frame_clear_matched.argtypes = [vp]
+        L.orc_stereo_frame_match.argtypes = [vp, vp, vp, i, vp, vp, i, vp, vp, vp, vp, vp, i, i]
+        for nm, rt in (("orc_stereo_frame_uright", C.POINTER(C.c_float)), ("orc_stereo_frame_depth", C.POINTER(C.c_float)),
+                       ("orc_stereo_frame_matched", C.POINTER(C.c_ubyte))):
+            getattr(L, nm).restype = rt
+            getattr(L, nm).argtypes = [vp]
+        L.orc_stereo_frame_dist_idx.argtypes = [vp, vp, i]
+        self.kl = np.ascontiguousarray(kl, dtype=KEYPOINT_DTYPE)
+        self.kr = np.ascontiguousarray(kr, dtype=KEYPOINT_DTYPE)
+        self.dl = np.ascontiguousarray(dl, dtype=np.uint8)
+        self.dr = np.ascontiguousarray(dr, dtype=np.uint8)
+        self.sf = np.ascontiguousarray(scale_factors, dtype=np.float32)
+        self.p = StereoParams(n_rows, mbf, mb, min_x)
+        self.delayed = bool(delayed)
+        self._h = L.orc_stereo_frame_new()
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().orc_stereo_frame_free(self._h)
+            self._h = None
+
+    def prepare(self):
+        """Frame::PrepareStereoCandidates called by the caller itself (Tracking.cc:613,649,681)"""
+        lib().orc_stereo_frame_prepare(self._h, len(self.kl), _p(self.kr), len(self.kr), _p(self.sf), self.p.n_rows)
+
+    def clear_matched(self):
+        """mvStereoMatched = vector<bool>(N,false) of the Frame constructor after its own call (Frame.cc:118)"""
+        lib().orc_stereo_frame_clear_matched(self._h)
+
+    def match(self, min_d=None, max_d=None, has_mp=None, online=False):
+        """one ComputeStereoMatches_Undistorted(online) call; returns (nmatched, mvuRight, mvDepth, mvDistIdx as (k,2) int32)"""
+        if min_d is not None:
+            min_d = np.ascontiguousarray(min_d, np.float32)
+            max_d = np.ascontiguousarray(max_d, np.float32)
+        if has_mp is not None:
+            has_mp = np.ascontiguousarray(has_mp, np.uint8)
+        nl = len(self.kl)
+        nm = lib().orc_stereo_frame_match(self._h, _p(self.kl), _p(self.dl), nl, _p(self.kr), _p(self.dr), len(self.kr), _p(self.sf),
+                                          C.byref(self.p), _p(min_d), _p(max_d), _p(has_mp), 1 if online else 0, 1 if self.delayed else 0)
+        return (nm,) + self.state()
+
+    def state(self):
+        L = lib()
+        nl = len(self.kl)
+        ur = np.ctypeslib.as_array(L.orc_stereo_frame_uright(self._h), (max(nl, 1),))[:nl].copy()
+        dp = np.ctypeslib.as_array(L.orc_stereo_frame_depth(self._h), (max(nl, 1),))[:nl].copy()
+        k = L.orc_stereo_frame_dist_idx(self._h, None, 0)
+        di = np.zeros((max(k, 1), 2), np.int32)
+        L.orc_stereo_frame_dist_idx(self._h, _p(di), k)
+        return ur, dp, di[:k]
+
+    def matched(self):
+        nl = len(self.kl)
+        return np.ctypeslib.as_array(lib().orc_stereo_frame_matched(self._h), (max(nl, 1),))[:nl].copy()
+
+
 def stereo_match_sad(ext_l, ext_r, kl, dl, kr, dr, mbf, mb):
     """Frame::ComputeStereoMatches (SAD variant); ext_l / ext_r are OracleExtractors that extracted the two images."""
     kl = np.ascontiguousarray(kl, dtype=KEYPOINT_DTYPE); kr = np.ascontiguousarray(kr, dtype=KEYPOINT_DTYPE)

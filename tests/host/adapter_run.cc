@@ -7,7 +7,9 @@
 //   B. ORBextractor::ComputePyramid (Frame.cc:182-183) and the 19-px framed levels behind mvImagePyramid;
 //   C. delete + new at one address (Tracking::updateORBExtractor, src/Tracking.cc:298-320), an empty image (ORBextractor.cc:1115-1116),
 //      an image without a corner (:1133-1134);
-//   D. the disparity-window form of the stereo association (Frame.cc:1220-1231: frames that carry map points);
+//   D. the disparity-window form of the stereo association (Frame.cc:1220-1231: frames that carry map points) as the SECOND call
+//      on a frame (Tracking.cc:941-954: state kept, mvDistIdx accumulated, Frame.cc:1173-1176), a third online call, the same
+//      windows on a fresh frame, and a call after the caller's own PrepareStereoCandidates;
 //   G. the online form of the association, ComputeStereoMatches_Undistorted(true): no outlier cut (Frame.cc:1290);
 //   E. ORBmatcher::SearchByProjection(Frame&, vector<MapPoint*>&, th) (ORBmatcher.cc:155-241);
 //   F. ORBmatcher::SearchByProjection(CurrentFrame, LastFrame, th, bMono, numVisible) (ORBmatcher.cc:1440-1593), including the
@@ -424,8 +426,30 @@ int main(int argc, char** argv)
                 owned.push_back(mp);
                 F.mvpMapPoints[i] = mp;
             }
+            // kept[2] already holds the association of its constructor's call (part A): THIS is the second call on one frame that
+            // Tracking.cc:941-954 makes once map points have narrowed the windows -- nothing is reset (Frame.cc:1173-1176), rejected
+            // keypoints keep their first values, mvDistIdx accumulates and is cut as a whole
+            CHECK(F.mvRowIndices.size() == (size_t)H, "D: the first call must leave mvRowIndices sized to nRows (%zu)", F.mvRowIndices.size());
+            const size_t before = F.mvDistIdx.size();
             const int ns = F.ComputeStereoMatches_Undistorted(false);
+            CHECK(F.mvDistIdx.size() > before, "D: a second call appends to mvDistIdx (%zu -> %zu)", before, F.mvDistIdx.size());
             dump_stereo("D", 2, F, ns);
+            // D3: a third call on the same frame, online: no cut, nothing reset
+            const int ns3 = F.ComputeStereoMatches_Undistorted(true);
+            dump_stereo("D3", 2, F, ns3);
+            // D2: the same arrays and map points in a NEW frame: the first call of a frame that carries map points
+            Frame* F2 = new Frame();
+            fill_frame(*F2, L, R, F.mvKeys, F.mDescriptors, F.mvKeysRight, F.mDescriptorsRight);
+            F2->SetPose(mat4(reinterpret_cast<const float*>(pose.data())));
+            F2->mvpMapPoints = F.mvpMapPoints;
+            const int ns2 = F2->ComputeStereoMatches_Undistorted(false);
+            dump_stereo("D2", 2, *F2, ns2);
+            // D4: PrepareStereoCandidates called by the caller (Tracking.cc:613,649,681) resets the frame; the member must not reset again
+            F2->PrepareStereoCandidates();
+            CHECK(F2->mvDistIdx.empty() && F2->mvuRight.size() == (size_t)F2->N && F2->mvuRight[0] == -1.0f, "D4: PrepareStereoCandidates resets");
+            const int ns4 = F2->ComputeStereoMatches_Undistorted(false);
+            dump_stereo("D4", 2, *F2, ns4);
+            delete F2;
         }
     }
 

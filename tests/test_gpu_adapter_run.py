@@ -94,7 +94,16 @@ def run(tmp_path_factory, oracle, euroc_l, euroc_r):
     d = (MBF / pc[:, 2]).astype(f32)
     min_d[ok] = np.maximum((d - f32(50.0)).astype(f32), f32(0))[ok]
     max_d[ok] = np.minimum((d + f32(50.0)).astype(f32), f32(MBF / MB))[ok]
-    ref["D"] = oracle.stereo_match(kl, dl, kr, dr, sf, 480, MBF, MB, 0.0, min_d, max_d)
+    # D is the SECOND call on frame 2 (its first was part A's, without windows): the literal member state of the oracle
+    SF = oracle.StereoFrame(kl, dl, kr, dr, sf, 480, MBF, MB)
+    ref["D_first"] = SF.match()
+    ref["D"] = SF.match(min_d, max_d, has.astype(np.uint8))
+    ref["D3"] = SF.match(min_d, max_d, has.astype(np.uint8), online=True)
+    ref["D2"] = oracle.stereo_match(kl, dl, kr, dr, sf, 480, MBF, MB, 0.0, min_d, max_d)        # the same windows on a fresh frame
+    SF4 = oracle.StereoFrame(kl, dl, kr, dr, sf, 480, MBF, MB)
+    SF4.match(min_d, max_d, has.astype(np.uint8))
+    SF4.prepare()
+    ref["D4"] = SF4.match(min_d, max_d, has.astype(np.uint8))
     ref["D_windows_used"] = int(ok.sum())
 
     # G: the online call on frame 0 (no outlier cut)
@@ -372,15 +381,42 @@ def test_extractor_recreated_at_one_address(run, euroc_l, euroc_r):
     assert _rd(run, "C_third_kl.bin", kd).tobytes() == k.tobytes() and _rd(run, "C_third_dl.bin", np.uint8).tobytes() == d.tobytes()
 
 
-def test_stereo_member_with_map_point_windows(run):
-    """Frame.cc:1220-1231: the adapter flattens MapPoint::isBad / GetWorldPos / Frame::WorldToCameraPoint into minD / maxD"""
-    nm, ur, dp, bd, bi = run["D"]
+def _stereo_state_equal(run, tag, want):
+    nm, ur, dp, di = want
+    assert _rd(run, f"{tag}_f02_uright.bin", np.float32).tobytes() == ur.tobytes(), tag
+    assert _rd(run, f"{tag}_f02_depth.bin", np.float32).tobytes() == dp.tobytes(), tag
+    assert _rd(run, f"{tag}_f02_distidx.bin", np.int32).reshape(-1, 2).tolist() == di.tolist(), tag
+    assert int(_rd(run, f"{tag}_f02_nstereo.bin", np.int32)[0]) == nm, tag
+
+
+def test_stereo_member_second_call_on_a_frame_keeps_its_state(run):
+    """Tracking.cc:941-954 calls ComputeStereoMatches_Undistorted a second time on mCurrentFrame once map points narrowed the windows
+    (Frame.cc:1220-1231).  Nothing is reset (mvRowIndices.size() == nRows, :1173-1176): a keypoint whose narrowed window rejects
+    its match keeps the first call's uRight / depth, accepted matches are appended to mvDistIdx (:1282) and the cut runs over the
+    accumulated list (:1290-1313).  Compared with the oracle's literal member state (orc_stereo_frame); a third, online call on the
+    same frame; and the same frame after the caller's own PrepareStereoCandidates (Tracking.cc:613)."""
     assert run["D_windows_used"] > 300
-    assert _rd(run, "D_f02_uright.bin", np.float32).tobytes() == ur.tobytes()
-    assert _rd(run, "D_f02_depth.bin", np.float32).tobytes() == dp.tobytes()
+    first, second, fresh = run["D_first"], run["D"], run["D2"]
+    assert first[1].tobytes() == run["frames"][2][4][1].tobytes()     # the state part A left is the fresh call's
+    _stereo_state_equal(run, "D", second)
+    _stereo_state_equal(run, "D3", run["D3"])
+    _stereo_state_equal(run, "D4", run["D4"])
+    # what makes it a second call: values survive that a fresh frame with the same windows does not have, the list has grown
+    survived = (fresh[1] < 0) & (second[1] >= 0)
+    assert survived.sum() > 20, survived.sum()
+    assert len(second[3]) > len(first[3])
+    assert len(run["D3"][3]) > len(second[3])
+
+
+def test_stereo_member_with_map_point_windows_on_a_fresh_frame(run):
+    """Frame.cc:1220-1231: the adapter flattens MapPoint::isBad / GetWorldPos / Frame::WorldToCameraPoint into minD / maxD; the
+    first call of a frame that already carries map points"""
+    nm, ur, dp, bd, bi = run["D2"]
+    assert _rd(run, "D2_f02_uright.bin", np.float32).tobytes() == ur.tobytes()
+    assert _rd(run, "D2_f02_depth.bin", np.float32).tobytes() == dp.tobytes()
     want = sorted((int(bd[i]), i) for i in range(len(bd)) if bd[i] >= 0)
-    assert [tuple(x) for x in _rd(run, "D_f02_distidx.bin", np.int32).reshape(-1, 2).tolist()] == want
-    assert int(_rd(run, "D_f02_nstereo.bin", np.int32)[0]) == nm
+    assert [tuple(x) for x in _rd(run, "D2_f02_distidx.bin", np.int32).reshape(-1, 2).tolist()] == want
+    assert int(_rd(run, "D2_f02_nstereo.bin", np.int32)[0]) == nm
     assert ur.tobytes() != run["frames"][2][4][1].tobytes()          # the windows changed the association
 
 

@@ -328,6 +328,106 @@ def test_stereo_row_table_equals_predicate_form(oracle):
         np.testing.assert_array_equal(a, b)
 
 
+def _stereo_fixture(oracle, step=1):
+    kd = oracle.KEYPOINT_DTYPE
+    kl = np.fromfile(os.path.join(GOLDEN, "EuRoC_l_kp.bin"), kd)[::step]
+    kr = np.fromfile(os.path.join(GOLDEN, "EuRoC_r_kp.bin"), kd)[::step]
+    dl = np.fromfile(os.path.join(GOLDEN, "EuRoC_l_desc.bin"), np.uint8).reshape(-1, 32)[::step]
+    dr = np.fromfile(os.path.join(GOLDEN, "EuRoC_r_desc.bin"), np.uint8).reshape(-1, 32)[::step]
+    return kl, dl, kr, dr, oracle.OracleExtractor().scale_factors
+
+
+def stereo_second_call_from_fresh_answers(oracle, kl, dl, kr, dr, sf, state, min_d, max_d, mbf, mb, online=False):
+    """What the adapter (adapter/matchers_gfo.cc) derives for a call on a frame that already holds an association, from the
+    answer a FRESH call with the same windows gives (gfo_stereo_match: arrays after its own cut, best_dist / best_idx before it):
+    state = (mvuRight, mvDepth, mvDistIdx) is kept, accepted matches overwrite and are appended, the cut runs over everything."""
+    ur, dp, di = state[0].copy(), state[1].copy(), [tuple(x) for x in state[2].tolist()]
+    nm, ur2, dp2, bd, bi = oracle.stereo_match(kl, dl, kr, dr, sf, 480, mbf, mb, 0.0, min_d, max_d)
+    acc = np.nonzero(bd >= 0)[0]
+    visited = nm + int(((bd >= 0) & (dp2 < 0)).sum())              # the fresh call's count + what its own cut took away
+    for i in acc:
+        uL = kl["x"][i]
+        bu = kr["x"][bi[i]]
+        disp = np.float32(uL - bu)
+        if disp <= 0:
+            disp = np.float32(0.01)
+            bu = np.float32(np.float64(uL) - 0.01)
+        dp[i] = np.float32(mbf) / disp
+        ur[i] = bu
+        di.append((int(bd[i]), int(i)))
+    nmatched = visited
+    if not online and di:
+        di.sort()
+        th = np.float32(1.5) * np.float32(1.4) * np.float32(di[len(di) // 2][0])
+        for d, i in reversed(di):
+            if np.float32(d) < th:
+                break
+            ur[i] = -1
+            dp[i] = -1
+            nmatched -= 1
+    return nmatched, ur, dp, np.array(di, np.int32).reshape(-1, 2)
+
+
+def test_stereo_frame_state_first_call_is_the_fresh_call(oracle):
+    """orc_stereo_frame (the Frame's stereo members across calls): its first call equals orc_stereo_match, offline and online"""
+    kl, dl, kr, dr, sf = _stereo_fixture(oracle)
+    for online in (False, True):
+        ref = oracle.stereo_match(kl, dl, kr, dr, sf, 480, BF, BF / FX, 0.0, online=online)
+        nm, ur, dp, di = oracle.StereoFrame(kl, dl, kr, dr, sf, 480, BF, BF / FX).match(online=online)
+        assert nm == ref[0]
+        np.testing.assert_array_equal(ur, ref[1])
+        np.testing.assert_array_equal(dp, ref[2])
+        want = [(int(ref[3][i]), i) for i in range(len(kl)) if ref[3][i] >= 0]
+        assert sorted(map(tuple, di.tolist())) == sorted(want)
+        if not online:
+            assert [tuple(x) for x in di.tolist()] == sorted(want)         # an offline call leaves mvDistIdx sorted (:1296)
+
+
+def test_stereo_frame_second_call_keeps_state(oracle):
+    """Frame.cc:1173-1176 + Tracking.cc:941-954: a second call on the same frame does not reset; the literal form against the
+    derivation the adapter makes from a fresh call's answer"""
+    kl, dl, kr, dr, sf = _stereo_fixture(oracle)
+    n = len(kl)
+    rng = np.random.default_rng(5)
+    mb = np.float32(BF / FX)
+    F = oracle.StereoFrame(kl, dl, kr, dr, sf, 480, BF, mb)
+    first = F.match()
+    # windows around the first call's disparity for most matched keypoints, a wrong window for some (their match is rejected now
+    # and the first call's value must survive), none for the rest
+    disp = np.where(first[1] >= 0, kl["x"] - first[1], rng.uniform(0, 40, n)).astype(np.float32)
+    has = rng.random(n) < 0.6
+    wrong = has & (rng.random(n) < 0.3)
+    centre = np.where(wrong, disp + 120, disp + rng.normal(0, 20, n)).astype(np.float32)
+    full = np.float32(np.float32(BF) / mb)
+    min_d = np.where(has, np.maximum(centre - 50, 0), 0).astype(np.float32)
+    max_d = np.where(has, np.minimum(centre + 50, full), full).astype(np.float32)
+    state1 = F.state()
+    want = stereo_second_call_from_fresh_answers(oracle, kl, dl, kr, dr, sf, state1, min_d, max_d, BF, mb)
+    got = F.match(min_d, max_d, has.astype(np.uint8))
+    assert got[0] == want[0]
+    np.testing.assert_array_equal(got[1], want[1])
+    np.testing.assert_array_equal(got[2], want[2])
+    np.testing.assert_array_equal(got[3], want[3])
+    # the point of it: this is NOT what a fresh frame would answer with the same windows
+    fresh = oracle.stereo_match(kl, dl, kr, dr, sf, 480, BF, mb, 0.0, min_d, max_d)
+    kept = (fresh[1] < 0) & (got[1] >= 0)
+    assert kept.sum() > 20, kept.sum()
+    assert len(got[3]) > len(state1[2])                                    # mvDistIdx accumulated (:1282)
+    # a third, online call on the same state: no cut, nothing reset
+    state2 = F.state()
+    want3 = stereo_second_call_from_fresh_answers(oracle, kl, dl, kr, dr, sf, state2, min_d, max_d, BF, mb, online=True)
+    got3 = F.match(min_d, max_d, has.astype(np.uint8), online=True)
+    assert got3[0] == want3[0]
+    for a, b in zip(got3[1:], want3[1:]):
+        np.testing.assert_array_equal(a, b)
+    # PrepareStereoCandidates called by the caller (Tracking.cc:613) resets everything: the next call is a first call again
+    F.prepare()
+    again = F.match()
+    assert again[0] == first[0]
+    for a, b in zip(again[1:], first[1:]):
+        np.testing.assert_array_equal(a, b)
+
+
 def bow_python(kd_, ka, valid, kfv, fd, fa, ffv, ratio, ori):
     """SearchByBoW written straight from ORBmatcher.cc:270-404 with Python containers."""
     kmap = {int(n): list(kfv[2][kfv[1][i]:kfv[1][i + 1]]) for i, n in enumerate(kfv[0])}
