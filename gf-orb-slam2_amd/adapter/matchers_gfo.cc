@@ -32,13 +32,12 @@
 #include "MapPoint.h"
 #include "ORBmatcher.h"
 
-// Variants of the reference that these bodies do NOT reproduce are refused at compile time instead of silently ignored:
-//   DELAYED_STEREO_MATCHING (include/Frame.h:40, off by default): the online call of ComputeStereoMatches_Undistorted visits only
-//     keypoints that carry a map point and the offline call only the rest (src/Frame.cc:1186-1199, mvStereoMatched), with
-//     mvDistIdx accumulated across the two calls;
+// Compile-time variants of the reference:
+//   DELAYED_STEREO_MATCHING (include/Frame.h:40, off by default) is reproduced: compile this file with the same macro as the rest of
+//     the tree and ComputeStereoMatches_Undistorted visits what src/Frame.cc:1186-1199 visits (tests/_build/adapter_run_delayed);
 //   BUDGETING_FEATURE_MATCHING (include/ORBmatcher.h:36, off by default): SearchByBoW / SearchByProjection(Cur, Last) stop after
-//     MAX_NUM_FEATURE_MATCHING accepted matches (src/ORBmatcher.cc:360, 1547-1552) -- an order-dependent early exit.
-// Build those configurations with the reference's own bodies (leave the corresponding GFO_ADAPTER_* guard off).
+//     MAX_NUM_FEATURE_MATCHING accepted matches (src/ORBmatcher.cc:360, 1547-1552) -- an order-dependent early exit that these
+//     bodies do NOT reproduce: refused at compile time instead of silently ignored (keep the reference's bodies in that build).
 #if defined(BUDGETING_FEATURE_MATCHING) && (defined(GFO_ADAPTER_PROJ_LAST) || defined(GFO_ADAPTER_BOW))
 #error "adapter/matchers_gfo.cc: GFO_ADAPTER_PROJ_LAST / GFO_ADAPTER_BOW do not reproduce BUDGETING_FEATURE_MATCHING (ORBmatcher.cc:360, 1547-1552); keep the reference's bodies in that build"
 #endif

@@ -225,6 +225,56 @@ static cv::Mat mat4(const float* p)
     return T;
 }
 
+#ifdef DELAYED_STEREO_MATCHING
+// The member as a DELAYED_STEREO_MATCHING build drives it (this file and adapter/matchers_gfo.cc compiled with the macro:
+// tests/_build/adapter_run_delayed).  One frame, in Tracking's order: the constructor leaves mvStereoMatched all false (Frame.cc:118)
+// and makes no association (:99); Tracking calls PrepareStereoCandidates (Tracking.cc:649); after the motion-model search the online
+// call visits the keypoints that carry a map point (:1519-1524); after SearchLocalPoints a second online call visits the ones that got
+// one since (:1587-1589); the offline call takes the rest and cuts over everything (:941-954); one more offline call visits nothing.
+static void delayed_scenario(ORBextractor* L, ORBextractor* R, const cv::Mat& imL, const cv::Mat& imR)
+{
+    const cv::Mat fl = roll(imL, 6, 0), fr = roll(imR, 6, 0);
+    std::vector<cv::KeyPoint> kl, kr;
+    cv::Mat dl, dr;
+    std::thread tl([&] { (*L)(fl, cv::Mat(), kl, dl); });
+    std::thread tr([&] { (*R)(fr, cv::Mat(), kr, dr); });
+    tl.join();
+    tr.join();
+    dump("DD_kl.bin", kl.data(), kl.size() * sizeof(cv::KeyPoint));
+    Frame F;
+    fill_frame(F, L, R, kl, dl, kr, dr);
+    F.mvStereoMatched.assign(F.N, false);
+    struct Rec { int32_t has, bad; float p[3]; };
+    std::vector<uint8_t> raw = slurp(g_in + "/D_windows.bin"), pose = slurp(g_in + "/D_pose.bin"), stg = slurp(g_in + "/DD_stage.bin");
+    const int n = (int)(raw.size() / sizeof(Rec));
+    CHECK(n == F.N && pose.size() == 64 && (int)(stg.size() / 4) == F.N, "DD: %d records for %d keypoints", n, F.N);
+    if (n != F.N || pose.size() != 64 || (int)(stg.size() / 4) != F.N) return;
+    const Rec* r = reinterpret_cast<const Rec*>(raw.data());
+    const int32_t* stage = reinterpret_cast<const int32_t*>(stg.data());
+    F.SetPose(mat4(reinterpret_cast<const float*>(pose.data())));
+    F.PrepareStereoCandidates();
+    std::vector<TestMP*> owned;
+    const char* names[4] = {"DD1", "DD2", "DD3", "DD4"};
+    for (int call = 0; call < 4; call++) {
+        if (call < 2)
+            for (int i = 0; i < n; i++) {
+                if (stage[i] != call + 1) continue;
+                TestMP* mp = new TestMP();
+                mp->world(r[i].p);
+                mp->bad(r[i].bad != 0);
+                owned.push_back(mp);
+                F.mvpMapPoints[i] = mp;
+            }
+        const int ns = F.ComputeStereoMatches_Undistorted(call < 2);
+        dump_stereo(names[call], 2, F, ns);
+        std::vector<uint8_t> m(F.N);
+        for (int i = 0; i < F.N; i++) m[i] = F.mvStereoMatched[i] ? 1 : 0;
+        dump(tag(names[call], 2, "matched"), m.data(), m.size());
+    }
+    for (size_t i = 0; i < owned.size(); i++) delete owned[i];
+}
+#endif
+
 int main(int argc, char** argv)
 {
     if (argc < 4) { fprintf(stderr, "usage: adapter_run <golden_dir> <in_dir> <out_dir> [frames]\n"); return 2; }
@@ -254,6 +304,13 @@ int main(int argc, char** argv)
         t.insert(t.end(), u.begin(), u.end()); t.insert(t.end(), v.begin(), v.end()); t.insert(t.end(), w.begin(), w.end());
         dump("A_tables.bin", t.data(), t.size() * 4);
     }
+#ifdef DELAYED_STEREO_MATCHING
+    delayed_scenario(L, R, imL, imR);
+    report("check_failures", g_fail);
+    delete L;
+    delete R;
+    return g_fail ? 1 : 0;
+#endif
     uint64_t created_mid = 0;
     std::vector<Frame*> kept;
     for (int f = 0; f < NF; f++) {

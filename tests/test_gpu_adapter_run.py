@@ -105,6 +105,15 @@ def run(tmp_path_factory, oracle, euroc_l, euroc_r):
     SF4.prepare()
     ref["D4"] = SF4.match(min_d, max_d, has.astype(np.uint8))
     ref["D_windows_used"] = int(ok.sum())
+    # DD: the same frame as a DELAYED_STEREO_MATCHING build drives it (tests/_build/adapter_run_delayed): map points arrive in two
+    # stages, an online call after each, then two offline calls (Frame.cc:1186-1199)
+    stage = np.where(has, np.where(rng.random(n) < 0.6, 1, 2), 0).astype(np.int32)
+    stage.tofile(ind / "DD_stage.bin")
+    SD = oracle.StereoFrame(kl, dl, kr, dr, sf, 480, MBF, MB, delayed=True)
+    SD.prepare()
+    ref["DD"] = []
+    for has_now, online in ((stage == 1, True), (stage >= 1, True), (stage >= 1, False), (stage >= 1, False)):
+        ref["DD"].append(SD.match(min_d, max_d, has_now.astype(np.uint8), online=online) + (SD.matched(),))
 
     # G: the online call on frame 0 (no outlier cut)
     kl, dl = ref["frames"][0][0], ref["frames"][0][1]
@@ -293,6 +302,10 @@ def run(tmp_path_factory, oracle, euroc_l, euroc_r):
     outd2 = tmp_path_factory.mktemp("adapter_out_full")
     p2 = subprocess.run([EXE, GOLDEN, str(ind), str(outd2), "2"], capture_output=True, text=True, timeout=600, env=dict(env, GFO_FULL_PYRAMID="1"))
     ref["full"] = {"rc": p2.returncode, "stderr": p2.stderr, "out": outd2}
+    outd3 = tmp_path_factory.mktemp("adapter_out_delayed")
+    if os.path.exists(EXE + "_delayed"):
+        p3 = subprocess.run([EXE + "_delayed", GOLDEN, str(ind), str(outd3), "3"], capture_output=True, text=True, timeout=600, env=env)
+        ref["delayed"] = {"rc": p3.returncode, "stderr": p3.stderr, "out": outd3}
     keep = os.path.join(ROOT, "gpurun_out")          # on the GPU box: the program's own report comes back with the call
     if os.path.isdir(keep) and (outd / "report.txt").exists():
         with open(os.path.join(keep, "adapter_run_report.txt"), "w") as fh:
@@ -406,6 +419,30 @@ def test_stereo_member_second_call_on_a_frame_keeps_its_state(run):
     assert survived.sum() > 20, survived.sum()
     assert len(second[3]) > len(first[3])
     assert len(run["D3"][3]) > len(second[3])
+
+
+def test_stereo_member_of_a_delayed_stereo_matching_build(run):
+    """adapter/matchers_gfo.cc + the harness compiled with -DDELAYED_STEREO_MATCHING (include/Frame.h:40): the online call visits only
+    unvisited keypoints that carry a map point, the offline call the other unvisited ones (Frame.cc:1186-1199), state and
+    mvDistIdx run through all four calls of the frame; against the oracle's literal member (orc_stereo_frame, delayed = 1)"""
+    if "delayed" not in run:
+        pytest.skip("tests/_build/adapter_run_delayed is missing (built by __graft_entry__.build() where the reference headers are)")
+    d = run["delayed"]
+    assert d["rc"] == 0, d["stderr"][-3000:]
+    assert "[gfo]" not in d["stderr"], d["stderr"][-2000:]
+    kd = run["oracle"].KEYPOINT_DTYPE
+    assert np.fromfile(d["out"] / "DD_kl.bin", kd).tobytes() == run["frames"][2][0].tobytes()
+    for call, (nm, ur, dp, di, matched) in enumerate(run["DD"]):
+        t = f"DD{call + 1}"
+        assert np.fromfile(d["out"] / f"{t}_f02_uright.bin", np.float32).tobytes() == ur.tobytes(), t
+        assert np.fromfile(d["out"] / f"{t}_f02_depth.bin", np.float32).tobytes() == dp.tobytes(), t
+        assert np.fromfile(d["out"] / f"{t}_f02_distidx.bin", np.int32).reshape(-1, 2).tolist() == di.tolist(), t
+        assert int(np.fromfile(d["out"] / f"{t}_f02_nstereo.bin", np.int32)[0]) == nm, t
+        assert np.fromfile(d["out"] / f"{t}_f02_matched.bin", np.uint8).tobytes() == matched.tobytes(), t
+    n1, n2, n3, n4 = (r[0] for r in run["DD"])
+    assert n1 > 200 and n2 > 100 and n3 > 300                     # every stage visited its share
+    assert n4 <= 0 and run["DD"][3][4].all()                      # the last call visits nothing; its cut only counts down (:1311)
+    assert (run["DD"][0][4].sum() < run["DD"][1][4].sum() < run["DD"][2][4].sum())
 
 
 def test_stereo_member_with_map_point_windows_on_a_fresh_frame(run):
