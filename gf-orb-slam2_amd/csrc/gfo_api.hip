@@ -1628,11 +1628,11 @@ extern "C" int gfo_stereo_match(gfo_ctx* c, const gfo_keypoint* kl, const uint8_
                                 const float* min_d, const float* max_d, float* u_right, float* depth,
                                 int32_t* best_dist, int32_t* best_idx_r, int* nmatched)
 {
-    if (!c || !p || !sf || !u_right || !depth || !nmatched || nl < 0 || nr < 0 || nlevels < 1 || nlevels > GFO_MAX_LEVELS)
+    if (!c || !p || !sf || !u_right || !depth || !nmatched || nl < 0 || nr < 0 || nlevels < 1 || nlevels > GFO_MAX_LEVELS ||
+        (nl > 0 && (!kl || !dl)) || (nr > 0 && (!kr || !dr)) || ((min_d == nullptr) != (max_d == nullptr)))
         return fail(c, GFO_ERR_INVALID, "bad argument");
     if (nr > 65535) return fail(c, GFO_ERR_INVALID, "more than 65535 right keypoints");
-    *nmatched = 0;
-    if (nl == 0) return GFO_OK;
+    if (nl == 0) { *nmatched = 0; return GFO_OK; }
     // a declared stereo rig (gfo_ctx_pair) whose last frame these arrays are, bit for bit: the association was computed with that
     // frame (and arrays this library delivered need no validation)
     if (gfo_has_pair(c) && gfo_pair_lookup(c, kl, dl, nl, kr, dr, nr, sf, nlevels, p, min_d, max_d, u_right, depth, best_dist, best_idx_r, nmatched) == 0)

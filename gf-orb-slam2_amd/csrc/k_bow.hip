@@ -253,6 +253,26 @@ __global__ __launch_bounds__(256) void k_bow_rotation(BowArgs a)
         }                                                                                         \
     } while (0)
 
+// A gfo_feature_vector is the caller's flattening of a DBoW2::FeatureVector (std::map<NodeId, std::vector<unsigned>>): the kernels
+// index the descriptor rows with its items and walk its node ranges, so a stale or damaged one (an mFeatVec of another frame, a
+// keypoint list that shrank) must be refused here instead of reading beside the arrays on the device.  O(items) on the host.
+static const char* bow_check_feature_vector(const gfo_feature_vector* fv, int n)
+{
+    if (fv->n_nodes < 0) return "negative node count";
+    if (fv->n_nodes == 0) return nullptr;
+    if (!fv->node_ids || !fv->node_start) return "null node_ids / node_start";
+    if (fv->node_start[0] != 0) return "node_start[0] must be 0";
+    for (int i = 0; i < fv->n_nodes; i++) {
+        if (fv->node_start[i + 1] < fv->node_start[i]) return "node_start must not decrease";
+        if (i > 0 && fv->node_ids[i] <= fv->node_ids[i - 1]) return "node_ids must ascend strictly (std::map order)";
+    }
+    const int items = fv->node_start[fv->n_nodes];
+    if (items > 0 && !fv->items) return "null items";
+    for (int k = 0; k < items; k++)
+        if (fv->items[k] >= (uint32_t)n) return "an item indexes past the keypoints";
+    return nullptr;
+}
+
 extern "C" int gfo_search_by_bow(gfo_ctx* c, const uint8_t* kf_desc, const float* kf_angle, const uint8_t* kf_mp_valid,
                                  int n_kf, const gfo_feature_vector* kf_fv, const uint8_t* f_desc, const float* f_angle,
                                  int n_f, const gfo_feature_vector* f_fv, float nn_ratio, int check_orientation,
@@ -262,6 +282,22 @@ extern "C" int gfo_search_by_bow(gfo_ctx* c, const uint8_t* kf_desc, const float
     if (!kf_fv || !f_fv || !out_kf_idx || !nmatches || n_kf < 0 || n_f < 0 || (n_kf > 0 && (!kf_desc || !kf_mp_valid)) ||
         (n_f > 0 && !f_desc) || (check_orientation && n_kf > 0 && n_f > 0 && (!kf_angle || !f_angle))) {
         c->err = "gfo_search_by_bow: bad argument";
+        return GFO_ERR_INVALID;
+    }
+    if (check_orientation) {
+        // the rotation histogram is indexed with round((angle_kf - angle_f [+ 360]) / 30) (ORBmatcher.cc:346-355, which asserts the
+        // bin): cv::KeyPoint::angle of oriented keypoints, 0..360 -- anything else would index beside the 30 bins
+        for (int i = 0; i < n_kf; i++)
+            if (!(kf_angle[i] >= 0.f && kf_angle[i] <= 360.f)) { c->err = "gfo_search_by_bow: keyframe keypoint angle outside 0..360"; return GFO_ERR_INVALID; }
+        for (int i = 0; i < n_f; i++)
+            if (!(f_angle[i] >= 0.f && f_angle[i] <= 360.f)) { c->err = "gfo_search_by_bow: frame keypoint angle outside 0..360"; return GFO_ERR_INVALID; }
+    }
+    if (const char* why = bow_check_feature_vector(kf_fv, n_kf)) {
+        c->err = std::string("gfo_search_by_bow: keyframe feature vector: ") + why;
+        return GFO_ERR_INVALID;
+    }
+    if (const char* why = bow_check_feature_vector(f_fv, n_f)) {
+        c->err = std::string("gfo_search_by_bow: frame feature vector: ") + why;
         return GFO_ERR_INVALID;
     }
     *nmatches = 0;

@@ -111,6 +111,23 @@ struct ProjQ {
     bool active, obs;
 };
 
+// float -> int as the reference's x86 build converts (cvttss2si): NaN, the infinities and anything beyond +-2^31 give INT_MIN.
+// (C++ leaves those conversions undefined; gfx950's v_cvt_i32_f32 saturates instead.)
+__device__ __forceinline__ int pj_cvt_x86(float f) { return (f >= 2147483648.f || f < -2147483648.f || f != f) ? (int)0x80000000 : (int)f; }
+
+// The early returns of Frame::GetFeaturesInArea (Frame.cc:602-617) with that conversion: a query whose window arithmetic leaves the
+// int range -- a NaN or infinite projection, a radius of 1e30 -- selects NOTHING in the reference (nMaxCell = min(63, INT_MIN) < 0),
+// where saturating conversions would scan the whole frame.  For every finite window inside the int range this says "empty" only
+// where the window lies wholly beside the grid, which the scan below finds empty as well.
+__device__ __forceinline__ bool pj_ref_window_empty(const ProjB& a, float x, float y, float r)
+{
+    if (max(0, pj_cvt_x86(floorf((x - a.fb.min_x - r) * a.inv_w))) >= GRID_COLS) return true;
+    if (min(GRID_COLS - 1, pj_cvt_x86(ceilf((x - a.fb.min_x + r) * a.inv_w))) < 0) return true;
+    if (max(0, pj_cvt_x86(floorf((y - a.fb.min_y - r) * a.inv_h))) >= GRID_ROWS) return true;
+    if (min(GRID_ROWS - 1, pj_cvt_x86(ceilf((y - a.fb.min_y + r) * a.inv_h))) < 0) return true;
+    return false;
+}
+
 __device__ __forceinline__ ProjQ load_query(const ProjB& a, int f, int iq)
 {
     ProjQ r;
@@ -134,6 +151,7 @@ __device__ __forceinline__ ProjQ load_query(const ProjB& a, int f, int iq)
         r.active = (p.flags & 1) && !(p.flags & 2) && lvl_ok;
         r.obs = (p.flags & 4) != 0;
     }
+    r.active = r.active && !pj_ref_window_empty(a, r.u, r.v, r.radius);
     return r;
 }
 
@@ -991,6 +1009,14 @@ extern "C" int gfo_search_by_projection_queries(gfo_ctx* c, const gfo_keypoint* 
     if (!(fb->max_x > fb->min_x) || !(fb->max_y > fb->min_y)) return pj_fail(c, GFO_ERR_INVALID, "gfo_search_by_projection: empty frame bounds");
     for (int i = 0; i < n; i++)
         if (kp_un[i].octave < 0 || kp_un[i].octave >= GFO_MAX_LEVELS) return pj_fail(c, GFO_ERR_INVALID, "gfo_search_by_projection: keypoint octave outside 0..15");
+    if (mode->check_orientation) {
+        // the rotation histogram is indexed with round((angle_q - angle_kp [+ 360]) / 30) (ORBmatcher.cc:1557-1565, which asserts the
+        // bin): angles are cv::KeyPoint::angle of oriented keypoints, 0..360 -- anything else would index beside the 30 bins
+        for (int i = 0; i < n; i++)
+            if (!(kp_angle[i] >= 0.f && kp_angle[i] <= 360.f)) return pj_fail(c, GFO_ERR_INVALID, "gfo_search_by_projection: keypoint angle outside 0..360");
+        for (int i = 0; i < m; i++)
+            if (!(queries[i].angle >= 0.f && queries[i].angle <= 360.f)) return pj_fail(c, GFO_ERR_INVALID, "gfo_search_by_projection: query angle outside 0..360");
+    }
     *nmatches = 0;
     for (int i = 0; i < n; i++) { out_mp[i] = -1; out_score[i] = 0; }
     if (n == 0 || m == 0) return GFO_OK;

@@ -1151,6 +1151,10 @@ typedef struct {
     float inv_w, inv_h;
 } grid_t;
 
+/* float -> int as the reference's x86 build converts (cvttss2si): NaN, the infinities and anything beyond +-2^31 give INT_MIN.  C
+ * leaves those conversions undefined; stated here so that what a garbage projection does is a definition, not an accident of -O3. */
+static int cvt_x86(float f) { return (f >= 2147483648.f || f < -2147483648.f || f != f) ? (-2147483647 - 1) : (int)f; }
+
 static void grid_build(grid_t* g, const orc_keypoint* kp, int n, const orc_frame_bounds* fb)
 {
     g->inv_w = (float)GRID_COLS / (fb->max_x - fb->min_x); /* Frame.cc:129-130 */
@@ -1159,8 +1163,8 @@ static void grid_build(grid_t* g, const orc_keypoint* kp, int n, const orc_frame
     int* cell = (int*)malloc(sizeof(int) * (n > 0 ? n : 1));
     g->start = (int*)calloc((size_t)ncell + 1, sizeof(int));
     for (int i = 0; i < n; i++) {
-        const int px = (int)roundf((kp[i].x - fb->min_x) * g->inv_w);
-        const int py = (int)roundf((kp[i].y - fb->min_y) * g->inv_h);
+        const int px = cvt_x86(roundf((kp[i].x - fb->min_x) * g->inv_w));
+        const int py = cvt_x86(roundf((kp[i].y - fb->min_y) * g->inv_h));
         if (px < 0 || px >= GRID_COLS || py < 0 || py >= GRID_ROWS) cell[i] = -1;
         else { cell[i] = px * GRID_ROWS + py; g->start[cell[i] + 1]++; }
     }
@@ -1178,16 +1182,16 @@ static int grid_query(const grid_t* g, const orc_keypoint* kp, const orc_frame_b
                       float x, float y, float r, int minLevel, int maxLevel, int* out, int cap)
 {
     int n = 0;
-    int nMinCellX = (int)floorf((x - fb->min_x - r) * g->inv_w);
+    int nMinCellX = cvt_x86(floorf((x - fb->min_x - r) * g->inv_w));
     if (nMinCellX < 0) nMinCellX = 0;
     if (nMinCellX >= GRID_COLS) return 0;
-    int nMaxCellX = (int)ceilf((x - fb->min_x + r) * g->inv_w);
+    int nMaxCellX = cvt_x86(ceilf((x - fb->min_x + r) * g->inv_w));
     if (nMaxCellX > GRID_COLS - 1) nMaxCellX = GRID_COLS - 1;
     if (nMaxCellX < 0) return 0;
-    int nMinCellY = (int)floorf((y - fb->min_y - r) * g->inv_h);
+    int nMinCellY = cvt_x86(floorf((y - fb->min_y - r) * g->inv_h));
     if (nMinCellY < 0) nMinCellY = 0;
     if (nMinCellY >= GRID_ROWS) return 0;
-    int nMaxCellY = (int)ceilf((y - fb->min_y + r) * g->inv_h);
+    int nMaxCellY = cvt_x86(ceilf((y - fb->min_y + r) * g->inv_h));
     if (nMaxCellY > GRID_ROWS - 1) nMaxCellY = GRID_ROWS - 1;
     if (nMaxCellY < 0) return 0;
     const int bCheckLevels = (minLevel > 0) || (maxLevel >= 0);
