@@ -69,7 +69,7 @@ class StageTime(C.Structure):
 
 # every symbol include/gfo.h declares (tests check the library exports all of them)
 SYMBOLS = [
-    "gfo_version", "gfo_ctx_create", "gfo_ctx_destroy", "gfo_last_error", "gfo_ctx_set_stream",
+    "gfo_version", "gfo_build_variant", "gfo_ctx_create", "gfo_ctx_destroy", "gfo_last_error", "gfo_ctx_set_stream",
     "gfo_ctx_synchronize", "gfo_ctx_chain", "gfo_ctx_tables", "gfo_ctx_max_keypoints", "gfo_extract", "gfo_extract_batch",
     "gfo_extract_stereo", "gfo_extract_batch_device", "gfo_batch_counts", "gfo_batch_fetch", "gfo_batch_device_views",
     "gfo_compute_pyramid", "gfo_pyramid_level", "gfo_hamming256", "gfo_stereo_match",
@@ -158,6 +158,7 @@ def load_library():
     ip = C.POINTER(C.c_int)
     L.gfo_version.restype = i
     L.gfo_ctx_create.argtypes = [C.POINTER(Params), i, C.POINTER(vp)]
+    L.gfo_build_variant.argtypes = [i]
     L.gfo_ctx_destroy.argtypes = [vp]
     L.gfo_ctx_destroy.restype = None
     L.gfo_last_error.argtypes = [vp]

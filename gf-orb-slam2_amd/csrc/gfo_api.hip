@@ -179,6 +179,24 @@ static void resize_tables(int ssize, int dsize, int* ofs, short* coef, bool clam
     }
 }
 
+#if GFO_OCV_RESIZE == 1
+// the float variant: the same sample positions, the FRACTION itself (as float bits) instead of the 11-bit pair; both axes clamp
+// (source index into [0, ssize - 1] with fraction 0 at either end), as a float bilinear does
+static void resize_tables_float(int ssize, int dsize, int* ofs, int* frac_bits)
+{
+    const double scale = 1. / ((double)dsize / ssize);
+    for (int d = 0; d < dsize; d++) {
+        float f = (float)((d + 0.5) * scale - 0.5);
+        int s = (int)floorf(f);
+        f -= s;
+        if (s < 0) { f = 0; s = 0; }
+        if (s >= ssize - 1) { f = 0; s = ssize - 1; }
+        ofs[d] = s;
+        memcpy(&frac_bits[d], &f, 4);
+    }
+}
+#endif
+
 int gfo_plan(gfo_ctx* c, int w, int h, int batch)
 {
     if (c->planned && c->g.w0 == w && c->g.h0 == h && batch <= c->cap_batch) return GFO_OK;
@@ -292,6 +310,24 @@ int gfo_plan(gfo_ctx* c, int w, int h, int batch)
         const int dw = g.lv[l].w, dh = g.lv[l].h;
         std::vector<int> ofs(dw > dh ? dw : dh);
         std::vector<short> coef(2 * ofs.size());
+#if GFO_OCV_RESIZE == 1
+        std::vector<int> fb(ofs.size());
+        resize_tables_float(g.lv[l - 1].w, dw, ofs.data(), fb.data());
+        for (int d = 0; d < dw + 3 + 4; d++) {
+            const int s_ = d < dw ? d : dw - 1;
+            if (g.lv[l].xtab_off + d >= xtab_n) break;
+            xtabv[2 * (g.lv[l].xtab_off + d)] = ofs[s_];
+            xtabv[2 * (g.lv[l].xtab_off + d) + 1] = fb[s_];
+        }
+        resize_tables_float(g.lv[l - 1].h, dh, ofs.data(), fb.data());
+        for (int d = 0; d < dh + 3 + 4; d++) {
+            const int s_ = d < dh ? d : dh - 1;
+            if (g.lv[l].ytab_off + d >= ytab_n) break;
+            ytabv[2 * (g.lv[l].ytab_off + d)] = ofs[s_];
+            ytabv[2 * (g.lv[l].ytab_off + d) + 1] = fb[s_];
+        }
+        (void)coef;
+#else
         resize_tables(g.lv[l - 1].w, dw, ofs.data(), coef.data(), true);
         for (int d = 0; d < dw + 3 + 4; d++) {
             const int s_ = d < dw ? d : dw - 1;
@@ -306,6 +342,7 @@ int gfo_plan(gfo_ctx* c, int w, int h, int batch)
             ytabv[2 * (g.lv[l].ytab_off + d)] = ofs[s_];
             ytabv[2 * (g.lv[l].ytab_off + d) + 1] = (int)((unsigned short)coef[2 * s_] | ((unsigned)(unsigned short)coef[2 * s_ + 1] << 16));
         }
+#endif
     }
     // banded pyramid: the levels are cut into groups of consecutive levels, each one launch of k_pyramid_bands
     // (a group of ONE level is an ordinary k_resize launch).  Greedy from level 1: the longest group (up to
@@ -520,6 +557,21 @@ int gfo_plan(gfo_ctx* c, int w, int h, int batch)
 // context
 // ---------------------------------------------------------------------------------------------
 extern "C" int gfo_version(void) { return GFO_VERSION; }
+
+extern "C" int gfo_build_variant(int key)
+{
+    static const int taps[4] = {GFO_GAUSS_TAPS};
+    switch (key) {
+    case 0: return GFO_OCV_RESIZE;
+    case 1: return GFO_OCV_ATAN_FMA;
+    case 2: return GFO_OCV_BLUR_ROUND;
+    case 3: case 9: return taps[0];
+    case 4: case 8: return taps[1];
+    case 5: case 7: return taps[2];
+    case 6: return taps[3];
+    default: return -1;
+    }
+}
 
 extern "C" const char* gfo_last_error(const gfo_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_err.c_str(); }
 

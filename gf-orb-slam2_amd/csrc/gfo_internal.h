@@ -16,6 +16,20 @@
 
 #include "../../include/gfo.h"
 
+// [OCV] build variants (include/gfo.h gfo_build_variant; same values as oracle/ocv_variants.json).  `make EXTRA="-DGFO_OCV_RESIZE=1"`.
+#ifndef GFO_OCV_RESIZE
+#define GFO_OCV_RESIZE 0        // 0: 11-bit fixed-point bilinear (resizeGeneric_), 1: float bilinear, rounded half to even once
+#endif
+#ifndef GFO_OCV_ATAN_FMA
+#define GFO_OCV_ATAN_FMA 0      // 0: fastAtan2's polynomial in separate multiplies and adds, 1: Horner steps fused
+#endif
+#ifndef GFO_OCV_BLUR_ROUND
+#define GFO_OCV_BLUR_ROUND 0    // 0: exact accumulation, one (v + 2^15) >> 16; 1: each pass rounded to 8 bits, (v + 128) >> 8
+#endif
+#ifndef GFO_GAUSS_TAPS
+#define GFO_GAUSS_TAPS 18, 34, 49, 55   // the outer three taps and the centre one, scale 256 (symmetric kernel)
+#endif
+
 #define GFO_EDGE 19          // EDGE_THRESHOLD, ORBextractor.cc:74
 #define GFO_HALF_PATCH 15    // HALF_PATCH_SIZE, ORBextractor.cc:73
 #define GFO_PATCH 31         // PATCH_SIZE, ORBextractor.cc:72

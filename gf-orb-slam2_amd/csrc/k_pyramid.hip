@@ -23,6 +23,15 @@ struct HQuad {
 
 typedef unsigned short gfo_u16x2 __attribute__((ext_vector_type(2)));
 
+#if GFO_OCV_RESIZE == 1
+// the float variant's horizontal step: S[x0] * (1 - fx) + S[x1] * fx in float (un-fused: -ffp-contract=off), kept as float bits
+__device__ __forceinline__ int resize_hlerp(unsigned p0, unsigned p1, int fx_bits)
+{
+    const float fx = __int_as_float(fx_bits);
+    return __float_as_int((float)p0 * (1.f - fx) + (float)p1 * fx);
+}
+#endif
+
 // One source row segment -> the four horizontal sums.
 // `fast`: the 12 bytes at base_x cover every tap.  The window is first shifted so that it starts at sx[0]
 // (two v_alignbyte), after which the byte pair of output k sits at the fixed offsets (rel[k], rel[k]+1) < 8:
@@ -40,16 +49,39 @@ __device__ __forceinline__ HQuad resize_hrow(const uint8_t* __restrict__ row, in
 #pragma unroll
         for (int k = 0; k < 4; k++) {
             const unsigned two = __builtin_amdgcn_perm(B, A, sel[k]);  // {byte rel, 0, byte rel+1, 0}
+#if GFO_OCV_RESIZE == 1
+            q.h[k] = resize_hlerp(two & 0xFFFFu, two >> 16, cw[k]);
+#else
             q.h[k] = (int)__builtin_amdgcn_udot2(__builtin_bit_cast(gfo_u16x2, two), __builtin_bit_cast(gfo_u16x2, (unsigned)cw[k]), 0u, false);
+#endif
         }
     } else {
 #pragma unroll
         for (int k = 0; k < 4; k++) {
             const int s1 = min(sx[k] + 1, sw - 1);
+#if GFO_OCV_RESIZE == 1
+            q.h[k] = resize_hlerp(row[sx[k]], row[s1], cw[k]);
+#else
             q.h[k] = (int)row[sx[k]] * (cw[k] & 0xFFFF) + (int)row[s1] * (int)((unsigned)cw[k] >> 16);
+#endif
         }
     }
     return q;
+}
+
+// One output byte from the horizontal results of its two source rows and the row-table entry.
+//   GFO_OCV_RESIZE 0: VResizeLinear<uchar,int,short>'s (((b0 * (r0 >> 4)) >> 16) + ((b1 * (r1 >> 4)) >> 16) + 2) >> 2 [OCV]
+//   GFO_OCV_RESIZE 1: cvRound(top * (1 - fy) + bot * fy) in float, saturated
+__device__ __forceinline__ unsigned resize_vblend(int bwj, int ha, int hb)
+{
+#if GFO_OCV_RESIZE == 1
+    const float fy = __int_as_float(bwj);
+    const float v = __int_as_float(ha) * (1.f - fy) + __int_as_float(hb) * fy;
+    return (unsigned)min(max(__float2int_rn(v), 0), 255);
+#else
+    const unsigned b0 = bwj & 0xFFFF, b1 = (unsigned)bwj >> 16;
+    return (((__umul24(b0, ha >> 4) >> 16) + (__umul24(b1, hb >> 4) >> 16) + 2u) >> 2) & 255u;   // operands < 2^16
+#endif
 }
 
 // Tables: one int2 per output column / row = {source offset, coef0 | coef1 << 16}; every level's table is
@@ -119,7 +151,6 @@ __device__ __forceinline__ void resize_block(const uint8_t* __restrict__ src, in
         for (int j = 0; j < RS_STRIP; j++) {
             const int dy = dy0 + j;
             if (dy >= dy1) break;
-            const unsigned b0 = bw[j] & 0xFFFF, b1 = (unsigned)bw[j] >> 16;
             const int i0 = min(max(syv[j], 0), sh - 1) - r_first, i1 = min(max(syv[j] + 1, 0), sh - 1) - r_first;
             HQuad ra = rows[0], rb = rows[0];
             // Output row j of the strip blends source rows (i0, i0 + 1) with i0 = j or j + 1 at scale factors up
@@ -166,10 +197,7 @@ __device__ __forceinline__ void resize_block(const uint8_t* __restrict__ src, in
             }
             unsigned packed = 0;
 #pragma unroll
-            for (int k = 0; k < 4; k++) {
-                const unsigned v = ((__umul24(b0, ra.h[k] >> 4) >> 16) + (__umul24(b1, rb.h[k] >> 4) >> 16) + 2u) >> 2;  // operands < 2^16
-                packed |= (v & 255u) << (8 * k);
-            }
+            for (int k = 0; k < 4; k++) packed |= resize_vblend(bw[j], ra.h[k], rb.h[k]) << (8 * k);
             // pitches are multiples of 16: the tail dword stays in-row
             if (!BAND || (dy >= own0 && dy < own1)) *reinterpret_cast<unsigned*>(dstg + (long long)dy * gpitch + dx0) = packed;
             if (BAND && dstl) *reinterpret_cast<unsigned*>(dstl + (dy - lrow0) * lpitch + dx0) = packed;
@@ -180,16 +208,12 @@ __device__ __forceinline__ void resize_block(const uint8_t* __restrict__ src, in
     for (int j = 0; j < RS_STRIP; j++) {  // steep scale factors: row by row
         const int dy = dy0 + j;
         if (dy >= dy1) break;
-        const unsigned b0 = bw[j] & 0xFFFF, b1 = (unsigned)bw[j] >> 16;
         const int sy0 = min(max(syv[j], 0), sh - 1), sy1 = min(max(syv[j] + 1, 0), sh - 1);
         const HQuad r0 = resize_hrow(src + (long long)sy0 * spitch, base_x, fast, sx, sel, cw, sw);
         const HQuad r1 = resize_hrow(src + (long long)sy1 * spitch, base_x, fast, sx, sel, cw, sw);
         unsigned packed = 0;
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const unsigned v = ((__umul24(b0, r0.h[k] >> 4) >> 16) + (__umul24(b1, r1.h[k] >> 4) >> 16) + 2u) >> 2;
-            packed |= (v & 255u) << (8 * k);
-        }
+        for (int k = 0; k < 4; k++) packed |= resize_vblend(bw[j], r0.h[k], r1.h[k]) << (8 * k);
         if (!BAND || (dy >= own0 && dy < own1)) *reinterpret_cast<unsigned*>(dstg + (long long)dy * gpitch + dx0) = packed;
         if (BAND && dstl) *reinterpret_cast<unsigned*>(dstl + (dy - lrow0) * lpitch + dx0) = packed;
     }

@@ -60,6 +60,14 @@ typedef struct {
 typedef struct gfo_ctx gfo_ctx;
 
 int gfo_version(void);
+/* The [OCV] arithmetic variant this library was COMPILED with (`make EXTRA=-DGFO_OCV_RESIZE=1 ...`, csrc/gfo_internal.h): the four
+ * pieces of OpenCV 3.4.1 that ORBextractor.cc:102,1155,1189 call and this library restates -- each a switch with the same values as
+ * oracle/ocv_variants.json, so that a run of tests/golden/check_against_cv2.py on a machine with cv2 3.4.x that names a switch is
+ * answered by a rebuild, not a rewrite.  key 0: resize (0 = 11-bit fixed point, 1 = float bilinear rounded once), 1: fastAtan2's
+ * polynomial (0 = separate multiplies and adds, 1 = fused), 2: GaussianBlur rounding (0 = once, (v + 2^15) >> 16; 1 = each pass to
+ * 8 bits), 3..9: the seven Gaussian taps (scale 256).  Returns -1 for an unknown key.  The default build is all zeros and
+ * {18,34,49,55,49,34,18}. */
+int gfo_build_variant(int key);
 
 /* Creates a context on HIP device `device`.  Arena memory is allocated lazily on the first
  * image (its size fixes the level geometry; a different size re-plans the arena). */

@@ -104,7 +104,11 @@ GFO_HD float gfo_fast_atan2f(float y, float x)
     const int steep = !(ax >= ay);
     const float c = (steep ? ax : ay) / ((steep ? ay : ax) + eps);
     const float c2 = c * c;
+#if defined(GFO_OCV_ATAN_FMA) && GFO_OCV_ATAN_FMA == 1
+    const float pa = fmaf(fmaf(fmaf(p7, c2, p5), c2, p3), c2, p1) * c;   /* a build of OpenCV whose v_fma fuses the Horner steps */
+#else
     const float pa = (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
+#endif
     float a = steep ? 90.f - pa : pa;
     if (x < 0) a = 180.f - a;
     if (y < 0) a = 360.f - a;

@@ -56,6 +56,18 @@ def diff_stats(a, b):
             "max_abs": int(np.abs(a.astype(np.int64) - b.astype(np.int64)).max()) if ne.any() else 0}
 
 
+def KERNEL_LINE(cv):
+    """the rebuild that makes the kernels follow a blur candidate (csrc/gfo_internal.h: GFO_OCV_BLUR_ROUND, GFO_GAUSS_TAPS = the outer
+    three taps and the centre)"""
+    fl = []
+    if "blur_round" in cv:
+        fl.append(f"-DGFO_OCV_BLUR_ROUND={cv['blur_round']}")
+    if "gauss_taps" in cv:
+        t = cv["gauss_taps"]
+        fl.append(f"-DGFO_GAUSS_TAPS={t[0]},{t[1]},{t[2]},{t[3]}")
+    return 'make -C gf-orb-slam2_amd/csrc -B EXTRA="' + " ".join(fl) + '"  (then tools/check_variant.py compares that build with the like-switched oracle)'
+
+
 def main():
     try:
         import cv2
@@ -101,7 +113,7 @@ def main():
         match = [v for v, (b, _) in per_variant.items() if b == 0]
         stage(f"resize/{iname}", per_variant[cur][0] == 0,
               {"differing_px_levels_1_7": per_variant[cur][0], "max_abs": per_variant[cur][1], "per_variant": {str(k): v[0] for k, v in per_variant.items()}},
-              f'set "resize": {match[0]} in oracle/ocv_variants.json' if match else "no variant of the table matches: restate cv::resize from this build's sources")
+              (f'set "resize": {match[0]} in oracle/ocv_variants.json; kernels: make -C gf-orb-slam2_amd/csrc -B EXTRA="-DGFO_OCV_RESIZE={match[0]}"') if match else "no variant of the table matches: restate cv::resize from this build's sources")
 
     # ---- copyMakeBorder(BORDER_REFLECT_101), ORBextractor.cc:1191-1197 ----
     print("copyMakeBorder (REFLECT_101, 19 px):")
@@ -134,7 +146,7 @@ def main():
         O.set_ocv_variants(**committed)
         match = [c for c, b in results.items() if b == 0]
         stage(f"blur/{iname}", results["committed"] == 0, {"differing_px": results["committed"], "per_candidate": results},
-              f"matching candidate: {match[0]} -> set blur_round / gauss_taps accordingly" if match else
+              (f"matching candidate: {match[0]} -> set blur_round / gauss_taps accordingly in oracle/ocv_variants.json; kernels: " + KERNEL_LINE(dict(candidates)[match[0]])) if match else
               "no candidate matches: print cv2.getGaussianKernel above against the taps, and the fixed-point path of this build")
 
     # ---- cv::FAST(threshold, nonmaxSuppression = true), ORBextractor.cc:811-817, on a whole level and on cell-sized crops ----
@@ -174,7 +186,7 @@ def main():
     cur = committed["atan_fma"]
     match = [v for v, r in res.items() if r[1] == 0]
     stage("fastAtan2/scalar", res[cur][1] == 0, {"differing_of_5000": res[cur][1], "per_variant": {str(k): v[1] for k, v in res.items()}},
-          f'set "atan_fma": {match[0]} in oracle/ocv_variants.json' if match else "neither Horner form matches: check the coefficients and the 90/180/360 folding")
+          (f'set "atan_fma": {match[0]} in oracle/ocv_variants.json; kernels: make -C gf-orb-slam2_amd/csrc -B EXTRA="-DGFO_OCV_ATAN_FMA={match[0]}"') if match else "neither Horner form matches: check the coefficients and the 90/180/360 folding")
     stage("fastAtan2/vector(cv2.phase)", res[cur][0] == 0, {"differing_of": [res[cur][0], len(y)], "max_abs_deg": res[cur][2],
                                                             "per_variant": {str(k): v[0] for k, v in res.items()}},
           "the array routine (SIMD) and the scalar call may legitimately differ in this build: the scalar line above is the call site's")
