@@ -537,7 +537,7 @@ class Job:
     """One workload on this rank: input batches resident in HBM, `nctx` independent contexts (arena + HIP stream)
     the steps alternate between, so the tail of one batch overlaps the head of the next."""
 
-    def __init__(self, G, torch, name, B, nctx, local_rank, rank, world, dist, n_inputs=4, prime=True, gather_every=1):
+    def __init__(self, G, torch, name, B, nctx, local_rank, rank, world, dist, n_inputs=4, prime=True, gather_every=1, one_stream=False):
         from gf_orb_slam2_amd.sharding import shard_pairs
         from gf_orb_slam2_amd.synth import synth_local_map, synth_stereo_pair, synth_stream
         self.G, self.torch, self.name, self.B, self.world, self.dist = G, torch, name, B, world, dist
@@ -545,10 +545,11 @@ class Job:
         w, h = self.w, self.h
         offs = None
         if self.matcher == "project":
-            frames, offs = synth_stream(w, h, B, idx=3 + rank)     # one scene per rank, a moving camera
+            frames, offs = synth_stream(w, h, B, idx=3 + (0 if one_stream else rank))     # one scene per rank, a moving camera
         else:
             frames = []
-            for p in shard_pairs(rank, world, B // 2):             # distinct pairs per rank (independent streams)
+            # weak scaling: distinct pairs per rank (independent camera streams); strong scaling: every rank holds the ONE stream
+            for p in shard_pairs(0 if one_stream else rank, 1 if one_stream else world, B // 2):
                 l, r = synth_stereo_pair(w, h, p)
                 frames += [l, r]
         base = np.stack(frames)
@@ -606,10 +607,21 @@ class Job:
         for k in range(n):
             self.exts[k].chain_after(self.exts[(k - 1) % n] if on else None, self.chain_stage)
 
-    def step(self, ctx=None, h2d_from=None, deliver=False):
+    def step(self, ctx=None, h2d_from=None, deliver=False, item=None, idle=False):
+        """one batch through the pipeline.  item: the batch's index in ONE stream dealt over the ranks (strong scaling: it picks the
+        input batch); idle: this rank has no item in the current round of such a stream -- it only takes part in the count exchange."""
         k = self.step_no % self.nctx if ctx is None else ctx
-        d_in = self.d_inputs[self.step_no % len(self.d_inputs)]
+        in_idx = (self.step_no if item is None else item) % len(self.d_inputs)
+        d_in = self.d_inputs[in_idx]
         self.step_no += 1
+        if not idle:
+            self.last_in, self.last_ctx = in_idx, k      # what verify() compares with the oracle
+        if idle:
+            if self.world > 1 and self.gather_every and self.step_no % self.gather_every == 0:
+                from gf_orb_slam2_amd.sharding import gather_counts
+                with self.torch.cuda.stream(self.streams[k]):
+                    gather_counts(self.counts_ts[k], self.world, self.dist, self.gathered[k])
+            return
         if h2d_from is not None:
             # PCIe-inclusive variant: the batch comes from pinned host memory first.  ONE copy stream feeds all contexts
             # (concurrent H2D copies from several streams share the link badly: 35 GB/s aggregate against 56 GB/s for one
@@ -672,6 +684,38 @@ class Job:
             dt = float(tt.item())
         return dt
 
+    def timed_strong(self, total_steps, warmup):
+        """STRONG scaling ("for single-stream scaling, round-robin batches of frames across ranks"): ONE stream of
+        total_steps batches, batch i goes to rank i % world (sharding.shard_round_robin); the work is fixed, every rank does its share,
+        the time is the slowest rank's between two barriers.  The count all-gather stays one per round of `world` batches; a rank
+        without a batch in the last, partial round only takes part in the exchange.  Returns (seconds, batches this rank processed)."""
+        from gf_orb_slam2_amd.sharding import shard_round_robin
+        torch, dist, world = self.torch, self.dist, self.world
+        rank = dist.get_rank() if (dist is not None and world > 1) else 0
+        mine = list(shard_round_robin(total_steps, rank, world))
+        rounds = (total_steps + world - 1) // world
+        for _ in range(warmup):
+            self.step()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for j in range(rounds):
+            i = j * world + rank
+            if i < total_steps:
+                self.step(item=i)
+            else:
+                self.step(idle=True)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt = float(tt.item())
+        return dt, len(mine)
+
     def verify(self, n_images=4, n_pairs=2):
         """The checker role of the oracle, outside every timed region: results of the LAST step submitted (still in that context's
         arena) -- n_images images (first pair and last pair of the batch) and n_pairs matcher units (stereo pairs / projected
@@ -679,8 +723,8 @@ class Job:
         from oracle import orb_oracle as O
         O.build()
         self.torch.cuda.synchronize()
-        k = (self.step_no - 1) % self.nctx
-        host = self.host_batches[(self.step_no - 1) % len(self.d_inputs)]
+        k = self.last_ctx
+        host = self.host_batches[self.last_in]
         ext, m = self.exts[k], self.matchers[k]
         B = self.B
         slots = ([0, 1] + [B - 2, B - 1] + list(range(2, B - 2)))[:max(2, n_images)]
@@ -835,6 +879,10 @@ def main():
                     help="do not measure roofline.traffic in this run.  Default (N = 1, rocprofv3 present, not under a profiler): two "
                          "rocprofv3 --pmc child passes (FETCH_SIZE, WRITE_SIZE) of this command, started before this process touches the "
                          "GPU, 75 s bound each (+10..15 s); if they cannot run the committed profiles/traffic_latest.json is used and labelled")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
+                    help="weak (default): every GPU its own camera stream, --steps batches EACH; strong: ONE stream of --steps batches dealt "
+                         "round robin over the GPUs (sharding.shard_round_robin), value = its frames / the slowest rank's time.  A weak "
+                         "run on N > 1 GPUs carries a short strong pass beside it (strong_scaling)")
     ap.add_argument("--gather-every", type=int, default=1,
                     help="N > 1 GPUs: all-gather the keypoint counts every this many steps (1 = every step, as north_star names it; "
                          "0 = never -- separates straggler coupling between ranks from kernel time on a real node)")
@@ -902,22 +950,41 @@ def main():
 
     B = args.batch - (args.batch & 1)
     nctx = args.streams if args.streams >= 1 else CONTEXTS[args.workload]   # 0: the workload's default
-    job = Job(G, torch, args.workload, B, nctx, local_rank, rank, world, dist, prime=not args.pmc_child, gather_every=args.gather_every)
+    strong = args.scaling == "strong"
+    job = Job(G, torch, args.workload, B, nctx, local_rank, rank, world, dist, prime=not args.pmc_child, gather_every=args.gather_every,
+              one_stream=strong)
     if args.pmc_child:      # only the kernels are wanted (counters are read per dispatch by the profiler around this process)
         job.timed(args.steps, args.warmup)
         job.close()
         return
-    dt = job.timed(args.steps, args.warmup)
-    total_frames = world * B * args.steps
+    if strong:
+        dt, my_steps = job.timed_strong(args.steps, args.warmup)     # EXACTLY --steps batches in all, dealt over the ranks
+        total_frames = B * args.steps
+    else:
+        dt = job.timed(args.steps, args.warmup)
+        total_frames = world * B * args.steps
     value = total_frames / dt
     verified = job.verify() if rank == 0 and not args.no_verify else None
 
     # a timed region shorter than half a second says little about a sustained rate: repeat for >= 1 s
     sustained = None
-    if dt < 0.5:
+    if dt < 0.5 and strong:
+        n_s = int(min(20000 * world, max(args.steps, 1.2 * args.steps / max(dt, 1e-6))))
+        dts, _ = job.timed_strong(n_s, 0)
+        sustained = {"value": round(B * n_s / dts, 1), "seconds": round(dts, 3), "steps": n_s}
+    elif dt < 0.5:
         n_s = int(min(20000, max(args.steps, 1.2 / max(dt / args.steps, 1e-6))))
         dts = job.timed(n_s, 0)
         sustained = {"value": round(world * B * n_s / dts, 1), "seconds": round(dts, 3), "steps": n_s}
+    # N > 1, weak headline: the strong-scaling figure beside it -- one stream of world x 40 batches dealt round robin (this rank's
+    # resident batches stand in for its share of that stream: same sizes, same kernels), fixed total work
+    strong_beside = None
+    if world > 1 and not strong:
+        n_b = 40 * world
+        dtb, mine_b = job.timed_strong(n_b, 2)
+        strong_beside = {"scaling": "strong", "value": round(B * n_b / dtb, 1), "unit": "frames/s", "stream_batches": n_b, "batches_this_rank": mine_b,
+                         "images_per_batch": B, "seconds": round(dtb, 4), "partition": "batch i -> rank i % N (sharding.shard_round_robin)",
+                         "note": "N = 1 value of the same figure is the headline's (one rank takes every batch)"}
 
     extra = {}
     if world == 1:
@@ -970,7 +1037,7 @@ def main():
         line = {
             "metric": "frames/sec ORB extract+match, 752x480 @2000 kp" if args.workload == "stereo752" else f"frames/sec ORB {args.workload}",
             "value": round(value, 1), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": args.scaling,
             "vs_baseline": None, "dtype": "u8", "data": "synthetic",
             # ranks whose counts are in the last all-gather's output: `collective_ranks` whatever the backend, `rccl_ranks` only when
             # the backend IS RCCL ("nccl"); a gloo rehearsal on one GPU reports rccl_ranks null
@@ -985,11 +1052,15 @@ def main():
                        "contexts_chained_after_stage": job.chain_stage if job.chained else None,
                        "priming_steps": PRIME_STEPS, "gather_every": args.gather_every if world > 1 else None,
                        "distinct_input_batches": len(job.d_inputs),
-                       "sharding": f"{world} x independent streams, RCCL all-gather of counts" if world > 1 else "single GPU"},
+                       "sharding": ("single GPU" if world == 1 else
+                                    f"ONE stream of {args.steps} batches, batch i -> rank i % {world} (shard_round_robin), all-gather of counts per round" if strong else
+                                    f"{world} x independent streams, RCCL all-gather of counts")},
             "roofline": roof,
         }
         if sustained:
             line["sustained"] = sustained
+        if strong_beside:
+            line["strong_scaling"] = strong_beside
         line.update(extra)
     job.close()
     del job

@@ -70,6 +70,12 @@ struct AtExit {
 // call is inside the library (GfoUse there), released afterwards
 gfo_ctx* gfo_context_pin(const ORBextractor* e) { return g_tab.acquire(e); }
 void gfo_context_unpin(const ORBextractor* e, gfo_ctx* c) { if (c) g_tab.release(e, c); }
+// several GPUs (GFO_DEVICES): the right extractor of a stereo rig follows its left one (gfo_context_table.h); the HIP ordinal an
+// extractor is placed on, and how many extractors have been moved so far
+bool gfo_context_colocate(const ORBextractor* follower, const ORBextractor* leader) { return g_tab.colocate(follower, leader); }
+int gfo_context_device(const ORBextractor* e) { return g_tab.device_of(e); }
+int gfo_context_slot(const ORBextractor* e) { return g_tab.slot_of(e); }       // index into GFO_DEVICES
+unsigned long gfo_contexts_moved() { return g_tab.moved(); }
 
 ORBextractor::ORBextractor(int _nfeatures, float _scaleFactor, int _nlevels, int _iniThFAST, int _minThFAST)
     : nfeatures(_nfeatures), scaleFactor(_scaleFactor), nlevels(_nlevels), iniThFAST(_iniThFAST), minThFAST(_minThFAST)

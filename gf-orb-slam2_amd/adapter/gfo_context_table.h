@@ -20,14 +20,25 @@
 //   * when the allocator does NOT reuse the address, the dead object's context simply goes idle and is reclaimed by the
 //     first rule; GFO_MAX_CONTEXTS (default 64) is only a ceiling against a runaway, enforced least-recently-used.
 //
+//   * SEVERAL GPUs (GFO_DEVICES=0,1,2,...; default: the one device GFO_DEVICE names, or 0): an extractor is placed when it is
+//     declared, on the listed device that carries the fewest extractors (a re-declared address keeps its device); the two
+//     extractors of a stereo rig must share a device -- the library pairs them into one submission (gfo_ctx_pair) and every matcher
+//     call of a frame runs in its LEFT extractor's context -- so the stereo member calls colocate(right, left) before it pins
+//     them: a rig found on two devices moves to the emptier of the two (the extractor that moves gives up its context and gets a
+//     new one there at its next call; never one with a call in flight).  One move per rig at most, on its first frame, after
+//     which K rigs sit on K devices; K camera threads of one process then spread over the node's GPUs, which the reference's
+//     `System` per camera cannot say by itself.
+//
 // No OpenCV in this header: tests/test_host_logic.py builds it against a counting stand-in of the four C entry points
 // it calls and drives exactly the scenarios above on the CPU.
 #pragma once
 
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <map>
 #include <mutex>
+#include <vector>
 
 #include "gfo.h"
 
@@ -46,7 +57,24 @@ public:
         unsigned long stamp;
         int in_use;            // calls inside the library with `ctx` (or `retired`) right now
         gfo_ctx* retired;      // the context of a dead object at this address that still had a user when the new object was declared
+        int slot;              // index into devices(): where this extractor's context lives (or will be created)
+        bool fresh;            // declared, no context created yet (counts as load of its slot)
     };
+
+    // GFO_DEVICES=0,1,...: the devices extractors are spread over; default: one entry, GFO_DEVICE (or 0).  A device may be listed
+    // more than once (two slots on one GPU; the tests do that to exercise placement and moves on a one-GPU box).
+    // (read from the environment at the table's first use; set_devices() replaces the list -- tests, or an application that knows
+    //  its node -- before any extractor exists)
+    void set_devices(const std::vector<int>& d)
+    {
+        std::lock_guard<std::mutex> lk(mu_);
+        if (!d.empty()) devs_ = d;
+    }
+    int device_count()
+    {
+        std::lock_guard<std::mutex> lk(mu_);
+        return (int)devices().size();
+    }
 
     // A context for the duration of one call: pins the entry so that reclaim() on another thread cannot destroy it.
     //   ContextTable::Use u(table, this);  if (gfo_ctx* c = u.ctx()) gfo_extract(c, ...);
@@ -75,6 +103,8 @@ public:
         e.stamp = ++clock_;
         e.in_use = 0;
         e.retired = NULL;
+        e.fresh = true;
+        e.slot = it != tab_.end() ? it->second.slot : least_loaded_slot_locked();   // a re-created extractor stays where it was
         if (it != tab_.end()) {
             Entry& old = it->second;
             if (old.ctx && old.in_use > 0 && !old.retired) {
@@ -119,6 +149,52 @@ public:
         }
         (void)c;
     }
+
+    // The two extractors of a stereo rig must live on one device.  When they do not, both go to whichever of their two slots carries
+    // fewer OTHER extractors (ties: the leader's) -- extractors are declared before anybody knows which two form a rig, and moving
+    // the pair to the emptier side is what leaves K rigs spread over K devices instead of piled onto the leaders' -- and the one
+    // that moves gives up its context: the next acquire() creates one on the new device.  Returns true when something moved.
+    // An extractor with a call in flight is never moved under its user (the other one moves instead, or the caller asks again
+    // with the next frame).
+    bool colocate(const void* follower, const void* leader)
+    {
+        std::lock_guard<std::mutex> lk(mu_);
+        if (devices().size() < 2) return false;
+        std::map<const void*, Entry>::iterator f = tab_.find(follower), l = tab_.find(leader);
+        if (f == tab_.end() || l == tab_.end() || f->second.slot == l->second.slot) return false;
+        int others_f = 0, others_l = 0;
+        for (std::map<const void*, Entry>::const_iterator it = tab_.begin(); it != tab_.end(); ++it) {
+            if (it == f || it == l || !(it->second.ctx || it->second.fresh)) continue;
+            others_f += it->second.slot == f->second.slot;
+            others_l += it->second.slot == l->second.slot;
+        }
+        std::map<const void*, Entry>::iterator mover = others_f < others_l ? l : f, stays = others_f < others_l ? f : l;
+        if (mover->second.in_use > 0) std::swap(mover, stays);
+        if (mover->second.in_use > 0) return false;
+        if (mover->second.ctx) {
+            gfo_ctx_destroy(mover->second.ctx);
+            mover->second.ctx = NULL;
+            destroyed_++;
+        }
+        mover->second.slot = stays->second.slot;
+        moved_++;
+        return true;
+    }
+
+    // the device (its HIP ordinal) an extractor is placed on; -1 for an address the table does not know
+    int device_of(const void* key)
+    {
+        std::lock_guard<std::mutex> lk(mu_);
+        std::map<const void*, Entry>::iterator it = tab_.find(key);
+        return it == tab_.end() ? -1 : devices()[it->second.slot];
+    }
+    int slot_of(const void* key)
+    {
+        std::lock_guard<std::mutex> lk(mu_);
+        std::map<const void*, Entry>::iterator it = tab_.find(key);
+        return it == tab_.end() ? -1 : it->second.slot;
+    }
+    unsigned long moved() const { return moved_; }
 
     // the context of a live extractor, created on first use; NULL (and a message) when the device refuses.  UNPINNED: for
     // single-threaded callers and the tests; the adapters go through Use.
@@ -167,18 +243,57 @@ private:
         Entry& e = it->second;
         e.stamp = ++clock_;
         if (!e.ctx) {
-            int dev = 0;
-            if (const char* d = getenv("GFO_DEVICE")) dev = atoi(d);
+            const int dev = devices()[e.slot];
             if (gfo_ctx_create(&e.prm, dev, &e.ctx) != GFO_OK) {
                 fprintf(stderr, "[gfo] ORBextractor: %s\n", gfo_last_error(NULL));
                 e.ctx = NULL;
                 return NULL;
             }
             created_++;
+            e.fresh = false;
             if (on_create) on_create(e.ctx);
             reclaim(key);
         }
         return e.ctx;
+    }
+
+    // the caller holds mu_
+    const std::vector<int>& devices()
+    {
+        if (devs_.empty()) devs_ = parse_devices();
+        return devs_;
+    }
+
+    static std::vector<int> parse_devices()
+    {
+        std::vector<int> v;
+        if (const char* s = getenv("GFO_DEVICES")) {
+            for (const char* p = s; *p;) {
+                char* end = NULL;
+                const long d = strtol(p, &end, 10);
+                if (end == p) break;
+                if (d >= 0 && d < 1024) v.push_back((int)d);
+                p = end;
+                while (*p == ',' || *p == ' ') p++;
+            }
+        }
+        if (v.empty()) v.push_back(getenv("GFO_DEVICE") ? atoi(getenv("GFO_DEVICE")) : 0);
+        return v;
+    }
+
+    // the slot with the fewest extractors on it: live contexts and declared-but-not-yet-used entries count, the entries of
+    // extractors that went idle and lost their context do not; ties go to the slot listed first.  The caller holds mu_.
+    int least_loaded_slot_locked()
+    {
+        const size_t n = devices().size();
+        if (n < 2) return 0;
+        std::vector<int> load(n, 0);
+        for (std::map<const void*, Entry>::const_iterator it = tab_.begin(); it != tab_.end(); ++it)
+            if (it->second.ctx || it->second.fresh) load[it->second.slot]++;
+        size_t best = 0;
+        for (size_t k = 1; k < n; k++)
+            if (load[k] < load[best]) best = k;
+        return (int)best;
     }
 
     int alive_locked() const
@@ -211,7 +326,8 @@ private:
 
     std::mutex mu_;
     std::map<const void*, Entry> tab_;
-    unsigned long clock_ = 0, created_ = 0, destroyed_ = 0;
+    std::vector<int> devs_;
+    unsigned long clock_ = 0, created_ = 0, destroyed_ = 0, moved_ = 0;
 };
 
 }  // namespace gfo_adapter

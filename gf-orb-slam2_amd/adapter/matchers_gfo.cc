@@ -58,6 +58,7 @@ namespace ORB_SLAM2
 
 gfo_ctx* gfo_context_pin(const ORBextractor* e);   // adapter/ORBextractor_gfo.cc
 void gfo_context_unpin(const ORBextractor* e, gfo_ctx* c);
+bool gfo_context_colocate(const ORBextractor* follower, const ORBextractor* leader);
 
 namespace
 {
@@ -195,6 +196,9 @@ int Frame::ComputeStereoMatches_Undistorted(bool isOnline)
     std::vector<int32_t> bestDist(N), bestIdx(N);
     int nmatched = 0;
     cv::Mat keepL, keepR;
+    // several GPUs (GFO_DEVICES): the rig's right extractor lives where its left one does -- the pair below needs one device, and
+    // every matcher call of this frame runs in the left extractor's context.  Moves the right one once, on the rig's first frame.
+    if (mpORBextractorRight) (void)gfo_context_colocate(mpORBextractorRight, mpORBextractorLeft);
     GfoUse use(mpORBextractorLeft), use_r(mpORBextractorRight);
     gfo_ctx* c = use.c;
     // the two extractors are one stereo rig with this calibration: from the next frame on their two operator() calls go to the

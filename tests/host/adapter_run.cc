@@ -48,6 +48,9 @@ namespace ORB_SLAM2
 {
 gfo_ctx* gfo_context_pin(const ORBextractor* e);   // adapter/ORBextractor_gfo.cc
 void gfo_context_unpin(const ORBextractor* e, gfo_ctx* c);
+int gfo_context_device(const ORBextractor* e);
+int gfo_context_slot(const ORBextractor* e);
+unsigned long gfo_contexts_moved();
 }
 
 using namespace ORB_SLAM2;
@@ -864,7 +867,13 @@ int main(int argc, char** argv)
         for (int k = 0; k < KC; k++) {
             CHECK(bad[k] == 0, "K: camera %d got %d frames that differ from the single-camera results", k, bad[k]);
             report((std::string("K_camera") + char('0' + k) + "_rig_answers").c_str(), answered[k]);
+            // several GPUs (GFO_DEVICES; the test lists one GPU three times = three slots): a rig's two extractors share a slot
+            CHECK(gfo_context_slot(ex[2 * k]) == gfo_context_slot(ex[2 * k + 1]) && gfo_context_slot(ex[2 * k]) >= 0,
+                  "K: camera %d has its extractors on slots %d and %d", k, gfo_context_slot(ex[2 * k]), gfo_context_slot(ex[2 * k + 1]));
+            report((std::string("K_camera") + char('0' + k) + "_slot").c_str(), gfo_context_slot(ex[2 * k]));
+            report((std::string("K_camera") + char('0' + k) + "_device").c_str(), gfo_context_device(ex[2 * k]));
         }
+        report("contexts_moved", (long long)gfo_contexts_moved());
         for (size_t i = 0; i < ex.size(); i++) delete ex[i];
     }
 

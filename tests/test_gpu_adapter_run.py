@@ -302,6 +302,12 @@ def run(tmp_path_factory, oracle, euroc_l, euroc_r):
     outd2 = tmp_path_factory.mktemp("adapter_out_full")
     p2 = subprocess.run([EXE, GOLDEN, str(ind), str(outd2), "2"], capture_output=True, text=True, timeout=600, env=dict(env, GFO_FULL_PYRAMID="1"))
     ref["full"] = {"rc": p2.returncode, "stderr": p2.stderr, "out": outd2}
+    # a third run with GFO_DEVICES=0,0,0: three SLOTS (this box has one GPU; a node lists its eight): extractors are placed per slot,
+    # the rigs are co-located on their first frame -- contexts are destroyed and re-created mid-stream -- and every result is the same
+    outd4 = tmp_path_factory.mktemp("adapter_out_devices")
+    p4 = subprocess.run([EXE, GOLDEN, str(ind), str(outd4), "6"], capture_output=True, text=True, timeout=600, env=dict(env, GFO_DEVICES="0,0,0"))
+    ref["devices"] = {"rc": p4.returncode, "stderr": p4.stderr, "out": outd4,
+                      "report": dict(l.split() for l in open(outd4 / "report.txt").read().splitlines() if l.strip()) if (outd4 / "report.txt").exists() else {}}
     outd3 = tmp_path_factory.mktemp("adapter_out_delayed")
     if os.path.exists(EXE + "_delayed"):
         p3 = subprocess.run([EXE + "_delayed", GOLDEN, str(ind), str(outd3), "3"], capture_output=True, text=True, timeout=600, env=env)
@@ -419,6 +425,29 @@ def test_stereo_member_second_call_on_a_frame_keeps_its_state(run):
     assert survived.sum() > 20, survived.sum()
     assert len(second[3]) > len(first[3])
     assert len(run["D3"][3]) > len(second[3])
+
+
+def test_extractors_spread_over_device_slots_and_rigs_are_colocated(run):
+    """GFO_DEVICES (adapter/gfo_context_table.h): the adapter places each ORBextractor on the least-loaded listed device and the
+    stereo member moves a rig onto one device before it pairs the two extractors.  Run with three slots (one GPU listed three
+    times): placement and moves are real -- contexts die and are re-created between frames -- and nothing in the results may change:
+    the program's own checks (every camera of part K equals part A) pass and part A still equals the oracle."""
+    d = run["devices"]
+    assert d["rc"] == 0, d["stderr"][-3000:]
+    rep = d["report"]
+    assert rep.get("check_failures") == "0"
+    assert "[gfo]" not in d["stderr"], d["stderr"][-2000:]
+    assert int(rep["contexts_moved"]) >= 1                                   # at least one rig was found on two slots and moved
+    slots = [int(rep[f"K_camera{k}_slot"]) for k in range(3)]
+    assert len(set(slots)) >= 2, slots                                       # three cameras do not pile onto one slot
+    assert all(int(rep[f"K_camera{k}_device"]) == 0 for k in range(3))
+    assert int(run["report"]["contexts_moved"]) == 0                         # the default (one device): nothing ever moves
+    kd = run["oracle"].KEYPOINT_DTYPE
+    for f in range(3):
+        kl, dl, kr, dr, st = run["frames"][f]
+        assert np.fromfile(d["out"] / f"A_f{f:02d}_kl.bin", kd).tobytes() == kl.tobytes(), f
+        assert np.fromfile(d["out"] / f"A_f{f:02d}_dr.bin", np.uint8).tobytes() == dr.tobytes(), f
+        assert np.fromfile(d["out"] / f"A_f{f:02d}_uright.bin", np.float32).tobytes() == st[1].tobytes(), f
 
 
 def test_stereo_member_of_a_delayed_stereo_matching_build(run):
