@@ -18,6 +18,6 @@ def build_library(force=False, jobs=8):
 
 def build_variants(jobs=8):
     """The [OCV] variant builds (csrc/Makefile `variants`, include/gfo.h gfo_build_variant): libgfo.so with one switch of
-    oracle/ocv_variants.json turned each, into gf-orb-slam2_amd/variants/ -- what tests/test_gpu_ocv_variants.py compares with the
+    the checker's table (ocv_variants.json) turned each, into gf-orb-slam2_amd/variants/ -- what tests/test_gpu_ocv_variants.py compares with the
     like-switched oracle.  Never loaded by the product (GFO_LIB selects a library explicitly)."""
     subprocess.check_call(["make", "-s", "-C", os.path.join(_HERE, "csrc"), "variants"])

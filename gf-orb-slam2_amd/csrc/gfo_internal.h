@@ -16,7 +16,7 @@
 
 #include "../../include/gfo.h"
 
-// [OCV] build variants (include/gfo.h gfo_build_variant; same values as oracle/ocv_variants.json).  `make EXTRA="-DGFO_OCV_RESIZE=1"`.
+// [OCV] build variants (include/gfo.h gfo_build_variant; same values as the checker's ocv_variants.json).  `make EXTRA="-DGFO_OCV_RESIZE=1"`.
 #ifndef GFO_OCV_RESIZE
 #define GFO_OCV_RESIZE 0        // 0: 11-bit fixed-point bilinear (resizeGeneric_), 1: float bilinear, rounded half to even once
 #endif
