@@ -826,6 +826,36 @@ class Job:
         def issue_frac(stage, ms_per_step):
             n = issue_all.get(stage)
             return round(n * ISSUE_CYCLES / (N_SIMDS * CLOCK_HZ * ms_per_step * 1e-3), 4) if n and ms_per_step > 0 else None
+        # Round 6: the flat 4 cycles replaced by what THIS kernel's instructions cost.  tools/opcode_histogram.py disassembles the
+        # gfx950 code object of every kernel, takes the opcode mix of its loops and prices it with the measured per-opcode issue rates
+        # (profiles/valu_rate_r02.txt: plain 32-bit logic / add / move ~2.4 cycles, everything packed, min / max, compares, v_perm,
+        # dot products ~4.2): a MEAN cost per vector instruction, multiplied here with the dynamic SQ_INSTS_VALU.  Two more pipes
+        # from the same counter pass: valu_busy (SQ_ACTIVE_INST_VALU, quad-cycles the vector ALUs were executing: the hardware's own
+        # figure) and the LDS pipe (SQ_LDS_IDX_ACTIVE cycles per CU, of which SQ_LDS_BANK_CONFLICT are replays).
+        mix, mix_src = {}, None
+        try:
+            mj = json.load(open(os.path.join(ROOT, "profiles", "opcode_mix_latest.json")))
+            mix = {k: v.get("mean_cycles_per_valu") for k, v in mj["kernels"].items()}
+            mix_src = "profiles/opcode_mix_latest.json (tools/opcode_histogram.py: opcode mix of the kernels' loops x profiles/valu_rate_r02.txt)"
+        except Exception:
+            pass
+        MIX_OF = {"stereo_match": "stereo_match"}
+        sq_all = {}
+        try:
+            sq_all = sj["per_stage_per_step"] if issue_all else {}
+        except Exception:
+            sq_all = {}
+
+        def pipes(stage, ms_per_step):
+            n, c = issue_all.get(stage), mix.get(MIX_OF.get(stage, stage))
+            sec = ms_per_step * 1e-3
+            q = sq_all.get(stage, {})
+            out = {"issue_frac_weighted": round(n * c / (N_SIMDS * CLOCK_HZ * sec), 4) if n and c and sec > 0 else None,
+                   "mean_cycles_per_valu": c,
+                   "valu_busy_frac": round(q["SQ_ACTIVE_INST_VALU"] * 4 / (N_SIMDS * CLOCK_HZ * sec), 4) if q.get("SQ_ACTIVE_INST_VALU") and sec > 0 else None,
+                   "lds_busy_frac": round(q["SQ_LDS_IDX_ACTIVE"] / (N_SIMDS / 4 * CLOCK_HZ * sec), 4) if q.get("SQ_LDS_IDX_ACTIVE") and sec > 0 else None,
+                   "lds_conflict_frac": round(q["SQ_LDS_BANK_CONFLICT"] / (N_SIMDS / 4 * CLOCK_HZ * sec), 4) if q.get("SQ_LDS_BANK_CONFLICT") and sec > 0 else None}
+            return out
         per_stage = {}
         for k, ms in stage_ms.items():
             lps = prof[k][1] / max(1, nsteps)
@@ -835,19 +865,30 @@ class Job:
                             "achieved_GBps": round(bpl / (al * 1e-3) / 1e9, 1), "frac": round(bpl / (al * 1e-3) / 8e12, 5),
                             "issue_frac": issue_frac(k, ms),
                             "traffic_per_step": tj_all.get(k), "traffic_counters_per_step": raw_all.get(k)}
+            per_stage[k].update(pipes(k, ms))
         dom_issue = issue_frac(dom, stage_ms[dom])
+        dom_pipes = pipes(dom, stage_ms[dom])
         hbm_frac = round(achieved / 8000.0, 5)
-        def bound_of(issue, hbm):      # no instruction count for this workload / stage: no claim about which wall binds
-            return None if issue is None else ("valu-issue" if issue > hbm else "hbm")
+        def bound_of(v, hbm):
+            """the pipe with the largest utilisation among HBM (the contract's fraction), vector issue (the weighted model; the flat
+            one where no opcode mix exists) and the LDS pipe; None without an instruction count: no claim about which wall binds"""
+            issue = v.get("issue_frac_weighted") if v.get("issue_frac_weighted") is not None else v.get("issue_frac")
+            if issue is None:
+                return None
+            cand = {"hbm": hbm, "valu-issue": issue, "lds": v.get("lds_busy_frac") or 0.0}
+            return max(cand, key=cand.get)
         for k, v in per_stage.items():
-            v["bound"] = bound_of(v["issue_frac"], v["frac"])
+            v["bound"] = bound_of(v, v["frac"])
         return n_kp_img, {
             # `bound` names the wall the dominant kernel actually sits against: whichever of the two fractions is larger.
             # achieved / peak / frac stay the HBM figures the contract defines; issue_frac is the other roofline.
-            "bound": bound_of(dom_issue, hbm_frac), "kernel": dom, "achieved": round(achieved, 2), "peak": 8000.0, "unit": "GB/s",
-            "frac": hbm_frac, "issue_frac": dom_issue,
+            "bound": bound_of(dict(dom_pipes, issue_frac=dom_issue), hbm_frac), "kernel": dom, "achieved": round(achieved, 2), "peak": 8000.0, "unit": "GB/s",
+            "frac": hbm_frac, "issue_frac": dom_issue, "issue_frac_weighted": dom_pipes["issue_frac_weighted"],
+            "valu_busy_frac": dom_pipes["valu_busy_frac"], "lds_busy_frac": dom_pipes["lds_busy_frac"], "lds_conflict_frac": dom_pipes["lds_conflict_frac"],
             "issue_model": {"valu_instructions_per_launch": int(issue_all[dom] / max(launches_per_step, 1e-9)) if issue_all.get(dom) else None,
-                            "cycles_per_wave_instruction": ISSUE_CYCLES, "simds": N_SIMDS, "clock_ghz": CLOCK_HZ / 1e9, "source": issue_src},
+                            "cycles_per_wave_instruction_flat": ISSUE_CYCLES, "cycles_per_wave_instruction_weighted": dom_pipes["mean_cycles_per_valu"],
+                            "simds": N_SIMDS, "clock_ghz": CLOCK_HZ / 1e9, "source": issue_src, "opcode_mix": mix_src,
+                            "bound_rule": "largest of frac (HBM), issue_frac_weighted and lds_busy_frac"},
             "traffic": traffic, "traffic_measured": bool(live), "traffic_source": traffic_source,
             "avg_launch_ms": round(avg_launch_ms, 4), "algorithmic_bytes_per_launch": int(bytes_per_launch),
             "pipeline_frac_hbm": round(value_per_gpu * survey_total / 8e12, 5),

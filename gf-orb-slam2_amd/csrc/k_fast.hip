@@ -90,6 +90,30 @@ __device__ __forceinline__ int corner_score(const uint8_t* __restrict__ tl, int 
     // LDS offsets are unsigned immediates: the ring is addressed from `tl`, one byte left of its top-left corner (so that the
     // caller's address is tile + py * TP + px, nothing added), the centre sits RB bytes further
     constexpr int RB = 3 * TP + 3 + GFO_FAST_XOFF;
+#ifdef GFO_FAST_RING64
+    // Round 6 experiment (profiles/fast_ring64_r06.txt has the A/B): the ring as SEVEN 8-byte reads, one per ring row
+    // from column -3 (bytes of columns -3 .. +4 at fixed positions, whatever the pixel's alignment: gfx950 takes an 8-byte LDS read at
+    // any byte address), the ring words cut out by one v_perm_b32 each (selector 0x0C = zero byte; sources: {S1 = bytes 0-3, S0 =
+    // bytes 4-7}) -- 7 LDS instructions instead of 17, the same 8 packing operations, one more for the centre.
+    struct __attribute__((packed)) row8 { unsigned lo, hi; };
+    const row8 Rm3 = *reinterpret_cast<const row8*>(tl + RB - 3 * TP - 3), Rm2 = *reinterpret_cast<const row8*>(tl + RB - 2 * TP - 3),
+               Rm1 = *reinterpret_cast<const row8*>(tl + RB - TP - 3), R0 = *reinterpret_cast<const row8*>(tl + RB - 3),
+               Rp1 = *reinterpret_cast<const row8*>(tl + RB + TP - 3), Rp2 = *reinterpret_cast<const row8*>(tl + RB + 2 * TP - 3),
+               Rp3 = *reinterpret_cast<const row8*>(tl + RB + 3 * TP - 3);
+    // column c of a row is byte c + 3 of its 8 bytes: lo holds columns -3 .. 0, hi columns +1 .. +4
+#define GFO_SEL(b0, b1) ((unsigned)(b0) | (0x0Cu << 8) | ((unsigned)(b1) << 16) | (0x0Cu << 24))
+    const unsigned v2 = __builtin_amdgcn_perm(0u, R0.lo, GFO_SEL(3, 3));   // the centre (column 0 = lo byte 3) in both halves
+    unsigned Q[8];
+    Q[0] = __builtin_amdgcn_perm(Rm3.lo, Rp3.lo, GFO_SEL(3, 4 + 3));     // (0,+3) | (0,-3): byte 3 of both lo words
+    Q[1] = __builtin_amdgcn_perm(Rm3.lo, Rp3.hi, GFO_SEL(0, 4 + 2));     // (+1,+3): hi byte 0 | (-1,-3): lo byte 2
+    Q[2] = __builtin_amdgcn_perm(Rm2.lo, Rp2.hi, GFO_SEL(1, 4 + 1));     // (+2,+2): hi byte 1 | (-2,-2): lo byte 1
+    Q[3] = __builtin_amdgcn_perm(Rm1.lo, Rp1.hi, GFO_SEL(2, 4 + 0));     // (+3,+1): hi byte 2 | (-3,-1): lo byte 0
+    Q[4] = __builtin_amdgcn_perm(R0.lo, R0.hi, GFO_SEL(2, 4 + 0));       // (+3, 0): hi byte 2 | (-3, 0): lo byte 0
+    Q[5] = __builtin_amdgcn_perm(Rp1.lo, Rm1.hi, GFO_SEL(2, 4 + 0));     // (+3,-1): hi byte 2 | (-3,+1): lo byte 0
+    Q[6] = __builtin_amdgcn_perm(Rp2.lo, Rm2.hi, GFO_SEL(1, 4 + 1));     // (+2,-2): hi byte 1 | (-2,+2): lo byte 1
+    Q[7] = __builtin_amdgcn_perm(Rp3.lo, Rm3.hi, GFO_SEL(0, 4 + 2));     // (+1,-3): hi byte 0 | (-1,+3): lo byte 2
+#undef GFO_SEL
+#else
     const unsigned v = tl[RB];
     const unsigned v2 = v | (v << 16);
     // ring words Q[k] = (r[k], r[k+8]).  (ds_read_u8_d16 / _d16_hi would deliver the pair packed, but with SRAM ECC on -- as
@@ -100,6 +124,7 @@ __device__ __forceinline__ int corner_score(const uint8_t* __restrict__ tl, int 
     unsigned Q[8];
 #pragma unroll
     for (int k = 0; k < 8; k++) Q[k] = r[k] | (r[k + 8] << 16);
+#endif
     // compass, on the ring words themselves (no differences yet -- their sign is not known): both halves of A / B are alike,
     //   both pairs (0,8), (4,12) hold a pixel darker than v - t    <=>  max(min(r0, r8), min(r4, r12)) < v - t
     //   both pairs hold a brighter one                              <=>  min(max(r0, r8), max(r4, r12)) > v + t

@@ -70,10 +70,26 @@ struct AngleRows {
 __device__ const AngleRows k_angle_rows = AngleRows();
 
 #define DW 37          // descriptor window (blurred level), rows
-#define DWP 48         // its LDS pitch: three 16-byte segments cover 37 px + up to 3 px of alignment slack
+#define DWP 48         // its LDS pitch: three 16-byte segments cover 37 px + up to 11 px of alignment slack
 #define OW 31          // orientation patch (unblurred level), rows
-#define OWP 48         // its LDS pitch: three 16-byte segments
+// The patch's LDS pitch.  Round 6 (profiles/orient_lds_r06.txt): 52 bytes = 13 dwords.  With 48 (12 dwords) the 30 storing lanes of
+// a half -- (row, segment) = (hl / 3, hl % 3), dword 12 * row + 4 * segment + k -- fall on EIGHT of the 32 banks a ds_write*_b32
+// sees (every start a multiple of 4): a four-way conflict on every one of the sixteen dword stores per lane, and the row reads of
+// the angle phase (lane = row, stride 12 dwords) the same on their dword read.  13 is odd: rows 13 dwords apart walk all 32 banks,
+// the stores land on 30 different banks but for a few pairs, and the row is read as nine conflict-free dwords.
+#ifndef OWP
+#define OWP 52
+#endif
+#define OD_REGION (DW * DWP + 16)   // one keypoint's LDS region and 16 bytes of slack behind it (= in front of the next region)
+static_assert(OW * OWP + 16 <= OD_REGION && OWP % 4 == 0 && OWP >= 48, "the patch must fit the window's region");
 #define OD_STEPS 4     // 10 rows per step: 4 steps cover the 31-row patch and the 37-row window
+// The window's segments are stored where they lie -- 16-byte-aligned ds_write_b128, conflict-free at a 48-byte pitch (eight
+// consecutive lanes cover the 32 banks exactly) -- and the row's first pixel sits at byte woff = 0 .. 11 of its LDS row: the
+// gathers address bytes, the offset is one more term of their base.  (Round 5 shifted the stores left to keep the pixel at byte
+// 0 .. 3: two ds_write2_b32 per segment, four-way conflicts on each.)  -DGFO_OD_WIN_ALIGNED=0: the shifted stores.
+#ifndef GFO_OD_WIN_ALIGNED
+#define GFO_OD_WIN_ALIGNED 1
+#endif
 
 // Sum over the 32 lanes of a half, left in every lane: four DPP steps inside the 16-lane rows (lane ^ 1, lane ^ 2, the other
 // quad of the eight, the other eight of the row -- each folds into its v_add) and one ds_swizzle across the two rows.
@@ -126,7 +142,9 @@ __global__ __launch_bounds__(64 * OD_WAVES) void k_orient_desc(const GfoGeom* __
     // the 37-row window, whose bytes wait in registers meanwhile.  14 KB per workgroup instead of 26 KB: LDS no longer
     // caps the kernel at 6 waves per SIMD (the registers allow 8), and the chain of dependent loads at the head of
     // every wave is what the extra waves hide.
-    __shared__ __attribute__((aligned(16))) uint8_t s_win_raw[16 + 2 * OD_WAVES * DW * DWP];   // 16 bytes of slack, then [wave*2 + half][DW * DWP]
+    // 16 bytes of slack, then [wave*2 + half][OD_REGION]: a region's slack is its own -- the patch's segments are stored up to 12 bytes
+    // to the left of their row (GFO_OD_ALIGN16), which for row 0 is the slack in front of the region, never a neighbour's bytes
+    __shared__ __attribute__((aligned(16))) uint8_t s_win_raw[16 + 2 * OD_WAVES * OD_REGION];
     // The two tables every wave needs -- the 256 test pairs (4 KB) and the disc's row weights (1.1 KB) -- are brought into LDS
     // ONCE per workgroup, 16 bytes per thread, instead of twelve 16-byte loads per lane and wave: this kernel is bound by the
     // rate at which a CU's texture path takes vector memory instructions (22 per wave were 62 % of its time; with the row
@@ -243,16 +261,21 @@ __global__ __launch_bounds__(64 * OD_WAVES) void k_orient_desc(const GfoGeom* __
     const int wx_al = (x - 18) & ~3;
 #endif
     // pixel 0 of a staged row sits at byte (offset & 3) of its LDS row; the segments are stored (offset & ~3) bytes to the left
+#if GFO_OD_ALIGN16 && GFO_OD_WIN_ALIGNED
+    const int ooff = ((x - GFO_HALF_PATCH) - ox_al) & 3, woff = (x - 18) - wx_al;   // window: 0 .. 11, the segments are stored where they lie
+    const int oshift = ((x - GFO_HALF_PATCH) - ox_al) & ~3;
+#else
     const int ooff = ((x - GFO_HALF_PATCH) - ox_al) & 3, woff = ((x - 18) - wx_al) & 3;
 #if GFO_OD_ALIGN16
     const int oshift = ((x - GFO_HALF_PATCH) - ox_al) & ~3, wshift = ((x - 18) - wx_al) & ~3;
+#endif
 #endif
     const int lpitch = L.pitch;
     const int rw = (hl * 11) >> 5, seg = hl - 3 * rw;   // hl / 3, hl % 3 for hl < 32; rw == 10: idle lanes
     const bool ld_on = rw < 10;
     const unsigned po = (unsigned)((y - GFO_HALF_PATCH) * pitch + ox_al + 16 * seg);     // row 0 of the patch, this lane's segment
     const unsigned wo = (unsigned)((y - 18) * lpitch + wx_al + 16 * seg);                // row 0 of the window
-    uint8_t* win = s_win_raw + 16 + (wave * 2 + half) * (DW * DWP);
+    uint8_t* win = s_win_raw + 16 + (wave * 2 + half) * OD_REGION;
     uint8_t* pat = win;   // same bytes, earlier in time
     uint4 vw0, vw1, vw2, vw3;   // the window's bytes, in registers until the patch has been consumed
     {
@@ -271,11 +294,13 @@ __global__ __launch_bounds__(64 * OD_WAVES) void k_orient_desc(const GfoGeom* __
         // exactly the bytes that lane rw == 0 of the next step writes to the same place; only the last step is
         // predicated (row 30)
 #if GFO_OD_ALIGN16
-        od_u4a4* pl = reinterpret_cast<od_u4a4*>(pat + rw * OWP + 16 * seg - oshift);
+        uint8_t* pl = pat + rw * OWP + 16 * seg - oshift;
 #pragma unroll
-        for (int k = 0; k < OD_STEPS - 1; k++) pl[k * (10 * OWP / 16)] = od_u4a4{vp[k].x, vp[k].y, vp[k].z, vp[k].w};
-        if (ld_on && 10 * (OD_STEPS - 1) + rw < OW) pl[(OD_STEPS - 1) * (10 * OWP / 16)] = od_u4a4{vp[OD_STEPS - 1].x, vp[OD_STEPS - 1].y, vp[OD_STEPS - 1].z, vp[OD_STEPS - 1].w};
+        for (int k = 0; k < OD_STEPS - 1; k++) *reinterpret_cast<od_u4a4*>(pl + k * (10 * OWP)) = od_u4a4{vp[k].x, vp[k].y, vp[k].z, vp[k].w};
+        if (ld_on && 10 * (OD_STEPS - 1) + rw < OW)
+            *reinterpret_cast<od_u4a4*>(pl + (OD_STEPS - 1) * (10 * OWP)) = od_u4a4{vp[OD_STEPS - 1].x, vp[OD_STEPS - 1].y, vp[OD_STEPS - 1].z, vp[OD_STEPS - 1].w};
 #else
+        static_assert(OWP % 16 == 0, "without GFO_OD_ALIGN16 the patch rows must be 16-byte aligned");
         uint4* pl = reinterpret_cast<uint4*>(pat + rw * OWP + 16 * seg);
 #pragma unroll
         for (int k = 0; k < OD_STEPS - 1; k++) pl[k * (10 * OWP / 16)] = vp[k];
@@ -308,11 +333,19 @@ __global__ __launch_bounds__(64 * OD_WAVES) void k_orient_desc(const GfoGeom* __
             aw[0] = a0.x; aw[1] = a0.y; aw[2] = a0.z; aw[3] = a0.w; aw[4] = a1.x; aw[5] = a1.y; aw[6] = a1.z; aw[7] = a1.w;
             aw[8] = a2.x; aw[9] = a2.y; aw[10] = a2.z; aw[11] = a2.w; aw[12] = a3.x; aw[13] = a3.y; aw[14] = a3.z; aw[15] = a3.w;
         }
+#if OWP % 16 == 0
         const uint4* prow = reinterpret_cast<const uint4*>(pat + hl * OWP);
         const uint4 q0 = prow[0], q1 = prow[1];
         const uint32_t q2 = reinterpret_cast<const uint32_t*>(prow)[8];
         // the row starts at byte `ooff` of the staged segment: shift it down (the shift count is the same for the whole half)
         const uint32_t d[9] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2};
+#else
+        // a pitch that is odd in dwords: nine dword reads, the lanes of a half on 32 different banks each time
+        const uint32_t* prow = reinterpret_cast<const uint32_t*>(pat + hl * OWP);
+        uint32_t d[9];
+#pragma unroll
+        for (int k = 0; k < 9; k++) d[k] = prow[k];
+#endif
         uint32_t s1 = 0, s0 = 0;
 #pragma unroll
         for (int k = 0; k < 8; k++) {
@@ -334,7 +367,7 @@ __global__ __launch_bounds__(64 * OD_WAVES) void k_orient_desc(const GfoGeom* __
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     {
-#if GFO_OD_ALIGN16
+#if GFO_OD_ALIGN16 && !GFO_OD_WIN_ALIGNED
         od_u4a4* wl = reinterpret_cast<od_u4a4*>(win + rw * DWP + 16 * seg - wshift);
         wl[0] = od_u4a4{vw0.x, vw0.y, vw0.z, vw0.w};
         wl[10 * DWP / 16] = od_u4a4{vw1.x, vw1.y, vw1.z, vw1.w};
