@@ -542,15 +542,17 @@ struct VocabularyView : public ORBVocabulary {
     }
     // A cheap identity of the vocabulary's CONTENT: the flattened copy is cached per object address, and an application that deletes
     // a vocabulary and loads another may get the same address back (round 5: tests/host/adapter_run.cc builds four vocabularies in
-    // one stack slot).  Shape, parameters and a sample of 64 nodes (weight, word id, eight descriptor bytes): a few hundred bytes per
-    // ComputeBoW call, against re-reading a million nodes.
+    // one stack slot).  Shape, parameters and a sample of 16 nodes (weight, word id, eight descriptor bytes): a few hundred bytes per
+    // ComputeBoW call, against re-reading a million nodes.  (Round 6, ORBvoc's size -- 1 111 111 Node objects, a quarter of a
+    // gigabyte: every sampled node is three dependent cache misses; 64 samples were 45 us of a 119-us call, 16 are what a call can
+    // afford.  Shape, parameters and the word count are in the hash whatever the samples say.)
     uint64_t fingerprint() const
     {
         uint64_t hsh = 1469598103934665603ull;
         auto mix = [&](uint64_t v) { hsh = (hsh ^ v) * 1099511628211ull; };
         const size_t n = m_nodes.size();
         mix(n); mix((uint64_t)m_k); mix((uint64_t)m_L); mix((uint64_t)m_weighting); mix((uint64_t)m_scoring); mix(m_words.size());
-        const size_t step = n > 64 ? n / 64 : 1;
+        const size_t step = n > 16 ? n / 16 : 1;
         for (size_t i = 0; i < n; i += step) {
             const Node& nd = m_nodes[i];
             uint64_t w;

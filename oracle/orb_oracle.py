@@ -431,6 +431,45 @@ def make_vocabulary(k, depth, seed=0, p_stop=0.05, ragged=True):
             "word_id": word, "weight": w, "weight64": w64, "depth": depth}
 
 
+def make_vocabulary_full(k, depth, seed=0, p_stop=0.02):
+    """The FULL k-ary tree of the given depth, breadth first, vectorised -- for vocabularies of the size the reference loads
+    (ORBvoc: k = 10, L = 6, 1 111 111 nodes, 35.5 MB of centres; test/test_Stereo.cpp:87).  Node i's children are k i + 1 .. k i + k;
+    a child's centre is its parent's with random bits flipped, sparser with every level (the AND of `level` random words), so that a
+    descent is decided at every level and ties are rare but present.  Same dictionary as make_vocabulary."""
+    rng = np.random.default_rng(seed)
+    n_level = [k ** l for l in range(depth + 1)]
+    n = sum(n_level)
+    n_internal = n - n_level[-1]
+    first = np.zeros(n, np.int32)
+    nch = np.zeros(n, np.int32)
+    first[:n_internal] = (np.arange(n_internal, dtype=np.int64) * k + 1).astype(np.int32)
+    nch[:n_internal] = k
+    desc = np.zeros((n, 4), np.uint64)
+    start = 1
+    prev = desc[0:1]
+    for l in range(1, depth + 1):
+        cnt = n_level[l]
+        mask = rng.integers(0, 1 << 63, (cnt, 4), dtype=np.uint64) << np.uint64(1) | rng.integers(0, 2, (cnt, 4), dtype=np.uint64)
+        for _ in range(l - 1):
+            mask &= rng.integers(0, 1 << 63, (cnt, 4), dtype=np.uint64) << np.uint64(1) | rng.integers(0, 2, (cnt, 4), dtype=np.uint64)
+        cur = np.repeat(prev, k, axis=0) ^ mask
+        desc[start:start + cnt] = cur
+        prev = cur
+        start += cnt
+    word = np.full(n, -1, np.int32)
+    word[n_internal:] = np.arange(n_level[-1], dtype=np.int32)
+    w = np.zeros(n, np.float32)
+    w[n_internal:] = rng.uniform(0.1, 5.0, n_level[-1]).astype(np.float32)
+    stop = rng.random(n_level[-1]) < p_stop
+    w[n_internal:][stop] = 0.0
+    w64 = np.zeros(n, np.float64)
+    w64[n_internal:] = np.log(rng.uniform(1.1, 400.0, n_level[-1]))
+    w64[w == 0.0] = 0.0
+    w64[:n_internal] = 0.0
+    return {"first_child": first, "n_children": nch, "descriptors": np.ascontiguousarray(desc).view(np.uint8).reshape(n, 32),
+            "word_id": word, "weight": w, "weight64": w64, "depth": depth}
+
+
 def bow_transform(voc, desc, levelsup=4):
     desc = np.ascontiguousarray(desc, np.uint8)
     n = len(desc)

@@ -289,11 +289,22 @@ def run(tmp_path_factory, oracle, euroc_l, euroc_r):
         voc["weight64"].astype(np.float64).tofile(ind / f"J{v}_weight.bin")
         voc["descriptors"].astype(np.uint8).tofile(ind / f"J{v}_desc.bin")
         ref["J"].append(oracle.compute_bow(voc, dl1, 4, weighting, norm))
+    # J4: a vocabulary of the size the reference loads (ORBvoc: k = 10, L = 6, 1 111 111 nodes), through the ORBVocabulary object:
+    # VocabularyView::flatten() walks a million Node objects, the fingerprint samples 64 of them per call (main run only: GFO_ADAPTER_BIGVOC)
+    vocb = oracle.make_vocabulary_full(10, 6, seed=21)
+    np.array([len(vocb["first_child"]), 10, 6, 0, 0], np.int32).tofile(ind / "J4_voc_hdr.bin")
+    vocb["first_child"].astype(np.int32).tofile(ind / "J4_first.bin")
+    vocb["n_children"].astype(np.int32).tofile(ind / "J4_nch.bin")
+    vocb["word_id"].astype(np.int32).tofile(ind / "J4_word.bin")
+    vocb["weight64"].astype(np.float64).tofile(ind / "J4_weight.bin")
+    vocb["descriptors"].astype(np.uint8).tofile(ind / "J4_desc.bin")
+    ref["Jbig"] = oracle.compute_bow(vocb, dl1, 4, 0, 1)
+    del vocb
 
     env = dict(os.environ)
     env.pop("GFO_COMBINE", None)
     env.pop("GFO_FULL_PYRAMID", None)
-    p = subprocess.run([EXE, GOLDEN, str(ind), str(outd), str(NF)], capture_output=True, text=True, timeout=600, env=env)
+    p = subprocess.run([EXE, GOLDEN, str(ind), str(outd), str(NF)], capture_output=True, text=True, timeout=600, env=dict(env, GFO_ADAPTER_BIGVOC="1"))
     ref["rc"], ref["stderr"], ref["out"] = p.returncode, p.stderr, outd
     ref["report"] = dict(l.split() for l in open(outd / "report.txt").read().splitlines() if l.strip()) if (outd / "report.txt").exists() else {}
     ref["oracle"] = oracle
@@ -560,6 +571,23 @@ def test_compute_bow_member(run):
         np.testing.assert_array_equal(_rd(run, f"J{v}_fv_nodes.bin", np.uint32), fn, err_msg=str(v))
         np.testing.assert_array_equal(_rd(run, f"J{v}_fv_start.bin", np.int32), fs, err_msg=str(v))
         np.testing.assert_array_equal(_rd(run, f"J{v}_fv_items.bin", np.uint32), fi, err_msg=str(v))
+
+
+def test_compute_bow_member_with_a_vocabulary_of_reference_size(run):
+    """the same member on an ORBVocabulary object of ORBvoc's shape (k = 10, L = 6: 1 111 111 Node objects, a million words): the
+    adapter's VocabularyView::flatten() + gfo_vocabulary_upload happen once (the first call), every later call pays the 64-node
+    fingerprint and the device call; results equal the oracle's"""
+    bw, bv, fn, fs, fi = run["Jbig"]
+    rep = run["report"]
+    assert int(rep["Jbig_nodes"]) == 1111111
+    np.testing.assert_array_equal(_rd(run, "J4_bow_words.bin", np.uint32), bw)
+    assert _rd(run, "J4_bow_values.bin", np.float64).tobytes() == bv.tobytes()
+    np.testing.assert_array_equal(_rd(run, "J4_fv_nodes.bin", np.uint32), fn)
+    np.testing.assert_array_equal(_rd(run, "J4_fv_start.bin", np.int32), fs)
+    np.testing.assert_array_equal(_rd(run, "J4_fv_items.bin", np.uint32), fi)
+    assert int(bw.max()) > 900000 and len(fn) > 50
+    # a steady-state call does not depend on the size of the tree (the small vocabulary of J0 on the same frame)
+    assert int(rep["Jbig_ComputeBoW_us"]) < 3 * int(rep["J_ComputeBoW_us"]) + 100, rep
 
 
 def test_three_cameras_through_the_adapters(run):

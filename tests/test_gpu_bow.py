@@ -150,3 +150,77 @@ def test_compute_bow_fold_against_the_reference_compiled_fixtures(oracle):
                 cases += 1
     assert cases == 60
     ext.close()
+
+
+def test_vocabulary_at_the_size_the_reference_loads(oracle):
+    """ORBvoc (test/test_Stereo.cpp:87, Tracking's mpORBVocabulary): k = 10, L = 6 -- 1 111 111 nodes, 35.5 MB of centres, a million
+    words.  A synthetic full tree of that shape through gfo_vocabulary_upload -> gfo_compute_bow (Frame::ComputeBoW, levelsup 4 as
+    Frame.cc:666 passes it) -> gfo_search_by_bow between a keyframe's and a frame's vectors, everything against the oracle; what the
+    sizes could break are 32-bit offsets (node index x 32 bytes, the 8-byte weights behind 50 MB of other arrays) and the per-call cost."""
+    import json
+    import time
+    import gf_orb_slam2_amd as G
+    from conftest import ROOT
+    voc = oracle.make_vocabulary_full(10, 6, seed=11)
+    assert len(voc["first_child"]) == 1111111 and int((voc["n_children"] == 0).sum()) == 10 ** 6
+    ext = G.ORBextractor(2000, 1.2, 8, 20, 7)
+    t0 = time.perf_counter()
+    V = G.ORBVocabulary(voc, ext)
+    t_up = time.perf_counter() - t0
+    assert V._L.gfo_vocabulary_nodes(ext.handle) == 1111111
+    kd = oracle.KEYPOINT_DTYPE
+    kl = np.fromfile(os.path.join(GOLDEN, "EuRoC_l_kp.bin"), kd)
+    dk = np.fromfile(os.path.join(GOLDEN, "EuRoC_l_desc.bin"), np.uint8).reshape(-1, 32)
+    rng = np.random.default_rng(2)
+    # the frame: the keyframe's descriptors with a few bits flipped, shuffled; plus descriptors that ARE deep nodes' centres (the last
+    # nodes of the array: the largest offsets) and their near neighbours
+    fd = dk.copy()
+    for _ in range(6):
+        sel = rng.random(len(fd)) < 0.5
+        bits = rng.integers(0, 256, len(fd))
+        fd[sel, bits[sel] >> 3] ^= (1 << (bits[sel] & 7)).astype(np.uint8)
+    perm = rng.permutation(len(fd))
+    fd = fd[perm]
+    deep = voc["descriptors"][-300:].copy()
+    deep[100:, 5] ^= 0x10
+    fd = np.concatenate([fd, deep])
+    fa = np.concatenate([(kl["angle"][perm] + rng.normal(0, 4, len(perm))) % 360, rng.uniform(0, 360, len(deep))]).astype(np.float32)
+    # ComputeBoW of both, all four weightings once
+    got_k = V.compute_bow(dk, 4, "TF_IDF", "L1")
+    ref_k = oracle.compute_bow(voc, dk, 4, 0, 1)
+    for (wn, nn), (W, Nn) in zip((("TF_IDF", "L1"), ("TF", "L2"), ("IDF", None), ("BINARY", "L1")), ((0, 1), (1, 2), (2, 0), (3, 1))):
+        (bw, bv), (fn, fs, fi) = V.compute_bow(fd, 4, wn, nn)
+        rw, rv, rn, rs, ri = oracle.compute_bow(voc, fd, 4, W, Nn)
+        np.testing.assert_array_equal(bw, rw)
+        assert bv.tobytes() == rv.tobytes(), (wn, nn)
+        np.testing.assert_array_equal(fn, rn); np.testing.assert_array_equal(fs, rs); np.testing.assert_array_equal(fi, ri)
+    assert int(rw.max()) > 990000 and int(rn.max()) > 100          # words from the far end of the table; level-2 nodes are 11 .. 110
+    (bwk, bvk), fvk = got_k
+    np.testing.assert_array_equal(bwk, ref_k[0]); assert bvk.tobytes() == ref_k[1].tobytes()
+    # the descent alone, levelsup 1 .. 6: node ids at every level of the tree
+    for levelsup in (1, 2, 6):
+        for a, b in zip(V.transform_raw(fd, levelsup), oracle.bow_transform(voc, fd, levelsup)):
+            assert a.tobytes() == b.tobytes(), levelsup
+    # SearchByBoW(KF, F) over the two feature vectors
+    fvf = (fn, fs, fi)
+    valid = (rng.random(len(dk)) > 0.1).astype(np.uint8)
+    M = G.ORBmatcher(0.7, True, extractor=ext)
+    got = M.SearchByBoW(dk, kl["angle"], valid, fvk, fd, fa, fvf)
+    ref = oracle.search_by_bow(dk, kl["angle"], valid, (ref_k[2], ref_k[3], ref_k[4]), fd, fa, (rn, rs, ri), 0.7, True)
+    assert got[0] == ref[0] and ref[0] > 500
+    np.testing.assert_array_equal(got[1], ref[1])
+    # per-call cost with the big vocabulary resident (median of 30)
+    ts = []
+    for _ in range(33):
+        t0 = time.perf_counter()
+        V.compute_bow(dk, 4, "TF_IDF", "L1")
+        ts.append(time.perf_counter() - t0)
+    ts = sorted(ts[3:])
+    rec = {"nodes": 1111111, "k": 10, "L": 6, "upload_ms": round(t_up * 1e3, 2), "compute_bow_ms_median": round(ts[len(ts) // 2] * 1e3, 4),
+           "descriptors": int(len(dk)), "words": int(len(bwk)), "feature_vector_nodes": int(len(fvk[0])), "search_by_bow_matches": int(got[0])}
+    keep = os.path.join(ROOT, "gpurun_out")
+    if os.path.isdir(keep):
+        with open(os.path.join(keep, "bigvoc.json"), "w") as fh:
+            json.dump(rec, fh)
+    assert rec["compute_bow_ms_median"] < 1.0, rec              # a call stays a call: the tree's size is not in it
+    ext.close()
