@@ -119,6 +119,24 @@ if ONLY in ("", "bow"):
     ms, r = median_ms(lambda: mb.SearchByBoW(desc, kp["angle"].copy(), valid, kfv, fd, kp["angle"].copy(), ffv))
     say("SearchByBoW(KF, F)", ms, {"keypoints": n, "nodes": len(kfv[0]), "matches": int(r[0])},
         f"SearchByBoW(KF, F): {n} x {n} keypoints over {len(kfv[0])} nodes: median {ms:.3f} ms, {r[0]} matches")
+# the same two calls with a vocabulary of the SIZE the reference loads (ORBvoc: k = 10, L = 6 -- 1 111 111 nodes, 35.5 MB of centres;
+# test/test_Stereo.cpp:87), levelsup 4 as Frame.cc:666 passes it: the upload happens once per context, the call does not grow with it
+if ONLY in ("", "cbow", "bow", "bigvoc"):
+    import time
+    big = synth_vocabulary(10, 6, seed=1)
+    t0 = time.perf_counter()
+    VB = G.ORBVocabulary(big, ext)
+    up_ms = (time.perf_counter() - t0) * 1e3
+    ms, r = median_ms(lambda: VB.compute_bow(desc, 4, "TF_IDF", "L1"), 50)
+    (bwb, bvb), kfvb = r
+    say("ComputeBoW (vocabulary of ORBvoc's size)", ms, {"descriptors": n, "k": 10, "L": 6, "levelsup": 4, "nodes": int(len(big["first_child"])),
+                                                         "vocabulary_upload_ms": round(up_ms, 2), "words": len(bwb), "feature_vector_nodes": len(kfvb[0])},
+        f"ComputeBoW({n} descriptors, k=10 L=6 = {len(big['first_child'])} nodes, levelsup 4): median {ms:.3f} ms, upload once {up_ms:.1f} ms, "
+        f"{len(bwb)} words, {len(kfvb[0])} feature-vector nodes")
+    ffvb = VB.compute_bow(fd, 4, "TF_IDF", "L1")[1]
+    ms, r = median_ms(lambda: mb.SearchByBoW(desc, kp["angle"].copy(), valid, kfvb, fd, kp["angle"].copy(), ffvb))
+    say("SearchByBoW(KF, F) (vocabulary of ORBvoc's size)", ms, {"keypoints": n, "nodes": len(kfvb[0]), "matches": int(r[0])},
+        f"SearchByBoW(KF, F) over {len(kfvb[0])} level-2 nodes of that vocabulary: median {ms:.3f} ms, {r[0]} matches")
 ext.close()
 if JSON:
     print(json.dumps(out), flush=True)
