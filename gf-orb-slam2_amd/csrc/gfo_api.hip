@@ -1497,6 +1497,7 @@ extern "C" int gfo_extract_batch(gfo_ctx* c, const uint8_t* const* imgs, int nim
         return GFO_OK;
     }
     if (stride < w) return fail(c, GFO_ERR_INVALID, "stride < width");
+    if (cap < 0) return fail(c, GFO_ERR_INVALID, "negative capacity");   // (found by the sanitizer harness of round 6: image i's arrays are kp + i * cap)
     if (c->combining && nimg == 1) {   // one frame of one caller: may share a device batch with other callers' frames
         gfo_keypoint* kps[1] = {kp};
         uint8_t* ds[1] = {desc};
@@ -1550,6 +1551,7 @@ extern "C" int gfo_extract_stereo(gfo_ctx* c, const uint8_t* img_l, const uint8_
     *n_l = *n_r = *nmatched = 0;
     if (!img_l || !img_r || w <= 0 || h <= 0) return GFO_OK;   // empty image: outputs untouched (:1115)
     if (stride < w) return fail(c, GFO_ERR_INVALID, "stride < width");
+    if (cap < 0) return fail(c, GFO_ERR_INVALID, "negative capacity");
     const uint8_t* imgs[2] = {img_l, img_r};
     gfo_keypoint* kps[2] = {kp_l, kp_r};
     uint8_t* ds[2] = {desc_l, desc_r};

@@ -326,7 +326,7 @@ void orc_get_level(const orc_extractor* e, int level, uint8_t* out, int out_stri
 /* [OCV] BORDER_REFLECT_101: -k -> k, n-1+k -> n-1-k */
 static int reflect101(int p, int n)
 {
-    if (n == 1) return 0;
+    if (n <= 1) return 0; /* (n == 0: a level that rounds to no pixels at all -- cv::resize would assert; nothing is read through it) */
     while (p < 0 || p >= n) {
         if (p < 0) p = -p;
         else p = 2 * (n - 1) - p;
@@ -337,6 +337,7 @@ static int reflect101(int p, int n)
 void orc_get_level_padded(const orc_extractor* e, int level, uint8_t* out, int out_stride)
 {
     const int w = e->w[level], h = e->h[level];
+    if (w <= 0 || h <= 0) return; /* an empty level has no frame to reflect into */
     for (int y = -EDGE_THRESHOLD; y < h + EDGE_THRESHOLD; y++) {
         const uint8_t* S = e->level[level] + (size_t)reflect101(y, h) * w;
         uint8_t* D = out + (size_t)(y + EDGE_THRESHOLD) * out_stride;
@@ -385,6 +386,8 @@ void orc_gaussian_blur7_u8(const uint8_t* src, int w, int h, int sstride, uint8_
 
 void orc_get_blurred_level(const orc_extractor* e, int level, uint8_t* out, int out_stride)
 {
+    if (!e->blurred[level]) return; /* a level without keypoints is never blurred (ORBextractor.cc:1150-1152): `out` stays as it is
+                                       (found by the sanitizer job of round 6: the copy read from a null plane) */
     for (int y = 0; y < e->h[level]; y++)
         memcpy(out + (size_t)y * out_stride, e->blurred[level] + (size_t)y * e->w[level], e->w[level]);
 }

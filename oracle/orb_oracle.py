@@ -10,7 +10,8 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB_PATH = os.path.join(_HERE, "liborb_oracle.so")
+# ORB_ORACLE_LIB: another build of the same file (oracle/Makefile `san`: -fsanitize=address,undefined, for tests/test_sanitizers.py)
+_LIB_PATH = os.environ.get("ORB_ORACLE_LIB") or os.path.join(_HERE, "liborb_oracle.so")
 
 KEYPOINT_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"),
                            ("response", "<f4"), ("octave", "<i4"), ("class_id", "<i4")])
@@ -34,6 +35,8 @@ class FrameBounds(C.Structure):
 
 
 def build(force=False):
+    if os.environ.get("ORB_ORACLE_LIB"):
+        return _LIB_PATH
     if force or not os.path.exists(_LIB_PATH) or any(
             os.path.getmtime(os.path.join(_HERE, f)) > os.path.getmtime(_LIB_PATH)
             for f in ("orb_oracle.c", "orb_oracle.h", "Makefile")):
