@@ -132,6 +132,9 @@ def pmc_bytes_per_step(csv_path, counter):
     return ({st: v / steps for st, v in per.items()} if steps else {}), steps
 
 
+LIVE_TRAFFIC_KILLED = None   # set when a counter pass had to be killed: the JSON line says so (roofline.traffic_pass_killed)
+
+
 def live_traffic(workload, batch):
     """HBM bytes per step and stage from the PMC counters, measured NOW: two child passes of this script under
     `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` (the two do not fit one pass on gfx950), run before this process
@@ -150,6 +153,10 @@ def live_traffic(workload, batch):
     raw, steps_seen = {}, 0
     logdir = os.path.join(ROOT, "gpurun_out") if os.path.isdir(os.path.join(ROOT, "gpurun_out")) else "/tmp"
     for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        if raw:
+            # both stalled passes of round 2 "followed another counter-collection session within a second"
+            # (profiles/NOTEBOOK.md); the cause was never established, so the second session does not follow the first at once
+            time.sleep(3.0)
         tmp = tempfile.mkdtemp(prefix="gfo_pmc_", dir="/tmp")
         cmd = [exe, "--pmc", counter, "--output-format", "csv", "-d", tmp, "--", "python3", os.path.join(ROOT, "bench.py"),
                "--pmc-child", "--workload", workload, "--batch", str(batch), "--steps", "6", "--warmup", "2", "--streams", "1"]
@@ -173,11 +180,24 @@ def live_traffic(workload, batch):
                         log.write(b"\n---- pass exceeded 75 s; process group at that moment ----\n" + ps)
                     except Exception:
                         pass
+                    pgid = proc.pid
                     try:
-                        os.killpg(proc.pid, signal.SIGKILL)
+                        os.killpg(pgid, signal.SIGKILL)
                     except OSError:
                         pass
                     proc.wait()
+                    # nothing of that group may still hold the GPU when the headline is timed: wait until the group is empty
+                    # (a killed process leaves the device once the kernel has reaped it), then a settling pause
+                    gone = False
+                    for _ in range(100):
+                        left = subprocess.run(["ps", "-o", "pid=", "-g", str(pgid)], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL).stdout.strip()
+                        if not left:
+                            gone = True
+                            break
+                        time.sleep(0.1)
+                    time.sleep(2.0)
+                    global LIVE_TRAFFIC_KILLED
+                    LIVE_TRAFFIC_KILLED = {"counter": counter, "process_group_gone": gone, "log": log_path}
                     return None, f"rocprofv3 --pmc {counter} pass did not finish in 75 s and was killed (evidence: {log_path})"
             files = glob.glob(os.path.join(tmp, "**", "*counter_collection.csv"), recursive=True)
             if rc != 0 or not files:
@@ -889,7 +909,7 @@ class Job:
                             "cycles_per_wave_instruction_flat": ISSUE_CYCLES, "cycles_per_wave_instruction_weighted": dom_pipes["mean_cycles_per_valu"],
                             "simds": N_SIMDS, "clock_ghz": CLOCK_HZ / 1e9, "source": issue_src, "opcode_mix": mix_src,
                             "bound_rule": "largest of frac (HBM), issue_frac_weighted and lds_busy_frac"},
-            "traffic": traffic, "traffic_measured": bool(live), "traffic_source": traffic_source,
+            "traffic": traffic, "traffic_measured": bool(live), "traffic_source": traffic_source, "traffic_pass_killed": LIVE_TRAFFIC_KILLED,
             "avg_launch_ms": round(avg_launch_ms, 4), "algorithmic_bytes_per_launch": int(bytes_per_launch),
             "pipeline_frac_hbm": round(value_per_gpu * survey_total / 8e12, 5),
             "stage_ms_per_step": {k: round(v, 4) for k, v in stage_ms.items()},

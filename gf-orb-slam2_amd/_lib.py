@@ -76,7 +76,7 @@ SYMBOLS = [
     "gfo_stereo_match_batch", "gfo_stereo_match_sad_batch", "gfo_stereo_fetch", "gfo_search_by_projection", "gfo_search_by_projection_queries",
     "gfo_map_upload", "gfo_search_by_projection_batch", "gfo_projection_fetch", "gfo_projection_device_views", "gfo_search_by_bow", "gfo_vocabulary_upload", "gfo_bow_transform", "gfo_compute_bow", "gfo_profile_enable",
     "gfo_profile_read", "gfo_debug_blurred_level", "gfo_debug_level_candidates",
-    "gfo_contexts_created", "gfo_arenas_planned", "gfo_kernels_preloaded", "gfo_ctx_id", "gfo_vocabulary_nodes", "gfo_ctx_set_combining", "gfo_combiner_stats", "gfo_ctx_pair", "gfo_combiner_counters",
+    "gfo_contexts_created", "gfo_arenas_planned", "gfo_kernels_preloaded", "gfo_ctx_id", "gfo_vocabulary_nodes", "gfo_ctx_set_combining", "gfo_combiner_stats", "gfo_ctx_pair", "gfo_combiner_counters", "gfo_tuning_set", "gfo_tuning_get",
     "gfo_batch_deliver", "gfo_deliver_wait", "gfo_host_register", "gfo_host_unregister",
 ]
 
@@ -211,6 +211,9 @@ def load_library():
     L.gfo_combiner_stats.argtypes = [vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
     L.gfo_ctx_pair.argtypes = [vp, vp, vp]
     L.gfo_combiner_counters.argtypes = [vp, C.POINTER(C.c_int64), i]
+    L.gfo_tuning_set.argtypes = [C.c_char_p, C.c_long]
+    L.gfo_tuning_get.argtypes = [C.c_char_p]
+    L.gfo_tuning_get.restype = C.c_long
     _lib = L
     return L
 

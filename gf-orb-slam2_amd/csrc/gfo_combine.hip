@@ -529,11 +529,29 @@ void gfo_pair_release(gfo_ctx* c)
 
 // gfo_extract of a paired, combining context.  Returns GFO_COMBINE_DIRECT when the frame is not taken here (no partner, the
 // partner does not show up, other geometry): the caller goes on as if there were no pair.
+// the rig's two timing parameters (include/gfo.h gfo_tuning_set): the environment gives the initial values
+static std::atomic<long> g_pair_wait_us{getenv("GFO_PAIR_WAIT_US") ? atol(getenv("GFO_PAIR_WAIT_US")) : 2000};
+static std::atomic<long> g_pair_spin_us{getenv("GFO_PAIR_SPIN_US") ? atol(getenv("GFO_PAIR_SPIN_US")) : 400};
+extern "C" int gfo_tuning_set(const char* key, long value)
+{
+    if (!key || value < 0) return GFO_ERR_INVALID;
+    if (strcmp(key, "pair_wait_us") == 0) { g_pair_wait_us.store(value); return GFO_OK; }
+    if (strcmp(key, "pair_spin_us") == 0) { g_pair_spin_us.store(value); return GFO_OK; }
+    return GFO_ERR_INVALID;
+}
+extern "C" long gfo_tuning_get(const char* key)
+{
+    if (!key) return -1;
+    if (strcmp(key, "pair_wait_us") == 0) return g_pair_wait_us.load();
+    if (strcmp(key, "pair_spin_us") == 0) return g_pair_spin_us.load();
+    return -1;
+}
+
 int gfo_pair_extract(gfo_ctx* c, const uint8_t* img, int w, int h, int stride, gfo_keypoint* kp, uint8_t* desc, int cap, int* n)
 {
     std::shared_ptr<GfoPair> P = pair_of(c);
     if (!P || (w & 15) != 0) return GFO_COMBINE_DIRECT;      // (tight rows of the staged pair must stay 16-byte aligned)
-    static const long wait_us = getenv("GFO_PAIR_WAIT_US") ? atol(getenv("GFO_PAIR_WAIT_US")) : 2000;
+    const long wait_us = g_pair_wait_us.load(std::memory_order_relaxed);
     if (wait_us <= 0) return GFO_COMBINE_DIRECT;
     std::unique_lock<std::mutex> lk(P->mu);
     const int side = P->ctx[1] == c ? 1 : 0;
@@ -612,7 +630,7 @@ int gfo_pair_extract(gfo_ctx* c, const uint8_t* img, int w, int h, int stride, g
         // frame's latency: it watches the state for up to GFO_PAIR_SPIN_US (400) before it goes to sleep on the condition
         // variable.  With several cameras the waiting sides sleep at once (their cores belong to the other cameras' threads).
         if (P->spin_ok) {
-            static const long spin_us = getenv("GFO_PAIR_SPIN_US") ? atol(getenv("GFO_PAIR_SPIN_US")) : 400;
+            const long spin_us = g_pair_spin_us.load(std::memory_order_relaxed);
             lk.unlock();
             const auto until = std::chrono::steady_clock::now() + std::chrono::microseconds(spin_us);
             for (int it = 0;; it++) {

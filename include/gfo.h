@@ -410,6 +410,15 @@ int gfo_ctx_pair(gfo_ctx* left, gfo_ctx* right, const gfo_stereo_params* p);
  * prepare no slot and its callers take the direct path, [5] stereo frames extracted as one submission through gfo_ctx_pair,
  * [6] gfo_stereo_match calls answered from such a frame, [7] frames whose partner did not show up.  n <= 8 entries are written. */
 int gfo_combiner_counters(const gfo_ctx* ctx, int64_t* out, int n);
+/* The two timing parameters of a stereo rig that a CALLER may need to change (everything else behind a GFO_* environment variable only
+ * picks between code paths that give the same results, and keeps its measured default): key "pair_wait_us" -- how long the first
+ * extractor of a declared rig waits for its partner's image before it extracts alone (default 2000; 0 switches the rigs off; the
+ * environment's GFO_PAIR_WAIT_US is the initial value), key "pair_spin_us" -- how long a lone camera's waiting side watches for its
+ * result before it sleeps (default 400, GFO_PAIR_SPIN_US).  Process-wide, effective from the next frame; results never depend on
+ * either (a frame whose partner is late is extracted alone and associated on request).  gfo_tuning_set returns GFO_ERR_INVALID for
+ * an unknown key or a negative value; gfo_tuning_get returns -1 for an unknown key. */
+int gfo_tuning_set(const char* key, long value);
+long gfo_tuning_get(const char* key);
 /* Process-wide monotonic counters: contexts created by gfo_ctx_create and arenas (re)planned -- hipMalloc of a whole
  * arena -- since the library was loaded.  A steady-state per-frame loop must leave both unchanged
  * (tools/c/boundary_throughput.c and the adapter's context table assert it). */

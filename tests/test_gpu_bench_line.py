@@ -52,7 +52,10 @@ def test_matcher_calls_block_of_the_line():
     d = json.loads(r.stdout.strip().splitlines()[-1])
     names = [c["call"] for c in d["calls"]]
     assert names == ["SearchByProjection(F, MapPoints)"] * 3 + ["ComputeStereoMatches(host arrays)", "SearchByProjection(Cur, Last)", "ComputeBoW",
-                     "SearchByBoW(KF, F)"]
+                     "SearchByBoW(KF, F)", "ComputeBoW (vocabulary of ORBvoc's size)", "SearchByBoW(KF, F) (vocabulary of ORBvoc's size)"]
+    big = d["calls"][-2]
+    assert big["nodes"] == 1111111 and big["L"] == 6 and 0 < big["vocabulary_upload_ms"] < 2000
+    assert big["ms"] < 3 * d["calls"][-4]["ms"] + 0.1            # a call does not grow with the vocabulary (the descent reads 6 x 10 centres)
     assert all(0 < c["ms"] < 50 for c in d["calls"])
     assert all(c.get("matches", c.get("words")) > 100 for c in d["calls"])
     src = open(os.path.join(ROOT, "tools", "matcher_call_latency.py")).read()

@@ -246,6 +246,19 @@ def test_adapter_pattern_end_to_end_from_many_threads(oracle, euroc_l, euroc_r):
         er.close()
 
 
+@pytest.fixture
+def patient_rigs():
+    """the tests below assert COUNTERS of the paired path (every frame met its partner); Python threads hand the GIL over every 5 ms,
+    the product's rig waits 2 ms: for these tests only, the first side waits 200 ms (include/gfo.h gfo_tuning_set; results never
+    depend on the wait)"""
+    from gf_orb_slam2_amd._lib import load_library
+    L = load_library()
+    before = L.gfo_tuning_get(b"pair_wait_us")
+    assert L.gfo_tuning_set(b"pair_wait_us", 200000) == 0
+    yield
+    L.gfo_tuning_set(b"pair_wait_us", before)
+
+
 def _rig_frame(el, er, m, l, r, sf, prm, win=(None, None)):
     """the adapter's per-frame pattern: right image on a thread of its own, left on this one, then the association"""
     out = {}
@@ -257,15 +270,12 @@ def _rig_frame(el, er, m, l, r, sf, prm, win=(None, None)):
     return (kl, dl, kr, dr), m.ComputeStereoMatches(kl, dl, kr, dr, sf, prm, *win)
 
 
-def test_declared_stereo_rig_extracts_as_one_submission_and_answers_the_association(oracle, euroc_l, euroc_r):
+def test_declared_stereo_rig_extracts_as_one_submission_and_answers_the_association(oracle, euroc_l, euroc_r, patient_rigs):
     """gfo_ctx_pair: the adapter's three calls per frame on a declared rig -- the two gfo_extract calls meet
     and run as ONE stereo submission, gfo_stereo_match on the arrays they returned is answered from it -- must return exactly what
     the undeclared pattern returns (= the oracle), frame after frame with CHANGING images; and every way of leaving the fast path
     must fall back to the computed answer: other calibration, disparity windows, modified arrays, a frame of one image only."""
-    import os
     import gf_orb_slam2_amd as G
-    if os.environ.get("GFO_PAIR_WAIT_US") == "0":
-        pytest.skip("GFO_PAIR_WAIT_US=0: rigs are switched off")
     oe = oracle.OracleExtractor(1990, 1.2, 8, 20, 7)
     sf = oe.scale_factors
     frames = [(euroc_l, euroc_r), (synth_frame(752, 480, 40), synth_frame(752, 480, 41)), (euroc_r, euroc_l), (euroc_l, euroc_r)]
@@ -354,13 +364,10 @@ def test_declared_stereo_rig_extracts_as_one_submission_and_answers_the_associat
     er.close()
 
 
-def test_rigs_from_many_threads_and_a_partner_destroyed_mid_stream(oracle, euroc_l, euroc_r):
+def test_rigs_from_many_threads_and_a_partner_destroyed_mid_stream(oracle, euroc_l, euroc_r, patient_rigs):
     """six declared rigs at once (their stereo requests share device batches), then a rig whose right extractor is destroyed and
     re-created (Tracking::updateORBExtractor, src/Tracking.cc:298-320): the left side extracts alone until the rig is declared again"""
-    import os
     import gf_orb_slam2_amd as G
-    if os.environ.get("GFO_PAIR_WAIT_US") == "0":
-        pytest.skip("GFO_PAIR_WAIT_US=0: rigs are switched off")
     RIGS, REPS = 6, 6
     oe = oracle.OracleExtractor(1500, 1.2, 8, 20, 7)
     sf = oe.scale_factors
@@ -459,3 +466,48 @@ def test_combiner_prepares_slots_as_concurrency_shows_and_survives_allocation_fa
     assert c["slots_prepared"] == 0 and c["engine_broken"] == 1 and c["batches"] == 0, c
     c = counters(_combine_subprocess({"GFO_COMBINE_FAIL_BATCH": "2"}, _COMBINE_BODY))
     assert c["batches_redone"] >= 1 and c["requests"] == 36, c
+
+
+def test_rig_with_a_late_partner_at_the_product_wait(oracle, euroc_l, euroc_r):
+    """the product's rig waits 2 ms (gfo_tuning_get("pair_wait_us")) for the partner's image.  A right camera thread that
+    shows up 15 ms late -- a loaded host -- must cost nothing but time: the left side extracts alone after its wait, the late right
+    image is extracted alone as well, the association is computed on request, and every array equals the oracle's; the next frame,
+    on time, is paired again.  Results are asserted, not counters (which frame met its partner depends on the scheduler)."""
+    import time
+    import gf_orb_slam2_amd as G
+    from gf_orb_slam2_amd._lib import load_library
+    L = load_library()
+    assert L.gfo_tuning_get(b"pair_wait_us") == 2000 and L.gfo_tuning_get(b"pair_spin_us") == 400      # nothing left the product values behind
+    assert L.gfo_tuning_set(b"no_such_key", 1) == -1 and L.gfo_tuning_get(b"no_such_key") == -1 and L.gfo_tuning_set(b"pair_wait_us", -5) == -1
+    oe = oracle.OracleExtractor(1990, 1.2, 8, 20, 7)
+    sf = oe.scale_factors
+    frames = [(euroc_l, euroc_r), (synth_frame(752, 480, 40), synth_frame(752, 480, 41)), (euroc_r, euroc_l)]
+    refs = [(oe(l), oe(r)) for l, r in frames]
+    prm = G.StereoParams(480, BF, BF / FX, 0.0)
+    el, er = G.ORBextractor(1990, 1.2, 8, 20, 7, combining=True), G.ORBextractor(1990, 1.2, 8, 20, 7, combining=True)
+    m = G.ORBmatcher(0.8, True, extractor=el)
+    el.pair_with(er, prm)
+    alone0 = el.combiner_counters()["rig_alone"]
+    for rep in range(9):
+        i = rep % 3
+        late = rep % 3 == 1                       # every third frame the right camera is late
+        out = {}
+
+        def right():
+            if late:
+                time.sleep(0.015)
+            out["r"] = er(frames[i][1])
+        t = threading.Thread(target=right)
+        t.start()
+        kl, dl = el(frames[i][0])
+        t.join()
+        kr, dr = out["r"]
+        (okl, odl), (okr, odr) = refs[i]
+        assert kl.tobytes() == okl.tobytes() and kr.tobytes() == okr.tobytes() and (dl == odl).all() and (dr == odr).all(), (rep, late)
+        got = m.ComputeStereoMatches(kl, dl, kr, dr, sf, prm)
+        ref = oracle.stereo_match(okl, odl, okr, odr, sf, prm.n_rows, prm.mbf, prm.mb, prm.min_x)
+        assert got[0] == ref[0] and all(a.tobytes() == b.tobytes() for a, b in zip(got[1:], ref[1:])), (rep, late)
+        el.pair_with(er, prm)                     # what the adapter does with every frame's association
+    assert el.combiner_counters()["rig_alone"] >= alone0 + 2      # the late frames did take the lone path (15 ms against a 2-ms wait)
+    el.close()
+    er.close()
