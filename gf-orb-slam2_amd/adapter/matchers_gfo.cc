@@ -32,14 +32,19 @@
 #include "MapPoint.h"
 #include "ORBmatcher.h"
 
-// Compile-time variants of the reference:
-//   DELAYED_STEREO_MATCHING (include/Frame.h:40, off by default) is reproduced: compile this file with the same macro as the rest of
-//     the tree and ComputeStereoMatches_Undistorted visits what src/Frame.cc:1186-1199 visits (tests/_build/adapter_run_delayed);
-//   BUDGETING_FEATURE_MATCHING (include/ORBmatcher.h:36, off by default): SearchByBoW / SearchByProjection(Cur, Last) stop after
-//     MAX_NUM_FEATURE_MATCHING accepted matches (src/ORBmatcher.cc:360, 1547-1552) -- an order-dependent early exit that these
-//     bodies do NOT reproduce: refused at compile time instead of silently ignored (keep the reference's bodies in that build).
-#if defined(BUDGETING_FEATURE_MATCHING) && (defined(GFO_ADAPTER_PROJ_LAST) || defined(GFO_ADAPTER_BOW))
-#error "adapter/matchers_gfo.cc: GFO_ADAPTER_PROJ_LAST / GFO_ADAPTER_BOW do not reproduce BUDGETING_FEATURE_MATCHING (ORBmatcher.cc:360, 1547-1552); keep the reference's bodies in that build"
+// Compile-time variants of the reference, both reproduced -- compile this file with the same macros as the rest of the tree:
+//   DELAYED_STEREO_MATCHING (include/Frame.h:40, off by default): ComputeStereoMatches_Undistorted visits what src/Frame.cc:1186-1199
+//     visits (tests/_build/adapter_run_delayed);
+//   BUDGETING_FEATURE_MATCHING (include/ORBmatcher.h:36-37, off by default): SearchByBoW / SearchByProjection(Cur, Last) stop adding
+//     matches at MAX_NUM_FEATURE_MATCHING exactly where src/ORBmatcher.cc:360-365 / 1547-1552 break (gfo_search_by_bow_budget,
+//     gfo_proj_mode::max_matches; tests/_build/adapter_run_budget).
+#ifdef BUDGETING_FEATURE_MATCHING
+#ifndef MAX_NUM_FEATURE_MATCHING
+#error "BUDGETING_FEATURE_MATCHING needs MAX_NUM_FEATURE_MATCHING (include/ORBmatcher.h:37)"
+#endif
+#define GFO_FEATURE_BUDGET (MAX_NUM_FEATURE_MATCHING)
+#else
+#define GFO_FEATURE_BUDGET 0
 #endif
 
 #include <algorithm>
@@ -313,8 +318,7 @@ int ORBmatcher::SearchByProjection(Frame& F, const std::vector<MapPoint*>& vpMap
 // TrackWithMotionModel's matcher (Tracking.cc:1516).  The projection of the last frame's map points (:1465-1497)
 // stays on the host -- it is the reference's own cv::Mat arithmetic, a few thousand 3x3 products -- and becomes the
 // query array; window search, Hamming, ordered resolution and the rotation histogram run on the device.
-// Compiled without BUDGETING_FEATURE_MATCHING (the reference's default; the budgeted variant stops after
-// MAX_NUM_FEATURE_MATCHING accepted matches, :1547-1552, which this body does not reproduce).
+// With BUDGETING_FEATURE_MATCHING the loop ends with the MAX_NUM_FEATURE_MATCHING-th match (:1547-1552): gfo_proj_mode::max_matches.
 int ORBmatcher::SearchByProjection(Frame& CurrentFrame, const Frame& LastFrame, const float th, const bool bMono,
                                    double& numVisibleMpt)
 {
@@ -369,7 +373,7 @@ int ORBmatcher::SearchByProjection(Frame& CurrentFrame, const Frame& LastFrame, 
         angle[i] = CurrentFrame.mvKeysUn[i].angle;
     }
     gfo_frame_bounds fb = {Frame::mnMinX, Frame::mnMinY, Frame::mnMaxX, Frame::mnMaxY};
-    gfo_proj_mode mode = {0, 0.f, TH_HIGH, mbCheckOrientation ? 1 : 0};      // no ratio test in this overload (:1541)
+    gfo_proj_mode mode = {0, 0.f, TH_HIGH, mbCheckOrientation ? 1 : 0, GFO_FEATURE_BUDGET};      // no ratio test in this overload (:1541)
     std::vector<int32_t> outQ(N), outScore(N);
     int nmatches = 0;
     cv::Mat keep;
@@ -447,7 +451,7 @@ int ORBmatcher::SearchByProjection(Frame& CurrentFrame, KeyFrame* pKF, const std
         angle[i] = CurrentFrame.mvKeysUn[i].angle;
     }
     gfo_frame_bounds fb = {Frame::mnMinX, Frame::mnMinY, Frame::mnMaxX, Frame::mnMaxY};
-    gfo_proj_mode mode = {0, 0.f, ORBdist, mbCheckOrientation ? 1 : 0};
+    gfo_proj_mode mode = {0, 0.f, ORBdist, mbCheckOrientation ? 1 : 0, 0};     // (this overload has no budget in the reference either)
     std::vector<int32_t> outQ(N), outScore(N);
     int nmatches = 0;
     cv::Mat keep;
@@ -489,9 +493,9 @@ int ORBmatcher::SearchByBoW(KeyFrame* pKF, Frame& F, std::vector<MapPoint*>& vpM
     cv::Mat keepK, keepF;
     GfoUse use(F.mpORBextractorLeft);
     gfo_ctx* c = use.c;
-    const int rc = gfo_search_by_bow(c, rows32(pKF->mDescriptors, keepK), kfAngle.data(), valid.data(), nKF, &kfv.view,
-                                     rows32(F.mDescriptors, keepF), fAngle.data(), nF, &ffv.view, mfNNratio,
-                                     mbCheckOrientation ? 1 : 0, out.data(), &nmatches);
+    const int rc = gfo_search_by_bow_budget(c, rows32(pKF->mDescriptors, keepK), kfAngle.data(), valid.data(), nKF, &kfv.view,
+                                            rows32(F.mDescriptors, keepF), fAngle.data(), nF, &ffv.view, mfNNratio,
+                                            mbCheckOrientation ? 1 : 0, GFO_FEATURE_BUDGET, out.data(), &nmatches);
     if (rc != GFO_OK) {
         report(c, "SearchByBoW");
         return 0;

@@ -36,11 +36,17 @@ struct BowArgs {
     int* counters;             // [0] nmatches
     int* h_out;                // host-visible pinned copies of `out` / counters[0], written by k_bow_rotation (null: copied back)
     int* h_count;
+    // BUDGETING_FEATURE_MATCHING (gfo_search_by_bow_budget), 0 = off: every accepted match records its node and its ordinal among the
+    // node's accepted matches, every node how many it accepted; k_bow_budget then keeps of node j the first min(full_j, max(1, K - before_j))
+    int max_matches;
+    int* ord;                  // [n_f]
+    int* node_of;              // [n_f]
+    int* node_acc;             // [npairs]
 };
 
 // A node with more frame keypoints than the lanes' registers hold (> 64 * BOW_R): every keyframe keypoint sweeps the node's frame
 // keypoints from memory, `out` carries the taken state (this wave is its only writer: same-wave program order + the fence below).
-__device__ __forceinline__ void bow_node_sweep(const BowArgs& a, int kb, int ke, int fb, int fe, int lane)
+__device__ __forceinline__ void bow_node_sweep(const BowArgs& a, int pi, int kb, int ke, int fb, int fe, int lane)
 {
     const float factor = 1.0f / HISTO_LENGTH;  // :284 (applied to degrees, as the reference does)
     int accepted = 0;
@@ -82,6 +88,7 @@ __device__ __forceinline__ void bow_node_sweep(const BowArgs& a, int kb, int ke,
                     if (bin == HISTO_LENGTH) bin = 0;
                     a.rot_bin[bestIdxF] = bin;
                 }
+                if (a.max_matches > 0) { a.ord[bestIdxF] = accepted; a.node_of[bestIdxF] = pi; }
             }
             accepted++;
             // make lane 0's store visible to the whole wave's next sweep
@@ -91,6 +98,7 @@ __device__ __forceinline__ void bow_node_sweep(const BowArgs& a, int kb, int ke,
         }
     }
     if (lane == 0 && accepted) atomicAdd(&a.counters[0], accepted);
+    if (lane == 0 && a.max_matches > 0) a.node_acc[pi] = accepted;
 }
 
 
@@ -110,7 +118,7 @@ __global__ __launch_bounds__(256) void k_bow_match(BowArgs a)
     const int kb = a.kf_start[pr.x], ke = a.kf_start[pr.x + 1];
     const int fb = a.f_start[pr.y], fe = a.f_start[pr.y + 1];
     if (fe - fb > 64 * BOW_R) {
-        bow_node_sweep(a, kb, ke, fb, fe, lane);
+        bow_node_sweep(a, pi, kb, ke, fb, fe, lane);
         return;
     }
     const float factor = 1.0f / HISTO_LENGTH;  // :284 (applied to degrees, as the reference does)
@@ -191,12 +199,44 @@ __global__ __launch_bounds__(256) void k_bow_match(BowArgs a)
                         if (bin == HISTO_LENGTH) bin = 0;
                         a.rot_bin[bestIdxF] = bin;
                     }
+                    if (a.max_matches > 0) { a.ord[bestIdxF] = accepted; a.node_of[bestIdxF] = pi; }
                 }
                 accepted++;
             }
         }
     }
     if (lane == 0 && accepted) atomicAdd(&a.counters[0], accepted);
+    if (lane == 0 && a.max_matches > 0) a.node_acc[pi] = accepted;
+}
+
+// BUDGETING_FEATURE_MATCHING, ORBmatcher.cc:360-365: `if (nmatches >= MAX_NUM_FEATURE_MATCHING) break;` sits in the loop over ONE node's
+// keyframe keypoints.  Nodes are independent (a frame keypoint belongs to one node), so the unbudgeted kernel above has every node's
+// accepted matches in order; the budget keeps of node j the first t_j = min(full_j, max(1, K - before_j)) of them, before_j = the
+// matches kept in the nodes in front of it (common nodes in ascending id order = pair order).  One workgroup: the serial recurrence
+// over the nodes on one lane (a few hundred nodes), then the sweep that un-matches what lies beyond a node's share.
+__global__ __launch_bounds__(256) void k_bow_budget(BowArgs a)
+{
+    const int tid = threadIdx.x;
+    if (tid == 0) {
+        int before = 0;
+        for (int j = 0; j < a.npairs; j++) {
+            const int full = a.node_acc[j];
+            const int want = a.max_matches - before > 1 ? a.max_matches - before : 1;
+            const int t = full < want ? full : want;
+            a.node_acc[j] = t;
+            before += t;
+        }
+        a.counters[0] = before;
+    }
+    __threadfence_block();
+    __syncthreads();
+    for (int i = tid; i < a.n_f; i += 256) {
+        if (a.out[i] < 0) continue;
+        if (a.ord[i] >= a.node_acc[a.node_of[i]]) {
+            a.out[i] = -1;
+            a.rot_bin[i] = -1;
+        }
+    }
 }
 
 __global__ __launch_bounds__(256) void k_bow_rotation(BowArgs a)
@@ -278,6 +318,15 @@ extern "C" int gfo_search_by_bow(gfo_ctx* c, const uint8_t* kf_desc, const float
                                  int n_f, const gfo_feature_vector* f_fv, float nn_ratio, int check_orientation,
                                  int32_t* out_kf_idx, int* nmatches)
 {
+    return gfo_search_by_bow_budget(c, kf_desc, kf_angle, kf_mp_valid, n_kf, kf_fv, f_desc, f_angle, n_f, f_fv, nn_ratio, check_orientation, 0,
+                                    out_kf_idx, nmatches);
+}
+
+extern "C" int gfo_search_by_bow_budget(gfo_ctx* c, const uint8_t* kf_desc, const float* kf_angle, const uint8_t* kf_mp_valid,
+                                        int n_kf, const gfo_feature_vector* kf_fv, const uint8_t* f_desc, const float* f_angle,
+                                        int n_f, const gfo_feature_vector* f_fv, float nn_ratio, int check_orientation, int max_matches,
+                                        int32_t* out_kf_idx, int* nmatches)
+{
     if (!c) return GFO_ERR_INVALID;
     if (!kf_fv || !f_fv || !out_kf_idx || !nmatches || n_kf < 0 || n_f < 0 || (n_kf > 0 && (!kf_desc || !kf_mp_valid)) ||
         (n_f > 0 && !f_desc) || (check_orientation && n_kf > 0 && n_f > 0 && (!kf_angle || !f_angle))) {
@@ -329,6 +378,9 @@ extern "C" int gfo_search_by_bow(gfo_ctx* c, const uint8_t* kf_desc, const float
                  o_fd = take(32 * (size_t)n_f), o_fa = take(4 * (size_t)n_f), o_fs = take(4 * (size_t)(f_fv->n_nodes + 1)),
                  o_fi = take(4 * (size_t)(nf_items > 0 ? nf_items : 1)), o_pr = take(sizeof(int2) * pairs.size()),
                  o_rb = take(4 * (size_t)n_f), o_out = take(4 * (size_t)n_f), o_cnt = take(16);
+    const bool budget = max_matches > 0;   // the budget's bookkeeping behind everything else: not part of the one copy in, never copied out
+    const size_t o_ord = take(budget ? 4 * (size_t)n_f : 0), o_nof = take(budget ? 4 * (size_t)n_f : 0), o_nacc = take(budget ? 4 * pairs.size() : 0);
+    const size_t in_bytes = o_cnt + 16;
     if (off > c->scratch_bytes) {
         (void)hipStreamSynchronize(c->stream);
         if (c->d_scratch) (void)hipFree(c->d_scratch);
@@ -341,7 +393,7 @@ extern "C" int gfo_search_by_bow(gfo_ctx* c, const uint8_t* kf_desc, const float
     hipStream_t st = c->stream;
     // ten inputs and the three cleared outputs in ONE copy through the pinned mirror of the scratch layout (GfoXfer)
     GfoXfer x(c);
-    if (int rc = x.in(off)) return rc;
+    if (int rc = x.in(in_bytes)) return rc;
     x.put(o_kd, kf_desc, 32 * (size_t)n_kf);
     if (kf_angle) x.put(o_ka, kf_angle, 4 * (size_t)n_kf);
     x.put(o_kv, kf_mp_valid, n_kf);
@@ -363,6 +415,8 @@ extern "C" int gfo_search_by_bow(gfo_ctx* c, const uint8_t* kf_desc, const float
     a.pairs = (const int2*)(S + o_pr); a.npairs = (int)pairs.size();
     a.n_f = n_f; a.nn_ratio = nn_ratio; a.check_ori = check_orientation ? 1 : 0;
     a.out = (int*)(S + o_out); a.rot_bin = (int*)(S + o_rb); a.counters = (int*)(S + o_cnt);
+    a.max_matches = budget ? max_matches : 0;
+    a.ord = (int*)(S + o_ord); a.node_of = (int*)(S + o_nof); a.node_acc = (int*)(S + o_nacc);
     if (int rc = x.out(o_cnt + 16 - o_out)) return rc;
     // with the rotation check its kernel is the last one and writes the answer into the pinned block itself; without it, one copy back
     // (out and the counters are neighbours in the scratch)
@@ -370,6 +424,7 @@ extern "C" int gfo_search_by_bow(gfo_ctx* c, const uint8_t* kf_desc, const float
     if (direct) { a.h_out = (int*)x.HO; a.h_count = (int*)(x.HO + (o_cnt - o_out)); }
     gfo_prof_begin(c, ST_BOW);
     GFO_LAUNCH(c, k_bow_match, dim3((a.npairs + 3) / 4), dim3(256), 0, st, a);
+    if (budget) GFO_LAUNCH(c, k_bow_budget, dim3(1), dim3(256), 0, st, a);
     if (a.check_ori) GFO_LAUNCH(c, k_bow_rotation, dim3(1), dim3(256), 0, st, a);
     gfo_prof_end(c);
     if (int lrc = gfo_take_launch_err(c)) return lrc;
@@ -896,6 +951,6 @@ extern "C" int gfo_compute_bow(gfo_ctx* c, const uint8_t* desc, int n, int level
 // mutex so that no two host threads ever race through that first-launch path (round 3: eight threads, first k_pack_results).
 void gfo_kernels_bow(std::vector<const void*>& v)
 {
-    v.push_back((const void*)k_bow_match); v.push_back((const void*)k_bow_rotation); v.push_back((const void*)k_bow_transform);
+    v.push_back((const void*)k_bow_match); v.push_back((const void*)k_bow_budget); v.push_back((const void*)k_bow_rotation); v.push_back((const void*)k_bow_transform);
     v.push_back((const void*)k_bow_fold<false>); v.push_back((const void*)k_bow_fold<true>);
 }

@@ -100,6 +100,7 @@ struct ProjB {
     const uint4* cp_src; uint4* cp_dst; int cp_n16;
     const gfo_keypoint* kp_grid;   // null: a.kp
     int grid_frames;               // frames of the launch (the copy workgroups come behind them)
+    int max_matches;               // > 0: BUDGETING_FEATURE_MATCHING (gfo_proj_mode::max_matches), host-array calls only
 #ifdef GFO_PROJ_DEBUG
     int dbg_stop;
 #endif
@@ -804,6 +805,32 @@ __global__ __launch_bounds__(1024) void k_proj_resolve(ProjB a)
             }
         }
     }
+    // ---- BUDGETING_FEATURE_MATCHING (ORBmatcher.h:36-37, ORBmatcher.cc:1547-1552): the reference's loop over the queries ends with
+    //      the query whose match makes nmatches reach the budget.  A query's outcome depends on earlier queries only, so the budgeted
+    //      answer is the fixed point above with every query behind that one taken out: the rank of an accepted query among the accepted
+    //      ones, in query order, by counting (a variant that is off by default: the live list is in no particular order and is not
+    //      sorted for it), the K-th one's index is the cut.  That K-th match is kept but never enters the rotation histogram (the
+    //      reference breaks in front of it).
+    __shared__ int s_cut;
+    if (a.max_matches > 0) {
+        if (tid == 0) s_cut = 0x7FFFFFFF;
+        __threadfence_block();
+        __syncthreads();
+        for (int t = tid; t < nlive; t += 1024) {
+            if (pick[t] < 0) continue;
+            const int iq = (int)(live[t] & 0x7FFFFFFFu);
+            int rank = 0;
+            for (int u = 0; u < nlive; u++) rank += (pick[u] >= 0 && (int)(live[u] & 0x7FFFFFFFu) < iq) ? 1 : 0;
+            if (rank == a.max_matches - 1) s_cut = iq;     // (one thread at most: ranks are distinct)
+        }
+        __syncthreads();
+        const int cut = s_cut;
+        __syncthreads();
+        for (int t = tid; t < nlive; t += 1024)
+            if (pick[t] >= 0 && (int)(live[t] & 0x7FFFFFFFu) > cut) pick[t] = -1;
+        __threadfence_block();
+        __syncthreads();
+    }
     // ---- epilogue ----
     if (tid < HISTO_LENGTH) histo[tid] = 0;
     for (int k = tid; k < n; k += 1024) { tab[k] = -1; sc[k] = 0; }
@@ -815,7 +842,8 @@ __global__ __launch_bounds__(1024) void k_proj_resolve(ProjB a)
         const int iq = (int)(live[t] & 0x7FFFFFFFu);
         atomicMax(&tab[k], iq);
         cnt++;
-        if (a.check_ori) {
+        if (a.check_ori && a.max_matches > 0 && iq == s_cut) rot_bin[t] = HISTO_LENGTH;   // the match that reached the budget: in no bin, never cleared
+        else if (a.check_ori) {
             const ProjQ q = load_query(a, f, iq);
             const float ka = a.kp_angle ? a.kp_angle[(long long)f * a.ang_stride + k] : a.kp[(long long)f * a.kp_stride + k].angle;
             float rot = q.angle - ka;
@@ -855,7 +883,7 @@ __global__ __launch_bounds__(1024) void k_proj_resolve(ProjB a)
             const int k = pick[t];
             if (k < 0) continue;
             const int b = rot_bin[t];
-            if (b != keep[0] && b != keep[1] && b != keep[2]) {
+            if (b < HISTO_LENGTH && b != keep[0] && b != keep[1] && b != keep[2]) {
                 // -2: matched by this call, then cleared by its rotation check (the reference stores NULL there, :1586)
                 if (TABG) __hip_atomic_store(&tab[k], -2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 else tab[k] = -2;   // benign race: every writer stores the same value
@@ -1077,6 +1105,7 @@ extern "C" int gfo_search_by_projection_queries(gfo_ctx* c, const gfo_keypoint* 
     a.nn_ratio = mode->nn_ratio;
     a.th_dist = mode->th_dist;
     a.check_ori = mode->check_orientation;
+    a.max_matches = mode->max_matches > 0 ? mode->max_matches : 0;
     pj_bind(c, &a);
     // the resolve kernel writes counters, out_mp and out_score into the pinned block itself (ProjB::h_*): no copy back
     const size_t o_hm = 256, o_hs = o_hm + al256(4 * (size_t)n);
@@ -1134,7 +1163,7 @@ extern "C" int gfo_search_by_projection(gfo_ctx* c, const gfo_keypoint* kp_un, c
         d.angle = 0.f;
         d.flags = (((p.flags & 1) && !(p.flags & 2) && lvl >= 0 && lvl < nlevels) ? 1 : 0) | (p.flags & 4);
     }
-    gfo_proj_mode mode = {1, nn_ratio, TH_HIGH, 0};
+    gfo_proj_mode mode = {1, nn_ratio, TH_HIGH, 0, 0};
     return gfo_search_by_projection_queries(c, kp_un, desc, u_right, nullptr, n, fb, q.data(), mp_desc, m, &mode, kp_taken,
                                             out_mp, out_score, nmatches);
 }

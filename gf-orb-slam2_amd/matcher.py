@@ -133,7 +133,7 @@ class ORBmatcher:
         check(self._L, self._ctx, self._L.gfo_projection_fetch(self._ctx, frame, ptr(out_mp), ptr(out_sc), cap, C.byref(nm)))
         return nm.value, out_mp, out_sc
 
-    def SearchByBoW(self, kf_desc, kf_angle, kf_mp_valid, kf_fv, f_desc, f_angle, f_fv):
+    def SearchByBoW(self, kf_desc, kf_angle, kf_mp_valid, kf_fv, f_desc, f_angle, f_fv, max_matches=0):
         """ORBmatcher::SearchByBoW(KeyFrame*, Frame&, vpMapPointMatches) -- ORBmatcher.h:272, ORBmatcher.cc:270-404.
         kf_fv / f_fv = (node_ids, node_start, items): the CSR of each DBoW2::FeatureVector.
         Returns (nmatches, out_kf_idx)."""
@@ -153,13 +153,14 @@ class ORBmatcher:
         n_f = len(f_desc)
         out = np.full(max(n_f, 1), -1, np.int32)
         nm = C.c_int()
-        check(self._L, self._ctx, self._L.gfo_search_by_bow(self._ctx, ptr(kf_desc), ptr(kf_angle), ptr(kf_mp_valid), len(kf_desc),
-                                                            C.byref(a), ptr(f_desc), ptr(f_angle), n_f, C.byref(b), self.mfNNratio,
-                                                            1 if self.mbCheckOrientation else 0, ptr(out), C.byref(nm)))
+        # max_matches > 0: the reference compiled with BUDGETING_FEATURE_MATCHING (ORBmatcher.h:36-37)
+        check(self._L, self._ctx, self._L.gfo_search_by_bow_budget(self._ctx, ptr(kf_desc), ptr(kf_angle), ptr(kf_mp_valid), len(kf_desc),
+                                                                   C.byref(a), ptr(f_desc), ptr(f_angle), n_f, C.byref(b), self.mfNNratio,
+                                                                   1 if self.mbCheckOrientation else 0, int(max_matches), ptr(out), C.byref(nm)))
         return nm.value, out[:n_f]
 
     def SearchByProjectionQueries(self, keys_un, desc, u_right, kp_angle, bounds, queries, q_desc, use_ratio=False,
-                                  th_dist=None, kp_taken=None):
+                                  th_dist=None, kp_taken=None, max_matches=0):
         """The query form both projection overloads reduce to (gfo_search_by_projection_queries); with
         use_ratio=False and mbCheckOrientation it is ORBmatcher::SearchByProjection(CurrentFrame, LastFrame, th, ...)
         (ORBmatcher.cc:1440-1593) once the caller has projected the last frame's map points.
@@ -174,7 +175,7 @@ class ORBmatcher:
         kp_taken = None if kp_taken is None else np.ascontiguousarray(kp_taken, np.uint8)
         fb = FrameBoundsC(*bounds)
         mode = ProjModeC(1 if use_ratio else 0, self.mfNNratio, self.TH_HIGH if th_dist is None else th_dist,
-                         1 if self.mbCheckOrientation else 0)
+                         1 if self.mbCheckOrientation else 0, int(max_matches))
         out_q = np.full(max(n, 1), -1, np.int32)
         out_s = np.zeros(max(n, 1), np.int32)
         nm = C.c_int()

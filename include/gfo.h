@@ -270,6 +270,9 @@ typedef struct {
     float nn_ratio;
     int32_t th_dist;            /* 0..255: TH_HIGH (100) or ORBdist; 256 is the reference's "no candidate" value of bestDist */
     int32_t check_orientation;
+    int32_t max_matches;        /* 0: no limit.  > 0: BUDGETING_FEATURE_MATCHING (include/ORBmatcher.h:36-37, MAX_NUM_FEATURE_MATCHING):
+                                 * the loop over the queries ends with the query whose match makes nmatches reach this number, and that
+                                 * match stays out of the rotation histogram (src/ORBmatcher.cc:1547-1552)                                */
 } gfo_proj_mode;
 int gfo_search_by_projection_queries(gfo_ctx* ctx, const gfo_keypoint* kp_un, const uint8_t* desc,
                                      const float* u_right, const float* kp_angle, int n,
@@ -329,6 +332,13 @@ int gfo_search_by_bow(gfo_ctx* ctx, const uint8_t* kf_desc, const float* kf_angl
                       int n_kf, const gfo_feature_vector* kf_fv, const uint8_t* f_desc, const float* f_angle,
                       int n_f, const gfo_feature_vector* f_fv, float nn_ratio, int check_orientation,
                       int32_t* out_kf_idx, int* nmatches);
+/* The same with BUDGETING_FEATURE_MATCHING compiled in (include/ORBmatcher.h:36-37, src/ORBmatcher.cc:360-365): once nmatches has reached
+ * max_matches the loop over a node's keyframe keypoints ends -- the reference breaks out of THAT loop only, so every later common node
+ * still contributes its first accepted match.  max_matches <= 0: gfo_search_by_bow. */
+int gfo_search_by_bow_budget(gfo_ctx* ctx, const uint8_t* kf_desc, const float* kf_angle, const uint8_t* kf_mp_valid,
+                             int n_kf, const gfo_feature_vector* kf_fv, const uint8_t* f_desc, const float* f_angle,
+                             int n_f, const gfo_feature_vector* f_fv, float nn_ratio, int check_orientation, int max_matches,
+                             int32_t* out_kf_idx, int* nmatches);
 
 /* Frame::ComputeBoW -> DBoW2 TemplatedVocabulary<FORB>::transform(features, BowVector&, FeatureVector&, levelsup)
  * src/Frame.cc:661-668, Thirdparty/DBoW2/DBoW2/TemplatedVocabulary.h:1140-1212 and the per-feature tree descent

@@ -1316,6 +1316,13 @@ void orc_three_maxima(const int* histo, int L, int* ind1, int* ind2, int* ind3)
     else if ((float)max3 < 0.1f * (float)max1) *ind3 = -1;
 }
 
+/* BUDGETING_FEATURE_MATCHING (ORBmatcher.h:36-37, off in the reference's default build; MAX_NUM_FEATURE_MATCHING 150): two matchers
+ * stop adding matches once nmatches reaches the budget -- SearchByBoW breaks out of the CURRENT node's keyframe loop (ORBmatcher.cc:360-365;
+ * the next common node starts again and breaks after its first accepted match), SearchByProjection(Cur, Last) out of the whole loop over
+ * the last frame's points, BEFORE the match that reached the budget enters the rotation histogram (:1547-1552).  0 = compiled without. */
+static int g_feature_budget = 0;
+void orc_set_feature_budget(int max_matches) { g_feature_budget = max_matches > 0 ? max_matches : 0; }
+
 /* ------------------------------------------------------------------------------------------
  * ORBmatcher::SearchByBoW(KeyFrame*, Frame&, vpMapPointMatches) -- ORBmatcher.cc:270-404.
  * TH_LOW = 50, HISTO_LENGTH = 30; note factor = 1/HISTO_LENGTH (:284) is applied to a rotation in
@@ -1360,6 +1367,7 @@ int orc_search_by_bow(const uint8_t* kf_desc, const float* kf_angle, const uint8
                             histo[bin]++;
                         }
                         nmatches++;
+                        if (g_feature_budget > 0 && nmatches >= g_feature_budget) break; /* :360-365: leaves this node's keyframe loop only */
                     }
                 }
             }
@@ -1436,6 +1444,7 @@ int orc_search_by_projection_queries(const orc_keypoint* kp, const uint8_t* desc
             out_score[bestIdx] = bestDist;
             blocked[bestIdx] = (p->flags & 4) ? 1 : 0;
             nmatches++;
+            if (g_feature_budget > 0 && nmatches >= g_feature_budget) break; /* :1547-1552: before the rotation histogram */
             if (mode->check_orientation) {
                 float rot = p->angle - kp_angle[bestIdx];
                 if (rot < 0.0) rot += 360.0f;

@@ -105,6 +105,9 @@ typedef struct {
     float mbf, mb; /* baseline*fx and baseline                       */
     float min_x;   /* mnMinX                                         */
 } orc_stereo_params;
+/* BUDGETING_FEATURE_MATCHING (ORBmatcher.h:36-37): max_matches > 0 makes orc_search_by_bow and orc_search_by_projection_queries stop
+ * as ORBmatcher.cc:360-365 / :1547-1552 do; 0 (default) = compiled without it */
+void orc_set_feature_budget(int max_matches);
 /* 1: the call is ComputeStereoMatches_Undistorted(true): no outlier cut (Frame.cc:1290 `if (!isOnline)`); 0 (default): (false) */
 void orc_set_stereo_online(int on);
 int orc_stereo_match(const orc_keypoint* kl, const uint8_t* dl, int nl,

@@ -680,3 +680,18 @@ def features_in_area(kp_un, bounds, x, y, r, min_level=-1, max_level=-1):
     out = np.zeros(max(n, 1), np.int32)
     k = lib().orc_features_in_area(_p(kp_un), n, C.byref(fb), x, y, r, min_level, max_level, _p(out), n)
     return out[:k].copy()
+
+
+class feature_budget:
+    """with feature_budget(150): ... -- the matchers inside run as compiled with BUDGETING_FEATURE_MATCHING (ORBmatcher.h:36-37)"""
+
+    def __init__(self, max_matches):
+        self.k = int(max_matches)
+
+    def __enter__(self):
+        lib().orc_set_feature_budget(self.k)
+        return self
+
+    def __exit__(self, *exc):
+        lib().orc_set_feature_budget(0)
+        return False

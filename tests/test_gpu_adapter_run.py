@@ -21,6 +21,7 @@ FX, FY, CX, CY = 435.2046959714599, 435.2046959714599, 367.4517211914062, 252.20
 MBF = np.float32(47.906)
 MB = np.float32(np.float32(47.906) / np.float32(435.2))
 NF = 20
+BUDGET = 150            # MAX_NUM_FEATURE_MATCHING of include/ORBmatcher.h:37, what tests/host/Makefile gives adapter_run_budget
 f32 = np.float32
 
 
@@ -213,6 +214,10 @@ def run(tmp_path_factory, oracle, euroc_l, euroc_r):
                                                            100, bool(ori), np.zeros(len(kl1), np.uint8))
         ref["F"].append({"nm": nm, "idx": np.where(out_q >= 0, qi[np.maximum(out_q, 0)], -1).astype(np.int32), "visible": len(qi),
                          "fwd": fwd, "bwd": bwd})
+        with oracle.feature_budget(BUDGET):        # the same call in a BUDGETING_FEATURE_MATCHING build (tests/_build/adapter_run_budget)
+            nmb, out_qb, _ = oracle.search_by_projection_queries(kl1, dl1, st1[1], kl1["angle"], (0.0, 0.0, 752.0, 480.0), q, qd[qi], False, 0.0,
+                                                                 100, bool(ori), np.zeros(len(kl1), np.uint8))
+        ref.setdefault("F_budget", []).append({"nm": nmb, "idx": np.where(out_qb >= 0, qi[np.maximum(out_qb, 0)], -1).astype(np.int32)})
     # H: SearchByProjection(Cur = frame 1, KeyFrame = frame 0, sAlreadyFound, th, ORBdist): the adapter's host side restated
     # (ORBmatcher.cc:1607-1650; PredictScale / the distance range hand back what the harness stored, adapter_link_support.cc)
     th_h, orbdist, ori_h = 10.0, 90, 1.0
@@ -275,6 +280,9 @@ def run(tmp_path_factory, oracle, euroc_l, euroc_r):
     kvalid.tofile(ind / "I_kf_valid.bin")
     ref["I"] = [oracle.search_by_bow(dl0, kl0["angle"], (kvalid == 1).astype(np.uint8), oracle.make_feature_vector(knode), dl1, kl1["angle"],
                                      oracle.make_feature_vector(fnode), 0.7, bool(o)) for o in (0, 1)]
+    with oracle.feature_budget(BUDGET):
+        ref["I_budget"] = [oracle.search_by_bow(dl0, kl0["angle"], (kvalid == 1).astype(np.uint8), oracle.make_feature_vector(knode), dl1, kl1["angle"],
+                                                oracle.make_feature_vector(fnode), 0.7, bool(o)) for o in (0, 1)]
 
     # J: Frame::ComputeBoW() on frame 1 with vocabularies of several shapes / weightings / scorings (levelsup = 4, Frame.cc:666)
     ref["J"] = []
@@ -319,6 +327,10 @@ def run(tmp_path_factory, oracle, euroc_l, euroc_r):
     p4 = subprocess.run([EXE, GOLDEN, str(ind), str(outd4), "6"], capture_output=True, text=True, timeout=600, env=dict(env, GFO_DEVICES="0,0,0"))
     ref["devices"] = {"rc": p4.returncode, "stderr": p4.stderr, "out": outd4,
                       "report": dict(l.split() for l in open(outd4 / "report.txt").read().splitlines() if l.strip()) if (outd4 / "report.txt").exists() else {}}
+    outd5 = tmp_path_factory.mktemp("adapter_out_budget")
+    if os.path.exists(EXE + "_budget"):
+        p5 = subprocess.run([EXE + "_budget", GOLDEN, str(ind), str(outd5), "3"], capture_output=True, text=True, timeout=600, env=env)
+        ref["budget"] = {"rc": p5.returncode, "stderr": p5.stderr, "out": outd5}
     outd3 = tmp_path_factory.mktemp("adapter_out_delayed")
     if os.path.exists(EXE + "_delayed"):
         p3 = subprocess.run([EXE + "_delayed", GOLDEN, str(ind), str(outd3), "3"], capture_output=True, text=True, timeout=600, env=env)
@@ -555,6 +567,32 @@ def test_search_by_bow_member(run):
         np.testing.assert_array_equal(got, out, err_msg=tag)
         assert int(_rd(run, f"I_nmatches{tag}.bin", np.int32)[0]) == nm
         assert nm > 100, (tag, nm)
+
+
+def test_matcher_members_of_a_budgeting_feature_matching_build(run):
+    """adapter/matchers_gfo.cc + the harness compiled with -DBUDGETING_FEATURE_MATCHING -DMAX_NUM_FEATURE_MATCHING=150
+    (include/ORBmatcher.h:36-37): SearchByProjection(Cur, Last) ends with the 150th match, which stays out of the rotation histogram
+    (ORBmatcher.cc:1547-1552); SearchByBoW leaves a node's loop once 150 is reached, every later node still adds its first match
+    (:360-365).  Against the oracle compiled the same way (orc_set_feature_budget); everything else of the program is unchanged."""
+    if "budget" not in run:
+        pytest.skip("tests/_build/adapter_run_budget is missing (built by __graft_entry__.build() where the reference headers are)")
+    b = run["budget"]
+    assert b["rc"] == 0, b["stderr"][-3000:]
+    assert "[gfo]" not in b["stderr"], b["stderr"][-2000:]
+    for v, want in enumerate(run["F_budget"]):
+        got = np.fromfile(b["out"] / f"F{v}_out_last_idx.bin", np.int32)
+        nm = int(np.fromfile(b["out"] / f"F{v}_nmatches_visible.bin", np.int32)[0])
+        np.testing.assert_array_equal(got, want["idx"], err_msg=f"variant {v}")
+        assert nm == want["nm"] and nm <= BUDGET, v
+        assert run["F"][v]["nm"] > BUDGET                                  # the budget bites in every variant
+    for tag, (nm, out), (nm_full, _) in zip(("", "_ori"), run["I_budget"], run["I"]):
+        np.testing.assert_array_equal(np.fromfile(b["out"] / f"I_out_kf_idx{tag}.bin", np.int32), out, err_msg=tag)
+        assert int(np.fromfile(b["out"] / f"I_nmatches{tag}.bin", np.int32)[0]) == nm
+        assert nm < nm_full, (tag, nm, nm_full)
+    # an extraction and an association of that build: untouched by the macro
+    kd = run["oracle"].KEYPOINT_DTYPE
+    assert np.fromfile(b["out"] / "A_f01_kl.bin", kd).tobytes() == run["frames"][1][0].tobytes()
+    assert np.fromfile(b["out"] / "A_f01_uright.bin", np.float32).tobytes() == run["frames"][1][4][1].tobytes()
 
 
 def test_compute_bow_member(run):

@@ -52,6 +52,23 @@ def test_bow_matches_oracle(ext, oracle, seed, flips, shift, sigma, ratio, ori):
         assert ref[0] > 200
 
 
+@pytest.mark.parametrize("K", [1, 40, 150, 600, 100000])
+def test_bow_with_a_feature_budget(ext, oracle, K):
+    """gfo_search_by_bow_budget = SearchByBoW compiled with BUDGETING_FEATURE_MATCHING (ORBmatcher.h:36-37, ORBmatcher.cc:360-365): the
+    break leaves ONE node's keyframe loop, so every common node after the one that reaches the budget still adds its first match;
+    nodes of a few and of hundreds of keypoints (both k_bow_match paths), with and without the rotation check"""
+    import gf_orb_slam2_amd as G
+    for seed, shift, ori in ((0, 2, True), (1, 4, True), (2, 6, False), (3, 0, True)):
+        kd_, ka, valid, kfv, fd, fa, ffv = _case(oracle, seed, 6, shift, 5.0)
+        with oracle.feature_budget(K):
+            ref = oracle.search_by_bow(kd_, ka, valid, kfv, fd, fa, ffv, 0.75, ori)
+        got = G.ORBmatcher(0.75, ori, extractor=ext).SearchByBoW(kd_, ka, valid, kfv, fd, fa, ffv, max_matches=K)
+        assert got[0] == ref[0], (K, seed)
+        np.testing.assert_array_equal(got[1], ref[1])
+    full = oracle.search_by_bow(kd_, ka, valid, kfv, fd, fa, ffv, 0.75, ori)
+    assert (ref[0] == full[0]) == (K >= full[0])
+
+
 def test_bow_edge_cases(ext, oracle):
     import gf_orb_slam2_amd as G
     m = G.ORBmatcher(0.7, True, extractor=ext)

@@ -428,7 +428,7 @@ def test_stereo_frame_second_call_keeps_state(oracle):
         np.testing.assert_array_equal(a, b)
 
 
-def bow_python(kd_, ka, valid, kfv, fd, fa, ffv, ratio, ori):
+def bow_python(kd_, ka, valid, kfv, fd, fa, ffv, ratio, ori, budget=0):
     """SearchByBoW written straight from ORBmatcher.cc:270-404 with Python containers."""
     kmap = {int(n): list(kfv[2][kfv[1][i]:kfv[1][i + 1]]) for i, n in enumerate(kfv[0])}
     fmap = {int(n): list(ffv[2][ffv[1][i]:ffv[1][i + 1]]) for i, n in enumerate(ffv[0])}
@@ -458,6 +458,8 @@ def bow_python(kd_, ka, valid, kfv, fd, fa, ffv, ratio, ori):
                     b = int(np.floor(v + 0.5))
                     hist[0 if b == 30 else b].append(bi)
                 nm += 1
+                if budget and nm >= budget:          # BUDGETING_FEATURE_MATCHING, ORBmatcher.cc:360-365: out of THIS node's loop
+                    break
     if ori:
         sizes = [len(h) for h in hist]
         order = sorted(range(30), key=lambda i: (-sizes[i], i))
@@ -498,6 +500,68 @@ def test_bow_oracle_against_python_statement(oracle):
         np.testing.assert_array_equal(got[1], ref[1])
     assert oracle.three_maxima([5, 1, 9, 0, 9, 3]) == (2, 4, 0)
     assert oracle.three_maxima([100, 5, 3] + [0] * 27) == (0, -1, -1)
+
+
+def test_feature_budget_variant_of_the_oracle(oracle):
+    """BUDGETING_FEATURE_MATCHING (ORBmatcher.h:36-37, ORBmatcher.cc:360-365, 1547-1552): SearchByBoW against the Python statement with
+    the same break; SearchByProjection(Cur, Last) against its defining property -- without the rotation check a budgeted run IS the
+    unbudgeted run over the prefix of queries that ends with the K-th accepted one"""
+    kd = oracle.KEYPOINT_DTYPE
+    kl = np.fromfile(os.path.join(GOLDEN, "EuRoC_l_kp.bin"), kd)
+    dl = np.fromfile(os.path.join(GOLDEN, "EuRoC_l_desc.bin"), np.uint8).reshape(-1, 32)
+    rng = np.random.default_rng(4)
+    fd = dl.copy()
+    bits = rng.integers(0, 256, (len(fd), 4))
+    for j in range(4):
+        fd[np.arange(len(fd)), bits[:, j] >> 3] ^= (1 << (bits[:, j] & 7)).astype(np.uint8)
+    node_k = (dl[:, 0] >> 3).astype(np.int64)
+    node_f = (fd[:, 0] >> 3).astype(np.int64)
+    kfv, ffv = oracle.make_feature_vector(node_k), oracle.make_feature_vector(node_f)
+    valid = np.ones(len(dl), np.uint8)
+    full = oracle.search_by_bow(dl, kl["angle"], valid, kfv, fd, kl["angle"], ffv, 0.75, True)
+    assert full[0] > 600
+    for K in (1, 37, 150, 400, 100000):
+        with oracle.feature_budget(K):
+            got = oracle.search_by_bow(dl, kl["angle"], valid, kfv, fd, kl["angle"], ffv, 0.75, True)
+        want = bow_python(dl, kl["angle"], valid, kfv, fd, kl["angle"], ffv, 0.75, True, budget=K)
+        assert got[0] == want[0], K
+        np.testing.assert_array_equal(got[1], want[1])
+        if K == 100000:
+            assert got[0] == full[0] and (got[1] == full[1]).all()
+        elif K == 150:
+            assert got[0] < full[0]                      # the budget bites; every node after the crossing still adds its first match
+    assert oracle.search_by_bow(dl, kl["angle"], valid, kfv, fd, kl["angle"], ffv, 0.75, True)[0] == full[0]      # the switch is off again
+    # projection queries (the (Cur, Last) form): m queries around the keypoints
+    n, m = len(kl), 1200
+    src = rng.integers(0, n, m)
+    q = np.zeros(m, oracle.PROJ_QUERY_DTYPE)
+    q["u"] = kl["x"][src] + rng.normal(0, 1.5, m); q["v"] = kl["y"][src] + rng.normal(0, 1.5, m); q["ur"] = q["u"] - 4
+    q["radius"] = (np.float32(7.0) * oracle.OracleExtractor().scale_factors[kl["octave"][src]]).astype(np.float32)
+    q["min_level"] = kl["octave"][src] - 1; q["max_level"] = kl["octave"][src] + 1
+    q["angle"] = kl["angle"][src]; q["flags"] = np.where(rng.random(m) < 0.8, 1 | 4, 1)
+    qd = dl[src].copy()
+    bounds = (0.0, 0.0, 752.0, 480.0)
+    plain = oracle.search_by_projection_queries(kl, dl, None, kl["angle"], bounds, q, qd, False, 0.9, 100, False)
+    assert plain[0] > 800
+    for K in (1, 150, 500):
+        with oracle.feature_budget(K):
+            got = oracle.search_by_projection_queries(kl, dl, None, kl["angle"], bounds, q, qd, False, 0.9, 100, False)
+        assert got[0] == K
+        # the prefix that ends with the K-th accepted query: the shortest prefix whose unbudgeted run accepts K
+        lo, hi = 1, m
+        while lo < hi:
+            mid = (lo + hi) // 2
+            if oracle.search_by_projection_queries(kl, dl, None, kl["angle"], bounds, q[:mid], qd[:mid], False, 0.9, 100, False)[0] >= K:
+                hi = mid
+            else:
+                lo = mid + 1
+        want = oracle.search_by_projection_queries(kl, dl, None, kl["angle"], bounds, q[:lo], qd[:lo], False, 0.9, 100, False)
+        assert want[0] == K
+        np.testing.assert_array_equal(got[1], want[1])
+        np.testing.assert_array_equal(got[2], want[2])
+    with oracle.feature_budget(150):                        # with the rotation check: the 150th match is not in the histogram, hence never cleared
+        got = oracle.search_by_projection_queries(kl, dl, None, kl["angle"], bounds, q, qd, False, 0.9, 100, True)
+    assert 0 < got[0] <= 150
 
 
 def test_ocv_variant_switches_are_single_and_restorable(oracle):
