@@ -898,7 +898,11 @@ class Job:
             cand = {"hbm": hbm, "valu-issue": issue, "lds": v.get("lds_busy_frac") or 0.0}
             return max(cand, key=cand.get)
         for k, v in per_stage.items():
-            v["bound"] = bound_of(v, v["frac"])
+            # HBM utilisation for the purpose of naming the wall: the bytes that really crossed the memory controllers where the PMC
+            # passes measured them (k_orient_desc's overlapping windows are served by L2: 0.55 x its algorithmic bytes), else `frac`
+            t = v.get("traffic_per_step")
+            v["hbm_traffic_frac"] = round(t / (stage_ms[k] * 1e-3) / 8e12, 5) if t and stage_ms.get(k, 0) > 0 else None
+            v["bound"] = bound_of(v, v["hbm_traffic_frac"] if v["hbm_traffic_frac"] is not None else v["frac"])
         return n_kp_img, {
             # `bound` names the wall the dominant kernel actually sits against: whichever of the two fractions is larger.
             # achieved / peak / frac stay the HBM figures the contract defines; issue_frac is the other roofline.
@@ -908,7 +912,7 @@ class Job:
             "issue_model": {"valu_instructions_per_launch": int(issue_all[dom] / max(launches_per_step, 1e-9)) if issue_all.get(dom) else None,
                             "cycles_per_wave_instruction_flat": ISSUE_CYCLES, "cycles_per_wave_instruction_weighted": dom_pipes["mean_cycles_per_valu"],
                             "simds": N_SIMDS, "clock_ghz": CLOCK_HZ / 1e9, "source": issue_src, "opcode_mix": mix_src,
-                            "bound_rule": "largest of frac (HBM), issue_frac_weighted and lds_busy_frac"},
+                            "bound_rule": "largest of HBM (measured traffic where a PMC pass gave it, else frac), issue_frac_weighted and lds_busy_frac"},
             "traffic": traffic, "traffic_measured": bool(live), "traffic_source": traffic_source, "traffic_pass_killed": LIVE_TRAFFIC_KILLED,
             "avg_launch_ms": round(avg_launch_ms, 4), "algorithmic_bytes_per_launch": int(bytes_per_launch),
             "pipeline_frac_hbm": round(value_per_gpu * survey_total / 8e12, 5),

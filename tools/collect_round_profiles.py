@@ -28,4 +28,11 @@ json.dump({"workload": old["workload"], "runs": runs}, open(os.path.join(P, f"bo
 for src, dst in ((f"bench_default_{tag}.json", f"bench_default_{tag}.json"), (f"latency_pair_{tag}.json", f"latency_pair_{tag}.json"),
                  (f"sq_counters_{tag}.txt", f"sq_counters_{tag}.txt"), (f"trace_boundary_{tag}_k8_combined.txt", f"boundary_trace_{tag}_k8_combined.txt")):
     shutil.copy(os.path.join(G, src), os.path.join(P, dst))
+# the per-stage, per-step SQ counters bench.py's issue / LDS model reads (tools/pmc_sq.sh)
+sq = os.path.join(G, "pmc_sq", "sq_per_step.json")
+if os.path.exists(sq):
+    j = json.load(open(sq))
+    j["tag"] = tag
+    for name in (f"sq_counters_{tag}.json", "sq_counters_latest.json"):
+        json.dump(j, open(os.path.join(P, name), "w"), indent=1)
 print("profiles/", tag, "refreshed")
