@@ -117,8 +117,10 @@ for it in range(cases):
             ratio = float(rng.choice([0.7, 0.9]))
             thd = int(rng.choice([0, 50, 100, 255]))
             ka = kp["angle"].copy()
-            ref = O.search_by_projection_queries(kp, desc, u_right, ka, bounds, q, qd, use_ratio, ratio, thd, ori, taken)
-            got = G.ORBmatcher(ratio, ori, extractor=ext).SearchByProjectionQueries(kp, desc, u_right, ka, bounds, q, qd, use_ratio, thd, taken)
+            budget = int(rng.integers(1, 700)) if rng.random() < 0.3 else 0        # BUDGETING_FEATURE_MATCHING (ORBmatcher.cc:1547-1552)
+            with O.feature_budget(budget):
+                ref = O.search_by_projection_queries(kp, desc, u_right, ka, bounds, q, qd, use_ratio, ratio, thd, ori, taken)
+            got = G.ORBmatcher(ratio, ori, extractor=ext).SearchByProjectionQueries(kp, desc, u_right, ka, bounds, q, qd, use_ratio, thd, taken, max_matches=budget)
         matches[kind] += int(ref[0])
         if got[0] != ref[0] or not (got[1] == ref[1]).all() or not (got[2] == ref[2]).all():
             mismatch(kind, it=it, n=n, m=m, wave=os.environ["GFO_PROJ_WAVE"], cap=os.environ["GFO_PROJ_SPILL_CAP"], got=got[0], ref=ref[0])
@@ -136,8 +138,10 @@ for it in range(cases):
         valid = (rng.random(nk) >= rng.uniform(0, 0.5)).astype(np.uint8)
         ratio, ori = float(rng.choice([0.6, 0.75, 0.9])), bool(rng.random() < 0.7)
         kfv, ffv = O.make_feature_vector(node_k), O.make_feature_vector(node_f)
-        ref = O.search_by_bow(kd, kk["angle"].copy(), valid, kfv, fd, fa, ffv, ratio, ori)
-        got = G.ORBmatcher(ratio, ori, extractor=ext).SearchByBoW(kd, kk["angle"].copy(), valid, kfv, fd, fa, ffv)
+        budget = int(rng.integers(1, 700)) if rng.random() < 0.3 else 0            # BUDGETING_FEATURE_MATCHING (ORBmatcher.cc:360-365)
+        with O.feature_budget(budget):
+            ref = O.search_by_bow(kd, kk["angle"].copy(), valid, kfv, fd, fa, ffv, ratio, ori)
+        got = G.ORBmatcher(ratio, ori, extractor=ext).SearchByBoW(kd, kk["angle"].copy(), valid, kfv, fd, fa, ffv, max_matches=budget)
         matches["bow"] += int(ref[0])
         if got[0] != ref[0] or not (got[1] == ref[1]).all():
             mismatch("bow", it=it, nk=nk, nf=nf, nnodes=nnodes, got=got[0], ref=ref[0])
