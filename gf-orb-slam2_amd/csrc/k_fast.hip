@@ -181,6 +181,20 @@ __device__ __forceinline__ int corner_score(const uint8_t* __restrict__ tl, int 
     return best;
 }
 
+// Round 6 experiment, NEGATIVE (profiles/fast_prefilter_r06.txt), off by default: a DWORD-level pre-filter in front of stage A of
+// the first round.  A pixel passes the compass test only if one of (U, D) and one of (L, R) differs from it by more than t, so for the
+// four pixels of a dword  min(max(SAD(C,U), SAD(C,D)), max(SAD(C,L), SAD(C,R))) > t  is necessary for ANY of them to pass: four
+// v_sad_u8, three min / max and a compare per dword instead of the 36 packed operations of the test itself; at iniThFAST 70 % of the
+// dwords of the synthetic stream (61 % of EuRoC's) fail it.  The survivors' ids go through a 128-entry ring in LDS and the full test
+// runs on 64 of them at a time.  Parity-green -- and 5 % fewer vector instructions for 5 % MORE time (256 -> 270 us): the survivors of
+// a cell rarely fill whole 64-lane passes (1.25 on average, most cells pay two), the gathered tile reads of the second stage conflict
+// where the row-major ones did not (SQ_LDS_BANK_CONFLICT +30 %), and the ring costs two wave fences per pass.
+// -DGFO_FAST_PREFILTER=1 builds it.
+#ifndef GFO_FAST_PREFILTER
+#define GFO_FAST_PREFILTER 0
+#endif
+#define GFO_FAST_RING_BYTES 0     // the ring lives in the last 128 entries of the pixel queue (a capped queue only: see q_cap below)
+
 // TP / SP: pitch of the pixel tile and of the score map in LDS, compile-time so that every ring and neighbour
 // offset is an immediate of the LDS instruction (three buckets cover cells up to 64 px).
 // XCD8: workgroups are dealt round-robin over the 8 XCDs (workgroup b runs on XCD b % 8), so with the plain
@@ -213,13 +227,23 @@ __global__ __launch_bounds__(256) void k_fast(const GfoGeom* __restrict__ gp, Gf
     // after the tile load it still takes a third of its time, tools/fast_phase_times.sh).  A cell that would overflow it
     // (noise-like imagery) scores what it has queued before it queues more, and drops the corner list for a dense pass over
     // the score map if even the corners do not fit (below).
+#if GFO_FAST_PREFILTER
+    // the pre-filter's ring takes the last 128 entries of a CAPPED queue (one that flushes anyway when it fills: 640 entries instead of
+    // 768); a queue that holds the whole scan area has no room to give and its cells take the plain loop
+    const bool prefilter = g.fast_q_cap < g.fast_npx_max && g.fast_q_cap >= 512;
+    const int q_cap = prefilter ? g.fast_q_cap - 128 : g.fast_q_cap;
+#else
     const int q_cap = g.fast_q_cap;
+#endif
     const bool q_capped = q_cap < g.fast_npx_max;                        // wave-uniform
-    const int per_wave = tile_bytes + smap_bytes + 2 * q_cap;
+    const int per_wave = tile_bytes + smap_bytes + 2 * g.fast_q_cap;
     uint8_t* tile = lds + wave * per_wave;
     uint8_t* smap = tile + tile_bytes;
     unsigned short* qa = reinterpret_cast<unsigned short*>(smap + smap_bytes);
     unsigned short* qb = qa;  // stage B1 writes entry j <= i after reading entry i (same wave, in order)
+#if GFO_FAST_PREFILTER
+    unsigned short* ring = qa + q_cap;   // 128 dword ids waiting for the full compass test (stage A of the first round)
+#endif
 
     if (cell >= g.total_cells) return;
     // cell -> (level, row, column) through the table plan() uploads: one scalar load instead of a search over the
@@ -349,6 +373,91 @@ __global__ __launch_bounds__(256) void k_fast(const GfoGeom* __restrict__ gp, Gf
         (void)tq2;
         int idx = (lr + 3) * tp4 + 1 + lq;
         int p0 = (lr << 6) + c0;                       // queue entry of the dword's pixel 0: px | py << 6 (cells are at most 64 px wide)
+#if GFO_FAST_PREFILTER
+        if (round == 0 && prefilter) {
+            // thresholds of a row's LAST dword (pixels right of scan column sw - 1 must not pass) and of every other one
+            const int nv_last = sw - 4 * (nq - 1);
+            const unsigned tq_full = (unsigned)tq | ((unsigned)tq << 16);
+            const unsigned tq_e_last = (nv_last > 0 ? (unsigned)tq : 0x7FFFu) | ((nv_last > 2 ? (unsigned)tq : 0x7FFFu) << 16);
+            const unsigned tq_o_last = (nv_last > 1 ? (unsigned)tq : 0x7FFFu) | ((nv_last > 3 ? (unsigned)tq : 0x7FFFu) << 16);
+            int wr = 0, rd = 0;                        // ring cursors (scalar): wr - rd dword ids are waiting
+            // the full compass test on `cnt` (<= 64) waiting dwords, lane i takes ring entry rd + i; survivors' pixels go to qa
+            auto full_pass = [&](int cnt) {
+                if (q_capped && na + 256 > q_cap) {
+                    wave_sync();
+                    score_queued(dense ? 0 : nb);
+                    wave_sync();
+                    na = dense ? 0 : nb;
+                    if (!dense && nb + 256 > q_cap) {
+                        dense = true;
+                        na = 0;
+                    }
+                }
+                const unsigned long long m_in = cnt >= 64 ? ~0ull : (1ull << cnt) - 1ull;
+                unsigned t_e = 0, t_o = 0;
+                int pd = 0;
+                if (__builtin_amdgcn_inverse_ballot_w64(m_in)) {
+                    pd = ring[(rd + lane) & 127];
+                    const int py = pd >> 6, px = pd & 63;
+                    const int di = (py + 3) * tp4 + 1 + (px >> 2);
+                    const unsigned C = t32[di], Wm = t32[di - 1], Wp = t32[di + 1];
+                    const unsigned U = t32[di + 3 * tp4], D = t32[di - 3 * tp4];
+                    const unsigned Lw = __builtin_amdgcn_alignbyte(C, Wm, 1);
+                    const unsigned Rw = __builtin_amdgcn_alignbyte(Wp, C, 3);
+                    const bool last = (px >> 2) == nq - 1;
+                    const unsigned te_l = last ? tq_e_last : tq_full, to_l = last ? tq_o_last : tq_full;
+#pragma unroll
+                    for (int h = 0; h < 2; h++) {
+                        const unsigned ps = h ? 0x0C030C01u : 0x0C020C00u;
+                        const s16x2 vc = __builtin_bit_cast(s16x2, __builtin_amdgcn_perm(0u, C, ps));
+                        const s16x2 pu = __builtin_bit_cast(s16x2, __builtin_amdgcn_perm(0u, U, ps));
+                        const s16x2 pr = __builtin_bit_cast(s16x2, __builtin_amdgcn_perm(0u, Rw, ps));
+                        const s16x2 pdn = __builtin_bit_cast(s16x2, __builtin_amdgcn_perm(0u, D, ps));
+                        const s16x2 pl = __builtin_bit_cast(s16x2, __builtin_amdgcn_perm(0u, Lw, ps));
+                        const s16x2 dk = vc - __builtin_elementwise_max(__builtin_elementwise_min(pu, pdn), __builtin_elementwise_min(pr, pl));
+                        const s16x2 br = __builtin_elementwise_min(__builtin_elementwise_max(pu, pdn), __builtin_elementwise_max(pr, pl)) - vc;
+                        const unsigned t1 = __builtin_bit_cast(unsigned, __builtin_bit_cast(s16x2, h ? to_l : te_l) - __builtin_elementwise_max(dk, br));
+                        if (h) t_o = t1; else t_e = t1;
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const unsigned tw = (j & 1) ? t_o : t_e;
+                    unsigned long long m;
+                    if (j & 2) m = __builtin_amdgcn_ballot_w64((int)tw < 0);
+                    else asm("v_cmp_gt_i16_e64 %0, 0, %1" : "=s"(m) : "v"(tw));
+                    unsigned short* qj = qa + na;
+                    if (__builtin_amdgcn_inverse_ballot_w64(m)) qj[__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u))] = (unsigned short)(pd + j);
+                    na += __popcll(m);
+                }
+                rd += cnt;
+            };
+            for (int y0 = 0; y0 < sh; y0 += rpi, idx += rpi * tp4, p0 += rpi << 6) {
+                bool keep = false;
+                if (lane_on && lr < sh - y0) {
+                    const unsigned C = t32[idx], Wm = t32[idx - 1], Wp = t32[idx + 1];
+                    const unsigned U = t32[idx + 3 * tp4], D = t32[idx - 3 * tp4];
+                    const unsigned Lw = __builtin_amdgcn_alignbyte(C, Wm, 1);
+                    const unsigned Rw = __builtin_amdgcn_alignbyte(Wp, C, 3);
+                    const unsigned sv = max(__builtin_amdgcn_sad_u8(C, U, 0u), __builtin_amdgcn_sad_u8(C, D, 0u));
+                    const unsigned shz = max(__builtin_amdgcn_sad_u8(C, Lw, 0u), __builtin_amdgcn_sad_u8(C, Rw, 0u));
+                    keep = min(sv, shz) > (unsigned)tq;
+                }
+                const unsigned long long m = __builtin_amdgcn_ballot_w64(keep);
+                if (__builtin_amdgcn_inverse_ballot_w64(m))
+                    ring[(wr + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u))) & 127] = (unsigned short)p0;
+                wr += __popcll(m);
+                if (wr - rd >= 64) {
+                    wave_sync();      // the ring entries written above are read by other lanes
+                    full_pass(64);
+                }
+            }
+            if (wr - rd > 0) {
+                wave_sync();
+                full_pass(wr - rd);
+            }
+        } else
+#endif
         for (int y0 = 0; y0 < sh; y0 += rpi, idx += rpi * tp4, p0 += rpi << 6) {
             if (q_capped && na + 256 > q_cap) {
                 // a pass queues up to 256 pixels: make room first -- score what is queued (its corners stay, compacted, at the
