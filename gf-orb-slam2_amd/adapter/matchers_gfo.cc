@@ -7,6 +7,7 @@
 //
 //   GFO_ADAPTER_STEREO        Frame::ComputeStereoMatches_Undistorted(bool)                     src/Frame.cc:1167-1316
 //   GFO_ADAPTER_PROJECTION    ORBmatcher::SearchByProjection(Frame&, vector<MapPoint*>&, th)    src/ORBmatcher.cc:155-241
+//   GFO_ADAPTER_PROJ_BUDGET   ORBmatcher::SearchByProjection_Budget(F, MapPoints, th, time)     src/ORBmatcher.cc:45-153
 //   GFO_ADAPTER_PROJ_LAST     ORBmatcher::SearchByProjection(Cur, Last, th, bMono, nVisible)    src/ORBmatcher.cc:1440-1593
 //   GFO_ADAPTER_PROJ_KF       ORBmatcher::SearchByProjection(Cur, KF*, sAlreadyFound, th, dist) src/ORBmatcher.cc:1595-1721
 //   GFO_ADAPTER_BOW           ORBmatcher::SearchByBoW(KeyFrame*, Frame&, vector<MapPoint*>&)    src/ORBmatcher.cc:270-404
@@ -21,6 +22,7 @@
 #ifdef GFO_ADAPTER_ALL
 #define GFO_ADAPTER_STEREO
 #define GFO_ADAPTER_PROJECTION
+#define GFO_ADAPTER_PROJ_BUDGET
 #define GFO_ADAPTER_PROJ_LAST
 #define GFO_ADAPTER_PROJ_KF
 #define GFO_ADAPTER_BOW
@@ -268,8 +270,13 @@ int Frame::ComputeStereoMatches_Undistorted(bool isOnline)
 #endif
 
 // ---------------------------------------------------------------------------------------------------------------
-#ifdef GFO_ADAPTER_PROJECTION
-int ORBmatcher::SearchByProjection(Frame& F, const std::vector<MapPoint*>& vpMapPoints, const float th)
+#if defined(GFO_ADAPTER_PROJECTION) || defined(GFO_ADAPTER_PROJ_BUDGET)
+namespace
+{
+// The loop of ORBmatcher.cc:155-241 (= :45-153 = include/ORBmatcher.h:71-150) for all of vpMapPoints in ONE device call.  outPoint (optional):
+// what every point did at its turn (gfo_search_by_projection_points).  false: the library refused the call (reported).
+bool project_map_points(Frame& F, const std::vector<MapPoint*>& vpMapPoints, const float th, const float nnRatio, std::vector<int32_t>& outMp,
+                        std::vector<int32_t>& outScore, std::vector<int32_t>* outPoint, int& nmatches, const char* who)
 {
     const int M = (int)vpMapPoints.size(), N = F.N;
     std::vector<gfo_map_point> mps(M);
@@ -292,22 +299,75 @@ int ORBmatcher::SearchByProjection(Frame& F, const std::vector<MapPoint*>& vpMap
     std::vector<uint8_t> taken(N);
     for (int i = 0; i < N; i++) taken[i] = F.mvpMapPoints[i] && F.mvpMapPoints[i]->Observations() > 0;
     gfo_frame_bounds fb = {Frame::mnMinX, Frame::mnMinY, Frame::mnMaxX, Frame::mnMaxY};
-    std::vector<int32_t> outMp(N), outScore(N);
-    int nmatches = 0;
+    outMp.assign(N, -1);
+    outScore.assign(N, 0);
+    if (outPoint) outPoint->assign(M, GFO_POINT_NONE);
+    nmatches = 0;
     cv::Mat keep;
     GfoUse use(F.mpORBextractorLeft);
     gfo_ctx* c = use.c;
-    const int rc = gfo_search_by_projection(c, as_gfo(F.mvKeysUn), rows32(F.mDescriptors, keep), F.mvuRight.data(), N,
-                                            F.mvScaleFactors.data(), (int)F.mvScaleFactors.size(), &fb, mps.data(), mpDesc.data, M,
-                                            th, mfNNratio, taken.data(), outMp.data(), outScore.data(), &nmatches);
+    const int rc = outPoint
+        ? gfo_search_by_projection_points(c, as_gfo(F.mvKeysUn), rows32(F.mDescriptors, keep), F.mvuRight.data(), N, F.mvScaleFactors.data(),
+                                          (int)F.mvScaleFactors.size(), &fb, mps.data(), mpDesc.data, M, th, nnRatio, taken.data(),
+                                          outMp.data(), outScore.data(), outPoint->data(), &nmatches)
+        : gfo_search_by_projection(c, as_gfo(F.mvKeysUn), rows32(F.mDescriptors, keep), F.mvuRight.data(), N, F.mvScaleFactors.data(),
+                                   (int)F.mvScaleFactors.size(), &fb, mps.data(), mpDesc.data, M, th, nnRatio, taken.data(),
+                                   outMp.data(), outScore.data(), &nmatches);
     if (rc != GFO_OK) {
-        report(c, "SearchByProjection(F, MapPoints)");
-        return 0;
+        report(c, who);
+        return false;
     }
-    for (int i = 0; i < N; i++)
+    return true;
+}
+}  // namespace
+#endif
+
+#ifdef GFO_ADAPTER_PROJECTION
+int ORBmatcher::SearchByProjection(Frame& F, const std::vector<MapPoint*>& vpMapPoints, const float th)
+{
+    std::vector<int32_t> outMp, outScore;
+    int nmatches = 0;
+    if (!project_map_points(F, vpMapPoints, th, mfNNratio, outMp, outScore, NULL, nmatches, "SearchByProjection(F, MapPoints)")) return 0;
+    for (int i = 0; i < F.N; i++)
         if (outMp[i] >= 0) {
             F.mvpMapPoints[i] = vpMapPoints[outMp[i]];   // ORBmatcher.cc:233
             F.mvpMatchScore[i] = outScore[i];            // :235
+        }
+    return nmatches;
+}
+#endif
+
+// ---------------------------------------------------------------------------------------------------------------
+#ifdef GFO_ADAPTER_PROJ_BUDGET
+// Tracking::SearchAdditionalMatchesInFrame's matcher (Tracking.cc:2166; GOOD_FEATURE_MAP_MATCHING, the reference's default build): the loop
+// of the overload above with IncreaseFound() per match (:91) and a wall clock read at the end of the loop body that ends the loop once
+// time_constr is spent (:96-102).  Here ALL points are answered by one device call and the clock is read once, after it:
+//   * the call took less than time_constr (every frame: a call is ~0.2 ms, the budget a few ms): the answer is what the reference gives
+//     whenever ITS clock does not run out -- every point visited;
+//   * time_constr <= 0 on entry (the visibility check of Tracking.cc:2127-2151 used up the frame's budget): the reference's FIRST clock
+//     reading ends the loop whatever the host's speed -- the first point that reaches the end of the body (a match, or candidates and
+//     none within TH_HIGH) is the last one; the same prefix is taken here (gfo_projection_points_prefix);
+//   * the call itself outlasted a positive time_constr: the reference would have stopped somewhere inside the list, where depends on
+//     its host; the work is done, every match is kept (a superset of any such prefix, each entry what the reference's loop computes
+//     for that point given the points before it).
+int ORBmatcher::SearchByProjection_Budget(Frame& F, const std::vector<MapPoint*>& vpMapPoints, const float th, const double time_constr)
+{
+    const int M = (int)vpMapPoints.size(), N = F.N;
+    std::vector<int32_t> outMp, outScore, outPoint;
+    int nmatches = 0;
+    if (!project_map_points(F, vpMapPoints, th, mfNNratio, outMp, outScore, &outPoint, nmatches, "SearchByProjection_Budget")) return 0;
+    int prefix = M;
+    if (!(time_constr > 0)) {
+        for (int p = 0; p < M; p++)
+            if (outPoint[p] >= 0 || outPoint[p] == GFO_POINT_FAR) { prefix = p + 1; break; }
+        if (gfo_projection_points_prefix(outPoint.data(), M, prefix, N, outMp.data(), outScore.data(), &nmatches) != GFO_OK) return 0;
+    }
+    for (int p = 0; p < prefix; p++)
+        if (outPoint[p] >= 0) vpMapPoints[p]->IncreaseFound();   // :91, once per match (also for a slot a later point takes over)
+    for (int i = 0; i < N; i++)
+        if (outMp[i] >= 0) {
+            F.mvpMapPoints[i] = vpMapPoints[outMp[i]];   // :89
+            F.mvpMatchScore[i] = outScore[i];            // :94
         }
     return nmatches;
 }

@@ -185,6 +185,7 @@ struct GfoProjBuf {
     int* counters = nullptr;
     int* out_mp = nullptr;
     int* out_score = nullptr;
+    int* out_q = nullptr;                   // [frames][m] per-point outcomes (gfo_search_by_projection_points)
 };
 
 enum GfoStage {

@@ -50,6 +50,14 @@
 #define TH_HIGH 100    // ORBmatcher.cc:57
 #define HISTO_LENGTH 30  // ORBmatcher.cc:59
 
+// what a point that matched nothing did (the reference's three ways out of the loop body, src/ORBmatcher.cc:60-92, 137-138):
+//   PJ_PT_NONE      not in view / bad / GetFeaturesInArea returned nothing -- `continue` before any distance is computed
+//   PJ_PT_RATIO     best candidate within TH_HIGH, rejected by the ratio test -- `continue`
+//   PJ_PT_FAR       candidates in the window, none usable within TH_HIGH -- falls through to the END of the loop body
+//                   (where SearchByProjection_Budget reads its clock, :96-102)
+enum { PJ_PT_NONE = -1, PJ_PT_RATIO = -2, PJ_PT_FAR = -3 };
+#define PJ_DIST_NONE 256    // accept_rule: no candidate, or the best one beyond the threshold
+#define PJ_DIST_RATIO 257   // accept_rule: rejected by the ratio test
 enum { PJ_NLIVE = 0, PJ_ROUNDS = 1, PJ_NMATCH = 2, PJ_ERR = 3, PJ_FALLBACK = 4, PJ_SPILL = 5, PJ_CNT = 8 };
 #define PJ_SPILL_PER_POINT 64   // the spill pool holds this many candidate keys per point of a wavefront-per-point call, on average
 #define PJ_K 7   // cached candidates per live point: 7 entries + 1 header word = 32 bytes
@@ -101,6 +109,9 @@ struct ProjB {
     const gfo_keypoint* kp_grid;   // null: a.kp
     int grid_frames;               // frames of the launch (the copy workgroups come behind them)
     int max_matches;               // > 0: BUDGETING_FEATURE_MATCHING (gfo_proj_mode::max_matches), host-array calls only
+    // per-POINT outcomes (gfo_search_by_projection_points: SearchByProjection_OnePoint's return value for every point taken in vector
+    // order, include/ORBmatcher.h:71-150): [m] per frame, null = not wanted.  keypoint | distance << 16, or PJ_PT_* below
+    int* out_q; int* h_out_q;
 #ifdef GFO_PROJ_DEBUG
     int dbg_stop;
 #endif
@@ -257,14 +268,14 @@ __device__ __forceinline__ unsigned long long cand_key(unsigned dist, unsigned m
 __device__ __forceinline__ void accept_rule(const ProjB& a, int e1, int e2, int* pick, int* dist)
 {
     *pick = -1;
-    *dist = 256;
+    *dist = PJ_DIST_NONE;
     if (e1 < 0) return;
     const int bestDist = e1 >> 23;
     if (bestDist > a.th_dist) return;
     if (a.use_ratio && e2 >= 0) {
         const int bestDist2 = e2 >> 23;
         // same level and not distinctive enough (:230); no second candidate: bestLevel2 = -1, always accepted
-        if (((e1 >> 16) & 0x7F) == ((e2 >> 16) & 0x7F) && (float)bestDist > a.nn_ratio * (float)bestDist2) return;
+        if (((e1 >> 16) & 0x7F) == ((e2 >> 16) & 0x7F) && (float)bestDist > a.nn_ratio * (float)bestDist2) { *dist = PJ_DIST_RATIO; return; }
     }
     *pick = e1 & 0xFFFF;
     *dist = bestDist;
@@ -279,9 +290,9 @@ __device__ __forceinline__ void accept_rule(const ProjB& a, int e1, int e2, int*
 #define PJ_HOLD 4
 #endif
 template <class StartT, class Blocked, class Sink>
-__device__ __forceinline__ void scan_candidates(const ProjB& a, int f, int n, int iq, const ProjQ& q, const StartT* cell_start,
+__device__ __forceinline__ bool scan_candidates(const ProjB& a, int f, int n, int iq, const ProjQ& q, const StartT* cell_start,
                                                 const float2* cell_xy, const unsigned* cell_meta, Blocked blocked, Sink sink)
-{
+{   // returns: the window holds a keypoint of the level range (the reference's vIndices is not empty)
     const float rs = q.radius, x = q.u, y = q.v;
     // the scan cells the window touches, with a hundredth of a cell of slack on either side: the window test below is
     // the reference's own (GetFeaturesInArea, Frame.cc:627-640), the cell range only has to be a superset
@@ -346,9 +357,9 @@ __device__ __forceinline__ void scan_candidates(const ProjB& a, int f, int n, in
         }
     }
 #ifdef GFO_PROJ_DEBUG
-    if (a.dbg_stop == 2) { if (nh == 12345) sink(0ull); return; }   // tools/pmc_proj_phases.sh: stop after the grid scan
+    if (a.dbg_stop == 2) { if (nh == 12345) sink(0ull); return nh > 0; }   // tools/pmc_proj_phases.sh: stop after the grid scan
 #endif
-    if (__builtin_amdgcn_ballot_w64(nh > 0) == 0) return;
+    if (__builtin_amdgcn_ballot_w64(nh > 0) == 0) return false;
     if (nh > 0) need_desc();
 #pragma unroll
     for (int s0 = 0; s0 < PJ_HOLD; s0 += 2) {
@@ -357,6 +368,7 @@ __device__ __forceinline__ void scan_candidates(const ProjB& a, int f, int n, in
         finish(nh > s0, hold[s0]);
         finish(nh > s0 + 1, hold[s0 + 1]);
     }
+    return nh > 0;
 }
 
 // cached form of a candidate: dist << 23 | octave << 16 | index (-1 = none).  A distance of 256 -- every bit differs --
@@ -405,7 +417,7 @@ __global__ __launch_bounds__(LDSGRID ? 1024 : 256, 8) void k_proj_round0(ProjB a
     for (int iq0 = q_begin; iq0 < q_end; iq0 += (int)blockDim.x) {
         const int iq = iq0 + (int)threadIdx.x;
         int pick = -1, dist = 256;
-        bool live = false, obs = false, trunc = false;
+        bool live = false, obs = false, trunc = false, seen = false;
         unsigned long long k[PJ_K];   // the PJ_K smallest keys, ascending
 #pragma unroll
         for (int s = 0; s < PJ_K; s++) k[s] = ~0ull;
@@ -426,8 +438,8 @@ __global__ __launch_bounds__(LDSGRID ? 1024 : 256, 8) void k_proj_round0(ProjB a
                     }
                     if (x != ~0ull) trunc = true;
                 };
-                if (LDSGRID) scan_candidates(a, f, n, iq, q, l_start, cell_xy, cell_meta, [](int) { return false; }, sink0);
-                else scan_candidates(a, f, n, iq, q, g_start, cell_xy, cell_meta, [](int) { return false; }, sink0);
+                if (LDSGRID) seen = scan_candidates(a, f, n, iq, q, l_start, cell_xy, cell_meta, [](int) { return false; }, sink0);
+                else seen = scan_candidates(a, f, n, iq, q, g_start, cell_xy, cell_meta, [](int) { return false; }, sink0);
                 if (k[0] != ~0ull) {
                     const int e1 = key_entry(k[0]), e2 = key_entry(k[1]);
                     live = (e1 >> 23) <= a.th_dist;   // :228 / :1536
@@ -435,6 +447,7 @@ __global__ __launch_bounds__(LDSGRID ? 1024 : 256, 8) void k_proj_round0(ProjB a
                 }
             }
         }
+        if (a.out_q && iq < q_end) a.out_q[(long long)f * a.m + iq] = seen ? PJ_PT_FAR : PJ_PT_NONE;   // the live points' entries: k_proj_resolve
         const unsigned long long mask = __builtin_amdgcn_ballot_w64(live);
         if (mask == 0) continue;
         const int leader = __ffsll((long long)mask) - 1;
@@ -543,6 +556,7 @@ __global__ __launch_bounds__(64 * PJ_WAVES) void k_proj_round0_wave(ProjB a)
 #pragma unroll
     for (int s = 0; s < PJ_K; s++) k[s] = ~0ull;
     int total = 0;
+    bool seen = false;   // vIndices not empty
     for (int cg = cx0; cg <= cx1; cg += 64) {
         const int ncol = min(64, cx1 - cg + 1);
         if (cg != cx0) load_columns(cg, ncol);
@@ -566,6 +580,7 @@ __global__ __launch_bounds__(64 * PJ_WAVES) void k_proj_round0_wave(ProjB a)
                     ok = !(oct < q.min_level) && !(q.max_level >= 0 && oct > q.max_level);
                 }
                 if (ok) {
+                    seen = true;
                     const int i = min((int)(meta & 0xFFFF), n - 1);
                     const uint4* dk = reinterpret_cast<const uint4*>(desc + (long long)i * 32);
                     const uint4 b0 = dk[0], b1 = dk[1];
@@ -602,6 +617,10 @@ __global__ __launch_bounds__(64 * PJ_WAVES) void k_proj_round0_wave(ProjB a)
         const int e1 = key_entry(k[0]), e2 = key_entry(k[1]);
         live = (e1 >> 23) <= a.th_dist;   // :228 / :1536: otherwise it can never match
         accept_rule(a, e1, e2, &pick, &dist);
+    }
+    if (a.out_q && iq < a.m) {   // the live points' entries: k_proj_resolve
+        const bool any = __builtin_amdgcn_ballot_w64(seen) != 0;
+        if (lane == 0) a.out_q[(long long)f * a.m + iq] = any ? PJ_PT_FAR : PJ_PT_NONE;
     }
     if (live && lane == 0) rank = atomicAdd(&s_n, 1);
     __syncthreads();
@@ -745,6 +764,7 @@ __global__ __launch_bounds__(1024) void k_proj_resolve(ProjB a)
                     if (from_cache((int)(lv[r] & 0x7FFFFFFFu), c0[r], &cand[2 * (tid + r * 1024) + 1], &e1, &e2)) {
                         accept_rule(a, e1, e2, &np, &nd);
                         if (np != pk[r]) { changed = 1; pk[r] = np; pick_dist[tid + r * 1024] = nd; }
+                        else if (a.out_q && np < 0) pick_dist[tid + r * 1024] = nd;   // WHY it matches nothing may change while the pick does not
                     } else redo |= 1u << r;
                 }
             }
@@ -760,6 +780,7 @@ __global__ __launch_bounds__(1024) void k_proj_resolve(ProjB a)
 #pragma unroll
                 for (int r2 = 0; r2 < PJ_RR; r2++)
                     if (r == r2 && np != pk[r2]) { changed = 1; pk[r2] = np; pick_dist[tid + r2 * 1024] = nd; }
+                if (a.out_q && np < 0) pick_dist[tid + r * 1024] = nd;
             }
             if (!__syncthreads_or(changed)) break;
             if (rounds > nlive + 1) {   // cannot happen (point i is final after rank(i) rounds); never spin
@@ -830,6 +851,19 @@ __global__ __launch_bounds__(1024) void k_proj_resolve(ProjB a)
             if (pick[t] >= 0 && (int)(live[t] & 0x7FFFFFFFu) > cut) pick[t] = -1;
         __threadfence_block();
         __syncthreads();
+    }
+    // ---- per-point outcomes (round 0 wrote PJ_PT_NONE / PJ_PT_FAR for every point; the live ones are settled here) ----
+    if (a.out_q) {
+        int* oq = a.out_q + (long long)f * a.m;
+        for (int t = tid; t < nlive; t += 1024) {
+            const int k = pick[t], d = pick_dist[t];
+            oq[live[t] & 0x7FFFFFFFu] = k >= 0 ? (k | (d << 16)) : (d == PJ_DIST_RATIO ? PJ_PT_RATIO : PJ_PT_FAR);
+        }
+        if (a.h_out_q) {
+            __threadfence_block();
+            __syncthreads();
+            for (int i = tid; i < a.m; i += 1024) a.h_out_q[i] = oq[i];
+        }
     }
     // ---- epilogue ----
     if (tid < HISTO_LENGTH) histo[tid] = 0;
@@ -948,13 +982,14 @@ static int pj_reserve(gfo_ctx* c, int frames, int m, int n_cap)
     const size_t o_cs = take(F * (NSG + 1) * 4), o_it = take(F * N * 8), o_me = take(F * N * 4), o_pk = take(F * M * 4),
                  o_pd = take(F * M * 4), o_lv = take(F * M * 4), o_cd = take(F * M * 32), o_rb = take(F * M * 4),
                  o_so = take(F * M * 4), o_sp = take(8 * (size_t)PJ_SPILL_PER_POINT * (F * M < 16384 ? F * M : 16384)),
-                 o_tg = take(F * N * 8), o_ct = take(F * PJ_CNT * 4), o_om = take(F * N * 4), o_os = take(F * N * 4);
+                 o_tg = take(F * N * 8), o_ct = take(F * PJ_CNT * 4), o_om = take(F * N * 4), o_os = take(F * N * 4), o_oq = take(F * M * 4);
     PTRY(c, hipMalloc(&b.base, off));
     uint8_t* S = (uint8_t*)b.base;
     b.cell_start = (int*)(S + o_cs); b.cell_xy = S + o_it; b.cell_meta = (unsigned*)(S + o_me);
     b.pick = (int*)(S + o_pk); b.pick_dist = (int*)(S + o_pd); b.live = (unsigned*)(S + o_lv); b.cand = S + o_cd; b.rot_bin = (int*)(S + o_rb);
     b.spill_off = (int*)(S + o_so); b.spill = (unsigned long long*)(S + o_sp); b.spill_cap = PJ_SPILL_PER_POINT * (int)(F * M < 16384 ? F * M : 16384);
     b.tab_g = (int*)(S + o_tg); b.counters = (int*)(S + o_ct); b.out_mp = (int*)(S + o_om); b.out_score = (int*)(S + o_os);
+    b.out_q = (int*)(S + o_oq);
     b.frames_cap = (int)F; b.m_cap = (int)M; b.n_cap = (int)N;
     return GFO_OK;
 }
@@ -1021,11 +1056,10 @@ static int pj_launch(gfo_ctx* c, const ProjB& a, int frames, int n_max)
     return GFO_OK;
 }
 
-extern "C" int gfo_search_by_projection_queries(gfo_ctx* c, const gfo_keypoint* kp_un, const uint8_t* desc,
-                                                const float* u_right, const float* kp_angle, int n,
-                                                const gfo_frame_bounds* fb, const gfo_proj_query* queries,
-                                                const uint8_t* q_desc, int m, const gfo_proj_mode* mode,
-                                                const uint8_t* kp_taken, int32_t* out_mp, int32_t* out_score, int* nmatches)
+// out_point (optional, [m]): the per-point outcomes of gfo_search_by_projection_points
+static int pj_queries(gfo_ctx* c, const gfo_keypoint* kp_un, const uint8_t* desc, const float* u_right, const float* kp_angle, int n,
+                      const gfo_frame_bounds* fb, const gfo_proj_query* queries, const uint8_t* q_desc, int m, const gfo_proj_mode* mode,
+                      const uint8_t* kp_taken, int32_t* out_mp, int32_t* out_score, int* nmatches, int32_t* out_point)
 {
     if (!c) return GFO_ERR_INVALID;
     if (!fb || !mode || !out_mp || !out_score || !nmatches || n < 0 || m < 0 || (n > 0 && (!kp_un || !desc)) ||
@@ -1047,6 +1081,7 @@ extern "C" int gfo_search_by_projection_queries(gfo_ctx* c, const gfo_keypoint* 
     }
     *nmatches = 0;
     for (int i = 0; i < n; i++) { out_mp[i] = -1; out_score[i] = 0; }
+    if (out_point) for (int i = 0; i < m; i++) out_point[i] = PJ_PT_NONE;
     if (n == 0 || m == 0) return GFO_OK;
     PTRY(c, hipSetDevice(c->device));
     size_t off = 0;
@@ -1108,25 +1143,29 @@ extern "C" int gfo_search_by_projection_queries(gfo_ctx* c, const gfo_keypoint* 
     a.max_matches = mode->max_matches > 0 ? mode->max_matches : 0;
     pj_bind(c, &a);
     // the resolve kernel writes counters, out_mp and out_score into the pinned block itself (ProjB::h_*): no copy back
-    const size_t o_hm = 256, o_hs = o_hm + al256(4 * (size_t)n);
-    if (int rc = x.out(o_hs + 4 * (size_t)n)) return rc;
+    const size_t o_hm = 256, o_hs = o_hm + al256(4 * (size_t)n), o_hq = o_hs + al256(4 * (size_t)n);
+    if (int rc = x.out(o_hq + (out_point ? 4 * (size_t)m : 0))) return rc;
     const bool direct = gfo_matcher_host_writes();
+    if (out_point) a.out_q = c->pj.out_q;
     if (direct) {
         a.h_counters = (int*)x.HO;
         a.h_out_mp = (int*)(x.HO + o_hm);
         a.h_out_score = (int*)(x.HO + o_hs);
+        if (out_point) a.h_out_q = (int*)(x.HO + o_hq);
     }
     if (int rc = pj_launch(c, a, 1, n)) return rc;
-    if (!direct) {   // three copies into the same places
+    if (!direct) {   // three (four) copies into the same places
         PTRY(c, hipMemcpyAsync(x.HO, a.counters, PJ_CNT * 4, hipMemcpyDeviceToHost, st));
         PTRY(c, hipMemcpyAsync(x.HO + o_hm, a.out_mp, 4 * (size_t)n, hipMemcpyDeviceToHost, st));
         PTRY(c, hipMemcpyAsync(x.HO + o_hs, a.out_score, 4 * (size_t)n, hipMemcpyDeviceToHost, st));
+        if (out_point) PTRY(c, hipMemcpyAsync(x.HO + o_hq, a.out_q, 4 * (size_t)m, hipMemcpyDeviceToHost, st));
     }
     PTRY(c, hipStreamSynchronize(st));
     int cnt[PJ_CNT];
     memcpy(cnt, x.HO, sizeof cnt);
     memcpy(out_mp, x.HO + o_hm, 4 * (size_t)n);
     memcpy(out_score, x.HO + o_hs, 4 * (size_t)n);
+    if (out_point) memcpy(out_point, x.HO + o_hq, 4 * (size_t)m);
     if (cnt[PJ_ERR]) return pj_fail(c, GFO_ERR_STATE, "gfo_search_by_projection: fixed point not reached");
     *nmatches = cnt[PJ_NMATCH];
     c->last_project_rounds = cnt[PJ_ROUNDS];
@@ -1136,12 +1175,21 @@ extern "C" int gfo_search_by_projection_queries(gfo_ctx* c, const gfo_keypoint* 
     return GFO_OK;
 }
 
+extern "C" int gfo_search_by_projection_queries(gfo_ctx* c, const gfo_keypoint* kp_un, const uint8_t* desc,
+                                                const float* u_right, const float* kp_angle, int n,
+                                                const gfo_frame_bounds* fb, const gfo_proj_query* queries,
+                                                const uint8_t* q_desc, int m, const gfo_proj_mode* mode,
+                                                const uint8_t* kp_taken, int32_t* out_mp, int32_t* out_score, int* nmatches)
+{
+    return pj_queries(c, kp_un, desc, u_right, kp_angle, n, fb, queries, q_desc, m, mode, kp_taken, out_mp, out_score, nmatches, nullptr);
+}
+
 // ORBmatcher::SearchByProjection(Frame&, const vector<MapPoint*>&, th): every map point becomes a query with
 // r = RadiusByViewingCos(viewCos) (* th), window r * scale[level], levels [level-1, level] (ORBmatcher.cc:171-180).
-extern "C" int gfo_search_by_projection(gfo_ctx* c, const gfo_keypoint* kp_un, const uint8_t* desc, const float* u_right,
-                                        int n, const float* sf, int nlevels, const gfo_frame_bounds* fb,
-                                        const gfo_map_point* mps, const uint8_t* mp_desc, int m, float th, float nn_ratio,
-                                        const uint8_t* kp_taken, int32_t* out_mp, int32_t* out_score, int* nmatches)
+static int pj_map_points(gfo_ctx* c, const gfo_keypoint* kp_un, const uint8_t* desc, const float* u_right,
+                         int n, const float* sf, int nlevels, const gfo_frame_bounds* fb,
+                         const gfo_map_point* mps, const uint8_t* mp_desc, int m, float th, float nn_ratio,
+                         const uint8_t* kp_taken, int32_t* out_mp, int32_t* out_score, int* nmatches, int32_t* out_point)
 {
     if (!c) return GFO_ERR_INVALID;
     if (!sf || nlevels < 1 || nlevels > GFO_MAX_LEVELS || m < 0 || (m > 0 && !mps))
@@ -1164,8 +1212,52 @@ extern "C" int gfo_search_by_projection(gfo_ctx* c, const gfo_keypoint* kp_un, c
         d.flags = (((p.flags & 1) && !(p.flags & 2) && lvl >= 0 && lvl < nlevels) ? 1 : 0) | (p.flags & 4);
     }
     gfo_proj_mode mode = {1, nn_ratio, TH_HIGH, 0, 0};
-    return gfo_search_by_projection_queries(c, kp_un, desc, u_right, nullptr, n, fb, q.data(), mp_desc, m, &mode, kp_taken,
-                                            out_mp, out_score, nmatches);
+    return pj_queries(c, kp_un, desc, u_right, nullptr, n, fb, q.data(), mp_desc, m, &mode, kp_taken, out_mp, out_score, nmatches, out_point);
+}
+
+extern "C" int gfo_search_by_projection(gfo_ctx* c, const gfo_keypoint* kp_un, const uint8_t* desc, const float* u_right,
+                                        int n, const float* sf, int nlevels, const gfo_frame_bounds* fb,
+                                        const gfo_map_point* mps, const uint8_t* mp_desc, int m, float th, float nn_ratio,
+                                        const uint8_t* kp_taken, int32_t* out_mp, int32_t* out_score, int* nmatches)
+{
+    return pj_map_points(c, kp_un, desc, u_right, n, sf, nlevels, fb, mps, mp_desc, m, th, nn_ratio, kp_taken, out_mp, out_score, nmatches, nullptr);
+}
+
+// ORBmatcher::SearchByProjection_Budget (src/ORBmatcher.cc:45-153) and SearchByProjection_OnePoint taken in vector order
+// (include/ORBmatcher.h:71-150): the same loop body as the overload above, plus what every point did at its turn.
+extern "C" int gfo_search_by_projection_points(gfo_ctx* c, const gfo_keypoint* kp_un, const uint8_t* desc, const float* u_right,
+                                               int n, const float* sf, int nlevels, const gfo_frame_bounds* fb,
+                                               const gfo_map_point* mps, const uint8_t* mp_desc, int m, float th, float nn_ratio,
+                                               const uint8_t* kp_taken, int32_t* out_mp, int32_t* out_score, int32_t* out_point,
+                                               int* nmatches)
+{
+    if (!c) return GFO_ERR_INVALID;
+    if (!out_point && m > 0) return pj_fail(c, GFO_ERR_INVALID, "gfo_search_by_projection_points: null out_point");
+    return pj_map_points(c, kp_un, desc, u_right, n, sf, nlevels, fb, mps, mp_desc, m, th, nn_ratio, kp_taken, out_mp, out_score, nmatches, out_point);
+}
+
+// The state of a frame after the FIRST `prefix` points of a gfo_search_by_projection_points call: a point's outcome depends on the
+// points in front of it only, so every way the reference cuts its loop short -- SearchByProjection_Budget's clock (:96-102), the
+// weighted match budget of Observability::runBaselineMapMatching (src/Observability.cc:1233-1262) -- is a prefix of the full answer.
+// Pure bookkeeping on the host (no distance is computed here): slot i holds the LAST point of the prefix that matched it (:89 overwrites).
+extern "C" int gfo_projection_points_prefix(const int32_t* out_point, int m, int prefix, int n, int32_t* out_mp, int32_t* out_score,
+                                            int* nmatches)
+{
+    if (m < 0 || n < 0 || prefix < 0 || (m > 0 && !out_point) || (n > 0 && (!out_mp || !out_score))) return GFO_ERR_INVALID;
+    if (prefix > m) prefix = m;
+    for (int i = 0; i < n; i++) { out_mp[i] = -1; out_score[i] = 0; }
+    int cnt = 0;
+    for (int p = 0; p < prefix; p++) {
+        const int v = out_point[p];
+        if (v < 0) continue;
+        const int k = v & 0xFFFF;
+        if (k >= n) return GFO_ERR_INVALID;
+        out_mp[k] = p;
+        out_score[k] = v >> 16;
+        cnt++;
+    }
+    if (nmatches) *nmatches = cnt;
+    return GFO_OK;
 }
 
 // ---- the resident local map and the batched, device-chained search --------------------------------------------

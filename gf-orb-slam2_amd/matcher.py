@@ -103,6 +103,46 @@ class ORBmatcher:
                                                                    ptr(out_mp), ptr(out_sc), C.byref(nm)))
         return nm.value, out_mp[:n], out_sc[:n]
 
+    POINT_NONE, POINT_RATIO, POINT_FAR = -1, -2, -3   # include/gfo.h GFO_POINT_*
+
+    def SearchByProjectionPoints(self, keys_un, desc, u_right, scale_factors, bounds, map_points, mp_desc, th=3.0, kp_taken=None):
+        """The good-feature matchers' common core (gfo_search_by_projection_points): SearchByProjection above plus what every point
+        did at its turn -- ORBmatcher::SearchByProjection_OnePoint's return value for the points taken in vector order
+        (include/ORBmatcher.h:71-150), which is also the loop of SearchByProjection_Budget (src/ORBmatcher.cc:45-153).
+        Returns (nmatches, out_mp, out_score, out_point); out_point[p] >= 0: keypoint | distance << 16, else POINT_*."""
+        kp = np.ascontiguousarray(keys_un, KEYPOINT_DTYPE)
+        desc = np.ascontiguousarray(desc, np.uint8)
+        mps = np.ascontiguousarray(map_points, MAP_POINT_DTYPE)
+        mpd = np.ascontiguousarray(mp_desc, np.uint8)
+        sf = np.ascontiguousarray(scale_factors, np.float32)
+        n, m = len(kp), len(mps)
+        if u_right is not None:
+            u_right = np.ascontiguousarray(u_right, np.float32)
+        if kp_taken is not None:
+            kp_taken = np.ascontiguousarray(kp_taken, np.uint8)
+        fb = FrameBoundsC(*bounds)
+        out_mp = np.full(max(n, 1), -1, np.int32)
+        out_sc = np.zeros(max(n, 1), np.int32)
+        out_pt = np.full(max(m, 1), -1, np.int32)
+        nm = C.c_int()
+        check(self._L, self._ctx, self._L.gfo_search_by_projection_points(self._ctx, ptr(kp), ptr(desc), ptr(u_right), n, ptr(sf), len(sf),
+                                                                          C.byref(fb), ptr(mps), ptr(mpd), m, th, self.mfNNratio,
+                                                                          ptr(kp_taken), ptr(out_mp), ptr(out_sc), ptr(out_pt), C.byref(nm)))
+        return nm.value, out_mp[:n], out_sc[:n], out_pt[:m]
+
+    def points_prefix(self, out_point, prefix, n):
+        """The frame after the first `prefix` points of a SearchByProjectionPoints call (gfo_projection_points_prefix): how every early
+        exit of the reference's loops -- the clock of SearchByProjection_Budget, the match budget of runBaselineMapMatching -- reads
+        the full answer.  Returns (nmatches, out_mp, out_score)."""
+        op = np.ascontiguousarray(out_point, np.int32)
+        out_mp = np.full(max(n, 1), -1, np.int32)
+        out_sc = np.zeros(max(n, 1), np.int32)
+        nm = C.c_int()
+        rc = self._L.gfo_projection_points_prefix(ptr(op), len(op), int(prefix), n, ptr(out_mp), ptr(out_sc), C.byref(nm))
+        if rc != 0:
+            raise ValueError("gfo_projection_points_prefix: %d" % rc)
+        return nm.value, out_mp[:n], out_sc[:n]
+
     # ---- device-resident chain: extract_batch_device -> [stereo_match_batch] -> search_by_projection_batch ----
     def map_upload(self, mp_desc):
         """Descriptors of the local map (MapPoint::GetDescriptor(), vector order); resident until replaced."""

@@ -280,6 +280,37 @@ int gfo_search_by_projection_queries(gfo_ctx* ctx, const gfo_keypoint* kp_un, co
                                      const uint8_t* q_desc, int m, const gfo_proj_mode* mode,
                                      const uint8_t* kp_taken, int32_t* out_q, int32_t* out_score, int* nmatches);
 
+/* The good-feature matchers (GOOD_FEATURE_MAP_MATCHING is the reference's default build, include/Tracking.h:75): the loop body of
+ * SearchByProjection(Frame&, vector<MapPoint*>&, th) exists three more times in the reference, word for word --
+ *   ORBmatcher::SearchByProjection_Budget(F, vpMapPoints, th, time_constr)      include/ORBmatcher.h:67, src/ORBmatcher.cc:45-153
+ *       (Tracking::SearchAdditionalMatchesInFrame, src/Tracking.cc:2166): the same loop, `pMP->IncreaseFound()` per match, and a
+ *       wall clock read at the END of the body (:96-102) that breaks the loop;
+ *   ORBmatcher::SearchByProjection_OnePoint(F, pMP, th)                         include/ORBmatcher.h:71-150
+ *       one point; called point after point by Observability::runBaselineMapMatching (src/Observability.cc:1233-1262, in a sorted
+ *       order, until a weighted match budget is met) and runActiveMapMatching (:975);
+ *   ORBmatcher::GetCandidates / MatchCandidates                                 include/ORBmatcher.h:152-250
+ * gfo_search_by_projection_points = gfo_search_by_projection that ALSO reports what every point did at its turn:
+ *   out_point[p] >= 0 : SearchByProjection_OnePoint's return value for point p (the keypoint it took) in bits 0-15, its distance
+ *                       (what the call stored in mvpMatchScore at that moment) in bits 16-24
+ *   GFO_POINT_NONE    : not in view / bad / no keypoint in its window (the reference `continue`s before computing a distance)
+ *   GFO_POINT_RATIO   : best candidate within TH_HIGH, rejected by the ratio test (`continue`, :85-86)
+ *   GFO_POINT_FAR     : keypoints in the window, none free and within TH_HIGH (falls through to the end of the loop body)
+ * A point's outcome depends on the points IN FRONT of it only, so every early exit of the reference is a PREFIX of this answer:
+ * gfo_projection_points_prefix rebuilds out_mp / out_score / nmatches for the first `prefix` points (host bookkeeping, no device
+ * call).  SearchByProjection_Budget's clock is read after a point whose outcome is >= 0 or GFO_POINT_FAR -- the other two leave the
+ * body early -- which is what a caller needs to place the cut for a given clock. */
+#define GFO_POINT_NONE (-1)
+#define GFO_POINT_RATIO (-2)
+#define GFO_POINT_FAR (-3)
+int gfo_search_by_projection_points(gfo_ctx* ctx, const gfo_keypoint* kp_un, const uint8_t* desc,
+                                    const float* u_right, int n, const float* scale_factors, int nlevels,
+                                    const gfo_frame_bounds* bounds, const gfo_map_point* mps,
+                                    const uint8_t* mp_desc, int m, float th, float nn_ratio,
+                                    const uint8_t* kp_taken, int32_t* out_mp, int32_t* out_score,
+                                    int32_t* out_point, int* nmatches);
+int gfo_projection_points_prefix(const int32_t* out_point, int m, int prefix, int n, int32_t* out_mp,
+                                 int32_t* out_score, int* nmatches);
+
 /* Device-resident, batched form of SearchByProjection(Frame&, vector<MapPoint*>&, th) -- the chain
  *   gfo_extract_batch_device -> [gfo_stereo_match_batch] -> gfo_search_by_projection_batch
  * never leaves the GPU: keypoints, descriptors (and mvuRight) are read where the extractor / stereo matcher

@@ -1294,6 +1294,162 @@ int orc_search_by_projection(const orc_keypoint* kp, const uint8_t* desc, const 
 }
 
 /* ------------------------------------------------------------------------------------------
+ * The good-feature matchers: the loop body above exists three more times in the reference.
+ *   ORBmatcher::SearchByProjection_OnePoint(F, pMP, th)            include/ORBmatcher.h:71-150
+ *   ORBmatcher::GetCandidates / MatchCandidates                    include/ORBmatcher.h:152-250
+ *   ORBmatcher::SearchByProjection_Budget(F, MPs, th, time_constr) src/ORBmatcher.cc:45-153
+ * A "projection frame" is the part of Frame these read and write between calls: the grid, mvpMapPoints (as the label of the point a
+ * slot holds and whether that point has observations), mvpMatchScore.
+ * ---------------------------------------------------------------------------------------- */
+struct orc_proj_frame {
+    const orc_keypoint* kp; const uint8_t* desc; const float* u_right; int n;
+    float sf[32]; int nlevels;
+    orc_frame_bounds fb;
+    grid_t g;
+    int* idx;            /* scratch for GetFeaturesInArea */
+    int* slot_mp;        /* F.mvpMapPoints[i]: label of the point, -1 = none of this session's */
+    uint8_t* slot_obs;   /* F.mvpMapPoints[i] && F.mvpMapPoints[i]->Observations() > 0 */
+    int* slot_score;     /* F.mvpMatchScore[i] */
+};
+
+orc_proj_frame* orc_proj_frame_new(const orc_keypoint* kp, const uint8_t* desc, const float* u_right, int n, const float* sf, int nlevels,
+                                   const orc_frame_bounds* fb, const uint8_t* kp_taken)
+{
+    if (nlevels < 1 || nlevels > 32) return NULL;
+    orc_proj_frame* f = (orc_proj_frame*)calloc(1, sizeof *f);
+    f->kp = kp; f->desc = desc; f->u_right = u_right; f->n = n; f->nlevels = nlevels; f->fb = *fb;
+    memcpy(f->sf, sf, sizeof(float) * (size_t)nlevels);
+    grid_build(&f->g, kp, n, fb);
+    f->idx = (int*)malloc(sizeof(int) * (n > 0 ? n : 1));
+    f->slot_mp = (int*)malloc(sizeof(int) * (n > 0 ? n : 1));
+    f->slot_obs = (uint8_t*)malloc(n > 0 ? n : 1);
+    f->slot_score = (int*)calloc(n > 0 ? n : 1, sizeof(int));
+    for (int i = 0; i < n; i++) { f->slot_mp[i] = -1; f->slot_obs[i] = kp_taken ? kp_taken[i] : 0; }
+    return f;
+}
+void orc_proj_frame_free(orc_proj_frame* f)
+{
+    if (!f) return;
+    grid_free(&f->g);
+    free(f->idx); free(f->slot_mp); free(f->slot_obs); free(f->slot_score);
+    free(f);
+}
+void orc_proj_frame_get(const orc_proj_frame* f, int* out_mp, int* out_score)
+{
+    for (int i = 0; i < f->n; i++) { out_mp[i] = f->slot_mp[i]; out_score[i] = f->slot_mp[i] >= 0 ? f->slot_score[i] : 0; }
+}
+
+/* the window of a point: RadiusByViewingCos (* th), times the scale factor of the predicted level (ORBmatcher.h:84-90) */
+static int proj_point_window(const orc_proj_frame* f, const orc_map_point* mp, float th, float* rs)
+{
+    if (!(mp->flags & 1)) return 0; /* mbTrackInView, :75 */
+    if (mp->flags & 2) return 0;    /* isBad(), :78 */
+    const int lvl = mp->level;
+    if (lvl < 0 || lvl >= f->nlevels) return 0; /* (see orc_search_by_projection: not a case the reference defines) */
+    float r = mp->view_cos > 0.998 ? 2.5f : 4.0f;
+    if (th != 1.0f) r *= th;
+    *rs = r * f->sf[lvl];
+    return 1;
+}
+
+/* ORBmatcher::GetCandidates (ORBmatcher.h:152-172): pMP->mvMatchCandidates = F.GetFeaturesInArea(...) */
+int orc_proj_frame_candidates(orc_proj_frame* f, const orc_map_point* mp, float th, int* out_idx, int cap)
+{
+    float rs;
+    if (!proj_point_window(f, mp, th, &rs)) return 0;
+    const int k = grid_query(&f->g, f->kp, &f->fb, mp->proj_x, mp->proj_y, rs, mp->level - 1, mp->level, f->idx, f->n);
+    for (int i = 0; i < k && i < cap; i++) out_idx[i] = f->idx[i];
+    return k;
+}
+
+/* the candidate loop and the acceptance rule shared by _OnePoint (ORBmatcher.h:101-149) and MatchCandidates (:205-249).
+ * why: 0 matched, 1 ratio-rejected, 2 nothing within TH_HIGH */
+static int proj_match_list(orc_proj_frame* f, const orc_map_point* mp, const uint8_t* mp_desc, float rs, const int* cand, int ncand,
+                           float nn_ratio, int label, int* why)
+{
+    const int TH_HIGH = 100;
+    int bestDist = 256, bestLevel = -1, bestDist2 = 256, bestLevel2 = -1, bestIdx = -1;
+    for (int k = 0; k < ncand; k++) {
+        const int i = cand[k];
+        if (f->slot_obs[i]) continue; /* F.mvpMapPoints[idx] && ->Observations() > 0 */
+        if (f->u_right && f->u_right[i] > 0) {
+            const float er = fabsf(mp->proj_xr - f->u_right[i]);
+            if (er > rs) continue;
+        }
+        const int dist = orc_hamming256(mp_desc, f->desc + (size_t)i * 32);
+        if (dist < bestDist) {
+            bestDist2 = bestDist; bestDist = dist;
+            bestLevel2 = bestLevel; bestLevel = f->kp[i].octave;
+            bestIdx = i;
+        } else if (dist < bestDist2) {
+            bestLevel2 = f->kp[i].octave;
+            bestDist2 = dist;
+        }
+    }
+    if (bestDist <= TH_HIGH) {
+        if (bestLevel == bestLevel2 && (float)bestDist > nn_ratio * (float)bestDist2) { if (why) *why = 1; return -1; }
+        f->slot_mp[bestIdx] = label;                        /* F.mvpMapPoints[bestIdx] = pMP */
+        f->slot_obs[bestIdx] = (mp->flags & 4) ? 1 : 0;
+        f->slot_score[bestIdx] = bestDist;                  /* F.mvpMatchScore[bestIdx] = bestDist */
+        if (why) *why = 0;
+        return bestIdx;
+    }
+    if (why) *why = 2;
+    return -1;
+}
+
+/* ORBmatcher::SearchByProjection_OnePoint (ORBmatcher.h:71-150).  *why as above, 3 = left before the candidate loop (:75-99) */
+int orc_proj_frame_one_point(orc_proj_frame* f, const orc_map_point* mp, const uint8_t* mp_desc, float th, float nn_ratio, int label, int* why)
+{
+    float rs;
+    if (why) *why = 3;
+    if (!proj_point_window(f, mp, th, &rs)) return -1;
+    const int k = grid_query(&f->g, f->kp, &f->fb, mp->proj_x, mp->proj_y, rs, mp->level - 1, mp->level, f->idx, f->n);
+    if (k == 0) return -1; /* vIndices.empty(), :96 */
+    return proj_match_list(f, mp, mp_desc, rs, f->idx, k, nn_ratio, label, why);
+}
+
+/* ORBmatcher::MatchCandidates (ORBmatcher.h:176-250) on a list orc_proj_frame_candidates returned earlier */
+int orc_proj_frame_match_candidates(orc_proj_frame* f, const orc_map_point* mp, const uint8_t* mp_desc, const int* cand, int ncand,
+                                    float th, float nn_ratio, int label)
+{
+    float rs;
+    if (!proj_point_window(f, mp, th, &rs)) return -1;
+    if (ncand == 0) return -1; /* :185 */
+    return proj_match_list(f, mp, mp_desc, rs, cand, ncand, nn_ratio, label, NULL);
+}
+
+/* ORBmatcher::SearchByProjection_Budget (ORBmatcher.cc:45-153).  The wall clock of :96-102 is an argument: `clock_trip` = k > 0 makes
+ * the k-th reading of the clock the one that finds the budget spent (0: never).  out_point[p]: what point p did -- keypoint |
+ * distance << 16, -1 / -2 / -3 as include/gfo.h's GFO_POINT_*, -4 = the loop had ended before it.  found[p] = IncreaseFound() calls. */
+int orc_search_by_projection_budget(const orc_keypoint* kp, const uint8_t* desc, const float* u_right, int n,
+                                    const float* sf, int nlevels, const orc_frame_bounds* fb,
+                                    const orc_map_point* mps, const uint8_t* mp_desc, int m,
+                                    float th, float nn_ratio, const uint8_t* kp_taken, int clock_trip,
+                                    int* out_mp, int* out_score, int* out_point, int* found)
+{
+    orc_proj_frame* f = orc_proj_frame_new(kp, desc, u_right, n, sf, nlevels, fb, kp_taken);
+    int nmatches = 0, readings = 0;
+    for (int p = 0; p < m; p++) { out_point[p] = -4; if (found) found[p] = 0; }
+    for (int iMP = 0; iMP < m; iMP++) {
+        int why = 3;
+        const int best = orc_proj_frame_one_point(f, &mps[iMP], mp_desc + (size_t)iMP * 32, th, nn_ratio, iMP, &why);
+        if (why == 3) { out_point[iMP] = -1; continue; }   /* :60-77 */
+        if (why == 1) { out_point[iMP] = -2; continue; }   /* :85-86 */
+        if (best >= 0) {
+            out_point[iMP] = best | (f->slot_score[best] << 16);
+            if (found) found[iMP]++;                       /* pMP->IncreaseFound(), :91 */
+            nmatches++;
+        } else out_point[iMP] = -3;
+        readings++;                                        /* time_Match = timer.toc(), :97 */
+        if (clock_trip > 0 && readings >= clock_trip) break;
+    }
+    orc_proj_frame_get(f, out_mp, out_score);
+    orc_proj_frame_free(f);
+    return nmatches;
+}
+
+/* ------------------------------------------------------------------------------------------
  * ORBmatcher::ComputeThreeMaxima -- ORBmatcher.cc:1723-1764
  * ---------------------------------------------------------------------------------------- */
 void orc_three_maxima(const int* histo, int L, int* ind1, int* ind2, int* ind3)

@@ -164,6 +164,23 @@ int orc_search_by_projection(const orc_keypoint* kp_un, const uint8_t* desc, con
                              const orc_map_point* mps, const uint8_t* mp_desc, int m,
                              float th, float nn_ratio, const uint8_t* kp_taken,
                              int* out_mp, int* out_score);   /* a map point whose level is outside [0, nlevels) is skipped (see the .c) */
+/* The good-feature matchers (see the .c): SearchByProjection_OnePoint / GetCandidates / MatchCandidates (include/ORBmatcher.h:71-250)
+ * on a "projection frame" that carries mvpMapPoints / mvpMatchScore between calls, and SearchByProjection_Budget
+ * (src/ORBmatcher.cc:45-153) with its wall clock as an argument. */
+typedef struct orc_proj_frame orc_proj_frame;
+orc_proj_frame* orc_proj_frame_new(const orc_keypoint* kp_un, const uint8_t* desc, const float* u_right, int n, const float* scale_factors,
+                                   int nlevels, const orc_frame_bounds* fb, const uint8_t* kp_taken);   /* the arrays must outlive the frame */
+void orc_proj_frame_free(orc_proj_frame* f);
+void orc_proj_frame_get(const orc_proj_frame* f, int* out_mp, int* out_score);
+int orc_proj_frame_candidates(orc_proj_frame* f, const orc_map_point* mp, float th, int* out_idx, int cap);
+int orc_proj_frame_one_point(orc_proj_frame* f, const orc_map_point* mp, const uint8_t* mp_desc32, float th, float nn_ratio, int label, int* why);
+int orc_proj_frame_match_candidates(orc_proj_frame* f, const orc_map_point* mp, const uint8_t* mp_desc32, const int* cand, int ncand,
+                                    float th, float nn_ratio, int label);
+int orc_search_by_projection_budget(const orc_keypoint* kp_un, const uint8_t* desc, const float* u_right, int n,
+                                    const float* scale_factors, int nlevels, const orc_frame_bounds* fb,
+                                    const orc_map_point* mps, const uint8_t* mp_desc, int m,
+                                    float th, float nn_ratio, const uint8_t* kp_taken, int clock_trip,
+                                    int* out_mp, int* out_score, int* out_point, int* found);
 int orc_features_in_area(const orc_keypoint* kp_un, int n, const orc_frame_bounds* fb,
                          float x, float y, float r, int min_level, int max_level,
                          int* out_idx, int cap);

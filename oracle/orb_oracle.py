@@ -392,6 +392,87 @@ def search_by_projection(kp_un, desc, u_right, scale_factors, bounds, mps, mp_de
     return nm, out_mp[:n], out_score[:n]
 
 
+def search_by_projection_budget(kp_un, desc, u_right, scale_factors, bounds, mps, mp_desc, th, nn_ratio, kp_taken=None, clock_trip=0):
+    """ORBmatcher::SearchByProjection_Budget (src/ORBmatcher.cc:45-153); clock_trip = k > 0: the k-th reading of the wall clock finds the
+    budget spent.  Returns nmatches, out_mp, out_score, out_point (keypoint | distance << 16, -1 / -2 / -3, -4 = never reached), found."""
+    kp_un = np.ascontiguousarray(kp_un, dtype=KEYPOINT_DTYPE)
+    desc = np.ascontiguousarray(desc, dtype=np.uint8)
+    mps = np.ascontiguousarray(mps, dtype=MAP_POINT_DTYPE)
+    mp_desc = np.ascontiguousarray(mp_desc, dtype=np.uint8)
+    sf = np.ascontiguousarray(scale_factors, dtype=np.float32)
+    n, m = len(kp_un), len(mps)
+    if u_right is not None:
+        u_right = np.ascontiguousarray(u_right, np.float32)
+    if kp_taken is not None:
+        kp_taken = np.ascontiguousarray(kp_taken, np.uint8)
+    fb = FrameBounds(*bounds)
+    out_mp = np.zeros(max(n, 1), np.int32); out_score = np.zeros(max(n, 1), np.int32)
+    out_point = np.zeros(max(m, 1), np.int32); found = np.zeros(max(m, 1), np.int32)
+    L = lib()
+    L.orc_search_by_projection_budget.restype = C.c_int
+    L.orc_search_by_projection_budget.argtypes = [C.c_void_p] * 3 + [C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
+                                                  C.c_float, C.c_float, C.c_void_p, C.c_int] + [C.c_void_p] * 4
+    nm = L.orc_search_by_projection_budget(_p(kp_un), _p(desc), _p(u_right), n, _p(sf), len(sf), C.byref(fb), _p(mps), _p(mp_desc), m,
+                                           th, nn_ratio, _p(kp_taken), clock_trip, _p(out_mp), _p(out_score), _p(out_point), _p(found))
+    return nm, out_mp[:n], out_score[:n], out_point[:m], found[:m]
+
+
+class ProjectionFrame:
+    """What SearchByProjection_OnePoint / GetCandidates / MatchCandidates (include/ORBmatcher.h:71-250) read and write in a Frame, kept
+    between calls: the grid, mvpMapPoints (label of the holder, whether it has observations) and mvpMatchScore."""
+
+    def __init__(self, kp_un, desc, u_right, scale_factors, bounds, kp_taken=None):
+        self.kp = np.ascontiguousarray(kp_un, dtype=KEYPOINT_DTYPE)
+        self.desc = np.ascontiguousarray(desc, dtype=np.uint8)
+        self.ur = None if u_right is None else np.ascontiguousarray(u_right, np.float32)
+        self.sf = np.ascontiguousarray(scale_factors, dtype=np.float32)
+        self.taken = None if kp_taken is None else np.ascontiguousarray(kp_taken, np.uint8)
+        self.n = len(self.kp)
+        fb = FrameBounds(*bounds)
+        L = lib()
+        vp = C.c_void_p
+        L.orc_proj_frame_new.restype = vp
+        L.orc_proj_frame_new.argtypes = [vp, vp, vp, C.c_int, vp, C.c_int, vp, vp]
+        L.orc_proj_frame_free.argtypes = [vp]
+        L.orc_proj_frame_get.argtypes = [vp, vp, vp]
+        L.orc_proj_frame_candidates.argtypes = [vp, vp, C.c_float, vp, C.c_int]
+        L.orc_proj_frame_one_point.argtypes = [vp, vp, vp, C.c_float, C.c_float, C.c_int, vp]
+        L.orc_proj_frame_match_candidates.argtypes = [vp, vp, vp, vp, C.c_int, C.c_float, C.c_float, C.c_int]
+        self._h = L.orc_proj_frame_new(_p(self.kp), _p(self.desc), _p(self.ur), self.n, _p(self.sf), len(self.sf), C.byref(fb), _p(self.taken))
+        assert self._h
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().orc_proj_frame_free(self._h)
+            self._h = None
+
+    def candidates(self, mp, th):
+        """GetCandidates: the keypoint indices in GetFeaturesInArea's order."""
+        mp = np.ascontiguousarray(mp, dtype=MAP_POINT_DTYPE).reshape(1)
+        out = np.zeros(max(self.n, 1), np.int32)
+        k = lib().orc_proj_frame_candidates(self._h, _p(mp), th, _p(out), self.n)
+        return out[:k].copy()
+
+    def one_point(self, mp, mp_desc, th, nn_ratio, label):
+        """SearchByProjection_OnePoint: returns (bestIdx or -1, why) with why 0 matched / 1 ratio / 2 nothing within TH_HIGH / 3 no candidates."""
+        mp = np.ascontiguousarray(mp, dtype=MAP_POINT_DTYPE).reshape(1)
+        d = np.ascontiguousarray(mp_desc, np.uint8)
+        why = C.c_int(0)
+        r = lib().orc_proj_frame_one_point(self._h, _p(mp), _p(d), th, nn_ratio, label, C.byref(why))
+        return r, why.value
+
+    def match_candidates(self, mp, mp_desc, cand, th, nn_ratio, label):
+        mp = np.ascontiguousarray(mp, dtype=MAP_POINT_DTYPE).reshape(1)
+        d = np.ascontiguousarray(mp_desc, np.uint8)
+        cand = np.ascontiguousarray(cand, np.int32)
+        return lib().orc_proj_frame_match_candidates(self._h, _p(mp), _p(d), _p(cand), len(cand), th, nn_ratio, label)
+
+    def state(self):
+        out_mp = np.zeros(max(self.n, 1), np.int32); out_score = np.zeros(max(self.n, 1), np.int32)
+        lib().orc_proj_frame_get(self._h, _p(out_mp), _p(out_score))
+        return out_mp[:self.n], out_score[:self.n]
+
+
 class VocabularyC(C.Structure):
     _fields_ = [("first_child", C.c_void_p), ("n_children", C.c_void_p), ("descriptors", C.c_void_p), ("word_id", C.c_void_p),
                 ("weight", C.c_void_p), ("n_nodes", C.c_int32), ("depth", C.c_int32), ("weight64", C.c_void_p)]

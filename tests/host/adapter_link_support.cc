@@ -74,6 +74,7 @@ int MapPoint::PredictScale(const float&, Frame*) { return mnTrackScaleLevel; }
 cv::Mat MapPoint::GetWorldPos() { return mWorldPos.clone(); }
 cv::Mat MapPoint::GetDescriptor() { return mDescriptor.clone(); }
 int MapPoint::Observations() { return nObs; }
+void MapPoint::IncreaseFound(int n) { mnFound += n; }
 bool MapPoint::isBad() { return mbBad; }
 
 // ---- KeyFrame: a keyframe is a frame's arrays frozen (include/KeyFrame.h:165-268: const members copied from the Frame) ---------

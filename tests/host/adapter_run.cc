@@ -12,6 +12,7 @@
 //      windows on a fresh frame, and a call after the caller's own PrepareStereoCandidates;
 //   G. the online form of the association, ComputeStereoMatches_Undistorted(true): no outlier cut (Frame.cc:1290);
 //   E. ORBmatcher::SearchByProjection(Frame&, vector<MapPoint*>&, th) (ORBmatcher.cc:155-241);
+//   E2. ORBmatcher::SearchByProjection_Budget(Frame&, vector<MapPoint*>&, th, time_constr) (ORBmatcher.cc:45-153), the good-feature build's;
 //   F. ORBmatcher::SearchByProjection(CurrentFrame, LastFrame, th, bMono, numVisible) (ORBmatcher.cc:1440-1593), including the
 //      host-side projection the adapter keeps (:1451-1502);
 //   H. ORBmatcher::SearchByProjection(CurrentFrame, KeyFrame*, sAlreadyFound, th, ORBdist) (ORBmatcher.cc:1595-1721), relocalisation's;
@@ -153,6 +154,7 @@ struct TestMP : public MapPoint {   // MapPoint() is the header's own "for unit 
         memcpy(mDescriptor.data, d, 32);
     }
     void bad(bool b) { mbBad = b; }
+    void found(int n) { mnFound = n; }
     void range(float mn, float mx) { mfMinDistance = mn; mfMaxDistance = mx; }
 };
 
@@ -580,6 +582,33 @@ int main(int argc, char** argv)
             report("E_map_points", M);
             report("E_SearchByProjection_F_MapPoints_us", median_us(20, [&]() { F.mvpMapPoints = before; }, [&]() { matcher.SearchByProjection(F, map, 3); }));
             F.mvpMapPoints = after;
+            // E2. SearchByProjection_Budget(F, local map, th = 0.5, time_constr) (ORBmatcher.cc:45-153; Tracking.cc:2166 calls it with
+            //     th 0.5 or 1 and what is left of the frame's budget): once with a budget no call can spend (every point visited), once
+            //     with none left (the reference's first clock reading ends its loop)
+            {
+                const double budgets[2] = {1.0, 0.0};
+                for (int v = 0; v < 2; v++) {
+                    F.mvpMapPoints = before;
+                    std::fill(F.mvpMatchScore.begin(), F.mvpMatchScore.end(), 0);
+                    for (int j = 0; j < M; j++) static_cast<TestMP*>(map[j])->found(0);
+                    const int nb = matcher.SearchByProjection_Budget(F, map, 0.5f, budgets[v]);
+                    std::vector<int32_t> bidx(F.N, -1), fnd(M);
+                    for (int i = 0; i < F.N; i++) {
+                        if (F.mvpMapPoints[i] == before[i]) continue;
+                        bidx[i] = -3;
+                        for (int j = 0; j < M; j++) if (map[j] == F.mvpMapPoints[i]) { bidx[i] = j; break; }
+                    }
+                    for (int j = 0; j < M; j++) fnd[j] = map[j]->GetFound();
+                    dump(tag("E2", v, "out_mp"), bidx.data(), bidx.size() * 4);
+                    dump(tag("E2", v, "out_score"), F.mvpMatchScore.data(), F.mvpMatchScore.size() * 4);
+                    dump(tag("E2", v, "found"), fnd.data(), fnd.size() * 4);
+                    int32_t nb32 = nb;
+                    dump(tag("E2", v, "nmatches"), &nb32, 4);
+                }
+                F.mvpMapPoints = before;
+                report("E2_SearchByProjection_Budget_us", median_us(20, [&]() { F.mvpMapPoints = before; }, [&]() { matcher.SearchByProjection_Budget(F, map, 0.5f, 1.0); }));
+                F.mvpMapPoints = after;
+            }
             // ... and what the library call inside it costs on the same inputs, already flattened (a context of the harness's own):
             // the difference is the adapter's walk over the MapPoint objects through the reference's accessors
             {

@@ -1,10 +1,11 @@
-// stands for adapter/matchers_gfo.cc: the same six members, every body answers 2
+// stands for adapter/matchers_gfo.cc: the same seven members, every body answers 2
 #include "decl.h"
 namespace ORB_SLAM2
 {
 int Frame::ComputeStereoMatches_Undistorted(bool) { return 2; }
 void Frame::ComputeBoW() { bow = 2; }
 int ORBmatcher::SearchByProjection(Frame&, const std::vector<MapPoint*>&, const float) { return 2; }
+int ORBmatcher::SearchByProjection_Budget(Frame&, const std::vector<MapPoint*>&, const float, const double) { return 2; }
 int ORBmatcher::SearchByProjection(Frame&, const Frame&, const float, const bool, double&) { return 2; }
 int ORBmatcher::SearchByProjection(Frame&, KeyFrame*, const std::set<MapPoint*>&, const float, const int) { return 2; }
 int ORBmatcher::SearchByBoW(KeyFrame*, Frame&, std::vector<MapPoint*>&) { return 2; }

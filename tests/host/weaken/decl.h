@@ -1,4 +1,4 @@
-// Declarations with the reference's names and signatures (include/Frame.h:267, include/ORBmatcher.h:64,259-272), nothing else of
+// Declarations with the reference's names and signatures (include/Frame.h:267, include/ORBmatcher.h:64,67,259-272), nothing else of
 // the classes: a mangled name depends on the names in a signature only.  tests/test_adapter_compiles.py checks that the symbols
 // this miniature defines ARE the ones in adapter/weaken_symbols.txt.
 #include <set>
@@ -19,6 +19,7 @@ class ORBmatcher
 {
 public:
     int SearchByProjection(Frame& F, const std::vector<MapPoint*>& vpMapPoints, const float th);
+    int SearchByProjection_Budget(Frame& F, const std::vector<MapPoint*>& vpMapPoints, const float th, const double time_constr);
     int SearchByProjection(Frame& CurrentFrame, const Frame& LastFrame, const float th, const bool bMono, double& numVisibleMpt);
     int SearchByProjection(Frame& CurrentFrame, KeyFrame* pKF, const std::set<MapPoint*>& sAlreadyFound, const float th, const int ORBdist);
     int SearchByBoW(KeyFrame* pKF, Frame& F, std::vector<MapPoint*>& vpMapPointMatches);

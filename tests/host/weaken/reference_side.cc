@@ -6,6 +6,7 @@ int Frame::ComputeStereoMatches_Undistorted(bool) { return 1; }
 void Frame::ComputeBoW() { bow = 1; }
 int Frame::construct() { return ComputeStereoMatches_Undistorted(false); }
 int ORBmatcher::SearchByProjection(Frame&, const std::vector<MapPoint*>&, const float) { return 1; }
+int ORBmatcher::SearchByProjection_Budget(Frame&, const std::vector<MapPoint*>&, const float, const double) { return 1; }
 int ORBmatcher::SearchByProjection(Frame&, const Frame&, const float, const bool, double&) { return 1; }
 int ORBmatcher::SearchByProjection(Frame&, KeyFrame*, const std::set<MapPoint*>&, const float, const int) { return 1; }
 int ORBmatcher::SearchByBoW(KeyFrame*, Frame&, std::vector<MapPoint*>&) { return 1; }

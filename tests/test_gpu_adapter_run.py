@@ -150,6 +150,9 @@ def run(tmp_path_factory, oracle, euroc_l, euroc_r):
     mpd.tofile(ind / "E_map_desc.bin")
     tk.tofile(ind / "E_taken.bin")
     ref["E"] = oracle.search_by_projection(kl, dl, st[1], sf, (0.0, 0.0, 752.0, 480.0), mps, mpd, 3.0, 0.8, (tk == 1).astype(np.uint8))
+    # E2: SearchByProjection_Budget on the same map at Tracking.cc:2166's th = 0.5: a clock that never trips / trips at its first reading
+    ref["E2"] = [oracle.search_by_projection_budget(kl, dl, st[1], sf, (0.0, 0.0, 752.0, 480.0), mps, mpd, 0.5, 0.8, (tk == 1).astype(np.uint8), trip)
+                 for trip in (0, 1)]
 
     # F: SearchByProjection(Cur = frame 1, Last = frame 0): the adapter projects on the host (ORBmatcher.cc:1451-1502), so this side
     # states the same float expressions independently
@@ -533,6 +536,20 @@ def test_search_by_projection_member(run):
     np.testing.assert_array_equal(sc[out_mp >= 0], out_sc[out_mp >= 0])
     assert (sc[out_mp < 0] == 0).all()
     assert int(_rd(run, "E_nmatches.bin", np.int32)[0]) == nm
+
+
+def test_search_by_projection_budget_member(run):
+    """ORBmatcher::SearchByProjection_Budget(F, MapPoints, th, time_constr) (ORBmatcher.h:67, .cc:45-153), the matcher of the reference's
+    default (good-feature) build behind Tracking::SearchAdditionalMatchesInFrame: slots, scores, the count, IncreaseFound() per match --
+    with a budget no call can spend (the oracle's clock never trips) and with none left on entry (its first reading trips)."""
+    for v, (nm, out_mp, out_sc, out_pt, found) in enumerate(run["E2"]):
+        np.testing.assert_array_equal(_rd(run, f"E2_f{v:02d}_out_mp.bin", np.int32), out_mp)
+        sc = _rd(run, f"E2_f{v:02d}_out_score.bin", np.int32)
+        np.testing.assert_array_equal(sc[out_mp >= 0], out_sc[out_mp >= 0])
+        assert (sc[out_mp < 0] == 0).all()
+        np.testing.assert_array_equal(_rd(run, f"E2_f{v:02d}_found.bin", np.int32), found)
+        assert int(_rd(run, f"E2_f{v:02d}_nmatches.bin", np.int32)[0]) == nm
+    assert run["E2"][0][0] > 200 and run["E2"][1][0] <= 1 and (run["E2"][1][3] == -4).sum() > 2900
 
 
 def test_search_by_projection_last_frame_member(run):

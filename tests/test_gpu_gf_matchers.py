@@ -1,0 +1,128 @@
+"""GPU parity tests of the good-feature matchers through the C ABI: gfo_search_by_projection_points against the oracle's literal
+statements of ORBmatcher::SearchByProjection_Budget (src/ORBmatcher.cc:45-153) and SearchByProjection_OnePoint
+(include/ORBmatcher.h:71-150).  Indices, distances and the three ways a point leaves the loop body: bit-exact."""
+import numpy as np
+import pytest
+
+import gf_cases as gc
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(params=["wavefront_per_point", "wavefront_per_point_small_pool", "thread_per_point"], autouse=True)
+def round0_form(request, monkeypatch):
+    """Both forms of round 0 write the points' first outcome (tests/test_gpu_projection.py has the details of the three settings)."""
+    monkeypatch.setenv("GFO_PROJ_WAVE", "0" if request.param == "thread_per_point" else "1")
+    if request.param == "wavefront_per_point_small_pool":
+        monkeypatch.setenv("GFO_PROJ_SPILL_CAP", "3000")
+    return request.param
+
+
+@pytest.fixture(scope="module")
+def ext():
+    import gf_orb_slam2_amd as G
+    e = G.ORBextractor(2000, 1.2, 8, 20, 7)
+    yield e
+    e.close()
+
+
+@pytest.mark.parametrize("seed,m,th,ratio,sigma", [(1, 1500, 1.0, 0.8, 3.0), (2, 4000, 0.5, 0.8, 2.0), (3, 3000, 3.0, 0.9, 3.0),
+                                                   (4, 20000, 1.0, 0.8, 3.0), (5, 9000, 5.0, 0.7, 6.0)])
+def test_every_point_reports_what_it_did(ext, oracle, seed, m, th, ratio, sigma):
+    import gf_orb_slam2_amd as G
+    kl, dl, u, _ = gc.frame(oracle)
+    sf = ext.GetScaleFactors()
+    mps, mpd, taken = gc.contended_map(oracle, kl, dl, seed, m, sigma)
+    ref = oracle.search_by_projection_budget(kl, dl, u, sf, gc.BOUNDS, mps, mpd, th, ratio, taken, 0)
+    mt = G.ORBmatcher(ratio, True, extractor=ext)
+    nm, out_mp, out_sc, out_pt = mt.SearchByProjectionPoints(kl, dl, u, sf, gc.BOUNDS, mps, mpd, th, taken)
+    assert nm == ref[0] and nm > 100
+    np.testing.assert_array_equal(out_pt, ref[3])
+    np.testing.assert_array_equal(out_mp, ref[1])
+    np.testing.assert_array_equal(out_sc, ref[2])
+    for code in (mt.POINT_NONE, mt.POINT_FAR) + ((mt.POINT_RATIO,) if th >= 1.0 else ()):   # (half-size windows rarely hold two close candidates)
+        assert (out_pt == code).any()
+    # the plain entry point is unchanged by the extra output
+    plain = mt.SearchByProjection(kl, dl, u, sf, gc.BOUNDS, mps, mpd, th, taken)
+    assert plain[0] == nm
+    np.testing.assert_array_equal(plain[1], out_mp)
+    np.testing.assert_array_equal(plain[2], out_sc)
+
+
+def test_the_clock_of_the_budget_matcher_cuts_a_prefix(ext, oracle):
+    """SearchByProjection_Budget with a clock that trips at its k-th reading = the first `cut` points of ONE device call."""
+    import gf_orb_slam2_amd as G
+    kl, dl, u, _ = gc.frame(oracle)
+    sf = ext.GetScaleFactors()
+    mps, mpd, taken = gc.contended_map(oracle, kl, dl, 5, 2500)
+    mt = G.ORBmatcher(0.8, True, extractor=ext)
+    _, _, _, out_pt = mt.SearchByProjectionPoints(kl, dl, u, sf, gc.BOUNDS, mps, mpd, 1.0, taken)
+    for k in (1, 2, 17, 300, 100000):
+        ref = oracle.search_by_projection_budget(kl, dl, u, sf, gc.BOUNDS, mps, mpd, 1.0, 0.8, taken, k)
+        cut = gc.clock_cut(out_pt, k)
+        nm, pm, ps = mt.points_prefix(out_pt, cut, len(kl))
+        assert nm == ref[0]
+        np.testing.assert_array_equal(pm, ref[1])
+        np.testing.assert_array_equal(ps, ref[2])
+        np.testing.assert_array_equal((out_pt[:cut] >= 0).astype(np.int32), ref[4][:cut])     # IncreaseFound() per match
+        assert not ref[4][cut:].any()
+
+
+@pytest.mark.parametrize("num_to_match", [30, 200, 1000])
+def test_baseline_map_matching_is_a_weighted_prefix(ext, oracle, num_to_match):
+    """Observability::runBaselineMapMatching (src/Observability.cc:1233-1262): the in-view points sorted by life, SearchByProjection_OnePoint
+    one after the other, `nMatched += 2` per match and `+ 1` when the matched keypoint has a depth, until nMatched >= num_to_match.  The
+    oracle walks that loop literally; the device answers all points in the sorted order at once and the loop's exit becomes a prefix."""
+    import gf_orb_slam2_amd as G
+    kl, dl, u, depth = gc.frame(oracle)
+    sf = ext.GetScaleFactors()
+    mps, mpd, taken = gc.contended_map(oracle, kl, dl, 11, 3000)
+    rng = np.random.default_rng(3)
+    n_visible = rng.integers(1, 50, len(mps))
+    valid = np.flatnonzero((mps["flags"] & 1).astype(bool) & ~(mps["flags"] & 2).astype(bool))      # :1203-1211
+    order = valid[np.argsort(-n_visible[valid], kind="stable")]                                    # BASELINE_LONGLIVE: sort by life
+    pf = oracle.ProjectionFrame(kl, dl, u, sf, gc.BOUNDS, taken)
+    n_matched, walked = 0, 0
+    for p in order:
+        if n_matched >= num_to_match:
+            break
+        best, _ = pf.one_point(mps[p], mpd[p], 1.0, 0.8, walked)
+        walked += 1
+        if best >= 0:
+            n_matched += 2
+            if depth[best] >= 0:
+                n_matched += 1
+    ref_mp, ref_sc = pf.state()
+    mt = G.ORBmatcher(0.8, True, extractor=ext)
+    _, _, _, out_pt = mt.SearchByProjectionPoints(kl, dl, u, sf, gc.BOUNDS, mps[order], mpd[order], 1.0, taken)
+    got, cut = 0, 0
+    while cut < len(order) and got < num_to_match:
+        v = int(out_pt[cut])
+        cut += 1
+        if v >= 0:
+            got += 2 + (1 if depth[v & 0xFFFF] >= 0 else 0)
+    assert cut == walked and got == n_matched and cut < len(order)
+    _, pm, ps = mt.points_prefix(out_pt, cut, len(kl))
+    np.testing.assert_array_equal(pm, ref_mp)
+    np.testing.assert_array_equal(ps, ref_sc)
+
+
+def test_points_edge_cases(ext, oracle):
+    import gf_orb_slam2_amd as G
+    kl, dl, u, _ = gc.frame(oracle)
+    sf = ext.GetScaleFactors()
+    mt = G.ORBmatcher(0.8, True, extractor=ext)
+    z = np.zeros(0, oracle.MAP_POINT_DTYPE)
+    nm, out_mp, _, out_pt = mt.SearchByProjectionPoints(kl, dl, None, sf, gc.BOUNDS, z, np.zeros((0, 32), np.uint8), 1.0, None)
+    assert nm == 0 and (out_mp == -1).all() and len(out_pt) == 0
+    mps, mpd, _ = gc.contended_map(oracle, kl, dl, 2, 64)
+    nm, out_mp, _, out_pt = mt.SearchByProjectionPoints(kl[:0], dl[:0], None, sf, gc.BOUNDS, mps, mpd, 1.0, None)
+    assert nm == 0 and (out_pt == -1).all()
+    # every point out of view / bad
+    mps["flags"] = 2 | 4
+    nm, _, _, out_pt = mt.SearchByProjectionPoints(kl, dl, u, sf, gc.BOUNDS, mps, mpd, 1.0, None)
+    assert nm == 0 and (out_pt == -1).all()
+    # the prefix helper refuses what cannot be a result of the call
+    with pytest.raises(ValueError):
+        mt.points_prefix(np.array([5 | (3 << 16)], np.int32), 1, 4)
+    assert mt.points_prefix(np.array([2 | (3 << 16), -3, 2 | (9 << 16)], np.int32), 3, 4)[1].tolist() == [-1, -1, 2, -1]

@@ -734,3 +734,78 @@ def test_bow_fold_against_the_reference_build_live(oracle):
                 b = oracle.ref_bow_fold(word, weight, node, w, nm)
                 for x, y in zip(a, b):
                     assert x.tobytes() == y.tobytes(), (trial, w, nm)
+
+
+# ---- the good-feature matchers: SearchByProjection_Budget / _OnePoint / GetCandidates / MatchCandidates -------------------------------
+@pytest.mark.parametrize("seed,m,th,ratio", [(1, 1500, 1.0, 0.8), (2, 4000, 0.5, 0.8), (3, 3000, 3.0, 0.9)])
+def test_budget_matcher_without_a_clock_is_the_plain_overload(oracle, seed, m, th, ratio):
+    """SearchByProjection_Budget (ORBmatcher.cc:45-153) differs from SearchByProjection (:155-241) by IncreaseFound() and the clock
+    only: with a clock that never trips the two restatements -- written separately -- must agree on every slot."""
+    import gf_cases as gc
+    kl, dl, u, _ = gc.frame(oracle)
+    sf = oracle.OracleExtractor(2000, 1.2, 8, 20, 7).scale_factors
+    mps, mpd, taken = gc.contended_map(oracle, kl, dl, seed, m)
+    ref = oracle.search_by_projection(kl, dl, u, sf, gc.BOUNDS, mps, mpd, th, ratio, taken)
+    nm, out_mp, out_sc, out_pt, found = oracle.search_by_projection_budget(kl, dl, u, sf, gc.BOUNDS, mps, mpd, th, ratio, taken, 0)
+    assert nm == ref[0] and nm > 100
+    np.testing.assert_array_equal(out_mp, ref[1])
+    np.testing.assert_array_equal(out_sc, ref[2])
+    np.testing.assert_array_equal(found, (out_pt >= 0).astype(np.int32))
+    assert (out_pt == -1).any() and (out_pt == -2).any() and (out_pt == -3).any() and (out_pt > -4).all()
+    # the same through the per-point entry the greedy selection calls (ORBmatcher.h:71-150), in vector order
+    pf = oracle.ProjectionFrame(kl, dl, u, sf, gc.BOUNDS, taken)
+    why_code = {0: None, 1: -2, 2: -3, 3: -1}
+    for p in range(m):
+        best, why = pf.one_point(mps[p], mpd[p], th, ratio, p)
+        if best >= 0:
+            assert out_pt[p] == (best | (pf.state()[1][best] << 16)) if p % 97 == 0 else (out_pt[p] & 0xFFFF) == best
+        else:
+            assert out_pt[p] == why_code[why]
+    st = pf.state()
+    np.testing.assert_array_equal(st[0], out_mp)
+    np.testing.assert_array_equal(st[1], out_sc)
+
+
+def test_budget_matcher_clock_cuts_a_prefix(oracle):
+    """Whatever the clock does, the answer is the full answer's prefix up to the point whose clock reading tripped -- the property the
+    device entry point rests on (one call for all points, gfo_projection_points_prefix for the cut)."""
+    import gf_cases as gc
+    kl, dl, u, _ = gc.frame(oracle)
+    sf = oracle.OracleExtractor(2000, 1.2, 8, 20, 7).scale_factors
+    mps, mpd, taken = gc.contended_map(oracle, kl, dl, 5, 2500)
+    full = oracle.search_by_projection_budget(kl, dl, u, sf, gc.BOUNDS, mps, mpd, 1.0, 0.8, taken, 0)
+    for k in (1, 2, 17, 300, 100000):
+        nm, out_mp, out_sc, out_pt, found = oracle.search_by_projection_budget(kl, dl, u, sf, gc.BOUNDS, mps, mpd, 1.0, 0.8, taken, k)
+        cut = gc.clock_cut(full[3], k)
+        np.testing.assert_array_equal(out_pt[:cut], full[3][:cut])
+        assert (out_pt[cut:] == -4).all()
+        cnt, pm, ps = gc.prefix_state(full[3], cut, len(kl))
+        assert cnt == nm
+        np.testing.assert_array_equal(out_mp, pm)
+        np.testing.assert_array_equal(out_sc, ps)
+    assert gc.clock_cut(full[3], 1) < 20
+
+
+def test_candidate_lists_then_match_equals_one_point(oracle):
+    """GetCandidates + MatchCandidates (ORBmatcher.h:152-250, the INFORMATION_EFFICIENCY_SCORE form) = SearchByProjection_OnePoint, in any
+    order of the points: two frames driven side by side in a shuffled order."""
+    import gf_cases as gc
+    kl, dl, u, _ = gc.frame(oracle)
+    sf = oracle.OracleExtractor(2000, 1.2, 8, 20, 7).scale_factors
+    mps, mpd, taken = gc.contended_map(oracle, kl, dl, 9, 1200)
+    a = oracle.ProjectionFrame(kl, dl, u, sf, gc.BOUNDS, taken)
+    b = oracle.ProjectionFrame(kl, dl, u, sf, gc.BOUNDS, taken)
+    cands = [b.candidates(mps[p], 1.0) for p in range(len(mps))]
+    assert max(len(c) for c in cands) > 5
+    for p in np.random.default_rng(0).permutation(len(mps)):
+        ra, _ = a.one_point(mps[p], mpd[p], 1.0, 0.8, int(p))
+        rb = b.match_candidates(mps[p], mpd[p], cands[p], 1.0, 0.8, int(p))
+        assert ra == rb
+    np.testing.assert_array_equal(a.state()[0], b.state()[0])
+    np.testing.assert_array_equal(a.state()[1], b.state()[1])
+    # a candidate list is GetFeaturesInArea's answer
+    for p in (0, 5, 77):
+        if mps["flags"][p] & 1 and not mps["flags"][p] & 2:
+            r = (2.5 if mps["view_cos"][p] > 0.998 else 4.0) * sf[mps["level"][p]]
+            ref = oracle.features_in_area(kl, gc.BOUNDS, mps["proj_x"][p], mps["proj_y"][p], np.float32(r), int(mps["level"][p]) - 1, int(mps["level"][p]))
+            np.testing.assert_array_equal(cands[p], ref)
