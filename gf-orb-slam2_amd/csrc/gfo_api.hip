@@ -683,6 +683,7 @@ extern "C" void gfo_ctx_destroy(gfo_ctx* c)
     if (c->h_min) (void)hipHostFree(c->h_min);
     if (c->h_mout) (void)hipHostFree(c->h_mout);
     if (c->pj.base) (void)hipFree(c->pj.base);
+    if (c->d_pj_cand) (void)hipFree(c->d_pj_cand);
     if (c->d_map_desc) (void)hipFree(c->d_map_desc);
     if (c->side_stream) {
         (void)hipStreamSynchronize(c->side_stream);

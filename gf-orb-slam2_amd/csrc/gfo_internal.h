@@ -273,6 +273,8 @@ struct gfo_ctx {
     // scratch for host-array matcher entry points
     void* d_scratch = nullptr;
     size_t scratch_bytes = 0;
+    void* d_pj_cand = nullptr;        // gfo_projection_candidates: offsets [m + 1], entries [cap] and the unsorted keys [cap] of the last call
+    size_t pj_cand_bytes = 0;
     int last_project_rounds = 0;
     // batched projection search: resident local-map descriptors + per-frame work buffers
     GfoProjBuf pj{};

@@ -948,6 +948,146 @@ __global__ __launch_bounds__(1024) void k_proj_resolve(ProjB a)
 }
 
 // ------------------------------------------------------------------------------------------------------------
+// The candidate table (gfo_projection_candidates): ORBmatcher::GetCandidates (include/ORBmatcher.h:152-172) for every map point at
+// once -- pMP->mvMatchCandidates = F.GetFeaturesInArea(...) -- and, per candidate, the two things MatchCandidates /
+// SearchByProjection_OnePoint compute that do not depend on what the frame's slots hold: the mvuRight gate (:118-123) and the
+// descriptor distance (:127).  A wavefront per point, two passes over the same scan: PASS 0 counts, k_proj_cand_scan turns the counts
+// into offsets, PASS 1 writes.  GetFeaturesInArea returns a window's keypoints in (grid column, grid row, index) order; the scan grid
+// has its own cells, so a point's entries are ranked by that key before they are written (in LDS up to 64 candidates -- every case
+// but pathological ones -- through device memory beyond).
+//   entry: keypoint index | octave << 16 | distance << 20 | (mvuRight gate closed) << 31
+template <int PASS>
+__global__ __launch_bounds__(64 * PJ_WAVES) void k_proj_candidates(ProjB a, int* start, unsigned* cand, unsigned* h_cand, unsigned long long* tmp, int cap)
+{
+    __shared__ unsigned long long s_keys[PASS ? PJ_WAVES : 1][64];
+    const int n = frame_n(a, 0);
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int iq = blockIdx.x * PJ_WAVES + wave;
+    ProjQ q{};
+    if (iq < a.m && n > 0) q = load_query(a, 0, iq);
+    const float rs = q.radius, x = q.u, y = q.v;
+    bool scan = iq < a.m && n > 0 && q.active && rs > 0.f;
+    int base = 0, T = 0;
+    if (PASS == 1) {
+        if (iq < a.m) { base = start[iq]; T = start[iq + 1] - base; }
+        scan = scan && T > 0 && base >= 0 && base + T <= cap;   // a table that does not fit the caller's array is not written (GFO_ERR_CAPACITY)
+    }
+    const int* g_start = a.cell_start;
+    const float2* cell_xy = a.cell_xy;
+    const unsigned* cell_meta = a.cell_meta;
+    uint4 a0 = make_uint4(0, 0, 0, 0), a1 = a0;
+    if (PASS == 1 && scan) {
+        const uint4* dq = reinterpret_cast<const uint4*>(a.q_desc + (long long)iq * 32);
+        a0 = dq[0]; a1 = dq[1];
+    }
+    // the scan cells the window touches: see scan_candidates
+    const float sgx = (float)(SG_COLS - 1), sgy = (float)(SG_ROWS - 1);
+    const int cx0 = (int)fminf(fmaxf(floorf((x - a.fb.min_x - rs) * a.sinv_w - 0.01f), 0.f), sgx);
+    const int cx1 = scan ? (int)fminf(fmaxf(floorf((x - a.fb.min_x + rs) * a.sinv_w + 0.01f), 0.f), sgx) : cx0 - 1;
+    const int cy0 = (int)fminf(fmaxf(floorf((y - a.fb.min_y - rs) * a.sinv_h - 0.01f), 0.f), sgy);
+    const int cy1 = (int)fminf(fmaxf(floorf((y - a.fb.min_y + rs) * a.sinv_h + 0.01f), 0.f), sgy);
+    const bool check_levels = (q.min_level > 0) || (q.max_level >= 0);
+    int total = 0;
+    for (int cg = cx0; cg <= cx1; cg += 64) {
+        const int ncol = min(64, cx1 - cg + 1);
+        int beg = 0, cnt = 0;
+        if (lane < ncol) {   // lane c holds column cg + c: cells (column, cy0..cy1) are contiguous in the CSR
+            beg = g_start[(cg + lane) * SG_ROWS + cy0];
+            cnt = g_start[(cg + lane) * SG_ROWS + cy1 + 1] - beg;
+        }
+        const int incl = st_wave_incl_scan(cnt);
+        const int excl = incl - cnt;
+        const int items = __builtin_amdgcn_readlane(incl, 63);
+        for (int t0 = 0; t0 < items; t0 += 64) {
+            const int t = t0 + lane;
+            int j = -1;
+            for (int cc = 0; cc < ncol; cc++) {
+                const int p = __builtin_amdgcn_readlane(excl, cc), cn = __builtin_amdgcn_readlane(cnt, cc), b = __builtin_amdgcn_readlane(beg, cc);
+                if (t >= p && t < p + cn) j = b + (t - p);
+            }
+            bool ok = false;
+            unsigned meta = 0;
+            if (j >= 0) {
+                const float2 it = cell_xy[j];
+                meta = cell_meta[j];
+                ok = fabsf(it.x - x) < rs && fabsf(it.y - y) < rs;   // GetFeaturesInArea, Frame.cc:627-640
+                if (ok && check_levels) {
+                    const int oct = (int)((meta >> 16) & 0xF);
+                    ok = !(oct < q.min_level) && !(q.max_level >= 0 && oct > q.max_level);
+                }
+            }
+            const unsigned long long have = __builtin_amdgcn_ballot_w64(ok);
+            if (PASS == 1 && ok) {
+                const int i = min((int)(meta & 0xFFFF), n - 1);
+                const uint4* dk = reinterpret_cast<const uint4*>(a.desc + (long long)i * 32);
+                const uint4 b0 = dk[0], b1 = dk[1];
+                const float ur = a.u_right ? a.u_right[i] : -1.0f;
+                const bool gated = ur > 0 && fabsf(q.ur - ur) > rs;   // ORBmatcher.h:118-123
+                const unsigned dist = (unsigned)(__popc(a0.x ^ b0.x) + __popc(a0.y ^ b0.y) + __popc(a0.z ^ b0.z) + __popc(a0.w ^ b0.w) +
+                                                 __popc(a1.x ^ b1.x) + __popc(a1.y ^ b1.y) + __popc(a1.z ^ b1.z) + __popc(a1.w ^ b1.w));
+                const unsigned entry = (meta & 0xFFFFFu) | (dist << 20) | (gated ? 0x80000000u : 0u);
+                const unsigned order = (((meta >> 20) & 63u) << 22) | ((meta >> 26) << 16) | (meta & 0xFFFFu);   // grid column, grid row, index
+                const unsigned long long key = ((unsigned long long)order << 32) | entry;
+                const int pos = total + __popcll(have & ((1ull << lane) - 1));
+                if (pos < T) {
+                    if (T <= 64) s_keys[wave][pos] = key;
+                    else tmp[base + pos] = key;
+                }
+            }
+            total += __popcll(have);
+        }
+    }
+    if (PASS == 0) {
+        if (lane == 0 && iq < a.m) start[iq] = total;
+        return;
+    }
+    __syncthreads();
+    if (!scan) return;
+    if (T <= 64) {
+        const unsigned long long key = lane < T ? s_keys[wave][lane] : ~0ull;
+        int rank = 0;
+        for (int t = 0; t < T; t++) rank += s_keys[wave][t] < key ? 1 : 0;
+        if (lane < T) {
+            cand[base + rank] = (unsigned)key;
+            if (h_cand) h_cand[base + rank] = (unsigned)key;
+        }
+    } else {
+        __threadfence();   // the wave's own keys, written above through the vector memory path, read back by other lanes
+        for (int t = lane; t < T; t += 64) {
+            const unsigned long long key = __hip_atomic_load(&tmp[base + t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            int rank = 0;
+            for (int u = 0; u < T; u++) rank += __hip_atomic_load(&tmp[base + u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < key ? 1 : 0;
+            cand[base + rank] = (unsigned)key;
+            if (h_cand) h_cand[base + rank] = (unsigned)key;
+        }
+    }
+}
+
+// counts [m] -> offsets [m + 1] in place (one workgroup; m <= a few ten thousand), mirrored into the caller-side pinned block
+__global__ __launch_bounds__(1024) void k_proj_cand_scan(int* start, int m, int* h_start)
+{
+    __shared__ int s_part[16];
+    const int tid = threadIdx.x;
+    const int chunk = (m + 1023) / 1024;
+    const int b = min(m, tid * chunk), e = min(m, b + chunk);
+    int sum = 0;
+    for (int i = b; i < e; i++) sum += start[i];
+    int tot = 0;
+    const int incl = st_block_incl_scan(sum, s_part, &tot);
+    int run = incl - sum;
+    for (int i = b; i < e; i++) {
+        const int cnt = start[i];
+        start[i] = run;
+        if (h_start) h_start[i] = run;
+        run += cnt;
+    }
+    if (tid == 0) {
+        start[m] = tot;
+        if (h_start) h_start[m] = tot;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------------------
 #define PTRY(c, expr)                                                                             \
@@ -1056,6 +1196,68 @@ static int pj_launch(gfo_ctx* c, const ProjB& a, int frames, int n_max)
     return GFO_OK;
 }
 
+// Stages the inputs of a host-array call: the arrays are packed into the pinned mirror of the scratch layout and cross in one copy
+// (or inside the grid launch, ProjB::cp_*), the work buffers are reserved, and `a` describes frame, queries and scratch -- everything
+// but the mode of the search.
+static int pj_stage(gfo_ctx* c, GfoXfer& x, const gfo_keypoint* kp_un, const uint8_t* desc, const float* u_right, const float* kp_angle, int n,
+                    const gfo_frame_bounds* fb, const gfo_proj_query* queries, const uint8_t* q_desc, int m, const uint8_t* kp_taken, ProjB& a)
+{
+    PTRY(c, hipSetDevice(c->device));
+    size_t off = 0;
+    auto take = [&](size_t bytes) { size_t o = off; off = al256(off + bytes); return o; };
+    const size_t o_kp = take(sizeof(gfo_keypoint) * n), o_desc = take(32 * (size_t)n), o_ur = take(4 * (size_t)n),
+                 o_tk = take(n), o_ang = take(4 * (size_t)n), o_q = take(sizeof(gfo_proj_query) * m),
+                 o_mpd = take(32 * (size_t)m);
+    if (off > c->scratch_bytes) {
+        (void)hipStreamSynchronize(c->stream);
+        if (c->d_scratch) (void)hipFree(c->d_scratch);
+        c->d_scratch = nullptr;
+        c->scratch_bytes = 0;
+        PTRY(c, hipMalloc(&c->d_scratch, off + off / 2));   // headroom: the next, slightly larger frame does not reallocate
+        c->scratch_bytes = off + off / 2;
+    }
+    if (int rc = pj_reserve(c, 1, m + m / 2, n + n / 2)) return rc;
+    uint8_t* S = (uint8_t*)c->d_scratch;
+    hipStream_t st = c->stream;
+    // the seven input arrays are packed into the pinned mirror of the scratch layout and cross in one copy: seven pageable
+    // hipMemcpyAsync calls cost ~95 us of the call's 190 us (profiles/proj_call_latency_r05.txt)
+    if (int rc = x.in(off)) return rc;
+    x.put(o_kp, kp_un, sizeof(gfo_keypoint) * n);
+    x.put(o_desc, desc, 32 * (size_t)n);
+    if (u_right) x.put(o_ur, u_right, 4 * (size_t)n);
+    if (kp_taken) x.put(o_tk, kp_taken, n);
+    if (kp_angle) x.put(o_ang, kp_angle, 4 * (size_t)n);
+    x.put(o_q, queries, sizeof(gfo_proj_query) * m);
+    x.put(o_mpd, q_desc, 32 * (size_t)m);
+    // up to 1 MB the inputs travel inside the grid launch (ProjB::cp_*); larger calls take the copy engine first
+    static const long fused_max = getenv("GFO_MATCHER_UPLOAD_KERNEL_MAX") ? atol(getenv("GFO_MATCHER_UPLOAD_KERNEL_MAX")) : (1L << 20);
+    static const bool fuse_ok = !(getenv("GFO_PROJ_FUSED_UPLOAD") && atoi(getenv("GFO_PROJ_FUSED_UPLOAD")) == 0);
+    const bool fused = fuse_ok && (long)off <= fused_max;
+    if (!fused) PTRY(c, x.up(S, off, st));
+    a = ProjB{};
+    if (fused) {
+        a.cp_src = (const uint4*)x.H; a.cp_dst = (uint4*)S; a.cp_n16 = (int)(off / 16);
+        a.kp_grid = (const gfo_keypoint*)(x.H + o_kp);
+    }
+    a.kp = (const gfo_keypoint*)(S + o_kp);
+    a.desc = S + o_desc;
+    a.u_right = u_right ? (const float*)(S + o_ur) : nullptr;
+    a.taken0 = kp_taken ? S + o_tk : nullptr;
+    a.kp_angle = kp_angle ? (const float*)(S + o_ang) : nullptr;
+    a.n_dev = nullptr; a.n_host = n;
+    a.fb = *fb;
+    a.inv_w = (float)GRID_COLS / (fb->max_x - fb->min_x);  // Frame.cc:129-130
+    a.inv_h = (float)GRID_ROWS / (fb->max_y - fb->min_y);
+    a.sinv_w = (float)SG_COLS / (fb->max_x - fb->min_x);
+    a.sinv_h = (float)SG_ROWS / (fb->max_y - fb->min_y);
+    a.form = 0;
+    a.q = S + o_q;
+    a.q_desc = S + o_mpd;
+    a.m = m;
+    pj_bind(c, &a);
+    return GFO_OK;
+}
+
 // out_point (optional, [m]): the per-point outcomes of gfo_search_by_projection_points
 static int pj_queries(gfo_ctx* c, const gfo_keypoint* kp_un, const uint8_t* desc, const float* u_right, const float* kp_angle, int n,
                       const gfo_frame_bounds* fb, const gfo_proj_query* queries, const uint8_t* q_desc, int m, const gfo_proj_mode* mode,
@@ -1083,65 +1285,15 @@ static int pj_queries(gfo_ctx* c, const gfo_keypoint* kp_un, const uint8_t* desc
     for (int i = 0; i < n; i++) { out_mp[i] = -1; out_score[i] = 0; }
     if (out_point) for (int i = 0; i < m; i++) out_point[i] = PJ_PT_NONE;
     if (n == 0 || m == 0) return GFO_OK;
-    PTRY(c, hipSetDevice(c->device));
-    size_t off = 0;
-    auto take = [&](size_t bytes) { size_t o = off; off = al256(off + bytes); return o; };
-    const size_t o_kp = take(sizeof(gfo_keypoint) * n), o_desc = take(32 * (size_t)n), o_ur = take(4 * (size_t)n),
-                 o_tk = take(n), o_ang = take(4 * (size_t)n), o_q = take(sizeof(gfo_proj_query) * m),
-                 o_mpd = take(32 * (size_t)m);
-    if (off > c->scratch_bytes) {
-        (void)hipStreamSynchronize(c->stream);
-        if (c->d_scratch) (void)hipFree(c->d_scratch);
-        c->d_scratch = nullptr;
-        c->scratch_bytes = 0;
-        PTRY(c, hipMalloc(&c->d_scratch, off + off / 2));   // headroom: the next, slightly larger frame does not reallocate
-        c->scratch_bytes = off + off / 2;
-    }
-    if (int rc = pj_reserve(c, 1, m + m / 2, n + n / 2)) return rc;
-    uint8_t* S = (uint8_t*)c->d_scratch;
-    hipStream_t st = c->stream;
-    // the seven input arrays are packed into the pinned mirror of the scratch layout and cross in one copy: seven pageable
-    // hipMemcpyAsync calls cost ~95 us of the call's 190 us (profiles/proj_call_latency_r05.txt)
     GfoXfer x(c);
-    if (int rc = x.in(off)) return rc;
-    x.put(o_kp, kp_un, sizeof(gfo_keypoint) * n);
-    x.put(o_desc, desc, 32 * (size_t)n);
-    if (u_right) x.put(o_ur, u_right, 4 * (size_t)n);
-    if (kp_taken) x.put(o_tk, kp_taken, n);
-    if (kp_angle) x.put(o_ang, kp_angle, 4 * (size_t)n);
-    x.put(o_q, queries, sizeof(gfo_proj_query) * m);
-    x.put(o_mpd, q_desc, 32 * (size_t)m);
-    // up to 1 MB the inputs travel inside the grid launch (ProjB::cp_*); larger calls take the copy engine first
-    static const long fused_max = getenv("GFO_MATCHER_UPLOAD_KERNEL_MAX") ? atol(getenv("GFO_MATCHER_UPLOAD_KERNEL_MAX")) : (1L << 20);
-    static const bool fuse_ok = !(getenv("GFO_PROJ_FUSED_UPLOAD") && atoi(getenv("GFO_PROJ_FUSED_UPLOAD")) == 0);
-    const bool fused = fuse_ok && (long)off <= fused_max;
-    if (!fused) PTRY(c, x.up(S, off, st));
     ProjB a{};
-    if (fused) {
-        a.cp_src = (const uint4*)x.H; a.cp_dst = (uint4*)S; a.cp_n16 = (int)(off / 16);
-        a.kp_grid = (const gfo_keypoint*)(x.H + o_kp);
-    }
-    a.kp = (const gfo_keypoint*)(S + o_kp);
-    a.desc = S + o_desc;
-    a.u_right = u_right ? (const float*)(S + o_ur) : nullptr;
-    a.taken0 = kp_taken ? S + o_tk : nullptr;
-    a.kp_angle = kp_angle ? (const float*)(S + o_ang) : nullptr;
-    a.n_dev = nullptr; a.n_host = n;
-    a.fb = *fb;
-    a.inv_w = (float)GRID_COLS / (fb->max_x - fb->min_x);  // Frame.cc:129-130
-    a.inv_h = (float)GRID_ROWS / (fb->max_y - fb->min_y);
-    a.sinv_w = (float)SG_COLS / (fb->max_x - fb->min_x);
-    a.sinv_h = (float)SG_ROWS / (fb->max_y - fb->min_y);
-    a.form = 0;
-    a.q = S + o_q;
-    a.q_desc = S + o_mpd;
-    a.m = m;
+    if (int rc = pj_stage(c, x, kp_un, desc, u_right, kp_angle, n, fb, queries, q_desc, m, kp_taken, a)) return rc;
+    hipStream_t st = c->stream;
     a.use_ratio = mode->use_ratio;
     a.nn_ratio = mode->nn_ratio;
     a.th_dist = mode->th_dist;
     a.check_ori = mode->check_orientation;
     a.max_matches = mode->max_matches > 0 ? mode->max_matches : 0;
-    pj_bind(c, &a);
     // the resolve kernel writes counters, out_mp and out_score into the pinned block itself (ProjB::h_*): no copy back
     const size_t o_hm = 256, o_hs = o_hm + al256(4 * (size_t)n), o_hq = o_hs + al256(4 * (size_t)n);
     if (int rc = x.out(o_hq + (out_point ? 4 * (size_t)m : 0))) return rc;
@@ -1186,15 +1338,8 @@ extern "C" int gfo_search_by_projection_queries(gfo_ctx* c, const gfo_keypoint* 
 
 // ORBmatcher::SearchByProjection(Frame&, const vector<MapPoint*>&, th): every map point becomes a query with
 // r = RadiusByViewingCos(viewCos) (* th), window r * scale[level], levels [level-1, level] (ORBmatcher.cc:171-180).
-static int pj_map_points(gfo_ctx* c, const gfo_keypoint* kp_un, const uint8_t* desc, const float* u_right,
-                         int n, const float* sf, int nlevels, const gfo_frame_bounds* fb,
-                         const gfo_map_point* mps, const uint8_t* mp_desc, int m, float th, float nn_ratio,
-                         const uint8_t* kp_taken, int32_t* out_mp, int32_t* out_score, int* nmatches, int32_t* out_point)
+static void pj_queries_of_map_points(const gfo_map_point* mps, int m, const float* sf, int nlevels, float th, gfo_proj_query* q)
 {
-    if (!c) return GFO_ERR_INVALID;
-    if (!sf || nlevels < 1 || nlevels > GFO_MAX_LEVELS || m < 0 || (m > 0 && !mps))
-        return pj_fail(c, GFO_ERR_INVALID, "gfo_search_by_projection: bad argument");
-    std::vector<gfo_proj_query> q((size_t)(m > 0 ? m : 1));
     const bool bFactor = th != 1.0f;
     for (int i = 0; i < m; i++) {
         const gfo_map_point& p = mps[i];
@@ -1211,6 +1356,18 @@ static int pj_map_points(gfo_ctx* c, const gfo_keypoint* kp_un, const uint8_t* d
         d.angle = 0.f;
         d.flags = (((p.flags & 1) && !(p.flags & 2) && lvl >= 0 && lvl < nlevels) ? 1 : 0) | (p.flags & 4);
     }
+}
+
+static int pj_map_points(gfo_ctx* c, const gfo_keypoint* kp_un, const uint8_t* desc, const float* u_right,
+                         int n, const float* sf, int nlevels, const gfo_frame_bounds* fb,
+                         const gfo_map_point* mps, const uint8_t* mp_desc, int m, float th, float nn_ratio,
+                         const uint8_t* kp_taken, int32_t* out_mp, int32_t* out_score, int* nmatches, int32_t* out_point)
+{
+    if (!c) return GFO_ERR_INVALID;
+    if (!sf || nlevels < 1 || nlevels > GFO_MAX_LEVELS || m < 0 || (m > 0 && !mps))
+        return pj_fail(c, GFO_ERR_INVALID, "gfo_search_by_projection: bad argument");
+    std::vector<gfo_proj_query> q((size_t)(m > 0 ? m : 1));
+    pj_queries_of_map_points(mps, m, sf, nlevels, th, q.data());
     gfo_proj_mode mode = {1, nn_ratio, TH_HIGH, 0, 0};
     return pj_queries(c, kp_un, desc, u_right, nullptr, n, fb, q.data(), mp_desc, m, &mode, kp_taken, out_mp, out_score, nmatches, out_point);
 }
@@ -1258,6 +1415,113 @@ extern "C" int gfo_projection_points_prefix(const int32_t* out_point, int m, int
     }
     if (nmatches) *nmatches = cnt;
     return GFO_OK;
+}
+
+// ORBmatcher::GetCandidates for all of vpMapPoints (include/ORBmatcher.h:152-172) + the static half of MatchCandidates (:176-250)
+extern "C" int gfo_projection_candidates(gfo_ctx* c, const gfo_keypoint* kp_un, const uint8_t* desc, const float* u_right, int n,
+                                         const float* sf, int nlevels, const gfo_frame_bounds* fb, const gfo_map_point* mps,
+                                         const uint8_t* mp_desc, int m, float th, int32_t* cand_start, uint32_t* cand, int cap, int* total)
+{
+    if (!c) return GFO_ERR_INVALID;
+    if (!sf || nlevels < 1 || nlevels > GFO_MAX_LEVELS || !fb || !cand_start || !total || n < 0 || m < 0 || cap < 0 || (cap > 0 && !cand) ||
+        (n > 0 && (!kp_un || !desc)) || (m > 0 && (!mps || !mp_desc)))
+        return pj_fail(c, GFO_ERR_INVALID, "gfo_projection_candidates: bad argument");
+    if (n > 65535) return pj_fail(c, GFO_ERR_INVALID, "gfo_projection_candidates: more than 65535 keypoints");
+    if (!(fb->max_x > fb->min_x) || !(fb->max_y > fb->min_y)) return pj_fail(c, GFO_ERR_INVALID, "gfo_projection_candidates: empty frame bounds");
+    for (int i = 0; i < n; i++)
+        if (kp_un[i].octave < 0 || kp_un[i].octave >= GFO_MAX_LEVELS) return pj_fail(c, GFO_ERR_INVALID, "gfo_projection_candidates: keypoint octave outside 0..15");
+    *total = 0;
+    for (int i = 0; i <= m; i++) cand_start[i] = 0;
+    if (n == 0 || m == 0) return GFO_OK;
+    std::vector<gfo_proj_query> q((size_t)m);
+    pj_queries_of_map_points(mps, m, sf, nlevels, th, q.data());
+    GfoXfer x(c);
+    ProjB a{};
+    if (int rc = pj_stage(c, x, kp_un, desc, u_right, nullptr, n, fb, q.data(), mp_desc, m, nullptr, a)) return rc;
+    hipStream_t st = c->stream;
+    // offsets [m + 1] | entries [cap] | unsorted keys [cap] (only the points with more than 64 candidates use them)
+    const size_t o_st = 0, o_cd = al256(4 * ((size_t)m + 1)), o_tmp = o_cd + al256(4 * (size_t)cap), need = o_tmp + 8 * (size_t)cap + 256;
+    if (need > c->pj_cand_bytes) {
+        PTRY(c, hipStreamSynchronize(st));
+        if (c->d_pj_cand) (void)hipFree(c->d_pj_cand);
+        c->d_pj_cand = nullptr;
+        c->pj_cand_bytes = 0;
+        PTRY(c, hipMalloc(&c->d_pj_cand, need + need / 2));
+        c->pj_cand_bytes = need + need / 2;
+    }
+    uint8_t* D = (uint8_t*)c->d_pj_cand;
+    int* d_start = (int*)(D + o_st);
+    unsigned* d_cand = (unsigned*)(D + o_cd);
+    unsigned long long* d_tmp = (unsigned long long*)(D + o_tmp);
+    const size_t o_hc = al256(4 * ((size_t)m + 1));
+    if (int rc = x.out(o_hc + 4 * (size_t)cap)) return rc;
+    const bool direct = gfo_matcher_host_writes();
+    int* h_start = direct ? (int*)x.HO : nullptr;
+    unsigned* h_cand = direct ? (unsigned*)(x.HO + o_hc) : nullptr;
+    gfo_prof_begin(c, ST_PROJECT);
+    {
+        ProjB g = a;
+        g.grid_frames = 1;
+        const int copy_blocks = a.cp_n16 > 0 ? (a.cp_n16 + 1023) / 1024 : 0;
+        GFO_LAUNCH(c, k_proj_grid, dim3(1 + copy_blocks), dim3(1024), 0, st, g);
+    }
+    const int blocks = (m + PJ_WAVES - 1) / PJ_WAVES;
+    GFO_LAUNCH(c, k_proj_candidates<0>, dim3(blocks), dim3(64 * PJ_WAVES), 0, st, a, d_start, d_cand, h_cand, d_tmp, cap);
+    GFO_LAUNCH(c, k_proj_cand_scan, dim3(1), dim3(1024), 0, st, d_start, m, h_start);
+    if (cap > 0) GFO_LAUNCH(c, k_proj_candidates<1>, dim3(blocks), dim3(64 * PJ_WAVES), 0, st, a, d_start, d_cand, h_cand, d_tmp, cap);
+    gfo_prof_end(c);
+    if (int lrc = gfo_take_launch_err(c)) return lrc;
+    PTRY(c, hipGetLastError());
+    if (!direct) PTRY(c, hipMemcpyAsync(x.HO, d_start, 4 * ((size_t)m + 1), hipMemcpyDeviceToHost, st));
+    PTRY(c, hipStreamSynchronize(st));
+    memcpy(cand_start, x.HO, 4 * ((size_t)m + 1));
+    const int tot = cand_start[m];
+    *total = tot;
+    c->have_projection = false;
+    if (tot < 0) return pj_fail(c, GFO_ERR_STATE, "gfo_projection_candidates: offsets overflowed");
+    if (tot > cap) {
+        c->err = "gfo_projection_candidates: the table has " + std::to_string(tot) + " entries, the caller's array " + std::to_string(cap);
+        return GFO_ERR_CAPACITY;
+    }
+    if (tot > 0) {
+        if (!direct) {
+            PTRY(c, hipMemcpyAsync(x.HO + o_hc, d_cand, 4 * (size_t)tot, hipMemcpyDeviceToHost, st));
+            PTRY(c, hipStreamSynchronize(st));
+        }
+        memcpy(cand, x.HO + o_hc, 4 * (size_t)tot);
+    }
+    return GFO_OK;
+}
+
+// ORBmatcher::MatchCandidates (include/ORBmatcher.h:176-250) = the candidate loop of SearchByProjection_OnePoint (:101-149) on one
+// point's entries of the table: what is left once window, level, gate and distance are known -- skip the slots a point with
+// observations holds NOW (:113-115), best and second best on strict `<` in the list's order, TH_HIGH, the ratio test between
+// candidates of one level.  Host bookkeeping (a few compares per candidate; no descriptor is read): the caller interleaves it
+// with its own selection loop (Observability::runActiveMapMatching) and updates slot_taken after each match.
+extern "C" int gfo_match_candidates(const uint32_t* cand, int ncand, const uint8_t* slot_taken, float nn_ratio, int* best_dist)
+{
+    int bestDist = 256, bestLevel = -1, bestDist2 = 256, bestLevel2 = -1, bestIdx = -1;
+    for (int k = 0; k < ncand; k++) {
+        const uint32_t e = cand[k];
+        const int idx = (int)(e & 0xFFFFu);
+        if (slot_taken && slot_taken[idx]) continue;
+        if (e & 0x80000000u) continue;
+        const int dist = (int)((e >> 20) & 0x1FFu), level = (int)((e >> 16) & 0xFu);
+        if (dist < bestDist) {
+            bestDist2 = bestDist; bestDist = dist;
+            bestLevel2 = bestLevel; bestLevel = level;
+            bestIdx = idx;
+        } else if (dist < bestDist2) {
+            bestLevel2 = level;
+            bestDist2 = dist;
+        }
+    }
+    if (best_dist) *best_dist = bestDist;
+    if (bestDist <= TH_HIGH) {
+        if (bestLevel == bestLevel2 && (float)bestDist > nn_ratio * (float)bestDist2) return GFO_POINT_RATIO;
+        return bestIdx;
+    }
+    return ncand > 0 ? GFO_POINT_FAR : GFO_POINT_NONE;
 }
 
 // ---- the resident local map and the batched, device-chained search --------------------------------------------
@@ -1390,4 +1654,5 @@ void gfo_kernels_project(std::vector<const void*>& v)
     v.push_back((const void*)k_proj_grid); v.push_back((const void*)k_proj_round0<true>); v.push_back((const void*)k_proj_round0<false>);
     v.push_back((const void*)k_proj_round0_wave);
     v.push_back((const void*)k_proj_resolve<true>); v.push_back((const void*)k_proj_resolve<false>);
+    v.push_back((const void*)k_proj_candidates<0>); v.push_back((const void*)k_proj_candidates<1>); v.push_back((const void*)k_proj_cand_scan);
 }

@@ -143,6 +143,41 @@ class ORBmatcher:
             raise ValueError("gfo_projection_points_prefix: %d" % rc)
         return nm.value, out_mp[:n], out_sc[:n]
 
+    def GetCandidates(self, keys_un, desc, u_right, scale_factors, bounds, map_points, mp_desc, th=1.0, cap=None):
+        """ORBmatcher::GetCandidates for every map point (include/ORBmatcher.h:152-172) with each candidate's distance and mvuRight
+        gate (gfo_projection_candidates).  Returns (cand_start[m + 1], cand[total]); an entry is keypoint | octave << 16 |
+        distance << 20 | gated << 31, in GetFeaturesInArea's order."""
+        kp = np.ascontiguousarray(keys_un, KEYPOINT_DTYPE)
+        desc = np.ascontiguousarray(desc, np.uint8)
+        mps = np.ascontiguousarray(map_points, MAP_POINT_DTYPE)
+        mpd = np.ascontiguousarray(mp_desc, np.uint8)
+        sf = np.ascontiguousarray(scale_factors, np.float32)
+        n, m = len(kp), len(mps)
+        if u_right is not None:
+            u_right = np.ascontiguousarray(u_right, np.float32)
+        fb = FrameBoundsC(*bounds)
+        start = np.zeros(m + 1, np.int32)
+        cap = 32 * m if cap is None else int(cap)
+        tot = C.c_int()
+        while True:
+            cand = np.zeros(max(cap, 1), np.uint32)
+            rc = self._L.gfo_projection_candidates(self._ctx, ptr(kp), ptr(desc), ptr(u_right), n, ptr(sf), len(sf), C.byref(fb), ptr(mps),
+                                                   ptr(mpd), m, th, ptr(start), ptr(cand), cap, C.byref(tot))
+            if rc == -3 and tot.value > cap:     # GFO_ERR_CAPACITY: the table is larger than the guess
+                cap = tot.value
+                continue
+            check(self._L, self._ctx, rc)
+            return start, cand[:tot.value]
+
+    def MatchCandidates(self, cand, slot_taken):
+        """ORBmatcher::MatchCandidates / the candidate loop of SearchByProjection_OnePoint on one point's entries (gfo_match_candidates).
+        Returns (keypoint or POINT_*, best distance)."""
+        cand = np.ascontiguousarray(cand, np.uint32)
+        tk = None if slot_taken is None else np.ascontiguousarray(slot_taken, np.uint8)
+        d = C.c_int()
+        r = self._L.gfo_match_candidates(ptr(cand), len(cand), ptr(tk), self.mfNNratio, C.byref(d))
+        return r, d.value
+
     # ---- device-resident chain: extract_batch_device -> [stereo_match_batch] -> search_by_projection_batch ----
     def map_upload(self, mp_desc):
         """Descriptors of the local map (MapPoint::GetDescriptor(), vector order); resident until replaced."""

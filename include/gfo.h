@@ -311,6 +311,31 @@ int gfo_search_by_projection_points(gfo_ctx* ctx, const gfo_keypoint* kp_un, con
 int gfo_projection_points_prefix(const int32_t* out_point, int m, int prefix, int n, int32_t* out_mp,
                                  int32_t* out_score, int* nmatches);
 
+/* ORBmatcher::GetCandidates (include/ORBmatcher.h:152-172) for EVERY map point in one call -- pMP->mvMatchCandidates =
+ * F.GetFeaturesInArea(mTrackProjX, mTrackProjY, r * mvScaleFactors[level], level - 1, level) -- together with the two things
+ * ORBmatcher::MatchCandidates (:176-250) and SearchByProjection_OnePoint (:71-150) compute per candidate that do not depend on what the
+ * frame's slots hold at the moment of the call: the mvuRight gate (:118-123) and the descriptor distance (:127).  What remains of
+ * those two functions is gfo_match_candidates: a few compares per candidate, interleaved by the caller with its own selection loop
+ * (Observability::runActiveMapMatching picks the next point from the outcome of the previous ones, src/Observability.cc:900-1100 --
+ * an order no batch can know in advance).
+ *   cand_start[m + 1] : CSR offsets; point p's candidates are cand[cand_start[p] .. cand_start[p + 1])
+ *   cand[]            : in GetFeaturesInArea's order (grid column, grid row, keypoint index):
+ *                       bits 0-15 keypoint index | 16-19 octave | 20-28 descriptor distance 0..256 | bit 31 the mvuRight gate rejects it
+ *                       (such an entry is part of mvMatchCandidates -- its size() is the cost term of INFORMATION_EFFICIENCY_SCORE --
+ *                       and is skipped by the match)
+ *   cap               : entries the caller's cand[] holds.  *total = entries of the table; more than cap: GFO_ERR_CAPACITY, cand_start is
+ *                       valid, cand[] is not (call again with room for *total; cap = 0 just asks for the size)
+ * A point that is not in view, bad, or whose level lies outside the table has no candidates.
+ * gfo_match_candidates(cand + cand_start[p], cand_start[p + 1] - cand_start[p], slot_taken, nn_ratio, &dist): slot_taken[i] = 1 where
+ * F.mvpMapPoints[i] is set with Observations() > 0 NOW (may be NULL: nothing taken).  Returns the keypoint index the reference's
+ * function returns (the caller then stores the point and its *best_dist in the slot, :143-146, and marks slot_taken if the point has
+ * observations), or GFO_POINT_NONE / _RATIO / _FAR.  Host arithmetic only; no device call, no descriptor read. */
+int gfo_projection_candidates(gfo_ctx* ctx, const gfo_keypoint* kp_un, const uint8_t* desc, const float* u_right, int n,
+                              const float* scale_factors, int nlevels, const gfo_frame_bounds* bounds,
+                              const gfo_map_point* mps, const uint8_t* mp_desc, int m, float th,
+                              int32_t* cand_start, uint32_t* cand, int cap, int* total);
+int gfo_match_candidates(const uint32_t* cand, int ncand, const uint8_t* slot_taken, float nn_ratio, int* best_dist);
+
 /* Device-resident, batched form of SearchByProjection(Frame&, vector<MapPoint*>&, th) -- the chain
  *   gfo_extract_batch_device -> [gfo_stereo_match_batch] -> gfo_search_by_projection_batch
  * never leaves the GPU: keypoints, descriptors (and mvuRight) are read where the extractor / stereo matcher

@@ -13,6 +13,7 @@
 //   G. the online form of the association, ComputeStereoMatches_Undistorted(true): no outlier cut (Frame.cc:1290);
 //   E. ORBmatcher::SearchByProjection(Frame&, vector<MapPoint*>&, th) (ORBmatcher.cc:155-241);
 //   E2. ORBmatcher::SearchByProjection_Budget(Frame&, vector<MapPoint*>&, th, time_constr) (ORBmatcher.cc:45-153), the good-feature build's;
+//   E3. ORBmatcher::SearchByProjection_OnePoint (include/ORBmatcher.h:71-150) pick by pick, through adapter/good_feature_matching_gfo.h;
 //   F. ORBmatcher::SearchByProjection(CurrentFrame, LastFrame, th, bMono, numVisible) (ORBmatcher.cc:1440-1593), including the
 //      host-side projection the adapter keeps (:1451-1502);
 //   H. ORBmatcher::SearchByProjection(CurrentFrame, KeyFrame*, sAlreadyFound, th, ORBdist) (ORBmatcher.cc:1595-1721), relocalisation's;
@@ -44,6 +45,7 @@
 #include <vector>
 
 #include "gfo.h"
+#include "good_feature_matching_gfo.h"
 
 namespace ORB_SLAM2
 {
@@ -608,6 +610,42 @@ int main(int argc, char** argv)
                 F.mvpMapPoints = before;
                 report("E2_SearchByProjection_Budget_us", median_us(20, [&]() { F.mvpMapPoints = before; }, [&]() { matcher.SearchByProjection_Budget(F, map, 0.5f, 1.0); }));
                 F.mvpMapPoints = after;
+            }
+            // E3. The good-feature selection loop's matcher, SearchByProjection_OnePoint (include/ORBmatcher.h:71-150), in an order the Python
+            //     side made up (a shuffle: Observability::runActiveMapMatching's order depends on the outcomes), through
+            //     adapter/good_feature_matching_gfo.h: one device call for the candidate table, then OnePoint() per pick.  One entry of the
+            //     vector is NULL, as the local map's may be (Observability.cc:872).
+            {
+                std::vector<uint8_t> ord = slurp(g_in + "/E3_order.bin", false);
+                const int K = (int)(ord.size() / 4);
+                const int32_t* order = reinterpret_cast<const int32_t*>(ord.data());
+                if (K > 0) {
+                    std::vector<MapPoint*> map3 = map;
+                    map3[7] = NULL;
+                    F.mvpMapPoints = before;
+                    std::fill(F.mvpMatchScore.begin(), F.mvpMatchScore.end(), 0);
+                    GfoCandidateTable table(F, map3, 1.0f, 0.8f);
+                    CHECK(table.ok(), "E3: the candidate table was refused");
+                    std::vector<int32_t> res(K), ncand(M), slot(F.N, -1);
+                    for (int k = 0; k < K; k++) res[k] = table.OnePoint(F, (size_t)order[k]);
+                    for (int j = 0; j < M; j++) ncand[j] = (int32_t)table.Candidates((size_t)j);
+                    for (int i = 0; i < F.N; i++) {
+                        if (F.mvpMapPoints[i] == before[i]) continue;
+                        slot[i] = -3;
+                        for (int j = 0; j < M; j++) if (map[j] == F.mvpMapPoints[i]) { slot[i] = j; break; }
+                    }
+                    dump("E3_results.bin", res.data(), res.size() * 4);
+                    dump("E3_ncand.bin", ncand.data(), ncand.size() * 4);
+                    dump("E3_out_mp.bin", slot.data(), slot.size() * 4);
+                    dump("E3_out_score.bin", F.mvpMatchScore.data(), F.mvpMatchScore.size() * 4);
+                    std::vector<size_t> lst;
+                    table.GetCandidates((size_t)order[0], lst);
+                    CHECK(lst.size() == table.Candidates((size_t)order[0]), "E3: GetCandidates gives %zu entries, Candidates %zu", lst.size(), table.Candidates((size_t)order[0]));
+                    report("E3_candidate_table_us", median_us(20, []() {}, [&]() { GfoCandidateTable t(F, map3, 1.0f, 0.8f); }));
+                    report("E3_OnePoint_picks", K);
+                    report("E3_all_OnePoint_picks_us", median_us(20, [&]() { F.mvpMapPoints = before; }, [&]() { for (int k = 0; k < K; k++) table.OnePoint(F, (size_t)order[k]); }));
+                    F.mvpMapPoints = after;
+                }
             }
             // ... and what the library call inside it costs on the same inputs, already flattened (a context of the harness's own):
             // the difference is the adapter's walk over the MapPoint objects through the reference's accessors

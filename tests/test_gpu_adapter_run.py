@@ -154,6 +154,14 @@ def run(tmp_path_factory, oracle, euroc_l, euroc_r):
     ref["E2"] = [oracle.search_by_projection_budget(kl, dl, st[1], sf, (0.0, 0.0, 752.0, 480.0), mps, mpd, 0.5, 0.8, (tk == 1).astype(np.uint8), trip)
                  for trip in (0, 1)]
 
+    # E3: SearchByProjection_OnePoint pick by pick in a made-up order (2000 of the 3000 points, shuffled; entry 7 of the vector is NULL)
+    order = rng.permutation(np.setdiff1d(np.arange(m), [7]))[:2000].astype(np.int32)
+    order.tofile(ind / "E3_order.bin")
+    pf = oracle.ProjectionFrame(kl, dl, st[1], sf, (0.0, 0.0, 752.0, 480.0), (tk == 1).astype(np.uint8))
+    ncand = np.array([0 if j == 7 else len(pf.candidates(mps[j], 1.0)) for j in range(m)], np.int32)
+    res = np.array([pf.one_point(mps[j], mpd[j], 1.0, 0.8, int(j))[0] for j in order], np.int32)
+    ref["E3"] = (order, res, ncand) + pf.state()
+
     # F: SearchByProjection(Cur = frame 1, Last = frame 0): the adapter projects on the host (ORBmatcher.cc:1451-1502), so this side
     # states the same float expressions independently
     kl0, dl0 = ref["frames"][0][0], ref["frames"][0][1]
@@ -550,6 +558,20 @@ def test_search_by_projection_budget_member(run):
         np.testing.assert_array_equal(_rd(run, f"E2_f{v:02d}_found.bin", np.int32), found)
         assert int(_rd(run, f"E2_f{v:02d}_nmatches.bin", np.int32)[0]) == nm
     assert run["E2"][0][0] > 200 and run["E2"][1][0] <= 1 and (run["E2"][1][3] == -4).sum() > 2900
+
+
+def test_one_point_matcher_of_the_good_feature_selection_loop(run):
+    """ORBmatcher::SearchByProjection_OnePoint (include/ORBmatcher.h:71-150), an inline member no link can swap, as
+    adapter/good_feature_matching_gfo.h offers it to Observability::runActiveMapMatching: the candidate table from ONE device call, then
+    2000 picks in an order made up on the Python side -- every pick's return value, the slots and scores the picks leave, and
+    mvMatchCandidates.size() of every point (GetCandidates, :152-172) against the oracle's literal statement."""
+    order, res, ncand, out_mp, out_sc = run["E3"]
+    np.testing.assert_array_equal(_rd(run, "E3_ncand.bin", np.int32), ncand)
+    np.testing.assert_array_equal(_rd(run, "E3_results.bin", np.int32), res)
+    np.testing.assert_array_equal(_rd(run, "E3_out_mp.bin", np.int32), out_mp)
+    sc = _rd(run, "E3_out_score.bin", np.int32)
+    np.testing.assert_array_equal(sc[out_mp >= 0], out_sc[out_mp >= 0])
+    assert (res >= 0).sum() > 150 and ncand.max() > 3
 
 
 def test_search_by_projection_last_frame_member(run):

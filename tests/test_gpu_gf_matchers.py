@@ -126,3 +126,124 @@ def test_points_edge_cases(ext, oracle):
     with pytest.raises(ValueError):
         mt.points_prefix(np.array([5 | (3 << 16)], np.int32), 1, 4)
     assert mt.points_prefix(np.array([2 | (3 << 16), -3, 2 | (9 << 16)], np.int32), 3, 4)[1].tolist() == [-1, -1, 2, -1]
+
+
+def _entries(cand):
+    return (cand & 0xFFFF).astype(np.int64), ((cand >> 16) & 0xF).astype(np.int64), ((cand >> 20) & 0x1FF).astype(np.int64), (cand >> 31).astype(bool)
+
+
+def _check_table(oracle, kl, dl, u, sf, mps, mpd, th, start, cand):
+    """Every list against ORBmatcher::GetCandidates as the oracle states it (order included); every entry's octave, distance and gate
+    against their definitions (numpy)."""
+    m = len(mps)
+    assert start[0] == 0 and (np.diff(start) >= 0).all() and start[m] == len(cand)
+    pf = oracle.ProjectionFrame(kl, dl, u, sf, gc.BOUNDS, None)
+    idx, octv, dist, gated = _entries(cand)
+    for p in range(m):
+        np.testing.assert_array_equal(idx[start[p]:start[p + 1]], pf.candidates(mps[p], th), err_msg=f"point {p}")
+    owner = np.repeat(np.arange(m), np.diff(start))
+    np.testing.assert_array_equal(octv, kl["octave"][idx])
+    x = np.bitwise_xor(mpd[owner], dl[idx])
+    np.testing.assert_array_equal(dist, np.unpackbits(x, axis=1).sum(axis=1))
+    r = np.where(mps["view_cos"].astype(np.float64) > 0.998, np.float32(2.5), np.float32(4.0)).astype(np.float32)
+    if th != 1.0:
+        r = (r * np.float32(th)).astype(np.float32)
+    rs = (r * sf[np.clip(mps["level"], 0, len(sf) - 1)]).astype(np.float32)
+    if u is None:
+        assert not gated.any()
+    else:
+        ur = u[idx]
+        want = (ur > 0) & (np.abs((mps["proj_xr"][owner] - ur).astype(np.float32)) > rs[owner])
+        np.testing.assert_array_equal(gated, want)
+
+
+@pytest.mark.parametrize("seed,m,th,sigma", [(1, 1500, 1.0, 3.0), (2, 4000, 0.5, 2.0), (3, 3000, 3.0, 3.0), (5, 6000, 5.0, 6.0)])
+def test_candidate_table_is_get_candidates_for_every_point(ext, oracle, seed, m, th, sigma):
+    import gf_orb_slam2_amd as G
+    kl, dl, u, _ = gc.frame(oracle)
+    sf = ext.GetScaleFactors()
+    mps, mpd, _ = gc.contended_map(oracle, kl, dl, seed, m, sigma)
+    mt = G.ORBmatcher(0.8, True, extractor=ext)
+    start, cand = mt.GetCandidates(kl, dl, u, sf, gc.BOUNDS, mps, mpd, th)
+    assert len(cand) > m // 4
+    _check_table(oracle, kl, dl, u, sf, mps, mpd, th, start, cand)
+
+
+def test_candidate_lists_longer_than_a_wavefront(ext, oracle):
+    """Four hundred keypoints inside one window: the lists that are ranked through device memory instead of LDS."""
+    import gf_orb_slam2_amd as G
+    kl, dl, u, _ = gc.frame(oracle)
+    kl = kl.copy()
+    rng = np.random.default_rng(8)
+    crowd = rng.choice(len(kl), 400, replace=False)
+    kl["x"][crowd] = 300 + rng.uniform(-12, 12, 400).astype(np.float32)
+    kl["y"][crowd] = 200 + rng.uniform(-12, 12, 400).astype(np.float32)
+    kl["octave"][crowd] = rng.integers(0, 2, 400)
+    sf = ext.GetScaleFactors()
+    mps, mpd, _ = gc.contended_map(oracle, kl, dl, 4, 600)
+    mps["proj_x"][:200] = 300 + rng.uniform(-6, 6, 200); mps["proj_y"][:200] = 200 + rng.uniform(-6, 6, 200)
+    mps["level"][:200] = rng.integers(0, 3, 200); mps["flags"][:200] = 5
+    mt = G.ORBmatcher(0.8, True, extractor=ext)
+    start, cand = mt.GetCandidates(kl, dl, u, sf, gc.BOUNDS, mps, mpd, 5.0)
+    assert np.diff(start).max() > 150
+    _check_table(oracle, kl, dl, u, sf, mps, mpd, 5.0, start, cand)
+
+
+@pytest.mark.parametrize("seed,m,th,ratio", [(1, 1500, 1.0, 0.8), (7, 5000, 3.0, 0.9)])
+def test_table_then_match_equals_one_point_in_any_order(ext, oracle, seed, m, th, ratio):
+    """The use the table is for: SearchByProjection_OnePoint called in an order nobody knows in advance (a shuffle stands for the greedy
+    selection of Observability::runActiveMapMatching).  Oracle: the literal function on a frame that carries its slots from call to
+    call.  Here: one device call for the table, then gfo_match_candidates per point with the caller keeping the slots."""
+    import gf_orb_slam2_amd as G
+    kl, dl, u, _ = gc.frame(oracle)
+    sf = ext.GetScaleFactors()
+    mps, mpd, taken = gc.contended_map(oracle, kl, dl, seed, m)
+    mt = G.ORBmatcher(ratio, True, extractor=ext)
+    start, cand = mt.GetCandidates(kl, dl, u, sf, gc.BOUNDS, mps, mpd, th)
+    pf = oracle.ProjectionFrame(kl, dl, u, sf, gc.BOUNDS, taken)
+    slot_taken = taken.copy()
+    slot_mp = np.full(len(kl), -1, np.int32); slot_sc = np.zeros(len(kl), np.int32)
+    why_code = {1: mt.POINT_RATIO, 2: mt.POINT_FAR, 3: mt.POINT_NONE}
+    nmatch = 0
+    for p in np.random.default_rng(seed).permutation(m):
+        ref, why = pf.one_point(mps[p], mpd[p], th, ratio, int(p))
+        got, d = mt.MatchCandidates(cand[start[p]:start[p + 1]], slot_taken)
+        if ref >= 0:
+            assert got == ref
+            slot_mp[got] = p; slot_sc[got] = d
+            slot_taken[got] = 1 if mps["flags"][p] & 4 else 0       # F.mvpMapPoints[bestIdx] = pMP: later points ask ITS Observations()
+            nmatch += 1
+        else:
+            assert got == why_code[why], (p, got, why)
+    assert nmatch > 200
+    st = pf.state()
+    np.testing.assert_array_equal(slot_mp, st[0])
+    np.testing.assert_array_equal(slot_sc[slot_mp >= 0], st[1][slot_mp >= 0])
+
+
+def test_candidate_table_capacity_and_edges(ext, oracle):
+    import ctypes as C
+    import gf_orb_slam2_amd as G
+    from gf_orb_slam2_amd._lib import ptr, FrameBoundsC
+    kl, dl, u, _ = gc.frame(oracle)
+    sf = ext.GetScaleFactors()
+    mps, mpd, _ = gc.contended_map(oracle, kl, dl, 1, 500)
+    mt = G.ORBmatcher(0.8, True, extractor=ext)
+    start, cand = mt.GetCandidates(kl, dl, u, sf, gc.BOUNDS, mps, mpd, 1.0)
+    start1, cand1 = mt.GetCandidates(kl, dl, u, sf, gc.BOUNDS, mps, mpd, 1.0, cap=1)      # first answer: GFO_ERR_CAPACITY and the size
+    np.testing.assert_array_equal(start, start1); np.testing.assert_array_equal(cand, cand1)
+    # the raw call: too small an array is refused with the size, offsets valid
+    fb = FrameBoundsC(*gc.BOUNDS)
+    st = np.zeros(len(mps) + 1, np.int32); small = np.zeros(8, np.uint32); tot = C.c_int()
+    kp = np.ascontiguousarray(kl); sfa = np.ascontiguousarray(sf, np.float32)
+    rc = mt._L.gfo_projection_candidates(mt._ctx, ptr(kp), ptr(dl), ptr(u), len(kl), ptr(sfa), len(sfa), C.byref(fb), ptr(mps), ptr(mpd),
+                                         len(mps), 1.0, ptr(st), ptr(small), 8, C.byref(tot))
+    assert rc == -3 and tot.value == len(cand)
+    np.testing.assert_array_equal(st, start)
+    # nothing to do
+    z = np.zeros(0, oracle.MAP_POINT_DTYPE)
+    s0, c0 = mt.GetCandidates(kl, dl, u, sf, gc.BOUNDS, z, np.zeros((0, 32), np.uint8), 1.0)
+    assert s0.tolist() == [0] and len(c0) == 0
+    s1, c1 = mt.GetCandidates(kl[:0], dl[:0], None, sf, gc.BOUNDS, mps, mpd, 1.0)
+    assert not s1.any() and len(c1) == 0
+    assert mt.MatchCandidates(np.zeros(0, np.uint32), None)[0] == mt.POINT_NONE
