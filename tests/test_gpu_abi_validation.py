@@ -285,6 +285,51 @@ def test_search_by_projection_refuses_malformed_arrays(env):
         np.testing.assert_array_equal(out_sc[ref[1] >= 0], ref[2][ref[1] >= 0])
 
 
+def test_good_feature_entry_points_refuse_the_same_malformed_arrays(env):
+    """gfo_search_by_projection_points and gfo_projection_candidates take the arrays of gfo_search_by_projection: the same damaged
+    inputs, refused the same way -- nothing written, the valid call afterwards equal to the oracle."""
+    O = env["oracle"]
+    L, FB = env["L"], env["lib"].FrameBoundsC
+    good = _proj_inputs(env)
+    ref = O.search_by_projection_budget(good["kp"], good["desc"], good["ur"], good["sf"], good["fb"], good["mps"], good["mpd"], good["th"], good["ratio"])
+    n, m = len(good["kp"]), len(good["mps"])
+
+    def points(a, out_mp, out_sc, out_pt, nm):
+        fb = FB(*a["fb"])
+        return L.gfo_search_by_projection_points(env["ctx"], _p(a["kp"]), _p(a["desc"]), _p(a["ur"]), a.get("n", len(a["kp"])), _p(a["sf"]),
+                                                 a.get("nlevels", len(a["sf"])), C.byref(fb), _p(a["mps"]), _p(a["mpd"]),
+                                                 a.get("m", 0 if a["mps"] is None else len(a["mps"])), C.c_float(a["th"]), C.c_float(a["ratio"]),
+                                                 None, _p(out_mp), _p(out_sc), _p(out_pt), C.byref(nm))
+
+    def table(a, start, cand, cap, tot):
+        fb = FB(*a["fb"])
+        return L.gfo_projection_candidates(env["ctx"], _p(a["kp"]), _p(a["desc"]), _p(a["ur"]), a.get("n", len(a["kp"])), _p(a["sf"]),
+                                           a.get("nlevels", len(a["sf"])), C.byref(fb), _p(a["mps"]), _p(a["mpd"]),
+                                           a.get("m", 0 if a["mps"] is None else len(a["mps"])), C.c_float(a["th"]), _p(start), _p(cand), cap, C.byref(tot))
+
+    cap = 64 * m
+    for what in PROJ_CASES + ["null out_point", "negative capacity", "null table"]:
+        a = _proj_inputs(env)
+        if what in PROJ_CASES:
+            _damage_proj(a, what)
+        out_mp, out_sc, out_pt, nm = np.full(n, SENT_I, np.int32), np.full(n, SENT_I, np.int32), np.full(m, SENT_I, np.int32), C.c_int(int(SENT_I))
+        if what not in ("negative capacity", "null table"):
+            rc = points(a, out_mp, out_sc, None if what == "null out_point" else out_pt, nm)
+            assert rc == GFO_ERR_INVALID, (what, rc)
+            assert (out_mp == SENT_I).all() and (out_sc == SENT_I).all() and (out_pt == SENT_I).all() and nm.value == int(SENT_I), what
+        start, cand, tot = np.full(m + 1, SENT_I, np.int32), np.full(cap, 0x5A5A5A5A, np.uint32), C.c_int(int(SENT_I))
+        if what != "null out_point":
+            rc = table(a, start, None if what == "null table" else cand, -1 if what == "negative capacity" else cap, tot)
+            assert rc == GFO_ERR_INVALID, (what, rc)
+            assert (start == SENT_I).all() and (cand == 0x5A5A5A5A).all() and tot.value == int(SENT_I), what
+        # a refused call leaves nothing behind
+        assert points(good, out_mp, out_sc, out_pt, nm) == 0, what
+        assert nm.value == ref[0]
+        np.testing.assert_array_equal(out_pt, ref[3]); np.testing.assert_array_equal(out_mp, ref[1])
+        assert table(good, start, cand, cap, tot) == 0, what
+        assert start[0] == 0 and start[m] == tot.value and 0 < tot.value <= cap
+
+
 def test_projection_points_outside_the_scale_table_are_skipped_not_indexed(env):
     """a map point whose predicted level lies outside the frame's scale table (ORBmatcher.cc:177-180 indexes mvScaleFactors unchecked):
     library and oracle skip it -- whatever the integer is, nothing is indexed with it"""
