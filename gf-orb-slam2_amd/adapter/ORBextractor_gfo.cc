@@ -70,6 +70,26 @@ struct AtExit {
 // call is inside the library (GfoUse there), released afterwards
 gfo_ctx* gfo_context_pin(const ORBextractor* e) { return g_tab.acquire(e); }
 void gfo_context_unpin(const ORBextractor* e, gfo_ctx* c) { if (c) g_tab.release(e, c); }
+// A context for a matcher call that has no Frame to take one from -- ORBmatcher::SearchByBoW between two KEYFRAMES runs in the loop-closing
+// thread, and a KeyFrame carries no extractor (include/KeyFrame.h): one context per calling thread, declared on its first use (it never
+// extracts: no arena is ever planned for it), pinned for the call like an extractor's, reclaimed when idle like any other.
+namespace
+{
+const void* thread_context_key()
+{
+    static thread_local char key;
+    static thread_local bool declared = false;
+    if (!declared) {
+        gfo_params prm;
+        prm.nfeatures = 1000; prm.scale_factor = 1.2f; prm.nlevels = 8; prm.ini_th_fast = 20; prm.min_th_fast = 7; prm.max_batch = 1;
+        g_tab.declare(&key, prm);
+        declared = true;
+    }
+    return &key;
+}
+}  // namespace
+gfo_ctx* gfo_context_pin_thread() { return g_tab.acquire(thread_context_key()); }
+void gfo_context_unpin_thread(gfo_ctx* c) { if (c) g_tab.release(thread_context_key(), c); }
 // several GPUs (GFO_DEVICES): the right extractor of a stereo rig follows its left one (gfo_context_table.h); the HIP ordinal an
 // extractor is placed on, and how many extractors have been moved so far
 bool gfo_context_colocate(const ORBextractor* follower, const ORBextractor* leader) { return g_tab.colocate(follower, leader); }

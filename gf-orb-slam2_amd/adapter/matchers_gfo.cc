@@ -11,6 +11,7 @@
 //   GFO_ADAPTER_PROJ_LAST     ORBmatcher::SearchByProjection(Cur, Last, th, bMono, nVisible)    src/ORBmatcher.cc:1440-1593
 //   GFO_ADAPTER_PROJ_KF       ORBmatcher::SearchByProjection(Cur, KF*, sAlreadyFound, th, dist) src/ORBmatcher.cc:1595-1721
 //   GFO_ADAPTER_BOW           ORBmatcher::SearchByBoW(KeyFrame*, Frame&, vector<MapPoint*>&)    src/ORBmatcher.cc:270-404
+//   GFO_ADAPTER_BOW_KF        ORBmatcher::SearchByBoW(KeyFrame*, KeyFrame*, vector<MapPoint*>&) src/ORBmatcher.cc:635-768
 //   GFO_ADAPTER_COMPUTE_BOW   Frame::ComputeBoW()                                               src/Frame.cc:661-668
 //
 // Each body flattens the reference's objects into plain arrays, calls the C ABI (include/gfo.h) and writes the
@@ -26,6 +27,7 @@
 #define GFO_ADAPTER_PROJ_LAST
 #define GFO_ADAPTER_PROJ_KF
 #define GFO_ADAPTER_BOW
+#define GFO_ADAPTER_BOW_KF
 #define GFO_ADAPTER_COMPUTE_BOW
 #endif
 
@@ -66,6 +68,8 @@ namespace ORB_SLAM2
 gfo_ctx* gfo_context_pin(const ORBextractor* e);   // adapter/ORBextractor_gfo.cc
 void gfo_context_unpin(const ORBextractor* e, gfo_ctx* c);
 bool gfo_context_colocate(const ORBextractor* follower, const ORBextractor* leader);
+gfo_ctx* gfo_context_pin_thread();                 // a context of the calling thread's own, for matcher calls without a Frame
+void gfo_context_unpin_thread(gfo_ctx* c);
 
 namespace
 {
@@ -562,6 +566,43 @@ int ORBmatcher::SearchByBoW(KeyFrame* pKF, Frame& F, std::vector<MapPoint*>& vpM
     }
     for (int i = 0; i < nF; i++)
         if (out[i] >= 0) vpMapPointMatches[i] = vpMapPointsKF[out[i]];      // :343
+    return nmatches;
+}
+#endif
+
+// ---------------------------------------------------------------------------------------------------------------
+#ifdef GFO_ADAPTER_BOW_KF
+// Loop closing's matcher (LoopClosing.cc:287): the keyframe-pair overload, ORBmatcher.cc:635-768.  No Frame, hence no extractor to take a
+// device context from: the calling thread's own (gfo_context_pin_thread, adapter/ORBextractor_gfo.cc).
+int ORBmatcher::SearchByBoW(KeyFrame* pKF1, KeyFrame* pKF2, std::vector<MapPoint*>& vpMatches12)
+{
+    const std::vector<MapPoint*> vpMapPoints1 = pKF1->GetMapPointMatches();
+    const std::vector<MapPoint*> vpMapPoints2 = pKF2->GetMapPointMatches();
+    vpMatches12 = std::vector<MapPoint*>(vpMapPoints1.size(), static_cast<MapPoint*>(NULL));   // :647
+    const int n1 = (int)vpMapPoints1.size(), n2 = (int)vpMapPoints2.size();
+    FlatFeatVec fv1(pKF1->mFeatVec), fv2(pKF2->mFeatVec);
+    std::vector<uint8_t> valid1(n1), valid2(n2);
+    std::vector<float> angle1(n1), angle2(n2);
+    for (int i = 0; i < n1; i++) {
+        valid1[i] = vpMapPoints1[i] && !vpMapPoints1[i]->isBad();      // :672-676
+        angle1[i] = pKF1->mvKeysUn[i].angle;                           // :722
+    }
+    for (int i = 0; i < n2; i++) {
+        valid2[i] = vpMapPoints2[i] && !vpMapPoints2[i]->isBad();      // :690-696
+        angle2[i] = pKF2->mvKeysUn[i].angle;
+    }
+    std::vector<int32_t> out(n1 > 0 ? n1 : 1);
+    int nmatches = 0;
+    cv::Mat keep1, keep2;
+    gfo_ctx* c = gfo_context_pin_thread();
+    const int rc = gfo_search_by_bow_keyframes(c, rows32(pKF1->mDescriptors, keep1), angle1.data(), valid1.data(), n1, &fv1.view,
+                                               rows32(pKF2->mDescriptors, keep2), angle2.data(), valid2.data(), n2, &fv2.view, mfNNratio,
+                                               mbCheckOrientation ? 1 : 0, out.data(), &nmatches);
+    if (rc != GFO_OK) report(c, "SearchByBoW(KF, KF)");
+    gfo_context_unpin_thread(c);
+    if (rc != GFO_OK) return 0;
+    for (int i = 0; i < n1; i++)
+        if (out[i] >= 0) vpMatches12[i] = vpMapPoints2[out[i]];      // :717
     return nmatches;
 }
 #endif

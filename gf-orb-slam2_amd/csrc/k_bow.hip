@@ -38,6 +38,7 @@ struct BowArgs {
     int* h_count;
     // BUDGETING_FEATURE_MATCHING (gfo_search_by_bow_budget), 0 = off: every accepted match records its node and its ordinal among the
     // node's accepted matches, every node how many it accepted; k_bow_budget then keeps of node j the first min(full_j, max(1, K - before_j))
+    int th_low;                // accept bestDist1 <= th_low: TH_LOW (:339), TH_LOW - 1 for the keyframe pair's strict test (:713)
     int max_matches;
     int* ord;                  // [n_f]
     int* node_of;              // [n_f]
@@ -77,7 +78,7 @@ __device__ __forceinline__ void bow_node_sweep(const BowArgs& a, int pi, int kb,
         if (b1 == 0xFFFFFFFFu) continue;
         const int bestDist1 = (int)(b1 >> 20);
         const int bestDist2 = b2 == 0xFFFFFFFFu ? 256 : (int)(b2 >> 20);
-        if (bestDist1 <= TH_LOW && (float)bestDist1 < a.nn_ratio * (float)bestDist2) {  // :339-341
+        if (bestDist1 <= a.th_low && (float)bestDist1 < a.nn_ratio * (float)bestDist2) {  // :339-341 (:713-715)
             const unsigned bestIdxF = a.f_items[fb + (int)(b1 & 0xFFFFF)];
             if (lane == 0) {
                 a.out[bestIdxF] = (int)realIdxKF;
@@ -179,7 +180,7 @@ __global__ __launch_bounds__(256) void k_bow_match(BowArgs a)
             const unsigned w2 = st_wave_min(b1 == w1 ? b2 : b1);
             const int bestDist1 = (int)(w1 >> 20);
             const int bestDist2 = w2 == 0xFFFFFFFFu ? 256 : (int)(w2 >> 20);
-            if (bestDist1 <= TH_LOW && (float)bestDist1 < a.nn_ratio * (float)bestDist2) {  // :339-341
+            if (bestDist1 <= a.th_low && (float)bestDist1 < a.nn_ratio * (float)bestDist2) {  // :339-341 (:713-715)
                 const int pos = (int)(w1 & 0xFFFFF);
                 const unsigned realIdxKF = (unsigned)__builtin_amdgcn_readlane((int)kidx, i);
                 const float ka = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(kang), i));
@@ -322,10 +323,13 @@ extern "C" int gfo_search_by_bow(gfo_ctx* c, const uint8_t* kf_desc, const float
                                     out_kf_idx, nmatches);
 }
 
-extern "C" int gfo_search_by_bow_budget(gfo_ctx* c, const uint8_t* kf_desc, const float* kf_angle, const uint8_t* kf_mp_valid,
-                                        int n_kf, const gfo_feature_vector* kf_fv, const uint8_t* f_desc, const float* f_angle,
-                                        int n_f, const gfo_feature_vector* f_fv, float nn_ratio, int check_orientation, int max_matches,
-                                        int32_t* out_kf_idx, int* nmatches)
+#define BOW_UNAVAILABLE 0x7FFFFFFF   // `out` of a second-side keypoint without a usable map point: "taken" from the start (:690-696)
+
+// f_valid (optional): the second side's map-point mask of the keyframe-pair overload; strict: `bestDist1 < TH_LOW` (:713)
+static int bow_search(gfo_ctx* c, const uint8_t* kf_desc, const float* kf_angle, const uint8_t* kf_mp_valid,
+                      int n_kf, const gfo_feature_vector* kf_fv, const uint8_t* f_desc, const float* f_angle, const uint8_t* f_valid,
+                      int n_f, const gfo_feature_vector* f_fv, float nn_ratio, int check_orientation, int max_matches, bool strict,
+                      int32_t* out_kf_idx, int* nmatches)
 {
     if (!c) return GFO_ERR_INVALID;
     if (!kf_fv || !f_fv || !out_kf_idx || !nmatches || n_kf < 0 || n_f < 0 || (n_kf > 0 && (!kf_desc || !kf_mp_valid)) ||
@@ -405,6 +409,10 @@ extern "C" int gfo_search_by_bow_budget(gfo_ctx* c, const uint8_t* kf_desc, cons
     if (nf_items) x.put(o_fi, f_fv->items, 4 * (size_t)nf_items);
     x.put(o_pr, pairs.data(), sizeof(int2) * pairs.size());
     memset(x.H + o_rb, 0xFF, o_cnt - o_rb);   // rot_bin and out = -1
+    if (f_valid) {
+        int* o = reinterpret_cast<int*>(x.H + o_out);
+        for (int i = 0; i < n_f; i++) if (!f_valid[i]) o[i] = BOW_UNAVAILABLE;
+    }
     memset(x.H + o_cnt, 0, 16);
     BTRY(c, x.up(S, o_cnt + 16, st));
     BowArgs a{};
@@ -416,6 +424,7 @@ extern "C" int gfo_search_by_bow_budget(gfo_ctx* c, const uint8_t* kf_desc, cons
     a.n_f = n_f; a.nn_ratio = nn_ratio; a.check_ori = check_orientation ? 1 : 0;
     a.out = (int*)(S + o_out); a.rot_bin = (int*)(S + o_rb); a.counters = (int*)(S + o_cnt);
     a.max_matches = budget ? max_matches : 0;
+    a.th_low = strict ? TH_LOW - 1 : TH_LOW;
     a.ord = (int*)(S + o_ord); a.node_of = (int*)(S + o_nof); a.node_acc = (int*)(S + o_nacc);
     if (int rc = x.out(o_cnt + 16 - o_out)) return rc;
     // with the rotation check its kernel is the last one and writes the answer into the pinned block itself; without it, one copy back
@@ -432,7 +441,41 @@ extern "C" int gfo_search_by_bow_budget(gfo_ctx* c, const uint8_t* kf_desc, cons
     if (!direct) BTRY(c, x.down(S + o_out, o_cnt + 16 - o_out, st));
     BTRY(c, hipStreamSynchronize(st));
     memcpy(out_kf_idx, x.HO, 4 * (size_t)n_f);
+    if (f_valid) for (int i = 0; i < n_f; i++) if (out_kf_idx[i] == BOW_UNAVAILABLE) out_kf_idx[i] = -1;
     *nmatches = reinterpret_cast<const int*>(x.HO + (o_cnt - o_out))[0];
+    return GFO_OK;
+}
+
+extern "C" int gfo_search_by_bow_budget(gfo_ctx* c, const uint8_t* kf_desc, const float* kf_angle, const uint8_t* kf_mp_valid,
+                                        int n_kf, const gfo_feature_vector* kf_fv, const uint8_t* f_desc, const float* f_angle,
+                                        int n_f, const gfo_feature_vector* f_fv, float nn_ratio, int check_orientation, int max_matches,
+                                        int32_t* out_kf_idx, int* nmatches)
+{
+    return bow_search(c, kf_desc, kf_angle, kf_mp_valid, n_kf, kf_fv, f_desc, f_angle, nullptr, n_f, f_fv, nn_ratio, check_orientation, max_matches,
+                      false, out_kf_idx, nmatches);
+}
+
+// ORBmatcher::SearchByBoW(KeyFrame* pKF1, KeyFrame* pKF2, vector<MapPoint*>& vpMatches12) (ORBmatcher.cc:635-768): the same walk over the
+// common nodes with the first keyframe in the (KeyFrame, Frame) overload's keyframe role and the second in its frame role -- a keypoint
+// of the second keyframe without a usable map point starts out "taken" (:690-696), the distance test is strict (:713).  Every keypoint of
+// either side is matched at most once, so the second side's answer (which keypoint of pKF1 took me) turned around is vpMatches12.
+extern "C" int gfo_search_by_bow_keyframes(gfo_ctx* c, const uint8_t* desc1, const float* angle1, const uint8_t* mp_valid1, int n1,
+                                           const gfo_feature_vector* fv1, const uint8_t* desc2, const float* angle2, const uint8_t* mp_valid2,
+                                           int n2, const gfo_feature_vector* fv2, float nn_ratio, int check_orientation, int32_t* out_idx2,
+                                           int* nmatches)
+{
+    if (!c) return GFO_ERR_INVALID;
+    if (!out_idx2 || n1 < 0 || n2 < 0 || (n2 > 0 && !mp_valid2)) {
+        c->err = "gfo_search_by_bow_keyframes: bad argument";
+        return GFO_ERR_INVALID;
+    }
+    std::vector<int32_t> taker((size_t)(n2 > 0 ? n2 : 1));
+    const int rc = bow_search(c, desc1, angle1, mp_valid1, n1, fv1, desc2, angle2, mp_valid2, n2, fv2, nn_ratio, check_orientation, 0, true,
+                              taker.data(), nmatches);
+    if (rc != GFO_OK) return rc;
+    for (int i = 0; i < n1; i++) out_idx2[i] = -1;
+    for (int j = 0; j < n2; j++)
+        if (taker[j] >= 0 && taker[j] < n1) out_idx2[taker[j]] = j;
     return GFO_OK;
 }
 

@@ -234,6 +234,28 @@ class ORBmatcher:
                                                                    1 if self.mbCheckOrientation else 0, int(max_matches), ptr(out), C.byref(nm)))
         return nm.value, out[:n_f]
 
+    def SearchByBoWKeyFrames(self, desc1, angle1, mp_valid1, fv1, desc2, angle2, mp_valid2, fv2):
+        """ORBmatcher::SearchByBoW(KeyFrame* pKF1, KeyFrame* pKF2, vpMatches12) -- ORBmatcher.h:273, ORBmatcher.cc:635-768 (loop closing).
+        Returns (nmatches, out_idx2[n1]): the keypoint of the second keyframe whose map point lands in vpMatches12[i], -1 = NULL."""
+        desc1 = np.ascontiguousarray(desc1, np.uint8); desc2 = np.ascontiguousarray(desc2, np.uint8)
+        angle1 = np.ascontiguousarray(angle1, np.float32); angle2 = np.ascontiguousarray(angle2, np.float32)
+        v1 = np.ascontiguousarray(mp_valid1, np.uint8); v2 = np.ascontiguousarray(mp_valid2, np.uint8)
+        keep = []
+
+        def fv(t):
+            ids, start, items = (np.ascontiguousarray(t[0], np.uint32), np.ascontiguousarray(t[1], np.int32),
+                                 np.ascontiguousarray(t[2], np.uint32))
+            keep.append((ids, start, items))
+            return FeatureVectorC(ids.ctypes.data, start.ctypes.data, items.ctypes.data, len(ids))
+        a, b = fv(fv1), fv(fv2)
+        n1 = len(desc1)
+        out = np.full(max(n1, 1), -1, np.int32)
+        nm = C.c_int()
+        check(self._L, self._ctx, self._L.gfo_search_by_bow_keyframes(self._ctx, ptr(desc1), ptr(angle1), ptr(v1), n1, C.byref(a), ptr(desc2),
+                                                                      ptr(angle2), ptr(v2), len(desc2), C.byref(b), self.mfNNratio,
+                                                                      1 if self.mbCheckOrientation else 0, ptr(out), C.byref(nm)))
+        return nm.value, out[:n1]
+
     def SearchByProjectionQueries(self, keys_un, desc, u_right, kp_angle, bounds, queries, q_desc, use_ratio=False,
                                   th_dist=None, kp_taken=None, max_matches=0):
         """The query form both projection overloads reduce to (gfo_search_by_projection_queries); with

@@ -396,6 +396,16 @@ int gfo_search_by_bow_budget(gfo_ctx* ctx, const uint8_t* kf_desc, const float* 
                              int n_f, const gfo_feature_vector* f_fv, float nn_ratio, int check_orientation, int max_matches,
                              int32_t* out_kf_idx, int* nmatches);
 
+/* ORBmatcher::SearchByBoW(KeyFrame* pKF1, KeyFrame* pKF2, vector<MapPoint*>& vpMatches12) -- include/ORBmatcher.h:273,
+ * src/ORBmatcher.cc:635-768 (loop closing, src/LoopClosing.cc:287).  As the (KeyFrame, Frame) overload with: a map-point mask on BOTH
+ * sides (mp_valid[i] = 1 where GetMapPointMatches()[i] is set and !isBad(), :672-676, :690-696), a strict distance test
+ * (bestDist1 < TH_LOW, :713), angles = mvKeysUn[i].angle of either keyframe, and the answer indexed by the FIRST keyframe:
+ * out_idx2[n1] = keypoint of pKF2 whose map point is left in vpMatches12[i], -1 = NULL. */
+int gfo_search_by_bow_keyframes(gfo_ctx* ctx, const uint8_t* desc1, const float* angle1, const uint8_t* mp_valid1, int n1,
+                                const gfo_feature_vector* fv1, const uint8_t* desc2, const float* angle2,
+                                const uint8_t* mp_valid2, int n2, const gfo_feature_vector* fv2, float nn_ratio,
+                                int check_orientation, int32_t* out_idx2, int* nmatches);
+
 /* Frame::ComputeBoW -> DBoW2 TemplatedVocabulary<FORB>::transform(features, BowVector&, FeatureVector&, levelsup)
  * src/Frame.cc:661-668, Thirdparty/DBoW2/DBoW2/TemplatedVocabulary.h:1140-1212 and the per-feature tree descent
  * :1231-1272 with FORB::distance (FORB.cpp:81).  The vocabulary tree is passed flattened: node 0 is the root,

@@ -1545,6 +1545,72 @@ int orc_search_by_bow(const uint8_t* kf_desc, const float* kf_angle, const uint8
     return nmatches;
 }
 
+/* ORBmatcher::SearchByBoW(KeyFrame* pKF1, KeyFrame* pKF2, vector<MapPoint*>& vpMatches12) -- ORBmatcher.cc:635-768 (loop closing,
+ * LoopClosing.cc:287).  Differences from the (KeyFrame, Frame) overload above, all kept: BOTH sides carry a map-point validity mask
+ * (:672-676, :690-696), the taken state is a flag per keypoint of the second keyframe (:648, :689), the distance test is strict
+ * (`bestDist1 < TH_LOW`, :713), results and rotation histogram are indexed by the FIRST keyframe's keypoint (:717, :730, :757).
+ * out12[n1]: keypoint of pKF2 whose map point is left in vpMatches12[i], -1 = NULL. */
+int orc_search_by_bow_keyframes(const uint8_t* desc1, const float* angle1, const uint8_t* valid1, int n1, const orc_feature_vector* fv1,
+                                const uint8_t* desc2, const float* angle2, const uint8_t* valid2, int n2, const orc_feature_vector* fv2,
+                                float nn_ratio, int check_orientation, int* out12)
+{
+    enum { HISTO_LENGTH = 30, TH_LOW_ = 50 };
+    for (int i = 0; i < n1; i++) out12[i] = -1;
+    uint8_t* matched2 = (uint8_t*)calloc(n2 > 0 ? n2 : 1, 1);   /* vbMatched2 */
+    int* rot_bin = (int*)malloc(sizeof(int) * (n1 > 0 ? n1 : 1));
+    for (int i = 0; i < n1; i++) rot_bin[i] = -1;
+    int histo[HISTO_LENGTH];
+    memset(histo, 0, sizeof histo);
+    const float factor = 1.0f / HISTO_LENGTH;
+    int nmatches = 0, a = 0, b = 0;
+    while (a < fv1->n_nodes && b < fv2->n_nodes) {
+        if (fv1->node_ids[a] == fv2->node_ids[b]) {
+            for (int i1 = fv1->node_start[a]; i1 < fv1->node_start[a + 1]; i1++) {
+                const unsigned idx1 = fv1->items[i1];
+                if (!valid1[idx1]) continue;                                   /* !pMP1 || pMP1->isBad() */
+                int bestDist1 = 256, bestIdx2 = -1, bestDist2 = 256;
+                for (int i2 = fv2->node_start[b]; i2 < fv2->node_start[b + 1]; i2++) {
+                    const unsigned idx2 = fv2->items[i2];
+                    if (matched2[idx2] || !valid2[idx2]) continue;             /* vbMatched2[idx2] || !pMP2 || pMP2->isBad() */
+                    const int dist = orc_hamming256(desc1 + (size_t)idx1 * 32, desc2 + (size_t)idx2 * 32);
+                    if (dist < bestDist1) { bestDist2 = bestDist1; bestDist1 = dist; bestIdx2 = (int)idx2; }
+                    else if (dist < bestDist2) bestDist2 = dist;
+                }
+                if (bestDist1 < TH_LOW_) {
+                    if ((float)bestDist1 < nn_ratio * (float)bestDist2) {
+                        out12[idx1] = bestIdx2;
+                        matched2[bestIdx2] = 1;
+                        if (check_orientation) {
+                            float rot = angle1[idx1] - angle2[bestIdx2];
+                            if (rot < 0.0) rot += 360.0f;
+                            int bin = (int)roundf(rot * factor);
+                            if (bin == HISTO_LENGTH) bin = 0;
+                            rot_bin[idx1] = bin;
+                            histo[bin]++;
+                        }
+                        nmatches++;
+                    }
+                }
+            }
+            a++; b++;
+        } else if (fv1->node_ids[a] < fv2->node_ids[b]) a++;
+        else b++;
+    }
+    if (check_orientation) {
+        int ind1 = -1, ind2 = -1, ind3 = -1;
+        orc_three_maxima(histo, HISTO_LENGTH, &ind1, &ind2, &ind3);
+        for (int i = 0; i < n1; i++) {
+            const int bin = rot_bin[i];
+            if (bin < 0 || bin == ind1 || bin == ind2 || bin == ind3) continue;
+            out12[i] = -1;
+            nmatches--;
+        }
+    }
+    free(rot_bin);
+    free(matched2);
+    return nmatches;
+}
+
 /* ------------------------------------------------------------------------------------------
  * ORBmatcher::SearchByProjection(Frame& CurrentFrame, const Frame& LastFrame, th, bMono, ...)
  * -- ORBmatcher.cc:1440-1593 -- on pre-projected queries; with use_ratio it is the map-point overload

@@ -226,6 +226,10 @@ typedef struct {
 int orc_search_by_bow(const uint8_t* kf_desc, const float* kf_angle, const uint8_t* kf_mp_valid, int n_kf,
                       const orc_feature_vector* kf_fv, const uint8_t* f_desc, const float* f_angle, int n_f,
                       const orc_feature_vector* f_fv, float nn_ratio, int check_orientation, int* out_kf_idx);
+/* ORBmatcher::SearchByBoW(KeyFrame*, KeyFrame*, vector<MapPoint*>&) -- ORBmatcher.cc:635-768; out12[n1] = keypoint of the second keyframe, -1 */
+int orc_search_by_bow_keyframes(const uint8_t* desc1, const float* angle1, const uint8_t* valid1, int n1, const orc_feature_vector* fv1,
+                                const uint8_t* desc2, const float* angle2, const uint8_t* valid2, int n2, const orc_feature_vector* fv2,
+                                float nn_ratio, int check_orientation, int* out12);
 /* ORBmatcher::ComputeThreeMaxima -- ORBmatcher.cc:1723-1764 on the bin sizes */
 void orc_three_maxima(const int* histo_sizes, int L, int* ind1, int* ind2, int* ind3);
 

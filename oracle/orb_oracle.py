@@ -745,6 +745,23 @@ def search_by_bow(kf_desc, kf_angle, kf_mp_valid, kf_fv, f_desc, f_angle, f_fv, 
     return nm, out[:len(f_desc)]
 
 
+def search_by_bow_keyframes(desc1, angle1, valid1, fv1, desc2, angle2, valid2, fv2, nn_ratio, check_orientation=True):
+    """ORBmatcher::SearchByBoW(KeyFrame*, KeyFrame*, vpMatches12), ORBmatcher.cc:635-768.  Returns (nmatches, out12[n1])."""
+    desc1 = np.ascontiguousarray(desc1, np.uint8); desc2 = np.ascontiguousarray(desc2, np.uint8)
+    angle1 = np.ascontiguousarray(angle1, np.float32); angle2 = np.ascontiguousarray(angle2, np.float32)
+    valid1 = np.ascontiguousarray(valid1, np.uint8); valid2 = np.ascontiguousarray(valid2, np.uint8)
+    a, keep_a = _fv_struct(fv1)
+    b, keep_b = _fv_struct(fv2)
+    out = np.full(max(len(desc1), 1), -1, np.int32)
+    L = lib()
+    vp = C.c_void_p
+    L.orc_search_by_bow_keyframes.argtypes = [vp, vp, vp, C.c_int, C.POINTER(FeatureVectorC), vp, vp, vp, C.c_int, C.POINTER(FeatureVectorC),
+                                              C.c_float, C.c_int, vp]
+    nm = L.orc_search_by_bow_keyframes(_p(desc1), _p(angle1), _p(valid1), len(desc1), C.byref(a), _p(desc2), _p(angle2), _p(valid2), len(desc2),
+                                       C.byref(b), nn_ratio, 1 if check_orientation else 0, _p(out))
+    return nm, out[:len(desc1)]
+
+
 def three_maxima(sizes):
     sizes = np.ascontiguousarray(sizes, np.int32)
     i1, i2, i3 = C.c_int(-1), C.c_int(-1), C.c_int(-1)

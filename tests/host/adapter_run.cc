@@ -16,6 +16,7 @@
 //   E3. ORBmatcher::SearchByProjection_OnePoint (include/ORBmatcher.h:71-150) pick by pick, through adapter/good_feature_matching_gfo.h;
 //   F. ORBmatcher::SearchByProjection(CurrentFrame, LastFrame, th, bMono, numVisible) (ORBmatcher.cc:1440-1593), including the
 //      host-side projection the adapter keeps (:1451-1502);
+//   I2. ORBmatcher::SearchByBoW(KeyFrame*, KeyFrame*, vpMatches12) (ORBmatcher.cc:635-768), loop closing's, from a thread of its own;
 //   H. ORBmatcher::SearchByProjection(CurrentFrame, KeyFrame*, sAlreadyFound, th, ORBdist) (ORBmatcher.cc:1595-1721), relocalisation's;
 //   I. ORBmatcher::SearchByBoW(KeyFrame*, Frame&, vpMapPointMatches) (ORBmatcher.cc:270-404) with real DBoW2::FeatureVector objects;
 //   J. Frame::ComputeBoW() (Frame.cc:661-668) on an ORBVocabulary object whose tree the harness fills: mBowVec and mFeatVec;
@@ -834,6 +835,44 @@ int main(int argc, char** argv)
                     if (ori) {
                         report("I_common_or_not_nodes_kf", (long long)kf.mFeatVec.size());
                         report("I_SearchByBoW_us", median_us(20, []() {}, [&]() { std::vector<MapPoint*> mm; matcher.SearchByBoW(&kf, F, mm); }));
+                    }
+                }
+                // I2. SearchByBoW(KeyFrame 1 = frame 0, KeyFrame 2 = frame 1, vpMatches12) (ORBmatcher.cc:635-768), called from a thread of its own
+                //     as LoopClosing does (LoopClosing.cc:287): no Frame in the call, the device context is the calling thread's
+                {
+                    std::vector<uint8_t> kv2 = slurp(g_in + "/I2_kf2_valid.bin", false);
+                    if ((int)kv2.size() == F.N) {
+                        TestKF kf2(F);
+                        std::vector<MapPoint*> kf2mp(F.N, static_cast<MapPoint*>(NULL));
+                        for (int i = 0; i < F.N; i++) {
+                            if (kv2[i] == 0) continue;
+                            TestMP* p = new TestMP();
+                            p->bad(kv2[i] == 2);
+                            owned.push_back(p);
+                            kf2mp[i] = p;
+                        }
+                        kf2.points(kf2mp);
+                        for (int ori = 0; ori < 2; ori++) {
+                            std::vector<MapPoint*> m12;
+                            int nm = -1;
+                            long long us = 0;
+                            std::thread([&]() {
+                                ORBmatcher matcher(0.75f, ori != 0);
+                                nm = matcher.SearchByBoW(&kf, &kf2, m12);
+                                if (ori) us = median_us(20, []() {}, [&]() { std::vector<MapPoint*> mm; matcher.SearchByBoW(&kf, &kf2, mm); });
+                            }).join();
+                            CHECK((int)m12.size() == F0.N, "I2: vpMatches12 has %zu entries for %d keypoints", m12.size(), F0.N);
+                            std::vector<int32_t> idx(F0.N, -1);
+                            for (int i = 0; i < F0.N && i < (int)m12.size(); i++) {
+                                if (!m12[i]) continue;
+                                idx[i] = -3;
+                                for (int j = 0; j < F.N; j++) if (kf2mp[j] == m12[i]) { idx[i] = j; break; }
+                            }
+                            dump(ori ? "I2_out_idx2_ori.bin" : "I2_out_idx2.bin", idx.data(), idx.size() * 4);
+                            int32_t n32 = nm;
+                            dump(ori ? "I2_nmatches_ori.bin" : "I2_nmatches.bin", &n32, 4);
+                            if (ori) report("I2_SearchByBoW_KF_KF_us", us);
+                        }
                     }
                 }
                 delete FP;

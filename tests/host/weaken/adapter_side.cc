@@ -1,4 +1,4 @@
-// stands for adapter/matchers_gfo.cc: the same seven members, every body answers 2
+// stands for adapter/matchers_gfo.cc: the same eight members, every body answers 2
 #include "decl.h"
 namespace ORB_SLAM2
 {
@@ -9,4 +9,5 @@ int ORBmatcher::SearchByProjection_Budget(Frame&, const std::vector<MapPoint*>&,
 int ORBmatcher::SearchByProjection(Frame&, const Frame&, const float, const bool, double&) { return 2; }
 int ORBmatcher::SearchByProjection(Frame&, KeyFrame*, const std::set<MapPoint*>&, const float, const int) { return 2; }
 int ORBmatcher::SearchByBoW(KeyFrame*, Frame&, std::vector<MapPoint*>&) { return 2; }
+int ORBmatcher::SearchByBoW(KeyFrame*, KeyFrame*, std::vector<MapPoint*>&) { return 2; }
 }  // namespace ORB_SLAM2

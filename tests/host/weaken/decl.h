@@ -23,6 +23,7 @@ public:
     int SearchByProjection(Frame& CurrentFrame, const Frame& LastFrame, const float th, const bool bMono, double& numVisibleMpt);
     int SearchByProjection(Frame& CurrentFrame, KeyFrame* pKF, const std::set<MapPoint*>& sAlreadyFound, const float th, const int ORBdist);
     int SearchByBoW(KeyFrame* pKF, Frame& F, std::vector<MapPoint*>& vpMapPointMatches);
+    int SearchByBoW(KeyFrame* pKF1, KeyFrame* pKF2, std::vector<MapPoint*>& vpMatches12);
     int untouched();   // a member the adapter does not replace
 };
 }  // namespace ORB_SLAM2

@@ -10,5 +10,6 @@ int ORBmatcher::SearchByProjection_Budget(Frame&, const std::vector<MapPoint*>&,
 int ORBmatcher::SearchByProjection(Frame&, const Frame&, const float, const bool, double&) { return 1; }
 int ORBmatcher::SearchByProjection(Frame&, KeyFrame*, const std::set<MapPoint*>&, const float, const int) { return 1; }
 int ORBmatcher::SearchByBoW(KeyFrame*, Frame&, std::vector<MapPoint*>&) { return 1; }
+int ORBmatcher::SearchByBoW(KeyFrame*, KeyFrame*, std::vector<MapPoint*>&) { return 1; }
 int ORBmatcher::untouched() { return 7; }
 }  // namespace ORB_SLAM2

@@ -291,6 +291,11 @@ def run(tmp_path_factory, oracle, euroc_l, euroc_r):
     kvalid.tofile(ind / "I_kf_valid.bin")
     ref["I"] = [oracle.search_by_bow(dl0, kl0["angle"], (kvalid == 1).astype(np.uint8), oracle.make_feature_vector(knode), dl1, kl1["angle"],
                                      oracle.make_feature_vector(fnode), 0.7, bool(o)) for o in (0, 1)]
+    # I2: SearchByBoW(KeyFrame 1 = frame 0, KeyFrame 2 = frame 1): the second keyframe carries a map-point list as well
+    kvalid2 = rng.choice([0, 1, 2], n1, p=[0.2, 0.75, 0.05]).astype(np.uint8)
+    kvalid2.tofile(ind / "I2_kf2_valid.bin")
+    ref["I2"] = [oracle.search_by_bow_keyframes(dl0, kl0["angle"], (kvalid == 1).astype(np.uint8), oracle.make_feature_vector(knode), dl1, kl1["angle"],
+                                                (kvalid2 == 1).astype(np.uint8), oracle.make_feature_vector(fnode), 0.75, bool(o)) for o in (0, 1)]
     with oracle.feature_budget(BUDGET):
         ref["I_budget"] = [oracle.search_by_bow(dl0, kl0["angle"], (kvalid == 1).astype(np.uint8), oracle.make_feature_vector(knode), dl1, kl1["angle"],
                                                 oracle.make_feature_vector(fnode), 0.7, bool(o)) for o in (0, 1)]
@@ -606,6 +611,17 @@ def test_search_by_bow_member(run):
         np.testing.assert_array_equal(got, out, err_msg=tag)
         assert int(_rd(run, f"I_nmatches{tag}.bin", np.int32)[0]) == nm
         assert nm > 100, (tag, nm)
+
+
+def test_search_by_bow_between_keyframes_member(run):
+    """ORBmatcher::SearchByBoW(KeyFrame*, KeyFrame*, vector<MapPoint*>&) (ORBmatcher.cc:635-768), loop closing's matcher, called from a
+    thread of its own: two KeyFrame objects with their map-point lists and real DBoW2::FeatureVector objects; the device context is
+    the calling thread's (no Frame, no extractor in the call)"""
+    for tag, (nm, out) in zip(("", "_ori"), run["I2"]):
+        got = _rd(run, f"I2_out_idx2{tag}.bin", np.int32)
+        np.testing.assert_array_equal(got, out, err_msg=tag)
+        assert int(_rd(run, f"I2_nmatches{tag}.bin", np.int32)[0]) == nm
+        assert nm > 80, (tag, nm)
 
 
 def test_matcher_members_of_a_budgeting_feature_matching_build(run):

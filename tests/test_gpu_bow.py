@@ -241,3 +241,29 @@ def test_vocabulary_at_the_size_the_reference_loads(oracle):
             json.dump(rec, fh)
     assert rec["compute_bow_ms_median"] < 1.0, rec              # a call stays a call: the tree's size is not in it
     ext.close()
+
+
+@pytest.mark.parametrize("seed,flips,shift,sigma,ratio,ori", [(0, 10, 2, 5.0, 0.7, True), (1, 4, 4, 40.0, 0.9, True),
+                                                              (2, 20, 0, 2.0, 0.6, False), (3, 0, 6, 0.0, 0.75, True), (4, 30, 3, 5.0, 0.95, True)])
+def test_bow_between_two_keyframes(ext, oracle, seed, flips, shift, sigma, ratio, ori):
+    """ORBmatcher::SearchByBoW(KeyFrame*, KeyFrame*, vpMatches12) (ORBmatcher.cc:635-768, loop closing): a map-point mask on both sides,
+    the strict `bestDist1 < TH_LOW`, the answer indexed by the first keyframe.  Seed 4 flips enough bits for distances of exactly
+    TH_LOW to occur (the one place the two overloads' thresholds differ)."""
+    import gf_orb_slam2_amd as G
+    d1, a1, v1, fv1, d2, a2, fv2 = _case(oracle, seed, flips, shift, sigma)
+    v2 = (np.random.default_rng(seed + 100).random(len(d2)) >= 0.15).astype(np.uint8)
+    ref = oracle.search_by_bow_keyframes(d1, a1, v1, fv1, d2, a2, v2, fv2, ratio, ori)
+    got = G.ORBmatcher(ratio, ori, extractor=ext).SearchByBoWKeyFrames(d1, a1, v1, fv1, d2, a2, v2, fv2)
+    assert got[0] == ref[0]
+    np.testing.assert_array_equal(got[1], ref[1])
+    m = ref[1] >= 0
+    assert v1[m].all() and v2[ref[1][m]].all() and len(set(ref[1][m].tolist())) == int(m.sum())
+    if flips <= 10:
+        assert ref[0] > 150
+    # nothing usable on the second side: nothing matches; the plain overload is untouched by the mask machinery
+    none = G.ORBmatcher(ratio, ori, extractor=ext).SearchByBoWKeyFrames(d1, a1, v1, fv1, d2, a2, np.zeros_like(v2), fv2)
+    assert none[0] == 0 and (none[1] == -1).all()
+    plain = G.ORBmatcher(ratio, ori, extractor=ext).SearchByBoW(d1, a1, v1, fv1, d2, a2, fv2)
+    refp = oracle.search_by_bow(d1, a1, v1, fv1, d2, a2, fv2, ratio, ori)
+    assert plain[0] == refp[0]
+    np.testing.assert_array_equal(plain[1], refp[1])

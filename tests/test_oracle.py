@@ -809,3 +809,82 @@ def test_candidate_lists_then_match_equals_one_point(oracle):
             r = (2.5 if mps["view_cos"][p] > 0.998 else 4.0) * sf[mps["level"][p]]
             ref = oracle.features_in_area(kl, gc.BOUNDS, mps["proj_x"][p], mps["proj_y"][p], np.float32(r), int(mps["level"][p]) - 1, int(mps["level"][p]))
             np.testing.assert_array_equal(cands[p], ref)
+
+
+def bow_keyframes_python(d1, a1, v1, fv1, d2, a2, v2, fv2, ratio, ori):
+    """ORBmatcher.cc:635-768 once more, in Python, written from the reference's text (not from the C restatement)."""
+    n1 = len(d1)
+    out = np.full(n1, -1, np.int64)
+    matched2 = np.zeros(len(d2), bool)
+    hist = [[] for _ in range(30)]
+    nm = 0
+    ids1, st1, it1 = fv1
+    ids2, st2, it2 = fv2
+    pos2 = {int(k): j for j, k in enumerate(ids2)}
+    for a, node in enumerate(ids1):
+        b = pos2.get(int(node))
+        if b is None:
+            continue
+        for idx1 in it1[st1[a]:st1[a + 1]]:
+            if not v1[idx1]:
+                continue
+            best1, best2, bidx = 256, 256, -1
+            for idx2 in it2[st2[b]:st2[b + 1]]:
+                if matched2[idx2] or not v2[idx2]:
+                    continue
+                dist = int(np.unpackbits(d1[idx1] ^ d2[idx2]).sum())
+                if dist < best1:
+                    best2, best1, bidx = best1, dist, int(idx2)
+                elif dist < best2:
+                    best2 = dist
+            if best1 < 50 and np.float32(best1) < np.float32(ratio) * np.float32(best2):
+                out[idx1] = bidx
+                matched2[bidx] = True
+                if ori:
+                    rot = np.float32(a1[idx1]) - np.float32(a2[bidx])
+                    if rot < 0:
+                        rot = np.float32(rot + np.float32(360.0))
+                    b_ = int(math.floor(float(np.float32(rot * np.float32(1.0 / 30))) + 0.5))    # C round(): halves away from zero
+                    if b_ == 30:
+                        b_ = 0
+                    hist[b_].append(int(idx1))
+                nm += 1
+    if ori:
+        keep = oracle_three_maxima([len(h) for h in hist])
+        for i, h in enumerate(hist):
+            if i in keep:
+                continue
+            for idx1 in h:
+                out[idx1] = -1
+                nm -= 1
+    return nm, out
+
+
+def oracle_three_maxima(sizes):
+    from oracle import orb_oracle
+    return set(orb_oracle.three_maxima(sizes))
+
+
+@pytest.mark.parametrize("seed,shift,ratio,ori", [(0, 3, 0.7, True), (1, 5, 0.9, False), (2, 4, 0.95, True)])
+def test_bow_keyframe_pair_oracle_against_python_statement(oracle, seed, shift, ratio, ori):
+    kd = oracle.KEYPOINT_DTYPE
+    kl = np.fromfile(os.path.join(GOLDEN, "EuRoC_l_kp.bin"), kd)[:700]
+    d1 = np.fromfile(os.path.join(GOLDEN, "EuRoC_l_desc.bin"), np.uint8).reshape(-1, 32)[:700]
+    rng = np.random.default_rng(seed)
+    d2 = d1.copy()
+    for _ in range(24):
+        sel = rng.random(len(d2)) < 0.5
+        bits = rng.integers(0, 256, len(d2))
+        d2[sel, bits[sel] >> 3] ^= (1 << (bits[sel] & 7)).astype(np.uint8)
+    perm = rng.permutation(len(d2))
+    d2 = d2[perm]
+    a1 = kl["angle"].copy()
+    a2 = ((a1[perm] + rng.normal(0, 8, len(d2))) % 360).astype(np.float32)
+    v1 = (rng.random(len(d1)) > 0.1).astype(np.uint8)
+    v2 = (rng.random(len(d2)) > 0.15).astype(np.uint8)
+    fv1 = oracle.make_feature_vector((d1[:, 0] >> shift).astype(np.int64))
+    fv2 = oracle.make_feature_vector((d2[:, 0] >> shift).astype(np.int64))
+    ref = bow_keyframes_python(d1, a1, v1, fv1, d2, a2, v2, fv2, ratio, ori)
+    got = oracle.search_by_bow_keyframes(d1, a1, v1, fv1, d2, a2, v2, fv2, ratio, ori)
+    assert got[0] == ref[0] and ref[0] > 30
+    np.testing.assert_array_equal(got[1], ref[1])
