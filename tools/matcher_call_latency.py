@@ -3,7 +3,7 @@ Per-call latency of the host-array matcher calls Tracking makes on every frame (
 synchronisation): SearchByProjection(F, local map) for several map sizes, SearchByProjection(Cur, Last), SearchByBoW(KF, F),
 ComputeBoW(F) -- on the EuRoC frame (2008 keypoints).  Every map point here imitates a random keypoint (8 flipped bits, N(0,2) px
 away), so with M > N several points COMPETE for one keypoint: the ordered resolve runs its worst case, not a typical local map.
-usage (through gpurun): [TH=1|3|5] [ONLY=map|stereo|last|cbow|bow] [JSON=1] python tools/matcher_call_latency.py [M ...]     (GFO_PROJ_STATS=1 prints
+usage (through gpurun): [TH=1|3|5] [ONLY=map|gf|stereo|last|cbow|bow] [JSON=1] python tools/matcher_call_latency.py [M ...]     (GFO_PROJ_STATS=1 prints
 rounds / fallbacks per call; JSON=1: one JSON object on stdout instead of the text lines)"""
 import json
 import os
@@ -70,6 +70,26 @@ for M in ([int(a) for a in sys.argv[1:]] or (1000, 2000, 4000)) if ONLY in ("", 
     ms, r = median_ms(lambda: m.SearchByProjection(kp, desc, u_right, sf, bounds, mps, mpd, TH, None))
     say("SearchByProjection(F, MapPoints)", ms, {"map_points": M, "th": TH, "keypoints": n, "matches": int(r[0])},
         f"SearchByProjection(F, {M} map points, th {TH:g}), {n} keypoints: median {ms:.3f} ms, {r[0]} matches")
+
+# the good-feature build's calls on a 2000-point map (GOOD_FEATURE_MAP_MATCHING, the reference's default): SearchByProjection_Budget's
+# device call (what every point did at its turn) and the candidate table behind SearchByProjection_OnePoint, then 2000 picks from it
+if ONLY in ("", "gf"):
+    M = 2000
+    mps = np.zeros(M, G.MAP_POINT_DTYPE)
+    src = rng.integers(0, n, M)
+    mpd = flipped(desc[src], 8)
+    mps["proj_x"] = kp["x"][src] + rng.normal(0, 2, M)
+    mps["proj_y"] = kp["y"][src] + rng.normal(0, 2, M)
+    mps["proj_xr"] = mps["proj_x"] - 5
+    mps["level"] = kp["octave"][src]
+    mps["view_cos"] = 1.0
+    mps["flags"] = 1 | 4
+    ms, r = median_ms(lambda: m.SearchByProjectionPoints(kp, desc, u_right, sf, bounds, mps, mpd, TH, None))
+    say("SearchByProjection_Budget (gfo_search_by_projection_points)", ms, {"map_points": M, "th": TH, "keypoints": n, "matches": int(r[0])},
+        f"SearchByProjection_Budget's call ({M} map points, th {TH:g}, per-point outcomes): median {ms:.3f} ms, {r[0]} matches")
+    ms, r = median_ms(lambda: m.GetCandidates(kp, desc, u_right, sf, bounds, mps, mpd, TH))
+    say("GetCandidates for every map point (gfo_projection_candidates)", ms, {"map_points": M, "th": TH, "keypoints": n, "entries": int(len(r[1]))},
+        f"candidate table ({M} map points, th {TH:g}): median {ms:.3f} ms, {len(r[1])} entries")
 
 # Frame::ComputeStereoMatches_Undistorted on caller arrays (what the adapter falls back on when the rig cannot answer from the extraction)
 if ONLY in ("", "stereo"):
