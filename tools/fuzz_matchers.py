@@ -98,7 +98,30 @@ for it in range(cases):
             ratio = float(rng.choice([0.6, 0.8, 0.9, 1.0]))
             # (levels -1 and 8 are outside the frame's scale table: library and oracle both skip such a point)
             ref = O.search_by_projection(kp, desc, u_right, SF, bounds, mps, qd, th, ratio, taken)
-            got = G.ORBmatcher(ratio, True, extractor=ext).SearchByProjection(kp, desc, u_right, SF, bounds, mps, qd, th, taken)
+            mt = G.ORBmatcher(ratio, True, extractor=ext)
+            got = mt.SearchByProjection(kp, desc, u_right, SF, bounds, mps, qd, th, taken)
+            if rng.random() < 0.5:
+                # the good-feature build's forms of the same loop: what every point did at its turn (SearchByProjection_Budget,
+                # ORBmatcher.cc:45-153), and the candidate table + per-point match driven in vector order (ORBmatcher.h:71-250)
+                count["gf"] = count.get("gf", 0) + 1
+                rb = O.search_by_projection_budget(kp, desc, u_right, SF, bounds, mps, qd, th, ratio, taken, 0)
+                gp = mt.SearchByProjectionPoints(kp, desc, u_right, SF, bounds, mps, qd, th, taken)
+                if gp[0] != rb[0] or not (gp[1] == rb[1]).all() or not (gp[2] == rb[2]).all() or not (gp[3] == rb[3]).all():
+                    mismatch("points", it=it, n=n, m=m, wave=os.environ["GFO_PROJ_WAVE"], cap=os.environ["GFO_PROJ_SPILL_CAP"], got=gp[0], ref=rb[0])
+                start, cand = mt.GetCandidates(kp, desc, u_right, SF, bounds, mps, qd, th, cap=int(rng.choice([0, 64, 32 * max(m, 1)])))
+                slot = np.zeros(max(n, 1), np.uint8) if taken is None else taken.copy()
+                okc = True
+                for p in range(m):
+                    r, d = mt.MatchCandidates(cand[start[p]:start[p + 1]], slot)
+                    want = int(rb[3][p])
+                    if r >= 0:
+                        okc = okc and want == (r | (d << 16))
+                        slot[r] = 1 if mps["flags"][p] & 4 else 0
+                    else:
+                        okc = okc and want == r
+                    if not okc:
+                        mismatch("table", it=it, n=n, m=m, point=p, got=r, want=want)
+                        break
         else:
             q = np.zeros(m, O.PROJ_QUERY_DTYPE)
             q["u"], q["v"] = px, py
@@ -145,6 +168,13 @@ for it in range(cases):
         matches["bow"] += int(ref[0])
         if got[0] != ref[0] or not (got[1] == ref[1]).all():
             mismatch("bow", it=it, nk=nk, nf=nf, nnodes=nnodes, got=got[0], ref=ref[0])
+        if rng.random() < 0.5:      # the keyframe-pair overload (ORBmatcher.cc:635-768) on the same arrays, a mask on the second side as well
+            count["bow_kf"] = count.get("bow_kf", 0) + 1
+            valid2 = (rng.random(nf) >= rng.uniform(0, 0.5)).astype(np.uint8)
+            refk = O.search_by_bow_keyframes(kd, kk["angle"].copy(), valid, kfv, fd, fa, valid2, ffv, ratio, ori)
+            gotk = G.ORBmatcher(ratio, ori, extractor=ext).SearchByBoWKeyFrames(kd, kk["angle"].copy(), valid, kfv, fd, fa, valid2, ffv)
+            if gotk[0] != refk[0] or not (gotk[1] == refk[1]).all():
+                mismatch("bow_kf", it=it, nk=nk, nf=nf, nnodes=nnodes, got=gotk[0], ref=refk[0])
     else:
         k, depth = int(rng.integers(2, 12)), int(rng.integers(1, 6))
         while k ** depth > 200000:
