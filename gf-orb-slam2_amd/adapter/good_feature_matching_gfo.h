@@ -31,6 +31,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 #include <vector>
 
 #include "Frame.h"
@@ -43,6 +44,18 @@ namespace ORB_SLAM2
 
 gfo_ctx* gfo_context_pin(const ORBextractor* e);   // adapter/ORBextractor_gfo.cc
 void gfo_context_unpin(const ORBextractor* e, gfo_ctx* c);
+
+// MapPoint::GetDescriptor() without its temporary: the same 32 bytes under the same mutex (src/MapPoint.cc:464-468 locks mMutexFeatures and
+// clones; both members are protected, include/MapPoint.h:173,193 -- a derived type reads them)
+struct GfoMapPointView : public MapPoint {
+    bool descriptor_into(uint8_t* dst)
+    {
+        std::unique_lock<std::mutex> lock(mMutexFeatures);
+        if (!(mDescriptor.data && mDescriptor.rows * mDescriptor.cols >= 32 && mDescriptor.isContinuous())) return false;
+        memcpy(dst, mDescriptor.data, 32);
+        return true;
+    }
+};
 
 class GfoCandidateTable
 {
@@ -66,6 +79,7 @@ public:
             m.flags = pMP->mbTrackInView ? 1 : 0;                // ORBmatcher.h:75-79: not in view / bad: no candidates
             if (!m.flags) continue;
             if (pMP->isBad()) { m.flags |= 2; continue; }
+            if (static_cast<GfoMapPointView*>(pMP)->descriptor_into(&desc[(size_t)i * 32])) continue;
             const cv::Mat d = pMP->GetDescriptor();
             if (d.data && d.rows * d.cols >= 32 && d.isContinuous()) memcpy(&desc[(size_t)i * 32], d.data, 32);
             else { cv::Mat row(1, 32, CV_8U, &desc[(size_t)i * 32]); d.copyTo(row); }

@@ -112,9 +112,22 @@ struct FlatFeatVec {
     }
 };
 
-// one map point's descriptor into row i of an M x 32 block (MapPoint::GetDescriptor returns a clone: 1 x 32 CV_8U, continuous)
+// One descriptor into row i of a block.  MapPoint::GetDescriptor() (src/MapPoint.cc:464-468) is `lock(mMutexFeatures); return
+// mDescriptor.clone();` -- an allocation and a release per point, a few thousand times per matcher call.  The same 32 bytes under the
+// same mutex, without the temporary: both members are protected (include/MapPoint.h:173,193), a derived type reads them -- the device
+// VocabularyView below uses for the vocabulary's tree.  (A descriptor of another shape goes through GetDescriptor() as before.)
+struct MapPointView : public MapPoint {
+    bool descriptor_into(uint8_t* dst)
+    {
+        std::unique_lock<std::mutex> lock(mMutexFeatures);
+        if (!(mDescriptor.data && mDescriptor.rows * mDescriptor.cols >= 32 && mDescriptor.isContinuous())) return false;
+        memcpy(dst, mDescriptor.data, 32);
+        return true;
+    }
+};
 inline void descriptor_row(MapPoint* pMP, cv::Mat& block, int i)
 {
+    if (static_cast<MapPointView*>(pMP)->descriptor_into(block.data + (size_t)i * 32)) return;
     const cv::Mat d = pMP->GetDescriptor();
     if (d.data && d.rows * d.cols >= 32 && d.isContinuous()) memcpy(block.data + (size_t)i * 32, d.data, 32);
     else d.copyTo(block.row(i));
