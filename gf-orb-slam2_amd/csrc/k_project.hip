@@ -970,7 +970,7 @@ __global__ __launch_bounds__(64 * PJ_WAVES) void k_proj_candidates(ProjB a, int*
     int base = 0, T = 0;
     if (PASS == 1) {
         if (iq < a.m) { base = start[iq]; T = start[iq + 1] - base; }
-        scan = scan && T > 0 && base >= 0 && base + T <= cap;   // a table that does not fit the caller's array is not written (GFO_ERR_CAPACITY)
+        scan = scan && T > 0 && base >= 0 && (long long)base + T <= (long long)cap;   // a table that does not fit the caller's array is not written (GFO_ERR_CAPACITY)
     }
     const int* g_start = a.cell_start;
     const float2* cell_xy = a.cell_xy;
@@ -1067,11 +1067,15 @@ __global__ __launch_bounds__(64 * PJ_WAVES) void k_proj_candidates(ProjB a, int*
 __global__ __launch_bounds__(1024) void k_proj_cand_scan(int* start, int m, int* h_start)
 {
     __shared__ int s_part[16];
+    __shared__ unsigned long long s_tot64;   // the table's size without wrap-around (a point has at most 65 535 candidates, a thread's chunk fits an int)
     const int tid = threadIdx.x;
+    if (tid == 0) s_tot64 = 0;
+    __syncthreads();
     const int chunk = (m + 1023) / 1024;
     const int b = min(m, tid * chunk), e = min(m, b + chunk);
     int sum = 0;
     for (int i = b; i < e; i++) sum += start[i];
+    if (sum) atomicAdd(&s_tot64, (unsigned long long)sum);
     int tot = 0;
     const int incl = st_block_incl_scan(sum, s_part, &tot);
     int run = incl - sum;
@@ -1082,6 +1086,7 @@ __global__ __launch_bounds__(1024) void k_proj_cand_scan(int* start, int m, int*
         run += cnt;
     }
     if (tid == 0) {
+        if (s_tot64 > 0x7FFFFFFFull) tot = -1;   // more than 2^31 entries: refused by the host (no caller array holds them)
         start[m] = tot;
         if (h_start) h_start[m] = tot;
     }
@@ -1478,7 +1483,7 @@ extern "C" int gfo_projection_candidates(gfo_ctx* c, const gfo_keypoint* kp_un, 
     const int tot = cand_start[m];
     *total = tot;
     c->have_projection = false;
-    if (tot < 0) return pj_fail(c, GFO_ERR_STATE, "gfo_projection_candidates: offsets overflowed");
+    if (tot < 0) return pj_fail(c, GFO_ERR_CAPACITY, "gfo_projection_candidates: the table has more than 2^31 entries");
     if (tot > cap) {
         c->err = "gfo_projection_candidates: the table has " + std::to_string(tot) + " entries, the caller's array " + std::to_string(cap);
         return GFO_ERR_CAPACITY;
