@@ -241,8 +241,8 @@ static int blur_mfma_blocks(const gfo_ctx* c)
 #if GFO_OCV_BLUR_ROUND == 1
     return 0;
 #else
-    static const int on = getenv("GFO_BLUR_MFMA") ? atoi(getenv("GFO_BLUR_MFMA")) : 1;
-    if (!on) return 0;
+    const char* e = getenv("GFO_BLUR_MFMA");   // read per call: tests/test_gpu_blur.py runs both forms in one process
+    if (e && atoi(e) == 0) return 0;
     int blocks = 0;
     for (int l = 0; l < c->g.nlevels; l++) {
         const int w = c->g.lv[l].w, h = c->g.lv[l].h;
