@@ -244,10 +244,11 @@ static int blur_mfma_blocks(const gfo_ctx* c)
     // GFO_BLUR_MFMA (read per call: tests/test_gpu_blur.py runs both forms in one process): 0 = the streaming form, 1 = the matrix cores
     // whatever the image, unset = by image width.  The matrix-core form wins where an image's levels stay in its XCD's L2 between the
     // overlapping window loads (752 x 480: +5.4 % extract-only, +2.5 % with the stereo association) and loses on larger images
-    // (1024 x 768: -2.7 %, 1241 x 376: -0.5 %, 1280 x 720: -4.0 %, 1920 x 1080: -6 %; tools/ab_blur_width.py): up to 960 px wide.
+    // (640 x 480: +5.5 %, 848 x 480: +0.6 %, 960 x 540: -2.3 %, 1024 x 768: -2.7 %, 1280 x 720: -4.0 %, 1920 x 1080: -6 %;
+    // tools/ab_blur_width.py): up to 896 px wide.
     const char* e = getenv("GFO_BLUR_MFMA");
     if (e && atoi(e) == 0) return 0;
-    if (!e && c->g.lv[0].w > 960) return 0;
+    if (!e && c->g.lv[0].w > 896) return 0;
     int blocks = 0;
     for (int l = 0; l < c->g.nlevels; l++) {
         const int w = c->g.lv[l].w, h = c->g.lv[l].h;
