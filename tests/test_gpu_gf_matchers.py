@@ -247,3 +247,37 @@ def test_candidate_table_capacity_and_edges(ext, oracle):
     s1, c1 = mt.GetCandidates(kl[:0], dl[:0], None, sf, gc.BOUNDS, mps, mpd, 1.0)
     assert not s1.any() and len(c1) == 0
     assert mt.MatchCandidates(np.zeros(0, np.uint32), None)[0] == mt.POINT_NONE
+
+
+def test_golden_good_feature_vectors(ext, oracle):
+    """The committed vectors (tests/golden/EuRoC_gf_matchers.npz) through the C ABI: per-point outcomes at th 0.5 and 1, the clock's
+    prefix, the candidate table's lists, SearchByBoW between the two golden extractions as keyframes."""
+    import os
+    import gf_orb_slam2_amd as G
+    from conftest import GOLDEN
+    kl, dl, u, _ = gc.frame(oracle)
+    kr = np.fromfile(os.path.join(GOLDEN, "EuRoC_r_kp.bin"), oracle.KEYPOINT_DTYPE)
+    dr = np.fromfile(os.path.join(GOLDEN, "EuRoC_r_desc.bin"), np.uint8).reshape(-1, 32)
+    p = np.load(os.path.join(GOLDEN, "EuRoC_projection.npz"))
+    g = np.load(os.path.join(GOLDEN, "EuRoC_gf_matchers.npz"))
+    sf = ext.GetScaleFactors()
+    mt = G.ORBmatcher(0.8, True, extractor=ext)
+    for tag, th in (("th05", 0.5), ("th1", 1.0)):
+        nm, out_mp, out_sc, out_pt = mt.SearchByProjectionPoints(kl, dl, u, sf, gc.BOUNDS, p["mps"], p["mp_desc"], th, p["taken"])
+        assert nm == int(g[f"{tag}_nmatches"])
+        np.testing.assert_array_equal(out_pt, g[f"{tag}_out_point"])
+        np.testing.assert_array_equal(out_mp, g[f"{tag}_out_mp"])
+        np.testing.assert_array_equal(out_sc, g[f"{tag}_out_score"])
+        np.testing.assert_array_equal((out_pt >= 0).astype(np.int32), g[f"{tag}_found"])
+    nm5, mp5, sc5 = mt.points_prefix(out_pt, gc.clock_cut(out_pt, 5), len(kl))
+    assert nm5 == int(g["th1_trip5_nmatches"])
+    np.testing.assert_array_equal(mp5, g["th1_trip5_out_mp"]); np.testing.assert_array_equal(sc5, g["th1_trip5_out_score"])
+    start, cand = mt.GetCandidates(kl, dl, u, sf, gc.BOUNDS, p["mps"], p["mp_desc"], 1.0)
+    np.testing.assert_array_equal(start, g["th1_cand_start"])
+    np.testing.assert_array_equal((cand & 0xFFFF).astype(np.int32), g["th1_cand_idx"])
+    n1 = (dl[:, 0] >> 2).astype(np.int64); n2 = (dr[:, 0] >> 2).astype(np.int64)
+    for ori in (0, 1):
+        nmk, o12 = G.ORBmatcher(0.75, bool(ori), extractor=ext).SearchByBoWKeyFrames(dl, kl["angle"], g["bowkf_valid1"], oracle.make_feature_vector(n1), dr,
+                                                                                     kr["angle"], g["bowkf_valid2"], oracle.make_feature_vector(n2))
+        assert nmk == int(g[f"bowkf_ori{ori}_nmatches"])
+        np.testing.assert_array_equal(o12, g[f"bowkf_ori{ori}_out12"])

@@ -888,3 +888,36 @@ def test_bow_keyframe_pair_oracle_against_python_statement(oracle, seed, shift, 
     got = oracle.search_by_bow_keyframes(d1, a1, v1, fv1, d2, a2, v2, fv2, ratio, ori)
     assert got[0] == ref[0] and ref[0] > 30
     np.testing.assert_array_equal(got[1], ref[1])
+
+
+def test_oracle_reproduces_golden_good_feature_matchers(oracle):
+    """tests/golden/EuRoC_gf_matchers.npz (made by tests/golden/make_gf_golden.py): the oracle still says what it said when the vectors
+    were committed -- SearchByProjection_Budget at th 0.5 / 1 / with a clock, GetCandidates for every point, SearchByBoW(KF, KF)."""
+    kd = oracle.KEYPOINT_DTYPE
+    kl = np.fromfile(os.path.join(GOLDEN, "EuRoC_l_kp.bin"), kd)
+    kr = np.fromfile(os.path.join(GOLDEN, "EuRoC_r_kp.bin"), kd)
+    dl = np.fromfile(os.path.join(GOLDEN, "EuRoC_l_desc.bin"), np.uint8).reshape(-1, 32)
+    dr = np.fromfile(os.path.join(GOLDEN, "EuRoC_r_desc.bin"), np.uint8).reshape(-1, 32)
+    u = np.load(os.path.join(GOLDEN, "EuRoC_stereo.npz"))["u_right"]
+    p = np.load(os.path.join(GOLDEN, "EuRoC_projection.npz"))
+    g = np.load(os.path.join(GOLDEN, "EuRoC_gf_matchers.npz"))
+    sf = oracle.OracleExtractor().scale_factors
+    b = (0.0, 0.0, 752.0, 480.0)
+    for tag, th in (("th05", 0.5), ("th1", 1.0)):
+        nm, out_mp, out_sc, out_pt, found = oracle.search_by_projection_budget(kl, dl, u, sf, b, p["mps"], p["mp_desc"], th, 0.8, p["taken"], 0)
+        assert nm == int(g[f"{tag}_nmatches"])
+        for a, name in ((out_mp, "out_mp"), (out_sc, "out_score"), (out_pt, "out_point"), (found, "found")):
+            np.testing.assert_array_equal(a, g[f"{tag}_{name}"], err_msg=f"{tag} {name}")
+    nm5, mp5, sc5, _, _ = oracle.search_by_projection_budget(kl, dl, u, sf, b, p["mps"], p["mp_desc"], 1.0, 0.8, p["taken"], 5)
+    assert nm5 == int(g["th1_trip5_nmatches"])
+    np.testing.assert_array_equal(mp5, g["th1_trip5_out_mp"]); np.testing.assert_array_equal(sc5, g["th1_trip5_out_score"])
+    pf = oracle.ProjectionFrame(kl, dl, u, sf, b, None)
+    st = g["th1_cand_start"]
+    for i in range(0, len(p["mps"]), 7):
+        np.testing.assert_array_equal(pf.candidates(p["mps"][i], 1.0), g["th1_cand_idx"][st[i]:st[i + 1]])
+    n1 = (dl[:, 0] >> 2).astype(np.int64); n2 = (dr[:, 0] >> 2).astype(np.int64)
+    for ori in (0, 1):
+        nmk, o12 = oracle.search_by_bow_keyframes(dl, kl["angle"], g["bowkf_valid1"], oracle.make_feature_vector(n1), dr, kr["angle"], g["bowkf_valid2"],
+                                                  oracle.make_feature_vector(n2), 0.75, bool(ori))
+        assert nmk == int(g[f"bowkf_ori{ori}_nmatches"])
+        np.testing.assert_array_equal(o12, g[f"bowkf_ori{ori}_out12"])
