@@ -186,7 +186,7 @@ def load_library():
     L.gfo_search_by_projection_points.argtypes = [vp, vp, vp, vp, i, vp, i, C.POINTER(FrameBoundsC), vp, vp, i, f, f, vp, vp, vp, vp, ip]
     L.gfo_projection_points_prefix.argtypes = [vp, i, i, i, vp, vp, ip]
     L.gfo_projection_candidates.argtypes = [vp, vp, vp, vp, i, vp, i, C.POINTER(FrameBoundsC), vp, vp, i, f, vp, vp, i, ip]
-    L.gfo_match_candidates.argtypes = [vp, i, vp, f, ip]
+    L.gfo_match_candidates.argtypes = [vp, i, vp, i, f, ip]
     L.gfo_search_by_projection_queries.argtypes = [vp, vp, vp, vp, vp, i, C.POINTER(FrameBoundsC), vp, vp, i, C.POINTER(ProjModeC),
                                                    vp, vp, vp, ip]
     L.gfo_map_upload.argtypes = [vp, vp, i]

@@ -136,7 +136,7 @@ public:
             mEntries[k] = (mEntries[k] & 0x7FFFFFFFu) | (gated ? 0x80000000u : 0u);
         }
         int bestDist = 256;
-        const int bestIdx = gfo_match_candidates(mEntries.data(), n, mTaken.data(), mfNNratio, &bestDist);
+        const int bestIdx = gfo_match_candidates(mEntries.data(), n, mTaken.data(), F.N, mfNNratio, &bestDist);
         if (bestIdx < 0) return -1;
         F.mvpMapPoints[bestIdx] = pMP;                           // :143
         F.mvpMatchScore[bestIdx] = bestDist;                     // :145

@@ -1503,12 +1503,15 @@ extern "C" int gfo_projection_candidates(gfo_ctx* c, const gfo_keypoint* kp_un, 
 // observations holds NOW (:113-115), best and second best on strict `<` in the list's order, TH_HIGH, the ratio test between
 // candidates of one level.  Host bookkeeping (a few compares per candidate; no descriptor is read): the caller interleaves it
 // with its own selection loop (Observability::runActiveMapMatching) and updates slot_taken after each match.
-extern "C" int gfo_match_candidates(const uint32_t* cand, int ncand, const uint8_t* slot_taken, float nn_ratio, int* best_dist)
+extern "C" int gfo_match_candidates(const uint32_t* cand, int ncand, const uint8_t* slot_taken, int n, float nn_ratio, int* best_dist)
 {
     int bestDist = 256, bestLevel = -1, bestDist2 = 256, bestLevel2 = -1, bestIdx = -1;
+    if (best_dist) *best_dist = 256;
+    if (ncand < 0 || (ncand > 0 && !cand) || n < 0) return GFO_ERR_INVALID - 16;   // (below every GFO_POINT_* code: not an answer)
     for (int k = 0; k < ncand; k++) {
         const uint32_t e = cand[k];
         const int idx = (int)(e & 0xFFFFu);
+        if (idx >= n) continue;                       // an entry of another frame's table: never a keypoint of this one
         if (slot_taken && slot_taken[idx]) continue;
         if (e & 0x80000000u) continue;
         const int dist = (int)((e >> 20) & 0x1FFu), level = (int)((e >> 16) & 0xFu);

@@ -175,7 +175,7 @@ class ORBmatcher:
         cand = np.ascontiguousarray(cand, np.uint32)
         tk = None if slot_taken is None else np.ascontiguousarray(slot_taken, np.uint8)
         d = C.c_int()
-        r = self._L.gfo_match_candidates(ptr(cand), len(cand), ptr(tk), self.mfNNratio, C.byref(d))
+        r = self._L.gfo_match_candidates(ptr(cand), len(cand), ptr(tk), 65536 if tk is None else len(tk), self.mfNNratio, C.byref(d))
         return r, d.value
 
     # ---- device-resident chain: extract_batch_device -> [stereo_match_batch] -> search_by_projection_batch ----

@@ -326,15 +326,16 @@ int gfo_projection_points_prefix(const int32_t* out_point, int m, int prefix, in
  *   cap               : entries the caller's cand[] holds.  *total = entries of the table; more than cap: GFO_ERR_CAPACITY, cand_start is
  *                       valid, cand[] is not (call again with room for *total; cap = 0 just asks for the size)
  * A point that is not in view, bad, or whose level lies outside the table has no candidates.
- * gfo_match_candidates(cand + cand_start[p], cand_start[p + 1] - cand_start[p], slot_taken, nn_ratio, &dist): slot_taken[i] = 1 where
- * F.mvpMapPoints[i] is set with Observations() > 0 NOW (may be NULL: nothing taken).  Returns the keypoint index the reference's
+ * gfo_match_candidates(cand + cand_start[p], cand_start[p + 1] - cand_start[p], slot_taken, n, nn_ratio, &dist): slot_taken[n], n = the frame's
+ * keypoints: slot_taken[i] = 1 where F.mvpMapPoints[i] is set with Observations() > 0 NOW (may be NULL: nothing taken); an entry whose
+ * keypoint index is not below n is ignored.  Returns the keypoint index the reference's
  * function returns (the caller then stores the point and its *best_dist in the slot, :143-146, and marks slot_taken if the point has
  * observations), or GFO_POINT_NONE / _RATIO / _FAR.  Host arithmetic only; no device call, no descriptor read. */
 int gfo_projection_candidates(gfo_ctx* ctx, const gfo_keypoint* kp_un, const uint8_t* desc, const float* u_right, int n,
                               const float* scale_factors, int nlevels, const gfo_frame_bounds* bounds,
                               const gfo_map_point* mps, const uint8_t* mp_desc, int m, float th,
                               int32_t* cand_start, uint32_t* cand, int cap, int* total);
-int gfo_match_candidates(const uint32_t* cand, int ncand, const uint8_t* slot_taken, float nn_ratio, int* best_dist);
+int gfo_match_candidates(const uint32_t* cand, int ncand, const uint8_t* slot_taken, int n, float nn_ratio, int* best_dist);
 
 /* Device-resident, batched form of SearchByProjection(Frame&, vector<MapPoint*>&, th) -- the chain
  *   gfo_extract_batch_device -> [gfo_stereo_match_batch] -> gfo_search_by_projection_batch

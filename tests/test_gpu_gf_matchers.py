@@ -247,6 +247,10 @@ def test_candidate_table_capacity_and_edges(ext, oracle):
     s1, c1 = mt.GetCandidates(kl[:0], dl[:0], None, sf, gc.BOUNDS, mps, mpd, 1.0)
     assert not s1.any() and len(c1) == 0
     assert mt.MatchCandidates(np.zeros(0, np.uint32), None)[0] == mt.POINT_NONE
+    # an entry that names a keypoint the frame does not have (another frame's table) is ignored, not read
+    foreign = np.array([40000 | (3 << 20), 7 | (9 << 20)], np.uint32)
+    assert mt.MatchCandidates(foreign, np.zeros(100, np.uint8)) == (7, 9)
+    assert mt._L.gfo_match_candidates(None, 3, None, 10, C.c_float(0.8), None) < mt.POINT_FAR
 
 
 def test_golden_good_feature_vectors(ext, oracle):
