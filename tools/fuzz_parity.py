@@ -59,6 +59,33 @@ for it in range(cases):
         continue
     finally:
         ext.close()
+    if it % 3 == 2:
+        # every third case also as a BATCH (beyond the per-frame path: separate blur launch) with the blur forced onto the matrix cores
+        # whatever the width (k_blur_mfma; levels narrower than 64 px send the launch back to the streaming form): every image against the
+        # oracle, every blurred pixel of one of them against the oracle's blur of its own level
+        os.environ["GFO_BLUR_MFMA"] = "1"
+        imgs = [img] + [np.ascontiguousarray(np.roll(img, (7 * k, 13 * k), (0, 1))) for k in range(1, 10)]
+        ext = G.ORBextractor(nf, sf, nl, ini, mn)
+        try:
+            gks, gds = ext.extract_batch(imgs)
+            j = int(rng.integers(0, len(imgs)))
+            oe = O.OracleExtractor(nf, sf, nl, ini, mn)
+            okj, odj = oe(imgs[j])
+            okb = len(gks[j]) == len(okj) and gks[j].tobytes() == okj.tobytes() and (gds[j] == odj).all()
+            for l in range(nl):
+                okb = okb and (ext.debug_blurred_level(l, image=j) == O.gaussian_blur7(oe.level(l))).all()
+            ok0, od0 = O.OracleExtractor(nf, sf, nl, ini, mn)(imgs[0])
+            okb = okb and gks[0].tobytes() == ok0.tobytes() and (gds[0] == od0).all()
+            if not okb:
+                bad += 1
+                print(f"MISMATCH (batch) case {it}: {w}x{h} nf={nf} sf={sf} nl={nl} th={ini}/{mn} kind={kind} image {j}", flush=True)
+        except G.GfoError as e:
+            if e.code != -1:
+                bad += 1
+                print(f"case {it} (batch): {e}", flush=True)
+        finally:
+            ext.close()
+            del os.environ["GFO_BLUR_MFMA"]
     ok, od = O.OracleExtractor(nf, sf, nl, ini, mn)(img)
     same = len(gk) == len(ok) and gk.tobytes() == ok.tobytes() and (gd == od).all()
     if not same:
