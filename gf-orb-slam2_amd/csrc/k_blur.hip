@@ -87,6 +87,8 @@ __device__ __forceinline__ void blur_body_mfma(const GfoGeom& g, const GfoInput&
     constexpr GfoGaussTaps T = gfo_gauss_taps();
     constexpr int S7 = (int)(2 * (T.a + T.b + T.c) + T.d);
     constexpr unsigned TAP7[7] = {T.a, T.b, T.c, T.d, T.c, T.b, T.a};
+    // signed bytes: a tap, and two taps that BORDER_REFLECT_101 folds onto one pixel (taps d and d' with d + d' = 6, 4 or 2), stay below 128
+    static_assert(T.d <= 127 && 2 * T.c <= 127 && T.b + T.d <= 127 && 2 * T.b <= 127 && T.a + T.c <= 127, "folded taps must fit a signed byte");
     int level = 0, base = 0;
     for (;;) {   // (scalar: a handful of levels)
         const int nb = blur_mf_blocks(g.lv[level].w, g.lv[level].h);
@@ -234,8 +236,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(GFO_BLUR_MF
 #endif
 }
 
-// the matrix-core form needs every level's interior to hold a 16-column strip and a 32-pixel load window, the build's single rounding
-// (GFO_OCV_BLUR_ROUND 0) and taps that fit the signed-byte arithmetic: otherwise the streaming form
+// the matrix-core form needs every level to be at least one 64-pixel window wide, a blurred plane whose pitch covers whole 64-column strips
+// (the last strip's store runs into the padding), and the build's single rounding (GFO_OCV_BLUR_ROUND 0; any taps of gfo_internal.h fit
+// the signed-byte arithmetic: a row sum <= 257, two folded taps <= 127): otherwise the streaming form for the whole launch
 static int blur_mfma_blocks(const gfo_ctx* c)
 {
 #if GFO_OCV_BLUR_ROUND == 1
