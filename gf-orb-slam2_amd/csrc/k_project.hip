@@ -1341,6 +1341,23 @@ extern "C" int gfo_search_by_projection_queries(gfo_ctx* c, const gfo_keypoint* 
     return pj_queries(c, kp_un, desc, u_right, kp_angle, n, fb, queries, q_desc, m, mode, kp_taken, out_mp, out_score, nmatches, nullptr);
 }
 
+// The query form with what every query did at its turn (before any rotation check).  Queries that block nothing (flags bit 2 clear)
+// against a frame whose slots only count as they were on entry are INDEPENDENT best-match searches: the form of ORBmatcher::Fuse
+// (ORBmatcher.cc:937-1212: best keypoint of the predicted levels in a window, TH_LOW, no ratio) and of either direction of SearchBySim3
+// (:1214-1438: TH_HIGH), whose side effects stay with the caller.
+extern "C" int gfo_search_by_projection_queries_points(gfo_ctx* c, const gfo_keypoint* kp_un, const uint8_t* desc,
+                                                       const float* u_right, const float* kp_angle, int n,
+                                                       const gfo_frame_bounds* fb, const gfo_proj_query* queries,
+                                                       const uint8_t* q_desc, int m, const gfo_proj_mode* mode,
+                                                       const uint8_t* kp_taken, int32_t* out_q, int32_t* out_score, int32_t* out_point,
+                                                       int* nmatches)
+{
+    if (!c) return GFO_ERR_INVALID;
+    if (!out_point && m > 0) return pj_fail(c, GFO_ERR_INVALID, "gfo_search_by_projection_queries_points: null out_point");
+    if (mode && mode->max_matches > 0) return pj_fail(c, GFO_ERR_INVALID, "gfo_search_by_projection_queries_points: no feature budget in this form");
+    return pj_queries(c, kp_un, desc, u_right, kp_angle, n, fb, queries, q_desc, m, mode, kp_taken, out_q, out_score, nmatches, out_point);
+}
+
 // ORBmatcher::SearchByProjection(Frame&, const vector<MapPoint*>&, th): every map point becomes a query with
 // r = RadiusByViewingCos(viewCos) (* th), window r * scale[level], levels [level-1, level] (ORBmatcher.cc:171-180).
 static void pj_queries_of_map_points(const gfo_map_point* mps, int m, const float* sf, int nlevels, float th, gfo_proj_query* q)

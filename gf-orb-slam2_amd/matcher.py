@@ -281,6 +281,29 @@ class ORBmatcher:
                                                                            ptr(out_q), ptr(out_s), C.byref(nm)))
         return nm.value, out_q[:n], out_s[:n]
 
+    def SearchByProjectionQueriesPoints(self, keys_un, desc, u_right, kp_angle, bounds, queries, q_desc, use_ratio=False, th_dist=None,
+                                        kp_taken=None):
+        """SearchByProjectionQueries + what every query did at its turn (gfo_search_by_projection_queries_points).  With non-blocking
+        queries: the independent best-match searches inside ORBmatcher::Fuse / SearchBySim3.
+        Returns (nmatches, out_query, out_score, out_point)."""
+        kp = np.ascontiguousarray(keys_un, KEYPOINT_DTYPE)
+        desc = np.ascontiguousarray(desc, np.uint8)
+        q = np.ascontiguousarray(queries, PROJ_QUERY_DTYPE)
+        qd = np.ascontiguousarray(q_desc, np.uint8)
+        n, m = len(kp), len(q)
+        u_right = None if u_right is None else np.ascontiguousarray(u_right, np.float32)
+        kp_angle = None if kp_angle is None else np.ascontiguousarray(kp_angle, np.float32)
+        kp_taken = None if kp_taken is None else np.ascontiguousarray(kp_taken, np.uint8)
+        fb = FrameBoundsC(*bounds)
+        mode = ProjModeC(1 if use_ratio else 0, self.mfNNratio, self.TH_HIGH if th_dist is None else th_dist,
+                         1 if self.mbCheckOrientation else 0, 0)
+        out_q = np.full(max(n, 1), -1, np.int32); out_s = np.zeros(max(n, 1), np.int32); out_p = np.full(max(m, 1), -1, np.int32)
+        nm = C.c_int()
+        check(self._L, self._ctx, self._L.gfo_search_by_projection_queries_points(self._ctx, ptr(kp), ptr(desc), ptr(u_right), ptr(kp_angle), n,
+                                                                                  C.byref(fb), ptr(q), ptr(qd), m, C.byref(mode), ptr(kp_taken),
+                                                                                  ptr(out_q), ptr(out_s), ptr(out_p), C.byref(nm)))
+        return nm.value, out_q[:n], out_s[:n], out_p[:m]
+
 
 class ORBVocabulary:
     """DBoW2 TemplatedVocabulary<FORB> as far as Frame::ComputeBoW needs it (Frame.cc:661-668): a flattened tree

@@ -337,6 +337,18 @@ int gfo_projection_candidates(gfo_ctx* ctx, const gfo_keypoint* kp_un, const uin
                               int32_t* cand_start, uint32_t* cand, int cap, int* total);
 int gfo_match_candidates(const uint32_t* cand, int ncand, const uint8_t* slot_taken, int n, float nn_ratio, int* best_dist);
 
+/* gfo_search_by_projection_queries that also reports what every QUERY did at its turn (out_point[m]: keypoint | distance << 16, or
+ * GFO_POINT_NONE / _RATIO / _FAR; before any rotation check; mode->max_matches must be 0).  With queries that block nothing (flags bit 2
+ * clear) every query is an independent best-match search over the frame as it was on entry -- the search inside ORBmatcher::Fuse
+ * (src/ORBmatcher.cc:937-1212: window, the two predicted levels, TH_LOW) and inside either direction of SearchBySim3 (:1214-1438),
+ * whose side effects (Replace / AddObservation, the mutual-agreement pass) stay with the caller. */
+int gfo_search_by_projection_queries_points(gfo_ctx* ctx, const gfo_keypoint* kp_un, const uint8_t* desc,
+                                            const float* u_right, const float* kp_angle, int n,
+                                            const gfo_frame_bounds* bounds, const gfo_proj_query* queries,
+                                            const uint8_t* q_desc, int m, const gfo_proj_mode* mode,
+                                            const uint8_t* kp_taken, int32_t* out_q, int32_t* out_score,
+                                            int32_t* out_point, int* nmatches);
+
 /* Device-resident, batched form of SearchByProjection(Frame&, vector<MapPoint*>&, th) -- the chain
  *   gfo_extract_batch_device -> [gfo_stereo_match_batch] -> gfo_search_by_projection_batch
  * never leaves the GPU: keypoints, descriptors (and mvuRight) are read where the extractor / stereo matcher

@@ -1616,6 +1616,10 @@ int orc_search_by_bow_keyframes(const uint8_t* desc1, const float* angle1, const
  * -- ORBmatcher.cc:1440-1593 -- on pre-projected queries; with use_ratio it is the map-point overload
  * (:155-241) again (used to cross-check the two oracle functions against each other).
  * ---------------------------------------------------------------------------------------- */
+/* optional per-QUERY record of the call below (orc_search_by_projection_queries_points): what query iq did at its turn, before any
+ * rotation check -- keypoint | distance << 16, -1 inactive / no keypoint in its window, -2 ratio test, -3 nothing usable within th_dist */
+static int* g_query_outcome = NULL;
+
 int orc_search_by_projection_queries(const orc_keypoint* kp, const uint8_t* desc, const float* u_right,
                                      const float* kp_angle, int n, const orc_frame_bounds* fb,
                                      const orc_proj_query* q, const uint8_t* q_desc, int m, const orc_proj_mode* mode,
@@ -1637,11 +1641,13 @@ int orc_search_by_projection_queries(const orc_keypoint* kp, const uint8_t* desc
     }
     const float factor = 1.0f / HISTO_LENGTH;
     int nmatches = 0;
+    if (g_query_outcome) for (int iq = 0; iq < m; iq++) g_query_outcome[iq] = -1;
     for (int iq = 0; iq < m; iq++) {
         const orc_proj_query* p = &q[iq];
         if (!(p->flags & 1)) continue;
         const int nidx = grid_query(&g, kp, fb, p->u, p->v, p->radius, p->min_level, p->max_level, idx, n);
         if (nidx == 0) continue;
+        if (g_query_outcome) g_query_outcome[iq] = -3;
         int bestDist = 256, bestLevel = -1, bestDist2 = 256, bestLevel2 = -1, bestIdx = -1;
         for (int k = 0; k < nidx; k++) {
             const int i = idx[k];
@@ -1661,7 +1667,11 @@ int orc_search_by_projection_queries(const orc_keypoint* kp, const uint8_t* desc
             }
         }
         if (bestIdx >= 0 && bestDist <= mode->th_dist) { /* th_dist < 256 in every caller of the reference: no candidate leaves bestDist = 256 */
-            if (mode->use_ratio && bestLevel == bestLevel2 && (float)bestDist > mode->nn_ratio * (float)bestDist2) continue;
+            if (mode->use_ratio && bestLevel == bestLevel2 && (float)bestDist > mode->nn_ratio * (float)bestDist2) {
+                if (g_query_outcome) g_query_outcome[iq] = -2;
+                continue;
+            }
+            if (g_query_outcome) g_query_outcome[iq] = bestIdx | (bestDist << 16);
             out_q[bestIdx] = iq;
             out_score[bestIdx] = bestDist;
             blocked[bestIdx] = (p->flags & 4) ? 1 : 0;
@@ -1693,6 +1703,19 @@ int orc_search_by_projection_queries(const orc_keypoint* kp, const uint8_t* desc
     free(idx); free(blocked); free(hist_kp); free(hist_bin);
     grid_free(&g);
     return nmatches;
+}
+
+/* ... the same call, also reporting what every query did at its turn (a query that blocks nothing -- flags bit 2 clear -- and finds the
+ * frame's slots as they were on entry is ONE independent best-match search: the form ORBmatcher::Fuse and SearchBySim3 use) */
+int orc_search_by_projection_queries_points(const orc_keypoint* kp, const uint8_t* desc, const float* u_right,
+                                            const float* kp_angle, int n, const orc_frame_bounds* fb,
+                                            const orc_proj_query* q, const uint8_t* q_desc, int m, const orc_proj_mode* mode,
+                                            const uint8_t* kp_taken, int* out_q, int* out_score, int* out_point)
+{
+    g_query_outcome = out_point;
+    const int nm = orc_search_by_projection_queries(kp, desc, u_right, kp_angle, n, fb, q, q_desc, m, mode, kp_taken, out_q, out_score);
+    g_query_outcome = NULL;
+    return nm;
 }
 
 /* ------------------------------------------------------------------------------------------

@@ -205,6 +205,11 @@ int orc_search_by_projection_queries(const orc_keypoint* kp_un, const uint8_t* d
                                      const float* kp_angle, int n, const orc_frame_bounds* fb,
                                      const orc_proj_query* q, const uint8_t* q_desc, int m, const orc_proj_mode* mode,
                                      const uint8_t* kp_taken, int* out_q, int* out_score);
+/* the same, with what every query did at its turn: keypoint | distance << 16, -1 / -2 / -3 as gfo.h's GFO_POINT_* (before any rotation check) */
+int orc_search_by_projection_queries_points(const orc_keypoint* kp, const uint8_t* desc, const float* u_right,
+                                            const float* kp_angle, int n, const orc_frame_bounds* fb,
+                                            const orc_proj_query* q, const uint8_t* q_desc, int m, const orc_proj_mode* mode,
+                                            const uint8_t* kp_taken, int* out_q, int* out_score, int* out_point);
 
 /* ORBmatcher::SearchByProjection(Frame& Cur, KeyFrame*, const set<MapPoint*>& sAlreadyFound, th, ORBdist) --
  * ORBmatcher.cc:1595-1721 on pre-projected map points: any set keypoint is skipped, no mvuRight gate, no ratio.

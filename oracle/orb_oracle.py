@@ -682,6 +682,29 @@ def search_by_projection_queries(kp_un, desc, u_right, kp_angle, bounds, queries
     return nm, out_q[:n], out_s[:n]
 
 
+def search_by_projection_queries_points(kp_un, desc, u_right, kp_angle, bounds, queries, q_desc, use_ratio, nn_ratio, th_dist,
+                                        check_orientation, kp_taken=None):
+    """search_by_projection_queries + what every query did at its turn (keypoint | distance << 16, -1 / -2 / -3)."""
+    kp_un = np.ascontiguousarray(kp_un, dtype=KEYPOINT_DTYPE)
+    desc = np.ascontiguousarray(desc, dtype=np.uint8)
+    queries = np.ascontiguousarray(queries, dtype=PROJ_QUERY_DTYPE)
+    q_desc = np.ascontiguousarray(q_desc, dtype=np.uint8)
+    n, m = len(kp_un), len(queries)
+    u_right = None if u_right is None else np.ascontiguousarray(u_right, np.float32)
+    kp_angle = None if kp_angle is None else np.ascontiguousarray(kp_angle, np.float32)
+    kp_taken = None if kp_taken is None else np.ascontiguousarray(kp_taken, np.uint8)
+    fb = FrameBounds(*bounds)
+    mode = ProjMode(1 if use_ratio else 0, nn_ratio, th_dist, 1 if check_orientation else 0)
+    out_q = np.zeros(max(n, 1), np.int32); out_s = np.zeros(max(n, 1), np.int32); out_p = np.zeros(max(m, 1), np.int32)
+    L = lib()
+    vp = C.c_void_p
+    L.orc_search_by_projection_queries_points.argtypes = [vp, vp, vp, vp, C.c_int, C.POINTER(FrameBounds), vp, vp, C.c_int,
+                                                          C.POINTER(ProjMode), vp, vp, vp, vp]
+    nm = L.orc_search_by_projection_queries_points(_p(kp_un), _p(desc), _p(u_right), _p(kp_angle), n, C.byref(fb), _p(queries),
+                                                   _p(q_desc), m, C.byref(mode), _p(kp_taken), _p(out_q), _p(out_s), _p(out_p))
+    return nm, out_q[:n], out_s[:n], out_p[:m]
+
+
 def search_by_projection_kf(kp_un, desc, kp_angle, bounds, queries, q_desc, orb_dist, check_orientation, kp_set=None):
     """ORBmatcher::SearchByProjection(CurrentFrame, KeyFrame*, sAlreadyFound, th, ORBdist), ORBmatcher.cc:1595-1721,
     on pre-projected map points (literal statement: any set keypoint is skipped)."""

@@ -311,3 +311,47 @@ def test_candidate_at_distance_256_is_no_candidate(ext, oracle):
         assert ref[0] == (1 if accepted else 0), "the oracle itself must follow :186-231"
         assert got[0] == ref[0]
         np.testing.assert_array_equal(got[1], ref[1]); np.testing.assert_array_equal(got[2], ref[2])
+
+
+@pytest.mark.parametrize("seed,th,fwd,bwd,ori,ratio", [(1, 7.0, False, False, True, False), (2, 15.0, True, False, True, True), (3, 15.0, False, True, False, True)])
+def test_query_form_reports_what_every_query_did(ext, oracle, seed, th, fwd, bwd, ori, ratio):
+    """gfo_search_by_projection_queries_points: the frame-to-frame cases again, with every query's own outcome (the keypoint and distance it took
+    at its turn, or why it took none) -- before the rotation check, which only touches the slots."""
+    import gf_orb_slam2_amd as G
+    kl, dl, u = _frame(oracle)
+    q, qd = _frame_queries(oracle, kl, dl, seed, th, fwd, bwd)
+    taken = (np.random.default_rng(seed).random(len(kl)) < 0.1).astype(np.uint8)
+    b = (0.0, 0.0, 752.0, 480.0)
+    ref = oracle.search_by_projection_queries_points(kl, dl, u, kl["angle"], b, q, qd, ratio, 0.9, 100, ori, taken)
+    got = G.ORBmatcher(0.9, ori, extractor=ext).SearchByProjectionQueriesPoints(kl, dl, u, kl["angle"], b, q, qd, use_ratio=ratio, kp_taken=taken)
+    assert got[0] == ref[0] and ref[0] > 300
+    np.testing.assert_array_equal(got[1], ref[1])
+    np.testing.assert_array_equal(got[3], ref[3])
+    assert (ref[3] == -1).any() and (ref[3] == -3).any() and ((ref[3] == -2).any() == ratio or not ratio)
+
+
+def test_non_blocking_queries_are_independent_searches(ext, oracle):
+    """The search inside ORBmatcher::Fuse (ORBmatcher.cc:937-1212): every map point looks for its best keypoint of the two predicted levels in
+    a window, TH_LOW, no ratio test, and NOTHING it finds hides a keypoint from the next point.  As queries that block nothing: each query's
+    outcome is what it would be alone, whatever the order -- checked by shuffling the queries and against a single-query call per sample."""
+    import gf_orb_slam2_amd as G
+    kl, dl, u = _frame(oracle)
+    q, qd = _frame_queries(oracle, kl, dl, 9, 3.0)
+    q["flags"] &= ~4                                  # nothing blocks
+    lev = kl["octave"][np.random.default_rng(9).integers(0, len(kl), len(q))]
+    q["min_level"], q["max_level"] = lev - 1, lev     # kpLevel < nPredictedLevel - 1 || kpLevel > nPredictedLevel: skipped (:1014)
+    b = (0.0, 0.0, 752.0, 480.0)
+    mt = G.ORBmatcher(0.9, False, extractor=ext)
+    ref = oracle.search_by_projection_queries_points(kl, dl, None, kl["angle"], b, q, qd, False, 0.9, 50, False, None)
+    got = mt.SearchByProjectionQueriesPoints(kl, dl, None, kl["angle"], b, q, qd, use_ratio=False, th_dist=50)
+    np.testing.assert_array_equal(got[3], ref[3])
+    assert (got[3] >= 0).sum() > 150
+    perm = np.random.default_rng(1).permutation(len(q))
+    shuffled = mt.SearchByProjectionQueriesPoints(kl, dl, None, kl["angle"], b, q[perm], qd[perm], use_ratio=False, th_dist=50)
+    np.testing.assert_array_equal(shuffled[3], got[3][perm])
+    for i in (0, 17, 400, 1234):
+        alone = mt.SearchByProjectionQueriesPoints(kl, dl, None, kl["angle"], b, q[i:i + 1], qd[i:i + 1], use_ratio=False, th_dist=50)
+        assert alone[3][0] == got[3][i]
+    # several points may name the same keypoint; the slot table keeps the last of them (Fuse decides per point what to do with it)
+    k = got[3][got[3] >= 0] & 0xFFFF
+    assert len(np.unique(k)) < len(k)
