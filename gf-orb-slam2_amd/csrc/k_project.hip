@@ -1342,8 +1342,8 @@ extern "C" int gfo_search_by_projection_queries(gfo_ctx* c, const gfo_keypoint* 
 }
 
 // The query form with what every query did at its turn (before any rotation check).  Queries that block nothing (flags bit 2 clear)
-// against a frame whose slots only count as they were on entry are INDEPENDENT best-match searches: the form of ORBmatcher::Fuse
-// (ORBmatcher.cc:937-1212: best keypoint of the predicted levels in a window, TH_LOW, no ratio) and of either direction of SearchBySim3
+// against a frame whose slots only count as they were on entry are INDEPENDENT best-match searches: the form of ORBmatcher::Fuse(KF, Scw, ..)
+// (ORBmatcher.cc:1089-1212: best keypoint of the predicted levels in a window, TH_LOW, no ratio) and of either direction of SearchBySim3
 // (:1214-1438: TH_HIGH), whose side effects stay with the caller.
 extern "C" int gfo_search_by_projection_queries_points(gfo_ctx* c, const gfo_keypoint* kp_un, const uint8_t* desc,
                                                        const float* u_right, const float* kp_angle, int n,

@@ -339,9 +339,10 @@ int gfo_match_candidates(const uint32_t* cand, int ncand, const uint8_t* slot_ta
 
 /* gfo_search_by_projection_queries that also reports what every QUERY did at its turn (out_point[m]: keypoint | distance << 16, or
  * GFO_POINT_NONE / _RATIO / _FAR; before any rotation check; mode->max_matches must be 0).  With queries that block nothing (flags bit 2
- * clear) every query is an independent best-match search over the frame as it was on entry -- the search inside ORBmatcher::Fuse
- * (src/ORBmatcher.cc:937-1212: window, the two predicted levels, TH_LOW) and inside either direction of SearchBySim3 (:1214-1438),
- * whose side effects (Replace / AddObservation, the mutual-agreement pass) stay with the caller. */
+ * clear) every query is an independent best-match search over the frame as it was on entry -- the search inside
+ * ORBmatcher::Fuse(KF, Scw, ...) (src/ORBmatcher.cc:1089-1212: window, the two predicted levels, TH_LOW) and inside either direction of
+ * SearchBySim3 (:1214-1438), whose side effects (Replace / AddObservation, the mutual-agreement pass) stay with the caller.
+ * (Fuse(KF, MapPoints, th), :937-1087, gates its candidates by reprojection error before picking the best: not this form.) */
 int gfo_search_by_projection_queries_points(gfo_ctx* ctx, const gfo_keypoint* kp_un, const uint8_t* desc,
                                             const float* u_right, const float* kp_angle, int n,
                                             const gfo_frame_bounds* bounds, const gfo_proj_query* queries,

@@ -331,7 +331,7 @@ def test_query_form_reports_what_every_query_did(ext, oracle, seed, th, fwd, bwd
 
 
 def test_non_blocking_queries_are_independent_searches(ext, oracle):
-    """The search inside ORBmatcher::Fuse (ORBmatcher.cc:937-1212): every map point looks for its best keypoint of the two predicted levels in
+    """The search inside ORBmatcher::Fuse(KF, Scw, ...) (ORBmatcher.cc:1089-1212): every map point looks for its best keypoint of the two predicted levels in
     a window, TH_LOW, no ratio test, and NOTHING it finds hides a keypoint from the next point.  As queries that block nothing: each query's
     outcome is what it would be alone, whatever the order -- checked by shuffling the queries and against a single-query call per sample."""
     import gf_orb_slam2_amd as G
@@ -339,7 +339,7 @@ def test_non_blocking_queries_are_independent_searches(ext, oracle):
     q, qd = _frame_queries(oracle, kl, dl, 9, 3.0)
     q["flags"] &= ~4                                  # nothing blocks
     lev = kl["octave"][np.random.default_rng(9).integers(0, len(kl), len(q))]
-    q["min_level"], q["max_level"] = lev - 1, lev     # kpLevel < nPredictedLevel - 1 || kpLevel > nPredictedLevel: skipped (:1014)
+    q["min_level"], q["max_level"] = lev - 1, lev     # kpLevel < nPredictedLevel - 1 || kpLevel > nPredictedLevel: skipped (:1172)
     b = (0.0, 0.0, 752.0, 480.0)
     mt = G.ORBmatcher(0.9, False, extractor=ext)
     ref = oracle.search_by_projection_queries_points(kl, dl, None, kl["angle"], b, q, qd, False, 0.9, 50, False, None)
