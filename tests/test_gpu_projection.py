@@ -339,7 +339,7 @@ def test_non_blocking_queries_are_independent_searches(ext, oracle):
     q, qd = _frame_queries(oracle, kl, dl, 9, 3.0)
     q["flags"] &= ~4                                  # nothing blocks
     lev = kl["octave"][np.random.default_rng(9).integers(0, len(kl), len(q))]
-    q["min_level"], q["max_level"] = lev - 1, lev     # kpLevel < nPredictedLevel - 1 || kpLevel > nPredictedLevel: skipped (:1178)
+    q["min_level"], q["max_level"] = lev - 1, lev     # kpLevel < nPredictedLevel - 1 || kpLevel > nPredictedLevel: skipped (:1179)
     b = (0.0, 0.0, 752.0, 480.0)
     mt = G.ORBmatcher(0.9, False, extractor=ext)
     ref = oracle.search_by_projection_queries_points(kl, dl, None, kl["angle"], b, q, qd, False, 0.9, 50, False, None)
