@@ -12,6 +12,8 @@
 //   GFO_ADAPTER_PROJ_KF       ORBmatcher::SearchByProjection(Cur, KF*, sAlreadyFound, th, dist) src/ORBmatcher.cc:1595-1721
 //   GFO_ADAPTER_BOW           ORBmatcher::SearchByBoW(KeyFrame*, Frame&, vector<MapPoint*>&)    src/ORBmatcher.cc:270-404
 //   GFO_ADAPTER_BOW_KF        ORBmatcher::SearchByBoW(KeyFrame*, KeyFrame*, vector<MapPoint*>&) src/ORBmatcher.cc:635-768
+//   GFO_ADAPTER_PROJ_SCW      ORBmatcher::SearchByProjection(KeyFrame*, Scw, points, matched, th)  src/ORBmatcher.cc:406-518
+//   GFO_ADAPTER_FUSE_SCW      ORBmatcher::Fuse(KeyFrame*, Scw, points, th, vpReplacePoint)         src/ORBmatcher.cc:1089-1212
 //   GFO_ADAPTER_COMPUTE_BOW   Frame::ComputeBoW()                                               src/Frame.cc:661-668
 //
 // Each body flattens the reference's objects into plain arrays, calls the C ABI (include/gfo.h) and writes the
@@ -28,6 +30,8 @@
 #define GFO_ADAPTER_PROJ_KF
 #define GFO_ADAPTER_BOW
 #define GFO_ADAPTER_BOW_KF
+#define GFO_ADAPTER_PROJ_SCW
+#define GFO_ADAPTER_FUSE_SCW
 #define GFO_ADAPTER_COMPUTE_BOW
 #endif
 
@@ -580,6 +584,155 @@ int ORBmatcher::SearchByBoW(KeyFrame* pKF, Frame& F, std::vector<MapPoint*>& vpM
     for (int i = 0; i < nF; i++)
         if (out[i] >= 0) vpMapPointMatches[i] = vpMapPointsKF[out[i]];      // :343
     return nmatches;
+}
+#endif
+
+// ---------------------------------------------------------------------------------------------------------------
+#if defined(GFO_ADAPTER_PROJ_SCW) || defined(GFO_ADAPTER_FUSE_SCW)
+namespace
+{
+// Loop closing projects candidate map points into a keyframe under a similarity Scw (ORBmatcher.cc:406-518 and :1089-1212 share this
+// part word for word, but for the literal `1 / z` against `1.0 / z`): the decomposition (:415-419 = :1098-1102) and, per point, the
+// visibility chain up to the search window (:441-477 = :1124-1161).  All of it is the reference's own cv::Mat arithmetic, on the host.
+struct ScwPose {
+    cv::Mat Rcw, tcw, Ow;
+    explicit ScwPose(const cv::Mat& Scw)
+    {
+        cv::Mat sRcw = Scw.rowRange(0, 3).colRange(0, 3);
+        const float scw = sqrt(sRcw.row(0).dot(sRcw.row(0)));
+        Rcw = sRcw / scw;
+        tcw = Scw.rowRange(0, 3).col(3) / scw;
+        Ow = -Rcw.t() * tcw;
+    }
+};
+// false: the reference `continue`s.  DOUBLE_INV: Fuse writes `1.0 / z` (a double quotient rounded to float), SearchByProjection `1 / z`
+template <bool DOUBLE_INV, class TH>
+bool project_under_scw(KeyFrame* pKF, MapPoint* pMP, const ScwPose& S, const TH th, gfo_proj_query& e)
+{
+    const float &fx = pKF->fx, &fy = pKF->fy, &cx = pKF->cx, &cy = pKF->cy;
+    cv::Mat p3Dw = pMP->GetWorldPos();
+    cv::Mat p3Dc = S.Rcw * p3Dw + S.tcw;
+    if (p3Dc.at<float>(2) < 0.0f) return false;                       // depth must be positive
+    const float invz = DOUBLE_INV ? (float)(1.0 / p3Dc.at<float>(2)) : 1 / p3Dc.at<float>(2);
+    const float x = p3Dc.at<float>(0) * invz;
+    const float y = p3Dc.at<float>(1) * invz;
+    const float u = fx * x + cx;
+    const float v = fy * y + cy;
+    if (!pKF->IsInImage(u, v)) return false;
+    const float maxDistance = pMP->GetMaxDistanceInvariance();
+    const float minDistance = pMP->GetMinDistanceInvariance();
+    cv::Mat PO = p3Dw - S.Ow;
+    const float dist = cv::norm(PO);
+    if (dist < minDistance || dist > maxDistance) return false;       // inside the scale invariance region of the point
+    cv::Mat Pn = pMP->GetNormal();
+    if (PO.dot(Pn) < 0.5 * dist) return false;                        // viewing angle below 60 degrees
+    const int nPredictedLevel = pMP->PredictScale(dist, pKF);
+    e.u = u;
+    e.v = v;
+    e.ur = 0.f;
+    e.radius = th * pKF->mvScaleFactors[nPredictedLevel];
+    e.min_level = nPredictedLevel - 1;                                // kpLevel < nPredictedLevel - 1 || kpLevel > nPredictedLevel: skipped
+    e.max_level = nPredictedLevel;
+    e.angle = 0.f;
+    e.flags = 1;
+    return true;
+}
+}  // namespace
+#endif
+
+#ifdef GFO_ADAPTER_PROJ_SCW
+// LoopClosing::ComputeSim3 / CorrectLoop's matcher (LoopClosing.cc:397): map points seen from the loop candidates, projected into the
+// current keyframe; a keypoint that holds a match (vpMatched) is skipped and every new match takes its keypoint (:487, :511), no ratio test,
+// TH_LOW.  The calling thread's own device context (no Frame in the call).
+int ORBmatcher::SearchByProjection(KeyFrame* pKF, cv::Mat Scw, const std::vector<MapPoint*>& vpPoints, std::vector<MapPoint*>& vpMatched, int th)
+{
+    const ScwPose S(Scw);
+    std::set<MapPoint*> spAlreadyFound(vpMatched.begin(), vpMatched.end());     // (a snapshot: matches made below do not enter it, :422)
+    spAlreadyFound.erase(static_cast<MapPoint*>(NULL));
+    std::vector<gfo_proj_query> q;
+    std::vector<MapPoint*> qmp;
+    for (int iMP = 0, iendMP = (int)vpPoints.size(); iMP < iendMP; iMP++) {
+        MapPoint* pMP = vpPoints[iMP];
+        if (pMP->isBad() || spAlreadyFound.count(pMP)) continue;
+        gfo_proj_query e;
+        if (!project_under_scw<false>(pKF, pMP, S, th, e)) continue;
+        e.flags = 1 | 4;                                                // vpMatched[bestIdx] = pMP hides the keypoint from the points behind
+        q.push_back(e);
+        qmp.push_back(pMP);
+    }
+    const int M = (int)q.size(), N = pKF->N;
+    if ((int)vpMatched.size() < N) return 0;
+    cv::Mat qDesc(M > 0 ? M : 1, 32, CV_8U);
+    for (int i = 0; i < M; i++) descriptor_row(qmp[i], qDesc, i);
+    std::vector<uint8_t> taken(N);
+    for (int i = 0; i < N; i++) taken[i] = vpMatched[i] != NULL;        // :487
+    gfo_frame_bounds fb = {(float)pKF->mnMinX, (float)pKF->mnMinY, (float)pKF->mnMaxX, (float)pKF->mnMaxY};
+    gfo_proj_mode mode = {0, 0.f, TH_LOW, 0, 0};
+    std::vector<int32_t> outQ(N > 0 ? N : 1), outScore(N > 0 ? N : 1);
+    int nmatches = 0;
+    cv::Mat keep;
+    gfo_ctx* c = gfo_context_pin_thread();
+    const int rc = gfo_search_by_projection_queries(c, as_gfo(pKF->mvKeysUn), rows32(pKF->mDescriptors, keep), NULL, NULL, N, &fb, q.data(),
+                                                    qDesc.data, M, &mode, taken.data(), outQ.data(), outScore.data(), &nmatches);
+    if (rc != GFO_OK) report(c, "SearchByProjection(KF, Scw)");
+    gfo_context_unpin_thread(c);
+    if (rc != GFO_OK) return 0;
+    for (int i = 0; i < N; i++)
+        if (outQ[i] >= 0) vpMatched[i] = qmp[outQ[i]];                 // :511
+    return nmatches;
+}
+#endif
+
+#ifdef GFO_ADAPTER_FUSE_SCW
+// LoopClosing::SearchAndFuse's matcher (LoopClosing.cc:621): the loop's map points projected into a keyframe of the current neighbourhood.
+// Every point looks for its best keypoint of the two predicted levels on its own -- nothing it finds hides a keypoint from the next point
+// (gfo_search_by_projection_queries_points with queries that block nothing) -- and what is done with the find (:1194-1208) happens here,
+// point after point in the vector's order, against the keyframe as the points before have left it.
+int ORBmatcher::Fuse(KeyFrame* pKF, cv::Mat Scw, const std::vector<MapPoint*>& vpPoints, float th, std::vector<MapPoint*>& vpReplacePoint)
+{
+    const ScwPose S(Scw);
+    const std::set<MapPoint*> spAlreadyFound = pKF->GetMapPoints();
+    const int nPoints = (int)vpPoints.size();
+    std::vector<gfo_proj_query> q;
+    std::vector<int> qpoint;
+    for (int iMP = 0; iMP < nPoints; iMP++) {
+        MapPoint* pMP = vpPoints[iMP];
+        if (pMP->isBad() || spAlreadyFound.count(pMP)) continue;
+        gfo_proj_query e;
+        if (!project_under_scw<true>(pKF, pMP, S, th, e)) continue;
+        q.push_back(e);
+        qpoint.push_back(iMP);
+    }
+    const int M = (int)q.size(), N = pKF->N;
+    cv::Mat qDesc(M > 0 ? M : 1, 32, CV_8U);
+    for (int i = 0; i < M; i++) descriptor_row(vpPoints[qpoint[i]], qDesc, i);
+    gfo_frame_bounds fb = {(float)pKF->mnMinX, (float)pKF->mnMinY, (float)pKF->mnMaxX, (float)pKF->mnMaxY};
+    gfo_proj_mode mode = {0, 0.f, TH_LOW, 0, 0};
+    std::vector<int32_t> outQ(N > 0 ? N : 1), outScore(N > 0 ? N : 1), outPoint(M > 0 ? M : 1);
+    int nmatches = 0;
+    cv::Mat keep;
+    gfo_ctx* c = gfo_context_pin_thread();
+    const int rc = gfo_search_by_projection_queries_points(c, as_gfo(pKF->mvKeysUn), rows32(pKF->mDescriptors, keep), NULL, NULL, N, &fb, q.data(),
+                                                           qDesc.data, M, &mode, NULL, outQ.data(), outScore.data(), outPoint.data(), &nmatches);
+    if (rc != GFO_OK) report(c, "Fuse(KF, Scw)");
+    gfo_context_unpin_thread(c);
+    if (rc != GFO_OK) return 0;
+    int nFused = 0;
+    for (int i = 0; i < M; i++) {
+        if (outPoint[i] < 0) continue;                                  // bestDist > TH_LOW, or nothing in the window
+        const int bestIdx = outPoint[i] & 0xFFFF;
+        const int iMP = qpoint[i];
+        MapPoint* pMP = vpPoints[iMP];
+        MapPoint* pMPinKF = pKF->GetMapPoint(bestIdx);                  // :1196: as the points in front of this one have left it
+        if (pMPinKF) {
+            if (!pMPinKF->isBad()) vpReplacePoint[iMP] = pMPinKF;
+        } else {
+            pMP->AddObservation(pKF, bestIdx);
+            pKF->AddMapPoint(pMP, bestIdx);
+        }
+        nFused++;
+    }
+    return nFused;
 }
 #endif
 

@@ -93,6 +93,16 @@ public:
         for (int i = 0; i < rows; i++) for (int j = 0; j < cols; j++) m.at<float>(j, i) = at<float>(i, j);
         return m;
     }
+    // (CV_32F only) the sum of products in double, as cv::Mat::dot returns it
+    double dot(const Mat& b) const
+    {
+        need32("dot"); b.need32("dot");
+        if (rows * cols != b.rows * b.cols) { fprintf(stderr, "[cv stand-in] dot: size mismatch\n"); abort(); }
+        double s = 0;
+        const bool av = rows >= cols, bv = b.rows >= b.cols;     // vectors either way round
+        for (int i = 0; i < rows * cols; i++) s += (double)(av ? at<float>(i, 0) : at<float>(0, i)) * (double)(bv ? b.at<float>(i, 0) : b.at<float>(0, i));
+        return s;
+    }
     Mat inv() const { fprintf(stderr, "[cv stand-in] Mat::inv is not provided\n"); abort(); }
     inline void copyTo(const _OutputArray& dst) const;
     bool isContinuous() const { return rows <= 1 || step == (size_t)cols * esz(type_); }
@@ -150,6 +160,13 @@ inline Mat combine(const Mat& a, const Mat& b, float sb)
     if (a.rows != b.rows || a.cols != b.cols) { fprintf(stderr, "[cv stand-in] operator+-: size mismatch\n"); abort(); }
     Mat m(a.rows, a.cols, CV_32F);
     for (int i = 0; i < a.rows; i++) for (int j = 0; j < a.cols; j++) m.at<float>(i, j) = a.at<float>(i, j) + sb * b.at<float>(i, j);
+    return m;
+}
+inline Mat operator/(const Mat& a, double f)
+{
+    a.need32("operator/");
+    Mat m(a.rows, a.cols, CV_32F);
+    for (int i = 0; i < a.rows; i++) for (int j = 0; j < a.cols; j++) m.at<float>(i, j) = a.at<float>(i, j) / (float)f;
     return m;
 }
 inline Mat operator*(const Mat& a, double f) { return scaled(a, (float)f); }

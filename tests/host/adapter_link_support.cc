@@ -70,6 +70,14 @@ std::mutex MapPoint::mGlobalMutex;
 float MapPoint::GetMinDistanceInvariance() { return mfMinDistance; }
 float MapPoint::GetMaxDistanceInvariance() { return mfMaxDistance; }
 int MapPoint::PredictScale(const float&, Frame*) { return mnTrackScaleLevel; }
+int MapPoint::PredictScale(const float&, KeyFrame*) { return mnTrackScaleLevel; }
+cv::Mat MapPoint::GetNormal() { return mNormalVector.clone(); }
+void MapPoint::AddObservation(KeyFrame* pKF, size_t idx)
+{
+    if (mObservations.count(pKF)) return;
+    mObservations[pKF] = idx;
+    nObs++;
+}
 
 cv::Mat MapPoint::GetWorldPos() { return mWorldPos.clone(); }
 cv::Mat MapPoint::GetDescriptor() { return mDescriptor.clone(); }
@@ -92,6 +100,16 @@ KeyFrame::KeyFrame(Frame& F, Map* pMap, KeyFrameDatabase* pKFDB)
     mnId = nNextId++;
 }
 std::vector<MapPoint*> KeyFrame::GetMapPointMatches() { return mvpMapPoints; }
+std::set<MapPoint*> KeyFrame::GetMapPoints()
+{
+    std::set<MapPoint*> s;
+    for (size_t i = 0; i < mvpMapPoints.size(); i++)
+        if (mvpMapPoints[i] && !mvpMapPoints[i]->isBad()) s.insert(mvpMapPoints[i]);
+    return s;
+}
+MapPoint* KeyFrame::GetMapPoint(const size_t& idx) { return mvpMapPoints[idx]; }
+void KeyFrame::AddMapPoint(MapPoint* pMP, const size_t& idx) { mvpMapPoints[idx] = pMP; }
+bool KeyFrame::IsInImage(const float& x, const float& y) const { return x >= mnMinX && x < mnMaxX && y >= mnMinY && y < mnMaxY; }
 
 // ---- ORBmatcher: constructor and the three public constants (include/ORBmatcher.h:46,294-296) --------------------------------
 const int ORBmatcher::TH_HIGH = 100;

@@ -16,6 +16,7 @@
 //   E3. ORBmatcher::SearchByProjection_OnePoint (include/ORBmatcher.h:71-150) pick by pick, through adapter/good_feature_matching_gfo.h;
 //   F. ORBmatcher::SearchByProjection(CurrentFrame, LastFrame, th, bMono, numVisible) (ORBmatcher.cc:1440-1593), including the
 //      host-side projection the adapter keeps (:1451-1502);
+//   L. ORBmatcher::SearchByProjection(KeyFrame*, Scw, ...) (ORBmatcher.cc:406-518) and Fuse(KeyFrame*, Scw, ...) (:1089-1212), loop closing's;
 //   I2. ORBmatcher::SearchByBoW(KeyFrame*, KeyFrame*, vpMatches12) (ORBmatcher.cc:635-768), loop closing's, from a thread of its own;
 //   H. ORBmatcher::SearchByProjection(CurrentFrame, KeyFrame*, sAlreadyFound, th, ORBdist) (ORBmatcher.cc:1595-1721), relocalisation's;
 //   I. ORBmatcher::SearchByBoW(KeyFrame*, Frame&, vpMapPointMatches) (ORBmatcher.cc:270-404) with real DBoW2::FeatureVector objects;
@@ -157,6 +158,12 @@ struct TestMP : public MapPoint {   // MapPoint() is the header's own "for unit 
         memcpy(mDescriptor.data, d, 32);
     }
     void bad(bool b) { mbBad = b; }
+    void normal(const float* p)
+    {
+        mNormalVector = cv::Mat(3, 1, CV_32F);
+        for (int i = 0; i < 3; i++) mNormalVector.at<float>(i) = p[i];
+    }
+    int observed_at(KeyFrame* kf) { return mObservations.count(kf) ? (int)mObservations[kf] : -1; }
     void found(int n) { mnFound = n; }
     void range(float mn, float mx) { mfMinDistance = mn; mfMaxDistance = mx; }
 };
@@ -787,6 +794,109 @@ int main(int argc, char** argv)
                 int32_t n32 = nm;
                 dump("H_nmatches.bin", &n32, 4);
                 delete CurP;
+            }
+        }
+    }
+
+    // ------------------------------------------------------------------------------------------------------------------
+    // L. Loop closing's two projection matchers under a similarity Scw, into KeyFrame = frame 1, from a thread of their own:
+    //    L1 SearchByProjection(KeyFrame*, Scw, vpPoints, vpMatched, th) (ORBmatcher.cc:406-518), L2 Fuse(KeyFrame*, Scw, vpPoints, th, vpReplacePoint)
+    //    (:1089-1212).  The candidate points come from the Python side (world position, normal, distance range, predicted level, descriptor);
+    //    the keyframe's own map-point list marks keypoints that hold a candidate point already, a foreign good point, or a foreign bad one.
+    if (kept.size() >= 2) {
+        struct Rec { int32_t bad, level; float p[3]; float nrm[3]; float dmin, dmax; };
+        std::vector<uint8_t> raw = slurp(g_in + "/L_points.bin", false), dsc = slurp(g_in + "/L_points_desc.bin", false), cal = slurp(g_in + "/L_scw.bin", false),
+                             mt = slurp(g_in + "/L_matched.bin", false), km = slurp(g_in + "/L_kfmp.bin", false);
+        const int m = (int)(raw.size() / sizeof(Rec));
+        Frame& F1 = *kept[1];
+        if (!raw.empty()) {
+            CHECK(cal.size() == (16 + 6) * 4 && (int)(mt.size() / 4) == F1.N && (int)(km.size() / 4) == F1.N && dsc.size() == (size_t)m * 32, "L: input files");
+            if (cal.size() == (16 + 6) * 4 && (int)(mt.size() / 4) == F1.N && (int)(km.size() / 4) == F1.N) {
+                const float* c = reinterpret_cast<const float*>(cal.data());
+                Frame::fx = c[16]; Frame::fy = c[17]; Frame::cx = c[18]; Frame::cy = c[19];
+                const int th_proj = (int)c[20];
+                const float th_fuse = c[21];
+                const Rec* r = reinterpret_cast<const Rec*>(raw.data());
+                const int32_t* matched0 = reinterpret_cast<const int32_t*>(mt.data());
+                const int32_t* kfmp0 = reinterpret_cast<const int32_t*>(km.data());
+                std::vector<MapPoint*> pts(m);
+                for (int j = 0; j < m; j++) {
+                    TestMP* p = new TestMP();
+                    p->world(r[j].p);
+                    p->normal(r[j].nrm);
+                    p->bad(r[j].bad != 0);
+                    p->mnTrackScaleLevel = r[j].level;
+                    p->range(r[j].dmin, r[j].dmax);
+                    p->descriptor(&dsc[(size_t)j * 32]);
+                    owned.push_back(p);
+                    pts[j] = p;
+                }
+                auto code_of = [&](MapPoint* q, const std::vector<MapPoint*>& foreign) {   // candidate index, -100 - keypoint for a foreign point, -1 NULL
+                    if (!q) return -1;
+                    for (int j = 0; j < m; j++) if (pts[j] == q) return j;
+                    for (int i = 0; i < (int)foreign.size(); i++) if (foreign[i] == q) return -100 - i;
+                    return -3;
+                };
+                // L1
+                {
+                    Frame* FP = new Frame();
+                    fill_frame(*FP, L, R, F1.mvKeys, F1.mDescriptors, F1.mvKeysRight, F1.mDescriptorsRight);
+                    TestKF kf(*FP);
+                    std::vector<MapPoint*> vpMatched(F1.N, static_cast<MapPoint*>(NULL));
+                    for (int i = 0; i < F1.N; i++) if (matched0[i] >= 0 && matched0[i] < m) vpMatched[i] = pts[matched0[i]];
+                    int nm = -1;
+                    long long us = 0;
+                    std::thread([&]() {
+                        ORBmatcher matcher(0.75f, true);
+                        std::vector<MapPoint*> vm = vpMatched;
+                        nm = matcher.SearchByProjection(&kf, mat4(c), pts, vm, th_proj);
+                        us = median_us(20, []() {}, [&]() { std::vector<MapPoint*> v2 = vpMatched; matcher.SearchByProjection(&kf, mat4(c), pts, v2, th_proj); });
+                        vpMatched = vm;
+                    }).join();
+                    std::vector<int32_t> out(F1.N);
+                    const std::vector<MapPoint*> none;
+                    for (int i = 0; i < F1.N; i++) out[i] = code_of(vpMatched[i], none);
+                    dump("L1_matched.bin", out.data(), out.size() * 4);
+                    int32_t n32 = nm;
+                    dump("L1_nmatches.bin", &n32, 4);
+                    report("L1_SearchByProjection_KF_Scw_us", us);
+                    report("L_points", m);
+                    delete FP;
+                }
+                // L2
+                {
+                    Frame* FP = new Frame();
+                    fill_frame(*FP, L, R, F1.mvKeys, F1.mDescriptors, F1.mvKeysRight, F1.mDescriptorsRight);
+                    TestKF kf(*FP);
+                    std::vector<MapPoint*> kfmp(F1.N, static_cast<MapPoint*>(NULL)), foreign(F1.N, static_cast<MapPoint*>(NULL));
+                    for (int i = 0; i < F1.N; i++) {
+                        if (kfmp0[i] >= 0 && kfmp0[i] < m) kfmp[i] = pts[kfmp0[i]];
+                        else if (kfmp0[i] == -2 || kfmp0[i] == -3) {
+                            TestMP* p = new TestMP();
+                            p->bad(kfmp0[i] == -3);
+                            owned.push_back(p);
+                            kfmp[i] = p;
+                            foreign[i] = p;
+                        }
+                    }
+                    kf.points(kfmp);
+                    std::vector<MapPoint*> repl(m, static_cast<MapPoint*>(NULL));
+                    int nf = -1;
+                    std::thread([&]() {
+                        ORBmatcher matcher(0.8f);
+                        nf = matcher.Fuse(&kf, mat4(c), pts, th_fuse, repl);
+                    }).join();
+                    std::vector<int32_t> rp(m), after(F1.N), obs(m);
+                    for (int j = 0; j < m; j++) { rp[j] = code_of(repl[j], foreign); obs[j] = static_cast<TestMP*>(pts[j])->observed_at(&kf); }
+                    const std::vector<MapPoint*> now = kf.GetMapPointMatches();
+                    for (int i = 0; i < F1.N; i++) after[i] = code_of(now[i], foreign);
+                    dump("L2_replace.bin", rp.data(), rp.size() * 4);
+                    dump("L2_kf_after.bin", after.data(), after.size() * 4);
+                    dump("L2_observed_at.bin", obs.data(), obs.size() * 4);
+                    int32_t n32 = nf;
+                    dump("L2_nfused.bin", &n32, 4);
+                    delete FP;
+                }
             }
         }
     }

@@ -3,6 +3,7 @@
 // this miniature defines ARE the ones in adapter/weaken_symbols.txt.
 #include <set>
 #include <vector>
+namespace cv { class Mat { public: int x; }; }   // (by value in two signatures: only the name enters the mangling)
 namespace ORB_SLAM2
 {
 class MapPoint;
@@ -24,6 +25,8 @@ public:
     int SearchByProjection(Frame& CurrentFrame, KeyFrame* pKF, const std::set<MapPoint*>& sAlreadyFound, const float th, const int ORBdist);
     int SearchByBoW(KeyFrame* pKF, Frame& F, std::vector<MapPoint*>& vpMapPointMatches);
     int SearchByBoW(KeyFrame* pKF1, KeyFrame* pKF2, std::vector<MapPoint*>& vpMatches12);
+    int SearchByProjection(KeyFrame* pKF, cv::Mat Scw, const std::vector<MapPoint*>& vpPoints, std::vector<MapPoint*>& vpMatched, int th);
+    int Fuse(KeyFrame* pKF, cv::Mat Scw, const std::vector<MapPoint*>& vpPoints, float th, std::vector<MapPoint*>& vpReplacePoint);
     int untouched();   // a member the adapter does not replace
 };
 }  // namespace ORB_SLAM2

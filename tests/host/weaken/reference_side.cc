@@ -11,5 +11,7 @@ int ORBmatcher::SearchByProjection(Frame&, const Frame&, const float, const bool
 int ORBmatcher::SearchByProjection(Frame&, KeyFrame*, const std::set<MapPoint*>&, const float, const int) { return 1; }
 int ORBmatcher::SearchByBoW(KeyFrame*, Frame&, std::vector<MapPoint*>&) { return 1; }
 int ORBmatcher::SearchByBoW(KeyFrame*, KeyFrame*, std::vector<MapPoint*>&) { return 1; }
+int ORBmatcher::SearchByProjection(KeyFrame*, cv::Mat, const std::vector<MapPoint*>&, std::vector<MapPoint*>&, int) { return 1; }
+int ORBmatcher::Fuse(KeyFrame*, cv::Mat, const std::vector<MapPoint*>&, float, std::vector<MapPoint*>&) { return 1; }
 int ORBmatcher::untouched() { return 7; }
 }  // namespace ORB_SLAM2

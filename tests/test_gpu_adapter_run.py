@@ -280,6 +280,108 @@ def run(tmp_path_factory, oracle, euroc_l, euroc_r):
     ref["H"] = {"nm": nm, "idx": np.where(out_q >= 0, qi[np.maximum(out_q, 0)], -1).astype(np.int32), "queries": len(qi),
                 "cleared": int((out_q == -2).sum())}       # (a slot this call wrote and its rotation check cleared is NULL again: -1)
 
+    # L: loop closing's projection matchers under a similarity, into KeyFrame = frame 1.  Candidate points = frame 0's keypoints moved to where
+    # they land in frame 1, as world points under Scw = s [R | t]; the adapter's host side restated with the stand-in's float semantics
+    # (ORBmatcher.cc:415-477 = :1098-1161: decomposition, projection, distance range, viewing angle, predicted level, radius)
+    mL = n0
+    s_scale = f32(1.7)
+    Tl = _pose(0.006, -0.004, 0.005, [0.03, -0.01, 0.02])
+    Scw = Tl.copy()
+    Scw[:3, :] = (Scw[:3, :] * s_scale).astype(f32)
+    sR = Scw[:3, :3]
+    scw = f32(np.sqrt(np.sum(sR[0].astype(np.float64) ** 2)))          # sqrt(row(0).dot(row(0))): a double sum, a float result
+    RcwL = (sR / scw).astype(f32)
+    tcwL = (Scw[:3, 3] / scw).astype(f32)
+    OwL = _mm((-(RcwL.T)).astype(f32), tcwL[None, :])[0]
+    zc = rng.uniform(1.5, 25.0, mL)
+    zc[rng.random(mL) < 0.03] *= -1
+    uc = kl0["x"] - 3.0 + rng.normal(0, 1.5, mL)
+    vc = kl0["y"] + rng.normal(0, 1.5, mL)
+    uc[rng.random(mL) < 0.03] += 900.0
+    pcam = np.stack([(uc - CX) / FX * zc, (vc - CY) / FY * zc, zc], 1)
+    pwL = ((pcam - tcwL.astype(np.float64)[None, :]) @ RcwL.astype(np.float64)).astype(f32)      # Rcw^T (pc - tcw)
+    POL = (pwL - OwL[None, :]).astype(f32)
+    dist3 = np.sqrt(np.sum(POL.astype(np.float64) ** 2, axis=1)).astype(f32)
+    nrm = (POL / np.maximum(dist3, 1e-6)[:, None]).astype(f32)            # looking straight at the camera ...
+    side = rng.random(mL) < 0.08                                          # ... except a few seen from the side (beyond 60 degrees)
+    nrm[side] = np.stack([nrm[side, 1], -nrm[side, 0], np.zeros(int(side.sum()), f32)], 1).astype(f32)
+    dminL = (dist3 * rng.choice([0.5, 0.9, 1.2], mL, p=[0.6, 0.35, 0.05])).astype(f32)
+    dmaxL = (dist3 * rng.choice([2.0, 1.1, 0.8], mL, p=[0.6, 0.35, 0.05])).astype(f32)
+    levL = np.clip(kl0["octave"] + rng.integers(0, 2, mL), 0, 7).astype(np.int32)
+    badL = rng.random(mL) < 0.04
+    qdL = dl0.copy()
+    for j in range(mL):
+        for b_ in rng.integers(0, 256, rng.integers(0, 40)):
+            qdL[j, b_ >> 3] ^= np.uint8(1 << (b_ & 7))
+    rec = np.zeros(mL, np.dtype([("bad", "<i4"), ("level", "<i4"), ("p", "<f4", 3), ("n", "<f4", 3), ("dmin", "<f4"), ("dmax", "<f4")]))
+    rec["bad"], rec["level"], rec["p"], rec["n"], rec["dmin"], rec["dmax"] = badL, levL, pwL, nrm, dminL, dmaxL
+    rec.tofile(ind / "L_points.bin")
+    qdL.tofile(ind / "L_points_desc.bin")
+    th_proj, th_fuse = 10, 4.0
+    np.concatenate([Scw.ravel(), np.array([FX, FY, CX, CY, th_proj, th_fuse], f32)]).astype(f32).tofile(ind / "L_scw.bin")
+    matched0 = np.where(rng.random(n1) < 0.08, rng.integers(0, mL, n1), -1).astype(np.int32)        # vpMatched on entry: candidate points (so they are "already found")
+    matched0.tofile(ind / "L_matched.bin")
+    kfmp0 = np.full(n1, -1, np.int32)
+    r_ = rng.random(n1)
+    kfmp0[r_ < 0.06] = rng.integers(0, mL, int((r_ < 0.06).sum()))                                  # the keyframe already sees some candidate points
+    kfmp0[(r_ >= 0.06) & (r_ < 0.30)] = -2                                                           # foreign good points
+    kfmp0[(r_ >= 0.30) & (r_ < 0.33)] = -3                                                           # foreign bad points
+    kfmp0.tofile(ind / "L_kfmp.bin")
+    x3 = (_mm(RcwL, pwL) + tcwL[None, :]).astype(f32)
+    fx, fy, cx, cy = f32(FX), f32(FY), f32(CX), f32(CY)
+
+    def visible(invz, th):
+        x = (x3[:, 0] * invz).astype(f32); y = (x3[:, 1] * invz).astype(f32)
+        u = ((fx * x).astype(f32) + cx).astype(f32); v = ((fy * y).astype(f32) + cy).astype(f32)
+        dot = np.sum(POL.astype(np.float64) * nrm.astype(np.float64), axis=1)
+        ok = ~(x3[:, 2] < 0) & (u >= 0) & (u < 752) & (v >= 0) & (v < 480) & ~(dist3 < dminL) & ~(dist3 > dmaxL) & ~(dot < 0.5 * dist3.astype(np.float64))
+        return u, v, ok, (f32(th) * sf[levL]).astype(f32)
+
+    with np.errstate(divide="ignore"):
+        inv_f = (f32(1) / x3[:, 2]).astype(f32)                             # SearchByProjection: `1 / z` in float
+        inv_d = (1.0 / x3[:, 2].astype(np.float64)).astype(f32)             # Fuse: `1.0 / z`, a double quotient rounded to float
+    # L1
+    u, v, ok, rad = visible(inv_f, th_proj)
+    found0 = set(int(j) for j in matched0 if j >= 0)
+    keep = ok & ~badL & ~np.isin(np.arange(mL), list(found0))
+    qi = np.nonzero(keep)[0]
+    q = np.zeros(len(qi), oracle.PROJ_QUERY_DTYPE)
+    q["u"], q["v"], q["radius"] = u[qi], v[qi], rad[qi]
+    q["min_level"], q["max_level"], q["flags"] = levL[qi] - 1, levL[qi], 1 | 4
+    nmL, out_q, _ = oracle.search_by_projection_queries(kl1, dl1, None, None, (0.0, 0.0, 752.0, 480.0), q, qdL[qi], False, 0.0, 50, False,
+                                                        (matched0 >= 0).astype(np.uint8))
+    ref["L1"] = {"nm": nmL, "matched": np.where(out_q >= 0, qi[np.maximum(out_q, 0)], matched0).astype(np.int32), "queries": len(qi)}
+    # L2
+    u, v, ok, rad = visible(inv_d, th_fuse)
+    seen = set(int(j) for j in kfmp0 if j >= 0)                            # pKF->GetMapPoints(): the good points the keyframe holds
+    seen = set(j for j in seen if not badL[j])
+    keep = ok & ~badL & ~np.isin(np.arange(mL), list(seen))
+    qi = np.nonzero(keep)[0]
+    q = np.zeros(len(qi), oracle.PROJ_QUERY_DTYPE)
+    q["u"], q["v"], q["radius"] = u[qi], v[qi], rad[qi]
+    q["min_level"], q["max_level"], q["flags"] = levL[qi] - 1, levL[qi], 1
+    _, _, _, out_p = oracle.search_by_projection_queries_points(kl1, dl1, None, None, (0.0, 0.0, 752.0, 480.0), q, qdL[qi], False, 0.0, 50, False, None)
+    kf_after = kfmp0.copy()
+    kf_after[kfmp0 == -2] = -100 - np.nonzero(kfmp0 == -2)[0]
+    kf_after[kfmp0 == -3] = -100 - np.nonzero(kfmp0 == -3)[0]
+    bad_foreign = set(int(i) for i in np.nonzero(kfmp0 == -3)[0])
+    repl = np.full(mL, -1, np.int32); obs_at = np.full(mL, -1, np.int32)
+    nf = 0
+    for k_, j in enumerate(qi):                                            # :1194-1208, point after point
+        if out_p[k_] < 0:
+            continue
+        best = int(out_p[k_]) & 0xFFFF
+        holder = int(kf_after[best])
+        if holder != -1:
+            is_bad = (holder <= -100 and (-100 - holder) in bad_foreign) or (holder >= 0 and bool(badL[holder]))
+            if not is_bad:
+                repl[j] = holder
+        else:
+            obs_at[j] = best
+            kf_after[best] = j
+        nf += 1
+    ref["L2"] = {"nf": nf, "replace": repl, "kf_after": kf_after.astype(np.int32), "observed_at": obs_at, "queries": len(qi)}
+
     # I: SearchByBoW(KeyFrame = frame 0, F = frame 1): feature vectors = a node id per keypoint (similar descriptors share a node)
     knode = (dl0[:, 0].astype(np.int32) >> 2)                       # 64 "vocabulary nodes" from the descriptors' first bits
     fnode = (dl1[:, 0].astype(np.int32) >> 2)
@@ -611,6 +713,22 @@ def test_search_by_bow_member(run):
         np.testing.assert_array_equal(got, out, err_msg=tag)
         assert int(_rd(run, f"I_nmatches{tag}.bin", np.int32)[0]) == nm
         assert nm > 100, (tag, nm)
+
+
+def test_loop_closing_projection_members_under_a_similarity(run):
+    """ORBmatcher::SearchByProjection(KeyFrame*, Scw, vpPoints, vpMatched, th) (ORBmatcher.cc:406-518) and Fuse(KeyFrame*, Scw, vpPoints, th,
+    vpReplacePoint) (:1089-1212), called from a thread of their own with the calling thread's device context: which candidate point ends in
+    which vpMatched slot; for Fuse every point's replacement, the keyframe's map points afterwards and where each point was added as an
+    observation -- the reference's serial side effects applied to ONE device call's independent searches."""
+    l1 = run["L1"]
+    np.testing.assert_array_equal(_rd(run, "L1_matched.bin", np.int32), l1["matched"])
+    assert int(_rd(run, "L1_nmatches.bin", np.int32)[0]) == l1["nm"] and l1["nm"] > 200 and l1["queries"] > 800
+    l2 = run["L2"]
+    assert int(_rd(run, "L2_nfused.bin", np.int32)[0]) == l2["nf"] and l2["nf"] > 200
+    np.testing.assert_array_equal(_rd(run, "L2_replace.bin", np.int32), l2["replace"])
+    np.testing.assert_array_equal(_rd(run, "L2_kf_after.bin", np.int32), l2["kf_after"])
+    np.testing.assert_array_equal(_rd(run, "L2_observed_at.bin", np.int32), l2["observed_at"])
+    assert (l2["replace"] >= 0).any() and (l2["replace"] <= -100).any() and (l2["observed_at"] >= 0).sum() > 100
 
 
 def test_search_by_bow_between_keyframes_member(run):
