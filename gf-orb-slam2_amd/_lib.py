@@ -73,7 +73,7 @@ SYMBOLS = [
     "gfo_ctx_synchronize", "gfo_ctx_chain", "gfo_ctx_tables", "gfo_ctx_max_keypoints", "gfo_extract", "gfo_extract_batch",
     "gfo_extract_stereo", "gfo_extract_batch_device", "gfo_batch_counts", "gfo_batch_fetch", "gfo_batch_device_views",
     "gfo_compute_pyramid", "gfo_pyramid_level", "gfo_hamming256", "gfo_stereo_match",
-    "gfo_stereo_match_batch", "gfo_stereo_match_sad_batch", "gfo_stereo_fetch", "gfo_search_by_projection", "gfo_search_by_projection_points", "gfo_projection_points_prefix", "gfo_projection_candidates", "gfo_match_candidates", "gfo_search_by_projection_queries_points", "gfo_search_by_projection_queries",
+    "gfo_stereo_match_batch", "gfo_stereo_match_sad_batch", "gfo_stereo_fetch", "gfo_search_by_projection", "gfo_search_by_projection_points", "gfo_projection_points_prefix", "gfo_projection_candidates", "gfo_match_candidates", "gfo_search_by_projection_queries_points", "gfo_search_for_fusion", "gfo_search_by_projection_queries",
     "gfo_map_upload", "gfo_search_by_projection_batch", "gfo_projection_fetch", "gfo_projection_device_views", "gfo_search_by_bow", "gfo_search_by_bow_budget", "gfo_search_by_bow_keyframes", "gfo_vocabulary_upload", "gfo_bow_transform", "gfo_compute_bow", "gfo_profile_enable",
     "gfo_profile_read", "gfo_debug_blurred_level", "gfo_debug_level_candidates",
     "gfo_contexts_created", "gfo_arenas_planned", "gfo_kernels_preloaded", "gfo_ctx_id", "gfo_vocabulary_nodes", "gfo_ctx_set_combining", "gfo_combiner_stats", "gfo_ctx_pair", "gfo_combiner_counters", "gfo_tuning_set", "gfo_tuning_get",
@@ -186,6 +186,7 @@ def load_library():
     L.gfo_search_by_projection_points.argtypes = [vp, vp, vp, vp, i, vp, i, C.POINTER(FrameBoundsC), vp, vp, i, f, f, vp, vp, vp, vp, ip]
     L.gfo_projection_points_prefix.argtypes = [vp, i, i, i, vp, vp, ip]
     L.gfo_search_by_projection_queries_points.argtypes = [vp, vp, vp, vp, vp, i, C.POINTER(FrameBoundsC), vp, vp, i, C.POINTER(ProjModeC), vp, vp, vp, vp, ip]
+    L.gfo_search_for_fusion.argtypes = [vp, vp, vp, vp, i, C.POINTER(FrameBoundsC), vp, i, vp, vp, i, i, vp]
     L.gfo_projection_candidates.argtypes = [vp, vp, vp, vp, i, vp, i, C.POINTER(FrameBoundsC), vp, vp, i, f, vp, vp, i, ip]
     L.gfo_match_candidates.argtypes = [vp, i, vp, i, f, ip]
     L.gfo_search_by_projection_queries.argtypes = [vp, vp, vp, vp, vp, i, C.POINTER(FrameBoundsC), vp, vp, i, C.POINTER(ProjModeC),

@@ -112,6 +112,10 @@ struct ProjB {
     // per-POINT outcomes (gfo_search_by_projection_points: SearchByProjection_OnePoint's return value for every point taken in vector
     // order, include/ORBmatcher.h:71-150): [m] per frame, null = not wanted.  keypoint | distance << 16, or PJ_PT_* below
     int* out_q; int* h_out_q;
+    // ORBmatcher::Fuse(KeyFrame*, MapPoints, th) (ORBmatcher.cc:1019-1051): a candidate is dropped when its reprojection error, weighted with
+    // its own level's inverse sigma^2, exceeds the chi-square bound (5.99; 7.8 with the right-image coordinate) -- INSTEAD of the mvuRight
+    // window gate of the tracking overloads.  0 = off
+    int fuse_gate; const float* inv_sigma2;   // [GFO_MAX_LEVELS] in device memory (a table in the kernel arguments would be indexed through scratch)
 #ifdef GFO_PROJ_DEBUG
     int dbg_stop;
 #endif
@@ -281,6 +285,22 @@ __device__ __forceinline__ void accept_rule(const ProjB& a, int e1, int e2, int*
     *dist = bestDist;
 }
 
+// the gate between a candidate and the descriptor distance: true = skipped.  Tracking overloads: |ur - uR| > r where the keypoint has a
+// right-image coordinate (ORBmatcher.cc:201-206).  Fuse: the chi-square test on the reprojection error (:1026-1050), float arithmetic as
+// the reference writes it (sum of squares left to right, un-fused; the product with the level's inverse sigma^2; the comparison in double)
+__device__ __forceinline__ bool pj_gated(const ProjB& a, const ProjQ& q, float rs, float kx, float ky, float ur, int octave)
+{
+    if (!a.fuse_gate) return ur > 0 && fabsf(q.ur - ur) > rs;
+    const float ex = q.u - kx, ey = q.v - ky;
+    if (ur >= 0) {
+        const float er = q.ur - ur;
+        const float e2 = ex * ex + ey * ey + er * er;
+        return (double)(e2 * a.inv_sigma2[octave]) > 7.8;
+    }
+    const float e2 = ex * ex + ey * ey;
+    return (double)(e2 * a.inv_sigma2[octave]) > 5.99;
+}
+
 // Scans the grid window of one projected point in two phases, so that no lane waits for HBM inside the divergent
 // scan loop: phase 1 walks the cells and keeps the (at most PJ_HOLD) items that pass the window and level tests --
 // for a 50 000-point map most lanes keep none; phase 2 fetches, for every kept item at once, what the remaining
@@ -319,7 +339,7 @@ __device__ __forceinline__ bool scan_candidates(const ProjB& a, int f, int n, in
         const uint4 b0 = dk[0], b1 = dk[1];
         const int tk = taken0 ? (int)taken0[i] : 0;            // F.mvpMapPoints[idx] with Observations() > 0, :197-199
         const float ur = u_right ? u_right[i] : -1.0f;         // :201-206
-        if (!valid || tk || blocked(i) || (ur > 0 && fabsf(q.ur - ur) > rs)) return;
+        if (!valid || tk || blocked(i) || (ur > 0 && fabsf(q.ur - ur) > rs)) return;   // (the fusion gate lives in the wavefront form only: pj_launch)
         const unsigned dist = (unsigned)(__popc(a0.x ^ b0.x) + __popc(a0.y ^ b0.y) + __popc(a0.z ^ b0.z) + __popc(a0.w ^ b0.w) +
                                          __popc(a1.x ^ b1.x) + __popc(a1.y ^ b1.y) + __popc(a1.z ^ b1.z) + __popc(a1.w ^ b1.w));
         sink(cand_key(dist, meta));
@@ -586,7 +606,7 @@ __global__ __launch_bounds__(64 * PJ_WAVES) void k_proj_round0_wave(ProjB a)
                     const uint4 b0 = dk[0], b1 = dk[1];
                     const int tk = taken0 ? (int)taken0[i] : 0;            // F.mvpMapPoints[idx] with Observations() > 0, :197-199
                     const float ur = u_right ? u_right[i] : -1.0f;         // :201-206
-                    if (!(tk || (ur > 0 && fabsf(q.ur - ur) > rs))) {
+                    if (!(tk || pj_gated(a, q, rs, it.x, it.y, ur, (int)((meta >> 16) & 0xF)))) {
                         const unsigned dist = (unsigned)(__popc(a0.x ^ b0.x) + __popc(a0.y ^ b0.y) + __popc(a0.z ^ b0.z) + __popc(a0.w ^ b0.w) +
                                                          __popc(a1.x ^ b1.x) + __popc(a1.y ^ b1.y) + __popc(a1.z ^ b1.z) + __popc(a1.w ^ b1.w));
                         key = cand_key(dist, meta);
@@ -1173,7 +1193,7 @@ static int pj_launch(gfo_ctx* c, const ProjB& a, int frames, int n_max)
     static const int lds_grid_on = getenv("GFO_PROJ_LDSGRID") ? atoi(getenv("GFO_PROJ_LDSGRID")) : 1;
     // few points (the host-array call Tracking makes per frame: a thousand or two against one frame): a WAVEFRONT per point
     const int wave_on = getenv("GFO_PROJ_WAVE") ? atoi(getenv("GFO_PROJ_WAVE")) : 1;   // read per call: the tests run both forms
-    if (wave_on && (long long)frames * a.m <= 16384) {
+    if ((wave_on || a.fuse_gate) && (long long)frames * a.m <= 16384) {   // (a fusion search always takes this form: gfo_search_for_fusion feeds it at most 16 384 points a call)
         GFO_LAUNCH(c, k_proj_round0_wave, dim3((a.m + PJ_WAVES - 1) / PJ_WAVES, frames), dim3(64 * PJ_WAVES), 0, st, a);
     } else if (lds_grid_on && grid_bytes <= 78 * 1024 && a.m >= 4096) {
         int per_frame = (512 + frames - 1) / frames;
@@ -1205,14 +1225,15 @@ static int pj_launch(gfo_ctx* c, const ProjB& a, int frames, int n_max)
 // (or inside the grid launch, ProjB::cp_*), the work buffers are reserved, and `a` describes frame, queries and scratch -- everything
 // but the mode of the search.
 static int pj_stage(gfo_ctx* c, GfoXfer& x, const gfo_keypoint* kp_un, const uint8_t* desc, const float* u_right, const float* kp_angle, int n,
-                    const gfo_frame_bounds* fb, const gfo_proj_query* queries, const uint8_t* q_desc, int m, const uint8_t* kp_taken, ProjB& a)
+                    const gfo_frame_bounds* fb, const gfo_proj_query* queries, const uint8_t* q_desc, int m, const uint8_t* kp_taken, ProjB& a,
+                    const float* fuse_inv_sigma2 = nullptr, int fuse_nlevels = 0)
 {
     PTRY(c, hipSetDevice(c->device));
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = off; off = al256(off + bytes); return o; };
     const size_t o_kp = take(sizeof(gfo_keypoint) * n), o_desc = take(32 * (size_t)n), o_ur = take(4 * (size_t)n),
                  o_tk = take(n), o_ang = take(4 * (size_t)n), o_q = take(sizeof(gfo_proj_query) * m),
-                 o_mpd = take(32 * (size_t)m);
+                 o_mpd = take(32 * (size_t)m), o_sig = take(4 * GFO_MAX_LEVELS);
     if (off > c->scratch_bytes) {
         (void)hipStreamSynchronize(c->stream);
         if (c->d_scratch) (void)hipFree(c->d_scratch);
@@ -1234,6 +1255,11 @@ static int pj_stage(gfo_ctx* c, GfoXfer& x, const gfo_keypoint* kp_un, const uin
     if (kp_angle) x.put(o_ang, kp_angle, 4 * (size_t)n);
     x.put(o_q, queries, sizeof(gfo_proj_query) * m);
     x.put(o_mpd, q_desc, 32 * (size_t)m);
+    {
+        float sig[GFO_MAX_LEVELS] = {0};
+        for (int l = 0; l < GFO_MAX_LEVELS && l < fuse_nlevels && fuse_inv_sigma2; l++) sig[l] = fuse_inv_sigma2[l];
+        x.put(o_sig, sig, sizeof sig);
+    }
     // up to 1 MB the inputs travel inside the grid launch (ProjB::cp_*); larger calls take the copy engine first
     static const long fused_max = getenv("GFO_MATCHER_UPLOAD_KERNEL_MAX") ? atol(getenv("GFO_MATCHER_UPLOAD_KERNEL_MAX")) : (1L << 20);
     static const bool fuse_ok = !(getenv("GFO_PROJ_FUSED_UPLOAD") && atoi(getenv("GFO_PROJ_FUSED_UPLOAD")) == 0);
@@ -1259,6 +1285,8 @@ static int pj_stage(gfo_ctx* c, GfoXfer& x, const gfo_keypoint* kp_un, const uin
     a.q = S + o_q;
     a.q_desc = S + o_mpd;
     a.m = m;
+    a.fuse_gate = fuse_inv_sigma2 ? 1 : 0;
+    a.inv_sigma2 = (const float*)(S + o_sig);
     pj_bind(c, &a);
     return GFO_OK;
 }
@@ -1266,7 +1294,8 @@ static int pj_stage(gfo_ctx* c, GfoXfer& x, const gfo_keypoint* kp_un, const uin
 // out_point (optional, [m]): the per-point outcomes of gfo_search_by_projection_points
 static int pj_queries(gfo_ctx* c, const gfo_keypoint* kp_un, const uint8_t* desc, const float* u_right, const float* kp_angle, int n,
                       const gfo_frame_bounds* fb, const gfo_proj_query* queries, const uint8_t* q_desc, int m, const gfo_proj_mode* mode,
-                      const uint8_t* kp_taken, int32_t* out_mp, int32_t* out_score, int* nmatches, int32_t* out_point)
+                      const uint8_t* kp_taken, int32_t* out_mp, int32_t* out_score, int* nmatches, int32_t* out_point,
+                      const float* fuse_inv_sigma2 = nullptr, int fuse_nlevels = 0)
 {
     if (!c) return GFO_ERR_INVALID;
     if (!fb || !mode || !out_mp || !out_score || !nmatches || n < 0 || m < 0 || (n > 0 && (!kp_un || !desc)) ||
@@ -1292,7 +1321,7 @@ static int pj_queries(gfo_ctx* c, const gfo_keypoint* kp_un, const uint8_t* desc
     if (n == 0 || m == 0) return GFO_OK;
     GfoXfer x(c);
     ProjB a{};
-    if (int rc = pj_stage(c, x, kp_un, desc, u_right, kp_angle, n, fb, queries, q_desc, m, kp_taken, a)) return rc;
+    if (int rc = pj_stage(c, x, kp_un, desc, u_right, kp_angle, n, fb, queries, q_desc, m, kp_taken, a, fuse_inv_sigma2, fuse_nlevels)) return rc;
     hipStream_t st = c->stream;
     a.use_ratio = mode->use_ratio;
     a.nn_ratio = mode->nn_ratio;
@@ -1356,6 +1385,35 @@ extern "C" int gfo_search_by_projection_queries_points(gfo_ctx* c, const gfo_key
     if (!out_point && m > 0) return pj_fail(c, GFO_ERR_INVALID, "gfo_search_by_projection_queries_points: null out_point");
     if (mode && mode->max_matches > 0) return pj_fail(c, GFO_ERR_INVALID, "gfo_search_by_projection_queries_points: no feature budget in this form");
     return pj_queries(c, kp_un, desc, u_right, kp_angle, n, fb, queries, q_desc, m, mode, kp_taken, out_q, out_score, nmatches, out_point);
+}
+
+// ORBmatcher::Fuse(KeyFrame*, const vector<MapPoint*>&, th) (ORBmatcher.cc:937-1087), its search: per point the best keypoint of the two
+// predicted levels in the window among those whose reprojection error passes the chi-square test with the keypoint's own level sigma
+// (:1019-1051), TH_LOW, nothing blocks.  What is done with a find (Replace / AddObservation, :1067-1083) stays with the caller.
+extern "C" int gfo_search_for_fusion(gfo_ctx* c, const gfo_keypoint* kp_un, const uint8_t* desc, const float* u_right, int n,
+                                     const gfo_frame_bounds* fb, const float* inv_level_sigma2, int nlevels, const gfo_proj_query* queries,
+                                     const uint8_t* q_desc, int m, int th_dist, int32_t* out_point)
+{
+    if (!c) return GFO_ERR_INVALID;
+    if (!inv_level_sigma2 || nlevels < 1 || nlevels > GFO_MAX_LEVELS || (m > 0 && !out_point) || n < 0)
+        return pj_fail(c, GFO_ERR_INVALID, "gfo_search_for_fusion: bad argument");
+    for (int i = 0; i < n && kp_un; i++)
+        if (kp_un[i].octave < 0 || kp_un[i].octave >= nlevels) return pj_fail(c, GFO_ERR_INVALID, "gfo_search_for_fusion: keypoint octave outside the sigma table");
+    std::vector<gfo_proj_query> q(queries && m > 0 ? queries : nullptr, queries && m > 0 ? queries + m : nullptr);
+    for (auto& e : q) e.flags &= ~4;                      // nothing a point finds hides a keypoint from the next one
+    std::vector<int32_t> out_q((size_t)(n > 0 ? n : 1)), out_score((size_t)(n > 0 ? n : 1));
+    gfo_proj_mode mode = {0, 0.f, th_dist, 0, 0};
+    int nm = 0;
+    if (m == 0) return pj_queries(c, kp_un, desc, u_right, nullptr, n, fb, nullptr, q_desc, 0, &mode, nullptr, out_q.data(), out_score.data(), &nm, out_point,
+                                  inv_level_sigma2, nlevels);
+    // the points are independent of each other, so a long list goes in pieces the wavefront-per-point form takes (the one that carries the gate)
+    for (int m0 = 0; m0 < m; m0 += 16384) {
+        const int mm = m - m0 < 16384 ? m - m0 : 16384;
+        const int rc = pj_queries(c, kp_un, desc, u_right, nullptr, n, fb, q.data() + m0, q_desc + (size_t)m0 * 32, mm, &mode, nullptr, out_q.data(),
+                                  out_score.data(), &nm, out_point + m0, inv_level_sigma2, nlevels);
+        if (rc != GFO_OK) return rc;
+    }
+    return GFO_OK;
 }
 
 // ORBmatcher::SearchByProjection(Frame&, const vector<MapPoint*>&, th): every map point becomes a query with

@@ -305,6 +305,22 @@ class ORBmatcher:
         return nm.value, out_q[:n], out_s[:n], out_p[:m]
 
 
+    def SearchForFusion(self, keys_un, desc, u_right, bounds, inv_level_sigma2, queries, q_desc, th_dist=None):
+        """The search of ORBmatcher::Fuse(KeyFrame*, MapPoints, th) (ORBmatcher.cc:937-1087) on pre-projected points
+        (gfo_search_for_fusion): per point the best keypoint that passes the reprojection-error gate.  Returns out_point[m]."""
+        kp = np.ascontiguousarray(keys_un, KEYPOINT_DTYPE)
+        desc = np.ascontiguousarray(desc, np.uint8)
+        q = np.ascontiguousarray(queries, PROJ_QUERY_DTYPE)
+        qd = np.ascontiguousarray(q_desc, np.uint8)
+        sig = np.ascontiguousarray(inv_level_sigma2, np.float32)
+        u_right = None if u_right is None else np.ascontiguousarray(u_right, np.float32)
+        fb = FrameBoundsC(*bounds)
+        out = np.full(max(len(q), 1), -1, np.int32)
+        check(self._L, self._ctx, self._L.gfo_search_for_fusion(self._ctx, ptr(kp), ptr(desc), ptr(u_right), len(kp), C.byref(fb), ptr(sig), len(sig),
+                                                                ptr(q), ptr(qd), len(q), self.TH_LOW if th_dist is None else th_dist, ptr(out)))
+        return out[:len(q)]
+
+
 class ORBVocabulary:
     """DBoW2 TemplatedVocabulary<FORB> as far as Frame::ComputeBoW needs it (Frame.cc:661-668): a flattened tree
     resident on the device and transform(descriptors, levelsup) -> (BowVector, FeatureVector)."""

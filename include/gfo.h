@@ -350,6 +350,20 @@ int gfo_search_by_projection_queries_points(gfo_ctx* ctx, const gfo_keypoint* kp
                                             const uint8_t* kp_taken, int32_t* out_q, int32_t* out_score,
                                             int32_t* out_point, int* nmatches);
 
+/* The search of ORBmatcher::Fuse(KeyFrame* pKF, const vector<MapPoint*>& vpMapPoints, th) -- include/ORBmatcher.h, src/ORBmatcher.cc:937-1087,
+ * local mapping's matcher (LocalMapping::SearchInNeighbors) -- on points the caller has projected into the keyframe (:955-1004: u, v,
+ * ur = u - bf / z, radius = th * mvScaleFactors[predicted level], levels [predicted - 1, predicted]): per point the most similar keypoint
+ * among those whose reprojection error passes the chi-square test with the KEYPOINT's level (:1019-1051: e2 * mvInvLevelSigma2[kpLevel]
+ * against 5.99, or 7.8 with the right-image coordinate where mvuRight[idx] >= 0), accepted up to th_dist (TH_LOW).  No point hides a
+ * keypoint from another (flags bit 2 is ignored); what is done with a find -- Replace / AddObservation + AddMapPoint, :1067-1083, which
+ * may turn a later point of the vector bad -- stays with the caller, in the vector's order.
+ * kp_un / desc / u_right = pKF->mvKeysUn / mDescriptors / mvuRight; inv_level_sigma2 = pKF->mvInvLevelSigma2 (every keypoint octave below
+ * nlevels).  out_point[m]: keypoint | distance << 16, or negative (GFO_POINT_NONE / GFO_POINT_FAR).  The sums of squares are evaluated left
+ * to right without fused multiply-adds, the products compared in double, as the expressions stand in the reference. */
+int gfo_search_for_fusion(gfo_ctx* ctx, const gfo_keypoint* kp_un, const uint8_t* desc, const float* u_right, int n,
+                          const gfo_frame_bounds* bounds, const float* inv_level_sigma2, int nlevels,
+                          const gfo_proj_query* queries, const uint8_t* q_desc, int m, int th_dist, int32_t* out_point);
+
 /* Device-resident, batched form of SearchByProjection(Frame&, vector<MapPoint*>&, th) -- the chain
  *   gfo_extract_batch_device -> [gfo_stereo_match_batch] -> gfo_search_by_projection_batch
  * never leaves the GPU: keypoints, descriptors (and mvuRight) are read where the extractor / stereo matcher

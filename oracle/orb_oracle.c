@@ -1619,6 +1619,9 @@ int orc_search_by_bow_keyframes(const uint8_t* desc1, const float* angle1, const
 /* optional per-QUERY record of the call below (orc_search_by_projection_queries_points): what query iq did at its turn, before any
  * rotation check -- keypoint | distance << 16, -1 inactive / no keypoint in its window, -2 ratio test, -3 nothing usable within th_dist */
 static int* g_query_outcome = NULL;
+/* ORBmatcher::Fuse(KeyFrame*, MapPoints, th) (ORBmatcher.cc:1019-1051) gates a candidate by its reprojection error instead of the mvuRight
+ * window of the tracking overloads: set (orc_search_for_fusion) = the inverse level sigma^2 table of the keyframe */
+static const float* g_fuse_inv_sigma2 = NULL;
 
 int orc_search_by_projection_queries(const orc_keypoint* kp, const uint8_t* desc, const float* u_right,
                                      const float* kp_angle, int n, const orc_frame_bounds* fb,
@@ -1652,7 +1655,19 @@ int orc_search_by_projection_queries(const orc_keypoint* kp, const uint8_t* desc
         for (int k = 0; k < nidx; k++) {
             const int i = idx[k];
             if (blocked[i]) continue;
-            if (u_right && u_right[i] > 0) {
+            if (g_fuse_inv_sigma2) {                       /* :1026-1050 */
+                const float kpx = kp[i].x, kpy = kp[i].y;
+                const float ex = p->u - kpx, ey = p->v - kpy;
+                if (u_right && u_right[i] >= 0) {
+                    const float kpr = u_right[i];
+                    const float er = p->ur - kpr;
+                    const float e2 = ex * ex + ey * ey + er * er;
+                    if (e2 * g_fuse_inv_sigma2[kp[i].octave] > 7.8) continue;
+                } else {
+                    const float e2 = ex * ex + ey * ey;
+                    if (e2 * g_fuse_inv_sigma2[kp[i].octave] > 5.99) continue;
+                }
+            } else if (u_right && u_right[i] > 0) {
                 const float er = fabsf(p->ur - u_right[i]);
                 if (er > p->radius) continue;
             }
@@ -1703,6 +1718,26 @@ int orc_search_by_projection_queries(const orc_keypoint* kp, const uint8_t* desc
     free(idx); free(blocked); free(hist_kp); free(hist_bin);
     grid_free(&g);
     return nmatches;
+}
+
+/* ORBmatcher::Fuse(KeyFrame* pKF, const vector<MapPoint*>&, th), its search (ORBmatcher.cc:1000-1063) on pre-projected points: the best
+ * keypoint of levels [l - 1, l] in the window whose reprojection error passes the chi-square test, accepted up to th_dist (TH_LOW); no
+ * point hides a keypoint from another (flags bit 2 is ignored).  out_point[m]: keypoint | distance << 16, or negative. */
+int orc_search_for_fusion(const orc_keypoint* kp, const uint8_t* desc, const float* u_right, int n, const orc_frame_bounds* fb,
+                          const float* inv_level_sigma2, const orc_proj_query* q, const uint8_t* q_desc, int m, int th_dist, int* out_point)
+{
+    orc_proj_query* qq = (orc_proj_query*)malloc(sizeof(orc_proj_query) * (m > 0 ? m : 1));
+    for (int i = 0; i < m; i++) { qq[i] = q[i]; qq[i].flags &= ~4; }
+    int* out_q = (int*)malloc(sizeof(int) * (n > 0 ? n : 1));
+    int* out_s = (int*)malloc(sizeof(int) * (n > 0 ? n : 1));
+    orc_proj_mode mode = {0, 0.f, th_dist, 0};
+    g_fuse_inv_sigma2 = inv_level_sigma2;
+    g_query_outcome = out_point;
+    orc_search_by_projection_queries(kp, desc, u_right, NULL, n, fb, qq, q_desc, m, &mode, NULL, out_q, out_s);
+    g_query_outcome = NULL;
+    g_fuse_inv_sigma2 = NULL;
+    free(qq); free(out_q); free(out_s);
+    return 0;
 }
 
 /* ... the same call, also reporting what every query did at its turn (a query that blocks nothing -- flags bit 2 clear -- and finds the

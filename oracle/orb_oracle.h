@@ -210,6 +210,9 @@ int orc_search_by_projection_queries_points(const orc_keypoint* kp, const uint8_
                                             const float* kp_angle, int n, const orc_frame_bounds* fb,
                                             const orc_proj_query* q, const uint8_t* q_desc, int m, const orc_proj_mode* mode,
                                             const uint8_t* kp_taken, int* out_q, int* out_score, int* out_point);
+/* the search of ORBmatcher::Fuse(KeyFrame*, MapPoints, th) (ORBmatcher.cc:1000-1063) on pre-projected points; out_point as above */
+int orc_search_for_fusion(const orc_keypoint* kp, const uint8_t* desc, const float* u_right, int n, const orc_frame_bounds* fb,
+                          const float* inv_level_sigma2, const orc_proj_query* q, const uint8_t* q_desc, int m, int th_dist, int* out_point);
 
 /* ORBmatcher::SearchByProjection(Frame& Cur, KeyFrame*, const set<MapPoint*>& sAlreadyFound, th, ORBdist) --
  * ORBmatcher.cc:1595-1721 on pre-projected map points: any set keypoint is skipped, no mvuRight gate, no ratio.

@@ -705,6 +705,23 @@ def search_by_projection_queries_points(kp_un, desc, u_right, kp_angle, bounds, 
     return nm, out_q[:n], out_s[:n], out_p[:m]
 
 
+def search_for_fusion(kp_un, desc, u_right, bounds, inv_level_sigma2, queries, q_desc, th_dist=50):
+    """The search of ORBmatcher::Fuse(KeyFrame*, MapPoints, th), ORBmatcher.cc:1000-1063, on pre-projected points.  Returns out_point[m]."""
+    kp_un = np.ascontiguousarray(kp_un, dtype=KEYPOINT_DTYPE)
+    desc = np.ascontiguousarray(desc, dtype=np.uint8)
+    queries = np.ascontiguousarray(queries, dtype=PROJ_QUERY_DTYPE)
+    q_desc = np.ascontiguousarray(q_desc, dtype=np.uint8)
+    sig = np.ascontiguousarray(inv_level_sigma2, np.float32)
+    u_right = None if u_right is None else np.ascontiguousarray(u_right, np.float32)
+    fb = FrameBounds(*bounds)
+    out = np.full(max(len(queries), 1), -1, np.int32)
+    L = lib()
+    vp = C.c_void_p
+    L.orc_search_for_fusion.argtypes = [vp, vp, vp, C.c_int, C.POINTER(FrameBounds), vp, vp, vp, C.c_int, C.c_int, vp]
+    L.orc_search_for_fusion(_p(kp_un), _p(desc), _p(u_right), len(kp_un), C.byref(fb), _p(sig), _p(queries), _p(q_desc), len(queries), th_dist, _p(out))
+    return out[:len(queries)]
+
+
 def search_by_projection_kf(kp_un, desc, kp_angle, bounds, queries, q_desc, orb_dist, check_orientation, kp_set=None):
     """ORBmatcher::SearchByProjection(CurrentFrame, KeyFrame*, sAlreadyFound, th, ORBdist), ORBmatcher.cc:1595-1721,
     on pre-projected map points (literal statement: any set keypoint is skipped)."""

@@ -355,3 +355,36 @@ def test_non_blocking_queries_are_independent_searches(ext, oracle):
     # several points may name the same keypoint; the slot table keeps the last of them (Fuse decides per point what to do with it)
     k = got[3][got[3] >= 0] & 0xFFFF
     assert len(np.unique(k)) < len(k)
+
+
+@pytest.mark.parametrize("seed,m,jitter,th", [(1, 2000, 1.0, 3.0), (2, 6000, 2.5, 4.0), (3, 20000, 1.5, 3.0)])
+def test_fusion_search_with_the_reprojection_error_gate(ext, oracle, seed, m, jitter, th):
+    """The search of ORBmatcher::Fuse(KeyFrame*, MapPoints, th) (ORBmatcher.cc:1000-1063; gfo_search_for_fusion): candidates are gated by
+    e2 * mvInvLevelSigma2[keypoint level] against 5.99 / 7.8 instead of the mvuRight window, nothing blocks, TH_LOW.  20 000 points go to
+    the device in two pieces (they are independent); the third form of this module's fixture asks for the thread-per-point kernels, which a
+    fusion search never takes."""
+    import gf_orb_slam2_amd as G
+    kl, dl, u = _frame(oracle)
+    rng = np.random.default_rng(seed)
+    sf = oracle.OracleExtractor().scale_factors
+    inv_sigma2 = (1.0 / (sf.astype(np.float32) ** 2)).astype(np.float32)
+    src = rng.integers(0, len(kl), m)
+    q = np.zeros(m, oracle.PROJ_QUERY_DTYPE)
+    q["u"] = kl["x"][src] + rng.normal(0, jitter, m); q["v"] = kl["y"][src] + rng.normal(0, jitter, m)
+    q["ur"] = np.where(u[src] >= 0, u[src] + rng.normal(0, jitter, m), q["u"] - 5).astype(np.float32)
+    lev = np.clip(kl["octave"][src] + rng.integers(0, 2, m), 0, 7)
+    q["radius"] = (np.float32(th) * sf[lev]).astype(np.float32)
+    q["min_level"], q["max_level"] = lev - 1, lev
+    q["flags"] = np.where(rng.random(m) < 0.95, 1 | 4, 0)
+    qd = dl[src].copy()
+    for _ in range(10):
+        sel = rng.random(m) < 0.5
+        bits = rng.integers(0, 256, m)
+        qd[sel, bits[sel] >> 3] ^= (1 << (bits[sel] & 7)).astype(np.uint8)
+    uu = u.copy()
+    uu[rng.random(len(uu)) < 0.05] = 0.0          # mvuRight == 0 counts as a right-image coordinate here (>= 0), unlike the tracking overloads (> 0)
+    b = (0.0, 0.0, 752.0, 480.0)
+    ref = oracle.search_for_fusion(kl, dl, uu, b, inv_sigma2, q, qd, 50)
+    got = G.ORBmatcher(0.8, True, extractor=ext).SearchForFusion(kl, dl, uu, b, inv_sigma2, q, qd)
+    np.testing.assert_array_equal(got, ref)
+    assert (ref >= 0).sum() > m // 4 and (ref == -3).any() and (ref == -1).any()
