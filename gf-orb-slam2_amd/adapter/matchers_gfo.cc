@@ -14,6 +14,7 @@
 //   GFO_ADAPTER_BOW_KF        ORBmatcher::SearchByBoW(KeyFrame*, KeyFrame*, vector<MapPoint*>&) src/ORBmatcher.cc:635-768
 //   GFO_ADAPTER_PROJ_SCW      ORBmatcher::SearchByProjection(KeyFrame*, Scw, points, matched, th)  src/ORBmatcher.cc:406-518
 //   GFO_ADAPTER_FUSE_SCW      ORBmatcher::Fuse(KeyFrame*, Scw, points, th, vpReplacePoint)         src/ORBmatcher.cc:1089-1212
+//   GFO_ADAPTER_FUSE          ORBmatcher::Fuse(KeyFrame*, vector<MapPoint*>&, th)                  src/ORBmatcher.cc:937-1087
 //   GFO_ADAPTER_COMPUTE_BOW   Frame::ComputeBoW()                                               src/Frame.cc:661-668
 //
 // Each body flattens the reference's objects into plain arrays, calls the C ABI (include/gfo.h) and writes the
@@ -32,6 +33,7 @@
 #define GFO_ADAPTER_BOW_KF
 #define GFO_ADAPTER_PROJ_SCW
 #define GFO_ADAPTER_FUSE_SCW
+#define GFO_ADAPTER_FUSE
 #define GFO_ADAPTER_COMPUTE_BOW
 #endif
 
@@ -726,6 +728,93 @@ int ORBmatcher::Fuse(KeyFrame* pKF, cv::Mat Scw, const std::vector<MapPoint*>& v
         MapPoint* pMPinKF = pKF->GetMapPoint(bestIdx);                  // :1196: as the points in front of this one have left it
         if (pMPinKF) {
             if (!pMPinKF->isBad()) vpReplacePoint[iMP] = pMPinKF;
+        } else {
+            pMP->AddObservation(pKF, bestIdx);
+            pKF->AddMapPoint(pMP, bestIdx);
+        }
+        nFused++;
+    }
+    return nFused;
+}
+#endif
+
+#ifdef GFO_ADAPTER_FUSE
+// LocalMapping::SearchInNeighbors' matcher (LocalMapping.cc:673, 698): the map points of one keyframe projected into a neighbour, a few dozen
+// calls per new keyframe.  The search of every point (ORBmatcher.cc:1000-1063: window, two levels, the reprojection-error gate, TH_LOW) depends
+// on the keyframe's keypoints only, so all of them are ONE device call (gfo_search_for_fusion); what a find leads to (:1067-1083) is applied
+// here, point after point in the vector's order -- Replace() can turn a LATER point of the vector bad, and the reference looks at isBad() /
+// IsInKeyFrame() at a point's own turn (:959), so that test is made again where the reference makes it.  (A point that is skipped there never
+// becomes searchable again, and nothing a point's turn does changes what a later point's search reads: position, normal, distance range and
+// descriptor of a point change only by Replace() INTO it, which puts it into the keyframe.)
+int ORBmatcher::Fuse(KeyFrame* pKF, const std::vector<MapPoint*>& vpMapPoints, const float th)
+{
+    cv::Mat Rcw = pKF->GetRotation();
+    cv::Mat tcw = pKF->GetTranslation();
+    const float &fx = pKF->fx, &fy = pKF->fy, &cx = pKF->cx, &cy = pKF->cy, &bf = pKF->mbf;
+    cv::Mat Ow = pKF->GetCameraCenter();
+    const int nMPs = (int)vpMapPoints.size();
+    std::vector<gfo_proj_query> q;
+    std::vector<int> query_of(nMPs, -1);
+    std::vector<MapPoint*> qmp;
+    for (int i = 0; i < nMPs; i++) {
+        MapPoint* pMP = vpMapPoints[i];
+        if (!pMP) continue;
+        if (pMP->isBad() || pMP->IsInKeyFrame(pKF)) continue;             // (tested again at the point's turn below)
+        cv::Mat p3Dw = pMP->GetWorldPos();
+        cv::Mat p3Dc = Rcw * p3Dw + tcw;
+        if (p3Dc.at<float>(2) < 0.0f) continue;                           // depth must be positive
+        const float invz = 1 / p3Dc.at<float>(2);
+        const float x = p3Dc.at<float>(0) * invz;
+        const float y = p3Dc.at<float>(1) * invz;
+        const float u = fx * x + cx;
+        const float v = fy * y + cy;
+        if (!pKF->IsInImage(u, v)) continue;
+        const float ur = u - bf * invz;
+        const float maxDistance = pMP->GetMaxDistanceInvariance();
+        const float minDistance = pMP->GetMinDistanceInvariance();
+        cv::Mat PO = p3Dw - Ow;
+        const float dist3D = cv::norm(PO);
+        if (dist3D < minDistance || dist3D > maxDistance) continue;
+        cv::Mat Pn = pMP->GetNormal();
+        if (PO.dot(Pn) < 0.5 * dist3D) continue;                          // viewing angle below 60 degrees
+        const int nPredictedLevel = pMP->PredictScale(dist3D, pKF);
+        gfo_proj_query e;
+        e.u = u; e.v = v; e.ur = ur;
+        e.radius = th * pKF->mvScaleFactors[nPredictedLevel];
+        e.min_level = nPredictedLevel - 1;
+        e.max_level = nPredictedLevel;
+        e.angle = 0.f;
+        e.flags = 1;
+        query_of[i] = (int)q.size();
+        q.push_back(e);
+        qmp.push_back(pMP);
+    }
+    const int M = (int)q.size(), N = pKF->N;
+    cv::Mat qDesc(M > 0 ? M : 1, 32, CV_8U);
+    for (int i = 0; i < M; i++) descriptor_row(qmp[i], qDesc, i);
+    gfo_frame_bounds fb = {(float)pKF->mnMinX, (float)pKF->mnMinY, (float)pKF->mnMaxX, (float)pKF->mnMaxY};
+    std::vector<int32_t> outPoint(M > 0 ? M : 1);
+    cv::Mat keep;
+    gfo_ctx* c = gfo_context_pin_thread();
+    const int rc = gfo_search_for_fusion(c, as_gfo(pKF->mvKeysUn), rows32(pKF->mDescriptors, keep), pKF->mvuRight.data(), N, &fb,
+                                         pKF->mvInvLevelSigma2.data(), (int)pKF->mvInvLevelSigma2.size(), q.data(), qDesc.data, M, TH_LOW, outPoint.data());
+    if (rc != GFO_OK) report(c, "Fuse(KF, MapPoints)");
+    gfo_context_unpin_thread(c);
+    if (rc != GFO_OK) return 0;
+    int nFused = 0;
+    for (int i = 0; i < nMPs; i++) {
+        MapPoint* pMP = vpMapPoints[i];
+        if (!pMP || query_of[i] < 0) continue;
+        if (pMP->isBad() || pMP->IsInKeyFrame(pKF)) continue;             // :959, at the point's own turn
+        const int found = outPoint[query_of[i]];
+        if (found < 0) continue;                                           // nothing within TH_LOW
+        const int bestIdx = found & 0xFFFF;
+        MapPoint* pMPinKF = pKF->GetMapPoint(bestIdx);
+        if (pMPinKF) {
+            if (!pMPinKF->isBad()) {
+                if (pMPinKF->Observations() > pMP->Observations()) pMP->Replace(pMPinKF);
+                else pMPinKF->Replace(pMP);
+            }
         } else {
             pMP->AddObservation(pKF, bestIdx);
             pKF->AddMapPoint(pMP, bestIdx);

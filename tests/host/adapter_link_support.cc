@@ -72,6 +72,26 @@ float MapPoint::GetMaxDistanceInvariance() { return mfMaxDistance; }
 int MapPoint::PredictScale(const float&, Frame*) { return mnTrackScaleLevel; }
 int MapPoint::PredictScale(const float&, KeyFrame*) { return mnTrackScaleLevel; }
 cv::Mat MapPoint::GetNormal() { return mNormalVector.clone(); }
+bool MapPoint::IsInKeyFrame(KeyFrame* pKF) { return mObservations.count(pKF) != 0; }
+MapPoint* MapPoint::GetReplaced() { return mpReplaced; }
+// MapPoint::Replace as far as ORBmatcher::Fuse can see it afterwards: this point is bad and names its replacement, its observations move to
+// the replacement (or the keyframe's slot is cleared where the replacement is there already).  The statistics, the descriptor recomputation
+// and the Map's bookkeeping of src/MapPoint.cc:332-371 are not the adapter's to test.
+void MapPoint::Replace(MapPoint* pMP)
+{
+    if (pMP == this) return;
+    std::map<KeyFrame*, size_t> obs = mObservations;
+    mObservations.clear();
+    mbBad = true;
+    mpReplaced = pMP;
+    for (std::map<KeyFrame*, size_t>::iterator it = obs.begin(); it != obs.end(); ++it) {
+        if (!pMP->IsInKeyFrame(it->first)) {
+            it->first->ReplaceMapPointMatch(it->second, pMP);
+            pMP->AddObservation(it->first, it->second);
+        } else
+            it->first->EraseMapPointMatch(it->second);
+    }
+}
 void MapPoint::AddObservation(KeyFrame* pKF, size_t idx)
 {
     if (mObservations.count(pKF)) return;
@@ -109,6 +129,11 @@ std::set<MapPoint*> KeyFrame::GetMapPoints()
 }
 MapPoint* KeyFrame::GetMapPoint(const size_t& idx) { return mvpMapPoints[idx]; }
 void KeyFrame::AddMapPoint(MapPoint* pMP, const size_t& idx) { mvpMapPoints[idx] = pMP; }
+void KeyFrame::ReplaceMapPointMatch(const size_t& idx, MapPoint* pMP) { mvpMapPoints[idx] = pMP; }
+void KeyFrame::EraseMapPointMatch(const size_t& idx) { mvpMapPoints[idx] = static_cast<MapPoint*>(NULL); }
+cv::Mat KeyFrame::GetRotation() { return Tcw.rowRange(0, 3).colRange(0, 3).clone(); }
+cv::Mat KeyFrame::GetTranslation() { return Tcw.rowRange(0, 3).col(3).clone(); }
+cv::Mat KeyFrame::GetCameraCenter() { return Ow.clone(); }
 bool KeyFrame::IsInImage(const float& x, const float& y) const { return x >= mnMinX && x < mnMaxX && y >= mnMinY && y < mnMaxY; }
 
 // ---- ORBmatcher: constructor and the three public constants (include/ORBmatcher.h:46,294-296) --------------------------------

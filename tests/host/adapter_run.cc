@@ -198,6 +198,12 @@ struct TestVoc : public ORBVocabulary {
 struct TestKF : public KeyFrame {   // a keyframe made of a frame's arrays; the harness fills the (protected) map-point list
     explicit TestKF(Frame& F) : KeyFrame(F, NULL, NULL) {}
     void points(const std::vector<MapPoint*>& v) { mvpMapPoints = v; }
+    void pose(const cv::Mat& T, const float* ow)   // Tcw and the camera centre the Python side computed from it (KeyFrame::SetPose is not compiled)
+    {
+        Tcw = T.clone();
+        Ow = cv::Mat(3, 1, CV_32F);
+        for (int i = 0; i < 3; i++) Ow.at<float>(i) = ow[i];
+    }
 };
 
 static const float MBF = 47.906f, MB = 47.906f / 435.2f;
@@ -862,6 +868,88 @@ int main(int argc, char** argv)
                     report("L1_SearchByProjection_KF_Scw_us", us);
                     report("L_points", m);
                     delete FP;
+                }
+                // L3. Fuse(KeyFrame*, vpMapPoints, th) (ORBmatcher.cc:937-1087), local mapping's: the same candidate points (a few entries NULL, a few
+                //     observed by the keyframe already), the keyframe posed at Tcw; foreign points in its slots carry 1 or 5 observations, the
+                //     candidates 3, so that Replace() runs in both directions.
+                {
+                    std::vector<uint8_t> cal3 = slurp(g_in + "/L3_pose.bin", false), sl3 = slurp(g_in + "/L3_kfmp.bin", false), nul3 = slurp(g_in + "/L3_null.bin", false),
+                                         raw3 = slurp(g_in + "/L3_points.bin", false);
+                    if (cal3.size() == (16 + 3 + 1) * 4 && (int)(sl3.size() / 4) == F1.N && (int)nul3.size() == m && raw3.size() == raw.size()) {
+                        const Rec* r = reinterpret_cast<const Rec*>(raw3.data());       // (the candidates as the keyframe's pose sees them)
+                        const float* c3 = reinterpret_cast<const float*>(cal3.data());
+                        const int32_t* slot0 = reinterpret_cast<const int32_t*>(sl3.data());
+                        Frame* FP = new Frame();
+                        fill_frame(*FP, L, R, F1.mvKeys, F1.mDescriptors, F1.mvKeysRight, F1.mDescriptorsRight);
+                        std::vector<uint8_t> ur3 = slurp(g_in + "/L3_uright.bin", false);
+                        FP->mvuRight.assign(reinterpret_cast<const float*>(ur3.data()), reinterpret_cast<const float*>(ur3.data()) + ur3.size() / 4);
+                        CHECK((int)FP->mvuRight.size() == F1.N, "L3: %zu right coordinates for %d keypoints", FP->mvuRight.size(), F1.N);
+                        FP->mvDepth.assign(F1.N, -1.f);
+                        FP->mvLevelSigma2 = L->GetScaleSigmaSquares();
+                        FP->mvInvLevelSigma2 = L->GetInverseScaleSigmaSquares();
+                        TestKF kf(*FP);
+                        kf.pose(mat4(c3), c3 + 16);
+                        // fresh candidate objects (L1 / L2 have used the others): same records
+                        std::vector<MapPoint*> cand(m);
+                        for (int j = 0; j < m; j++) {
+                            TestMP* p = new TestMP();
+                            p->world(r[j].p); p->normal(r[j].nrm); p->bad(r[j].bad != 0);
+                            p->mnTrackScaleLevel = r[j].level; p->range(r[j].dmin, r[j].dmax);
+                            p->descriptor(&dsc[(size_t)j * 32]);
+                            p->nObs = 3;
+                            owned.push_back(p);
+                            cand[j] = p;
+                        }
+                        std::vector<MapPoint*> slots(F1.N, static_cast<MapPoint*>(NULL)), foreign(F1.N, static_cast<MapPoint*>(NULL));
+                        for (int i = 0; i < F1.N; i++) {
+                            const int v = slot0[i];
+                            if (v >= 0 && v < m) { slots[i] = cand[v]; }
+                            else if (v <= -2) {            // -2: foreign, 1 observation; -3: foreign, 5 observations; -4: foreign and bad
+                                TestMP* p = new TestMP();
+                                p->nObs = v == -3 ? 5 : 1;
+                                p->bad(v == -4);
+                                owned.push_back(p);
+                                slots[i] = p; foreign[i] = p;
+                            }
+                        }
+                        kf.points(slots);
+                        for (int i = 0; i < F1.N; i++) if (slots[i]) slots[i]->AddObservation(&kf, (size_t)i);   // (counts as one more observation each)
+                        std::vector<MapPoint*> list = cand;
+                        for (int j = 0; j < m; j++) if (nul3[j]) list[j] = static_cast<MapPoint*>(NULL);
+                        auto code3 = [&](MapPoint* q) {
+                            if (!q) return -1;
+                            for (int j = 0; j < m; j++) if (cand[j] == q) return j;
+                            for (int i = 0; i < F1.N; i++) if (foreign[i] == q) return -100 - i;
+                            return -3;
+                        };
+                        int nf = -1;
+                        long long us = 0;
+                        std::thread([&]() {
+                            ORBmatcher matcher(0.8f);
+                            nf = matcher.Fuse(&kf, list, c3[19]);
+                        }).join();
+                        std::vector<int32_t> after(F1.N), bad(m), repl(m), at(m), fbad(F1.N, 0), frepl(F1.N, -1);
+                        const std::vector<MapPoint*> now = kf.GetMapPointMatches();
+                        for (int i = 0; i < F1.N; i++) {
+                            after[i] = code3(now[i]);
+                            if (foreign[i]) { fbad[i] = foreign[i]->isBad(); frepl[i] = code3(foreign[i]->GetReplaced()); }
+                        }
+                        for (int j = 0; j < m; j++) {
+                            bad[j] = cand[j]->isBad();
+                            repl[j] = code3(cand[j]->GetReplaced());
+                            at[j] = static_cast<TestMP*>(cand[j])->observed_at(&kf);
+                        }
+                        dump("L3_kf_after.bin", after.data(), after.size() * 4);
+                        dump("L3_bad.bin", bad.data(), bad.size() * 4);
+                        dump("L3_replaced_by.bin", repl.data(), repl.size() * 4);
+                        dump("L3_observed_at.bin", at.data(), at.size() * 4);
+                        dump("L3_foreign_bad.bin", fbad.data(), fbad.size() * 4);
+                        dump("L3_foreign_replaced_by.bin", frepl.data(), frepl.size() * 4);
+                        int32_t n32 = nf;
+                        dump("L3_nfused.bin", &n32, 4);
+                        (void)us;
+                        delete FP;
+                    }
                 }
                 // L2
                 {

@@ -1,4 +1,4 @@
-// stands for adapter/matchers_gfo.cc: the same ten members, every body answers 2
+// stands for adapter/matchers_gfo.cc: the same eleven members, every body answers 2
 #include "decl.h"
 namespace ORB_SLAM2
 {
@@ -12,4 +12,5 @@ int ORBmatcher::SearchByBoW(KeyFrame*, Frame&, std::vector<MapPoint*>&) { return
 int ORBmatcher::SearchByBoW(KeyFrame*, KeyFrame*, std::vector<MapPoint*>&) { return 2; }
 int ORBmatcher::SearchByProjection(KeyFrame*, cv::Mat, const std::vector<MapPoint*>&, std::vector<MapPoint*>&, int) { return 2; }
 int ORBmatcher::Fuse(KeyFrame*, cv::Mat, const std::vector<MapPoint*>&, float, std::vector<MapPoint*>&) { return 2; }
+int ORBmatcher::Fuse(KeyFrame*, const std::vector<MapPoint*>&, const float) { return 2; }
 }  // namespace ORB_SLAM2

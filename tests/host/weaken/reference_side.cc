@@ -13,5 +13,6 @@ int ORBmatcher::SearchByBoW(KeyFrame*, Frame&, std::vector<MapPoint*>&) { return
 int ORBmatcher::SearchByBoW(KeyFrame*, KeyFrame*, std::vector<MapPoint*>&) { return 1; }
 int ORBmatcher::SearchByProjection(KeyFrame*, cv::Mat, const std::vector<MapPoint*>&, std::vector<MapPoint*>&, int) { return 1; }
 int ORBmatcher::Fuse(KeyFrame*, cv::Mat, const std::vector<MapPoint*>&, float, std::vector<MapPoint*>&) { return 1; }
+int ORBmatcher::Fuse(KeyFrame*, const std::vector<MapPoint*>&, const float) { return 1; }
 int ORBmatcher::untouched() { return 7; }
 }  // namespace ORB_SLAM2

@@ -382,6 +382,98 @@ def run(tmp_path_factory, oracle, euroc_l, euroc_r):
         nf += 1
     ref["L2"] = {"nf": nf, "replace": repl, "kf_after": kf_after.astype(np.int32), "observed_at": obs_at, "queries": len(qi)}
 
+    # L3: Fuse(KeyFrame = frame 1 posed at Tl, the same candidate records, th = 3): host side restated (ORBmatcher.cc:939-1004), the search by
+    # the oracle (reprojection-error gate), the side effects (:1067-1083 with the link support's Replace) in the vector's order
+    th3 = f32(3.0)
+    Rk, tk = Tl[:3, :3], Tl[:3, 3]
+    Owk = _mm((-(Rk.T)).astype(f32), tk[None, :])[0]
+    np.concatenate([Tl.ravel(), Owk, np.array([th3], f32)]).astype(f32).tofile(ind / "L3_pose.bin")
+    # (the candidate records were made for the similarity's Rcw / tcw; under Tl they land elsewhere -- some inside the image, which is all this needs)
+    pcam3 = np.stack([(uc - CX) / FX * zc, (vc - CY) / FY * zc, zc], 1)
+    pw3 = ((pcam3 - tk.astype(np.float64)[None, :]) @ Rk.astype(np.float64)).astype(f32)
+    rec3 = rec.copy()
+    rec3["p"] = pw3
+    PO3 = (pw3 - Owk[None, :]).astype(f32)
+    d3 = np.sqrt(np.sum(PO3.astype(np.float64) ** 2, axis=1)).astype(f32)
+    n3 = (PO3 / np.maximum(d3, 1e-6)[:, None]).astype(f32)
+    n3[side] = np.stack([n3[side, 1], -n3[side, 0], np.zeros(int(side.sum()), f32)], 1).astype(f32)
+    rec3["n"] = n3
+    rec3["dmin"] = (d3 * rng.choice([0.5, 0.9, 1.2], mL, p=[0.6, 0.35, 0.05])).astype(f32)
+    rec3["dmax"] = (d3 * rng.choice([2.0, 1.1, 0.8], mL, p=[0.6, 0.35, 0.05])).astype(f32)
+    rec3.tofile(ind / "L3_points.bin")
+    ur_kf = np.where(rng.random(n1) < 0.7, kl1["x"] - rng.uniform(0.5, 40.0, n1), -1.0).astype(f32)
+    ur_kf[rng.random(n1) < 0.03] = 0.0
+    ur_kf.tofile(ind / "L3_uright.bin")
+    slot0 = np.full(n1, -1, np.int32)
+    r_ = rng.random(n1)
+    slot0[r_ < 0.05] = rng.choice(mL, int((r_ < 0.05).sum()), replace=False)
+    slot0[(r_ >= 0.05) & (r_ < 0.20)] = -2
+    slot0[(r_ >= 0.20) & (r_ < 0.35)] = -3
+    slot0[(r_ >= 0.35) & (r_ < 0.38)] = -4
+    slot0.tofile(ind / "L3_kfmp.bin")
+    null3 = (rng.random(mL) < 0.03).astype(np.uint8)
+    null3.tofile(ind / "L3_null.bin")
+    x3k = (_mm(Rk, pw3) + tk[None, :]).astype(f32)
+    with np.errstate(divide="ignore"):
+        invz3 = (f32(1) / x3k[:, 2]).astype(f32)
+    xk = (x3k[:, 0] * invz3).astype(f32); yk = (x3k[:, 1] * invz3).astype(f32)
+    u3 = ((fx * xk).astype(f32) + cx).astype(f32); v3 = ((fy * yk).astype(f32) + cy).astype(f32)
+    ur3 = (u3 - (f32(MBF) * invz3).astype(f32)).astype(f32)
+    dot3 = np.sum(PO3.astype(np.float64) * n3.astype(np.float64), axis=1)
+    ok3 = ~(x3k[:, 2] < 0) & (u3 >= 0) & (u3 < 752) & (v3 >= 0) & (v3 < 480) & ~(d3 < rec3["dmin"]) & ~(d3 > rec3["dmax"]) & ~(dot3 < 0.5 * d3.astype(np.float64))
+    in_kf0 = np.zeros(mL, bool)
+    in_kf0[slot0[slot0 >= 0]] = True
+    searched = ok3 & ~badL & ~in_kf0 & (null3 == 0)
+    qi3 = np.nonzero(searched)[0]
+    q3 = np.zeros(len(qi3), oracle.PROJ_QUERY_DTYPE)
+    q3["u"], q3["v"], q3["ur"] = u3[qi3], v3[qi3], ur3[qi3]
+    q3["radius"] = (th3 * sf[levL[qi3]]).astype(f32)
+    q3["min_level"], q3["max_level"], q3["flags"] = levL[qi3] - 1, levL[qi3], 1
+    inv_sig = (f32(1.0) / (sf * sf).astype(f32)).astype(f32)
+    ref["L3_inv_sigma2"] = inv_sig
+    outp3 = oracle.search_for_fusion(kl1, dl1, ur_kf, (0.0, 0.0, 752.0, 480.0), inv_sig, q3, qdL[qi3], 50)
+    found_of = np.full(mL, -1, np.int64)
+    found_of[qi3] = outp3
+    # the serial part (:1067-1083) with the link support's Replace: holder codes as in the harness (candidate index, -100 - keypoint for a foreign point)
+    holder = np.full(n1, -1, np.int64)
+    cand_bad = badL.copy(); cand_repl = np.full(mL, -1, np.int64); cand_at = np.full(mL, -1, np.int64); cand_obs = np.full(mL, 3, np.int64)
+    f_bad = np.zeros(n1, bool); f_repl = np.full(n1, -1, np.int64); f_obs = np.zeros(n1, np.int64); f_at = np.full(n1, -1, np.int64)
+    for i in range(n1):
+        v_ = int(slot0[i])
+        if v_ >= 0:
+            holder[i] = v_; cand_at[v_] = i; cand_obs[v_] += 1
+        elif v_ <= -2:
+            holder[i] = -100 - i; f_obs[i] = (5 if v_ == -3 else 1) + 1; f_bad[i] = v_ == -4; f_at[i] = i
+    nf3 = 0
+    for j in range(mL):
+        if null3[j] or not searched[j]:
+            continue
+        if cand_bad[j] or cand_at[j] >= 0:                  # isBad() || IsInKeyFrame(pKF) at the point's own turn
+            continue
+        v_ = int(found_of[j])
+        if v_ < 0:
+            continue
+        best = v_ & 0xFFFF
+        h = int(holder[best])
+        if h != -1:
+            h_bad = bool(f_bad[-100 - h]) if h <= -100 else bool(cand_bad[h])
+            if not h_bad:
+                h_obs = int(f_obs[-100 - h]) if h <= -100 else int(cand_obs[h])
+                if h_obs > cand_obs[j]:                      # pMP->Replace(pMPinKF): the candidate goes, the keyframe's point stays (it is in the keyframe: its slot stands)
+                    cand_bad[j] = True; cand_repl[j] = h     # (the candidate has no observation in this keyframe to move)
+                else:                                        # pMPinKF->Replace(pMP): the holder's observation of this keyframe moves to the candidate
+                    if h <= -100:
+                        f_bad[-100 - h] = True; f_repl[-100 - h] = j; f_at[-100 - h] = -1
+                    else:
+                        cand_bad[h] = True; cand_repl[h] = j; cand_at[h] = -1
+                    holder[best] = j; cand_at[j] = best; cand_obs[j] += 1
+        else:
+            cand_at[j] = best; cand_obs[j] += 1; holder[best] = j
+        nf3 += 1
+    ref["L3"] = {"nf": nf3, "kf_after": holder.astype(np.int32), "bad": cand_bad.astype(np.int32), "replaced_by": cand_repl.astype(np.int32),
+                 "observed_at": cand_at.astype(np.int32), "foreign_bad": f_bad.astype(np.int32), "foreign_replaced_by": f_repl.astype(np.int32),
+                 "searched": int(searched.sum())}
+
     # I: SearchByBoW(KeyFrame = frame 0, F = frame 1): feature vectors = a node id per keypoint (similar descriptors share a node)
     knode = (dl0[:, 0].astype(np.int32) >> 2)                       # 64 "vocabulary nodes" from the descriptors' first bits
     fnode = (dl1[:, 0].astype(np.int32) >> 2)
@@ -729,6 +821,18 @@ def test_loop_closing_projection_members_under_a_similarity(run):
     np.testing.assert_array_equal(_rd(run, "L2_kf_after.bin", np.int32), l2["kf_after"])
     np.testing.assert_array_equal(_rd(run, "L2_observed_at.bin", np.int32), l2["observed_at"])
     assert (l2["replace"] >= 0).any() and (l2["replace"] <= -100).any() and (l2["observed_at"] >= 0).sum() > 100
+
+
+def test_local_mapping_fuse_member(run):
+    """ORBmatcher::Fuse(KeyFrame*, const vector<MapPoint*>&, th) (ORBmatcher.cc:937-1087), LocalMapping::SearchInNeighbors' matcher: every
+    point's gated search from ONE device call, then the reference's serial side effects -- which candidate replaced which point or was
+    replaced, who is bad afterwards, the keyframe's slots, the observations added -- against the oracle's search + a Python walk of
+    :1067-1083.  Replace() runs in both directions (foreign points with 2 and 6 observations against candidates with 3)."""
+    l3 = run["L3"]
+    assert int(_rd(run, "L3_nfused.bin", np.int32)[0]) == l3["nf"] and l3["nf"] > 150 and l3["searched"] > 500
+    for name in ("kf_after", "bad", "replaced_by", "observed_at", "foreign_bad", "foreign_replaced_by"):
+        np.testing.assert_array_equal(_rd(run, f"L3_{name}.bin", np.int32), l3[name], err_msg=name)
+    assert (l3["replaced_by"] <= -100).any() and (l3["foreign_replaced_by"] >= 0).any() and (l3["observed_at"] >= 0).sum() > 100
 
 
 def test_search_by_bow_between_keyframes_member(run):
