@@ -15,6 +15,7 @@
 //   GFO_ADAPTER_PROJ_SCW      ORBmatcher::SearchByProjection(KeyFrame*, Scw, points, matched, th)  src/ORBmatcher.cc:406-518
 //   GFO_ADAPTER_FUSE_SCW      ORBmatcher::Fuse(KeyFrame*, Scw, points, th, vpReplacePoint)         src/ORBmatcher.cc:1089-1212
 //   GFO_ADAPTER_FUSE          ORBmatcher::Fuse(KeyFrame*, vector<MapPoint*>&, th)                  src/ORBmatcher.cc:937-1087
+//   GFO_ADAPTER_SIM3          ORBmatcher::SearchBySim3(KF1, KF2, vpMatches12, s12, R12, t12, th)    src/ORBmatcher.cc:1214-1438
 //   GFO_ADAPTER_COMPUTE_BOW   Frame::ComputeBoW()                                               src/Frame.cc:661-668
 //
 // Each body flattens the reference's objects into plain arrays, calls the C ABI (include/gfo.h) and writes the
@@ -34,6 +35,7 @@
 #define GFO_ADAPTER_PROJ_SCW
 #define GFO_ADAPTER_FUSE_SCW
 #define GFO_ADAPTER_FUSE
+#define GFO_ADAPTER_SIM3
 #define GFO_ADAPTER_COMPUTE_BOW
 #endif
 
@@ -822,6 +824,120 @@ int ORBmatcher::Fuse(KeyFrame* pKF, const std::vector<MapPoint*>& vpMapPoints, c
         nFused++;
     }
     return nFused;
+}
+#endif
+
+#ifdef GFO_ADAPTER_SIM3
+// LoopClosing::ComputeSim3's guided matcher (LoopClosing.cc:345): the map points of each keyframe projected into the other under the
+// estimated similarity, every point looking for its most similar keypoint of the two predicted levels on its own (TH_HIGH; nothing blocks),
+// and a pair kept only where both directions agree (:1419-1435).  Two device calls (gfo_search_by_projection_queries_points with queries
+// that block nothing), the projections (:1258-1298, :1338-1378: the reference's cv::Mat arithmetic, intrinsics of pKF1 in both directions
+// as written there) and the agreement on the host.
+namespace
+{
+// one direction: the points of `vpMapPoints` (skipping those flagged in vbAlready) through `proj` into pKFto; vnMatch[i] = keypoint of pKFto or -1
+template <class Project>
+bool sim3_direction(ORBmatcher* self, KeyFrame* pKFfrom, KeyFrame* pKFto, const std::vector<MapPoint*>& vpMapPoints, const std::vector<bool>& vbAlready,
+                    const float th, const float fx, const float fy, const float cx, const float cy, Project proj, std::vector<int>& vnMatch, gfo_ctx* c)
+{
+    (void)self; (void)pKFfrom;
+    const int N = (int)vpMapPoints.size();
+    std::vector<gfo_proj_query> q;
+    std::vector<int> src;
+    std::vector<MapPoint*> qmp;
+    for (int i = 0; i < N; i++) {
+        MapPoint* pMP = vpMapPoints[i];
+        if (!pMP || vbAlready[i]) continue;
+        if (pMP->isBad()) continue;
+        cv::Mat p3Dw = pMP->GetWorldPos();
+        cv::Mat p3Dc = proj(p3Dw);                                        // in the target keyframe's camera
+        if (p3Dc.at<float>(2) < 0.0) continue;
+        const float invz = 1.0 / p3Dc.at<float>(2);
+        const float x = p3Dc.at<float>(0) * invz;
+        const float y = p3Dc.at<float>(1) * invz;
+        const float u = fx * x + cx;
+        const float v = fy * y + cy;
+        if (!pKFto->IsInImage(u, v)) continue;
+        const float maxDistance = pMP->GetMaxDistanceInvariance();
+        const float minDistance = pMP->GetMinDistanceInvariance();
+        const float dist3D = cv::norm(p3Dc);
+        if (dist3D < minDistance || dist3D > maxDistance) continue;
+        const int nPredictedLevel = pMP->PredictScale(dist3D, pKFto);
+        gfo_proj_query e;
+        e.u = u; e.v = v; e.ur = 0.f;
+        e.radius = th * pKFto->mvScaleFactors[nPredictedLevel];
+        e.min_level = nPredictedLevel - 1;
+        e.max_level = nPredictedLevel;
+        e.angle = 0.f;
+        e.flags = 1;
+        q.push_back(e);
+        src.push_back(i);
+        qmp.push_back(pMP);
+    }
+    const int M = (int)q.size(), Nto = pKFto->N;
+    cv::Mat qDesc(M > 0 ? M : 1, 32, CV_8U);
+    for (int i = 0; i < M; i++) descriptor_row(qmp[i], qDesc, i);
+    gfo_frame_bounds fb = {(float)pKFto->mnMinX, (float)pKFto->mnMinY, (float)pKFto->mnMaxX, (float)pKFto->mnMaxY};
+    gfo_proj_mode mode = {0, 0.f, ORBmatcher::TH_HIGH, 0, 0};
+    std::vector<int32_t> outQ(Nto > 0 ? Nto : 1), outScore(Nto > 0 ? Nto : 1), outPoint(M > 0 ? M : 1);
+    int nm = 0;
+    cv::Mat keep;
+    const int rc = gfo_search_by_projection_queries_points(c, as_gfo(pKFto->mvKeysUn), rows32(pKFto->mDescriptors, keep), NULL, NULL, Nto, &fb, q.data(),
+                                                           qDesc.data, M, &mode, NULL, outQ.data(), outScore.data(), outPoint.data(), &nm);
+    if (rc != GFO_OK) {
+        report(c, "SearchBySim3");
+        return false;
+    }
+    for (int k = 0; k < M; k++)
+        if (outPoint[k] >= 0) vnMatch[src[k]] = outPoint[k] & 0xFFFF;
+    return true;
+}
+}  // namespace
+
+int ORBmatcher::SearchBySim3(KeyFrame* pKF1, KeyFrame* pKF2, std::vector<MapPoint*>& vpMatches12, const float& s12, const cv::Mat& R12, const cv::Mat& t12,
+                             const float th)
+{
+    const float &fx = pKF1->fx, &fy = pKF1->fy, &cx = pKF1->cx, &cy = pKF1->cy;
+    cv::Mat R1w = pKF1->GetRotation();
+    cv::Mat t1w = pKF1->GetTranslation();
+    cv::Mat R2w = pKF2->GetRotation();
+    cv::Mat t2w = pKF2->GetTranslation();
+    cv::Mat sR12 = s12 * R12;
+    cv::Mat sR21 = (1.0 / s12) * R12.t();
+    cv::Mat t21 = -sR21 * t12;
+    const std::vector<MapPoint*> vpMapPoints1 = pKF1->GetMapPointMatches();
+    const int N1 = (int)vpMapPoints1.size();
+    const std::vector<MapPoint*> vpMapPoints2 = pKF2->GetMapPointMatches();
+    const int N2 = (int)vpMapPoints2.size();
+    std::vector<bool> vbAlreadyMatched1(N1, false), vbAlreadyMatched2(N2, false);
+    for (int i = 0; i < N1; i++) {
+        MapPoint* pMP = vpMatches12[i];
+        if (pMP) {
+            vbAlreadyMatched1[i] = true;
+            int idx2 = pMP->GetIndexInKeyFrame(pKF2);
+            if (idx2 >= 0 && idx2 < N2) vbAlreadyMatched2[idx2] = true;
+        }
+    }
+    std::vector<int> vnMatch1(N1, -1), vnMatch2(N2, -1);
+    gfo_ctx* c = gfo_context_pin_thread();
+    bool ok = sim3_direction(this, pKF1, pKF2, vpMapPoints1, vbAlreadyMatched1, th, fx, fy, cx, cy,
+                             [&](const cv::Mat& p3Dw) { cv::Mat p3Dc1 = R1w * p3Dw + t1w; return cv::Mat(sR21 * p3Dc1 + t21); }, vnMatch1, c);
+    ok = ok && sim3_direction(this, pKF2, pKF1, vpMapPoints2, vbAlreadyMatched2, th, fx, fy, cx, cy,
+                              [&](const cv::Mat& p3Dw) { cv::Mat p3Dc2 = R2w * p3Dw + t2w; return cv::Mat(sR12 * p3Dc2 + t12); }, vnMatch2, c);
+    gfo_context_unpin_thread(c);
+    if (!ok) return 0;
+    int nFound = 0;                                                       // :1419-1435
+    for (int i1 = 0; i1 < N1; i1++) {
+        const int idx2 = vnMatch1[i1];
+        if (idx2 >= 0) {
+            const int idx1 = vnMatch2[idx2];
+            if (idx1 == i1) {
+                vpMatches12[i1] = vpMapPoints2[idx2];
+                nFound++;
+            }
+        }
+    }
+    return nFound;
 }
 #endif
 

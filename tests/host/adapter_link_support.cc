@@ -74,6 +74,7 @@ int MapPoint::PredictScale(const float&, KeyFrame*) { return mnTrackScaleLevel; 
 cv::Mat MapPoint::GetNormal() { return mNormalVector.clone(); }
 bool MapPoint::IsInKeyFrame(KeyFrame* pKF) { return mObservations.count(pKF) != 0; }
 MapPoint* MapPoint::GetReplaced() { return mpReplaced; }
+int MapPoint::GetIndexInKeyFrame(KeyFrame* pKF) { return mObservations.count(pKF) ? (int)mObservations[pKF] : -1; }
 // MapPoint::Replace as far as ORBmatcher::Fuse can see it afterwards: this point is bad and names its replacement, its observations move to
 // the replacement (or the keyframe's slot is cleared where the replacement is there already).  The statistics, the descriptor recomputation
 // and the Map's bookkeeping of src/MapPoint.cc:332-371 are not the adapter's to test.

@@ -951,6 +951,64 @@ int main(int argc, char** argv)
                         delete FP;
                     }
                 }
+                // L4. SearchBySim3(KF1 = frame 0, KF2 = frame 1, vpMatches12, s12, R12, t12, th) (ORBmatcher.cc:1214-1438): both keyframes carry map
+                //     points of their own (records as above), a few pairs are matched on entry
+                {
+                    std::vector<uint8_t> p1 = slurp(g_in + "/L4_points1.bin", false), p2 = slurp(g_in + "/L4_points2.bin", false), d1 = slurp(g_in + "/L4_desc1.bin", false),
+                                         d2 = slurp(g_in + "/L4_desc2.bin", false), cal4 = slurp(g_in + "/L4_calib.bin", false), m12 = slurp(g_in + "/L4_matches12.bin", false);
+                    Frame& F0 = *kept[0];
+                    if ((int)(p1.size() / sizeof(Rec)) == F0.N && (int)(p2.size() / sizeof(Rec)) == F1.N && cal4.size() == (16 + 16 + 1 + 9 + 3 + 1) * 4 &&
+                        (int)(m12.size() / 4) == F0.N) {
+                        const float* c4 = reinterpret_cast<const float*>(cal4.data());
+                        Frame* FA = new Frame();
+                        Frame* FB = new Frame();
+                        fill_frame(*FA, L, R, F0.mvKeys, F0.mDescriptors, F0.mvKeysRight, F0.mDescriptorsRight);
+                        fill_frame(*FB, L, R, F1.mvKeys, F1.mDescriptors, F1.mvKeysRight, F1.mDescriptorsRight);
+                        TestKF kf1(*FA), kf2(*FB);
+                        kf1.pose(mat4(c4), c4);          // (the camera centre is not read by this member)
+                        kf2.pose(mat4(c4 + 16), c4);
+                        const float s12 = c4[32];
+                        cv::Mat R12(3, 3, CV_32F), t12(3, 1, CV_32F);
+                        for (int i = 0; i < 9; i++) R12.at<float>(i / 3, i % 3) = c4[33 + i];
+                        for (int i = 0; i < 3; i++) t12.at<float>(i) = c4[42 + i];
+                        const float th4 = c4[45];
+                        auto make = [&](const std::vector<uint8_t>& raw_, const std::vector<uint8_t>& dsc_, int n_, TestKF& kf) {
+                            const Rec* rr = reinterpret_cast<const Rec*>(raw_.data());
+                            std::vector<MapPoint*> v(n_, static_cast<MapPoint*>(NULL));
+                            for (int i = 0; i < n_; i++) {
+                                if (rr[i].level < 0) continue;          // level -1: the keypoint has no map point
+                                TestMP* p = new TestMP();
+                                p->world(rr[i].p); p->bad(rr[i].bad != 0);
+                                p->mnTrackScaleLevel = rr[i].level; p->range(rr[i].dmin, rr[i].dmax);
+                                p->descriptor(&dsc_[(size_t)i * 32]);
+                                owned.push_back(p);
+                                v[i] = p;
+                            }
+                            kf.points(v);
+                            for (int i = 0; i < n_; i++) if (v[i]) v[i]->AddObservation(&kf, (size_t)i);
+                            return v;
+                        };
+                        const std::vector<MapPoint*> mp1 = make(p1, d1, F0.N, kf1), mp2 = make(p2, d2, F1.N, kf2);
+                        const int32_t* m0 = reinterpret_cast<const int32_t*>(m12.data());
+                        std::vector<MapPoint*> vpMatches12(F0.N, static_cast<MapPoint*>(NULL));
+                        for (int i = 0; i < F0.N; i++) if (m0[i] >= 0 && m0[i] < F1.N && mp2[m0[i]]) vpMatches12[i] = mp2[m0[i]];
+                        int nfound = -1;
+                        std::thread([&]() {
+                            ORBmatcher matcher(0.75f, true);
+                            nfound = matcher.SearchBySim3(&kf1, &kf2, vpMatches12, s12, R12, t12, th4);
+                        }).join();
+                        std::vector<int32_t> out(F0.N, -1);
+                        for (int i = 0; i < F0.N; i++) {
+                            if (!vpMatches12[i]) continue;
+                            out[i] = -3;
+                            for (int j = 0; j < F1.N; j++) if (mp2[j] == vpMatches12[i]) { out[i] = j; break; }
+                        }
+                        dump("L4_matches12_out.bin", out.data(), out.size() * 4);
+                        int32_t n32 = nfound;
+                        dump("L4_nfound.bin", &n32, 4);
+                        delete FA; delete FB;
+                    }
+                }
                 // L2
                 {
                     Frame* FP = new Frame();

@@ -1,4 +1,4 @@
-// stands for adapter/matchers_gfo.cc: the same eleven members, every body answers 2
+// stands for adapter/matchers_gfo.cc: the same twelve members, every body answers 2
 #include "decl.h"
 namespace ORB_SLAM2
 {
@@ -13,4 +13,5 @@ int ORBmatcher::SearchByBoW(KeyFrame*, KeyFrame*, std::vector<MapPoint*>&) { ret
 int ORBmatcher::SearchByProjection(KeyFrame*, cv::Mat, const std::vector<MapPoint*>&, std::vector<MapPoint*>&, int) { return 2; }
 int ORBmatcher::Fuse(KeyFrame*, cv::Mat, const std::vector<MapPoint*>&, float, std::vector<MapPoint*>&) { return 2; }
 int ORBmatcher::Fuse(KeyFrame*, const std::vector<MapPoint*>&, const float) { return 2; }
+int ORBmatcher::SearchBySim3(KeyFrame*, KeyFrame*, std::vector<MapPoint*>&, const float&, const cv::Mat&, const cv::Mat&, const float) { return 2; }
 }  // namespace ORB_SLAM2

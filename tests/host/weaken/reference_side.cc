@@ -14,5 +14,6 @@ int ORBmatcher::SearchByBoW(KeyFrame*, KeyFrame*, std::vector<MapPoint*>&) { ret
 int ORBmatcher::SearchByProjection(KeyFrame*, cv::Mat, const std::vector<MapPoint*>&, std::vector<MapPoint*>&, int) { return 1; }
 int ORBmatcher::Fuse(KeyFrame*, cv::Mat, const std::vector<MapPoint*>&, float, std::vector<MapPoint*>&) { return 1; }
 int ORBmatcher::Fuse(KeyFrame*, const std::vector<MapPoint*>&, const float) { return 1; }
+int ORBmatcher::SearchBySim3(KeyFrame*, KeyFrame*, std::vector<MapPoint*>&, const float&, const cv::Mat&, const cv::Mat&, const float) { return 1; }
 int ORBmatcher::untouched() { return 7; }
 }  // namespace ORB_SLAM2

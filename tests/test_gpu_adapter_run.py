@@ -474,6 +474,84 @@ def run(tmp_path_factory, oracle, euroc_l, euroc_r):
                  "observed_at": cand_at.astype(np.int32), "foreign_bad": f_bad.astype(np.int32), "foreign_replaced_by": f_repl.astype(np.int32),
                  "searched": int(searched.sum())}
 
+    # L4: SearchBySim3(KF1 = frame 0, KF2 = frame 1): both keyframes at pose Tl, map points of each placed where the OTHER frame's matching
+    # keypoint sits (frame 1 = frame 0 moved by 3 columns), a similarity close to the identity; host side restated (ORBmatcher.cc:1224-1300, 1338-1380)
+    s12 = f32(1.02)
+    R12 = _pose(0.001, -0.0015, 0.0008, [0, 0, 0])[:3, :3]
+    t12 = np.array([0.004, -0.003, 0.006], f32)
+    th4 = f32(7.5)
+    recdt = np.dtype([("bad", "<i4"), ("level", "<i4"), ("p", "<f4", 3), ("n", "<f4", 3), ("dmin", "<f4"), ("dmax", "<f4")])
+
+    def kf_points(kfrom, shift, nn):
+        z = rng.uniform(2.0, 20.0, nn)
+        uu = kfrom["x"] + shift + rng.normal(0, 1.2, nn)
+        vv_ = kfrom["y"] + rng.normal(0, 1.2, nn)
+        pc = np.stack([(uu - CX) / FX * z, (vv_ - CY) / FY * z, z], 1)
+        pw_ = ((pc - tk.astype(np.float64)[None, :]) @ Rk.astype(np.float64)).astype(f32)
+        r4 = np.zeros(nn, recdt)
+        has = rng.random(nn) < 0.8
+        r4["level"] = np.where(has, np.clip(kfrom["octave"] + rng.integers(0, 2, nn), 0, 7), -1)
+        r4["bad"] = rng.random(nn) < 0.04
+        r4["p"] = pw_
+        dd = np.sqrt(np.sum(pc ** 2, axis=1)).astype(f32)
+        r4["dmin"] = (dd * rng.choice([0.5, 0.9, 1.3], nn, p=[0.6, 0.35, 0.05])).astype(f32)
+        r4["dmax"] = (dd * rng.choice([2.0, 1.1, 0.7], nn, p=[0.6, 0.35, 0.05])).astype(f32)
+        return r4
+
+    def flipped(dsrc):
+        dd = dsrc.copy()
+        for j in range(len(dd)):
+            for b_ in rng.integers(0, 256, rng.integers(0, 60)):
+                dd[j, b_ >> 3] ^= np.uint8(1 << (b_ & 7))
+        return dd
+
+    r41, r42 = kf_points(kl0, -3.0, n0), kf_points(kl1, 3.0, n1)
+    d41, d42 = flipped(dl0), flipped(dl1)
+    r41.tofile(ind / "L4_points1.bin"); r42.tofile(ind / "L4_points2.bin")
+    d41.tofile(ind / "L4_desc1.bin"); d42.tofile(ind / "L4_desc2.bin")
+    m12_0 = np.where(rng.random(n0) < 0.05, rng.integers(0, n1, n0), -1).astype(np.int32)
+    m12_0[(m12_0 >= 0) & (r42["level"][np.maximum(m12_0, 0)] < 0)] = -1          # (a pair can only name a keypoint of KF2 that has a map point)
+    m12_0.tofile(ind / "L4_matches12.bin")
+    np.concatenate([Tl.ravel(), Tl.ravel(), np.array([s12], f32), R12.ravel(), t12, np.array([th4], f32)]).astype(f32).tofile(ind / "L4_calib.bin")
+    sR12 = (R12 * s12).astype(f32)
+    sR21 = (R12.T * f32(1.0 / float(s12))).astype(f32)                           # (1.0 / s12) * R12.t(): the factor rounded to float once
+    t21 = _mm((-sR21).astype(f32), t12[None, :])[0]
+    already1 = m12_0 >= 0
+    already2 = np.zeros(n1, bool)
+    already2[m12_0[m12_0 >= 0]] = True                                            # GetIndexInKeyFrame(pKF2) of the matched point = its keypoint there
+
+    def direction(rfrom, dfrom, already, first_R, first_t, second_R, second_t, kto, dto, nto):
+        has = rfrom["level"] >= 0
+        pc_a = (_mm(first_R, rfrom["p"]) + first_t[None, :]).astype(f32)
+        pc_b = (_mm(second_R, pc_a) + second_t[None, :]).astype(f32)
+        with np.errstate(divide="ignore"):
+            invz = (1.0 / pc_b[:, 2].astype(np.float64)).astype(f32)
+        x_ = (pc_b[:, 0] * invz).astype(f32); y_ = (pc_b[:, 1] * invz).astype(f32)
+        u_ = ((fx * x_).astype(f32) + cx).astype(f32); v_ = ((fy * y_).astype(f32) + cy).astype(f32)
+        dist = np.sqrt(np.sum(pc_b.astype(np.float64) ** 2, axis=1)).astype(f32)
+        keep_ = has & ~already & (rfrom["bad"] == 0) & ~(pc_b[:, 2] < 0) & (u_ >= 0) & (u_ < 752) & (v_ >= 0) & (v_ < 480) & ~(dist < rfrom["dmin"]) & ~(dist > rfrom["dmax"])
+        qi_ = np.nonzero(keep_)[0]
+        qq = np.zeros(len(qi_), oracle.PROJ_QUERY_DTYPE)
+        lv = rfrom["level"][qi_]
+        qq["u"], qq["v"] = u_[qi_], v_[qi_]
+        qq["radius"] = (th4 * sf[lv]).astype(f32)
+        qq["min_level"], qq["max_level"], qq["flags"] = lv - 1, lv, 1
+        op = oracle.search_by_projection_queries_points(kto, dto, None, None, (0.0, 0.0, 752.0, 480.0), qq, dfrom[qi_], False, 0.0, 100, False, None)[3]
+        match = np.full(len(rfrom), -1, np.int64)
+        match[qi_] = np.where(op >= 0, op & 0xFFFF, -1)
+        return match, len(qi_)
+
+    vn1, nq1 = direction(r41, d41, already1, Rk, tk, sR21, t21, kl1, dl1, n1)
+    vn2, nq2 = direction(r42, d42, already2, Rk, tk, sR12, t12, kl0, dl0, n0)
+    out12 = m12_0.copy()
+    nfound = 0
+    for i1 in range(n0):
+        i2 = int(vn1[i1])
+        if i2 >= 0 and int(vn2[i2]) == i1:
+            out12[i1] = i2
+            nfound += 1
+    ref["L4"] = {"nfound": nfound, "matches12": out12.astype(np.int32), "queries": (nq1, nq2)}
+
     # I: SearchByBoW(KeyFrame = frame 0, F = frame 1): feature vectors = a node id per keypoint (similar descriptors share a node)
     knode = (dl0[:, 0].astype(np.int32) >> 2)                       # 64 "vocabulary nodes" from the descriptors' first bits
     fnode = (dl1[:, 0].astype(np.int32) >> 2)
@@ -833,6 +911,14 @@ def test_local_mapping_fuse_member(run):
     for name in ("kf_after", "bad", "replaced_by", "observed_at", "foreign_bad", "foreign_replaced_by"):
         np.testing.assert_array_equal(_rd(run, f"L3_{name}.bin", np.int32), l3[name], err_msg=name)
     assert (l3["replaced_by"] <= -100).any() and (l3["foreign_replaced_by"] >= 0).any() and (l3["observed_at"] >= 0).sum() > 100
+
+
+def test_search_by_sim3_member(run):
+    """ORBmatcher::SearchBySim3(KF1, KF2, vpMatches12, s12, R12, t12, th) (ORBmatcher.cc:1214-1438), loop closing's guided matcher: both
+    directions' independent searches from two device calls, the pairs both directions agree on, the pairs matched on entry left alone."""
+    l4 = run["L4"]
+    assert int(_rd(run, "L4_nfound.bin", np.int32)[0]) == l4["nfound"] and l4["nfound"] > 150 and min(l4["queries"]) > 600
+    np.testing.assert_array_equal(_rd(run, "L4_matches12_out.bin", np.int32), l4["matches12"])
 
 
 def test_search_by_bow_between_keyframes_member(run):
