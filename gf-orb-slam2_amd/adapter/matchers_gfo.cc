@@ -16,6 +16,7 @@
 //   GFO_ADAPTER_FUSE_SCW      ORBmatcher::Fuse(KeyFrame*, Scw, points, th, vpReplacePoint)         src/ORBmatcher.cc:1089-1212
 //   GFO_ADAPTER_FUSE          ORBmatcher::Fuse(KeyFrame*, vector<MapPoint*>&, th)                  src/ORBmatcher.cc:937-1087
 //   GFO_ADAPTER_SIM3          ORBmatcher::SearchBySim3(KF1, KF2, vpMatches12, s12, R12, t12, th)    src/ORBmatcher.cc:1214-1438
+//   GFO_ADAPTER_TRIANGULATION ORBmatcher::SearchForTriangulation(KF1, KF2, F12, vMatchedPairs, bOnlyStereo) src/ORBmatcher.cc:770-935
 //   GFO_ADAPTER_COMPUTE_BOW   Frame::ComputeBoW()                                               src/Frame.cc:661-668
 //
 // Each body flattens the reference's objects into plain arrays, calls the C ABI (include/gfo.h) and writes the
@@ -36,6 +37,7 @@
 #define GFO_ADAPTER_FUSE_SCW
 #define GFO_ADAPTER_FUSE
 #define GFO_ADAPTER_SIM3
+#define GFO_ADAPTER_TRIANGULATION
 #define GFO_ADAPTER_COMPUTE_BOW
 #endif
 
@@ -974,6 +976,54 @@ int ORBmatcher::SearchByBoW(KeyFrame* pKF1, KeyFrame* pKF2, std::vector<MapPoint
     if (rc != GFO_OK) return 0;
     for (int i = 0; i < n1; i++)
         if (out[i] >= 0) vpMatches12[i] = vpMapPoints2[out[i]];      // :717
+    return nmatches;
+}
+#endif
+
+// ---------------------------------------------------------------------------------------------------------------
+#ifdef GFO_ADAPTER_TRIANGULATION
+// Local mapping's matcher for new map points (LocalMapping::CreateNewMapPoints, LocalMapping.cc:435), ORBmatcher.cc:770-935: keypoints
+// WITHOUT a map point of two keyframes under the epipolar constraint.  The epipole is computed here with the same cv::Mat expressions
+// the reference uses (:777-783); the sweep, CheckDistEpipolarLine and the rotation histogram run on the device.
+int ORBmatcher::SearchForTriangulation(KeyFrame* pKF1, KeyFrame* pKF2, cv::Mat F12, std::vector<std::pair<size_t, size_t> >& vMatchedPairs,
+                                       const bool bOnlyStereo)
+{
+    cv::Mat Cw = pKF1->GetCameraCenter();
+    cv::Mat R2w = pKF2->GetRotation();
+    cv::Mat t2w = pKF2->GetTranslation();
+    cv::Mat C2 = R2w * Cw + t2w;
+    const float invz = 1.0f / C2.at<float>(2);
+    const float ex = pKF2->fx * C2.at<float>(0) * invz + pKF2->cx;
+    const float ey = pKF2->fy * C2.at<float>(1) * invz + pKF2->cy;
+
+    vMatchedPairs.clear();
+    const int n1 = pKF1->N, n2 = pKF2->N;
+    if (n1 <= 0 || n2 <= 0) return 0;
+    float f12[9];
+    for (int r = 0; r < 3; r++)
+        for (int q = 0; q < 3; q++) f12[3 * r + q] = F12.at<float>(r, q);
+    FlatFeatVec fv1(pKF1->mFeatVec), fv2(pKF2->mFeatVec);
+    // GetMapPoint(idx) != NULL for every keypoint: one locked copy of each keyframe's vector instead of a lock per keypoint (the
+    // reference reads them one at a time while tracking may add points; either is a snapshot local mapping tolerates, :812, :835)
+    const std::vector<MapPoint*> mp1 = pKF1->GetMapPointMatches(), mp2 = pKF2->GetMapPointMatches();
+    std::vector<uint8_t> has1(n1, 0), has2(n2, 0);
+    for (int i = 0; i < n1 && i < (int)mp1.size(); i++) has1[i] = mp1[i] != NULL;
+    for (int i = 0; i < n2 && i < (int)mp2.size(); i++) has2[i] = mp2[i] != NULL;
+    std::vector<int32_t> out(n1);
+    int nmatches = 0;
+    cv::Mat keep1, keep2;
+    gfo_ctx* c = gfo_context_pin_thread();
+    const int rc = gfo_search_for_triangulation(c, as_gfo(pKF1->mvKeysUn), rows32(pKF1->mDescriptors, keep1), has1.data(), pKF1->mvuRight.data(), n1,
+                                                &fv1.view, as_gfo(pKF2->mvKeysUn), rows32(pKF2->mDescriptors, keep2), has2.data(),
+                                                pKF2->mvuRight.data(), n2, &fv2.view, pKF2->mvScaleFactors.data(), pKF2->mvLevelSigma2.data(),
+                                                (int)pKF2->mvScaleFactors.size(), f12, ex, ey, bOnlyStereo ? 1 : 0, mbCheckOrientation ? 1 : 0,
+                                                out.data(), &nmatches);
+    if (rc != GFO_OK) report(c, "SearchForTriangulation");
+    gfo_context_unpin_thread(c);
+    if (rc != GFO_OK) return 0;
+    vMatchedPairs.reserve(nmatches > 0 ? nmatches : 0);                    // :922-930
+    for (int i = 0; i < n1; i++)
+        if (out[i] >= 0) vMatchedPairs.push_back(std::make_pair((size_t)i, (size_t)out[i]));
     return nmatches;
 }
 #endif

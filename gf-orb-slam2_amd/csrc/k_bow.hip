@@ -285,6 +285,96 @@ __global__ __launch_bounds__(256) void k_bow_rotation(BowArgs a)
     }
 }
 
+// ORBmatcher::SearchForTriangulation (ORBmatcher.cc:770-935), local mapping's matcher for NEW map points: keypoints without a map point in two
+// keyframes, node by node of the shared vocabulary level.  Unlike the overloads above nothing a keypoint finds hides a candidate from the next
+// one -- vbMatched2 is declared and tested but never set (:790, :832) -- so every keypoint of the first keyframe is a search of its own: the
+// candidate with the smallest distance <= TH_LOW among those that pass the stereo / epipole / epipolar-line gates (:836-860), the LAST such
+// candidate of the node's list on a tie (`dist > bestDist` skips, an equal distance replaces).  One wavefront per common node; the lanes take
+// the node's second-keyframe keypoints side by side for one first-keyframe keypoint at a time.
+struct TriArgs {
+    const uint8_t* desc1; const gfo_keypoint* kp1; const uint8_t* flag1;   // flag: bit 0 has a map point, bit 1 mvuRight >= 0
+    const int* start1; const unsigned* items1;
+    const uint8_t* desc2; const gfo_keypoint* kp2; const uint8_t* flag2;
+    const int* start2; const unsigned* items2;
+    const int2* pairs; int npairs;
+    float f12[9]; float ex, ey;
+    const float* scale2; const float* sigma2;   // pKF2->mvScaleFactors, mvLevelSigma2 (device)
+    int only_stereo, check_ori, n1;
+    int* out; int* rot_bin; int* counters;
+};
+
+// CheckDistEpipolarLine (ORBmatcher.cc:251-268): the expressions as written, float, left to right, un-fused; the last comparison in double
+__device__ __forceinline__ bool tri_epipolar_ok(const TriArgs& a, float x1, float y1, float x2, float y2, int octave2)
+{
+    const float la = x1 * a.f12[0] + y1 * a.f12[3] + a.f12[6];
+    const float lb = x1 * a.f12[1] + y1 * a.f12[4] + a.f12[7];
+    const float lc = x1 * a.f12[2] + y1 * a.f12[5] + a.f12[8];
+    const float num = la * x2 + lb * y2 + lc;
+    const float den = la * la + lb * lb;
+    if (den == 0) return false;
+    const float dsqr = num * num / den;
+    return (double)dsqr < 3.84 * (double)a.sigma2[octave2];
+}
+
+__global__ __launch_bounds__(256) void k_bow_triangulate(TriArgs a)
+{
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int pi = blockIdx.x * 4 + wave;
+    if (pi >= a.npairs) return;
+    const int2 pr = a.pairs[pi];
+    const int b1 = a.start1[pr.x], e1 = a.start1[pr.x + 1];
+    const int b2 = a.start2[pr.y], e2 = a.start2[pr.y + 1];
+    const float factor = 1.0f / HISTO_LENGTH;
+    int accepted = 0;
+    for (int i1 = b1; i1 < e1; i1++) {
+        const unsigned idx1 = a.items1[i1];
+        const unsigned fl1 = a.flag1[idx1];
+        if (fl1 & 1) continue;                               // pMP1: there is a map point already (:812-815)
+        const bool stereo1 = (fl1 & 2) != 0;
+        if (a.only_stereo && !stereo1) continue;             // :819-821
+        const gfo_keypoint k1 = a.kp1[idx1];
+        const uint4* d1 = reinterpret_cast<const uint4*>(a.desc1 + (long long)idx1 * 32);
+        const uint4 p0 = d1[0], p1 = d1[1];
+        unsigned best = 0xFFFFFFFFu;                         // dist << 20 | (0xFFFFF - position): the smallest distance, the LAST position on a tie
+        for (int j = b2 + lane; j < e2; j += 64) {
+            const unsigned idx2 = a.items2[j];
+            const unsigned fl2 = a.flag2[idx2];
+            if (fl2 & 1) continue;                           // vbMatched2[idx2] (never set) || pMP2 (:832-833)
+            const bool stereo2 = (fl2 & 2) != 0;
+            if (a.only_stereo && !stereo2) continue;
+            const uint4* d2 = reinterpret_cast<const uint4*>(a.desc2 + (long long)idx2 * 32);
+            const uint4 q0 = d2[0], q1 = d2[1];
+            const unsigned dist = __popc(p0.x ^ q0.x) + __popc(p0.y ^ q0.y) + __popc(p0.z ^ q0.z) + __popc(p0.w ^ q0.w) +
+                                  __popc(p1.x ^ q1.x) + __popc(p1.y ^ q1.y) + __popc(p1.z ^ q1.z) + __popc(p1.w ^ q1.w);
+            if (dist > TH_LOW) continue;                     // :845 (the running `dist > bestDist` only prunes what could not win)
+            const gfo_keypoint k2 = a.kp2[idx2];
+            const int oct2 = min(max(k2.octave, 0), GFO_MAX_LEVELS - 1);
+            if (!stereo1 && !stereo2) {                      // :850-856: too close to the epipole
+                const float distex = a.ex - k2.x, distey = a.ey - k2.y;
+                if (distex * distex + distey * distey < 100 * a.scale2[oct2]) continue;
+            }
+            if (!tri_epipolar_ok(a, k1.x, k1.y, k2.x, k2.y, oct2)) continue;
+            const unsigned key = (dist << 20) | (0xFFFFFu - (unsigned)(j - b2));
+            best = min(best, key);
+        }
+        best = st_wave_min(best);
+        if (best == 0xFFFFFFFFu) continue;
+        const unsigned idx2 = a.items2[b2 + (int)(0xFFFFFu - (best & 0xFFFFFu))];
+        if (lane == 0) {
+            a.out[idx1] = (int)idx2;
+            if (a.check_ori) {
+                float rot = k1.angle - a.kp2[idx2].angle;
+                if (rot < 0.0f) rot += 360.0f;
+                int bin = (int)roundf(rot * factor);
+                if (bin == HISTO_LENGTH) bin = 0;
+                a.rot_bin[idx1] = bin;
+            }
+        }
+        accepted++;
+    }
+    if (lane == 0 && accepted) atomicAdd(&a.counters[0], accepted);
+}
+
 #define BTRY(c, expr)                                                                             \
     do {                                                                                          \
         hipError_t e_ = (expr);                                                                   \
@@ -476,6 +566,106 @@ extern "C" int gfo_search_by_bow_keyframes(gfo_ctx* c, const uint8_t* desc1, con
     for (int i = 0; i < n1; i++) out_idx2[i] = -1;
     for (int j = 0; j < n2; j++)
         if (taker[j] >= 0 && taker[j] < n1) out_idx2[taker[j]] = j;
+    return GFO_OK;
+}
+
+extern "C" int gfo_search_for_triangulation(gfo_ctx* c, const gfo_keypoint* kp1, const uint8_t* desc1, const uint8_t* has_mp1, const float* u_right1, int n1,
+                                            const gfo_feature_vector* fv1, const gfo_keypoint* kp2, const uint8_t* desc2, const uint8_t* has_mp2,
+                                            const float* u_right2, int n2, const gfo_feature_vector* fv2, const float* scale_factors2,
+                                            const float* level_sigma2_2, int nlevels, const float* f12, float ex, float ey, int only_stereo,
+                                            int check_orientation, int32_t* out_idx2, int* nmatches)
+{
+    if (!c) return GFO_ERR_INVALID;
+    if (!fv1 || !fv2 || !out_idx2 || !nmatches || !f12 || !scale_factors2 || !level_sigma2_2 || nlevels < 1 || nlevels > GFO_MAX_LEVELS || n1 < 0 || n2 < 0 ||
+        (n1 > 0 && (!kp1 || !desc1 || !has_mp1)) || (n2 > 0 && (!kp2 || !desc2 || !has_mp2))) {
+        c->err = "gfo_search_for_triangulation: bad argument";
+        return GFO_ERR_INVALID;
+    }
+    for (int i = 0; i < n2; i++)
+        if (kp2[i].octave < 0 || kp2[i].octave >= nlevels) { c->err = "gfo_search_for_triangulation: keypoint octave outside the level tables"; return GFO_ERR_INVALID; }
+    if (check_orientation) {
+        for (int i = 0; i < n1; i++)
+            if (!(kp1[i].angle >= 0.f && kp1[i].angle <= 360.f)) { c->err = "gfo_search_for_triangulation: keypoint angle outside 0..360"; return GFO_ERR_INVALID; }
+        for (int i = 0; i < n2; i++)
+            if (!(kp2[i].angle >= 0.f && kp2[i].angle <= 360.f)) { c->err = "gfo_search_for_triangulation: keypoint angle outside 0..360"; return GFO_ERR_INVALID; }
+    }
+    if (const char* why = bow_check_feature_vector(fv1, n1)) { c->err = std::string("gfo_search_for_triangulation: first feature vector: ") + why; return GFO_ERR_INVALID; }
+    if (const char* why = bow_check_feature_vector(fv2, n2)) { c->err = std::string("gfo_search_for_triangulation: second feature vector: ") + why; return GFO_ERR_INVALID; }
+    *nmatches = 0;
+    for (int i = 0; i < n1; i++) out_idx2[i] = -1;
+    if (n1 == 0 || n2 == 0) return GFO_OK;
+    std::vector<int2> pairs;
+    for (int a = 0, b = 0; a < fv1->n_nodes && b < fv2->n_nodes;) {
+        if (fv1->node_ids[a] == fv2->node_ids[b]) { pairs.push_back(make_int2(a, b)); a++; b++; }
+        else if (fv1->node_ids[a] < fv2->node_ids[b]) a++;
+        else b++;
+    }
+    if (pairs.empty()) return GFO_OK;
+    for (const int2& pr : pairs)
+        if (fv2->node_start[pr.y + 1] - fv2->node_start[pr.y] >= (1 << 20)) { c->err = "gfo_search_for_triangulation: node with more than 2^20 keypoints"; return GFO_ERR_INVALID; }
+    BTRY(c, hipSetDevice(c->device));
+    const int it1 = fv1->node_start[fv1->n_nodes], it2 = fv2->node_start[fv2->n_nodes];
+    size_t off = 0;
+    auto take = [&](size_t bytes) { size_t o = off; off = (off + bytes + 255) / 256 * 256; return o; };
+    const size_t o_d1 = take(32 * (size_t)n1), o_k1 = take(sizeof(gfo_keypoint) * (size_t)n1), o_f1 = take(n1), o_s1 = take(4 * (size_t)(fv1->n_nodes + 1)),
+                 o_i1 = take(4 * (size_t)(it1 > 0 ? it1 : 1)), o_d2 = take(32 * (size_t)n2), o_k2 = take(sizeof(gfo_keypoint) * (size_t)n2), o_f2 = take(n2),
+                 o_s2 = take(4 * (size_t)(fv2->n_nodes + 1)), o_i2 = take(4 * (size_t)(it2 > 0 ? it2 : 1)), o_pr = take(sizeof(int2) * pairs.size()),
+                 o_sc = take(4 * GFO_MAX_LEVELS), o_sg = take(4 * GFO_MAX_LEVELS), o_rb = take(4 * (size_t)n1), o_out = take(4 * (size_t)n1), o_cnt = take(16);
+    if (off > c->scratch_bytes) {
+        (void)hipStreamSynchronize(c->stream);
+        if (c->d_scratch) (void)hipFree(c->d_scratch);
+        c->d_scratch = nullptr;
+        c->scratch_bytes = 0;
+        BTRY(c, hipMalloc(&c->d_scratch, off + off / 2));
+        c->scratch_bytes = off + off / 2;
+    }
+    uint8_t* S = (uint8_t*)c->d_scratch;
+    hipStream_t st = c->stream;
+    GfoXfer x(c);
+    if (int rc = x.in(o_cnt + 16)) return rc;
+    x.put(o_d1, desc1, 32 * (size_t)n1); x.put(o_k1, kp1, sizeof(gfo_keypoint) * (size_t)n1);
+    x.put(o_d2, desc2, 32 * (size_t)n2); x.put(o_k2, kp2, sizeof(gfo_keypoint) * (size_t)n2);
+    for (int i = 0; i < n1; i++) x.H[o_f1 + i] = (uint8_t)((has_mp1[i] ? 1 : 0) | (u_right1 && u_right1[i] >= 0 ? 2 : 0));   // bStereo1, :817
+    for (int i = 0; i < n2; i++) x.H[o_f2 + i] = (uint8_t)((has_mp2[i] ? 1 : 0) | (u_right2 && u_right2[i] >= 0 ? 2 : 0));
+    x.put(o_s1, fv1->node_start, 4 * (size_t)(fv1->n_nodes + 1));
+    if (it1) x.put(o_i1, fv1->items, 4 * (size_t)it1);
+    x.put(o_s2, fv2->node_start, 4 * (size_t)(fv2->n_nodes + 1));
+    if (it2) x.put(o_i2, fv2->items, 4 * (size_t)it2);
+    x.put(o_pr, pairs.data(), sizeof(int2) * pairs.size());
+    {
+        float tab[GFO_MAX_LEVELS] = {0};
+        for (int l = 0; l < nlevels; l++) tab[l] = scale_factors2[l];
+        x.put(o_sc, tab, sizeof tab);
+        for (int l = 0; l < nlevels; l++) tab[l] = level_sigma2_2[l];
+        x.put(o_sg, tab, sizeof tab);
+    }
+    memset(x.H + o_rb, 0xFF, o_cnt - o_rb);   // rot_bin and out = -1
+    memset(x.H + o_cnt, 0, 16);
+    BTRY(c, x.up(S, o_cnt + 16, st));
+    TriArgs a{};
+    a.desc1 = S + o_d1; a.kp1 = (const gfo_keypoint*)(S + o_k1); a.flag1 = S + o_f1; a.start1 = (const int*)(S + o_s1); a.items1 = (const unsigned*)(S + o_i1);
+    a.desc2 = S + o_d2; a.kp2 = (const gfo_keypoint*)(S + o_k2); a.flag2 = S + o_f2; a.start2 = (const int*)(S + o_s2); a.items2 = (const unsigned*)(S + o_i2);
+    a.pairs = (const int2*)(S + o_pr); a.npairs = (int)pairs.size();
+    for (int i = 0; i < 9; i++) a.f12[i] = f12[i];
+    a.ex = ex; a.ey = ey;
+    a.scale2 = (const float*)(S + o_sc); a.sigma2 = (const float*)(S + o_sg);
+    a.only_stereo = only_stereo ? 1 : 0; a.check_ori = check_orientation ? 1 : 0; a.n1 = n1;
+    a.out = (int*)(S + o_out); a.rot_bin = (int*)(S + o_rb); a.counters = (int*)(S + o_cnt);
+    if (int rc = x.out(o_cnt + 16 - o_out)) return rc;
+    gfo_prof_begin(c, ST_BOW);
+    GFO_LAUNCH(c, k_bow_triangulate, dim3((a.npairs + 3) / 4), dim3(256), 0, st, a);
+    if (a.check_ori) {   // the rotation histogram over the FIRST keyframe's keypoints (:876, :913-917): the same kernel, its arrays of length n1
+        BowArgs r{};
+        r.n_f = n1; r.out = a.out; r.rot_bin = a.rot_bin; r.counters = a.counters; r.check_ori = 1;
+        GFO_LAUNCH(c, k_bow_rotation, dim3(1), dim3(256), 0, st, r);
+    }
+    gfo_prof_end(c);
+    if (int lrc = gfo_take_launch_err(c)) return lrc;
+    BTRY(c, hipGetLastError());
+    BTRY(c, x.down(S + o_out, o_cnt + 16 - o_out, st));
+    BTRY(c, hipStreamSynchronize(st));
+    memcpy(out_idx2, x.HO, 4 * (size_t)n1);
+    *nmatches = reinterpret_cast<const int*>(x.HO + (o_cnt - o_out))[0];
     return GFO_OK;
 }
 
@@ -994,6 +1184,6 @@ extern "C" int gfo_compute_bow(gfo_ctx* c, const uint8_t* desc, int n, int level
 // mutex so that no two host threads ever race through that first-launch path (round 3: eight threads, first k_pack_results).
 void gfo_kernels_bow(std::vector<const void*>& v)
 {
-    v.push_back((const void*)k_bow_match); v.push_back((const void*)k_bow_budget); v.push_back((const void*)k_bow_rotation); v.push_back((const void*)k_bow_transform);
+    v.push_back((const void*)k_bow_match); v.push_back((const void*)k_bow_budget); v.push_back((const void*)k_bow_rotation); v.push_back((const void*)k_bow_triangulate); v.push_back((const void*)k_bow_transform);
     v.push_back((const void*)k_bow_fold<false>); v.push_back((const void*)k_bow_fold<true>);
 }

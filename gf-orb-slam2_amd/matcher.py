@@ -256,6 +256,34 @@ class ORBmatcher:
                                                                       1 if self.mbCheckOrientation else 0, ptr(out), C.byref(nm)))
         return nm.value, out[:n1]
 
+    def SearchForTriangulation(self, kp1, desc1, has_mp1, u_right1, fv1, kp2, desc2, has_mp2, u_right2, fv2, scale_factors2, level_sigma2_2, f12, ex, ey,
+                               only_stereo=False):
+        """ORBmatcher::SearchForTriangulation(pKF1, pKF2, F12, vMatchedPairs, bOnlyStereo) -- ORBmatcher.cc:770-935.
+        Returns (nmatches, out_idx2[n1])."""
+        kp1 = np.ascontiguousarray(kp1, KEYPOINT_DTYPE); kp2 = np.ascontiguousarray(kp2, KEYPOINT_DTYPE)
+        desc1 = np.ascontiguousarray(desc1, np.uint8); desc2 = np.ascontiguousarray(desc2, np.uint8)
+        h1 = np.ascontiguousarray(has_mp1, np.uint8); h2 = np.ascontiguousarray(has_mp2, np.uint8)
+        u1 = None if u_right1 is None else np.ascontiguousarray(u_right1, np.float32)
+        u2 = None if u_right2 is None else np.ascontiguousarray(u_right2, np.float32)
+        sf2 = np.ascontiguousarray(scale_factors2, np.float32); sg2 = np.ascontiguousarray(level_sigma2_2, np.float32)
+        f = np.ascontiguousarray(f12, np.float32).reshape(9)
+        keep = []
+
+        def fv(t):
+            ids, start, items = (np.ascontiguousarray(t[0], np.uint32), np.ascontiguousarray(t[1], np.int32),
+                                 np.ascontiguousarray(t[2], np.uint32))
+            keep.append((ids, start, items))
+            return FeatureVectorC(ids.ctypes.data, start.ctypes.data, items.ctypes.data, len(ids))
+        a, b = fv(fv1), fv(fv2)
+        n1 = len(kp1)
+        out = np.full(max(n1, 1), -1, np.int32)
+        nm = C.c_int()
+        check(self._L, self._ctx, self._L.gfo_search_for_triangulation(self._ctx, ptr(kp1), ptr(desc1), ptr(h1), ptr(u1), n1, C.byref(a), ptr(kp2), ptr(desc2),
+                                                                       ptr(h2), ptr(u2), len(kp2), C.byref(b), ptr(sf2), ptr(sg2), len(sf2), ptr(f),
+                                                                       float(ex), float(ey), 1 if only_stereo else 0,
+                                                                       1 if self.mbCheckOrientation else 0, ptr(out), C.byref(nm)))
+        return nm.value, out[:n1]
+
     def SearchByProjectionQueries(self, keys_un, desc, u_right, kp_angle, bounds, queries, q_desc, use_ratio=False,
                                   th_dist=None, kp_taken=None, max_matches=0):
         """The query form both projection overloads reduce to (gfo_search_by_projection_queries); with

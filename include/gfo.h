@@ -434,6 +434,22 @@ int gfo_search_by_bow_keyframes(gfo_ctx* ctx, const uint8_t* desc1, const float*
                                 const uint8_t* mp_valid2, int n2, const gfo_feature_vector* fv2, float nn_ratio,
                                 int check_orientation, int32_t* out_idx2, int* nmatches);
 
+/* ORBmatcher::SearchForTriangulation(KeyFrame* pKF1, KeyFrame* pKF2, cv::Mat F12, vector<pair<size_t, size_t>>& vMatchedPairs, bOnlyStereo)
+ * -- include/ORBmatcher.h, src/ORBmatcher.cc:770-935; local mapping's matcher for NEW map points (LocalMapping::CreateNewMapPoints,
+ * src/LocalMapping.cc:435).  Keypoints WITHOUT a map point (has_mp = GetMapPoint(i) != NULL) of two keyframes, node by node of their
+ * feature vectors: for a keypoint of pKF1 the candidate of pKF2 with the smallest distance <= TH_LOW among those that pass the gates of
+ * :836-860 -- both stereo when only_stereo (u_right >= 0), not within 100 * mvScaleFactors[octave] (squared pixels) of the epipole
+ * (ex, ey) when neither is stereo, CheckDistEpipolarLine (:251-268: distance^2 to the epipolar line x1' F12 below 3.84 * mvLevelSigma2[
+ * octave]; f12 row-major) -- and on a tie the LAST one of the node's list.  Nothing a keypoint finds hides a candidate from the next one
+ * (the reference declares vbMatched2 and never sets it).  Rotation histogram over the pairs as in the other matchers when
+ * check_orientation.  out_idx2[n1] = vMatches12 (-1 none); vMatchedPairs = the (i, out_idx2[i]) with out_idx2[i] >= 0 in ascending i.
+ * Float expressions are evaluated as written (left to right, no fused multiply-adds, a correctly rounded division). */
+int gfo_search_for_triangulation(gfo_ctx* ctx, const gfo_keypoint* kp1, const uint8_t* desc1, const uint8_t* has_mp1, const float* u_right1, int n1,
+                                 const gfo_feature_vector* fv1, const gfo_keypoint* kp2, const uint8_t* desc2, const uint8_t* has_mp2,
+                                 const float* u_right2, int n2, const gfo_feature_vector* fv2, const float* scale_factors2,
+                                 const float* level_sigma2_2, int nlevels, const float* f12, float ex, float ey, int only_stereo,
+                                 int check_orientation, int32_t* out_idx2, int* nmatches);
+
 /* Frame::ComputeBoW -> DBoW2 TemplatedVocabulary<FORB>::transform(features, BowVector&, FeatureVector&, levelsup)
  * src/Frame.cc:661-668, Thirdparty/DBoW2/DBoW2/TemplatedVocabulary.h:1140-1212 and the per-feature tree descent
  * :1231-1272 with FORB::distance (FORB.cpp:81).  The vocabulary tree is passed flattened: node 0 is the root,

@@ -1611,6 +1611,93 @@ int orc_search_by_bow_keyframes(const uint8_t* desc1, const float* angle1, const
     return nmatches;
 }
 
+/* ORBmatcher::CheckDistEpipolarLine -- ORBmatcher.cc:251-268 (f12 row-major: F12.at<float>(r, c) = f12[3 r + c]) */
+static int check_dist_epipolar_line(float x1, float y1, float x2, float y2, const float* f12, float sigma2)
+{
+    const float a = x1 * f12[0] + y1 * f12[3] + f12[6];
+    const float b = x1 * f12[1] + y1 * f12[4] + f12[7];
+    const float c = x1 * f12[2] + y1 * f12[5] + f12[8];
+    const float num = a * x2 + b * y2 + c;
+    const float den = a * a + b * b;
+    if (den == 0) return 0;
+    const float dsqr = num * num / den;
+    return dsqr < 3.84 * sigma2;
+}
+
+/* ORBmatcher::SearchForTriangulation -- ORBmatcher.cc:770-935.  has_mp = GetMapPoint(i) != NULL; u_right = mvuRight (may be NULL: monocular);
+ * (ex, ey) the epipole the caller computed (:777-783).  vbMatched2 is declared and tested in the reference but never set: kept, unset.
+ * out12[n1] = vMatches12. */
+int orc_search_for_triangulation(const orc_keypoint* kp1, const uint8_t* desc1, const uint8_t* has_mp1, const float* u_right1, int n1,
+                                 const orc_feature_vector* fv1, const orc_keypoint* kp2, const uint8_t* desc2, const uint8_t* has_mp2,
+                                 const float* u_right2, int n2, const orc_feature_vector* fv2, const float* scale_factors2, const float* level_sigma2_2,
+                                 const float* f12, float ex, float ey, int only_stereo, int check_orientation, int* out12)
+{
+    enum { HISTO_LENGTH = 30, TH_LOW_ = 50 };
+    int nmatches = 0;
+    uint8_t* vbMatched2 = (uint8_t*)calloc(n2 > 0 ? n2 : 1, 1);
+    for (int i = 0; i < n1; i++) out12[i] = -1;
+    int* rot_bin = (int*)malloc(sizeof(int) * (n1 > 0 ? n1 : 1));
+    for (int i = 0; i < n1; i++) rot_bin[i] = -1;
+    int histo[HISTO_LENGTH];
+    memset(histo, 0, sizeof histo);
+    const float factor = 1.0f / HISTO_LENGTH;
+    int a = 0, b = 0;
+    while (a < fv1->n_nodes && b < fv2->n_nodes) {
+        if (fv1->node_ids[a] == fv2->node_ids[b]) {
+            for (int i1 = fv1->node_start[a]; i1 < fv1->node_start[a + 1]; i1++) {
+                const unsigned idx1 = fv1->items[i1];
+                if (has_mp1[idx1]) continue;
+                const int bStereo1 = u_right1 && u_right1[idx1] >= 0;
+                if (only_stereo && !bStereo1) continue;
+                int bestDist = TH_LOW_, bestIdx2 = -1;
+                for (int i2 = fv2->node_start[b]; i2 < fv2->node_start[b + 1]; i2++) {
+                    const unsigned idx2 = fv2->items[i2];
+                    if (vbMatched2[idx2] || has_mp2[idx2]) continue;
+                    const int bStereo2 = u_right2 && u_right2[idx2] >= 0;
+                    if (only_stereo && !bStereo2) continue;
+                    const int dist = orc_hamming256(desc1 + (size_t)idx1 * 32, desc2 + (size_t)idx2 * 32);
+                    if (dist > TH_LOW_ || dist > bestDist) continue;
+                    if (!bStereo1 && !bStereo2) {
+                        const float distex = ex - kp2[idx2].x, distey = ey - kp2[idx2].y;
+                        if (distex * distex + distey * distey < 100 * scale_factors2[kp2[idx2].octave]) continue;
+                    }
+                    if (check_dist_epipolar_line(kp1[idx1].x, kp1[idx1].y, kp2[idx2].x, kp2[idx2].y, f12, level_sigma2_2[kp2[idx2].octave])) {
+                        bestIdx2 = (int)idx2;
+                        bestDist = dist;
+                    }
+                }
+                if (bestIdx2 >= 0) {
+                    out12[idx1] = bestIdx2;
+                    nmatches++;
+                    if (check_orientation) {
+                        float rot = kp1[idx1].angle - kp2[bestIdx2].angle;
+                        if (rot < 0.0) rot += 360.0f;
+                        int bin = (int)roundf(rot * factor);
+                        if (bin == HISTO_LENGTH) bin = 0;
+                        rot_bin[idx1] = bin;
+                        histo[bin]++;
+                    }
+                }
+            }
+            a++; b++;
+        } else if (fv1->node_ids[a] < fv2->node_ids[b]) a++;
+        else b++;
+    }
+    if (check_orientation) {
+        int ind1 = -1, ind2 = -1, ind3 = -1;
+        orc_three_maxima(histo, HISTO_LENGTH, &ind1, &ind2, &ind3);
+        for (int i = 0; i < n1; i++) {
+            const int bin = rot_bin[i];
+            if (bin < 0 || bin == ind1 || bin == ind2 || bin == ind3) continue;
+            out12[i] = -1;
+            nmatches--;
+        }
+    }
+    free(rot_bin);
+    free(vbMatched2);
+    return nmatches;
+}
+
 /* ------------------------------------------------------------------------------------------
  * ORBmatcher::SearchByProjection(Frame& CurrentFrame, const Frame& LastFrame, th, bMono, ...)
  * -- ORBmatcher.cc:1440-1593 -- on pre-projected queries; with use_ratio it is the map-point overload

@@ -238,6 +238,11 @@ int orc_search_by_bow(const uint8_t* kf_desc, const float* kf_angle, const uint8
 int orc_search_by_bow_keyframes(const uint8_t* desc1, const float* angle1, const uint8_t* valid1, int n1, const orc_feature_vector* fv1,
                                 const uint8_t* desc2, const float* angle2, const uint8_t* valid2, int n2, const orc_feature_vector* fv2,
                                 float nn_ratio, int check_orientation, int* out12);
+/* ORBmatcher::SearchForTriangulation -- ORBmatcher.cc:770-935 (+ CheckDistEpipolarLine :251-268); out12[n1] = vMatches12 */
+int orc_search_for_triangulation(const orc_keypoint* kp1, const uint8_t* desc1, const uint8_t* has_mp1, const float* u_right1, int n1,
+                                 const orc_feature_vector* fv1, const orc_keypoint* kp2, const uint8_t* desc2, const uint8_t* has_mp2,
+                                 const float* u_right2, int n2, const orc_feature_vector* fv2, const float* scale_factors2, const float* level_sigma2_2,
+                                 const float* f12, float ex, float ey, int only_stereo, int check_orientation, int* out12);
 /* ORBmatcher::ComputeThreeMaxima -- ORBmatcher.cc:1723-1764 on the bin sizes */
 void orc_three_maxima(const int* histo_sizes, int L, int* ind1, int* ind2, int* ind3);
 

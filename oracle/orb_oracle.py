@@ -802,6 +802,28 @@ def search_by_bow_keyframes(desc1, angle1, valid1, fv1, desc2, angle2, valid2, f
     return nm, out[:len(desc1)]
 
 
+def search_for_triangulation(kp1, desc1, has_mp1, u_right1, fv1, kp2, desc2, has_mp2, u_right2, fv2, scale_factors2, level_sigma2_2, f12, ex, ey,
+                             only_stereo=False, check_orientation=True):
+    """ORBmatcher::SearchForTriangulation, ORBmatcher.cc:770-935.  Returns (nmatches, out12[n1])."""
+    kp1 = np.ascontiguousarray(kp1, KEYPOINT_DTYPE); kp2 = np.ascontiguousarray(kp2, KEYPOINT_DTYPE)
+    desc1 = np.ascontiguousarray(desc1, np.uint8); desc2 = np.ascontiguousarray(desc2, np.uint8)
+    h1 = np.ascontiguousarray(has_mp1, np.uint8); h2 = np.ascontiguousarray(has_mp2, np.uint8)
+    u1 = None if u_right1 is None else np.ascontiguousarray(u_right1, np.float32)
+    u2 = None if u_right2 is None else np.ascontiguousarray(u_right2, np.float32)
+    sf2 = np.ascontiguousarray(scale_factors2, np.float32); sg2 = np.ascontiguousarray(level_sigma2_2, np.float32)
+    f = np.ascontiguousarray(f12, np.float32).reshape(9)
+    a, keep_a = _fv_struct(fv1)
+    b, keep_b = _fv_struct(fv2)
+    out = np.full(max(len(kp1), 1), -1, np.int32)
+    L = lib()
+    vp = C.c_void_p
+    L.orc_search_for_triangulation.argtypes = [vp, vp, vp, vp, C.c_int, C.POINTER(FeatureVectorC), vp, vp, vp, vp, C.c_int, C.POINTER(FeatureVectorC), vp, vp,
+                                               vp, C.c_float, C.c_float, C.c_int, C.c_int, vp]
+    nm = L.orc_search_for_triangulation(_p(kp1), _p(desc1), _p(h1), _p(u1), len(kp1), C.byref(a), _p(kp2), _p(desc2), _p(h2), _p(u2), len(kp2), C.byref(b),
+                                        _p(sf2), _p(sg2), _p(f), ex, ey, 1 if only_stereo else 0, 1 if check_orientation else 0, _p(out))
+    return nm, out[:len(kp1)]
+
+
 def three_maxima(sizes):
     sizes = np.ascontiguousarray(sizes, np.int32)
     i1, i2, i3 = C.c_int(-1), C.c_int(-1), C.c_int(-1)

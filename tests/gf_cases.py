@@ -63,3 +63,57 @@ def prefix_state(out_point, prefix, n):
             out_sc[v & 0xFFFF] = v >> 16
             cnt += 1
     return cnt, out_mp, out_sc
+
+
+def two_view_geometry(rng, fx=458.0, fy=457.0, cx=367.0, cy=248.0, baseline=0.3, rot_deg=4.0, forward=False):
+    """A second camera a short way from the first: (R21, t21, K, F12 as ORB-SLAM's ComputeF12 lays it out: x1' F12 x2 = 0, the epipole
+    of camera 1 in image 2).  float32 like the cv::Mat it stands for."""
+    w = rng.normal(0, np.deg2rad(rot_deg), 3)
+    th = np.linalg.norm(w)
+    k = w / th if th > 0 else np.array([1.0, 0, 0])
+    Kx = np.array([[0, -k[2], k[1]], [k[2], 0, -k[0]], [-k[1], k[0], 0]])
+    R21 = np.eye(3) + np.sin(th) * Kx + (1 - np.cos(th)) * Kx @ Kx
+    t21 = rng.normal(0, baseline, 3)
+    if forward:                                                    # motion along the optical axis: the epipole falls inside the image
+        t21 = np.array([rng.normal(0, 0.03), rng.normal(0, 0.03), -0.5 - abs(rng.normal(0, baseline))])
+    K = np.array([[fx, 0, cx], [0, fy, cy], [0, 0, 1.0]])
+    R12, t12 = R21.T, -R21.T @ t21
+    tx = np.array([[0, -t12[2], t12[1]], [t12[2], 0, -t12[0]], [-t12[1], t12[0], 0]])
+    F12 = np.linalg.inv(K).T @ tx @ R12 @ np.linalg.inv(K)
+    c1_in_2 = t21                                                  # camera 1's centre in camera 2's frame
+    ex, ey = fx * c1_in_2[0] / c1_in_2[2] + cx, fy * c1_in_2[1] / c1_in_2[2] + cy
+    return R21, t21, K, F12.astype(np.float32), np.float32(ex), np.float32(ey)
+
+
+def triangulation_case(oracle, kp1, desc1, rng, flips=6, noise=0.6, p_mp=0.3, p_stereo=0.5, node_shift=3, p_outlier=0.1, **cam):
+    """The second keyframe of SearchForTriangulation from the first: every keypoint seen again at a random depth under a random
+    relative pose, its pixel disturbed (some far off the epipolar line), descriptor bits flipped, the order shuffled; map-point and
+    stereo flags on both sides; a toy vocabulary (the node of a descriptor = its leading bits)."""
+    n = len(kp1)
+    R21, t21, K, F12, ex, ey = two_view_geometry(rng, **cam)
+    z = rng.uniform(1.0, 12.0, n)
+    X1 = np.stack([(kp1["x"] - K[0, 2]) / K[0, 0] * z, (kp1["y"] - K[1, 2]) / K[1, 1] * z, z], 1)
+    X2 = X1 @ R21.T + t21
+    u2 = K[0, 0] * X2[:, 0] / X2[:, 2] + K[0, 2] + rng.normal(0, noise, n)
+    v2 = K[1, 1] * X2[:, 1] / X2[:, 2] + K[1, 2] + rng.normal(0, noise, n)
+    out = rng.random(n) < p_outlier
+    v2[out] += rng.normal(0, 8.0, int(out.sum()))
+    perm = rng.permutation(n)
+    kp2 = kp1[perm].copy()
+    kp2["x"], kp2["y"] = u2[perm].astype(np.float32), v2[perm].astype(np.float32)
+    kp2["angle"] = ((kp1["angle"][perm] + rng.normal(0, 6.0, n)) % 360).astype(np.float32)
+    d2 = desc1[perm].copy()
+    for _ in range(flips):
+        sel = rng.random(n) < 0.5
+        bits = rng.integers(0, 256, n)
+        d2[sel, bits[sel] >> 3] ^= (1 << (bits[sel] & 7)).astype(np.uint8)
+    has1 = (rng.random(n) < p_mp).astype(np.uint8)
+    has2 = (rng.random(n) < p_mp).astype(np.uint8)
+    ur1 = np.where(rng.random(n) < p_stereo, kp1["x"] - rng.uniform(1, 40, n), -1).astype(np.float32)
+    ur2 = np.where(rng.random(n) < p_stereo, kp2["x"] - rng.uniform(1, 40, n), -1).astype(np.float32)
+    node1 = (desc1[:, 0] >> node_shift).astype(np.int64)
+    node2 = (d2[:, 0] >> node_shift).astype(np.int64)
+    node1[rng.random(n) < 0.02] = -1
+    node2[rng.random(n) < 0.02] = -1
+    return dict(kp1=kp1, desc1=desc1, has1=has1, ur1=ur1, fv1=oracle.make_feature_vector(node1), kp2=kp2, desc2=d2, has2=has2, ur2=ur2,
+                fv2=oracle.make_feature_vector(node2), f12=F12, ex=ex, ey=ey, node1=node1, node2=node2, R21=R21, t21=t21)

@@ -18,6 +18,7 @@
 //      host-side projection the adapter keeps (:1451-1502);
 //   L. ORBmatcher::SearchByProjection(KeyFrame*, Scw, ...) (ORBmatcher.cc:406-518) and Fuse(KeyFrame*, Scw, ...) (:1089-1212), loop closing's;
 //   I2. ORBmatcher::SearchByBoW(KeyFrame*, KeyFrame*, vpMatches12) (ORBmatcher.cc:635-768), loop closing's, from a thread of its own;
+//   I3. ORBmatcher::SearchForTriangulation(KF1, KF2, F12, vMatchedPairs, bOnlyStereo) (ORBmatcher.cc:770-935), local mapping's, likewise;
 //   H. ORBmatcher::SearchByProjection(CurrentFrame, KeyFrame*, sAlreadyFound, th, ORBdist) (ORBmatcher.cc:1595-1721), relocalisation's;
 //   I. ORBmatcher::SearchByBoW(KeyFrame*, Frame&, vpMapPointMatches) (ORBmatcher.cc:270-404) with real DBoW2::FeatureVector objects;
 //   J. Frame::ComputeBoW() (Frame.cc:661-668) on an ORBVocabulary object whose tree the harness fills: mBowVec and mFeatVec;
@@ -1129,6 +1130,65 @@ int main(int argc, char** argv)
                             dump(ori ? "I2_nmatches_ori.bin" : "I2_nmatches.bin", &n32, 4);
                             if (ori) report("I2_SearchByBoW_KF_KF_us", us);
                         }
+                    }
+                }
+                // I3. SearchForTriangulation(KF1 = frame 0, KF2 = a second view of it, F12, vMatchedPairs, bOnlyStereo) (ORBmatcher.cc:770-935), local
+                //     mapping's, from a thread of its own: map-point flags, mvuRight and the relative geometry come from the Python side
+                {
+                    std::vector<uint8_t> k2 = slurp(g_in + "/I3_kp2.bin", false), dd2 = slurp(g_in + "/I3_desc2.bin", false), nd1 = slurp(g_in + "/I3_nodes1.bin", false),
+                                         nd2 = slurp(g_in + "/I3_nodes2.bin", false), h1 = slurp(g_in + "/I3_has1.bin", false), h2 = slurp(g_in + "/I3_has2.bin", false),
+                                         r1 = slurp(g_in + "/I3_uright1.bin", false), r2 = slurp(g_in + "/I3_uright2.bin", false), ge = slurp(g_in + "/I3_geom.bin", false);
+                    const int n3 = F0.N;
+                    if ((int)(k2.size() / sizeof(cv::KeyPoint)) == n3 && (int)dd2.size() == n3 * 32 && (int)(nd1.size() / 4) == n3 && (int)(nd2.size() / 4) == n3 &&
+                        (int)h1.size() == n3 && (int)h2.size() == n3 && (int)(r1.size() / 4) == n3 && (int)(r2.size() / 4) == n3 && ge.size() == (16 + 16 + 3 + 9 + 4) * 4) {
+                        const float* g3 = reinterpret_cast<const float*>(ge.data());
+                        Frame::fx = g3[44]; Frame::fy = g3[45]; Frame::cx = g3[46]; Frame::cy = g3[47];
+                        std::vector<cv::KeyPoint> kp2v(n3);
+                        memcpy(kp2v.data(), k2.data(), k2.size());
+                        cv::Mat desc2(n3, 32, CV_8U);
+                        memcpy(desc2.data, dd2.data(), dd2.size());
+                        Frame* FA = new Frame();
+                        Frame* FB = new Frame();
+                        fill_frame(*FA, L, R, F0.mvKeys, F0.mDescriptors, F0.mvKeysRight, F0.mDescriptorsRight);
+                        fill_frame(*FB, L, R, kp2v, desc2, F0.mvKeysRight, F0.mDescriptorsRight);
+                        FA->mvLevelSigma2 = L->GetScaleSigmaSquares();
+                        FB->mvLevelSigma2 = L->GetScaleSigmaSquares();
+                        FA->mvuRight.assign(reinterpret_cast<const float*>(r1.data()), reinterpret_cast<const float*>(r1.data()) + n3);
+                        FB->mvuRight.assign(reinterpret_cast<const float*>(r2.data()), reinterpret_cast<const float*>(r2.data()) + n3);
+                        const int32_t* node1 = reinterpret_cast<const int32_t*>(nd1.data());
+                        const int32_t* node2 = reinterpret_cast<const int32_t*>(nd2.data());
+                        for (int i = 0; i < n3; i++) {
+                            if (node1[i] >= 0) FA->mFeatVec.addFeature((DBoW2::NodeId)node1[i], (unsigned)i);
+                            if (node2[i] >= 0) FB->mFeatVec.addFeature((DBoW2::NodeId)node2[i], (unsigned)i);
+                        }
+                        TestKF kf1(*FA), kf2(*FB);
+                        kf1.pose(mat4(g3), g3 + 32);
+                        kf2.pose(mat4(g3 + 16), g3 + 32);     // (the second keyframe's own centre is not read by this member)
+                        std::vector<MapPoint*> mp1(n3, static_cast<MapPoint*>(NULL)), mp2(n3, static_cast<MapPoint*>(NULL));
+                        for (int i = 0; i < n3; i++) {
+                            if (h1[i]) { TestMP* q = new TestMP(); q->bad(h1[i] == 2); owned.push_back(q); mp1[i] = q; }   // a BAD point still occupies its keypoint (:812-816)
+                            if (h2[i]) { TestMP* q = new TestMP(); q->bad(h2[i] == 2); owned.push_back(q); mp2[i] = q; }
+                        }
+                        kf1.points(mp1);
+                        kf2.points(mp2);
+                        cv::Mat F12(3, 3, CV_32F);
+                        for (int i = 0; i < 9; i++) F12.at<float>(i / 3, i % 3) = g3[35 + i];
+                        for (int only = 0; only < 2; only++) {
+                            std::vector<std::pair<size_t, size_t> > pairs(7, std::make_pair((size_t)1, (size_t)1));   // cleared by the member (:919)
+                            int nm = -1;
+                            long long us = 0;
+                            std::thread([&]() {
+                                ORBmatcher matcher(0.6f, only == 0);      // LocalMapping.cc:384 constructs it with (0.6, false); the histogram is covered in the first pass
+                                nm = matcher.SearchForTriangulation(&kf1, &kf2, F12, pairs, only != 0);
+                                if (!only) us = median_us(20, []() {}, [&]() { std::vector<std::pair<size_t, size_t> > pp; matcher.SearchForTriangulation(&kf1, &kf2, F12, pp, false); });
+                            }).join();
+                            std::vector<int32_t> flat;
+                            for (size_t i = 0; i < pairs.size(); i++) { flat.push_back((int32_t)pairs[i].first); flat.push_back((int32_t)pairs[i].second); }
+                            flat.push_back(nm); flat.push_back((int32_t)pairs.size());
+                            dump(only ? "I3_pairs_stereo.bin" : "I3_pairs.bin", flat.data(), flat.size() * 4);
+                            if (!only) report("I3_SearchForTriangulation_us", us);
+                        }
+                        delete FA; delete FB;
                     }
                 }
                 delete FP;

@@ -14,4 +14,5 @@ int ORBmatcher::SearchByProjection(KeyFrame*, cv::Mat, const std::vector<MapPoin
 int ORBmatcher::Fuse(KeyFrame*, cv::Mat, const std::vector<MapPoint*>&, float, std::vector<MapPoint*>&) { return 2; }
 int ORBmatcher::Fuse(KeyFrame*, const std::vector<MapPoint*>&, const float) { return 2; }
 int ORBmatcher::SearchBySim3(KeyFrame*, KeyFrame*, std::vector<MapPoint*>&, const float&, const cv::Mat&, const cv::Mat&, const float) { return 2; }
+int ORBmatcher::SearchForTriangulation(KeyFrame*, KeyFrame*, cv::Mat, std::vector<std::pair<std::size_t, std::size_t> >&, const bool) { return 2; }
 }  // namespace ORB_SLAM2

@@ -1,7 +1,9 @@
 // Declarations with the reference's names and signatures (include/Frame.h:267, include/ORBmatcher.h:64,67,259-272), nothing else of
 // the classes: a mangled name depends on the names in a signature only.  tests/test_adapter_compiles.py checks that the symbols
 // this miniature defines ARE the ones in adapter/weaken_symbols.txt.
+#include <cstddef>
 #include <set>
+#include <utility>
 #include <vector>
 namespace cv { class Mat { public: int x; }; }   // (by value in two signatures: only the name enters the mangling)
 namespace ORB_SLAM2
@@ -29,6 +31,7 @@ public:
     int Fuse(KeyFrame* pKF, cv::Mat Scw, const std::vector<MapPoint*>& vpPoints, float th, std::vector<MapPoint*>& vpReplacePoint);
     int Fuse(KeyFrame* pKF, const std::vector<MapPoint*>& vpMapPoints, const float th = 3.0);
     int SearchBySim3(KeyFrame* pKF1, KeyFrame* pKF2, std::vector<MapPoint*>& vpMatches12, const float& s12, const cv::Mat& R12, const cv::Mat& t12, const float th);
+    int SearchForTriangulation(KeyFrame* pKF1, KeyFrame* pKF2, cv::Mat F12, std::vector<std::pair<std::size_t, std::size_t> >& vMatchedPairs, const bool bOnlyStereo);
     int untouched();   // a member the adapter does not replace
 };
 }  // namespace ORB_SLAM2

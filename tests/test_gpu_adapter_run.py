@@ -568,6 +568,31 @@ def run(tmp_path_factory, oracle, euroc_l, euroc_r):
     kvalid2.tofile(ind / "I2_kf2_valid.bin")
     ref["I2"] = [oracle.search_by_bow_keyframes(dl0, kl0["angle"], (kvalid == 1).astype(np.uint8), oracle.make_feature_vector(knode), dl1, kl1["angle"],
                                                 (kvalid2 == 1).astype(np.uint8), oracle.make_feature_vector(fnode), 0.75, bool(o)) for o in (0, 1)]
+    # I3: SearchForTriangulation(KF1 = frame 0, KF2 = frame 0 seen from a second pose): the epipole from the member's own cv::Mat lines
+    # (float, the stand-in's plain loops), flags 0 / 1 / 2 = no map point / a good one / a bad one (a bad one still occupies its keypoint)
+    import gf_cases
+    c3 = gf_cases.triangulation_case(oracle, kl0, dl0, np.random.default_rng(31), fx=FX, fy=FY, cx=CX, cy=CY)
+    h31 = np.where(c3["has1"] > 0, rng.choice([1, 2], n0, p=[0.9, 0.1]), 0).astype(np.uint8)
+    h32 = np.where(c3["has2"] > 0, rng.choice([1, 2], n0, p=[0.9, 0.1]), 0).astype(np.uint8)
+    ow1 = np.array([0.4, -0.2, 0.1], f32)                              # the first keyframe's centre in the world: Tcw1 = [I | -ow1]
+    T1 = np.eye(4, dtype=f32); T1[:3, 3] = -ow1
+    T2 = np.eye(4, dtype=f32); T2[:3, :3] = c3["R21"].astype(f32); T2[:3, 3] = (c3["t21"] - c3["R21"] @ ow1.astype(np.float64)).astype(f32)
+    c2 = np.zeros(3, f32)
+    for i_ in range(3):
+        s_ = f32(0)
+        for k_ in range(3):
+            s_ = f32(s_ + f32(T2[i_, k_] * ow1[k_]))
+        c2[i_] = f32(s_ + T2[i_, 3])
+    invz3 = f32(1) / c2[2]
+    ex3 = f32(f32(f32(f32(FX) * c2[0]) * invz3) + f32(CX)); ey3 = f32(f32(f32(f32(FY) * c2[1]) * invz3) + f32(CY))
+    c3["kp2"].tofile(ind / "I3_kp2.bin"); c3["desc2"].tofile(ind / "I3_desc2.bin")
+    c3["node1"].astype(np.int32).tofile(ind / "I3_nodes1.bin"); c3["node2"].astype(np.int32).tofile(ind / "I3_nodes2.bin")
+    h31.tofile(ind / "I3_has1.bin"); h32.tofile(ind / "I3_has2.bin")
+    c3["ur1"].tofile(ind / "I3_uright1.bin"); c3["ur2"].tofile(ind / "I3_uright2.bin")
+    np.concatenate([T1.ravel(), T2.ravel(), ow1, c3["f12"].ravel(), np.array([FX, FY, CX, CY], f32)]).astype(f32).tofile(ind / "I3_geom.bin")
+    sf3 = np.cumprod(np.concatenate([[f32(1)], np.full(7, f32(1.2))]).astype(f32)).astype(f32)
+    ref["I3"] = [oracle.search_for_triangulation(kl0, dl0, h31, c3["ur1"], c3["fv1"], c3["kp2"], c3["desc2"], h32, c3["ur2"], c3["fv2"], sf3, (sf3 * sf3).astype(f32),
+                                                 c3["f12"], ex3, ey3, bool(only), not only) for only in (0, 1)]
     with oracle.feature_budget(BUDGET):
         ref["I_budget"] = [oracle.search_by_bow(dl0, kl0["angle"], (kvalid == 1).astype(np.uint8), oracle.make_feature_vector(knode), dl1, kl1["angle"],
                                                 oracle.make_feature_vector(fnode), 0.7, bool(o)) for o in (0, 1)]
@@ -930,6 +955,20 @@ def test_search_by_bow_between_keyframes_member(run):
         np.testing.assert_array_equal(got, out, err_msg=tag)
         assert int(_rd(run, f"I2_nmatches{tag}.bin", np.int32)[0]) == nm
         assert nm > 80, (tag, nm)
+
+
+def test_search_for_triangulation_member(run):
+    """ORBmatcher::SearchForTriangulation(KF1, KF2, F12, vMatchedPairs, bOnlyStereo) (ORBmatcher.cc:770-935), local mapping's matcher, from a
+    thread of its own: two KeyFrame objects (map-point lists, mvuRight, real DBoW2::FeatureVector objects, poses), the epipole from the
+    member's own cv::Mat lines, vMatchedPairs cleared and refilled in ascending first index"""
+    for name, (nm, out) in zip(("I3_pairs.bin", "I3_pairs_stereo.bin"), run["I3"]):
+        flat = _rd(run, name, np.int32)
+        assert int(flat[-2]) == nm and int(flat[-1]) == nm, (name, flat[-2:], nm)
+        pairs = flat[:-2].reshape(-1, 2)
+        want = np.flatnonzero(out >= 0)
+        np.testing.assert_array_equal(pairs[:, 0], want, err_msg=name)
+        np.testing.assert_array_equal(pairs[:, 1], out[want], err_msg=name)
+        assert nm > 100, (name, nm)
 
 
 def test_matcher_members_of_a_budgeting_feature_matching_build(run):

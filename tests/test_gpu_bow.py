@@ -267,3 +267,73 @@ def test_bow_between_two_keyframes(ext, oracle, seed, flips, shift, sigma, ratio
     refp = oracle.search_by_bow(d1, a1, v1, fv1, d2, a2, fv2, ratio, ori)
     assert plain[0] == refp[0]
     np.testing.assert_array_equal(plain[1], refp[1])
+
+
+@pytest.mark.parametrize("seed,flips,shift,noise,only_stereo,ori,mono,forward", [(0, 6, 3, 0.6, False, True, False, False), (1, 2, 5, 0.3, True, True, False, False),
+                                                                                 (2, 12, 1, 1.5, False, False, False, True), (3, 0, 0, 0.0, False, True, True, False),
+                                                                                 (4, 8, 8, 0.8, False, True, False, False), (5, 4, 2, 0.5, False, True, True, True)])
+def test_search_for_triangulation(ext, oracle, seed, flips, shift, noise, only_stereo, ori, mono, forward):
+    """ORBmatcher::SearchForTriangulation (ORBmatcher.cc:770-935, local mapping): keypoints WITHOUT map points of two keyframes, the
+    epipolar gate of CheckDistEpipolarLine in floats, the epipole gate for mono pairs, the last candidate on a distance tie, no blocking.
+    shift 8 puts every keypoint in one node (a 2000 x 2000 sweep); mono runs without mvuRight at all."""
+    import gf_orb_slam2_amd as G
+    import gf_cases
+    kl = np.fromfile(os.path.join(GOLDEN, "EuRoC_l_kp.bin"), oracle.KEYPOINT_DTYPE)
+    dl = np.fromfile(os.path.join(GOLDEN, "EuRoC_l_desc.bin"), np.uint8).reshape(-1, 32)
+    c = gf_cases.triangulation_case(oracle, kl, dl, np.random.default_rng(seed), flips=flips, noise=noise, node_shift=shift, forward=forward)
+    sf = np.cumprod(np.concatenate([[np.float32(1)], np.full(7, np.float32(1.2))]).astype(np.float32)).astype(np.float32)
+    sg = (sf * sf).astype(np.float32)
+    ur1, ur2 = (None, None) if mono else (c["ur1"], c["ur2"])
+    ref = oracle.search_for_triangulation(c["kp1"], c["desc1"], c["has1"], ur1, c["fv1"], c["kp2"], c["desc2"], c["has2"], ur2, c["fv2"], sf, sg,
+                                          c["f12"], c["ex"], c["ey"], only_stereo, ori)
+    got = G.ORBmatcher(0.6, ori, extractor=ext).SearchForTriangulation(c["kp1"], c["desc1"], c["has1"], ur1, c["fv1"], c["kp2"], c["desc2"], c["has2"], ur2,
+                                                                       c["fv2"], sf, sg, c["f12"], c["ex"], c["ey"], only_stereo)
+    assert got[0] == ref[0]
+    np.testing.assert_array_equal(got[1], ref[1])
+    m = ref[1] >= 0
+    assert not c["has1"][m].any() and not c["has2"][ref[1][m]].any()
+    if only_stereo and not mono:
+        assert (c["ur1"][m] >= 0).all() and (c["ur2"][ref[1][m]] >= 0).all()
+    if mono and not forward:
+        assert ref[0] > 300          # the geometry is exact and the descriptors equal: most unmatched keypoints pair up
+    # the epipolar gate does reject: without it (a sigma table of 1e9) strictly more pairs
+    loose = oracle.search_for_triangulation(c["kp1"], c["desc1"], c["has1"], ur1, c["fv1"], c["kp2"], c["desc2"], c["has2"], ur2, c["fv2"], sf,
+                                            np.full(8, 1e9, np.float32), c["f12"], c["ex"], c["ey"], only_stereo, False)
+    ref0 = oracle.search_for_triangulation(c["kp1"], c["desc1"], c["has1"], ur1, c["fv1"], c["kp2"], c["desc2"], c["has2"], ur2, c["fv2"], sf, sg, c["f12"],
+                                           c["ex"], c["ey"], only_stereo, False)
+    if forward:                      # the epipole is inside the image and its gate does fire: with the epipole moved away, more pairs
+        far = oracle.search_for_triangulation(c["kp1"], c["desc1"], c["has1"], ur1, c["fv1"], c["kp2"], c["desc2"], c["has2"], ur2, c["fv2"], sf, sg, c["f12"],
+                                              np.float32(-1e6), np.float32(-1e6), only_stereo, False)
+        assert 0 <= c["ex"] < 752 and 0 <= c["ey"] < 480
+        assert far[0] >= ref0[0] + (1 if mono else 0)
+    if noise > 0:
+        assert loose[0] > ref0[0]
+
+
+def test_search_for_triangulation_edge_cases(ext, oracle):
+    import gf_orb_slam2_amd as G
+    import gf_cases
+    kl = np.fromfile(os.path.join(GOLDEN, "EuRoC_l_kp.bin"), oracle.KEYPOINT_DTYPE)
+    dl = np.fromfile(os.path.join(GOLDEN, "EuRoC_l_desc.bin"), np.uint8).reshape(-1, 32)
+    c = gf_cases.triangulation_case(oracle, kl[:300], dl[:300], np.random.default_rng(9))
+    sf = np.cumprod(np.concatenate([[np.float32(1)], np.full(7, np.float32(1.2))]).astype(np.float32)).astype(np.float32)
+    sg = (sf * sf).astype(np.float32)
+    M = G.ORBmatcher(0.6, True, extractor=ext)
+    args = lambda **kw: [{**c, **kw}[k] for k in ("kp1", "desc1", "has1", "ur1", "fv1", "kp2", "desc2", "has2", "ur2", "fv2")]
+    # every keypoint of one side already has a map point: nothing to do
+    n, out = M.SearchForTriangulation(*args(has1=np.ones(300, np.uint8)), sf, sg, c["f12"], c["ex"], c["ey"])
+    assert n == 0 and (out == -1).all()
+    n, out = M.SearchForTriangulation(*args(has2=np.ones(300, np.uint8)), sf, sg, c["f12"], c["ex"], c["ey"])
+    assert n == 0 and (out == -1).all()
+    # a degenerate fundamental matrix: den == 0 everywhere, CheckDistEpipolarLine answers false (:262-263)
+    n, out = M.SearchForTriangulation(*args(), sf, sg, np.zeros(9, np.float32), c["ex"], c["ey"])
+    assert n == 0
+    # no common node
+    empty = (np.zeros(0, np.uint32), np.zeros(1, np.int32), np.zeros(0, np.uint32))
+    n, out = M.SearchForTriangulation(*args(fv2=empty), sf, sg, c["f12"], c["ex"], c["ey"])
+    assert n == 0
+    # an octave past the scale table is refused, not read
+    bad = c["kp2"].copy()
+    bad["octave"][5] = 8
+    with pytest.raises(G.GfoError):
+        M.SearchForTriangulation(*args(kp2=bad), sf, sg, c["f12"], c["ex"], c["ey"])

@@ -1,6 +1,6 @@
 """Randomised parity sweep of the HOST-ARRAY matcher calls against the oracle, bit for bit (not part of the test suite: minutes of GPU +
 oracle time): SearchByProjection (map-point and query form, both round-0 forms, candidate-list pools of random size), SearchByBoW (nodes
-from a handful to hundreds of keypoints, both k_bow_match paths), ComputeBoW (vocabularies of random shape, 1..20 000 descriptors).
+from a handful to hundreds of keypoints, both k_bow_match paths), SearchForTriangulation (random relative poses), ComputeBoW (vocabularies of random shape, 1..20 000 descriptors).
 Synthetic frames: keypoints clustered like corners are, descriptors drawn around a few hundred prototypes so that small distances and
 exact ties are common.   usage: python tools/fuzz_matchers.py [cases] [seed]"""
 import os
@@ -10,6 +10,8 @@ import time
 import numpy as np
 
 sys.path.insert(0, ".")
+sys.path.insert(0, "tests")
+import gf_cases
 import gf_orb_slam2_amd as G
 from oracle import orb_oracle as O
 
@@ -19,7 +21,7 @@ rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 ext = G.ORBextractor(1000, 1.2, 8, 20, 7)
 SF = ext.GetScaleFactors()
 bad = 0
-count = {"map": 0, "query": 0, "bow": 0, "cbow": 0}
+count = {"map": 0, "query": 0, "bow": 0, "cbow": 0, "tri": 0}
 matches = {"map": 0, "query": 0, "bow": 0, "cbow_words": 0}
 t0 = time.time()
 
@@ -65,7 +67,7 @@ def mismatch(what, **kw):
 
 
 for it in range(cases):
-    kind = rng.choice(["map", "query", "bow", "cbow"], p=[0.4, 0.25, 0.2, 0.15])
+    kind = rng.choice(["map", "query", "bow", "cbow", "tri"], p=[0.35, 0.22, 0.18, 0.13, 0.12])
     count[kind] += 1
     w, h = float(rng.choice([320, 752, 1241, 1920])), float(rng.choice([240, 480, 376, 1080]))
     bounds = (float(rng.choice([0.0, -12.5])), float(rng.choice([0.0, -7.25])), w, h)
@@ -175,6 +177,21 @@ for it in range(cases):
             gotk = G.ORBmatcher(ratio, ori, extractor=ext).SearchByBoWKeyFrames(kd, kk["angle"].copy(), valid, kfv, fd, fa, valid2, ffv)
             if gotk[0] != refk[0] or not (gotk[1] == refk[1]).all():
                 mismatch("bow_kf", it=it, nk=nk, nf=nf, nnodes=nnodes, got=gotk[0], ref=refk[0])
+    elif kind == "tri":
+        # SearchForTriangulation (ORBmatcher.cc:770-935): a second view of a synthetic keyframe under a random relative pose
+        n = int(rng.choice([1, 40, 900, 2000, 4000]))
+        k1, d1 = frame(n, w, h)
+        c = gf_cases.triangulation_case(O, k1, d1, rng, flips=int(rng.integers(0, 16)), noise=float(rng.choice([0.0, 0.5, 2.0])), p_mp=float(rng.uniform(0, 0.8)),
+                                        p_stereo=float(rng.choice([0.0, 0.5, 1.0])), node_shift=int(rng.choice([0, 2, 4, 6, 8])), forward=bool(rng.random() < 0.5))
+        only, ori, mono = bool(rng.random() < 0.3), bool(rng.random() < 0.6), bool(rng.random() < 0.2)
+        u1, u2 = (None, None) if mono else (c["ur1"], c["ur2"])
+        sg = (SF * SF).astype(np.float32)
+        a = (c["kp1"], c["desc1"], c["has1"], u1, c["fv1"], c["kp2"], c["desc2"], c["has2"], u2, c["fv2"], SF, sg, c["f12"], c["ex"], c["ey"])
+        ref = O.search_for_triangulation(*a, only, ori)
+        got = G.ORBmatcher(0.6, ori, extractor=ext).SearchForTriangulation(*a, only)
+        matches["tri"] = matches.get("tri", 0) + int(ref[0])
+        if got[0] != ref[0] or not (got[1] == ref[1]).all():
+            mismatch("tri", it=it, n=n, only=only, ori=ori, mono=mono, got=got[0], ref=ref[0])
     else:
         k, depth = int(rng.integers(2, 12)), int(rng.integers(1, 6))
         while k ** depth > 200000:
