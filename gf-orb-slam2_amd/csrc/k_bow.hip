@@ -316,17 +316,18 @@ __device__ __forceinline__ bool tri_epipolar_ok(const TriArgs& a, float x1, floa
     return (double)dsqr < 3.84 * (double)a.sigma2[octave2];
 }
 
+#define TRI_SPLIT 4
 __global__ __launch_bounds__(256) void k_bow_triangulate(TriArgs a)
 {
+    // a common node is shared by TRI_WAVES wavefronts (4 of a block x gridDim.y blocks): the first keyframe's keypoints of the node are
+    // independent searches (nothing one finds hides a candidate from the next), dealt round robin
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-    const int pi = blockIdx.x * 4 + wave;
-    if (pi >= a.npairs) return;
-    const int2 pr = a.pairs[pi];
+    const int2 pr = a.pairs[blockIdx.x];
     const int b1 = a.start1[pr.x], e1 = a.start1[pr.x + 1];
     const int b2 = a.start2[pr.y], e2 = a.start2[pr.y + 1];
     const float factor = 1.0f / HISTO_LENGTH;
     int accepted = 0;
-    for (int i1 = b1; i1 < e1; i1++) {
+    for (int i1 = b1 + (int)blockIdx.y * 4 + wave; i1 < e1; i1 += 4 * (int)gridDim.y) {
         const unsigned idx1 = a.items1[i1];
         const unsigned fl1 = a.flag1[idx1];
         if (fl1 & 1) continue;                               // pMP1: there is a map point already (:812-815)
@@ -653,7 +654,7 @@ extern "C" int gfo_search_for_triangulation(gfo_ctx* c, const gfo_keypoint* kp1,
     a.out = (int*)(S + o_out); a.rot_bin = (int*)(S + o_rb); a.counters = (int*)(S + o_cnt);
     if (int rc = x.out(o_cnt + 16 - o_out)) return rc;
     gfo_prof_begin(c, ST_BOW);
-    GFO_LAUNCH(c, k_bow_triangulate, dim3((a.npairs + 3) / 4), dim3(256), 0, st, a);
+    GFO_LAUNCH(c, k_bow_triangulate, dim3(a.npairs, TRI_SPLIT), dim3(256), 0, st, a);
     if (a.check_ori) {   // the rotation histogram over the FIRST keyframe's keypoints (:876, :913-917): the same kernel, its arrays of length n1
         BowArgs r{};
         r.n_f = n1; r.out = a.out; r.rot_bin = a.rot_bin; r.counters = a.counters; r.check_ori = 1;

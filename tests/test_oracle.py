@@ -890,6 +890,92 @@ def test_bow_keyframe_pair_oracle_against_python_statement(oracle, seed, shift, 
     np.testing.assert_array_equal(got[1], ref[1])
 
 
+def triangulation_python(c, sf, sg, only_stereo, ori, mono):
+    """ORBmatcher.cc:770-935 (+ :251-268) once more, in Python, written from the reference's text (not from the C restatement)."""
+    f = np.float32
+    kp1, kp2, d1, d2 = c["kp1"], c["kp2"], c["desc1"], c["desc2"]
+    F = c["f12"].reshape(3, 3)
+    n1 = len(kp1)
+    out = np.full(n1, -1, np.int64)
+    hist = [[] for _ in range(30)]
+    nm = 0
+    ids1, st1, it1 = c["fv1"]
+    ids2, st2, it2 = c["fv2"]
+    pos2 = {int(k): j for j, k in enumerate(ids2)}
+
+    def epipolar_ok(k1, k2):
+        a = f(f(f(k1["x"] * F[0, 0]) + f(k1["y"] * F[1, 0])) + F[2, 0])
+        b = f(f(f(k1["x"] * F[0, 1]) + f(k1["y"] * F[1, 1])) + F[2, 1])
+        cc = f(f(f(k1["x"] * F[0, 2]) + f(k1["y"] * F[1, 2])) + F[2, 2])
+        num = f(f(f(a * k2["x"]) + f(b * k2["y"])) + cc)
+        den = f(f(a * a) + f(b * b))
+        if den == 0:
+            return False
+        dsqr = f(f(num * num) / den)
+        return float(dsqr) < 3.84 * float(sg[k2["octave"]])
+    for a, node in enumerate(ids1):
+        b = pos2.get(int(node))
+        if b is None:
+            continue
+        for idx1 in it1[st1[a]:st1[a + 1]]:
+            if c["has1"][idx1]:
+                continue
+            s1 = (not mono) and c["ur1"][idx1] >= 0
+            if only_stereo and not s1:
+                continue
+            best, bidx = 50, -1
+            for idx2 in it2[st2[b]:st2[b + 1]]:
+                if c["has2"][idx2]:
+                    continue
+                s2 = (not mono) and c["ur2"][idx2] >= 0
+                if only_stereo and not s2:
+                    continue
+                dist = int(np.unpackbits(d1[idx1] ^ d2[idx2]).sum())
+                if dist > 50 or dist > best:
+                    continue
+                if not s1 and not s2:
+                    dx, dy = f(c["ex"] - kp2["x"][idx2]), f(c["ey"] - kp2["y"][idx2])
+                    if f(f(dx * dx) + f(dy * dy)) < f(f(100) * sf[kp2["octave"][idx2]]):
+                        continue
+                if epipolar_ok(kp1[idx1], kp2[idx2]):
+                    best, bidx = dist, int(idx2)
+            if bidx >= 0:
+                out[idx1] = bidx
+                nm += 1
+                if ori:
+                    rot = f(kp1["angle"][idx1]) - f(kp2["angle"][bidx])
+                    if rot < 0:
+                        rot = f(rot + f(360.0))
+                    b_ = int(math.floor(float(f(rot * f(1.0 / 30))) + 0.5))
+                    if b_ == 30:
+                        b_ = 0
+                    hist[b_].append(int(idx1))
+    if ori:
+        keep = oracle_three_maxima([len(h) for h in hist])
+        for i, h in enumerate(hist):
+            if i in keep:
+                continue
+            for idx1 in h:
+                out[idx1] = -1
+                nm -= 1
+    return nm, out
+
+
+@pytest.mark.parametrize("seed,only_stereo,ori,mono,forward", [(0, False, True, False, False), (1, True, False, False, False), (2, False, True, True, True)])
+def test_triangulation_oracle_against_python_statement(oracle, seed, only_stereo, ori, mono, forward):
+    import gf_cases
+    kl = np.fromfile(os.path.join(GOLDEN, "EuRoC_l_kp.bin"), oracle.KEYPOINT_DTYPE)[:500]
+    dl = np.fromfile(os.path.join(GOLDEN, "EuRoC_l_desc.bin"), np.uint8).reshape(-1, 32)[:500]
+    c = gf_cases.triangulation_case(oracle, kl, dl, np.random.default_rng(seed), node_shift=5, forward=forward, noise=1.0)
+    sf = np.cumprod(np.concatenate([[np.float32(1)], np.full(7, np.float32(1.2))]).astype(np.float32)).astype(np.float32)
+    sg = (sf * sf).astype(np.float32)
+    ref = triangulation_python(c, sf, sg, only_stereo, ori, mono)
+    got = oracle.search_for_triangulation(c["kp1"], c["desc1"], c["has1"], None if mono else c["ur1"], c["fv1"], c["kp2"], c["desc2"], c["has2"],
+                                          None if mono else c["ur2"], c["fv2"], sf, sg, c["f12"], c["ex"], c["ey"], only_stereo, ori)
+    assert got[0] == ref[0] and ref[0] > (20 if only_stereo else 100)
+    np.testing.assert_array_equal(got[1], ref[1])
+
+
 def test_oracle_reproduces_golden_good_feature_matchers(oracle):
     """tests/golden/EuRoC_gf_matchers.npz (made by tests/golden/make_gf_golden.py): the oracle still says what it said when the vectors
     were committed -- SearchByProjection_Budget at th 0.5 / 1 / with a clock, GetCandidates for every point, SearchByBoW(KF, KF)."""

@@ -3,7 +3,7 @@ Per-call latency of the host-array matcher calls Tracking makes on every frame (
 synchronisation): SearchByProjection(F, local map) for several map sizes, SearchByProjection(Cur, Last), SearchByBoW(KF, F),
 ComputeBoW(F) -- on the EuRoC frame (2008 keypoints).  Every map point here imitates a random keypoint (8 flipped bits, N(0,2) px
 away), so with M > N several points COMPETE for one keypoint: the ordered resolve runs its worst case, not a typical local map.
-usage (through gpurun): [TH=1|3|5] [ONLY=map|gf|stereo|last|cbow|bow] [JSON=1] python tools/matcher_call_latency.py [M ...]     (GFO_PROJ_STATS=1 prints
+usage (through gpurun): [TH=1|3|5] [ONLY=map|gf|stereo|last|cbow|bow|tri] [JSON=1] python tools/matcher_call_latency.py [M ...]     (GFO_PROJ_STATS=1 prints
 rounds / fallbacks per call; JSON=1: one JSON object on stdout instead of the text lines)"""
 import json
 import os
@@ -118,7 +118,7 @@ if ONLY in ("", "last"):
     say("SearchByProjection(Cur, Last)", ms, {"tracked_points": nq, "th": 7, "keypoints": n, "matches": int(r[0])},
         f"SearchByProjection(Cur, Last): {nq} tracked points, th 7, rotation check: median {ms:.3f} ms, {r[0]} matches")
 
-if ONLY not in ("", "cbow", "bow"):
+if ONLY not in ("", "cbow", "bow", "tri"):
     ext.close()
     if JSON:
         print(json.dumps(out), flush=True)
@@ -139,9 +139,23 @@ if ONLY in ("", "bow"):
     ms, r = median_ms(lambda: mb.SearchByBoW(desc, kp["angle"].copy(), valid, kfv, fd, kp["angle"].copy(), ffv))
     say("SearchByBoW(KF, F)", ms, {"keypoints": n, "nodes": len(kfv[0]), "matches": int(r[0])},
         f"SearchByBoW(KF, F): {n} x {n} keypoints over {len(kfv[0])} nodes: median {ms:.3f} ms, {r[0]} matches")
+if ONLY in ("", "bow", "tri"):
+    # SearchForTriangulation(KF1, KF2, F12, ...) (local mapping): the second keyframe = the first displaced along x (F12 of a pure
+    # x translation: the epipolar line of a keypoint is its own row), rows disturbed by N(0, 0.7) px; half the keypoints of either side
+    # have map points already
+    kp2 = kp.copy()
+    kp2["x"] = (kp["x"] - rng.uniform(2, 40, n)).astype(np.float32)
+    kp2["y"] = (kp["y"] + rng.normal(0, 0.7, n)).astype(np.float32)
+    has1, has2 = (rng.random(n) < 0.5).astype(np.uint8), (rng.random(n) < 0.5).astype(np.uint8)
+    f12 = np.array([0, 0, 0, 0, 0, -1, 0, 1, 0], np.float32)
+    sg = (sf * sf).astype(np.float32)
+    mt = G.ORBmatcher(0.6, False, extractor=ext)
+    ms, r = median_ms(lambda: mt.SearchForTriangulation(kp, desc, has1, u_right, kfv, kp2, fd, has2, u_right, ffv, sf, sg, f12, -1e5, 240.0))
+    say("SearchForTriangulation(KF1, KF2)", ms, {"keypoints": n, "nodes": len(kfv[0]), "matches": int(r[0])},
+        f"SearchForTriangulation(KF1, KF2): {n} x {n} keypoints over {len(kfv[0])} nodes: median {ms:.3f} ms, {r[0]} pairs")
 # the same two calls with a vocabulary of the SIZE the reference loads (ORBvoc: k = 10, L = 6 -- 1 111 111 nodes, 35.5 MB of centres;
 # test/test_Stereo.cpp:87), levelsup 4 as Frame.cc:666 passes it: the upload happens once per context, the call does not grow with it
-if ONLY in ("", "cbow", "bow", "bigvoc"):
+if ONLY in ("", "cbow", "bow", "bigvoc", "tri"):
     import time
     big = synth_vocabulary(10, 6, seed=1)
     t0 = time.perf_counter()
@@ -157,6 +171,9 @@ if ONLY in ("", "cbow", "bow", "bigvoc"):
     ms, r = median_ms(lambda: mb.SearchByBoW(desc, kp["angle"].copy(), valid, kfvb, fd, kp["angle"].copy(), ffvb))
     say("SearchByBoW(KF, F) (vocabulary of ORBvoc's size)", ms, {"keypoints": n, "nodes": len(kfvb[0]), "matches": int(r[0])},
         f"SearchByBoW(KF, F) over {len(kfvb[0])} level-2 nodes of that vocabulary: median {ms:.3f} ms, {r[0]} matches")
+    ms, r = median_ms(lambda: mt.SearchForTriangulation(kp, desc, has1, u_right, kfvb, kp2, fd, has2, u_right, ffvb, sf, sg, f12, -1e5, 240.0))
+    say("SearchForTriangulation(KF1, KF2) (vocabulary of ORBvoc's size)", ms, {"keypoints": n, "nodes": len(kfvb[0]), "matches": int(r[0])},
+        f"SearchForTriangulation(KF1, KF2) over {len(kfvb[0])} level-2 nodes of that vocabulary: median {ms:.3f} ms, {r[0]} pairs")
 ext.close()
 if JSON:
     print(json.dumps(out), flush=True)
