@@ -74,7 +74,7 @@ SYMBOLS = [
     "gfo_extract_stereo", "gfo_extract_batch_device", "gfo_batch_counts", "gfo_batch_fetch", "gfo_batch_device_views",
     "gfo_compute_pyramid", "gfo_pyramid_level", "gfo_hamming256", "gfo_stereo_match",
     "gfo_stereo_match_batch", "gfo_stereo_match_sad_batch", "gfo_stereo_fetch", "gfo_search_by_projection", "gfo_search_by_projection_points", "gfo_projection_points_prefix", "gfo_projection_candidates", "gfo_match_candidates", "gfo_search_by_projection_queries_points", "gfo_search_for_fusion", "gfo_search_by_projection_queries",
-    "gfo_map_upload", "gfo_search_by_projection_batch", "gfo_projection_fetch", "gfo_projection_device_views", "gfo_search_by_bow", "gfo_search_by_bow_budget", "gfo_search_by_bow_keyframes", "gfo_search_for_triangulation", "gfo_vocabulary_upload", "gfo_bow_transform", "gfo_compute_bow", "gfo_profile_enable",
+    "gfo_map_upload", "gfo_search_by_projection_batch", "gfo_projection_fetch", "gfo_projection_device_views", "gfo_search_by_bow", "gfo_search_by_bow_budget", "gfo_search_by_bow_keyframes", "gfo_search_for_triangulation", "gfo_search_for_initialization", "gfo_vocabulary_upload", "gfo_bow_transform", "gfo_compute_bow", "gfo_profile_enable",
     "gfo_profile_read", "gfo_debug_blurred_level", "gfo_debug_level_candidates",
     "gfo_contexts_created", "gfo_arenas_planned", "gfo_kernels_preloaded", "gfo_ctx_id", "gfo_vocabulary_nodes", "gfo_ctx_set_combining", "gfo_combiner_stats", "gfo_ctx_pair", "gfo_combiner_counters", "gfo_tuning_set", "gfo_tuning_get",
     "gfo_batch_deliver", "gfo_deliver_wait", "gfo_host_register", "gfo_host_unregister",
@@ -196,6 +196,7 @@ def load_library():
     L.gfo_projection_fetch.argtypes = [vp, i, vp, vp, i, ip]
     L.gfo_projection_device_views.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), ip, ip]
     L.gfo_search_by_bow.argtypes = [vp, vp, vp, vp, i, C.POINTER(FeatureVectorC), vp, vp, i, C.POINTER(FeatureVectorC), f, i, vp, ip]
+    L.gfo_search_for_initialization.argtypes = [vp, vp, vp, i, vp, vp, vp, i, C.POINTER(FrameBoundsC), i, f, i, vp, ip]
     L.gfo_search_for_triangulation.argtypes = [vp, vp, vp, vp, vp, i, C.POINTER(FeatureVectorC), vp, vp, vp, vp, i, C.POINTER(FeatureVectorC), vp, vp, i, vp, f, f, i, i, vp, ip]
     L.gfo_search_by_bow_keyframes.argtypes = [vp, vp, vp, vp, i, C.POINTER(FeatureVectorC), vp, vp, vp, i, C.POINTER(FeatureVectorC), f, i, vp, ip]
     L.gfo_search_by_bow_budget.argtypes = [vp, vp, vp, vp, i, C.POINTER(FeatureVectorC), vp, vp, i, C.POINTER(FeatureVectorC), f, i, i, vp, ip]

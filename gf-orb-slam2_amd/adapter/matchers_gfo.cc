@@ -17,6 +17,7 @@
 //   GFO_ADAPTER_FUSE          ORBmatcher::Fuse(KeyFrame*, vector<MapPoint*>&, th)                  src/ORBmatcher.cc:937-1087
 //   GFO_ADAPTER_SIM3          ORBmatcher::SearchBySim3(KF1, KF2, vpMatches12, s12, R12, t12, th)    src/ORBmatcher.cc:1214-1438
 //   GFO_ADAPTER_TRIANGULATION ORBmatcher::SearchForTriangulation(KF1, KF2, F12, vMatchedPairs, bOnlyStereo) src/ORBmatcher.cc:770-935
+//   GFO_ADAPTER_INIT          ORBmatcher::SearchForInitialization(F1, F2, vbPrevMatched, vnMatches12, windowSize) src/ORBmatcher.cc:520-633
 //   GFO_ADAPTER_COMPUTE_BOW   Frame::ComputeBoW()                                               src/Frame.cc:661-668
 //
 // Each body flattens the reference's objects into plain arrays, calls the C ABI (include/gfo.h) and writes the
@@ -38,6 +39,7 @@
 #define GFO_ADAPTER_FUSE
 #define GFO_ADAPTER_SIM3
 #define GFO_ADAPTER_TRIANGULATION
+#define GFO_ADAPTER_INIT
 #define GFO_ADAPTER_COMPUTE_BOW
 #endif
 
@@ -1024,6 +1026,38 @@ int ORBmatcher::SearchForTriangulation(KeyFrame* pKF1, KeyFrame* pKF2, cv::Mat F
     vMatchedPairs.reserve(nmatches > 0 ? nmatches : 0);                    // :922-930
     for (int i = 0; i < n1; i++)
         if (out[i] >= 0) vMatchedPairs.push_back(std::make_pair((size_t)i, (size_t)out[i]));
+    return nmatches;
+}
+#endif
+
+// ---------------------------------------------------------------------------------------------------------------
+#ifdef GFO_ADAPTER_INIT
+// The monocular bootstrap's matcher (Tracking::MonocularInitialization, Tracking.cc:1322), ORBmatcher.cc:520-633.  One call: the windows
+// of F2's grid around vbPrevMatched and every candidate's distance on the device, the ordered pass (a closer keypoint takes a match from an
+// earlier one) inside the library; vbPrevMatched is updated in place as :626-629 do.
+int ORBmatcher::SearchForInitialization(Frame& F1, Frame& F2, std::vector<cv::Point2f>& vbPrevMatched, std::vector<int>& vnMatches12, int windowSize)
+{
+    static_assert(sizeof(cv::Point2f) == 2 * sizeof(float), "vbPrevMatched is handed over as (x, y) pairs");
+    static_assert(sizeof(int) == sizeof(int32_t), "vnMatches12 is handed over as int32");
+    const int n1 = (int)F1.mvKeysUn.size(), n2 = (int)F2.mvKeysUn.size();
+    vnMatches12 = std::vector<int>(n1, -1);                               // :523
+    if (n1 == 0 || n2 == 0) return 0;
+    if ((int)vbPrevMatched.size() < n1) {                                 // (the reference indexes it unchecked, :538)
+        fprintf(stderr, "[gfo] SearchForInitialization: vbPrevMatched has %zu entries for %d keypoints\n", vbPrevMatched.size(), n1);
+        return 0;
+    }
+    gfo_frame_bounds fb = {Frame::mnMinX, Frame::mnMinY, Frame::mnMaxX, Frame::mnMaxY};
+    cv::Mat keep1, keep2;
+    int nmatches = 0;
+    GfoUse use(F2.mpORBextractorLeft);
+    const int rc = gfo_search_for_initialization(use.c, as_gfo(F1.mvKeysUn), rows32(F1.mDescriptors, keep1), n1, reinterpret_cast<float*>(vbPrevMatched.data()),
+                                                 as_gfo(F2.mvKeysUn), rows32(F2.mDescriptors, keep2), n2, &fb, windowSize, mfNNratio,
+                                                 mbCheckOrientation ? 1 : 0, reinterpret_cast<int32_t*>(vnMatches12.data()), &nmatches);
+    if (rc != GFO_OK) {
+        report(use.c, "SearchForInitialization");
+        std::fill(vnMatches12.begin(), vnMatches12.end(), -1);
+        return 0;
+    }
     return nmatches;
 }
 #endif

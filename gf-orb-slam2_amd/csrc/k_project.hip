@@ -33,6 +33,7 @@
 // second-best pair is the two smallest keys (a stable sort by distance).
 #include "gfo_internal.h"
 #include "k_wave.inc"
+#include <limits.h>
 #include <stdlib.h>
 
 #define GRID_COLS 64   // FRAME_GRID_COLS, Frame.h:92
@@ -1498,14 +1499,11 @@ extern "C" int gfo_projection_points_prefix(const int32_t* out_point, int m, int
 }
 
 // ORBmatcher::GetCandidates for all of vpMapPoints (include/ORBmatcher.h:152-172) + the static half of MatchCandidates (:176-250)
-extern "C" int gfo_projection_candidates(gfo_ctx* c, const gfo_keypoint* kp_un, const uint8_t* desc, const float* u_right, int n,
-                                         const float* sf, int nlevels, const gfo_frame_bounds* fb, const gfo_map_point* mps,
-                                         const uint8_t* mp_desc, int m, float th, int32_t* cand_start, uint32_t* cand, int cap, int* total)
+// the candidate table of m window queries (GetFeaturesInArea's order within a query, each entry with its descriptor distance): the body of
+// gfo_projection_candidates, on queries
+static int pj_candidates(gfo_ctx* c, const gfo_keypoint* kp_un, const uint8_t* desc, const float* u_right, int n, const gfo_frame_bounds* fb,
+                         const gfo_proj_query* q, const uint8_t* q_desc, int m, int32_t* cand_start, uint32_t* cand, int cap, int* total)
 {
-    if (!c) return GFO_ERR_INVALID;
-    if (!sf || nlevels < 1 || nlevels > GFO_MAX_LEVELS || !fb || !cand_start || !total || n < 0 || m < 0 || cap < 0 || (cap > 0 && !cand) ||
-        (n > 0 && (!kp_un || !desc)) || (m > 0 && (!mps || !mp_desc)))
-        return pj_fail(c, GFO_ERR_INVALID, "gfo_projection_candidates: bad argument");
     if (n > 65535) return pj_fail(c, GFO_ERR_INVALID, "gfo_projection_candidates: more than 65535 keypoints");
     if (!(fb->max_x > fb->min_x) || !(fb->max_y > fb->min_y)) return pj_fail(c, GFO_ERR_INVALID, "gfo_projection_candidates: empty frame bounds");
     for (int i = 0; i < n; i++)
@@ -1513,11 +1511,9 @@ extern "C" int gfo_projection_candidates(gfo_ctx* c, const gfo_keypoint* kp_un, 
     *total = 0;
     for (int i = 0; i <= m; i++) cand_start[i] = 0;
     if (n == 0 || m == 0) return GFO_OK;
-    std::vector<gfo_proj_query> q((size_t)m);
-    pj_queries_of_map_points(mps, m, sf, nlevels, th, q.data());
     GfoXfer x(c);
     ProjB a{};
-    if (int rc = pj_stage(c, x, kp_un, desc, u_right, nullptr, n, fb, q.data(), mp_desc, m, nullptr, a)) return rc;
+    if (int rc = pj_stage(c, x, kp_un, desc, u_right, nullptr, n, fb, q, q_desc, m, nullptr, a)) return rc;
     hipStream_t st = c->stream;
     // offsets [m + 1] | entries [cap] | unsorted keys [cap] (only the points with more than 64 candidates use them)
     const size_t o_st = 0, o_cd = al256(4 * ((size_t)m + 1)), o_tmp = o_cd + al256(4 * (size_t)cap), need = o_tmp + 8 * (size_t)cap + 256;
@@ -1570,6 +1566,113 @@ extern "C" int gfo_projection_candidates(gfo_ctx* c, const gfo_keypoint* kp_un, 
         }
         memcpy(cand, x.HO + o_hc, 4 * (size_t)tot);
     }
+    return GFO_OK;
+}
+
+extern "C" int gfo_projection_candidates(gfo_ctx* c, const gfo_keypoint* kp_un, const uint8_t* desc, const float* u_right, int n,
+                                         const float* sf, int nlevels, const gfo_frame_bounds* fb, const gfo_map_point* mps,
+                                         const uint8_t* mp_desc, int m, float th, int32_t* cand_start, uint32_t* cand, int cap, int* total)
+{
+    if (!c) return GFO_ERR_INVALID;
+    if (!sf || nlevels < 1 || nlevels > GFO_MAX_LEVELS || !fb || !cand_start || !total || n < 0 || m < 0 || cap < 0 || (cap > 0 && !cand) ||
+        (n > 0 && (!kp_un || !desc)) || (m > 0 && (!mps || !mp_desc)))
+        return pj_fail(c, GFO_ERR_INVALID, "gfo_projection_candidates: bad argument");
+    std::vector<gfo_proj_query> q((size_t)(m > 0 ? m : 1));
+    pj_queries_of_map_points(mps, m, sf, nlevels, th, q.data());
+    return pj_candidates(c, kp_un, desc, u_right, n, fb, q.data(), mp_desc, m, cand_start, cand, cap, total);
+}
+
+// ORBmatcher::SearchForInitialization (ORBmatcher.cc:520-633), the monocular bootstrap's matcher.  Two halves: every level-0 keypoint of
+// F1 looks at F2's level-0 keypoints within windowSize of where it was matched last (GetFeaturesInArea, :538) and takes their descriptor
+// distances -- the device's candidate table, one call --; then the reference's loop over that table on the host, in keypoint order, because
+// a later keypoint may TAKE a keypoint of F2 from an earlier one when it is strictly closer (vMatchedDistance / vnMatches21, :557-581): a
+// chain of thefts has no bound, and the whole pass is a few ten thousand table entries.
+extern "C" int gfo_search_for_initialization(gfo_ctx* c, const gfo_keypoint* kp1, const uint8_t* desc1, int n1, float* prev_matched,
+                                             const gfo_keypoint* kp2, const uint8_t* desc2, int n2, const gfo_frame_bounds* fb, int window_size,
+                                             float nn_ratio, int check_orientation, int32_t* matches12, int* nmatches)
+{
+    if (!c) return GFO_ERR_INVALID;
+    if (!fb || !nmatches || n1 < 0 || n2 < 0 || window_size < 0 || (n1 > 0 && (!kp1 || !desc1 || !prev_matched || !matches12)) ||
+        (n2 > 0 && (!kp2 || !desc2)))
+        return pj_fail(c, GFO_ERR_INVALID, "gfo_search_for_initialization: bad argument");
+    *nmatches = 0;
+    for (int i = 0; i < n1; i++) matches12[i] = -1;                                  // :523
+    if (n1 == 0 || n2 == 0) return GFO_OK;
+    std::vector<gfo_proj_query> q((size_t)n1);
+    for (int i = 0; i < n1; i++) {
+        gfo_proj_query& d = q[i];
+        d.u = prev_matched[2 * i];
+        d.v = prev_matched[2 * i + 1];
+        d.ur = -1.f;
+        d.radius = (float)window_size;                                              // `const float& r` of GetFeaturesInArea
+        d.min_level = 0;                                                             // level1, level1 (:538) with level1 == 0 (:534-536)
+        d.max_level = 0;
+        d.angle = 0.f;
+        d.flags = kp1[i].octave > 0 ? 0 : 1;
+    }
+    std::vector<int32_t> start((size_t)n1 + 1);
+    std::vector<uint32_t> cand;
+    int cap = 64 * n1, total = 0, rc = GFO_OK;
+    for (int attempt = 0; attempt < 2; attempt++) {                                  // a table larger than the guess: the first pass says how large
+        cand.resize((size_t)(cap > 0 ? cap : 1));
+        rc = pj_candidates(c, kp2, desc2, nullptr, n2, fb, q.data(), desc1, n1, start.data(), cand.data(), cap, &total);
+        if (rc != GFO_ERR_CAPACITY || total < 0) break;
+        cap = total;
+    }
+    if (rc != GFO_OK) return rc;
+    const int HISTO = 30, TH_LOW_ = 50;
+    const float factor = 1.0f / HISTO;
+    std::vector<int> matched_dist((size_t)n2, INT_MAX), matches21((size_t)n2, -1), rot_bin((size_t)n1, -1);
+    int histo[30] = {0};
+    int nm = 0;
+    for (int i1 = 0; i1 < n1; i1++) {
+        if (kp1[i1].octave > 0) continue;
+        int bestDist = INT_MAX, bestDist2 = INT_MAX, bestIdx2 = -1;
+        for (int k = start[i1]; k < start[i1 + 1]; k++) {
+            const int i2 = (int)(cand[k] & 0xFFFFu), dist = (int)((cand[k] >> 20) & 0x7FFu);
+            if (matched_dist[i2] <= dist) continue;                                  // :557
+            if (dist < bestDist) { bestDist2 = bestDist; bestDist = dist; bestIdx2 = i2; }
+            else if (dist < bestDist2) bestDist2 = dist;
+        }
+        if (bestDist > TH_LOW_ || !((float)bestDist < (float)bestDist2 * nn_ratio)) continue;
+        if (matches21[bestIdx2] >= 0) {                                              // :575-579: taken from the keypoint that had it
+            matches12[matches21[bestIdx2]] = -1;
+            nm--;
+        }
+        matches12[i1] = bestIdx2;
+        matches21[bestIdx2] = i1;
+        matched_dist[bestIdx2] = bestDist;
+        nm++;
+        if (check_orientation) {
+            float rot = kp1[i1].angle - kp2[bestIdx2].angle;
+            if (rot < 0.0f) rot += 360.0f;
+            int bin = (int)roundf(rot * factor);
+            if (bin == HISTO) bin = 0;
+            if (bin >= 0 && bin < HISTO) { rot_bin[i1] = bin; histo[bin]++; }        // (the reference asserts the range)
+        }
+    }
+    if (check_orientation) {                                                         // ComputeThreeMaxima, :1723-1764
+        int max1 = 0, max2 = 0, max3 = 0, ind1 = -1, ind2 = -1, ind3 = -1;
+        for (int i = 0; i < HISTO; i++) {
+            const int sz = histo[i];
+            if (sz > max1) { max3 = max2; max2 = max1; max1 = sz; ind3 = ind2; ind2 = ind1; ind1 = i; }
+            else if (sz > max2) { max3 = max2; max2 = sz; ind3 = ind2; ind2 = i; }
+            else if (sz > max3) { max3 = sz; ind3 = i; }
+        }
+        if ((float)max2 < 0.1f * (float)max1) { ind2 = -1; ind3 = -1; }
+        else if ((float)max3 < 0.1f * (float)max1) ind3 = -1;
+        for (int i1 = 0; i1 < n1; i1++) {
+            const int b = rot_bin[i1];
+            if (b < 0 || b == ind1 || b == ind2 || b == ind3) continue;
+            if (matches12[i1] >= 0) { matches12[i1] = -1; nm--; }                    // (a keypoint robbed since is in the histogram still, :612)
+        }
+    }
+    for (int i1 = 0; i1 < n1; i1++)                                                  // :626-629
+        if (matches12[i1] >= 0) {
+            prev_matched[2 * i1] = kp2[matches12[i1]].x;
+            prev_matched[2 * i1 + 1] = kp2[matches12[i1]].y;
+        }
+    *nmatches = nm;
     return GFO_OK;
 }
 

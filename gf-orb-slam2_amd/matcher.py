@@ -256,6 +256,23 @@ class ORBmatcher:
                                                                       1 if self.mbCheckOrientation else 0, ptr(out), C.byref(nm)))
         return nm.value, out[:n1]
 
+    def SearchForInitialization(self, kp1, desc1, prev_matched, kp2, desc2, bounds, window_size=100):
+        """ORBmatcher::SearchForInitialization(F1, F2, vbPrevMatched, vnMatches12, windowSize) -- ORBmatcher.cc:520-633.
+        prev_matched: (n1, 2) float32, updated IN PLACE where a keypoint matched (:626-629).  Returns (nmatches, vnMatches12[n1])."""
+        kp1 = np.ascontiguousarray(kp1, KEYPOINT_DTYPE); kp2 = np.ascontiguousarray(kp2, KEYPOINT_DTYPE)
+        desc1 = np.ascontiguousarray(desc1, np.uint8); desc2 = np.ascontiguousarray(desc2, np.uint8)
+        if not (isinstance(prev_matched, np.ndarray) and prev_matched.dtype == np.float32 and prev_matched.flags.c_contiguous and
+                prev_matched.shape == (len(kp1), 2)):
+            raise ValueError("prev_matched: a C-contiguous float32 array of shape (n1, 2), updated in place")
+        fb = FrameBoundsC(*bounds)
+        n1 = len(kp1)
+        out = np.full(max(n1, 1), -1, np.int32)
+        nm = C.c_int()
+        check(self._L, self._ctx, self._L.gfo_search_for_initialization(self._ctx, ptr(kp1), ptr(desc1), n1, ptr(prev_matched), ptr(kp2), ptr(desc2), len(kp2),
+                                                                        C.byref(fb), int(window_size), self.mfNNratio,
+                                                                        1 if self.mbCheckOrientation else 0, ptr(out), C.byref(nm)))
+        return nm.value, out[:n1]
+
     def SearchForTriangulation(self, kp1, desc1, has_mp1, u_right1, fv1, kp2, desc2, has_mp2, u_right2, fv2, scale_factors2, level_sigma2_2, f12, ex, ey,
                                only_stereo=False):
         """ORBmatcher::SearchForTriangulation(pKF1, pKF2, F12, vMatchedPairs, bOnlyStereo) -- ORBmatcher.cc:770-935.

@@ -434,6 +434,19 @@ int gfo_search_by_bow_keyframes(gfo_ctx* ctx, const uint8_t* desc1, const float*
                                 const uint8_t* mp_valid2, int n2, const gfo_feature_vector* fv2, float nn_ratio,
                                 int check_orientation, int32_t* out_idx2, int* nmatches);
 
+/* ORBmatcher::SearchForInitialization(Frame& F1, Frame& F2, vector<cv::Point2f>& vbPrevMatched, vector<int>& vnMatches12, int windowSize)
+ * -- include/ORBmatcher.h, src/ORBmatcher.cc:520-633; the monocular bootstrap's matcher (Tracking::MonocularInitialization,
+ * src/Tracking.cc:1322).  kp1 / desc1 = F1.mvKeysUn / mDescriptors, kp2 / desc2 = F2's, fb = F2's image bounds (its grid is rebuilt from them,
+ * Frame.cc:461-476); prev_matched = vbPrevMatched as n1 (x, y) pairs, IN and OUT (:626-629).  Only level-0 keypoints of F1 search, and only
+ * F2's level-0 keypoints within window_size of prev_matched[i] are looked at (GetFeaturesInArea, :538); best and second-best distance,
+ * TH_LOW, the ratio test; a later keypoint of F1 takes a keypoint of F2 from an earlier one when strictly closer (:557, :575-581);
+ * rotation histogram when check_orientation (a robbed keypoint still counts in its bin, as in the reference).  matches12[n1] =
+ * vnMatches12.  The windows and every candidate's descriptor distance come from one device call (the candidate table of
+ * gfo_projection_candidates); the ordered pass over the table runs on the host inside this call. */
+int gfo_search_for_initialization(gfo_ctx* ctx, const gfo_keypoint* kp1, const uint8_t* desc1, int n1, float* prev_matched, const gfo_keypoint* kp2,
+                                  const uint8_t* desc2, int n2, const gfo_frame_bounds* fb, int window_size, float nn_ratio,
+                                  int check_orientation, int32_t* matches12, int* nmatches);
+
 /* ORBmatcher::SearchForTriangulation(KeyFrame* pKF1, KeyFrame* pKF2, cv::Mat F12, vector<pair<size_t, size_t>>& vMatchedPairs, bOnlyStereo)
  * -- include/ORBmatcher.h, src/ORBmatcher.cc:770-935; local mapping's matcher for NEW map points (LocalMapping::CreateNewMapPoints,
  * src/LocalMapping.cc:435).  Keypoints WITHOUT a map point (has_mp = GetMapPoint(i) != NULL) of two keyframes, node by node of their

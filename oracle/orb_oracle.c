@@ -10,6 +10,7 @@
 #include "orb_oracle.h"
 
 #include <float.h>
+#include <limits.h>
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
@@ -1225,6 +1226,80 @@ int orc_features_in_area(const orc_keypoint* kp_un, int n, const orc_frame_bound
     const int k = grid_query(&g, kp_un, fb, x, y, r, min_level, max_level, out_idx, cap);
     grid_free(&g);
     return k;
+}
+
+/* ORBmatcher::SearchForInitialization -- ORBmatcher.cc:520-633 (monocular bootstrap).  prev_matched = vbPrevMatched as (x, y) pairs, in and
+ * out; fb = F2's image bounds (its grid).  rotHist is kept as the reference keeps it: a list per bin, entries never removed. */
+int orc_search_for_initialization(const orc_keypoint* kp1, const uint8_t* desc1, int n1, float* prev_matched, const orc_keypoint* kp2,
+                                  const uint8_t* desc2, int n2, const orc_frame_bounds* fb, int window_size, float nn_ratio,
+                                  int check_orientation, int* vnMatches12)
+{
+    enum { HISTO_LENGTH = 30, TH_LOW_ = 50 };
+    int nmatches = 0;
+    for (int i = 0; i < n1; i++) vnMatches12[i] = -1;
+    int* rot_list = (int*)malloc(sizeof(int) * (n1 > 0 ? n1 : 1));     /* (i1, bin) in push order */
+    int* rot_bin = (int*)malloc(sizeof(int) * (n1 > 0 ? n1 : 1));
+    int nrot = 0;
+    int histo[HISTO_LENGTH];
+    memset(histo, 0, sizeof histo);
+    const float factor = 1.0f / HISTO_LENGTH;
+    int* vMatchedDistance = (int*)malloc(sizeof(int) * (n2 > 0 ? n2 : 1));
+    int* vnMatches21 = (int*)malloc(sizeof(int) * (n2 > 0 ? n2 : 1));
+    for (int i = 0; i < n2; i++) { vMatchedDistance[i] = INT_MAX; vnMatches21[i] = -1; }
+    int* vIndices2 = (int*)malloc(sizeof(int) * (n2 > 0 ? n2 : 1));
+    grid_t g;
+    grid_build(&g, kp2, n2, fb);
+    for (int i1 = 0; i1 < n1; i1++) {
+        const int level1 = kp1[i1].octave;
+        if (level1 > 0) continue;
+        const int nv = grid_query(&g, kp2, fb, prev_matched[2 * i1], prev_matched[2 * i1 + 1], (float)window_size, level1, level1, vIndices2, n2);
+        if (nv == 0) continue;
+        int bestDist = INT_MAX, bestDist2 = INT_MAX, bestIdx2 = -1;
+        for (int k = 0; k < nv; k++) {
+            const int i2 = vIndices2[k];
+            const int dist = orc_hamming256(desc1 + (size_t)i1 * 32, desc2 + (size_t)i2 * 32);
+            if (vMatchedDistance[i2] <= dist) continue;
+            if (dist < bestDist) { bestDist2 = bestDist; bestDist = dist; bestIdx2 = i2; }
+            else if (dist < bestDist2) bestDist2 = dist;
+        }
+        if (bestDist <= TH_LOW_) {
+            if (bestDist < (float)bestDist2 * nn_ratio) {
+                if (vnMatches21[bestIdx2] >= 0) {
+                    vnMatches12[vnMatches21[bestIdx2]] = -1;
+                    nmatches--;
+                }
+                vnMatches12[i1] = bestIdx2;
+                vnMatches21[bestIdx2] = i1;
+                vMatchedDistance[bestIdx2] = bestDist;
+                nmatches++;
+                if (check_orientation) {
+                    float rot = kp1[i1].angle - kp2[bestIdx2].angle;
+                    if (rot < 0.0) rot += 360.0f;
+                    int bin = (int)roundf(rot * factor);
+                    if (bin == HISTO_LENGTH) bin = 0;
+                    rot_list[nrot] = i1; rot_bin[nrot] = bin; nrot++;
+                    histo[bin]++;
+                }
+            }
+        }
+    }
+    if (check_orientation) {
+        int ind1 = -1, ind2 = -1, ind3 = -1;
+        orc_three_maxima(histo, HISTO_LENGTH, &ind1, &ind2, &ind3);
+        for (int k = 0; k < nrot; k++) {
+            if (rot_bin[k] == ind1 || rot_bin[k] == ind2 || rot_bin[k] == ind3) continue;
+            const int idx1 = rot_list[k];
+            if (vnMatches12[idx1] >= 0) { vnMatches12[idx1] = -1; nmatches--; }
+        }
+    }
+    for (int i1 = 0; i1 < n1; i1++)
+        if (vnMatches12[i1] >= 0) {
+            prev_matched[2 * i1] = kp2[vnMatches12[i1]].x;
+            prev_matched[2 * i1 + 1] = kp2[vnMatches12[i1]].y;
+        }
+    grid_free(&g);
+    free(vIndices2); free(vnMatches21); free(vMatchedDistance); free(rot_bin); free(rot_list);
+    return nmatches;
 }
 
 /* ORBmatcher::SearchByProjection(Frame&, vector<MapPoint*>&, th) -- ORBmatcher.cc:155-249 */

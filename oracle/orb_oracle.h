@@ -181,6 +181,10 @@ int orc_search_by_projection_budget(const orc_keypoint* kp_un, const uint8_t* de
                                     const orc_map_point* mps, const uint8_t* mp_desc, int m,
                                     float th, float nn_ratio, const uint8_t* kp_taken, int clock_trip,
                                     int* out_mp, int* out_score, int* out_point, int* found);
+/* ORBmatcher::SearchForInitialization -- ORBmatcher.cc:520-633; prev_matched (x, y pairs) in and out */
+int orc_search_for_initialization(const orc_keypoint* kp1, const uint8_t* desc1, int n1, float* prev_matched, const orc_keypoint* kp2,
+                                  const uint8_t* desc2, int n2, const orc_frame_bounds* fb, int window_size, float nn_ratio,
+                                  int check_orientation, int* vnMatches12);
 int orc_features_in_area(const orc_keypoint* kp_un, int n, const orc_frame_bounds* fb,
                          float x, float y, float r, int min_level, int max_level,
                          int* out_idx, int cap);

@@ -802,6 +802,22 @@ def search_by_bow_keyframes(desc1, angle1, valid1, fv1, desc2, angle2, valid2, f
     return nm, out[:len(desc1)]
 
 
+def search_for_initialization(kp1, desc1, prev_matched, kp2, desc2, bounds, window_size=100, nn_ratio=0.9, check_orientation=True):
+    """ORBmatcher::SearchForInitialization, ORBmatcher.cc:520-633.  prev_matched (n1, 2) float32 is updated in place.
+    Returns (nmatches, vnMatches12[n1])."""
+    kp1 = np.ascontiguousarray(kp1, KEYPOINT_DTYPE); kp2 = np.ascontiguousarray(kp2, KEYPOINT_DTYPE)
+    desc1 = np.ascontiguousarray(desc1, np.uint8); desc2 = np.ascontiguousarray(desc2, np.uint8)
+    assert prev_matched.dtype == np.float32 and prev_matched.flags.c_contiguous and prev_matched.shape == (len(kp1), 2)
+    fb = FrameBounds(*bounds)
+    out = np.full(max(len(kp1), 1), -1, np.int32)
+    L = lib()
+    vp = C.c_void_p
+    L.orc_search_for_initialization.argtypes = [vp, vp, C.c_int, vp, vp, vp, C.c_int, C.POINTER(FrameBounds), C.c_int, C.c_float, C.c_int, vp]
+    nm = L.orc_search_for_initialization(_p(kp1), _p(desc1), len(kp1), _p(prev_matched), _p(kp2), _p(desc2), len(kp2), C.byref(fb), int(window_size),
+                                         nn_ratio, 1 if check_orientation else 0, _p(out))
+    return nm, out[:len(kp1)]
+
+
 def search_for_triangulation(kp1, desc1, has_mp1, u_right1, fv1, kp2, desc2, has_mp2, u_right2, fv2, scale_factors2, level_sigma2_2, f12, ex, ey,
                              only_stereo=False, check_orientation=True):
     """ORBmatcher::SearchForTriangulation, ORBmatcher.cc:770-935.  Returns (nmatches, out12[n1])."""

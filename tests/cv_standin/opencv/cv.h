@@ -32,9 +32,11 @@
 
 namespace cv
 {
-struct Point { int x, y; Point() : x(0), y(0) {} Point(int a, int b) : x(a), y(b) {} };
-typedef Point Point2i;
-struct Point2f { float x, y; Point2f() : x(0), y(0) {} Point2f(float a, float b) : x(a), y(b) {} };
+// (templates as in OpenCV, so that a signature with cv::Point2f mangles to the name a real build has: N2cv6Point_IfEE)
+template <class T> struct Point_ { T x, y; Point_() : x(0), y(0) {} Point_(T a, T b) : x(a), y(b) {} };
+typedef Point_<int> Point2i;
+typedef Point2i Point;
+typedef Point_<float> Point2f;
 struct Rect { int x, y, width, height; Rect(int a, int b, int c, int d) : x(a), y(b), width(c), height(d) {} };
 struct Scalar { double v; Scalar(double a = 0) : v(a) {} };
 struct KeyPoint {

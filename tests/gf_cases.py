@@ -117,3 +117,21 @@ def triangulation_case(oracle, kp1, desc1, rng, flips=6, noise=0.6, p_mp=0.3, p_
     node2[rng.random(n) < 0.02] = -1
     return dict(kp1=kp1, desc1=desc1, has1=has1, ur1=ur1, fv1=oracle.make_feature_vector(node1), kp2=kp2, desc2=d2, has2=has2, ur2=ur2,
                 fv2=oracle.make_feature_vector(node2), f12=F12, ex=ex, ey=ey, node1=node1, node2=node2, R21=R21, t21=t21)
+
+
+def initialization_case(oracle, kp1, desc1, rng, flips=8, sigma=15.0, resample=True):
+    """The second frame of SearchForInitialization: F1's keypoints drawn WITH replacement (some are seen twice, some not at all: several
+    keypoints of F1 then want one keypoint of F2 and the closer one takes it), moved by N(0, sigma) px, bits flipped, shuffled."""
+    n = len(kp1)
+    src = rng.integers(0, n, n) if resample else rng.permutation(n)
+    kp2 = kp1[src].copy()
+    kp2["x"] = (kp2["x"] + rng.normal(0, sigma, n)).astype(np.float32)
+    kp2["y"] = (kp2["y"] + rng.normal(0, sigma, n)).astype(np.float32)
+    kp2["angle"] = ((kp2["angle"] + rng.normal(0, 5.0, n)) % 360).astype(np.float32)
+    d2 = desc1[src].copy()
+    for _ in range(flips):
+        sel = rng.random(n) < 0.5
+        bits = rng.integers(0, 256, n)
+        d2[sel, bits[sel] >> 3] ^= (1 << (bits[sel] & 7)).astype(np.uint8)
+    prev = np.stack([kp1["x"], kp1["y"]], 1).astype(np.float32).copy()      # Tracking.cc:1300-1302: where the keypoint is in F1
+    return kp2, d2, prev

@@ -19,6 +19,7 @@
 //   L. ORBmatcher::SearchByProjection(KeyFrame*, Scw, ...) (ORBmatcher.cc:406-518) and Fuse(KeyFrame*, Scw, ...) (:1089-1212), loop closing's;
 //   I2. ORBmatcher::SearchByBoW(KeyFrame*, KeyFrame*, vpMatches12) (ORBmatcher.cc:635-768), loop closing's, from a thread of its own;
 //   I3. ORBmatcher::SearchForTriangulation(KF1, KF2, F12, vMatchedPairs, bOnlyStereo) (ORBmatcher.cc:770-935), local mapping's, likewise;
+//   M. ORBmatcher::SearchForInitialization(F1, F2, vbPrevMatched, vnMatches12, windowSize) (ORBmatcher.cc:520-633), the monocular bootstrap's;
 //   H. ORBmatcher::SearchByProjection(CurrentFrame, KeyFrame*, sAlreadyFound, th, ORBdist) (ORBmatcher.cc:1595-1721), relocalisation's;
 //   I. ORBmatcher::SearchByBoW(KeyFrame*, Frame&, vpMapPointMatches) (ORBmatcher.cc:270-404) with real DBoW2::FeatureVector objects;
 //   J. Frame::ComputeBoW() (Frame.cc:661-668) on an ORBVocabulary object whose tree the harness fills: mBowVec and mFeatVec;
@@ -1188,6 +1189,36 @@ int main(int argc, char** argv)
                             dump(only ? "I3_pairs_stereo.bin" : "I3_pairs.bin", flat.data(), flat.size() * 4);
                             if (!only) report("I3_SearchForTriangulation_us", us);
                         }
+                        delete FA; delete FB;
+                    }
+                }
+                // M. SearchForInitialization(F1 = frame 0, F2 = a displaced resampling of it, vbPrevMatched, vnMatches12, windowSize) (ORBmatcher.cc:520-633),
+                //    twice in a row on the same vbPrevMatched, as Tracking::MonocularInitialization does frame after frame
+                {
+                    std::vector<uint8_t> k2 = slurp(g_in + "/M_kp2.bin", false), dd2 = slurp(g_in + "/M_desc2.bin", false), pv = slurp(g_in + "/M_prev.bin", false);
+                    const int nm1 = F0.N, nm2 = (int)(k2.size() / sizeof(cv::KeyPoint));
+                    if (nm2 > 0 && (int)dd2.size() == nm2 * 32 && (int)(pv.size() / 8) == nm1) {
+                        std::vector<cv::KeyPoint> kp2v(nm2);
+                        memcpy(kp2v.data(), k2.data(), k2.size());
+                        cv::Mat desc2(nm2, 32, CV_8U);
+                        memcpy(desc2.data, dd2.data(), dd2.size());
+                        Frame* FA = new Frame();
+                        Frame* FB = new Frame();
+                        fill_frame(*FA, L, R, F0.mvKeys, F0.mDescriptors, F0.mvKeysRight, F0.mDescriptorsRight);
+                        fill_frame(*FB, L, R, kp2v, desc2, F0.mvKeysRight, F0.mDescriptorsRight);
+                        std::vector<cv::Point2f> prev(nm1);
+                        memcpy(prev.data(), pv.data(), pv.size());
+                        ORBmatcher matcher(0.9f, true);                  // Tracking.cc:1319
+                        for (int rep = 0; rep < 2; rep++) {
+                            std::vector<int> m12(3, 7);                   // replaced by the member (:523)
+                            const int nm = matcher.SearchForInitialization(*FA, *FB, prev, m12, 100);
+                            CHECK((int)m12.size() == nm1, "M: vnMatches12 has %zu entries for %d keypoints", m12.size(), nm1);
+                            std::vector<int32_t> o(m12.begin(), m12.end());
+                            o.push_back(nm);
+                            dump(rep ? "M_matches12_again.bin" : "M_matches12.bin", o.data(), o.size() * 4);
+                            dump(rep ? "M_prev_again.bin" : "M_prev_out.bin", prev.data(), prev.size() * 8);
+                        }
+                        report("M_SearchForInitialization_us", median_us(20, []() {}, [&]() { std::vector<int> mm; std::vector<cv::Point2f> pp(prev); matcher.SearchForInitialization(*FA, *FB, pp, mm, 100); }));
                         delete FA; delete FB;
                     }
                 }

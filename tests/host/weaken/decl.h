@@ -6,6 +6,7 @@
 #include <utility>
 #include <vector>
 namespace cv { class Mat { public: int x; }; }   // (by value in two signatures: only the name enters the mangling)
+namespace cv { template <class T> struct Point_ { T x, y; }; typedef Point_<float> Point2f; }   // (cv::Point2f is a typedef of a template: the name that enters the mangling)
 namespace ORB_SLAM2
 {
 class MapPoint;
@@ -32,6 +33,7 @@ public:
     int Fuse(KeyFrame* pKF, const std::vector<MapPoint*>& vpMapPoints, const float th = 3.0);
     int SearchBySim3(KeyFrame* pKF1, KeyFrame* pKF2, std::vector<MapPoint*>& vpMatches12, const float& s12, const cv::Mat& R12, const cv::Mat& t12, const float th);
     int SearchForTriangulation(KeyFrame* pKF1, KeyFrame* pKF2, cv::Mat F12, std::vector<std::pair<std::size_t, std::size_t> >& vMatchedPairs, const bool bOnlyStereo);
+    int SearchForInitialization(Frame& F1, Frame& F2, std::vector<cv::Point2f>& vbPrevMatched, std::vector<int>& vnMatches12, int windowSize = 10);
     int untouched();   // a member the adapter does not replace
 };
 }  // namespace ORB_SLAM2

@@ -16,5 +16,6 @@ int ORBmatcher::Fuse(KeyFrame*, cv::Mat, const std::vector<MapPoint*>&, float, s
 int ORBmatcher::Fuse(KeyFrame*, const std::vector<MapPoint*>&, const float) { return 1; }
 int ORBmatcher::SearchBySim3(KeyFrame*, KeyFrame*, std::vector<MapPoint*>&, const float&, const cv::Mat&, const cv::Mat&, const float) { return 1; }
 int ORBmatcher::SearchForTriangulation(KeyFrame*, KeyFrame*, cv::Mat, std::vector<std::pair<std::size_t, std::size_t> >&, const bool) { return 1; }
+int ORBmatcher::SearchForInitialization(Frame&, Frame&, std::vector<cv::Point2f>&, std::vector<int>&, int) { return 1; }
 int ORBmatcher::untouched() { return 7; }
 }  // namespace ORB_SLAM2

@@ -60,14 +60,14 @@ def test_the_reference_variants_compile_into_the_adapter(variant):
 @pytest.mark.skipif(shutil.which("g++") is None, reason="g++ missing")
 def test_weaken_list_is_what_the_adapter_defines():
     """adapter/weaken_symbols.txt (committed) = the Frame:: / ORBmatcher:: text symbols of matchers_gfo.cc compiled against the
-    reference's unchanged headers (tools/make_weaken_list.py --print): thirteen members, the names a maintainer weakens in Frame.o /
+    reference's unchanged headers (tools/make_weaken_list.py --print): fourteen members, the names a maintainer weakens in Frame.o /
     ORBmatcher.o."""
     import sys
     out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "make_weaken_list.py"), "--print"], capture_output=True, text=True)
     assert out.returncode == 0, out.stderr[-2000:]
     committed = open(os.path.join(ROOT, "gf-orb-slam2_amd", "adapter", "weaken_symbols.txt")).read()
     assert out.stdout == committed
-    assert len([l for l in committed.splitlines() if l and not l.startswith("#")]) == 13
+    assert len([l for l in committed.splitlines() if l and not l.startswith("#")]) == 14
 
 
 CLANG = "/opt/rocm/lib/llvm/bin/clang++"
@@ -78,7 +78,7 @@ CLANG = "/opt/rocm/lib/llvm/bin/clang++"
 def test_link_time_swap_of_the_matcher_bodies(tmp_path, shared, cxx, extra):
     """"Tracking.cc and Frame.cc link unchanged", literally.  A two-TU miniature with the REAL mangled names:
     reference_side.cc (stands for src/Frame.cc + src/ORBmatcher.cc, bodies answer 1) and adapter_side.cc (stands for
-    adapter/matchers_gfo.cc, bodies answer 2) both define the thirteen members.  Untouched, the link fails (duplicate definitions);
+    adapter/matchers_gfo.cc, bodies answer 2) both define the fourteen members.  Untouched, the link fails (duplicate definitions);
     after tools/weaken_reference_objects.sh on the reference-side object it succeeds and EVERY call reaches the adapter's body --
     from outside (main.cc = Tracking.cc) and from inside the reference's own object (Frame::construct = Frame::Frame calling
     ComputeStereoMatches_Undistorted, Frame.cc:100) -- while a member the adapter does not define keeps the reference's body.
@@ -118,7 +118,7 @@ def test_link_time_swap_of_the_matcher_bodies(tmp_path, shared, cxx, extra):
     r = link()
     assert r.returncode == 0, r.stderr[-2000:]
     out = subprocess.run([exe], capture_output=True, text=True)
-    assert out.returncode == 0 and out.stdout.split() == ["2"] * 14 + ["7"], out.stdout
+    assert out.returncode == 0 and out.stdout.split() == ["2"] * 15 + ["7"], out.stdout
 
 
 @pytest.mark.skipif(not os.path.exists(os.path.join(REF_INC, "ORBextractor.h")), reason="reference headers not mounted")

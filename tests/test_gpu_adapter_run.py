@@ -593,6 +593,14 @@ def run(tmp_path_factory, oracle, euroc_l, euroc_r):
     sf3 = np.cumprod(np.concatenate([[f32(1)], np.full(7, f32(1.2))]).astype(f32)).astype(f32)
     ref["I3"] = [oracle.search_for_triangulation(kl0, dl0, h31, c3["ur1"], c3["fv1"], c3["kp2"], c3["desc2"], h32, c3["ur2"], c3["fv2"], sf3, (sf3 * sf3).astype(f32),
                                                  c3["f12"], ex3, ey3, bool(only), not only) for only in (0, 1)]
+    # M: SearchForInitialization(F1 = frame 0, F2 = a displaced resampling of it), twice on the same vbPrevMatched
+    kpm, dm, prevm = gf_cases.initialization_case(oracle, kl0, dl0, np.random.default_rng(41))
+    kpm.tofile(ind / "M_kp2.bin"); dm.tofile(ind / "M_desc2.bin"); prevm.tofile(ind / "M_prev.bin")
+    ref["M"] = []
+    pm = prevm.copy()
+    for _ in range(2):
+        nm_, m12_ = oracle.search_for_initialization(kl0, dl0, pm, kpm, dm, (0.0, 0.0, 752.0, 480.0), 100, 0.9, True)
+        ref["M"].append((nm_, m12_.copy(), pm.copy()))
     with oracle.feature_budget(BUDGET):
         ref["I_budget"] = [oracle.search_by_bow(dl0, kl0["angle"], (kvalid == 1).astype(np.uint8), oracle.make_feature_vector(knode), dl1, kl1["angle"],
                                                 oracle.make_feature_vector(fnode), 0.7, bool(o)) for o in (0, 1)]
@@ -969,6 +977,17 @@ def test_search_for_triangulation_member(run):
         np.testing.assert_array_equal(pairs[:, 0], want, err_msg=name)
         np.testing.assert_array_equal(pairs[:, 1], out[want], err_msg=name)
         assert nm > 100, (name, nm)
+
+
+def test_search_for_initialization_member(run):
+    """ORBmatcher::SearchForInitialization(F1, F2, vbPrevMatched, vnMatches12, windowSize) (ORBmatcher.cc:520-633), the monocular bootstrap's
+    matcher: vnMatches12 replaced, vbPrevMatched updated in place, and the second call on the updated vector"""
+    for (a, b), (nm, m12, prev) in zip((("M_matches12.bin", "M_prev_out.bin"), ("M_matches12_again.bin", "M_prev_again.bin")), run["M"]):
+        got = _rd(run, a, np.int32)
+        assert int(got[-1]) == nm and nm > 100, (a, got[-1], nm)
+        np.testing.assert_array_equal(got[:-1], m12, err_msg=a)
+        assert _rd(run, b, np.float32).tobytes() == prev.tobytes(), b
+    assert run["M"][1][2].tobytes() != run["M"][0][2].tobytes() or run["M"][1][0] == run["M"][0][0]
 
 
 def test_matcher_members_of_a_budgeting_feature_matching_build(run):

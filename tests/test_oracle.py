@@ -976,6 +976,75 @@ def test_triangulation_oracle_against_python_statement(oracle, seed, only_stereo
     np.testing.assert_array_equal(got[1], ref[1])
 
 
+def initialization_python(oracle, kp1, d1, prev, kp2, d2, bounds, window, ratio, ori):
+    """ORBmatcher.cc:520-633 once more, in Python, from the reference's text; the window through features_in_area (tested on its own)."""
+    f = np.float32
+    n1, n2 = len(kp1), len(kp2)
+    m12 = np.full(n1, -1, np.int64)
+    mdist = np.full(n2, 2 ** 31 - 1, np.int64)
+    m21 = np.full(n2, -1, np.int64)
+    hist = [[] for _ in range(30)]
+    nm = 0
+    thefts = 0
+    for i1 in range(n1):
+        if kp1["octave"][i1] > 0:
+            continue
+        idx = oracle.features_in_area(kp2, bounds, prev[i1, 0], prev[i1, 1], f(window), 0, 0)
+        best, best2, bidx = 2 ** 31 - 1, 2 ** 31 - 1, -1
+        for i2 in idx:
+            dist = int(np.unpackbits(d1[i1] ^ d2[i2]).sum())
+            if mdist[i2] <= dist:
+                continue
+            if dist < best:
+                best2, best, bidx = best, dist, int(i2)
+            elif dist < best2:
+                best2 = dist
+        if best <= 50 and f(best) < f(f(best2) * f(ratio)):
+            if m21[bidx] >= 0:
+                m12[m21[bidx]] = -1
+                nm -= 1
+                thefts += 1
+            m12[i1], m21[bidx], mdist[bidx] = bidx, i1, best
+            nm += 1
+            if ori:
+                rot = f(kp1["angle"][i1]) - f(kp2["angle"][bidx])
+                if rot < 0:
+                    rot = f(rot + f(360.0))
+                b_ = int(math.floor(float(f(rot * f(1.0 / 30))) + 0.5))
+                hist[0 if b_ == 30 else b_].append(i1)
+    if ori:
+        keep = oracle_three_maxima([len(h) for h in hist])
+        for i, h in enumerate(hist):
+            if i in keep:
+                continue
+            for i1 in h:
+                if m12[i1] >= 0:
+                    m12[i1] = -1
+                    nm -= 1
+    for i1 in range(n1):
+        if m12[i1] >= 0:
+            prev[i1] = (kp2["x"][m12[i1]], kp2["y"][m12[i1]])
+    return nm, m12, thefts
+
+
+@pytest.mark.parametrize("seed,window,ratio,ori", [(0, 100, 0.9, True), (1, 40, 0.8, False), (2, 300, 0.9, True)])
+def test_initialization_oracle_against_python_statement(oracle, seed, window, ratio, ori):
+    import gf_cases
+    kl = np.fromfile(os.path.join(GOLDEN, "EuRoC_l_kp.bin"), oracle.KEYPOINT_DTYPE)
+    dl = np.fromfile(os.path.join(GOLDEN, "EuRoC_l_desc.bin"), np.uint8).reshape(-1, 32)
+    keep = np.flatnonzero(kl["octave"] <= 1)[:450]                      # level 0 searches; level 1 must be ignored on both sides
+    kl, dl = kl[keep], dl[keep]
+    kp2, d2, prev = gf_cases.initialization_case(oracle, kl, dl, np.random.default_rng(seed), flips=10, sigma=12.0)
+    bounds = (0.0, 0.0, 752.0, 480.0)
+    p_ref, p_got = prev.copy(), prev.copy()
+    ref = initialization_python(oracle, kl, dl, p_ref, kp2, d2, bounds, window, ratio, ori)
+    got = oracle.search_for_initialization(kl, dl, p_got, kp2, d2, bounds, window, ratio, ori)
+    assert got[0] == ref[0] and ref[0] > 40
+    np.testing.assert_array_equal(got[1], ref[1])
+    assert p_got.tobytes() == p_ref.tobytes() and p_got.tobytes() != prev.tobytes()
+    assert ref[2] > 0                                                    # keypoints of F2 did change hands
+
+
 def test_oracle_reproduces_golden_good_feature_matchers(oracle):
     """tests/golden/EuRoC_gf_matchers.npz (made by tests/golden/make_gf_golden.py): the oracle still says what it said when the vectors
     were committed -- SearchByProjection_Budget at th 0.5 / 1 / with a clock, GetCandidates for every point, SearchByBoW(KF, KF)."""

@@ -1,6 +1,6 @@
 """Randomised parity sweep of the HOST-ARRAY matcher calls against the oracle, bit for bit (not part of the test suite: minutes of GPU +
 oracle time): SearchByProjection (map-point and query form, both round-0 forms, candidate-list pools of random size), SearchByBoW (nodes
-from a handful to hundreds of keypoints, both k_bow_match paths), SearchForTriangulation (random relative poses), ComputeBoW (vocabularies of random shape, 1..20 000 descriptors).
+from a handful to hundreds of keypoints, both k_bow_match paths), SearchForTriangulation (random relative poses), SearchForInitialization (windows from none to the whole frame), ComputeBoW (vocabularies of random shape, 1..20 000 descriptors).
 Synthetic frames: keypoints clustered like corners are, descriptors drawn around a few hundred prototypes so that small distances and
 exact ties are common.   usage: python tools/fuzz_matchers.py [cases] [seed]"""
 import os
@@ -21,7 +21,7 @@ rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 ext = G.ORBextractor(1000, 1.2, 8, 20, 7)
 SF = ext.GetScaleFactors()
 bad = 0
-count = {"map": 0, "query": 0, "bow": 0, "cbow": 0, "tri": 0}
+count = {"map": 0, "query": 0, "bow": 0, "cbow": 0, "tri": 0, "init": 0}
 matches = {"map": 0, "query": 0, "bow": 0, "cbow_words": 0}
 t0 = time.time()
 
@@ -67,7 +67,7 @@ def mismatch(what, **kw):
 
 
 for it in range(cases):
-    kind = rng.choice(["map", "query", "bow", "cbow", "tri"], p=[0.35, 0.22, 0.18, 0.13, 0.12])
+    kind = rng.choice(["map", "query", "bow", "cbow", "tri", "init"], p=[0.3, 0.2, 0.16, 0.12, 0.11, 0.11])
     count[kind] += 1
     w, h = float(rng.choice([320, 752, 1241, 1920])), float(rng.choice([240, 480, 376, 1080]))
     bounds = (float(rng.choice([0.0, -12.5])), float(rng.choice([0.0, -7.25])), w, h)
@@ -177,6 +177,24 @@ for it in range(cases):
             gotk = G.ORBmatcher(ratio, ori, extractor=ext).SearchByBoWKeyFrames(kd, kk["angle"].copy(), valid, kfv, fd, fa, valid2, ffv)
             if gotk[0] != refk[0] or not (gotk[1] == refk[1]).all():
                 mismatch("bow_kf", it=it, nk=nk, nf=nf, nnodes=nnodes, got=gotk[0], ref=refk[0])
+    elif kind == "init":
+        # SearchForInitialization (ORBmatcher.cc:520-633): windows around vbPrevMatched, thefts, two calls in a row on the updated vector
+        n = int(rng.choice([1, 40, 900, 2000, 4000]))
+        k1, d1 = frame(n, w, h)
+        k1["octave"] = rng.choice([0, 0, 0, 1, 3], n)
+        k2, d2, prev = gf_cases.initialization_case(O, k1, d1, rng, flips=int(rng.integers(0, 20)), sigma=float(rng.choice([0.0, 4.0, 20.0, 80.0])),
+                                                    resample=bool(rng.random() < 0.7))
+        n2 = int(rng.choice([n, max(1, n // 3)]))
+        k2, d2 = k2[:n2], d2[:n2]
+        win, ratio, ori = int(rng.choice([0, 10, 100, 100, 2000])), float(rng.choice([0.6, 0.9, 1.0])), bool(rng.random() < 0.6)
+        pr, pg = prev.copy(), prev.copy()
+        for rep in range(2):
+            ref = O.search_for_initialization(k1, d1, pr, k2, d2, bounds, win, ratio, ori)
+            got = G.ORBmatcher(ratio, ori, extractor=ext).SearchForInitialization(k1, d1, pg, k2, d2, bounds, win)
+            matches["init"] = matches.get("init", 0) + int(ref[0])
+            if got[0] != ref[0] or not (got[1] == ref[1]).all() or pr.tobytes() != pg.tobytes():
+                mismatch("init", it=it, n=n, n2=n2, win=win, ratio=ratio, ori=ori, rep=rep, got=got[0], ref=ref[0])
+                break
     elif kind == "tri":
         # SearchForTriangulation (ORBmatcher.cc:770-935): a second view of a synthetic keyframe under a random relative pose
         n = int(rng.choice([1, 40, 900, 2000, 4000]))
