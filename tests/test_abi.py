@@ -34,6 +34,19 @@ def test_library_exports_every_declared_symbol(G):
     assert sorted(SYMBOLS) == syms
 
 
+def test_variant_libraries_export_the_same_symbols(G):
+    """The [OCV]-switch builds (gf-orb-slam2_amd/variants, `make variants`) are the product library with other compile-time switches: a
+    variant left over from before an entry point was added would fail to load on the GPU box, so it is caught here."""
+    import glob
+    libs = sorted(glob.glob(os.path.join(ROOT, "gf-orb-slam2_amd", "variants", "libgfo_*.so")))
+    if not libs:
+        pytest.skip("variants not built (G.build_variants())")
+    for path in libs:
+        lib = ctypes.CDLL(path)
+        for s in header_symbols():
+            assert hasattr(lib, s), f"{os.path.basename(path)} lacks {s}: rebuild with `make -C gf-orb-slam2_amd/csrc variants`"
+
+
 def test_keypoint_layout_matches_cv_keypoint(G):
     assert G.KEYPOINT_DTYPE.itemsize == 28
     assert [G.KEYPOINT_DTYPE.fields[n][1] for n in ("x", "y", "size", "angle", "response", "octave", "class_id")] == [0, 4, 8, 12, 16, 20, 24]
