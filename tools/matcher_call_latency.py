@@ -3,7 +3,7 @@ Per-call latency of the host-array matcher calls Tracking makes on every frame (
 synchronisation): SearchByProjection(F, local map) for several map sizes, SearchByProjection(Cur, Last), SearchByBoW(KF, F),
 ComputeBoW(F) -- on the EuRoC frame (2008 keypoints).  Every map point here imitates a random keypoint (8 flipped bits, N(0,2) px
 away), so with M > N several points COMPETE for one keypoint: the ordered resolve runs its worst case, not a typical local map.
-usage (through gpurun): [TH=1|3|5] [ONLY=map|gf|stereo|last|cbow|bow|tri] [JSON=1] python tools/matcher_call_latency.py [M ...]     (GFO_PROJ_STATS=1 prints
+usage (through gpurun): [TH=1|3|5] [ONLY=map|gf|stereo|last|init|cbow|bow|tri] [JSON=1] python tools/matcher_call_latency.py [M ...]     (GFO_PROJ_STATS=1 prints
 rounds / fallbacks per call; JSON=1: one JSON object on stdout instead of the text lines)"""
 import json
 import os
@@ -117,6 +117,18 @@ if ONLY in ("", "last"):
     ms, r = median_ms(lambda: m.SearchByProjectionQueries(kp, desc, u_right, kp["angle"].copy(), bounds, q, qd))
     say("SearchByProjection(Cur, Last)", ms, {"tracked_points": nq, "th": 7, "keypoints": n, "matches": int(r[0])},
         f"SearchByProjection(Cur, Last): {nq} tracked points, th 7, rotation check: median {ms:.3f} ms, {r[0]} matches")
+
+if ONLY in ("", "init"):
+    # SearchForInitialization(F1, F2, vbPrevMatched, vnMatches12, 100) (monocular bootstrap): F2 = F1 moved by N(0, 10) px, 6 bits flipped
+    kpi = kp.copy()
+    kpi["x"] = (kp["x"] + rng.normal(0, 10, n)).astype(np.float32)
+    kpi["y"] = (kp["y"] + rng.normal(0, 10, n)).astype(np.float32)
+    fdi = flipped(desc, 6)
+    prev0 = np.stack([kp["x"], kp["y"]], 1).astype(np.float32)
+    mi = G.ORBmatcher(0.9, True, extractor=ext)
+    ms, r = median_ms(lambda: mi.SearchForInitialization(kp, desc, prev0.copy(), kpi, fdi, bounds, 100))
+    say("SearchForInitialization(F1, F2)", ms, {"keypoints": n, "level0": int((kp["octave"] == 0).sum()), "window": 100, "matches": int(r[0])},
+        f"SearchForInitialization(F1, F2): {int((kp['octave'] == 0).sum())} level-0 keypoints of {n}, window 100: median {ms:.3f} ms, {r[0]} matches")
 
 if ONLY not in ("", "cbow", "bow", "tri"):
     ext.close()
