@@ -974,13 +974,14 @@ __global__ __launch_bounds__(1024) void k_proj_resolve(ProjB a)
 // SearchByProjection_OnePoint compute that do not depend on what the frame's slots hold: the mvuRight gate (:118-123) and the
 // descriptor distance (:127).  A wavefront per point, two passes over the same scan: PASS 0 counts, k_proj_cand_scan turns the counts
 // into offsets, PASS 1 writes.  GetFeaturesInArea returns a window's keypoints in (grid column, grid row, index) order; the scan grid
-// has its own cells, so a point's entries are ranked by that key before they are written (in LDS up to 64 candidates -- every case
-// but pathological ones -- through device memory beyond).
+// has its own cells, so a point's entries are ranked by that key before they are written (in LDS up to PJ_CAND_LDS candidates -- every
+// tracking window and the 100-px windows of SearchForInitialization -- through device memory beyond).
 //   entry: keypoint index | octave << 16 | distance << 20 | (mvuRight gate closed) << 31
+#define PJ_CAND_LDS 256   // candidates of one point ranked in LDS (32 KB per workgroup of 16 points); a longer list goes through device memory
 template <int PASS>
 __global__ __launch_bounds__(64 * PJ_WAVES) void k_proj_candidates(ProjB a, int* start, unsigned* cand, unsigned* h_cand, unsigned long long* tmp, int cap)
 {
-    __shared__ unsigned long long s_keys[PASS ? PJ_WAVES : 1][64];
+    __shared__ unsigned long long s_keys[PASS ? PJ_WAVES : 1][PASS ? PJ_CAND_LDS : 1];
     const int n = frame_n(a, 0);
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int iq = blockIdx.x * PJ_WAVES + wave;
@@ -1051,7 +1052,7 @@ __global__ __launch_bounds__(64 * PJ_WAVES) void k_proj_candidates(ProjB a, int*
                 const unsigned long long key = ((unsigned long long)order << 32) | entry;
                 const int pos = total + __popcll(have & ((1ull << lane) - 1));
                 if (pos < T) {
-                    if (T <= 64) s_keys[wave][pos] = key;
+                    if (T <= PJ_CAND_LDS) s_keys[wave][pos] = key;
                     else tmp[base + pos] = key;
                 }
             }
@@ -1064,13 +1065,16 @@ __global__ __launch_bounds__(64 * PJ_WAVES) void k_proj_candidates(ProjB a, int*
     }
     __syncthreads();
     if (!scan) return;
-    if (T <= 64) {
-        const unsigned long long key = lane < T ? s_keys[wave][lane] : ~0ull;
-        int rank = 0;
-        for (int t = 0; t < T; t++) rank += s_keys[wave][t] < key ? 1 : 0;
-        if (lane < T) {
-            cand[base + rank] = (unsigned)key;
-            if (h_cand) h_cand[base + rank] = (unsigned)key;
+    if (T <= PJ_CAND_LDS) {
+        for (int t0 = 0; t0 < T; t0 += 64) {                   // (wave-uniform trip count; keys are distinct: the keypoint index is in them)
+            const int t = t0 + lane;
+            const unsigned long long key = t < T ? s_keys[wave][t] : ~0ull;
+            int rank = 0;
+            for (int u = 0; u < T; u++) rank += s_keys[wave][u] < key ? 1 : 0;
+            if (t < T) {
+                cand[base + rank] = (unsigned)key;
+                if (h_cand) h_cand[base + rank] = (unsigned)key;
+            }
         }
     } else {
         __threadfence();   // the wave's own keys, written above through the vector memory path, read back by other lanes

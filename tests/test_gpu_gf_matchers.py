@@ -170,22 +170,24 @@ def test_candidate_table_is_get_candidates_for_every_point(ext, oracle, seed, m,
 
 
 def test_candidate_lists_longer_than_a_wavefront(ext, oracle):
-    """Four hundred keypoints inside one window: the lists that are ranked through device memory instead of LDS."""
+    """Seven hundred keypoints inside one window: lists ranked in LDS in several rounds (65..256 entries) and the ones that go through
+    device memory instead (beyond 256)."""
     import gf_orb_slam2_amd as G
     kl, dl, u, _ = gc.frame(oracle)
     kl = kl.copy()
     rng = np.random.default_rng(8)
-    crowd = rng.choice(len(kl), 400, replace=False)
-    kl["x"][crowd] = 300 + rng.uniform(-12, 12, 400).astype(np.float32)
-    kl["y"][crowd] = 200 + rng.uniform(-12, 12, 400).astype(np.float32)
-    kl["octave"][crowd] = rng.integers(0, 2, 400)
+    crowd = rng.choice(len(kl), 700, replace=False)
+    kl["x"][crowd] = 300 + rng.uniform(-12, 12, 700).astype(np.float32)
+    kl["y"][crowd] = 200 + rng.uniform(-12, 12, 700).astype(np.float32)
+    kl["octave"][crowd] = rng.integers(0, 2, 700)
     sf = ext.GetScaleFactors()
     mps, mpd, _ = gc.contended_map(oracle, kl, dl, 4, 600)
     mps["proj_x"][:200] = 300 + rng.uniform(-6, 6, 200); mps["proj_y"][:200] = 200 + rng.uniform(-6, 6, 200)
     mps["level"][:200] = rng.integers(0, 3, 200); mps["flags"][:200] = 5
     mt = G.ORBmatcher(0.8, True, extractor=ext)
     start, cand = mt.GetCandidates(kl, dl, u, sf, gc.BOUNDS, mps, mpd, 5.0)
-    assert np.diff(start).max() > 150
+    sizes = np.diff(start)
+    assert sizes.max() > 256 and ((sizes > 64) & (sizes <= 256)).any(), np.sort(sizes)[-10:]
     _check_table(oracle, kl, dl, u, sf, mps, mpd, 5.0, start, cand)
 
 
