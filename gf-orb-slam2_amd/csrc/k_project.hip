@@ -982,6 +982,7 @@ template <int PASS>
 __global__ __launch_bounds__(64 * PJ_WAVES) void k_proj_candidates(ProjB a, int* start, unsigned* cand, unsigned* h_cand, unsigned long long* tmp, int cap)
 {
     __shared__ unsigned long long s_keys[PASS ? PJ_WAVES : 1][PASS ? PJ_CAND_LDS : 1];
+    __shared__ int2 s_col[PJ_WAVES][64];
     const int n = frame_n(a, 0);
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int iq = blockIdx.x * PJ_WAVES + wave;
@@ -1020,12 +1021,26 @@ __global__ __launch_bounds__(64 * PJ_WAVES) void k_proj_candidates(ProjB a, int*
         const int incl = st_wave_incl_scan(cnt);
         const int excl = incl - cnt;
         const int items = __builtin_amdgcn_readlane(incl, 63);
+        // item t of the window belongs to the LAST column whose first item is <= t (empty columns share their successor's start): a
+        // six-step search of the wave's own 64 starts in LDS.  (A loop over the columns with three readlanes each cost 37 + 44 us per call
+        // on the 35-column windows of SearchForInitialization; LDS operations of one wave execute in order, a compiler fence suffices.)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        s_col[wave][lane] = make_int2(excl, beg);             // lanes beyond ncol: excl = items, never chosen
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         for (int t0 = 0; t0 < items; t0 += 64) {
             const int t = t0 + lane;
             int j = -1;
-            for (int cc = 0; cc < ncol; cc++) {
-                const int p = __builtin_amdgcn_readlane(excl, cc), cn = __builtin_amdgcn_readlane(cnt, cc), b = __builtin_amdgcn_readlane(beg, cc);
-                if (t >= p && t < p + cn) j = b + (t - p);
+            if (t < items) {
+                int lo = 0;
+#pragma unroll
+                for (int step = 32; step > 0; step >>= 1) {
+                    const int c = lo + step;
+                    if (c < 64 && s_col[wave][c].x <= t) lo = c;
+                }
+                const int2 e = s_col[wave][lo];
+                j = e.y + (t - e.x);
             }
             bool ok = false;
             unsigned meta = 0;
