@@ -133,6 +133,17 @@ for case in range(cases):
             else:
                 O.search_by_projection_kf(kp, desc, kp["angle"], bounds, q, qd, int(rng.integers(0, 256)), bool(rng.integers(0, 2)), taken)
                 done["kf"] += 1
+        if n and what == 5:                         # SearchForInitialization: the frame against a shuffled half of itself, two calls in a row
+            n2 = max(1, n // 2)
+            sel = rng.permutation(n)[:n2]
+            prev = np.stack([kp["x"], kp["y"]], 1).astype(np.float32)
+            prev[rng.random(n) < 0.02] = np.nan
+            k1 = kp.copy()
+            k1["octave"] = rng.choice([0, 0, 1], n)
+            for _ in range(2):
+                O.search_for_initialization(k1, desc, prev, kp[sel], flips(desc[sel], 8), bounds, int(rng.choice([0, 10, 100, 5000])),
+                                            float(rng.choice([0.6, 0.9])), bool(rng.integers(0, 2)))
+            done["init"] = done.get("init", 0) + 1
         if n:
             O.features_in_area(kp, bounds, float(rng.uniform(-50, w + 50)), float(rng.uniform(-50, h + 50)), float(rng.choice([0.0, 5.0, 1e9])),
                                int(rng.integers(-1, 8)), int(rng.integers(-1, 8)))
@@ -147,6 +158,18 @@ for case in range(cases):
         O.search_by_bow(dk, kk["angle"], (rng.random(nk) < 0.9).astype(np.uint8), O.make_feature_vector(node_k), df, kf["angle"],
                         O.make_feature_vector(node_f), float(rng.choice([0.6, 0.75, 0.9])), bool(rng.integers(0, 2)))
         done["bow"] += 1
+        if nk and nf:                               # the keyframe-pair overload and SearchForTriangulation on the same two keyframes
+            v1, v2 = (rng.random(nk) < 0.8).astype(np.uint8), (rng.random(nf) < 0.8).astype(np.uint8)
+            O.search_by_bow_keyframes(dk, kk["angle"], v1, O.make_feature_vector(node_k), df, kf["angle"], v2, O.make_feature_vector(node_f),
+                                      float(rng.choice([0.6, 0.9])), bool(rng.integers(0, 2)))
+            mono = rng.random() < 0.3
+            u1 = None if mono else np.where(rng.random(nk) < 0.5, kk["x"] - 5, -1).astype(np.float32)
+            u2 = None if mono else np.where(rng.random(nf) < 0.5, kf["x"] - 5, -1).astype(np.float32)
+            f12 = rng.normal(0, 1e-3, 9).astype(np.float32) if rng.random() < 0.9 else np.zeros(9, np.float32)
+            O.search_for_triangulation(kk, dk, 1 - v1, u1, O.make_feature_vector(node_k), kf, df, 1 - v2, u2, O.make_feature_vector(node_f), SF,
+                                       (SF * SF).astype(np.float32), f12, float(rng.uniform(-100, 900)), float(rng.uniform(-100, 600)),
+                                       bool(rng.integers(0, 2)), bool(rng.integers(0, 2)))
+            done["bow_kf_tri"] = done.get("bow_kf_tri", 0) + 1
     elif what == 8:                                 # ComputeBoW on ragged vocabularies of random shape
         voc = O.make_vocabulary(int(rng.integers(2, 11)), int(rng.integers(1, 5)), seed=int(rng.integers(0, 1 << 30)), p_stop=float(rng.choice([0, 0.1, 0.9])))
         n = int(rng.integers(0, 600))
