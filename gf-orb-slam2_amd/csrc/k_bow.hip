@@ -592,18 +592,18 @@ extern "C" int gfo_search_for_triangulation(gfo_ctx* c, const gfo_keypoint* kp1,
     }
     if (const char* why = bow_check_feature_vector(fv1, n1)) { c->err = std::string("gfo_search_for_triangulation: first feature vector: ") + why; return GFO_ERR_INVALID; }
     if (const char* why = bow_check_feature_vector(fv2, n2)) { c->err = std::string("gfo_search_for_triangulation: second feature vector: ") + why; return GFO_ERR_INVALID; }
-    *nmatches = 0;
-    for (int i = 0; i < n1; i++) out_idx2[i] = -1;
-    if (n1 == 0 || n2 == 0) return GFO_OK;
     std::vector<int2> pairs;
     for (int a = 0, b = 0; a < fv1->n_nodes && b < fv2->n_nodes;) {
         if (fv1->node_ids[a] == fv2->node_ids[b]) { pairs.push_back(make_int2(a, b)); a++; b++; }
         else if (fv1->node_ids[a] < fv2->node_ids[b]) a++;
         else b++;
     }
-    if (pairs.empty()) return GFO_OK;
     for (const int2& pr : pairs)
         if (fv2->node_start[pr.y + 1] - fv2->node_start[pr.y] >= (1 << 20)) { c->err = "gfo_search_for_triangulation: node with more than 2^20 keypoints"; return GFO_ERR_INVALID; }
+    // (nothing above has written to the caller's arrays: a refused call leaves them as they were)
+    *nmatches = 0;
+    for (int i = 0; i < n1; i++) out_idx2[i] = -1;
+    if (n1 == 0 || n2 == 0 || pairs.empty()) return GFO_OK;
     BTRY(c, hipSetDevice(c->device));
     const int it1 = fv1->node_start[fv1->n_nodes], it2 = fv2->node_start[fv2->n_nodes];
     size_t off = 0;

@@ -1614,6 +1614,11 @@ extern "C" int gfo_search_for_initialization(gfo_ctx* c, const gfo_keypoint* kp1
     if (!fb || !nmatches || n1 < 0 || n2 < 0 || window_size < 0 || (n1 > 0 && (!kp1 || !desc1 || !prev_matched || !matches12)) ||
         (n2 > 0 && (!kp2 || !desc2)))
         return pj_fail(c, GFO_ERR_INVALID, "gfo_search_for_initialization: bad argument");
+    // everything the table pass would refuse, before the caller's arrays are touched
+    if (n2 > 65535) return pj_fail(c, GFO_ERR_INVALID, "gfo_search_for_initialization: more than 65535 keypoints in F2");
+    if (!(fb->max_x > fb->min_x) || !(fb->max_y > fb->min_y)) return pj_fail(c, GFO_ERR_INVALID, "gfo_search_for_initialization: empty frame bounds");
+    for (int i = 0; i < n2; i++)
+        if (kp2[i].octave < 0 || kp2[i].octave >= GFO_MAX_LEVELS) return pj_fail(c, GFO_ERR_INVALID, "gfo_search_for_initialization: keypoint octave outside 0..15");
     *nmatches = 0;
     for (int i = 0; i < n1; i++) matches12[i] = -1;                                  // :523
     if (n1 == 0 || n2 == 0) return GFO_OK;

@@ -444,3 +444,155 @@ def test_compute_bow_refuses_bad_modes_and_leaves_outputs_alone(env):
     (bw, bv), (fn, fs, fi) = voc.compute_bow(dl, 2, "TF_IDF", "L1")
     np.testing.assert_array_equal(bw, ref[0]); assert bv.tobytes() == ref[1].tobytes()
     np.testing.assert_array_equal(fi, ref[4])
+
+
+# ------------------------------------------------------------------------------------------------------------------------------
+# gfo_search_for_triangulation, gfo_search_for_initialization
+# ------------------------------------------------------------------------------------------------------------------------------
+def _tri_inputs(env):
+    import gf_cases
+    O = env["oracle"]
+    c = gf_cases.triangulation_case(O, env["kl"], env["dl"], np.random.default_rng(3))
+    sf = env["sf"]
+    return {"kp1": c["kp1"].copy(), "d1": c["desc1"], "h1": c["has1"], "u1": c["ur1"], "fv1": [a.copy() for a in c["fv1"]], "kp2": c["kp2"].copy(),
+            "d2": c["desc2"], "h2": c["has2"], "u2": c["ur2"], "fv2": [a.copy() for a in c["fv2"]], "sf": sf, "sg": (sf * sf).astype(np.float32),
+            "f12": c["f12"].reshape(9).copy(), "ex": float(c["ex"]), "ey": float(c["ey"]), "nlevels": len(sf)}
+
+
+def _tri_call(env, a, out, nm):
+    FV = env["lib"].FeatureVectorC
+    keep = []
+
+    def fv(t):
+        ids, start, items = (None if x is None else np.ascontiguousarray(x, dt) for x, dt in zip(t[:3], (np.uint32, np.int32, np.uint32)))
+        keep.append((ids, start, items))
+        return FV(None if ids is None else ids.ctypes.data, None if start is None else start.ctypes.data, None if items is None else items.ctypes.data,
+                  t[3] if len(t) > 3 else len(ids))
+    f1, f2 = fv(a["fv1"]), fv(a["fv2"])
+    return env["L"].gfo_search_for_triangulation(env["ctx"], _p(a["kp1"]), _p(a["d1"]), _p(a["h1"]), _p(a["u1"]), a.get("n1", len(a["kp1"])), C.byref(f1),
+                                                 _p(a["kp2"]), _p(a["d2"]), _p(a["h2"]), _p(a["u2"]), a.get("n2", len(a["kp2"])), C.byref(f2), _p(a["sf"]),
+                                                 _p(a["sg"]), a["nlevels"], _p(a["f12"]), C.c_float(a["ex"]), C.c_float(a["ey"]), 0, 1, _p(out), C.byref(nm))
+
+
+def _damage_tri(a, what):
+    if what == "second item == n2":
+        a["fv2"][2][5] = len(a["kp2"])
+    elif what == "first item huge":
+        a["fv1"][2][0] = 0xFFFFFFF0
+    elif what == "node_start decreases":
+        a["fv1"][1][3] = a["fv1"][1][2] - 1
+    elif what == "node_ids not ascending":
+        a["fv2"][0][1], a["fv2"][0][2] = a["fv2"][0][2], a["fv2"][0][1]
+    elif what == "second octave == nlevels":
+        a["kp2"]["octave"][9] = a["nlevels"]
+    elif what == "second octave negative":
+        a["kp2"]["octave"][0] = -2
+    elif what == "nlevels beyond the table":
+        a["nlevels"] = 64
+    elif what == "null fundamental matrix":
+        a["f12"] = None
+    elif what == "null map-point flags":
+        a["h2"] = None
+    elif what == "null sigma table":
+        a["sg"] = None
+    elif what == "negative count":
+        a["n1"] = -1
+    elif what == "first angle NaN":
+        a["kp1"]["angle"][4] = np.nan
+    else:
+        raise KeyError(what)
+
+
+TRI_CASES = ["second item == n2", "first item huge", "node_start decreases", "node_ids not ascending", "second octave == nlevels", "second octave negative",
+             "nlevels beyond the table", "null fundamental matrix", "null map-point flags", "null sigma table", "negative count", "first angle NaN"]
+
+
+def test_search_for_triangulation_refuses_malformed_arrays(env):
+    O = env["oracle"]
+    good = _tri_inputs(env)
+    ref = O.search_for_triangulation(good["kp1"], good["d1"], good["h1"], good["u1"], tuple(good["fv1"]), good["kp2"], good["d2"], good["h2"], good["u2"],
+                                     tuple(good["fv2"]), good["sf"], good["sg"], good["f12"], good["ex"], good["ey"], False, True)
+    assert ref[0] > 300
+    for what in TRI_CASES:
+        a = _tri_inputs(env)
+        _damage_tri(a, what)
+        out = np.full(len(a["kp1"]), SENT_I, np.int32)
+        nm = C.c_int(int(SENT_I))
+        rc = _tri_call(env, a, out, nm)
+        assert rc == GFO_ERR_INVALID, (what, rc)
+        assert (out == SENT_I).all() and nm.value == int(SENT_I), f"{what}: outputs were written by a refused call"
+        assert "gfo_search_for_triangulation" in env["L"].gfo_last_error(env["ctx"]).decode(), what
+        out = np.full(len(good["kp1"]), SENT_I, np.int32)
+        nm = C.c_int(-7)
+        assert _tri_call(env, good, out, nm) == 0, what
+        assert nm.value == ref[0], what
+        np.testing.assert_array_equal(out, ref[1])
+
+
+def _init_inputs(env):
+    import gf_cases
+    kp2, d2, prev = gf_cases.initialization_case(env["oracle"], env["kl"], env["dl"], np.random.default_rng(5))
+    return {"kp1": env["kl"].copy(), "d1": env["dl"], "prev": prev, "kp2": kp2, "d2": d2, "fb": (0.0, 0.0, 752.0, 480.0), "win": 100}
+
+
+def _init_call(env, a, out, nm):
+    fb = None if a["fb"] is None else env["lib"].FrameBoundsC(*a["fb"])
+    return env["L"].gfo_search_for_initialization(env["ctx"], _p(a["kp1"]), _p(a["d1"]), a.get("n1", len(a["kp1"])), _p(a["prev"]), _p(a["kp2"]), _p(a["d2"]),
+                                                  a.get("n2", len(a["kp2"])), None if fb is None else C.byref(fb), a["win"], C.c_float(0.9), 1, _p(out),
+                                                  C.byref(nm))
+
+
+def _damage_init(a, what):
+    if what == "second octave 16":
+        a["kp2"]["octave"][3] = 16
+    elif what == "second octave negative":
+        a["kp2"]["octave"][-1] = -1
+    elif what == "empty frame bounds":
+        a["fb"] = (0.0, 0.0, 0.0, 480.0)
+    elif what == "NaN frame bounds":
+        a["fb"] = (0.0, 0.0, float("nan"), 480.0)
+    elif what == "null frame bounds":
+        a["fb"] = None
+    elif what == "negative window":
+        a["win"] = -3
+    elif what == "null vbPrevMatched":
+        a["prev_keep"], a["prev"] = a["prev"], None
+    elif what == "null second descriptors":
+        a["d2"] = None
+    elif what == "negative count":
+        a["n2"] = -4
+    elif what == "more than 65535 keypoints in F2":
+        k = np.zeros(70000, a["kp2"].dtype)
+        k["x"] = 100; k["y"] = 100
+        a["kp2"], a["d2"] = k, np.zeros((70000, 32), np.uint8)
+    else:
+        raise KeyError(what)
+
+
+INIT_CASES = ["second octave 16", "second octave negative", "empty frame bounds", "NaN frame bounds", "null frame bounds", "negative window",
+              "null vbPrevMatched", "null second descriptors", "negative count", "more than 65535 keypoints in F2"]
+
+
+def test_search_for_initialization_refuses_malformed_arrays(env):
+    O = env["oracle"]
+    good = _init_inputs(env)
+    p_ref = good["prev"].copy()
+    ref = O.search_for_initialization(good["kp1"], good["d1"], p_ref, good["kp2"], good["d2"], good["fb"], 100, 0.9, True)
+    assert ref[0] > 100
+    for what in INIT_CASES:
+        a = _init_inputs(env)
+        _damage_init(a, what)
+        before = None if a["prev"] is None else a["prev"].copy()
+        out = np.full(len(a["kp1"]), SENT_I, np.int32)
+        nm = C.c_int(int(SENT_I))
+        rc = _init_call(env, a, out, nm)
+        assert rc == GFO_ERR_INVALID, (what, rc)
+        assert (out == SENT_I).all() and nm.value == int(SENT_I), f"{what}: outputs were written by a refused call"
+        assert before is None or a["prev"].tobytes() == before.tobytes(), f"{what}: vbPrevMatched was written by a refused call"
+        g = _init_inputs(env)
+        out = np.full(len(g["kp1"]), SENT_I, np.int32)
+        nm = C.c_int(-7)
+        assert _init_call(env, g, out, nm) == 0, what
+        assert nm.value == ref[0], what
+        np.testing.assert_array_equal(out, ref[1])
+        assert g["prev"].tobytes() == p_ref.tobytes(), what
