@@ -1415,7 +1415,7 @@ extern "C" int gfo_search_for_fusion(gfo_ctx* c, const gfo_keypoint* kp_un, cons
                                      const uint8_t* q_desc, int m, int th_dist, int32_t* out_point)
 {
     if (!c) return GFO_ERR_INVALID;
-    if (!inv_level_sigma2 || nlevels < 1 || nlevels > GFO_MAX_LEVELS || (m > 0 && !out_point) || n < 0)
+    if (!inv_level_sigma2 || nlevels < 1 || nlevels > GFO_MAX_LEVELS || (m > 0 && (!out_point || !queries || !q_desc)) || n < 0 || m < 0)
         return pj_fail(c, GFO_ERR_INVALID, "gfo_search_for_fusion: bad argument");
     for (int i = 0; i < n && kp_un; i++)
         if (kp_un[i].octave < 0 || kp_un[i].octave >= nlevels) return pj_fail(c, GFO_ERR_INVALID, "gfo_search_for_fusion: keypoint octave outside the sigma table");

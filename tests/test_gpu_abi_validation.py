@@ -596,3 +596,102 @@ def test_search_for_initialization_refuses_malformed_arrays(env):
         assert nm.value == ref[0], what
         np.testing.assert_array_equal(out, ref[1])
         assert g["prev"].tobytes() == p_ref.tobytes(), what
+
+
+# ------------------------------------------------------------------------------------------------------------------------------
+# gfo_search_by_bow_keyframes (the damaged CSRs of the table above on either side), gfo_search_for_fusion,
+# gfo_search_by_projection_queries_points
+# ------------------------------------------------------------------------------------------------------------------------------
+def _bow_kf_call(env, a, out, nm):
+    FV = env["lib"].FeatureVectorC
+    keep = []
+
+    def fv(t):
+        ids, start, items = (None if x is None else np.ascontiguousarray(x, dt) for x, dt in zip(t[:3], (np.uint32, np.int32, np.uint32)))
+        keep.append((ids, start, items))
+        return FV(None if ids is None else ids.ctypes.data, None if start is None else start.ctypes.data, None if items is None else items.ctypes.data,
+                  t[3] if len(t) > 3 else len(ids))
+    f1, f2 = fv(a["kfv"]), fv(a["ffv"])
+    return env["L"].gfo_search_by_bow_keyframes(env["ctx"], _p(a["kd"]), _p(a["ka"]), _p(a["valid"]), len(a["kd"]), C.byref(f1), _p(a["fd"]), _p(a["fa"]),
+                                                _p(a.get("valid2", a["valid"])), len(a["fd"]), C.byref(f2), C.c_float(0.75), 1, _p(out), C.byref(nm))
+
+
+def test_search_by_bow_between_keyframes_refuses_the_same_damage(env):
+    O = env["oracle"]
+    good = _bow_inputs(env)
+    ref = O.search_by_bow_keyframes(good["kd"], good["ka"], good["valid"], tuple(good["kfv"]), good["fd"], good["fa"], good["valid"], tuple(good["ffv"]), 0.75,
+                                    True)
+    assert ref[0] > 300
+    for what in BOW_CASES + ["null second mask"]:
+        a = _bow_inputs(env)
+        if what == "null second mask":
+            a["valid2"] = None
+        else:
+            _damage_bow(a, what)
+        out = np.full(len(a["kd"]), SENT_I, np.int32)
+        nm = C.c_int(int(SENT_I))
+        rc = _bow_kf_call(env, a, out, nm)
+        assert rc == GFO_ERR_INVALID, (what, rc)
+        assert (out == SENT_I).all() and nm.value == int(SENT_I), f"{what}: outputs were written by a refused call"
+        out = np.full(len(good["kd"]), SENT_I, np.int32)
+        nm = C.c_int(-7)
+        assert _bow_kf_call(env, good, out, nm) == 0, what
+        assert nm.value == ref[0], what
+        np.testing.assert_array_equal(out, ref[1])
+
+
+def _fuse_inputs(env):
+    G = env["G"]
+    kl, dl = env["kl"], env["dl"]
+    rng = np.random.default_rng(17)
+    m = 1500
+    src = rng.integers(0, len(kl), m)
+    q = np.zeros(m, G.PROJ_QUERY_DTYPE)
+    q["u"] = kl["x"][src] + rng.normal(0, 1.5, m); q["v"] = kl["y"][src] + rng.normal(0, 1.5, m)
+    q["ur"] = -1
+    q["radius"] = 3.0 * env["sf"][kl["octave"][src]]
+    q["min_level"] = kl["octave"][src] - 1; q["max_level"] = kl["octave"][src]
+    q["flags"] = 1
+    qd = dl[src].copy()
+    bits = rng.integers(0, 256, m)
+    qd[np.arange(m), bits >> 3] ^= (1 << (bits & 7)).astype(np.uint8)
+    sf = env["sf"]
+    return {"kp": kl.copy(), "desc": dl, "fb": (0.0, 0.0, 752.0, 480.0), "inv": (1.0 / (sf * sf)).astype(np.float32), "nlevels": len(sf), "q": q, "qd": qd,
+            "th": 50}
+
+
+def _fuse_call(env, a, out):
+    fb = None if a["fb"] is None else env["lib"].FrameBoundsC(*a["fb"])
+    return env["L"].gfo_search_for_fusion(env["ctx"], _p(a["kp"]), _p(a["desc"]), None, a["n"] if "n" in a else len(a["kp"]), None if fb is None else C.byref(fb),
+                                          _p(a["inv"]), a["nlevels"], _p(a["q"]), _p(a["qd"]), a.get("m", len(a["q"])), a["th"], _p(out))
+
+
+FUSE_CASES = {"keypoint octave == nlevels": lambda a: a["kp"]["octave"].__setitem__(5, a["nlevels"]),
+              "keypoint octave negative": lambda a: a["kp"]["octave"].__setitem__(0, -1),
+              "null sigma table": lambda a: a.__setitem__("inv", None),
+              "nlevels zero": lambda a: a.__setitem__("nlevels", 0),
+              "nlevels beyond the table": lambda a: a.__setitem__("nlevels", 17),
+              "empty frame bounds": lambda a: a.__setitem__("fb", (10.0, 0.0, 10.0, 480.0)),
+              "null frame bounds": lambda a: a.__setitem__("fb", None),
+              "null query descriptors": lambda a: a.__setitem__("qd", None),
+              "null keypoints": lambda a: (a.__setitem__("n", len(a["kp"])), a.__setitem__("kp", None)),
+              "threshold 256": lambda a: a.__setitem__("th", 256),
+              "negative keypoint count": lambda a: a.__setitem__("n", -1),
+              "negative point count": lambda a: a.__setitem__("m", -2)}
+
+
+def test_search_for_fusion_refuses_malformed_arrays(env):
+    O = env["oracle"]
+    good = _fuse_inputs(env)
+    ref = O.search_for_fusion(good["kp"], good["desc"], None, good["fb"], good["inv"], good["q"], good["qd"], good["th"])
+    assert (ref >= 0).sum() > 800
+    for what, damage in FUSE_CASES.items():
+        a = _fuse_inputs(env)
+        damage(a)
+        out = np.full(len(good["q"]), SENT_I, np.int32)
+        rc = _fuse_call(env, a, out)
+        assert rc == GFO_ERR_INVALID, (what, rc)
+        assert (out == SENT_I).all(), f"{what}: outputs were written by a refused call"
+        out = np.full(len(good["q"]), SENT_I, np.int32)
+        assert _fuse_call(env, good, out) == 0, what
+        np.testing.assert_array_equal(out, ref, err_msg=what)
