@@ -195,7 +195,8 @@ __global__ __launch_bounds__(64 * OD_WAVES) void k_orient_desc(const GfoGeom* __
     //  outside its buffers).  All of them are requested together (a loop over g.nlevels compiled into one dependent scalar
     //  load per level: ~2 us at the head of every wave).
     int total = 0, prefix = 0, cnt = 0;
-    {
+#ifndef GFO_OD_VECTOR_COUNTS
+    {   // sixteen scalar loads and clamp / select / add chains: a third of the wave's ~380 scalar instructions
         const int nl = ok.nlevels;
         const int* sc = sel_cnt + img * nl;
         int craw[GFO_MAX_LEVELS];
@@ -209,6 +210,26 @@ __global__ __launch_bounds__(64 * OD_WAVES) void k_orient_desc(const GfoGeom* __
             total += c;
         }
     }
+#else
+    {   // Round 6 experiment (-DGFO_OD_VECTOR_COUNTS): lane l holds level l's count -- one vector load, the clamp, a prefix sum over a DPP
+        // row, three readlanes.  530 -> 274 scalar instructions in the kernel's text, +17 vector ones; same-box ABAB: 231-233 us against
+        // 230-231, headline 290.6 k against 293.4 k -- the scalar instructions were not what the kernel waits for, and the dependent
+        // vector load + DPP chain at the head of every wave is longer than sixteen independent scalar loads.  Off.
+        const int nl = ok.nlevels;
+        const int ll = min(lane & 15, nl - 1);                                    // (clamped index: never past the image's entries)
+        const int craw = sel_cnt[img * nl + ll];
+        const int cap = g.lv[ll].sel_cap;
+        int c = (lane & 15) < nl ? min(max(craw, 0), cap) : 0;
+        const int own = c;
+        c += __builtin_amdgcn_update_dpp(0, c, 0x111, 0xF, 0xF, false);  // row_shr:1
+        c += __builtin_amdgcn_update_dpp(0, c, 0x112, 0xF, 0xF, false);  // row_shr:2
+        c += __builtin_amdgcn_update_dpp(0, c, 0x114, 0xF, 0xF, false);  // row_shr:4
+        c += __builtin_amdgcn_update_dpp(0, c, 0x118, 0xF, 0xF, false);  // row_shr:8
+        total = __builtin_amdgcn_readlane(c, 15);
+        cnt = __builtin_amdgcn_readlane(own, level);
+        prefix = __builtin_amdgcn_readlane(c, level) - cnt;
+    }
+#endif
     if (blk == 0 && wave == 0 && lane == 0) {
         kp_cnt[img] = min(total, ok.kp_stride);
         if (total > ok.kp_stride) atomicOr(&flags[0], 8);
