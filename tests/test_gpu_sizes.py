@@ -272,3 +272,77 @@ def test_quadtree_level_groups_and_key_overflow_to_l2(oracle, monkeypatch, group
         assert ds[i].tobytes() == od.tobytes(), (groups, i)
     assert most > 3072          # the L2-key path was taken by at least one (image, level)
     ext.close()
+
+
+def _crowded_frame(oracle, rng, n, w, h, nproto=3000):
+    """n keypoints over a w x h image, descriptors around prototypes (small distances and ties are common)"""
+    kp = np.zeros(n, oracle.KEYPOINT_DTYPE)
+    kp["x"] = rng.uniform(0, w, n).astype(np.float32)
+    kp["y"] = rng.uniform(0, h, n).astype(np.float32)
+    kp["octave"] = rng.choice(8, n, p=[0.3, 0.2, 0.15, 0.1, 0.1, 0.06, 0.05, 0.04])
+    kp["angle"] = rng.uniform(0, 360, n).astype(np.float32)
+    kp["size"] = 31.0; kp["response"] = 40; kp["class_id"] = -1
+    protos = rng.integers(0, 256, (nproto, 32), dtype=np.uint8)
+    desc = protos[rng.integers(0, nproto, n)].copy()
+    for _ in range(6):
+        sel = rng.random(n) < 0.5
+        bits = rng.integers(0, 256, n)
+        desc[sel, bits[sel] >> 3] ^= (1 << (bits[sel] & 7)).astype(np.uint8)
+    return kp, desc
+
+
+def test_matchers_at_the_keypoint_limit(oracle):
+    """65 535 keypoints in a frame -- the most the 16-bit keypoint index of the candidate keys allows (include/gfo.h) -- through the
+    matchers that carry that index: SearchByProjection against 20 000 map points, SearchForInitialization (a 30-px window: ~20 candidates
+    a keypoint, a table of several hundred thousand entries), SearchForTriangulation and SearchByBoW(KF, KF) over 4096 nodes."""
+    import gf_orb_slam2_amd as G
+    import gf_cases
+    rng = np.random.default_rng(65535)
+    n, w, h = 65535, 1920.0, 1080.0
+    kp, desc = _crowded_frame(oracle, rng, n, w, h)
+    bounds = (0.0, 0.0, w, h)
+    ext = G.ORBextractor(2000, 1.2, 8, 20, 7)
+    sf = np.asarray(ext.GetScaleFactors(), np.float32)
+    try:
+        # SearchByProjection(F, MapPoints)
+        m = 20000
+        src = rng.integers(0, n, m)
+        mps = np.zeros(m, oracle.MAP_POINT_DTYPE)
+        mps["proj_x"] = kp["x"][src] + rng.normal(0, 1.5, m); mps["proj_y"] = kp["y"][src] + rng.normal(0, 1.5, m)
+        mps["proj_xr"] = mps["proj_x"] - 10
+        mps["level"] = kp["octave"][src]; mps["view_cos"] = 1.0; mps["flags"] = 5
+        mpd = desc[src].copy()
+        bits = rng.integers(0, 256, m)
+        mpd[np.arange(m), bits >> 3] ^= (1 << (bits & 7)).astype(np.uint8)
+        ref = oracle.search_by_projection(kp, desc, None, sf, bounds, mps, mpd, 1.0, 0.8, None)
+        got = G.ORBmatcher(0.8, True, extractor=ext).SearchByProjection(kp, desc, None, sf, bounds, mps, mpd, 1.0, None)
+        assert got[0] == ref[0] and ref[0] > 8000, (got[0], ref[0])
+        np.testing.assert_array_equal(got[1], ref[1])
+        np.testing.assert_array_equal(got[2], ref[2])
+        assert np.flatnonzero(ref[1] >= 0).max() > 65000    # keypoints at the top of the index range are matched
+        # SearchForInitialization
+        kp2, d2, prev = gf_cases.initialization_case(oracle, kp, desc, rng, flips=6, sigma=6.0)
+        p_ref, p_got = prev.copy(), prev.copy()
+        ref = oracle.search_for_initialization(kp, desc, p_ref, kp2, d2, bounds, 30, 0.9, True)
+        got = G.ORBmatcher(0.9, True, extractor=ext).SearchForInitialization(kp, desc, p_got, kp2, d2, bounds, 30)
+        assert got[0] == ref[0] and ref[0] > 5000, (got[0], ref[0])
+        np.testing.assert_array_equal(got[1], ref[1])
+        assert p_got.tobytes() == p_ref.tobytes()
+        # SearchForTriangulation / SearchByBoW(KF, KF): 4096 nodes of ~16 keypoints
+        c = gf_cases.triangulation_case(oracle, kp, desc, rng, flips=6, noise=0.5, node_shift=0, fx=1000.0, fy=1000.0, cx=960.0, cy=540.0)
+        node1 = (desc[:, 0].astype(np.int64) << 4) | (desc[:, 1] >> 4)
+        node2 = (c["desc2"][:, 0].astype(np.int64) << 4) | (c["desc2"][:, 1] >> 4)
+        fv1, fv2 = oracle.make_feature_vector(node1), oracle.make_feature_vector(node2)
+        sg = (sf * sf).astype(np.float32)
+        a = (kp, desc, c["has1"], c["ur1"], fv1, c["kp2"], c["desc2"], c["has2"], c["ur2"], fv2, sf, sg, c["f12"], c["ex"], c["ey"])
+        ref = oracle.search_for_triangulation(*a, False, True)
+        got = G.ORBmatcher(0.6, True, extractor=ext).SearchForTriangulation(*a, False)
+        assert got[0] == ref[0] and ref[0] > 5000, (got[0], ref[0])
+        np.testing.assert_array_equal(got[1], ref[1])
+        v1, v2 = (1 - c["has1"]).astype(np.uint8), (1 - c["has2"]).astype(np.uint8)
+        ref = oracle.search_by_bow_keyframes(desc, kp["angle"], v1, fv1, c["desc2"], c["kp2"]["angle"], v2, fv2, 0.75, True)
+        got = G.ORBmatcher(0.75, True, extractor=ext).SearchByBoWKeyFrames(desc, kp["angle"], v1, fv1, c["desc2"], c["kp2"]["angle"], v2, fv2)
+        assert got[0] == ref[0] and ref[0] > 5000, (got[0], ref[0])
+        np.testing.assert_array_equal(got[1], ref[1])
+    finally:
+        ext.close()
