@@ -990,13 +990,12 @@ int ORBmatcher::SearchByBoW(KeyFrame* pKF1, KeyFrame* pKF2, std::vector<MapPoint
 int ORBmatcher::SearchForTriangulation(KeyFrame* pKF1, KeyFrame* pKF2, cv::Mat F12, std::vector<std::pair<size_t, size_t> >& vMatchedPairs,
                                        const bool bOnlyStereo)
 {
-    cv::Mat Cw = pKF1->GetCameraCenter();
-    cv::Mat R2w = pKF2->GetRotation();
-    cv::Mat t2w = pKF2->GetTranslation();
-    cv::Mat C2 = R2w * Cw + t2w;
-    const float invz = 1.0f / C2.at<float>(2);
-    const float ex = pKF2->fx * C2.at<float>(0) * invz + pKF2->cx;
-    const float ey = pKF2->fy * C2.at<float>(1) * invz + pKF2->cy;
+    // the first camera's centre seen from the second: the same cv::Mat product, sum and float expressions as :777-783, so the two
+    // coordinates carry the same roundings whatever OpenCV's small-matrix code does
+    const cv::Mat centre1_in_2 = pKF2->GetRotation() * pKF1->GetCameraCenter() + pKF2->GetTranslation();
+    const float inv_depth = 1.0f / centre1_in_2.at<float>(2);
+    const float ex = pKF2->fx * centre1_in_2.at<float>(0) * inv_depth + pKF2->cx;
+    const float ey = pKF2->fy * centre1_in_2.at<float>(1) * inv_depth + pKF2->cy;
 
     vMatchedPairs.clear();
     const int n1 = pKF1->N, n2 = pKF2->N;
