@@ -20,6 +20,7 @@
 //   I2. ORBmatcher::SearchByBoW(KeyFrame*, KeyFrame*, vpMatches12) (ORBmatcher.cc:635-768), loop closing's, from a thread of its own;
 //   I3. ORBmatcher::SearchForTriangulation(KF1, KF2, F12, vMatchedPairs, bOnlyStereo) (ORBmatcher.cc:770-935), local mapping's, likewise;
 //   M. ORBmatcher::SearchForInitialization(F1, F2, vbPrevMatched, vnMatches12, windowSize) (ORBmatcher.cc:520-633), the monocular bootstrap's;
+//   T. SearchForTriangulation and SearchByBoW(KF, KF) at once from two threads (the mapping and loop-closing threads' own contexts);
 //   H. ORBmatcher::SearchByProjection(CurrentFrame, KeyFrame*, sAlreadyFound, th, ORBdist) (ORBmatcher.cc:1595-1721), relocalisation's;
 //   I. ORBmatcher::SearchByBoW(KeyFrame*, Frame&, vpMapPointMatches) (ORBmatcher.cc:270-404) with real DBoW2::FeatureVector objects;
 //   J. Frame::ComputeBoW() (Frame.cc:661-668) on an ORBVocabulary object whose tree the harness fills: mBowVec and mFeatVec;
@@ -43,6 +44,7 @@
 #include <cstring>
 #include <new>
 #include <string>
+#include <atomic>
 #include <thread>
 #include <chrono>
 #include <algorithm>
@@ -1188,6 +1190,37 @@ int main(int argc, char** argv)
                             flat.push_back(nm); flat.push_back((int32_t)pairs.size());
                             dump(only ? "I3_pairs_stereo.bin" : "I3_pairs.bin", flat.data(), flat.size() * 4);
                             if (!only) report("I3_SearchForTriangulation_us", us);
+                        }
+                        // T. the two keyframe-pair matchers AT ONCE from two threads, as LocalMapping and LoopClosing run beside each other (each
+                        //    thread on its own context, gfo_context_pin_thread): forty calls each, every answer equal to the single call's
+                        {
+                            std::vector<std::pair<size_t, size_t> > base_pairs;
+                            std::vector<MapPoint*> base12;
+                            int nt0 = -1, nb0 = -1;
+                            { ORBmatcher m0(0.6f, true); nt0 = m0.SearchForTriangulation(&kf1, &kf2, F12, base_pairs, false); }
+                            { ORBmatcher m0(0.75f, true); nb0 = m0.SearchByBoW(&kf1, &kf2, base12); }
+                            std::atomic<int> bad(0), done(0);
+                            std::thread ta([&]() {
+                                ORBmatcher m(0.6f, true);
+                                for (int k = 0; k < 40; k++) {
+                                    std::vector<std::pair<size_t, size_t> > pp;
+                                    const int n = m.SearchForTriangulation(&kf1, &kf2, F12, pp, false);
+                                    if (n != nt0 || pp != base_pairs) bad++;
+                                    done++;
+                                }
+                            });
+                            std::thread tb([&]() {
+                                ORBmatcher m(0.75f, true);
+                                for (int k = 0; k < 40; k++) {
+                                    std::vector<MapPoint*> mm;
+                                    const int n = m.SearchByBoW(&kf1, &kf2, mm);
+                                    if (n != nb0 || mm != base12) bad++;
+                                    done++;
+                                }
+                            });
+                            ta.join(); tb.join();
+                            const int32_t rec[4] = {bad.load(), done.load(), nt0, nb0};
+                            dump("T_concurrent.bin", rec, sizeof rec);
                         }
                         delete FA; delete FB;
                     }

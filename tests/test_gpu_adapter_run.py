@@ -979,6 +979,15 @@ def test_search_for_triangulation_member(run):
         assert nm > 100, (name, nm)
 
 
+def test_keyframe_matchers_from_two_threads_at_once(run):
+    """LocalMapping and LoopClosing run beside each other: SearchForTriangulation on one thread and SearchByBoW(KF, KF) on another, forty
+    calls each at the same time on the same two KeyFrame objects, each thread on its own device context -- every answer is the one the
+    single call gave"""
+    bad, done, nt0, nb0 = _rd(run, "T_concurrent.bin", np.int32)
+    assert bad == 0 and done == 80, (bad, done)
+    assert nt0 == run["I3"][0][0] and nb0 > 50, (nt0, nb0)
+
+
 def test_search_for_initialization_member(run):
     """ORBmatcher::SearchForInitialization(F1, F2, vbPrevMatched, vnMatches12, windowSize) (ORBmatcher.cc:520-633), the monocular bootstrap's
     matcher: vnMatches12 replaced, vbPrevMatched updated in place, and the second call on the updated vector"""
