@@ -125,6 +125,9 @@ __device__ __forceinline__ void blur_body_mfma(const GfoGeom& g, const GfoInput&
         if (ws < w_min) ws = w_max;
         wp[q] = ws;
     }
+#ifdef BLUR_MF_SHARE
+    const bool share = wp[1] == wp[0] + 32;   // wave-uniform
+#endif
     gfo_v4i B1[4];
 #pragma unroll
     for (int k = 0; k < 4; k++) {
@@ -157,6 +160,16 @@ __device__ __forceinline__ void blur_body_mfma(const GfoGeom& g, const GfoInput&
         const int y = gfo_reflect101(r0 + 16 * t - 3 + n16, h);
         const uint8_t* row = src + (long long)y * pitch + 16 * g4;
         Raw r;
+#ifdef BLUR_MF_SHARE
+        // (experiment) interior strips: the second window starts 32 bytes behind the first, so its lower half IS the first one's upper
+        // half -- only the lanes of its upper half load (96 bytes a row instead of 128), the rest comes over the lanes in pass1
+        if (share) {
+            r.v[0] = *reinterpret_cast<const gfo_v4i*>(row + wp[0]);
+            r.v[1] = r.v[0];
+            if (g4 >= 2) r.v[1] = *reinterpret_cast<const gfo_v4i*>(row + wp[1]);
+            return r;
+        }
+#endif
 #pragma unroll
         for (int q = 0; q < 2; q++) {
 #ifdef BLUR_MF_NOLOAD
@@ -173,6 +186,22 @@ __device__ __forceinline__ void blur_body_mfma(const GfoGeom& g, const GfoInput&
 #pragma unroll
         for (int q = 0; q < 2; q++)
             a[q] = gfo_v4i{raw.v[q][0] ^ (int)0x80808080, raw.v[q][1] ^ (int)0x80808080, raw.v[q][2] ^ (int)0x80808080, raw.v[q][3] ^ (int)0x80808080};
+#ifdef BLUR_MF_SHARE
+        if (share) {   // lanes 0-31 of the second window: what lanes 32-63 hold of the first
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+#ifdef BLUR_MF_SHARE_LDS
+                const int up = __builtin_amdgcn_ds_bpermute(4 * ((lane + 32) & 63), a[0][i]);
+                a[1][i] = g4 < 2 ? up : a[1][i];
+#else
+                // v_permlane32_swap: the upper half of its first operand changes places with the lower half of the second -- the second
+                // result is (first window's upper lanes, second window's own upper lanes)
+                const auto sw = __builtin_amdgcn_permlane32_swap((unsigned)a[0][i], (unsigned)a[1][i], false, false);
+                a[1][i] = (int)sw[1];
+#endif
+            }
+        }
+#endif
 #pragma unroll
         for (int k = 0; k < 4; k++) {
             const gfo_v4i d = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[k >> 1], B1[k], C1, 0, 0, 0);
